@@ -1,0 +1,174 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see field.hpp header).
+// C API over the oracle so tests can drive it with ctypes.  All field elements cross this
+// API as canonical (non-Montgomery) little-endian 4 x u64 unless the name says `mont`.
+#include <cstdio>
+#include <chrono>
+#include "field.hpp"
+#include "curve.hpp"
+#include "poseidon.hpp"
+#include "steps.hpp"
+#include "r1cs.hpp"
+
+using namespace orc;
+
+#define FIELD_SWITCH(fid, BODY)                          \
+  switch (fid) {                                         \
+    case 0: { typedef BnFr F; BODY; } break;             \
+    case 1: { typedef BnFq F; BODY; } break;             \
+    case 2: { typedef PallasFp F; BODY; } break;         \
+    default: { typedef VestaFq F; BODY; } break;         \
+  }
+#define CURVE_SWITCH(cid, BODY)                          \
+  switch (cid) {                                         \
+    case 0: { typedef BnG1 C; BODY; } break;             \
+    case 1: { typedef Grumpkin C; BODY; } break;         \
+    case 2: { typedef Pallas C; BODY; } break;           \
+    default: { typedef Vesta C; BODY; } break;           \
+  }
+
+template <class C>
+static typename C::Aff load_aff(const u64* xy) {
+  typename C::Aff a;
+  a.x = C::Base::from_canonical(xy); a.y = C::Base::from_canonical(xy + 4);
+  return a;
+}
+template <class C>
+static void store_aff(const typename C::Aff& a, u64* xy) { a.x.to_canonical(xy); a.y.to_canonical(xy + 4); }
+
+extern "C" {
+
+// ---------------- fields ----------------
+void orc_field_modulus(int fid, u64* out) { FIELD_SWITCH(fid, memcpy(out, F::P().p, 32)); }
+void orc_field_consts(int fid, u64* r1, u64* r2, u64* n0) {
+  FIELD_SWITCH(fid, { memcpy(r1, F::P().r1, 32); memcpy(r2, F::P().r2, 32); *n0 = F::P().n0; });
+}
+void orc_f_add(int fid, const u64* a, const u64* b, u64* o) { FIELD_SWITCH(fid, (F::from_canonical(a) + F::from_canonical(b)).to_canonical(o)); }
+void orc_f_sub(int fid, const u64* a, const u64* b, u64* o) { FIELD_SWITCH(fid, (F::from_canonical(a) - F::from_canonical(b)).to_canonical(o)); }
+void orc_f_mul(int fid, const u64* a, const u64* b, u64* o) { FIELD_SWITCH(fid, (F::from_canonical(a) * F::from_canonical(b)).to_canonical(o)); }
+void orc_f_inv(int fid, const u64* a, u64* o) { FIELD_SWITCH(fid, F::from_canonical(a).inv().to_canonical(o)); }
+void orc_f_to_mont(int fid, const u64* a, u64* o, size_t n) { FIELD_SWITCH(fid, for (size_t i = 0; i < n; i++) { F x = F::from_canonical(a + 4 * i); memcpy(o + 4 * i, x.l, 32); }); }
+void orc_f_from_mont(int fid, const u64* a, u64* o, size_t n) { FIELD_SWITCH(fid, for (size_t i = 0; i < n; i++) F::from_mont_limbs(a + 4 * i).to_canonical(o + 4 * i)); }
+
+// ---------------- curves ----------------
+int orc_curve_on(int cid, const u64* xy) { CURVE_SWITCH(cid, return C::on_curve(load_aff<C>(xy)) ? 1 : 0); return 0; }
+void orc_curve_add(int cid, const u64* p, const u64* q, u64* o) {
+  CURVE_SWITCH(cid, store_aff<C>(C::to_affine(C::add(C::from_affine(load_aff<C>(p)), C::from_affine(load_aff<C>(q)))), o));
+}
+void orc_curve_mul(int cid, const u64* p, const u64* k, u64* o) {
+  CURVE_SWITCH(cid, store_aff<C>(C::to_affine(C::mul(load_aff<C>(p), k)), o));
+}
+// bases: n x 8 limbs canonical affine; scalars: n x 4 limbs canonical; out: affine canonical
+void orc_msm(int cid, const u64* bases, const u64* scalars, size_t n, int threads, u64* out) {
+  CURVE_SWITCH(cid, {
+    std::vector<C::Aff> b(n);
+    for (size_t i = 0; i < n; i++) b[i] = load_aff<C>(bases + 8 * i);
+    store_aff<C>(C::to_affine(C::msm(b.data(), scalars, n, threads)), out);
+  });
+}
+// Same but bases already in Montgomery form (what the product keeps resident); returns seconds spent in the
+// MSM proper (conversion excluded) for the cpu_baseline leg.
+double orc_msm_mont_timed(int cid, const u64* bases_mont, const u64* scalars, size_t n, int threads, u64* out) {
+  double secs = 0;
+  CURVE_SWITCH(cid, {
+    auto t0 = std::chrono::steady_clock::now();
+    auto r = C::msm(reinterpret_cast<const C::Aff*>(bases_mont), scalars, n, threads);
+    secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    store_aff<C>(C::to_affine(r), out);
+  });
+  return secs;
+}
+// Deterministic test bases: P_i = (seed + i + 1) * G computed incrementally (G canonical affine in).
+void orc_curve_seq_bases(int cid, const u64* g, const u64* start, size_t n, u64* out) {
+  CURVE_SWITCH(cid, {
+    C::Aff G = load_aff<C>(g);
+    C::Jac acc = C::mul(G, start);
+    for (size_t i = 0; i < n; i++) {
+      acc = C::add_mixed(acc, G);
+      store_aff<C>(C::to_affine(acc), out + 8 * i);
+    }
+  });
+}
+
+// ---------------- Poseidon / hashers (BN254 Fr) ----------------
+void orc_poseidon(const u64* in, int n, u64* out) {
+  std::vector<BnFr> v(n);
+  for (int i = 0; i < n; i++) v[i] = BnFr::from_canonical(in + 4 * i);
+  poseidon(v.data(), n).to_canonical(out);
+}
+void orc_poseidon_constants(int t, u64* C_out, u64* M_out, int* rf, int* rp) {
+  const PoseidonParams& P = poseidon_params(t);
+  *rf = P.rf; *rp = P.rp;
+  if (C_out) for (size_t i = 0; i < P.C.size(); i++) P.C[i].to_canonical(C_out + 4 * i);
+  if (M_out) for (size_t i = 0; i < P.M.size(); i++) P.M[i].to_canonical(M_out + 4 * i);
+}
+void orc_array_hash(const u64* in, int L, u64* out) {
+  std::vector<BnFr> v(L);
+  for (int i = 0; i < L; i++) v[i] = BnFr::from_canonical(in + 4 * i);
+  array_hash(v.data(), L).to_canonical(out);
+}
+void orc_head_tail_hash(const u64* head, const u64* tail, int L, u64* out) {
+  std::vector<BnFr> v(L);
+  for (int i = 0; i < L; i++) v[i] = BnFr::from_canonical(tail + 4 * i);
+  head_tail_hash(BnFr::from_canonical(head), v.data(), L).to_canonical(out);
+}
+// running image hash: acc_{k+1} = HeadTailHasher(width)(acc_k, row_k)  (circuits/image_running_hash.circom:8-19)
+void orc_image_hash(const u64* rows, int nrows, int width, u64* out) {
+  BnFr acc = BnFr::zero();
+  std::vector<BnFr> v(width);
+  for (int r = 0; r < nrows; r++) {
+    for (int i = 0; i < width; i++) v[i] = BnFr::from_canonical(rows + 4 * ((size_t)r * width + i));
+    acc = head_tail_hash(acc, v.data(), width);
+  }
+  acc.to_canonical(out);
+}
+
+// ---------------- step semantics ----------------
+int orc_ivc_state_len(int t) { return ivc_state_len(t); }
+int orc_step_input_width(int t, int width, int width2, int rows_in, int rows_out, int crop_h) {
+  StepShape s = {width, width2, rows_in, rows_out, crop_h};
+  return step_input_width(t, s);
+}
+// returns 1 if the step relation holds, 0 otherwise; z_out always written.
+int orc_step_eval(int t, int width, int width2, int rows_in, int rows_out, int crop_h,
+                  const u64* z_in, const u64* inputs, u64* z_out) {
+  StepShape s = {width, width2, rows_in, rows_out, crop_h};
+  int L = ivc_state_len(t);
+  std::vector<BnFr> z(L);
+  for (int i = 0; i < L; i++) z[i] = BnFr::from_canonical(z_in + 4 * i);
+  StepOut r = step_eval(t, s, z, inputs);
+  for (int i = 0; i < L; i++) r.z[i].to_canonical(z_out + 4 * i);
+  return r.ok ? 1 : 0;
+}
+
+// ---------------- relaxed R1CS algebra ----------------
+#define VEC(F, name, ptr, n) std::vector<F> name(n); for (size_t _i = 0; _i < (size_t)(n); _i++) name[_i] = F::from_canonical((ptr) + 4 * _i)
+#define OUT(vec, ptr) for (size_t _i = 0; _i < vec.size(); _i++) vec[_i].to_canonical((ptr) + 4 * _i)
+
+void orc_spmv(int fid, size_t nrows, size_t ncols, const uint32_t* row_ptr, const uint32_t* col, const u64* val,
+              const u64* z, u64* out, int threads) {
+  FIELD_SWITCH(fid, { VEC(F, zz, z, ncols); std::vector<F> o(nrows); spmv<F>(nrows, row_ptr, col, val, zz.data(), o.data(), threads); OUT(o, out); });
+}
+void orc_cross_term(int fid, size_t n, const u64* az1, const u64* bz1, const u64* cz1, const u64* u1,
+                    const u64* az2, const u64* bz2, const u64* cz2, const u64* u2, u64* T) {
+  FIELD_SWITCH(fid, {
+    VEC(F, a1, az1, n); VEC(F, b1, bz1, n); VEC(F, c1, cz1, n); VEC(F, a2, az2, n); VEC(F, b2, bz2, n); VEC(F, c2, cz2, n);
+    std::vector<F> t(n);
+    cross_term<F>(n, a1.data(), b1.data(), c1.data(), F::from_canonical(u1), a2.data(), b2.data(), c2.data(), F::from_canonical(u2), t.data());
+    OUT(t, T);
+  });
+}
+void orc_axpy(int fid, size_t n, const u64* a, const u64* r, const u64* b, u64* out) {
+  FIELD_SWITCH(fid, { VEC(F, aa, a, n); VEC(F, bb, b, n); std::vector<F> o(n); axpy<F>(n, aa.data(), F::from_canonical(r), bb.data(), o.data()); OUT(o, out); });
+}
+// returns -1 if Az∘Bz == u·Cz + E for every row, else the first failing row.  E may be NULL (= 0).
+long orc_first_unsat(int fid, size_t n, const u64* az, const u64* bz, const u64* cz, const u64* u, const u64* E) {
+  long res = -1;
+  FIELD_SWITCH(fid, {
+    VEC(F, a, az, n); VEC(F, b, bz, n); VEC(F, c, cz, n);
+    std::vector<F> e; if (E) { e.resize(n); for (size_t i = 0; i < n; i++) e[i] = F::from_canonical(E + 4 * i); }
+    res = first_unsat_relaxed<F>(n, a.data(), b.data(), c.data(), F::from_canonical(u), E ? e.data() : nullptr);
+  });
+  return res;
+}
+
+}  // extern "C"
