@@ -1,0 +1,107 @@
+/* vimz_hip.h — C ABI of the MI355X (gfx950) Nova-folding accelerator for VIMz.
+ *
+ * This is the drop-in boundary: the entry points a patched nova-snark 0.23.0 / nova-scotia 0.5.0 would
+ * bind over FFI in place of its CPU arithmetic (INTEGRATION.md shows the Rust stubs).
+ * The reference has no FFI seam today — the seam is cut inside the third-party crates reached from
+ *   vimz/src/nova_snark_backend/folding.rs:22-23  (load_r1cs, create_public_params)
+ *   vimz/src/nova_snark_backend/folding.rs:35-41  (create_recursive_circuit -> RecursiveSNARK::prove_step)
+ *   vimz/src/nova_snark_backend/folding.rs:53-55  (RecursiveSNARK::verify)
+ * Each function below names the crate interface it replaces.
+ *
+ * Conventions
+ *  - Plain C: opaque handles, pointers and sizes.  No C++/torch types cross this boundary.
+ *  - A field element is 4 x uint64_t little-endian limbs (32 bytes).  `form` says whether a buffer holds
+ *    canonical integers (VIMZ_FORM_CANONICAL, what .r1cs/.wtns/JSON carry) or Montgomery residues with
+ *    R = 2^256 (VIMZ_FORM_MONTGOMERY, the in-memory layout of halo2curves / pasta_curves field types, so
+ *    Rust slices can be passed without conversion).
+ *  - An affine point is {x, y} = 8 limbs (64 bytes); the identity is (0, 0).
+ *  - The caller owns every host buffer; the library owns device memory behind handles (explicit *_free).
+ *  - Every function returns VIMZ_OK (0) or a negative error code and never throws or aborts;
+ *    vimz_last_error() returns a description for the calling context.
+ *  - One vimz_ctx per GPU.  Entry points are thread-safe (serialised per context); work is issued on the
+ *    context's own HIP stream.
+ *  - Results are exact field / group elements: outputs are bit-identical to the CPU reference.
+ */
+#ifndef VIMZ_HIP_H
+#define VIMZ_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VIMZ_OK 0
+#define VIMZ_ERR_INVALID (-1)  /* bad argument */
+#define VIMZ_ERR_HIP (-2)      /* HIP runtime failure (see vimz_last_error) */
+#define VIMZ_ERR_NO_DEVICE (-3)/* no gfx950 device / extension cannot run */
+#define VIMZ_ERR_UNSAT (-4)    /* witness does not satisfy the step relation */
+
+#define VIMZ_FORM_CANONICAL 0
+#define VIMZ_FORM_MONTGOMERY 1
+
+/* curves: coordinate field / scalar field */
+#define VIMZ_CURVE_BN254_G1 0 /* Fq / Fr : primary curve of the reference (nova_snark_backend/mod.rs:19) */
+#define VIMZ_CURVE_GRUMPKIN 1 /* Fr / Fq : secondary curve (nova_snark_backend/mod.rs:20) */
+#define VIMZ_CURVE_PALLAS 2
+#define VIMZ_CURVE_VESTA 3
+
+#define VIMZ_FIELD_BN254_FR 0
+#define VIMZ_FIELD_BN254_FQ 1
+#define VIMZ_FIELD_PALLAS_FP 2
+#define VIMZ_FIELD_VESTA_FQ 3
+
+typedef struct vimz_ctx vimz_ctx;
+typedef struct vimz_bases vimz_bases; /* commitment key resident in HBM */
+typedef struct vimz_vec vimz_vec;     /* vector of field elements resident in HBM (Montgomery form) */
+
+/* ---- context ------------------------------------------------------------------------------------- */
+int vimz_ctx_create(int device, vimz_ctx** out);
+void vimz_ctx_destroy(vimz_ctx* ctx);
+const char* vimz_last_error(const vimz_ctx* ctx);
+const char* vimz_version(void);
+/* name: caller buffer; cus / hbm_bytes may be NULL */
+int vimz_device_info(vimz_ctx* ctx, char* name, size_t name_len, int* cus, uint64_t* hbm_bytes);
+int vimz_sync(vimz_ctx* ctx);
+
+/* Stream-ordered timing with HIP events on the context's stream (used by bench.py for the roofline). */
+int vimz_timer_start(vimz_ctx* ctx);
+int vimz_timer_stop(vimz_ctx* ctx, float* ms_out);
+/* When enabled, vimz_msm* record per-kernel HIP-event durations, readable with vimz_msm_last_profile. */
+int vimz_set_profiling(vimz_ctx* ctx, int enabled);
+/* ms[6] = {hist, scan, scatter, accumulate, combine, reduce}; info[4] = {window bits, windows, sub-buckets, entries} */
+int vimz_msm_last_profile(vimz_ctx* ctx, float ms[6], uint32_t info[4]);
+
+/* ---- commitment key (replaces the `ck: Vec<G::PreprocessedGroupElement>` of nova-snark's
+ *      CommitmentKey, built by PublicParams::setup reached from folding.rs:23) ------------------------- */
+int vimz_bases_upload(vimz_ctx* ctx, int curve, const uint64_t* xy, size_t n, int form, vimz_bases** out);
+size_t vimz_bases_len(const vimz_bases* b);
+void vimz_bases_free(vimz_ctx* ctx, vimz_bases* b);
+
+/* ---- device vectors -------------------------------------------------------------------------------- */
+int vimz_vec_alloc(vimz_ctx* ctx, int field, size_t n, vimz_vec** out); /* zero-filled */
+int vimz_vec_upload(vimz_ctx* ctx, vimz_vec* v, size_t offset, const uint64_t* host, size_t n, int form);
+int vimz_vec_download(vimz_ctx* ctx, const vimz_vec* v, size_t offset, uint64_t* host, size_t n, int form);
+size_t vimz_vec_len(const vimz_vec* v);
+void vimz_vec_free(vimz_ctx* ctx, vimz_vec* v);
+
+/* ---- MSM: replaces `G::vartime_multiscalar_mul(scalars, bases)` behind `CE::commit(ck, v)`
+ *      (nova-snark 0.23.0 provider).  Computes sum_i scalars[i] * bases[i]
+ *      over the first n bases.  window_bits = 0 lets the library choose.  out_xy: affine, `out_form`. ---- */
+int vimz_msm(vimz_ctx* ctx, const vimz_bases* bases, const uint64_t* scalars, size_t n, int form,
+             int window_bits, uint64_t out_xy[8], int out_form);
+/* same, scalars already resident: elements [offset, offset+n) of v against bases [base_offset, base_offset+n) */
+int vimz_msm_vec(vimz_ctx* ctx, const vimz_bases* bases, size_t base_offset, const vimz_vec* v, size_t offset,
+                 size_t n, int window_bits, uint64_t out_xy[8], int out_form);
+
+/* ---- field-arithmetic probes (element-wise on the GPU; used by the parity tests to pin the device
+ *      Montgomery arithmetic against the oracle).  op: 0 add, 1 sub, 2 mul, 3 inverse (b ignored). -------- */
+int vimz_field_op(vimz_ctx* ctx, int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);
+/* group probes: out[i] = p[i] + q[i] (affine canonical in/out), through the device XYZZ formulas */
+int vimz_curve_add(vimz_ctx* ctx, int curve, const uint64_t* p_xy, const uint64_t* q_xy, uint64_t* out_xy, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VIMZ_HIP_H */

@@ -1,0 +1,191 @@
+"""GPU parity: device Montgomery arithmetic, XYZZ group law and the Pippenger MSM pipeline, each called
+through the C ABI (include/vimz_hip.h) and compared bit-for-bit with the CPU oracle."""
+import random
+
+import numpy as np
+import pytest
+
+from tests._oracle import CURVE_BASE, CURVE_SCALAR, GENERATORS, from_limbs, to_limbs
+
+pytestmark = pytest.mark.gpu
+
+MODULI = {
+    0: 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001,
+    1: 0x30644e72e131a029b85045b68181585d97816a916871ca8d3c208c16d87cfd47,
+    2: 0x40000000000000000000000000000000224698fc094cf91b992d30ed00000001,
+    3: 0x40000000000000000000000000000000224698fc0994a8dd8c46eb2100000001,
+}
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from vimz_amd import hip
+    c = hip.Context(0)
+    yield c
+    c.close()
+
+
+def rand_scalars(rng, n, mod):
+    return np.array([[(v >> (64 * k)) & 0xFFFFFFFFFFFFFFFF for k in range(4)] for v in (rng.randrange(mod) for _ in range(n))], dtype=np.uint64)
+
+
+@pytest.mark.parametrize("fid", [0, 1, 2, 3])
+def test_field_ops_match_oracle(ctx, oracle, fid):
+    p = MODULI[fid]
+    rng = random.Random(100 + fid)
+    edge = [0, 1, 2, p - 1, p - 2, (1 << 255) % p, (1 << 128) - 1, (1 << 32) - 1, 1 << 32, (1 << 224)]
+    a = edge + [rng.randrange(p) for _ in range(2000)]
+    b = list(reversed(edge)) + [rng.randrange(p) for _ in range(2000)]
+    A, B = to_limbs(a), to_limbs(b)
+    assert from_limbs(ctx.field_op(fid, "add", A, B)) == [(x + y) % p for x, y in zip(a, b)]
+    assert from_limbs(ctx.field_op(fid, "sub", A, B)) == [(x - y) % p for x, y in zip(a, b)]
+    got = from_limbs(ctx.field_op(fid, "mul", A, B))
+    assert got == [(x * y) % p for x, y in zip(a, b)]
+    # and against the oracle's own Montgomery implementation on a sample
+    for i in range(0, 60):
+        assert got[i] == oracle.f_mul(fid, a[i], b[i])
+    inv = from_limbs(ctx.field_op(fid, "inv", A[:64]))
+    assert inv == [pow(x, p - 2, p) for x in a[:64]]
+
+
+@pytest.mark.parametrize("cid", [0, 1, 2, 3])
+def test_group_law_matches_oracle(ctx, oracle, cid):
+    r = MODULI[CURVE_SCALAR[cid]]
+    G = GENERATORS[cid]
+    rng = random.Random(cid)
+    ks = [rng.randrange(r) for _ in range(24)]
+    pts = [oracle.curve_mul(cid, G, k) for k in ks]
+    P = pts[:12] + [pts[0], pts[1], (0, 0), pts[2], (0, 0)]
+    negp1 = oracle.curve_mul(cid, G, r - ks[1])
+    Q = pts[12:] + [pts[0], negp1, pts[3], (0, 0), (0, 0)]          # doubling, cancellation, identities
+    got = ctx.curve_add(cid, np.array([to_limbs(p).reshape(-1) for p in P]), np.array([to_limbs(q).reshape(-1) for q in Q]))
+    want = [oracle.curve_add(cid, p, q) for p, q in zip(P, Q)]
+    assert [tuple(from_limbs(g)) for g in got] == want
+    assert want[13] == (0, 0)
+
+
+def _msm_case(ctx, oracle, cid, n, scal_ints, bases=None, window_bits=0, mont=False):
+    from vimz_amd import _lib
+    if bases is None:
+        bases = oracle.seq_bases(cid, n)
+    S = to_limbs(scal_ints)
+    want = oracle.msm(cid, bases, S, threads=8)
+    B = ctx.bases_upload(cid, bases)
+    try:
+        if mont:
+            Sm = oracle.to_mont(CURVE_SCALAR[cid], S)
+            got = ctx.msm(B, Sm, form=_lib.FORM_MONTGOMERY, window_bits=window_bits)
+        else:
+            got = ctx.msm(B, S, window_bits=window_bits)
+    finally:
+        B.free()
+    assert tuple(from_limbs(got)) == want
+    return want
+
+
+@pytest.mark.parametrize("cid", [0, 1, 2, 3])
+@pytest.mark.parametrize("n", [1, 2, 33, 1000])
+def test_msm_small_all_curves(ctx, oracle, cid, n):
+    r = MODULI[CURVE_SCALAR[cid]]
+    rng = random.Random(n * 10 + cid)
+    sc = [rng.randrange(r) for _ in range(n)]
+    _msm_case(ctx, oracle, cid, n, sc)
+
+
+def test_msm_empty(ctx, oracle):
+    B = ctx.bases_upload(0, oracle.seq_bases(0, 4))
+    assert tuple(from_limbs(ctx.msm(B, np.zeros((0, 4), dtype=np.uint64)))) == (0, 0)
+    B.free()
+
+
+@pytest.mark.parametrize("c", [4, 7, 10, 13, 16])
+def test_msm_window_sizes(ctx, oracle, c):
+    r = MODULI[0]
+    rng = random.Random(c)
+    n = 3000
+    _msm_case(ctx, oracle, 0, n, [rng.randrange(r) for _ in range(n)], window_bits=c)
+
+
+def test_msm_edge_scalars(ctx, oracle):
+    r = MODULI[0]
+    n = 2048
+    rng = random.Random(5)
+    sc = [0, 1, r - 1, r - 2, 2, (1 << 253), (1 << 128) - 1, (1 << 64), 255, 256] * 8
+    sc += [rng.randrange(r) for _ in range(n - len(sc))]
+    _msm_case(ctx, oracle, 0, n, sc)
+    _msm_case(ctx, oracle, 0, n, [0] * n)
+    _msm_case(ctx, oracle, 0, n, [r - 1] * n)
+    _msm_case(ctx, oracle, 0, n, [1] * n)
+
+
+def test_msm_repeated_and_identity_bases(ctx, oracle):
+    """All bases equal (forces the doubling branch inside bucket accumulation) + identity bases."""
+    n = 4096
+    G = to_limbs(GENERATORS[0]).reshape(1, 8)
+    bases = np.tile(G, (n, 1))
+    bases[7] = 0
+    bases[100:110] = 0
+    rng = random.Random(9)
+    sc = [rng.randrange(1 << 20) for _ in range(n)]
+    sc[:64] = [3] * 64
+    got = _msm_case(ctx, oracle, 0, n, sc, bases=bases)
+    k = sum(s for i, s in enumerate(sc) if i != 7 and not (100 <= i < 110)) % MODULI[0]
+    assert got == oracle.curve_mul(0, GENERATORS[0], k)
+    # P and -P in the same bucket: cancellation inside a bucket
+    negG = oracle.curve_mul(0, GENERATORS[0], MODULI[0] - 1)
+    bases2 = np.tile(G, (64, 1))
+    bases2[1::2] = to_limbs(negG).reshape(1, 8)
+    assert _msm_case(ctx, oracle, 0, 64, [5] * 64, bases=bases2) == (0, 0)
+
+
+def test_msm_witness_like_scalars(ctx, oracle):
+    """~95 % bits/bytes, 5 % full-width: one bucket holds a third of all points -> sub-bucket split + combine."""
+    r = MODULI[0]
+    n = 60000
+    rng = random.Random(11)
+    sc = []
+    for i in range(n):
+        u = rng.random()
+        sc.append(rng.randrange(2) if u < 0.8 else rng.randrange(256) if u < 0.95 else rng.randrange(r))
+    _msm_case(ctx, oracle, 0, n, sc)
+
+
+def test_msm_montgomery_scalars_and_resident_vectors(ctx, oracle):
+    from vimz_amd import _lib
+    r = MODULI[0]
+    n = 5000
+    rng = random.Random(13)
+    sc = [rng.randrange(r) for _ in range(n)]
+    want = _msm_case(ctx, oracle, 0, n, sc, mont=True)
+    bases = oracle.seq_bases(0, n)
+    B = ctx.bases_upload(0, oracle.to_mont(CURVE_BASE[0], bases.reshape(-1, 4)).reshape(-1, 8), form=_lib.FORM_MONTGOMERY)
+    v = ctx.vec_from_host(_lib.FIELD_BN254_FR, to_limbs(sc))
+    assert tuple(from_limbs(ctx.msm_vec(B, v))) == want
+    assert from_limbs(v.download()) == sc
+    # sub-range against a base offset: sum_{i in [100,600)} s_i * P_i
+    sub = oracle.msm(0, bases[100:600], to_limbs(sc[100:600]))
+    assert tuple(from_limbs(ctx.msm_vec(B, v, n=500, offset=100, base_offset=100))) == sub
+    v.free(); B.free()
+
+
+def test_msm_large_dense(ctx, oracle):
+    """n = 2^17 uniform 254-bit scalars (the MSM(T) shape); linearity check at full size."""
+    r = MODULI[0]
+    n = 1 << 17
+    rs = np.random.default_rng(1)
+    raw = rs.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+    raw[:, 3] &= np.uint64((1 << 60) - 1)       # < 2^252 < r
+    bases = oracle.seq_bases(0, n)
+    want = oracle.msm(0, bases, raw, threads=8)
+    B = ctx.bases_upload(0, bases)
+    got = tuple(from_limbs(ctx.msm(B, raw)))
+    assert got == want
+    # linearity: MSM(s) + MSM(s') == MSM(s + s')  (size-independent property)
+    raw2 = rs.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+    raw2[:, 3] &= np.uint64((1 << 60) - 1)
+    s1, s2 = from_limbs(raw), from_limbs(raw2)
+    ssum = to_limbs([(a + b) % r for a, b in zip(s1, s2)])
+    g2 = tuple(from_limbs(ctx.msm(B, raw2)))
+    g3 = tuple(from_limbs(ctx.msm(B, ssum)))
+    assert oracle.curve_add(0, got, g2) == g3
+    B.free()

@@ -1,0 +1,315 @@
+// C ABI (include/vimz_hip.h) over the gfx950 kernels.  One translation unit: the kernels are templates
+// over the four curves / fields and are instantiated from here.
+#include <hip/hip_runtime.h>
+#include <mutex>
+#include <new>
+#include <string>
+#include <cstring>
+#include <cstdio>
+
+#include "../../include/vimz_hip.h"
+#include "ec.hpp"
+#include "msm_api.hpp"
+#include "vecops_api.hpp"
+
+using namespace vz;
+
+struct vimz_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t t0 = nullptr, t1 = nullptr;
+  hipEvent_t ev[7] = {};
+  bool profiling = false;
+  MsmWorkspace msm_ws;
+  MsmStats last_msm = {};
+  std::mutex mu;
+  std::string err;
+  void* scratch = nullptr;  // device staging for host-scalar MSM / probes
+  size_t scratch_bytes = 0;
+};
+struct vimz_bases { int curve; size_t n; uint32_t* d; };
+struct vimz_vec { int field; size_t n; uint32_t* d; };
+
+static thread_local std::string g_err_noctx;
+
+static int fail(vimz_ctx* c, int code, const char* what, hipError_t e = hipSuccess) {
+  std::string m = what;
+  if (e != hipSuccess) { m += ": "; m += hipGetErrorString(e); }
+  if (c) c->err = m; else g_err_noctx = m;
+  return code;
+}
+#define HIP_TRY(c, x) do { hipError_t _e = (x); if (_e != hipSuccess) return fail(c, VIMZ_ERR_HIP, #x, _e); } while (0)
+
+static int ensure_scratch(vimz_ctx* c, size_t bytes) {
+  if (bytes <= c->scratch_bytes) return VIMZ_OK;
+  if (c->scratch) hipFree(c->scratch);
+  c->scratch = nullptr; c->scratch_bytes = 0;
+  HIP_TRY(c, hipMalloc(&c->scratch, bytes));
+  c->scratch_bytes = bytes;
+  return VIMZ_OK;
+}
+
+template <class Fn>
+static int field_dispatch(int field, Fn fn) {
+  switch (field) {
+    case VIMZ_FIELD_BN254_FR: return fn(Fp<BnFr>());
+    case VIMZ_FIELD_BN254_FQ: return fn(Fp<BnFq>());
+    case VIMZ_FIELD_PALLAS_FP: return fn(Fp<PallasFp>());
+    case VIMZ_FIELD_VESTA_FQ: return fn(Fp<VestaFq>());
+  }
+  return VIMZ_ERR_INVALID;
+}
+template <class Fn>
+static int curve_dispatch(int curve, Fn fn) {
+  switch (curve) {
+    case VIMZ_CURVE_BN254_G1: return fn(BnG1());
+    case VIMZ_CURVE_GRUMPKIN: return fn(Grumpkin());
+    case VIMZ_CURVE_PALLAS: return fn(Pallas());
+    case VIMZ_CURVE_VESTA: return fn(Vesta());
+  }
+  return VIMZ_ERR_INVALID;
+}
+static int curve_base_field(int curve) {
+  switch (curve) {
+    case VIMZ_CURVE_BN254_G1: return VIMZ_FIELD_BN254_FQ;
+    case VIMZ_CURVE_GRUMPKIN: return VIMZ_FIELD_BN254_FR;
+    case VIMZ_CURVE_PALLAS: return VIMZ_FIELD_PALLAS_FP;
+    default: return VIMZ_FIELD_VESTA_FQ;
+  }
+}
+static int curve_scalar_field(int curve) {
+  switch (curve) {
+    case VIMZ_CURVE_BN254_G1: return VIMZ_FIELD_BN254_FR;
+    case VIMZ_CURVE_GRUMPKIN: return VIMZ_FIELD_BN254_FQ;
+    case VIMZ_CURVE_PALLAS: return VIMZ_FIELD_VESTA_FQ;
+    default: return VIMZ_FIELD_PALLAS_FP;
+  }
+}
+
+extern "C" {
+
+const char* vimz_version(void) { return "vimz-hip 0.1 (gfx950)"; }
+
+int vimz_ctx_create(int device, vimz_ctx** out) {
+  if (!out) return fail(nullptr, VIMZ_ERR_INVALID, "out is NULL");
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count == 0) return fail(nullptr, VIMZ_ERR_NO_DEVICE, "no HIP device visible", e);
+  if (device < 0 || device >= count) return fail(nullptr, VIMZ_ERR_INVALID, "device index out of range");
+  vimz_ctx* c = new (std::nothrow) vimz_ctx();
+  if (!c) return fail(nullptr, VIMZ_ERR_INVALID, "out of host memory");
+  c->device = device;
+  if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
+      (e = hipEventCreate(&c->t0)) != hipSuccess || (e = hipEventCreate(&c->t1)) != hipSuccess) {
+    delete c; return fail(nullptr, VIMZ_ERR_HIP, "context setup", e);
+  }
+  for (int i = 0; i < 7; i++) if ((e = hipEventCreate(&c->ev[i])) != hipSuccess) { delete c; return fail(nullptr, VIMZ_ERR_HIP, "event", e); }
+  *out = c;
+  return VIMZ_OK;
+}
+
+void vimz_ctx_destroy(vimz_ctx* c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  hipStreamSynchronize(c->stream);
+  c->msm_ws.release();
+  if (c->scratch) hipFree(c->scratch);
+  for (int i = 0; i < 7; i++) if (c->ev[i]) hipEventDestroy(c->ev[i]);
+  hipEventDestroy(c->t0); hipEventDestroy(c->t1);
+  hipStreamDestroy(c->stream);
+  delete c;
+}
+
+const char* vimz_last_error(const vimz_ctx* c) { return c ? c->err.c_str() : g_err_noctx.c_str(); }
+
+int vimz_device_info(vimz_ctx* c, char* name, size_t name_len, int* cus, uint64_t* hbm_bytes) {
+  if (!c) return VIMZ_ERR_INVALID;
+  hipDeviceProp_t p;
+  HIP_TRY(c, hipGetDeviceProperties(&p, c->device));
+  if (name && name_len) { snprintf(name, name_len, "%s (%s)", p.name, p.gcnArchName); }
+  if (cus) *cus = p.multiProcessorCount;
+  if (hbm_bytes) *hbm_bytes = p.totalGlobalMem;
+  return VIMZ_OK;
+}
+
+int vimz_sync(vimz_ctx* c) {
+  if (!c) return VIMZ_ERR_INVALID;
+  std::lock_guard<std::mutex> g(c->mu);
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return VIMZ_OK;
+}
+
+int vimz_timer_start(vimz_ctx* c) {
+  if (!c) return VIMZ_ERR_INVALID;
+  std::lock_guard<std::mutex> g(c->mu);
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipEventRecord(c->t0, c->stream));
+  return VIMZ_OK;
+}
+int vimz_timer_stop(vimz_ctx* c, float* ms) {
+  if (!c || !ms) return VIMZ_ERR_INVALID;
+  std::lock_guard<std::mutex> g(c->mu);
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipEventRecord(c->t1, c->stream));
+  HIP_TRY(c, hipEventSynchronize(c->t1));
+  HIP_TRY(c, hipEventElapsedTime(ms, c->t0, c->t1));
+  return VIMZ_OK;
+}
+int vimz_set_profiling(vimz_ctx* c, int enabled) { if (!c) return VIMZ_ERR_INVALID; c->profiling = enabled != 0; return VIMZ_OK; }
+int vimz_msm_last_profile(vimz_ctx* c, float ms[6], uint32_t info[4]) {
+  if (!c) return VIMZ_ERR_INVALID;
+  if (ms) memcpy(ms, c->last_msm.ms, sizeof(float) * 6);
+  if (info) { info[0] = c->last_msm.c; info[1] = c->last_msm.K; info[2] = c->last_msm.subs; info[3] = c->last_msm.entries; }
+  return VIMZ_OK;
+}
+
+// ---- commitment key ----------------------------------------------------------------------------------
+int vimz_bases_upload(vimz_ctx* c, int curve, const uint64_t* xy, size_t n, int form, vimz_bases** out) {
+  if (!c || !out || (!xy && n) || curve < 0 || curve > 3) return fail(c, VIMZ_ERR_INVALID, "vimz_bases_upload: bad argument");
+  std::lock_guard<std::mutex> g(c->mu);
+  HIP_TRY(c, hipSetDevice(c->device));
+  vimz_bases* b = new vimz_bases{curve, n, nullptr};
+  if (n) {
+    hipError_t e = hipMalloc(&b->d, 64 * n);
+    if (e != hipSuccess) { delete b; return fail(c, VIMZ_ERR_HIP, "hipMalloc(bases)", e); }
+    e = hipMemcpyAsync(b->d, xy, 64 * n, hipMemcpyHostToDevice, c->stream);
+    if (e != hipSuccess) { hipFree(b->d); delete b; return fail(c, VIMZ_ERR_HIP, "copy bases", e); }
+    if (form == VIMZ_FORM_CANONICAL) {
+      int rc = field_dispatch(curve_base_field(curve), [&](auto f) { typedef decltype(f) F; launch_to_mont<F>(c->stream, b->d, 2 * n); return VIMZ_OK; });
+      if (rc) { hipFree(b->d); delete b; return rc; }
+    }
+    e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { hipFree(b->d); delete b; return fail(c, VIMZ_ERR_HIP, "bases sync", e); }
+  }
+  *out = b;
+  return VIMZ_OK;
+}
+size_t vimz_bases_len(const vimz_bases* b) { return b ? b->n : 0; }
+void vimz_bases_free(vimz_ctx* c, vimz_bases* b) {
+  if (!b) return;
+  if (c) { std::lock_guard<std::mutex> g(c->mu); hipSetDevice(c->device); hipStreamSynchronize(c->stream); if (b->d) hipFree(b->d); }
+  delete b;
+}
+
+// ---- device vectors ----------------------------------------------------------------------------------
+int vimz_vec_alloc(vimz_ctx* c, int field, size_t n, vimz_vec** out) {
+  if (!c || !out || field < 0 || field > 3) return fail(c, VIMZ_ERR_INVALID, "vimz_vec_alloc: bad argument");
+  std::lock_guard<std::mutex> g(c->mu);
+  HIP_TRY(c, hipSetDevice(c->device));
+  vimz_vec* v = new vimz_vec{field, n, nullptr};
+  if (n) {
+    hipError_t e = hipMalloc(&v->d, 32 * n);
+    if (e != hipSuccess) { delete v; return fail(c, VIMZ_ERR_HIP, "hipMalloc(vec)", e); }
+    e = hipMemsetAsync(v->d, 0, 32 * n, c->stream);
+    if (e != hipSuccess) { hipFree(v->d); delete v; return fail(c, VIMZ_ERR_HIP, "memset(vec)", e); }
+  }
+  *out = v;
+  return VIMZ_OK;
+}
+int vimz_vec_upload(vimz_ctx* c, vimz_vec* v, size_t offset, const uint64_t* host, size_t n, int form) {
+  if (!c || !v || (!host && n) || offset + n > v->n) return fail(c, VIMZ_ERR_INVALID, "vimz_vec_upload: bad argument");
+  if (!n) return VIMZ_OK;
+  std::lock_guard<std::mutex> g(c->mu);
+  HIP_TRY(c, hipSetDevice(c->device));
+  uint32_t* dst = v->d + 8 * offset;
+  HIP_TRY(c, hipMemcpyAsync(dst, host, 32 * n, hipMemcpyHostToDevice, c->stream));
+  if (form == VIMZ_FORM_CANONICAL)
+    field_dispatch(v->field, [&](auto f) { typedef decltype(f) F; launch_to_mont<F>(c->stream, dst, n); return VIMZ_OK; });
+  HIP_TRY(c, hipStreamSynchronize(c->stream));  // host buffer may be reused by the caller
+  return VIMZ_OK;
+}
+int vimz_vec_download(vimz_ctx* c, const vimz_vec* v, size_t offset, uint64_t* host, size_t n, int form) {
+  if (!c || !v || (!host && n) || offset + n > v->n) return fail(c, VIMZ_ERR_INVALID, "vimz_vec_download: bad argument");
+  if (!n) return VIMZ_OK;
+  std::lock_guard<std::mutex> g(c->mu);
+  HIP_TRY(c, hipSetDevice(c->device));
+  const uint32_t* src = v->d + 8 * offset;
+  if (form == VIMZ_FORM_CANONICAL) {
+    int rc = ensure_scratch(c, 32 * n); if (rc) return rc;
+    field_dispatch(v->field, [&](auto f) { typedef decltype(f) F; launch_from_mont<F>(c->stream, src, (uint32_t*)c->scratch, n); return VIMZ_OK; });
+    src = (const uint32_t*)c->scratch;
+  }
+  HIP_TRY(c, hipMemcpyAsync(host, src, 32 * n, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return VIMZ_OK;
+}
+size_t vimz_vec_len(const vimz_vec* v) { return v ? v->n : 0; }
+void vimz_vec_free(vimz_ctx* c, vimz_vec* v) {
+  if (!v) return;
+  if (c) { std::lock_guard<std::mutex> g(c->mu); hipSetDevice(c->device); hipStreamSynchronize(c->stream); if (v->d) hipFree(v->d); }
+  delete v;
+}
+
+// ---- MSM ---------------------------------------------------------------------------------------------
+static int msm_device(vimz_ctx* c, const vimz_bases* bases, size_t base_offset, const uint32_t* d_scalars, size_t n,
+                      int scalars_mont, int window_bits, uint64_t out_xy[8], int out_form) {
+  return curve_dispatch(bases->curve, [&](auto cv) {
+    typedef decltype(cv) C;
+    typedef typename C::Base F;
+    Affine<F> r;
+    hipError_t e = msm_run<C>(c->stream, c->msm_ws, bases->d + 16 * base_offset, d_scalars, n, scalars_mont, window_bits, &r,
+                              &c->last_msm, c->profiling ? c->ev : nullptr);
+    if (e != hipSuccess) return fail(c, VIMZ_ERR_HIP, "msm", e);
+    if (out_form == VIMZ_FORM_CANONICAL) { r.x = F::from_mont(r.x); r.y = F::from_mont(r.y); }
+    memcpy(out_xy, r.x.v, 32); memcpy(out_xy + 4, r.y.v, 32);
+    return VIMZ_OK;
+  });
+}
+
+int vimz_msm(vimz_ctx* c, const vimz_bases* bases, const uint64_t* scalars, size_t n, int form, int window_bits,
+             uint64_t out_xy[8], int out_form) {
+  if (!c || !bases || !out_xy || (!scalars && n) || n > bases->n) return fail(c, VIMZ_ERR_INVALID, "vimz_msm: bad argument");
+  std::lock_guard<std::mutex> g(c->mu);
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (n) {
+    int rc = ensure_scratch(c, 32 * n); if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->scratch, scalars, 32 * n, hipMemcpyHostToDevice, c->stream));
+  }
+  return msm_device(c, bases, 0, (const uint32_t*)c->scratch, n, form == VIMZ_FORM_MONTGOMERY, window_bits, out_xy, out_form);
+}
+
+int vimz_msm_vec(vimz_ctx* c, const vimz_bases* bases, size_t base_offset, const vimz_vec* v, size_t offset, size_t n,
+                 int window_bits, uint64_t out_xy[8], int out_form) {
+  if (!c || !bases || !v || !out_xy || offset + n > v->n || base_offset + n > bases->n)
+    return fail(c, VIMZ_ERR_INVALID, "vimz_msm_vec: bad argument");
+  if (v->field != curve_scalar_field(bases->curve)) return fail(c, VIMZ_ERR_INVALID, "vimz_msm_vec: vector is not over the curve's scalar field");
+  std::lock_guard<std::mutex> g(c->mu);
+  HIP_TRY(c, hipSetDevice(c->device));
+  return msm_device(c, bases, base_offset, v->d + 8 * offset, n, 1, window_bits, out_xy, out_form);
+}
+
+// ---- probes ------------------------------------------------------------------------------------------
+int vimz_field_op(vimz_ctx* c, int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
+  if (!c || !a || !out || op < 0 || op > 3 || (op != 3 && !b)) return fail(c, VIMZ_ERR_INVALID, "vimz_field_op: bad argument");
+  if (!n) return VIMZ_OK;
+  std::lock_guard<std::mutex> g(c->mu);
+  HIP_TRY(c, hipSetDevice(c->device));
+  int rc = ensure_scratch(c, 96 * n); if (rc) return rc;
+  uint32_t* da = (uint32_t*)c->scratch; uint32_t* db = da + 8 * n; uint32_t* dout = db + 8 * n;
+  HIP_TRY(c, hipMemcpyAsync(da, a, 32 * n, hipMemcpyHostToDevice, c->stream));
+  if (b) HIP_TRY(c, hipMemcpyAsync(db, b, 32 * n, hipMemcpyHostToDevice, c->stream));
+  rc = field_dispatch(field, [&](auto f) { typedef decltype(f) F; launch_field_probe<F>(c->stream, op, da, db, dout, n); return VIMZ_OK; });
+  if (rc) return fail(c, rc, "vimz_field_op: bad field");
+  HIP_TRY(c, hipMemcpyAsync(out, dout, 32 * n, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return VIMZ_OK;
+}
+
+int vimz_curve_add(vimz_ctx* c, int curve, const uint64_t* p, const uint64_t* q, uint64_t* out, size_t n) {
+  if (!c || !p || !q || !out) return fail(c, VIMZ_ERR_INVALID, "vimz_curve_add: bad argument");
+  if (!n) return VIMZ_OK;
+  std::lock_guard<std::mutex> g(c->mu);
+  HIP_TRY(c, hipSetDevice(c->device));
+  int rc = ensure_scratch(c, 192 * n); if (rc) return rc;
+  uint32_t* dp = (uint32_t*)c->scratch; uint32_t* dq = dp + 16 * n; uint32_t* dout = dq + 16 * n;
+  HIP_TRY(c, hipMemcpyAsync(dp, p, 64 * n, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(dq, q, 64 * n, hipMemcpyHostToDevice, c->stream));
+  rc = curve_dispatch(curve, [&](auto cv) { typedef typename decltype(cv)::Base F; launch_curve_add_probe<F>(c->stream, dp, dq, dout, n); return VIMZ_OK; });
+  if (rc) return fail(c, rc, "vimz_curve_add: bad curve");
+  HIP_TRY(c, hipMemcpyAsync(out, dout, 64 * n, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return VIMZ_OK;
+}
+
+}  // extern "C"

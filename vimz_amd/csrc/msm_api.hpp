@@ -1,0 +1,108 @@
+// Pippenger multi-scalar multiplication for gfx950 — replaces `cpu_best_multiexp` / `pasta_msm`
+// behind `CommitmentEngine::commit` in nova-snark 0.23.0 (SURVEY.md §8a rows M1/M2, §8b "MSM" seam).
+//
+// Pipeline (all on one HIP stream, no host round trip until the K window sums come back):
+//   1. k_hist      signed-digit recode of every scalar (window c bits, digits in [-2^(c-1), 2^(c-1)]),
+//                  histogram of (window, |digit|) buckets with global atomics.
+//   2. k_scan      one workgroup: exclusive scan of bucket sizes -> entry offsets, and of
+//                  ceil(size/SUB) -> sub-bucket offsets.  Large buckets (witness scalars are ~95 % bits
+//                  and bytes, so bucket "1" of window 0 can hold a third of all points) are split into
+//                  sub-buckets of at most SUB entries so no thread owns an unbounded chain.
+//   3. k_scatter   counting-sort scatter of (point index | sign) into bucket order.
+//   4. k_accum     one thread per sub-bucket: gathers its affine bases (64 B each, served from L2 /
+//                  Infinity Cache — the base table is reused by every window) and accumulates in XYZZ.
+//   5. k_combine   log2 passes folding the sub-bucket partials of each bucket pairwise.
+//   6. k_reduce    per window: chunked running sums + LDS tree -> Σ b·B_b.
+//   7. host        Horner over the K window sums (K·c doublings) and one inversion to affine.
+// Addition order inside a bucket depends on atomics, but the result is an exact group element, so
+// the affine output is bit-identical run to run and to the CPU oracle.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <vector>
+#include <algorithm>
+#include "ec.hpp"
+
+namespace vz {
+
+#define VZ_HIP_CHECK(x) do { hipError_t _e = (x); if (_e != hipSuccess) return _e; } while (0)
+
+constexpr int MSM_SUB = 128;         // max entries one thread accumulates in k_accum
+constexpr int MSM_MAX_WINDOWS = 64;
+
+struct MsmPlan {
+  int c;            // window bits
+  int K;            // windows
+  uint32_t nbw;     // buckets per window = 2^(c-1)
+  uint32_t nb;      // total buckets
+};
+
+static inline MsmPlan msm_plan(size_t n, int scalar_bits, int c_override) {
+  MsmPlan p;
+  int c = c_override;
+  if (c <= 0) {
+    // bucket-accumulate cost ~ n*K adds, reduce cost ~ 2*K*2^(c-1): pick c minimising the sum
+    double best = 1e300; c = 8;
+    for (int t = 6; t <= 16; t++) {
+      int K = (scalar_bits + 1 + t - 1) / t;
+      double cost = (double)n * K + 2.5 * K * (double)(1u << (t - 1));
+      if (cost < best) { best = cost; c = t; }
+    }
+  }
+  p.c = c;
+  p.K = (scalar_bits + 1 + c - 1) / c;
+  p.nbw = 1u << (c - 1);
+  p.nb = p.nbw * (uint32_t)p.K;
+  return p;
+}
+
+struct MsmWorkspace {  // device buffers, grown on demand and reused across calls
+  uint32_t* counts = nullptr;      // nb
+  uint32_t* cursor = nullptr;      // nb
+  uint32_t* bucket_off = nullptr;  // nb + 1
+  uint32_t* sub_off = nullptr;     // nb + 1
+  uint32_t* sorted = nullptr;      // K * n
+  uint32_t* sub_bucket = nullptr;  // max_subs
+  uint32_t* sub_k = nullptr;       // max_subs
+  void* partial = nullptr;         // max_subs * sizeof(XYZZ)
+  void* window_sums = nullptr;     // K * sizeof(XYZZ)
+  uint32_t* totals = nullptr;      // [0] = total subs
+  size_t cap_nb = 0, cap_entries = 0, cap_subs = 0;
+  void* host_pinned = nullptr;     // MSM_MAX_WINDOWS * 128 B
+
+  hipError_t reserve(uint32_t nb, size_t entries, size_t subs) {
+    if (nb > cap_nb) {
+      hipFree(counts); hipFree(cursor); hipFree(bucket_off); hipFree(sub_off);
+      VZ_HIP_CHECK(hipMalloc(&counts, 4 * (size_t)nb)); VZ_HIP_CHECK(hipMalloc(&cursor, 4 * (size_t)nb));
+      VZ_HIP_CHECK(hipMalloc(&bucket_off, 4 * ((size_t)nb + 1))); VZ_HIP_CHECK(hipMalloc(&sub_off, 4 * ((size_t)nb + 1)));
+      cap_nb = nb;
+    }
+    if (entries > cap_entries) {
+      hipFree(sorted); VZ_HIP_CHECK(hipMalloc(&sorted, 4 * entries)); cap_entries = entries;
+    }
+    if (subs > cap_subs) {
+      hipFree(sub_bucket); hipFree(sub_k); hipFree(partial);
+      VZ_HIP_CHECK(hipMalloc(&sub_bucket, 4 * subs)); VZ_HIP_CHECK(hipMalloc(&sub_k, 4 * subs));
+      VZ_HIP_CHECK(hipMalloc(&partial, 128 * subs)); cap_subs = subs;
+    }
+    if (!window_sums) VZ_HIP_CHECK(hipMalloc(&window_sums, 128 * MSM_MAX_WINDOWS));
+    if (!totals) VZ_HIP_CHECK(hipMalloc(&totals, 64));
+    if (!host_pinned) VZ_HIP_CHECK(hipHostMalloc(&host_pinned, 128 * MSM_MAX_WINDOWS));
+    return hipSuccess;
+  }
+  void release() {
+    hipFree(counts); hipFree(cursor); hipFree(bucket_off); hipFree(sub_off); hipFree(sorted);
+    hipFree(sub_bucket); hipFree(sub_k); hipFree(partial); hipFree(window_sums); hipFree(totals);
+    if (host_pinned) hipHostFree(host_pinned);
+    *this = MsmWorkspace();
+  }
+};
+
+struct MsmStats { int c, K; uint32_t subs, entries; float ms[6]; };  // ms: hist, scan, scatter, accum, combine, reduce
+
+// Defined in msm.hpp; explicitly instantiated per curve in msm_inst_*.hip.
+template <class C>
+hipError_t msm_run(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_bases, const uint32_t* d_scalars, size_t n,
+                   int scalars_mont, int c_override, Affine<typename C::Base>* out_affine_mont, MsmStats* stats,
+                   hipEvent_t* ev /* 7 events or nullptr */);
+
+}  // namespace vz

@@ -1,0 +1,6 @@
+// Explicit instantiation of the MSM pipeline for one curve (one TU per curve so the build parallelises).
+#include "msm.hpp"
+namespace vz {
+template hipError_t msm_run<Pallas>(hipStream_t, MsmWorkspace&, const uint32_t*, const uint32_t*, size_t, int, int,
+                                  Affine<Pallas::Base>*, MsmStats*, hipEvent_t*);
+}

@@ -1,0 +1,148 @@
+"""Thin object wrapper over the C ABI (include/vimz_hip.h) for Python callers: tests, bench.py and the
+host-side folding driver.  Arrays are numpy uint64 with 4 limbs per field element; nothing is computed here.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _u64(a):
+    return np.ascontiguousarray(a, dtype=np.uint64)
+
+
+class DeviceVec:
+    def __init__(self, ctx, handle, field, n):
+        self.ctx, self.h, self.field, self.n = ctx, handle, field, n
+
+    def upload(self, host, offset=0, form=L.FORM_CANONICAL):
+        host = _u64(host)
+        self.ctx._chk(self.ctx.lib.vimz_vec_upload(self.ctx.h, self.h, offset, _ptr(host), host.size // 4, form))
+        return self
+
+    def download(self, offset=0, n=None, form=L.FORM_CANONICAL):
+        n = self.n - offset if n is None else n
+        out = np.zeros((n, 4), dtype=np.uint64)
+        self.ctx._chk(self.ctx.lib.vimz_vec_download(self.ctx.h, self.h, offset, _ptr(out), n, form))
+        return out
+
+    def free(self):
+        if self.h:
+            self.ctx.lib.vimz_vec_free(self.ctx.h, self.h)
+            self.h = None
+
+
+class Bases:
+    def __init__(self, ctx, handle, curve, n):
+        self.ctx, self.h, self.curve, self.n = ctx, handle, curve, n
+
+    def free(self):
+        if self.h:
+            self.ctx.lib.vimz_bases_free(self.ctx.h, self.h)
+            self.h = None
+
+
+class Context:
+    """One per GPU (vimz_ctx)."""
+
+    def __init__(self, device=0):
+        self.lib = L.lib()
+        h = C.c_void_p()
+        rc = self.lib.vimz_ctx_create(device, C.byref(h))
+        if rc != L.OK:
+            raise L.VimzError(rc, self.lib.vimz_last_error(None).decode())
+        self.h = h
+
+    def _chk(self, rc):
+        if rc != L.OK:
+            raise L.VimzError(rc, self.lib.vimz_last_error(self.h).decode())
+
+    def close(self):
+        if self.h:
+            self.lib.vimz_ctx_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        cus, hbm = C.c_int(), C.c_uint64()
+        self._chk(self.lib.vimz_device_info(self.h, name, 256, C.byref(cus), C.byref(hbm)))
+        return {"name": name.value.decode(), "cus": cus.value, "hbm_bytes": hbm.value}
+
+    def sync(self):
+        self._chk(self.lib.vimz_sync(self.h))
+
+    def timer_start(self):
+        self._chk(self.lib.vimz_timer_start(self.h))
+
+    def timer_stop(self):
+        ms = C.c_float()
+        self._chk(self.lib.vimz_timer_stop(self.h, C.byref(ms)))
+        return ms.value
+
+    def set_profiling(self, on):
+        self._chk(self.lib.vimz_set_profiling(self.h, 1 if on else 0))
+
+    def msm_last_profile(self):
+        ms = (C.c_float * 6)()
+        info = (C.c_uint32 * 4)()
+        self._chk(self.lib.vimz_msm_last_profile(self.h, ms, info))
+        names = ["hist", "scan", "scatter", "accumulate", "combine", "reduce"]
+        return {"ms": dict(zip(names, list(ms))), "window_bits": info[0], "windows": info[1], "sub_buckets": info[2], "entries": info[3]}
+
+    # ---- commitment key / vectors
+    def bases_upload(self, curve, xy, form=L.FORM_CANONICAL):
+        xy = _u64(xy)
+        n = xy.size // 8
+        h = C.c_void_p()
+        self._chk(self.lib.vimz_bases_upload(self.h, curve, _ptr(xy), n, form, C.byref(h)))
+        return Bases(self, h, curve, n)
+
+    def vec_alloc(self, field, n):
+        h = C.c_void_p()
+        self._chk(self.lib.vimz_vec_alloc(self.h, field, n, C.byref(h)))
+        return DeviceVec(self, h, field, n)
+
+    def vec_from_host(self, field, host, form=L.FORM_CANONICAL):
+        host = _u64(host)
+        v = self.vec_alloc(field, host.size // 4)
+        return v.upload(host, 0, form)
+
+    # ---- MSM
+    def msm(self, bases, scalars, form=L.FORM_CANONICAL, window_bits=0, out_form=L.FORM_CANONICAL):
+        scalars = _u64(scalars)
+        out = np.zeros(8, dtype=np.uint64)
+        self._chk(self.lib.vimz_msm(self.h, bases.h, _ptr(scalars), scalars.size // 4, form, window_bits, _ptr(out), out_form))
+        return out
+
+    def msm_vec(self, bases, vec, n=None, offset=0, base_offset=0, window_bits=0, out_form=L.FORM_CANONICAL):
+        n = vec.n - offset if n is None else n
+        out = np.zeros(8, dtype=np.uint64)
+        self._chk(self.lib.vimz_msm_vec(self.h, bases.h, base_offset, vec.h, offset, n, window_bits, _ptr(out), out_form))
+        return out
+
+    # ---- probes
+    def field_op(self, field, op, a, b=None):
+        a = _u64(a)
+        n = a.size // 4
+        b = _u64(b) if b is not None else None
+        out = np.zeros((n, 4), dtype=np.uint64)
+        self._chk(self.lib.vimz_field_op(self.h, field, {"add": 0, "sub": 1, "mul": 2, "inv": 3}[op], _ptr(a), _ptr(b), _ptr(out), n))
+        return out
+
+    def curve_add(self, curve, p, q):
+        p, q = _u64(p), _u64(q)
+        n = p.size // 8
+        out = np.zeros((n, 8), dtype=np.uint64)
+        self._chk(self.lib.vimz_curve_add(self.h, curve, _ptr(p), _ptr(q), _ptr(out), n))
+        return out
