@@ -76,6 +76,10 @@ int vimz_msm_last_profile(vimz_ctx* ctx, float ms[6], uint32_t info[4]);
 /* ---- commitment key (replaces the `ck: Vec<G::PreprocessedGroupElement>` of nova-snark's
  *      CommitmentKey, built by PublicParams::setup reached from folding.rs:23) ------------------------- */
 int vimz_bases_upload(vimz_ctx* ctx, int curve, const uint64_t* xy, size_t n, int form, vimz_bases** out);
+/* Derive n generators on the GPU: ck_i = try-and-increment(SHAKE256(label || LE64(i) || LE32(ctr))), see
+ * vimz_amd/csrc/ckgen.hpp (the role of nova-snark's `CommitmentKey::setup(b"ck", n)`; not byte-compatible with it). */
+int vimz_bases_generate(vimz_ctx* ctx, int curve, const char* label, size_t label_len, size_t n, vimz_bases** out);
+int vimz_bases_download(vimz_ctx* ctx, const vimz_bases* b, size_t offset, uint64_t* xy, size_t n, int form);
 size_t vimz_bases_len(const vimz_bases* b);
 void vimz_bases_free(vimz_ctx* ctx, vimz_bases* b);
 

@@ -189,3 +189,20 @@ def test_msm_large_dense(ctx, oracle):
     g3 = tuple(from_limbs(ctx.msm(B, ssum)))
     assert oracle.curve_add(0, got, g2) == g3
     B.free()
+
+
+@pytest.mark.parametrize("cid", [0, 1, 2, 3])
+def test_commitment_key_derivation(ctx, oracle, cid):
+    """GPU SHAKE256 try-and-increment generators == Python hashlib restatement; all on the curve."""
+    from tests._oracle import ck_derive
+    n = 300
+    B = ctx.bases_generate(cid, n, label=b"ck")
+    pts = B.download()
+    B.free()
+    for i in list(range(40)) + [n - 1]:
+        got = tuple(from_limbs(pts[i]))
+        assert got == ck_derive(cid, b"ck", i), i
+        assert oracle.on_curve(cid, got)
+    B2 = ctx.bases_generate(cid, 8, label=b"other")
+    assert tuple(from_limbs(B2.download()[0])) == ck_derive(cid, b"other", 0) != tuple(from_limbs(pts[0]))
+    B2.free()

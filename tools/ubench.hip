@@ -87,7 +87,7 @@ __global__ void k_fpmul(uint32_t* out, uint32_t seed, int iters) {
 __global__ void k_madd(uint32_t* out, uint32_t seed, int iters) {
   Affine<F> q; q.x = F::one(); q.y = F::dbl(F::one());  // (1,2) is on BN254 G1
   XYZZ<F> acc = dbl_affine(q);
-  if (seed == 12345 && threadIdx.x == 9999) acc.X.v[0] ^= 1;
+  acc.X.v[0] ^= threadIdx.x + seed; acc.Y.v[1] ^= blockIdx.x;  // lane-dependent (keeps the work on the VALU)
   for (int i = 0; i < iters; i++) add_mixed(acc, q);
   uint32_t r = 0; for (int k = 0; k < 8; k++) r ^= acc.X.v[k] ^ acc.ZZ.v[k];
   out[blockIdx.x * blockDim.x + threadIdx.x] = r;

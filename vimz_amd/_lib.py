@@ -50,6 +50,8 @@ def lib():
         L.vimz_set_profiling.argtypes = [vp, i]
         L.vimz_msm_last_profile.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
         L.vimz_bases_upload.argtypes = [vp, i, u64p, sz, i, C.POINTER(vp)]
+        L.vimz_bases_generate.argtypes = [vp, i, C.c_char_p, sz, sz, C.POINTER(vp)]
+        L.vimz_bases_download.argtypes = [vp, vp, sz, u64p, sz, i]
         L.vimz_bases_len.argtypes = [vp]
         L.vimz_bases_len.restype = sz
         L.vimz_bases_free.argtypes = [vp, vp]

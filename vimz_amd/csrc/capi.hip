@@ -11,6 +11,7 @@
 #include "ec.hpp"
 #include "msm_api.hpp"
 #include "vecops_api.hpp"
+#include "ckgen.hpp"
 
 using namespace vz;
 
@@ -183,6 +184,42 @@ int vimz_bases_upload(vimz_ctx* c, int curve, const uint64_t* xy, size_t n, int 
     if (e != hipSuccess) { hipFree(b->d); delete b; return fail(c, VIMZ_ERR_HIP, "bases sync", e); }
   }
   *out = b;
+  return VIMZ_OK;
+}
+int vimz_bases_generate(vimz_ctx* c, int curve, const char* label, size_t label_len, size_t n, vimz_bases** out) {
+  if (!c || !out || (!label && label_len) || label_len > 64 || curve < 0 || curve > 3) return fail(c, VIMZ_ERR_INVALID, "vimz_bases_generate: bad argument");
+  std::lock_guard<std::mutex> g(c->mu);
+  HIP_TRY(c, hipSetDevice(c->device));
+  vimz_bases* b = new vimz_bases{curve, n, nullptr};
+  if (n) {
+    hipError_t e = hipMalloc(&b->d, 64 * n);
+    if (e != hipSuccess) { delete b; return fail(c, VIMZ_ERR_HIP, "hipMalloc(bases)", e); }
+    CkLabel L; memset(&L, 0, sizeof(L)); memcpy(L.bytes, label, label_len); L.len = (int)label_len;
+    static const int B_COEF[4] = {3, -17, 5, 5};
+    int rc = field_dispatch(curve_base_field(curve), [&](auto f) {
+      typedef decltype(f) F;
+      hipError_t e2 = ckgen_run<F>(c->stream, L, B_COEF[curve], 0, n, b->d);
+      if (e2 == hipSuccess) e2 = hipStreamSynchronize(c->stream);
+      return e2 == hipSuccess ? VIMZ_OK : fail(c, VIMZ_ERR_HIP, "ckgen", e2);
+    });
+    if (rc) { hipFree(b->d); delete b; return rc; }
+  }
+  *out = b;
+  return VIMZ_OK;
+}
+int vimz_bases_download(vimz_ctx* c, const vimz_bases* b, size_t offset, uint64_t* xy, size_t n, int form) {
+  if (!c || !b || (!xy && n) || offset + n > b->n) return fail(c, VIMZ_ERR_INVALID, "vimz_bases_download: bad argument");
+  if (!n) return VIMZ_OK;
+  std::lock_guard<std::mutex> g(c->mu);
+  HIP_TRY(c, hipSetDevice(c->device));
+  const uint32_t* src = b->d + 16 * offset;
+  if (form == VIMZ_FORM_CANONICAL) {
+    int rc = ensure_scratch(c, 64 * n); if (rc) return rc;
+    field_dispatch(curve_base_field(b->curve), [&](auto f) { typedef decltype(f) F; launch_from_mont<F>(c->stream, src, (uint32_t*)c->scratch, 2 * n); return VIMZ_OK; });
+    src = (const uint32_t*)c->scratch;
+  }
+  HIP_TRY(c, hipMemcpyAsync(xy, src, 64 * n, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
   return VIMZ_OK;
 }
 size_t vimz_bases_len(const vimz_bases* b) { return b ? b->n : 0; }

@@ -1,0 +1,5 @@
+// Explicit instantiation of commitment-key derivation over one coordinate field.
+#include "ckgen_impl.hpp"
+namespace vz {
+template hipError_t ckgen_run<Fp<BnFq>>(hipStream_t, const CkLabel&, int, size_t, size_t, uint32_t*);
+}

@@ -57,13 +57,38 @@ __device__ __forceinline__ void for_each_digit(const uint32_t* s, int c, int K, 
   }
 }
 
+// Wave-aggregated "fetch-and-increment": lanes of a wave that target the same counter are served by one
+// atomic.  Witness scalars are ~80 % bits, so most lanes of a wave hit the same (window 0, digit 1) bucket and
+// plain per-lane atomics serialise on one address (measured 1.4 ms vs 0.2 ms for the histogram at n = 315 k).
+// Called by the active lanes only; falls back to per-lane atomics once the groups get small.
+__device__ __forceinline__ uint32_t agg_atomic_inc(uint32_t* __restrict__ ctr, uint32_t g) {
+  const uint32_t lane = __lane_id();
+  bool done = false;
+  uint32_t pos = 0;
+  for (int round = 0; round < 4; round++) {
+    const uint64_t pending = __ballot(!done);
+    if (pending == 0) break;
+    const int leader = __ffsll((unsigned long long)pending) - 1;
+    const uint32_t lg = __shfl(g, leader);
+    const bool mine = !done && g == lg;
+    const uint64_t same = __ballot(mine);
+    uint32_t base = 0;
+    if (mine && lane == (uint32_t)leader) base = atomicAdd(&ctr[g], (uint32_t)__popcll(same));
+    base = __shfl(base, leader);
+    if (mine) { pos = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull)); done = true; }
+    if (__popcll(same) < 4) break;
+  }
+  if (!done) pos = atomicAdd(&ctr[g], 1u);
+  return pos;
+}
+
 template <class S>
 __global__ void k_hist(const uint32_t* __restrict__ scalars, size_t n, int mont, int c, int K, uint32_t nbw,
                        uint32_t* __restrict__ counts) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     uint32_t s[8];
     load_scalar<S>(scalars, i, mont, s);
-    for_each_digit(s, c, K, [&](int w, uint32_t b, uint32_t) { atomicAdd(&counts[(uint32_t)w * nbw + b], 1u); });
+    for_each_digit(s, c, K, [&](int w, uint32_t b, uint32_t) { agg_atomic_inc(counts, (uint32_t)w * nbw + b); });
   }
 }
 
@@ -105,7 +130,7 @@ __global__ void k_scatter(const uint32_t* __restrict__ scalars, size_t n, int mo
     load_scalar<S>(scalars, i, mont, s);
     for_each_digit(s, c, K, [&](int w, uint32_t b, uint32_t neg) {
       uint32_t g = (uint32_t)w * nbw + b;
-      uint32_t pos = bucket_off[g] + atomicAdd(&cursor[g], 1u);
+      uint32_t pos = bucket_off[g] + agg_atomic_inc(cursor, g);
       sorted[pos] = (uint32_t)i | (neg << 31);
     });
   }

@@ -26,7 +26,7 @@ namespace vz {
 
 #define VZ_HIP_CHECK(x) do { hipError_t _e = (x); if (_e != hipSuccess) return _e; } while (0)
 
-constexpr int MSM_SUB = 128;         // max entries one thread accumulates in k_accum
+constexpr int MSM_SUB = 32;          // max entries one thread accumulates in k_accum (small: occupancy beats the extra combines)
 constexpr int MSM_MAX_WINDOWS = 64;
 
 struct MsmPlan {
@@ -40,13 +40,10 @@ static inline MsmPlan msm_plan(size_t n, int scalar_bits, int c_override) {
   MsmPlan p;
   int c = c_override;
   if (c <= 0) {
-    // bucket-accumulate cost ~ n*K adds, reduce cost ~ 2*K*2^(c-1): pick c minimising the sum
-    double best = 1e300; c = 8;
-    for (int t = 6; t <= 16; t++) {
-      int K = (scalar_bits + 1 + t - 1) / t;
-      double cost = (double)n * K + 2.5 * K * (double)(1u << (t - 1));
-      if (cost < best) { best = cost; c = t; }
-    }
+    // Measured on MI355X (profiles/r01_msm_phases.txt): k_accum is throughput-bound (~n*K mixed adds) while
+    // k_reduce is a latency-bound serial chain whose depth grows with 2^c / 256, so the optimum sits at a
+    // much smaller window than the classic ln(n) rule: c = 11 from 2^15 points up, shrinking below.
+    c = n >= (1u << 15) ? 11 : n >= (1u << 12) ? 9 : n >= 256 ? 7 : 5;
   }
   p.c = c;
   p.K = (scalar_bits + 1 + c - 1) / c;

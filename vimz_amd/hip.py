@@ -41,6 +41,12 @@ class Bases:
     def __init__(self, ctx, handle, curve, n):
         self.ctx, self.h, self.curve, self.n = ctx, handle, curve, n
 
+    def download(self, offset=0, n=None, form=L.FORM_CANONICAL):
+        n = self.n - offset if n is None else n
+        out = np.zeros((n, 8), dtype=np.uint64)
+        self.ctx._chk(self.ctx.lib.vimz_bases_download(self.ctx.h, self.h, offset, _ptr(out), n, form))
+        return out
+
     def free(self):
         if self.h:
             self.ctx.lib.vimz_bases_free(self.ctx.h, self.h)
@@ -106,6 +112,11 @@ class Context:
         n = xy.size // 8
         h = C.c_void_p()
         self._chk(self.lib.vimz_bases_upload(self.h, curve, _ptr(xy), n, form, C.byref(h)))
+        return Bases(self, h, curve, n)
+
+    def bases_generate(self, curve, n, label=b"ck"):
+        h = C.c_void_p()
+        self._chk(self.lib.vimz_bases_generate(self.h, curve, label, len(label), n, C.byref(h)))
         return Bases(self, h, curve, n)
 
     def vec_alloc(self, field, n):
