@@ -99,6 +99,53 @@ int vimz_msm(vimz_ctx* ctx, const vimz_bases* bases, const uint64_t* scalars, si
 int vimz_msm_vec(vimz_ctx* ctx, const vimz_bases* bases, size_t base_offset, const vimz_vec* v, size_t offset,
                  size_t n, int window_bits, uint64_t out_xy[8], int out_form);
 
+/* ---- step circuits: R1CS shape + witness program (replaces the `.r1cs` that nova_scotia::circom::reader::load_r1cs
+ *      reads at vimz/src/nova_snark_backend/folding.rs:22 and the circom witness generator named by
+ *      Config::witness_generator_file(), folding.rs:36).  Host-only: usable without a GPU. -------------------- */
+typedef struct vimz_circuit vimz_circuit;
+/* transformation ids follow the reference's enum order (vimz/src/transformation.rs:7-18) */
+#define VIMZ_T_BLUR 0
+#define VIMZ_T_BRIGHTNESS 1
+#define VIMZ_T_CONTRAST 2
+#define VIMZ_T_CROP 3
+#define VIMZ_T_GRAYSCALE 4
+#define VIMZ_T_HASH 5
+#define VIMZ_T_REDACT 6
+#define VIMZ_T_RESIZE 7
+#define VIMZ_T_SHARPNESS 8
+/* width = packed elements per original row (128 HD / 384 4K / 768 8K; 160 for redact blocks);
+ * width2 / rows_in / rows_out: resize geometry (64,3,2 at HD; w/2,2,1 at 4K/8K); crop_height: crop only. */
+int vimz_circuit_build(int transformation, int width, int width2, int rows_in, int rows_out, int crop_height,
+                       vimz_circuit** out);
+void vimz_circuit_free(vimz_circuit* c);
+const char* vimz_circuit_last_error(void);
+#define VIMZ_CIRCUIT_INFO_LEN 16
+/* info = {wires, constraints (incl. linear), linear constraints, len_z, private inputs, nnz A, nnz B, nnz C,
+ *         dictionary size, decomposition groups, lane groups, lane instructions, lane rows, hash jobs, chains, field ops} */
+int vimz_circuit_info(const vimz_circuit* c, uint64_t info[VIMZ_CIRCUIT_INFO_LEN]);
+/* raw tables (CSR of A,B,C with a coefficient dictionary; witness-program tables of vimz_amd/csrc/circuit/program.hpp) */
+#define VIMZ_CX_A_ROWPTR 0
+#define VIMZ_CX_A_COL 1
+#define VIMZ_CX_A_COEF 2
+#define VIMZ_CX_B_ROWPTR 3
+#define VIMZ_CX_B_COL 4
+#define VIMZ_CX_B_COEF 5
+#define VIMZ_CX_C_ROWPTR 6
+#define VIMZ_CX_C_COL 7
+#define VIMZ_CX_C_COEF 8
+#define VIMZ_CX_DICT_MONT 9
+#define VIMZ_CX_DICT_CANON 10
+#define VIMZ_CX_DECOMP 11
+#define VIMZ_CX_LANE_GROUPS 12
+#define VIMZ_CX_LANE_INSTR 13
+#define VIMZ_CX_LANE_ROWS 14
+#define VIMZ_CX_JOBS 15
+#define VIMZ_CX_CHAINS 16
+#define VIMZ_CX_FOPS 17
+#define VIMZ_CX_ZOUT 18
+/* returns the table's size in bytes (copies it when buf != NULL and cap is large enough), negative on error */
+int64_t vimz_circuit_export(const vimz_circuit* c, int what, void* buf, size_t cap);
+
 /* ---- field-arithmetic probes (element-wise on the GPU; used by the parity tests to pin the device
  *      Montgomery arithmetic against the oracle).  op: 0 add, 1 sub, 2 mul, 3 inverse (b ignored). -------- */
 int vimz_field_op(vimz_ctx* ctx, int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);

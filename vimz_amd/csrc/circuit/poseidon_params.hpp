@@ -1,0 +1,95 @@
+// circomlib Poseidon parameters over BN254 Fr, regenerated from the Poseidon reference Grain LFSR
+// (circomlib is a package.json dependency of the reference, circuits/package.json:7,
+// not vendored).  Host code; the tables are uploaded to the GPU for the witness kernels.
+#pragma once
+#include <vector>
+#include "builder.hpp"
+
+namespace vz {
+namespace cb {
+
+struct PoseidonTable {
+  int t = 0, rf = 8, rp = 0;
+  std::vector<Fe> C;  // (rf+rp)*t
+  std::vector<Fe> M;  // t*t row-major
+};
+
+inline int poseidon_rp(int t) {
+  static const int RP[16] = {56, 57, 56, 60, 60, 63, 64, 63, 60, 66, 60, 65, 70, 60, 64, 68};
+  return RP[t - 2];
+}
+
+class GrainLfsr {
+  bool s_[80];
+ public:
+  GrainLfsr(unsigned field_bits, unsigned t, unsigned rf, unsigned rp) {
+    int k = 0;
+    auto put = [&](unsigned v, int w) { for (int i = w - 1; i >= 0; i--) s_[k++] = (v >> i) & 1u; };
+    put(1, 2); put(0, 4); put(field_bits, 12); put(t, 12); put(rf, 10); put(rp, 10);
+    while (k < 80) s_[k++] = true;
+    for (int i = 0; i < 160; i++) step();
+  }
+  bool step() {
+    bool b = s_[62] ^ s_[51] ^ s_[38] ^ s_[23] ^ s_[13] ^ s_[0];
+    for (int i = 0; i < 79; i++) s_[i] = s_[i + 1];
+    s_[79] = b;
+    return b;
+  }
+  bool filtered() { for (;;) { bool keep = step(); bool v = step(); if (keep) return v; } }
+  // 254-bit big-endian sample into canonical little-endian limbs
+  void sample(uint32_t out[8]) {
+    for (int i = 0; i < 8; i++) out[i] = 0;
+    for (int i = 253; i >= 0; i--) if (filtered()) out[i >> 5] |= 1u << (i & 31);
+  }
+};
+
+inline const PoseidonTable& poseidon_table(int t) {
+  static PoseidonTable cache[18];
+  PoseidonTable& P = cache[t];
+  if (P.t == t) return P;
+  P.t = t; P.rf = 8; P.rp = poseidon_rp(t);
+  GrainLfsr g(254, (unsigned)t, (unsigned)P.rf, (unsigned)P.rp);
+  auto below_modulus = [](const uint32_t* v) {
+    for (int i = 7; i >= 0; i--) if (v[i] != BnFr::MOD.w[i]) return v[i] < BnFr::MOD.w[i];
+    return false;
+  };
+  auto to_fe_reduced = [&](uint32_t* v) {  // v < 2^254 < 2p: one conditional subtraction
+    if (!below_modulus(v)) { uint64_t br = 0; for (int i = 0; i < 8; i++) { uint64_t d = (uint64_t)v[i] - BnFr::MOD.w[i] - br; v[i] = (uint32_t)d; br = (d >> 32) & 1; } }
+    Fe x; for (int i = 0; i < 8; i++) x.v[i] = v[i];
+    return Fe::to_mont(x);
+  };
+  while ((int)P.C.size() < (P.rf + P.rp) * t) {
+    uint32_t v[8]; g.sample(v);
+    if (below_modulus(v)) P.C.push_back(to_fe_reduced(v));  // rejection sampling for round constants
+  }
+  std::vector<Fe> xs(t), ys(t);
+  for (int i = 0; i < t; i++) { uint32_t v[8]; g.sample(v); xs[i] = to_fe_reduced(v); }  // MDS seeds: mod r, no rejection
+  for (int i = 0; i < t; i++) { uint32_t v[8]; g.sample(v); ys[i] = to_fe_reduced(v); }
+  P.M.resize((size_t)t * t);
+  for (int i = 0; i < t; i++) for (int j = 0; j < t; j++) P.M[(size_t)i * t + j] = Fe::pow_pm2(Fe::add(xs[i], ys[j]));
+  return P;
+}
+
+// Numeric permutation on the host (used for the IVC state chain between witness batches).
+inline Fe poseidon_hash(const Fe* in, int n) {
+  const int t = n + 1;
+  const PoseidonTable& P = poseidon_table(t);
+  Fe s[POSEIDON_MAX_T], u[POSEIDON_MAX_T];
+  s[0] = Fe::zero();
+  for (int i = 0; i < n; i++) s[i + 1] = in[i];
+  for (int r = 0; r < P.rf + P.rp; r++) {
+    for (int i = 0; i < t; i++) s[i] = Fe::add(s[i], P.C[(size_t)r * t + i]);
+    const bool full = r < P.rf / 2 || r >= P.rf / 2 + P.rp;
+    for (int i = 0; i < (full ? t : 1); i++) { Fe x2 = Fe::sqr(s[i]); Fe x4 = Fe::sqr(x2); s[i] = Fe::mul(x4, s[i]); }
+    for (int i = 0; i < t; i++) {
+      Fe acc = Fe::zero();
+      for (int j = 0; j < t; j++) acc = Fe::add(acc, Fe::mul(P.M[(size_t)i * t + j], s[j]));
+      u[i] = acc;
+    }
+    for (int i = 0; i < t; i++) s[i] = u[i];
+  }
+  return s[0];
+}
+
+}  // namespace cb
+}  // namespace vz
