@@ -8,6 +8,7 @@
 #include "poseidon.hpp"
 #include "steps.hpp"
 #include "r1cs.hpp"
+#include "witness.hpp"
 
 using namespace orc;
 
@@ -169,6 +170,62 @@ long orc_first_unsat(int fid, size_t n, const u64* az, const u64* bz, const u64*
     res = first_unsat_relaxed<F>(n, a.data(), b.data(), c.data(), F::from_canonical(u), E ? e.data() : nullptr);
   });
   return res;
+}
+
+// ---------------- witness program executor ----------------
+// sizes[] = {n_wires, len_z, n_priv, n_decomp, n_groups, n_jobs, n_chains, n_fops}; tables are the raw POD arrays
+// exported by the product (format: witness.hpp).  z_wires_out: n_wires x 4 canonical; z_state_out: len_z x 4.
+int orc_witness_execute(const uint32_t* sizes, const void* decomp, const void* groups, const void* instr, const void* rows,
+                        const void* jobs, const void* chains, const void* fops, const void* zout,
+                        const u64* z_in, const u64* priv, u64* z_wires_out, u64* z_state_out) {
+  wp::Program P;
+  P.n_wires = sizes[0]; P.len_z = sizes[1]; P.n_priv = sizes[2];
+  P.decomp = (const wp::DecompGroup*)decomp; P.n_decomp = sizes[3];
+  P.groups = (const wp::LaneGroup*)groups; P.n_groups = sizes[4];
+  P.instr = (const wp::LaneInstr*)instr; P.rows = (const wp::LaneRow*)rows;
+  P.jobs = (const wp::HashJob*)jobs; P.n_jobs = sizes[5];
+  P.chains = (const wp::Chain*)chains; P.n_chains = sizes[6];
+  P.fops = (const wp::FieldOp*)fops; P.n_fops = sizes[7];
+  P.zout = (const wp::ZOut*)zout;
+  std::vector<BnFr> z, zo;
+  int st = wp::execute(P, z_in, priv, z, zo);
+  if (st == 2) return 2;
+  if (z_wires_out) for (size_t i = 0; i < z.size(); i++) z[i].to_canonical(z_wires_out + 4 * i);
+  if (z_state_out) for (size_t i = 0; i < zo.size(); i++) zo[i].to_canonical(z_state_out + 4 * i);
+  return st;
+}
+int orc_witness_struct_sizes(int which) {
+  switch (which) {
+    case 0: return sizeof(wp::DecompGroup); case 1: return sizeof(wp::LaneGroup); case 2: return sizeof(wp::LaneInstr);
+    case 3: return sizeof(wp::LaneRow); case 4: return sizeof(wp::HashJob); case 5: return sizeof(wp::Chain);
+    case 6: return sizeof(wp::FieldOp); default: return sizeof(wp::ZOut);
+  }
+}
+// A z, B z, C z with dictionary-compressed CSR (coef = index into dict, canonical); then the first row where
+// Az*Bz != Cz (or -1).  Also returns the three products when the out pointers are non-NULL.
+long orc_r1cs_check(size_t nrows, size_t ncols, const uint32_t* const* row_ptr, const uint32_t* const* col, const uint32_t* const* coef,
+                    const u64* dict, size_t ndict, const u64* z, u64* az_out, u64* bz_out, u64* cz_out, int threads) {
+  std::vector<BnFr> D(ndict), Z(ncols);
+  for (size_t i = 0; i < ndict; i++) D[i] = BnFr::from_canonical(dict + 4 * i);
+  for (size_t i = 0; i < ncols; i++) Z[i] = BnFr::from_canonical(z + 4 * i);
+  std::vector<BnFr> out[3];
+  for (int m = 0; m < 3; m++) {
+    out[m].resize(nrows);
+    auto work = [&, m](size_t lo, size_t hi) {
+      for (size_t r = lo; r < hi; r++) {
+        BnFr acc = BnFr::zero();
+        for (uint32_t k = row_ptr[m][r]; k < row_ptr[m][r + 1]; k++) acc = acc + D[coef[m][k]] * Z[col[m][k]];
+        out[m][r] = acc;
+      }
+    };
+    std::vector<std::thread> th; size_t chunk = (nrows + threads - 1) / (threads > 0 ? threads : 1);
+    for (int t = 0; t < threads; t++) th.emplace_back(work, std::min(nrows, t * chunk), std::min(nrows, (t + 1) * chunk));
+    for (auto& x : th) x.join();
+  }
+  u64* outs[3] = {az_out, bz_out, cz_out};
+  for (int m = 0; m < 3; m++) if (outs[m]) for (size_t r = 0; r < nrows; r++) out[m][r].to_canonical(outs[m] + 4 * r);
+  for (size_t r = 0; r < nrows; r++) if (out[0][r] * out[1][r] != out[2][r]) return (long)r;
+  return -1;
 }
 
 }  // extern "C"

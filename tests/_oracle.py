@@ -246,6 +246,46 @@ def ck_derive(cid, label, i):
         return x, y
 
 
+def witness_execute(orc, circuit, z_in, priv_limbs):
+    """Run the oracle's independent executor over the product-built witness program of `circuit`
+    (vimz_amd.circuit.Circuit).  Returns (status, z (n_wires,4) canonical, z_out ints)."""
+    lib = orc.lib
+    names = ["DECOMP", "LANE_GROUPS", "LANE_INSTR", "LANE_ROWS", "JOBS", "CHAINS", "FOPS", "ZOUT"]
+    if not hasattr(circuit, "_tables"):
+        circuit._tables = {n: np.ascontiguousarray(circuit.export(n)) for n in names}
+        for i, n in enumerate(names):
+            sz = lib.orc_witness_struct_sizes(i)
+            assert circuit._tables[n].size % sz == 0, (n, sz)
+    T = circuit._tables
+    sizes = np.array([circuit.n_wires, circuit.len_z, circuit.n_priv, circuit.n_decomp, circuit.n_lane_groups, circuit.n_jobs,
+                      circuit.n_chains, circuit.n_fops], dtype=np.uint32)
+    z = np.zeros((circuit.n_wires, 4), dtype=np.uint64)
+    zo = np.zeros((circuit.len_z, 4), dtype=np.uint64)
+    priv = np.ascontiguousarray(priv_limbs, dtype=np.uint64)
+    assert priv.size == 4 * circuit.n_priv
+    st = lib.orc_witness_execute(_p(sizes), *[_p(T[n]) for n in names], _p(to_limbs(z_in)), _p(priv), _p(z), _p(zo))
+    return st, z, from_limbs(zo)
+
+
+def r1cs_check(orc, circuit, z, want_products=False, threads=8):
+    """First row where Az∘Bz != Cz for the circuit's R1CS (-1 if satisfied), computed by the oracle."""
+    lib = orc.lib
+    lib.orc_r1cs_check.restype = C.c_long
+    if not hasattr(circuit, "_csr"):
+        circuit._csr = [tuple(np.ascontiguousarray(a) for a in circuit.csr(m)) for m in "ABC"]
+        circuit._dict = np.ascontiguousarray(circuit.export("DICT_CANON", np.uint64))
+    PP = C.c_void_p * 3
+    rp = PP(*[a[0].ctypes.data for a in circuit._csr])
+    col = PP(*[a[1].ctypes.data for a in circuit._csr])
+    coef = PP(*[a[2].ctypes.data for a in circuit._csr])
+    n = circuit.n_constraints
+    outs = [np.zeros((n, 4), dtype=np.uint64) if want_products else None for _ in range(3)]
+    z = np.ascontiguousarray(z, dtype=np.uint64)
+    r = lib.orc_r1cs_check(C.c_size_t(n), C.c_size_t(circuit.n_wires), rp, col, coef, _p(circuit._dict), C.c_size_t(circuit.n_dict),
+                           _p(z), *[(_p(o) if o is not None else None) for o in outs], threads)
+    return (r, outs) if want_products else r
+
+
 _cached = None
 
 
