@@ -146,6 +146,31 @@ int vimz_circuit_info(const vimz_circuit* c, uint64_t info[VIMZ_CIRCUIT_INFO_LEN
 /* returns the table's size in bytes (copies it when buf != NULL and cap is large enough), negative on error */
 int64_t vimz_circuit_export(const vimz_circuit* c, int what, void* buf, size_t cap);
 
+/* ---- folding prover: the body of `fold_input` (vimz/src/nova_snark_backend/folding.rs:27-43), i.e. the per-row loop of
+ *      nova_scotia::create_recursive_circuit around nova-snark's RecursiveSNARK::prove_step, with W, E and the running
+ *      (A,B,C)·Z resident in HBM.  The instance folded is the step circuit's R1CS with X = (z_{i+1}, z_i); nova-snark's
+ *      augmented verifier circuit and secondary curve are not part of this round. ------------------------ */
+typedef struct vimz_prover vimz_prover;
+/* ck must be on BN254 G1 with at least max(wires, constraints) generators; max_batch = rows whose witnesses are
+ * generated together (memory: max_batch * wires * 32 bytes). */
+int vimz_prover_create(vimz_ctx* ctx, const vimz_circuit* circuit, const vimz_bases* ck, size_t max_batch, vimz_prover** out);
+void vimz_prover_free(vimz_prover* p);
+/* z0: len_z canonical elements (Transformation::ivc_initial_state, vimz/src/transformation.rs:25-40) */
+int vimz_prover_reset(vimz_prover* p, const uint64_t* z0);
+/* step_inputs: nsteps x private-input-count canonical elements in the per-step order of
+ * vimz/src/nova_snark_backend/input.rs:57-96.  Returns VIMZ_ERR_UNSAT if a row violates the step relation. */
+int vimz_prover_fold(vimz_prover* p, const uint64_t* step_inputs, size_t nsteps);
+/* verify_folded_proof (folding.rs:45-56): 0 = accepted; bit0 relation, bit1 comm_W, bit2 comm_E, bit3 running products */
+int vimz_prover_verify(vimz_prover* p, uint32_t* result);
+int vimz_prover_instance(vimz_prover* p, uint64_t comm_W[8], uint64_t comm_E[8], uint64_t u[4], uint64_t* z_current, uint64_t* steps);
+int vimz_prover_running(vimz_prover* p, uint64_t* z_run, uint64_t* E);
+/* seconds[9]/counts[9]: witness, state chain (host), spmv, msm(W), cross term, msm(T), RO (host), fold, host EC */
+int vimz_prover_profile(const vimz_prover* p, double seconds[9], uint64_t counts[9]);
+/* parity hooks: GPU witness generation alone (replaces the circom witness generator process) and
+ * the GPU sparse mat-vec alone (R1CSShape::multiply_vec; row V1).  All buffers canonical. */
+int vimz_prover_witness(vimz_prover* p, const uint64_t* inputs, size_t rows, uint64_t* z_wires_out, uint64_t* zs_out, uint32_t* status_out);
+int vimz_prover_spmv(vimz_prover* p, const uint64_t* z, uint64_t* az, uint64_t* bz, uint64_t* cz);
+
 /* ---- field-arithmetic probes (element-wise on the GPU; used by the parity tests to pin the device
  *      Montgomery arithmetic against the oracle).  op: 0 add, 1 sub, 2 mul, 3 inverse (b ignored). -------- */
 int vimz_field_op(vimz_ctx* ctx, int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);

@@ -1,0 +1,194 @@
+"""GPU parity for the folding path (SURVEY.md §8a rows W, V1, V2, M1, M2, F1', X1), through the C ABI:
+witness generation vs the oracle's executor, sparse mat-vec vs the oracle, and whole folds checked
+(a) by the library's own verify, (b) against the pinned IVC-state chain, (c) for the small `hash` circuit,
+against an independent re-computation of every folded quantity with the oracle."""
+import numpy as np
+import pytest
+
+from tests._oracle import from_limbs, r1cs_check, to_limbs, witness_execute
+from tests.test_circuits import ORC_T, step_inputs
+from vimz_amd import _lib
+from vimz_amd.circuit import Circuit
+
+pytestmark = pytest.mark.gpu
+
+R_MOD = 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001
+OPS = ["hash", "grayscale", "contrast", "brightness", "blur", "sharpness", "resize", "redact"]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from vimz_amd import hip
+    c = hip.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def ck(ctx):
+    b = ctx.bases_generate(_lib.CURVE_BN254_G1, 1 << 19)
+    yield b
+    b.free()
+
+
+@pytest.fixture(scope="module")
+def circuits():
+    return {op: Circuit.for_resolution(op, "HD") for op in OPS}
+
+
+@pytest.mark.parametrize("op", OPS)
+def test_witness_matches_oracle_executor(ctx, ck, oracle, circuits, op):
+    from vimz_amd import hip
+    c = circuits[op]
+    z0, inputs = step_inputs(op)
+    P = hip.Prover(ctx, c, ck, max_batch=4)
+    try:
+        P.reset(z0)
+        zw, zs, st = P.witness(np.stack(inputs[:4]))
+        assert not st.any()
+        z = list(z0)
+        for i in range(4):
+            status, want, z_out = witness_execute(oracle, c, z, inputs[i])
+            assert status == 0
+            assert from_limbs(zs[i]) == z and from_limbs(zs[i + 1]) == z_out
+            diff = np.nonzero((zw[i] != want).any(axis=1))[0]
+            assert diff.size == 0, f"{op} row {i}: {diff.size} wires differ, first {diff[:5]}"
+            z = z_out
+        # an unsatisfiable row is flagged, not silently accepted
+        bad = np.stack(inputs[:2]).copy()
+        if c.n_lane_groups:
+            bad[1, -1, 0] ^= np.uint64(0x40)
+            _, _, st = P.witness(bad, want_wires=False)
+            assert st[0] == 0 and st[1] & 1
+    finally:
+        P.close()
+
+
+@pytest.mark.parametrize("op", ["grayscale", "sharpness"])
+def test_spmv_matches_oracle(ctx, ck, oracle, circuits, op):
+    from vimz_amd import hip
+    c = circuits[op]
+    z0, inputs = step_inputs(op)
+    _, wires, _ = witness_execute(oracle, c, z0, inputs[0])
+    rng = np.random.default_rng(3)
+    dense = rng.integers(0, 1 << 62, size=wires.shape, dtype=np.uint64)
+    dense[:, 3] &= np.uint64((1 << 58) - 1)
+    P = hip.Prover(ctx, c, ck, max_batch=1)
+    try:
+        for z in (wires, dense):
+            bad, want = r1cs_check(oracle, c, z, want_products=True)
+            got = P.spmv(z)
+            for g, w in zip(got, want):
+                assert np.array_equal(g, w)
+    finally:
+        P.close()
+
+
+@pytest.mark.parametrize("op", OPS)
+def test_fold_ten_steps_verifies_and_tracks_state(ctx, ck, oracle, circuits, op):
+    """DEMO_STEPS = 10 rows (vimz/src/lib.rs:9), as `make run-nova-snark-benchmarks` does in the reference."""
+    from vimz_amd import hip
+    c = circuits[op]
+    z0, inputs = step_inputs(op)
+    kw = dict(width=160) if op == "redact" else {}
+    P = hip.Prover(ctx, c, ck, max_batch=4)          # 4+4+2: exercises batch boundaries
+    try:
+        P.reset(z0)
+        P.fold(np.stack(inputs))
+        assert P.verify() == 0
+        inst = P.instance()
+        assert inst["steps"] == 10
+        z = list(z0)
+        for i in range(10):
+            ok, z = oracle.step_eval(ORC_T[op], z, inputs[i], **kw)
+            assert ok
+        assert from_limbs(inst["z"]) == z
+    finally:
+        P.close()
+
+
+def test_fold_rejects_tampered_row(ctx, ck, circuits):
+    from vimz_amd import hip
+    c = circuits["contrast"]
+    z0, inputs = step_inputs("contrast")
+    bad = np.stack(inputs[:3]).copy()
+    bad[2, -1, 0] ^= np.uint64(0x40)
+    P = hip.Prover(ctx, c, ck, max_batch=2)
+    try:
+        P.reset(z0)
+        with pytest.raises(_lib.VimzError) as e:
+            P.fold(bad)
+        assert e.value.code == _lib.ERR_UNSAT
+    finally:
+        P.close()
+
+
+def _ro_point(pt):
+    x, y = pt
+    return [x & ((1 << 128) - 1), (x >> 128) | ((y & 1) << 126)]
+
+
+def test_hash_circuit_fold_recomputed_by_oracle(ctx, ck, oracle, circuits):
+    """Every quantity of a 3-step fold re-derived independently: commitments (oracle Pippenger over the downloaded
+    key), cross term, Fiat–Shamir challenge (oracle Poseidon over the documented transcript), folded W, E, u."""
+    from vimz_amd import hip
+    c = circuits["hash"]
+    z0, inputs = step_inputs("hash")
+    n_aux = c.n_wires - 1 - 2 * c.len_z
+    key = ck.download(0, max(n_aux, c.n_constraints))
+    P = hip.Prover(ctx, c, ck, max_batch=2)
+    try:
+        P.reset(z0)
+        P.fold(np.stack(inputs[:3]))
+        inst = P.instance()
+        z_run, E_run = P.running()
+    finally:
+        P.close()
+    # --- oracle side
+    zi = list(z0)
+    wit, prods = [], []
+    for i in range(3):
+        st, w, zo = witness_execute(oracle, c, zi, inputs[i])
+        bad, abc = r1cs_check(oracle, c, w, want_products=True)
+        assert st == 0 and bad == -1
+        wit.append(w); prods.append(abc); zi = zo
+    aux0 = 1 + 2 * c.len_z
+    commit = lambda v, n: oracle.msm(0, key[:n], v, threads=8)
+    ro = oracle.poseidon([0x56494d7a, c.n_constraints, c.n_wires, c.len_z, 5, 128])
+    zdig = 0
+    for v in z0:
+        zdig = oracle.poseidon([zdig, v])
+    # step 0: running := fresh
+    zchain = list(z0)
+    st, _, z1 = witness_execute(oracle, c, zchain, inputs[0])
+    for v in z1:
+        zdig = oracle.poseidon([zdig, v])
+    cW = commit(wit[0][aux0:], n_aux)
+    ro = oracle.poseidon([ro] + _ro_point(cW) + [zdig])
+    Z, (AZ, BZ, CZ) = wit[0], prods[0]
+    E = np.zeros((c.n_constraints, 4), dtype=np.uint64)
+    cE = (0, 0)
+    u = 1
+    znext = z1
+    for i in (1, 2):
+        st, _, znext2 = witness_execute(oracle, c, znext, inputs[i])
+        for v in znext2:
+            zdig = oracle.poseidon([zdig, v])
+        znext = znext2
+        a2, b2, c2 = prods[i]
+        T = oracle.cross_term(0, AZ, BZ, CZ, u, a2, b2, c2, 1)
+        cW2 = commit(wit[i][aux0:], n_aux)
+        cT = commit(T, c.n_constraints)
+        ro = oracle.poseidon([ro] + _ro_point(cW2) + _ro_point(cT) + [zdig])
+        r = ro & ((1 << 128) - 1)
+        Z = oracle.axpy(0, Z, r, wit[i]); E = oracle.axpy(0, E, r, T)
+        AZ = oracle.axpy(0, AZ, r, a2); BZ = oracle.axpy(0, BZ, r, b2); CZ = oracle.axpy(0, CZ, r, c2)
+        cW = oracle.curve_add(0, cW, oracle.curve_mul(0, cW2, r))
+        cE = oracle.curve_add(0, cE, oracle.curve_mul(0, cT, r))
+        u = (u + r) % R_MOD
+    assert np.array_equal(z_run, Z)
+    assert np.array_equal(E_run, E)
+    assert from_limbs(inst["u"])[0] == u == from_limbs(z_run[0])[0]
+    assert tuple(from_limbs(inst["comm_W"])) == cW
+    assert tuple(from_limbs(inst["comm_E"])) == cE
+    assert oracle.first_unsat(0, AZ, BZ, CZ, u=u, E=E) == -1

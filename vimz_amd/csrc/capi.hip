@@ -7,41 +7,27 @@
 #include <cstring>
 #include <cstdio>
 
-#include "../../include/vimz_hip.h"
-#include "ec.hpp"
-#include "msm_api.hpp"
+#include "internal.hpp"
+#define HIP_TRY(c, x) do { hipError_t _e = (x); if (_e != hipSuccess) return vz::vz_fail(c, VIMZ_ERR_HIP, #x, _e); } while (0)
 #include "vecops_api.hpp"
 #include "ckgen.hpp"
 
 using namespace vz;
 
-struct vimz_ctx {
-  int device = 0;
-  hipStream_t stream = nullptr;
-  hipEvent_t t0 = nullptr, t1 = nullptr;
-  hipEvent_t ev[7] = {};
-  bool profiling = false;
-  MsmWorkspace msm_ws;
-  MsmStats last_msm = {};
-  std::mutex mu;
-  std::string err;
-  void* scratch = nullptr;  // device staging for host-scalar MSM / probes
-  size_t scratch_bytes = 0;
-};
-struct vimz_bases { int curve; size_t n; uint32_t* d; };
-struct vimz_vec { int field; size_t n; uint32_t* d; };
-
 static thread_local std::string g_err_noctx;
 
-static int fail(vimz_ctx* c, int code, const char* what, hipError_t e = hipSuccess) {
+namespace vz {
+int vz_fail(vimz_ctx* c, int code, const char* what, hipError_t e) {
   std::string m = what;
   if (e != hipSuccess) { m += ": "; m += hipGetErrorString(e); }
   if (c) c->err = m; else g_err_noctx = m;
   return code;
 }
-#define HIP_TRY(c, x) do { hipError_t _e = (x); if (_e != hipSuccess) return fail(c, VIMZ_ERR_HIP, #x, _e); } while (0)
+}  // namespace vz
+static int fail(vimz_ctx* c, int code, const char* what, hipError_t e = hipSuccess) { return vz::vz_fail(c, code, what, e); }
 
-static int ensure_scratch(vimz_ctx* c, size_t bytes) {
+namespace vz {
+int vz_ensure_scratch(vimz_ctx* c, size_t bytes) {
   if (bytes <= c->scratch_bytes) return VIMZ_OK;
   if (c->scratch) hipFree(c->scratch);
   c->scratch = nullptr; c->scratch_bytes = 0;
@@ -49,6 +35,8 @@ static int ensure_scratch(vimz_ctx* c, size_t bytes) {
   c->scratch_bytes = bytes;
   return VIMZ_OK;
 }
+}  // namespace vz
+static int ensure_scratch(vimz_ctx* c, size_t bytes) { return vz::vz_ensure_scratch(c, bytes); }
 
 template <class Fn>
 static int field_dispatch(int field, Fn fn) {
@@ -85,6 +73,27 @@ static int curve_scalar_field(int curve) {
     case VIMZ_CURVE_PALLAS: return VIMZ_FIELD_VESTA_FQ;
     default: return VIMZ_FIELD_PALLAS_FP;
   }
+}
+
+namespace vz {
+int vz_msm_device(vimz_ctx* c, const vimz_bases* bases, size_t base_offset, const uint32_t* d_scalars, size_t n,
+                      int scalars_mont, int window_bits, uint64_t out_xy[8], int out_form) {
+  return curve_dispatch(bases->curve, [&](auto cv) {
+    typedef decltype(cv) C;
+    typedef typename C::Base F;
+    Affine<F> r;
+    hipError_t e = msm_run<C>(c->stream, c->msm_ws, bases->d + 16 * base_offset, d_scalars, n, scalars_mont, window_bits, &r,
+                              &c->last_msm, c->profiling ? c->ev : nullptr);
+    if (e != hipSuccess) return vz_fail(c, VIMZ_ERR_HIP, "msm", e);
+    if (out_form == VIMZ_FORM_CANONICAL) { r.x = F::from_mont(r.x); r.y = F::from_mont(r.y); }
+    memcpy(out_xy, r.x.v, 32); memcpy(out_xy + 4, r.y.v, 32);
+    return VIMZ_OK;
+  });
+}
+}  // namespace vz
+static int msm_device(vimz_ctx* c, const vimz_bases* bases, size_t base_offset, const uint32_t* d_scalars, size_t n,
+                      int scalars_mont, int window_bits, uint64_t out_xy[8], int out_form) {
+  return vz::vz_msm_device(c, bases, base_offset, d_scalars, n, scalars_mont, window_bits, out_xy, out_form);
 }
 
 extern "C" {
@@ -279,21 +288,6 @@ void vimz_vec_free(vimz_ctx* c, vimz_vec* v) {
 }
 
 // ---- MSM ---------------------------------------------------------------------------------------------
-static int msm_device(vimz_ctx* c, const vimz_bases* bases, size_t base_offset, const uint32_t* d_scalars, size_t n,
-                      int scalars_mont, int window_bits, uint64_t out_xy[8], int out_form) {
-  return curve_dispatch(bases->curve, [&](auto cv) {
-    typedef decltype(cv) C;
-    typedef typename C::Base F;
-    Affine<F> r;
-    hipError_t e = msm_run<C>(c->stream, c->msm_ws, bases->d + 16 * base_offset, d_scalars, n, scalars_mont, window_bits, &r,
-                              &c->last_msm, c->profiling ? c->ev : nullptr);
-    if (e != hipSuccess) return fail(c, VIMZ_ERR_HIP, "msm", e);
-    if (out_form == VIMZ_FORM_CANONICAL) { r.x = F::from_mont(r.x); r.y = F::from_mont(r.y); }
-    memcpy(out_xy, r.x.v, 32); memcpy(out_xy + 4, r.y.v, 32);
-    return VIMZ_OK;
-  });
-}
-
 int vimz_msm(vimz_ctx* c, const vimz_bases* bases, const uint64_t* scalars, size_t n, int form, int window_bits,
              uint64_t out_xy[8], int out_form) {
   if (!c || !bases || !out_xy || (!scalars && n) || n > bases->n) return fail(c, VIMZ_ERR_INVALID, "vimz_msm: bad argument");

@@ -44,7 +44,7 @@ struct CircuitBuild {
   uint32_t out0 = 1, in0 = 0, priv0 = 0;
   CircuitBuild() : g(b) {}
   uint32_t out_wire(int i) const { return out0 + i; }
-  FV zin(int i) const { return fv_wire(in0 + i); }
+  FV zin(int i) const { return FV{LC::wire(in0 + i), ValRef{REF_ZIN, (uint32_t)i}}; }
   std::vector<FV> row_fv(uint32_t src, int len) const { std::vector<FV> v; for (int i = 0; i < len; i++) v.push_back(fv_wire(src + i)); return v; }
 
   // HeadTailHasher(w)(head, row) -> out wire: phase-A chain for the row, phase-B pair hash

@@ -46,6 +46,11 @@ constexpr uint32_t ct_n0(uint32_t p0) {  // -p^-1 mod 2^32
   for (int i = 0; i < 5; i++) inv *= 2 - p0 * inv;
   return 0u - inv;
 }
+constexpr uint64_t ct_n0_64(uint64_t p0) {  // -p^-1 mod 2^64
+  uint64_t inv = 1;
+  for (int i = 0; i < 6; i++) inv *= 2 - p0 * inv;
+  return 0ull - inv;
+}
 constexpr int ct_bits(const U256& p) {
   for (int i = 255; i >= 0; i--) if ((p.w[i / 32] >> (i % 32)) & 1) return i + 1;
   return 0;
@@ -57,6 +62,7 @@ constexpr int ct_bits(const U256& p) {
     static constexpr U256 R1 = ct_pow2_mod(256, MOD);                          \
     static constexpr U256 R2 = ct_pow2_mod(512, MOD);                          \
     static constexpr uint32_t N0 = ct_n0(w0);                                  \
+    static constexpr uint64_t N0_64 = ct_n0_64((uint64_t)w0 | ((uint64_t)w1 << 32)); \
     static constexpr int BITS = ct_bits(MOD);                                  \
   };
 
@@ -109,6 +115,25 @@ struct Fp {
 
   // CIOS Montgomery product a*b/R mod p.
   static VZ_HD Fp mul(const Fp& a, const Fp& b) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+    // Host pass: same CIOS over 4 x 64-bit limbs (x86-64 has the 64x64->128 multiplier the GPU lacks).
+    typedef unsigned __int128 u128;
+    uint64_t A[4], B[4], M[4], t[5] = {0, 0, 0, 0, 0};
+    __builtin_memcpy(A, a.v, 32); __builtin_memcpy(B, b.v, 32); __builtin_memcpy(M, P::MOD.w, 32);  // little-endian host
+    const uint64_t n0 = P::N0_64;
+    for (int i = 0; i < 4; i++) {
+      u128 c = 0;
+      for (int j = 0; j < 4; j++) { c += (u128)A[j] * B[i] + t[j]; t[j] = (uint64_t)c; c >>= 64; }
+      uint64_t t4 = t[4] + (uint64_t)c;
+      uint64_t m = t[0] * n0;
+      c = (u128)m * M[0] + t[0]; c >>= 64;
+      for (int j = 1; j < 4; j++) { c += (u128)m * M[j] + t[j]; t[j - 1] = (uint64_t)c; c >>= 64; }
+      c += t4; t[3] = (uint64_t)c; t[4] = (uint64_t)(c >> 64);
+    }
+    uint32_t w[8];
+    __builtin_memcpy(w, t, 32);
+    return reduce_once(w);
+#else
     uint32_t t[9];
 #pragma unroll
     for (int i = 0; i < 9; i++) t[i] = 0;
@@ -125,6 +150,7 @@ struct Fp {
       c += t8; t[7] = (uint32_t)c; t[8] = (uint32_t)(c >> 32);
     }
     return reduce_once(t);
+#endif
   }
   static VZ_HD Fp sqr(const Fp& a) { return mul(a, a); }
 

@@ -1,0 +1,33 @@
+// Internal definitions shared by the translation units behind the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <mutex>
+#include <string>
+#include "../../include/vimz_hip.h"
+#include "ec.hpp"
+#include "msm_api.hpp"
+
+struct vimz_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t t0 = nullptr, t1 = nullptr;
+  hipEvent_t ev[7] = {};
+  bool profiling = false;
+  vz::MsmWorkspace msm_ws;
+  vz::MsmStats last_msm = {};
+  std::mutex mu;
+  std::string err;
+  void* scratch = nullptr;  // device staging for host-scalar MSM / probes
+  size_t scratch_bytes = 0;
+};
+struct vimz_bases { int curve; size_t n; uint32_t* d; };
+struct vimz_vec { int field; size_t n; uint32_t* d; };
+
+
+namespace vz {
+int vz_fail(vimz_ctx* c, int code, const char* what, hipError_t e = hipSuccess);
+int vz_ensure_scratch(vimz_ctx* c, size_t bytes);
+// MSM over device-resident scalars on the context's stream (caller holds c->mu and has set the device)
+int vz_msm_device(vimz_ctx* c, const vimz_bases* bases, size_t base_offset, const uint32_t* d_scalars, size_t n,
+                  int scalars_mont, int window_bits, uint64_t out_xy[8], int out_form);
+}

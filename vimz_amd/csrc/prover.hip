@@ -1,0 +1,480 @@
+// Folding prover: the body of `fold_input` (vimz/src/nova_snark_backend/folding.rs:27-43), i.e. what
+// nova_scotia::create_recursive_circuit + nova-snark's RecursiveSNARK::prove_step do per image row
+// (SURVEY.md §3.1, §8a), restated as a host loop over HIP kernels with every vector resident in HBM:
+//
+//   per batch of rows   GPU witness generation (witness.hpp)  — replaces one circom child process per step
+//   per step            (A,B,C)·z2  ->  comm_W2 = MSM(ck, W2)  ->  T  ->  comm_T = MSM(ck, T)
+//                       r = RO(...) on the host  ->  one fused fold of W, E and the running Az,Bz,Cz
+//
+// What is NOT here (DESIGN.md "scope"): nova-snark's augmented verifier circuit and the secondary-curve half
+// of prove_step (≈3 % of a step, host-side in the reference design).  The instance
+// folded is the step circuit's R1CS itself with public IO X = (z_{i+1}, z_i); the fold algebra, the
+// commitments and the acceptance check (is_sat_relaxed + commitment openings) are exactly Nova's NIFS.
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include <cstring>
+#include <vector>
+
+#include "internal.hpp"
+#include "circuit_handle.hpp"
+#include "r1cs_ops.hpp"
+#include "witness.hpp"
+
+using namespace vz;
+typedef cb::Fe Fe;                 // host Montgomery Fr
+typedef Fp<BnFq> Fq;
+typedef Affine<Fq> G1Aff;
+typedef XYZZ<Fq> G1;
+
+#define P_TRY(x) do { hipError_t _e = (x); if (_e != hipSuccess) return vz_fail(ctx, VIMZ_ERR_HIP, #x, _e); } while (0)
+
+namespace {
+
+template <class T>
+hipError_t upload(const std::vector<T>& v, const T** out) {
+  *out = nullptr;
+  if (v.empty()) return hipSuccess;
+  void* d; hipError_t e = hipMalloc(&d, v.size() * sizeof(T));
+  if (e != hipSuccess) return e;
+  e = hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+  *out = (const T*)d;
+  return e;
+}
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// scalar (canonical 128-bit, little-endian words) * affine point
+G1 scalar_mul(const G1Aff& p, const uint32_t* k, int bits) {
+  G1 acc = G1::identity();
+  for (int i = bits - 1; i >= 0; i--) {
+    acc = dbl(acc);
+    if ((k[i >> 5] >> (i & 31)) & 1) add_mixed(acc, p);
+  }
+  return acc;
+}
+
+}  // namespace
+
+enum { PH_WITNESS = 0, PH_ZCHAIN, PH_SPMV, PH_MSM_W, PH_CROSS, PH_MSM_T, PH_RO, PH_FOLD, PH_HOST_EC, PH_COUNT };
+
+struct vimz_prover {
+  vimz_ctx* ctx = nullptr;
+  const vimz_circuit* circuit = nullptr;
+  const vimz_bases* ck = nullptr;
+  uint32_t n_wires = 0, n_c = 0, len_z = 0, n_priv = 0, n_aux = 0, n_jobs = 0, n_fops = 0;
+  size_t max_batch = 0;
+  // device: shape
+  CsrDev A{}, B{}, C{};
+  const uint32_t* dict = nullptr;
+  WitnessDev wd{};
+  std::vector<void*> owned;   // every device allocation, for cleanup
+  // device: batch buffers
+  uint32_t *priv_d = nullptr, *zs_d = nullptr, *Z_d = nullptr, *job_out_d = nullptr, *status_d = nullptr;
+  // device: running instance and per-step scratch
+  uint32_t *Zrun = nullptr, *E = nullptr, *AZ = nullptr, *BZ = nullptr, *CZ = nullptr, *T = nullptr, *az2 = nullptr, *bz2 = nullptr, *cz2 = nullptr;
+  uint32_t* bad_d = nullptr;
+  // host: running instance
+  G1Aff comm_W{}, comm_E{};
+  Fe u = Fe::zero();
+  std::vector<Fe> z_cur, z0;      // IVC state (Montgomery)
+  Fe ro = Fe::zero(), zdigest = Fe::zero();
+  uint64_t steps = 0;
+  double phase_s[PH_COUNT] = {};
+  uint64_t phase_n[PH_COUNT] = {};
+  std::vector<uint32_t> last_status;
+};
+
+namespace {
+
+Fe fe_from_canon(const uint64_t* c) { Fe x; memcpy(x.v, c, 32); return Fe::to_mont(x); }
+void fe_to_canon(const Fe& m, uint64_t* out) { Fe c = Fe::from_mont(m); memcpy(out, c.v, 32); }
+
+// numeric value of a reference on the host, for the IVC state chain (phase-B jobs / field ops only)
+struct HostEval {
+  const vimz_prover* P; const cb::Builder* b;
+  const uint64_t* priv;            // canonical private inputs of this row
+  const Fe* job_a;                 // phase-A job outputs of this row (Montgomery), indexed by job
+  std::vector<Fe> job_b, fop;      // computed here
+  const Fe* zin;
+  Fe value(const ValRef& r) const {
+    switch (r.kind) {
+      case REF_WIRE:
+        if (r.idx > b->len_z && r.idx <= 2 * b->len_z) return zin[r.idx - 1 - b->len_z];        // a step_in wire
+        if (r.idx >= 1 + 2 * b->len_z && r.idx < 1 + 2 * b->len_z + b->n_priv) return fe_from_canon(priv + 4 * (size_t)(r.idx - (1 + 2 * b->len_z)));
+        return Fe::zero();  // the builder never references other wires from phase-B inputs
+      case REF_JOB: return b->chains[b->jobs[r.idx].chain].phase == 0 ? job_a[r.idx] : job_b[r.idx];
+      case REF_FOP: return fop[r.idx];
+      case REF_ZIN: return zin[r.idx];
+      default: return Fe::zero();
+    }
+  }
+};
+
+}  // namespace
+
+extern "C" {
+
+void vimz_prover_free(vimz_prover* p) {
+  if (!p) return;
+  if (p->ctx) {
+    std::lock_guard<std::mutex> g(p->ctx->mu);
+    hipSetDevice(p->ctx->device);
+    hipStreamSynchronize(p->ctx->stream);
+    for (void* d : p->owned) hipFree(d);
+  }
+  delete p;
+}
+
+int vimz_prover_create(vimz_ctx* ctx, const vimz_circuit* circuit, const vimz_bases* ck, size_t max_batch, vimz_prover** out) {
+  if (!ctx || !circuit || !ck || !out || max_batch == 0) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_prover_create: bad argument");
+  if (ck->curve != VIMZ_CURVE_BN254_G1) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_prover_create: the step circuits are over BN254 Fr; the key must be on BN254 G1");
+  const cb::Builder& b = circuit->build->b;
+  const uint32_t n_aux = b.n_wires - 1 - 2 * b.len_z;
+  if (ck->n < n_aux || ck->n < b.n_constraints()) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_prover_create: commitment key shorter than max(witness, constraints)");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  P_TRY(hipSetDevice(ctx->device));
+  auto* p = new vimz_prover();
+  p->ctx = ctx; p->circuit = circuit; p->ck = ck; p->max_batch = max_batch;
+  p->n_wires = b.n_wires; p->n_c = b.n_constraints(); p->len_z = b.len_z; p->n_priv = b.n_priv; p->n_aux = n_aux;
+  p->n_jobs = (uint32_t)b.jobs.size(); p->n_fops = (uint32_t)b.fops.size();
+  auto fail_free = [&](const char* what, hipError_t e) { for (void* d : p->owned) hipFree(d); delete p; return vz_fail(ctx, VIMZ_ERR_HIP, what, e); };
+  hipError_t e;
+#define UP(vec, dst) do { e = upload(vec, &dst); if (dst) p->owned.push_back((void*)dst); if (e != hipSuccess) return fail_free("upload " #vec, e); } while (0)
+  UP(b.A.row_ptr, p->A.row_ptr); UP(b.A.col, p->A.col); UP(b.A.coef, p->A.coef);
+  UP(b.B.row_ptr, p->B.row_ptr); UP(b.B.col, p->B.col); UP(b.B.coef, p->B.coef);
+  UP(b.C.row_ptr, p->C.row_ptr); UP(b.C.col, p->C.col); UP(b.C.coef, p->C.coef);
+  { const Fe* d = nullptr; UP(b.dict, d); p->dict = (const uint32_t*)d; }
+  WitnessDev& W = p->wd;
+  UP(b.decomp, W.decomp); UP(b.lane_groups, W.groups); UP(b.lane_instr, W.instr); UP(b.lane_rows, W.rows);
+  UP(b.jobs, W.jobs); UP(b.chains, W.chains); UP(b.fops, W.fops);
+  W.n_decomp = (uint32_t)b.decomp.size(); W.n_groups = (uint32_t)b.lane_groups.size(); W.n_jobs = p->n_jobs;
+  W.n_chains = (uint32_t)b.chains.size(); W.n_fops = p->n_fops; W.n_wires = b.n_wires; W.len_z = b.len_z; W.n_priv = b.n_priv;
+  {
+    const cb::PoseidonTable& t3 = cb::poseidon_table(3); const cb::PoseidonTable& t9 = cb::poseidon_table(9);
+    const Fe* d;
+    UP(t3.C, d); W.pc3 = (const uint32_t*)d; UP(t3.M, d); W.pm3 = (const uint32_t*)d;
+    UP(t9.C, d); W.pc9 = (const uint32_t*)d; UP(t9.M, d); W.pm9 = (const uint32_t*)d;
+    W.rp3 = (uint32_t)t3.rp; W.rp9 = (uint32_t)t9.rp;
+  }
+#undef UP
+  auto dalloc = [&](uint32_t** dst, size_t bytes) { e = hipMalloc((void**)dst, bytes ? bytes : 32); if (e == hipSuccess) { p->owned.push_back(*dst); e = hipMemset(*dst, 0, bytes ? bytes : 32); } return e; };
+  const size_t B = max_batch;
+  if (dalloc(&p->priv_d, 32 * B * p->n_priv) != hipSuccess || dalloc(&p->zs_d, 32 * (B + 1) * p->len_z) != hipSuccess ||
+      dalloc(&p->Z_d, 32 * B * (size_t)p->n_wires) != hipSuccess || dalloc(&p->job_out_d, 32 * B * (size_t)(p->n_jobs + p->n_fops)) != hipSuccess ||
+      dalloc(&p->status_d, 4 * B) != hipSuccess || dalloc(&p->Zrun, 32 * (size_t)p->n_wires) != hipSuccess ||
+      dalloc(&p->E, 32 * (size_t)p->n_c) != hipSuccess || dalloc(&p->AZ, 32 * (size_t)p->n_c) != hipSuccess ||
+      dalloc(&p->BZ, 32 * (size_t)p->n_c) != hipSuccess || dalloc(&p->CZ, 32 * (size_t)p->n_c) != hipSuccess ||
+      dalloc(&p->T, 32 * (size_t)p->n_c) != hipSuccess || dalloc(&p->az2, 32 * (size_t)p->n_c) != hipSuccess ||
+      dalloc(&p->bz2, 32 * (size_t)p->n_c) != hipSuccess || dalloc(&p->cz2, 32 * (size_t)p->n_c) != hipSuccess ||
+      dalloc(&p->bad_d, 64) != hipSuccess)
+    return fail_free("device allocation", e);
+  p->z_cur.assign(p->len_z, Fe::zero()); p->z0 = p->z_cur;
+  *out = p;
+  return VIMZ_OK;
+}
+
+// Start a new IVC: z0 (len_z canonical elements).
+int vimz_prover_reset(vimz_prover* p, const uint64_t* z0) {
+  if (!p || !z0) return VIMZ_ERR_INVALID;
+  vimz_ctx* ctx = p->ctx;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  P_TRY(hipSetDevice(ctx->device));
+  for (uint32_t i = 0; i < p->len_z; i++) p->z_cur[i] = fe_from_canon(z0 + 4 * i);
+  p->z0 = p->z_cur;
+  p->steps = 0; p->u = Fe::zero();
+  p->comm_W.x = Fq::zero(); p->comm_W.y = Fq::zero(); p->comm_E = p->comm_W;
+  // RO state seeded with a digest of the shape (stand-in for nova-snark's pp digest)
+  Fe seed[6] = {cb::fe_from_u64(0x56494d7a), cb::fe_from_u64(p->n_c), cb::fe_from_u64(p->n_wires), cb::fe_from_u64(p->len_z),
+                cb::fe_from_u64((uint64_t)p->circuit->transformation), cb::fe_from_u64((uint64_t)p->circuit->shape.width)};
+  p->ro = cb::poseidon_hash(seed, 6);
+  p->zdigest = Fe::zero();
+  for (uint32_t i = 0; i < p->len_z; i++) { Fe in[2] = {p->zdigest, p->z_cur[i]}; p->zdigest = cb::poseidon_hash(in, 2); }
+  memset(p->phase_s, 0, sizeof(p->phase_s)); memset(p->phase_n, 0, sizeof(p->phase_n));
+  P_TRY(hipMemsetAsync(p->Zrun, 0, 32 * (size_t)p->n_wires, ctx->stream));
+  P_TRY(hipMemsetAsync(p->E, 0, 32 * (size_t)p->n_c, ctx->stream));
+  P_TRY(hipMemsetAsync(p->AZ, 0, 32 * (size_t)p->n_c, ctx->stream));
+  P_TRY(hipMemsetAsync(p->BZ, 0, 32 * (size_t)p->n_c, ctx->stream));
+  P_TRY(hipMemsetAsync(p->CZ, 0, 32 * (size_t)p->n_c, ctx->stream));
+  P_TRY(hipStreamSynchronize(ctx->stream));
+  return VIMZ_OK;
+}
+
+// Witness generation for `rows` steps starting from the prover's current IVC state.  Leaves Z_d filled and advances
+// nothing.  zs_host receives the IVC states z_k..z_{k+rows} (canonical, (rows+1) x len_z).  Caller holds the lock.
+static int witness_batch_locked(vimz_prover* p, const uint64_t* inputs, size_t rows, std::vector<Fe>& zs) {
+  vimz_ctx* ctx = p->ctx;
+  const cb::Builder& b = p->circuit->build->b;
+  hipStream_t s = ctx->stream;
+  const WitnessDev& W = p->wd;
+  double t0 = now_s();
+  P_TRY(hipMemcpyAsync(p->priv_d, inputs, 32 * rows * p->n_priv, hipMemcpyHostToDevice, s));
+  P_TRY(hipMemsetAsync(p->status_d, 0, 4 * rows, s));
+  const dim3 rows_y(1, (unsigned)rows);
+  for (uint32_t g = 0; g < W.n_decomp; g++) {
+    const uint32_t total = (b.decomp[g].nbits - 1) * b.decomp[g].count;
+    hipLaunchKernelGGL(k_wit_decomp, dim3((total + 255) / 256, (unsigned)rows), dim3(256), 0, s, W, g, p->priv_d, p->Z_d, p->status_d);
+  }
+  // phase-A chains need only the private inputs: run them first so the host can start the state chain
+  uint32_t nA = 0, nB = 0;
+  for (auto& c : b.chains) (c.phase == 0 ? nA : nB)++;
+  // (inputs are read from Z by the chain kernels, so private inputs must be in Z first; z parts are filled later)
+  std::vector<Fe> zs_tmp((rows + 1) * p->len_z, Fe::zero());
+  P_TRY(hipMemsetAsync(p->zs_d, 0, 32 * (rows + 1) * p->len_z, s));
+  hipLaunchKernelGGL(k_wit_inputs, dim3(((1 + 2 * p->len_z + p->n_priv) + 255) / 256, (unsigned)rows), dim3(256), 0, s, W, p->priv_d, p->zs_d, p->Z_d, 0u);
+  if (nA) hipLaunchKernelGGL(k_wit_chains, dim3((nA + 3) / 4, (unsigned)rows), dim3(64), 0, s, W, 0u, p->Z_d, p->job_out_d);
+  P_TRY(hipGetLastError());
+  // host: IVC state chain z_k -> z_{k+rows} from the phase-A hash outputs
+  const size_t jstride = p->n_jobs + p->n_fops;
+  std::vector<Fe> jobA(rows * jstride);
+  P_TRY(hipMemcpyAsync(jobA.data(), p->job_out_d, 32 * rows * jstride, hipMemcpyDeviceToHost, s));
+  P_TRY(hipStreamSynchronize(s));
+  p->phase_s[PH_WITNESS] += now_s() - t0; t0 = now_s();
+  zs.assign((rows + 1) * p->len_z, Fe::zero());
+  for (uint32_t i = 0; i < p->len_z; i++) zs[i] = p->z_cur[i];
+  HostEval ev; ev.P = p; ev.b = &b;
+  for (size_t r = 0; r < rows; r++) {
+    ev.priv = inputs + 4 * r * p->n_priv; ev.job_a = jobA.data() + r * jstride; ev.zin = zs.data() + r * p->len_z;
+    ev.job_b.assign(p->n_jobs, Fe::zero()); ev.fop.assign(p->n_fops, Fe::zero());
+    for (auto& c : b.chains) {
+      if (c.phase != 1) continue;
+      for (uint32_t k = 0; k < c.job_cnt; k++) {
+        const HashJob& J = b.jobs[c.job_off + k];
+        Fe in[POSEIDON_MAX_T];
+        for (uint32_t i = 0; i + 1 < J.t; i++) in[i] = ev.value(J.in[i]);
+        ev.job_b[c.job_off + k] = cb::poseidon_hash(in, (int)J.t - 1);
+      }
+    }
+    for (uint32_t f = 0; f < p->n_fops; f++) {
+      const FieldOp& F = b.fops[f];
+      if (F.op == FOP_ISZERO) { Fe in = ev.value(F.a); ev.fop[f] = in.is_zero() ? Fe::one() : Fe::zero(); }
+      else { Fe sv = ev.value(F.a), c0 = ev.value(F.b), c1 = ev.value(F.c); ev.fop[f] = Fe::add(Fe::mul(Fe::sub(c1, c0), sv), c0); }
+    }
+    Fe* zn = zs.data() + (r + 1) * p->len_z;
+    for (uint32_t i = 0; i < p->len_z; i++) zn[i] = Fe::add(ev.value(b.zout[i].ref), cb::fe_from_i64(b.zout[i].add));
+  }
+  std::vector<Fe> zs_canon(zs.size());
+  for (size_t i = 0; i < zs.size(); i++) zs_canon[i] = Fe::from_mont(zs[i]);
+  p->phase_s[PH_ZCHAIN] += now_s() - t0; t0 = now_s();
+  P_TRY(hipMemcpyAsync(p->zs_d, zs_canon.data(), 32 * zs_canon.size(), hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_wit_inputs, dim3(((1 + 2 * p->len_z) + 255) / 256, (unsigned)rows), dim3(256), 0, s, W, p->priv_d, p->zs_d, p->Z_d, 0u);
+  for (uint32_t g = 0; g < W.n_groups; g++)
+    hipLaunchKernelGGL(k_wit_lanes, dim3((b.lane_groups[g].lanes + LANE_TB - 1) / LANE_TB, (unsigned)rows), dim3(LANE_TB), 0, s, W, g, p->priv_d, p->zs_d, 0u, p->Z_d, p->status_d);
+  if (nB) hipLaunchKernelGGL(k_wit_chains, dim3((nB + 3) / 4, (unsigned)rows), dim3(64), 0, s, W, 1u, p->Z_d, p->job_out_d);
+  if (p->n_fops) hipLaunchKernelGGL(k_wit_fops, dim3(((unsigned)rows + 63) / 64), dim3(64), 0, s, W, p->Z_d, p->job_out_d, (uint32_t)rows);
+  P_TRY(hipGetLastError());
+  p->last_status.assign(rows, 0);
+  P_TRY(hipMemcpyAsync(p->last_status.data(), p->status_d, 4 * rows, hipMemcpyDeviceToHost, s));
+  P_TRY(hipStreamSynchronize(s));
+  p->phase_s[PH_WITNESS] += now_s() - t0; p->phase_n[PH_WITNESS] += rows; p->phase_n[PH_ZCHAIN] += rows;
+  (void)rows_y;
+  return VIMZ_OK;
+}
+
+// Witness generation only (parity hook for row W): fills the batch buffer and returns the full witness vectors.
+// inputs: rows x n_priv canonical; z_wires_out (optional): rows x n_wires canonical; zs_out (optional): (rows+1) x len_z;
+// status_out (optional): rows x uint32 (bit 0 = step relation unsatisfiable).
+int vimz_prover_witness(vimz_prover* p, const uint64_t* inputs, size_t rows, uint64_t* z_wires_out, uint64_t* zs_out, uint32_t* status_out) {
+  if (!p || !inputs || rows == 0 || rows > p->max_batch) return vz_fail(p ? p->ctx : nullptr, VIMZ_ERR_INVALID, "vimz_prover_witness: bad argument");
+  vimz_ctx* ctx = p->ctx;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  P_TRY(hipSetDevice(ctx->device));
+  std::vector<Fe> zs;
+  int rc = witness_batch_locked(p, inputs, rows, zs);
+  if (rc) return rc;
+  if (zs_out) for (size_t i = 0; i < zs.size(); i++) fe_to_canon(zs[i], zs_out + 4 * i);
+  if (status_out) memcpy(status_out, p->last_status.data(), 4 * rows);
+  if (z_wires_out) {
+    const size_t n = rows * (size_t)p->n_wires;
+    rc = vz_ensure_scratch(ctx, 32 * n); if (rc) return rc;
+    launch_from_mont<Fr>(ctx->stream, p->Z_d, (uint32_t*)ctx->scratch, n);
+    P_TRY(hipMemcpyAsync(z_wires_out, ctx->scratch, 32 * n, hipMemcpyDeviceToHost, ctx->stream));
+    P_TRY(hipStreamSynchronize(ctx->stream));
+  }
+  return VIMZ_OK;
+}
+
+// (A,B,C)·z on the GPU for a host vector z (n_wires canonical) -> three n_constraints canonical vectors (parity hook, row V1).
+int vimz_prover_spmv(vimz_prover* p, const uint64_t* z, uint64_t* az, uint64_t* bz, uint64_t* cz) {
+  if (!p || !z || !az || !bz || !cz) return VIMZ_ERR_INVALID;
+  vimz_ctx* ctx = p->ctx;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  P_TRY(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  int rc = vz_ensure_scratch(ctx, 32 * (size_t)p->n_wires); if (rc) return rc;
+  uint32_t* zd = (uint32_t*)ctx->scratch;
+  P_TRY(hipMemcpyAsync(zd, z, 32 * (size_t)p->n_wires, hipMemcpyHostToDevice, s));
+  launch_to_mont<Fr>(s, zd, p->n_wires);
+  hipLaunchKernelGGL(k_spmv3<Fr>, dim3(stream_grid(p->n_c)), dim3(256), 0, s, p->A, p->B, p->C, p->dict, (size_t)p->n_c, zd, p->az2, p->bz2, p->cz2);
+  uint32_t* src[3] = {p->az2, p->bz2, p->cz2}; uint64_t* dst[3] = {az, bz, cz};
+  for (int m = 0; m < 3; m++) {
+    launch_from_mont<Fr>(s, src[m], p->T, p->n_c);
+    P_TRY(hipMemcpyAsync(dst[m], p->T, 32 * (size_t)p->n_c, hipMemcpyDeviceToHost, s));
+    P_TRY(hipStreamSynchronize(s));
+  }
+  return VIMZ_OK;
+}
+
+static void ro_absorb_point(const G1Aff& pt, Fe* out2) {  // (x_lo128, x_hi | parity(y) << 126) of the canonical coordinates
+  Fq xc = Fq::from_mont(pt.x), yc = Fq::from_mont(pt.y);
+  Fe lo = Fe::zero(), hi = Fe::zero();
+  for (int i = 0; i < 4; i++) { lo.v[i] = xc.v[i]; hi.v[i] = xc.v[4 + i]; }
+  hi.v[3] |= (yc.v[0] & 1u) << 30;
+  out2[0] = Fe::to_mont(lo); out2[1] = Fe::to_mont(hi);
+}
+
+// Fold `nsteps` more rows.  step_inputs: nsteps x n_priv canonical elements, in the flattened order of
+// vimz/src/nova_snark_backend/input.rs:57-96 (row_orig rows, then row_tran rows; redact: block then indicator).
+int vimz_prover_fold(vimz_prover* p, const uint64_t* step_inputs, size_t nsteps) {
+  if (!p || (!step_inputs && nsteps)) return VIMZ_ERR_INVALID;
+  vimz_ctx* ctx = p->ctx;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  P_TRY(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  const size_t nw = p->n_wires, nc = p->n_c;
+  const uint32_t aux0 = 1 + 2 * p->len_z;
+  size_t done = 0;
+  while (done < nsteps) {
+    const size_t rows = std::min(p->max_batch, nsteps - done);
+    std::vector<Fe> zs;
+    int rc = witness_batch_locked(p, step_inputs + 4 * done * p->n_priv, rows, zs);
+    if (rc) return rc;
+    for (size_t r = 0; r < rows; r++) if (p->last_status[r]) {
+      char msg[128]; snprintf(msg, sizeof(msg), "step %llu: the step relation is not satisfiable for these rows", (unsigned long long)(p->steps + r));
+      return vz_fail(ctx, VIMZ_ERR_UNSAT, msg);
+    }
+    for (size_t r = 0; r < rows; r++) {
+      uint32_t* Zi = p->Z_d + 8 * r * nw;
+      double t0 = now_s();
+      hipLaunchKernelGGL(k_spmv3<Fr>, dim3(stream_grid(nc)), dim3(256), 0, s, p->A, p->B, p->C, p->dict, nc, Zi, p->az2, p->bz2, p->cz2);
+      P_TRY(hipGetLastError());
+      uint64_t pt[8];
+      // comm_W2 over the aux part of z (everything after [1 | X])
+      rc = vz_msm_device(ctx, p->ck, 0, Zi + 8 * (size_t)aux0, p->n_aux, 1, 0, pt, VIMZ_FORM_MONTGOMERY);
+      if (rc) return rc;
+      p->phase_s[PH_SPMV] += 0; p->phase_s[PH_MSM_W] += now_s() - t0; p->phase_n[PH_MSM_W]++;
+      G1Aff cW2; memcpy(cW2.x.v, pt, 32); memcpy(cW2.y.v, pt + 4, 32);
+      const Fe* znext = zs.data() + (r + 1) * p->len_z;
+      for (uint32_t i = 0; i < p->len_z; i++) { Fe in[2] = {p->zdigest, znext[i]}; p->zdigest = cb::poseidon_hash(in, 2); }
+      if (p->steps == 0) {
+        // base case: the running instance IS the first fresh instance (u = 1, E = 0), as RecursiveSNARK::new does
+        P_TRY(hipMemcpyAsync(p->Zrun, Zi, 32 * nw, hipMemcpyDeviceToDevice, s));
+        P_TRY(hipMemcpyAsync(p->AZ, p->az2, 32 * nc, hipMemcpyDeviceToDevice, s));
+        P_TRY(hipMemcpyAsync(p->BZ, p->bz2, 32 * nc, hipMemcpyDeviceToDevice, s));
+        P_TRY(hipMemcpyAsync(p->CZ, p->cz2, 32 * nc, hipMemcpyDeviceToDevice, s));
+        p->comm_W = cW2; p->u = Fe::one();
+        Fe ab[8]; Fe cw[2]; ro_absorb_point(cW2, cw);
+        ab[0] = p->ro; ab[1] = cw[0]; ab[2] = cw[1]; ab[3] = p->zdigest;
+        p->ro = cb::poseidon_hash(ab, 4);
+      } else {
+        t0 = now_s();
+        hipLaunchKernelGGL(k_cross_term<Fr>, dim3(stream_grid(nc)), dim3(256), 0, s, nc, p->AZ, p->BZ, p->CZ, p->u, p->az2, p->bz2, p->cz2, Fe::one(), p->T);
+        P_TRY(hipGetLastError());
+        rc = vz_msm_device(ctx, p->ck, 0, p->T, nc, 1, 0, pt, VIMZ_FORM_MONTGOMERY);
+        if (rc) return rc;
+        p->phase_s[PH_MSM_T] += now_s() - t0; p->phase_n[PH_MSM_T]++;
+        t0 = now_s();
+        G1Aff cT; memcpy(cT.x.v, pt, 32); memcpy(cT.y.v, pt + 4, 32);
+        // r = low 128 bits of Poseidon(ro, comm_W2, comm_T, digest of the IVC states so far)
+        Fe ab[6]; Fe a2[2];
+        ab[0] = p->ro; ro_absorb_point(cW2, a2); ab[1] = a2[0]; ab[2] = a2[1]; ro_absorb_point(cT, a2); ab[3] = a2[0]; ab[4] = a2[1]; ab[5] = p->zdigest;
+        p->ro = cb::poseidon_hash(ab, 6);
+        Fe rc_canon = Fe::from_mont(p->ro);
+        Fe r128 = Fe::zero(); for (int i = 0; i < 4; i++) r128.v[i] = rc_canon.v[i];
+        const Fe rm = Fe::to_mont(r128);
+        p->phase_s[PH_RO] += now_s() - t0; p->phase_n[PH_RO]++; t0 = now_s();
+        Fold5 f;
+        f.x1[0] = p->Zrun; f.x2[0] = Zi; f.n[0] = nw;
+        f.x1[1] = p->E; f.x2[1] = p->T; f.n[1] = nc;
+        f.x1[2] = p->AZ; f.x2[2] = p->az2; f.n[2] = nc;
+        f.x1[3] = p->BZ; f.x2[3] = p->bz2; f.n[3] = nc;
+        f.x1[4] = p->CZ; f.x2[4] = p->cz2; f.n[4] = nc;
+        hipLaunchKernelGGL(k_fold5<Fr>, dim3(2048), dim3(256), 0, s, f, rm);
+        P_TRY(hipGetLastError());
+        // host side of the fold, overlapped with the kernel above
+        G1 a = from_affine(p->comm_W); G1 rb = scalar_mul(cW2, r128.v, 128); add_full(a, rb); p->comm_W = to_affine(a);
+        G1 e1 = from_affine(p->comm_E); G1 rt = scalar_mul(cT, r128.v, 128); add_full(e1, rt); p->comm_E = to_affine(e1);
+        p->u = Fe::add(p->u, rm);
+        p->phase_s[PH_HOST_EC] += now_s() - t0; p->phase_n[PH_HOST_EC]++;
+        t0 = now_s();
+        P_TRY(hipStreamSynchronize(s));
+        p->phase_s[PH_FOLD] += now_s() - t0; p->phase_n[PH_FOLD]++;
+      }
+      p->steps++;
+    }
+    for (uint32_t i = 0; i < p->len_z; i++) p->z_cur[i] = zs[rows * p->len_z + i];
+    done += rows;
+  }
+  P_TRY(hipStreamSynchronize(s));
+  return VIMZ_OK;
+}
+
+// Running instance: comm_W, comm_E (affine canonical), u, X = (z_i, z_0 ...) — here X is read back from Zrun.
+int vimz_prover_instance(vimz_prover* p, uint64_t comm_W[8], uint64_t comm_E[8], uint64_t u[4], uint64_t* z_current, uint64_t* steps) {
+  if (!p) return VIMZ_ERR_INVALID;
+  if (comm_W) { Fq x = Fq::from_mont(p->comm_W.x), y = Fq::from_mont(p->comm_W.y); memcpy(comm_W, x.v, 32); memcpy(comm_W + 4, y.v, 32); }
+  if (comm_E) { Fq x = Fq::from_mont(p->comm_E.x), y = Fq::from_mont(p->comm_E.y); memcpy(comm_E, x.v, 32); memcpy(comm_E + 4, y.v, 32); }
+  if (u) fe_to_canon(p->u, u);
+  if (z_current) for (uint32_t i = 0; i < p->len_z; i++) fe_to_canon(p->z_cur[i], z_current + 4 * i);
+  if (steps) *steps = p->steps;
+  return VIMZ_OK;
+}
+
+// Download the running witness vectors (canonical): z_run n_wires ([u | X | W]), E n_constraints.
+int vimz_prover_running(vimz_prover* p, uint64_t* z_run, uint64_t* E) {
+  if (!p) return VIMZ_ERR_INVALID;
+  vimz_ctx* ctx = p->ctx;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  P_TRY(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  const size_t mx = std::max((size_t)p->n_wires, (size_t)p->n_c);
+  int rc = vz_ensure_scratch(ctx, 32 * mx); if (rc) return rc;
+  if (z_run) { launch_from_mont<Fr>(s, p->Zrun, (uint32_t*)ctx->scratch, p->n_wires); P_TRY(hipMemcpyAsync(z_run, ctx->scratch, 32 * (size_t)p->n_wires, hipMemcpyDeviceToHost, s)); P_TRY(hipStreamSynchronize(s)); }
+  if (E) { launch_from_mont<Fr>(s, p->E, (uint32_t*)ctx->scratch, p->n_c); P_TRY(hipMemcpyAsync(E, ctx->scratch, 32 * (size_t)p->n_c, hipMemcpyDeviceToHost, s)); P_TRY(hipStreamSynchronize(s)); }
+  return VIMZ_OK;
+}
+
+// verify_folded_proof (vimz/src/nova_snark_backend/folding.rs:45-56 -> RecursiveSNARK::verify's is_sat_relaxed):
+// recompute (A,B,C)·Z from the folded witness, check Az∘Bz = u·Cz + E row by row, and re-open both commitments.
+// result: 0 = accepted; bit 0 = relation violated, bit 1 = comm_W mismatch, bit 2 = comm_E mismatch, bit 3 = running products drifted.
+int vimz_prover_verify(vimz_prover* p, uint32_t* result) {
+  if (!p || !result) return VIMZ_ERR_INVALID;
+  vimz_ctx* ctx = p->ctx;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  P_TRY(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  const size_t nc = p->n_c;
+  uint32_t res = 0;
+  hipLaunchKernelGGL(k_spmv3<Fr>, dim3(stream_grid(nc)), dim3(256), 0, s, p->A, p->B, p->C, p->dict, nc, p->Zrun, p->az2, p->bz2, p->cz2);
+  uint32_t init[2] = {0, 0xffffffffu};
+  P_TRY(hipMemcpyAsync(p->bad_d, init, 8, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_check_relaxed<Fr>, dim3(stream_grid(nc)), dim3(256), 0, s, nc, p->az2, p->bz2, p->cz2, p->u, (const uint32_t*)p->E, p->bad_d);
+  uint32_t bad[2];
+  P_TRY(hipMemcpyAsync(bad, p->bad_d, 8, hipMemcpyDeviceToHost, s));
+  P_TRY(hipStreamSynchronize(s));
+  if (bad[0]) res |= 1;
+  // running products must equal the recomputed ones (linearity bookkeeping)
+  P_TRY(hipMemcpyAsync(p->bad_d, init, 8, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_check_relaxed<Fr>, dim3(stream_grid(nc)), dim3(256), 0, s, nc, p->AZ, p->BZ, p->CZ, p->u, (const uint32_t*)p->E, p->bad_d);
+  P_TRY(hipMemcpyAsync(bad, p->bad_d, 8, hipMemcpyDeviceToHost, s));
+  P_TRY(hipStreamSynchronize(s));
+  if (bad[0]) res |= 8;
+  uint64_t pt[8];
+  int rc = vz_msm_device(ctx, p->ck, 0, p->Zrun + 8 * (size_t)(1 + 2 * p->len_z), p->n_aux, 1, 0, pt, VIMZ_FORM_MONTGOMERY);
+  if (rc) return rc;
+  if (memcmp(pt, p->comm_W.x.v, 32) || memcmp(pt + 4, p->comm_W.y.v, 32)) res |= 2;
+  rc = vz_msm_device(ctx, p->ck, 0, p->E, nc, 1, 0, pt, VIMZ_FORM_MONTGOMERY);
+  if (rc) return rc;
+  if (memcmp(pt, p->comm_E.x.v, 32) || memcmp(pt + 4, p->comm_E.y.v, 32)) res |= 4;
+  *result = res;
+  return VIMZ_OK;
+}
+
+// seconds[9] / counts[9]: witness, state chain (host), spmv, msm(W), cross term, msm(T), RO (host), fold, host EC
+int vimz_prover_profile(const vimz_prover* p, double seconds[9], uint64_t counts[9]) {
+  if (!p) return VIMZ_ERR_INVALID;
+  if (seconds) memcpy(seconds, p->phase_s, sizeof(double) * PH_COUNT);
+  if (counts) memcpy(counts, p->phase_n, sizeof(uint64_t) * PH_COUNT);
+  return VIMZ_OK;
+}
+
+}  // extern "C"

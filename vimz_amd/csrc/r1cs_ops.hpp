@@ -1,0 +1,79 @@
+// Relaxed-R1CS kernels of one Nova fold (SURVEY.md §8a rows V1, V2, F1', X1) over vectors resident in HBM.
+//   k_spmv3        (A,B,C)·z for a fresh witness — replaces R1CSShape::multiply_vec (nova-snark 0.23.0).
+//                  CSR with a coefficient dictionary: 8 B per non-zero (column, dictionary index); the few-10^3-entry
+//                  dictionary and the hot part of z live in L2.  One thread per constraint row.
+//   k_cross_term   T = Az1∘Bz2 + Az2∘Bz1 − u1·Cz2 − u2·Cz1          (commit_T's cross term)
+//   k_fold5        W, E, Az, Bz, Cz  <-  x1 + r·x2  in one pass  (RelaxedR1CSWitness::fold + the running products,
+//                  kept by linearity so the running instance never needs an SpMV again)
+//   k_check_relaxed  counts rows with Az∘Bz != u·Cz + E             (is_sat_relaxed)
+// All element-wise kernels are HBM streaming kernels: 32 B per element per operand, two 16-byte accesses per lane.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "vecops.hpp"
+
+namespace vz {
+
+struct CsrDev { const uint32_t* row_ptr; const uint32_t* col; const uint32_t* coef; };
+
+template <class F>
+__global__ void __launch_bounds__(256) k_spmv3(CsrDev A, CsrDev B, CsrDev C, const uint32_t* __restrict__ dict, size_t nrows,
+                                               const uint32_t* __restrict__ z, uint32_t* __restrict__ az, uint32_t* __restrict__ bz, uint32_t* __restrict__ cz) {
+  VZ_GRID_STRIDE(r, nrows) {
+    const CsrDev M[3] = {A, B, C};
+    uint32_t* out[3] = {az, bz, cz};
+#pragma unroll 1
+    for (int m = 0; m < 3; m++) {
+      F acc = F::zero();
+      const uint32_t lo = M[m].row_ptr[r], hi = M[m].row_ptr[r + 1];
+      for (uint32_t k = lo; k < hi; k++) {
+        const F c = load_fe<F>(dict, M[m].coef[k]);
+        const F v = load_fe<F>(z, M[m].col[k]);
+        acc = F::add(acc, F::mul(c, v));
+      }
+      store_fe(out[m], r, acc);
+    }
+  }
+}
+
+template <class F>
+__global__ void __launch_bounds__(256) k_cross_term(size_t n, const uint32_t* __restrict__ az1, const uint32_t* __restrict__ bz1, const uint32_t* __restrict__ cz1, F u1,
+                                                    const uint32_t* __restrict__ az2, const uint32_t* __restrict__ bz2, const uint32_t* __restrict__ cz2, F u2,
+                                                    uint32_t* __restrict__ T) {
+  VZ_GRID_STRIDE(i, n) {
+    F t = F::mul(load_fe<F>(az1, i), load_fe<F>(bz2, i));
+    t = F::add(t, F::mul(load_fe<F>(az2, i), load_fe<F>(bz1, i)));
+    t = F::sub(t, F::mul(u1, load_fe<F>(cz2, i)));
+    t = F::sub(t, F::mul(u2, load_fe<F>(cz1, i)));
+    store_fe(T, i, t);
+  }
+}
+
+// x1[i] += r * x2[i]
+template <class F>
+__global__ void __launch_bounds__(256) k_axpy_inplace(size_t n, uint32_t* __restrict__ x1, F r, const uint32_t* __restrict__ x2) {
+  VZ_GRID_STRIDE(i, n) store_fe(x1, i, F::add(load_fe<F>(x1, i), F::mul(r, load_fe<F>(x2, i))));
+}
+
+struct Fold5 { uint32_t* x1[5]; const uint32_t* x2[5]; size_t n[5]; };
+template <class F>
+__global__ void __launch_bounds__(256) k_fold5(Fold5 a, F r) {
+#pragma unroll 1
+  for (int v = 0; v < 5; v++) {
+    uint32_t* x1 = a.x1[v]; const uint32_t* x2 = a.x2[v];
+    if (!x1) continue;
+    VZ_GRID_STRIDE(i, a.n[v]) store_fe(x1, i, F::add(load_fe<F>(x1, i), F::mul(r, load_fe<F>(x2, i))));
+  }
+}
+
+template <class F>
+__global__ void __launch_bounds__(256) k_check_relaxed(size_t n, const uint32_t* __restrict__ az, const uint32_t* __restrict__ bz, const uint32_t* __restrict__ cz,
+                                                       F u, const uint32_t* __restrict__ E, uint32_t* __restrict__ bad /* [0]=count, [1]=first row+1 */) {
+  VZ_GRID_STRIDE(i, n) {
+    F lhs = F::mul(load_fe<F>(az, i), load_fe<F>(bz, i));
+    F rhs = F::mul(u, load_fe<F>(cz, i));
+    if (E) rhs = F::add(rhs, load_fe<F>(E, i));
+    if (!lhs.eq(rhs)) { atomicAdd(&bad[0], 1u); atomicMin(&bad[1], (uint32_t)i); }
+  }
+}
+
+}  // namespace vz

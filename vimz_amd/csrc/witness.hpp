@@ -1,0 +1,276 @@
+// GPU witness generation for a BATCH of folding steps — replaces the circom witness generator that
+// nova-scotia spawns as a child process once per step (reference call site
+// vimz/src/nova_snark_backend/folding.rs:35-41).  Executes the witness program (circuit/program.hpp).
+//
+// All rows of a batch are independent given the IVC states, so the batch dimension supplies the
+// parallelism the sequential Poseidon chains lack:
+//   k_wit_inputs   z[0] = 1, step_out, step_in, private inputs (canonical -> Montgomery)
+//   k_wit_decomp   Num2Bits(240) of every packed element; thread = (row, bit, element), bit-major wires
+//                  so consecutive lanes write consecutive 32-byte wires
+//   k_wit_lanes    the integer lane programs; thread = (row, lane), registers in LDS, slot-major wires
+//   k_wit_chains   Poseidon chains; 16 lanes co-operate on one permutation (lane i owns state[i], the MDS
+//                  row is gathered with wave shuffles), 4 chains per wave
+//   k_wit_fops     IsZero / Mux1 on full-width values
+// Layout in HBM: Z[row][wire], 32-byte Montgomery elements, row stride = n_wires.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "fp.hpp"
+#include "circuit/program.hpp"
+#include "vecops.hpp"
+
+namespace vz {
+
+typedef Fp<BnFr> Fr;
+
+struct WitnessDev {  // device copies of the program tables
+  const DecompGroup* decomp; uint32_t n_decomp;
+  const LaneGroup* groups; uint32_t n_groups;
+  const LaneInstr* instr;
+  const LaneRow* rows;
+  const HashJob* jobs; uint32_t n_jobs;
+  const Chain* chains; uint32_t n_chains;
+  const FieldOp* fops; uint32_t n_fops;
+  const uint32_t* pc3; const uint32_t* pm3;   // Poseidon constants t=3 (Montgomery): C then M
+  const uint32_t* pc9; const uint32_t* pm9;   // t=9
+  uint32_t rp3, rp9;
+  uint32_t n_wires, len_z, n_priv;
+};
+
+__device__ __forceinline__ Fr fr_from_small(long long v) {  // small signed integer -> Montgomery
+  Fr x = Fr::zero();
+  unsigned long long m = v < 0 ? (unsigned long long)(-v) : (unsigned long long)v;
+  x.v[0] = (uint32_t)m; x.v[1] = (uint32_t)(m >> 32);
+  x = Fr::to_mont(x);
+  return v < 0 ? Fr::neg(x) : x;
+}
+
+// status bits per row
+enum : uint32_t { WIT_UNSAT = 1u, WIT_BAD_INPUT = 2u };
+
+__global__ void __launch_bounds__(256) k_wit_inputs(WitnessDev P, const uint32_t* __restrict__ priv, const uint32_t* __restrict__ zs,
+                                                    uint32_t* __restrict__ Z, uint32_t first_row) {
+  const uint32_t row = blockIdx.y;
+  const size_t zrow = (size_t)row * P.n_wires;
+  const uint32_t n = 1 + 2 * P.len_z + P.n_priv;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    Fr v;
+    if (i == 0) v = Fr::one();
+    else if (i <= P.len_z) v = Fr::to_mont(load_fe<Fr>(zs, (size_t)(first_row + row + 1) * P.len_z + (i - 1)));       // step_out = z_{k+1}
+    else if (i <= 2 * P.len_z) v = Fr::to_mont(load_fe<Fr>(zs, (size_t)(first_row + row) * P.len_z + (i - 1 - P.len_z)));  // step_in = z_k
+    else v = Fr::to_mont(load_fe<Fr>(priv, (size_t)row * P.n_priv + (i - 1 - 2 * P.len_z)));
+    store_fe(Z, zrow + i, v);
+  }
+}
+
+__global__ void __launch_bounds__(256) k_wit_decomp(WitnessDev P, uint32_t g, const uint32_t* __restrict__ priv, uint32_t* __restrict__ Z,
+                                                    uint32_t* __restrict__ status) {
+  const DecompGroup D = P.decomp[g];
+  const uint32_t row = blockIdx.y;
+  const uint32_t total = (D.nbits - 1) * D.count;
+  const uint32_t priv0 = 1 + 2 * P.len_z;
+  const Fr one = Fr::one(), zero = Fr::zero();
+  for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const uint32_t k = idx / D.count + 1, j = idx % D.count;
+    const uint32_t* v = priv + 8 * ((size_t)row * P.n_priv + (D.src_wire - priv0 + j));
+    const uint32_t bit = (v[k >> 5] >> (k & 31)) & 1u;
+    store_fe(Z, (size_t)row * P.n_wires + D.bit_base + idx, bit ? one : zero);
+    if (k == 1) {  // one lane per element checks the range
+      uint32_t hi = 0;
+      for (uint32_t b = D.nbits; b < 256; b++) hi |= (v[b >> 5] >> (b & 31)) & 1u;
+      if (hi) atomicOr(&status[row], WIT_UNSAT);
+    }
+  }
+}
+
+constexpr int LANE_TB = 64;
+constexpr int LANE_REGS = 60;
+
+__global__ void __launch_bounds__(LANE_TB) k_wit_lanes(WitnessDev P, uint32_t g, const uint32_t* __restrict__ priv, const uint32_t* __restrict__ zs,
+                                                        uint32_t first_row, uint32_t* __restrict__ Z, uint32_t* __restrict__ status) {
+  __shared__ long long regs[LANE_REGS][LANE_TB];
+  const LaneGroup G = P.groups[g];
+  const uint32_t row = blockIdx.y;
+  const uint32_t lane = blockIdx.x * LANE_TB + threadIdx.x;
+  if (lane >= G.lanes) return;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t x = lane % G.pixels, col = (lane / G.pixels) % G.colours;
+  const uint32_t priv0 = 1 + 2 * P.len_z;
+  const size_t zrow = (size_t)row * P.n_wires;
+  const uint32_t* prow = priv + 8 * (size_t)row * P.n_priv;
+  uint32_t st = 0;
+  const Fr one = Fr::one(), zero = Fr::zero();
+  for (uint32_t pc = 0; pc < G.prog_len; pc++) {
+    const LaneInstr I = P.instr[G.prog_off + pc];
+    switch (I.op) {
+      case LOP_LDB: {
+        const LaneRow R = P.rows[G.row_off + I.a];
+        const long px = (long)x * I.imm2 + I.imm;
+        const int c = I.b == 3 ? (int)col : (int)I.b;
+        long long v = 0;
+        if (px >= 0 && px < (long)R.count * 10) {
+          const uint32_t* e = prow + 8 * (size_t)(R.src_wire - priv0 + (uint32_t)(px / 10));
+          const int byte = (int)(px % 10) * 3 + c;
+          v = (e[byte >> 2] >> (8 * (byte & 3))) & 0xff;
+        }
+        regs[I.d][tid] = v;
+        break;
+      }
+      case LOP_LDZ: {
+        const uint32_t* e = zs + 8 * ((size_t)(first_row + row) * P.len_z + (uint32_t)I.imm);
+        uint32_t hi = (e[1] >> 8) | e[2] | e[3] | e[4] | e[5] | e[6] | e[7];
+        if (hi) st |= WIT_UNSAT;
+        regs[I.d][tid] = (long long)(((unsigned long long)(e[1] & 0xff) << 32) | e[0]);
+        break;
+      }
+      case LOP_LI: regs[I.d][tid] = I.imm; break;
+      case LOP_ADD: regs[I.d][tid] = regs[I.a][tid] + regs[I.b][tid]; break;
+      case LOP_SUB: regs[I.d][tid] = regs[I.a][tid] - regs[I.b][tid]; break;
+      case LOP_MUL: regs[I.d][tid] = regs[I.a][tid] * regs[I.b][tid]; break;
+      case LOP_MULI: regs[I.d][tid] = regs[I.a][tid] * I.imm; break;
+      case LOP_ADDI: regs[I.d][tid] = regs[I.a][tid] + I.imm; break;
+      case LOP_LEQ: {
+        const long long v = regs[I.a][tid] + (1ll << I.imm) - (regs[I.b][tid] + 1);
+        regs[I.d][tid] = ((v >> I.imm) & 1) ? 0 : 1;
+        break;
+      }
+      case LOP_SEL: regs[I.d][tid] = regs[I.a][tid] ? regs[I.b][tid] : regs[I.imm][tid]; break;
+      case LOP_BITS: {
+        const long long v = regs[I.a][tid];
+        const bool ok = v >= 0 && v < (1ll << I.imm);
+        if (!ok) st |= WIT_UNSAT;
+        for (int k = 1; k < I.imm; k++) {
+          const bool bit = ok && ((v >> k) & 1);
+          store_fe(Z, zrow + G.wire_base + (size_t)(I.imm2 + k - 1) * G.lanes + lane, bit ? one : zero);
+        }
+        break;
+      }
+      case LOP_EMIT:
+        store_fe(Z, zrow + G.wire_base + (size_t)I.imm * G.lanes + lane, fr_from_small(regs[I.a][tid]));
+        break;
+      default: st |= WIT_BAD_INPUT; break;
+    }
+  }
+  if (st) atomicOr(&status[row], st);
+}
+
+// ---- Poseidon chains: 16 lanes per chain ---------------------------------------------------------------
+__device__ __forceinline__ Fr shfl_fe(const Fr& v, int src_lane) {
+  Fr r;
+#pragma unroll
+  for (int k = 0; k < 8; k++) r.v[k] = __shfl(v.v[k], src_lane);
+  return r;
+}
+
+__device__ __forceinline__ Fr wit_value(const WitnessDev& P, const ValRef& r, const uint32_t* __restrict__ Zrow, const uint32_t* __restrict__ job_out_row) {
+  switch (r.kind) {
+    case REF_WIRE: return load_fe<Fr>(Zrow, r.idx);
+    case REF_JOB: return load_fe<Fr>(job_out_row, r.idx);
+    case REF_FOP: return load_fe<Fr>(job_out_row, P.n_jobs + r.idx);
+    case REF_ZIN: return load_fe<Fr>(Zrow, 1 + P.len_z + r.idx);
+    default: return Fr::zero();
+  }
+}
+
+// grid.x covers chains of `phase` in groups of 16 lanes; grid.y = row.  job_out: [row][n_jobs + n_fops] Montgomery.
+__global__ void __launch_bounds__(64) k_wit_chains(WitnessDev P, uint32_t phase, uint32_t* __restrict__ Z, uint32_t* __restrict__ job_out) {
+  const uint32_t row = blockIdx.y;
+  const uint32_t sub = threadIdx.x >> 4, li = threadIdx.x & 15;
+  const int lane_base = (int)(threadIdx.x & ~15u);
+  // the k-th chain of this phase
+  uint32_t want = blockIdx.x * 4 + sub, seen = 0, cid = 0xffffffffu;
+  for (uint32_t c = 0; c < P.n_chains; c++) if (P.chains[c].phase == phase) { if (seen == want) { cid = c; break; } seen++; }
+  const bool active_chain = cid != 0xffffffffu;
+  uint32_t* Zrow = Z + 8 * (size_t)row * P.n_wires;
+  uint32_t* jrow = job_out + 8 * (size_t)row * (P.n_jobs + P.n_fops);
+  const uint32_t njobs = active_chain ? P.chains[cid].job_cnt : 0;
+  // all 64 lanes run the same number of iterations of the outer loop as the longest chain in the wave so that the
+  // shuffles stay convergent: take the maximum over the wave
+  uint32_t max_jobs = njobs;
+  for (int off = 32; off >= 16; off >>= 1) max_jobs = max(max_jobs, (uint32_t)__shfl_xor((int)max_jobs, off));
+  Fr prev_out = Fr::zero();  // output of the previous job of this chain, kept in registers (no memory round trip)
+  for (uint32_t k = 0; k < max_jobs; k++) {
+    const bool live = k < njobs;
+    HashJob J;
+    if (live) J = P.jobs[P.chains[cid].job_off + k]; else { J.t = 3; J.wire_base = 0; J.out_wire = 0; }
+    const uint32_t t = J.t;
+    const uint32_t* PC = t == 3 ? P.pc3 : P.pc9;
+    const uint32_t* PM = t == 3 ? P.pm3 : P.pm9;
+    const uint32_t rp = t == 3 ? P.rp3 : P.rp9;
+    const uint32_t R = 8 + rp;
+    // initial state: lane 0 -> 0, lane i -> input i-1
+    Fr s = Fr::zero();
+    bool in_const = true;
+    if (live && li >= 1 && li < t) {
+      const ValRef ref = J.in[li - 1];
+      in_const = ref.kind == REF_CONST_ZERO;
+      if (ref.kind == REF_JOB && k > 0 && ref.idx == P.chains[cid].job_off + k - 1) s = prev_out;
+      else s = wit_value(P, ref, Zrow, jrow);
+    }
+    // number of non-folded round-0 S-boxes before this lane / in total (lanes 1..t-1 with non-constant input)
+    const unsigned long long nf_mask = __ballot(live && li >= 1 && li < t && !in_const);
+    const uint32_t grp_mask16 = (uint32_t)((nf_mask >> lane_base) & 0xffffull);
+    const uint32_t nf_before = __popc(grp_mask16 & ((1u << li) - 1u));
+    const uint32_t nf0 = __popc(grp_mask16);
+    const uint32_t elim_slot = 3 * (nf0 + 3 * t + rp + 3 * t) + 2;  // x5 of (last round, lane 0)
+    for (uint32_t r = 0; r < R; r++) {
+      const bool full = r < 4 || r >= 4 + rp;
+      const bool mine = li < t;
+      if (mine) s = Fr::add(s, load_fe<Fr>(PC, (size_t)r * t + li));
+      if (mine && (full || li == 0)) {
+        const Fr x2 = Fr::sqr(s), x4 = Fr::sqr(x2), x5 = Fr::mul(x4, s);
+        const bool folded = r == 0 && in_const;
+        if (live && !folded) {
+          uint32_t index;
+          if (r == 0) index = nf_before;
+          else if (r < 4) index = nf0 + (r - 1) * t + li;
+          else if (r < 4 + rp) index = nf0 + 3 * t + (r - 4);
+          else index = nf0 + 3 * t + rp + (r - 4 - rp) * t + li;
+          uint32_t slot = 3 * index;
+          const bool bound = J.out_wire != 0;
+          auto wire_of = [&](uint32_t sl) { return J.wire_base + sl - ((bound && sl > elim_slot) ? 1u : 0u); };
+          store_fe(Zrow, wire_of(slot), x2);
+          store_fe(Zrow, wire_of(slot + 1), x4);
+          if (!(bound && slot + 2 == elim_slot)) store_fe(Zrow, wire_of(slot + 2), x5);
+        }
+        s = x5;
+      }
+      // MDS: new[i] = sum_j M[i][j] * s[j]
+      Fr acc = Fr::zero();
+      for (uint32_t j = 0; j < t; j++) {
+        const Fr sj = shfl_fe(s, lane_base + (int)j);
+        if (mine) acc = Fr::add(acc, Fr::mul(load_fe<Fr>(PM, (size_t)li * t + j), sj));
+      }
+      s = acc;
+    }
+    prev_out = shfl_fe(s, lane_base);
+    if (live && li == 0) {
+      store_fe(jrow, P.chains[cid].job_off + k, s);
+      if (J.out_wire) store_fe(Zrow, J.out_wire, s);
+    }
+    __threadfence_block();  // later jobs of this chain (same 16 lanes) read job_out / wires written above
+  }
+}
+
+__global__ void __launch_bounds__(64) k_wit_fops(WitnessDev P, uint32_t* __restrict__ Z, uint32_t* __restrict__ job_out, uint32_t rows) {
+  const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= rows) return;
+  uint32_t* Zrow = Z + 8 * (size_t)row * P.n_wires;
+  uint32_t* jrow = job_out + 8 * (size_t)row * (P.n_jobs + P.n_fops);
+  for (uint32_t f = 0; f < P.n_fops; f++) {
+    const FieldOp F = P.fops[f];
+    if (F.op == FOP_ISZERO) {
+      const Fr in = wit_value(P, F.a, Zrow, jrow);
+      const Fr inv = Fr::pow_pm2(in);                 // 0 -> 0
+      const Fr out = Fr::sub(Fr::one(), Fr::mul(in, inv));
+      store_fe(Zrow, F.wire, inv); store_fe(Zrow, F.wire + 1, out);
+      store_fe(jrow, P.n_jobs + f, out);
+    } else if (F.op == FOP_MUX) {
+      const Fr s = wit_value(P, F.a, Zrow, jrow), c0 = wit_value(P, F.b, Zrow, jrow), c1 = wit_value(P, F.c, Zrow, jrow);
+      const Fr prod = Fr::mul(Fr::sub(c1, c0), s), out = Fr::add(prod, c0);
+      store_fe(Zrow, F.wire, F.bound ? out : prod);
+      store_fe(jrow, P.n_jobs + f, out);
+    }
+  }
+}
+
+}  // namespace vz

@@ -157,3 +157,86 @@ class Context:
         out = np.zeros((n, 8), dtype=np.uint64)
         self._chk(self.lib.vimz_curve_add(self.h, curve, _ptr(p), _ptr(q), _ptr(out), n))
         return out
+
+
+class Prover:
+    """vimz_prover: GPU folding of one transformation's step circuit (mirrors `fold_input`,
+    vimz/src/nova_snark_backend/folding.rs:27-43)."""
+    PHASES = ["witness", "state_chain_host", "spmv", "msm_w", "cross_term", "msm_t", "ro_host", "fold", "host_ec"]
+
+    def __init__(self, ctx, circuit, ck, max_batch=16):
+        self.ctx, self.circuit, self.ck = ctx, circuit, ck
+        lib = ctx.lib
+        vp, sz = C.c_void_p, C.c_size_t
+        lib.vimz_prover_create.argtypes = [vp, vp, vp, sz, C.POINTER(vp)]
+        lib.vimz_prover_free.argtypes = [vp]
+        lib.vimz_prover_free.restype = None
+        lib.vimz_prover_reset.argtypes = [vp, vp]
+        lib.vimz_prover_fold.argtypes = [vp, vp, sz]
+        lib.vimz_prover_verify.argtypes = [vp, C.POINTER(C.c_uint32)]
+        lib.vimz_prover_instance.argtypes = [vp, vp, vp, vp, vp, C.POINTER(C.c_uint64)]
+        lib.vimz_prover_running.argtypes = [vp, vp, vp]
+        lib.vimz_prover_profile.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+        lib.vimz_prover_witness.argtypes = [vp, vp, sz, vp, vp, vp]
+        lib.vimz_prover_spmv.argtypes = [vp, vp, vp, vp, vp]
+        h = vp()
+        ctx._chk(lib.vimz_prover_create(ctx.h, circuit.h, ck.h, max_batch, C.byref(h)))
+        self.h = h
+        self.max_batch = max_batch
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.vimz_prover_free(self.h)
+            self.h = None
+
+    def reset(self, z0):
+        z = np.zeros((self.circuit.len_z, 4), dtype=np.uint64)
+        for i, v in enumerate(z0):
+            for k in range(4):
+                z[i, k] = (int(v) >> (64 * k)) & 0xFFFFFFFFFFFFFFFF
+        self.ctx._chk(self.ctx.lib.vimz_prover_reset(self.h, _ptr(z)))
+
+    def fold(self, step_inputs):
+        """step_inputs: (nsteps, n_priv, 4) uint64 canonical."""
+        a = _u64(step_inputs).reshape(-1, self.circuit.n_priv, 4)
+        self.ctx._chk(self.ctx.lib.vimz_prover_fold(self.h, _ptr(a), a.shape[0]))
+
+    def verify(self):
+        r = C.c_uint32()
+        self.ctx._chk(self.ctx.lib.vimz_prover_verify(self.h, C.byref(r)))
+        return r.value
+
+    def instance(self):
+        cw, ce, u = np.zeros(8, dtype=np.uint64), np.zeros(8, dtype=np.uint64), np.zeros(4, dtype=np.uint64)
+        z = np.zeros((self.circuit.len_z, 4), dtype=np.uint64)
+        steps = C.c_uint64()
+        self.ctx._chk(self.ctx.lib.vimz_prover_instance(self.h, _ptr(cw), _ptr(ce), _ptr(u), _ptr(z), C.byref(steps)))
+        return {"comm_W": cw, "comm_E": ce, "u": u, "z": z, "steps": steps.value}
+
+    def running(self):
+        z = np.zeros((self.circuit.n_wires, 4), dtype=np.uint64)
+        E = np.zeros((self.circuit.n_constraints, 4), dtype=np.uint64)
+        self.ctx._chk(self.ctx.lib.vimz_prover_running(self.h, _ptr(z), _ptr(E)))
+        return z, E
+
+    def profile(self):
+        s = (C.c_double * 9)()
+        n = (C.c_uint64 * 9)()
+        self.ctx._chk(self.ctx.lib.vimz_prover_profile(self.h, s, n))
+        return {k: {"seconds": s[i], "count": int(n[i])} for i, k in enumerate(self.PHASES)}
+
+    def witness(self, inputs, want_wires=True):
+        a = _u64(inputs).reshape(-1, self.circuit.n_priv, 4)
+        rows = a.shape[0]
+        zw = np.zeros((rows, self.circuit.n_wires, 4), dtype=np.uint64) if want_wires else None
+        zs = np.zeros((rows + 1, self.circuit.len_z, 4), dtype=np.uint64)
+        st = np.zeros(rows, dtype=np.uint32)
+        self.ctx._chk(self.ctx.lib.vimz_prover_witness(self.h, _ptr(a), rows, _ptr(zw), _ptr(zs), _ptr(st)))
+        return zw, zs, st
+
+    def spmv(self, z):
+        z = _u64(z)
+        n = self.circuit.n_constraints
+        out = [np.zeros((n, 4), dtype=np.uint64) for _ in range(3)]
+        self.ctx._chk(self.ctx.lib.vimz_prover_spmv(self.h, _ptr(z), *[_ptr(o) for o in out]))
+        return out
