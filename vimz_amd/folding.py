@@ -1,0 +1,115 @@
+"""Host-side mirror of the reference's nova-snark backend glue (vimz/src/nova_snark_backend/{input,folding}.rs):
+same function names, argument meaning and error behaviour, driving the GPU through the C ABI.
+
+    prepare_input   (input.rs:25-40)    VIMzInput -> per-step inputs + z0
+    prepare_folding (folding.rs:20-25)  load_r1cs + create_public_params -> (circuit, FoldingParams)
+    fold_input      (folding.rs:27-43)  create_recursive_circuit -> FoldingProof
+    verify_folded_proof (folding.rs:45-56)
+"""
+import time
+
+import numpy as np
+
+from . import _lib
+from .circuit import Circuit, default_shape
+
+DEMO_STEPS = 10  # vimz/src/lib.rs:9
+
+# vimz/src/transformation.rs:93-123
+ITERATION_COUNT = {"SD": 480, "HD": 720, "FHD": 1080, "4K": 2160, "8K": 4320}
+ITERATION_COUNT_BLOCK = {"HD": 576}
+RATIO_TO_LOWER = {"HD": (3, 2), "FHD": (3, 2), "4K": (2, 1), "8K": (2, 1)}
+
+
+def ivc_initial_state(transformation, inp):
+    """Transformation::ivc_initial_state (vimz/src/transformation.rs:25-40)."""
+    if transformation in ("blur", "sharpness"):
+        return [0, 0, 0, 0]
+    if transformation in ("brightness", "contrast"):
+        return [0, 0, int(inp["factor"])]
+    if transformation == "crop":
+        return [0, 0, int(inp["info"])]
+    if transformation in ("grayscale", "redact", "resize"):
+        return [0, 0]
+    if transformation == "hash":
+        return [0]
+    raise ValueError(transformation)
+
+
+def iteration_count(transformation, resolution):
+    if transformation == "redact":
+        return ITERATION_COUNT_BLOCK[resolution]
+    if transformation == "resize":
+        return ITERATION_COUNT[resolution] // RATIO_TO_LOWER[resolution][0]
+    return ITERATION_COUNT[resolution]
+
+
+def prepare_step_input(step, transformation, inp, resolution):
+    """prepare_step_input (input.rs:57-96): flattened private inputs of one step as (n, 4) limbs."""
+    o, t = inp["original"], inp.get("transformed")
+    if transformation in ("brightness", "contrast", "grayscale"):
+        return np.concatenate([o[step], t[step]])
+    if transformation in ("blur", "sharpness"):
+        return np.concatenate([o[step:step + 3].reshape(-1, 4), t[step]])
+    if transformation in ("crop", "hash"):
+        return o[step]
+    if transformation == "redact":
+        ind = np.array([[int(inp["redact"][step]), 0, 0, 0]], dtype=np.uint64)
+        return np.concatenate([o[step], ind])
+    if transformation == "resize":
+        a, b = RATIO_TO_LOWER[resolution]
+        return np.concatenate([o[step * a:(step + 1) * a].reshape(-1, 4), t[step * b:(step + 1) * b].reshape(-1, 4)])
+    raise ValueError(transformation)
+
+
+def prepare_input(transformation, inp, resolution="HD", demo=False):
+    """prepare_input (input.rs:25-40): returns (ivc_step_inputs (steps, n_priv, 4), initial_state)."""
+    n = iteration_count(transformation, resolution)
+    if demo:
+        n = min(n, DEMO_STEPS)
+    steps = np.stack([prepare_step_input(i, transformation, inp, resolution) for i in range(n)])
+    return steps, ivc_initial_state(transformation, inp)
+
+
+class FoldingParams:
+    """The analogue of nova-snark's PublicParams: R1CS shape + commitment key, resident on one GPU."""
+
+    def __init__(self, ctx, circuit, ck, keygen_seconds):
+        self.ctx, self.circuit, self.ck, self.keygen_seconds = ctx, circuit, ck, keygen_seconds
+
+
+def prepare_folding(ctx, transformation, resolution="HD", ck_label=b"ck"):
+    """prepare_folding (folding.rs:20-25): build the step circuit and derive the commitment key on the GPU."""
+    t0 = time.time()
+    circuit = Circuit(transformation, *default_shape(transformation, resolution))
+    n_aux = circuit.n_wires - 1 - 2 * circuit.len_z
+    n = 1 << (max(n_aux, circuit.n_constraints) - 1).bit_length()   # next power of two, as nova-snark sizes ck
+    ck = ctx.bases_generate(_lib.CURVE_BN254_G1, n, ck_label)
+    return circuit, FoldingParams(ctx, circuit, ck, time.time() - t0)
+
+
+class FoldingProof:
+    def __init__(self, prover, steps, z0):
+        self.prover, self.steps, self.z0 = prover, steps, z0
+
+    def instance(self):
+        return self.prover.instance()
+
+
+def fold_input(params, ivc_step_inputs, initial_state, max_batch=16, prover=None):
+    """fold_input (folding.rs:27-43).  Raises VimzError (the reference panics with "Failed to fold input")."""
+    from .hip import Prover
+    p = prover or Prover(params.ctx, params.circuit, params.ck, max_batch=max_batch)
+    p.reset(initial_state)
+    p.fold(ivc_step_inputs)
+    return FoldingProof(p, len(ivc_step_inputs), list(initial_state))
+
+
+def verify_folded_proof(proof, params, num_steps, initial_state):
+    """verify_folded_proof (folding.rs:45-56); raises like the reference's expect("Failed to verify folded proof")."""
+    inst = proof.prover.instance()
+    if inst["steps"] != num_steps or list(initial_state) != list(proof.z0):
+        raise _lib.VimzError(_lib.ERR_INVALID, "Failed to verify folded proof: step count / initial state mismatch")
+    r = proof.prover.verify()
+    if r != 0:
+        raise _lib.VimzError(_lib.ERR_UNSAT, f"Failed to verify folded proof (flags {r:#x})")
