@@ -75,7 +75,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--transformation", default="contrast")
     ap.add_argument("--resolution", default="HD")
-    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

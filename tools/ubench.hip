@@ -93,6 +93,25 @@ __global__ void k_madd(uint32_t* out, uint32_t seed, int iters) {
   out[blockIdx.x * blockDim.x + threadIdx.x] = r;
 }
 
+typedef Fp29<BnFq> G;
+__global__ void k_fp29mul(uint32_t* out, uint32_t seed, int iters) {
+  G a = G::one(), b = G::one();
+  a.v[0] ^= (threadIdx.x + seed) & 0xffff; b.v[1] ^= blockIdx.x & 0xffff;
+  G c = a, d = b;
+  for (int i = 0; i < iters; i++) { a = G::mul(a, b); c = G::mul(c, d); }
+  a = G::add(a, c);
+  uint32_t r = 0; for (int k = 0; k < 9; k++) r ^= a.v[k];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
+__global__ void k_madd29(uint32_t* out, uint32_t seed, int iters) {
+  Affine<G> q; q.x = G::one(); q.y = G::dbl(G::one());
+  XYZZ<G> acc = dbl_affine(q);
+  acc.X.v[0] ^= (threadIdx.x + seed) & 0xffff; acc.Y.v[1] ^= blockIdx.x & 0xffff;
+  for (int i = 0; i < iters; i++) add_mixed(acc, q);
+  uint32_t r = 0; for (int k = 0; k < 9; k++) r ^= acc.X.v[k] ^ acc.ZZ.v[k];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
+
 template <class K, class... A>
 double time_kernel(K k, dim3 g, dim3 b, A... args) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -122,6 +141,12 @@ int main() {
   int it = 512;
   t = time_kernel(k_fpmul, dim3(blocks), dim3(tb), (uint32_t*)buf, 1u, it); printf("Fp::mul (BN254 Fq, 8x32 CIOS): %8.2f Gmul/s  (%.1f ns per wave-mul-pair)\n", lanes * it * 2 / t * 1e-9, t / it * 1e9);
   t = time_kernel(k_madd, dim3(blocks), dim3(tb), (uint32_t*)buf, 1u, it);  printf("XYZZ mixed add               : %8.2f Gadd/s\n", lanes * it / t * 1e-9);
+  t = time_kernel(k_fp29mul, dim3(blocks), dim3(tb), (uint32_t*)buf, 1u, it); printf("Fp29::mul (BN254 Fq, 9x29 columns): %8.2f Gmul/s\n", lanes * it * 2 / t * 1e-9);
+  t = time_kernel(k_madd29, dim3(blocks), dim3(tb), (uint32_t*)buf, 1u, it);  printf("XYZZ mixed add (Fp29)             : %8.2f Gadd/s\n", lanes * it / t * 1e-9);
+  t = time_kernel(k_madd29, dim3(p.multiProcessorCount), dim3(tb), (uint32_t*)buf, 1u, it);
+  printf("  mixed add (Fp29) @ 1 WG/CU       : %8.2f Gadd/s  (%.2f us per dependent add)\n", (double)p.multiProcessorCount * tb * it / t * 1e-9, t / it * 1e6);
+  t = time_kernel(k_madd, dim3(p.multiProcessorCount), dim3(tb), (uint32_t*)buf, 1u, it);
+  printf("  mixed add (8x32) @ 1 WG/CU       : %8.2f Gadd/s  (%.2f us per dependent add)\n", (double)p.multiProcessorCount * tb * it / t * 1e-9, t / it * 1e6);
   for (int wg = 1; wg <= 8; wg *= 2) {
     t = time_kernel(k_madd, dim3(p.multiProcessorCount * wg), dim3(tb), (uint32_t*)buf, 1u, it);
     printf("  mixed add @ %d WG/CU of 256: %8.2f Gadd/s\n", wg, (double)p.multiProcessorCount * wg * tb * it / t * 1e-9);

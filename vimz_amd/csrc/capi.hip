@@ -82,7 +82,7 @@ int vz_msm_device(vimz_ctx* c, const vimz_bases* bases, size_t base_offset, cons
     typedef decltype(cv) C;
     typedef typename C::Base F;
     Affine<F> r;
-    hipError_t e = msm_run<C>(c->stream, c->msm_ws, bases->d + 16 * base_offset, d_scalars, n, scalars_mont, window_bits, &r,
+    hipError_t e = msm_run<C>(c->stream, c->msm_ws, bases->d + (size_t)AFFINE_WORDS * base_offset, d_scalars, n, scalars_mont, window_bits, &r,
                               &c->last_msm, c->profiling ? c->ev : nullptr);
     if (e != hipSuccess) return vz_fail(c, VIMZ_ERR_HIP, "msm", e);
     if (out_form == VIMZ_FORM_CANONICAL) { r.x = F::from_mont(r.x); r.y = F::from_mont(r.y); }
@@ -181,14 +181,13 @@ int vimz_bases_upload(vimz_ctx* c, int curve, const uint64_t* xy, size_t n, int 
   HIP_TRY(c, hipSetDevice(c->device));
   vimz_bases* b = new vimz_bases{curve, n, nullptr};
   if (n) {
-    hipError_t e = hipMalloc(&b->d, 64 * n);
+    int rc = ensure_scratch(c, 64 * n); if (rc) { delete b; return rc; }
+    hipError_t e = hipMalloc(&b->d, 4 * (size_t)AFFINE_WORDS * n);
     if (e != hipSuccess) { delete b; return fail(c, VIMZ_ERR_HIP, "hipMalloc(bases)", e); }
-    e = hipMemcpyAsync(b->d, xy, 64 * n, hipMemcpyHostToDevice, c->stream);
+    e = hipMemcpyAsync(c->scratch, xy, 64 * n, hipMemcpyHostToDevice, c->stream);
     if (e != hipSuccess) { hipFree(b->d); delete b; return fail(c, VIMZ_ERR_HIP, "copy bases", e); }
-    if (form == VIMZ_FORM_CANONICAL) {
-      int rc = field_dispatch(curve_base_field(curve), [&](auto f) { typedef decltype(f) F; launch_to_mont<F>(c->stream, b->d, 2 * n); return VIMZ_OK; });
-      if (rc) { hipFree(b->d); delete b; return rc; }
-    }
+    // resident form: 9 x 29-bit Montgomery coordinates (fp29.hpp)
+    field_dispatch(curve_base_field(curve), [&](auto f) { typedef decltype(f) F; launch_points_to_internal<F>(c->stream, (const uint32_t*)c->scratch, form == VIMZ_FORM_CANONICAL, b->d, n); return VIMZ_OK; });
     e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) { hipFree(b->d); delete b; return fail(c, VIMZ_ERR_HIP, "bases sync", e); }
   }
@@ -201,14 +200,15 @@ int vimz_bases_generate(vimz_ctx* c, int curve, const char* label, size_t label_
   HIP_TRY(c, hipSetDevice(c->device));
   vimz_bases* b = new vimz_bases{curve, n, nullptr};
   if (n) {
-    hipError_t e = hipMalloc(&b->d, 64 * n);
+    int rcs = ensure_scratch(c, 64 * n); if (rcs) { delete b; return rcs; }
+    hipError_t e = hipMalloc(&b->d, 4 * (size_t)AFFINE_WORDS * n);
     if (e != hipSuccess) { delete b; return fail(c, VIMZ_ERR_HIP, "hipMalloc(bases)", e); }
     CkLabel L; memset(&L, 0, sizeof(L)); memcpy(L.bytes, label, label_len); L.len = (int)label_len;
     static const int B_COEF[4] = {3, -17, 5, 5};
     int rc = field_dispatch(curve_base_field(curve), [&](auto f) {
       typedef decltype(f) F;
-      hipError_t e2 = ckgen_run<F>(c->stream, L, B_COEF[curve], 0, n, b->d);
-      if (e2 == hipSuccess) e2 = hipStreamSynchronize(c->stream);
+      hipError_t e2 = ckgen_run<F>(c->stream, L, B_COEF[curve], 0, n, (uint32_t*)c->scratch);
+      if (e2 == hipSuccess) { launch_points_to_internal<F>(c->stream, (const uint32_t*)c->scratch, 0, b->d, n); e2 = hipStreamSynchronize(c->stream); }
       return e2 == hipSuccess ? VIMZ_OK : fail(c, VIMZ_ERR_HIP, "ckgen", e2);
     });
     if (rc) { hipFree(b->d); delete b; return rc; }
@@ -221,13 +221,9 @@ int vimz_bases_download(vimz_ctx* c, const vimz_bases* b, size_t offset, uint64_
   if (!n) return VIMZ_OK;
   std::lock_guard<std::mutex> g(c->mu);
   HIP_TRY(c, hipSetDevice(c->device));
-  const uint32_t* src = b->d + 16 * offset;
-  if (form == VIMZ_FORM_CANONICAL) {
-    int rc = ensure_scratch(c, 64 * n); if (rc) return rc;
-    field_dispatch(curve_base_field(b->curve), [&](auto f) { typedef decltype(f) F; launch_from_mont<F>(c->stream, src, (uint32_t*)c->scratch, 2 * n); return VIMZ_OK; });
-    src = (const uint32_t*)c->scratch;
-  }
-  HIP_TRY(c, hipMemcpyAsync(xy, src, 64 * n, hipMemcpyDeviceToHost, c->stream));
+  int rc = ensure_scratch(c, 64 * n); if (rc) return rc;
+  field_dispatch(curve_base_field(b->curve), [&](auto f) { typedef decltype(f) F; launch_points_from_internal<F>(c->stream, b->d + (size_t)AFFINE_WORDS * offset, form == VIMZ_FORM_CANONICAL, (uint32_t*)c->scratch, n); return VIMZ_OK; });
+  HIP_TRY(c, hipMemcpyAsync(xy, c->scratch, 64 * n, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return VIMZ_OK;
 }

@@ -4,6 +4,7 @@
 // Affine identity is (0,0), the encoding halo2curves/pasta_curves hand over.
 #pragma once
 #include "fp.hpp"
+#include "fp29.hpp"
 
 namespace vz {
 
@@ -122,9 +123,15 @@ VZ_HD Affine<F> to_affine(const XYZZ<F>& p) {  // one inversion; identity -> (0,
 }
 
 // The four curves.  `Base` = coordinate field, `Scalar` = scalar field (group order).
-struct BnG1 { typedef Fp<BnFq> Base; typedef Fp<BnFr> Scalar; };
-struct Grumpkin { typedef Fp<BnFr> Base; typedef Fp<BnFq> Scalar; };
-struct Pallas { typedef Fp<PallasFp> Base; typedef Fp<VestaFq> Scalar; };
-struct Vesta { typedef Fp<VestaFq> Base; typedef Fp<PallasFp> Scalar; };
+// `Coord` = the device-internal form of the coordinate field (fp29.hpp).
+struct BnG1 { typedef Fp<BnFq> Base; typedef Fp29<BnFq> Coord; typedef Fp<BnFr> Scalar; };
+struct Grumpkin { typedef Fp<BnFr> Base; typedef Fp29<BnFr> Coord; typedef Fp<BnFq> Scalar; };
+struct Pallas { typedef Fp<PallasFp> Base; typedef Fp29<PallasFp> Coord; typedef Fp<VestaFq> Scalar; };
+struct Vesta { typedef Fp<VestaFq> Base; typedef Fp29<VestaFq> Coord; typedef Fp<PallasFp> Scalar; };
+
+// Device storage of curve data: coordinates at a stride of 10 words (40 B): affine = 20 words, XYZZ = 40 words.
+constexpr int COORD_WORDS = 10;
+constexpr int AFFINE_WORDS = 2 * COORD_WORDS;
+constexpr int XYZZ_WORDS = 4 * COORD_WORDS;
 
 }  // namespace vz

@@ -1,0 +1,158 @@
+// Reduced-radix field arithmetic for the curve coordinates: 9 limbs of 29 bits (Montgomery, R' = 2^261).
+//
+// Why a second representation.  On gfx950 the multiply primitive is v_mad_u64_u32 (32x32 + 64 -> 64) and there is no
+// add-with-carry-in form of it, so the saturated 8 x 32-bit CIOS of fp.hpp spends more instructions shuffling
+// carries than multiplying (measured: 128 mad + 142 64-bit adds + 315 moves per product, and every mad depends on
+// the previous one's carry: ~1280 cycles of latency per product at one wave per SIMD).  With 29-bit limbs a
+// 58-bit partial product leaves 6 bits of headroom, so a whole column of 9 products (plus 9 reduction products)
+// accumulates in one 64-bit register with plain mad chains — no carry handling, columns independent of each other
+// (instruction-level parallelism for the latency-bound bucket reductions), carries resolved once per column by a
+// shift.  162 mad + ~110 simple ops per product.
+//
+// Only device-resident curve data uses this form (commitment key, bucket accumulators); the C ABI keeps the
+// standard [u64;4] Montgomery form (R = 2^256) and converts at upload / result time.  Storage stride is 10 words
+// (40 B) per element so points stay 16-byte aligned: affine 80 B, XYZZ 160 B.
+#pragma once
+#include "fp.hpp"
+
+namespace vz {
+
+struct L29x9 { uint32_t l[9]; };
+
+constexpr L29x9 ct_split29(const U256& x) {
+  L29x9 r{};
+  for (int i = 0; i < 9; i++) {
+    const int bit = 29 * i, w = bit >> 5, off = bit & 31;
+    uint64_t v = (uint64_t)x.w[w] >> off;
+    if (off > 3 && w + 1 < 8) v |= (uint64_t)x.w[w + 1] << (32 - off);
+    r.l[i] = (uint32_t)(v & 0x1fffffffu);
+  }
+  return r;
+}
+
+template <class P>
+struct Fp29 {
+  typedef P Params;
+  static constexpr int NW = 9;      // limbs used
+  static constexpr int NWS = 10;    // storage stride in words
+  static constexpr uint32_t MASK = 0x1fffffffu;
+  static constexpr L29x9 MOD29 = ct_split29(P::MOD);
+  static constexpr L29x9 ONE29 = ct_split29(ct_pow2_mod(261, P::MOD));
+  static constexpr L29x9 R2_29 = ct_split29(ct_pow2_mod(522, P::MOD));
+  static constexpr uint32_t N0_29 = P::N0 & MASK;   // -p^-1 mod 2^29
+
+  uint32_t v[9];
+
+  static VZ_HD Fp29 zero() { Fp29 r; for (int i = 0; i < 9; i++) r.v[i] = 0; return r; }
+  static VZ_HD Fp29 one() { Fp29 r; for (int i = 0; i < 9; i++) r.v[i] = ONE29.l[i]; return r; }
+  VZ_HD bool is_zero() const { uint32_t o = 0; for (int i = 0; i < 9; i++) o |= v[i]; return o == 0; }
+  VZ_HD bool eq(const Fp29& b) const { uint32_t o = 0; for (int i = 0; i < 9; i++) o |= v[i] ^ b.v[i]; return o == 0; }
+
+  // t (limbs < 2^29, value < 2p) -> t mod p
+  static VZ_HD Fp29 reduce_once(const uint32_t* t) {
+    uint32_t s[9]; uint32_t br = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) { uint32_t d = t[i] - MOD29.l[i] - br; br = d >> 31; s[i] = d & MASK; }
+    Fp29 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = br ? t[i] : s[i];
+    return r;
+  }
+  static VZ_HD Fp29 add(const Fp29& a, const Fp29& b) {
+    uint32_t t[9]; uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) { uint32_t x = a.v[i] + b.v[i] + c; c = x >> 29; t[i] = x & MASK; }
+    return reduce_once(t);
+  }
+  static VZ_HD Fp29 sub(const Fp29& a, const Fp29& b) {
+    uint32_t t[9]; uint32_t br = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) { uint32_t d = a.v[i] - b.v[i] - br; br = d >> 31; t[i] = d & MASK; }
+    const uint32_t m = br ? 0xffffffffu : 0u;
+    Fp29 r; uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) { uint32_t x = t[i] + (MOD29.l[i] & m) + c; c = x >> 29; r.v[i] = x & MASK; }
+    return r;
+  }
+  static VZ_HD Fp29 neg(const Fp29& a) { return sub(zero(), a); }
+  static VZ_HD Fp29 dbl(const Fp29& a) { return add(a, a); }
+
+  // Montgomery product a*b / 2^261 mod p: column-wise product, then word-by-word reduction.
+  static VZ_HD Fp29 mul(const Fp29& a, const Fp29& b) {
+    uint64_t acc[18];
+#pragma unroll
+    for (int k = 0; k < 18; k++) acc[k] = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++)
+#pragma unroll
+      for (int j = 0; j < 9; j++) acc[i + j] += (uint64_t)a.v[i] * b.v[j];
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      const uint32_t m = ((uint32_t)acc[i] * N0_29) & MASK;
+#pragma unroll
+      for (int j = 0; j < 9; j++) acc[i + j] += (uint64_t)m * MOD29.l[j];
+      acc[i + 1] += acc[i] >> 29;   // low 29 bits of acc[i] are now zero
+    }
+    uint32_t t[9];
+#pragma unroll
+    for (int k = 9; k < 18; k++) {
+      t[k - 9] = (uint32_t)acc[k] & MASK;
+      if (k < 17) acc[k + 1] += acc[k] >> 29;
+    }
+    return reduce_once(t);
+  }
+  static VZ_HD Fp29 sqr(const Fp29& a) { return mul(a, a); }
+
+  static VZ_HD Fp29 pow_pm2(const Fp29& a) {  // a^(p-2)
+    uint32_t e[8]; uint64_t br = 2;
+    for (int i = 0; i < 8; i++) { uint64_t d = (uint64_t)P::MOD.w[i] - br; e[i] = (uint32_t)d; br = (d >> 32) & 1; }
+    Fp29 acc = one();
+    for (int i = 255; i >= 0; i--) {
+      acc = sqr(acc);
+      if ((e[i >> 5] >> (i & 31)) & 1) acc = mul(acc, a);
+    }
+    return acc;
+  }
+
+  // ---- conversions with the standard representation (fp.hpp, 8 x 32 limbs, R = 2^256) ---------------------
+  static VZ_HD Fp29 pack(const uint32_t* w8) {   // 256-bit integer -> 29-bit limbs (no arithmetic)
+    Fp29 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      const int bit = 29 * i, w = bit >> 5, off = bit & 31;
+      uint64_t x = (uint64_t)w8[w] >> off;
+      if (off > 3 && w + 1 < 8) x |= (uint64_t)w8[w + 1] << (32 - off);
+      r.v[i] = (uint32_t)x & MASK;
+    }
+    return r;
+  }
+  VZ_HD void unpack(uint32_t* w8) const {        // 29-bit limbs -> 256-bit integer
+    uint64_t buf = 0; int have = 0, o = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      buf |= (uint64_t)v[i] << have; have += 29;
+      if (have >= 32) { w8[o++] = (uint32_t)buf; buf >>= 32; have -= 32; }
+    }
+    if (o < 8) w8[o] = (uint32_t)buf;
+  }
+  // y = x*2^256 (standard Montgomery)  ->  x*2^261
+  static VZ_HD Fp29 from_std(const Fp<P>& y) {
+    Fp<P> t = y;
+#pragma unroll
+    for (int k = 0; k < 5; k++) t = Fp<P>::dbl(t);
+    return pack(t.v);
+  }
+  // x*2^261 -> x*2^256: five modular halvings
+  VZ_HD Fp<P> to_std() const {
+    uint32_t w[8]; unpack(w);
+    for (int k = 0; k < 5; k++) {
+      uint64_t c = 0;
+      if (w[0] & 1) { for (int i = 0; i < 8; i++) { c += (uint64_t)w[i] + P::MOD.w[i]; w[i] = (uint32_t)c; c >>= 32; } }
+      for (int i = 0; i < 8; i++) w[i] = (w[i] >> 1) | (i < 7 ? w[i + 1] << 31 : (uint32_t)c << 31);
+    }
+    Fp<P> r; for (int i = 0; i < 8; i++) r.v[i] = w[i];
+    return r;
+  }
+};
+
+}  // namespace vz

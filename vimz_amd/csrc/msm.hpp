@@ -136,45 +136,41 @@ __global__ void k_scatter(const uint32_t* __restrict__ scalars, size_t n, int mo
   }
 }
 
+// Curve data in HBM: coordinates of COORD_WORDS (10) words, 9 used — every point starts 16-byte aligned.
+template <class F>
+__device__ __forceinline__ void load_words20(const uint32_t* __restrict__ p, F& a, F& b) {
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  const uint4 w0 = q[0], w1 = q[1], w2 = q[2], w3 = q[3], w4 = q[4];
+  a.v[0] = w0.x; a.v[1] = w0.y; a.v[2] = w0.z; a.v[3] = w0.w; a.v[4] = w1.x; a.v[5] = w1.y; a.v[6] = w1.z; a.v[7] = w1.w; a.v[8] = w2.x;
+  b.v[0] = w2.z; b.v[1] = w2.w; b.v[2] = w3.x; b.v[3] = w3.y; b.v[4] = w3.z; b.v[5] = w3.w; b.v[6] = w4.x; b.v[7] = w4.y; b.v[8] = w4.z;
+}
+template <class F>
+__device__ __forceinline__ void store_words20(uint32_t* __restrict__ p, const F& a, const F& b) {
+  uint4* q = reinterpret_cast<uint4*>(p);
+  q[0] = make_uint4(a.v[0], a.v[1], a.v[2], a.v[3]); q[1] = make_uint4(a.v[4], a.v[5], a.v[6], a.v[7]);
+  q[2] = make_uint4(a.v[8], 0u, b.v[0], b.v[1]); q[3] = make_uint4(b.v[2], b.v[3], b.v[4], b.v[5]);
+  q[4] = make_uint4(b.v[6], b.v[7], b.v[8], 0u);
+}
 template <class F>
 __device__ __forceinline__ Affine<F> load_affine(const uint32_t* __restrict__ bases, uint32_t idx) {
-  const uint4* p = reinterpret_cast<const uint4*>(bases + 16 * (size_t)idx);
-  uint4 a = p[0], b = p[1], c = p[2], d = p[3];
-  Affine<F> q;
-  q.x.v[0] = a.x; q.x.v[1] = a.y; q.x.v[2] = a.z; q.x.v[3] = a.w; q.x.v[4] = b.x; q.x.v[5] = b.y; q.x.v[6] = b.z; q.x.v[7] = b.w;
-  q.y.v[0] = c.x; q.y.v[1] = c.y; q.y.v[2] = c.z; q.y.v[3] = c.w; q.y.v[4] = d.x; q.y.v[5] = d.y; q.y.v[6] = d.z; q.y.v[7] = d.w;
-  return q;
-}
-
-template <class F>
-__device__ __forceinline__ void store_xyzz(XYZZ<F>* dst, const XYZZ<F>& p) {
-  uint4* o = reinterpret_cast<uint4*>(dst);
-  const F* f[4] = {&p.X, &p.Y, &p.ZZ, &p.ZZZ};
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    o[2 * k] = make_uint4(f[k]->v[0], f[k]->v[1], f[k]->v[2], f[k]->v[3]);
-    o[2 * k + 1] = make_uint4(f[k]->v[4], f[k]->v[5], f[k]->v[6], f[k]->v[7]);
-  }
+  Affine<F> q; load_words20(bases + (size_t)AFFINE_WORDS * idx, q.x, q.y); return q;
 }
 template <class F>
-__device__ __forceinline__ XYZZ<F> load_xyzz(const XYZZ<F>* src) {
-  const uint4* o = reinterpret_cast<const uint4*>(src);
-  XYZZ<F> p;
-  F* f[4] = {&p.X, &p.Y, &p.ZZ, &p.ZZZ};
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    uint4 a = o[2 * k], b = o[2 * k + 1];
-    f[k]->v[0] = a.x; f[k]->v[1] = a.y; f[k]->v[2] = a.z; f[k]->v[3] = a.w;
-    f[k]->v[4] = b.x; f[k]->v[5] = b.y; f[k]->v[6] = b.z; f[k]->v[7] = b.w;
-  }
-  return p;
+__device__ __forceinline__ void store_xyzz(uint32_t* __restrict__ base, size_t idx, const XYZZ<F>& p) {
+  uint32_t* d = base + (size_t)XYZZ_WORDS * idx;
+  store_words20(d, p.X, p.Y); store_words20(d + AFFINE_WORDS, p.ZZ, p.ZZZ);
+}
+template <class F>
+__device__ __forceinline__ XYZZ<F> load_xyzz(const uint32_t* __restrict__ base, size_t idx) {
+  const uint32_t* d = base + (size_t)XYZZ_WORDS * idx;
+  XYZZ<F> p; load_words20(d, p.X, p.Y); load_words20(d + AFFINE_WORDS, p.ZZ, p.ZZZ); return p;
 }
 
 template <class F>
 __global__ void __launch_bounds__(256) k_accum(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
                                                const uint32_t* __restrict__ bucket_off, const uint32_t* __restrict__ sub_off,
                                                uint32_t nb, const uint32_t* __restrict__ totals,
-                                               XYZZ<F>* __restrict__ partial, uint32_t* __restrict__ sub_bucket,
+                                               uint32_t* __restrict__ partial, uint32_t* __restrict__ sub_bucket,
                                                uint32_t* __restrict__ sub_k) {
   const uint32_t total = totals[0];
   uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -195,30 +191,58 @@ __global__ void __launch_bounds__(256) k_accum(const uint32_t* __restrict__ base
     if ((ent >> 31) && !aff_is_identity(q)) q.y = F::neg(q.y);
     add_mixed(acc, q);
   }
-  store_xyzz(&partial[s], acc);
+  store_xyzz(partial, s, acc);
   sub_bucket[s] = b; sub_k[s] = k;
 }
 
+constexpr uint32_t MSM_HEAVY = 24;   // buckets with more sub-buckets than this are combined by a whole workgroup
+
+// One thread per bucket folds the bucket's sub-bucket partials into partial[sub_off[b]].  Buckets with more than
+// MSM_HEAVY partials (only the few hot buckets of witness-like scalars) are queued for k_combine_heavy instead.
 template <class F>
-__global__ void __launch_bounds__(256) k_combine(XYZZ<F>* __restrict__ partial, const uint32_t* __restrict__ sub_bucket,
-                                                 const uint32_t* __restrict__ sub_k, const uint32_t* __restrict__ totals,
-                                                 uint32_t stride) {
-  const uint32_t total = totals[0];
-  uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= total || s + stride >= total) return;
-  if (sub_k[s] % (2 * stride) != 0) return;
-  if (sub_bucket[s + stride] != sub_bucket[s]) return;
-  XYZZ<F> a = load_xyzz(&partial[s]);
-  XYZZ<F> b = load_xyzz(&partial[s + stride]);
-  add_full(a, b);
-  store_xyzz(&partial[s], a);
+__global__ void __launch_bounds__(256) k_combine(uint32_t* __restrict__ partial, const uint32_t* __restrict__ sub_off, uint32_t nb,
+                                                 uint32_t* __restrict__ heavy /* [0] = count, then bucket ids */, uint32_t heavy_cap) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nb) return;
+  const uint32_t s0 = sub_off[b], m = sub_off[b + 1] - s0;
+  if (m < 2) return;
+  if (m > MSM_HEAVY) {
+    const uint32_t slot = atomicAdd(&heavy[0], 1u);
+    if (slot < heavy_cap) { heavy[1 + slot] = b; return; }
+    // list full (cannot happen for heavy_cap >= entries / (MSM_SUB * MSM_HEAVY)); fall through to the serial path
+  }
+  XYZZ<F> acc = load_xyzz<F>(partial, s0);
+  for (uint32_t k = 1; k < m; k++) { XYZZ<F> q = load_xyzz<F>(partial, s0 + k); add_full(acc, q); }
+  store_xyzz(partial, s0, acc);
+}
+
+// One workgroup per queued heavy bucket: strided accumulation by 256 threads, then an LDS tree.
+template <class F>
+__global__ void __launch_bounds__(256) k_combine_heavy(uint32_t* __restrict__ partial, const uint32_t* __restrict__ sub_off,
+                                                       const uint32_t* __restrict__ heavy, uint32_t heavy_cap) {
+  __shared__ XYZZ<F> sh[256];
+  const uint32_t count = min(heavy[0], heavy_cap), t = threadIdx.x;
+  for (uint32_t h = blockIdx.x; h < count; h += gridDim.x) {
+    const uint32_t b = heavy[1 + h];
+    const uint32_t s0 = sub_off[b], m = sub_off[b + 1] - s0;
+    XYZZ<F> acc = XYZZ<F>::identity();
+    for (uint32_t k = t; k < m; k += 256) { XYZZ<F> q = load_xyzz<F>(partial, s0 + k); add_full(acc, q); }
+    __syncthreads();
+    sh[t] = acc;
+    __syncthreads();
+    for (uint32_t d = 128; d > 0; d >>= 1) {
+      if (t < d) { XYZZ<F> a = sh[t]; add_full(a, sh[t + d]); sh[t] = a; }
+      __syncthreads();
+    }
+    if (t == 0) store_xyzz(partial, s0, sh[0]);
+  }
 }
 
 // grid = K workgroups of T threads (T = min(256, nbw)); window sum = Σ_{idx} (idx+1)·B_idx
 template <class F>
-__global__ void __launch_bounds__(256) k_reduce(const XYZZ<F>* __restrict__ partial, const uint32_t* __restrict__ counts,
+__global__ void __launch_bounds__(256) k_reduce(const uint32_t* __restrict__ partial, const uint32_t* __restrict__ counts,
                                                 const uint32_t* __restrict__ sub_off, uint32_t nbw,
-                                                XYZZ<F>* __restrict__ window_sums) {
+                                                uint32_t* __restrict__ window_sums) {
   __shared__ XYZZ<F> sh[256];
   const uint32_t w = blockIdx.x, t = threadIdx.x, T = blockDim.x;
   const uint32_t ch = nbw / T;
@@ -226,7 +250,7 @@ __global__ void __launch_bounds__(256) k_reduce(const XYZZ<F>* __restrict__ part
   XYZZ<F> run = XYZZ<F>::identity(), sum = XYZZ<F>::identity();
   for (uint32_t j = ch; j-- > 0;) {
     uint32_t g = w * nbw + lo + j;
-    if (counts[g]) { XYZZ<F> B = load_xyzz(&partial[sub_off[g]]); add_full(run, B); }
+    if (counts[g]) { XYZZ<F> B = load_xyzz<F>(partial, sub_off[g]); add_full(run, B); }
     add_full(sum, run);
   }
   // sum = Σ (j+1)·B_{lo+j}; add lo·run
@@ -244,7 +268,7 @@ __global__ void __launch_bounds__(256) k_reduce(const XYZZ<F>* __restrict__ part
     if (t < d) { XYZZ<F> a = sh[t]; add_full(a, sh[t + d]); sh[t] = a; }
     __syncthreads();
   }
-  if (t == 0) store_xyzz(&window_sums[w], sh[0]);
+  if (t == 0) store_xyzz(window_sums, w, sh[0]);
 }
 
 // ---- host driver ---------------------------------------------------------------------------------
@@ -253,10 +277,10 @@ template <class C>
 hipError_t msm_run(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_bases, const uint32_t* d_scalars, size_t n,
                    int scalars_mont, int c_override, Affine<typename C::Base>* out_affine_mont, MsmStats* stats,
                    hipEvent_t* ev /* 7 events or nullptr */) {
-  typedef typename C::Base F;
+  typedef typename C::Coord F;      // internal 9 x 29-bit form: bases, accumulators, window sums
+  typedef typename C::Base FS;      // standard form of the result
   typedef typename C::Scalar S;
-  static_assert(sizeof(XYZZ<F>) == 128, "XYZZ layout");
-  if (n == 0) { out_affine_mont->x = F::zero(); out_affine_mont->y = F::zero(); return hipSuccess; }
+  if (n == 0) { out_affine_mont->x = FS::zero(); out_affine_mont->y = FS::zero(); return hipSuccess; }
   if (n >= (1u << 31)) return hipErrorInvalidValue;
   const MsmPlan pl = msm_plan(n, S::Params::BITS, c_override);
   if (pl.K > MSM_MAX_WINDOWS || pl.c > 16 || pl.c < 2) return hipErrorInvalidValue;
@@ -266,6 +290,7 @@ hipError_t msm_run(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_bases
 
   VZ_HIP_CHECK(hipMemsetAsync(ws.counts, 0, 4 * (size_t)pl.nb, stream));
   VZ_HIP_CHECK(hipMemsetAsync(ws.cursor, 0, 4 * (size_t)pl.nb, stream));
+  VZ_HIP_CHECK(hipMemsetAsync(ws.heavy, 0, 4, stream));
   const int TB = 256;
 #define VZ_EV(i) do { if (ev) VZ_HIP_CHECK(hipEventRecord(ev[i], stream)); } while (0)
   VZ_EV(0);
@@ -277,34 +302,39 @@ hipError_t msm_run(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_bases
   hipLaunchKernelGGL(k_scatter<S>, dim3(gs), dim3(TB), 0, stream, d_scalars, n, scalars_mont, pl.c, pl.K, pl.nbw,
                      ws.bucket_off, ws.cursor, ws.sorted);
   VZ_EV(3);
-  XYZZ<F>* partial = reinterpret_cast<XYZZ<F>*>(ws.partial);
+  uint32_t* partial = reinterpret_cast<uint32_t*>(ws.partial);
   const unsigned ga = (unsigned)((max_subs + TB - 1) / TB);
   hipLaunchKernelGGL(k_accum<F>, dim3(ga), dim3(TB), 0, stream, d_bases, ws.sorted, ws.bucket_off, ws.sub_off, pl.nb,
                      ws.totals, partial, ws.sub_bucket, ws.sub_k);
   VZ_EV(4);
-  // a bucket holds at most n entries -> at most ceil(n/SUB) sub-buckets -> that many halving passes
-  const size_t max_m = (n + MSM_SUB - 1) / MSM_SUB;
-  for (size_t stride = 1; stride < max_m; stride <<= 1)
-    hipLaunchKernelGGL(k_combine<F>, dim3(ga), dim3(TB), 0, stream, partial, ws.sub_bucket, ws.sub_k, ws.totals, (uint32_t)stride);
+  hipLaunchKernelGGL(k_combine<F>, dim3((pl.nb + TB - 1) / TB), dim3(TB), 0, stream, partial, ws.sub_off, pl.nb, ws.heavy, MsmWorkspace::HEAVY_CAP);
+  hipLaunchKernelGGL(k_combine_heavy<F>, dim3(64), dim3(256), 0, stream, partial, ws.sub_off, ws.heavy, MsmWorkspace::HEAVY_CAP);
   VZ_EV(5);
   const unsigned T = pl.nbw < 256 ? pl.nbw : 256;
-  XYZZ<F>* wsum = reinterpret_cast<XYZZ<F>*>(ws.window_sums);
+  uint32_t* wsum = reinterpret_cast<uint32_t*>(ws.window_sums);
   hipLaunchKernelGGL(k_reduce<F>, dim3(pl.K), dim3(T), 0, stream, partial, ws.counts, ws.sub_off, pl.nbw, wsum);
   VZ_EV(6);
 #undef VZ_EV
   VZ_HIP_CHECK(hipGetLastError());
-  VZ_HIP_CHECK(hipMemcpyAsync(ws.host_pinned, wsum, sizeof(XYZZ<F>) * pl.K, hipMemcpyDeviceToHost, stream));
+  VZ_HIP_CHECK(hipMemcpyAsync(ws.host_pinned, wsum, 4 * (size_t)XYZZ_WORDS * pl.K, hipMemcpyDeviceToHost, stream));
   uint32_t h_tot[2] = {0, 0};
   if (stats) VZ_HIP_CHECK(hipMemcpyAsync(h_tot, ws.totals, 8, hipMemcpyDeviceToHost, stream));
   VZ_HIP_CHECK(hipStreamSynchronize(stream));
 
-  const XYZZ<F>* hw = reinterpret_cast<const XYZZ<F>*>(ws.host_pinned);
+  const uint32_t* hw = reinterpret_cast<const uint32_t*>(ws.host_pinned);
+  auto host_point = [&](int w) {
+    XYZZ<F> p; const uint32_t* d = hw + (size_t)XYZZ_WORDS * w;
+    F* f[4] = {&p.X, &p.Y, &p.ZZ, &p.ZZZ};
+    for (int k = 0; k < 4; k++) for (int i = 0; i < 9; i++) f[k]->v[i] = d[COORD_WORDS * k + i];
+    return p;
+  };
   XYZZ<F> acc = XYZZ<F>::identity();
   for (int w = pl.K - 1; w >= 0; w--) {
     for (int k = 0; k < pl.c; k++) acc = dbl(acc);
-    add_full(acc, hw[w]);
+    add_full(acc, host_point(w));
   }
-  *out_affine_mont = to_affine(acc);
+  const Affine<F> r29 = to_affine(acc);
+  out_affine_mont->x = r29.x.to_std(); out_affine_mont->y = r29.y.to_std();
   if (stats && ev) for (int i = 0; i < 6; i++) VZ_HIP_CHECK(hipEventElapsedTime(&stats->ms[i], ev[i], ev[i + 1]));
   if (stats) { stats->c = pl.c; stats->K = pl.K; stats->subs = h_tot[0]; stats->entries = h_tot[1]; }
   return hipSuccess;

@@ -63,6 +63,8 @@ struct MsmWorkspace {  // device buffers, grown on demand and reused across call
   void* partial = nullptr;         // max_subs * sizeof(XYZZ)
   void* window_sums = nullptr;     // K * sizeof(XYZZ)
   uint32_t* totals = nullptr;      // [0] = total subs
+  uint32_t* heavy = nullptr;       // [0] = count, then ids of buckets with many sub-buckets
+  static constexpr uint32_t HEAVY_CAP = 65536;
   size_t cap_nb = 0, cap_entries = 0, cap_subs = 0;
   void* host_pinned = nullptr;     // MSM_MAX_WINDOWS * 128 B
 
@@ -79,16 +81,17 @@ struct MsmWorkspace {  // device buffers, grown on demand and reused across call
     if (subs > cap_subs) {
       hipFree(sub_bucket); hipFree(sub_k); hipFree(partial);
       VZ_HIP_CHECK(hipMalloc(&sub_bucket, 4 * subs)); VZ_HIP_CHECK(hipMalloc(&sub_k, 4 * subs));
-      VZ_HIP_CHECK(hipMalloc(&partial, 128 * subs)); cap_subs = subs;
+      VZ_HIP_CHECK(hipMalloc(&partial, 4 * XYZZ_WORDS * subs)); cap_subs = subs;
     }
-    if (!window_sums) VZ_HIP_CHECK(hipMalloc(&window_sums, 128 * MSM_MAX_WINDOWS));
+    if (!window_sums) VZ_HIP_CHECK(hipMalloc(&window_sums, 4 * XYZZ_WORDS * MSM_MAX_WINDOWS));
     if (!totals) VZ_HIP_CHECK(hipMalloc(&totals, 64));
-    if (!host_pinned) VZ_HIP_CHECK(hipHostMalloc(&host_pinned, 128 * MSM_MAX_WINDOWS));
+    if (!heavy) VZ_HIP_CHECK(hipMalloc(&heavy, 4 * (HEAVY_CAP + 1)));
+    if (!host_pinned) VZ_HIP_CHECK(hipHostMalloc(&host_pinned, 4 * XYZZ_WORDS * MSM_MAX_WINDOWS));
     return hipSuccess;
   }
   void release() {
     hipFree(counts); hipFree(cursor); hipFree(bucket_off); hipFree(sub_off); hipFree(sorted);
-    hipFree(sub_bucket); hipFree(sub_k); hipFree(partial); hipFree(window_sums); hipFree(totals);
+    hipFree(sub_bucket); hipFree(sub_k); hipFree(partial); hipFree(window_sums); hipFree(totals); hipFree(heavy);
     if (host_pinned) hipHostFree(host_pinned);
     *this = MsmWorkspace();
   }

@@ -14,6 +14,7 @@
 #include <chrono>
 #include <cstring>
 #include <vector>
+#include <algorithm>
 
 #include "internal.hpp"
 #include "circuit_handle.hpp"
@@ -66,6 +67,7 @@ struct vimz_prover {
   // device: shape
   CsrDev A{}, B{}, C{};
   const uint32_t* dict = nullptr;
+  const uint32_t* long_items = nullptr; uint32_t n_long = 0;
   WitnessDev wd{};
   std::vector<void*> owned;   // every device allocation, for cleanup
   // device: batch buffers
@@ -112,6 +114,14 @@ struct HostEval {
 
 }  // namespace
 
+static void launch_spmv(vimz_prover* p, hipStream_t s, const uint32_t* z, uint32_t* az, uint32_t* bz, uint32_t* cz) {
+  hipLaunchKernelGGL(k_spmv3<Fr>, dim3(stream_grid(p->n_c)), dim3(256), 0, s, p->A, p->B, p->C, p->dict, (size_t)p->n_c, z, az, bz, cz);
+  if (p->n_long) {
+    const unsigned blocks = (unsigned)std::min<uint32_t>((p->n_long + 3) / 4, 4096);
+    hipLaunchKernelGGL(k_spmv_long<Fr>, dim3(blocks), dim3(256), 0, s, p->A, p->B, p->C, p->dict, p->long_items, p->n_long, z, az, bz, cz);
+  }
+}
+
 extern "C" {
 
 void vimz_prover_free(vimz_prover* p) {
@@ -131,6 +141,7 @@ int vimz_prover_create(vimz_ctx* ctx, const vimz_circuit* circuit, const vimz_ba
   const cb::Builder& b = circuit->build->b;
   const uint32_t n_aux = b.n_wires - 1 - 2 * b.len_z;
   if (ck->n < n_aux || ck->n < b.n_constraints()) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_prover_create: commitment key shorter than max(witness, constraints)");
+  for (auto& J : b.jobs) if (J.t != 3 && J.t != 9) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_prover_create: the GPU Poseidon kernel supports widths 3 and 9 only (row widths must be multiples of 8... of the window fold)");
   std::lock_guard<std::mutex> g(ctx->mu);
   P_TRY(hipSetDevice(ctx->device));
   auto* p = new vimz_prover();
@@ -144,6 +155,15 @@ int vimz_prover_create(vimz_ctx* ctx, const vimz_circuit* circuit, const vimz_ba
   UP(b.B.row_ptr, p->B.row_ptr); UP(b.B.col, p->B.col); UP(b.B.coef, p->B.coef);
   UP(b.C.row_ptr, p->C.row_ptr); UP(b.C.col, p->C.col); UP(b.C.coef, p->C.coef);
   { const Fe* d = nullptr; UP(b.dict, d); p->dict = (const uint32_t*)d; }
+  {
+    std::vector<uint32_t> items;
+    const cb::Csr* Ms[3] = {&b.A, &b.B, &b.C};
+    for (uint32_t m = 0; m < 3; m++)
+      for (uint32_t r = 0; r + 1 < Ms[m]->row_ptr.size(); r++)
+        if (Ms[m]->row_ptr[r + 1] - Ms[m]->row_ptr[r] > SPMV_LONG) items.push_back((m << 30) | r);
+    p->n_long = (uint32_t)items.size();
+    UP(items, p->long_items);
+  }
   WitnessDev& W = p->wd;
   UP(b.decomp, W.decomp); UP(b.lane_groups, W.groups); UP(b.lane_instr, W.instr); UP(b.lane_rows, W.rows);
   UP(b.jobs, W.jobs); UP(b.chains, W.chains); UP(b.fops, W.fops);
@@ -304,7 +324,7 @@ int vimz_prover_spmv(vimz_prover* p, const uint64_t* z, uint64_t* az, uint64_t* 
   uint32_t* zd = (uint32_t*)ctx->scratch;
   P_TRY(hipMemcpyAsync(zd, z, 32 * (size_t)p->n_wires, hipMemcpyHostToDevice, s));
   launch_to_mont<Fr>(s, zd, p->n_wires);
-  hipLaunchKernelGGL(k_spmv3<Fr>, dim3(stream_grid(p->n_c)), dim3(256), 0, s, p->A, p->B, p->C, p->dict, (size_t)p->n_c, zd, p->az2, p->bz2, p->cz2);
+  launch_spmv(p, s, zd, p->az2, p->bz2, p->cz2);
   uint32_t* src[3] = {p->az2, p->bz2, p->cz2}; uint64_t* dst[3] = {az, bz, cz};
   for (int m = 0; m < 3; m++) {
     launch_from_mont<Fr>(s, src[m], p->T, p->n_c);
@@ -345,7 +365,7 @@ int vimz_prover_fold(vimz_prover* p, const uint64_t* step_inputs, size_t nsteps)
     for (size_t r = 0; r < rows; r++) {
       uint32_t* Zi = p->Z_d + 8 * r * nw;
       double t0 = now_s();
-      hipLaunchKernelGGL(k_spmv3<Fr>, dim3(stream_grid(nc)), dim3(256), 0, s, p->A, p->B, p->C, p->dict, nc, Zi, p->az2, p->bz2, p->cz2);
+      launch_spmv(p, s, Zi, p->az2, p->bz2, p->cz2);
       P_TRY(hipGetLastError());
       uint64_t pt[8];
       // comm_W2 over the aux part of z (everything after [1 | X])
@@ -444,7 +464,7 @@ int vimz_prover_verify(vimz_prover* p, uint32_t* result) {
   hipStream_t s = ctx->stream;
   const size_t nc = p->n_c;
   uint32_t res = 0;
-  hipLaunchKernelGGL(k_spmv3<Fr>, dim3(stream_grid(nc)), dim3(256), 0, s, p->A, p->B, p->C, p->dict, nc, p->Zrun, p->az2, p->bz2, p->cz2);
+  launch_spmv(p, s, p->Zrun, p->az2, p->bz2, p->cz2);
   uint32_t init[2] = {0, 0xffffffffu};
   P_TRY(hipMemcpyAsync(p->bad_d, init, 8, hipMemcpyHostToDevice, s));
   hipLaunchKernelGGL(k_check_relaxed<Fr>, dim3(stream_grid(nc)), dim3(256), 0, s, nc, p->az2, p->bz2, p->cz2, p->u, (const uint32_t*)p->E, p->bad_d);

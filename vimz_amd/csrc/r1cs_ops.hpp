@@ -15,6 +15,18 @@ namespace vz {
 
 struct CsrDev { const uint32_t* row_ptr; const uint32_t* col; const uint32_t* coef; };
 
+constexpr uint32_t SPMV_LONG = 16;   // (matrix,row) items with more terms than this go to the wave-per-item kernel
+
+// acc += c * v, skipping the multiply for the values a fresh witness is made of (0 and 1)
+template <class F>
+__device__ __forceinline__ void spmv_term(F& acc, const uint32_t* __restrict__ dict, uint32_t coef, const uint32_t* __restrict__ z, uint32_t col) {
+  const F v = load_fe<F>(z, col);
+  if (v.is_zero()) return;
+  const F c = load_fe<F>(dict, coef);
+  if (v.eq(F::one())) acc = F::add(acc, c); else acc = F::add(acc, F::mul(c, v));
+}
+
+// One thread per constraint row; rows of a matrix longer than SPMV_LONG are left to k_spmv_long.
 template <class F>
 __global__ void __launch_bounds__(256) k_spmv3(CsrDev A, CsrDev B, CsrDev C, const uint32_t* __restrict__ dict, size_t nrows,
                                                const uint32_t* __restrict__ z, uint32_t* __restrict__ az, uint32_t* __restrict__ bz, uint32_t* __restrict__ cz) {
@@ -23,15 +35,39 @@ __global__ void __launch_bounds__(256) k_spmv3(CsrDev A, CsrDev B, CsrDev C, con
     uint32_t* out[3] = {az, bz, cz};
 #pragma unroll 1
     for (int m = 0; m < 3; m++) {
-      F acc = F::zero();
       const uint32_t lo = M[m].row_ptr[r], hi = M[m].row_ptr[r + 1];
-      for (uint32_t k = lo; k < hi; k++) {
-        const F c = load_fe<F>(dict, M[m].coef[k]);
-        const F v = load_fe<F>(z, M[m].col[k]);
-        acc = F::add(acc, F::mul(c, v));
-      }
+      if (hi - lo > SPMV_LONG) continue;
+      F acc = F::zero();
+      for (uint32_t k = lo; k < hi; k++) spmv_term<F>(acc, dict, M[m].coef[k], z, M[m].col[k]);
       store_fe(out[m], r, acc);
     }
+  }
+}
+
+// One wave per long (matrix,row) item: lanes stride over the terms, then a shuffle tree adds the 64 partial sums.
+// items: packed (matrix << 30 | row).  The long rows are the substituted-bit rows of Num2Bits(240) (240 terms) and
+// the Poseidon partial rounds (up to ~70 terms); with one thread per row they stalled whole waves.
+template <class F>
+__global__ void __launch_bounds__(256) k_spmv_long(CsrDev A, CsrDev B, CsrDev C, const uint32_t* __restrict__ dict, const uint32_t* __restrict__ items,
+                                                   uint32_t n_items, const uint32_t* __restrict__ z, uint32_t* __restrict__ az, uint32_t* __restrict__ bz,
+                                                   uint32_t* __restrict__ cz) {
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (uint32_t it = wave; it < n_items; it += nwaves) {
+    const uint32_t packed = items[it], m = packed >> 30, r = packed & 0x3fffffffu;
+    const CsrDev M = m == 0 ? A : (m == 1 ? B : C);
+    uint32_t* out = m == 0 ? az : (m == 1 ? bz : cz);
+    const uint32_t lo = M.row_ptr[r], hi = M.row_ptr[r + 1];
+    F acc = F::zero();
+    for (uint32_t k = lo + lane; k < hi; k += 64) spmv_term<F>(acc, dict, M.coef[k], z, M.col[k]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      F o;
+#pragma unroll
+      for (int w = 0; w < 8; w++) o.v[w] = __shfl_xor(acc.v[w], off);
+      acc = F::add(acc, o);
+    }
+    if (lane == 0) store_fe(out, r, acc);
   }
 }
 

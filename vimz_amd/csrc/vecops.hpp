@@ -61,22 +61,54 @@ void launch_field_probe(hipStream_t s, int op, const uint32_t* a, const uint32_t
 }
 
 template <class F>
+__global__ void k_points_to_internal(const uint32_t* __restrict__ in, int canonical, uint32_t* __restrict__ out, size_t n) {
+  VZ_GRID_STRIDE(i, n) {
+    F x = load_fe<F>(in, 2 * i), y = load_fe<F>(in, 2 * i + 1);
+    if (canonical) { x = F::to_mont(x); y = F::to_mont(y); }
+    const Fp29<typename F::Params> a = Fp29<typename F::Params>::from_std(x), b = Fp29<typename F::Params>::from_std(y);
+    uint32_t* o = out + (size_t)AFFINE_WORDS * i;
+    for (int k = 0; k < 9; k++) { o[k] = a.v[k]; o[COORD_WORDS + k] = b.v[k]; }
+    o[9] = 0; o[COORD_WORDS + 9] = 0;
+  }
+}
+template <class F>
+__global__ void k_points_from_internal(const uint32_t* __restrict__ in, int canonical, uint32_t* __restrict__ out, size_t n) {
+  VZ_GRID_STRIDE(i, n) {
+    Fp29<typename F::Params> a, b;
+    const uint32_t* p = in + (size_t)AFFINE_WORDS * i;
+    for (int k = 0; k < 9; k++) { a.v[k] = p[k]; b.v[k] = p[COORD_WORDS + k]; }
+    F x = a.to_std(), y = b.to_std();
+    if (canonical) { x = F::from_mont(x); y = F::from_mont(y); }
+    store_fe(out, 2 * i, x); store_fe(out, 2 * i + 1, y);
+  }
+}
+template <class F>
+void launch_points_to_internal(hipStream_t s, const uint32_t* in, int canonical, uint32_t* out, size_t n) {
+  hipLaunchKernelGGL(k_points_to_internal<F>, dim3(stream_grid(n)), dim3(256), 0, s, in, canonical, out, n);
+}
+template <class F>
+void launch_points_from_internal(hipStream_t s, const uint32_t* in, int canonical, uint32_t* out, size_t n) {
+  hipLaunchKernelGGL(k_points_from_internal<F>, dim3(stream_grid(n)), dim3(256), 0, s, in, canonical, out, n);
+}
+
+template <class F>
 __global__ void k_curve_add_probe(const uint32_t* __restrict__ p, const uint32_t* __restrict__ q, uint32_t* __restrict__ o, size_t n) {
   VZ_GRID_STRIDE(i, n) {
-    Affine<F> P, Q;
-    P.x = F::to_mont(load_fe<F>(p, 2 * i)); P.y = F::to_mont(load_fe<F>(p, 2 * i + 1));
-    Q.x = F::to_mont(load_fe<F>(q, 2 * i)); Q.y = F::to_mont(load_fe<F>(q, 2 * i + 1));
+    typedef Fp29<typename F::Params> G;   // the representation the MSM kernels compute in
+    Affine<G> P, Q;
+    P.x = G::from_std(F::to_mont(load_fe<F>(p, 2 * i))); P.y = G::from_std(F::to_mont(load_fe<F>(p, 2 * i + 1)));
+    Q.x = G::from_std(F::to_mont(load_fe<F>(q, 2 * i))); Q.y = G::from_std(F::to_mont(load_fe<F>(q, 2 * i + 1)));
     // exercise both the mixed and the full formulas: ((P) + Q) via mixed, then + identity via full
-    XYZZ<F> acc = from_affine(P);
+    XYZZ<G> acc = from_affine(P);
     add_mixed(acc, Q);
-    XYZZ<F> acc2 = from_affine(Q);
-    XYZZ<F> pp = from_affine(P);
+    XYZZ<G> acc2 = from_affine(Q);
+    XYZZ<G> pp = from_affine(P);
     add_full(acc2, pp);
-    Affine<F> r1 = to_affine(acc), r2 = to_affine(acc2);
+    Affine<G> r1 = to_affine(acc), r2 = to_affine(acc2);
     bool same = r1.x.eq(r2.x) && r1.y.eq(r2.y);
     F bad = F::zero(); bad.v[0] = 0xdeadbeefu;  // mismatch marker (not a valid coordinate pair)
-    store_fe(o, 2 * i, same ? F::from_mont(r1.x) : bad);
-    store_fe(o, 2 * i + 1, same ? F::from_mont(r1.y) : bad);
+    store_fe(o, 2 * i, same ? F::from_mont(r1.x.to_std()) : bad);
+    store_fe(o, 2 * i + 1, same ? F::from_mont(r1.y.to_std()) : bad);
   }
 }
 template <class F>

@@ -171,20 +171,73 @@ __device__ __forceinline__ Fr wit_value(const WitnessDev& P, const ValRef& r, co
   }
 }
 
-// grid.x covers chains of `phase` in groups of 16 lanes; grid.y = row.  job_out: [row][n_jobs + n_fops] Montgomery.
+// One Poseidon permutation by a 16-lane group (lane li < T owns state[li]).  T is a template parameter so the MDS
+// row is held in registers and its T products are independent instructions (the chain is latency-bound: one wave per
+// SIMD, so instruction-level parallelism inside the round is what shortens it).
+template <int T>
+__device__ __forceinline__ Fr poseidon_group(const WitnessDev& P, const HashJob& J, bool live, Fr s, bool in_const, uint32_t li, int lane_base,
+                                             uint32_t* __restrict__ Zrow) {
+  const uint32_t* PC = T == 3 ? P.pc3 : P.pc9;
+  const uint32_t* PM = T == 3 ? P.pm3 : P.pm9;
+  const uint32_t rp = T == 3 ? P.rp3 : P.rp9;
+  const uint32_t R = 8 + rp;
+  const bool mine = li < (uint32_t)T;
+  Fr Mrow[T];
+#pragma unroll
+  for (int j = 0; j < T; j++) Mrow[j] = mine ? load_fe<Fr>(PM, (size_t)li * T + j) : Fr::zero();
+  // number of non-folded round-0 S-boxes before this lane / in total (lanes 1..T-1 with non-constant input)
+  const unsigned long long nf_mask = __ballot(live && li >= 1 && mine && !in_const);
+  const uint32_t grp_mask16 = (uint32_t)((nf_mask >> lane_base) & 0xffffull);
+  const uint32_t nf_before = __popc(grp_mask16 & ((1u << li) - 1u));
+  const uint32_t nf0 = __popc(grp_mask16);
+  const uint32_t elim_slot = 3 * (nf0 + 3 * T + rp + 3 * T) + 2;  // x5 of (last round, lane 0)
+  const bool bound = J.out_wire != 0;
+  for (uint32_t r = 0; r < R; r++) {
+    const bool full = r < 4 || r >= 4 + rp;
+    if (mine) s = Fr::add(s, load_fe<Fr>(PC, (size_t)r * T + li));
+    if (mine && (full || li == 0)) {
+      const Fr x2 = Fr::sqr(s), x4 = Fr::sqr(x2), x5 = Fr::mul(x4, s);
+      const bool folded = r == 0 && in_const;
+      if (live && !folded) {
+        uint32_t index;
+        if (r == 0) index = nf_before;
+        else if (r < 4) index = nf0 + (r - 1) * T + li;
+        else if (r < 4 + rp) index = nf0 + 3 * T + (r - 4);
+        else index = nf0 + 3 * T + rp + (r - 4 - rp) * T + li;
+        const uint32_t slot = 3 * index;
+        auto wire_of = [&](uint32_t sl) { return J.wire_base + sl - ((bound && sl > elim_slot) ? 1u : 0u); };
+        store_fe(Zrow, wire_of(slot), x2);
+        store_fe(Zrow, wire_of(slot + 1), x4);
+        if (!(bound && slot + 2 == elim_slot)) store_fe(Zrow, wire_of(slot + 2), x5);
+      }
+      s = x5;
+    }
+    // MDS: new[i] = sum_j M[i][j] * s[j] — T independent products, then a short add tree
+    Fr prod[T];
+#pragma unroll
+    for (int j = 0; j < T; j++) prod[j] = Fr::mul(Mrow[j], shfl_fe(s, lane_base + j));
+#pragma unroll
+    for (int stride = 1; stride < T; stride <<= 1)
+#pragma unroll
+      for (int j = 0; j + stride < T; j += 2 * stride) prod[j] = Fr::add(prod[j], prod[j + stride]);
+    s = prod[0];
+  }
+  return s;
+}
+
+// grid.x covers chains of `phase` in groups of 16 lanes (4 chains per wave); grid.y = row.
+// job_out: [row][n_jobs + n_fops] Montgomery.
 __global__ void __launch_bounds__(64) k_wit_chains(WitnessDev P, uint32_t phase, uint32_t* __restrict__ Z, uint32_t* __restrict__ job_out) {
   const uint32_t row = blockIdx.y;
   const uint32_t sub = threadIdx.x >> 4, li = threadIdx.x & 15;
   const int lane_base = (int)(threadIdx.x & ~15u);
-  // the k-th chain of this phase
   uint32_t want = blockIdx.x * 4 + sub, seen = 0, cid = 0xffffffffu;
   for (uint32_t c = 0; c < P.n_chains; c++) if (P.chains[c].phase == phase) { if (seen == want) { cid = c; break; } seen++; }
   const bool active_chain = cid != 0xffffffffu;
   uint32_t* Zrow = Z + 8 * (size_t)row * P.n_wires;
   uint32_t* jrow = job_out + 8 * (size_t)row * (P.n_jobs + P.n_fops);
   const uint32_t njobs = active_chain ? P.chains[cid].job_cnt : 0;
-  // all 64 lanes run the same number of iterations of the outer loop as the longest chain in the wave so that the
-  // shuffles stay convergent: take the maximum over the wave
+  // every lane of the wave runs as many iterations as the longest chain in it, so the shuffles stay convergent
   uint32_t max_jobs = njobs;
   for (int off = 32; off >= 16; off >>= 1) max_jobs = max(max_jobs, (uint32_t)__shfl_xor((int)max_jobs, off));
   Fr prev_out = Fr::zero();  // output of the previous job of this chain, kept in registers (no memory round trip)
@@ -193,10 +246,6 @@ __global__ void __launch_bounds__(64) k_wit_chains(WitnessDev P, uint32_t phase,
     HashJob J;
     if (live) J = P.jobs[P.chains[cid].job_off + k]; else { J.t = 3; J.wire_base = 0; J.out_wire = 0; }
     const uint32_t t = J.t;
-    const uint32_t* PC = t == 3 ? P.pc3 : P.pc9;
-    const uint32_t* PM = t == 3 ? P.pm3 : P.pm9;
-    const uint32_t rp = t == 3 ? P.rp3 : P.rp9;
-    const uint32_t R = 8 + rp;
     // initial state: lane 0 -> 0, lane i -> input i-1
     Fr s = Fr::zero();
     bool in_const = true;
@@ -206,48 +255,16 @@ __global__ void __launch_bounds__(64) k_wit_chains(WitnessDev P, uint32_t phase,
       if (ref.kind == REF_JOB && k > 0 && ref.idx == P.chains[cid].job_off + k - 1) s = prev_out;
       else s = wit_value(P, ref, Zrow, jrow);
     }
-    // number of non-folded round-0 S-boxes before this lane / in total (lanes 1..t-1 with non-constant input)
-    const unsigned long long nf_mask = __ballot(live && li >= 1 && li < t && !in_const);
-    const uint32_t grp_mask16 = (uint32_t)((nf_mask >> lane_base) & 0xffffull);
-    const uint32_t nf_before = __popc(grp_mask16 & ((1u << li) - 1u));
-    const uint32_t nf0 = __popc(grp_mask16);
-    const uint32_t elim_slot = 3 * (nf0 + 3 * t + rp + 3 * t) + 2;  // x5 of (last round, lane 0)
-    for (uint32_t r = 0; r < R; r++) {
-      const bool full = r < 4 || r >= 4 + rp;
-      const bool mine = li < t;
-      if (mine) s = Fr::add(s, load_fe<Fr>(PC, (size_t)r * t + li));
-      if (mine && (full || li == 0)) {
-        const Fr x2 = Fr::sqr(s), x4 = Fr::sqr(x2), x5 = Fr::mul(x4, s);
-        const bool folded = r == 0 && in_const;
-        if (live && !folded) {
-          uint32_t index;
-          if (r == 0) index = nf_before;
-          else if (r < 4) index = nf0 + (r - 1) * t + li;
-          else if (r < 4 + rp) index = nf0 + 3 * t + (r - 4);
-          else index = nf0 + 3 * t + rp + (r - 4 - rp) * t + li;
-          uint32_t slot = 3 * index;
-          const bool bound = J.out_wire != 0;
-          auto wire_of = [&](uint32_t sl) { return J.wire_base + sl - ((bound && sl > elim_slot) ? 1u : 0u); };
-          store_fe(Zrow, wire_of(slot), x2);
-          store_fe(Zrow, wire_of(slot + 1), x4);
-          if (!(bound && slot + 2 == elim_slot)) store_fe(Zrow, wire_of(slot + 2), x5);
-        }
-        s = x5;
-      }
-      // MDS: new[i] = sum_j M[i][j] * s[j]
-      Fr acc = Fr::zero();
-      for (uint32_t j = 0; j < t; j++) {
-        const Fr sj = shfl_fe(s, lane_base + (int)j);
-        if (mine) acc = Fr::add(acc, Fr::mul(load_fe<Fr>(PM, (size_t)li * t + j), sj));
-      }
-      s = acc;
-    }
-    prev_out = shfl_fe(s, lane_base);
+    // the four chains of a wave may mix widths: run both variants under wave-uniform votes so shuffles stay convergent
+    const bool any9 = __any(live && t == 9), any3 = __any(!(live && t == 9));
+    Fr out = Fr::zero();
+    if (any9) { Fr o = poseidon_group<9>(P, J, live && t == 9, s, in_const, li, lane_base, Zrow); if (t == 9) out = o; }
+    if (any3) { Fr o = poseidon_group<3>(P, J, live && t == 3, s, in_const, li, lane_base, Zrow); if (t != 9) out = o; }
+    prev_out = shfl_fe(out, lane_base);
     if (live && li == 0) {
-      store_fe(jrow, P.chains[cid].job_off + k, s);
-      if (J.out_wire) store_fe(Zrow, J.out_wire, s);
+      store_fe(jrow, P.chains[cid].job_off + k, out);
+      if (J.out_wire) store_fe(Zrow, J.out_wire, out);
     }
-    __threadfence_block();  // later jobs of this chain (same 16 lanes) read job_out / wires written above
   }
 }
 
