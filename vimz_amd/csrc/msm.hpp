@@ -273,21 +273,21 @@ __global__ void __launch_bounds__(256) k_reduce(const uint32_t* __restrict__ par
 
 // ---- host driver ---------------------------------------------------------------------------------
 
+// Enqueue the whole pipeline on `stream` and the copy of the K window sums into `pinned_dst` (host-pinned,
+// K * XYZZ_WORDS words).  Does not synchronise: the caller waits on the stream (or an event recorded after this call)
+// and then calls msm_finish.  `ws` must not be used by another stream concurrently.
 template <class C>
-hipError_t msm_run(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_bases, const uint32_t* d_scalars, size_t n,
-                   int scalars_mont, int c_override, Affine<typename C::Base>* out_affine_mont, MsmStats* stats,
-                   hipEvent_t* ev /* 7 events or nullptr */) {
-  typedef typename C::Coord F;      // internal 9 x 29-bit form: bases, accumulators, window sums
-  typedef typename C::Base FS;      // standard form of the result
+hipError_t msm_launch(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_bases, const uint32_t* d_scalars, size_t n,
+                      int scalars_mont, int c_override, void* pinned_dst, MsmPlan* plan_out, hipEvent_t* ev) {
+  typedef typename C::Coord F;
   typedef typename C::Scalar S;
-  if (n == 0) { out_affine_mont->x = FS::zero(); out_affine_mont->y = FS::zero(); return hipSuccess; }
-  if (n >= (1u << 31)) return hipErrorInvalidValue;
+  if (n == 0 || n >= (1u << 31)) return hipErrorInvalidValue;
   const MsmPlan pl = msm_plan(n, S::Params::BITS, c_override);
   if (pl.K > MSM_MAX_WINDOWS || pl.c > 16 || pl.c < 2) return hipErrorInvalidValue;
+  *plan_out = pl;
   const size_t entries = (size_t)pl.K * n;
   const size_t max_subs = entries / MSM_SUB + pl.nb + 1;
   VZ_HIP_CHECK(ws.reserve(pl.nb, entries, max_subs));
-
   VZ_HIP_CHECK(hipMemsetAsync(ws.counts, 0, 4 * (size_t)pl.nb, stream));
   VZ_HIP_CHECK(hipMemsetAsync(ws.cursor, 0, 4 * (size_t)pl.nb, stream));
   VZ_HIP_CHECK(hipMemsetAsync(ws.heavy, 0, 4, stream));
@@ -316,25 +316,44 @@ hipError_t msm_run(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_bases
   VZ_EV(6);
 #undef VZ_EV
   VZ_HIP_CHECK(hipGetLastError());
-  VZ_HIP_CHECK(hipMemcpyAsync(ws.host_pinned, wsum, 4 * (size_t)XYZZ_WORDS * pl.K, hipMemcpyDeviceToHost, stream));
-  uint32_t h_tot[2] = {0, 0};
-  if (stats) VZ_HIP_CHECK(hipMemcpyAsync(h_tot, ws.totals, 8, hipMemcpyDeviceToHost, stream));
-  VZ_HIP_CHECK(hipStreamSynchronize(stream));
+  VZ_HIP_CHECK(hipMemcpyAsync(pinned_dst, wsum, 4 * (size_t)XYZZ_WORDS * pl.K, hipMemcpyDeviceToHost, stream));
+  return hipSuccess;
+}
 
-  const uint32_t* hw = reinterpret_cast<const uint32_t*>(ws.host_pinned);
+// Host tail: Horner over the K window sums (converted to the standard form, whose host multiply is the fast 4x64 path)
+// and one inversion.  Result affine, standard Montgomery form.
+template <class C>
+Affine<typename C::Base> msm_finish(const MsmPlan& pl, const void* pinned) {
+  typedef typename C::Coord F;
+  typedef typename C::Base FS;
+  const uint32_t* hw = reinterpret_cast<const uint32_t*>(pinned);
   auto host_point = [&](int w) {
-    XYZZ<F> p; const uint32_t* d = hw + (size_t)XYZZ_WORDS * w;
-    F* f[4] = {&p.X, &p.Y, &p.ZZ, &p.ZZZ};
-    for (int k = 0; k < 4; k++) for (int i = 0; i < 9; i++) f[k]->v[i] = d[COORD_WORDS * k + i];
+    XYZZ<FS> p; const uint32_t* d = hw + (size_t)XYZZ_WORDS * w;
+    FS* f[4] = {&p.X, &p.Y, &p.ZZ, &p.ZZZ};
+    for (int k = 0; k < 4; k++) { F t; for (int i = 0; i < 9; i++) t.v[i] = d[COORD_WORDS * k + i]; *f[k] = t.to_std(); }
     return p;
   };
-  XYZZ<F> acc = XYZZ<F>::identity();
+  XYZZ<FS> acc = XYZZ<FS>::identity();
   for (int w = pl.K - 1; w >= 0; w--) {
     for (int k = 0; k < pl.c; k++) acc = dbl(acc);
     add_full(acc, host_point(w));
   }
-  const Affine<F> r29 = to_affine(acc);
-  out_affine_mont->x = r29.x.to_std(); out_affine_mont->y = r29.y.to_std();
+  return to_affine(acc);
+}
+
+template <class C>
+hipError_t msm_run(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_bases, const uint32_t* d_scalars, size_t n,
+                   int scalars_mont, int c_override, Affine<typename C::Base>* out_affine_mont, MsmStats* stats,
+                   hipEvent_t* ev /* 7 events or nullptr */) {
+  typedef typename C::Base FS;
+  if (n == 0) { out_affine_mont->x = FS::zero(); out_affine_mont->y = FS::zero(); return hipSuccess; }
+  if (!ws.host_pinned) VZ_HIP_CHECK(hipHostMalloc(&ws.host_pinned, 4 * XYZZ_WORDS * MSM_MAX_WINDOWS));
+  MsmPlan pl;
+  VZ_HIP_CHECK(msm_launch<C>(stream, ws, d_bases, d_scalars, n, scalars_mont, c_override, ws.host_pinned, &pl, ev));
+  uint32_t h_tot[2] = {0, 0};
+  if (stats) VZ_HIP_CHECK(hipMemcpyAsync(h_tot, ws.totals, 8, hipMemcpyDeviceToHost, stream));
+  VZ_HIP_CHECK(hipStreamSynchronize(stream));
+  *out_affine_mont = msm_finish<C>(pl, ws.host_pinned);
   if (stats && ev) for (int i = 0; i < 6; i++) VZ_HIP_CHECK(hipEventElapsedTime(&stats->ms[i], ev[i], ev[i + 1]));
   if (stats) { stats->c = pl.c; stats->K = pl.K; stats->subs = h_tot[0]; stats->entries = h_tot[1]; }
   return hipSuccess;

@@ -101,6 +101,11 @@ struct MsmStats { int c, K; uint32_t subs, entries; float ms[6]; };  // ms: hist
 
 // Defined in msm.hpp; explicitly instantiated per curve in msm_inst_*.hip.
 template <class C>
+hipError_t msm_launch(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_bases, const uint32_t* d_scalars, size_t n,
+                      int scalars_mont, int c_override, void* pinned_dst, MsmPlan* plan_out, hipEvent_t* ev);
+template <class C>
+Affine<typename C::Base> msm_finish(const MsmPlan& pl, const void* pinned);
+template <class C>
 hipError_t msm_run(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_bases, const uint32_t* d_scalars, size_t n,
                    int scalars_mont, int c_override, Affine<typename C::Base>* out_affine_mont, MsmStats* stats,
                    hipEvent_t* ev /* 7 events or nullptr */);

@@ -3,4 +3,6 @@
 namespace vz {
 template hipError_t msm_run<BnG1>(hipStream_t, MsmWorkspace&, const uint32_t*, const uint32_t*, size_t, int, int,
                                   Affine<BnG1::Base>*, MsmStats*, hipEvent_t*);
+template hipError_t msm_launch<BnG1>(hipStream_t, MsmWorkspace&, const uint32_t*, const uint32_t*, size_t, int, int, void*, MsmPlan*, hipEvent_t*);
+template Affine<BnG1::Base> msm_finish<BnG1>(const MsmPlan&, const void*);
 }

@@ -3,4 +3,6 @@
 namespace vz {
 template hipError_t msm_run<Vesta>(hipStream_t, MsmWorkspace&, const uint32_t*, const uint32_t*, size_t, int, int,
                                   Affine<Vesta::Base>*, MsmStats*, hipEvent_t*);
+template hipError_t msm_launch<Vesta>(hipStream_t, MsmWorkspace&, const uint32_t*, const uint32_t*, size_t, int, int, void*, MsmPlan*, hipEvent_t*);
+template Affine<Vesta::Base> msm_finish<Vesta>(const MsmPlan&, const void*);
 }

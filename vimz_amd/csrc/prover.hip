@@ -75,6 +75,14 @@ struct vimz_prover {
   // device: running instance and per-step scratch
   uint32_t *Zrun = nullptr, *E = nullptr, *AZ = nullptr, *BZ = nullptr, *CZ = nullptr, *T = nullptr, *az2 = nullptr, *bz2 = nullptr, *cz2 = nullptr;
   uint32_t* bad_d = nullptr;
+  // second stream: everything of a step that does not depend on the running instance (the fresh instance's
+  // (A,B,C)·z and its witness commitment) is issued for the whole batch up front and overlaps the sequential chain
+  hipStream_t sB = nullptr;
+  std::vector<hipEvent_t> evB;
+  uint32_t *az2b = nullptr, *bz2b = nullptr, *cz2b = nullptr;   // [batch][n_c]
+  MsmWorkspace wsB;
+  void* pinB = nullptr;                                          // [batch][MSM_MAX_WINDOWS] window sums
+  MsmPlan planB{};
   // host: running instance
   G1Aff comm_W{}, comm_E{};
   Fe u = Fe::zero();
@@ -130,6 +138,10 @@ void vimz_prover_free(vimz_prover* p) {
     std::lock_guard<std::mutex> g(p->ctx->mu);
     hipSetDevice(p->ctx->device);
     hipStreamSynchronize(p->ctx->stream);
+    if (p->sB) { hipStreamSynchronize(p->sB); hipStreamDestroy(p->sB); }
+    for (auto e : p->evB) hipEventDestroy(e);
+    p->wsB.release();
+    if (p->pinB) hipHostFree(p->pinB);
     for (void* d : p->owned) hipFree(d);
   }
   delete p;
@@ -186,8 +198,13 @@ int vimz_prover_create(vimz_ctx* ctx, const vimz_circuit* circuit, const vimz_ba
       dalloc(&p->BZ, 32 * (size_t)p->n_c) != hipSuccess || dalloc(&p->CZ, 32 * (size_t)p->n_c) != hipSuccess ||
       dalloc(&p->T, 32 * (size_t)p->n_c) != hipSuccess || dalloc(&p->az2, 32 * (size_t)p->n_c) != hipSuccess ||
       dalloc(&p->bz2, 32 * (size_t)p->n_c) != hipSuccess || dalloc(&p->cz2, 32 * (size_t)p->n_c) != hipSuccess ||
-      dalloc(&p->bad_d, 64) != hipSuccess)
+      dalloc(&p->bad_d, 64) != hipSuccess || dalloc(&p->az2b, 32 * B * (size_t)p->n_c) != hipSuccess ||
+      dalloc(&p->bz2b, 32 * B * (size_t)p->n_c) != hipSuccess || dalloc(&p->cz2b, 32 * B * (size_t)p->n_c) != hipSuccess)
     return fail_free("device allocation", e);
+  if ((e = hipStreamCreateWithFlags(&p->sB, hipStreamNonBlocking)) != hipSuccess) return fail_free("stream", e);
+  p->evB.resize(B);
+  for (size_t i = 0; i < B; i++) if ((e = hipEventCreateWithFlags(&p->evB[i], hipEventDisableTiming)) != hipSuccess) return fail_free("event", e);
+  if ((e = hipHostMalloc(&p->pinB, 4 * (size_t)XYZZ_WORDS * MSM_MAX_WINDOWS * B)) != hipSuccess) return fail_free("pinned", e);
   p->z_cur.assign(p->len_z, Fe::zero()); p->z0 = p->z_cur;
   *out = p;
   return VIMZ_OK;
@@ -362,32 +379,39 @@ int vimz_prover_fold(vimz_prover* p, const uint64_t* step_inputs, size_t nsteps)
       char msg[128]; snprintf(msg, sizeof(msg), "step %llu: the step relation is not satisfiable for these rows", (unsigned long long)(p->steps + r));
       return vz_fail(ctx, VIMZ_ERR_UNSAT, msg);
     }
+    // ---- stream B: fresh-instance work of the whole batch, issued up front ---------------------------------
+    const size_t pin_stride = 4 * (size_t)XYZZ_WORDS * MSM_MAX_WINDOWS;
+    for (size_t r = 0; r < rows; r++) {
+      const uint32_t* Zi = p->Z_d + 8 * r * nw;
+      launch_spmv(p, p->sB, Zi, p->az2b + 8 * r * nc, p->bz2b + 8 * r * nc, p->cz2b + 8 * r * nc);
+      P_TRY(msm_launch<BnG1>(p->sB, p->wsB, p->ck->d, Zi + 8 * (size_t)aux0, p->n_aux, 1, 0, (char*)p->pinB + r * pin_stride, &p->planB, nullptr));
+      P_TRY(hipEventRecord(p->evB[r], p->sB));
+    }
+    // ---- stream A: the sequential chain --------------------------------------------------------------------
     for (size_t r = 0; r < rows; r++) {
       uint32_t* Zi = p->Z_d + 8 * r * nw;
+      uint32_t *az2 = p->az2b + 8 * r * nc, *bz2 = p->bz2b + 8 * r * nc, *cz2 = p->cz2b + 8 * r * nc;
       double t0 = now_s();
-      launch_spmv(p, s, Zi, p->az2, p->bz2, p->cz2);
-      P_TRY(hipGetLastError());
+      P_TRY(hipEventSynchronize(p->evB[r]));              // host needs comm_W2 ...
+      P_TRY(hipStreamWaitEvent(s, p->evB[r], 0));         // ... and stream A needs (A,B,C)·z2
+      const G1Aff cW2 = msm_finish<BnG1>(p->planB, (char*)p->pinB + r * pin_stride);
+      p->phase_s[PH_MSM_W] += now_s() - t0; p->phase_n[PH_MSM_W]++;
       uint64_t pt[8];
-      // comm_W2 over the aux part of z (everything after [1 | X])
-      rc = vz_msm_device(ctx, p->ck, 0, Zi + 8 * (size_t)aux0, p->n_aux, 1, 0, pt, VIMZ_FORM_MONTGOMERY);
-      if (rc) return rc;
-      p->phase_s[PH_SPMV] += 0; p->phase_s[PH_MSM_W] += now_s() - t0; p->phase_n[PH_MSM_W]++;
-      G1Aff cW2; memcpy(cW2.x.v, pt, 32); memcpy(cW2.y.v, pt + 4, 32);
       const Fe* znext = zs.data() + (r + 1) * p->len_z;
       for (uint32_t i = 0; i < p->len_z; i++) { Fe in[2] = {p->zdigest, znext[i]}; p->zdigest = cb::poseidon_hash(in, 2); }
       if (p->steps == 0) {
         // base case: the running instance IS the first fresh instance (u = 1, E = 0), as RecursiveSNARK::new does
         P_TRY(hipMemcpyAsync(p->Zrun, Zi, 32 * nw, hipMemcpyDeviceToDevice, s));
-        P_TRY(hipMemcpyAsync(p->AZ, p->az2, 32 * nc, hipMemcpyDeviceToDevice, s));
-        P_TRY(hipMemcpyAsync(p->BZ, p->bz2, 32 * nc, hipMemcpyDeviceToDevice, s));
-        P_TRY(hipMemcpyAsync(p->CZ, p->cz2, 32 * nc, hipMemcpyDeviceToDevice, s));
+        P_TRY(hipMemcpyAsync(p->AZ, az2, 32 * nc, hipMemcpyDeviceToDevice, s));
+        P_TRY(hipMemcpyAsync(p->BZ, bz2, 32 * nc, hipMemcpyDeviceToDevice, s));
+        P_TRY(hipMemcpyAsync(p->CZ, cz2, 32 * nc, hipMemcpyDeviceToDevice, s));
         p->comm_W = cW2; p->u = Fe::one();
         Fe ab[8]; Fe cw[2]; ro_absorb_point(cW2, cw);
         ab[0] = p->ro; ab[1] = cw[0]; ab[2] = cw[1]; ab[3] = p->zdigest;
         p->ro = cb::poseidon_hash(ab, 4);
       } else {
         t0 = now_s();
-        hipLaunchKernelGGL(k_cross_term<Fr>, dim3(stream_grid(nc)), dim3(256), 0, s, nc, p->AZ, p->BZ, p->CZ, p->u, p->az2, p->bz2, p->cz2, Fe::one(), p->T);
+        hipLaunchKernelGGL(k_cross_term<Fr>, dim3(stream_grid(nc)), dim3(256), 0, s, nc, p->AZ, p->BZ, p->CZ, p->u, az2, bz2, cz2, Fe::one(), p->T);
         P_TRY(hipGetLastError());
         rc = vz_msm_device(ctx, p->ck, 0, p->T, nc, 1, 0, pt, VIMZ_FORM_MONTGOMERY);
         if (rc) return rc;
@@ -405,9 +429,9 @@ int vimz_prover_fold(vimz_prover* p, const uint64_t* step_inputs, size_t nsteps)
         Fold5 f;
         f.x1[0] = p->Zrun; f.x2[0] = Zi; f.n[0] = nw;
         f.x1[1] = p->E; f.x2[1] = p->T; f.n[1] = nc;
-        f.x1[2] = p->AZ; f.x2[2] = p->az2; f.n[2] = nc;
-        f.x1[3] = p->BZ; f.x2[3] = p->bz2; f.n[3] = nc;
-        f.x1[4] = p->CZ; f.x2[4] = p->cz2; f.n[4] = nc;
+        f.x1[2] = p->AZ; f.x2[2] = az2; f.n[2] = nc;
+        f.x1[3] = p->BZ; f.x2[3] = bz2; f.n[3] = nc;
+        f.x1[4] = p->CZ; f.x2[4] = cz2; f.n[4] = nc;
         hipLaunchKernelGGL(k_fold5<Fr>, dim3(2048), dim3(256), 0, s, f, rm);
         P_TRY(hipGetLastError());
         // host side of the fold, overlapped with the kernel above
@@ -415,12 +439,12 @@ int vimz_prover_fold(vimz_prover* p, const uint64_t* step_inputs, size_t nsteps)
         G1 e1 = from_affine(p->comm_E); G1 rt = scalar_mul(cT, r128.v, 128); add_full(e1, rt); p->comm_E = to_affine(e1);
         p->u = Fe::add(p->u, rm);
         p->phase_s[PH_HOST_EC] += now_s() - t0; p->phase_n[PH_HOST_EC]++;
-        t0 = now_s();
-        P_TRY(hipStreamSynchronize(s));
-        p->phase_s[PH_FOLD] += now_s() - t0; p->phase_n[PH_FOLD]++;
       }
       p->steps++;
     }
+    // the batch buffers (Z_d, az2b..) are rewritten by the next batch: drain both streams first
+    P_TRY(hipStreamSynchronize(s));
+    P_TRY(hipStreamSynchronize(p->sB));
     for (uint32_t i = 0; i < p->len_z; i++) p->z_cur[i] = zs[rows * p->len_z + i];
     done += rows;
   }
