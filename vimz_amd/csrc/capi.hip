@@ -109,7 +109,11 @@ int vimz_ctx_create(int device, vimz_ctx** out) {
   vimz_ctx* c = new (std::nothrow) vimz_ctx();
   if (!c) return fail(nullptr, VIMZ_ERR_INVALID, "out of host memory");
   c->device = device;
-  if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
+  // the context's stream carries the latency-critical sequential chain of a fold: give it the highest priority so the
+  // batch producer (a second stream inside the prover) cannot delay it
+  int prio_lo = 0, prio_hi = 0;
+  hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+  if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_hi)) != hipSuccess ||
       (e = hipEventCreate(&c->t0)) != hipSuccess || (e = hipEventCreate(&c->t1)) != hipSuccess) {
     delete c; return fail(nullptr, VIMZ_ERR_HIP, "context setup", e);
   }

@@ -78,11 +78,18 @@ struct vimz_prover {
   // second stream: everything of a step that does not depend on the running instance (the fresh instance's
   // (A,B,C)·z and its witness commitment) is issued for the whole batch up front and overlaps the sequential chain
   hipStream_t sB = nullptr;
-  std::vector<hipEvent_t> evB;
-  uint32_t *az2b = nullptr, *bz2b = nullptr, *cz2b = nullptr;   // [batch][n_c]
+  struct BatchBuf {                       // double-buffered: batch k+1 is produced while batch k is folded
+    uint32_t *Z = nullptr, *job_out = nullptr, *status = nullptr, *az = nullptr, *bz = nullptr, *cz = nullptr;
+    void* pin = nullptr;                  // [batch][MSM_MAX_WINDOWS] window sums of the witness commitments (pinned)
+    uint32_t* status_host = nullptr;      // pinned
+    std::vector<hipEvent_t> ev;           // per row: fresh-instance work done
+    hipEvent_t wit_done = nullptr;
+  } buf[2];
   MsmWorkspace wsB;
-  void* pinB = nullptr;                                          // [batch][MSM_MAX_WINDOWS] window sums
   MsmPlan planB{};
+  // per fold call: all private inputs, all IVC states and all row hashes resident
+  uint32_t *priv_all_d = nullptr, *zs_all_d = nullptr, *job_all_d = nullptr;
+  size_t cap_priv_all = 0, cap_zs_all = 0, cap_job_all = 0;
   // host: running instance
   G1Aff comm_W{}, comm_E{};
   Fe u = Fe::zero();
@@ -139,9 +146,14 @@ void vimz_prover_free(vimz_prover* p) {
     hipSetDevice(p->ctx->device);
     hipStreamSynchronize(p->ctx->stream);
     if (p->sB) { hipStreamSynchronize(p->sB); hipStreamDestroy(p->sB); }
-    for (auto e : p->evB) hipEventDestroy(e);
+    for (auto& bb : p->buf) {
+      for (auto e : bb.ev) hipEventDestroy(e);
+      if (bb.wit_done) hipEventDestroy(bb.wit_done);
+      if (bb.pin) hipHostFree(bb.pin);
+      if (bb.status_host) hipHostFree(bb.status_host);
+    }
     p->wsB.release();
-    if (p->pinB) hipHostFree(p->pinB);
+    hipFree(p->priv_all_d); hipFree(p->zs_all_d); hipFree(p->job_all_d);
     for (void* d : p->owned) hipFree(d);
   }
   delete p;
@@ -198,13 +210,23 @@ int vimz_prover_create(vimz_ctx* ctx, const vimz_circuit* circuit, const vimz_ba
       dalloc(&p->BZ, 32 * (size_t)p->n_c) != hipSuccess || dalloc(&p->CZ, 32 * (size_t)p->n_c) != hipSuccess ||
       dalloc(&p->T, 32 * (size_t)p->n_c) != hipSuccess || dalloc(&p->az2, 32 * (size_t)p->n_c) != hipSuccess ||
       dalloc(&p->bz2, 32 * (size_t)p->n_c) != hipSuccess || dalloc(&p->cz2, 32 * (size_t)p->n_c) != hipSuccess ||
-      dalloc(&p->bad_d, 64) != hipSuccess || dalloc(&p->az2b, 32 * B * (size_t)p->n_c) != hipSuccess ||
-      dalloc(&p->bz2b, 32 * B * (size_t)p->n_c) != hipSuccess || dalloc(&p->cz2b, 32 * B * (size_t)p->n_c) != hipSuccess)
+      dalloc(&p->bad_d, 64) != hipSuccess)
     return fail_free("device allocation", e);
-  if ((e = hipStreamCreateWithFlags(&p->sB, hipStreamNonBlocking)) != hipSuccess) return fail_free("stream", e);
-  p->evB.resize(B);
-  for (size_t i = 0; i < B; i++) if ((e = hipEventCreateWithFlags(&p->evB[i], hipEventDisableTiming)) != hipSuccess) return fail_free("event", e);
-  if ((e = hipHostMalloc(&p->pinB, 4 * (size_t)XYZZ_WORDS * MSM_MAX_WINDOWS * B)) != hipSuccess) return fail_free("pinned", e);
+  { int lo = 0, hi = 0; hipDeviceGetStreamPriorityRange(&lo, &hi);
+    if ((e = hipStreamCreateWithPriority(&p->sB, hipStreamNonBlocking, lo)) != hipSuccess) return fail_free("stream", e); }
+  for (int k = 0; k < 2; k++) {
+    auto& bb = p->buf[k];
+    if (k == 0) { bb.Z = p->Z_d; bb.job_out = p->job_out_d; bb.status = p->status_d; }   // buffer 0 is shared with the witness hook
+    else if (dalloc(&bb.Z, 32 * B * (size_t)p->n_wires) != hipSuccess || dalloc(&bb.job_out, 32 * B * (size_t)(p->n_jobs + p->n_fops)) != hipSuccess ||
+             dalloc(&bb.status, 4 * B) != hipSuccess) return fail_free("device allocation", e);
+    if (dalloc(&bb.az, 32 * B * (size_t)p->n_c) != hipSuccess || dalloc(&bb.bz, 32 * B * (size_t)p->n_c) != hipSuccess ||
+        dalloc(&bb.cz, 32 * B * (size_t)p->n_c) != hipSuccess) return fail_free("device allocation", e);
+    bb.ev.resize(B);
+    for (size_t i = 0; i < B; i++) if ((e = hipEventCreateWithFlags(&bb.ev[i], hipEventDisableTiming)) != hipSuccess) return fail_free("event", e);
+    if ((e = hipEventCreateWithFlags(&bb.wit_done, hipEventDisableTiming)) != hipSuccess) return fail_free("event", e);
+    if ((e = hipHostMalloc(&bb.pin, 4 * (size_t)XYZZ_WORDS * MSM_MAX_WINDOWS * B)) != hipSuccess) return fail_free("pinned", e);
+    if ((e = hipHostMalloc((void**)&bb.status_host, 4 * B)) != hipSuccess) return fail_free("pinned", e);
+  }
   p->z_cur.assign(p->len_z, Fe::zero()); p->z0 = p->z_cur;
   *out = p;
   return VIMZ_OK;
@@ -258,7 +280,7 @@ static int witness_batch_locked(vimz_prover* p, const uint64_t* inputs, size_t r
   std::vector<Fe> zs_tmp((rows + 1) * p->len_z, Fe::zero());
   P_TRY(hipMemsetAsync(p->zs_d, 0, 32 * (rows + 1) * p->len_z, s));
   hipLaunchKernelGGL(k_wit_inputs, dim3(((1 + 2 * p->len_z + p->n_priv) + 255) / 256, (unsigned)rows), dim3(256), 0, s, W, p->priv_d, p->zs_d, p->Z_d, 0u);
-  if (nA) hipLaunchKernelGGL(k_wit_chains, dim3((nA + 3) / 4, (unsigned)rows), dim3(64), 0, s, W, 0u, p->Z_d, p->job_out_d);
+  if (nA) hipLaunchKernelGGL(k_wit_chains, dim3((nA + 3) / 4, (unsigned)rows), dim3(64), 0, s, W, 0u, p->Z_d, p->job_out_d, (const uint32_t*)nullptr);
   P_TRY(hipGetLastError());
   // host: IVC state chain z_k -> z_{k+rows} from the phase-A hash outputs
   const size_t jstride = p->n_jobs + p->n_fops;
@@ -296,7 +318,7 @@ static int witness_batch_locked(vimz_prover* p, const uint64_t* inputs, size_t r
   hipLaunchKernelGGL(k_wit_inputs, dim3(((1 + 2 * p->len_z) + 255) / 256, (unsigned)rows), dim3(256), 0, s, W, p->priv_d, p->zs_d, p->Z_d, 0u);
   for (uint32_t g = 0; g < W.n_groups; g++)
     hipLaunchKernelGGL(k_wit_lanes, dim3((b.lane_groups[g].lanes + LANE_TB - 1) / LANE_TB, (unsigned)rows), dim3(LANE_TB), 0, s, W, g, p->priv_d, p->zs_d, 0u, p->Z_d, p->status_d);
-  if (nB) hipLaunchKernelGGL(k_wit_chains, dim3((nB + 3) / 4, (unsigned)rows), dim3(64), 0, s, W, 1u, p->Z_d, p->job_out_d);
+  if (nB) hipLaunchKernelGGL(k_wit_chains, dim3((nB + 3) / 4, (unsigned)rows), dim3(64), 0, s, W, 1u, p->Z_d, p->job_out_d, (const uint32_t*)nullptr);
   if (p->n_fops) hipLaunchKernelGGL(k_wit_fops, dim3(((unsigned)rows + 63) / 64), dim3(64), 0, s, W, p->Z_d, p->job_out_d, (uint32_t)rows);
   P_TRY(hipGetLastError());
   p->last_status.assign(rows, 0);
@@ -359,45 +381,145 @@ static void ro_absorb_point(const G1Aff& pt, Fe* out2) {  // (x_lo128, x_hi | pa
   out2[0] = Fe::to_mont(lo); out2[1] = Fe::to_mont(hi);
 }
 
+// Host IVC-state chain for `rows` rows: zs[(r+1)] from zs[r] and the row hashes (phase-A job outputs) of row r.
+static void host_state_chain(const vimz_prover* p, const uint64_t* inputs, size_t rows, const Fe* jobA, size_t jstride, std::vector<Fe>& zs) {
+  const cb::Builder& b = p->circuit->build->b;
+  HostEval ev; ev.P = p; ev.b = &b;
+  for (size_t r = 0; r < rows; r++) {
+    ev.priv = inputs + 4 * r * p->n_priv; ev.job_a = jobA + r * jstride; ev.zin = zs.data() + r * p->len_z;
+    ev.job_b.assign(p->n_jobs, Fe::zero()); ev.fop.assign(p->n_fops, Fe::zero());
+    for (auto& c : b.chains) {
+      if (c.phase != 1) continue;
+      for (uint32_t k = 0; k < c.job_cnt; k++) {
+        const HashJob& J = b.jobs[c.job_off + k];
+        Fe in[POSEIDON_MAX_T];
+        for (uint32_t i = 0; i + 1 < J.t; i++) in[i] = ev.value(J.in[i]);
+        ev.job_b[c.job_off + k] = cb::poseidon_hash(in, (int)J.t - 1);
+      }
+    }
+    for (uint32_t f = 0; f < p->n_fops; f++) {
+      const FieldOp& F = b.fops[f];
+      if (F.op == FOP_ISZERO) { Fe in = ev.value(F.a); ev.fop[f] = in.is_zero() ? Fe::one() : Fe::zero(); }
+      else { Fe sv = ev.value(F.a), c0 = ev.value(F.b), c1 = ev.value(F.c); ev.fop[f] = Fe::add(Fe::mul(Fe::sub(c1, c0), sv), c0); }
+    }
+    Fe* zn = zs.data() + (r + 1) * p->len_z;
+    for (uint32_t i = 0; i < p->len_z; i++) zn[i] = Fe::add(ev.value(b.zout[i].ref), cb::fe_from_i64(b.zout[i].add));
+  }
+}
+
+static hipError_t grow(uint32_t** d, size_t* cap, size_t bytes) {
+  if (bytes <= *cap) return hipSuccess;
+  hipFree(*d); *d = nullptr; *cap = 0;
+  hipError_t e = hipMalloc((void**)d, bytes);
+  if (e == hipSuccess) *cap = bytes;
+  return e;
+}
+
 // Fold `nsteps` more rows.  step_inputs: nsteps x n_priv canonical elements, in the flattened order of
 // vimz/src/nova_snark_backend/input.rs:57-96 (row_orig rows, then row_tran rows; redact: block then indicator).
+//
+// Schedule (all resident):
+//   0. every private input to HBM; ONE hash-only pass of the phase-A Poseidon chains over ALL rows (they depend on the
+//      row data only) -> the host runs the whole IVC state chain z_0..z_n (two pair hashes per row) and uploads it;
+//   1. per batch, on stream B: full witness generation, then per row (A,B,C)·z and the witness commitment;
+//      batch k+1 is produced while
+//   2. stream A folds batch k sequentially: cross term, MSM(T), challenge, fused fold.
 int vimz_prover_fold(vimz_prover* p, const uint64_t* step_inputs, size_t nsteps) {
   if (!p || (!step_inputs && nsteps)) return VIMZ_ERR_INVALID;
+  if (!nsteps) return VIMZ_OK;
   vimz_ctx* ctx = p->ctx;
   std::lock_guard<std::mutex> g(ctx->mu);
   P_TRY(hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
-  const size_t nw = p->n_wires, nc = p->n_c;
+  const cb::Builder& b = p->circuit->build->b;
+  const WitnessDev& W = p->wd;
+  const size_t nw = p->n_wires, nc = p->n_c, jstride = p->n_jobs + p->n_fops, B = p->max_batch;
   const uint32_t aux0 = 1 + 2 * p->len_z;
-  size_t done = 0;
-  while (done < nsteps) {
-    const size_t rows = std::min(p->max_batch, nsteps - done);
-    std::vector<Fe> zs;
-    int rc = witness_batch_locked(p, step_inputs + 4 * done * p->n_priv, rows, zs);
-    if (rc) return rc;
-    for (size_t r = 0; r < rows; r++) if (p->last_status[r]) {
+  uint32_t nA = 0, nB = 0;
+  for (auto& c : b.chains) (c.phase == 0 ? nA : nB)++;
+  int rc;
+
+  // ---- 0. inputs, row hashes, IVC state chain ------------------------------------------------------------------
+  double t0 = now_s();
+  P_TRY(grow(&p->priv_all_d, &p->cap_priv_all, 32 * nsteps * (size_t)p->n_priv));
+  P_TRY(grow(&p->zs_all_d, &p->cap_zs_all, 32 * (nsteps + 1) * (size_t)p->len_z));
+  P_TRY(grow(&p->job_all_d, &p->cap_job_all, 32 * nsteps * jstride));
+  P_TRY(hipMemcpyAsync(p->priv_all_d, step_inputs, 32 * nsteps * (size_t)p->n_priv, hipMemcpyHostToDevice, s));
+  P_TRY(hipMemsetAsync(p->job_all_d, 0, 32 * nsteps * jstride, s));
+  for (size_t off = 0; off < nsteps && nA; off += 32768) {
+    const unsigned rows = (unsigned)std::min<size_t>(32768, nsteps - off);
+    hipLaunchKernelGGL(k_wit_chains, dim3((nA + 3) / 4, rows), dim3(64), 0, s, W, 0u, (uint32_t*)nullptr, p->job_all_d + 8 * off * jstride,
+                       (const uint32_t*)(p->priv_all_d + 8 * off * p->n_priv));
+  }
+  P_TRY(hipGetLastError());
+  std::vector<Fe> jobA(nsteps * jstride);
+  P_TRY(hipMemcpyAsync(jobA.data(), p->job_all_d, 32 * nsteps * jstride, hipMemcpyDeviceToHost, s));
+  P_TRY(hipStreamSynchronize(s));
+  p->phase_s[PH_WITNESS] += now_s() - t0; t0 = now_s();
+  std::vector<Fe> zs((nsteps + 1) * p->len_z, Fe::zero());
+  for (uint32_t i = 0; i < p->len_z; i++) zs[i] = p->z_cur[i];
+  host_state_chain(p, step_inputs, nsteps, jobA.data(), jstride, zs);
+  {
+    std::vector<Fe> zc(zs.size());
+    for (size_t i = 0; i < zs.size(); i++) zc[i] = Fe::from_mont(zs[i]);
+    P_TRY(hipMemcpyAsync(p->zs_all_d, zc.data(), 32 * zc.size(), hipMemcpyHostToDevice, s));
+    P_TRY(hipStreamSynchronize(s));
+  }
+  p->phase_s[PH_ZCHAIN] += now_s() - t0; p->phase_n[PH_ZCHAIN] += nsteps; p->phase_n[PH_WITNESS] += nsteps;
+
+  // ---- 1. producer: one batch on stream B ------------------------------------------------------------------------
+  const size_t pin_stride = 4 * (size_t)XYZZ_WORDS * MSM_MAX_WINDOWS;
+  const size_t nbatches = (nsteps + B - 1) / B;
+  auto issue = [&](size_t k) -> int {
+    auto& bb = p->buf[k & 1];
+    const size_t first = k * B, rows = std::min(B, nsteps - first);
+    hipStream_t sb = p->sB;
+    const uint32_t* priv = p->priv_all_d + 8 * first * p->n_priv;
+    P_TRY(hipMemsetAsync(bb.status, 0, 4 * rows, sb));
+    for (uint32_t gI = 0; gI < W.n_decomp; gI++) {
+      const uint32_t total = (b.decomp[gI].nbits - 1) * b.decomp[gI].count;
+      hipLaunchKernelGGL(k_wit_decomp, dim3((total + 255) / 256, (unsigned)rows), dim3(256), 0, sb, W, gI, priv, bb.Z, bb.status);
+    }
+    hipLaunchKernelGGL(k_wit_inputs, dim3(((1 + 2 * p->len_z + p->n_priv) + 255) / 256, (unsigned)rows), dim3(256), 0, sb, W, priv, (const uint32_t*)p->zs_all_d, bb.Z, (uint32_t)first);
+    for (uint32_t gI = 0; gI < W.n_groups; gI++)
+      hipLaunchKernelGGL(k_wit_lanes, dim3((b.lane_groups[gI].lanes + LANE_TB - 1) / LANE_TB, (unsigned)rows), dim3(LANE_TB), 0, sb, W, gI, priv, (const uint32_t*)p->zs_all_d, (uint32_t)first, bb.Z, bb.status);
+    if (nA) hipLaunchKernelGGL(k_wit_chains, dim3((nA + 3) / 4, (unsigned)rows), dim3(64), 0, sb, W, 0u, bb.Z, bb.job_out, (const uint32_t*)nullptr);
+    if (nB) hipLaunchKernelGGL(k_wit_chains, dim3((nB + 3) / 4, (unsigned)rows), dim3(64), 0, sb, W, 1u, bb.Z, bb.job_out, (const uint32_t*)nullptr);
+    if (p->n_fops) hipLaunchKernelGGL(k_wit_fops, dim3(((unsigned)rows + 63) / 64), dim3(64), 0, sb, W, bb.Z, bb.job_out, (uint32_t)rows);
+    P_TRY(hipGetLastError());
+    P_TRY(hipMemcpyAsync(bb.status_host, bb.status, 4 * rows, hipMemcpyDeviceToHost, sb));
+    P_TRY(hipEventRecord(bb.wit_done, sb));
+    for (size_t r = 0; r < rows; r++) {
+      const uint32_t* Zi = bb.Z + 8 * r * nw;
+      launch_spmv(p, sb, Zi, bb.az + 8 * r * nc, bb.bz + 8 * r * nc, bb.cz + 8 * r * nc);
+      P_TRY(msm_launch<BnG1>(sb, p->wsB, p->ck->d, Zi + 8 * (size_t)aux0, p->n_aux, 1, 0, (char*)bb.pin + r * pin_stride, &p->planB, nullptr));
+      P_TRY(hipEventRecord(bb.ev[r], sb));
+    }
+    return VIMZ_OK;
+  };
+
+  // ---- 2. consumer: the sequential chain on stream A ------------------------------------------------------------
+  if ((rc = issue(0))) return rc;
+  for (size_t k = 0; k < nbatches; k++) {
+    auto& bb = p->buf[k & 1];
+    const size_t first = k * B, rows = std::min(B, nsteps - first);
+    if (k + 1 < nbatches && (rc = issue(k + 1))) return rc;
+    P_TRY(hipEventSynchronize(bb.wit_done));
+    for (size_t r = 0; r < rows; r++) if (bb.status_host[r]) {
       char msg[128]; snprintf(msg, sizeof(msg), "step %llu: the step relation is not satisfiable for these rows", (unsigned long long)(p->steps + r));
+      hipStreamSynchronize(p->sB);
       return vz_fail(ctx, VIMZ_ERR_UNSAT, msg);
     }
-    // ---- stream B: fresh-instance work of the whole batch, issued up front ---------------------------------
-    const size_t pin_stride = 4 * (size_t)XYZZ_WORDS * MSM_MAX_WINDOWS;
     for (size_t r = 0; r < rows; r++) {
-      const uint32_t* Zi = p->Z_d + 8 * r * nw;
-      launch_spmv(p, p->sB, Zi, p->az2b + 8 * r * nc, p->bz2b + 8 * r * nc, p->cz2b + 8 * r * nc);
-      P_TRY(msm_launch<BnG1>(p->sB, p->wsB, p->ck->d, Zi + 8 * (size_t)aux0, p->n_aux, 1, 0, (char*)p->pinB + r * pin_stride, &p->planB, nullptr));
-      P_TRY(hipEventRecord(p->evB[r], p->sB));
-    }
-    // ---- stream A: the sequential chain --------------------------------------------------------------------
-    for (size_t r = 0; r < rows; r++) {
-      uint32_t* Zi = p->Z_d + 8 * r * nw;
-      uint32_t *az2 = p->az2b + 8 * r * nc, *bz2 = p->bz2b + 8 * r * nc, *cz2 = p->cz2b + 8 * r * nc;
-      double t0 = now_s();
-      P_TRY(hipEventSynchronize(p->evB[r]));              // host needs comm_W2 ...
-      P_TRY(hipStreamWaitEvent(s, p->evB[r], 0));         // ... and stream A needs (A,B,C)·z2
-      const G1Aff cW2 = msm_finish<BnG1>(p->planB, (char*)p->pinB + r * pin_stride);
+      uint32_t* Zi = bb.Z + 8 * r * nw;
+      uint32_t *az2 = bb.az + 8 * r * nc, *bz2 = bb.bz + 8 * r * nc, *cz2 = bb.cz + 8 * r * nc;
+      t0 = now_s();
+      P_TRY(hipEventSynchronize(bb.ev[r]));              // host needs comm_W2 ...
+      P_TRY(hipStreamWaitEvent(s, bb.ev[r], 0));         // ... and stream A needs (A,B,C)·z2
+      const G1Aff cW2 = msm_finish<BnG1>(p->planB, (char*)bb.pin + r * pin_stride);
       p->phase_s[PH_MSM_W] += now_s() - t0; p->phase_n[PH_MSM_W]++;
       uint64_t pt[8];
-      const Fe* znext = zs.data() + (r + 1) * p->len_z;
+      const Fe* znext = zs.data() + (first + r + 1) * p->len_z;
       for (uint32_t i = 0; i < p->len_z; i++) { Fe in[2] = {p->zdigest, znext[i]}; p->zdigest = cb::poseidon_hash(in, 2); }
       if (p->steps == 0) {
         // base case: the running instance IS the first fresh instance (u = 1, E = 0), as RecursiveSNARK::new does
@@ -442,13 +564,11 @@ int vimz_prover_fold(vimz_prover* p, const uint64_t* step_inputs, size_t nsteps)
       }
       p->steps++;
     }
-    // the batch buffers (Z_d, az2b..) are rewritten by the next batch: drain both streams first
+    // this buffer is rewritten by batch k+2: the folds that read it must have finished
     P_TRY(hipStreamSynchronize(s));
-    P_TRY(hipStreamSynchronize(p->sB));
-    for (uint32_t i = 0; i < p->len_z; i++) p->z_cur[i] = zs[rows * p->len_z + i];
-    done += rows;
   }
-  P_TRY(hipStreamSynchronize(s));
+  P_TRY(hipStreamSynchronize(p->sB));
+  for (uint32_t i = 0; i < p->len_z; i++) p->z_cur[i] = zs[nsteps * p->len_z + i];
   return VIMZ_OK;
 }
 

@@ -161,9 +161,12 @@ __device__ __forceinline__ Fr shfl_fe(const Fr& v, int src_lane) {
   return r;
 }
 
-__device__ __forceinline__ Fr wit_value(const WitnessDev& P, const ValRef& r, const uint32_t* __restrict__ Zrow, const uint32_t* __restrict__ job_out_row) {
+__device__ __forceinline__ Fr wit_value(const WitnessDev& P, const ValRef& r, const uint32_t* __restrict__ Zrow, const uint32_t* __restrict__ job_out_row,
+                                         const uint32_t* __restrict__ priv_row = nullptr) {
   switch (r.kind) {
-    case REF_WIRE: return load_fe<Fr>(Zrow, r.idx);
+    case REF_WIRE:
+      if (priv_row) return Fr::to_mont(load_fe<Fr>(priv_row, r.idx - (1 + 2 * P.len_z)));   // hash-only pass: private inputs only
+      return load_fe<Fr>(Zrow, r.idx);
     case REF_JOB: return load_fe<Fr>(job_out_row, r.idx);
     case REF_FOP: return load_fe<Fr>(job_out_row, P.n_jobs + r.idx);
     case REF_ZIN: return load_fe<Fr>(Zrow, 1 + P.len_z + r.idx);
@@ -176,7 +179,7 @@ __device__ __forceinline__ Fr wit_value(const WitnessDev& P, const ValRef& r, co
 // SIMD, so instruction-level parallelism inside the round is what shortens it).
 template <int T>
 __device__ __forceinline__ Fr poseidon_group(const WitnessDev& P, const HashJob& J, bool live, Fr s, bool in_const, uint32_t li, int lane_base,
-                                             uint32_t* __restrict__ Zrow) {
+                                             uint32_t* __restrict__ Zrow) {   // Zrow == nullptr: compute the hash only, write no wires
   const uint32_t* PC = T == 3 ? P.pc3 : P.pc9;
   const uint32_t* PM = T == 3 ? P.pm3 : P.pm9;
   const uint32_t rp = T == 3 ? P.rp3 : P.rp9;
@@ -198,7 +201,7 @@ __device__ __forceinline__ Fr poseidon_group(const WitnessDev& P, const HashJob&
     if (mine && (full || li == 0)) {
       const Fr x2 = Fr::sqr(s), x4 = Fr::sqr(x2), x5 = Fr::mul(x4, s);
       const bool folded = r == 0 && in_const;
-      if (live && !folded) {
+      if (live && !folded && Zrow) {
         uint32_t index;
         if (r == 0) index = nf_before;
         else if (r < 4) index = nf0 + (r - 1) * T + li;
@@ -227,14 +230,18 @@ __device__ __forceinline__ Fr poseidon_group(const WitnessDev& P, const HashJob&
 
 // grid.x covers chains of `phase` in groups of 16 lanes (4 chains per wave); grid.y = row.
 // job_out: [row][n_jobs + n_fops] Montgomery.
-__global__ void __launch_bounds__(64) k_wit_chains(WitnessDev P, uint32_t phase, uint32_t* __restrict__ Z, uint32_t* __restrict__ job_out) {
+// priv_rows != nullptr selects the hash-only pass: inputs come from the canonical private-input rows, no wire is written
+// (used once per fold call over ALL rows to get the row hashes the IVC state chain needs).
+__global__ void __launch_bounds__(64) k_wit_chains(WitnessDev P, uint32_t phase, uint32_t* __restrict__ Z, uint32_t* __restrict__ job_out,
+                                                   const uint32_t* __restrict__ priv_rows) {
   const uint32_t row = blockIdx.y;
   const uint32_t sub = threadIdx.x >> 4, li = threadIdx.x & 15;
   const int lane_base = (int)(threadIdx.x & ~15u);
   uint32_t want = blockIdx.x * 4 + sub, seen = 0, cid = 0xffffffffu;
   for (uint32_t c = 0; c < P.n_chains; c++) if (P.chains[c].phase == phase) { if (seen == want) { cid = c; break; } seen++; }
   const bool active_chain = cid != 0xffffffffu;
-  uint32_t* Zrow = Z + 8 * (size_t)row * P.n_wires;
+  uint32_t* Zrow = priv_rows ? nullptr : Z + 8 * (size_t)row * P.n_wires;
+  const uint32_t* prow = priv_rows ? priv_rows + 8 * (size_t)row * P.n_priv : nullptr;
   uint32_t* jrow = job_out + 8 * (size_t)row * (P.n_jobs + P.n_fops);
   const uint32_t njobs = active_chain ? P.chains[cid].job_cnt : 0;
   // every lane of the wave runs as many iterations as the longest chain in it, so the shuffles stay convergent
@@ -253,7 +260,7 @@ __global__ void __launch_bounds__(64) k_wit_chains(WitnessDev P, uint32_t phase,
       const ValRef ref = J.in[li - 1];
       in_const = ref.kind == REF_CONST_ZERO;
       if (ref.kind == REF_JOB && k > 0 && ref.idx == P.chains[cid].job_off + k - 1) s = prev_out;
-      else s = wit_value(P, ref, Zrow, jrow);
+      else s = wit_value(P, ref, Zrow, jrow, prow);
     }
     // the four chains of a wave may mix widths: run both variants under wave-uniform votes so shuffles stay convergent
     const bool any9 = __any(live && t == 9), any3 = __any(!(live && t == 9));
@@ -263,7 +270,7 @@ __global__ void __launch_bounds__(64) k_wit_chains(WitnessDev P, uint32_t phase,
     prev_out = shfl_fe(out, lane_base);
     if (live && li == 0) {
       store_fe(jrow, P.chains[cid].job_off + k, out);
-      if (J.out_wire) store_fe(Zrow, J.out_wire, out);
+      if (J.out_wire && Zrow) store_fe(Zrow, J.out_wire, out);
     }
   }
 }
