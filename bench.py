@@ -7,8 +7,9 @@
 A "step" is one folding step = one image row through witness generation -> (A,B,C)·z -> MSM(W) -> cross term ->
 MSM(T) -> challenge -> fold.  Workload at any N: contrast_step at HD (the configuration the reference's headline
 number is quoted on: 720 steps in 371.7 s = 1.94 steps/s, README.md:52), rows of the reference's sample image
-(tests/golden/img2.png, contrast factor 1.4), each rank folding its own row segment (independent row-folds, weak
-scaling, no data-path collective).  Prints ONE JSON line on rank 0.
+(tests/golden/img2.png, contrast factor 1.4).  Every rank folds its own contiguous row segment of W+K rows into its own
+running instance (independent row-folds, weak scaling, no data-path collective); after the timed region rank 0 gathers
+the exported instances and performs the host-side sequential final fold, then verifies.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -22,7 +23,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-MIXED_ADD_PEAK_GOPS = 8.75       # measured ceiling of the XYZZ mixed addition (profiles/r01_ubench_gfx950_b.txt)
+MIXED_ADD_PEAK_GOPS = 12.65      # measured ceiling of the XYZZ mixed addition in the 9x29-bit form (profiles/r01_ubench_fp29.txt)
 
 
 def build_inputs(transformation, resolution):
@@ -40,22 +41,22 @@ def build_inputs(transformation, resolution):
     return steps, z0
 
 
-def cpu_baseline(circuit, steps, z0, ck_host, n_steps, threads):
-    """The oracle (CPU restatement, kind "port") timed on the same workload: witness, (A,B,C)·z, MSM(W), cross term,
-    MSM(T), folds for `n_steps` rows.  Reported beside the GPU number; never the thing measured as `value`."""
+def cpu_baseline(circuit, steps, z0, ck_host, budget_s, threads):
+    """The oracle (CPU restatement, kind "port") timed on the same workload for about `budget_s` seconds: witness,
+    (A,B,C)·z, MSM(W), cross term, MSM(T), folds.  Reported beside the GPU number; never the thing measured as `value`."""
     from tests import _oracle
     orc = _oracle.load()
     aux0 = 1 + 2 * circuit.len_z
-    n_aux = circuit.n_wires - aux0
     key_m = orc.to_mont(1, ck_host.reshape(-1, 4)).reshape(-1, 8)      # Montgomery bases, as the product keeps them
     z = list(z0)
     t0 = time.time()
-    run = None
-    for i in range(n_steps):
-        st, w, z = _oracle.witness_execute(orc, circuit, z, steps[i])
+    run, n = None, 0
+    while n < len(steps) and (n < 2 or time.time() - t0 < budget_s):
+        st, w, z = _oracle.witness_execute(orc, circuit, z, steps[n])
         bad, (a2, b2, c2) = _oracle.r1cs_check(orc, circuit, w, want_products=True, threads=threads)
         assert st == 0 and bad == -1
         _, cW = orc.msm_mont_timed(0, key_m, np.ascontiguousarray(w[aux0:]), threads)
+        n += 1
         if run is None:
             run = [w, a2, b2, c2, np.zeros_like(a2), 1]
             continue
@@ -65,17 +66,18 @@ def cpu_baseline(circuit, steps, z0, ck_host, n_steps, threads):
         run = [orc.axpy(0, run[0], r, w), orc.axpy(0, run[1], r, a2), orc.axpy(0, run[2], r, b2), orc.axpy(0, run[3], r, c2),
                orc.axpy(0, run[4], r, T), (run[5] + r) % orc.modulus[0]]
     dt = time.time() - t0
-    return n_steps / dt, dt
+    return n / dt, dt, n
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=96)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=256)
+    ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--transformation", default="contrast")
     ap.add_argument("--resolution", default="HD")
     ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -86,21 +88,30 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="gloo")      # timing barrier / max only: the data path has no collective
+        dist.init_process_group(backend="gloo")      # timing barrier / max / final gather only: the data path has no collective
     if torch.cuda.is_available():
         torch.cuda.set_device(local_rank)
 
-    from vimz_amd import folding, hip
+    from vimz_amd import _lib, folding, hip
+    from vimz_amd.distributed import segment_bounds
     ctx = hip.Context(local_rank)
     t_setup = time.time()
     circuit, params = folding.prepare_folding(ctx, args.transformation, args.resolution)
     steps_all, z0 = build_inputs(args.transformation, args.resolution)
     n_rows = steps_all.shape[0]
-    # each rank folds its own contiguous row segment (wrapping around the image when K exceeds the segment)
-    seg = n_rows // world
-    idx = [(rank * seg + (i % seg)) % n_rows for i in range(args.warmup + args.steps)]
-    mine = np.ascontiguousarray(steps_all[idx])
+    per_rank = args.warmup + args.steps
+    # global row list = concatenation of the ranks' segments; rank r folds rows [r*per_rank, (r+1)*per_rank) of it
+    # (image rows are reused cyclically when the list is longer than the image)
+    glob = [i % n_rows for i in range(world * per_rank)]
+    lo, hi = segment_bounds(world * per_rank, world)[rank]
+    mine = np.ascontiguousarray(steps_all[glob[lo:hi]])
     prover = hip.Prover(ctx, circuit, params.ck, max_batch=args.batch)
+    # IVC state at which this rank's segment starts (hash-only chain over the rows before it)
+    if lo:
+        zs = prover.state_chain(z0, steps_all[glob[:lo]])
+        z_start = [int(a[0]) | int(a[1]) << 64 | int(a[2]) << 128 | int(a[3]) << 192 for a in zs[-1]]
+    else:
+        z_start = list(z0)
     setup_s = time.time() - t_setup
 
     def sync_all():
@@ -110,44 +121,46 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    prover.reset(z0)
+    prover.reset(z_start)
     if args.warmup:
         prover.fold(mine[:args.warmup])
+    ctx.set_profiling(True)                # HIP events around every kernel of the MSM(T) launches on the context's stream
+    ctx.msm_profile_totals(reset=True)
     sync_all()
     t0 = time.time()
     prover.fold(mine[args.warmup:])
     sync_all()
     dt = time.time() - t0
+    tot = ctx.msm_profile_totals()
+    ctx.set_profiling(False)
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0])
-    ok = prover.verify() == 0
     prof = prover.profile()
 
-    # dominant kernel: bucket accumulation of MSM(T).  HIP-event timing on the library's own stream.
-    ctx.set_profiling(True)
-    rs = np.random.default_rng(1)
-    dense = rs.integers(0, 1 << 63, size=(circuit.n_constraints, 4), dtype=np.uint64)
-    dense[:, 3] &= np.uint64((1 << 60) - 1)
-    from vimz_amd import _lib
-    v = ctx.vec_from_host(_lib.FIELD_BN254_FR, dense)
-    acc_ms, tot_ms, reps = 0.0, 0.0, 5
-    for _ in range(reps):
-        ctx.msm_vec(params.ck, v, n=circuit.n_constraints)
-        p = ctx.msm_last_profile()
-        acc_ms += p["ms"]["accumulate"]; tot_ms += sum(p["ms"].values())
-    acc_ms /= reps; tot_ms /= reps
-    entries = p["entries"]
-    ctx.set_profiling(False)
-    v.free()
-    alg_bytes = 96.0 * circuit.n_constraints      # 32 B scalar + 64 B affine base per point
-    achieved = alg_bytes / (acc_ms * 1e-3) / 1e9
+    # host-side sequential final fold of the row segments (outside the timed region; reported separately)
+    t_ff = time.time()
+    if world > 1:
+        blob = prover.export()
+        gathered = [None] * world if rank == 0 else None
+        dist.gather_object(np.asarray(blob).tobytes(), gathered, dst=0)
+        if rank == 0:
+            for r in range(1, world):
+                prover.merge(np.frombuffer(gathered[r], dtype=np.uint8))
+    final_fold_s = time.time() - t_ff
+    ok = (prover.verify() == 0) if rank == 0 else True
+    inst = prover.instance()
 
-    out = None
     if rank == 0:
         nnz = circuit.nnz_a + circuit.nnz_b + circuit.nnz_c
         n_w, n_c = circuit.n_wires, circuit.n_constraints
+        calls = max(1, tot["calls"])
+        acc_ms = tot["ms"]["accumulate"] / calls                   # mean k_accum duration of the MSM(T) launches in the timed region
+        msm_ms = sum(tot["ms"].values()) / calls
+        alg_bytes = 96.0 * n_c                                     # 32 B scalar + 64 B affine base per point
+        achieved = alg_bytes / (acc_ms * 1e-3) / 1e9 if acc_ms else 0.0
+        adds = tot["entries"] / calls
         step_bytes = 96 * n_w + 96 * n_c + 8 * nnz + 32 * n_w + 96 * n_c + 7 * 32 * n_c + 3 * 32 * n_w + 12 * 32 * n_c
         out = {
             "metric": "nova_folding_steps_per_sec",
@@ -160,27 +173,29 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u32x8 (256-bit Montgomery integers over BN254 Fr/Fq)",
+            "dtype": "u32 limbs (256-bit Montgomery integers over BN254 Fr/Fq)",
             "data": "synthetic: rows of the reference sample image img2.png, contrast factor 1.4" + ("" if args.resolution == "HD" else f", upscaled to {args.resolution}"),
             "config": {"workload": f"{args.transformation}_step_{args.resolution}", "constraints": n_c, "wires": n_w, "nnz": nnz,
-                       "rows_per_rank": args.steps, "witness_batch": args.batch, "parallelism": f"{world} independent row segments"},
+                       "rows_per_rank": args.steps, "witness_batch": args.batch, "parallelism": f"{world} independent row segments + host final fold"},
             "verified": bool(ok),
-            "end_to_end_estimate_s": {"keygen_and_setup": setup_s, "fold_720_steps": 720 * dt / args.steps},
+            "folded_steps_total": inst["steps"],
+            "final_fold_s": final_fold_s if world > 1 else 0.0,
+            "end_to_end_estimate_s": {"keygen_and_setup": setup_s, "fold_720_steps_one_gpu": 720 * dt / args.steps},
             "published_reference": {"contrast_HD_steps_per_s_cpu_server": 1.94, "source": "README.md:52 (720 steps / 371.7 s)"},
             "phase_ms_per_step": {k: 1e3 * v["seconds"] / max(1, (args.steps + args.warmup)) for k, v in prof.items()},
-            "roofline": {"bound": "hbm", "kernel": "k_accum (bucket accumulation of MSM(T))", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                         "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": acc_ms, "msm_total_ms": tot_ms,
-                         "mixed_adds_per_launch": entries, "int_utilisation": entries / (acc_ms * 1e-3) / 1e9 / MIXED_ADD_PEAK_GOPS,
-                         "step_algorithmic_bytes": step_bytes},
+            "roofline": {"bound": "hbm", "kernel": "k_accum (bucket accumulation) of the MSM(T) launches in the timed region", "achieved": achieved,
+                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": acc_ms, "launches": tot["calls"], "msm_gpu_ms": msm_ms,
+                         "mixed_adds_per_launch": adds,
+                         "int_utilisation": (adds / (acc_ms * 1e-3) / 1e9 / MIXED_ADD_PEAK_GOPS) if acc_ms else 0.0,
+                         "step_algorithmic_bytes": step_bytes, "step_hbm_frac": step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBPS},
         }
         if not args.no_cpu_baseline:
             cores = os.cpu_count() or 1
-            n_cpu = 24
             ck_host = params.ck.download(0, max(n_c, n_w))
-            sps, secs = cpu_baseline(circuit, mine, z0, ck_host, n_cpu, cores)
+            sps, secs, n_cpu = cpu_baseline(circuit, mine, z_start, ck_host, args.cpu_seconds, cores)
             out["cpu_baseline"] = {"value": sps, "unit": "steps/s", "cores": cores, "kind": "port",
-                                   "sample": f"{n_cpu} folding steps of the same workload with the CPU oracle (C++ restatement, not the Rust binary), {secs:.1f} s"}
+                                   "sample": f"{n_cpu} folding steps of the same workload with the CPU oracle (C++ restatement, std::thread over all cores; not the Rust binary), {secs:.1f} s"}
         print(json.dumps(out), flush=True)
     prover.close()
     params.ck.free()

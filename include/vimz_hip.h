@@ -72,6 +72,9 @@ int vimz_timer_stop(vimz_ctx* ctx, float* ms_out);
 int vimz_set_profiling(vimz_ctx* ctx, int enabled);
 /* ms[6] = {hist, scan, scatter, accumulate, combine, reduce}; info[4] = {window bits, windows, sub-buckets, entries} */
 int vimz_msm_last_profile(vimz_ctx* ctx, float ms[6], uint32_t info[4]);
+/* sums over every profiled MSM issued on the context's stream since the last reset (the MSM(T) launches of a fold):
+ * ms[6] as above; counts[3] = {MSM calls, points, bucket entries (= mixed additions)} */
+int vimz_msm_profile_totals(vimz_ctx* ctx, double ms[6], uint64_t counts[3], int reset);
 
 /* ---- commitment key (replaces the `ck: Vec<G::PreprocessedGroupElement>` of nova-snark's
  *      CommitmentKey, built by PublicParams::setup reached from folding.rs:23) ------------------------- */
@@ -164,6 +167,14 @@ int vimz_prover_fold(vimz_prover* p, const uint64_t* step_inputs, size_t nsteps)
 int vimz_prover_verify(vimz_prover* p, uint32_t* result);
 int vimz_prover_instance(vimz_prover* p, uint64_t comm_W[8], uint64_t comm_E[8], uint64_t u[4], uint64_t* z_current, uint64_t* steps);
 int vimz_prover_running(vimz_prover* p, uint64_t* z_run, uint64_t* E);
+/* IVC state chain only: zs_out = (nsteps+1) x len_z canonical elements starting at z_start (one hash-only GPU pass over the
+ * rows + the host pair-hash chain).  Lets a multi-GPU driver find the state at which each row segment starts. */
+int vimz_prover_state_chain(vimz_prover* p, const uint64_t* z_start, const uint64_t* step_inputs, size_t nsteps, uint64_t* zs_out);
+/* Host-side final fold of row segments folded on different GPUs (north_star: "host-side sequential final fold"):
+ * export one prover's running relaxed instance as a byte blob, merge it into another's (NIFS for two relaxed instances). */
+size_t vimz_prover_export_size(const vimz_prover* p);
+int vimz_prover_export(vimz_prover* p, uint8_t* blob, size_t cap);
+int vimz_prover_merge(vimz_prover* p, const uint8_t* blob, size_t len);
 /* seconds[9]/counts[9]: witness, state chain (host), spmv, msm(W), cross term, msm(T), RO (host), fold, host EC */
 int vimz_prover_profile(const vimz_prover* p, double seconds[9], uint64_t counts[9]);
 /* parity hooks: GPU witness generation alone (replaces the circom witness generator process) and

@@ -192,3 +192,46 @@ def test_hash_circuit_fold_recomputed_by_oracle(ctx, ck, oracle, circuits):
     assert tuple(from_limbs(inst["comm_W"])) == cW
     assert tuple(from_limbs(inst["comm_E"])) == cE
     assert oracle.first_unsat(0, AZ, BZ, CZ, u=u, E=E) == -1
+
+
+def test_segment_merge_matches_oracle_prover(ctx, ck, oracle, circuits):
+    """Multi-GPU final fold on one GPU: two row segments folded by two provers, exported, merged (relaxed+relaxed NIFS);
+    the merged accumulator verifies and equals the oracle-backed prover's bit for bit."""
+    from tests._oracle_prover import OracleProver
+    from vimz_amd import hip
+    from vimz_amd.distributed import fold_sharded
+    c = circuits["hash"]
+    z0, inputs = step_inputs("hash")
+    rows = np.stack(inputs[:5])
+    A, B = hip.Prover(ctx, c, ck, max_batch=2), hip.Prover(ctx, c, ck, max_batch=2)
+    try:
+        zs = A.state_chain(z0, rows[:3])
+        z_mid = from_limbs(zs[-1])
+        A.reset(z0); A.fold(rows[:3])
+        B.reset(z_mid); B.fold(rows[3:])
+        assert A.verify() == 0 and B.verify() == 0
+        A.merge(B.export())
+        assert A.verify() == 0
+        inst = A.instance()
+        z_run, E_run = A.running()
+    finally:
+        A.close(); B.close()
+    n_aux = c.n_wires - 1 - 2 * c.len_z
+    key = ck.download(0, max(n_aux, c.n_constraints))
+    oa, ob = OracleProver(oracle, c, key), OracleProver(oracle, c, key)
+    oa.reset(z0); oa.fold(rows[:3])
+    assert oa.z == z_mid
+    ob.reset(z_mid); ob.fold(rows[3:])
+    oa.merge(ob.export())
+    assert oa.verify() == 0
+    assert inst["steps"] == 5 and from_limbs(inst["z"]) == oa.z
+    assert from_limbs(inst["u"])[0] == oa.u
+    assert tuple(from_limbs(inst["comm_W"])) == oa.cW and tuple(from_limbs(inst["comm_E"])) == oa.cE
+    assert np.array_equal(z_run, oa.Z) and np.array_equal(E_run, oa.E)
+    # and the single-process driver path
+    P = hip.Prover(ctx, c, ck, max_batch=4)
+    try:
+        res = fold_sharded(P, rows, z0)
+        assert res["verified"] and res["steps"] == 5
+    finally:
+        P.close()

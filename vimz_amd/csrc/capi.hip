@@ -85,6 +85,10 @@ int vz_msm_device(vimz_ctx* c, const vimz_bases* bases, size_t base_offset, cons
     hipError_t e = msm_run<C>(c->stream, c->msm_ws, bases->d + (size_t)AFFINE_WORDS * base_offset, d_scalars, n, scalars_mont, window_bits, &r,
                               &c->last_msm, c->profiling ? c->ev : nullptr);
     if (e != hipSuccess) return vz_fail(c, VIMZ_ERR_HIP, "msm", e);
+    if (c->profiling && n) {
+      for (int i = 0; i < 6; i++) c->msm_tot_ms[i] += c->last_msm.ms[i];
+      c->msm_tot_calls++; c->msm_tot_points += n; c->msm_tot_entries += c->last_msm.entries;
+    }
     if (out_form == VIMZ_FORM_CANONICAL) { r.x = F::from_mont(r.x); r.y = F::from_mont(r.y); }
     memcpy(out_xy, r.x.v, 32); memcpy(out_xy + 4, r.y.v, 32);
     return VIMZ_OK;
@@ -175,6 +179,15 @@ int vimz_msm_last_profile(vimz_ctx* c, float ms[6], uint32_t info[4]) {
   if (!c) return VIMZ_ERR_INVALID;
   if (ms) memcpy(ms, c->last_msm.ms, sizeof(float) * 6);
   if (info) { info[0] = c->last_msm.c; info[1] = c->last_msm.K; info[2] = c->last_msm.subs; info[3] = c->last_msm.entries; }
+  return VIMZ_OK;
+}
+
+int vimz_msm_profile_totals(vimz_ctx* c, double ms[6], uint64_t counts[3], int reset) {
+  if (!c) return VIMZ_ERR_INVALID;
+  std::lock_guard<std::mutex> g(c->mu);
+  if (ms) memcpy(ms, c->msm_tot_ms, sizeof(double) * 6);
+  if (counts) { counts[0] = c->msm_tot_calls; counts[1] = c->msm_tot_points; counts[2] = c->msm_tot_entries; }
+  if (reset) { memset(c->msm_tot_ms, 0, sizeof(c->msm_tot_ms)); c->msm_tot_calls = c->msm_tot_points = c->msm_tot_entries = 0; }
   return VIMZ_OK;
 }
 

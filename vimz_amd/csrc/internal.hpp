@@ -15,6 +15,8 @@ struct vimz_ctx {
   bool profiling = false;
   vz::MsmWorkspace msm_ws;
   vz::MsmStats last_msm = {};
+  double msm_tot_ms[6] = {};            // sums over every profiled MSM since the last reset
+  uint64_t msm_tot_calls = 0, msm_tot_points = 0, msm_tot_entries = 0;
   std::mutex mu;
   std::string err;
   void* scratch = nullptr;  // device staging for host-scalar MSM / probes

@@ -572,6 +572,139 @@ int vimz_prover_fold(vimz_prover* p, const uint64_t* step_inputs, size_t nsteps)
   return VIMZ_OK;
 }
 
+// IVC state chain only (no folding): zs_out[(nsteps+1) x len_z] canonical, starting from z_start.  One hash-only GPU pass
+// over the rows + the host pair-hash chain.  A multi-GPU driver uses it to find the state at which a row segment starts.
+int vimz_prover_state_chain(vimz_prover* p, const uint64_t* z_start, const uint64_t* step_inputs, size_t nsteps, uint64_t* zs_out) {
+  if (!p || !z_start || !zs_out || (!step_inputs && nsteps)) return VIMZ_ERR_INVALID;
+  vimz_ctx* ctx = p->ctx;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  P_TRY(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  const cb::Builder& b = p->circuit->build->b;
+  const size_t jstride = p->n_jobs + p->n_fops;
+  uint32_t nA = 0; for (auto& c : b.chains) if (c.phase == 0) nA++;
+  std::vector<Fe> zs((nsteps + 1) * p->len_z, Fe::zero());
+  for (uint32_t i = 0; i < p->len_z; i++) zs[i] = fe_from_canon(z_start + 4 * i);
+  if (nsteps) {
+    P_TRY(grow(&p->priv_all_d, &p->cap_priv_all, 32 * nsteps * (size_t)p->n_priv));
+    P_TRY(grow(&p->job_all_d, &p->cap_job_all, 32 * nsteps * jstride));
+    P_TRY(hipMemcpyAsync(p->priv_all_d, step_inputs, 32 * nsteps * (size_t)p->n_priv, hipMemcpyHostToDevice, s));
+    P_TRY(hipMemsetAsync(p->job_all_d, 0, 32 * nsteps * jstride, s));
+    for (size_t off = 0; off < nsteps && nA; off += 32768) {
+      const unsigned rows = (unsigned)std::min<size_t>(32768, nsteps - off);
+      hipLaunchKernelGGL(k_wit_chains, dim3((nA + 3) / 4, rows), dim3(64), 0, s, p->wd, 0u, (uint32_t*)nullptr, p->job_all_d + 8 * off * jstride,
+                         (const uint32_t*)(p->priv_all_d + 8 * off * p->n_priv));
+    }
+    P_TRY(hipGetLastError());
+    std::vector<Fe> jobA(nsteps * jstride);
+    P_TRY(hipMemcpyAsync(jobA.data(), p->job_all_d, 32 * nsteps * jstride, hipMemcpyDeviceToHost, s));
+    P_TRY(hipStreamSynchronize(s));
+    host_state_chain(p, step_inputs, nsteps, jobA.data(), jstride, zs);
+  }
+  for (size_t i = 0; i < zs.size(); i++) fe_to_canon(zs[i], zs_out + 4 * i);
+  return VIMZ_OK;
+}
+
+// ---- export / merge of running instances: the host-side final fold of row segments folded on different GPUs ----------
+// Blob: header (8 x u64) | u | comm_W | comm_E | ro | zdigest | z_cur | z0 | Zrun | E | AZ | BZ | CZ   (Montgomery limbs)
+struct BlobHeader { uint64_t magic, n_wires, n_c, len_z, steps, transformation, width, reserved; };
+static const uint64_t BLOB_MAGIC = 0x315a4d4956ull;  // "VIMZ1"
+
+size_t vimz_prover_export_size(const vimz_prover* p) {
+  if (!p) return 0;
+  return sizeof(BlobHeader) + 32 + 64 + 64 + 32 + 32 + 64 * (size_t)p->len_z + 32 * ((size_t)p->n_wires + 4 * (size_t)p->n_c);
+}
+
+int vimz_prover_export(vimz_prover* p, uint8_t* blob, size_t cap) {
+  if (!p || !blob || cap < vimz_prover_export_size(p)) return vz_fail(p ? p->ctx : nullptr, VIMZ_ERR_INVALID, "vimz_prover_export: buffer too small");
+  vimz_ctx* ctx = p->ctx;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  P_TRY(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  BlobHeader h{BLOB_MAGIC, p->n_wires, p->n_c, p->len_z, p->steps, (uint64_t)p->circuit->transformation, (uint64_t)p->circuit->shape.width, 0};
+  uint8_t* o = blob;
+  memcpy(o, &h, sizeof(h)); o += sizeof(h);
+  memcpy(o, p->u.v, 32); o += 32;
+  memcpy(o, &p->comm_W, 64); o += 64; memcpy(o, &p->comm_E, 64); o += 64;
+  memcpy(o, p->ro.v, 32); o += 32; memcpy(o, p->zdigest.v, 32); o += 32;
+  memcpy(o, p->z_cur.data(), 32 * p->len_z); o += 32 * p->len_z;
+  memcpy(o, p->z0.data(), 32 * p->len_z); o += 32 * p->len_z;
+  const uint32_t* src[5] = {p->Zrun, p->E, p->AZ, p->BZ, p->CZ};
+  const size_t len[5] = {p->n_wires, p->n_c, p->n_c, p->n_c, p->n_c};
+  for (int k = 0; k < 5; k++) { P_TRY(hipMemcpyAsync(o, src[k], 32 * len[k], hipMemcpyDeviceToHost, s)); o += 32 * len[k]; }
+  P_TRY(hipStreamSynchronize(s));
+  return VIMZ_OK;
+}
+
+// Fold the exported relaxed instance (U2, W2) into this prover's running instance (U1, W1) — Nova's NIFS for two relaxed
+// instances:  T = Az1∘Bz2 + Az2∘Bz1 − u1·Cz2 − u2·Cz1,  E = E1 + r·T + r²·E2,  W = W1 + r·W2,  u = u1 + r·u2,
+// comm_W = comm_W1 + r·comm_W2,  comm_E = comm_E1 + r·comm_T + r²·comm_E2,  r = Poseidon(ro1, ro2, comm_T) mod 2^128.
+int vimz_prover_merge(vimz_prover* p, const uint8_t* blob, size_t len) {
+  if (!p || !blob || len < sizeof(BlobHeader)) return VIMZ_ERR_INVALID;
+  vimz_ctx* ctx = p->ctx;
+  BlobHeader h; memcpy(&h, blob, sizeof(h));
+  if (h.magic != BLOB_MAGIC || h.n_wires != p->n_wires || h.n_c != p->n_c || h.len_z != p->len_z || len < vimz_prover_export_size(p))
+    return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_prover_merge: blob does not match this prover's circuit");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  P_TRY(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  const size_t nw = p->n_wires, nc = p->n_c;
+  const uint8_t* o = blob + sizeof(h);
+  Fe u2; memcpy(u2.v, o, 32); o += 32;
+  G1Aff cW2, cE2; memcpy(&cW2, o, 64); o += 64; memcpy(&cE2, o, 64); o += 64;
+  Fe ro2, zd2; memcpy(ro2.v, o, 32); o += 32; memcpy(zd2.v, o, 32); o += 32;
+  std::vector<Fe> zcur2(p->len_z), z02(p->len_z);
+  memcpy(zcur2.data(), o, 32 * p->len_z); o += 32 * p->len_z; memcpy(z02.data(), o, 32 * p->len_z); o += 32 * p->len_z;
+  if (h.steps == 0) return VIMZ_OK;   // nothing to fold in
+  // stage the other instance's vectors in the (idle) batch buffer 0: Z | E | AZ | BZ | CZ
+  auto& bb = p->buf[0];
+  if (p->max_batch * nw < nw || false) return VIMZ_ERR_INVALID;
+  uint32_t *Z2 = bb.Z, *E2 = p->az2, *AZ2 = bb.az, *BZ2 = bb.bz, *CZ2 = bb.cz;
+  P_TRY(hipMemcpyAsync(Z2, o, 32 * nw, hipMemcpyHostToDevice, s)); o += 32 * nw;
+  P_TRY(hipMemcpyAsync(E2, o, 32 * nc, hipMemcpyHostToDevice, s)); o += 32 * nc;
+  P_TRY(hipMemcpyAsync(AZ2, o, 32 * nc, hipMemcpyHostToDevice, s)); o += 32 * nc;
+  P_TRY(hipMemcpyAsync(BZ2, o, 32 * nc, hipMemcpyHostToDevice, s)); o += 32 * nc;
+  P_TRY(hipMemcpyAsync(CZ2, o, 32 * nc, hipMemcpyHostToDevice, s)); o += 32 * nc;
+  if (p->steps == 0) {   // this prover is empty: adopt the other instance
+    P_TRY(hipMemcpyAsync(p->Zrun, Z2, 32 * nw, hipMemcpyDeviceToDevice, s)); P_TRY(hipMemcpyAsync(p->E, E2, 32 * nc, hipMemcpyDeviceToDevice, s));
+    P_TRY(hipMemcpyAsync(p->AZ, AZ2, 32 * nc, hipMemcpyDeviceToDevice, s)); P_TRY(hipMemcpyAsync(p->BZ, BZ2, 32 * nc, hipMemcpyDeviceToDevice, s));
+    P_TRY(hipMemcpyAsync(p->CZ, CZ2, 32 * nc, hipMemcpyDeviceToDevice, s)); P_TRY(hipStreamSynchronize(s));
+    p->u = u2; p->comm_W = cW2; p->comm_E = cE2; p->ro = ro2; p->zdigest = zd2; p->z_cur = zcur2; p->z0 = z02; p->steps = h.steps;
+    return VIMZ_OK;
+  }
+  hipLaunchKernelGGL(k_cross_term<Fr>, dim3(stream_grid(nc)), dim3(256), 0, s, nc, p->AZ, p->BZ, p->CZ, p->u, AZ2, BZ2, CZ2, u2, p->T);
+  P_TRY(hipGetLastError());
+  uint64_t pt[8];
+  int rc = vz_msm_device(ctx, p->ck, 0, p->T, nc, 1, 0, pt, VIMZ_FORM_MONTGOMERY);
+  if (rc) return rc;
+  G1Aff cT; memcpy(cT.x.v, pt, 32); memcpy(cT.y.v, pt + 4, 32);
+  Fe ab[4]; Fe a2[2]; ro_absorb_point(cT, a2);
+  ab[0] = p->ro; ab[1] = ro2; ab[2] = a2[0]; ab[3] = a2[1];
+  p->ro = cb::poseidon_hash(ab, 4);
+  { Fe zz[2] = {p->zdigest, zd2}; p->zdigest = cb::poseidon_hash(zz, 2); }
+  Fe rc_canon = Fe::from_mont(p->ro);
+  Fe r128 = Fe::zero(); for (int i = 0; i < 4; i++) r128.v[i] = rc_canon.v[i];
+  const Fe rm = Fe::to_mont(r128), rm2 = Fe::sqr(rm);
+  Fold5 f;
+  f.x1[0] = p->Zrun; f.x2[0] = Z2; f.n[0] = nw;
+  f.x1[1] = p->E; f.x2[1] = p->T; f.n[1] = nc;
+  f.x1[2] = p->AZ; f.x2[2] = AZ2; f.n[2] = nc;
+  f.x1[3] = p->BZ; f.x2[3] = BZ2; f.n[3] = nc;
+  f.x1[4] = p->CZ; f.x2[4] = CZ2; f.n[4] = nc;
+  hipLaunchKernelGGL(k_fold5<Fr>, dim3(2048), dim3(256), 0, s, f, rm);
+  hipLaunchKernelGGL(k_axpy_inplace<Fr>, dim3(stream_grid(nc)), dim3(256), 0, s, nc, p->E, rm2, (const uint32_t*)E2);
+  P_TRY(hipGetLastError());
+  Fe r2c = Fe::from_mont(rm2);   // r^2 as a canonical 256-bit scalar
+  G1 a = from_affine(p->comm_W); G1 t1 = scalar_mul(cW2, r128.v, 128); add_full(a, t1); p->comm_W = to_affine(a);
+  G1 e = from_affine(p->comm_E); G1 t2 = scalar_mul(cT, r128.v, 128); add_full(e, t2);
+  G1 t3 = scalar_mul(cE2, r2c.v, 256); add_full(e, t3); p->comm_E = to_affine(e);
+  p->u = Fe::add(p->u, Fe::mul(rm, u2));
+  p->steps += h.steps;
+  p->z_cur = zcur2;     // segments are merged in row order: the merged chain ends where the later segment ends
+  P_TRY(hipStreamSynchronize(s));
+  return VIMZ_OK;
+}
+
 // Running instance: comm_W, comm_E (affine canonical), u, X = (z_i, z_0 ...) — here X is read back from Zrun.
 int vimz_prover_instance(vimz_prover* p, uint64_t comm_W[8], uint64_t comm_E[8], uint64_t u[4], uint64_t* z_current, uint64_t* steps) {
   if (!p) return VIMZ_ERR_INVALID;

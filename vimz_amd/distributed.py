@@ -1,0 +1,46 @@
+"""Row-segment sharding of one fold over the GPUs of a node (BASELINE.json north_star: "independent row-folds shard
+embarrassingly across the 8 GPUs ... host-side sequential final fold; no RCCL collectives needed").
+
+One process per GPU.  Every rank folds a contiguous segment of rows into its own running instance; the only exchange
+is the gather of the G exported instances on rank 0, which merges them in row order (relaxed+relaxed NIFS) and verifies.
+The prover object is duck-typed (reset / fold / state_chain / export / merge / verify) so the same driver runs over the
+GPU prover (vimz_amd.hip.Prover) and, in the CPU tests, over an oracle-backed stand-in.
+"""
+import numpy as np
+
+
+def segment_bounds(n_steps, world):
+    """Contiguous row segments, sizes differing by at most one (earlier ranks take the remainder)."""
+    base, rem = divmod(n_steps, world)
+    bounds, start = [], 0
+    for r in range(world):
+        size = base + (1 if r < rem else 0)
+        bounds.append((start, start + size))
+        start += size
+    return bounds
+
+
+def fold_sharded(prover, step_inputs, z0, rank=0, world=1, dist=None, verify=True):
+    """Fold `step_inputs` (n, n_priv, 4) starting from IVC state z0 across `world` ranks.
+    Returns on rank 0: dict(steps, z_final, verified); on other ranks: None."""
+    n = len(step_inputs)
+    lo, hi = segment_bounds(n, world)[rank]
+    # state at which this rank's segment starts: hash-only chain over the rows before it (cheap; no folding)
+    if lo > 0:
+        zs = prover.state_chain(z0, step_inputs[:lo])
+        z_start = [int(a[0]) | int(a[1]) << 64 | int(a[2]) << 128 | int(a[3]) << 192 for a in np.asarray(zs)[-1]]
+    else:
+        z_start = list(z0)
+    prover.reset(z_start)
+    if hi > lo:
+        prover.fold(step_inputs[lo:hi])
+    if world == 1:
+        return {"steps": hi - lo, "verified": (prover.verify() == 0) if verify else None}
+    blob = prover.export()
+    gathered = [None] * world if rank == 0 else None
+    dist.gather_object(np.asarray(blob).tobytes(), gathered, dst=0)
+    if rank != 0:
+        return None
+    for r in range(1, world):          # host-side sequential final fold, in row order
+        prover.merge(np.frombuffer(gathered[r], dtype=np.uint8))
+    return {"steps": n, "verified": (prover.verify() == 0) if verify else None}

@@ -106,6 +106,14 @@ class Context:
         names = ["hist", "scan", "scatter", "accumulate", "combine", "reduce"]
         return {"ms": dict(zip(names, list(ms))), "window_bits": info[0], "windows": info[1], "sub_buckets": info[2], "entries": info[3]}
 
+    def msm_profile_totals(self, reset=False):
+        self.lib.vimz_msm_profile_totals.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]
+        ms = (C.c_double * 6)()
+        cnt = (C.c_uint64 * 3)()
+        self._chk(self.lib.vimz_msm_profile_totals(self.h, ms, cnt, 1 if reset else 0))
+        names = ["hist", "scan", "scatter", "accumulate", "combine", "reduce"]
+        return {"ms": dict(zip(names, list(ms))), "calls": int(cnt[0]), "points": int(cnt[1]), "entries": int(cnt[2])}
+
     # ---- commitment key / vectors
     def bases_upload(self, curve, xy, form=L.FORM_CANONICAL):
         xy = _u64(xy)
@@ -240,3 +248,33 @@ class Prover:
         out = [np.zeros((n, 4), dtype=np.uint64) for _ in range(3)]
         self.ctx._chk(self.ctx.lib.vimz_prover_spmv(self.h, _ptr(z), *[_ptr(o) for o in out]))
         return out
+
+    # ---- multi-GPU support: state chain, export / merge of running instances
+    def state_chain(self, z_start, inputs):
+        a = _u64(inputs).reshape(-1, self.circuit.n_priv, 4)
+        n = a.shape[0]
+        z = np.zeros((self.circuit.len_z, 4), dtype=np.uint64)
+        for i, v in enumerate(z_start):
+            for k in range(4):
+                z[i, k] = (int(v) >> (64 * k)) & 0xFFFFFFFFFFFFFFFF
+        out = np.zeros((n + 1, self.circuit.len_z, 4), dtype=np.uint64)
+        lib = self.ctx.lib
+        lib.vimz_prover_state_chain.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        self.ctx._chk(lib.vimz_prover_state_chain(self.h, _ptr(z), _ptr(a), n, _ptr(out)))
+        return out
+
+    def export(self):
+        lib = self.ctx.lib
+        lib.vimz_prover_export_size.argtypes = [C.c_void_p]
+        lib.vimz_prover_export_size.restype = C.c_size_t
+        lib.vimz_prover_export.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        n = lib.vimz_prover_export_size(self.h)
+        buf = np.zeros(n, dtype=np.uint8)
+        self.ctx._chk(lib.vimz_prover_export(self.h, _ptr(buf), n))
+        return buf
+
+    def merge(self, blob):
+        lib = self.ctx.lib
+        lib.vimz_prover_merge.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        self.ctx._chk(lib.vimz_prover_merge(self.h, _ptr(blob), blob.size))
