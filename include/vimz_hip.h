@@ -102,6 +102,12 @@ int vimz_msm(vimz_ctx* ctx, const vimz_bases* bases, const uint64_t* scalars, si
 int vimz_msm_vec(vimz_ctx* ctx, const vimz_bases* bases, size_t base_offset, const vimz_vec* v, size_t offset,
                  size_t n, int window_bits, uint64_t out_xy[8], int out_form);
 
+/* flags: VIMZ_MSM_SPLIT_ONES sums the bases of unit scalars with a dedicated tree kernel instead of the bucket sort
+ * (witness vectors are ~80 % bits); the result is identical. */
+#define VIMZ_MSM_SPLIT_ONES 1
+int vimz_msm_vec_ex(vimz_ctx* ctx, const vimz_bases* bases, size_t base_offset, const vimz_vec* v, size_t offset,
+                    size_t n, int window_bits, int flags, uint64_t out_xy[8], int out_form);
+
 /* ---- step circuits: R1CS shape + witness program (replaces the `.r1cs` that nova_scotia::circom::reader::load_r1cs
  *      reads at vimz/src/nova_snark_backend/folding.rs:22 and the circom witness generator named by
  *      Config::witness_generator_file(), folding.rs:36).  Host-only: usable without a GPU. -------------------- */

@@ -150,6 +150,27 @@ def test_msm_witness_like_scalars(ctx, oracle):
     _msm_case(ctx, oracle, 0, n, sc)
 
 
+def test_msm_split_ones_path(ctx, oracle):
+    """Unit scalars summed by the dedicated tree kernel: same result as the oracle, for witness-like and edge inputs."""
+    from vimz_amd import _lib
+    r = MODULI[0]
+    rng = random.Random(17)
+    for n, mk in ((1, lambda: 1), (64, lambda: 1), (40000, lambda: rng.choice([0, 1, 1, 1, rng.randrange(256), rng.randrange(r)])), (3000, lambda: 0)):
+        sc = [mk() for _ in range(n)]
+        bases = oracle.seq_bases(0, n)
+        if n == 64:
+            bases[::2] = to_limbs(GENERATORS[0]).reshape(1, 8)       # repeated bases: doubling inside the ones tree
+            bases[1::2] = to_limbs(oracle.curve_mul(0, GENERATORS[0], r - 1)).reshape(1, 8)   # and cancellation
+        want = oracle.msm(0, bases, to_limbs(sc), threads=8)
+        B = ctx.bases_upload(0, bases)
+        v = ctx.vec_from_host(_lib.FIELD_BN254_FR, to_limbs(sc))
+        try:
+            assert tuple(from_limbs(ctx.msm_vec(B, v, split_ones=True))) == want
+            assert tuple(from_limbs(ctx.msm_vec(B, v, split_ones=False))) == want
+        finally:
+            v.free(); B.free()
+
+
 def test_msm_montgomery_scalars_and_resident_vectors(ctx, oracle):
     from vimz_amd import _lib
     r = MODULI[0]

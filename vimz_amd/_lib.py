@@ -65,6 +65,7 @@ def lib():
         L.vimz_vec_free.restype = None
         L.vimz_msm.argtypes = [vp, vp, u64p, sz, i, i, u64p, i]
         L.vimz_msm_vec.argtypes = [vp, vp, sz, vp, sz, sz, i, u64p, i]
+        L.vimz_msm_vec_ex.argtypes = [vp, vp, sz, vp, sz, sz, i, i, u64p, i]
         L.vimz_field_op.argtypes = [vp, i, i, u64p, u64p, u64p, sz]
         L.vimz_curve_add.argtypes = [vp, i, u64p, u64p, u64p, sz]
         _lib = L

@@ -77,13 +77,13 @@ static int curve_scalar_field(int curve) {
 
 namespace vz {
 int vz_msm_device(vimz_ctx* c, const vimz_bases* bases, size_t base_offset, const uint32_t* d_scalars, size_t n,
-                      int scalars_mont, int window_bits, uint64_t out_xy[8], int out_form) {
+                      int scalars_mont, int window_bits, uint64_t out_xy[8], int out_form, int split_ones) {
   return curve_dispatch(bases->curve, [&](auto cv) {
     typedef decltype(cv) C;
     typedef typename C::Base F;
     Affine<F> r;
     hipError_t e = msm_run<C>(c->stream, c->msm_ws, bases->d + (size_t)AFFINE_WORDS * base_offset, d_scalars, n, scalars_mont, window_bits, &r,
-                              &c->last_msm, c->profiling ? c->ev : nullptr);
+                              &c->last_msm, c->profiling ? c->ev : nullptr, split_ones);
     if (e != hipSuccess) return vz_fail(c, VIMZ_ERR_HIP, "msm", e);
     if (c->profiling && n) {
       for (int i = 0; i < 6; i++) c->msm_tot_ms[i] += c->last_msm.ms[i];
@@ -321,6 +321,16 @@ int vimz_msm_vec(vimz_ctx* c, const vimz_bases* bases, size_t base_offset, const
   std::lock_guard<std::mutex> g(c->mu);
   HIP_TRY(c, hipSetDevice(c->device));
   return msm_device(c, bases, base_offset, v->d + 8 * offset, n, 1, window_bits, out_xy, out_form);
+}
+
+int vimz_msm_vec_ex(vimz_ctx* c, const vimz_bases* bases, size_t base_offset, const vimz_vec* v, size_t offset, size_t n,
+                    int window_bits, int flags, uint64_t out_xy[8], int out_form) {
+  if (!c || !bases || !v || !out_xy || offset + n > v->n || base_offset + n > bases->n)
+    return fail(c, VIMZ_ERR_INVALID, "vimz_msm_vec_ex: bad argument");
+  if (v->field != curve_scalar_field(bases->curve)) return fail(c, VIMZ_ERR_INVALID, "vimz_msm_vec_ex: vector is not over the curve's scalar field");
+  std::lock_guard<std::mutex> g(c->mu);
+  HIP_TRY(c, hipSetDevice(c->device));
+  return vz::vz_msm_device(c, bases, base_offset, v->d + 8 * offset, n, 1, window_bits, out_xy, out_form, (flags & VIMZ_MSM_SPLIT_ONES) ? 1 : 0);
 }
 
 // ---- probes ------------------------------------------------------------------------------------------

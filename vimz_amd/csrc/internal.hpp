@@ -31,5 +31,5 @@ int vz_fail(vimz_ctx* c, int code, const char* what, hipError_t e = hipSuccess);
 int vz_ensure_scratch(vimz_ctx* c, size_t bytes);
 // MSM over device-resident scalars on the context's stream (caller holds c->mu and has set the device)
 int vz_msm_device(vimz_ctx* c, const vimz_bases* bases, size_t base_offset, const uint32_t* d_scalars, size_t n,
-                  int scalars_mont, int window_bits, uint64_t out_xy[8], int out_form);
+                  int scalars_mont, int window_bits, uint64_t out_xy[8], int out_form, int split_ones = 0);
 }

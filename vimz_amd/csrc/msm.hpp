@@ -32,15 +32,24 @@ __device__ __forceinline__ uint32_t window_bits(const uint32_t* s, int lo, int c
   return (uint32_t)(v >> off) & ((1u << c) - 1);
 }
 
+// returns false when the scalar is to be skipped (zero, or the unit when `skip_ones`: units are summed by k_ones_partial)
 template <class S>
-__device__ __forceinline__ void load_scalar(const uint32_t* __restrict__ scalars, size_t i, int mont, uint32_t* s) {
+__device__ __forceinline__ bool load_scalar(const uint32_t* __restrict__ scalars, size_t i, int mont, int skip_ones, uint32_t* s) {
   const uint4* p = reinterpret_cast<const uint4*>(scalars + 8 * i);
   uint4 a = p[0], b = p[1];
   S x;
   x.v[0] = a.x; x.v[1] = a.y; x.v[2] = a.z; x.v[3] = a.w; x.v[4] = b.x; x.v[5] = b.y; x.v[6] = b.z; x.v[7] = b.w;
+  if (x.is_zero()) return false;
+  if (skip_ones) {
+    bool one;
+    if (mont) one = x.eq(S::one());
+    else { uint32_t o = x.v[0] ^ 1u; for (int k = 1; k < 8; k++) o |= x.v[k]; one = o == 0; }
+    if (one) return false;
+  }
   if (mont) x = S::from_mont(x);
 #pragma unroll
   for (int k = 0; k < 8; k++) s[k] = x.v[k];
+  return true;
 }
 
 // Calls f(window, bucket_index_in_window, negative) for every non-zero signed digit.
@@ -83,11 +92,11 @@ __device__ __forceinline__ uint32_t agg_atomic_inc(uint32_t* __restrict__ ctr, u
 }
 
 template <class S>
-__global__ void k_hist(const uint32_t* __restrict__ scalars, size_t n, int mont, int c, int K, uint32_t nbw,
+__global__ void k_hist(const uint32_t* __restrict__ scalars, size_t n, int mont, int skip_ones, int c, int K, uint32_t nbw,
                        uint32_t* __restrict__ counts) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     uint32_t s[8];
-    load_scalar<S>(scalars, i, mont, s);
+    if (!load_scalar<S>(scalars, i, mont, skip_ones, s)) continue;
     for_each_digit(s, c, K, [&](int w, uint32_t b, uint32_t) { agg_atomic_inc(counts, (uint32_t)w * nbw + b); });
   }
 }
@@ -122,12 +131,12 @@ __global__ void __launch_bounds__(1024) k_scan(const uint32_t* __restrict__ coun
 }
 
 template <class S>
-__global__ void k_scatter(const uint32_t* __restrict__ scalars, size_t n, int mont, int c, int K, uint32_t nbw,
+__global__ void k_scatter(const uint32_t* __restrict__ scalars, size_t n, int mont, int skip_ones, int c, int K, uint32_t nbw,
                           const uint32_t* __restrict__ bucket_off, uint32_t* __restrict__ cursor,
                           uint32_t* __restrict__ sorted) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     uint32_t s[8];
-    load_scalar<S>(scalars, i, mont, s);
+    if (!load_scalar<S>(scalars, i, mont, skip_ones, s)) continue;
     for_each_digit(s, c, K, [&](int w, uint32_t b, uint32_t neg) {
       uint32_t g = (uint32_t)w * nbw + b;
       uint32_t pos = bucket_off[g] + agg_atomic_inc(cursor, g);
@@ -193,6 +202,42 @@ __global__ void __launch_bounds__(256) k_accum(const uint32_t* __restrict__ base
   }
   store_xyzz(partial, s, acc);
   sub_bucket[s] = b; sub_k[s] = k;
+}
+
+// ---- unit scalars -------------------------------------------------------------------------------------------------
+// A fresh witness is ~80 % bits, so its commitment is mostly "the sum of the bases whose wire is 1".  Pushing those
+// through the sort makes one bucket hold a third of all points and serialises ~10^3 device-scope atomics on one
+// address.  Instead the units are summed directly: thread t adds the bases of the unit scalars among t, t+G, t+2G, ...
+// (coalesced scalar reads; which subset a thread takes is irrelevant, everything is summed), then a two-level LDS tree.
+constexpr uint32_t ONES_THREADS = 16384;   // partial sums of level 0
+template <class S, class F>
+__global__ void __launch_bounds__(256) k_ones_partial(const uint32_t* __restrict__ scalars, const uint32_t* __restrict__ bases, size_t n, int mont,
+                                                      uint32_t* __restrict__ out /* ONES_THREADS XYZZ */) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  XYZZ<F> acc = XYZZ<F>::identity();
+  for (size_t i = t; i < n; i += ONES_THREADS) {
+    const uint4* p = reinterpret_cast<const uint4*>(scalars + 8 * i);
+    const uint4 a = p[0], b = p[1];
+    bool one;
+    if (mont) one = a.x == S::Params::R1.w[0] && a.y == S::Params::R1.w[1] && a.z == S::Params::R1.w[2] && a.w == S::Params::R1.w[3] &&
+                    b.x == S::Params::R1.w[4] && b.y == S::Params::R1.w[5] && b.z == S::Params::R1.w[6] && b.w == S::Params::R1.w[7];
+    else one = a.x == 1u && (a.y | a.z | a.w | b.x | b.y | b.z | b.w) == 0u;
+    if (one) { Affine<F> q = load_affine<F>(bases, (uint32_t)i); add_mixed(acc, q); }
+  }
+  store_xyzz(out, t, acc);
+}
+// in: m points, out: ceil(m/256) points (one LDS tree per workgroup)
+template <class F>
+__global__ void __launch_bounds__(256) k_tree256(const uint32_t* __restrict__ in, uint32_t m, uint32_t* __restrict__ out) {
+  __shared__ XYZZ<F> sh[256];
+  const uint32_t t = threadIdx.x, i = blockIdx.x * 256 + t;
+  sh[t] = i < m ? load_xyzz<F>(in, i) : XYZZ<F>::identity();
+  __syncthreads();
+  for (uint32_t d = 128; d > 0; d >>= 1) {
+    if (t < d) { XYZZ<F> a = sh[t]; add_full(a, sh[t + d]); sh[t] = a; }
+    __syncthreads();
+  }
+  if (t == 0) store_xyzz(out, blockIdx.x, sh[0]);
 }
 
 constexpr uint32_t MSM_HEAVY = 24;   // buckets with more sub-buckets than this are combined by a whole workgroup
@@ -278,12 +323,13 @@ __global__ void __launch_bounds__(256) k_reduce(const uint32_t* __restrict__ par
 // and then calls msm_finish.  `ws` must not be used by another stream concurrently.
 template <class C>
 hipError_t msm_launch(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_bases, const uint32_t* d_scalars, size_t n,
-                      int scalars_mont, int c_override, void* pinned_dst, MsmPlan* plan_out, hipEvent_t* ev) {
+                      int scalars_mont, int c_override, void* pinned_dst, MsmPlan* plan_out, hipEvent_t* ev, int split_ones) {
   typedef typename C::Coord F;
   typedef typename C::Scalar S;
   if (n == 0 || n >= (1u << 31)) return hipErrorInvalidValue;
-  const MsmPlan pl = msm_plan(n, S::Params::BITS, c_override);
-  if (pl.K > MSM_MAX_WINDOWS || pl.c > 16 || pl.c < 2) return hipErrorInvalidValue;
+  MsmPlan pl = msm_plan(n, S::Params::BITS, c_override);
+  if (pl.K + 1 > MSM_MAX_WINDOWS || pl.c > 16 || pl.c < 2) return hipErrorInvalidValue;
+  pl.split_ones = split_ones;
   *plan_out = pl;
   const size_t entries = (size_t)pl.K * n;
   const size_t max_subs = entries / MSM_SUB + pl.nb + 1;
@@ -295,11 +341,11 @@ hipError_t msm_launch(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_ba
 #define VZ_EV(i) do { if (ev) VZ_HIP_CHECK(hipEventRecord(ev[i], stream)); } while (0)
   VZ_EV(0);
   const unsigned gs = (unsigned)std::min<size_t>((n + TB - 1) / TB, 256 * 16);
-  hipLaunchKernelGGL(k_hist<S>, dim3(gs), dim3(TB), 0, stream, d_scalars, n, scalars_mont, pl.c, pl.K, pl.nbw, ws.counts);
+  hipLaunchKernelGGL(k_hist<S>, dim3(gs), dim3(TB), 0, stream, d_scalars, n, scalars_mont, split_ones, pl.c, pl.K, pl.nbw, ws.counts);
   VZ_EV(1);
   hipLaunchKernelGGL(k_scan<MSM_SUB>, dim3(1), dim3(1024), 0, stream, ws.counts, pl.nb, ws.bucket_off, ws.sub_off, ws.totals);
   VZ_EV(2);
-  hipLaunchKernelGGL(k_scatter<S>, dim3(gs), dim3(TB), 0, stream, d_scalars, n, scalars_mont, pl.c, pl.K, pl.nbw,
+  hipLaunchKernelGGL(k_scatter<S>, dim3(gs), dim3(TB), 0, stream, d_scalars, n, scalars_mont, split_ones, pl.c, pl.K, pl.nbw,
                      ws.bucket_off, ws.cursor, ws.sorted);
   VZ_EV(3);
   uint32_t* partial = reinterpret_cast<uint32_t*>(ws.partial);
@@ -315,8 +361,15 @@ hipError_t msm_launch(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_ba
   hipLaunchKernelGGL(k_reduce<F>, dim3(pl.K), dim3(T), 0, stream, partial, ws.counts, ws.sub_off, pl.nbw, wsum);
   VZ_EV(6);
 #undef VZ_EV
+  if (split_ones) {   // sum of the bases with unit scalar -> window_sums[K]
+    uint32_t* lvl0 = reinterpret_cast<uint32_t*>(ws.ones_partial);
+    hipLaunchKernelGGL((k_ones_partial<S, F>), dim3(ONES_THREADS / 256), dim3(256), 0, stream, d_scalars, d_bases, n, scalars_mont, lvl0);
+    uint32_t* lvl1 = lvl0 + (size_t)XYZZ_WORDS * ONES_THREADS;
+    hipLaunchKernelGGL(k_tree256<F>, dim3(ONES_THREADS / 256), dim3(256), 0, stream, lvl0, ONES_THREADS, lvl1);
+    hipLaunchKernelGGL(k_tree256<F>, dim3(1), dim3(256), 0, stream, lvl1, ONES_THREADS / 256, wsum + (size_t)XYZZ_WORDS * pl.K);
+  }
   VZ_HIP_CHECK(hipGetLastError());
-  VZ_HIP_CHECK(hipMemcpyAsync(pinned_dst, wsum, 4 * (size_t)XYZZ_WORDS * pl.K, hipMemcpyDeviceToHost, stream));
+  VZ_HIP_CHECK(hipMemcpyAsync(pinned_dst, wsum, 4 * (size_t)XYZZ_WORDS * (pl.K + (split_ones ? 1 : 0)), hipMemcpyDeviceToHost, stream));
   return hipSuccess;
 }
 
@@ -338,18 +391,19 @@ Affine<typename C::Base> msm_finish(const MsmPlan& pl, const void* pinned) {
     for (int k = 0; k < pl.c; k++) acc = dbl(acc);
     add_full(acc, host_point(w));
   }
+  if (pl.split_ones) add_full(acc, host_point(pl.K));
   return to_affine(acc);
 }
 
 template <class C>
 hipError_t msm_run(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_bases, const uint32_t* d_scalars, size_t n,
                    int scalars_mont, int c_override, Affine<typename C::Base>* out_affine_mont, MsmStats* stats,
-                   hipEvent_t* ev /* 7 events or nullptr */) {
+                   hipEvent_t* ev /* 7 events or nullptr */, int split_ones) {
   typedef typename C::Base FS;
   if (n == 0) { out_affine_mont->x = FS::zero(); out_affine_mont->y = FS::zero(); return hipSuccess; }
   if (!ws.host_pinned) VZ_HIP_CHECK(hipHostMalloc(&ws.host_pinned, 4 * XYZZ_WORDS * MSM_MAX_WINDOWS));
   MsmPlan pl;
-  VZ_HIP_CHECK(msm_launch<C>(stream, ws, d_bases, d_scalars, n, scalars_mont, c_override, ws.host_pinned, &pl, ev));
+  VZ_HIP_CHECK(msm_launch<C>(stream, ws, d_bases, d_scalars, n, scalars_mont, c_override, ws.host_pinned, &pl, ev, split_ones));
   uint32_t h_tot[2] = {0, 0};
   if (stats) VZ_HIP_CHECK(hipMemcpyAsync(h_tot, ws.totals, 8, hipMemcpyDeviceToHost, stream));
   VZ_HIP_CHECK(hipStreamSynchronize(stream));

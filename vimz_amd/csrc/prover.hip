@@ -492,7 +492,7 @@ int vimz_prover_fold(vimz_prover* p, const uint64_t* step_inputs, size_t nsteps)
     for (size_t r = 0; r < rows; r++) {
       const uint32_t* Zi = bb.Z + 8 * r * nw;
       launch_spmv(p, sb, Zi, bb.az + 8 * r * nc, bb.bz + 8 * r * nc, bb.cz + 8 * r * nc);
-      P_TRY(msm_launch<BnG1>(sb, p->wsB, p->ck->d, Zi + 8 * (size_t)aux0, p->n_aux, 1, 0, (char*)bb.pin + r * pin_stride, &p->planB, nullptr));
+      P_TRY(msm_launch<BnG1>(sb, p->wsB, p->ck->d, Zi + 8 * (size_t)aux0, p->n_aux, 1, 0, (char*)bb.pin + r * pin_stride, &p->planB, nullptr, 1));
       P_TRY(hipEventRecord(bb.ev[r], sb));
     }
     return VIMZ_OK;
@@ -510,60 +510,99 @@ int vimz_prover_fold(vimz_prover* p, const uint64_t* step_inputs, size_t nsteps)
       hipStreamSynchronize(p->sB);
       return vz_fail(ctx, VIMZ_ERR_UNSAT, msg);
     }
-    for (size_t r = 0; r < rows; r++) {
-      uint32_t* Zi = bb.Z + 8 * r * nw;
-      uint32_t *az2 = bb.az + 8 * r * nc, *bz2 = bb.bz + 8 * r * nc, *cz2 = bb.cz + 8 * r * nc;
-      t0 = now_s();
-      P_TRY(hipEventSynchronize(bb.ev[r]));              // host needs comm_W2 ...
-      P_TRY(hipStreamWaitEvent(s, bb.ev[r], 0));         // ... and stream A needs (A,B,C)·z2
-      const G1Aff cW2 = msm_finish<BnG1>(p->planB, (char*)bb.pin + r * pin_stride);
-      p->phase_s[PH_MSM_W] += now_s() - t0; p->phase_n[PH_MSM_W]++;
-      uint64_t pt[8];
+    // Software-pipelined sequential chain.  While the GPU runs MSM(T) of row r the host finishes the previous row's
+    // commitment folds and prepares row r+1 (witness-commitment Horner, state digest); the cross term and MSM(T) of
+    // row r+1 are enqueued right behind the fold of row r, so stream A never waits for host arithmetic other than the
+    // MSM tail (Horner + inversion) and the challenge hash.
+    struct Prep { G1Aff cW2; Fe zdig; bool ready = false; };
+    std::vector<Prep> prep(rows);
+    auto do_prep = [&](size_t r) -> int {          // host side of the fresh instance of row r
+      double tp = now_s();
+      P_TRY(hipEventSynchronize(bb.ev[r]));
+      prep[r].cW2 = msm_finish<BnG1>(p->planB, (char*)bb.pin + r * pin_stride);
+      Fe zd = r == 0 ? p->zdigest : prep[r - 1].zdig;
       const Fe* znext = zs.data() + (first + r + 1) * p->len_z;
-      for (uint32_t i = 0; i < p->len_z; i++) { Fe in[2] = {p->zdigest, znext[i]}; p->zdigest = cb::poseidon_hash(in, 2); }
-      if (p->steps == 0) {
-        // base case: the running instance IS the first fresh instance (u = 1, E = 0), as RecursiveSNARK::new does
-        P_TRY(hipMemcpyAsync(p->Zrun, Zi, 32 * nw, hipMemcpyDeviceToDevice, s));
-        P_TRY(hipMemcpyAsync(p->AZ, az2, 32 * nc, hipMemcpyDeviceToDevice, s));
-        P_TRY(hipMemcpyAsync(p->BZ, bz2, 32 * nc, hipMemcpyDeviceToDevice, s));
-        P_TRY(hipMemcpyAsync(p->CZ, cz2, 32 * nc, hipMemcpyDeviceToDevice, s));
-        p->comm_W = cW2; p->u = Fe::one();
-        Fe ab[8]; Fe cw[2]; ro_absorb_point(cW2, cw);
-        ab[0] = p->ro; ab[1] = cw[0]; ab[2] = cw[1]; ab[3] = p->zdigest;
-        p->ro = cb::poseidon_hash(ab, 4);
-      } else {
-        t0 = now_s();
-        hipLaunchKernelGGL(k_cross_term<Fr>, dim3(stream_grid(nc)), dim3(256), 0, s, nc, p->AZ, p->BZ, p->CZ, p->u, az2, bz2, cz2, Fe::one(), p->T);
-        P_TRY(hipGetLastError());
-        rc = vz_msm_device(ctx, p->ck, 0, p->T, nc, 1, 0, pt, VIMZ_FORM_MONTGOMERY);
-        if (rc) return rc;
-        p->phase_s[PH_MSM_T] += now_s() - t0; p->phase_n[PH_MSM_T]++;
-        t0 = now_s();
-        G1Aff cT; memcpy(cT.x.v, pt, 32); memcpy(cT.y.v, pt + 4, 32);
-        // r = low 128 bits of Poseidon(ro, comm_W2, comm_T, digest of the IVC states so far)
-        Fe ab[6]; Fe a2[2];
-        ab[0] = p->ro; ro_absorb_point(cW2, a2); ab[1] = a2[0]; ab[2] = a2[1]; ro_absorb_point(cT, a2); ab[3] = a2[0]; ab[4] = a2[1]; ab[5] = p->zdigest;
-        p->ro = cb::poseidon_hash(ab, 6);
-        Fe rc_canon = Fe::from_mont(p->ro);
-        Fe r128 = Fe::zero(); for (int i = 0; i < 4; i++) r128.v[i] = rc_canon.v[i];
-        const Fe rm = Fe::to_mont(r128);
-        p->phase_s[PH_RO] += now_s() - t0; p->phase_n[PH_RO]++; t0 = now_s();
-        Fold5 f;
-        f.x1[0] = p->Zrun; f.x2[0] = Zi; f.n[0] = nw;
-        f.x1[1] = p->E; f.x2[1] = p->T; f.n[1] = nc;
-        f.x1[2] = p->AZ; f.x2[2] = az2; f.n[2] = nc;
-        f.x1[3] = p->BZ; f.x2[3] = bz2; f.n[3] = nc;
-        f.x1[4] = p->CZ; f.x2[4] = cz2; f.n[4] = nc;
-        hipLaunchKernelGGL(k_fold5<Fr>, dim3(2048), dim3(256), 0, s, f, rm);
-        P_TRY(hipGetLastError());
-        // host side of the fold, overlapped with the kernel above
-        G1 a = from_affine(p->comm_W); G1 rb = scalar_mul(cW2, r128.v, 128); add_full(a, rb); p->comm_W = to_affine(a);
-        G1 e1 = from_affine(p->comm_E); G1 rt = scalar_mul(cT, r128.v, 128); add_full(e1, rt); p->comm_E = to_affine(e1);
-        p->u = Fe::add(p->u, rm);
-        p->phase_s[PH_HOST_EC] += now_s() - t0; p->phase_n[PH_HOST_EC]++;
+      for (uint32_t i = 0; i < p->len_z; i++) { Fe in[2] = {zd, znext[i]}; zd = cb::poseidon_hash(in, 2); }
+      prep[r].zdig = zd; prep[r].ready = true;
+      p->phase_s[PH_MSM_W] += now_s() - tp; p->phase_n[PH_MSM_W]++;
+      return VIMZ_OK;
+    };
+    MsmPlan planT{};
+    auto launch_T = [&](size_t r) -> int {         // cross term + MSM(T) of row r, asynchronous on stream A
+      P_TRY(hipStreamWaitEvent(s, bb.ev[r], 0));
+      hipLaunchKernelGGL(k_cross_term<Fr>, dim3(stream_grid(nc)), dim3(256), 0, s, nc, p->AZ, p->BZ, p->CZ, p->u,
+                         bb.az + 8 * r * nc, bb.bz + 8 * r * nc, bb.cz + 8 * r * nc, Fe::one(), p->T);
+      P_TRY(hipGetLastError());
+      if (!ctx->msm_ws.host_pinned) P_TRY(hipHostMalloc(&ctx->msm_ws.host_pinned, 4 * XYZZ_WORDS * MSM_MAX_WINDOWS));
+      P_TRY(msm_launch<BnG1>(s, ctx->msm_ws, p->ck->d, p->T, nc, 1, 0, ctx->msm_ws.host_pinned, &planT, ctx->profiling ? ctx->ev : nullptr, 0));
+      if (ctx->profiling) P_TRY(hipMemcpyAsync(&ctx->last_msm.subs, ctx->msm_ws.totals, 8, hipMemcpyDeviceToHost, s));
+      return VIMZ_OK;
+    };
+    struct Deferred { bool pending = false; G1Aff cW2, cT; Fe r128; } dfr;
+    auto flush_deferred = [&]() {                  // comm_W, comm_E <- folded (host EC, off the GPU's critical path)
+      if (!dfr.pending) return;
+      double te = now_s();
+      G1 a = from_affine(p->comm_W); G1 rb = scalar_mul(dfr.cW2, dfr.r128.v, 128); add_full(a, rb); p->comm_W = to_affine(a);
+      G1 e1 = from_affine(p->comm_E); G1 rt = scalar_mul(dfr.cT, dfr.r128.v, 128); add_full(e1, rt); p->comm_E = to_affine(e1);
+      dfr.pending = false;
+      p->phase_s[PH_HOST_EC] += now_s() - te; p->phase_n[PH_HOST_EC]++;
+    };
+    size_t r0 = 0;
+    if ((rc = do_prep(0))) return rc;
+    if (p->steps == 0) {
+      // base case: the running instance IS the first fresh instance (u = 1, E = 0), as RecursiveSNARK::new does
+      P_TRY(hipStreamWaitEvent(s, bb.ev[0], 0));
+      P_TRY(hipMemcpyAsync(p->Zrun, bb.Z, 32 * nw, hipMemcpyDeviceToDevice, s));
+      P_TRY(hipMemcpyAsync(p->AZ, bb.az, 32 * nc, hipMemcpyDeviceToDevice, s));
+      P_TRY(hipMemcpyAsync(p->BZ, bb.bz, 32 * nc, hipMemcpyDeviceToDevice, s));
+      P_TRY(hipMemcpyAsync(p->CZ, bb.cz, 32 * nc, hipMemcpyDeviceToDevice, s));
+      p->comm_W = prep[0].cW2; p->u = Fe::one(); p->zdigest = prep[0].zdig;
+      Fe ab[4]; Fe cw[2]; ro_absorb_point(prep[0].cW2, cw);
+      ab[0] = p->ro; ab[1] = cw[0]; ab[2] = cw[1]; ab[3] = p->zdigest;
+      p->ro = cb::poseidon_hash(ab, 4);
+      p->steps++;
+      r0 = 1;
+      if (rows > 1 && (rc = do_prep(1))) return rc;
+    }
+    if (r0 < rows && (rc = launch_T(r0))) return rc;
+    for (size_t r = r0; r < rows; r++) {
+      // host work hidden behind MSM(T) of row r
+      flush_deferred();
+      if (r + 1 < rows && (rc = do_prep(r + 1))) return rc;
+      t0 = now_s();
+      P_TRY(hipStreamSynchronize(s));
+      const G1Aff cT = msm_finish<BnG1>(planT, ctx->msm_ws.host_pinned);
+      if (ctx->profiling) {
+        float ms[6];
+        for (int i = 0; i < 6; i++) { P_TRY(hipEventElapsedTime(&ms[i], ctx->ev[i], ctx->ev[i + 1])); ctx->last_msm.ms[i] = ms[i]; ctx->msm_tot_ms[i] += ms[i]; }
+        ctx->last_msm.c = planT.c; ctx->last_msm.K = planT.K;
+        ctx->msm_tot_calls++; ctx->msm_tot_points += nc; ctx->msm_tot_entries += ctx->last_msm.entries;
       }
+      p->phase_s[PH_MSM_T] += now_s() - t0; p->phase_n[PH_MSM_T]++;
+      t0 = now_s();
+      // r = low 128 bits of Poseidon(ro, comm_W2, comm_T, digest of the IVC states so far)
+      p->zdigest = prep[r].zdig;
+      Fe ab[6]; Fe a2[2];
+      ab[0] = p->ro; ro_absorb_point(prep[r].cW2, a2); ab[1] = a2[0]; ab[2] = a2[1]; ro_absorb_point(cT, a2); ab[3] = a2[0]; ab[4] = a2[1]; ab[5] = p->zdigest;
+      p->ro = cb::poseidon_hash(ab, 6);
+      Fe rc_canon = Fe::from_mont(p->ro);
+      Fe r128 = Fe::zero(); for (int i = 0; i < 4; i++) r128.v[i] = rc_canon.v[i];
+      const Fe rm = Fe::to_mont(r128);
+      p->phase_s[PH_RO] += now_s() - t0; p->phase_n[PH_RO]++;
+      Fold5 f;
+      f.x1[0] = p->Zrun; f.x2[0] = bb.Z + 8 * r * nw; f.n[0] = nw;
+      f.x1[1] = p->E; f.x2[1] = p->T; f.n[1] = nc;
+      f.x1[2] = p->AZ; f.x2[2] = bb.az + 8 * r * nc; f.n[2] = nc;
+      f.x1[3] = p->BZ; f.x2[3] = bb.bz + 8 * r * nc; f.n[3] = nc;
+      f.x1[4] = p->CZ; f.x2[4] = bb.cz + 8 * r * nc; f.n[4] = nc;
+      hipLaunchKernelGGL(k_fold5<Fr>, dim3(2048), dim3(256), 0, s, f, rm);
+      P_TRY(hipGetLastError());
+      p->u = Fe::add(p->u, rm);
+      if (r + 1 < rows && (rc = launch_T(r + 1))) return rc;     // next row's GPU work is queued before any host EC
+      dfr.pending = true; dfr.cW2 = prep[r].cW2; dfr.cT = cT; dfr.r128 = r128;
       p->steps++;
     }
+    flush_deferred();
     // this buffer is rewritten by batch k+2: the folds that read it must have finished
     P_TRY(hipStreamSynchronize(s));
   }

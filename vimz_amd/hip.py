@@ -144,10 +144,13 @@ class Context:
         self._chk(self.lib.vimz_msm(self.h, bases.h, _ptr(scalars), scalars.size // 4, form, window_bits, _ptr(out), out_form))
         return out
 
-    def msm_vec(self, bases, vec, n=None, offset=0, base_offset=0, window_bits=0, out_form=L.FORM_CANONICAL):
+    def msm_vec(self, bases, vec, n=None, offset=0, base_offset=0, window_bits=0, out_form=L.FORM_CANONICAL, split_ones=False):
         n = vec.n - offset if n is None else n
         out = np.zeros(8, dtype=np.uint64)
-        self._chk(self.lib.vimz_msm_vec(self.h, bases.h, base_offset, vec.h, offset, n, window_bits, _ptr(out), out_form))
+        if split_ones:
+            self._chk(self.lib.vimz_msm_vec_ex(self.h, bases.h, base_offset, vec.h, offset, n, window_bits, 1, _ptr(out), out_form))
+        else:
+            self._chk(self.lib.vimz_msm_vec(self.h, bases.h, base_offset, vec.h, offset, n, window_bits, _ptr(out), out_form))
         return out
 
     # ---- probes
