@@ -161,6 +161,12 @@ def main():
         alg_bytes = 96.0 * n_c                                     # 32 B scalar + 64 B affine base per point
         achieved = alg_bytes / (acc_ms * 1e-3) / 1e9 if acc_ms else 0.0
         adds = tot["entries"] / calls
+        traffic = None          # HBM bytes per launch of the roofline kernel from PMC passes of this same command (profiles/)
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fp:
+                traffic = json.load(fp).get(f"{args.transformation}_step_{args.resolution}", {}).get("hbm_bytes_per_launch")
+        except OSError:
+            pass
         step_bytes = 96 * n_w + 96 * n_c + 8 * nnz + 32 * n_w + 96 * n_c + 7 * 32 * n_c + 3 * 32 * n_w + 12 * 32 * n_c
         out = {
             "metric": "nova_folding_steps_per_sec",
@@ -184,7 +190,7 @@ def main():
             "published_reference": {"contrast_HD_steps_per_s_cpu_server": 1.94, "source": "README.md:52 (720 steps / 371.7 s)"},
             "phase_ms_per_step": {k: 1e3 * v["seconds"] / max(1, (args.steps + args.warmup)) for k, v in prof.items()},
             "roofline": {"bound": "hbm", "kernel": "k_accum (bucket accumulation) of the MSM(T) launches in the timed region", "achieved": achieved,
-                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": acc_ms, "launches": tot["calls"], "msm_gpu_ms": msm_ms,
                          "mixed_adds_per_launch": adds, "msm_phase_ms": {k: v / calls for k, v in tot["ms"].items()},
                          "int_utilisation": (adds / (acc_ms * 1e-3) / 1e9 / MIXED_ADD_PEAK_GOPS) if acc_ms else 0.0,
