@@ -227,3 +227,34 @@ def test_commitment_key_derivation(ctx, oracle, cid):
     B2 = ctx.bases_generate(cid, 8, label=b"other")
     assert tuple(from_limbs(B2.download()[0])) == ck_derive(cid, b"other", 0) != tuple(from_limbs(pts[0]))
     B2.free()
+
+
+@pytest.mark.parametrize("cid", [0, 1, 2, 3])
+def test_msm_with_window_tables(ctx, oracle, cid):
+    """Precomputed window tables (one shared bucket set, no Horner) give the same points as the oracle: dense scalars,
+    witness-like scalars with the unit split, sub-ranges with a base offset, and an explicit window override (classic path)."""
+    from vimz_amd import _lib
+    r = MODULI[CURVE_SCALAR[cid]]
+    n = 6000
+    rng = random.Random(31 + cid)
+    bases = oracle.seq_bases(cid, n)
+    bases[11] = 0                                              # an identity base stays the identity in every table row
+    dense = [rng.randrange(r) for _ in range(n)]
+    dense[:6] = [0, 1, r - 1, 1 << 200, 65535, 65536]
+    wit = [rng.choice([0, 1, 1, rng.randrange(256), rng.randrange(r)]) for _ in range(n)]
+    B = ctx.bases_upload(cid, bases).precompute()
+    try:
+        for sc, split in ((dense, False), (wit, True), (wit, False)):
+            v = ctx.vec_from_host(CURVE_SCALAR[cid], to_limbs(sc))
+            assert tuple(from_limbs(ctx.msm_vec(B, v, split_ones=split))) == oracle.msm(cid, bases, to_limbs(sc), threads=8)
+            assert tuple(from_limbs(ctx.msm_vec(B, v, n=700, offset=100, base_offset=300, split_ones=split))) == \
+                oracle.msm(cid, bases[300:1000], to_limbs(sc[100:800]), threads=8)
+            assert tuple(from_limbs(ctx.msm_vec(B, v, window_bits=9))) == oracle.msm(cid, bases, to_limbs(sc), threads=8)
+            v.free()
+        if cid == 0:
+            B.precompute(12)                                   # another table width
+            v = ctx.vec_from_host(CURVE_SCALAR[cid], to_limbs(dense))
+            assert tuple(from_limbs(ctx.msm_vec(B, v))) == oracle.msm(cid, bases, to_limbs(dense), threads=8)
+            v.free()
+    finally:
+        B.free()

@@ -52,6 +52,7 @@ def lib():
         L.vimz_bases_upload.argtypes = [vp, i, u64p, sz, i, C.POINTER(vp)]
         L.vimz_bases_generate.argtypes = [vp, i, C.c_char_p, sz, sz, C.POINTER(vp)]
         L.vimz_bases_download.argtypes = [vp, vp, sz, u64p, sz, i]
+        L.vimz_bases_precompute.argtypes = [vp, vp, i]
         L.vimz_bases_len.argtypes = [vp]
         L.vimz_bases_len.restype = sz
         L.vimz_bases_free.argtypes = [vp, vp]

@@ -82,8 +82,9 @@ int vz_msm_device(vimz_ctx* c, const vimz_bases* bases, size_t base_offset, cons
     typedef decltype(cv) C;
     typedef typename C::Base F;
     Affine<F> r;
+    const BaseTables tb = bases->tb(base_offset);
     hipError_t e = msm_run<C>(c->stream, c->msm_ws, bases->d + (size_t)AFFINE_WORDS * base_offset, d_scalars, n, scalars_mont, window_bits, &r,
-                              &c->last_msm, c->profiling ? c->ev : nullptr, split_ones);
+                              &c->last_msm, c->profiling ? c->ev : nullptr, split_ones, bases->tables ? &tb : nullptr);
     if (e != hipSuccess) return vz_fail(c, VIMZ_ERR_HIP, "msm", e);
     if (c->profiling && n) {
       for (int i = 0; i < 6; i++) c->msm_tot_ms[i] += c->last_msm.ms[i];
@@ -196,7 +197,7 @@ int vimz_bases_upload(vimz_ctx* c, int curve, const uint64_t* xy, size_t n, int 
   if (!c || !out || (!xy && n) || curve < 0 || curve > 3) return fail(c, VIMZ_ERR_INVALID, "vimz_bases_upload: bad argument");
   std::lock_guard<std::mutex> g(c->mu);
   HIP_TRY(c, hipSetDevice(c->device));
-  vimz_bases* b = new vimz_bases{curve, n, nullptr};
+  vimz_bases* b = new vimz_bases(); b->curve = curve; b->n = n; b->d = nullptr;
   if (n) {
     int rc = ensure_scratch(c, 64 * n); if (rc) { delete b; return rc; }
     hipError_t e = hipMalloc(&b->d, 4 * (size_t)AFFINE_WORDS * n);
@@ -215,7 +216,7 @@ int vimz_bases_generate(vimz_ctx* c, int curve, const char* label, size_t label_
   if (!c || !out || (!label && label_len) || label_len > 64 || curve < 0 || curve > 3) return fail(c, VIMZ_ERR_INVALID, "vimz_bases_generate: bad argument");
   std::lock_guard<std::mutex> g(c->mu);
   HIP_TRY(c, hipSetDevice(c->device));
-  vimz_bases* b = new vimz_bases{curve, n, nullptr};
+  vimz_bases* b = new vimz_bases(); b->curve = curve; b->n = n; b->d = nullptr;
   if (n) {
     int rcs = ensure_scratch(c, 64 * n); if (rcs) { delete b; return rcs; }
     hipError_t e = hipMalloc(&b->d, 4 * (size_t)AFFINE_WORDS * n);
@@ -247,8 +248,30 @@ int vimz_bases_download(vimz_ctx* c, const vimz_bases* b, size_t offset, uint64_
 size_t vimz_bases_len(const vimz_bases* b) { return b ? b->n : 0; }
 void vimz_bases_free(vimz_ctx* c, vimz_bases* b) {
   if (!b) return;
-  if (c) { std::lock_guard<std::mutex> g(c->mu); hipSetDevice(c->device); hipStreamSynchronize(c->stream); if (b->d) hipFree(b->d); }
+  if (c) { std::lock_guard<std::mutex> g(c->mu); hipSetDevice(c->device); hipStreamSynchronize(c->stream); if (b->d) hipFree(b->d); if (b->tables) hipFree(b->tables); }
   delete b;
+}
+// Window tables T_j[i] = 2^(c j) P_i for the whole key (c = window_bits, 0 -> 16): K x the key's size in HBM
+// (0.67 GB for 2^19 points).  Afterwards MSMs over this key with window_bits = 0 use one shared bucket set.
+int vimz_bases_precompute(vimz_ctx* c, vimz_bases* b, int window_bits) {
+  if (!c || !b) return fail(c, VIMZ_ERR_INVALID, "vimz_bases_precompute: bad argument");
+  const int cw = window_bits > 0 ? window_bits : 16;
+  if (cw < 10 || cw > 16) return fail(c, VIMZ_ERR_INVALID, "vimz_bases_precompute: window_bits must be in [10, 16]");
+  std::lock_guard<std::mutex> g(c->mu);
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (b->tables) { hipFree(b->tables); b->tables = nullptr; }
+  if (!b->n) return VIMZ_OK;
+  return curve_dispatch(b->curve, [&](auto cv) {
+    typedef decltype(cv) C;
+    const int K = (C::Scalar::Params::BITS + 1 + cw - 1) / cw;
+    hipError_t e = hipMalloc(&b->tables, 4 * (size_t)AFFINE_WORDS * b->n * K);
+    if (e != hipSuccess) return fail(c, VIMZ_ERR_HIP, "hipMalloc(window tables)", e);
+    e = build_tables<C>(c->stream, b->d, b->n, cw, K, b->tables);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { hipFree(b->tables); b->tables = nullptr; return fail(c, VIMZ_ERR_HIP, "build_tables", e); }
+    b->table_c = cw; b->table_K = K;
+    return VIMZ_OK;
+  });
 }
 
 // ---- device vectors ----------------------------------------------------------------------------------

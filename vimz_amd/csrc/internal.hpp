@@ -22,7 +22,11 @@ struct vimz_ctx {
   void* scratch = nullptr;  // device staging for host-scalar MSM / probes
   size_t scratch_bytes = 0;
 };
-struct vimz_bases { int curve; size_t n; uint32_t* d; };
+struct vimz_bases {
+  int curve; size_t n; uint32_t* d;
+  uint32_t* tables = nullptr; int table_c = 0, table_K = 0;   // optional window tables (vimz_bases_precompute)
+  vz::BaseTables tb(size_t offset) const { return vz::BaseTables{tables, n, offset, table_c, table_K}; }
+};
 struct vimz_vec { int field; size_t n; uint32_t* d; };
 
 

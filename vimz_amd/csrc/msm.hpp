@@ -92,7 +92,7 @@ __device__ __forceinline__ uint32_t agg_atomic_inc(uint32_t* __restrict__ ctr, u
 }
 
 template <class S>
-__global__ void k_hist(const uint32_t* __restrict__ scalars, size_t n, int mont, int skip_ones, int c, int K, uint32_t nbw,
+__global__ void k_hist(const uint32_t* __restrict__ scalars, size_t n, int mont, int skip_ones, int c, int K, uint32_t nbw /* bucket stride per window: 2^(c-1), or 0 with window tables */,
                        uint32_t* __restrict__ counts) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     uint32_t s[8];
@@ -132,6 +132,7 @@ __global__ void __launch_bounds__(1024) k_scan(const uint32_t* __restrict__ coun
 
 template <class S>
 __global__ void k_scatter(const uint32_t* __restrict__ scalars, size_t n, int mont, int skip_ones, int c, int K, uint32_t nbw,
+                          uint32_t pt_stride /* 0, or the table row length: entry = window * pt_stride + point */,
                           const uint32_t* __restrict__ bucket_off, uint32_t* __restrict__ cursor,
                           uint32_t* __restrict__ sorted) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -140,12 +141,75 @@ __global__ void k_scatter(const uint32_t* __restrict__ scalars, size_t n, int mo
     for_each_digit(s, c, K, [&](int w, uint32_t b, uint32_t neg) {
       uint32_t g = (uint32_t)w * nbw + b;
       uint32_t pos = bucket_off[g] + agg_atomic_inc(cursor, g);
-      sorted[pos] = (uint32_t)i | (neg << 31);
+      sorted[pos] = ((uint32_t)i + (uint32_t)w * pt_stride) | (neg << 31);
     });
   }
 }
 
 // Curve data in HBM: coordinates of COORD_WORDS (10) words, 9 used — every point starts 16-byte aligned.
+// ---- contention-free counting sort ---------------------------------------------------------------------------------
+// The cross-term vector T of a real fold is far from uniform: wires that were 1 in every row so far share one running
+// value, so tens of thousands of scalars are EQUAL and hit the same 24 buckets.  Device-scope atomics on one address
+// serialise across XCDs (~0.5 us each), which made k_hist / k_scatter 5x slower on real data than on random data.
+// Here each workgroup histograms its own contiguous chunk of scalars in LDS (all buckets fit: 24 x 1024 counters = 96 KiB),
+// a scan kernel turns the per-workgroup histograms into global bucket sizes and per-workgroup offsets, and the scatter
+// ranks its entries with LDS atomics again.  No global atomic is issued at all.
+constexpr uint32_t SORT_BLOCKS = 256;      // one workgroup per CU
+constexpr uint32_t SORT_THREADS = 1024;
+
+template <class S>
+__global__ void __launch_bounds__(SORT_THREADS) k_hist_lds(const uint32_t* __restrict__ scalars, size_t n, int mont, int skip_ones, int c, int K,
+                                                           uint32_t nbw, uint32_t nb, uint32_t* __restrict__ block_hist /* [SORT_BLOCKS][nb] */) {
+  extern __shared__ uint32_t lds_cnt[];
+  for (uint32_t g = threadIdx.x; g < nb; g += SORT_THREADS) lds_cnt[g] = 0;
+  __syncthreads();
+  const size_t chunk = (n + SORT_BLOCKS - 1) / SORT_BLOCKS;
+  const size_t lo = blockIdx.x * chunk, hi = lo + chunk < n ? lo + chunk : n;
+  for (size_t i = lo + threadIdx.x; i < hi; i += SORT_THREADS) {
+    uint32_t s[8];
+    if (!load_scalar<S>(scalars, i, mont, skip_ones, s)) continue;
+    for_each_digit(s, c, K, [&](int w, uint32_t b, uint32_t) { atomicAdd(&lds_cnt[(uint32_t)w * nbw + b], 1u); });
+  }
+  __syncthreads();
+  uint32_t* out = block_hist + (size_t)blockIdx.x * nb;
+  for (uint32_t g = threadIdx.x; g < nb; g += SORT_THREADS) out[g] = lds_cnt[g];
+}
+
+// per bucket: total over workgroups -> counts[g]; block_hist[blk][g] becomes the exclusive prefix over workgroups
+template <int DUMMY>
+__global__ void __launch_bounds__(256) k_block_prefix(uint32_t* __restrict__ block_hist, uint32_t nb, uint32_t* __restrict__ counts) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= nb) return;
+  uint32_t run = 0;
+  for (uint32_t blk = 0; blk < SORT_BLOCKS; blk++) {
+    const size_t idx = (size_t)blk * nb + g;
+    const uint32_t v = block_hist[idx];
+    block_hist[idx] = run;
+    run += v;
+  }
+  counts[g] = run;
+}
+
+template <class S>
+__global__ void __launch_bounds__(SORT_THREADS) k_scatter_lds(const uint32_t* __restrict__ scalars, size_t n, int mont, int skip_ones, int c, int K,
+                                                              uint32_t nbw, uint32_t nb, uint32_t pt_stride, const uint32_t* __restrict__ bucket_off,
+                                                              const uint32_t* __restrict__ block_hist, uint32_t* __restrict__ sorted) {
+  extern __shared__ uint32_t lds_pos[];
+  const uint32_t* mine = block_hist + (size_t)blockIdx.x * nb;
+  for (uint32_t g = threadIdx.x; g < nb; g += SORT_THREADS) lds_pos[g] = bucket_off[g] + mine[g];
+  __syncthreads();
+  const size_t chunk = (n + SORT_BLOCKS - 1) / SORT_BLOCKS;
+  const size_t lo = blockIdx.x * chunk, hi = lo + chunk < n ? lo + chunk : n;
+  for (size_t i = lo + threadIdx.x; i < hi; i += SORT_THREADS) {
+    uint32_t s[8];
+    if (!load_scalar<S>(scalars, i, mont, skip_ones, s)) continue;
+    for_each_digit(s, c, K, [&](int w, uint32_t b, uint32_t neg) {
+      const uint32_t pos = atomicAdd(&lds_pos[(uint32_t)w * nbw + b], 1u);
+      sorted[pos] = ((uint32_t)i + (uint32_t)w * pt_stride) | (neg << 31);
+    });
+  }
+}
+
 template <class F>
 __device__ __forceinline__ void load_words20(const uint32_t* __restrict__ p, F& a, F& b) {
   const uint4* q = reinterpret_cast<const uint4*>(p);
@@ -318,16 +382,105 @@ __global__ void __launch_bounds__(256) k_reduce(const uint32_t* __restrict__ par
 
 // ---- host driver ---------------------------------------------------------------------------------
 
+// ---- window tables: one bucket set for all windows ---------------------------------------------------------------------
+// With T_j[i] = 2^(c·j)·P_i precomputed (the commitment key is fixed for the whole proof and HBM is plentiful), digit j of
+// scalar i is an entry (T_j[i], bucket |d|): every window shares ONE set of 2^(c-1) buckets, so c can be large (fewer
+// digits per scalar => fewer sort entries and fewer additions), the bucket reduction runs once, and no Horner is left.
+//   level 1: workgroup w owns buckets [256w, 256w+256): R_w = Σ_t (t+1)·B, S_w = Σ_t B      (double-and-add + LDS trees)
+//   level 2: total = Σ_w R_w + 256·Σ_w w·S_w
+template <class F>
+__device__ __forceinline__ XYZZ<F> small_mul(const XYZZ<F>& p, uint32_t k) {
+  XYZZ<F> acc = XYZZ<F>::identity();
+  if (!k) return acc;
+  for (int bit = 31 - __clz(k); bit >= 0; bit--) { acc = dbl(acc); if ((k >> bit) & 1) add_full(acc, p); }
+  return acc;
+}
+template <class F>
+__global__ void __launch_bounds__(256) k_reduce_big1(const uint32_t* __restrict__ partial, const uint32_t* __restrict__ counts,
+                                                     const uint32_t* __restrict__ sub_off, uint32_t* __restrict__ rs /* [2][gridDim.x] */) {
+  __shared__ XYZZ<F> sh[256];
+  const uint32_t w = blockIdx.x, t = threadIdx.x, g = w * 256 + t;
+  XYZZ<F> B = XYZZ<F>::identity();
+  if (counts[g]) B = load_xyzz<F>(partial, sub_off[g]);
+  XYZZ<F> v = small_mul(B, t + 1);
+  for (int pass = 0; pass < 2; pass++) {
+    sh[t] = pass == 0 ? v : B;
+    __syncthreads();
+    for (uint32_t d = 128; d > 0; d >>= 1) {
+      if (t < d) { XYZZ<F> a = sh[t]; add_full(a, sh[t + d]); sh[t] = a; }
+      __syncthreads();
+    }
+    if (t == 0) store_xyzz(rs, (size_t)pass * gridDim.x + w, sh[0]);
+    __syncthreads();
+  }
+}
+template <class F>
+__global__ void __launch_bounds__(256) k_reduce_big2(const uint32_t* __restrict__ rs, uint32_t nwg, uint32_t* __restrict__ window_sums) {
+  __shared__ XYZZ<F> sh[256];
+  const uint32_t t = threadIdx.x;
+  XYZZ<F> total = XYZZ<F>::identity();
+  for (int pass = 0; pass < 2; pass++) {
+    XYZZ<F> acc = XYZZ<F>::identity();
+    for (uint32_t w = t; w < nwg; w += 256) {
+      XYZZ<F> p = load_xyzz<F>(rs, (size_t)pass * nwg + w);
+      if (pass == 1) p = small_mul(p, w);
+      add_full(acc, p);
+    }
+    sh[t] = acc;
+    __syncthreads();
+    for (uint32_t d = 128; d > 0; d >>= 1) {
+      if (t < d) { XYZZ<F> a = sh[t]; add_full(a, sh[t + d]); sh[t] = a; }
+      __syncthreads();
+    }
+    if (t == 0) {
+      XYZZ<F> r = sh[0];
+      if (pass == 1) for (int k = 0; k < 8; k++) r = dbl(r);   // x 256
+      add_full(total, r);
+    }
+    __syncthreads();
+  }
+  if (t == 0) store_xyzz(window_sums, 0, total);
+}
+
+// Table construction: tables[j][i] = 2^(c j) * P_i in affine internal form (row 0 = the key itself).
+template <class F>
+__global__ void __launch_bounds__(256) k_build_tables(const uint32_t* __restrict__ bases, size_t n, int c, int K, uint32_t* __restrict__ tables) {
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Affine<F> p = load_affine<F>(bases, (uint32_t)i);
+  store_words20(tables + (size_t)AFFINE_WORDS * i, p.x, p.y);
+  for (int j = 1; j < K; j++) {
+    XYZZ<F> acc = from_affine(p);
+    for (int k = 0; k < c; k++) acc = dbl(acc);
+    p = to_affine(acc);
+    store_words20(tables + (size_t)AFFINE_WORDS * ((size_t)j * n + i), p.x, p.y);
+  }
+}
+template <class C>
+hipError_t build_tables(hipStream_t stream, const uint32_t* d_bases, size_t n, int c, int K, uint32_t* d_tables) {
+  typedef typename C::Coord F;
+  if (!n) return hipSuccess;
+  hipLaunchKernelGGL(k_build_tables<F>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_bases, n, c, K, d_tables);
+  return hipGetLastError();
+}
+
 // Enqueue the whole pipeline on `stream` and the copy of the K window sums into `pinned_dst` (host-pinned,
 // K * XYZZ_WORDS words).  Does not synchronise: the caller waits on the stream (or an event recorded after this call)
 // and then calls msm_finish.  `ws` must not be used by another stream concurrently.
 template <class C>
 hipError_t msm_launch(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_bases, const uint32_t* d_scalars, size_t n,
-                      int scalars_mont, int c_override, void* pinned_dst, MsmPlan* plan_out, hipEvent_t* ev, int split_ones) {
+                      int scalars_mont, int c_override, void* pinned_dst, MsmPlan* plan_out, hipEvent_t* ev, int split_ones,
+                      const BaseTables* tb) {
   typedef typename C::Coord F;
   typedef typename C::Scalar S;
   if (n == 0 || n >= (1u << 31)) return hipErrorInvalidValue;
-  MsmPlan pl = msm_plan(n, S::Params::BITS, c_override);
+  const bool tabled = tb && tb->d && c_override <= 0;
+  MsmPlan pl = msm_plan(n, S::Params::BITS, tabled ? tb->c : c_override);
+  if (tabled) {            // one bucket set shared by all windows
+    if (tb->K != pl.K || pl.nbw < 256 || (size_t)tb->K * tb->n_total >= (1u << 31)) return hipErrorInvalidValue;
+    pl.nb = pl.nbw; pl.tabled = 1;
+    d_bases = tb->d + (size_t)AFFINE_WORDS * tb->offset;
+  }
   if (pl.K + 1 > MSM_MAX_WINDOWS || pl.c > 16 || pl.c < 2) return hipErrorInvalidValue;
   pl.split_ones = split_ones;
   *plan_out = pl;
@@ -341,12 +494,31 @@ hipError_t msm_launch(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_ba
 #define VZ_EV(i) do { if (ev) VZ_HIP_CHECK(hipEventRecord(ev[i], stream)); } while (0)
   VZ_EV(0);
   const unsigned gs = (unsigned)std::min<size_t>((n + TB - 1) / TB, 256 * 16);
-  hipLaunchKernelGGL(k_hist<S>, dim3(gs), dim3(TB), 0, stream, d_scalars, n, scalars_mont, split_ones, pl.c, pl.K, pl.nbw, ws.counts);
+  // all buckets' counters fit in one workgroup's LDS at the default window (24 x 1024 x 4 B = 96 KiB): contention-free sort
+  const bool lds_sort = (size_t)pl.nb * 4 <= 144 * 1024;
+  const uint32_t bstride = tabled ? 0u : pl.nbw, pstride = tabled ? (uint32_t)tb->n_total : 0u;
+  if (lds_sort) {
+    VZ_HIP_CHECK(ws.reserve_block_hist((size_t)SORT_BLOCKS * pl.nb));
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&k_hist_lds<S>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_lds<S>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(k_hist_lds<S>, dim3(SORT_BLOCKS), dim3(SORT_THREADS), pl.nb * 4, stream, d_scalars, n, scalars_mont, split_ones, pl.c, pl.K, bstride, pl.nb, ws.block_hist);
+    hipLaunchKernelGGL(k_block_prefix<0>, dim3((pl.nb + 255) / 256), dim3(256), 0, stream, ws.block_hist, pl.nb, ws.counts);
+  } else {
+    hipLaunchKernelGGL(k_hist<S>, dim3(gs), dim3(TB), 0, stream, d_scalars, n, scalars_mont, split_ones, pl.c, pl.K, bstride, ws.counts);
+  }
   VZ_EV(1);
   hipLaunchKernelGGL(k_scan<MSM_SUB>, dim3(1), dim3(1024), 0, stream, ws.counts, pl.nb, ws.bucket_off, ws.sub_off, ws.totals);
   VZ_EV(2);
-  hipLaunchKernelGGL(k_scatter<S>, dim3(gs), dim3(TB), 0, stream, d_scalars, n, scalars_mont, split_ones, pl.c, pl.K, pl.nbw,
-                     ws.bucket_off, ws.cursor, ws.sorted);
+  if (lds_sort)
+    hipLaunchKernelGGL(k_scatter_lds<S>, dim3(SORT_BLOCKS), dim3(SORT_THREADS), pl.nb * 4, stream, d_scalars, n, scalars_mont, split_ones, pl.c, pl.K, bstride, pl.nb,
+                       pstride, ws.bucket_off, ws.block_hist, ws.sorted);
+  else
+    hipLaunchKernelGGL(k_scatter<S>, dim3(gs), dim3(TB), 0, stream, d_scalars, n, scalars_mont, split_ones, pl.c, pl.K, bstride, pstride,
+                       ws.bucket_off, ws.cursor, ws.sorted);
   VZ_EV(3);
   uint32_t* partial = reinterpret_cast<uint32_t*>(ws.partial);
   const unsigned ga = (unsigned)((max_subs + TB - 1) / TB);
@@ -358,6 +530,12 @@ hipError_t msm_launch(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_ba
   VZ_EV(5);
   const unsigned T = pl.nbw < 256 ? pl.nbw : 256;
   uint32_t* wsum = reinterpret_cast<uint32_t*>(ws.window_sums);
+  const int kout = tabled ? 1 : pl.K;     // window sums produced
+  if (tabled) {
+    uint32_t* rs = reinterpret_cast<uint32_t*>(ws.ones_partial);   // scratch: 2 x (nbw/256) points (<= 2 x 128 of the 16448)
+    hipLaunchKernelGGL(k_reduce_big1<F>, dim3(pl.nbw / 256), dim3(256), 0, stream, partial, ws.counts, ws.sub_off, rs + (size_t)XYZZ_WORDS * 16448);
+    hipLaunchKernelGGL(k_reduce_big2<F>, dim3(1), dim3(256), 0, stream, rs + (size_t)XYZZ_WORDS * 16448, pl.nbw / 256, wsum);
+  } else
   hipLaunchKernelGGL(k_reduce<F>, dim3(pl.K), dim3(T), 0, stream, partial, ws.counts, ws.sub_off, pl.nbw, wsum);
   VZ_EV(6);
 #undef VZ_EV
@@ -366,10 +544,10 @@ hipError_t msm_launch(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_ba
     hipLaunchKernelGGL((k_ones_partial<S, F>), dim3(ONES_THREADS / 256), dim3(256), 0, stream, d_scalars, d_bases, n, scalars_mont, lvl0);
     uint32_t* lvl1 = lvl0 + (size_t)XYZZ_WORDS * ONES_THREADS;
     hipLaunchKernelGGL(k_tree256<F>, dim3(ONES_THREADS / 256), dim3(256), 0, stream, lvl0, ONES_THREADS, lvl1);
-    hipLaunchKernelGGL(k_tree256<F>, dim3(1), dim3(256), 0, stream, lvl1, ONES_THREADS / 256, wsum + (size_t)XYZZ_WORDS * pl.K);
+    hipLaunchKernelGGL(k_tree256<F>, dim3(1), dim3(256), 0, stream, lvl1, ONES_THREADS / 256, wsum + (size_t)XYZZ_WORDS * kout);
   }
   VZ_HIP_CHECK(hipGetLastError());
-  VZ_HIP_CHECK(hipMemcpyAsync(pinned_dst, wsum, 4 * (size_t)XYZZ_WORDS * (pl.K + (split_ones ? 1 : 0)), hipMemcpyDeviceToHost, stream));
+  VZ_HIP_CHECK(hipMemcpyAsync(pinned_dst, wsum, 4 * (size_t)XYZZ_WORDS * (kout + (split_ones ? 1 : 0)), hipMemcpyDeviceToHost, stream));
   return hipSuccess;
 }
 
@@ -387,23 +565,24 @@ Affine<typename C::Base> msm_finish(const MsmPlan& pl, const void* pinned) {
     return p;
   };
   XYZZ<FS> acc = XYZZ<FS>::identity();
-  for (int w = pl.K - 1; w >= 0; w--) {
-    for (int k = 0; k < pl.c; k++) acc = dbl(acc);
+  const int kout = pl.tabled ? 1 : pl.K;
+  for (int w = kout - 1; w >= 0; w--) {
+    if (!pl.tabled) for (int k = 0; k < pl.c; k++) acc = dbl(acc);
     add_full(acc, host_point(w));
   }
-  if (pl.split_ones) add_full(acc, host_point(pl.K));
+  if (pl.split_ones) add_full(acc, host_point(kout));
   return to_affine(acc);
 }
 
 template <class C>
 hipError_t msm_run(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_bases, const uint32_t* d_scalars, size_t n,
                    int scalars_mont, int c_override, Affine<typename C::Base>* out_affine_mont, MsmStats* stats,
-                   hipEvent_t* ev /* 7 events or nullptr */, int split_ones) {
+                   hipEvent_t* ev /* 7 events or nullptr */, int split_ones, const BaseTables* tb) {
   typedef typename C::Base FS;
   if (n == 0) { out_affine_mont->x = FS::zero(); out_affine_mont->y = FS::zero(); return hipSuccess; }
   if (!ws.host_pinned) VZ_HIP_CHECK(hipHostMalloc(&ws.host_pinned, 4 * XYZZ_WORDS * MSM_MAX_WINDOWS));
   MsmPlan pl;
-  VZ_HIP_CHECK(msm_launch<C>(stream, ws, d_bases, d_scalars, n, scalars_mont, c_override, ws.host_pinned, &pl, ev, split_ones));
+  VZ_HIP_CHECK(msm_launch<C>(stream, ws, d_bases, d_scalars, n, scalars_mont, c_override, ws.host_pinned, &pl, ev, split_ones, tb));
   uint32_t h_tot[2] = {0, 0};
   if (stats) VZ_HIP_CHECK(hipMemcpyAsync(h_tot, ws.totals, 8, hipMemcpyDeviceToHost, stream));
   VZ_HIP_CHECK(hipStreamSynchronize(stream));

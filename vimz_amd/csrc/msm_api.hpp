@@ -35,11 +35,15 @@ struct MsmPlan {
   uint32_t nbw;     // buckets per window = 2^(c-1)
   uint32_t nb;      // total buckets
   int split_ones;   // unit scalars summed separately (window_sums[K])
+  int tabled;       // window tables: one bucket set, one window sum, no Horner
 };
+
+// Precomputed window tables of a commitment key: d[j][i] = 2^(c j) * P_i, affine internal form, row length n_total.
+struct BaseTables { const uint32_t* d; size_t n_total; size_t offset; int c, K; };
 
 static inline MsmPlan msm_plan(size_t n, int scalar_bits, int c_override) {
   MsmPlan p;
-  p.split_ones = 0;
+  p.split_ones = 0; p.tabled = 0;
   int c = c_override;
   if (c <= 0) {
     // Measured on MI355X (profiles/r01_msm_phases.txt): k_accum is throughput-bound (~n*K mixed adds) while
@@ -65,6 +69,8 @@ struct MsmWorkspace {  // device buffers, grown on demand and reused across call
   void* partial = nullptr;         // max_subs * sizeof(XYZZ)
   void* window_sums = nullptr;     // K * sizeof(XYZZ)
   uint32_t* totals = nullptr;      // [0] = total subs
+  uint32_t* block_hist = nullptr;  // [256][nb] per-workgroup histograms of the LDS counting sort
+  size_t cap_block_hist = 0;
   void* ones_partial = nullptr;    // (16384 + 64) XYZZ partial sums of the unit-scalar path
   uint32_t* heavy = nullptr;       // [0] = count, then ids of buckets with many sub-buckets
   static constexpr uint32_t HEAVY_CAP = 65536;
@@ -89,13 +95,20 @@ struct MsmWorkspace {  // device buffers, grown on demand and reused across call
     if (!window_sums) VZ_HIP_CHECK(hipMalloc(&window_sums, 4 * XYZZ_WORDS * MSM_MAX_WINDOWS));
     if (!totals) VZ_HIP_CHECK(hipMalloc(&totals, 64));
     if (!heavy) VZ_HIP_CHECK(hipMalloc(&heavy, 4 * (HEAVY_CAP + 1)));
-    if (!ones_partial) VZ_HIP_CHECK(hipMalloc(&ones_partial, 4 * (size_t)XYZZ_WORDS * (16384 + 64)));
+    if (!ones_partial) VZ_HIP_CHECK(hipMalloc(&ones_partial, 4 * (size_t)XYZZ_WORDS * (16384 + 64 + 512)));
     if (!host_pinned) VZ_HIP_CHECK(hipHostMalloc(&host_pinned, 4 * XYZZ_WORDS * MSM_MAX_WINDOWS));
+    return hipSuccess;
+  }
+  hipError_t reserve_block_hist(size_t words) {
+    if (words <= cap_block_hist) return hipSuccess;
+    hipFree(block_hist); block_hist = nullptr; cap_block_hist = 0;
+    VZ_HIP_CHECK(hipMalloc(&block_hist, 4 * words));
+    cap_block_hist = words;
     return hipSuccess;
   }
   void release() {
     hipFree(counts); hipFree(cursor); hipFree(bucket_off); hipFree(sub_off); hipFree(sorted);
-    hipFree(sub_bucket); hipFree(sub_k); hipFree(partial); hipFree(window_sums); hipFree(totals); hipFree(heavy); hipFree(ones_partial);
+    hipFree(sub_bucket); hipFree(sub_k); hipFree(partial); hipFree(window_sums); hipFree(totals); hipFree(heavy); hipFree(ones_partial); hipFree(block_hist);
     if (host_pinned) hipHostFree(host_pinned);
     *this = MsmWorkspace();
   }
@@ -106,12 +119,15 @@ struct MsmStats { int c, K; uint32_t subs, entries; float ms[6]; };  // ms: hist
 // Defined in msm.hpp; explicitly instantiated per curve in msm_inst_*.hip.
 template <class C>
 hipError_t msm_launch(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_bases, const uint32_t* d_scalars, size_t n,
-                      int scalars_mont, int c_override, void* pinned_dst, MsmPlan* plan_out, hipEvent_t* ev, int split_ones);
+                      int scalars_mont, int c_override, void* pinned_dst, MsmPlan* plan_out, hipEvent_t* ev, int split_ones,
+                      const BaseTables* tb = nullptr);
+template <class C>
+hipError_t build_tables(hipStream_t stream, const uint32_t* d_bases, size_t n, int c, int K, uint32_t* d_tables);
 template <class C>
 Affine<typename C::Base> msm_finish(const MsmPlan& pl, const void* pinned);
 template <class C>
 hipError_t msm_run(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_bases, const uint32_t* d_scalars, size_t n,
                    int scalars_mont, int c_override, Affine<typename C::Base>* out_affine_mont, MsmStats* stats,
-                   hipEvent_t* ev /* 7 events or nullptr */, int split_ones);
+                   hipEvent_t* ev /* 7 events or nullptr */, int split_ones, const BaseTables* tb = nullptr);
 
 }  // namespace vz

@@ -467,6 +467,7 @@ int vimz_prover_fold(vimz_prover* p, const uint64_t* step_inputs, size_t nsteps)
   }
   p->phase_s[PH_ZCHAIN] += now_s() - t0; p->phase_n[PH_ZCHAIN] += nsteps; p->phase_n[PH_WITNESS] += nsteps;
 
+  const BaseTables tbl = p->ck->tb(0);
   // ---- 1. producer: one batch on stream B ------------------------------------------------------------------------
   const size_t pin_stride = 4 * (size_t)XYZZ_WORDS * MSM_MAX_WINDOWS;
   const size_t nbatches = (nsteps + B - 1) / B;
@@ -492,7 +493,7 @@ int vimz_prover_fold(vimz_prover* p, const uint64_t* step_inputs, size_t nsteps)
     for (size_t r = 0; r < rows; r++) {
       const uint32_t* Zi = bb.Z + 8 * r * nw;
       launch_spmv(p, sb, Zi, bb.az + 8 * r * nc, bb.bz + 8 * r * nc, bb.cz + 8 * r * nc);
-      P_TRY(msm_launch<BnG1>(sb, p->wsB, p->ck->d, Zi + 8 * (size_t)aux0, p->n_aux, 1, 0, (char*)bb.pin + r * pin_stride, &p->planB, nullptr, 1));
+      P_TRY(msm_launch<BnG1>(sb, p->wsB, p->ck->d, Zi + 8 * (size_t)aux0, p->n_aux, 1, 0, (char*)bb.pin + r * pin_stride, &p->planB, nullptr, 1, p->ck->tables ? &tbl : nullptr));
       P_TRY(hipEventRecord(bb.ev[r], sb));
     }
     return VIMZ_OK;
@@ -534,7 +535,7 @@ int vimz_prover_fold(vimz_prover* p, const uint64_t* step_inputs, size_t nsteps)
                          bb.az + 8 * r * nc, bb.bz + 8 * r * nc, bb.cz + 8 * r * nc, Fe::one(), p->T);
       P_TRY(hipGetLastError());
       if (!ctx->msm_ws.host_pinned) P_TRY(hipHostMalloc(&ctx->msm_ws.host_pinned, 4 * XYZZ_WORDS * MSM_MAX_WINDOWS));
-      P_TRY(msm_launch<BnG1>(s, ctx->msm_ws, p->ck->d, p->T, nc, 1, 0, ctx->msm_ws.host_pinned, &planT, ctx->profiling ? ctx->ev : nullptr, 0));
+      P_TRY(msm_launch<BnG1>(s, ctx->msm_ws, p->ck->d, p->T, nc, 1, 0, ctx->msm_ws.host_pinned, &planT, ctx->profiling ? ctx->ev : nullptr, 0, p->ck->tables ? &tbl : nullptr));
       if (ctx->profiling) P_TRY(hipMemcpyAsync(&ctx->last_msm.subs, ctx->msm_ws.totals, 8, hipMemcpyDeviceToHost, s));
       return VIMZ_OK;
     };

@@ -41,6 +41,11 @@ class Bases:
     def __init__(self, ctx, handle, curve, n):
         self.ctx, self.h, self.curve, self.n = ctx, handle, curve, n
 
+    def precompute(self, window_bits=0):
+        """Window tables in HBM (vimz_bases_precompute): later MSMs over this key share one bucket set."""
+        self.ctx._chk(self.ctx.lib.vimz_bases_precompute(self.ctx.h, self.h, window_bits))
+        return self
+
     def download(self, offset=0, n=None, form=L.FORM_CANONICAL):
         n = self.n - offset if n is None else n
         out = np.zeros((n, 8), dtype=np.uint64)
