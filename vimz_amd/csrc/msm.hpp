@@ -526,7 +526,7 @@ hipError_t msm_launch(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_ba
                      ws.totals, partial, ws.sub_bucket, ws.sub_k);
   VZ_EV(4);
   hipLaunchKernelGGL(k_combine<F>, dim3((pl.nb + TB - 1) / TB), dim3(TB), 0, stream, partial, ws.sub_off, pl.nb, ws.heavy, MsmWorkspace::HEAVY_CAP);
-  hipLaunchKernelGGL(k_combine_heavy<F>, dim3(64), dim3(256), 0, stream, partial, ws.sub_off, ws.heavy, MsmWorkspace::HEAVY_CAP);
+  hipLaunchKernelGGL(k_combine_heavy<F>, dim3(1024), dim3(256), 0, stream, partial, ws.sub_off, ws.heavy, MsmWorkspace::HEAVY_CAP);
   VZ_EV(5);
   const unsigned T = pl.nbw < 256 ? pl.nbw : 256;
   uint32_t* wsum = reinterpret_cast<uint32_t*>(ws.window_sums);
