@@ -132,6 +132,10 @@ int vimz_circuit_build(int transformation, int width, int width2, int rows_in, i
                        vimz_circuit** out);
 void vimz_circuit_free(vimz_circuit* c);
 const char* vimz_circuit_last_error(void);
+/* iden3 binary formats: load a circom-built `.r1cs` (BN254 Fr, as many public outputs as inputs — a Nova step circuit), and
+ * read a `.wtns`.  A loaded circuit has no witness program; fold it with vimz_prover_fold_witness. */
+int vimz_circuit_load_r1cs(const uint8_t* data, size_t len, vimz_circuit** out);
+int vimz_wtns_load(const uint8_t* data, size_t len, uint64_t* out, size_t cap_elems, size_t* n_out);
 #define VIMZ_CIRCUIT_INFO_LEN 16
 /* info = {wires, constraints (incl. linear), linear constraints, len_z, private inputs, nnz A, nnz B, nnz C,
  *         dictionary size, decomposition groups, lane groups, lane instructions, lane rows, hash jobs, chains, field ops} */
@@ -173,6 +177,9 @@ int vimz_prover_reset(vimz_prover* p, const uint64_t* z0);
 /* step_inputs: nsteps x private-input-count canonical elements in the per-step order of
  * vimz/src/nova_snark_backend/input.rs:57-96.  Returns VIMZ_ERR_UNSAT if a row violates the step relation. */
 int vimz_prover_fold(vimz_prover* p, const uint64_t* step_inputs, size_t nsteps);
+/* Same fold, but the witnesses come from outside (circom's generator): witnesses = nsteps x wires canonical elements in
+ * iden3 wire order; step i's public inputs must equal step i-1's public outputs (checked). */
+int vimz_prover_fold_witness(vimz_prover* p, const uint64_t* witnesses, size_t nsteps);
 /* verify_folded_proof (folding.rs:45-56): 0 = accepted; bit0 relation, bit1 comm_W, bit2 comm_E, bit3 running products */
 int vimz_prover_verify(vimz_prover* p, uint32_t* result);
 int vimz_prover_instance(vimz_prover* p, uint64_t comm_W[8], uint64_t comm_E[8], uint64_t u[4], uint64_t* z_current, uint64_t* steps);

@@ -1,0 +1,82 @@
+"""iden3 `.r1cs` / `.wtns` readers: a circuit written out in circom's binary format and read back by the
+native loader is the same R1CS, and accepts the same witnesses."""
+import numpy as np
+import pytest
+
+from tests import _iden3
+from tests._oracle import r1cs_check, witness_execute
+from tests.test_circuits import step_inputs
+from vimz_amd.circuit import Circuit, wtns_load
+
+
+@pytest.fixture(scope="module")
+def hash_circuit():
+    return Circuit.for_resolution("hash", "HD")
+
+
+def _to_r1cs_bytes(c):
+    csr = [c.csr(m) for m in "ABC"]
+    return _iden3.write_r1cs(c.n_wires, c.len_z, c.len_z, c.n_priv, csr, c.export("DICT_CANON", np.uint64).reshape(-1, 4))
+
+
+def test_r1cs_round_trip(oracle, hash_circuit):
+    c = hash_circuit
+    loaded = Circuit.from_r1cs(_to_r1cs_bytes(c))
+    assert (loaded.n_wires, loaded.n_constraints, loaded.len_z, loaded.n_priv) == (c.n_wires, c.n_constraints, c.len_z, c.n_priv)
+    assert (loaded.nnz_a, loaded.nnz_b, loaded.nnz_c) == (c.nnz_a, c.nnz_b, c.nnz_c)
+    for m in "ABC":
+        a, b = c.csr(m), loaded.csr(m)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        da, db = c.export("DICT_CANON", np.uint64).reshape(-1, 4), loaded.export("DICT_CANON", np.uint64).reshape(-1, 4)
+        assert np.array_equal(da[a[2]], db[b[2]])                      # same coefficients, dictionary order may differ
+    z0, inputs = step_inputs("hash")
+    st, wires, _ = witness_execute(oracle, c, z0, inputs[0])
+    assert r1cs_check(oracle, loaded, wires) == -1
+    bad = wires.copy(); bad[-3, 0] ^= np.uint64(1)
+    assert r1cs_check(oracle, loaded, bad) != -1
+
+
+def test_wtns_round_trip(oracle, hash_circuit):
+    z0, inputs = step_inputs("hash")
+    _, wires, _ = witness_execute(oracle, hash_circuit, z0, inputs[0])
+    assert np.array_equal(wtns_load(_iden3.write_wtns(wires)), wires)
+
+
+def test_malformed_files_are_rejected():
+    from vimz_amd import _lib
+    with pytest.raises(_lib.VimzError):
+        Circuit.from_r1cs(b"r1cs" + b"\\x00" * 40)
+    with pytest.raises(_lib.VimzError):
+        wtns_load(b"nope")
+
+
+@pytest.mark.gpu
+def test_fold_external_witnesses_of_loaded_r1cs(oracle, hash_circuit):
+    """The drop-in seam for circom artefacts: .r1cs loaded, .wtns witnesses folded on the GPU, accumulator verifies."""
+    from vimz_amd import _lib, hip
+    from tests._oracle import from_limbs
+    c = hash_circuit
+    loaded = Circuit.from_r1cs(_to_r1cs_bytes(c))
+    z0, inputs = step_inputs("hash")
+    z, wits = list(z0), []
+    for i in range(5):
+        _, w, z = witness_execute(oracle, c, z, inputs[i])
+        wits.append(wtns_load(_iden3.write_wtns(w)))
+    ctx = hip.Context(0)
+    ck = ctx.bases_generate(_lib.CURVE_BN254_G1, 1 << 13)
+    P = hip.Prover(ctx, loaded, ck, max_batch=2)
+    try:
+        P.reset(z0)
+        P.fold_witness(np.stack(wits))
+        assert P.verify() == 0
+        inst = P.instance()
+        assert inst["steps"] == 5 and from_limbs(inst["z"]) == z
+        # a witness that does not continue the chain is refused
+        P.reset(z0)
+        with pytest.raises(_lib.VimzError):
+            P.fold_witness(np.stack([wits[1]]))
+        # the native-program path refuses a loaded circuit
+        with pytest.raises(_lib.VimzError):
+            P.fold(np.stack(inputs[:1]))
+    finally:
+        P.close(); ck.free(); ctx.close()

@@ -58,6 +58,31 @@ class Circuit:
     def for_resolution(cls, transformation, resolution="HD"):
         return cls(transformation, *default_shape(transformation, resolution))
 
+    @classmethod
+    def from_r1cs(cls, data):
+        """Load a circom-built iden3 `.r1cs` (bytes) — the analogue of load_r1cs (folding.rs:22).  The circuit has no
+        witness program: fold it with Prover.fold_witness."""
+        self = cls.__new__(cls)
+        self.lib = L.lib()
+        self.lib.vimz_circuit_last_error.restype = C.c_char_p
+        self.lib.vimz_circuit_export.restype = C.c_int64
+        self.lib.vimz_circuit_export.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+        self.lib.vimz_circuit_free.argtypes = [C.c_void_p]
+        self.lib.vimz_circuit_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        self.lib.vimz_circuit_load_r1cs.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p)]
+        self.transformation, self.t, self.shape = None, -1, (0, 0, 0, 0, 0)
+        h = C.c_void_p()
+        rc = self.lib.vimz_circuit_load_r1cs(bytes(data), len(data), C.byref(h))
+        if rc != L.OK:
+            raise L.VimzError(rc, self.lib.vimz_circuit_last_error().decode())
+        self.h = h
+        info = (C.c_uint64 * 16)()
+        self.lib.vimz_circuit_info(self.h, info)
+        (self.n_wires, self.n_constraints, self.n_linear, self.len_z, self.n_priv, self.nnz_a, self.nnz_b, self.nnz_c,
+         self.n_dict, self.n_decomp, self.n_lane_groups, self.n_lane_instr, self.n_lane_rows, self.n_jobs, self.n_chains,
+         self.n_fops) = [int(x) for x in info]
+        return self
+
     def export(self, what, dtype=np.uint8):
         n = self.lib.vimz_circuit_export(self.h, CX[what], None, 0)
         if n < 0:
@@ -80,3 +105,16 @@ class Circuit:
             self.close()
         except Exception:
             pass
+
+
+def wtns_load(data):
+    """Parse an iden3 `.wtns` (bytes) -> (n, 4) uint64 canonical witness."""
+    lib = L.lib()
+    lib.vimz_wtns_load.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    n = C.c_size_t()
+    rc = lib.vimz_wtns_load(bytes(data), len(data), None, 0, C.byref(n))
+    if rc != L.OK:
+        raise L.VimzError(rc, "vimz_wtns_load")
+    out = np.zeros((n.value, 4), dtype=np.uint64)
+    lib.vimz_wtns_load(bytes(data), len(data), out.ctypes.data_as(C.c_void_p), n.value, C.byref(n))
+    return out

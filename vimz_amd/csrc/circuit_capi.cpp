@@ -2,6 +2,7 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <algorithm>
 #include "../../include/vimz_hip.h"
 #include "circuit/circuits.hpp"
 #include "circuit_handle.hpp"
@@ -10,6 +11,16 @@ using namespace vz;
 using namespace vz::cb;
 
 static thread_local std::string g_circuit_err;
+
+namespace {
+struct Reader {
+  const uint8_t* p; size_t len, pos = 0; bool ok = true;
+  template <class T> T get() { T v{}; if (pos + sizeof(T) > len) { ok = false; return v; } memcpy(&v, p + pos, sizeof(T)); pos += sizeof(T); return v; }
+  const uint8_t* bytes(size_t n) { if (pos + n > len) { ok = false; return nullptr; } const uint8_t* r = p + pos; pos += n; return r; }
+};
+const uint8_t BN254_FR_LE[32] = {0x01, 0x00, 0x00, 0xf0, 0x93, 0xf5, 0xe1, 0x43, 0x91, 0x70, 0xb9, 0x79, 0x48, 0xe8, 0x33, 0x28,
+                                 0x5d, 0x58, 0x81, 0x81, 0xb6, 0x45, 0x50, 0xb8, 0x29, 0xa0, 0x31, 0xe1, 0x72, 0x4e, 0x64, 0x30};
+}  // namespace
 
 extern "C" {
 
@@ -79,6 +90,84 @@ int64_t vimz_circuit_export(const vimz_circuit* c, int what, void* buf, size_t c
   }
   if (buf && cap >= bytes && bytes) memcpy(buf, src, bytes);
   return (int64_t)bytes;
+}
+
+// ---- iden3 binary formats: what circom writes and nova_scotia::circom::reader::load_r1cs reads
+//      (vimz/src/nova_snark_backend/folding.rs:22).  A circom-built circuit loaded this way has no witness program: its
+//      witnesses come from circom's own generator (.wtns) and are folded with vimz_prover_fold_witness. -----------------
+
+int vimz_circuit_load_r1cs(const uint8_t* data, size_t len, vimz_circuit** out) {
+  if (!data || !out) { g_circuit_err = "vimz_circuit_load_r1cs: bad argument"; return VIMZ_ERR_INVALID; }
+  Reader R{data, len};
+  const uint8_t* magic = R.bytes(4);
+  if (!magic || memcmp(magic, "r1cs", 4) != 0 || R.get<uint32_t>() != 1) { g_circuit_err = "not an iden3 r1cs v1 file"; return VIMZ_ERR_INVALID; }
+  const uint32_t nsec = R.get<uint32_t>();
+  size_t hdr_pos = 0, con_pos = 0, con_size = 0;
+  for (uint32_t i = 0; i < nsec && R.ok; i++) {
+    const uint32_t type = R.get<uint32_t>(); const uint64_t size = R.get<uint64_t>();
+    if (type == 1) hdr_pos = R.pos; else if (type == 2) { con_pos = R.pos; con_size = size; }
+    R.bytes(size);
+  }
+  if (!R.ok || !hdr_pos || !con_pos) { g_circuit_err = "r1cs: missing header or constraint section"; return VIMZ_ERR_INVALID; }
+  R.pos = hdr_pos;
+  const uint32_t fs = R.get<uint32_t>();
+  const uint8_t* prime = R.bytes(32);
+  if (fs != 32 || !prime || memcmp(prime, BN254_FR_LE, 32) != 0) { g_circuit_err = "r1cs: field is not BN254 Fr"; return VIMZ_ERR_INVALID; }
+  const uint32_t n_wires = R.get<uint32_t>(), n_out = R.get<uint32_t>(), n_in = R.get<uint32_t>(), n_prv = R.get<uint32_t>();
+  R.get<uint64_t>();  // labels
+  const uint32_t n_con = R.get<uint32_t>();
+  if (!R.ok || n_out != n_in || 1 + n_out + n_in + n_prv > n_wires) { g_circuit_err = "r1cs: step circuits need as many public outputs as public inputs"; return VIMZ_ERR_INVALID; }
+  auto h = std::make_unique<vimz_circuit>();
+  h->transformation = -1; h->shape = StepShape{0, 0, 0, 0, 0};
+  h->build = std::make_unique<CircuitBuild>();
+  Builder& b = h->build->b;
+  b.n_wires = n_wires; b.len_z = n_out; b.n_priv = n_prv;
+  R.pos = con_pos;
+  const size_t con_end = con_pos + con_size;
+  for (uint32_t k = 0; k < n_con; k++) {
+    Csr* M[3] = {&b.A, &b.B, &b.C};
+    for (int m = 0; m < 3; m++) {
+      const uint32_t nt = R.get<uint32_t>();
+      LC lc; lc.t.reserve(nt);
+      for (uint32_t t = 0; t < nt && R.ok; t++) {
+        const uint32_t w = R.get<uint32_t>();
+        const uint8_t* c = R.bytes(32);
+        if (!c || w >= n_wires) { R.ok = false; break; }
+        Fe x; memcpy(x.v, c, 32);
+        lc.t.push_back({w, Fe::to_mont(x)});
+      }
+      std::sort(lc.t.begin(), lc.t.end(), [](const Term& a, const Term& c2) { return a.w < c2.w; });
+      b.push_row(*M[m], lc);
+    }
+    if (!R.ok || R.pos > con_end) { g_circuit_err = "r1cs: truncated constraint section"; return VIMZ_ERR_INVALID; }
+  }
+  *out = h.release();
+  return VIMZ_OK;
+}
+
+// .wtns -> n_out canonical elements (returns the witness length through n_out; copies when out != NULL and cap is enough)
+int vimz_wtns_load(const uint8_t* data, size_t len, uint64_t* out, size_t cap_elems, size_t* n_out) {
+  if (!data || !n_out) return VIMZ_ERR_INVALID;
+  Reader R{data, len};
+  const uint8_t* magic = R.bytes(4);
+  if (!magic || memcmp(magic, "wtns", 4) != 0) { g_circuit_err = "not an iden3 wtns file"; return VIMZ_ERR_INVALID; }
+  R.get<uint32_t>();  // version
+  const uint32_t nsec = R.get<uint32_t>();
+  uint32_t nw = 0; const uint8_t* vals = nullptr;
+  for (uint32_t i = 0; i < nsec && R.ok; i++) {
+    const uint32_t type = R.get<uint32_t>(); const uint64_t size = R.get<uint64_t>();
+    const size_t start = R.pos;
+    if (type == 1) {
+      const uint32_t fs = R.get<uint32_t>(); const uint8_t* prime = R.bytes(32);
+      if (fs != 32 || !prime || memcmp(prime, BN254_FR_LE, 32) != 0) { g_circuit_err = "wtns: field is not BN254 Fr"; return VIMZ_ERR_INVALID; }
+      nw = R.get<uint32_t>();
+    } else if (type == 2) vals = data + R.pos;
+    R.pos = start; R.bytes(size);
+  }
+  if (!R.ok || !vals || !nw || (size_t)(vals - data) + 32 * (size_t)nw > len) { g_circuit_err = "wtns: malformed"; return VIMZ_ERR_INVALID; }
+  *n_out = nw;
+  if (out && cap_elems >= nw) memcpy(out, vals, 32 * (size_t)nw);
+  return VIMZ_OK;
 }
 
 }  // extern "C"

@@ -424,8 +424,18 @@ static hipError_t grow(uint32_t** d, size_t* cap, size_t bytes) {
 //   1. per batch, on stream B: full witness generation, then per row (A,B,C)·z and the witness commitment;
 //      batch k+1 is produced while
 //   2. stream A folds batch k sequentially: cross term, MSM(T), challenge, fused fold.
+static int fold_core(vimz_prover* p, const uint64_t* step_inputs, const uint64_t* witnesses, size_t nsteps);
 int vimz_prover_fold(vimz_prover* p, const uint64_t* step_inputs, size_t nsteps) {
   if (!p || (!step_inputs && nsteps)) return VIMZ_ERR_INVALID;
+  if (p->circuit->build->b.zout.empty() && nsteps) return vz_fail(p->ctx, VIMZ_ERR_INVALID, "this circuit was loaded from an .r1cs and has no witness program: use vimz_prover_fold_witness");
+  return fold_core(p, step_inputs, nullptr, nsteps);
+}
+int vimz_prover_fold_witness(vimz_prover* p, const uint64_t* witnesses, size_t nsteps) {
+  if (!p || (!witnesses && nsteps)) return VIMZ_ERR_INVALID;
+  return fold_core(p, nullptr, witnesses, nsteps);
+}
+}  // extern "C"
+static int fold_core(vimz_prover* p, const uint64_t* step_inputs, const uint64_t* witnesses, size_t nsteps) {
   if (!nsteps) return VIMZ_OK;
   vimz_ctx* ctx = p->ctx;
   std::lock_guard<std::mutex> g(ctx->mu);
@@ -439,8 +449,23 @@ int vimz_prover_fold(vimz_prover* p, const uint64_t* step_inputs, size_t nsteps)
   for (auto& c : b.chains) (c.phase == 0 ? nA : nB)++;
   int rc;
 
-  // ---- 0. inputs, row hashes, IVC state chain ------------------------------------------------------------------
+  std::vector<Fe> zs((nsteps + 1) * p->len_z, Fe::zero());
+  for (uint32_t i = 0; i < p->len_z; i++) zs[i] = p->z_cur[i];
   double t0 = now_s();
+  if (witnesses) {
+    // external witnesses: the state chain is read off their public wires, and checked for continuity
+    for (size_t r = 0; r < nsteps; r++) {
+      const uint64_t* w = witnesses + 4 * r * nw;
+      for (uint32_t i = 0; i < p->len_z; i++) {
+        if (!fe_from_canon(w + 4 * (1 + p->len_z + i)).eq(zs[r * p->len_z + i])) {
+          char msg[128]; snprintf(msg, sizeof(msg), "witness %llu: step_in does not continue the IVC state", (unsigned long long)r);
+          return vz_fail(ctx, VIMZ_ERR_UNSAT, msg);
+        }
+        zs[(r + 1) * p->len_z + i] = fe_from_canon(w + 4 * (1 + i));
+      }
+    }
+  } else {
+  // ---- 0. inputs, row hashes, IVC state chain ------------------------------------------------------------------
   P_TRY(grow(&p->priv_all_d, &p->cap_priv_all, 32 * nsteps * (size_t)p->n_priv));
   P_TRY(grow(&p->zs_all_d, &p->cap_zs_all, 32 * (nsteps + 1) * (size_t)p->len_z));
   P_TRY(grow(&p->job_all_d, &p->cap_job_all, 32 * nsteps * jstride));
@@ -456,8 +481,6 @@ int vimz_prover_fold(vimz_prover* p, const uint64_t* step_inputs, size_t nsteps)
   P_TRY(hipMemcpyAsync(jobA.data(), p->job_all_d, 32 * nsteps * jstride, hipMemcpyDeviceToHost, s));
   P_TRY(hipStreamSynchronize(s));
   p->phase_s[PH_WITNESS] += now_s() - t0; t0 = now_s();
-  std::vector<Fe> zs((nsteps + 1) * p->len_z, Fe::zero());
-  for (uint32_t i = 0; i < p->len_z; i++) zs[i] = p->z_cur[i];
   host_state_chain(p, step_inputs, nsteps, jobA.data(), jstride, zs);
   {
     std::vector<Fe> zc(zs.size());
@@ -467,6 +490,7 @@ int vimz_prover_fold(vimz_prover* p, const uint64_t* step_inputs, size_t nsteps)
   }
   p->phase_s[PH_ZCHAIN] += now_s() - t0; p->phase_n[PH_ZCHAIN] += nsteps; p->phase_n[PH_WITNESS] += nsteps;
 
+  }
   const BaseTables tbl = p->ck->tb(0);
   // ---- 1. producer: one batch on stream B ------------------------------------------------------------------------
   const size_t pin_stride = 4 * (size_t)XYZZ_WORDS * MSM_MAX_WINDOWS;
@@ -475,8 +499,12 @@ int vimz_prover_fold(vimz_prover* p, const uint64_t* step_inputs, size_t nsteps)
     auto& bb = p->buf[k & 1];
     const size_t first = k * B, rows = std::min(B, nsteps - first);
     hipStream_t sb = p->sB;
-    const uint32_t* priv = p->priv_all_d + 8 * first * p->n_priv;
     P_TRY(hipMemsetAsync(bb.status, 0, 4 * rows, sb));
+    if (witnesses) {
+      P_TRY(hipMemcpyAsync(bb.Z, witnesses + 4 * first * nw, 32 * rows * nw, hipMemcpyHostToDevice, sb));
+      launch_to_mont<Fr>(sb, bb.Z, rows * nw);
+    } else {
+    const uint32_t* priv = p->priv_all_d + 8 * first * p->n_priv;
     for (uint32_t gI = 0; gI < W.n_decomp; gI++) {
       const uint32_t total = (b.decomp[gI].nbits - 1) * b.decomp[gI].count;
       hipLaunchKernelGGL(k_wit_decomp, dim3((total + 255) / 256, (unsigned)rows), dim3(256), 0, sb, W, gI, priv, bb.Z, bb.status);
@@ -487,6 +515,7 @@ int vimz_prover_fold(vimz_prover* p, const uint64_t* step_inputs, size_t nsteps)
     if (nA) hipLaunchKernelGGL(k_wit_chains, dim3((nA + 3) / 4, (unsigned)rows), dim3(64), 0, sb, W, 0u, bb.Z, bb.job_out, (const uint32_t*)nullptr);
     if (nB) hipLaunchKernelGGL(k_wit_chains, dim3((nB + 3) / 4, (unsigned)rows), dim3(64), 0, sb, W, 1u, bb.Z, bb.job_out, (const uint32_t*)nullptr);
     if (p->n_fops) hipLaunchKernelGGL(k_wit_fops, dim3(((unsigned)rows + 63) / 64), dim3(64), 0, sb, W, bb.Z, bb.job_out, (uint32_t)rows);
+    }
     P_TRY(hipGetLastError());
     P_TRY(hipMemcpyAsync(bb.status_host, bb.status, 4 * rows, hipMemcpyDeviceToHost, sb));
     P_TRY(hipEventRecord(bb.wit_done, sb));
@@ -612,6 +641,7 @@ int vimz_prover_fold(vimz_prover* p, const uint64_t* step_inputs, size_t nsteps)
   return VIMZ_OK;
 }
 
+extern "C" {
 // IVC state chain only (no folding): zs_out[(nsteps+1) x len_z] canonical, starting from z_start.  One hash-only GPU pass
 // over the rows + the host pair-hash chain.  A multi-GPU driver uses it to find the state at which a row segment starts.
 int vimz_prover_state_chain(vimz_prover* p, const uint64_t* z_start, const uint64_t* step_inputs, size_t nsteps, uint64_t* zs_out) {

@@ -217,6 +217,13 @@ class Prover:
         a = _u64(step_inputs).reshape(-1, self.circuit.n_priv, 4)
         self.ctx._chk(self.ctx.lib.vimz_prover_fold(self.h, _ptr(a), a.shape[0]))
 
+    def fold_witness(self, witnesses):
+        """witnesses: (nsteps, n_wires, 4) uint64 canonical, iden3 wire order (e.g. parsed from circom's .wtns files)."""
+        a = _u64(witnesses).reshape(-1, self.circuit.n_wires, 4)
+        lib = self.ctx.lib
+        lib.vimz_prover_fold_witness.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        self.ctx._chk(lib.vimz_prover_fold_witness(self.h, _ptr(a), a.shape[0]))
+
     def verify(self):
         r = C.c_uint32()
         self.ctx._chk(self.ctx.lib.vimz_prover_verify(self.h, C.byref(r)))
