@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--transformation", default="contrast")
     ap.add_argument("--resolution", default="HD")
     ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--segments", type=int, default=3, help="row segments folded concurrently on each GPU (own context + streams each)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -89,12 +90,16 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group(backend="gloo")      # timing barrier / max / final gather only: the data path has no collective
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 1
+    device = local_rank % max(1, ndev)            # (several ranks may share a GPU when the node has fewer GPUs than ranks)
     if torch.cuda.is_available():
-        torch.cuda.set_device(local_rank)
+        torch.cuda.set_device(device)
 
     from vimz_amd import _lib, folding, hip
     from vimz_amd.distributed import segment_bounds
-    ctx = hip.Context(local_rank)
+    S = max(1, args.segments)
+    ctxs = [hip.Context(device) for _ in range(S)]
+    ctx = ctxs[0]
     t_setup = time.time()
     circuit, params = folding.prepare_folding(ctx, args.transformation, args.resolution)
     steps_all, z0 = build_inputs(args.transformation, args.resolution)
@@ -105,7 +110,8 @@ def main():
     glob = [i % n_rows for i in range(world * per_rank)]
     lo, hi = segment_bounds(world * per_rank, world)[rank]
     mine = np.ascontiguousarray(steps_all[glob[lo:hi]])
-    prover = hip.Prover(ctx, circuit, params.ck, max_batch=args.batch)
+    provers = [hip.Prover(c, circuit, params.ck, max_batch=args.batch) for c in ctxs]   # the key and the shape are shared, read-only
+    prover = provers[0]
     # IVC state at which this rank's segment starts (hash-only chain over the rows before it)
     if lo:
         zs = prover.state_chain(z0, steps_all[glob[:lo]])
@@ -114,30 +120,46 @@ def main():
         z_start = list(z0)
     setup_s = time.time() - t_setup
 
+    from vimz_amd.distributed import fold_local_segments
+
     def sync_all():
-        ctx.sync()
+        for c in ctxs:
+            c.sync()
         if torch.cuda.is_available():
             torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
 
-    prover.reset(z_start)
+    # warm-up: the rank's first W rows, folded with the same local segmentation and merged, exactly like the timed part
     if args.warmup:
-        prover.fold(mine[:args.warmup])
-    ctx.set_profiling(True)                # HIP events around every kernel of the MSM(T) launches on the context's stream
-    ctx.msm_profile_totals(reset=True)
+        fold_local_segments(provers, mine[:args.warmup], z_start)
+        z_timed = [int(a[0]) | int(a[1]) << 64 | int(a[2]) << 128 | int(a[3]) << 192 for a in prover.instance()["z"]]
+    else:
+        z_timed = z_start
+    warm_blob = prover.export() if args.warmup else None
+    for c in ctxs:
+        c.set_profiling(True)              # HIP events around every kernel of the MSM(T) launches on each context's stream
+        c.msm_profile_totals(reset=True)
     sync_all()
     t0 = time.time()
-    prover.fold(mine[args.warmup:])
+    fold_local_segments(provers, mine[args.warmup:], z_timed)      # K rows: S concurrent segments + S-1 on-device merges
     sync_all()
     dt = time.time() - t0
-    tot = ctx.msm_profile_totals()
-    ctx.set_profiling(False)
+    tots = [c.msm_profile_totals() for c in ctxs]
+    tot = {"ms": {k: sum(t["ms"][k] for t in tots) for k in tots[0]["ms"]}, "calls": sum(t["calls"] for t in tots),
+           "points": sum(t["points"] for t in tots), "entries": sum(t["entries"] for t in tots)}
+    for c in ctxs:
+        c.set_profiling(False)
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0])
     prof = prover.profile()
+    if warm_blob is not None:              # put the warm-up rows back in front of the timed ones: one accumulator per rank
+        timed_blob = prover.export()
+        prover.reset(z_start)
+        prover.merge(warm_blob)
+        prover.merge(timed_blob)
 
     # host-side sequential final fold of the row segments (outside the timed region; reported separately)
     t_ff = time.time()
@@ -182,7 +204,7 @@ def main():
             "dtype": "u32 limbs (256-bit Montgomery integers over BN254 Fr/Fq)",
             "data": "synthetic: rows of the reference sample image img2.png, contrast factor 1.4" + ("" if args.resolution == "HD" else f", upscaled to {args.resolution}"),
             "config": {"workload": f"{args.transformation}_step_{args.resolution}", "constraints": n_c, "wires": n_w, "nnz": nnz,
-                       "rows_per_rank": args.steps, "witness_batch": args.batch, "parallelism": f"{world} independent row segments + host final fold"},
+                       "rows_per_rank": args.steps, "segments_per_gpu": S, "witness_batch": args.batch, "parallelism": f"{world} independent row segments + host final fold"},
             "verified": bool(ok),
             "folded_steps_total": inst["steps"],
             "final_fold_s": final_fold_s if world > 1 else 0.0,
@@ -203,9 +225,11 @@ def main():
             out["cpu_baseline"] = {"value": sps, "unit": "steps/s", "cores": cores, "kind": "port",
                                    "sample": f"{n_cpu} folding steps of the same workload with the CPU oracle (C++ restatement, std::thread over all cores; not the Rust binary), {secs:.1f} s"}
         print(json.dumps(out), flush=True)
-    prover.close()
+    for p_ in provers:
+        p_.close()
     params.ck.free()
-    ctx.close()
+    for c in ctxs:
+        c.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -192,6 +192,8 @@ int vimz_prover_state_chain(vimz_prover* p, const uint64_t* z_start, const uint6
 size_t vimz_prover_export_size(const vimz_prover* p);
 int vimz_prover_export(vimz_prover* p, uint8_t* blob, size_t cap);
 int vimz_prover_merge(vimz_prover* p, const uint8_t* blob, size_t len);
+/* the same final fold between two provers on the same GPU (segments folded concurrently on one device), no host copy */
+int vimz_prover_merge_prover(vimz_prover* p, vimz_prover* src);
 /* seconds[9]/counts[9]: witness, state chain (host), spmv, msm(W), cross term, msm(T), RO (host), fold, host EC */
 int vimz_prover_profile(const vimz_prover* p, double seconds[9], uint64_t counts[9]);
 /* parity hooks: GPU witness generation alone (replaces the circom witness generator process) and

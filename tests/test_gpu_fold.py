@@ -235,3 +235,39 @@ def test_segment_merge_matches_oracle_prover(ctx, ck, oracle, circuits):
         assert res["verified"] and res["steps"] == 5
     finally:
         P.close()
+
+
+def test_concurrent_local_segments_match_oracle(ck, oracle, circuits):
+    """Three row segments folded concurrently on one GPU (own context + streams each, host threads) and merged on the
+    device equal the oracle-backed segment folds merged in the same order."""
+    from tests._oracle_prover import OracleProver
+    from vimz_amd import hip
+    from vimz_amd.distributed import fold_local_segments, segment_bounds
+    c = circuits["hash"]
+    z0, inputs = step_inputs("hash")
+    rows = np.stack(inputs[:7])
+    ctxs = [hip.Context(0) for _ in range(3)]
+    provers = [hip.Prover(cx, c, ck, max_batch=2) for cx in ctxs]
+    try:
+        merged = fold_local_segments(provers, rows, z0)
+        assert merged.verify() == 0
+        inst = merged.instance()
+        z_run, E_run = merged.running()
+    finally:
+        for p in provers:
+            p.close()
+        for cx in ctxs:
+            cx.close()
+    n_aux = c.n_wires - 1 - 2 * c.len_z
+    key = ck.download(0, max(n_aux, c.n_constraints))
+    acc, z = None, list(z0)
+    for lo, hi in segment_bounds(7, 3):
+        op = OracleProver(oracle, c, key)
+        op.reset(z); op.fold(rows[lo:hi]); z = op.z
+        if acc is None:
+            acc = op
+        else:
+            acc.merge(op.export())
+    assert inst["steps"] == 7 and from_limbs(inst["z"]) == acc.z and from_limbs(inst["u"])[0] == acc.u
+    assert tuple(from_limbs(inst["comm_W"])) == acc.cW and tuple(from_limbs(inst["comm_E"])) == acc.cE
+    assert np.array_equal(z_run, acc.Z) and np.array_equal(E_run, acc.E)

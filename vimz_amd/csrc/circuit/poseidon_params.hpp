@@ -2,6 +2,7 @@
 // (circomlib is a package.json dependency of the reference, circuits/package.json:7,
 // not vendored).  Host code; the tables are uploaded to the GPU for the witness kernels.
 #pragma once
+#include <mutex>
 #include <vector>
 #include "builder.hpp"
 
@@ -45,6 +46,8 @@ class GrainLfsr {
 
 inline const PoseidonTable& poseidon_table(int t) {
   static PoseidonTable cache[18];
+  static std::mutex mu;                       // several provers (one per row segment) may fold from different threads
+  std::lock_guard<std::mutex> guard(mu);
   PoseidonTable& P = cache[t];
   if (P.t == t) return P;
   P.t = t; P.rf = 8; P.rp = poseidon_rp(t);

@@ -709,6 +709,57 @@ int vimz_prover_export(vimz_prover* p, uint8_t* blob, size_t cap) {
 // Fold the exported relaxed instance (U2, W2) into this prover's running instance (U1, W1) — Nova's NIFS for two relaxed
 // instances:  T = Az1∘Bz2 + Az2∘Bz1 − u1·Cz2 − u2·Cz1,  E = E1 + r·T + r²·E2,  W = W1 + r·W2,  u = u1 + r·u2,
 // comm_W = comm_W1 + r·comm_W2,  comm_E = comm_E1 + r·comm_T + r²·comm_E2,  r = Poseidon(ro1, ro2, comm_T) mod 2^128.
+struct OtherInstance {       // a relaxed instance to fold in: host scalars + device vectors (Montgomery)
+  Fe u, ro, zdigest; G1Aff cW, cE; std::vector<Fe> z_cur, z0; uint64_t steps;
+  const uint32_t *Z, *E, *AZ, *BZ, *CZ;
+};
+
+// caller holds p->ctx->mu, has set the device, and guarantees the other instance's vectors are complete and stay valid
+static int merge_core(vimz_prover* p, const OtherInstance& o) {
+  vimz_ctx* ctx = p->ctx;
+  hipStream_t s = ctx->stream;
+  const size_t nw = p->n_wires, nc = p->n_c;
+  if (o.steps == 0) return VIMZ_OK;
+  if (p->steps == 0) {   // this prover is empty: adopt the other instance
+    P_TRY(hipMemcpyAsync(p->Zrun, o.Z, 32 * nw, hipMemcpyDeviceToDevice, s)); P_TRY(hipMemcpyAsync(p->E, o.E, 32 * nc, hipMemcpyDeviceToDevice, s));
+    P_TRY(hipMemcpyAsync(p->AZ, o.AZ, 32 * nc, hipMemcpyDeviceToDevice, s)); P_TRY(hipMemcpyAsync(p->BZ, o.BZ, 32 * nc, hipMemcpyDeviceToDevice, s));
+    P_TRY(hipMemcpyAsync(p->CZ, o.CZ, 32 * nc, hipMemcpyDeviceToDevice, s)); P_TRY(hipStreamSynchronize(s));
+    p->u = o.u; p->comm_W = o.cW; p->comm_E = o.cE; p->ro = o.ro; p->zdigest = o.zdigest; p->z_cur = o.z_cur; p->z0 = o.z0; p->steps = o.steps;
+    return VIMZ_OK;
+  }
+  hipLaunchKernelGGL(k_cross_term<Fr>, dim3(stream_grid(nc)), dim3(256), 0, s, nc, p->AZ, p->BZ, p->CZ, p->u, o.AZ, o.BZ, o.CZ, o.u, p->T);
+  P_TRY(hipGetLastError());
+  uint64_t pt[8];
+  int rc = vz_msm_device(ctx, p->ck, 0, p->T, nc, 1, 0, pt, VIMZ_FORM_MONTGOMERY);
+  if (rc) return rc;
+  G1Aff cT; memcpy(cT.x.v, pt, 32); memcpy(cT.y.v, pt + 4, 32);
+  Fe ab[4]; Fe a2[2]; ro_absorb_point(cT, a2);
+  ab[0] = p->ro; ab[1] = o.ro; ab[2] = a2[0]; ab[3] = a2[1];
+  p->ro = cb::poseidon_hash(ab, 4);
+  { Fe zz[2] = {p->zdigest, o.zdigest}; p->zdigest = cb::poseidon_hash(zz, 2); }
+  Fe rc_canon = Fe::from_mont(p->ro);
+  Fe r128 = Fe::zero(); for (int i = 0; i < 4; i++) r128.v[i] = rc_canon.v[i];
+  const Fe rm = Fe::to_mont(r128), rm2 = Fe::sqr(rm);
+  Fold5 f;
+  f.x1[0] = p->Zrun; f.x2[0] = o.Z; f.n[0] = nw;
+  f.x1[1] = p->E; f.x2[1] = p->T; f.n[1] = nc;
+  f.x1[2] = p->AZ; f.x2[2] = o.AZ; f.n[2] = nc;
+  f.x1[3] = p->BZ; f.x2[3] = o.BZ; f.n[3] = nc;
+  f.x1[4] = p->CZ; f.x2[4] = o.CZ; f.n[4] = nc;
+  hipLaunchKernelGGL(k_fold5<Fr>, dim3(2048), dim3(256), 0, s, f, rm);
+  hipLaunchKernelGGL(k_axpy_inplace<Fr>, dim3(stream_grid(nc)), dim3(256), 0, s, nc, p->E, rm2, o.E);
+  P_TRY(hipGetLastError());
+  Fe r2c = Fe::from_mont(rm2);   // r^2 as a canonical 256-bit scalar
+  G1 a = from_affine(p->comm_W); G1 t1 = scalar_mul(o.cW, r128.v, 128); add_full(a, t1); p->comm_W = to_affine(a);
+  G1 e = from_affine(p->comm_E); G1 t2 = scalar_mul(cT, r128.v, 128); add_full(e, t2);
+  G1 t3 = scalar_mul(o.cE, r2c.v, 256); add_full(e, t3); p->comm_E = to_affine(e);
+  p->u = Fe::add(p->u, Fe::mul(rm, o.u));
+  p->steps += o.steps;
+  p->z_cur = o.z_cur;     // segments are merged in row order: the merged chain ends where the later segment ends
+  P_TRY(hipStreamSynchronize(s));
+  return VIMZ_OK;
+}
+
 int vimz_prover_merge(vimz_prover* p, const uint8_t* blob, size_t len) {
   if (!p || !blob || len < sizeof(BlobHeader)) return VIMZ_ERR_INVALID;
   vimz_ctx* ctx = p->ctx;
@@ -720,59 +771,40 @@ int vimz_prover_merge(vimz_prover* p, const uint8_t* blob, size_t len) {
   hipStream_t s = ctx->stream;
   const size_t nw = p->n_wires, nc = p->n_c;
   const uint8_t* o = blob + sizeof(h);
-  Fe u2; memcpy(u2.v, o, 32); o += 32;
-  G1Aff cW2, cE2; memcpy(&cW2, o, 64); o += 64; memcpy(&cE2, o, 64); o += 64;
-  Fe ro2, zd2; memcpy(ro2.v, o, 32); o += 32; memcpy(zd2.v, o, 32); o += 32;
-  std::vector<Fe> zcur2(p->len_z), z02(p->len_z);
-  memcpy(zcur2.data(), o, 32 * p->len_z); o += 32 * p->len_z; memcpy(z02.data(), o, 32 * p->len_z); o += 32 * p->len_z;
-  if (h.steps == 0) return VIMZ_OK;   // nothing to fold in
+  OtherInstance oi; oi.steps = h.steps;
+  memcpy(oi.u.v, o, 32); o += 32;
+  memcpy(&oi.cW, o, 64); o += 64; memcpy(&oi.cE, o, 64); o += 64;
+  memcpy(oi.ro.v, o, 32); o += 32; memcpy(oi.zdigest.v, o, 32); o += 32;
+  oi.z_cur.resize(p->len_z); oi.z0.resize(p->len_z);
+  memcpy(oi.z_cur.data(), o, 32 * p->len_z); o += 32 * p->len_z; memcpy(oi.z0.data(), o, 32 * p->len_z); o += 32 * p->len_z;
+  if (h.steps == 0) return VIMZ_OK;
   // stage the other instance's vectors in the (idle) batch buffer 0: Z | E | AZ | BZ | CZ
   auto& bb = p->buf[0];
-  if (p->max_batch * nw < nw || false) return VIMZ_ERR_INVALID;
   uint32_t *Z2 = bb.Z, *E2 = p->az2, *AZ2 = bb.az, *BZ2 = bb.bz, *CZ2 = bb.cz;
   P_TRY(hipMemcpyAsync(Z2, o, 32 * nw, hipMemcpyHostToDevice, s)); o += 32 * nw;
   P_TRY(hipMemcpyAsync(E2, o, 32 * nc, hipMemcpyHostToDevice, s)); o += 32 * nc;
   P_TRY(hipMemcpyAsync(AZ2, o, 32 * nc, hipMemcpyHostToDevice, s)); o += 32 * nc;
   P_TRY(hipMemcpyAsync(BZ2, o, 32 * nc, hipMemcpyHostToDevice, s)); o += 32 * nc;
   P_TRY(hipMemcpyAsync(CZ2, o, 32 * nc, hipMemcpyHostToDevice, s)); o += 32 * nc;
-  if (p->steps == 0) {   // this prover is empty: adopt the other instance
-    P_TRY(hipMemcpyAsync(p->Zrun, Z2, 32 * nw, hipMemcpyDeviceToDevice, s)); P_TRY(hipMemcpyAsync(p->E, E2, 32 * nc, hipMemcpyDeviceToDevice, s));
-    P_TRY(hipMemcpyAsync(p->AZ, AZ2, 32 * nc, hipMemcpyDeviceToDevice, s)); P_TRY(hipMemcpyAsync(p->BZ, BZ2, 32 * nc, hipMemcpyDeviceToDevice, s));
-    P_TRY(hipMemcpyAsync(p->CZ, CZ2, 32 * nc, hipMemcpyDeviceToDevice, s)); P_TRY(hipStreamSynchronize(s));
-    p->u = u2; p->comm_W = cW2; p->comm_E = cE2; p->ro = ro2; p->zdigest = zd2; p->z_cur = zcur2; p->z0 = z02; p->steps = h.steps;
-    return VIMZ_OK;
-  }
-  hipLaunchKernelGGL(k_cross_term<Fr>, dim3(stream_grid(nc)), dim3(256), 0, s, nc, p->AZ, p->BZ, p->CZ, p->u, AZ2, BZ2, CZ2, u2, p->T);
-  P_TRY(hipGetLastError());
-  uint64_t pt[8];
-  int rc = vz_msm_device(ctx, p->ck, 0, p->T, nc, 1, 0, pt, VIMZ_FORM_MONTGOMERY);
-  if (rc) return rc;
-  G1Aff cT; memcpy(cT.x.v, pt, 32); memcpy(cT.y.v, pt + 4, 32);
-  Fe ab[4]; Fe a2[2]; ro_absorb_point(cT, a2);
-  ab[0] = p->ro; ab[1] = ro2; ab[2] = a2[0]; ab[3] = a2[1];
-  p->ro = cb::poseidon_hash(ab, 4);
-  { Fe zz[2] = {p->zdigest, zd2}; p->zdigest = cb::poseidon_hash(zz, 2); }
-  Fe rc_canon = Fe::from_mont(p->ro);
-  Fe r128 = Fe::zero(); for (int i = 0; i < 4; i++) r128.v[i] = rc_canon.v[i];
-  const Fe rm = Fe::to_mont(r128), rm2 = Fe::sqr(rm);
-  Fold5 f;
-  f.x1[0] = p->Zrun; f.x2[0] = Z2; f.n[0] = nw;
-  f.x1[1] = p->E; f.x2[1] = p->T; f.n[1] = nc;
-  f.x1[2] = p->AZ; f.x2[2] = AZ2; f.n[2] = nc;
-  f.x1[3] = p->BZ; f.x2[3] = BZ2; f.n[3] = nc;
-  f.x1[4] = p->CZ; f.x2[4] = CZ2; f.n[4] = nc;
-  hipLaunchKernelGGL(k_fold5<Fr>, dim3(2048), dim3(256), 0, s, f, rm);
-  hipLaunchKernelGGL(k_axpy_inplace<Fr>, dim3(stream_grid(nc)), dim3(256), 0, s, nc, p->E, rm2, (const uint32_t*)E2);
-  P_TRY(hipGetLastError());
-  Fe r2c = Fe::from_mont(rm2);   // r^2 as a canonical 256-bit scalar
-  G1 a = from_affine(p->comm_W); G1 t1 = scalar_mul(cW2, r128.v, 128); add_full(a, t1); p->comm_W = to_affine(a);
-  G1 e = from_affine(p->comm_E); G1 t2 = scalar_mul(cT, r128.v, 128); add_full(e, t2);
-  G1 t3 = scalar_mul(cE2, r2c.v, 256); add_full(e, t3); p->comm_E = to_affine(e);
-  p->u = Fe::add(p->u, Fe::mul(rm, u2));
-  p->steps += h.steps;
-  p->z_cur = zcur2;     // segments are merged in row order: the merged chain ends where the later segment ends
-  P_TRY(hipStreamSynchronize(s));
-  return VIMZ_OK;
+  oi.Z = Z2; oi.E = E2; oi.AZ = AZ2; oi.BZ = BZ2; oi.CZ = CZ2;
+  return merge_core(p, oi);
+}
+
+// Same final fold when both provers live on the same GPU (row segments folded concurrently on one device): the vectors
+// are read in place, no host round trip.  `src` is left unchanged.
+int vimz_prover_merge_prover(vimz_prover* p, vimz_prover* src) {
+  if (!p || !src || p == src) return VIMZ_ERR_INVALID;
+  if (p->n_wires != src->n_wires || p->n_c != src->n_c || p->len_z != src->len_z || p->ctx->device != src->ctx->device)
+    return vz_fail(p->ctx, VIMZ_ERR_INVALID, "vimz_prover_merge_prover: provers must share circuit shape and device");
+  vimz_ctx* ctx = p->ctx;
+  std::unique_lock<std::mutex> g1(p->ctx->mu, std::defer_lock), g2(src->ctx->mu, std::defer_lock);
+  if (p->ctx == src->ctx) g1.lock(); else std::lock(g1, g2);
+  P_TRY(hipSetDevice(ctx->device));
+  P_TRY(hipStreamSynchronize(src->ctx->stream));
+  OtherInstance oi;
+  oi.u = src->u; oi.ro = src->ro; oi.zdigest = src->zdigest; oi.cW = src->comm_W; oi.cE = src->comm_E; oi.z_cur = src->z_cur; oi.z0 = src->z0;
+  oi.steps = src->steps; oi.Z = src->Zrun; oi.E = src->E; oi.AZ = src->AZ; oi.BZ = src->BZ; oi.CZ = src->CZ;
+  return merge_core(p, oi);
 }
 
 // Running instance: comm_W, comm_E (affine canonical), u, X = (z_i, z_0 ...) — here X is read back from Zrun.

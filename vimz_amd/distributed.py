@@ -44,3 +44,34 @@ def fold_sharded(prover, step_inputs, z0, rank=0, world=1, dist=None, verify=Tru
     for r in range(1, world):          # host-side sequential final fold, in row order
         prover.merge(np.frombuffer(gathered[r], dtype=np.uint8))
     return {"steps": n, "verified": (prover.verify() == 0) if verify else None}
+
+
+def fold_local_segments(provers, step_inputs, z0, merge=True):
+    """One GPU, several row segments folded CONCURRENTLY: a single sequential chain leaves most of an MI355X idle (the MSM
+    tail is a latency chain), so a proof is split into len(provers) contiguous segments, each folded by its own prover
+    (own context = own streams) from its own host thread (ctypes releases the GIL), then merged in row order on the device
+    (vimz_prover_merge_prover).  Returns the merged prover (provers[0])."""
+    from concurrent.futures import ThreadPoolExecutor
+    n, S = len(step_inputs), len(provers)
+    bounds = segment_bounds(n, S)
+    starts = [list(z0)]
+    for lo, hi in bounds[:-1]:
+        zs = provers[0].state_chain(starts[-1], step_inputs[lo:hi])
+        starts.append([int(a[0]) | int(a[1]) << 64 | int(a[2]) << 128 | int(a[3]) << 192 for a in np.asarray(zs)[-1]])
+    for p, z in zip(provers, starts):
+        p.reset(z)
+
+    def work(i):
+        lo, hi = bounds[i]
+        if hi > lo:
+            provers[i].fold(step_inputs[lo:hi])
+
+    if S == 1:
+        work(0)
+    else:
+        with ThreadPoolExecutor(S) as ex:
+            list(ex.map(work, range(S)))
+    if merge:
+        for i in range(1, S):
+            provers[0].merge_prover(provers[i])
+    return provers[0]

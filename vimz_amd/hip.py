@@ -288,6 +288,12 @@ class Prover:
         self.ctx._chk(lib.vimz_prover_export(self.h, _ptr(buf), n))
         return buf
 
+    def merge_prover(self, other):
+        """Final fold with another prover on the same GPU (vimz_prover_merge_prover): no host round trip."""
+        lib = self.ctx.lib
+        lib.vimz_prover_merge_prover.argtypes = [C.c_void_p, C.c_void_p]
+        self.ctx._chk(lib.vimz_prover_merge_prover(self.h, other.h))
+
     def merge(self, blob):
         lib = self.ctx.lib
         lib.vimz_prover_merge.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
