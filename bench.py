@@ -77,7 +77,7 @@ def main():
     ap.add_argument("--transformation", default="contrast")
     ap.add_argument("--resolution", default="HD")
     ap.add_argument("--batch", type=int, default=64)
-    ap.add_argument("--segments", type=int, default=3, help="row segments folded concurrently on each GPU (own context + streams each)")
+    ap.add_argument("--segments", type=int, default=2, help="row segments folded concurrently on each GPU (own context + streams each)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
