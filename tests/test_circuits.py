@@ -105,3 +105,30 @@ def test_wrong_witness_wire_breaks_r1cs(oracle, circuits):
     wires2 = wires.copy()
     wires2[c.n_wires - 5, 0] ^= np.uint64(1)
     assert r1cs_check(oracle, c, wires2) != -1
+
+
+def synthetic_resize_2to1(width=16, steps=3, seed=5):
+    """Rows for the 2->1 resize relation used at 4K/8K (|a+b+c+d - 4t| <= 4): random pixels, exact box average."""
+    rng = np.random.default_rng(seed)
+    img = rng.integers(0, 256, size=(2 * steps, 10 * width, 3), dtype=np.uint8)
+    small = ((img[0::2, 0::2].astype(np.int64) + img[0::2, 1::2] + img[1::2, 0::2] + img[1::2, 1::2]) // 4).astype(np.uint8)
+    o, t = ie.compress_by_rows(img), ie.compress_by_rows(small)
+    return [0, 0], [np.concatenate([o[2 * i:2 * i + 2].reshape(-1, 4), t[i]]) for i in range(steps)]
+
+
+def test_resize_2to1_extension(oracle):
+    """Our extension for the 4K/8K configs (the reference only instantiates 3->2, resize_step.circom:81): builder, oracle
+    executor and semantic oracle agree, and a wrong average is rejected."""
+    c = Circuit("resize", 16, 8, 2, 1, 0)
+    z, inputs = synthetic_resize_2to1()
+    for i in range(3):
+        st, wires, z_out = witness_execute(oracle, c, z, inputs[i])
+        assert st == 0 and r1cs_check(oracle, c, wires) == -1
+        ok, z_sem = oracle.step_eval(T_RESIZE, z, inputs[i], width=16, width2=8, rows_in=2, rows_out=1)
+        assert ok and z_sem == z_out
+        z = z_out
+    bad = inputs[0].copy()
+    bad[-1, 0] ^= np.uint64(0x20)
+    st, wires, _ = witness_execute(oracle, c, [0, 0], bad)
+    assert st == 1 or r1cs_check(oracle, c, wires) != -1
+    assert not oracle.step_eval(T_RESIZE, [0, 0], bad, width=16, width2=8, rows_in=2, rows_out=1)[0]

@@ -271,3 +271,24 @@ def test_concurrent_local_segments_match_oracle(ck, oracle, circuits):
     assert inst["steps"] == 7 and from_limbs(inst["z"]) == acc.z and from_limbs(inst["u"])[0] == acc.u
     assert tuple(from_limbs(inst["comm_W"])) == acc.cW and tuple(from_limbs(inst["comm_E"])) == acc.cE
     assert np.array_equal(z_run, acc.Z) and np.array_equal(E_run, acc.E)
+
+
+def test_resize_2to1_on_gpu(ctx, ck, oracle):
+    """The 4K/8K resize geometry (2 rows -> 1) at a small width: GPU witness bit-equal to the oracle executor, fold verifies."""
+    from tests.test_circuits import synthetic_resize_2to1
+    from vimz_amd import hip
+    c = Circuit("resize", 16, 8, 2, 1, 0)
+    z0, inputs = synthetic_resize_2to1(steps=4)
+    P = hip.Prover(ctx, c, ck, max_batch=3)
+    try:
+        P.reset(z0)
+        zw, zs, st = P.witness(np.stack(inputs[:3]))
+        assert not st.any()
+        z = list(z0)
+        for i in range(3):
+            _, want, z = witness_execute(oracle, c, z, inputs[i])
+            assert np.array_equal(zw[i], want)
+        P.fold(np.stack(inputs))
+        assert P.verify() == 0 and P.instance()["steps"] == 4
+    finally:
+        P.close()

@@ -1,21 +1,23 @@
 // Pippenger multi-scalar multiplication for gfx950 — replaces `cpu_best_multiexp` / `pasta_msm`
 // behind `CommitmentEngine::commit` in nova-snark 0.23.0 (SURVEY.md §8a rows M1/M2, §8b "MSM" seam).
 //
-// Pipeline (all on one HIP stream, no host round trip until the K window sums come back):
-//   1. k_hist      signed-digit recode of every scalar (window c bits, digits in [-2^(c-1), 2^(c-1)]),
-//                  histogram of (window, |digit|) buckets with global atomics.
-//   2. k_scan      one workgroup: exclusive scan of bucket sizes -> entry offsets, and of
-//                  ceil(size/SUB) -> sub-bucket offsets.  Large buckets (witness scalars are ~95 % bits
-//                  and bytes, so bucket "1" of window 0 can hold a third of all points) are split into
-//                  sub-buckets of at most SUB entries so no thread owns an unbounded chain.
-//   3. k_scatter   counting-sort scatter of (point index | sign) into bucket order.
-//   4. k_accum     one thread per sub-bucket: gathers its affine bases (64 B each, served from L2 /
-//                  Infinity Cache — the base table is reused by every window) and accumulates in XYZZ.
-//   5. k_combine   log2 passes folding the sub-bucket partials of each bucket pairwise.
-//   6. k_reduce    per window: chunked running sums + LDS tree -> Σ b·B_b.
-//   7. host        Horner over the K window sums (K·c doublings) and one inversion to affine.
-// Addition order inside a bucket depends on atomics, but the result is an exact group element, so
-// the affine output is bit-identical run to run and to the CPU oracle.
+// Pipeline (all on one HIP stream, no host round trip until the window sums come back):
+//   1. k_hist_lds / k_block_prefix   signed-digit recode of every scalar (window c bits, digits in [-2^(c-1), 2^(c-1)]);
+//                  per-workgroup LDS histograms of the (window, |digit|) buckets, then bucket totals and per-workgroup
+//                  offsets — no global atomics (k_hist / k_scatter with wave-aggregated global atomics remain as the
+//                  fallback for windows whose counters do not fit LDS).
+//   2. k_scan      one workgroup: exclusive scan of bucket sizes -> entry offsets, and of ceil(size/SUB) -> sub-bucket
+//                  offsets.  Buckets are split into sub-buckets of at most SUB entries so no thread owns a long chain.
+//   3. k_scatter_lds  counting-sort scatter of (point index | sign) into bucket order, ranks from LDS counters.
+//   4. k_accum     one thread per sub-bucket: gathers its affine bases (80 B each, from L2 / Infinity Cache — the key is
+//                  re-read by every window) and accumulates in XYZZ over the 9x29-bit coordinate field.
+//   5. k_combine (+ k_combine_heavy)  folds the sub-bucket partials of each bucket; hot buckets by a workgroup tree.
+//   6. k_reduce    per window: chunked running sums + LDS tree -> sum_b b*B_b.
+//      (unit scalars, when split: k_ones_partial + k_tree256 -> one extra "window sum")
+//   7. host        Horner over the K window sums (K*c doublings) and one inversion to affine (msm_finish).
+// Optional window tables (k_build_tables, vimz_bases_precompute): one bucket set for all windows, k_reduce_big1/2, no Horner.
+// Addition order inside a bucket is arbitrary, but the result is an exact group element, so the affine output is
+// bit-identical run to run and to the CPU oracle.
 #pragma once
 #include "msm_api.hpp"
 
@@ -243,8 +245,7 @@ template <class F>
 __global__ void __launch_bounds__(256) k_accum(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
                                                const uint32_t* __restrict__ bucket_off, const uint32_t* __restrict__ sub_off,
                                                uint32_t nb, const uint32_t* __restrict__ totals,
-                                               uint32_t* __restrict__ partial, uint32_t* __restrict__ sub_bucket,
-                                               uint32_t* __restrict__ sub_k) {
+                                               uint32_t* __restrict__ partial) {
   const uint32_t total = totals[0];
   uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= total) return;
@@ -265,7 +266,6 @@ __global__ void __launch_bounds__(256) k_accum(const uint32_t* __restrict__ base
     add_mixed(acc, q);
   }
   store_xyzz(partial, s, acc);
-  sub_bucket[s] = b; sub_k[s] = k;
 }
 
 // ---- unit scalars -------------------------------------------------------------------------------------------------
@@ -523,7 +523,7 @@ hipError_t msm_launch(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_ba
   uint32_t* partial = reinterpret_cast<uint32_t*>(ws.partial);
   const unsigned ga = (unsigned)((max_subs + TB - 1) / TB);
   hipLaunchKernelGGL(k_accum<F>, dim3(ga), dim3(TB), 0, stream, d_bases, ws.sorted, ws.bucket_off, ws.sub_off, pl.nb,
-                     ws.totals, partial, ws.sub_bucket, ws.sub_k);
+                     ws.totals, partial);
   VZ_EV(4);
   hipLaunchKernelGGL(k_combine<F>, dim3((pl.nb + TB - 1) / TB), dim3(TB), 0, stream, partial, ws.sub_off, pl.nb, ws.heavy, MsmWorkspace::HEAVY_CAP);
   hipLaunchKernelGGL(k_combine_heavy<F>, dim3(1024), dim3(256), 0, stream, partial, ws.sub_off, ws.heavy, MsmWorkspace::HEAVY_CAP);

@@ -64,8 +64,6 @@ struct MsmWorkspace {  // device buffers, grown on demand and reused across call
   uint32_t* bucket_off = nullptr;  // nb + 1
   uint32_t* sub_off = nullptr;     // nb + 1
   uint32_t* sorted = nullptr;      // K * n
-  uint32_t* sub_bucket = nullptr;  // max_subs
-  uint32_t* sub_k = nullptr;       // max_subs
   void* partial = nullptr;         // max_subs * sizeof(XYZZ)
   void* window_sums = nullptr;     // K * sizeof(XYZZ)
   uint32_t* totals = nullptr;      // [0] = total subs
@@ -88,8 +86,7 @@ struct MsmWorkspace {  // device buffers, grown on demand and reused across call
       hipFree(sorted); VZ_HIP_CHECK(hipMalloc(&sorted, 4 * entries)); cap_entries = entries;
     }
     if (subs > cap_subs) {
-      hipFree(sub_bucket); hipFree(sub_k); hipFree(partial);
-      VZ_HIP_CHECK(hipMalloc(&sub_bucket, 4 * subs)); VZ_HIP_CHECK(hipMalloc(&sub_k, 4 * subs));
+      hipFree(partial);
       VZ_HIP_CHECK(hipMalloc(&partial, 4 * XYZZ_WORDS * subs)); cap_subs = subs;
     }
     if (!window_sums) VZ_HIP_CHECK(hipMalloc(&window_sums, 4 * XYZZ_WORDS * MSM_MAX_WINDOWS));
@@ -108,7 +105,7 @@ struct MsmWorkspace {  // device buffers, grown on demand and reused across call
   }
   void release() {
     hipFree(counts); hipFree(cursor); hipFree(bucket_off); hipFree(sub_off); hipFree(sorted);
-    hipFree(sub_bucket); hipFree(sub_k); hipFree(partial); hipFree(window_sums); hipFree(totals); hipFree(heavy); hipFree(ones_partial); hipFree(block_hist);
+    hipFree(partial); hipFree(window_sums); hipFree(totals); hipFree(heavy); hipFree(ones_partial); hipFree(block_hist);
     if (host_pinned) hipHostFree(host_pinned);
     *this = MsmWorkspace();
   }
