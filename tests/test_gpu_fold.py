@@ -292,3 +292,30 @@ def test_resize_2to1_on_gpu(ctx, ck, oracle):
         assert P.verify() == 0 and P.instance()["steps"] == 4
     finally:
         P.close()
+
+
+@pytest.mark.parametrize("proof,image,op,kw", [("img2-contrast", "img2", "contrast", {"factor": 1.4}), ("img1-grayscale", "img1", "grayscale", {})])
+def test_full_image_fold_ends_in_the_references_committed_state(ctx, ck, proof, image, op, kw):
+    """All 720 rows of the reference's sample image folded on the GPU (two concurrent segments + on-device final fold):
+    the accumulator verifies and the IVC state equals the final state inside the reference's committed proof
+    (marketplace/proofs/*.proof, via tests/golden/kat.json)."""
+    from tests import _data
+    from vimz_amd import folding, hip, image_editor as ie
+    from vimz_amd.distributed import fold_local_segments
+    P = _data.kat()["proofs"][proof]
+    inp = ie.build_input(op, _data.load_image(image), **kw)
+    rows, z0 = folding.prepare_input(op, inp, "HD")
+    assert len(rows) == P["steps"] == 720 and z0 == [int(v) for v in P["z0"]]
+    c = Circuit.for_resolution(op, "HD")
+    ctx2 = hip.Context(0)
+    provers = [hip.Prover(ctx, c, ck, max_batch=32), hip.Prover(ctx2, c, ck, max_batch=32)]
+    try:
+        merged = fold_local_segments(provers, rows, z0)
+        assert merged.verify() == 0
+        inst = merged.instance()
+        assert inst["steps"] == 720
+        assert from_limbs(inst["z"]) == [int(v) for v in P["z_final"]]
+    finally:
+        for p in provers:
+            p.close()
+        ctx2.close()

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""End-to-end run of one transformation on the GPU, the way `vimz -b nova-snark -f <t>` sequences it
+(vimz/src/nova_snark_backend/mod.rs:22-80): prepare input -> prepare folding (circuit + key) -> fold every row -> verify.
+Prints the span times the reference logs ("Prepare input", "Prepare folding", "Fold input", "Verify folded proof").
+usage: e2e.py <transformation> <resolution> [segments]"""
+import json
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, __file__.rsplit("/tools/", 1)[0])
+import bench  # noqa: E402
+from vimz_amd import folding, hip  # noqa: E402
+from vimz_amd.distributed import fold_local_segments  # noqa: E402
+
+
+def main():
+    t, res = sys.argv[1], sys.argv[2]
+    S = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+    spans = {}
+    t0 = time.time()
+    rows, z0 = bench.build_inputs(t, res)
+    spans["Prepare input"] = time.time() - t0
+    t0 = time.time()
+    ctxs = [hip.Context(0) for _ in range(S)]
+    circuit, params = folding.prepare_folding(ctxs[0], t, res)
+    provers = [hip.Prover(c, circuit, params.ck, max_batch=64 if res == "HD" else 32) for c in ctxs]
+    spans["Prepare folding"] = time.time() - t0
+    t0 = time.time()
+    merged = fold_local_segments(provers, rows, z0)
+    for c in ctxs:
+        c.sync()
+    spans["Fold input"] = time.time() - t0
+    t0 = time.time()
+    ok = merged.verify() == 0
+    spans["Verify folded proof"] = time.time() - t0
+    inst = merged.instance()
+    print(json.dumps({"config": f"{t}_step_{res}", "steps": inst["steps"], "segments": S, "verified": ok, "spans_s": spans,
+                      "steps_per_s": inst["steps"] / spans["Fold input"], "total_s": sum(spans.values()),
+                      "final_state": [hex(int(a[0]) | int(a[1]) << 64 | int(a[2]) << 128 | int(a[3]) << 192) for a in inst["z"]]}))
+
+
+if __name__ == "__main__":
+    main()

@@ -259,11 +259,15 @@ __global__ void __launch_bounds__(256) k_accum(const uint32_t* __restrict__ base
   const uint32_t beg = bucket_off[b] + k * MSM_SUB;
   const uint32_t end = min(bucket_off[b + 1], beg + MSM_SUB);
   XYZZ<F> acc = XYZZ<F>::identity();
+  // software pipeline: the gather of entry e+1 (index, then 80-byte base) is in flight while entry e is added
+  uint32_t ent = beg < end ? sorted[beg] : 0u;
+  Affine<F> q = load_affine<F>(bases, ent & 0x7fffffffu);
   for (uint32_t e = beg; e < end; e++) {
-    uint32_t ent = sorted[e];
-    Affine<F> q = load_affine<F>(bases, ent & 0x7fffffffu);
+    const uint32_t ent_n = e + 1 < end ? sorted[e + 1] : ent;
+    const Affine<F> q_n = load_affine<F>(bases, ent_n & 0x7fffffffu);
     if ((ent >> 31) && !aff_is_identity(q)) q.y = F::neg(q.y);
     add_mixed(acc, q);
+    ent = ent_n; q = q_n;
   }
   store_xyzz(partial, s, acc);
 }
