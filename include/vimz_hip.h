@@ -116,7 +116,9 @@ int vimz_msm_vec_ex(vimz_ctx* ctx, const vimz_bases* bases, size_t base_offset, 
  *      reads at vimz/src/nova_snark_backend/folding.rs:22 and the circom witness generator named by
  *      Config::witness_generator_file(), folding.rs:36).  Host-only: usable without a GPU. -------------------- */
 typedef struct vimz_circuit vimz_circuit;
-/* transformation ids follow the reference's enum order (vimz/src/transformation.rs:7-18) */
+/* (crop is built as R1CS + witness program for external / CPU-computed witnesses only: no GPU witness kernels yet, so
+ * vimz_prover_fold refuses it and vimz_prover_fold_witness is the way in.)
+ * transformation ids follow the reference's enum order (vimz/src/transformation.rs:7-18) */
 #define VIMZ_T_BLUR 0
 #define VIMZ_T_BRIGHTNESS 1
 #define VIMZ_T_CONTRAST 2
@@ -160,6 +162,7 @@ int vimz_circuit_info(const vimz_circuit* c, uint64_t info[VIMZ_CIRCUIT_INFO_LEN
 #define VIMZ_CX_CHAINS 16
 #define VIMZ_CX_FOPS 17
 #define VIMZ_CX_ZOUT 18
+#define VIMZ_CX_LC_TERMS 19
 /* returns the table's size in bytes (copies it when buf != NULL and cap is large enough), negative on error */
 int64_t vimz_circuit_export(const vimz_circuit* c, int what, void* buf, size_t cap);
 

@@ -176,7 +176,7 @@ long orc_first_unsat(int fid, size_t n, const u64* az, const u64* bz, const u64*
 // sizes[] = {n_wires, len_z, n_priv, n_decomp, n_groups, n_jobs, n_chains, n_fops}; tables are the raw POD arrays
 // exported by the product (format: witness.hpp).  z_wires_out: n_wires x 4 canonical; z_state_out: len_z x 4.
 int orc_witness_execute(const uint32_t* sizes, const void* decomp, const void* groups, const void* instr, const void* rows,
-                        const void* jobs, const void* chains, const void* fops, const void* zout,
+                        const void* jobs, const void* chains, const void* fops, const void* zout, const void* lc_terms, const u64* dict_canon,
                         const u64* z_in, const u64* priv, u64* z_wires_out, u64* z_state_out) {
   wp::Program P;
   P.n_wires = sizes[0]; P.len_z = sizes[1]; P.n_priv = sizes[2];
@@ -187,6 +187,7 @@ int orc_witness_execute(const uint32_t* sizes, const void* decomp, const void* g
   P.chains = (const wp::Chain*)chains; P.n_chains = sizes[6];
   P.fops = (const wp::FieldOp*)fops; P.n_fops = sizes[7];
   P.zout = (const wp::ZOut*)zout;
+  P.lc_terms = (const wp::LcTerm*)lc_terms; P.dict_canon = dict_canon;
   std::vector<BnFr> z, zo;
   int st = wp::execute(P, z_in, priv, z, zo);
   if (st == 2) return 2;

@@ -21,10 +21,12 @@ struct LaneRow { uint32_t src_wire, count; };
 struct LaneGroup { uint32_t lanes, pixels, colours, wire_base, slots, prog_off, prog_len, row_off, row_cnt, rows_out, row_stride_a, pad; };
 struct HashJob { uint32_t t, wire_base, out_wire, chain; ValRef in[8]; };
 struct Chain { uint32_t job_off, job_cnt, phase, pad; };
-struct FieldOp { uint32_t op, wire, bound, pad; ValRef a, b, c; };
+struct FieldOp { uint32_t op, wire, bound, early; ValRef a, b, c; };
+struct LcTerm { uint32_t wire, coef; };
 struct ZOut { ValRef ref; int64_t add; };
 
-enum { LOP_LDB = 1, LOP_LDZ, LOP_LI, LOP_ADD, LOP_SUB, LOP_MUL, LOP_MULI, LOP_ADDI, LOP_LEQ, LOP_SEL, LOP_BITS, LOP_EMIT, LOP_ROWSEL };
+enum { LOP_LDB = 1, LOP_LDZ, LOP_LI, LOP_ADD, LOP_SUB, LOP_MUL, LOP_MULI, LOP_ADDI, LOP_LEQ, LOP_SEL, LOP_BITS, LOP_EMIT, LOP_ROWSEL,
+       LOP_LANE, LOP_ANDI, LOP_SHRI, LOP_EQ, LOP_LDBR };
 
 struct Program {
   uint32_t n_wires, len_z, n_priv;
@@ -36,6 +38,7 @@ struct Program {
   const Chain* chains; size_t n_chains;
   const FieldOp* fops; size_t n_fops;
   const ZOut* zout;
+  const LcTerm* lc_terms; const u64* dict_canon;   // for FOP_LC (may be null when the program has none)
 };
 
 static inline BnFr fe_i64(long long v) { return BnFr::from_i64(v); }
@@ -140,6 +143,19 @@ static inline int execute(const Program& Pg, const u64* z_in_canon, const u64* p
             break;
           }
           case LOP_EMIT: z[G.wire_base + (uint32_t)I.imm * G.lanes + lane] = fe_i64(r[I.a]); break;
+          case LOP_LANE: r[I.d] = (long long)x + I.imm; break;
+          case LOP_ANDI: r[I.d] = r[I.a] & (long long)I.imm; break;
+          case LOP_SHRI: r[I.d] = r[I.a] >> I.imm; break;
+          case LOP_EQ: r[I.d] = r[I.a] == r[I.b] ? 1 : 0; break;
+          case LOP_LDBR: {
+            const LaneRow& R = Pg.rows[G.row_off + I.a];
+            const long long px = (long long)x * I.imm2 + I.imm + r[I.b];
+            if (px < 0 || px >= (long long)R.count * 10) { r[I.d] = 0; break; }
+            const u64* v = priv_limbs(R.src_wire + (uint32_t)(px / 10));
+            const int byte = (int)(px % 10) * 3;
+            r[I.d] = (long long)((v[byte / 8] >> (8 * (byte % 8))) & 0xff);
+            break;
+          }
           default: return 2;
         }
       }
@@ -156,7 +172,35 @@ static inline int execute(const Program& Pg, const u64* z_in_canon, const u64* p
       default: return BnFr::zero();
     }
   };
-  for (int phase = 0; phase < 2; phase++)
+  auto run_fops = [&](uint32_t early) -> int {
+    for (size_t f = 0; f < Pg.n_fops; f++) {
+      const FieldOp& F = Pg.fops[f];
+      if (F.early != early) continue;
+      if (F.op == 1) {  // IsZero: inv, out
+        BnFr in = value(F.a);
+        BnFr inv = in.is_zero() ? BnFr::zero() : in.inv();
+        BnFr out = BnFr::one() - in * inv;
+        z[F.wire] = inv; z[F.wire + 1] = out;
+        fop_out[f] = out;
+      } else if (F.op == 2) {  // Mux1 on full-width values
+        BnFr s = value(F.a), c0 = value(F.b), c1 = value(F.c);
+        BnFr prod = (c1 - c0) * s, out = prod + c0;
+        z[F.wire] = F.bound ? out : prod;
+        fop_out[f] = out;
+      } else if (F.op == 3) {  // value of a stored linear combination of wires
+        if (!Pg.lc_terms || !Pg.dict_canon) return 2;
+        BnFr acc = BnFr::zero();
+        for (uint32_t k = 0; k < F.b.idx; k++) {
+          const LcTerm& T = Pg.lc_terms[F.a.idx + k];
+          acc = acc + BnFr::from_canonical(Pg.dict_canon + 4 * (size_t)T.coef) * z[T.wire];
+        }
+        fop_out[f] = acc;
+      } else return 2;
+    }
+    return 0;
+  };
+  for (int phase = 0; phase < 2; phase++) {
+    if (phase == 1 && run_fops(1)) return 2;
     for (size_t c = 0; c < Pg.n_chains; c++) {
       const Chain& C = Pg.chains[c];
       if ((int)C.phase != phase) continue;
@@ -167,21 +211,8 @@ static inline int execute(const Program& Pg, const u64* z_in_canon, const u64* p
         job_out[C.job_off + k] = poseidon_job(J, in, cst, z);
       }
     }
-  for (size_t f = 0; f < Pg.n_fops; f++) {
-    const FieldOp& F = Pg.fops[f];
-    if (F.op == 1) {  // IsZero: inv, out
-      BnFr in = value(F.a);
-      BnFr inv = in.is_zero() ? BnFr::zero() : in.inv();
-      BnFr out = BnFr::one() - in * inv;
-      z[F.wire] = inv; z[F.wire + 1] = out;
-      fop_out[f] = out;
-    } else if (F.op == 2) {  // Mux1 on full-width values
-      BnFr s = value(F.a), c0 = value(F.b), c1 = value(F.c);
-      BnFr prod = (c1 - c0) * s, out = prod + c0;
-      z[F.wire] = F.bound ? out : prod;
-      fop_out[f] = out;
-    } else return 2;
   }
+  if (run_fops(0)) return 2;
   z_out.resize(Pg.len_z);
   for (uint32_t i = 0; i < Pg.len_z; i++) {
     z_out[i] = value(Pg.zout[i].ref) + fe_i64(Pg.zout[i].add);

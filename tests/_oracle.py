@@ -263,7 +263,10 @@ def witness_execute(orc, circuit, z_in, priv_limbs):
     zo = np.zeros((circuit.len_z, 4), dtype=np.uint64)
     priv = np.ascontiguousarray(priv_limbs, dtype=np.uint64)
     assert priv.size == 4 * circuit.n_priv
-    st = lib.orc_witness_execute(_p(sizes), *[_p(T[n]) for n in names], _p(to_limbs(z_in)), _p(priv), _p(z), _p(zo))
+    if "_lc" not in T:
+        T["_lc"] = np.ascontiguousarray(circuit.export("LC_TERMS"))
+        T["_dict"] = np.ascontiguousarray(circuit.export("DICT_CANON", np.uint64))
+    st = lib.orc_witness_execute(_p(sizes), *[_p(T[n]) for n in names], _p(T["_lc"]), _p(T["_dict"]), _p(to_limbs(z_in)), _p(priv), _p(z), _p(zo))
     return st, z, from_limbs(zo)
 
 

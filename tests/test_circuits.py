@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from tests import _data
-from tests._oracle import (T_BLUR, T_BRIGHTNESS, T_CONTRAST, T_GRAYSCALE, T_HASH, T_REDACT, T_RESIZE, T_SHARPNESS,
+from tests._oracle import (T_BLUR, T_BRIGHTNESS, T_CONTRAST, T_CROP, T_GRAYSCALE, T_HASH, T_REDACT, T_RESIZE, T_SHARPNESS,
                            from_limbs, r1cs_check, witness_execute)
 from vimz_amd import image_editor as ie
 from vimz_amd.circuit import Circuit
@@ -132,3 +132,44 @@ def test_resize_2to1_extension(oracle):
     st, wires, _ = witness_execute(oracle, c, [0, 0], bad)
     assert st == 1 or r1cs_check(oracle, c, wires) != -1
     assert not oracle.step_eval(T_RESIZE, [0, 0], bad, width=16, width2=8, rows_in=2, rows_out=1)[0]
+
+
+@pytest.fixture(scope="module")
+def crop_circuit():
+    return Circuit.for_resolution("crop", "HD")
+
+
+def test_crop_sizes_match_reference_compile_log(crop_circuit):
+    """BASELINE config #1 (crop_step at HD): the builder reproduces circom's counts exactly
+    (circuits/nova_snark/circuit_parameters.csv:5: 672 272 non-linear + 1 linear constraints, 671 633 wires)."""
+    c, ref = crop_circuit, KAT["circuit_sizes"]["crop"]
+    assert c.n_constraints - c.n_linear == ref["constraints"] == 672272 and c.n_linear == 1
+    assert c.n_wires == ref["wires"] == 671633
+    assert c.len_z == 3 and c.n_priv == ref["private_inputs"] == 128
+
+
+def test_crop_witness_and_semantics(oracle, crop_circuit):
+    """Crop followed literally from the Circom text (x = info bits 0-11 and `info + 1` advances x): the
+    executor's witness satisfies the R1CS and the state equals the oracle's literal restatement, inside and outside the
+    row window."""
+    c = crop_circuit
+    fx = _data.rows10("crop")
+    o = ie.hex_to_rows(fx["original"])
+    for info in (fx["info"], (150 << 24) | (100 << 12) | 37):      # row_index 200 (outside y..y+480? 100<=200<580: inside), then x = 37
+        z = [0, 0, info]
+        for i in range(2):
+            st, wires, z_out = witness_execute(oracle, c, z, o[i])
+            assert st == 0
+            assert r1cs_check(oracle, c, wires) == -1
+            ok, z_sem = oracle.step_eval(T_CROP, z, o[i], width=128, width2=64, crop_h=480)
+            assert ok and z_sem == z_out and z_out[2] == z[2] + 1
+            z = z_out
+    # a row index below the window leaves the cropped hash untouched
+    z = [5, 7, (50 << 24) | (100 << 12)]
+    st, wires, z_out = witness_execute(oracle, c, z, o[0])
+    assert st == 0 and r1cs_check(oracle, c, wires) == -1 and z_out[1] == 7
+    # x beyond the row: the Decoder has no solution
+    z = [0, 0, (200 << 24) | (100 << 12) | 1280]
+    st, wires, _ = witness_execute(oracle, c, z, o[0])
+    assert st == 1 or r1cs_check(oracle, c, wires) != -1
+    assert not oracle.step_eval(T_CROP, z, o[0], width=128, width2=64, crop_h=480)[0]

@@ -319,3 +319,38 @@ def test_full_image_fold_ends_in_the_references_committed_state(ctx, ck, proof, 
         for p in provers:
             p.close()
         ctx2.close()
+
+
+def test_crop_steps_fold_from_supplied_witnesses(oracle):
+    """BASELINE config #1 (crop_step HD, 672 k constraints): no GPU witness kernels yet, so the witnesses come from the
+    oracle's executor and go through the external-witness seam; SpMV, both MSMs, folds and verify run on the GPU."""
+    from tests import _data
+    from tests._oracle import T_CROP
+    from vimz_amd import hip, image_editor as ie
+    c = Circuit.for_resolution("crop", "HD")
+    fx = _data.rows10("crop")
+    o = ie.hex_to_rows(fx["original"])
+    z0 = [0, 0, fx["info"]]
+    z, wits = list(z0), []
+    for i in range(3):
+        st, w, z = witness_execute(oracle, c, z, o[i])
+        assert st == 0
+        wits.append(w)
+    cx = hip.Context(0)
+    key = cx.bases_generate(_lib.CURVE_BN254_G1, 1 << 20)
+    P = hip.Prover(cx, c, key, max_batch=2)
+    try:
+        P.reset(z0)
+        with pytest.raises(_lib.VimzError):
+            P.fold(np.stack(o[:1]))                     # refused: no GPU witness program for crop
+        P.fold_witness(np.stack(wits))
+        assert P.verify() == 0
+        inst = P.instance()
+        assert inst["steps"] == 3 and from_limbs(inst["z"]) == z
+        zz = list(z0)
+        for i in range(3):
+            ok, zz = oracle.step_eval(T_CROP, zz, o[i], width=128, width2=64, crop_h=480)
+            assert ok
+        assert zz == z
+    finally:
+        P.close(); key.free(); cx.close()

@@ -11,7 +11,7 @@ TRANSFORMATIONS = ["blur", "brightness", "contrast", "crop", "grayscale", "hash"
 T_ID = {n: i for i, n in enumerate(TRANSFORMATIONS)}
 
 CX = dict(A_ROWPTR=0, A_COL=1, A_COEF=2, B_ROWPTR=3, B_COL=4, B_COEF=5, C_ROWPTR=6, C_COL=7, C_COEF=8, DICT_MONT=9,
-          DICT_CANON=10, DECOMP=11, LANE_GROUPS=12, LANE_INSTR=13, LANE_ROWS=14, JOBS=15, CHAINS=16, FOPS=17, ZOUT=18)
+          DICT_CANON=10, DECOMP=11, LANE_GROUPS=12, LANE_INSTR=13, LANE_ROWS=14, JOBS=15, CHAINS=16, FOPS=17, ZOUT=18, LC_TERMS=19)
 
 # packed elements per row at each resolution (vimz/src/transformation.rs:93-101 rows; width = pixels / 10)
 RESOLUTION_WIDTH = {"SD": 64, "HD": 128, "FHD": 192, "4K": 384, "8K": 768}

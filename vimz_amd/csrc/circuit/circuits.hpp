@@ -9,7 +9,7 @@
 //   resize      circuits/src/resize_step.circom:10-112
 //   redact      circuits/src/redact_step.circom:7-26
 // State updates: circuits/src/utils/state.circom:11-79.  IVC state layouts: vimz/src/transformation.rs:25-50.
-// (crop — BASELINE config #1, "plumbing, no GPU" — is not built yet; see DESIGN.md scope table.)
+//   crop        circuits/src/crop_step.circom:9-120 (R1CS + witness program for the CPU executor; no GPU witness kernels yet)
 #pragma once
 #include "gadgets.hpp"
 
@@ -222,8 +222,85 @@ inline std::unique_ptr<CircuitBuild> build_step_circuit(int t, const StepShape& 
       b.zout[1] = ZOut{ValRef{REF_FOP, (uint32_t)b.fops.size() - 1}, 0};
       break;
     }
+    case T_CROP: {
+      // CropHash(widthOrig = w, widthCrop = S.width2, heightCrop = S.crop_height), followed literally
+      // (circuits/src/crop_step.circom:9-83, MultiplexerCrop :85-120; SURVEY.md F6: x = info bits 0-11, y = 12-23,
+      // row_index = 24-35, and `step_out.info <== step_in.info + 1`).  No GPU witness kernels yet (b.gpu_witness = false).
+      b.gpu_witness = false;
+      const int wc = S.width2, H = S.crop_height, W10 = 10 * w, C10 = 10 * wc;
+      auto d0 = g.decompress_row(P, w);
+      // --- CropInfoDecompressor + the row-range test: one lane
+      LC x_lc, y_lc, ri_lc, s_lc; uint32_t s_wire = 0;
+      g.lane_group(1, 1, 1, {}, [&](LaneCtx& L) {
+        LV info = L.zin(2);
+        std::vector<LC> bits = L.num2bits(info, 36);
+        LC xl, yl, rl;
+        if (!L.counting) for (int i = 0; i < 12; i++) { xl = xl + bits[i].scaled(fe_pow2(i)); yl = yl + bits[12 + i].scaled(fe_pow2(i)); rl = rl + bits[24 + i].scaled(fe_pow2(i)); }
+        LV y = L.andi(L.shri(info, 12), 0xfff, yl), ri = L.andi(L.shri(info, 24), 0xfff, rl);
+        LV gte = L.less_eq(12, y, ri);                                   // GreaterEqThan(12)(row_index, y)
+        LV lt = L.less_eq(12, ri, L.addi(y, H - 1));                     // LessThan(12)(row_index, y + heightCrop)
+        LV sel = L.mul(gte, lt);                                         // selector.s <== gte.out * lt.out
+        if (!L.counting) { x_lc = xl; y_lc = yl; ri_lc = rl; s_lc = sel.lc; s_wire = sel.lc.t[0].w; }
+      });
+      // --- Decoder(W10): out[k] <-- (x == k); out[k]*(x - k) === 0; sum(out) === 1 substitutes out[0]
+      std::vector<LC> dec(W10);
+      g.lane_group(W10 - 1, W10 - 1, 1, {}, [&](LaneCtx& L) {
+        LV info = L.zin(2);
+        LV xv = L.andi(info, 0xfff, x_lc);
+        LV k = L.lane_index(1);
+        LV o = L.eq_hint(xv, k);
+        L.enforce(o.lc, xv.lc - k.lc, LC());
+        if (!L.counting) dec[L.lane + 1] = o.lc;
+      });
+      { LC sum; for (int k = 1; k < W10; k++) sum = sum + dec[k]; dec[0] = LC::constant(Fe::one()) - sum; b.enforce(dec[0], x_lc, LC()); }
+      // --- EscalarProduct rows: out[h] = sum_k inp[k+h] * dec[k]   (one constraint per non-constant product)
+      std::vector<LC> mux_out(C10);
+      for (int h = 0; h < C10; h++) {
+        g.lane_group(W10 - h, W10 - h, 1, {d0}, [&](LaneCtx& L) {
+          LV inp = L.byte(0, h, 0);
+          LV info = L.zin(2);
+          LV xv = L.andi(info, 0xfff, LC());
+          LV k = L.lane_index(0);
+          LV dv = L.eq_value(xv, k, L.counting ? LC() : dec[L.lane]);
+          LV aux = L.mul(inp, dv);
+          if (!L.counting) mux_out[h] = mux_out[h] + aux.lc;
+        });
+      }
+      // --- CompressorCrop: Num2Bits(24) of every selected value
+      g.lane_group(C10, C10, 1, {d0}, [&](LaneCtx& L) {
+        LV info = L.zin(2);
+        LV xv = L.andi(info, 0xfff, LC());
+        LV v = L.byte_rel(0, xv, L.counting ? LC() : mux_out[L.lane]);
+        L.num2bits(v, 24);
+      });
+      // --- hash of the cropped row, conditional chaining, state update
+      std::vector<FV> cropped;
+      for (int i = 0; i < wc; i++) {
+        LC lc;
+        for (int j = 0; j < 10; j++) lc = lc + mux_out[10 * i + j].scaled(fe_pow2(24 * j));
+        FieldOp f; memset(&f, 0, sizeof(f)); f.op = FOP_LC; f.early = 1;
+        f.a = ValRef{0, (uint32_t)b.lc_terms.size()}; f.b = ValRef{0, (uint32_t)lc.t.size()};
+        for (auto& tm : lc.t) b.lc_terms.push_back(LcTerm{tm.w, b.coef_id(tm.c)});
+        b.fops.push_back(f);
+        cropped.push_back(FV{lc, ValRef{REF_FOP, (uint32_t)b.fops.size() - 1}});
+      }
+      g.begin_chain(1);
+      FV th = g.array_hash(cropped);
+      g.begin_chain(1);
+      FV c1 = g.pair_hash(c.zin(1), th);
+      FV c0 = c.zin(1);
+      b.enforce(c1.lc - c0.lc, s_lc, LC::wire(c.out_wire(1)) - c0.lc);      // Mux1, out is step_out.base.tran_hash
+      { FieldOp f; memset(&f, 0, sizeof(f)); f.op = FOP_MUX; f.wire = c.out_wire(1); f.bound = 1; f.a = ValRef{REF_WIRE, s_wire}; f.b = c0.ref; f.c = c1.ref;
+        b.fops.push_back(f); b.zout[1] = ZOut{ValRef{REF_FOP, (uint32_t)b.fops.size() - 1}, 0}; }
+      c.head_tail_to_output(c.zin(0), P, w, 0);
+      b.enforce(LC::constant(Fe::one()), LC::wire(c.in0 + 2) + LC::constant(Fe::one()), LC::wire(c.out_wire(2)));   // info + 1 (linear)
+      b.n_linear++;
+      b.zout[2] = ZOut{ValRef{REF_ZIN, 2}, 1};
+      (void)y_lc; (void)ri_lc;
+      break;
+    }
     default:
-      throw std::runtime_error("transformation not built (crop is out of scope this round)");
+      throw std::runtime_error("unknown transformation");
   }
   return cbp;
 }

@@ -330,6 +330,22 @@ struct Gadgets {
       LV v = sub(addi(a, (int32_t)((1 << n) - 1)), c);
       num2bits(v, n);
     }
+    // ---- crop support: lane index, masks/shifts, equality hint, register-relative byte load ----
+    LV lane_index(int32_t add) { LV r; r.reg = reg(); ins(LOP_LANE, r.reg, 0, 0, add, 0); if (!counting) r.lc = LC::constant_i((int64_t)x() + add); return r; }
+    LV andi(const LV& a, int32_t m, const LC& lc) { LV r; r.reg = reg(); ins(LOP_ANDI, r.reg, a.reg, 0, m, 0); r.lc = lc; return r; }   // caller supplies the LC
+    LV shri(const LV& a, int32_t k) { LV r; r.reg = reg(); ins(LOP_SHRI, r.reg, a.reg, 0, k, 0); return r; }                            // value only
+    // signal <-- (a == c): a hinted wire (no constraint of its own; the caller constrains it)
+    LV eq_hint(const LV& a, const LV& c) {
+      LV r; r.reg = reg(); ins(LOP_EQ, r.reg, a.reg, c.reg, 0, 0);
+      const uint32_t s = slot++; ins(LOP_EMIT, 0, r.reg, 0, (int32_t)s, 0);
+      if (!counting) r.lc = LC::wire(wire_of_slot(s));
+      return r;
+    }
+    LV eq_value(const LV& a, const LV& c, const LC& lc) { LV r; r.reg = reg(); ins(LOP_EQ, r.reg, a.reg, c.reg, 0, 0); r.lc = lc; return r; }
+    // byte (colour 0) of row `row` at pixel x + off(reg): value only, the caller supplies the LC
+    LV byte_rel(int row, const LV& off, const LC& lc) { LV r; r.reg = reg(); ins(LOP_LDBR, r.reg, row, off.reg, 0, 1); r.lc = lc; return r; }
+    void enforce(const LC& a, const LC& c, const LC& d) { if (!counting) b.enforce(a, c, d); }
+
     // Mux1: out = (c1 - c0) * s + c0
     LV mux(const LV& s, const LV& c0, const LV& c1) {
       LV d = sub(c1, c0);

@@ -41,7 +41,11 @@ enum : uint8_t {
   LOP_SEL,       // r[d] = r[a] ? r[b] : r[imm]
   LOP_BITS,      // bits 1..imm-1 of r[a] -> slots imm2.. ; r[a] must be in [0, 2^imm) else the row is UNSAT
   LOP_EMIT,      // wire slot imm = r[a] as a field element
-  LOP_ROWSEL     // r[d] = index of the lane's output row (resize: lane -> (row, x, colour))
+  LOP_ROWSEL,    // (reserved)
+  LOP_LANE,      // r[d] = x + imm                      (x = lane % pixels)
+  LOP_ANDI, LOP_SHRI,   // r[d] = r[a] & imm ; r[d] = r[a] >> imm
+  LOP_EQ,        // r[d] = (r[a] == r[b])
+  LOP_LDBR       // r[d] = byte: row a, colour 0, pixel = x*imm2 + imm + r[b]   (register-relative; 0 if out of range)
 };
 struct LaneInstr { uint8_t op, d, a, b; int32_t imm, imm2; };
 
@@ -70,13 +74,14 @@ struct HashJob {
 };
 struct Chain { uint32_t job_off, job_cnt, phase, pad; };  // phase 0 = A (row data only), 1 = B (needs step_in)
 
-enum : uint32_t { FOP_ISZERO = 1, FOP_MUX = 2 };
+enum : uint32_t { FOP_ISZERO = 1, FOP_MUX = 2, FOP_LC = 3 };
+struct LcTerm { uint32_t wire; uint32_t coef; };   // coef = index into the R1CS coefficient dictionary
 struct FieldOp {
   uint32_t op;
   uint32_t wire;        // ISZERO: inv wire (out wire = wire+1) ; MUX: product/out wire
   uint32_t bound;       // MUX: 1 if `wire` is the bound public output (holds the mux result), 0 if it holds (c1-c0)*s
-  uint32_t pad;
-  ValRef a, b, c;       // ISZERO: a = in ; MUX: a = s, b = c0, c = c1
+  uint32_t early;       // 1: evaluated before the phase-B hash chains (its value feeds them), 0: after all chains
+  ValRef a, b, c;       // ISZERO: a = in ; MUX: a = s, b = c0, c = c1 ; LC: value = sum of lc_terms[a.idx .. a.idx + b.idx)
 };
 
 struct ZOut { ValRef ref; int64_t add; };  // step_out[i] = value(ref) + add

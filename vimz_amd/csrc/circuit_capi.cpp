@@ -86,6 +86,7 @@ int64_t vimz_circuit_export(const vimz_circuit* c, int what, void* buf, size_t c
     case VIMZ_CX_CHAINS: vec(b.chains); break;
     case VIMZ_CX_FOPS: vec(b.fops); break;
     case VIMZ_CX_ZOUT: vec(b.zout); break;
+    case VIMZ_CX_LC_TERMS: vec(b.lc_terms); break;
     default: return VIMZ_ERR_INVALID;
   }
   if (buf && cap >= bytes && bytes) memcpy(buf, src, bytes);

@@ -334,6 +334,7 @@ static int witness_batch_locked(vimz_prover* p, const uint64_t* inputs, size_t r
 // status_out (optional): rows x uint32 (bit 0 = step relation unsatisfiable).
 int vimz_prover_witness(vimz_prover* p, const uint64_t* inputs, size_t rows, uint64_t* z_wires_out, uint64_t* zs_out, uint32_t* status_out) {
   if (!p || !inputs || rows == 0 || rows > p->max_batch) return vz_fail(p ? p->ctx : nullptr, VIMZ_ERR_INVALID, "vimz_prover_witness: bad argument");
+  if (!p->circuit->build->b.gpu_witness || p->circuit->build->b.zout.empty()) return vz_fail(p->ctx, VIMZ_ERR_INVALID, "vimz_prover_witness: this circuit has no GPU witness program");
   vimz_ctx* ctx = p->ctx;
   std::lock_guard<std::mutex> g(ctx->mu);
   P_TRY(hipSetDevice(ctx->device));
@@ -428,6 +429,7 @@ static int fold_core(vimz_prover* p, const uint64_t* step_inputs, const uint64_t
 int vimz_prover_fold(vimz_prover* p, const uint64_t* step_inputs, size_t nsteps) {
   if (!p || (!step_inputs && nsteps)) return VIMZ_ERR_INVALID;
   if (p->circuit->build->b.zout.empty() && nsteps) return vz_fail(p->ctx, VIMZ_ERR_INVALID, "this circuit was loaded from an .r1cs and has no witness program: use vimz_prover_fold_witness");
+  if (!p->circuit->build->b.gpu_witness && nsteps) return vz_fail(p->ctx, VIMZ_ERR_INVALID, "no GPU witness kernels for this step circuit (crop) yet: supply witnesses with vimz_prover_fold_witness");
   return fold_core(p, step_inputs, nullptr, nsteps);
 }
 int vimz_prover_fold_witness(vimz_prover* p, const uint64_t* witnesses, size_t nsteps) {
