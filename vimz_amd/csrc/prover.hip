@@ -497,9 +497,10 @@ static int fold_core(vimz_prover* p, const uint64_t* step_inputs, const uint64_t
   // ---- 1. producer: one batch on stream B ------------------------------------------------------------------------
   const size_t pin_stride = 4 * (size_t)XYZZ_WORDS * MSM_MAX_WINDOWS;
   const size_t nbatches = (nsteps + B - 1) / B;
+  const size_t Bk = (nsteps + nbatches - 1) / nbatches;     // even batches (85 rows -> 43 + 42, not 64 + 21): no short tail batch
   auto issue = [&](size_t k) -> int {
     auto& bb = p->buf[k & 1];
-    const size_t first = k * B, rows = std::min(B, nsteps - first);
+    const size_t first = k * Bk, rows = std::min(Bk, nsteps - first);
     hipStream_t sb = p->sB;
     P_TRY(hipMemsetAsync(bb.status, 0, 4 * rows, sb));
     if (witnesses) {
@@ -534,7 +535,7 @@ static int fold_core(vimz_prover* p, const uint64_t* step_inputs, const uint64_t
   if ((rc = issue(0))) return rc;
   for (size_t k = 0; k < nbatches; k++) {
     auto& bb = p->buf[k & 1];
-    const size_t first = k * B, rows = std::min(B, nsteps - first);
+    const size_t first = k * Bk, rows = std::min(Bk, nsteps - first);
     if (k + 1 < nbatches && (rc = issue(k + 1))) return rc;
     P_TRY(hipEventSynchronize(bb.wit_done));
     for (size_t r = 0; r < rows; r++) if (bb.status_host[r]) {
