@@ -354,3 +354,52 @@ def test_crop_steps_fold_from_supplied_witnesses(oracle):
         assert zz == z
     finally:
         P.close(); key.free(); cx.close()
+
+
+def test_fold_in_several_calls_equals_one_call(ctx, ck, circuits):
+    """Ragged use of the ABI: folding 0, 3 and then 4 more rows gives exactly the accumulator of one 7-row call."""
+    from vimz_amd import hip
+    c = circuits["grayscale"]
+    z0, inputs = step_inputs("grayscale")
+    rows = np.stack(inputs[:7])
+    A, B = hip.Prover(ctx, c, ck, max_batch=3), hip.Prover(ctx, c, ck, max_batch=5)
+    try:
+        A.reset(z0); A.fold(rows)
+        B.reset(z0); B.fold(rows[:0]); B.fold(rows[:3]); B.fold(rows[3:])
+        ia, ib = A.instance(), B.instance()
+        for k in ("comm_W", "comm_E", "u", "z"):
+            assert np.array_equal(ia[k], ib[k]), k
+        assert ia["steps"] == ib["steps"] == 7 and A.verify() == 0 and B.verify() == 0
+        za, ea = A.running(); zb, eb = B.running()
+        assert np.array_equal(za, zb) and np.array_equal(ea, eb)
+    finally:
+        A.close(); B.close()
+
+
+def test_largest_single_gpu_config_contrast_4k(oracle):
+    """BASELINE config #3 (contrast at 4K, width 384: 914 593 constraints): three rows of a synthetic 4K image fold, verify,
+    and track the oracle's step semantics."""
+    from tests import _data
+    from tests._oracle import T_CONTRAST
+    from vimz_amd import folding, hip, image_editor as ie
+    img = _data.load_image("img2")[:4]
+    img = np.repeat(np.repeat(img, 3, axis=0), 3, axis=1)[:3]          # 3 rows x 3840 px
+    inp = ie.build_input("contrast", img, factor=1.4)
+    rows = np.stack([np.concatenate([inp["original"][i], inp["transformed"][i]]) for i in range(3)])
+    c = Circuit.for_resolution("contrast", "4K")
+    assert c.n_constraints == 914593 and rows.shape[1] == c.n_priv == 768
+    cx = hip.Context(0)
+    key = cx.bases_generate(_lib.CURVE_BN254_G1, 1 << 20)
+    P = hip.Prover(cx, c, key, max_batch=2)
+    try:
+        z0 = [0, 0, 14]
+        P.reset(z0)
+        P.fold(rows)
+        assert P.verify() == 0
+        z = list(z0)
+        for i in range(3):
+            ok, z = oracle.step_eval(T_CONTRAST, z, rows[i], width=384)
+            assert ok
+        assert from_limbs(P.instance()["z"]) == z
+    finally:
+        P.close(); key.free(); cx.close()
