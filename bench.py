@@ -80,9 +80,13 @@ def main():
     ap.add_argument("--segments", type=int, default=2, help="row segments folded concurrently on each GPU (own context + streams each)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--proof-set", default="", help="comma-separated transformations: rank r proves proof_set[r %% len] (BASELINE config 5: independent proofs, replicas only)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
+    if args.proof_set:
+        ps = [t.strip() for t in args.proof_set.split(",") if t.strip()]
+        args.transformation = ps[rank % len(ps)]
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
@@ -163,7 +167,7 @@ def main():
 
     # host-side sequential final fold of the row segments (outside the timed region; reported separately)
     t_ff = time.time()
-    if world > 1:
+    if world > 1 and not args.proof_set:
         blob = prover.export()
         gathered = [None] * world if rank == 0 else None
         dist.gather_object(np.asarray(blob).tobytes(), gathered, dst=0)
@@ -171,7 +175,11 @@ def main():
             for r in range(1, world):
                 prover.merge(np.frombuffer(gathered[r], dtype=np.uint8))
     final_fold_s = time.time() - t_ff
-    ok = (prover.verify() == 0) if rank == 0 else True
+    ok = prover.verify() == 0 if (rank == 0 or args.proof_set) else True
+    if args.proof_set and dist is not None:      # independent proofs: every rank verifies its own; AND them
+        t = torch.tensor([1 if ok else 0], dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        ok = bool(int(t[0]))
     inst = prover.instance()
 
     if rank == 0:
@@ -204,7 +212,7 @@ def main():
             "dtype": "u32 limbs (256-bit Montgomery integers over BN254 Fr/Fq)",
             "data": "synthetic: rows of the reference sample image img2.png, contrast factor 1.4" + ("" if args.resolution == "HD" else f", upscaled to {args.resolution}"),
             "config": {"workload": f"{args.transformation}_step_{args.resolution}", "constraints": n_c, "wires": n_w, "nnz": nnz,
-                       "rows_per_rank": args.steps, "segments_per_gpu": S, "witness_batch": args.batch, "parallelism": f"{world} independent row segments + host final fold"},
+                       "rows_per_rank": args.steps, "segments_per_gpu": S, "witness_batch": args.batch, "parallelism": (f"{world} independent proofs ({args.proof_set}), replicas only" if args.proof_set else f"{world} independent row segments + host final fold")},
             "verified": bool(ok),
             "folded_steps_total": inst["steps"],
             "final_fold_s": final_fold_s if world > 1 else 0.0,
