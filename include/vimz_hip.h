@@ -204,6 +204,60 @@ int vimz_prover_profile(const vimz_prover* p, double seconds[9], uint64_t counts
 int vimz_prover_witness(vimz_prover* p, const uint64_t* inputs, size_t rows, uint64_t* z_wires_out, uint64_t* zs_out, uint32_t* status_out);
 int vimz_prover_spmv(vimz_prover* p, const uint64_t* z, uint64_t* az, uint64_t* bz, uint64_t* cz);
 
+/* ---- Nova IVC: RecursiveSNARK::{new, prove_step, verify} in full, with the augmented verifier circuits on the
+ *      BN254 / Grumpkin cycle (reference entry vimz/src/nova_snark_backend/folding.rs:27-56,
+ *      curves nova_snark_backend/mod.rs:19-20).  nova-snark 0.23.0's own circuit is not vendored: the circuits here
+ *      (vimz_amd/csrc/aug/) state the same relation — see DESIGN.md §5 — and are NOT byte-compatible with its proof object.
+ *
+ *      Per step: the step circuit's witness / commitment / (A,B,C)·z come from the batch producer exactly as in
+ *      vimz_prover_fold; the verifier circuit's ~7.6 k wires are computed on the host (as in the reference), committed and
+ *      multiplied on the GPU; the secondary circuit (7.6 k constraints over BN254 Fq, commitments on Grumpkin) is folded on
+ *      the GPU with the same kernels instantiated for that field/curve. ---------------------------------------------------- */
+typedef struct vimz_ivc vimz_ivc;
+/* ck_primary on BN254 G1 (>= max(wires, constraints) of the augmented step circuit), ck_secondary on Grumpkin (>= 8192). */
+int vimz_ivc_create(vimz_ctx* ctx, const vimz_circuit* step_circuit, const vimz_bases* ck_primary, const vimz_bases* ck_secondary,
+                    size_t max_batch, vimz_ivc** out);
+void vimz_ivc_free(vimz_ivc* v);
+int vimz_ivc_reset(vimz_ivc* v, const uint64_t* z0);
+/* same inputs as vimz_prover_fold / vimz_prover_fold_witness */
+int vimz_ivc_fold(vimz_ivc* v, const uint64_t* step_inputs, size_t nsteps);
+int vimz_ivc_fold_witness(vimz_ivc* v, const uint64_t* witnesses, size_t nsteps);
+/* RecursiveSNARK::verify: both output hashes, is_sat_relaxed of both running instances, is_sat of the last secondary instance,
+ * every commitment re-opened.  result: 0 = accepted; bit 0/1 hash of the primary/secondary chain; bit 2 primary relaxed relation;
+ * bit 3 primary comm_W; bit 4 primary comm_E; bit 5 secondary relaxed relation; bit 6/7 secondary comm_W/comm_E; bit 8 last
+ * secondary instance's relation; bit 9 its comm_W; bit 10 instance scalars differ from the witness vectors. */
+int vimz_ivc_verify(vimz_ivc* v, uint32_t* result);
+/* info[0..11]: steps, primary wires, primary constraints, step wires, step constraints, secondary wires, secondary constraints,
+ * len_z, verifier-circuit wires (primary), nnz(A+B+C) primary, nnz secondary, reserved */
+int vimz_ivc_info(const vimz_ivc* v, uint64_t info[12]);
+int vimz_ivc_state(const vimz_ivc* v, uint64_t* z_current /* len_z x 4 */, uint64_t* steps);
+/* seconds[8]/counts[8]: verifier-circuit witness primary (host), secondary (host), wait for secondary MSMs, wait for primary MSMs,
+ * uploads+launches, producer wait, reserved, total */
+int vimz_ivc_profile(const vimz_ivc* v, double seconds[8], uint64_t counts[8]);
+/* Everything an independent verifier needs, canonical little-endian 4 x u64 per element (the parity tests hand these to the
+ * CPU oracle's verifier).  side 0 = primary (BN254 Fr / G1), 1 = secondary (BN254 Fq / Grumpkin).
+ *   what = VIMZ_CX_{A,B,C}_{ROWPTR,COL,COEF}, VIMZ_CX_DICT_CANON : the augmented circuit's R1CS
+ *   what = VIMZ_IX_*  below.  Returns the byte size (copies when buf is large enough). */
+#define VIMZ_IX_RUNNING_Z 100   /* running witness vector [u | W | X0 X1] (wire order) */
+#define VIMZ_IX_RUNNING_E 101
+#define VIMZ_IX_FRESH_Z 102     /* side 1 only: the last fresh secondary witness vector */
+#define VIMZ_IX_INSTANCE 103    /* running instance: comm_W.x, comm_W.y, comm_E.x, comm_E.y, u, X0, X1  (7 elements; coordinates in the
+                                   commitment curve's base field, u/X in this side's scalar field) */
+#define VIMZ_IX_FRESH_INSTANCE 104  /* side 1 only: comm_W.x, comm_W.y, x0, x1 */
+#define VIMZ_IX_INFO 106        /* u64[4]: wires, constraints, step wires, step constraints */
+#define VIMZ_IX_PARAMS 105      /* digest, pz, z0..., z_i...  (2 + 2 len_z elements of this side's field; secondary len_z = 1) */
+int64_t vimz_ivc_export(vimz_ivc* v, int side, int what, void* buf, size_t cap);
+/* Host-only hooks for the parity tests of the verifier circuit itself (no GPU): build the augmented circuit of one side over a
+ * trivial step circuit (z_out = z_in, arity 1), export it, and run its witness generator on given inputs.
+ *   inputs (canonical elements): pz, i, z_i, U = (W.x, W.y, E.x, E.y, u, X0, X1), u = (W.x, W.y, x0, x1), T = (x, y)   -> 16 elements
+ *   wires_out: n_wires elements (the full witness incl. the constant and the trivial step)
+ *   outputs: U_new (7), rho (1), x0, x1 (2), flag (1: 1 = some range check failed)                                      -> 11 elements */
+typedef struct vimz_augcircuit vimz_augcircuit;
+int vimz_augcircuit_build(int side, vimz_augcircuit** out);
+void vimz_augcircuit_free(vimz_augcircuit* c);
+int64_t vimz_augcircuit_export(const vimz_augcircuit* c, int what, void* buf, size_t cap);   /* VIMZ_CX_* R1CS codes, VIMZ_IX_INFO */
+int vimz_augcircuit_witness(const vimz_augcircuit* c, const uint64_t* inputs, uint64_t* wires_out, uint64_t* outputs);
+
 /* ---- field-arithmetic probes (element-wise on the GPU; used by the parity tests to pin the device
  *      Montgomery arithmetic against the oracle).  op: 0 add, 1 sub, 2 mul, 3 inverse (b ignored). -------- */
 int vimz_field_op(vimz_ctx* ctx, int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n);

@@ -25,32 +25,32 @@
 namespace vz {
 namespace cb {
 
-typedef Fp<BnFr> Fe;
+template <class F> inline F f_from_u64(uint64_t v) { F x = F::zero(); x.v[0] = (uint32_t)v; x.v[1] = (uint32_t)(v >> 32); return F::to_mont(x); }
+template <class F> inline F f_from_i64(int64_t v) { return v >= 0 ? f_from_u64<F>((uint64_t)v) : F::neg(f_from_u64<F>((uint64_t)(-v))); }
+template <class F> inline F f_pow2(int k) { F x = F::zero(); x.v[k >> 5] = 1u << (k & 31); return F::to_mont(x); }
 
-inline Fe fe_from_u64(uint64_t v) { Fe x = Fe::zero(); x.v[0] = (uint32_t)v; x.v[1] = (uint32_t)(v >> 32); return Fe::to_mont(x); }
-inline Fe fe_from_i64(int64_t v) { return v >= 0 ? fe_from_u64((uint64_t)v) : Fe::neg(fe_from_u64((uint64_t)(-v))); }
-inline Fe fe_pow2(int k) { Fe x = Fe::zero(); x.v[k >> 5] = 1u << (k & 31); return Fe::to_mont(x); }
-
-struct Term { uint32_t w; Fe c; };
+template <class Fe> struct TermT { uint32_t w; Fe c; };
 
 // Linear combination over wires; wire 0 is the constant one.  Terms sorted by wire, no zero coefficients.
-struct LC {
+template <class Fe>
+struct LCT {
+  typedef TermT<Fe> Term;
   std::vector<Term> t;
-  LC() {}
-  static LC constant(const Fe& c) { LC r; if (!c.is_zero()) r.t.push_back({0, c}); return r; }
-  static LC constant_i(int64_t v) { return constant(fe_from_i64(v)); }
-  static LC wire(uint32_t w) { LC r; r.t.push_back({w, Fe::one()}); return r; }
-  static LC wire(uint32_t w, const Fe& c) { LC r; if (!c.is_zero()) r.t.push_back({w, c}); return r; }
+  LCT() {}
+  static LCT constant(const Fe& c) { LCT r; if (!c.is_zero()) r.t.push_back({0, c}); return r; }
+  static LCT constant_i(int64_t v) { return constant(f_from_i64<Fe>(v)); }
+  static LCT wire(uint32_t w) { LCT r; r.t.push_back({w, Fe::one()}); return r; }
+  static LCT wire(uint32_t w, const Fe& c) { LCT r; if (!c.is_zero()) r.t.push_back({w, c}); return r; }
   bool is_const() const { return t.empty() || (t.size() == 1 && t[0].w == 0); }
   Fe const_value() const { return t.empty() ? Fe::zero() : t[0].c; }
-  LC scaled(const Fe& k) const {
-    LC r; if (k.is_zero()) return r;
+  LCT scaled(const Fe& k) const {
+    LCT r; if (k.is_zero()) return r;
     r.t.reserve(t.size());
     for (auto& x : t) r.t.push_back({x.w, Fe::mul(x.c, k)});
     return r;
   }
-  static LC axpy(const LC& a, const Fe& k, const LC& b) {  // a + k*b
-    LC r; r.t.reserve(a.t.size() + b.t.size());
+  static LCT axpy(const LCT& a, const Fe& k, const LCT& b) {  // a + k*b
+    LCT r; r.t.reserve(a.t.size() + b.t.size());
     size_t i = 0, j = 0;
     while (i < a.t.size() || j < b.t.size()) {
       if (j >= b.t.size() || (i < a.t.size() && a.t[i].w < b.t[j].w)) r.t.push_back(a.t[i++]);
@@ -59,10 +59,17 @@ struct LC {
     }
     return r;
   }
-  LC operator+(const LC& b) const { return axpy(*this, Fe::one(), b); }
-  LC operator-(const LC& b) const { return axpy(*this, Fe::neg(Fe::one()), b); }
-  LC add_const(int64_t v) const { return *this + constant_i(v); }
+  LCT operator+(const LCT& b) const { return axpy(*this, Fe::one(), b); }
+  LCT operator-(const LCT& b) const { return axpy(*this, Fe::neg(Fe::one()), b); }
+  LCT add_const(int64_t v) const { return *this + constant_i(v); }
 };
+
+typedef Fp<BnFr> Fe;                 // the step circuits' field (the reference compiles them for bn128)
+typedef TermT<Fe> Term;
+typedef LCT<Fe> LC;
+inline Fe fe_from_u64(uint64_t v) { return f_from_u64<Fe>(v); }
+inline Fe fe_from_i64(int64_t v) { return f_from_i64<Fe>(v); }
+inline Fe fe_pow2(int k) { return f_pow2<Fe>(k); }
 
 struct FeKey {
   uint32_t v[8];
@@ -76,7 +83,9 @@ struct Csr {
   std::vector<uint32_t> coef;  // index into Builder::dict
 };
 
-struct Builder {
+template <class Fe>
+struct BuilderT {
+  typedef LCT<Fe> LC;
   uint32_t n_wires = 1;   // wire 0 = one
   uint32_t len_z = 0, n_priv = 0;
   Csr A, B, C;
@@ -115,6 +124,8 @@ struct Builder {
   uint32_t mul_wire(const LC& a, const LC& b) { uint32_t w = alloc(1); enforce(a, b, LC::wire(w)); return w; }
   void mul_into(const LC& a, const LC& b, uint32_t w) { enforce(a, b, LC::wire(w)); }
 };
+
+typedef BuilderT<Fe> Builder;
 
 }  // namespace cb
 }  // namespace vz

@@ -9,11 +9,13 @@
 namespace vz {
 namespace cb {
 
-struct PoseidonTable {
+template <class F>
+struct PoseidonTableT {
   int t = 0, rf = 8, rp = 0;
-  std::vector<Fe> C;  // (rf+rp)*t
-  std::vector<Fe> M;  // t*t row-major
+  std::vector<F> C;  // (rf+rp)*t
+  std::vector<F> M;  // t*t row-major
 };
+typedef PoseidonTableT<Fe> PoseidonTable;
 
 inline int poseidon_rp(int t) {
   static const int RP[16] = {56, 57, 56, 60, 60, 63, 64, 63, 60, 66, 60, 65, 70, 60, 64, 68};
@@ -44,39 +46,50 @@ class GrainLfsr {
   }
 };
 
-inline const PoseidonTable& poseidon_table(int t) {
-  static PoseidonTable cache[18];
+// Parameters for the prime of field parameters P.  For BnFr these are circomlib's; for the other fields the same
+// procedure (Grain LFSR seeded with field=1, sbox=0, n=254|255, t, R_F, R_P; rejection-sampled round constants; Cauchy MDS)
+// over that prime — used by the augmented circuits' hashes on the second curve of the cycle (aug/).
+template <class P>
+inline const PoseidonTableT<Fp<P>>& poseidon_table_t(int t) {
+  typedef Fp<P> F;
+  static PoseidonTableT<F> cache[18];
   static std::mutex mu;                       // several provers (one per row segment) may fold from different threads
   std::lock_guard<std::mutex> guard(mu);
-  PoseidonTable& P = cache[t];
-  if (P.t == t) return P;
-  P.t = t; P.rf = 8; P.rp = poseidon_rp(t);
-  GrainLfsr g(254, (unsigned)t, (unsigned)P.rf, (unsigned)P.rp);
+  PoseidonTableT<F>& T = cache[t];
+  if (T.t == t) return T;
+  T.rf = 8; T.rp = poseidon_rp(t);
+  GrainLfsr g((unsigned)P::BITS, (unsigned)t, (unsigned)T.rf, (unsigned)T.rp);
+  const int nbits = P::BITS;
+  auto sample = [&](uint32_t* out) { for (int i = 0; i < 8; i++) out[i] = 0; for (int i = nbits - 1; i >= 0; i--) if (g.filtered()) out[i >> 5] |= 1u << (i & 31); };
   auto below_modulus = [](const uint32_t* v) {
-    for (int i = 7; i >= 0; i--) if (v[i] != BnFr::MOD.w[i]) return v[i] < BnFr::MOD.w[i];
+    for (int i = 7; i >= 0; i--) if (v[i] != P::MOD.w[i]) return v[i] < P::MOD.w[i];
     return false;
   };
-  auto to_fe_reduced = [&](uint32_t* v) {  // v < 2^254 < 2p: one conditional subtraction
-    if (!below_modulus(v)) { uint64_t br = 0; for (int i = 0; i < 8; i++) { uint64_t d = (uint64_t)v[i] - BnFr::MOD.w[i] - br; v[i] = (uint32_t)d; br = (d >> 32) & 1; } }
-    Fe x; for (int i = 0; i < 8; i++) x.v[i] = v[i];
-    return Fe::to_mont(x);
+  auto to_fe_reduced = [&](uint32_t* v) {  // v < 2^BITS < 2p: one conditional subtraction
+    if (!below_modulus(v)) { uint64_t br = 0; for (int i = 0; i < 8; i++) { uint64_t d = (uint64_t)v[i] - P::MOD.w[i] - br; v[i] = (uint32_t)d; br = (d >> 32) & 1; } }
+    F x; for (int i = 0; i < 8; i++) x.v[i] = v[i];
+    return F::to_mont(x);
   };
-  while ((int)P.C.size() < (P.rf + P.rp) * t) {
-    uint32_t v[8]; g.sample(v);
-    if (below_modulus(v)) P.C.push_back(to_fe_reduced(v));  // rejection sampling for round constants
+  while ((int)T.C.size() < (T.rf + T.rp) * t) {
+    uint32_t v[8]; sample(v);
+    if (below_modulus(v)) T.C.push_back(to_fe_reduced(v));  // rejection sampling for round constants
   }
-  std::vector<Fe> xs(t), ys(t);
-  for (int i = 0; i < t; i++) { uint32_t v[8]; g.sample(v); xs[i] = to_fe_reduced(v); }  // MDS seeds: mod r, no rejection
-  for (int i = 0; i < t; i++) { uint32_t v[8]; g.sample(v); ys[i] = to_fe_reduced(v); }
-  P.M.resize((size_t)t * t);
-  for (int i = 0; i < t; i++) for (int j = 0; j < t; j++) P.M[(size_t)i * t + j] = Fe::pow_pm2(Fe::add(xs[i], ys[j]));
-  return P;
+  std::vector<F> xs(t), ys(t);
+  for (int i = 0; i < t; i++) { uint32_t v[8]; sample(v); xs[i] = to_fe_reduced(v); }  // MDS seeds: mod p, no rejection
+  for (int i = 0; i < t; i++) { uint32_t v[8]; sample(v); ys[i] = to_fe_reduced(v); }
+  T.M.resize((size_t)t * t);
+  for (int i = 0; i < t; i++) for (int j = 0; j < t; j++) T.M[(size_t)i * t + j] = F::pow_pm2(F::add(xs[i], ys[j]));
+  T.t = t;
+  return T;
 }
+inline const PoseidonTable& poseidon_table(int t) { return poseidon_table_t<BnFr>(t); }
 
 // Numeric permutation on the host (used for the IVC state chain between witness batches).
-inline Fe poseidon_hash(const Fe* in, int n) {
+template <class FP>
+inline Fp<FP> poseidon_hash_t(const Fp<FP>* in, int n) {
+  typedef Fp<FP> Fe;
   const int t = n + 1;
-  const PoseidonTable& P = poseidon_table(t);
+  const PoseidonTableT<Fe>& P = poseidon_table_t<FP>(t);
   Fe s[POSEIDON_MAX_T], u[POSEIDON_MAX_T];
   s[0] = Fe::zero();
   for (int i = 0; i < n; i++) s[i + 1] = in[i];
@@ -93,6 +106,7 @@ inline Fe poseidon_hash(const Fe* in, int n) {
   }
   return s[0];
 }
+inline Fe poseidon_hash(const Fe* in, int n) { return poseidon_hash_t<BnFr>(in, n); }
 
 }  // namespace cb
 }  // namespace vz

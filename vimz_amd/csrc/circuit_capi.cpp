@@ -172,3 +172,35 @@ int vimz_wtns_load(const uint8_t* data, size_t len, uint64_t* out, size_t cap_el
 }
 
 }  // extern "C"
+
+// ---- the augmented verifier circuits on their own (host-only parity hooks; the IVC prover is in ivc.hip) ---------------------
+#include "aug/export.hpp"
+struct vimz_augcircuit {
+  int side;
+  vz::aug::AugCircuit<vz::BnFr> c1;
+  vz::aug::AugCircuit<vz::BnFq> c2;
+};
+extern "C" {
+int vimz_augcircuit_build(int side, vimz_augcircuit** out) {
+  if (!out || (side != 0 && side != 1)) { g_circuit_err = "vimz_augcircuit_build: bad argument"; return VIMZ_ERR_INVALID; }
+  try {
+    auto h = std::make_unique<vimz_augcircuit>();
+    h->side = side;
+    if (side == 0) { h->c1.init_trivial_step(); h->c1.finish(true); }
+    else { h->c2.init_trivial_step(); h->c2.finish(false); }
+    *out = h.release();
+    return VIMZ_OK;
+  } catch (const std::exception& e) { g_circuit_err = e.what(); return VIMZ_ERR_INVALID; }
+}
+void vimz_augcircuit_free(vimz_augcircuit* c) { delete c; }
+int64_t vimz_augcircuit_export(const vimz_augcircuit* c, int what, void* buf, size_t cap) {
+  if (!c) return VIMZ_ERR_INVALID;
+  return c->side == 0 ? vz::aug::export_r1cs(c->c1, what, buf, cap) : vz::aug::export_r1cs(c->c2, what, buf, cap);
+}
+int vimz_augcircuit_witness(const vimz_augcircuit* c, const uint64_t* inputs, uint64_t* wires_out, uint64_t* outputs) {
+  if (!c || !inputs) return VIMZ_ERR_INVALID;
+  try {
+    return c->side == 0 ? vz::aug::witness_flat(c->c1, inputs, wires_out, outputs) : vz::aug::witness_flat(c->c2, inputs, wires_out, outputs);
+  } catch (const std::exception& e) { g_circuit_err = e.what(); return VIMZ_ERR_INVALID; }
+}
+}  // extern "C"

@@ -1,0 +1,484 @@
+// Nova IVC on the BN254 / Grumpkin cycle: RecursiveSNARK::{new, prove_step, verify} in full (SURVEY.md §8a rows S1, S2, X1;
+// reference entry points vimz/src/nova_snark_backend/folding.rs:27-56 through nova_scotia::create_recursive_circuit).
+//
+// Per step i (z_i -> z_{i+1}), following nova-snark's prove_step order:
+//   1. NIFS on the secondary curve: fold the previous fresh secondary instance u2 into the running U2
+//      (cross term and its commitment MSM(T2) were queued on the GPU as soon as u2's witness existed);
+//   2. primary augmented circuit: the step circuit's part of the witness, its commitment and (A,B,C)·z come from the batch
+//      producer (prover_internal.hpp); the verifier circuit's wires (aug/circuit.hpp: checks u2's hash, derives the challenge,
+//      folds U2 <- U2 + rho·u2 in-circuit, hashes the result) are computed on the host, uploaded, committed (MSM over the
+//      verifier slice of ck) and multiplied (verifier rows of A,B,C) on the GPU  ->  fresh primary instance u1;
+//   3. NIFS on the primary curve: cross term, MSM(T1), fused fold of W, E, Az, Bz, Cz;
+//   4. secondary augmented circuit (7.6 k constraints over BN254 Fq): host witness, then SpMV / MSM(W2) / cross term /
+//      MSM(T2) on the GPU with the same kernels instantiated for Fq / Grumpkin.
+// The challenges are the ones the circuits derive (rho = 2^128 + low 128 bits of a Poseidon hash), so the folded instances
+// the prover holds are exactly the ones the circuits compute: vimz_ivc_verify checks that.
+#include "prover_internal.hpp"
+#include <type_traits>
+#include "aug/export.hpp"
+
+using namespace vz::aug;
+typedef Affine<Fe> G2Aff;          // Grumpkin point: coordinates in BN254 Fr
+typedef XYZZ<Fe> G2;
+
+namespace {
+
+struct SecDev {                    // secondary circuit on the device (field BN254 Fq, commitments on Grumpkin)
+  CsrDev A{}, B{}, C{};
+  const uint32_t* dict = nullptr;
+  const uint32_t* long_items = nullptr; uint32_t n_long = 0;
+  uint32_t n_w = 0, n_c = 0;
+  uint32_t *Zrun = nullptr, *E = nullptr, *AZ = nullptr, *BZ = nullptr, *CZ = nullptr;   // running instance
+  uint32_t *z2 = nullptr, *az2 = nullptr, *bz2 = nullptr, *cz2 = nullptr, *T = nullptr;  // fresh instance, cross term
+  uint32_t* bad = nullptr;
+};
+
+template <class To, class From>
+To cross_field(const From& m) {     // the same integer (< both primes) as an element of the other field
+  From c = From::from_mont(m);
+  To t; for (int k = 0; k < 8; k++) t.v[k] = c.v[k];
+  return To::to_mont(t);
+}
+template <class F>
+F rho_element(const uint32_t low[4]) { F c = F::zero(); for (int k = 0; k < 4; k++) c.v[k] = low[k]; c.v[4] = 1; return F::to_mont(c); }
+
+template <class F>
+void sec_spmv(const SecDev& S, hipStream_t s, const uint32_t* z, uint32_t* az, uint32_t* bz, uint32_t* cz) {
+  hipLaunchKernelGGL(k_spmv3<F>, dim3(stream_grid(S.n_c)), dim3(256), 0, s, S.A, S.B, S.C, S.dict, (size_t)S.n_c, z, az, bz, cz);
+  if (S.n_long) {
+    const unsigned blocks = (unsigned)std::min<uint32_t>((S.n_long + 3) / 4, 4096);
+    hipLaunchKernelGGL(k_spmv_long<F>, dim3(blocks), dim3(256), 0, s, S.A, S.B, S.C, S.dict, S.long_items, S.n_long, z, az, bz, cz);
+  }
+}
+
+}  // namespace
+
+enum { IP_SYNTH1 = 0, IP_SYNTH2, IP_WAIT_SEC, IP_WAIT_PRI, IP_LAUNCH, IP_PRODUCER, IP_RESERVED, IP_TOTAL, IP_COUNT };
+
+struct vimz_ivc {
+  vimz_ctx* ctx = nullptr;
+  std::unique_ptr<vimz_circuit> circ1;            // the step circuit's copy, with the verifier circuit appended
+  std::unique_ptr<AugCircuit<BnFr>> c1;
+  AugCircuit<BnFq> c2;
+  vimz_prover* pri = nullptr;
+  const vimz_bases *ck1 = nullptr, *ck2 = nullptr;
+  SecDev sec;
+  std::vector<void*> owned;
+  char* pin = nullptr;                            // pinned: 4 MSM results, then staging for the two host-made witnesses
+  size_t pin_res = 0;
+  MsmPlan plan_aug{}, plan_T1{}, plan_W2{}, plan_T2{};
+  // host state of the recursion
+  uint64_t i = 0;
+  Fe pz1 = Fe::zero(); Fq pz2 = Fq::zero();
+  std::vector<Fe> z0;
+  RelaxedInst<Fe> U2;       // running secondary instance (commitments on Grumpkin), as the primary circuit sees it
+  RelaxedInst<Fq> U1;       // running primary instance (commitments on BN254 G1), as the secondary circuit sees it
+  FreshInst<Fe> u2;         // last fresh secondary instance
+  G2Aff T2;                 // commitment to the cross term of (U2, u2)
+  Fe u1_run = Fe::zero(); Fq u2_run = Fq::zero();   // the running scalars in the fields their vectors live in
+  bool pending_sec = false, sec_T_valid = false;
+  double ph_s[IP_COUNT] = {}; uint64_t ph_n[IP_COUNT] = {};
+};
+
+namespace {
+
+// read the results of the queued secondary MSMs (comm_W of the fresh instance, comm_T of its fold)
+int finish_secondary(vimz_ivc* v) {
+  if (!v->pending_sec) return VIMZ_OK;
+  vimz_ctx* ctx = v->ctx;
+  double t0 = now_s();
+  P_TRY(hipStreamSynchronize(ctx->stream));
+  v->ph_s[IP_WAIT_SEC] += now_s() - t0; v->ph_n[IP_WAIT_SEC]++;
+  v->u2.W = msm_finish<Grumpkin>(v->plan_W2, v->pin + 2 * v->pin_res);
+  if (v->sec_T_valid) v->T2 = msm_finish<Grumpkin>(v->plan_T2, v->pin + 3 * v->pin_res);
+  else { v->T2.x = Fe::zero(); v->T2.y = Fe::zero(); }
+  v->pending_sec = false;
+  return VIMZ_OK;
+}
+
+int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witnesses, size_t nsteps) {
+  if (!nsteps) return VIMZ_OK;
+  vimz_ctx* ctx = v->ctx;
+  vimz_prover* p = v->pri;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  P_TRY(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  const size_t nw = p->n_wires, nc = p->n_c, sw = p->step_wires;
+  const size_t aw1 = v->c1->aug_wires();
+  SecDev& S = v->sec;
+  int rc;
+  const double t_all = now_s();
+  FoldJob job; job.step_inputs = step_inputs; job.witnesses = witnesses; job.nsteps = nsteps;
+  if ((rc = fold_prepare(p, job))) return rc;
+  const std::vector<Fe>& zs = job.zs;
+  const size_t pin_stride = FoldJob::pin_stride;
+  char* pin_aug1 = v->pin + 4 * v->pin_res;
+  char* pin_w2 = pin_aug1 + 32 * aw1;
+  const Fq zero_q = Fq::zero();
+
+  if ((rc = fold_issue(p, job, 0))) return rc;
+  for (size_t k = 0; k < job.nbatches; k++) {
+    auto& bb = p->buf[k & 1];
+    const size_t first = k * job.Bk, rows = std::min(job.Bk, nsteps - first);
+    if (k + 1 < job.nbatches && (rc = fold_issue(p, job, k + 1))) return rc;
+    double t0 = now_s();
+    P_TRY(hipEventSynchronize(bb.wit_done));
+    v->ph_s[IP_PRODUCER] += now_s() - t0;
+    for (size_t r = 0; r < rows; r++) if (bb.status_host[r]) {
+      char msg[128]; snprintf(msg, sizeof(msg), "step %llu: the step relation is not satisfiable for these rows", (unsigned long long)(v->i + r));
+      hipStreamSynchronize(p->sB);
+      return vz_fail(ctx, VIMZ_ERR_UNSAT, msg);
+    }
+    for (size_t r = 0; r < rows; r++) {
+      const uint64_t i = v->i;
+      uint32_t* Zi = bb.Z + 8 * r * nw;
+      uint32_t *az = bb.az + 8 * r * nc, *bz = bb.bz + 8 * r * nc, *cz = bb.cz + 8 * r * nc;
+      // ---- 1. the previous fresh secondary instance is complete once its two MSMs are back -------------------------------------
+      if ((rc = finish_secondary(v))) return rc;
+      // ---- 2. primary verifier circuit on the host: folds (U2, u2) and hashes the result ----------------------------------------
+      t0 = now_s();
+      AugIn<BnFr> in1; in1.pz = v->pz1; in1.i = i; in1.U = v->U2; in1.u = v->u2; in1.T = v->T2;
+      std::vector<Fe> aug1; bool bad = false;
+      AugOut<BnFr> o1 = v->c1->witness(in1, zs.data() + (first + r) * p->len_z, zs.data() + (first + r + 1) * p->len_z, aug1, &bad);
+      if (bad) return vz_fail(ctx, VIMZ_ERR_UNSAT, "primary verifier circuit: inconsistent incoming instance");
+      v->ph_s[IP_SYNTH1] += now_s() - t0; v->ph_n[IP_SYNTH1]++;
+      t0 = now_s();
+      if (i > 0) {   // the same fold on the witness vectors
+        const Fq rho2 = rho_element<Fq>(o1.rho_low);
+        Fold5 f;
+        f.x1[0] = S.Zrun; f.x2[0] = S.z2; f.n[0] = S.n_w;
+        f.x1[1] = v->sec_T_valid ? S.E : nullptr; f.x2[1] = S.T; f.n[1] = S.n_c;
+        f.x1[2] = S.AZ; f.x2[2] = S.az2; f.n[2] = S.n_c;
+        f.x1[3] = S.BZ; f.x2[3] = S.bz2; f.n[3] = S.n_c;
+        f.x1[4] = S.CZ; f.x2[4] = S.cz2; f.n[4] = S.n_c;
+        hipLaunchKernelGGL(k_fold5<Fq>, dim3(256), dim3(256), 0, s, f, rho2);
+        v->u2_run = Fq::add(v->u2_run, rho2);
+      }
+      v->U2 = o1.U_new;
+      // ---- fresh primary instance: upload the verifier wires, finish (A,B,C)·z and the commitment ---------------------------------
+      memcpy(pin_aug1, aug1.data(), 32 * aw1);
+      P_TRY(hipStreamWaitEvent(s, bb.ev[r], 0));
+      P_TRY(hipMemcpyAsync(Zi + 8 * sw, pin_aug1, 32 * aw1, hipMemcpyHostToDevice, s));
+      launch_spmv(p, s, Zi, az, bz, cz, 2);
+      P_TRY(msm_launch<BnG1>(s, ctx->msm_ws, p->ck->d + (size_t)AFFINE_WORDS * (sw - 1), Zi + 8 * sw, aw1 - 2, 1, 0, v->pin, &v->plan_aug, nullptr, 1, nullptr));
+      // ---- 3. NIFS on the primary curve ------------------------------------------------------------------------------------------------
+      if (i > 0) {
+        hipLaunchKernelGGL(k_cross_term<Fr>, dim3(stream_grid(nc)), dim3(256), 0, s, nc, p->AZ, p->BZ, p->CZ, v->u1_run, az, bz, cz, Fe::one(), p->T);
+        P_TRY(hipGetLastError());
+        P_TRY(msm_launch<BnG1>(s, ctx->msm_ws, p->ck->d, p->T, nc, 1, 0, v->pin + v->pin_res, &v->plan_T1, nullptr, 0, nullptr));
+      }
+      v->ph_s[IP_LAUNCH] += now_s() - t0;
+      t0 = now_s();
+      P_TRY(hipEventSynchronize(bb.ev[r]));
+      G1Aff cW_step = msm_finish<BnG1>(p->planB, (char*)bb.pin + r * pin_stride);
+      P_TRY(hipStreamSynchronize(s));
+      v->ph_s[IP_WAIT_PRI] += now_s() - t0; v->ph_n[IP_WAIT_PRI]++;
+      t0 = now_s();
+      G1Aff cW_aug = msm_finish<BnG1>(v->plan_aug, v->pin);
+      G1 sum = from_affine(cW_step); add_mixed(sum, cW_aug);
+      FreshInst<Fq> u1; u1.W = to_affine(sum); u1.x0 = cross_field<Fq>(o1.x0); u1.x1 = cross_field<Fq>(o1.x1);
+      G1Aff T1; T1.x = Fq::zero(); T1.y = Fq::zero();
+      if (i > 0) T1 = msm_finish<BnG1>(v->plan_T1, v->pin + v->pin_res);
+      // ---- 4. secondary verifier circuit on the host: folds (U1, u1) ---------------------------------------------------------------------
+      AugIn<BnFq> in2; in2.pz = v->pz2; in2.i = i; in2.U = v->U1; in2.u = u1; in2.T = T1;
+      std::vector<Fq> aug2;
+      AugOut<BnFq> o2 = v->c2.witness(in2, &zero_q, &zero_q, aug2, &bad);
+      if (bad) return vz_fail(ctx, VIMZ_ERR_UNSAT, "secondary verifier circuit: inconsistent incoming instance");
+      v->ph_s[IP_SYNTH2] += now_s() - t0; v->ph_n[IP_SYNTH2]++;
+      t0 = now_s();
+      {
+        const Fe rho1 = rho_element<Fe>(o2.rho_low);
+        Fold5 f;
+        f.x1[0] = p->Zrun; f.x2[0] = Zi; f.n[0] = nw;
+        f.x1[1] = i > 0 ? p->E : nullptr; f.x2[1] = p->T; f.n[1] = nc;
+        f.x1[2] = p->AZ; f.x2[2] = az; f.n[2] = nc;
+        f.x1[3] = p->BZ; f.x2[3] = bz; f.n[3] = nc;
+        f.x1[4] = p->CZ; f.x2[4] = cz; f.n[4] = nc;
+        hipLaunchKernelGGL(k_fold5<Fr>, dim3(2048), dim3(256), 0, s, f, rho1);
+        v->u1_run = Fe::add(v->u1_run, rho1);
+      }
+      v->U1 = o2.U_new;
+      // fresh secondary instance on the device: [1 | z_out | z_in | verifier wires]
+      {
+        Fq* w2 = (Fq*)pin_w2;
+        w2[0] = Fq::one(); w2[1] = zero_q; w2[2] = zero_q;
+        memcpy(w2 + 3, aug2.data(), 32 * aug2.size());
+        P_TRY(hipMemcpyAsync(S.z2, pin_w2, 32 * (size_t)S.n_w, hipMemcpyHostToDevice, s));
+        sec_spmv<Fq>(S, s, S.z2, S.az2, S.bz2, S.cz2);
+        P_TRY(msm_launch<Grumpkin>(s, ctx->msm_ws, v->ck2->d, S.z2 + 8, S.n_w - 3, 1, 0, v->pin + 2 * v->pin_res, &v->plan_W2, nullptr, 1, nullptr));
+        v->sec_T_valid = i > 0;    // U2 is still the zero instance after step 0: its cross term with anything is zero
+        if (v->sec_T_valid) {
+          hipLaunchKernelGGL(k_cross_term<Fq>, dim3(stream_grid(S.n_c)), dim3(256), 0, s, (size_t)S.n_c, S.AZ, S.BZ, S.CZ, v->u2_run, S.az2, S.bz2, S.cz2, Fq::one(), S.T);
+          P_TRY(msm_launch<Grumpkin>(s, ctx->msm_ws, v->ck2->d, S.T, S.n_c, 1, 0, v->pin + 3 * v->pin_res, &v->plan_T2, nullptr, 0, nullptr));
+        }
+        P_TRY(hipGetLastError());
+        v->u2.x0 = cross_field<Fe>(o2.x0); v->u2.x1 = cross_field<Fe>(o2.x1);
+        v->pending_sec = true;
+      }
+      v->ph_s[IP_LAUNCH] += now_s() - t0;
+      v->i++; p->steps++;
+    }
+    // this buffer is rewritten by batch k+2: the folds that read it must have finished
+    P_TRY(hipStreamSynchronize(s));
+  }
+  if ((rc = finish_secondary(v))) return rc;
+  P_TRY(hipStreamSynchronize(p->sB));
+  for (uint32_t k = 0; k < p->len_z; k++) p->z_cur[k] = zs[nsteps * p->len_z + k];
+  v->ph_s[IP_TOTAL] += now_s() - t_all; v->ph_n[IP_TOTAL] += nsteps;
+  return VIMZ_OK;
+}
+
+template <class F>
+bool fetch_elements(hipStream_t s, const uint32_t* d, size_t idx, size_t n, F* out) {
+  return hipMemcpyAsync(out, d + 8 * idx, 32 * n, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+}
+
+}  // namespace
+
+extern "C" {
+
+void vimz_ivc_free(vimz_ivc* v) {
+  if (!v) return;
+  if (v->pri) vimz_prover_free(v->pri);
+  if (v->ctx) {
+    std::lock_guard<std::mutex> g(v->ctx->mu);
+    hipSetDevice(v->ctx->device);
+    hipStreamSynchronize(v->ctx->stream);
+    for (void* d : v->owned) hipFree(d);
+    if (v->pin) hipHostFree(v->pin);
+  }
+  delete v;
+}
+
+int vimz_ivc_create(vimz_ctx* ctx, const vimz_circuit* step_circuit, const vimz_bases* ck1, const vimz_bases* ck2, size_t max_batch, vimz_ivc** out) {
+  if (!ctx || !step_circuit || !ck1 || !ck2 || !out || max_batch == 0) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_ivc_create: bad argument");
+  if (ck1->curve != VIMZ_CURVE_BN254_G1 || ck2->curve != VIMZ_CURVE_GRUMPKIN) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_ivc_create: keys must be on BN254 G1 (primary) and Grumpkin (secondary)");
+  std::unique_ptr<vimz_ivc> v(new vimz_ivc());
+  v->ctx = ctx; v->ck1 = ck1; v->ck2 = ck2;
+  try {
+    v->circ1.reset(new vimz_circuit());
+    v->circ1->transformation = step_circuit->transformation; v->circ1->shape = step_circuit->shape;
+    v->circ1->build.reset(new cb::CircuitBuild());
+    v->circ1->build->b = step_circuit->build->b;
+    v->c1.reset(new AugCircuit<BnFr>(v->circ1->build->b));
+    v->c1->finish(true);
+    v->c2.init_trivial_step();
+    v->c2.finish(false);
+  } catch (const std::exception& e) { return vz_fail(ctx, VIMZ_ERR_INVALID, e.what()); }
+  const uint32_t nw2 = v->c2.n_wires(), nc2 = v->c2.n_constraints();
+  if (ck2->n < nw2 || ck2->n < nc2) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_ivc_create: secondary commitment key shorter than the secondary circuit");
+  int rc = vz_prover_create_layout(ctx, v->circ1.get(), ck1, max_batch, 1, v->c1->step_wires, v->c1->step_constraints, &v->pri);
+  if (rc) return rc;
+  std::unique_lock<std::mutex> lk(ctx->mu);
+  P_TRY(hipSetDevice(ctx->device));
+  SecDev& S = v->sec;
+  S.n_w = nw2; S.n_c = nc2;
+  const cb::BuilderT<Fq>& b2 = v->c2.b;
+  hipError_t e = hipSuccess;
+  auto fail = [&](const char* what) { const hipError_t ee = e; lk.unlock(); vimz_ivc_free(v.release()); return vz_fail(ctx, VIMZ_ERR_HIP, what, ee); };
+#define UP2(vec, dst) do { e = upload(vec, &dst); if (dst) v->owned.push_back((void*)dst); if (e != hipSuccess) return fail("upload " #vec); } while (0)
+  UP2(b2.A.row_ptr, S.A.row_ptr); UP2(b2.A.col, S.A.col); UP2(b2.A.coef, S.A.coef);
+  UP2(b2.B.row_ptr, S.B.row_ptr); UP2(b2.B.col, S.B.col); UP2(b2.B.coef, S.B.coef);
+  UP2(b2.C.row_ptr, S.C.row_ptr); UP2(b2.C.col, S.C.col); UP2(b2.C.coef, S.C.coef);
+  { const Fq* d = nullptr; UP2(b2.dict, d); S.dict = (const uint32_t*)d; }
+  {
+    std::vector<uint32_t> items;
+    const cb::Csr* Ms[3] = {&b2.A, &b2.B, &b2.C};
+    for (uint32_t m = 0; m < 3; m++)
+      for (uint32_t r = 0; r + 1 < Ms[m]->row_ptr.size(); r++)
+        if (Ms[m]->row_ptr[r + 1] - Ms[m]->row_ptr[r] > SPMV_LONG) items.push_back((m << 30) | r);
+    S.n_long = (uint32_t)items.size();
+    UP2(items, S.long_items);
+  }
+#undef UP2
+  auto dalloc = [&](uint32_t** dst, size_t bytes) { e = hipMalloc((void**)dst, bytes); if (e == hipSuccess) { v->owned.push_back(*dst); e = hipMemset(*dst, 0, bytes); } return e; };
+  uint32_t** vw[] = {&S.Zrun, &S.z2};
+  uint32_t** vc[] = {&S.E, &S.AZ, &S.BZ, &S.CZ, &S.az2, &S.bz2, &S.cz2, &S.T};
+  for (auto d : vw) if (dalloc(d, 32 * (size_t)nw2) != hipSuccess) return fail("device allocation");
+  for (auto d : vc) if (dalloc(d, 32 * (size_t)nc2) != hipSuccess) return fail("device allocation");
+  if (dalloc(&S.bad, 64) != hipSuccess) return fail("device allocation");
+  v->pin_res = 4 * (size_t)XYZZ_WORDS * MSM_MAX_WINDOWS;
+  if ((e = hipHostMalloc((void**)&v->pin, 4 * v->pin_res + 32 * (size_t)v->c1->aug_wires() + 32 * (size_t)nw2)) != hipSuccess) return fail("pinned");
+  v->z0.assign(v->c1->len_z, Fe::zero());
+  v->U1 = RelaxedInst<Fq>::zero(); v->U2 = RelaxedInst<Fe>::zero(); v->u2 = FreshInst<Fe>::zero(); v->T2.x = v->T2.y = Fe::zero();
+  *out = v.release();
+  return VIMZ_OK;
+}
+
+int vimz_ivc_reset(vimz_ivc* v, const uint64_t* z0) {
+  if (!v || !z0) return VIMZ_ERR_INVALID;
+  int rc = vimz_prover_reset(v->pri, z0);
+  if (rc) return rc;
+  vimz_ctx* ctx = v->ctx;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  P_TRY(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  SecDev& S = v->sec;
+  uint32_t* zw[] = {S.Zrun, S.z2};
+  uint32_t* zc[] = {S.E, S.AZ, S.BZ, S.CZ, S.az2, S.bz2, S.cz2, S.T};
+  for (auto d : zw) P_TRY(hipMemsetAsync(d, 0, 32 * (size_t)S.n_w, s));
+  for (auto d : zc) P_TRY(hipMemsetAsync(d, 0, 32 * (size_t)S.n_c, s));
+  P_TRY(hipStreamSynchronize(s));
+  v->i = 0;
+  for (uint32_t k = 0; k < v->c1->len_z; k++) v->z0[k] = v->pri->z_cur[k];
+  v->pz1 = v->c1->pz(v->z0.data());
+  const Fq zq = Fq::zero();
+  v->pz2 = v->c2.pz(&zq);
+  v->U1 = RelaxedInst<Fq>::zero(); v->U2 = RelaxedInst<Fe>::zero(); v->u2 = FreshInst<Fe>::zero(); v->T2.x = v->T2.y = Fe::zero();
+  v->u1_run = Fe::zero(); v->u2_run = Fq::zero();
+  v->pending_sec = false; v->sec_T_valid = false;
+  memset(v->ph_s, 0, sizeof(v->ph_s)); memset(v->ph_n, 0, sizeof(v->ph_n));
+  return VIMZ_OK;
+}
+
+int vimz_ivc_fold(vimz_ivc* v, const uint64_t* step_inputs, size_t nsteps) {
+  if (!v || (!step_inputs && nsteps)) return VIMZ_ERR_INVALID;
+  const cb::Builder& b = v->circ1->build->b;
+  if (b.zout.empty() && nsteps) return vz_fail(v->ctx, VIMZ_ERR_INVALID, "this circuit was loaded from an .r1cs and has no witness program: use vimz_ivc_fold_witness");
+  if (!b.gpu_witness && nsteps) return vz_fail(v->ctx, VIMZ_ERR_INVALID, "no GPU witness kernels for this step circuit (crop) yet: supply witnesses with vimz_ivc_fold_witness");
+  try { return ivc_fold_core(v, step_inputs, nullptr, nsteps); } catch (const std::exception& e) { return vz_fail(v->ctx, VIMZ_ERR_INVALID, e.what()); }
+}
+int vimz_ivc_fold_witness(vimz_ivc* v, const uint64_t* witnesses, size_t nsteps) {
+  if (!v || (!witnesses && nsteps)) return VIMZ_ERR_INVALID;
+  try { return ivc_fold_core(v, nullptr, witnesses, nsteps); } catch (const std::exception& e) { return vz_fail(v->ctx, VIMZ_ERR_INVALID, e.what()); }
+}
+
+int vimz_ivc_info(const vimz_ivc* v, uint64_t info[12]) {
+  if (!v || !info) return VIMZ_ERR_INVALID;
+  const cb::Builder& b1 = v->circ1->build->b; const cb::BuilderT<Fq>& b2 = v->c2.b;
+  info[0] = v->i; info[1] = b1.n_wires; info[2] = b1.n_constraints(); info[3] = v->c1->step_wires; info[4] = v->c1->step_constraints;
+  info[5] = b2.n_wires; info[6] = b2.n_constraints(); info[7] = v->c1->len_z; info[8] = v->c1->aug_wires();
+  info[9] = b1.A.col.size() + b1.B.col.size() + b1.C.col.size(); info[10] = b2.A.col.size() + b2.B.col.size() + b2.C.col.size(); info[11] = 0;
+  return VIMZ_OK;
+}
+int vimz_ivc_state(const vimz_ivc* v, uint64_t* z_current, uint64_t* steps) {
+  if (!v) return VIMZ_ERR_INVALID;
+  if (z_current) for (uint32_t k = 0; k < v->pri->len_z; k++) fe_to_canon(v->pri->z_cur[k], z_current + 4 * k);
+  if (steps) *steps = v->i;
+  return VIMZ_OK;
+}
+int vimz_ivc_profile(const vimz_ivc* v, double seconds[8], uint64_t counts[8]) {
+  if (!v) return VIMZ_ERR_INVALID;
+  if (seconds) memcpy(seconds, v->ph_s, sizeof(double) * IP_COUNT);
+  if (counts) memcpy(counts, v->ph_n, sizeof(uint64_t) * IP_COUNT);
+  return VIMZ_OK;
+}
+
+int vimz_ivc_verify(vimz_ivc* v, uint32_t* result) {
+  if (!v || !result) return VIMZ_ERR_INVALID;
+  vimz_ctx* ctx = v->ctx;
+  vimz_prover* p = v->pri;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  P_TRY(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  SecDev& S = v->sec;
+  uint32_t res = 0;
+  if (v->i == 0) { *result = 0; return VIMZ_OK; }
+  // 1. the two hashes carried by the last fresh secondary instance
+  {
+    Fe h1 = instance_hash_native<BnFr>(v->pz1, v->i, p->z_cur, v->U2);
+    if (!h1.eq(v->u2.x0)) res |= 1;
+    std::vector<Fq> zq = {Fq::zero()};
+    Fq h2 = instance_hash_native<BnFq>(v->pz2, v->i, zq, v->U1);
+    if (!cross_field<Fe>(h2).eq(v->u2.x1)) res |= 2;
+  }
+  const uint32_t init[2] = {0, 0xffffffffu};
+  uint32_t bad[2];
+  uint64_t pt[8];
+  int rc;
+  // 2. running primary instance
+  launch_spmv(p, s, p->Zrun, p->az2, p->bz2, p->cz2, 0);
+  P_TRY(hipMemcpyAsync(p->bad_d, init, 8, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_check_relaxed<Fr>, dim3(stream_grid(p->n_c)), dim3(256), 0, s, (size_t)p->n_c, p->az2, p->bz2, p->cz2, v->u1_run, (const uint32_t*)p->E, p->bad_d);
+  P_TRY(hipMemcpyAsync(bad, p->bad_d, 8, hipMemcpyDeviceToHost, s));
+  P_TRY(hipStreamSynchronize(s));
+  if (bad[0]) res |= 4;
+  if ((rc = vz_msm_device(ctx, p->ck, 0, p->Zrun + 8, p->n_wires - 3, 1, 0, pt, VIMZ_FORM_MONTGOMERY))) return rc;
+  if (memcmp(pt, v->U1.W.x.v, 32) || memcmp(pt + 4, v->U1.W.y.v, 32)) res |= 8;
+  if ((rc = vz_msm_device(ctx, p->ck, 0, p->E, p->n_c, 1, 0, pt, VIMZ_FORM_MONTGOMERY))) return rc;
+  if (memcmp(pt, v->U1.E.x.v, 32) || memcmp(pt + 4, v->U1.E.y.v, 32)) res |= 16;
+  {
+    Fe e[3];
+    if (!fetch_elements(s, p->Zrun, 0, 1, &e[0]) || !fetch_elements(s, p->Zrun, p->n_wires - 2, 2, &e[1])) return vz_fail(ctx, VIMZ_ERR_HIP, "verify: download");
+    if (!e[0].eq(v->u1_run) || !cross_field<Fq>(e[0]).eq(v->U1.u)) res |= 1024;
+    if (memcmp(to_u256(e[1]).w, v->U1.X0.w, 32) || memcmp(to_u256(e[2]).w, v->U1.X1.w, 32)) res |= 1024;
+  }
+  // 3. running secondary instance
+  sec_spmv<Fq>(S, s, S.Zrun, S.az2, S.bz2, S.cz2);     // (the fresh products are recomputed below)
+  P_TRY(hipMemcpyAsync(S.bad, init, 8, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_check_relaxed<Fq>, dim3(stream_grid(S.n_c)), dim3(256), 0, s, (size_t)S.n_c, S.az2, S.bz2, S.cz2, v->u2_run, (const uint32_t*)S.E, S.bad);
+  P_TRY(hipMemcpyAsync(bad, S.bad, 8, hipMemcpyDeviceToHost, s));
+  P_TRY(hipStreamSynchronize(s));
+  if (bad[0]) res |= 32;
+  if ((rc = vz_msm_device(ctx, v->ck2, 0, S.Zrun + 8, S.n_w - 3, 1, 0, pt, VIMZ_FORM_MONTGOMERY))) return rc;
+  if (memcmp(pt, v->U2.W.x.v, 32) || memcmp(pt + 4, v->U2.W.y.v, 32)) res |= 64;
+  if ((rc = vz_msm_device(ctx, v->ck2, 0, S.E, S.n_c, 1, 0, pt, VIMZ_FORM_MONTGOMERY))) return rc;
+  if (memcmp(pt, v->U2.E.x.v, 32) || memcmp(pt + 4, v->U2.E.y.v, 32)) res |= 128;
+  {
+    Fq e[3];
+    if (!fetch_elements(s, S.Zrun, 0, 1, &e[0]) || !fetch_elements(s, S.Zrun, S.n_w - 2, 2, &e[1])) return vz_fail(ctx, VIMZ_ERR_HIP, "verify: download");
+    if (!e[0].eq(v->u2_run) || !cross_field<Fe>(e[0]).eq(v->U2.u)) res |= 1024;
+    if (memcmp(to_u256(e[1]).w, v->U2.X0.w, 32) || memcmp(to_u256(e[2]).w, v->U2.X1.w, 32)) res |= 1024;
+  }
+  // 4. the last fresh secondary instance (strict R1CS)
+  sec_spmv<Fq>(S, s, S.z2, S.az2, S.bz2, S.cz2);
+  P_TRY(hipMemcpyAsync(S.bad, init, 8, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(k_check_relaxed<Fq>, dim3(stream_grid(S.n_c)), dim3(256), 0, s, (size_t)S.n_c, S.az2, S.bz2, S.cz2, Fq::one(), (const uint32_t*)nullptr, S.bad);
+  P_TRY(hipMemcpyAsync(bad, S.bad, 8, hipMemcpyDeviceToHost, s));
+  P_TRY(hipStreamSynchronize(s));
+  if (bad[0]) res |= 256;
+  if ((rc = vz_msm_device(ctx, v->ck2, 0, S.z2 + 8, S.n_w - 3, 1, 0, pt, VIMZ_FORM_MONTGOMERY))) return rc;
+  if (memcmp(pt, v->u2.W.x.v, 32) || memcmp(pt + 4, v->u2.W.y.v, 32)) res |= 512;
+  {
+    Fq e[3];
+    if (!fetch_elements(s, S.z2, 0, 1, &e[0]) || !fetch_elements(s, S.z2, S.n_w - 2, 2, &e[1])) return vz_fail(ctx, VIMZ_ERR_HIP, "verify: download");
+    if (!e[0].eq(Fq::one()) || !cross_field<Fe>(e[1]).eq(v->u2.x0) || !cross_field<Fe>(e[2]).eq(v->u2.x1)) res |= 1024;
+  }
+  *result = res;
+  return VIMZ_OK;
+}
+
+int64_t vimz_ivc_export(vimz_ivc* v, int side, int what, void* buf, size_t cap) {
+  if (!v || (side != 0 && side != 1)) return VIMZ_ERR_INVALID;
+  if (what < 100 || what == VIMZ_IX_INFO) return side == 0 ? export_r1cs(*v->c1, what, buf, cap) : export_r1cs(v->c2, what, buf, cap);
+  vimz_ctx* ctx = v->ctx;
+  vimz_prover* p = v->pri;
+  SecDev& S = v->sec;
+  auto put = [](uint64_t* dst, const auto& m) { auto x = std::decay_t<decltype(m)>::from_mont(m); memcpy(dst, x.v, 32); };
+  if (what == VIMZ_IX_INSTANCE || what == VIMZ_IX_FRESH_INSTANCE || what == VIMZ_IX_PARAMS) {
+    std::vector<uint64_t> o;
+    auto push = [&](const auto& m) { o.resize(o.size() + 4); put(o.data() + o.size() - 4, m); };
+    auto push_u = [&](const U256w& x) { o.insert(o.end(), x.w, x.w + 4); };
+    if (what == VIMZ_IX_INSTANCE) {
+      if (side == 0) { push(v->U1.W.x); push(v->U1.W.y); push(v->U1.E.x); push(v->U1.E.y); push(v->U1.u); push_u(v->U1.X0); push_u(v->U1.X1); }
+      else { push(v->U2.W.x); push(v->U2.W.y); push(v->U2.E.x); push(v->U2.E.y); push(v->U2.u); push_u(v->U2.X0); push_u(v->U2.X1); }
+    } else if (what == VIMZ_IX_FRESH_INSTANCE) {
+      if (side != 1) return VIMZ_ERR_INVALID;
+      push(v->u2.W.x); push(v->u2.W.y); push(v->u2.x0); push(v->u2.x1);
+    } else {
+      if (side == 0) { push(v->c1->digest); push(v->pz1); for (auto& z : v->z0) push(z); for (auto& z : p->z_cur) push(z); }
+      else { push(v->c2.digest); push(v->pz2); push(Fq::zero()); push(Fq::zero()); }
+    }
+    const size_t bytes = o.size() * 8;
+    if (buf && cap >= bytes) memcpy(buf, o.data(), bytes);
+    return (int64_t)bytes;
+  }
+  const uint32_t* src = nullptr; size_t n = 0;
+  switch (what) {
+    case VIMZ_IX_RUNNING_Z: src = side == 0 ? p->Zrun : S.Zrun; n = side == 0 ? p->n_wires : S.n_w; break;
+    case VIMZ_IX_RUNNING_E: src = side == 0 ? p->E : S.E; n = side == 0 ? p->n_c : S.n_c; break;
+    case VIMZ_IX_FRESH_Z: if (side != 1) return VIMZ_ERR_INVALID; src = S.z2; n = S.n_w; break;
+    default: return VIMZ_ERR_INVALID;
+  }
+  const size_t bytes = 32 * n;
+  if (!buf || cap < bytes) return (int64_t)bytes;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  if (hipSetDevice(ctx->device) != hipSuccess) return VIMZ_ERR_HIP;
+  hipStream_t s = ctx->stream;
+  int rc = vz_ensure_scratch(ctx, bytes); if (rc) return rc;
+  if (side == 0) launch_from_mont<Fr>(s, src, (uint32_t*)ctx->scratch, n); else launch_from_mont<Fq>(s, src, (uint32_t*)ctx->scratch, n);
+  if (hipMemcpyAsync(buf, ctx->scratch, bytes, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return VIMZ_ERR_HIP;
+  return (int64_t)bytes;
+}
+
+}  // extern "C"

@@ -10,132 +10,7 @@
 // of prove_step (≈3 % of a step, host-side in the reference design).  The instance
 // folded is the step circuit's R1CS itself with public IO X = (z_{i+1}, z_i); the fold algebra, the
 // commitments and the acceptance check (is_sat_relaxed + commitment openings) are exactly Nova's NIFS.
-#include <hip/hip_runtime.h>
-#include <chrono>
-#include <cstring>
-#include <vector>
-#include <algorithm>
-
-#include "internal.hpp"
-#include "circuit_handle.hpp"
-#include "r1cs_ops.hpp"
-#include "witness.hpp"
-
-using namespace vz;
-typedef cb::Fe Fe;                 // host Montgomery Fr
-typedef Fp<BnFq> Fq;
-typedef Affine<Fq> G1Aff;
-typedef XYZZ<Fq> G1;
-
-#define P_TRY(x) do { hipError_t _e = (x); if (_e != hipSuccess) return vz_fail(ctx, VIMZ_ERR_HIP, #x, _e); } while (0)
-
-namespace {
-
-template <class T>
-hipError_t upload(const std::vector<T>& v, const T** out) {
-  *out = nullptr;
-  if (v.empty()) return hipSuccess;
-  void* d; hipError_t e = hipMalloc(&d, v.size() * sizeof(T));
-  if (e != hipSuccess) return e;
-  e = hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
-  *out = (const T*)d;
-  return e;
-}
-
-double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-
-// scalar (canonical 128-bit, little-endian words) * affine point
-G1 scalar_mul(const G1Aff& p, const uint32_t* k, int bits) {
-  G1 acc = G1::identity();
-  for (int i = bits - 1; i >= 0; i--) {
-    acc = dbl(acc);
-    if ((k[i >> 5] >> (i & 31)) & 1) add_mixed(acc, p);
-  }
-  return acc;
-}
-
-}  // namespace
-
-enum { PH_WITNESS = 0, PH_ZCHAIN, PH_SPMV, PH_MSM_W, PH_CROSS, PH_MSM_T, PH_RO, PH_FOLD, PH_HOST_EC, PH_COUNT };
-
-struct vimz_prover {
-  vimz_ctx* ctx = nullptr;
-  const vimz_circuit* circuit = nullptr;
-  const vimz_bases* ck = nullptr;
-  uint32_t n_wires = 0, n_c = 0, len_z = 0, n_priv = 0, n_aux = 0, n_jobs = 0, n_fops = 0;
-  size_t max_batch = 0;
-  // device: shape
-  CsrDev A{}, B{}, C{};
-  const uint32_t* dict = nullptr;
-  const uint32_t* long_items = nullptr; uint32_t n_long = 0;
-  WitnessDev wd{};
-  std::vector<void*> owned;   // every device allocation, for cleanup
-  // device: batch buffers
-  uint32_t *priv_d = nullptr, *zs_d = nullptr, *Z_d = nullptr, *job_out_d = nullptr, *status_d = nullptr;
-  // device: running instance and per-step scratch
-  uint32_t *Zrun = nullptr, *E = nullptr, *AZ = nullptr, *BZ = nullptr, *CZ = nullptr, *T = nullptr, *az2 = nullptr, *bz2 = nullptr, *cz2 = nullptr;
-  uint32_t* bad_d = nullptr;
-  // second stream: everything of a step that does not depend on the running instance (the fresh instance's
-  // (A,B,C)·z and its witness commitment) is issued for the whole batch up front and overlaps the sequential chain
-  hipStream_t sB = nullptr;
-  struct BatchBuf {                       // double-buffered: batch k+1 is produced while batch k is folded
-    uint32_t *Z = nullptr, *job_out = nullptr, *status = nullptr, *az = nullptr, *bz = nullptr, *cz = nullptr;
-    void* pin = nullptr;                  // [batch][MSM_MAX_WINDOWS] window sums of the witness commitments (pinned)
-    uint32_t* status_host = nullptr;      // pinned
-    std::vector<hipEvent_t> ev;           // per row: fresh-instance work done
-    hipEvent_t wit_done = nullptr;
-  } buf[2];
-  MsmWorkspace wsB;
-  MsmPlan planB{};
-  // per fold call: all private inputs, all IVC states and all row hashes resident
-  uint32_t *priv_all_d = nullptr, *zs_all_d = nullptr, *job_all_d = nullptr;
-  size_t cap_priv_all = 0, cap_zs_all = 0, cap_job_all = 0;
-  // host: running instance
-  G1Aff comm_W{}, comm_E{};
-  Fe u = Fe::zero();
-  std::vector<Fe> z_cur, z0;      // IVC state (Montgomery)
-  Fe ro = Fe::zero(), zdigest = Fe::zero();
-  uint64_t steps = 0;
-  double phase_s[PH_COUNT] = {};
-  uint64_t phase_n[PH_COUNT] = {};
-  std::vector<uint32_t> last_status;
-};
-
-namespace {
-
-Fe fe_from_canon(const uint64_t* c) { Fe x; memcpy(x.v, c, 32); return Fe::to_mont(x); }
-void fe_to_canon(const Fe& m, uint64_t* out) { Fe c = Fe::from_mont(m); memcpy(out, c.v, 32); }
-
-// numeric value of a reference on the host, for the IVC state chain (phase-B jobs / field ops only)
-struct HostEval {
-  const vimz_prover* P; const cb::Builder* b;
-  const uint64_t* priv;            // canonical private inputs of this row
-  const Fe* job_a;                 // phase-A job outputs of this row (Montgomery), indexed by job
-  std::vector<Fe> job_b, fop;      // computed here
-  const Fe* zin;
-  Fe value(const ValRef& r) const {
-    switch (r.kind) {
-      case REF_WIRE:
-        if (r.idx > b->len_z && r.idx <= 2 * b->len_z) return zin[r.idx - 1 - b->len_z];        // a step_in wire
-        if (r.idx >= 1 + 2 * b->len_z && r.idx < 1 + 2 * b->len_z + b->n_priv) return fe_from_canon(priv + 4 * (size_t)(r.idx - (1 + 2 * b->len_z)));
-        return Fe::zero();  // the builder never references other wires from phase-B inputs
-      case REF_JOB: return b->chains[b->jobs[r.idx].chain].phase == 0 ? job_a[r.idx] : job_b[r.idx];
-      case REF_FOP: return fop[r.idx];
-      case REF_ZIN: return zin[r.idx];
-      default: return Fe::zero();
-    }
-  }
-};
-
-}  // namespace
-
-static void launch_spmv(vimz_prover* p, hipStream_t s, const uint32_t* z, uint32_t* az, uint32_t* bz, uint32_t* cz) {
-  hipLaunchKernelGGL(k_spmv3<Fr>, dim3(stream_grid(p->n_c)), dim3(256), 0, s, p->A, p->B, p->C, p->dict, (size_t)p->n_c, z, az, bz, cz);
-  if (p->n_long) {
-    const unsigned blocks = (unsigned)std::min<uint32_t>((p->n_long + 3) / 4, 4096);
-    hipLaunchKernelGGL(k_spmv_long<Fr>, dim3(blocks), dim3(256), 0, s, p->A, p->B, p->C, p->dict, p->long_items, p->n_long, z, az, bz, cz);
-  }
-}
+#include "prover_internal.hpp"
 
 extern "C" {
 
@@ -160,10 +35,18 @@ void vimz_prover_free(vimz_prover* p) {
 }
 
 int vimz_prover_create(vimz_ctx* ctx, const vimz_circuit* circuit, const vimz_bases* ck, size_t max_batch, vimz_prover** out) {
+  return vz_prover_create_layout(ctx, circuit, ck, max_batch, 0, 0, 0, out);
+}
+}  // extern "C"
+
+// step_wires != 0: `circuit` is an augmented circuit (aug/augmented.hpp) whose first step_wires wires / step_c rows are the
+// step circuit; the prover is laid out for IVC (public IO = the last two wires, everything else committed).
+int vz_prover_create_layout(vimz_ctx* ctx, const vimz_circuit* circuit, const vimz_bases* ck, size_t max_batch, int ivc, uint32_t step_wires, uint32_t step_c, vimz_prover** out) {
   if (!ctx || !circuit || !ck || !out || max_batch == 0) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_prover_create: bad argument");
   if (ck->curve != VIMZ_CURVE_BN254_G1) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_prover_create: the step circuits are over BN254 Fr; the key must be on BN254 G1");
   const cb::Builder& b = circuit->build->b;
-  const uint32_t n_aux = b.n_wires - 1 - 2 * b.len_z;
+  const uint32_t c0 = ivc ? 1u : 1 + 2 * b.len_z;
+  const uint32_t n_aux = ivc ? b.n_wires - 3 : b.n_wires - 1 - 2 * b.len_z;
   if (ck->n < n_aux || ck->n < b.n_constraints()) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_prover_create: commitment key shorter than max(witness, constraints)");
   for (auto& J : b.jobs) if (J.t != 3 && J.t != 9) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_prover_create: the GPU Poseidon kernel supports widths 3 and 9 only (row widths must be multiples of 8... of the window fold)");
   std::lock_guard<std::mutex> g(ctx->mu);
@@ -172,6 +55,7 @@ int vimz_prover_create(vimz_ctx* ctx, const vimz_circuit* circuit, const vimz_ba
   p->ctx = ctx; p->circuit = circuit; p->ck = ck; p->max_batch = max_batch;
   p->n_wires = b.n_wires; p->n_c = b.n_constraints(); p->len_z = b.len_z; p->n_priv = b.n_priv; p->n_aux = n_aux;
   p->n_jobs = (uint32_t)b.jobs.size(); p->n_fops = (uint32_t)b.fops.size();
+  p->ivc = ivc != 0; p->c0 = c0; p->step_wires = ivc ? step_wires : b.n_wires; p->step_c = ivc ? step_c : b.n_constraints();
   auto fail_free = [&](const char* what, hipError_t e) { for (void* d : p->owned) hipFree(d); delete p; return vz_fail(ctx, VIMZ_ERR_HIP, what, e); };
   hipError_t e;
 #define UP(vec, dst) do { e = upload(vec, &dst); if (dst) p->owned.push_back((void*)dst); if (e != hipSuccess) return fail_free("upload " #vec, e); } while (0)
@@ -180,13 +64,13 @@ int vimz_prover_create(vimz_ctx* ctx, const vimz_circuit* circuit, const vimz_ba
   UP(b.C.row_ptr, p->C.row_ptr); UP(b.C.col, p->C.col); UP(b.C.coef, p->C.coef);
   { const Fe* d = nullptr; UP(b.dict, d); p->dict = (const uint32_t*)d; }
   {
-    std::vector<uint32_t> items;
+    std::vector<uint32_t> items, items_aug;
     const cb::Csr* Ms[3] = {&b.A, &b.B, &b.C};
     for (uint32_t m = 0; m < 3; m++)
       for (uint32_t r = 0; r + 1 < Ms[m]->row_ptr.size(); r++)
-        if (Ms[m]->row_ptr[r + 1] - Ms[m]->row_ptr[r] > SPMV_LONG) items.push_back((m << 30) | r);
-    p->n_long = (uint32_t)items.size();
-    UP(items, p->long_items);
+        if (Ms[m]->row_ptr[r + 1] - Ms[m]->row_ptr[r] > SPMV_LONG) (r < p->step_c ? items : items_aug).push_back((m << 30) | r);
+    p->n_long = (uint32_t)items.size(); p->n_long_aug = (uint32_t)items_aug.size();
+    UP(items, p->long_items); UP(items_aug, p->long_items_aug);
   }
   WitnessDev& W = p->wd;
   UP(b.decomp, W.decomp); UP(b.lane_groups, W.groups); UP(b.lane_instr, W.instr); UP(b.lane_rows, W.rows);
@@ -232,6 +116,7 @@ int vimz_prover_create(vimz_ctx* ctx, const vimz_circuit* circuit, const vimz_ba
   return VIMZ_OK;
 }
 
+extern "C" {
 // Start a new IVC: z0 (len_z canonical elements).
 int vimz_prover_reset(vimz_prover* p, const uint64_t* z0) {
   if (!p || !z0) return VIMZ_ERR_INVALID;
@@ -382,39 +267,6 @@ static void ro_absorb_point(const G1Aff& pt, Fe* out2) {  // (x_lo128, x_hi | pa
   out2[0] = Fe::to_mont(lo); out2[1] = Fe::to_mont(hi);
 }
 
-// Host IVC-state chain for `rows` rows: zs[(r+1)] from zs[r] and the row hashes (phase-A job outputs) of row r.
-static void host_state_chain(const vimz_prover* p, const uint64_t* inputs, size_t rows, const Fe* jobA, size_t jstride, std::vector<Fe>& zs) {
-  const cb::Builder& b = p->circuit->build->b;
-  HostEval ev; ev.P = p; ev.b = &b;
-  for (size_t r = 0; r < rows; r++) {
-    ev.priv = inputs + 4 * r * p->n_priv; ev.job_a = jobA + r * jstride; ev.zin = zs.data() + r * p->len_z;
-    ev.job_b.assign(p->n_jobs, Fe::zero()); ev.fop.assign(p->n_fops, Fe::zero());
-    for (auto& c : b.chains) {
-      if (c.phase != 1) continue;
-      for (uint32_t k = 0; k < c.job_cnt; k++) {
-        const HashJob& J = b.jobs[c.job_off + k];
-        Fe in[POSEIDON_MAX_T];
-        for (uint32_t i = 0; i + 1 < J.t; i++) in[i] = ev.value(J.in[i]);
-        ev.job_b[c.job_off + k] = cb::poseidon_hash(in, (int)J.t - 1);
-      }
-    }
-    for (uint32_t f = 0; f < p->n_fops; f++) {
-      const FieldOp& F = b.fops[f];
-      if (F.op == FOP_ISZERO) { Fe in = ev.value(F.a); ev.fop[f] = in.is_zero() ? Fe::one() : Fe::zero(); }
-      else { Fe sv = ev.value(F.a), c0 = ev.value(F.b), c1 = ev.value(F.c); ev.fop[f] = Fe::add(Fe::mul(Fe::sub(c1, c0), sv), c0); }
-    }
-    Fe* zn = zs.data() + (r + 1) * p->len_z;
-    for (uint32_t i = 0; i < p->len_z; i++) zn[i] = Fe::add(ev.value(b.zout[i].ref), cb::fe_from_i64(b.zout[i].add));
-  }
-}
-
-static hipError_t grow(uint32_t** d, size_t* cap, size_t bytes) {
-  if (bytes <= *cap) return hipSuccess;
-  hipFree(*d); *d = nullptr; *cap = 0;
-  hipError_t e = hipMalloc((void**)d, bytes);
-  if (e == hipSuccess) *cap = bytes;
-  return e;
-}
 
 // Fold `nsteps` more rows.  step_inputs: nsteps x n_priv canonical elements, in the flattened order of
 // vimz/src/nova_snark_backend/input.rs:57-96 (row_orig rows, then row_tran rows; redact: block then indicator).
@@ -439,97 +291,20 @@ int vimz_prover_fold_witness(vimz_prover* p, const uint64_t* witnesses, size_t n
 }  // extern "C"
 static int fold_core(vimz_prover* p, const uint64_t* step_inputs, const uint64_t* witnesses, size_t nsteps) {
   if (!nsteps) return VIMZ_OK;
+  if (p->ivc) return vz_fail(p->ctx, VIMZ_ERR_INVALID, "this prover belongs to an IVC (vimz_ivc_*): fold through vimz_ivc_fold");
   vimz_ctx* ctx = p->ctx;
   std::lock_guard<std::mutex> g(ctx->mu);
   P_TRY(hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
-  const cb::Builder& b = p->circuit->build->b;
-  const WitnessDev& W = p->wd;
-  const size_t nw = p->n_wires, nc = p->n_c, jstride = p->n_jobs + p->n_fops, B = p->max_batch;
-  const uint32_t aux0 = 1 + 2 * p->len_z;
-  uint32_t nA = 0, nB = 0;
-  for (auto& c : b.chains) (c.phase == 0 ? nA : nB)++;
+  const size_t nw = p->n_wires, nc = p->n_c;
   int rc;
-
-  std::vector<Fe> zs((nsteps + 1) * p->len_z, Fe::zero());
-  for (uint32_t i = 0; i < p->len_z; i++) zs[i] = p->z_cur[i];
-  double t0 = now_s();
-  if (witnesses) {
-    // external witnesses: the state chain is read off their public wires, and checked for continuity
-    for (size_t r = 0; r < nsteps; r++) {
-      const uint64_t* w = witnesses + 4 * r * nw;
-      for (uint32_t i = 0; i < p->len_z; i++) {
-        if (!fe_from_canon(w + 4 * (1 + p->len_z + i)).eq(zs[r * p->len_z + i])) {
-          char msg[128]; snprintf(msg, sizeof(msg), "witness %llu: step_in does not continue the IVC state", (unsigned long long)r);
-          return vz_fail(ctx, VIMZ_ERR_UNSAT, msg);
-        }
-        zs[(r + 1) * p->len_z + i] = fe_from_canon(w + 4 * (1 + i));
-      }
-    }
-  } else {
-  // ---- 0. inputs, row hashes, IVC state chain ------------------------------------------------------------------
-  P_TRY(grow(&p->priv_all_d, &p->cap_priv_all, 32 * nsteps * (size_t)p->n_priv));
-  P_TRY(grow(&p->zs_all_d, &p->cap_zs_all, 32 * (nsteps + 1) * (size_t)p->len_z));
-  P_TRY(grow(&p->job_all_d, &p->cap_job_all, 32 * nsteps * jstride));
-  P_TRY(hipMemcpyAsync(p->priv_all_d, step_inputs, 32 * nsteps * (size_t)p->n_priv, hipMemcpyHostToDevice, s));
-  P_TRY(hipMemsetAsync(p->job_all_d, 0, 32 * nsteps * jstride, s));
-  for (size_t off = 0; off < nsteps && nA; off += 32768) {
-    const unsigned rows = (unsigned)std::min<size_t>(32768, nsteps - off);
-    hipLaunchKernelGGL(k_wit_chains, dim3((nA + 3) / 4, rows), dim3(64), 0, s, W, 0u, (uint32_t*)nullptr, p->job_all_d + 8 * off * jstride,
-                       (const uint32_t*)(p->priv_all_d + 8 * off * p->n_priv));
-  }
-  P_TRY(hipGetLastError());
-  std::vector<Fe> jobA(nsteps * jstride);
-  P_TRY(hipMemcpyAsync(jobA.data(), p->job_all_d, 32 * nsteps * jstride, hipMemcpyDeviceToHost, s));
-  P_TRY(hipStreamSynchronize(s));
-  p->phase_s[PH_WITNESS] += now_s() - t0; t0 = now_s();
-  host_state_chain(p, step_inputs, nsteps, jobA.data(), jstride, zs);
-  {
-    std::vector<Fe> zc(zs.size());
-    for (size_t i = 0; i < zs.size(); i++) zc[i] = Fe::from_mont(zs[i]);
-    P_TRY(hipMemcpyAsync(p->zs_all_d, zc.data(), 32 * zc.size(), hipMemcpyHostToDevice, s));
-    P_TRY(hipStreamSynchronize(s));
-  }
-  p->phase_s[PH_ZCHAIN] += now_s() - t0; p->phase_n[PH_ZCHAIN] += nsteps; p->phase_n[PH_WITNESS] += nsteps;
-
-  }
-  const BaseTables tbl = p->ck->tb(0);
-  // ---- 1. producer: one batch on stream B ------------------------------------------------------------------------
-  const size_t pin_stride = 4 * (size_t)XYZZ_WORDS * MSM_MAX_WINDOWS;
-  const size_t nbatches = (nsteps + B - 1) / B;
-  const size_t Bk = (nsteps + nbatches - 1) / nbatches;     // even batches (85 rows -> 43 + 42, not 64 + 21): no short tail batch
-  auto issue = [&](size_t k) -> int {
-    auto& bb = p->buf[k & 1];
-    const size_t first = k * Bk, rows = std::min(Bk, nsteps - first);
-    hipStream_t sb = p->sB;
-    P_TRY(hipMemsetAsync(bb.status, 0, 4 * rows, sb));
-    if (witnesses) {
-      P_TRY(hipMemcpyAsync(bb.Z, witnesses + 4 * first * nw, 32 * rows * nw, hipMemcpyHostToDevice, sb));
-      launch_to_mont<Fr>(sb, bb.Z, rows * nw);
-    } else {
-    const uint32_t* priv = p->priv_all_d + 8 * first * p->n_priv;
-    for (uint32_t gI = 0; gI < W.n_decomp; gI++) {
-      const uint32_t total = (b.decomp[gI].nbits - 1) * b.decomp[gI].count;
-      hipLaunchKernelGGL(k_wit_decomp, dim3((total + 255) / 256, (unsigned)rows), dim3(256), 0, sb, W, gI, priv, bb.Z, bb.status);
-    }
-    hipLaunchKernelGGL(k_wit_inputs, dim3(((1 + 2 * p->len_z + p->n_priv) + 255) / 256, (unsigned)rows), dim3(256), 0, sb, W, priv, (const uint32_t*)p->zs_all_d, bb.Z, (uint32_t)first);
-    for (uint32_t gI = 0; gI < W.n_groups; gI++)
-      hipLaunchKernelGGL(k_wit_lanes, dim3((b.lane_groups[gI].lanes + LANE_TB - 1) / LANE_TB, (unsigned)rows), dim3(LANE_TB), 0, sb, W, gI, priv, (const uint32_t*)p->zs_all_d, (uint32_t)first, bb.Z, bb.status);
-    if (nA) hipLaunchKernelGGL(k_wit_chains, dim3((nA + 3) / 4, (unsigned)rows), dim3(64), 0, sb, W, 0u, bb.Z, bb.job_out, (const uint32_t*)nullptr);
-    if (nB) hipLaunchKernelGGL(k_wit_chains, dim3((nB + 3) / 4, (unsigned)rows), dim3(64), 0, sb, W, 1u, bb.Z, bb.job_out, (const uint32_t*)nullptr);
-    if (p->n_fops) hipLaunchKernelGGL(k_wit_fops, dim3(((unsigned)rows + 63) / 64), dim3(64), 0, sb, W, bb.Z, bb.job_out, (uint32_t)rows);
-    }
-    P_TRY(hipGetLastError());
-    P_TRY(hipMemcpyAsync(bb.status_host, bb.status, 4 * rows, hipMemcpyDeviceToHost, sb));
-    P_TRY(hipEventRecord(bb.wit_done, sb));
-    for (size_t r = 0; r < rows; r++) {
-      const uint32_t* Zi = bb.Z + 8 * r * nw;
-      launch_spmv(p, sb, Zi, bb.az + 8 * r * nc, bb.bz + 8 * r * nc, bb.cz + 8 * r * nc);
-      P_TRY(msm_launch<BnG1>(sb, p->wsB, p->ck->d, Zi + 8 * (size_t)aux0, p->n_aux, 1, 0, (char*)bb.pin + r * pin_stride, &p->planB, nullptr, 1, p->ck->tables ? &tbl : nullptr));
-      P_TRY(hipEventRecord(bb.ev[r], sb));
-    }
-    return VIMZ_OK;
-  };
+  double t0;
+  FoldJob job; job.step_inputs = step_inputs; job.witnesses = witnesses; job.nsteps = nsteps;
+  if ((rc = fold_prepare(p, job))) return rc;
+  const std::vector<Fe>& zs = job.zs;
+  const BaseTables& tbl = job.tbl;
+  const size_t pin_stride = FoldJob::pin_stride, nbatches = job.nbatches, Bk = job.Bk;
+  auto issue = [&](size_t k) -> int { return fold_issue(p, job, k); };
 
   // ---- 2. consumer: the sequential chain on stream A ------------------------------------------------------------
   if ((rc = issue(0))) return rc;
@@ -861,7 +636,7 @@ int vimz_prover_verify(vimz_prover* p, uint32_t* result) {
   P_TRY(hipStreamSynchronize(s));
   if (bad[0]) res |= 8;
   uint64_t pt[8];
-  int rc = vz_msm_device(ctx, p->ck, 0, p->Zrun + 8 * (size_t)(1 + 2 * p->len_z), p->n_aux, 1, 0, pt, VIMZ_FORM_MONTGOMERY);
+  int rc = vz_msm_device(ctx, p->ck, 0, p->Zrun + 8 * (size_t)p->c0, p->n_aux, 1, 0, pt, VIMZ_FORM_MONTGOMERY);
   if (rc) return rc;
   if (memcmp(pt, p->comm_W.x.v, 32) || memcmp(pt + 4, p->comm_W.y.v, 32)) res |= 2;
   rc = vz_msm_device(ctx, p->ck, 0, p->E, nc, 1, 0, pt, VIMZ_FORM_MONTGOMERY);

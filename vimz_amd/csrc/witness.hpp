@@ -47,7 +47,7 @@ __device__ __forceinline__ Fr fr_from_small(long long v) {  // small signed inte
 // status bits per row
 enum : uint32_t { WIT_UNSAT = 1u, WIT_BAD_INPUT = 2u };
 
-__global__ void __launch_bounds__(256) k_wit_inputs(WitnessDev P, const uint32_t* __restrict__ priv, const uint32_t* __restrict__ zs,
+static __global__ void __launch_bounds__(256) k_wit_inputs(WitnessDev P, const uint32_t* __restrict__ priv, const uint32_t* __restrict__ zs,
                                                     uint32_t* __restrict__ Z, uint32_t first_row) {
   const uint32_t row = blockIdx.y;
   const size_t zrow = (size_t)row * P.n_wires;
@@ -62,7 +62,7 @@ __global__ void __launch_bounds__(256) k_wit_inputs(WitnessDev P, const uint32_t
   }
 }
 
-__global__ void __launch_bounds__(256) k_wit_decomp(WitnessDev P, uint32_t g, const uint32_t* __restrict__ priv, uint32_t* __restrict__ Z,
+static __global__ void __launch_bounds__(256) k_wit_decomp(WitnessDev P, uint32_t g, const uint32_t* __restrict__ priv, uint32_t* __restrict__ Z,
                                                     uint32_t* __restrict__ status) {
   const DecompGroup D = P.decomp[g];
   const uint32_t row = blockIdx.y;
@@ -85,7 +85,7 @@ __global__ void __launch_bounds__(256) k_wit_decomp(WitnessDev P, uint32_t g, co
 constexpr int LANE_TB = 64;
 constexpr int LANE_REGS = 60;
 
-__global__ void __launch_bounds__(LANE_TB) k_wit_lanes(WitnessDev P, uint32_t g, const uint32_t* __restrict__ priv, const uint32_t* __restrict__ zs,
+static __global__ void __launch_bounds__(LANE_TB) k_wit_lanes(WitnessDev P, uint32_t g, const uint32_t* __restrict__ priv, const uint32_t* __restrict__ zs,
                                                         uint32_t first_row, uint32_t* __restrict__ Z, uint32_t* __restrict__ status) {
   __shared__ long long regs[LANE_REGS][LANE_TB];
   const LaneGroup G = P.groups[g];
@@ -232,7 +232,7 @@ __device__ __forceinline__ Fr poseidon_group(const WitnessDev& P, const HashJob&
 // job_out: [row][n_jobs + n_fops] Montgomery.
 // priv_rows != nullptr selects the hash-only pass: inputs come from the canonical private-input rows, no wire is written
 // (used once per fold call over ALL rows to get the row hashes the IVC state chain needs).
-__global__ void __launch_bounds__(64) k_wit_chains(WitnessDev P, uint32_t phase, uint32_t* __restrict__ Z, uint32_t* __restrict__ job_out,
+static __global__ void __launch_bounds__(64) k_wit_chains(WitnessDev P, uint32_t phase, uint32_t* __restrict__ Z, uint32_t* __restrict__ job_out,
                                                    const uint32_t* __restrict__ priv_rows) {
   const uint32_t row = blockIdx.y;
   const uint32_t sub = threadIdx.x >> 4, li = threadIdx.x & 15;
@@ -275,7 +275,7 @@ __global__ void __launch_bounds__(64) k_wit_chains(WitnessDev P, uint32_t phase,
   }
 }
 
-__global__ void __launch_bounds__(64) k_wit_fops(WitnessDev P, uint32_t* __restrict__ Z, uint32_t* __restrict__ job_out, uint32_t rows) {
+static __global__ void __launch_bounds__(64) k_wit_fops(WitnessDev P, uint32_t* __restrict__ Z, uint32_t* __restrict__ job_out, uint32_t rows) {
   const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= rows) return;
   uint32_t* Zrow = Z + 8 * (size_t)row * P.n_wires;

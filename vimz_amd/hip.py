@@ -299,3 +299,149 @@ class Prover:
         lib.vimz_prover_merge.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         blob = np.ascontiguousarray(blob, dtype=np.uint8)
         self.ctx._chk(lib.vimz_prover_merge(self.h, _ptr(blob), blob.size))
+
+
+# ---- Nova IVC (include/vimz_hip.h: vimz_ivc_*) --------------------------------------------------------------------------
+CX_R1CS = {"A_rowptr": 0, "A_col": 1, "A_coef": 2, "B_rowptr": 3, "B_col": 4, "B_coef": 5, "C_rowptr": 6, "C_col": 7, "C_coef": 8,
+           "dict_canon": 10}
+IX_RUNNING_Z, IX_RUNNING_E, IX_FRESH_Z, IX_INSTANCE, IX_FRESH_INSTANCE, IX_PARAMS, IX_INFO = 100, 101, 102, 103, 104, 105, 106
+
+
+def _export(fn, *args):
+    """Two-call export protocol of the ABI: size query, then copy."""
+    n = fn(*args, None, 0)
+    if n < 0:
+        raise L.VimzError(n, "export")
+    buf = np.zeros(max(n // 8, 1), dtype=np.uint64)
+    got = fn(*args, _ptr(buf), n)
+    if got != n:
+        raise L.VimzError(got, "export")
+    return buf[: n // 8]
+
+
+def _r1cs_tables(fn, *args):
+    out = {}
+    for name, code in CX_R1CS.items():
+        a = _export(fn, *args, code)
+        out[name] = a.reshape(-1, 4) if name == "dict_canon" else a.view(np.uint32)
+    return out
+
+
+class IVC:
+    """vimz_ivc: Nova IVC of one transformation's step circuit with the augmented verifier circuits on the BN254/Grumpkin cycle
+    (RecursiveSNARK::new / prove_step / verify; reference entry vimz/src/nova_snark_backend/folding.rs:27-56)."""
+    PHASES = ["verifier_circuit_primary_host", "verifier_circuit_secondary_host", "wait_secondary_msm", "wait_primary_msm",
+              "upload_launch", "producer_wait", "reserved", "total"]
+
+    def __init__(self, ctx, circuit, ck_primary, ck_secondary, max_batch=16):
+        self.ctx, self.circuit = ctx, circuit
+        lib = ctx.lib
+        vp, sz = C.c_void_p, C.c_size_t
+        lib.vimz_ivc_create.argtypes = [vp, vp, vp, vp, sz, C.POINTER(vp)]
+        lib.vimz_ivc_free.argtypes = [vp]
+        lib.vimz_ivc_free.restype = None
+        lib.vimz_ivc_reset.argtypes = [vp, vp]
+        lib.vimz_ivc_fold.argtypes = [vp, vp, sz]
+        lib.vimz_ivc_fold_witness.argtypes = [vp, vp, sz]
+        lib.vimz_ivc_verify.argtypes = [vp, C.POINTER(C.c_uint32)]
+        lib.vimz_ivc_info.argtypes = [vp, vp]
+        lib.vimz_ivc_state.argtypes = [vp, vp, C.POINTER(C.c_uint64)]
+        lib.vimz_ivc_profile.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+        lib.vimz_ivc_export.argtypes = [vp, C.c_int, C.c_int, vp, sz]
+        lib.vimz_ivc_export.restype = C.c_int64
+        h = vp()
+        ctx._chk(lib.vimz_ivc_create(ctx.h, circuit.h, ck_primary.h, ck_secondary.h, max_batch, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.vimz_ivc_free(self.h)
+            self.h = None
+
+    def reset(self, z0):
+        z = np.zeros((self.circuit.len_z, 4), dtype=np.uint64)
+        for i, v in enumerate(z0):
+            for k in range(4):
+                z[i, k] = (int(v) >> (64 * k)) & 0xFFFFFFFFFFFFFFFF
+        self.ctx._chk(self.ctx.lib.vimz_ivc_reset(self.h, _ptr(z)))
+
+    def fold(self, step_inputs):
+        a = _u64(step_inputs).reshape(-1, self.circuit.n_priv, 4)
+        self.ctx._chk(self.ctx.lib.vimz_ivc_fold(self.h, _ptr(a), a.shape[0]))
+
+    def fold_witness(self, witnesses):
+        a = _u64(witnesses).reshape(-1, self.circuit.n_wires, 4)
+        self.ctx._chk(self.ctx.lib.vimz_ivc_fold_witness(self.h, _ptr(a), a.shape[0]))
+
+    def verify(self):
+        r = C.c_uint32()
+        self.ctx._chk(self.ctx.lib.vimz_ivc_verify(self.h, C.byref(r)))
+        return r.value
+
+    def info(self):
+        a = np.zeros(12, dtype=np.uint64)
+        self.ctx._chk(self.ctx.lib.vimz_ivc_info(self.h, _ptr(a)))
+        keys = ["steps", "primary_wires", "primary_constraints", "step_wires", "step_constraints", "secondary_wires", "secondary_constraints",
+                "len_z", "verifier_wires", "primary_nnz", "secondary_nnz"]
+        return {k: int(a[i]) for i, k in enumerate(keys)}
+
+    def state(self):
+        z = np.zeros((self.circuit.len_z, 4), dtype=np.uint64)
+        steps = C.c_uint64()
+        self.ctx._chk(self.ctx.lib.vimz_ivc_state(self.h, _ptr(z), C.byref(steps)))
+        return [sum(int(z[i, k]) << (64 * k) for k in range(4)) for i in range(self.circuit.len_z)], steps.value
+
+    def profile(self):
+        s = (C.c_double * 8)()
+        n = (C.c_uint64 * 8)()
+        self.ctx._chk(self.ctx.lib.vimz_ivc_profile(self.h, s, n))
+        return {k: (s[i], n[i]) for i, k in enumerate(self.PHASES)}
+
+    def export(self, side, what):
+        return _export(self.ctx.lib.vimz_ivc_export, self.h, side, what)
+
+    def r1cs(self, side):
+        return _r1cs_tables(self.ctx.lib.vimz_ivc_export, self.h, side)
+
+
+class AugCircuit:
+    """vimz_augcircuit: one side's verifier circuit over a trivial step circuit — host-only hook for the circuit's own tests."""
+
+    def __init__(self, side):
+        lib = L.lib()
+        vp = C.c_void_p
+        lib.vimz_augcircuit_build.argtypes = [C.c_int, C.POINTER(vp)]
+        lib.vimz_augcircuit_free.argtypes = [vp]
+        lib.vimz_augcircuit_free.restype = None
+        lib.vimz_augcircuit_export.argtypes = [vp, C.c_int, vp, C.c_size_t]
+        lib.vimz_augcircuit_export.restype = C.c_int64
+        lib.vimz_augcircuit_witness.argtypes = [vp, vp, vp, vp]
+        self.lib, self.side = lib, side
+        h = vp()
+        rc = lib.vimz_augcircuit_build(side, C.byref(h))
+        if rc:
+            raise L.VimzError(rc, "vimz_augcircuit_build")
+        self.h = h
+        info = _export(lib.vimz_augcircuit_export, self.h, IX_INFO)
+        self.n_wires, self.n_constraints = int(info[0]), int(info[1])
+
+    def close(self):
+        if self.h:
+            self.lib.vimz_augcircuit_free(self.h)
+            self.h = None
+
+    def r1cs(self):
+        return _r1cs_tables(self.lib.vimz_augcircuit_export, self.h)
+
+    def witness(self, inputs):
+        """inputs: 16 integers (pz, i, z, U[7], u[4], T[2]).  Returns (wires[n_wires] ints as (n,4) u64, outputs: list of 11 ints)."""
+        a = np.zeros((16, 4), dtype=np.uint64)
+        for i, v in enumerate(inputs):
+            for k in range(4):
+                a[i, k] = (int(v) >> (64 * k)) & 0xFFFFFFFFFFFFFFFF
+        wires = np.zeros((self.n_wires, 4), dtype=np.uint64)
+        out = np.zeros((11, 4), dtype=np.uint64)
+        rc = self.lib.vimz_augcircuit_witness(self.h, _ptr(a), _ptr(wires), _ptr(out))
+        if rc:
+            raise L.VimzError(rc, "vimz_augcircuit_witness")
+        return wires, [sum(int(out[i, k]) << (64 * k) for k in range(4)) for i in range(11)]
