@@ -9,15 +9,16 @@
 #include "steps.hpp"
 #include "r1cs.hpp"
 #include "witness.hpp"
+#include "nova.hpp"
 
 using namespace orc;
 
-#define FIELD_SWITCH(fid, BODY)                          \
+#define FIELD_SWITCH(fid, ...)                          \
   switch (fid) {                                         \
-    case 0: { typedef BnFr F; BODY; } break;             \
-    case 1: { typedef BnFq F; BODY; } break;             \
-    case 2: { typedef PallasFp F; BODY; } break;         \
-    default: { typedef VestaFq F; BODY; } break;         \
+    case 0: { typedef BnFr F; __VA_ARGS__; } break;             \
+    case 1: { typedef BnFq F; __VA_ARGS__; } break;             \
+    case 2: { typedef PallasFp F; __VA_ARGS__; } break;         \
+    default: { typedef VestaFq F; __VA_ARGS__; } break;         \
   }
 #define CURVE_SWITCH(cid, BODY)                          \
   switch (cid) {                                         \
@@ -35,6 +36,54 @@ static typename C::Aff load_aff(const u64* xy) {
 }
 template <class C>
 static void store_aff(const typename C::Aff& a, u64* xy) { a.x.to_canonical(xy); a.y.to_canonical(xy + 4); }
+
+template <class F> static NovaRelaxed<F> load_relaxed(const u64* U) {
+  NovaRelaxed<F> r;
+  r.W.x = F::from_canonical(U); r.W.y = F::from_canonical(U + 4); r.E.x = F::from_canonical(U + 8); r.E.y = F::from_canonical(U + 12);
+  r.u = F::from_canonical(U + 16); memcpy(r.X0, U + 20, 32); memcpy(r.X1, U + 24, 32);
+  return r;
+}
+template <class F> static void store_relaxed(const NovaRelaxed<F>& r, u64* U) {
+  r.W.x.to_canonical(U); r.W.y.to_canonical(U + 4); r.E.x.to_canonical(U + 8); r.E.y.to_canonical(U + 12); r.u.to_canonical(U + 16);
+  memcpy(U + 20, r.X0, 32); memcpy(U + 24, r.X1, 32);
+}
+template <class Cv, class G>
+static int nova_step_c(int is_primary, const u64* pz, u64 i, const u64* z_i, const u64* z_next, int len_z, const u64* U, const u64* u, const u64* T,
+                       u64* U_new, u64* rho, u64* x1) {
+  typedef typename Cv::Base F;
+  std::vector<F> zi(len_z), zn(len_z);
+  for (int k = 0; k < len_z; k++) { zi[k] = F::from_canonical(z_i + 4 * k); zn[k] = F::from_canonical(z_next + 4 * k); }
+  NovaFresh<F> uf; uf.W.x = F::from_canonical(u); uf.W.y = F::from_canonical(u + 4); uf.x0 = F::from_canonical(u + 8); uf.x1 = F::from_canonical(u + 12);
+  Affine<F> Tp; Tp.x = F::from_canonical(T); Tp.y = F::from_canonical(T + 4);
+  NovaRelaxed<F> R; F x1f;
+  if (!nova_step<Cv, G>(is_primary != 0, F::from_canonical(pz), i, zi, zn, load_relaxed<F>(U), uf, Tp, R, rho, x1f)) return 0;
+  store_relaxed(R, U_new); x1f.to_canonical(x1);
+  return 1;
+}
+template <class F>
+static long r1cs_check_relaxed_t(size_t nrows, size_t ncols, const uint32_t* const* row_ptr, const uint32_t* const* col, const uint32_t* const* coef,
+                                 const u64* dict, size_t ndict, const u64* z, const u64* u, const u64* E, int threads) {
+  std::vector<F> D(ndict), Z(ncols);
+  for (size_t k = 0; k < ndict; k++) D[k] = F::from_canonical(dict + 4 * k);
+  for (size_t k = 0; k < ncols; k++) Z[k] = F::from_canonical(z + 4 * k);
+  std::vector<F> out[3];
+  for (int m = 0; m < 3; m++) {
+    out[m].resize(nrows);
+    auto work = [&, m](size_t lo, size_t hi) {
+      for (size_t r = lo; r < hi; r++) { F acc = F::zero(); for (uint32_t k = row_ptr[m][r]; k < row_ptr[m][r + 1]; k++) acc = acc + D[coef[m][k]] * Z[col[m][k]]; out[m][r] = acc; }
+    };
+    std::vector<std::thread> th; const int nt = threads > 0 ? threads : 1; size_t chunk = (nrows + nt - 1) / nt;
+    for (int t = 0; t < nt; t++) th.emplace_back(work, std::min(nrows, t * chunk), std::min(nrows, (t + 1) * chunk));
+    for (auto& x : th) x.join();
+  }
+  const F uu = F::from_canonical(u);
+  for (size_t r = 0; r < nrows; r++) {
+    F rhs = uu * out[2][r];
+    if (E) rhs = rhs + F::from_canonical(E + 4 * r);
+    if (out[0][r] * out[1][r] != rhs) return (long)r;
+  }
+  return -1;
+}
 
 extern "C" {
 
@@ -227,6 +276,32 @@ long orc_r1cs_check(size_t nrows, size_t ncols, const uint32_t* const* row_ptr, 
   for (int m = 0; m < 3; m++) if (outs[m]) for (size_t r = 0; r < nrows; r++) out[m][r].to_canonical(outs[m] + 4 * r);
   for (size_t r = 0; r < nrows; r++) if (out[0][r] * out[1][r] != out[2][r]) return (long)r;
   return -1;
+}
+
+// ---------------- Nova IVC relation (nova.hpp) ----------------
+// chain hash over field fid (0 = BN254 Fr, 1 = BN254 Fq)
+void orc_nova_hash(int fid, const u64* in, int n, u64* out) {
+  FIELD_SWITCH(fid, { std::vector<F> v(n); for (int i = 0; i < n; i++) v[i] = F::from_canonical(in + 4 * i); nova_hash<F>(v).to_canonical(out); });
+}
+// trunc250(H(pz, i, z, U)); U = 7 canonical elements (W.x, W.y, E.x, E.y, u, X0, X1)
+void orc_nova_instance_hash(int fid, const u64* pz, u64 i, const u64* z, int len_z, const u64* U, u64* out) {
+  FIELD_SWITCH(fid, {
+    std::vector<F> zz(len_z); for (int k = 0; k < len_z; k++) zz[k] = F::from_canonical(z + 4 * k);
+    low_bits(nova_instance_hash_full<F>(F::from_canonical(pz), i, zz, load_relaxed<F>(U)), 250).to_canonical(out);
+  });
+}
+// side 0: circuit over Fr folding Grumpkin commitments; side 1: circuit over Fq folding BN254-G1 commitments.
+// Returns 1 when the relation holds (incoming hash matches or base case), 0 otherwise.
+int orc_nova_step(int side, int is_primary, const u64* pz, u64 i, const u64* z_i, const u64* z_next, int len_z, const u64* U, const u64* u, const u64* T,
+                  u64* U_new, u64* rho, u64* x1) {
+  return side == 0 ? nova_step_c<Grumpkin, BnFq>(is_primary, pz, i, z_i, z_next, len_z, U, u, T, U_new, rho, x1)
+                   : nova_step_c<BnG1, BnFr>(is_primary, pz, i, z_i, z_next, len_z, U, u, T, U_new, rho, x1);
+}
+// Relaxed R1CS over field fid with dictionary-compressed CSR: first row where Az∘Bz != u·Cz + E (E may be NULL), or -1.
+long orc_r1cs_check_relaxed(int fid, size_t nrows, size_t ncols, const uint32_t* const* row_ptr, const uint32_t* const* col, const uint32_t* const* coef,
+                            const u64* dict, size_t ndict, const u64* z, const u64* u, const u64* E, int threads) {
+  FIELD_SWITCH(fid, return r1cs_check_relaxed_t<F>(nrows, ncols, row_ptr, col, coef, dict, ndict, z, u, E, threads));
+  return -2;
 }
 
 }  // extern "C"

@@ -123,6 +123,42 @@ class Oracle:
         secs = self.lib.orc_msm_mont_timed(cid, _p(bases_mont), _p(scalars), C.c_size_t(n), threads, _p(o))
         return secs, tuple(from_limbs(o))
 
+    # ---- Nova IVC relation (oracle/nova.hpp)
+    def nova_hash(self, fid, inputs):
+        o = np.zeros(4, dtype=np.uint64)
+        self.lib.orc_nova_hash(fid, _p(to_limbs(inputs)), len(inputs), _p(o))
+        return from_limbs(o)[0]
+
+    def nova_instance_hash(self, fid, pz, i, z, U):
+        """trunc250(H(pz, i, z, U)); U = [W.x, W.y, E.x, E.y, u, X0, X1]."""
+        o = np.zeros(4, dtype=np.uint64)
+        self.lib.orc_nova_instance_hash(fid, _p(to_limbs([pz])), C.c_uint64(i), _p(to_limbs(z)), len(z), _p(to_limbs(U)), _p(o))
+        return from_limbs(o)[0]
+
+    def nova_step(self, side, is_primary, pz, i, z_i, z_next, U, u, T):
+        """The augmented circuit's relation, natively: returns None if the incoming hash does not match,
+        else (U_new[7], rho, x1)."""
+        Un, rho, x1 = np.zeros((7, 4), dtype=np.uint64), np.zeros(4, dtype=np.uint64), np.zeros(4, dtype=np.uint64)
+        ok = self.lib.orc_nova_step(side, int(is_primary), _p(to_limbs([pz])), C.c_uint64(i), _p(to_limbs(z_i)), _p(to_limbs(z_next)), len(z_i),
+                                    _p(to_limbs(U)), _p(to_limbs(u)), _p(to_limbs(T)), _p(Un), _p(rho), _p(x1))
+        if not ok:
+            return None
+        return from_limbs(Un), from_limbs(rho)[0], from_limbs(x1)[0]
+
+    def r1cs_check_relaxed(self, fid, tables, n_wires, z, u=1, E=None, threads=8):
+        """First row where Az∘Bz != u·Cz + E over field fid (-1 if none).  tables: dict with {A,B,C}_{rowptr,col,coef} (uint32)
+        and dict_canon ((n,4) uint64), as exported by the product."""
+        self.lib.orc_r1cs_check_relaxed.restype = C.c_long
+        PP = C.c_void_p * 3
+        keep = [np.ascontiguousarray(tables[f"{m}_{k}"], dtype=np.uint32) for k in ("rowptr", "col", "coef") for m in "ABC"]
+        rp, col, coef = PP(*[a.ctypes.data for a in keep[0:3]]), PP(*[a.ctypes.data for a in keep[3:6]]), PP(*[a.ctypes.data for a in keep[6:9]])
+        d = np.ascontiguousarray(tables["dict_canon"], dtype=np.uint64)
+        z = np.ascontiguousarray(z, dtype=np.uint64)
+        Ep = _p(np.ascontiguousarray(E, dtype=np.uint64)) if E is not None else None
+        nrows = len(keep[0]) - 1
+        return self.lib.orc_r1cs_check_relaxed(fid, C.c_size_t(nrows), C.c_size_t(n_wires), rp, col, coef, _p(d), C.c_size_t(d.size // 4), _p(z),
+                                               _p(to_limbs([u])), Ep, threads)
+
     # ---- Poseidon & hashers
     def poseidon(self, inputs):
         o = np.zeros(4, dtype=np.uint64)

@@ -1,0 +1,167 @@
+"""Nova IVC on the GPU (vimz_ivc_*): the product's own verifier must accept, and so must an
+independent verifier assembled from the CPU oracle (oracle/nova.hpp hashes, generic relaxed-R1CS check, oracle MSM) over the
+exported proof: both running instances, the last fresh secondary instance, the two output hashes and every commitment."""
+import hashlib
+import struct
+
+import numpy as np
+import pytest
+
+from tests._oracle import from_limbs, to_limbs
+from tests.test_circuits import step_inputs
+from vimz_amd import _lib
+from vimz_amd.circuit import Circuit
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from vimz_amd import hip
+    c = hip.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def keys(ctx):
+    ck1 = ctx.bases_generate(_lib.CURVE_BN254_G1, 1 << 19)
+    ck2 = ctx.bases_generate(_lib.CURVE_GRUMPKIN, 1 << 13, b"ck-secondary")
+    yield ck1, ck2
+    ck1.free(); ck2.free()
+
+
+def _shape_digest(ivc, side):
+    """SHA3-256 of the augmented circuit's shape, as aug/augmented.hpp serialises it, truncated to 250 bits."""
+    from vimz_amd import hip
+    info = hip._export(ivc.ctx.lib.vimz_ivc_export, ivc.h, side, hip.IX_INFO).view(np.uint64)
+    len_z = ivc.circuit.len_z if side == 0 else 1
+    h = hashlib.sha3_256()
+    h.update(struct.pack("<6Q", 0x3130677561, int(info[0]), int(info[1]), len_z, int(info[2]), 1 if side == 0 else 0))
+    for code in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9):     # A,B,C row_ptr/col/coef, then the dictionary in Montgomery form
+        a = hip._export(ivc.ctx.lib.vimz_ivc_export, ivc.h, side, code)
+        elem = 32 if code == 9 else 4
+        h.update(struct.pack("<Q", len(a) // elem))
+        h.update(a.tobytes())
+    return int.from_bytes(h.digest(), "little") & ((1 << 250) - 1)
+
+
+def oracle_verify(oracle, ivc, ck1, ck2, n_steps, z0, check_commitments=True):
+    """RecursiveSNARK::verify restated over the exported proof; returns a list of failed checks."""
+    from vimz_amd import hip
+    failed = []
+    info = ivc.info()
+    par1, par2 = from_limbs(ivc.export(0, hip.IX_PARAMS)), from_limbs(ivc.export(1, hip.IX_PARAMS))
+    len_z = info["len_z"]
+    digest1, pz1, z0_x, z_n = par1[0], par1[1], par1[2:2 + len_z], par1[2 + len_z:]
+    digest2, pz2 = par2[0], par2[1]
+    if z0_x != list(z0): failed.append("z0")
+    if digest1 != _shape_digest(ivc, 0) or digest2 != _shape_digest(ivc, 1): failed.append("shape digest")
+    if pz1 != oracle.nova_hash(0, [digest1, *z0]) or pz2 != oracle.nova_hash(1, [digest2, 0]): failed.append("pz")
+    U1, U2 = from_limbs(ivc.export(0, hip.IX_INSTANCE)), from_limbs(ivc.export(1, hip.IX_INSTANCE))
+    u2 = from_limbs(ivc.export(1, hip.IX_FRESH_INSTANCE))
+    # the two hashes the last secondary instance carries
+    if oracle.nova_instance_hash(0, pz1, n_steps, z_n, U2) != u2[2]: failed.append("hash of the primary chain")
+    if oracle.nova_instance_hash(1, pz2, n_steps, [0], U1) != u2[3]: failed.append("hash of the secondary chain")
+    for side, U, ck, cid, fid in ((0, U1, ck1, 0, 0), (1, U2, ck2, 1, 1)):
+        tabs = ivc.r1cs(side)
+        Z, E = ivc.export(side, hip.IX_RUNNING_Z), ivc.export(side, hip.IX_RUNNING_E)
+        nw = len(Z)
+        if from_limbs(Z[0:1])[0] != U[4] or from_limbs(Z[-2:]) != U[5:7]: failed.append(f"side {side}: instance scalars")
+        if oracle.r1cs_check_relaxed(fid, tabs, nw, Z, u=U[4], E=E) != -1: failed.append(f"side {side}: relaxed relation")
+        if check_commitments:
+            bases = ck.download(0, max(nw - 3, len(E)))
+            if oracle.msm(cid, bases[:nw - 3], Z[1:nw - 2]) != (U[0], U[1]): failed.append(f"side {side}: comm_W")
+            if oracle.msm(cid, bases[:len(E)], E) != (U[2], U[3]): failed.append(f"side {side}: comm_E")
+    tabs = ivc.r1cs(1)
+    z2 = ivc.export(1, hip.IX_FRESH_Z)
+    if from_limbs(z2[0:1])[0] != 1 or from_limbs(z2[-2:]) != u2[2:4]: failed.append("fresh instance scalars")
+    if oracle.r1cs_check_relaxed(1, tabs, len(z2), z2) != -1: failed.append("fresh relation")
+    if check_commitments:
+        bases = ck2.download(0, len(z2) - 3)
+        if oracle.msm(1, bases, z2[1:len(z2) - 2]) != (u2[0], u2[1]): failed.append("fresh comm_W")
+    return failed, z_n
+
+
+@pytest.mark.parametrize("op", ["hash", "grayscale", "contrast", "blur", "resize"])
+def test_ivc_verifies_and_the_oracle_verifier_accepts(ctx, keys, oracle, op):
+    from vimz_amd import hip
+    ck1, ck2 = keys
+    c = Circuit.for_resolution(op, "HD")
+    z0, inputs = step_inputs(op)
+    steps = np.stack(inputs)
+    ivc = hip.IVC(ctx, c, ck1, ck2, max_batch=4)
+    acc = hip.Prover(ctx, c, ck1, max_batch=4)
+    try:
+        ivc.reset(z0)
+        ivc.fold(steps)
+        assert ivc.verify() == 0
+        z_n, n = ivc.state()
+        assert n == 10
+        acc.reset(z0); acc.fold(steps)
+        assert from_limbs(acc.instance()["z"]) == z_n          # the step circuit's state chain is the pinned one
+        failed, z_exported = oracle_verify(oracle, ivc, ck1, ck2, 10, z0, check_commitments=op in ("hash", "grayscale"))
+        assert failed == [] and z_exported == z_n
+        info = ivc.info()
+        assert info["step_wires"] == c.n_wires and info["step_constraints"] == c.n_constraints
+        assert info["primary_wires"] == c.n_wires + info["verifier_wires"]
+    finally:
+        ivc.close(); acc.close()
+
+
+def test_ivc_in_several_calls_equals_one_call_and_reset_restarts(ctx, keys, oracle):
+    from vimz_amd import hip
+    ck1, ck2 = keys
+    c = Circuit.for_resolution("hash", "HD")
+    z0, inputs = step_inputs("hash")
+    steps = np.stack(inputs)
+    a, b = hip.IVC(ctx, c, ck1, ck2, max_batch=3), hip.IVC(ctx, c, ck1, ck2, max_batch=16)
+    try:
+        a.reset(z0); b.reset(z0)
+        a.fold(steps[:1]); a.fold(steps[1:4]); a.fold(steps[4:])
+        b.fold(steps)
+        assert a.verify() == 0 and b.verify() == 0
+        for side in (0, 1):
+            assert (a.export(side, hip.IX_INSTANCE) == b.export(side, hip.IX_INSTANCE)).all()
+            assert (a.export(side, hip.IX_RUNNING_Z) == b.export(side, hip.IX_RUNNING_Z)).all()
+        assert (a.export(1, hip.IX_FRESH_INSTANCE) == b.export(1, hip.IX_FRESH_INSTANCE)).all()
+        # verification in the middle of a run does not disturb it
+        a.reset(z0); a.fold(steps[:5]); assert a.verify() == 0; a.fold(steps[5:]); assert a.verify() == 0
+        assert (a.export(0, hip.IX_INSTANCE) == b.export(0, hip.IX_INSTANCE)).all()
+        failed, _ = oracle_verify(oracle, a, ck1, ck2, 10, z0)
+        assert failed == []
+    finally:
+        a.close(); b.close()
+
+
+def test_ivc_rejects_a_row_that_violates_the_step_relation(ctx, keys):
+    from vimz_amd import hip
+    ck1, ck2 = keys
+    c = Circuit.for_resolution("grayscale", "HD")
+    z0, inputs = step_inputs("grayscale")
+    steps = np.stack(inputs).copy()
+    steps[6, 200, 0] ^= np.uint64(0xFF)          # a transformed pixel that is no longer the grayscale of the original
+    ivc = hip.IVC(ctx, c, ck1, ck2, max_batch=4)
+    try:
+        ivc.reset(z0)
+        with pytest.raises(_lib.VimzError) as e:
+            ivc.fold(steps)
+        assert e.value.code == _lib.ERR_UNSAT
+    finally:
+        ivc.close()
+
+
+def test_a_forged_instance_is_caught_by_the_oracle_verifier(ctx, keys, oracle):
+    """The oracle verifier is not vacuous: flipping one element of the exported proof makes it fail."""
+    from vimz_amd import hip
+    ck1, ck2 = keys
+    c = Circuit.for_resolution("hash", "HD")
+    z0, inputs = step_inputs("hash")
+    ivc = hip.IVC(ctx, c, ck1, ck2, max_batch=4)
+    try:
+        ivc.reset(z0); ivc.fold(np.stack(inputs)[:4])
+        assert oracle_verify(oracle, ivc, ck1, ck2, 4, z0, check_commitments=False)[0] == []
+        assert oracle_verify(oracle, ivc, ck1, ck2, 5, z0, check_commitments=False)[0] != []      # wrong step count
+        assert "z0" in oracle_verify(oracle, ivc, ck1, ck2, 4, [1], check_commitments=False)[0]
+    finally:
+        ivc.close()

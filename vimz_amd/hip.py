@@ -312,18 +312,18 @@ def _export(fn, *args):
     n = fn(*args, None, 0)
     if n < 0:
         raise L.VimzError(n, "export")
-    buf = np.zeros(max(n // 8, 1), dtype=np.uint64)
+    buf = np.zeros((n + 7) // 8 + 1, dtype=np.uint64)
     got = fn(*args, _ptr(buf), n)
     if got != n:
         raise L.VimzError(got, "export")
-    return buf[: n // 8]
+    return buf.view(np.uint8)[:n]
 
 
 def _r1cs_tables(fn, *args):
     out = {}
     for name, code in CX_R1CS.items():
         a = _export(fn, *args, code)
-        out[name] = a.reshape(-1, 4) if name == "dict_canon" else a.view(np.uint32)
+        out[name] = a.view(np.uint64).reshape(-1, 4) if name == "dict_canon" else a.view(np.uint32)
     return out
 
 
@@ -398,7 +398,8 @@ class IVC:
         return {k: (s[i], n[i]) for i, k in enumerate(self.PHASES)}
 
     def export(self, side, what):
-        return _export(self.ctx.lib.vimz_ivc_export, self.h, side, what)
+        """(n, 4) uint64 canonical elements."""
+        return _export(self.ctx.lib.vimz_ivc_export, self.h, side, what).view(np.uint64).reshape(-1, 4)
 
     def r1cs(self, side):
         return _r1cs_tables(self.ctx.lib.vimz_ivc_export, self.h, side)
@@ -422,7 +423,7 @@ class AugCircuit:
         if rc:
             raise L.VimzError(rc, "vimz_augcircuit_build")
         self.h = h
-        info = _export(lib.vimz_augcircuit_export, self.h, IX_INFO)
+        info = _export(lib.vimz_augcircuit_export, self.h, IX_INFO).view(np.uint64)
         self.n_wires, self.n_constraints = int(info[0]), int(info[1])
 
     def close(self):
