@@ -7,6 +7,7 @@
 // Constraint rows: the step circuit's rows first, then the verifier circuit's.
 #pragma once
 #include "circuit.hpp"
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include "../keccak.hpp"
@@ -60,6 +61,9 @@ struct AugCircuit {
   explicit AugCircuit(cb::BuilderT<F>& ext) : b(ext) {}
   uint32_t len_z = 0, step_wires = 0, step_constraints = 0;
   F digest;                 // SHA3-256 of the shape, truncated to 250 bits
+  mutable HashCache<F> cache;                 // the output hash of the last witness() call, replayed by the next (cs.hpp)
+  mutable std::unique_ptr<Worker> worker;     // helper thread for the scalar-multiplication chains (created on first use)
+  bool use_worker = std::thread::hardware_concurrency() > 1 && !getenv("VIMZ_AUG_NO_THREADS");
 
   uint32_t n_wires() const { return b.n_wires; }
   uint32_t n_constraints() const { return b.n_constraints(); }
@@ -97,9 +101,10 @@ struct AugCircuit {
   AugOut<FP> witness(const AugIn<FP>& in, const F* z_i, const F* z_next, std::vector<F>& aug, bool* bad) const {
     CS<FP> cs; cs.base = step_wires;
     cs.w.reserve(aug_wires());
+    if (use_worker) { if (!worker) worker.reset(new Worker()); cs.worker = worker.get(); }
     std::vector<Num<F>> zi(len_z), zn(len_z);
     for (uint32_t k = 0; k < len_z; k++) { zi[k].v = z_i[k]; zn[k].v = z_next[k]; }
-    AugOut<FP> o = synthesize_augmented<FP, OP>(cs, in, zi, zn, primary, CycleSide<FP>::b(), CycleSide<FP>::G());
+    AugOut<FP> o = synthesize_augmented<FP, OP>(cs, in, zi, zn, primary, CycleSide<FP>::b(), CycleSide<FP>::G(), &cache);
     if (cs.w.size() != aug_wires()) throw std::runtime_error("aug: witness length differs from the shape");
     if (bad) *bad = cs.bad;
     aug.swap(cs.w);

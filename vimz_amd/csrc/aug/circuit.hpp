@@ -77,7 +77,7 @@ struct AugOut {
 // constraint system).  curve_b, G: the other curve (y^2 = x^3 + b over F) and a fixed finite point on it.
 template <class FP, class OP>
 AugOut<FP> synthesize_augmented(CS<FP>& cs, const AugIn<FP>& in, const std::vector<Num<Fp<FP>>>& z_i, const std::vector<Num<Fp<FP>>>& z_next,
-                                bool is_primary, const Fp<FP>& curve_b, const Affine<Fp<FP>>& G) {
+                                bool is_primary, const Fp<FP>& curve_b, const Affine<Fp<FP>>& G, HashCache<Fp<FP>>* cache = nullptr) {
   typedef Fp<FP> F;
   typedef Num<F> N;
   typedef EcGadgets<FP> Ec;
@@ -118,7 +118,7 @@ AugOut<FP> synthesize_augmented(CS<FP>& cs, const AugIn<FP>& in, const std::vect
   hin.push_back(UW.x); hin.push_back(UW.y); hin.push_back(UE.x); hin.push_back(UE.y); hin.push_back(Uu);
   for (int j = 0; j < 4; j++) hin.push_back(UX0[j]);
   for (int j = 0; j < 4; j++) hin.push_back(UX1[j]);
-  N h_chk = cs.hash(hin);
+  N h_chk = cs.hash_cached(hin, cache, nullptr);
   std::vector<N> hb = cs.bits(h_chk, FP::BITS);
   N h250 = cs.pack(hb, 0, 250);
   cs.enforce(nb, cs.sub(h250, ux0), cs.zero());
@@ -145,7 +145,7 @@ AugOut<FP> synthesize_augmented(CS<FP>& cs, const AugIn<FP>& in, const std::vect
 
   std::vector<Affine<F>> ops = {Ec::scalar_operand(in.u.W, G), Ec::scalar_operand(in.T, G)};
   std::vector<typename Ec::ChainHints> hints;
-  Ec::chain_hints(ops, out.rho_low, 128, hints);
+  Ec::chain_hints_parallel(ops, out.rho_low, 128, hints, cs.worker);
   Pt rW = ec.scalar_mul(uW, rb, 128, hints[0]);
   Pt rT = ec.scalar_mul(T, rb, 128, hints[1]);
   Pt Wn = ec.add(We, rW), En = ec.add(Ee, rT);
@@ -172,7 +172,7 @@ AugOut<FP> synthesize_augmented(CS<FP>& cs, const AugIn<FP>& in, const std::vect
   hout.push_back(Wo.x); hout.push_back(Wo.y); hout.push_back(Eo.x); hout.push_back(Eo.y); hout.push_back(uo);
   for (int j = 0; j < 4; j++) hout.push_back(X0n[j]);
   for (int j = 0; j < 4; j++) hout.push_back(X1n[j]);
-  N h_new = cs.hash(hout);
+  N h_new = cs.hash_cached(hout, nullptr, cache);
   std::vector<N> hnb = cs.bits(h_new, FP::BITS);
   N hn250 = cs.pack(hnb, 0, 250);
 

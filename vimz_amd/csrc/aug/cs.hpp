@@ -10,7 +10,13 @@
 // combinations are built, inversions are batched (Montgomery's trick) by the gadgets that need many.
 #pragma once
 #include <stdint.h>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <stdexcept>
+#include <thread>
 #include <vector>
 #include "../circuit/builder.hpp"
 #include "../circuit/poseidon_params.hpp"
@@ -25,6 +31,50 @@ struct Num {
   F v;
   bool konst = false;   // value is a circuit constant (same in every run): products with it cost nothing
 };
+
+// One helper thread per prover for the two independent scalar-multiplication chains of a step (host cores are plentiful
+// next to a GPU; the chains are the largest sequential piece of the verifier circuit's witness).
+struct Worker {
+  // The next job arrives a few milliseconds after the last one while a proof is being folded, and waking a sleeping thread
+  // costs more than the job saves: the helper spins for a while after each job and only then goes to sleep.
+  std::thread th; std::mutex m; std::condition_variable cv;
+  std::function<void()> job;
+  std::atomic<int> state{0};          // 0 idle, 1 job posted, 2 job done
+  std::atomic<bool> sleeping{false}, stop{false};
+  Worker() { th = std::thread([this] { loop(); }); }
+  ~Worker() { stop = true; { std::lock_guard<std::mutex> g(m); } cv.notify_all(); th.join(); }
+  void loop() {
+    for (;;) {
+      const auto t0 = std::chrono::steady_clock::now();
+      int spins = 0;
+      while (state.load(std::memory_order_acquire) != 1) {
+        if (stop) return;
+        std::this_thread::yield();      // free on an idle core; hands the core over when there is only one
+        if ((++spins & 63) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) {
+          std::unique_lock<std::mutex> lk(m);
+          sleeping = true;
+          cv.wait(lk, [this] { return state.load() == 1 || stop; });
+          sleeping = false;
+          if (stop) return;
+          break;
+        }
+      }
+      job();
+      state.store(2, std::memory_order_release);
+    }
+  }
+  void start(std::function<void()> f) {
+    job = std::move(f);
+    state.store(1, std::memory_order_release);
+    if (sleeping.load()) { { std::lock_guard<std::mutex> g(m); } cv.notify_all(); }
+  }
+  void wait() { while (state.load(std::memory_order_acquire) != 2) std::this_thread::yield(); state.store(0, std::memory_order_relaxed); }
+};
+
+// Wires of one hash whose inputs recur: H(pz, i+1, z_{i+1}, U_new) computed at the end of a step is exactly the hash the next
+// step's circuit recomputes to check its incoming instance, so its S-box wires are kept and replayed.
+template <class F>
+struct HashCache { std::vector<F> in, wires; F out; bool valid = false; };
 
 // Montgomery batch inversion; zeros are left as zero.
 template <class F>
@@ -53,6 +103,7 @@ struct CS {
   uint32_t base = 0;              // index of the first wire this synthesis allocates
   std::vector<F> w;               // values of the wires allocated by this synthesis, in order
   bool bad = false;               // witness mode: some value did not fit its range (the witness will not satisfy)
+  Worker* worker = nullptr;       // witness mode: optional helper thread
 
   bool shape() const { return b != nullptr; }
 
@@ -131,6 +182,18 @@ struct CS {
   N poseidon(const std::vector<N>& in) {
     const int t = (int)in.size() + 1;
     if (t > POSEIDON_MAX_T) throw std::runtime_error("aug poseidon: too many inputs");
+    if (!b) {   // witness mode: values only, partial rounds in sparse form; emits exactly the wires the shape mode allocates
+      bool plain = true;
+      for (auto& x : in) plain = plain && !x.konst;
+      if (plain) {
+        F s[POSEIDON_MAX_T];
+        s[0] = F::zero();
+        for (int i = 1; i < t; i++) s[i] = in[i - 1].v;
+        cb::poseidon_permute<FP>(s, t, true, &w);
+        N r; r.v = s[0];
+        return r;
+      }
+    }
     const cb::PoseidonTableT<F>& P = cb::poseidon_table_t<FP>(t);
     std::vector<N> st((size_t)t), nx((size_t)t);
     st[0] = zero();
@@ -152,6 +215,24 @@ struct CS {
       st.swap(nx);
     }
     return st[0];
+  }
+  // hash() with replay: `read` (if its inputs match) supplies the wires; `write` receives them for a later replay
+  N hash_cached(const std::vector<N>& in, const HashCache<F>* read, HashCache<F>* write) {
+    if (b) return hash(in);
+    if (read && read->valid && read->in.size() == in.size()) {
+      bool same = true;
+      for (size_t i = 0; i < in.size() && same; i++) same = read->in[i].eq(in[i].v);
+      if (same) { w.insert(w.end(), read->wires.begin(), read->wires.end()); N r; r.v = read->out; return r; }
+    }
+    const size_t w0 = w.size();
+    N h = hash(in);
+    if (write) {
+      write->in.resize(in.size());
+      for (size_t i = 0; i < in.size(); i++) write->in[i] = in[i].v;
+      write->wires.assign(w.begin() + w0, w.end());
+      write->out = h.v; write->valid = true;
+    }
+    return h;
   }
   // Hash of any number of elements: the first permutation absorbs 8, every further one the running hash + 7.
   N hash(const std::vector<N>& in) {
@@ -290,6 +371,18 @@ struct EcGadgets {
         out[j].lam_a[i] = F::mul(F::sub(Ps[j].y, Da[ix].y), den[2 * ix + 1]);
       }
     }
+  }
+
+  // the same with the operands split between the calling thread and a helper
+  static void chain_hints_parallel(const std::vector<Affine<F>>& Ps, const uint32_t* k, int nbits, std::vector<ChainHints>& out, Worker* wk) {
+    if (!wk || Ps.size() != 2) { chain_hints(Ps, k, nbits, out); return; }
+    std::vector<ChainHints> o1;
+    const std::vector<Affine<F>> p1 = {Ps[1]};
+    wk->start([&] { chain_hints(p1, k, nbits, o1); });
+    std::vector<ChainHints> o0;
+    chain_hints(std::vector<Affine<F>>{Ps[0]}, k, nbits, o0);
+    wk->wait();
+    out.clear(); out.push_back(std::move(o0[0])); out.push_back(std::move(o1[0]));
   }
 
   // (2^nbits + sum bits[i] 2^i) · P.  An identity P gives the identity.  9 constraints per bit.

@@ -3,6 +3,7 @@
 // not vendored).  Host code; the tables are uploaded to the GPU for the witness kernels.
 #pragma once
 #include <mutex>
+#include <stdexcept>
 #include <vector>
 #include "builder.hpp"
 
@@ -84,9 +85,127 @@ inline const PoseidonTableT<Fp<P>>& poseidon_table_t(int t) {
 }
 inline const PoseidonTable& poseidon_table(int t) { return poseidon_table_t<BnFr>(t); }
 
-// Numeric permutation on the host (used for the IVC state chain between witness batches).
+// ---- partial rounds in sparse form ------------------------------------------------------------------------------------
+// A partial round x <- M·S0(x + c) applies the S-box to lane 0 only, so the change of basis diag(1, N) on the other lanes
+// commutes with it.  Pushing that basis through the rounds (Poseidon paper, App. B) turns every partial round's dense
+// matrix into  [[d00, v^T], [w', I]]  (2t-1 products instead of t^2) with transformed constants; one (t-1)x(t-1) matrix is
+// applied after the last partial round.  Lane 0 — the only value a circuit needs from these rounds — is unchanged.
+template <class F>
+struct PoseidonSparseT {
+  int t = 0;
+  std::vector<F> ctil;   // rp * t      transformed round constants
+  std::vector<F> row;    // rp * t      first row of each round's sparse matrix
+  std::vector<F> col;    // rp * (t-1)  first column below the corner
+  std::vector<F> Pfin;   // (t-1)^2     basis change applied to lanes 1.. after the last partial round
+};
+
+template <class F>
+inline std::vector<F> mat_inverse(std::vector<F> a, int n) {   // Gauss-Jordan, row-major n x n
+  std::vector<F> inv((size_t)n * n, F::zero());
+  for (int i = 0; i < n; i++) inv[(size_t)i * n + i] = F::one();
+  for (int c = 0; c < n; c++) {
+    int piv = c; while (piv < n && a[(size_t)piv * n + c].is_zero()) piv++;
+    if (piv == n) throw std::runtime_error("poseidon: singular matrix");
+    if (piv != c) for (int j = 0; j < n; j++) { std::swap(a[(size_t)piv * n + j], a[(size_t)c * n + j]); std::swap(inv[(size_t)piv * n + j], inv[(size_t)c * n + j]); }
+    const F pi = F::pow_pm2(a[(size_t)c * n + c]);
+    for (int j = 0; j < n; j++) { a[(size_t)c * n + j] = F::mul(a[(size_t)c * n + j], pi); inv[(size_t)c * n + j] = F::mul(inv[(size_t)c * n + j], pi); }
+    for (int r = 0; r < n; r++) {
+      if (r == c) continue;
+      const F f = a[(size_t)r * n + c];
+      if (f.is_zero()) continue;
+      for (int j = 0; j < n; j++) { a[(size_t)r * n + j] = F::sub(a[(size_t)r * n + j], F::mul(f, a[(size_t)c * n + j])); inv[(size_t)r * n + j] = F::sub(inv[(size_t)r * n + j], F::mul(f, inv[(size_t)c * n + j])); }
+    }
+  }
+  return inv;
+}
+
+template <class P>
+inline const PoseidonSparseT<Fp<P>>& poseidon_sparse_t(int t) {
+  typedef Fp<P> F;
+  const PoseidonTableT<F>& T = poseidon_table_t<P>(t);
+  static PoseidonSparseT<F> cache[18];
+  static std::mutex mu;
+  std::lock_guard<std::mutex> guard(mu);
+  PoseidonSparseT<F>& S = cache[t];
+  if (S.t == t) return S;
+  const int m = t - 1, rp = T.rp;
+  S.ctil.resize((size_t)rp * t); S.row.resize((size_t)rp * t); S.col.resize((size_t)rp * m);
+  std::vector<F> N((size_t)m * m, F::zero());
+  for (int i = 0; i < m; i++) N[(size_t)i * m + i] = F::one();
+  for (int r = 0; r < rp; r++) {
+    const F* c = &T.C[(size_t)(T.rf / 2 + r) * t];
+    const std::vector<F> Ninv = mat_inverse(N, m);
+    S.ctil[(size_t)r * t] = c[0];
+    for (int i = 0; i < m; i++) { F acc = F::zero(); for (int k = 0; k < m; k++) acc = F::add(acc, F::mul(Ninv[(size_t)i * m + k], c[1 + k])); S.ctil[(size_t)r * t + 1 + i] = acc; }
+    std::vector<F> D((size_t)t * t);                 // D = M · diag(1, N)
+    for (int i = 0; i < t; i++) {
+      D[(size_t)i * t] = T.M[(size_t)i * t];
+      for (int j = 0; j < m; j++) { F acc = F::zero(); for (int k = 0; k < m; k++) acc = F::add(acc, F::mul(T.M[(size_t)i * t + 1 + k], N[(size_t)k * m + j])); D[(size_t)i * t + 1 + j] = acc; }
+    }
+    std::vector<F> Dhat((size_t)m * m), w(m);
+    for (int i = 0; i < m; i++) { w[i] = D[(size_t)(1 + i) * t]; for (int j = 0; j < m; j++) Dhat[(size_t)i * m + j] = D[(size_t)(1 + i) * t + 1 + j]; }
+    const std::vector<F> Dinv = mat_inverse(Dhat, m);
+    for (int j = 0; j < t; j++) S.row[(size_t)r * t + j] = D[j];
+    for (int i = 0; i < m; i++) { F acc = F::zero(); for (int k = 0; k < m; k++) acc = F::add(acc, F::mul(Dinv[(size_t)i * m + k], w[k])); S.col[(size_t)r * m + i] = acc; }
+    N.swap(Dhat);
+  }
+  S.Pfin = N;
+  S.t = t;
+  return S;
+}
+
+// The permutation on values: state[0..t) in place.  wires (optional): receives x^2, x^4, x^5 of every S-box in (round, lane)
+// order, skipping S-boxes whose input is the constant (0 + C) — lane 0 of round 0 when lane0_const — i.e. exactly the wires
+// the constraint systems allocate (aug/cs.hpp).
+template <class FP>
+inline void poseidon_permute(Fp<FP>* s, int t, bool lane0_const, std::vector<Fp<FP>>* wires) {
+  typedef Fp<FP> F;
+  const PoseidonTableT<F>& P = poseidon_table_t<FP>(t);
+  const PoseidonSparseT<F>& S = poseidon_sparse_t<FP>(t);
+  F u[POSEIDON_MAX_T];
+  auto sbox = [&](F& x, bool emit) { const F x2 = F::sqr(x), x4 = F::sqr(x2), x5 = F::mul(x4, x); if (wires && emit) { wires->push_back(x2); wires->push_back(x4); wires->push_back(x5); } x = x5; };
+  auto mix = [&]() {
+    for (int i = 0; i < t; i++) { F acc = F::zero(); for (int j = 0; j < t; j++) acc = F::add(acc, F::mul(P.M[(size_t)i * t + j], s[j])); u[i] = acc; }
+    for (int i = 0; i < t; i++) s[i] = u[i];
+  };
+  const int half = P.rf / 2;
+  for (int r = 0; r < half; r++) {
+    for (int i = 0; i < t; i++) s[i] = F::add(s[i], P.C[(size_t)r * t + i]);
+    for (int i = 0; i < t; i++) sbox(s[i], !(r == 0 && i == 0 && lane0_const));
+    mix();
+  }
+  const int m = t - 1;
+  for (int r = 0; r < P.rp; r++) {
+    const F* ct = &S.ctil[(size_t)r * t]; const F* row = &S.row[(size_t)r * t]; const F* col = &S.col[(size_t)r * m];
+    for (int i = 0; i < t; i++) s[i] = F::add(s[i], ct[i]);
+    sbox(s[0], true);
+    F n0 = F::mul(row[0], s[0]);
+    for (int i = 1; i < t; i++) n0 = F::add(n0, F::mul(row[i], s[i]));
+    for (int i = 1; i < t; i++) s[i] = F::add(s[i], F::mul(col[i - 1], s[0]));
+    s[0] = n0;
+  }
+  for (int i = 0; i < m; i++) { F acc = F::zero(); for (int k = 0; k < m; k++) acc = F::add(acc, F::mul(S.Pfin[(size_t)i * m + k], s[1 + k])); u[i] = acc; }
+  for (int i = 0; i < m; i++) s[1 + i] = u[i];
+  for (int r = half + P.rp; r < P.rf + P.rp; r++) {
+    for (int i = 0; i < t; i++) s[i] = F::add(s[i], P.C[(size_t)r * t + i]);
+    for (int i = 0; i < t; i++) sbox(s[i], true);
+    mix();
+  }
+}
+
+// Numeric hash on the host (IVC state chain, transcript, instance hashes).
 template <class FP>
 inline Fp<FP> poseidon_hash_t(const Fp<FP>* in, int n) {
+  typedef Fp<FP> F;
+  F s[POSEIDON_MAX_T];
+  s[0] = F::zero();
+  for (int i = 0; i < n; i++) s[i + 1] = in[i];
+  poseidon_permute<FP>(s, n + 1, true, nullptr);
+  return s[0];
+}
+// The dense textbook form (kept for the tests of the sparse form).
+template <class FP>
+inline Fp<FP> poseidon_hash_dense_t(const Fp<FP>* in, int n) {
   typedef Fp<FP> Fe;
   const int t = n + 1;
   const PoseidonTableT<Fe>& P = poseidon_table_t<FP>(t);

@@ -95,12 +95,39 @@ struct Fp {
   }
 
   static VZ_HD Fp add(const Fp& a, const Fp& b) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+    {  // host pass: 4 x 64-bit limbs
+      typedef unsigned __int128 u128;
+      uint64_t A[4], B[4], M[4], t[4], s[4];
+      __builtin_memcpy(A, a.v, 32); __builtin_memcpy(B, b.v, 32); __builtin_memcpy(M, P::MOD.w, 32);
+      u128 c = 0;
+      for (int i = 0; i < 4; i++) { c += (u128)A[i] + B[i]; t[i] = (uint64_t)c; c >>= 64; }
+      uint64_t br = 0;
+      for (int i = 0; i < 4; i++) { u128 d = (u128)t[i] - M[i] - br; s[i] = (uint64_t)d; br = (uint64_t)(d >> 64) & 1; }
+      Fp r; __builtin_memcpy(r.v, br ? t : s, 32);
+      return r;
+    }
+#endif
     uint32_t t[8]; uint64_t c = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) { c += (uint64_t)a.v[i] + b.v[i]; t[i] = (uint32_t)c; c >>= 32; }
     return reduce_once(t);  // a + b < 2p < 2^256: no carry out
   }
   static VZ_HD Fp sub(const Fp& a, const Fp& b) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+    {
+      typedef unsigned __int128 u128;
+      uint64_t A[4], B[4], M[4], t[4];
+      __builtin_memcpy(A, a.v, 32); __builtin_memcpy(B, b.v, 32); __builtin_memcpy(M, P::MOD.w, 32);
+      uint64_t br = 0;
+      for (int i = 0; i < 4; i++) { u128 d = (u128)A[i] - B[i] - br; t[i] = (uint64_t)d; br = (uint64_t)(d >> 64) & 1; }
+      const uint64_t mask = br ? ~(uint64_t)0 : 0;
+      u128 c = 0;
+      for (int i = 0; i < 4; i++) { c += (u128)t[i] + (M[i] & mask); t[i] = (uint64_t)c; c >>= 64; }
+      Fp r; __builtin_memcpy(r.v, t, 32);
+      return r;
+    }
+#endif
     uint32_t t[8]; uint64_t br = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) { uint64_t d = (uint64_t)a.v[i] - b.v[i] - br; t[i] = (uint32_t)d; br = (d >> 32) & 1; }
@@ -116,23 +143,38 @@ struct Fp {
   // CIOS Montgomery product a*b/R mod p.
   static VZ_HD Fp mul(const Fp& a, const Fp& b) {
 #if !defined(__HIP_DEVICE_COMPILE__)
-    // Host pass: same CIOS over 4 x 64-bit limbs (x86-64 has the 64x64->128 multiplier the GPU lacks).
+    // Host pass: CIOS over 4 x 64-bit limbs (x86-64 has the 64x64->128 multiplier the GPU lacks), in the "no-carry" form
+    // valid for moduli whose top limb is below 2^63 - 1 (all four fields here): the two carry chains never overflow a limb.
     typedef unsigned __int128 u128;
-    uint64_t A[4], B[4], M[4], t[5] = {0, 0, 0, 0, 0};
+    uint64_t A[4], B[4], M[4], t0 = 0, t1 = 0, t2 = 0, t3 = 0;
     __builtin_memcpy(A, a.v, 32); __builtin_memcpy(B, b.v, 32); __builtin_memcpy(M, P::MOD.w, 32);  // little-endian host
     const uint64_t n0 = P::N0_64;
+#define VZ_MAC(hi, lo, x, y, z) do { u128 _p = (u128)(x) * (y) + (z); lo = (uint64_t)_p; hi = (uint64_t)(_p >> 64); } while (0)
+#define VZ_MAC2(hi, lo, x, y, z, w) do { u128 _p = (u128)(x) * (y) + (z) + (w); lo = (uint64_t)_p; hi = (uint64_t)(_p >> 64); } while (0)
     for (int i = 0; i < 4; i++) {
-      u128 c = 0;
-      for (int j = 0; j < 4; j++) { c += (u128)A[j] * B[i] + t[j]; t[j] = (uint64_t)c; c >>= 64; }
-      uint64_t t4 = t[4] + (uint64_t)c;
-      uint64_t m = t[0] * n0;
-      c = (u128)m * M[0] + t[0]; c >>= 64;
-      for (int j = 1; j < 4; j++) { c += (u128)m * M[j] + t[j]; t[j - 1] = (uint64_t)c; c >>= 64; }
-      c += t4; t[3] = (uint64_t)c; t[4] = (uint64_t)(c >> 64);
+      const uint64_t bi = B[i];
+      uint64_t Ah, Ch, lo, m;
+      VZ_MAC(Ah, t0, A[0], bi, t0);
+      m = t0 * n0;
+      VZ_MAC(Ch, lo, m, M[0], t0);
+      VZ_MAC2(Ah, t1, A[1], bi, t1, Ah);
+      VZ_MAC2(Ch, t0, m, M[1], t1, Ch);
+      VZ_MAC2(Ah, t2, A[2], bi, t2, Ah);
+      VZ_MAC2(Ch, t1, m, M[2], t2, Ch);
+      VZ_MAC2(Ah, t3, A[3], bi, t3, Ah);
+      VZ_MAC2(Ch, t2, m, M[3], t3, Ch);
+      t3 = Ch + Ah;
+      (void)lo;
     }
-    uint32_t w[8];
-    __builtin_memcpy(w, t, 32);
-    return reduce_once(w);
+#undef VZ_MAC
+#undef VZ_MAC2
+    {
+      uint64_t t[4] = {t0, t1, t2, t3}, s[4];
+      uint64_t br = 0;
+      for (int i = 0; i < 4; i++) { u128 d = (u128)t[i] - M[i] - br; s[i] = (uint64_t)d; br = (uint64_t)(d >> 64) & 1; }
+      Fp r; __builtin_memcpy(r.v, br ? t : s, 32);
+      return r;
+    }
 #else
     uint32_t t[9];
 #pragma unroll

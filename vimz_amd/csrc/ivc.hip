@@ -67,6 +67,8 @@ struct vimz_ivc {
   char* pin = nullptr;                            // pinned: 4 MSM results, then staging for the two host-made witnesses
   size_t pin_res = 0;
   MsmPlan plan_aug{}, plan_T1{}, plan_W2{}, plan_T2{};
+  // the witness commitment and the cross-term commitment of one instance are independent: they run side by side
+  hipStream_t s2 = nullptr; hipEvent_t ev_fork = nullptr; MsmWorkspace ws2;
   // host state of the recursion
   uint64_t i = 0;
   Fe pz1 = Fe::zero(); Fq pz2 = Fq::zero();
@@ -88,6 +90,7 @@ int finish_secondary(vimz_ivc* v) {
   vimz_ctx* ctx = v->ctx;
   double t0 = now_s();
   P_TRY(hipStreamSynchronize(ctx->stream));
+  P_TRY(hipStreamSynchronize(v->s2));
   v->ph_s[IP_WAIT_SEC] += now_s() - t0; v->ph_n[IP_WAIT_SEC]++;
   v->u2.W = msm_finish<Grumpkin>(v->plan_W2, v->pin + 2 * v->pin_res);
   if (v->sec_T_valid) v->T2 = msm_finish<Grumpkin>(v->plan_T2, v->pin + 3 * v->pin_res);
@@ -160,7 +163,9 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
       P_TRY(hipStreamWaitEvent(s, bb.ev[r], 0));
       P_TRY(hipMemcpyAsync(Zi + 8 * sw, pin_aug1, 32 * aw1, hipMemcpyHostToDevice, s));
       launch_spmv(p, s, Zi, az, bz, cz, 2);
-      P_TRY(msm_launch<BnG1>(s, ctx->msm_ws, p->ck->d + (size_t)AFFINE_WORDS * (sw - 1), Zi + 8 * sw, aw1 - 2, 1, 0, v->pin, &v->plan_aug, nullptr, 1, nullptr));
+      P_TRY(hipEventRecord(v->ev_fork, s));
+      P_TRY(hipStreamWaitEvent(v->s2, v->ev_fork, 0));
+      P_TRY(msm_launch<BnG1>(v->s2, v->ws2, p->ck->d + (size_t)AFFINE_WORDS * (sw - 1), Zi + 8 * sw, aw1 - 2, 1, 0, v->pin, &v->plan_aug, nullptr, 1, nullptr));
       // ---- 3. NIFS on the primary curve ------------------------------------------------------------------------------------------------
       if (i > 0) {
         hipLaunchKernelGGL(k_cross_term<Fr>, dim3(stream_grid(nc)), dim3(256), 0, s, nc, p->AZ, p->BZ, p->CZ, v->u1_run, az, bz, cz, Fe::one(), p->T);
@@ -171,6 +176,7 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
       t0 = now_s();
       P_TRY(hipEventSynchronize(bb.ev[r]));
       G1Aff cW_step = msm_finish<BnG1>(p->planB, (char*)bb.pin + r * pin_stride);
+      P_TRY(hipStreamSynchronize(v->s2));
       P_TRY(hipStreamSynchronize(s));
       v->ph_s[IP_WAIT_PRI] += now_s() - t0; v->ph_n[IP_WAIT_PRI]++;
       t0 = now_s();
@@ -205,7 +211,9 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
         memcpy(w2 + 3, aug2.data(), 32 * aug2.size());
         P_TRY(hipMemcpyAsync(S.z2, pin_w2, 32 * (size_t)S.n_w, hipMemcpyHostToDevice, s));
         sec_spmv<Fq>(S, s, S.z2, S.az2, S.bz2, S.cz2);
-        P_TRY(msm_launch<Grumpkin>(s, ctx->msm_ws, v->ck2->d, S.z2 + 8, S.n_w - 3, 1, 0, v->pin + 2 * v->pin_res, &v->plan_W2, nullptr, 1, nullptr));
+        P_TRY(hipEventRecord(v->ev_fork, s));
+        P_TRY(hipStreamWaitEvent(v->s2, v->ev_fork, 0));
+        P_TRY(msm_launch<Grumpkin>(v->s2, v->ws2, v->ck2->d, S.z2 + 8, S.n_w - 3, 1, 0, v->pin + 2 * v->pin_res, &v->plan_W2, nullptr, 1, nullptr));
         v->sec_T_valid = i > 0;    // U2 is still the zero instance after step 0: its cross term with anything is zero
         if (v->sec_T_valid) {
           hipLaunchKernelGGL(k_cross_term<Fq>, dim3(stream_grid(S.n_c)), dim3(256), 0, s, (size_t)S.n_c, S.AZ, S.BZ, S.CZ, v->u2_run, S.az2, S.bz2, S.cz2, Fq::one(), S.T);
@@ -220,6 +228,7 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
     }
     // this buffer is rewritten by batch k+2: the folds that read it must have finished
     P_TRY(hipStreamSynchronize(s));
+    P_TRY(hipStreamSynchronize(v->s2));
   }
   if ((rc = finish_secondary(v))) return rc;
   P_TRY(hipStreamSynchronize(p->sB));
@@ -244,6 +253,9 @@ void vimz_ivc_free(vimz_ivc* v) {
     std::lock_guard<std::mutex> g(v->ctx->mu);
     hipSetDevice(v->ctx->device);
     hipStreamSynchronize(v->ctx->stream);
+    if (v->s2) { hipStreamSynchronize(v->s2); hipStreamDestroy(v->s2); }
+    if (v->ev_fork) hipEventDestroy(v->ev_fork);
+    v->ws2.release();
     for (void* d : v->owned) hipFree(d);
     if (v->pin) hipHostFree(v->pin);
   }
@@ -297,6 +309,9 @@ int vimz_ivc_create(vimz_ctx* ctx, const vimz_circuit* step_circuit, const vimz_
   for (auto d : vw) if (dalloc(d, 32 * (size_t)nw2) != hipSuccess) return fail("device allocation");
   for (auto d : vc) if (dalloc(d, 32 * (size_t)nc2) != hipSuccess) return fail("device allocation");
   if (dalloc(&S.bad, 64) != hipSuccess) return fail("device allocation");
+  { int lo = 0, hi = 0; hipDeviceGetStreamPriorityRange(&lo, &hi);
+    if ((e = hipStreamCreateWithPriority(&v->s2, hipStreamNonBlocking, hi)) != hipSuccess) return fail("stream");
+    if ((e = hipEventCreateWithFlags(&v->ev_fork, hipEventDisableTiming)) != hipSuccess) return fail("event"); }
   v->pin_res = 4 * (size_t)XYZZ_WORDS * MSM_MAX_WINDOWS;
   if ((e = hipHostMalloc((void**)&v->pin, 4 * v->pin_res + 32 * (size_t)v->c1->aug_wires() + 32 * (size_t)nw2)) != hipSuccess) return fail("pinned");
   v->z0.assign(v->c1->len_z, Fe::zero());

@@ -107,13 +107,13 @@ __global__ void k_hist(const uint32_t* __restrict__ scalars, size_t n, int mont,
 template <int SUB>
 __global__ void __launch_bounds__(1024) k_scan(const uint32_t* __restrict__ counts, uint32_t nb,
                                                uint32_t* __restrict__ bucket_off, uint32_t* __restrict__ sub_off,
-                                               uint32_t* __restrict__ totals) {
+                                               uint32_t* __restrict__ totals, uint32_t sub) {
   __shared__ uint32_t sh_e[1024], sh_s[1024];
   const uint32_t t = threadIdx.x;
   const uint32_t per = (nb + 1023) / 1024;
   const uint32_t lo = min(nb, t * per), hi = min(nb, lo + per);
   uint32_t e = 0, s = 0;
-  for (uint32_t b = lo; b < hi; b++) { uint32_t cnt = counts[b]; e += cnt; s += (cnt + SUB - 1) / SUB; }
+  for (uint32_t b = lo; b < hi; b++) { uint32_t cnt = counts[b]; e += cnt; s += (cnt + sub - 1) / sub; }
   sh_e[t] = e; sh_s[t] = s;
   __syncthreads();
   for (uint32_t d = 1; d < 1024; d <<= 1) {  // Hillis-Steele inclusive scan
@@ -127,7 +127,7 @@ __global__ void __launch_bounds__(1024) k_scan(const uint32_t* __restrict__ coun
   for (uint32_t b = lo; b < hi; b++) {
     uint32_t cnt = counts[b];
     bucket_off[b] = be; sub_off[b] = bs;
-    be += cnt; bs += (cnt + SUB - 1) / SUB;
+    be += cnt; bs += (cnt + sub - 1) / sub;
   }
   if (t == 1023) { bucket_off[nb] = sh_e[1023]; sub_off[nb] = sh_s[1023]; totals[0] = sh_s[1023]; totals[1] = sh_e[1023]; }
 }
@@ -245,7 +245,7 @@ template <class F>
 __global__ void __launch_bounds__(256) k_accum(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
                                                const uint32_t* __restrict__ bucket_off, const uint32_t* __restrict__ sub_off,
                                                uint32_t nb, const uint32_t* __restrict__ totals,
-                                               uint32_t* __restrict__ partial) {
+                                               uint32_t* __restrict__ partial, uint32_t sub) {
   const uint32_t total = totals[0];
   uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= total) return;
@@ -256,8 +256,8 @@ __global__ void __launch_bounds__(256) k_accum(const uint32_t* __restrict__ base
     if (sub_off[mid] <= s) lo = mid; else hi = mid;
   }
   const uint32_t b = lo, k = s - sub_off[b];
-  const uint32_t beg = bucket_off[b] + k * MSM_SUB;
-  const uint32_t end = min(bucket_off[b + 1], beg + MSM_SUB);
+  const uint32_t beg = bucket_off[b] + k * sub;
+  const uint32_t end = min(bucket_off[b + 1], beg + sub);
   XYZZ<F> acc = XYZZ<F>::identity();
   // software pipeline: the gather of entry e+1 (index, then 80-byte base) is in flight while entry e is added
   uint32_t ent = beg < end ? sorted[beg] : 0u;
@@ -489,7 +489,9 @@ hipError_t msm_launch(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_ba
   pl.split_ones = split_ones;
   *plan_out = pl;
   const size_t entries = (size_t)pl.K * n;
-  const size_t max_subs = entries / MSM_SUB + pl.nb + 1;
+  // small MSMs are latency-bound (one dependent addition ~ 6-10 us): shorter chains per thread, more threads
+  const uint32_t sub = n < (1u << 15) ? 8u : (uint32_t)MSM_SUB;
+  const size_t max_subs = entries / sub + pl.nb + 1;
   VZ_HIP_CHECK(ws.reserve(pl.nb, entries, max_subs));
   VZ_HIP_CHECK(hipMemsetAsync(ws.counts, 0, 4 * (size_t)pl.nb, stream));
   VZ_HIP_CHECK(hipMemsetAsync(ws.cursor, 0, 4 * (size_t)pl.nb, stream));
@@ -515,7 +517,7 @@ hipError_t msm_launch(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_ba
     hipLaunchKernelGGL(k_hist<S>, dim3(gs), dim3(TB), 0, stream, d_scalars, n, scalars_mont, split_ones, pl.c, pl.K, bstride, ws.counts);
   }
   VZ_EV(1);
-  hipLaunchKernelGGL(k_scan<MSM_SUB>, dim3(1), dim3(1024), 0, stream, ws.counts, pl.nb, ws.bucket_off, ws.sub_off, ws.totals);
+  hipLaunchKernelGGL(k_scan<MSM_SUB>, dim3(1), dim3(1024), 0, stream, ws.counts, pl.nb, ws.bucket_off, ws.sub_off, ws.totals, sub);
   VZ_EV(2);
   if (lds_sort)
     hipLaunchKernelGGL(k_scatter_lds<S>, dim3(SORT_BLOCKS), dim3(SORT_THREADS), pl.nb * 4, stream, d_scalars, n, scalars_mont, split_ones, pl.c, pl.K, bstride, pl.nb,
@@ -527,7 +529,7 @@ hipError_t msm_launch(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_ba
   uint32_t* partial = reinterpret_cast<uint32_t*>(ws.partial);
   const unsigned ga = (unsigned)((max_subs + TB - 1) / TB);
   hipLaunchKernelGGL(k_accum<F>, dim3(ga), dim3(TB), 0, stream, d_bases, ws.sorted, ws.bucket_off, ws.sub_off, pl.nb,
-                     ws.totals, partial);
+                     ws.totals, partial, sub);
   VZ_EV(4);
   hipLaunchKernelGGL(k_combine<F>, dim3((pl.nb + TB - 1) / TB), dim3(TB), 0, stream, partial, ws.sub_off, pl.nb, ws.heavy, MsmWorkspace::HEAVY_CAP);
   hipLaunchKernelGGL(k_combine_heavy<F>, dim3(1024), dim3(256), 0, stream, partial, ws.sub_off, ws.heavy, MsmWorkspace::HEAVY_CAP);
