@@ -5,7 +5,13 @@
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 A "step" is one folding step = one image row through witness generation -> (A,B,C)·z -> MSM(W) -> cross term ->
-MSM(T) -> challenge -> fold.  Workload at any N: contrast_step at HD (the configuration the reference's headline
+MSM(T) -> challenge -> fold.  Two modes:
+  --mode ivc (default)   RecursiveSNARK::prove_step in full: Nova IVC with the augmented verifier circuits on the BN254/Grumpkin
+                         cycle (vimz_ivc_*; SURVEY.md §8a incl. rows S1/S2).  A rank proves its rows as `--segments` independent
+                         IVC proofs of contiguous row segments (IVC chains cannot be merged), folded concurrently.
+  --mode accumulator     the NIFS accumulator over the step circuit's own instances (vimz_prover_*): row segments fold
+                         independently and are merged by a host-side final fold (BASELINE.json north_star's sharding picture).
+Workload at any N: contrast_step at HD (the configuration the reference's headline
 number is quoted on: 720 steps in 371.7 s = 1.94 steps/s, README.md:52), rows of the reference's sample image
 (tests/golden/img2.png, contrast factor 1.4).  Every rank folds its own contiguous row segment of W+K rows into its own
 running instance (independent row-folds, weak scaling, no data-path collective); after the timed region rank 0 gathers
@@ -69,6 +75,135 @@ def cpu_baseline(circuit, steps, z0, ck_host, budget_s, threads):
     return n / dt, dt, n
 
 
+def main_ivc(args, rank, world, dist, torch, ctxs, circuit, params, steps_all, glob, lo, hi, mine, z0, t_setup):
+    """Nova IVC (the default mode).  The rank's W+K rows are cut into S contiguous segments; segment s is one IVC proof on its own
+    context, warmed up with its first W/S rows and timed on the rest.  All S proofs of all ranks must verify."""
+    from vimz_amd import _lib, hip
+    from vimz_amd.distributed import fold_concurrently, ivc_segments
+    ctx = ctxs[0]
+    S = len(ctxs)
+    ck2 = ctx.bases_generate(_lib.CURVE_GRUMPKIN, 1 << 13, b"ck-secondary")
+    ivcs = [hip.IVC(c, circuit, params.ck, ck2, max_batch=args.batch) for c in ctxs]
+    z_rank = list(z0)
+    if lo:
+        zs = ivcs[0].state_chain(z0, steps_all[glob[:lo]])
+        z_rank = [int(a[0]) | int(a[1]) << 64 | int(a[2]) << 128 | int(a[3]) << 192 for a in zs[-1]]
+    segs = ivc_segments(ivcs, mine, z_rank)
+    setup_s = time.time() - t_setup
+    w_each = args.warmup // S
+
+    def sync_all():
+        for c in ctxs:
+            c.sync()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for ivc, rows, z in segs:
+        ivc.reset(z)
+    fold_concurrently([(ivc, rows[:w_each]) for ivc, rows, z in segs])
+    timed_rows = sum(len(rows) - min(w_each, len(rows)) for _, rows, _ in segs)
+    for c in ctxs:
+        c.set_profiling(True)              # HIP events around every kernel of the primary MSM(T) launches on each context's stream
+        c.msm_profile_totals(reset=True)
+    prof0 = [ivc.profile() for ivc in ivcs]
+    sync_all()
+    t0 = time.time()
+    fold_concurrently([(ivc, rows[w_each:]) for ivc, rows, z in segs])
+    sync_all()
+    dt = time.time() - t0
+    tots = [c.msm_profile_totals() for c in ctxs]
+    tot = {"ms": {k: sum(t["ms"][k] for t in tots) for k in tots[0]["ms"]}, "calls": sum(t["calls"] for t in tots),
+           "points": sum(t["points"] for t in tots), "entries": sum(t["entries"] for t in tots)}
+    for c in ctxs:
+        c.set_profiling(False)
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0])
+    # acceptance (outside the timed region): every segment proof verifies, and the segments' boundary states chain
+    t_v = time.time()
+    ok = all(ivc.verify() == 0 for ivc in ivcs)
+    ends = [ivc.state()[0] for ivc in ivcs]
+    ok = ok and all(ends[i] == segs[i + 1][2] for i in range(S - 1))
+    verify_s = time.time() - t_v
+    folded = sum(ivc.state()[1] for ivc in ivcs)
+    if dist is not None:
+        t = torch.tensor([1 if ok else 0, folded, timed_rows], dtype=torch.int64)
+        m = t.clone(); dist.all_reduce(m, op=dist.ReduceOp.MIN)
+        a = t.clone(); dist.all_reduce(a, op=dist.ReduceOp.SUM)
+        ok, folded, timed_total = bool(int(m[0])), int(a[1]), int(a[2])
+    else:
+        timed_total = timed_rows
+    if rank == 0:
+        info = ivcs[0].info()
+        n_w, n_c, nnz = info["primary_wires"], info["primary_constraints"], info["primary_nnz"]
+        calls = max(1, tot["calls"])
+        acc_ms = tot["ms"]["accumulate"] / calls
+        msm_ms = sum(tot["ms"].values()) / calls
+        alg_bytes = 96.0 * n_c
+        achieved = alg_bytes / (acc_ms * 1e-3) / 1e9 if acc_ms else 0.0
+        adds = tot["entries"] / calls
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fp:
+                traffic = json.load(fp).get(f"{args.transformation}_step_{args.resolution}_ivc", {}).get("hbm_bytes_per_launch")
+        except OSError:
+            pass
+        n_w2, n_c2, nnz2 = info["secondary_wires"], info["secondary_constraints"], info["secondary_nnz"]
+        step_bytes = sum(96 * w + 96 * c + 8 * z + 32 * w + 96 * c + 7 * 32 * c + 3 * 32 * w + 12 * 32 * c for w, c, z in ((n_w, n_c, nnz), (n_w2, n_c2, nnz2)))
+        prof1 = [ivc.profile() for ivc in ivcs]
+        phases = {k: 1e3 * sum(p1[k][0] - p0[k][0] for p0, p1 in zip(prof0, prof1)) / max(1, timed_rows) for k in prof1[0]}
+        out = {
+            "metric": "nova_folding_steps_per_sec",
+            "value": timed_total / dt,
+            "unit": "steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / max(1, timed_rows) * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32 limbs (256-bit Montgomery integers over BN254 Fr/Fq)",
+            "data": "synthetic: rows of the reference sample image img2.png, contrast factor 1.4" + ("" if args.resolution == "HD" else f", upscaled to {args.resolution}"),
+            "config": {"workload": f"{args.transformation}_step_{args.resolution}", "mode": "ivc (augmented circuits on BN254/Grumpkin: RecursiveSNARK::prove_step in full)",
+                       "constraints": n_c, "wires": n_w, "nnz": nnz, "step_circuit_constraints": info["step_constraints"], "step_circuit_wires": info["step_wires"],
+                       "secondary_constraints": n_c2, "secondary_wires": n_w2,
+                       "rows_per_rank": args.steps, "segments_per_gpu": S, "witness_batch": args.batch,
+                       "parallelism": f"{world * S} independent IVC proofs of contiguous row segments ({S} per GPU, folded concurrently), chained boundary states, no final fold"},
+            "verified": bool(ok),
+            "folded_steps_total": folded,
+            "verify_s": verify_s,
+            "end_to_end_estimate_s": {"keygen_and_setup": setup_s, "fold_720_steps_one_gpu": 720 * dt / max(1, timed_rows)},
+            "published_reference": {"contrast_HD_steps_per_s_cpu_server": 1.94, "source": "README.md:52 (720 steps / 371.7 s)"},
+            "phase_ms_per_step_per_proof": phases,
+            "roofline": {"bound": "hbm", "kernel": "k_accum (bucket accumulation) of the primary MSM(T) launches in the timed region", "achieved": achieved,
+                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": acc_ms, "launches": tot["calls"], "msm_gpu_ms": msm_ms,
+                         "mixed_adds_per_launch": adds, "msm_phase_ms": {k: v / calls for k, v in tot["ms"].items()},
+                         "int_utilisation": (adds / (acc_ms * 1e-3) / 1e9 / MIXED_ADD_PEAK_GOPS) if acc_ms else 0.0,
+                         "step_algorithmic_bytes": step_bytes, "step_hbm_frac": step_bytes / (dt / max(1, timed_rows)) / 1e9 / HBM_PEAK_GBPS},
+        }
+        if not args.no_cpu_baseline:
+            cores = os.cpu_count() or 1
+            ck_host = params.ck.download(0, max(circuit.n_constraints, circuit.n_wires))
+            sps, secs, n_cpu = cpu_baseline(circuit, mine, z_rank, ck_host, args.cpu_seconds, cores)
+            out["cpu_baseline"] = {"value": sps, "unit": "steps/s", "cores": cores, "kind": "port",
+                                   "sample": f"{n_cpu} folding steps of the step circuit's instances with the CPU oracle (C++ restatement, std::thread over all cores; not the Rust binary; "
+                                             f"without the augmented circuits, i.e. less work per step than the GPU number), {secs:.1f} s"}
+        print(json.dumps(out), flush=True)
+    for v in ivcs:
+        v.close()
+    params.ck.free(); ck2.free()
+    for c in ctxs:
+        c.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -80,6 +215,7 @@ def main():
     ap.add_argument("--segments", type=int, default=2, help="row segments folded concurrently on each GPU (own context + streams each)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", default="ivc", choices=["ivc", "accumulator"])
     ap.add_argument("--proof-set", default="", help="comma-separated transformations: rank r proves proof_set[r %% len] (BASELINE config 5: independent proofs, replicas only)")
     args = ap.parse_args()
 
@@ -114,6 +250,8 @@ def main():
     glob = [i % n_rows for i in range(world * per_rank)]
     lo, hi = segment_bounds(world * per_rank, world)[rank]
     mine = np.ascontiguousarray(steps_all[glob[lo:hi]])
+    if args.mode == "ivc":
+        return main_ivc(args, rank, world, dist, torch, ctxs, circuit, params, steps_all, glob, lo, hi, mine, z0, t_setup)
     provers = [hip.Prover(c, circuit, params.ck, max_batch=args.batch) for c in ctxs]   # the key and the shape are shared, read-only
     prover = provers[0]
     # IVC state at which this rank's segment starts (hash-only chain over the rows before it)
@@ -211,7 +349,7 @@ def main():
             "vs_baseline": None,
             "dtype": "u32 limbs (256-bit Montgomery integers over BN254 Fr/Fq)",
             "data": "synthetic: rows of the reference sample image img2.png, contrast factor 1.4" + ("" if args.resolution == "HD" else f", upscaled to {args.resolution}"),
-            "config": {"workload": f"{args.transformation}_step_{args.resolution}", "constraints": n_c, "wires": n_w, "nnz": nnz,
+            "config": {"workload": f"{args.transformation}_step_{args.resolution}", "mode": "accumulator", "constraints": n_c, "wires": n_w, "nnz": nnz,
                        "rows_per_rank": args.steps, "segments_per_gpu": S, "witness_batch": args.batch, "parallelism": (f"{world} independent proofs ({args.proof_set}), replicas only" if args.proof_set else f"{world} independent row segments + host final fold")},
             "verified": bool(ok),
             "folded_steps_total": inst["steps"],

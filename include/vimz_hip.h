@@ -231,6 +231,8 @@ int vimz_ivc_verify(vimz_ivc* v, uint32_t* result);
  * len_z, verifier-circuit wires (primary), nnz(A+B+C) primary, nnz secondary, reserved */
 int vimz_ivc_info(const vimz_ivc* v, uint64_t info[12]);
 int vimz_ivc_state(const vimz_ivc* v, uint64_t* z_current /* len_z x 4 */, uint64_t* steps);
+/* IVC state chain only (as vimz_prover_state_chain): where a row segment proven by another IVC starts */
+int vimz_ivc_state_chain(vimz_ivc* v, const uint64_t* z_start, const uint64_t* step_inputs, size_t nsteps, uint64_t* zs_out);
 /* seconds[8]/counts[8]: verifier-circuit witness primary (host), secondary (host), wait for secondary MSMs, wait for primary MSMs,
  * uploads+launches, producer wait, reserved, total */
 int vimz_ivc_profile(const vimz_ivc* v, double seconds[8], uint64_t counts[8]);

@@ -170,7 +170,8 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
       if (i > 0) {
         hipLaunchKernelGGL(k_cross_term<Fr>, dim3(stream_grid(nc)), dim3(256), 0, s, nc, p->AZ, p->BZ, p->CZ, v->u1_run, az, bz, cz, Fe::one(), p->T);
         P_TRY(hipGetLastError());
-        P_TRY(msm_launch<BnG1>(s, ctx->msm_ws, p->ck->d, p->T, nc, 1, 0, v->pin + v->pin_res, &v->plan_T1, nullptr, 0, nullptr));
+        P_TRY(msm_launch<BnG1>(s, ctx->msm_ws, p->ck->d, p->T, nc, 1, 0, v->pin + v->pin_res, &v->plan_T1, ctx->profiling ? ctx->ev : nullptr, 0, nullptr));
+        if (ctx->profiling) P_TRY(hipMemcpyAsync(&ctx->last_msm.subs, ctx->msm_ws.totals, 8, hipMemcpyDeviceToHost, s));
       }
       v->ph_s[IP_LAUNCH] += now_s() - t0;
       t0 = now_s();
@@ -185,6 +186,12 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
       FreshInst<Fq> u1; u1.W = to_affine(sum); u1.x0 = cross_field<Fq>(o1.x0); u1.x1 = cross_field<Fq>(o1.x1);
       G1Aff T1; T1.x = Fq::zero(); T1.y = Fq::zero();
       if (i > 0) T1 = msm_finish<BnG1>(v->plan_T1, v->pin + v->pin_res);
+      if (i > 0 && ctx->profiling) {       // HIP-event durations of the phases of this MSM(T), accumulated for the roofline figure
+        float ms[6];
+        for (int q = 0; q < 6; q++) { P_TRY(hipEventElapsedTime(&ms[q], ctx->ev[q], ctx->ev[q + 1])); ctx->last_msm.ms[q] = ms[q]; ctx->msm_tot_ms[q] += ms[q]; }
+        ctx->last_msm.c = v->plan_T1.c; ctx->last_msm.K = v->plan_T1.K;
+        ctx->msm_tot_calls++; ctx->msm_tot_points += nc; ctx->msm_tot_entries += ctx->last_msm.entries;
+      }
       // ---- 4. secondary verifier circuit on the host: folds (U1, u1) ---------------------------------------------------------------------
       AugIn<BnFq> in2; in2.pz = v->pz2; in2.i = i; in2.U = v->U1; in2.u = u1; in2.T = T1;
       std::vector<Fq> aug2;
@@ -371,6 +378,10 @@ int vimz_ivc_state(const vimz_ivc* v, uint64_t* z_current, uint64_t* steps) {
   if (z_current) for (uint32_t k = 0; k < v->pri->len_z; k++) fe_to_canon(v->pri->z_cur[k], z_current + 4 * k);
   if (steps) *steps = v->i;
   return VIMZ_OK;
+}
+int vimz_ivc_state_chain(vimz_ivc* v, const uint64_t* z_start, const uint64_t* step_inputs, size_t nsteps, uint64_t* zs_out) {
+  if (!v) return VIMZ_ERR_INVALID;
+  return vimz_prover_state_chain(v->pri, z_start, step_inputs, nsteps, zs_out);
 }
 int vimz_ivc_profile(const vimz_ivc* v, double seconds[8], uint64_t counts[8]) {
   if (!v) return VIMZ_ERR_INVALID;

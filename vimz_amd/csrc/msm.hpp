@@ -308,34 +308,87 @@ __global__ void __launch_bounds__(256) k_tree256(const uint32_t* __restrict__ in
   if (t == 0) store_xyzz(out, blockIdx.x, sh[0]);
 }
 
-constexpr uint32_t MSM_HEAVY = 24;   // buckets with more sub-buckets than this are combined by a whole workgroup
+constexpr uint32_t MSM_HEAVY = 64;   // buckets with more sub-buckets than this are combined by a whole workgroup
 
-// One thread per bucket folds the bucket's sub-bucket partials into partial[sub_off[b]].  Buckets with more than
-// MSM_HEAVY partials (only the few hot buckets of witness-like scalars) are queued for k_combine_heavy instead.
+// Sixteen lanes per bucket fold the bucket's sub-bucket partials into partial[sub_off[b]]: strided partial sums, then a
+// four-level tree through LDS — the dependent chain is ceil(m/16) + 4 additions instead of m - 1 (one dependent addition
+// costs 6-10 us, and cross-term scalars repeat, so some buckets carry many sub-buckets).  Buckets with more than MSM_HEAVY
+// partials (the few hot buckets of witness-like scalars) are queued for k_combine_heavy instead.
 template <class F>
 __global__ void __launch_bounds__(256) k_combine(uint32_t* __restrict__ partial, const uint32_t* __restrict__ sub_off, uint32_t nb,
                                                  uint32_t* __restrict__ heavy /* [0] = count, then bucket ids */, uint32_t heavy_cap) {
-  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= nb) return;
-  const uint32_t s0 = sub_off[b], m = sub_off[b + 1] - s0;
-  if (m < 2) return;
+  __shared__ XYZZ<F> sh[256];
+  const uint32_t t = threadIdx.x, lane = t & 15u;
+  const uint32_t b = blockIdx.x * 16u + (t >> 4);
+  uint32_t s0 = 0, m = 0;
+  if (b < nb) { s0 = sub_off[b]; m = sub_off[b + 1] - s0; }
   if (m > MSM_HEAVY) {
-    const uint32_t slot = atomicAdd(&heavy[0], 1u);
-    if (slot < heavy_cap) { heavy[1 + slot] = b; return; }
-    // list full (cannot happen for heavy_cap >= entries / (MSM_SUB * MSM_HEAVY)); fall through to the serial path
+    bool queued = true;
+    if (lane == 0) {
+      const uint32_t slot = atomicAdd(&heavy[0], 1u);
+      if (slot < heavy_cap) heavy[1 + slot] = b; else queued = false;   // list full (cannot happen for heavy_cap >= subs / MSM_HEAVY)
+    }
+    queued = __shfl(queued ? 1 : 0, (int)(t & 48u), 64) != 0;              // lane 0 of this 16-lane group
+    if (queued) m = 0;
   }
-  XYZZ<F> acc = load_xyzz<F>(partial, s0);
-  for (uint32_t k = 1; k < m; k++) { XYZZ<F> q = load_xyzz<F>(partial, s0 + k); add_full(acc, q); }
-  store_xyzz(partial, s0, acc);
+  XYZZ<F> acc = XYZZ<F>::identity();
+  for (uint32_t k = lane; k < m; k += 16) { XYZZ<F> q = load_xyzz<F>(partial, s0 + k); add_full(acc, q); }
+  sh[t] = acc;
+  __syncthreads();
+  for (uint32_t d = 8; d > 0; d >>= 1) {
+    if (lane < d && lane + d < m) { XYZZ<F> a = sh[t]; add_full(a, sh[t + d]); sh[t] = a; }
+    __syncthreads();
+  }
+  if (lane == 0 && m >= 2) store_xyzz(partial, s0, sh[t]);
 }
 
-// One workgroup per queued heavy bucket: strided accumulation by 256 threads, then an LDS tree.
+// Heavy buckets.  With 254-bit scalars and c = 11 the top window holds one bit plus a carry, so a third of ALL points of a
+// dense MSM meet in one or two buckets (10^4 partials); witness-like scalars add a few hot buckets of small values.  The first
+// MSM_HEAVY_SPLIT queued buckets are therefore folded in two stages — MSM_HEAVY_PARTS workgroups per bucket (strided sums +
+// LDS tree) into a scratch row, then one 32-lane tree per bucket — and any further ones by a single workgroup each.
+constexpr uint32_t MSM_HEAVY_PARTS = 32, MSM_HEAVY_SPLIT = 1024;
+template <class F>
+__global__ void __launch_bounds__(256) k_combine_heavy1(const uint32_t* __restrict__ partial, const uint32_t* __restrict__ sub_off,
+                                                        const uint32_t* __restrict__ heavy, uint32_t heavy_cap, uint32_t* __restrict__ scratch) {
+  __shared__ XYZZ<F> sh[256];
+  const uint32_t count = min(min(heavy[0], heavy_cap), MSM_HEAVY_SPLIT), t = threadIdx.x;
+  for (uint32_t it = blockIdx.x; it < count * MSM_HEAVY_PARTS; it += gridDim.x) {
+    const uint32_t b = heavy[1 + it / MSM_HEAVY_PARTS], part = it % MSM_HEAVY_PARTS;
+    const uint32_t s0 = sub_off[b], m = sub_off[b + 1] - s0;
+    const uint32_t per = (m + MSM_HEAVY_PARTS - 1) / MSM_HEAVY_PARTS, lo = part * per, hi = min(m, lo + per);
+    XYZZ<F> acc = XYZZ<F>::identity();
+    for (uint32_t k = lo + t; k < hi; k += 256) { XYZZ<F> q = load_xyzz<F>(partial, s0 + k); add_full(acc, q); }
+    __syncthreads();
+    sh[t] = acc;
+    __syncthreads();
+    for (uint32_t d = 128; d > 0; d >>= 1) {
+      if (t < d) { XYZZ<F> a = sh[t]; add_full(a, sh[t + d]); sh[t] = a; }
+      __syncthreads();
+    }
+    if (t == 0) store_xyzz(scratch, it, sh[0]);
+  }
+}
+template <class F>
+__global__ void __launch_bounds__(256) k_combine_heavy2(uint32_t* __restrict__ partial, const uint32_t* __restrict__ sub_off,
+                                                        const uint32_t* __restrict__ heavy, uint32_t heavy_cap, const uint32_t* __restrict__ scratch) {
+  __shared__ XYZZ<F> sh[256];
+  const uint32_t count = min(min(heavy[0], heavy_cap), MSM_HEAVY_SPLIT), t = threadIdx.x, lane = t & 31u;
+  const uint32_t h = blockIdx.x * 8u + (t >> 5);
+  sh[t] = h < count ? load_xyzz<F>(scratch, h * MSM_HEAVY_PARTS + lane) : XYZZ<F>::identity();
+  __syncthreads();
+  for (uint32_t d = 16; d > 0; d >>= 1) {
+    if (lane < d) { XYZZ<F> a = sh[t]; add_full(a, sh[t + d]); sh[t] = a; }
+    __syncthreads();
+  }
+  if (lane == 0 && h < count) store_xyzz(partial, sub_off[heavy[1 + h]], sh[t]);
+}
+// One workgroup per remaining heavy bucket (those after the first `first`): strided accumulation by 256 threads, then an LDS tree.
 template <class F>
 __global__ void __launch_bounds__(256) k_combine_heavy(uint32_t* __restrict__ partial, const uint32_t* __restrict__ sub_off,
-                                                       const uint32_t* __restrict__ heavy, uint32_t heavy_cap) {
+                                                       const uint32_t* __restrict__ heavy, uint32_t heavy_cap, uint32_t first) {
   __shared__ XYZZ<F> sh[256];
   const uint32_t count = min(heavy[0], heavy_cap), t = threadIdx.x;
-  for (uint32_t h = blockIdx.x; h < count; h += gridDim.x) {
+  for (uint32_t h = first + blockIdx.x; h < count; h += gridDim.x) {
     const uint32_t b = heavy[1 + h];
     const uint32_t s0 = sub_off[b], m = sub_off[b + 1] - s0;
     XYZZ<F> acc = XYZZ<F>::identity();
@@ -490,7 +543,7 @@ hipError_t msm_launch(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_ba
   *plan_out = pl;
   const size_t entries = (size_t)pl.K * n;
   // small MSMs are latency-bound (one dependent addition ~ 6-10 us): shorter chains per thread, more threads
-  const uint32_t sub = n < (1u << 15) ? 8u : (uint32_t)MSM_SUB;
+  const uint32_t sub = n < (1u << 15) ? 8u : (uint32_t)MSM_SUB;   // MSM_SUB for everything large
   const size_t max_subs = entries / sub + pl.nb + 1;
   VZ_HIP_CHECK(ws.reserve(pl.nb, entries, max_subs));
   VZ_HIP_CHECK(hipMemsetAsync(ws.counts, 0, 4 * (size_t)pl.nb, stream));
@@ -531,8 +584,10 @@ hipError_t msm_launch(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_ba
   hipLaunchKernelGGL(k_accum<F>, dim3(ga), dim3(TB), 0, stream, d_bases, ws.sorted, ws.bucket_off, ws.sub_off, pl.nb,
                      ws.totals, partial, sub);
   VZ_EV(4);
-  hipLaunchKernelGGL(k_combine<F>, dim3((pl.nb + TB - 1) / TB), dim3(TB), 0, stream, partial, ws.sub_off, pl.nb, ws.heavy, MsmWorkspace::HEAVY_CAP);
-  hipLaunchKernelGGL(k_combine_heavy<F>, dim3(1024), dim3(256), 0, stream, partial, ws.sub_off, ws.heavy, MsmWorkspace::HEAVY_CAP);
+  hipLaunchKernelGGL(k_combine<F>, dim3((pl.nb + 15) / 16), dim3(256), 0, stream, partial, ws.sub_off, pl.nb, ws.heavy, MsmWorkspace::HEAVY_CAP);
+  hipLaunchKernelGGL(k_combine_heavy1<F>, dim3(2048), dim3(256), 0, stream, partial, ws.sub_off, ws.heavy, MsmWorkspace::HEAVY_CAP, ws.heavy_scratch);
+  hipLaunchKernelGGL(k_combine_heavy2<F>, dim3(MSM_HEAVY_SPLIT / 8), dim3(256), 0, stream, partial, ws.sub_off, ws.heavy, MsmWorkspace::HEAVY_CAP, ws.heavy_scratch);
+  hipLaunchKernelGGL(k_combine_heavy<F>, dim3(256), dim3(256), 0, stream, partial, ws.sub_off, ws.heavy, MsmWorkspace::HEAVY_CAP, MSM_HEAVY_SPLIT);
   VZ_EV(5);
   const unsigned T = pl.nbw < 256 ? pl.nbw : 256;
   uint32_t* wsum = reinterpret_cast<uint32_t*>(ws.window_sums);

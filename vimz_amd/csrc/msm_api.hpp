@@ -26,7 +26,8 @@ namespace vz {
 
 #define VZ_HIP_CHECK(x) do { hipError_t _e = (x); if (_e != hipSuccess) return _e; } while (0)
 
-constexpr int MSM_SUB = 32;          // max entries one thread accumulates in k_accum (small: occupancy beats the extra combines)
+constexpr int MSM_SUB = 16;          // max entries one thread accumulates in k_accum: the chain of dependent additions per thread;
+                                     // the partials of a bucket are then folded by a 16-lane tree (k_combine)
 constexpr int MSM_MAX_WINDOWS = 96;
 
 struct MsmPlan {
@@ -71,6 +72,7 @@ struct MsmWorkspace {  // device buffers, grown on demand and reused across call
   size_t cap_block_hist = 0;
   void* ones_partial = nullptr;    // (16384 + 64) XYZZ partial sums of the unit-scalar path
   uint32_t* heavy = nullptr;       // [0] = count, then ids of buckets with many sub-buckets
+  uint32_t* heavy_scratch = nullptr;   // 1024 x 32 partial sums of the split heavy buckets
   static constexpr uint32_t HEAVY_CAP = 65536;
   size_t cap_nb = 0, cap_entries = 0, cap_subs = 0;
   void* host_pinned = nullptr;     // MSM_MAX_WINDOWS * 128 B
@@ -92,6 +94,7 @@ struct MsmWorkspace {  // device buffers, grown on demand and reused across call
     if (!window_sums) VZ_HIP_CHECK(hipMalloc(&window_sums, 4 * XYZZ_WORDS * MSM_MAX_WINDOWS));
     if (!totals) VZ_HIP_CHECK(hipMalloc(&totals, 64));
     if (!heavy) VZ_HIP_CHECK(hipMalloc(&heavy, 4 * (HEAVY_CAP + 1)));
+    if (!heavy_scratch) VZ_HIP_CHECK(hipMalloc(&heavy_scratch, 4 * (size_t)XYZZ_WORDS * 1024 * 32));
     if (!ones_partial) VZ_HIP_CHECK(hipMalloc(&ones_partial, 4 * (size_t)XYZZ_WORDS * (16384 + 64 + 512)));
     if (!host_pinned) VZ_HIP_CHECK(hipHostMalloc(&host_pinned, 4 * XYZZ_WORDS * MSM_MAX_WINDOWS));
     return hipSuccess;
@@ -105,7 +108,7 @@ struct MsmWorkspace {  // device buffers, grown on demand and reused across call
   }
   void release() {
     hipFree(counts); hipFree(cursor); hipFree(bucket_off); hipFree(sub_off); hipFree(sorted);
-    hipFree(partial); hipFree(window_sums); hipFree(totals); hipFree(heavy); hipFree(ones_partial); hipFree(block_hist);
+    hipFree(partial); hipFree(window_sums); hipFree(totals); hipFree(heavy); hipFree(heavy_scratch); hipFree(ones_partial); hipFree(block_hist);
     if (host_pinned) hipHostFree(host_pinned);
     *this = MsmWorkspace();
   }

@@ -75,3 +75,34 @@ def fold_local_segments(provers, step_inputs, z0, merge=True):
         for i in range(1, S):
             provers[0].merge_prover(provers[i])
     return provers[0]
+
+
+def ivc_segments(ivcs, step_inputs, z0):
+    """Split `step_inputs` into len(ivcs) contiguous row segments and return [(ivc, rows, z_start)], where z_start is the IVC
+    state at which the segment begins (hash-only chain over the rows before it).  In IVC mode (vimz_amd.hip.IVC) two running
+    instances cannot be merged — Nova IVC is a chain — so an image proven on several streams / GPUs is a LIST of IVC proofs,
+    one per row segment, whose boundary states chain: z_end of segment j = z_start of segment j+1 (checked by the caller)."""
+    n, S = len(step_inputs), len(ivcs)
+    bounds = segment_bounds(n, S)
+    starts = [list(z0)]
+    for lo, hi in bounds[:-1]:
+        zs = ivcs[0].state_chain(starts[-1], step_inputs[lo:hi])
+        starts.append([int(a[0]) | int(a[1]) << 64 | int(a[2]) << 128 | int(a[3]) << 192 for a in np.asarray(zs)[-1]])
+    return [(ivcs[i], step_inputs[bounds[i][0]:bounds[i][1]], starts[i]) for i in range(S)]
+
+
+def fold_concurrently(jobs):
+    """jobs: [(ivc, rows)] folded from one host thread each (ctypes releases the GIL; every IVC has its own context = streams).
+    A single IVC alternates between host work (the verifier circuits' witnesses) and GPU work; several of them interleave."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    def work(j):
+        ivc, rows = j
+        if len(rows):
+            ivc.fold(rows)
+
+    if len(jobs) == 1:
+        work(jobs[0])
+    else:
+        with ThreadPoolExecutor(len(jobs)) as ex:
+            list(ex.map(work, jobs))

@@ -391,6 +391,19 @@ class IVC:
         self.ctx._chk(self.ctx.lib.vimz_ivc_state(self.h, _ptr(z), C.byref(steps)))
         return [sum(int(z[i, k]) << (64 * k) for k in range(4)) for i in range(self.circuit.len_z)], steps.value
 
+    def state_chain(self, z_start, inputs):
+        a = _u64(inputs).reshape(-1, self.circuit.n_priv, 4)
+        n = a.shape[0]
+        z = np.zeros((self.circuit.len_z, 4), dtype=np.uint64)
+        for i, v in enumerate(z_start):
+            for k in range(4):
+                z[i, k] = (int(v) >> (64 * k)) & 0xFFFFFFFFFFFFFFFF
+        out = np.zeros((n + 1, self.circuit.len_z, 4), dtype=np.uint64)
+        lib = self.ctx.lib
+        lib.vimz_ivc_state_chain.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        self.ctx._chk(lib.vimz_ivc_state_chain(self.h, _ptr(z), _ptr(a), n, _ptr(out)))
+        return out
+
     def profile(self):
         s = (C.c_double * 8)()
         n = (C.c_uint64 * 8)()
