@@ -84,3 +84,41 @@ def test_merge_of_oracle_provers_satisfies_relaxed_r1cs(oracle):
     assert a.verify() == 0 and a.steps == 4
     a.E[0, 0] ^= np.uint64(1)
     assert a.verify() & 1
+
+
+def test_ivc_segments_chain_their_boundary_states(oracle):
+    """IVC mode shards an image as a list of IVC proofs of contiguous row segments (Nova IVC chains cannot be merged): the host
+    logic that cuts the rows and finds each segment's start state, over a stand-in whose state chain is the oracle's."""
+    from tests._oracle import T_HASH
+    from tests.test_circuits import step_inputs
+    from vimz_amd.distributed import fold_concurrently, ivc_segments
+    z0, inputs = step_inputs("hash")
+    rows = np.stack(inputs)
+
+    class Stub:
+        def __init__(self): self.z, self.n = None, 0
+        def state_chain(self, z_start, rws):
+            zs, z = [list(z_start)], list(z_start)
+            for r in rws:
+                ok, z = oracle.step_eval(T_HASH, z, r)
+                assert ok
+                zs.append(list(z))
+            from tests._oracle import to_limbs
+            return np.stack([to_limbs(s) for s in zs])
+        def reset(self, z): self.z, self.n = list(z), 0
+        def fold(self, rws):
+            for r in rws:
+                ok, self.z = oracle.step_eval(T_HASH, self.z, r)
+                assert ok
+                self.n += 1
+
+    stubs = [Stub() for _ in range(3)]
+    segs = ivc_segments(stubs, rows, z0)
+    assert [len(r) for _, r, _ in segs] == [4, 3, 3] and segs[0][2] == list(z0)
+    for s, r, z in segs:
+        s.reset(z)
+    fold_concurrently([(s, r) for s, r, z in segs])
+    for i in range(2):
+        assert segs[i][0].z == segs[i + 1][2]            # z_end of segment i = z_start of segment i+1
+    single = Stub(); single.reset(z0); single.fold(rows)
+    assert segs[2][0].z == single.z and sum(s.n for s in stubs) == 10

@@ -347,6 +347,7 @@ __global__ void __launch_bounds__(256) k_combine(uint32_t* __restrict__ partial,
 // MSM_HEAVY_SPLIT queued buckets are therefore folded in two stages — MSM_HEAVY_PARTS workgroups per bucket (strided sums +
 // LDS tree) into a scratch row, then one 32-lane tree per bucket — and any further ones by a single workgroup each.
 constexpr uint32_t MSM_HEAVY_PARTS = 32, MSM_HEAVY_SPLIT = 1024;
+constexpr uint32_t MSM_HEAVY_SPLIT_MIN = 2048;   // buckets with fewer partials than this are left to one workgroup (one tree, no second stage)
 template <class F>
 __global__ void __launch_bounds__(256) k_combine_heavy1(const uint32_t* __restrict__ partial, const uint32_t* __restrict__ sub_off,
                                                         const uint32_t* __restrict__ heavy, uint32_t heavy_cap, uint32_t* __restrict__ scratch) {
@@ -355,6 +356,7 @@ __global__ void __launch_bounds__(256) k_combine_heavy1(const uint32_t* __restri
   for (uint32_t it = blockIdx.x; it < count * MSM_HEAVY_PARTS; it += gridDim.x) {
     const uint32_t b = heavy[1 + it / MSM_HEAVY_PARTS], part = it % MSM_HEAVY_PARTS;
     const uint32_t s0 = sub_off[b], m = sub_off[b + 1] - s0;
+    if (m < MSM_HEAVY_SPLIT_MIN) continue;
     const uint32_t per = (m + MSM_HEAVY_PARTS - 1) / MSM_HEAVY_PARTS, lo = part * per, hi = min(m, lo + per);
     XYZZ<F> acc = XYZZ<F>::identity();
     for (uint32_t k = lo + t; k < hi; k += 256) { XYZZ<F> q = load_xyzz<F>(partial, s0 + k); add_full(acc, q); }
@@ -374,23 +376,28 @@ __global__ void __launch_bounds__(256) k_combine_heavy2(uint32_t* __restrict__ p
   __shared__ XYZZ<F> sh[256];
   const uint32_t count = min(min(heavy[0], heavy_cap), MSM_HEAVY_SPLIT), t = threadIdx.x, lane = t & 31u;
   const uint32_t h = blockIdx.x * 8u + (t >> 5);
-  sh[t] = h < count ? load_xyzz<F>(scratch, h * MSM_HEAVY_PARTS + lane) : XYZZ<F>::identity();
+  bool mine = false;
+  if (h < count) { const uint32_t b = heavy[1 + h]; mine = sub_off[b + 1] - sub_off[b] >= MSM_HEAVY_SPLIT_MIN; }
+  if (!__syncthreads_or(mine ? 1 : 0)) return;       // nothing split among this workgroup's eight buckets
+  sh[t] = mine ? load_xyzz<F>(scratch, h * MSM_HEAVY_PARTS + lane) : XYZZ<F>::identity();
   __syncthreads();
   for (uint32_t d = 16; d > 0; d >>= 1) {
     if (lane < d) { XYZZ<F> a = sh[t]; add_full(a, sh[t + d]); sh[t] = a; }
     __syncthreads();
   }
-  if (lane == 0 && h < count) store_xyzz(partial, sub_off[heavy[1 + h]], sh[t]);
+  if (lane == 0 && mine) store_xyzz(partial, sub_off[heavy[1 + h]], sh[t]);
 }
-// One workgroup per remaining heavy bucket (those after the first `first`): strided accumulation by 256 threads, then an LDS tree.
+// One workgroup per remaining heavy bucket (moderately heavy ones, and any beyond the first `first` of the list): strided
+// accumulation by 256 threads, then an LDS tree.
 template <class F>
 __global__ void __launch_bounds__(256) k_combine_heavy(uint32_t* __restrict__ partial, const uint32_t* __restrict__ sub_off,
                                                        const uint32_t* __restrict__ heavy, uint32_t heavy_cap, uint32_t first) {
   __shared__ XYZZ<F> sh[256];
   const uint32_t count = min(heavy[0], heavy_cap), t = threadIdx.x;
-  for (uint32_t h = first + blockIdx.x; h < count; h += gridDim.x) {
+  for (uint32_t h = blockIdx.x; h < count; h += gridDim.x) {
     const uint32_t b = heavy[1 + h];
     const uint32_t s0 = sub_off[b], m = sub_off[b + 1] - s0;
+    if (h < first && m >= MSM_HEAVY_SPLIT_MIN) continue;      // folded by the two-stage path
     XYZZ<F> acc = XYZZ<F>::identity();
     for (uint32_t k = t; k < m; k += 256) { XYZZ<F> q = load_xyzz<F>(partial, s0 + k); add_full(acc, q); }
     __syncthreads();
@@ -587,7 +594,7 @@ hipError_t msm_launch(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_ba
   hipLaunchKernelGGL(k_combine<F>, dim3((pl.nb + 15) / 16), dim3(256), 0, stream, partial, ws.sub_off, pl.nb, ws.heavy, MsmWorkspace::HEAVY_CAP);
   hipLaunchKernelGGL(k_combine_heavy1<F>, dim3(2048), dim3(256), 0, stream, partial, ws.sub_off, ws.heavy, MsmWorkspace::HEAVY_CAP, ws.heavy_scratch);
   hipLaunchKernelGGL(k_combine_heavy2<F>, dim3(MSM_HEAVY_SPLIT / 8), dim3(256), 0, stream, partial, ws.sub_off, ws.heavy, MsmWorkspace::HEAVY_CAP, ws.heavy_scratch);
-  hipLaunchKernelGGL(k_combine_heavy<F>, dim3(256), dim3(256), 0, stream, partial, ws.sub_off, ws.heavy, MsmWorkspace::HEAVY_CAP, MSM_HEAVY_SPLIT);
+  hipLaunchKernelGGL(k_combine_heavy<F>, dim3(1024), dim3(256), 0, stream, partial, ws.sub_off, ws.heavy, MsmWorkspace::HEAVY_CAP, MSM_HEAVY_SPLIT);
   VZ_EV(5);
   const unsigned T = pl.nbw < 256 ? pl.nbw : 256;
   uint32_t* wsum = reinterpret_cast<uint32_t*>(ws.window_sums);
