@@ -165,3 +165,31 @@ def test_a_forged_instance_is_caught_by_the_oracle_verifier(ctx, keys, oracle):
         assert "z0" in oracle_verify(oracle, ivc, ck1, ck2, 4, [1], check_commitments=False)[0]
     finally:
         ivc.close()
+
+
+def test_full_image_as_two_ivc_proofs_ends_in_the_references_committed_state(ctx, keys):
+    """All 720 rows of the reference's sample image (img2, contrast 1.4) proven as two Nova IVC proofs of contiguous row
+    segments folded concurrently: both verify, the boundary states chain, and the last state is the final state inside the
+    reference's committed proof (marketplace/proofs/img2-contrast.proof via tests/golden/kat.json)."""
+    from tests import _data
+    from vimz_amd import folding, hip, image_editor as ie
+    from vimz_amd.distributed import fold_concurrently, ivc_segments
+    ck1, ck2 = keys
+    P = _data.kat()["proofs"]["img2-contrast"]
+    inp = ie.build_input("contrast", _data.load_image("img2"), factor=1.4)
+    rows, z0 = folding.prepare_input("contrast", inp, "HD")
+    c = Circuit.for_resolution("contrast", "HD")
+    ctx2 = hip.Context(0)
+    ivcs = [hip.IVC(ctx, c, ck1, ck2, max_batch=32), hip.IVC(ctx2, c, ck1, ck2, max_batch=32)]
+    try:
+        segs = ivc_segments(ivcs, rows, z0)
+        for v, r, z in segs:
+            v.reset(z)
+        fold_concurrently([(v, r) for v, r, z in segs])
+        assert [v.verify() for v in ivcs] == [0, 0]
+        assert ivcs[0].state() == (segs[1][2], 360)
+        assert ivcs[1].state() == ([int(x) for x in P["z_final"]], 360)
+    finally:
+        for v in ivcs:
+            v.close()
+        ctx2.close()

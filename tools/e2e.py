@@ -2,7 +2,9 @@
 """End-to-end run of one transformation on the GPU, the way `vimz -b nova-snark -f <t>` sequences it
 (vimz/src/nova_snark_backend/mod.rs:22-80): prepare input -> prepare folding (circuit + key) -> fold every row -> verify.
 Prints the span times the reference logs ("Prepare input", "Prepare folding", "Fold input", "Verify folded proof").
-usage: e2e.py <transformation> <resolution> [segments]"""
+usage: e2e.py <transformation> <resolution> [segments] [ivc|accumulator]
+ivc (default): the rows are proven as `segments` Nova IVC proofs of contiguous row segments (chained boundary states);
+accumulator: NIFS accumulators of the segments merged by a final fold."""
 import json
 import sys
 import time
@@ -11,13 +13,14 @@ import numpy as np
 
 sys.path.insert(0, __file__.rsplit("/tools/", 1)[0])
 import bench  # noqa: E402
-from vimz_amd import folding, hip  # noqa: E402
-from vimz_amd.distributed import fold_local_segments  # noqa: E402
+from vimz_amd import _lib, folding, hip  # noqa: E402
+from vimz_amd.distributed import fold_concurrently, fold_local_segments, ivc_segments  # noqa: E402
 
 
 def main():
     t, res = sys.argv[1], sys.argv[2]
     S = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+    mode = sys.argv[4] if len(sys.argv) > 4 else "ivc"
     spans = {}
     t0 = time.time()
     rows, z0 = bench.build_inputs(t, res)
@@ -25,6 +28,26 @@ def main():
     t0 = time.time()
     ctxs = [hip.Context(0) for _ in range(S)]
     circuit, params = folding.prepare_folding(ctxs[0], t, res)
+    if mode == "ivc":
+        ck2 = ctxs[0].bases_generate(_lib.CURVE_GRUMPKIN, 1 << 13, b"ck-secondary")
+        ivcs = [hip.IVC(c, circuit, params.ck, ck2, max_batch=64 if res == "HD" else 32) for c in ctxs]
+        spans["Prepare folding"] = time.time() - t0
+        t0 = time.time()
+        segs = ivc_segments(ivcs, rows, z0)
+        for v, r, z in segs:
+            v.reset(z)
+        fold_concurrently([(v, r) for v, r, z in segs])
+        for c in ctxs:
+            c.sync()
+        spans["Fold input"] = time.time() - t0
+        t0 = time.time()
+        ok = all(v.verify() == 0 for v in ivcs) and all(segs[i][0].state()[0] == segs[i + 1][2] for i in range(S - 1))
+        spans["Verify folded proof"] = time.time() - t0
+        n = sum(v.state()[1] for v in ivcs)
+        print(json.dumps({"config": f"{t}_step_{res}", "mode": "ivc", "steps": n, "segment_proofs": S, "verified": ok, "spans_s": spans,
+                          "steps_per_s": n / spans["Fold input"], "total_s": sum(spans.values()),
+                          "final_state": [hex(z) for z in ivcs[-1].state()[0]]}))
+        return
     provers = [hip.Prover(c, circuit, params.ck, max_batch=64 if res == "HD" else 32) for c in ctxs]
     spans["Prepare folding"] = time.time() - t0
     t0 = time.time()
@@ -36,7 +59,7 @@ def main():
     ok = merged.verify() == 0
     spans["Verify folded proof"] = time.time() - t0
     inst = merged.instance()
-    print(json.dumps({"config": f"{t}_step_{res}", "steps": inst["steps"], "segments": S, "verified": ok, "spans_s": spans,
+    print(json.dumps({"config": f"{t}_step_{res}", "mode": "accumulator", "steps": inst["steps"], "segments": S, "verified": ok, "spans_s": spans,
                       "steps_per_s": inst["steps"] / spans["Fold input"], "total_s": sum(spans.values()),
                       "final_state": [hex(int(a[0]) | int(a[1]) << 64 | int(a[2]) << 128 | int(a[3]) << 192) for a in inst["z"]]}))
 
