@@ -444,6 +444,134 @@ __global__ void __launch_bounds__(256) k_reduce(const uint32_t* __restrict__ par
   if (t == 0) store_xyzz(window_sums, w, sh[0]);
 }
 
+// ---- fused small MSM -------------------------------------------------------------------------------------------------
+// Below ~16 k points the general pipeline is pure latency: ten launches, a sort through global memory, a per-window reduce
+// that is 23-31 dependent additions deep.  Nova's augmented circuits need four such MSMs per step (7.6 k points each), on the
+// critical path.  Here one launch does everything: workgroup (w, q) owns window w (c = 7: 37 windows of 64 signed buckets)
+// and point chunk q (<= 1024 points): digits -> counting sort in LDS -> one thread per sub-bucket of <= 8 entries ->
+// segmented tree over a bucket's sub-buckets -> sum_b (b+1)·B_b as the sum of the 64 suffix sums (scan + tree, 12 deep) ->
+// the last workgroup of a window to finish adds the chunk results.  Depth: 8 + log2(max sub-buckets) + 12 + log2(chunks).
+constexpr int SMALL_C = 7;
+constexpr uint32_t SMALL_NBW = 1u << (SMALL_C - 1), SMALL_SUB = 8, SMALL_CHUNK = 1024, SMALL_MAXQ = 16;
+constexpr size_t MSM_SMALL_MAX = (size_t)SMALL_CHUNK * SMALL_MAXQ;
+
+__device__ __forceinline__ int signed_digit(const uint32_t* s, int c, int w) {
+  uint32_t carry = 0, d = 0;
+  const uint32_t half = 1u << (c - 1);
+  for (int j = 0; j <= w; j++) {
+    d = window_bits(s, j * c, c) + carry;
+    carry = d > half;
+  }
+  return d > half ? (int)d - (1 << c) : (int)d;
+}
+
+template <class S, class F>
+__global__ void __launch_bounds__(256) k_msm_small(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ scalars, uint32_t n, int mont,
+                                                   uint32_t Q, uint32_t chunk, uint32_t* __restrict__ chunk_out /* K*Q points */,
+                                                   uint32_t* __restrict__ done /* K counters, zero between launches */, uint32_t* __restrict__ window_sums) {
+  __shared__ XYZZ<F> sh[256];
+  __shared__ uint32_t cnt[SMALL_NBW], off[SMALL_NBW + 1], soff[SMALL_NBW + 1], cur[SMALL_NBW];
+  __shared__ uint16_t list[SMALL_CHUNK];
+  __shared__ uint8_t subb[256];
+  __shared__ uint32_t s_maxm, s_ticket;
+  const uint32_t t = threadIdx.x, w = blockIdx.x, q = blockIdx.y;
+  const uint32_t lo = q * chunk, hi = min(n, lo + chunk);
+  if (t < SMALL_NBW) { cnt[t] = 0; cur[t] = 0; }
+  __syncthreads();
+  int dig[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    dig[k] = 0;
+    const uint32_t i = lo + t + 256u * k;
+    if (i < hi) {
+      uint32_t sc[8];
+      if (load_scalar<S>(scalars, i, mont, 0, sc)) {
+        dig[k] = signed_digit(sc, SMALL_C, (int)w);
+        if (dig[k]) atomicAdd(&cnt[(dig[k] < 0 ? -dig[k] : dig[k]) - 1], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  if (t == 0) {
+    uint32_t e = 0, sb = 0, mx = 0;
+    for (uint32_t b = 0; b < SMALL_NBW; b++) { off[b] = e; soff[b] = sb; const uint32_t m = (cnt[b] + SMALL_SUB - 1) / SMALL_SUB; e += cnt[b]; sb += m; mx = m > mx ? m : mx; }
+    off[SMALL_NBW] = e; soff[SMALL_NBW] = sb; s_maxm = mx;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    if (dig[k]) {
+      const uint32_t b = (uint32_t)(dig[k] < 0 ? -dig[k] : dig[k]) - 1;
+      const uint32_t pos = atomicAdd(&cur[b], 1u);
+      list[off[b] + pos] = (uint16_t)((t + 256u * k) | (dig[k] < 0 ? 0x8000u : 0u));
+    }
+  }
+  if (t < SMALL_NBW) for (uint32_t sb = soff[t]; sb < soff[t + 1]; sb++) subb[sb] = (uint8_t)t;
+  __syncthreads();
+  const uint32_t nsubs = soff[SMALL_NBW];
+  XYZZ<F> acc = XYZZ<F>::identity();
+  uint32_t kk = 0, mb = 0;
+  if (t < nsubs) {
+    const uint32_t b = subb[t];
+    kk = t - soff[b]; mb = soff[b + 1] - soff[b];
+    const uint32_t beg = off[b] + kk * SMALL_SUB, end = min(off[b + 1], beg + SMALL_SUB);
+    for (uint32_t e = beg; e < end; e++) {
+      const uint32_t ent = list[e];
+      Affine<F> pt = load_affine<F>(bases, lo + (ent & 0x7fffu));
+      if ((ent & 0x8000u) && !aff_is_identity(pt)) pt.y = F::neg(pt.y);
+      add_mixed(acc, pt);
+    }
+  }
+  sh[t] = acc;
+  __syncthreads();
+  for (uint32_t d = 1; d < s_maxm; d <<= 1) {       // a bucket's sub-buckets are contiguous: stride-doubling tree inside each segment
+    if (t < nsubs && (kk & (2 * d - 1)) == 0 && kk + d < mb) { XYZZ<F> a = sh[t]; add_full(a, sh[t + d]); sh[t] = a; }
+    __syncthreads();
+  }
+  XYZZ<F> bk = XYZZ<F>::identity();
+  if (t < SMALL_NBW && cnt[t]) bk = sh[soff[t]];
+  __syncthreads();
+  if (t < SMALL_NBW) sh[t] = bk;
+  __syncthreads();
+  for (uint32_t d = 1; d < SMALL_NBW; d <<= 1) {    // inclusive suffix sums of the buckets
+    const bool act = t + d < SMALL_NBW;
+    XYZZ<F> o = XYZZ<F>::identity();
+    if (act) o = sh[t + d];
+    __syncthreads();
+    if (act) { XYZZ<F> a = sh[t]; add_full(a, o); sh[t] = a; }
+    __syncthreads();
+  }
+  for (uint32_t d = SMALL_NBW / 2; d > 0; d >>= 1) {   // sum_b (b+1)·B_b = sum of the suffix sums
+    if (t < d) { XYZZ<F> a = sh[t]; add_full(a, sh[t + d]); sh[t] = a; }
+    __syncthreads();
+  }
+  if (Q == 1) { if (t == 0) store_xyzz(window_sums, w, sh[0]); return; }
+  if (t == 0) {
+    store_xyzz(chunk_out, (size_t)w * Q + q, sh[0]);
+    __threadfence();
+    s_ticket = atomicAdd(&done[w], 1u);
+  }
+  __syncthreads();
+  if (s_ticket != Q - 1) return;
+  __threadfence();
+  XYZZ<F> v = XYZZ<F>::identity();
+  if (t < Q) {   // the other workgroups' results: agent-scope loads (this CU's vector cache may hold stale lines of the buffer)
+    uint32_t wd[XYZZ_WORDS];
+    const uint32_t* src = chunk_out + (size_t)XYZZ_WORDS * ((size_t)w * Q + t);
+    for (int k = 0; k < XYZZ_WORDS; k++) wd[k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    F* f[4] = {&v.X, &v.Y, &v.ZZ, &v.ZZZ};
+    for (int c4 = 0; c4 < 4; c4++) for (int i = 0; i < 9; i++) f[c4]->v[i] = wd[COORD_WORDS * c4 + i];
+  }
+  __syncthreads();
+  sh[t] = v;
+  __syncthreads();
+  for (uint32_t d = SMALL_MAXQ / 2; d > 0; d >>= 1) {
+    if (t < d) { XYZZ<F> a = sh[t]; add_full(a, sh[t + d]); sh[t] = a; }
+    __syncthreads();
+  }
+  if (t == 0) { store_xyzz(window_sums, w, sh[0]); done[w] = 0; }
+}
+
 // ---- host driver ---------------------------------------------------------------------------------
 
 // ---- window tables: one bucket set for all windows ---------------------------------------------------------------------
@@ -539,6 +667,21 @@ hipError_t msm_launch(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_ba
   typedef typename C::Scalar S;
   if (n == 0 || n >= (1u << 31)) return hipErrorInvalidValue;
   const bool tabled = tb && tb->d && c_override <= 0;
+  if (!tabled && c_override <= 0 && n <= MSM_SMALL_MAX) {      // fused single-launch path
+    MsmPlan ps; ps.c = SMALL_C; ps.K = (S::Params::BITS + SMALL_C) / SMALL_C; ps.nbw = SMALL_NBW; ps.nb = SMALL_NBW * (uint32_t)ps.K; ps.split_ones = 0; ps.tabled = 0;
+    *plan_out = ps;
+    VZ_HIP_CHECK(ws.reserve_small());
+    const uint32_t Q = (uint32_t)((n + SMALL_CHUNK - 1) / SMALL_CHUNK), chunk = (uint32_t)((n + Q - 1) / Q);
+    uint32_t* done = reinterpret_cast<uint32_t*>(ws.small_buf);
+    uint32_t* chunk_out = done + 128;
+    if (ev) for (int i = 0; i < 4; i++) VZ_HIP_CHECK(hipEventRecord(ev[i], stream));
+    hipLaunchKernelGGL((k_msm_small<S, F>), dim3(ps.K, Q), dim3(256), 0, stream, d_bases, d_scalars, (uint32_t)n, scalars_mont, Q, chunk, chunk_out, done,
+                       reinterpret_cast<uint32_t*>(ws.window_sums));
+    if (ev) for (int i = 4; i < 7; i++) VZ_HIP_CHECK(hipEventRecord(ev[i], stream));
+    VZ_HIP_CHECK(hipGetLastError());
+    VZ_HIP_CHECK(hipMemcpyAsync(pinned_dst, ws.window_sums, 4 * (size_t)XYZZ_WORDS * ps.K, hipMemcpyDeviceToHost, stream));
+    return hipSuccess;
+  }
   MsmPlan pl = msm_plan(n, S::Params::BITS, tabled ? tb->c : c_override);
   if (tabled) {            // one bucket set shared by all windows
     if (tb->K != pl.K || pl.nbw < 256 || (size_t)tb->K * tb->n_total >= (1u << 31)) return hipErrorInvalidValue;

@@ -99,6 +99,16 @@ struct MsmWorkspace {  // device buffers, grown on demand and reused across call
     if (!host_pinned) VZ_HIP_CHECK(hipHostMalloc(&host_pinned, 4 * XYZZ_WORDS * MSM_MAX_WINDOWS));
     return hipSuccess;
   }
+  void* small_buf = nullptr;       // fused small MSM: 128 completion counters, then MSM_MAX_WINDOWS x 16 chunk results
+  hipError_t reserve_small() {
+    if (!window_sums) VZ_HIP_CHECK(hipMalloc(&window_sums, 4 * XYZZ_WORDS * MSM_MAX_WINDOWS));
+    if (!host_pinned) VZ_HIP_CHECK(hipHostMalloc(&host_pinned, 4 * XYZZ_WORDS * MSM_MAX_WINDOWS));
+    if (!totals) { VZ_HIP_CHECK(hipMalloc(&totals, 64)); VZ_HIP_CHECK(hipMemset(totals, 0, 64)); }
+    if (small_buf) return hipSuccess;
+    const size_t bytes = 512 + 4 * (size_t)XYZZ_WORDS * MSM_MAX_WINDOWS * 16;
+    VZ_HIP_CHECK(hipMalloc(&small_buf, bytes));
+    return hipMemset(small_buf, 0, bytes);
+  }
   hipError_t reserve_block_hist(size_t words) {
     if (words <= cap_block_hist) return hipSuccess;
     hipFree(block_hist); block_hist = nullptr; cap_block_hist = 0;
@@ -108,7 +118,7 @@ struct MsmWorkspace {  // device buffers, grown on demand and reused across call
   }
   void release() {
     hipFree(counts); hipFree(cursor); hipFree(bucket_off); hipFree(sub_off); hipFree(sorted);
-    hipFree(partial); hipFree(window_sums); hipFree(totals); hipFree(heavy); hipFree(heavy_scratch); hipFree(ones_partial); hipFree(block_hist);
+    hipFree(partial); hipFree(window_sums); hipFree(totals); hipFree(heavy); hipFree(heavy_scratch); hipFree(small_buf); hipFree(ones_partial); hipFree(block_hist);
     if (host_pinned) hipHostFree(host_pinned);
     *this = MsmWorkspace();
   }
