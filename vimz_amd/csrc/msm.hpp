@@ -448,11 +448,13 @@ __global__ void __launch_bounds__(256) k_reduce(const uint32_t* __restrict__ par
 // Below ~16 k points the general pipeline is pure latency: ten launches, a sort through global memory, a per-window reduce
 // that is 23-31 dependent additions deep.  Nova's augmented circuits need four such MSMs per step (7.6 k points each), on the
 // critical path.  Here one launch does everything: workgroup (w, q) owns window w (c = 7: 37 windows of 64 signed buckets)
-// and point chunk q (<= 1024 points): digits -> counting sort in LDS -> one thread per sub-bucket of <= 8 entries ->
+// and point chunk q (<= 1536 points): digits -> counting sort in LDS -> one thread per sub-bucket of <= 8 entries ->
 // segmented tree over a bucket's sub-buckets -> sum_b (b+1)·B_b as the sum of the 64 suffix sums (scan + tree, 12 deep) ->
 // the last workgroup of a window to finish adds the chunk results.  Depth: 8 + log2(max sub-buckets) + 12 + log2(chunks).
 constexpr int SMALL_C = 7;
-constexpr uint32_t SMALL_NBW = 1u << (SMALL_C - 1), SMALL_SUB = 8, SMALL_CHUNK = 1024, SMALL_MAXQ = 16;
+constexpr uint32_t SMALL_NBW = 1u << (SMALL_C - 1), SMALL_SUB = 8, SMALL_PER_THREAD = 6, SMALL_CHUNK = 256 * SMALL_PER_THREAD, SMALL_MAXQ = 16;
+// (1536 points per workgroup: at most 1536/8 + 64 = 256 sub-buckets, one per thread; 7.6 k points -> 37 x 5 = 185 workgroups,
+//  fewer than the 256 CUs, so no two workgroups' single-wave scan phases share a SIMD)
 constexpr size_t MSM_SMALL_MAX = (size_t)SMALL_CHUNK * SMALL_MAXQ;
 
 __device__ __forceinline__ int signed_digit(const uint32_t* s, int c, int w) {
@@ -478,9 +480,9 @@ __global__ void __launch_bounds__(256) k_msm_small(const uint32_t* __restrict__ 
   const uint32_t lo = q * chunk, hi = min(n, lo + chunk);
   if (t < SMALL_NBW) { cnt[t] = 0; cur[t] = 0; }
   __syncthreads();
-  int dig[4];
+  int dig[SMALL_PER_THREAD];
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
+  for (int k = 0; k < (int)SMALL_PER_THREAD; k++) {
     dig[k] = 0;
     const uint32_t i = lo + t + 256u * k;
     if (i < hi) {
@@ -499,7 +501,7 @@ __global__ void __launch_bounds__(256) k_msm_small(const uint32_t* __restrict__ 
   }
   __syncthreads();
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
+  for (int k = 0; k < (int)SMALL_PER_THREAD; k++) {
     if (dig[k]) {
       const uint32_t b = (uint32_t)(dig[k] < 0 ? -dig[k] : dig[k]) - 1;
       const uint32_t pos = atomicAdd(&cur[b], 1u);
