@@ -212,7 +212,7 @@ def main():
     ap.add_argument("--transformation", default="contrast")
     ap.add_argument("--resolution", default="HD")
     ap.add_argument("--batch", type=int, default=64)
-    ap.add_argument("--segments", type=int, default=2, help="row segments folded concurrently on each GPU (own context + streams each)")
+    ap.add_argument("--segments", type=int, default=0, help="row segments folded concurrently on each GPU, own context + streams each (default: 3 IVC proofs, 2 accumulators)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", default="ivc", choices=["ivc", "accumulator"])
@@ -237,7 +237,7 @@ def main():
 
     from vimz_amd import _lib, folding, hip
     from vimz_amd.distributed import segment_bounds
-    S = max(1, args.segments)
+    S = args.segments if args.segments > 0 else (3 if args.mode == "ivc" else 2)
     ctxs = [hip.Context(device) for _ in range(S)]
     ctx = ctxs[0]
     t_setup = time.time()
