@@ -108,11 +108,10 @@ def test_tampered_witness_and_off_curve_points_are_rejected(oracle, circuits, si
     pz, i, z, U, u, T = _case(oracle, side, "generic", rng)
     wires, out = c.witness([pz, i, z, *U, *u, *T])
     assert oracle.r1cs_check_relaxed(fid, tabs[side], c.n_wires, wires) == -1
-    for _ in range(12):
-        k = rng.randrange(3, c.n_wires)
+    for k in rng.sample(range(1, c.n_wires), 1500):
         w = wires.copy()
         w[k] = to_limbs([(from_limbs(w[k:k + 1])[0] + 1) % p])[0]
-        assert oracle.r1cs_check_relaxed(fid, tabs[side], c.n_wires, w) >= 0, f"wire {k} is unconstrained"
+        assert oracle.r1cs_check_relaxed(fid, tabs[side], c.n_wires, w, threads=2) >= 0, f"wire {k} is unconstrained"
     # a fresh commitment that is not on the curve
     bad_u = list(u); bad_u[1] = (bad_u[1] + 1) % p
     bad_u[2] = u[2]
