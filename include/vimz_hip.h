@@ -225,7 +225,8 @@ int vimz_ivc_fold_witness(vimz_ivc* v, const uint64_t* witnesses, size_t nsteps)
 /* RecursiveSNARK::verify: both output hashes, is_sat_relaxed of both running instances, is_sat of the last secondary instance,
  * every commitment re-opened.  result: 0 = accepted; bit 0/1 hash of the primary/secondary chain; bit 2 primary relaxed relation;
  * bit 3 primary comm_W; bit 4 primary comm_E; bit 5 secondary relaxed relation; bit 6/7 secondary comm_W/comm_E; bit 8 last
- * secondary instance's relation; bit 9 its comm_W; bit 10 instance scalars differ from the witness vectors. */
+ * secondary instance's relation; bit 9 its comm_W; bit 10 instance scalars differ from the witness vectors; bit 11 the running products (A,B,C)·Z kept for the next
+ * fold violate the relation (prover-side bookkeeping, not part of the proof). */
 int vimz_ivc_verify(vimz_ivc* v, uint32_t* result);
 /* info[0..11]: steps, primary wires, primary constraints, step wires, step constraints, secondary wires, secondary constraints,
  * len_z, verifier-circuit wires (primary), nnz(A+B+C) primary, nnz secondary, reserved */
@@ -236,6 +237,11 @@ int vimz_ivc_state_chain(vimz_ivc* v, const uint64_t* z_start, const uint64_t* s
 /* seconds[8]/counts[8]: verifier-circuit witness primary (host), secondary (host), wait for secondary MSMs, wait for primary MSMs,
  * uploads+launches, producer wait, reserved, total */
 int vimz_ivc_profile(const vimz_ivc* v, double seconds[8], uint64_t counts[8]);
+/* The proof as an object of its own (RecursiveSNARK serialisation; checkpoint / resume): everything vimz_ivc_verify reads and the
+ * next vimz_ivc_fold needs.  Import into a vimz_ivc created for the same step circuit and keys, then verify or keep folding. */
+size_t vimz_ivc_proof_size(const vimz_ivc* v);
+int vimz_ivc_proof_export(vimz_ivc* v, uint8_t* blob, size_t cap);
+int vimz_ivc_proof_import(vimz_ivc* v, const uint8_t* blob, size_t len);
 /* Everything an independent verifier needs, canonical little-endian 4 x u64 per element (the parity tests hand these to the
  * CPU oracle's verifier).  side 0 = primary (BN254 Fr / G1), 1 = secondary (BN254 Fq / Grumpkin).
  *   what = VIMZ_CX_{A,B,C}_{ROWPTR,COL,COEF}, VIMZ_CX_DICT_CANON : the augmented circuit's R1CS

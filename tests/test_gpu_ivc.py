@@ -193,3 +193,40 @@ def test_full_image_as_two_ivc_proofs_ends_in_the_references_committed_state(ctx
         for v in ivcs:
             v.close()
         ctx2.close()
+
+
+def test_proof_export_import_verifies_elsewhere_and_resumes(ctx, keys, oracle):
+    """The serialised proof verifies in a fresh vimz_ivc (another prover object = what another process would build), folding
+    resumes from it and ends exactly where an uninterrupted run ends; a corrupted blob is rejected by the verifier."""
+    from vimz_amd import hip
+    ck1, ck2 = keys
+    c = Circuit.for_resolution("grayscale", "HD")
+    z0, inputs = step_inputs("grayscale")
+    steps = np.stack(inputs)
+    a, b, ref = (hip.IVC(ctx, c, ck1, ck2, max_batch=4) for _ in range(3))
+    try:
+        a.reset(z0); a.fold(steps[:6])
+        blob = a.proof_export()
+        b.proof_import(blob)
+        assert b.verify() == 0 and b.state() == a.state()
+        b.fold(steps[6:])
+        ref.reset(z0); ref.fold(steps)
+        assert b.verify() == 0
+        for side in (0, 1):
+            assert (b.export(side, hip.IX_INSTANCE) == ref.export(side, hip.IX_INSTANCE)).all()
+            assert (b.export(side, hip.IX_RUNNING_Z) == ref.export(side, hip.IX_RUNNING_Z)).all()
+        assert (b.export(1, hip.IX_FRESH_INSTANCE) == ref.export(1, hip.IX_FRESH_INSTANCE)).all()
+        failed, _ = oracle_verify(oracle, b, ck1, ck2, 10, z0, check_commitments=False)
+        assert failed == []
+        nc2 = a.info()["secondary_constraints"]
+        # in the running products / the primary witness / the last fresh secondary witness (the vectors after it — products of the
+        # fresh instance and the pending cross term — are resume state that verification recomputes or never reads)
+        for where in (len(blob) // 2, 4096, len(blob) - 32 * 8 * nc2 - 40):
+            bad = blob.copy()
+            bad[where] ^= 1
+            a.proof_import(bad)
+            assert a.verify() != 0, where
+        with pytest.raises(_lib.VimzError):
+            a.proof_import(blob[:1000])
+    finally:
+        a.close(); b.close(); ref.close()

@@ -419,6 +419,13 @@ int vimz_ivc_verify(vimz_ivc* v, uint32_t* result) {
   P_TRY(hipMemcpyAsync(bad, p->bad_d, 8, hipMemcpyDeviceToHost, s));
   P_TRY(hipStreamSynchronize(s));
   if (bad[0]) res |= 4;
+  // the running products kept by linearity must equal the recomputed ones (they feed the next cross term)
+  P_TRY(hipMemcpyAsync(p->bad_d, init, 8, hipMemcpyHostToDevice, s));
+  { const uint32_t* kept[3] = {p->AZ, p->BZ, p->CZ}; const uint32_t* fresh[3] = {p->az2, p->bz2, p->cz2};
+    for (int m = 0; m < 3; m++) hipLaunchKernelGGL(k_count_diff, dim3(stream_grid(p->n_c)), dim3(256), 0, s, (size_t)p->n_c, kept[m], fresh[m], p->bad_d); }
+  P_TRY(hipMemcpyAsync(bad, p->bad_d, 8, hipMemcpyDeviceToHost, s));
+  P_TRY(hipStreamSynchronize(s));
+  if (bad[0]) res |= 2048;
   if ((rc = vz_msm_device(ctx, p->ck, 0, p->Zrun + 8, p->n_wires - 3, 1, 0, pt, VIMZ_FORM_MONTGOMERY))) return rc;
   if (memcmp(pt, v->U1.W.x.v, 32) || memcmp(pt + 4, v->U1.W.y.v, 32)) res |= 8;
   if ((rc = vz_msm_device(ctx, p->ck, 0, p->E, p->n_c, 1, 0, pt, VIMZ_FORM_MONTGOMERY))) return rc;
@@ -436,6 +443,12 @@ int vimz_ivc_verify(vimz_ivc* v, uint32_t* result) {
   P_TRY(hipMemcpyAsync(bad, S.bad, 8, hipMemcpyDeviceToHost, s));
   P_TRY(hipStreamSynchronize(s));
   if (bad[0]) res |= 32;
+  P_TRY(hipMemcpyAsync(S.bad, init, 8, hipMemcpyHostToDevice, s));
+  { const uint32_t* kept[3] = {S.AZ, S.BZ, S.CZ}; const uint32_t* fresh[3] = {S.az2, S.bz2, S.cz2};
+    for (int m = 0; m < 3; m++) hipLaunchKernelGGL(k_count_diff, dim3(stream_grid(S.n_c)), dim3(256), 0, s, (size_t)S.n_c, kept[m], fresh[m], S.bad); }
+  P_TRY(hipMemcpyAsync(bad, S.bad, 8, hipMemcpyDeviceToHost, s));
+  P_TRY(hipStreamSynchronize(s));
+  if (bad[0]) res |= 2048;
   if ((rc = vz_msm_device(ctx, v->ck2, 0, S.Zrun + 8, S.n_w - 3, 1, 0, pt, VIMZ_FORM_MONTGOMERY))) return rc;
   if (memcmp(pt, v->U2.W.x.v, 32) || memcmp(pt + 4, v->U2.W.y.v, 32)) res |= 64;
   if ((rc = vz_msm_device(ctx, v->ck2, 0, S.E, S.n_c, 1, 0, pt, VIMZ_FORM_MONTGOMERY))) return rc;
@@ -505,6 +518,78 @@ int64_t vimz_ivc_export(vimz_ivc* v, int side, int what, void* buf, size_t cap) 
   if (side == 0) launch_from_mont<Fr>(s, src, (uint32_t*)ctx->scratch, n); else launch_from_mont<Fq>(s, src, (uint32_t*)ctx->scratch, n);
   if (hipMemcpyAsync(buf, ctx->scratch, bytes, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return VIMZ_ERR_HIP;
   return (int64_t)bytes;
+}
+
+// ---- the proof as an object of its own: RecursiveSNARK serialisation / checkpoint-resume ------------------------------------------
+// Blob = header | host state | device vectors (Montgomery limbs as they sit in HBM).  It holds everything vimz_ivc_verify reads and
+// everything the next vimz_ivc_fold needs, so a proof can be verified by another process (import into a fresh vimz_ivc built for the
+// same step circuit and keys) or folding can resume after a restart.
+namespace {
+struct ProofHeader { uint64_t magic, steps, n_w1, n_c1, n_w2, n_c2, len_z, flags; };
+const uint64_t PROOF_MAGIC = 0x3143564956ull;   // "VIVC1"
+struct ProofHost {
+  Fe pz1; Fq pz2; RelaxedInst<Fe> U2; RelaxedInst<Fq> U1; FreshInst<Fe> u2; G2Aff T2; Fe u1_run; Fq u2_run; Fe digest1; Fq digest2;
+};
+size_t proof_vec_bytes(const vimz_ivc* v) {
+  const size_t nw1 = v->pri->n_wires, nc1 = v->pri->n_c, nw2 = v->sec.n_w, nc2 = v->sec.n_c;
+  return 32 * (nw1 + 4 * nc1 + 2 * nw2 + 8 * nc2);
+}
+}  // namespace
+
+size_t vimz_ivc_proof_size(const vimz_ivc* v) {
+  if (!v) return 0;
+  return sizeof(ProofHeader) + sizeof(ProofHost) + 64 * (size_t)v->pri->len_z + proof_vec_bytes(v);
+}
+
+int vimz_ivc_proof_export(vimz_ivc* v, uint8_t* blob, size_t cap) {
+  if (!v || !blob || cap < vimz_ivc_proof_size(v)) return vz_fail(v ? v->ctx : nullptr, VIMZ_ERR_INVALID, "vimz_ivc_proof_export: buffer too small");
+  vimz_ctx* ctx = v->ctx; vimz_prover* p = v->pri; SecDev& S = v->sec;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  P_TRY(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  ProofHeader h{PROOF_MAGIC, v->i, p->n_wires, p->n_c, S.n_w, S.n_c, p->len_z, (uint64_t)(v->sec_T_valid ? 1 : 0)};
+  ProofHost hs; memset(&hs, 0, sizeof(hs));
+  hs.pz1 = v->pz1; hs.pz2 = v->pz2; hs.U2 = v->U2; hs.U1 = v->U1; hs.u2 = v->u2; hs.T2 = v->T2; hs.u1_run = v->u1_run; hs.u2_run = v->u2_run;
+  hs.digest1 = v->c1->digest; hs.digest2 = v->c2.digest;
+  uint8_t* o = blob;
+  memcpy(o, &h, sizeof(h)); o += sizeof(h);
+  memcpy(o, &hs, sizeof(hs)); o += sizeof(hs);
+  memcpy(o, v->z0.data(), 32 * p->len_z); o += 32 * p->len_z;
+  memcpy(o, p->z_cur.data(), 32 * p->len_z); o += 32 * p->len_z;
+  const uint32_t* src[] = {p->Zrun, p->E, p->AZ, p->BZ, p->CZ, S.Zrun, S.z2, S.E, S.AZ, S.BZ, S.CZ, S.az2, S.bz2, S.cz2, S.T};
+  const size_t len[] = {p->n_wires, p->n_c, p->n_c, p->n_c, p->n_c, S.n_w, S.n_w, S.n_c, S.n_c, S.n_c, S.n_c, S.n_c, S.n_c, S.n_c, S.n_c};
+  for (int k = 0; k < 15; k++) { P_TRY(hipMemcpyAsync(o, src[k], 32 * len[k], hipMemcpyDeviceToHost, s)); o += 32 * len[k]; }
+  P_TRY(hipStreamSynchronize(s));
+  return VIMZ_OK;
+}
+
+int vimz_ivc_proof_import(vimz_ivc* v, const uint8_t* blob, size_t len) {
+  if (!v || !blob || len < sizeof(ProofHeader)) return VIMZ_ERR_INVALID;
+  vimz_ctx* ctx = v->ctx; vimz_prover* p = v->pri; SecDev& S = v->sec;
+  ProofHeader h; memcpy(&h, blob, sizeof(h));
+  if (h.magic != PROOF_MAGIC || h.n_w1 != p->n_wires || h.n_c1 != p->n_c || h.n_w2 != S.n_w || h.n_c2 != S.n_c || h.len_z != p->len_z || len < vimz_ivc_proof_size(v))
+    return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_ivc_proof_import: the blob does not match this IVC's circuits");
+  ProofHost hs; memcpy(&hs, blob + sizeof(h), sizeof(hs));
+  if (!hs.digest1.eq(v->c1->digest) || !hs.digest2.eq(v->c2.digest)) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_ivc_proof_import: shape digest differs");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  P_TRY(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  const uint8_t* o = blob + sizeof(h) + sizeof(hs);
+  memcpy(v->z0.data(), o, 32 * p->len_z); o += 32 * p->len_z;
+  memcpy(p->z_cur.data(), o, 32 * p->len_z); o += 32 * p->len_z;
+  p->z0 = v->z0;
+  uint32_t* dst[] = {p->Zrun, p->E, p->AZ, p->BZ, p->CZ, S.Zrun, S.z2, S.E, S.AZ, S.BZ, S.CZ, S.az2, S.bz2, S.cz2, S.T};
+  const size_t ln[] = {p->n_wires, p->n_c, p->n_c, p->n_c, p->n_c, S.n_w, S.n_w, S.n_c, S.n_c, S.n_c, S.n_c, S.n_c, S.n_c, S.n_c, S.n_c};
+  for (int k = 0; k < 15; k++) { P_TRY(hipMemcpyAsync(dst[k], o, 32 * ln[k], hipMemcpyHostToDevice, s)); o += 32 * ln[k]; }
+  P_TRY(hipStreamSynchronize(s));
+  v->i = h.steps; p->steps = h.steps;
+  v->pz1 = hs.pz1; v->pz2 = hs.pz2; v->U2 = hs.U2; v->U1 = hs.U1; v->u2 = hs.u2; v->T2 = hs.T2; v->u1_run = hs.u1_run; v->u2_run = hs.u2_run;
+  v->sec_T_valid = (h.flags & 1) != 0; v->pending_sec = false;
+  // pz must be what this IVC derives from its own digests and the blob's z0 (a forged pz would make the hashes unverifiable anyway)
+  const Fq zq = Fq::zero();
+  if (!v->pz1.eq(v->c1->pz(v->z0.data())) || !v->pz2.eq(v->c2.pz(&zq))) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_ivc_proof_import: pz does not match z0");
+  v->c1->cache.valid = false; v->c2.cache.valid = false;
+  return VIMZ_OK;
 }
 
 }  // extern "C"

@@ -112,4 +112,14 @@ __global__ void __launch_bounds__(256) k_check_relaxed(size_t n, const uint32_t*
   }
 }
 
+// counts elements where a != b (raw limbs)
+static __global__ void __launch_bounds__(256) k_count_diff(size_t n, const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, uint32_t* __restrict__ bad) {
+  VZ_GRID_STRIDE(i, n) {
+    uint32_t d = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) d |= a[8 * i + k] ^ b[8 * i + k];
+    if (d) atomicAdd(&bad[0], 1u);
+  }
+}
+
 }  // namespace vz

@@ -410,6 +410,23 @@ class IVC:
         self.ctx._chk(self.ctx.lib.vimz_ivc_profile(self.h, s, n))
         return {k: (s[i], n[i]) for i, k in enumerate(self.PHASES)}
 
+    def proof_export(self):
+        """The proof (and resume state) as bytes: vimz_ivc_proof_export."""
+        lib = self.ctx.lib
+        lib.vimz_ivc_proof_size.argtypes = [C.c_void_p]
+        lib.vimz_ivc_proof_size.restype = C.c_size_t
+        lib.vimz_ivc_proof_export.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        n = lib.vimz_ivc_proof_size(self.h)
+        buf = np.zeros(n, dtype=np.uint8)
+        self.ctx._chk(lib.vimz_ivc_proof_export(self.h, _ptr(buf), n))
+        return buf
+
+    def proof_import(self, blob):
+        lib = self.ctx.lib
+        lib.vimz_ivc_proof_import.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        b = np.ascontiguousarray(blob, dtype=np.uint8)
+        self.ctx._chk(lib.vimz_ivc_proof_import(self.h, _ptr(b), b.size))
+
     def export(self, side, what):
         """(n, 4) uint64 canonical elements."""
         return _export(self.ctx.lib.vimz_ivc_export, self.h, side, what).view(np.uint64).reshape(-1, 4)
