@@ -124,7 +124,8 @@ def main_ivc(args, rank, world, dist, torch, ctxs, circuit, params, steps_all, g
         dt = float(t[0])
     # acceptance (outside the timed region): every segment proof verifies, and the segments' boundary states chain
     t_v = time.time()
-    ok = all(ivc.verify() == 0 for ivc in ivcs)
+    codes = [ivc.verify() for ivc in ivcs]
+    ok = all(c == 0 for c in codes)
     ends = [ivc.state()[0] for ivc in ivcs]
     ok = ok and all(ends[i] == segs[i + 1][2] for i in range(S - 1))
     verify_s = time.time() - t_v
@@ -174,6 +175,7 @@ def main_ivc(args, rank, world, dist, torch, ctxs, circuit, params, steps_all, g
                        "rows_per_rank": args.steps, "segments_per_gpu": S, "witness_batch": args.batch,
                        "parallelism": f"{world * S} independent IVC proofs of contiguous row segments ({S} per GPU, folded concurrently), chained boundary states, no final fold"},
             "verified": bool(ok),
+            "verify_codes": codes,
             "folded_steps_total": folded,
             "verify_s": verify_s,
             "end_to_end_estimate_s": {"keygen_and_setup": setup_s, "fold_720_steps_one_gpu": 720 * dt / max(1, timed_rows)},

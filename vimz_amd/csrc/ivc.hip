@@ -15,6 +15,8 @@
 // the prover holds are exactly the ones the circuits compute: vimz_ivc_verify checks that.
 #include "prover_internal.hpp"
 #include <type_traits>
+#include <cstdio>
+#include <cstdlib>
 #include "aug/export.hpp"
 
 using namespace vz::aug;
@@ -95,6 +97,16 @@ int finish_secondary(vimz_ivc* v) {
   v->u2.W = msm_finish<Grumpkin>(v->plan_W2, v->pin + 2 * v->pin_res);
   if (v->sec_T_valid) v->T2 = msm_finish<Grumpkin>(v->plan_T2, v->pin + 3 * v->pin_res);
   else { v->T2.x = Fe::zero(); v->T2.y = Fe::zero(); }
+  static const bool dbg = getenv("VIMZ_DEBUG_CHECK_MSM") != nullptr;
+  if (dbg) {   // recompute both on the main stream, alone
+    G2Aff r; MsmStats st;
+    P_TRY(msm_run<Grumpkin>(ctx->stream, ctx->msm_ws, v->ck2->d, v->sec.z2 + 8, v->sec.n_w - 3, 1, 0, &r, &st, nullptr, 0, nullptr));
+    if (!r.x.eq(v->u2.W.x) || !r.y.eq(v->u2.W.y)) fprintf(stderr, "[dbg] step %llu: MSM(W2) on stream 2 differs from the recomputation\n", (unsigned long long)v->i);
+    if (v->sec_T_valid) {
+      P_TRY(msm_run<Grumpkin>(ctx->stream, ctx->msm_ws, v->ck2->d, v->sec.T, v->sec.n_c, 1, 0, &r, &st, nullptr, 0, nullptr));
+      if (!r.x.eq(v->T2.x) || !r.y.eq(v->T2.y)) fprintf(stderr, "[dbg] step %llu: MSM(T2) differs from the recomputation\n", (unsigned long long)v->i);
+    }
+  }
   v->pending_sec = false;
   return VIMZ_OK;
 }
@@ -164,8 +176,11 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
       P_TRY(hipMemcpyAsync(Zi + 8 * sw, pin_aug1, 32 * aw1, hipMemcpyHostToDevice, s));
       launch_spmv(p, s, Zi, az, bz, cz, 2);
       P_TRY(hipEventRecord(v->ev_fork, s));
-      P_TRY(hipStreamWaitEvent(v->s2, v->ev_fork, 0));
-      P_TRY(msm_launch<BnG1>(v->s2, v->ws2, p->ck->d + (size_t)AFFINE_WORDS * (sw - 1), Zi + 8 * sw, aw1 - 2, 1, 0, v->pin, &v->plan_aug, nullptr, 0, nullptr));
+      { static const int fs = getenv("VIMZ_DEBUG_FORK_SYNC") ? atoi(getenv("VIMZ_DEBUG_FORK_SYNC")) : 0; if (fs & 1) P_TRY(hipStreamSynchronize(s)); }
+      static const int fork_mask = getenv("VIMZ_DEBUG_FORK_MASK") ? atoi(getenv("VIMZ_DEBUG_FORK_MASK")) : 3;
+      hipStream_t sa = (fork_mask & 1) ? v->s2 : s;
+      P_TRY(hipStreamWaitEvent(sa, v->ev_fork, 0));
+      P_TRY(msm_launch<BnG1>(sa, v->ws2, p->ck->d + (size_t)AFFINE_WORDS * (sw - 1), Zi + 8 * sw, aw1 - 2, 1, 0, v->pin, &v->plan_aug, nullptr, 0, nullptr));
       // ---- 3. NIFS on the primary curve ------------------------------------------------------------------------------------------------
       if (i > 0) {
         hipLaunchKernelGGL(k_cross_term<Fr>, dim3(stream_grid(nc)), dim3(256), 0, s, nc, p->AZ, p->BZ, p->CZ, v->u1_run, az, bz, cz, Fe::one(), p->T);
@@ -182,10 +197,38 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
       v->ph_s[IP_WAIT_PRI] += now_s() - t0; v->ph_n[IP_WAIT_PRI]++;
       t0 = now_s();
       G1Aff cW_aug = msm_finish<BnG1>(v->plan_aug, v->pin);
+      {
+        static const bool dbg = getenv("VIMZ_DEBUG_CHECK_MSM") != nullptr;
+        if (dbg) {
+          G1Aff r; MsmStats st;
+          P_TRY(msm_run<BnG1>(s, ctx->msm_ws, p->ck->d + (size_t)AFFINE_WORDS * (sw - 1), Zi + 8 * sw, aw1 - 2, 1, 0, &r, &st, nullptr, 0, nullptr));
+          if (!r.x.eq(cW_aug.x) || !r.y.eq(cW_aug.y)) fprintf(stderr, "[dbg] step %llu: MSM(aug) on stream 2 differs from the recomputation\n", (unsigned long long)i);
+          P_TRY(msm_run<BnG1>(s, ctx->msm_ws, p->ck->d, Zi + 8, sw - 1, 1, 0, &r, &st, nullptr, 1, nullptr));
+          if (!r.x.eq(cW_step.x) || !r.y.eq(cW_step.y)) fprintf(stderr, "[dbg] step %llu: producer MSM(W) differs from the recomputation\n", (unsigned long long)i);
+        }
+      }
       G1 sum = from_affine(cW_step); add_mixed(sum, cW_aug);
       FreshInst<Fq> u1; u1.W = to_affine(sum); u1.x0 = cross_field<Fq>(o1.x0); u1.x1 = cross_field<Fq>(o1.x1);
       G1Aff T1; T1.x = Fq::zero(); T1.y = Fq::zero();
       if (i > 0) T1 = msm_finish<BnG1>(v->plan_T1, v->pin + v->pin_res);
+      {
+        static const bool dbgp = getenv("VIMZ_DEBUG_CHECK_POINTS") != nullptr;
+        if (dbgp) {
+          auto on = [](const G1Aff& q) { if (aff_is_identity(q)) return true; return Fq::sqr(q.y).eq(Fq::add(Fq::mul(Fq::sqr(q.x), q.x), cb::f_from_u64<Fq>(3))); };
+          if (!on(cW_step)) fprintf(stderr, "[dbg] step %llu: producer comm_W is not on the curve\n", (unsigned long long)i);
+          if (!on(cW_aug)) {
+            fprintf(stderr, "[dbg] step %llu: comm_W(aug) is not on the curve; window sums off curve:", (unsigned long long)i);
+            const uint32_t* hw = reinterpret_cast<const uint32_t*>(v->pin);
+            for (int w = 0; w < v->plan_aug.K; w++) {
+              typedef BnG1::Coord C29; XYZZ<Fq> pt; Fq* f[4] = {&pt.X, &pt.Y, &pt.ZZ, &pt.ZZZ};
+              for (int k = 0; k < 4; k++) { C29 t; for (int q = 0; q < 9; q++) t.v[q] = hw[(size_t)XYZZ_WORDS * w + COORD_WORDS * k + q]; *f[k] = t.to_std(); }
+              if (!on(to_affine(pt))) fprintf(stderr, " %d", w);
+            }
+            fprintf(stderr, "\n");
+          }
+          if (!on(T1)) fprintf(stderr, "[dbg] step %llu: comm_T1 is not on the curve\n", (unsigned long long)i);
+        }
+      }
       if (i > 0 && ctx->profiling) {       // HIP-event durations of the phases of this MSM(T), accumulated for the roofline figure
         float ms[6];
         for (int q = 0; q < 6; q++) { P_TRY(hipEventElapsedTime(&ms[q], ctx->ev[q], ctx->ev[q + 1])); ctx->last_msm.ms[q] = ms[q]; ctx->msm_tot_ms[q] += ms[q]; }
@@ -219,8 +262,11 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
         P_TRY(hipMemcpyAsync(S.z2, pin_w2, 32 * (size_t)S.n_w, hipMemcpyHostToDevice, s));
         sec_spmv<Fq>(S, s, S.z2, S.az2, S.bz2, S.cz2);
         P_TRY(hipEventRecord(v->ev_fork, s));
-        P_TRY(hipStreamWaitEvent(v->s2, v->ev_fork, 0));
-        P_TRY(msm_launch<Grumpkin>(v->s2, v->ws2, v->ck2->d, S.z2 + 8, S.n_w - 3, 1, 0, v->pin + 2 * v->pin_res, &v->plan_W2, nullptr, 0, nullptr));
+        { static const int fs = getenv("VIMZ_DEBUG_FORK_SYNC") ? atoi(getenv("VIMZ_DEBUG_FORK_SYNC")) : 0; if (fs & 2) P_TRY(hipStreamSynchronize(s)); }
+        static const int fork_mask2 = getenv("VIMZ_DEBUG_FORK_MASK") ? atoi(getenv("VIMZ_DEBUG_FORK_MASK")) : 3;
+        hipStream_t sb2 = (fork_mask2 & 2) ? v->s2 : s;
+        P_TRY(hipStreamWaitEvent(sb2, v->ev_fork, 0));
+        P_TRY(msm_launch<Grumpkin>(sb2, v->ws2, v->ck2->d, S.z2 + 8, S.n_w - 3, 1, 0, v->pin + 2 * v->pin_res, &v->plan_W2, nullptr, 0, nullptr));
         v->sec_T_valid = i > 0;    // U2 is still the zero instance after step 0: its cross term with anything is zero
         if (v->sec_T_valid) {
           hipLaunchKernelGGL(k_cross_term<Fq>, dim3(stream_grid(S.n_c)), dim3(256), 0, s, (size_t)S.n_c, S.AZ, S.BZ, S.CZ, v->u2_run, S.az2, S.bz2, S.cz2, Fq::one(), S.T);
@@ -260,7 +306,7 @@ void vimz_ivc_free(vimz_ivc* v) {
     std::lock_guard<std::mutex> g(v->ctx->mu);
     hipSetDevice(v->ctx->device);
     hipStreamSynchronize(v->ctx->stream);
-    if (v->s2) { hipStreamSynchronize(v->s2); hipStreamDestroy(v->s2); }
+    if (v->s2 && v->s2 != v->ctx->stream) { hipStreamSynchronize(v->s2); hipStreamDestroy(v->s2); }
     if (v->ev_fork) hipEventDestroy(v->ev_fork);
     v->ws2.release();
     for (void* d : v->owned) hipFree(d);
@@ -317,10 +363,12 @@ int vimz_ivc_create(vimz_ctx* ctx, const vimz_circuit* step_circuit, const vimz_
   for (auto d : vc) if (dalloc(d, 32 * (size_t)nc2) != hipSuccess) return fail("device allocation");
   if (dalloc(&S.bad, 64) != hipSuccess) return fail("device allocation");
   { int lo = 0, hi = 0; hipDeviceGetStreamPriorityRange(&lo, &hi);
-    if ((e = hipStreamCreateWithPriority(&v->s2, hipStreamNonBlocking, hi)) != hipSuccess) return fail("stream");
+    if (getenv("VIMZ_DEBUG_NO_S2")) v->s2 = ctx->stream;
+    else if ((e = hipStreamCreateWithPriority(&v->s2, hipStreamNonBlocking, hi)) != hipSuccess) return fail("stream");
     if ((e = hipEventCreateWithFlags(&v->ev_fork, hipEventDisableTiming)) != hipSuccess) return fail("event"); }
   v->pin_res = 4 * (size_t)XYZZ_WORDS * MSM_MAX_WINDOWS;
   if ((e = hipHostMalloc((void**)&v->pin, 4 * v->pin_res + 32 * (size_t)v->c1->aug_wires() + 32 * (size_t)nw2)) != hipSuccess) return fail("pinned");
+  if ((e = hipStreamSynchronize(nullptr)) != hipSuccess) return fail("sync");   // the hipMemset fills above ran on the null stream
   v->z0.assign(v->c1->len_z, Fe::zero());
   v->U1 = RelaxedInst<Fq>::zero(); v->U2 = RelaxedInst<Fe>::zero(); v->u2 = FreshInst<Fe>::zero(); v->T2.x = v->T2.y = Fe::zero();
   *out = v.release();

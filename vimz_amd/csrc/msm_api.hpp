@@ -103,11 +103,13 @@ struct MsmWorkspace {  // device buffers, grown on demand and reused across call
   hipError_t reserve_small() {
     if (!window_sums) VZ_HIP_CHECK(hipMalloc(&window_sums, 4 * XYZZ_WORDS * MSM_MAX_WINDOWS));
     if (!host_pinned) VZ_HIP_CHECK(hipHostMalloc(&host_pinned, 4 * XYZZ_WORDS * MSM_MAX_WINDOWS));
-    if (!totals) { VZ_HIP_CHECK(hipMalloc(&totals, 64)); VZ_HIP_CHECK(hipMemset(totals, 0, 64)); }
+    // NOTE: hipMemset on device memory runs on the null stream and may return before it has executed; the MSM streams are
+    // non-blocking, so every such fill is followed by a null-stream synchronise (a fill landing after the first kernel's
+    // writes cost a day: it zeroed chunk results of the very first small MSM of a prover, only under heavy multi-stream load).
+    if (!totals) { VZ_HIP_CHECK(hipMalloc(&totals, 64)); VZ_HIP_CHECK(hipMemset(totals, 0, 64)); VZ_HIP_CHECK(hipStreamSynchronize(nullptr)); }
     if (small_buf) return hipSuccess;
     const size_t bytes = 512 + 4 * (size_t)XYZZ_WORDS * MSM_MAX_WINDOWS * 16;
-    VZ_HIP_CHECK(hipMalloc(&small_buf, bytes));
-    return hipMemset(small_buf, 0, bytes);
+    return hipMalloc(&small_buf, bytes);     // chunk results: fully written by every launch before they are read
   }
   hipError_t reserve_block_hist(size_t words) {
     if (words <= cap_block_hist) return hipSuccess;

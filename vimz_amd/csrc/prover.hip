@@ -85,7 +85,7 @@ int vz_prover_create_layout(vimz_ctx* ctx, const vimz_circuit* circuit, const vi
     W.rp3 = (uint32_t)t3.rp; W.rp9 = (uint32_t)t9.rp;
   }
 #undef UP
-  auto dalloc = [&](uint32_t** dst, size_t bytes) { e = hipMalloc((void**)dst, bytes ? bytes : 32); if (e == hipSuccess) { p->owned.push_back(*dst); e = hipMemset(*dst, 0, bytes ? bytes : 32); } return e; };
+  auto dalloc = [&](uint32_t** dst, size_t bytes) { e = hipMalloc((void**)dst, bytes ? bytes : 32); if (e == hipSuccess) { p->owned.push_back(*dst); e = hipMemset(*dst, 0, bytes ? bytes : 32); } return e; };   // (null-stream fills: synchronised below)
   const size_t B = max_batch;
   if (dalloc(&p->priv_d, 32 * B * p->n_priv) != hipSuccess || dalloc(&p->zs_d, 32 * (B + 1) * p->len_z) != hipSuccess ||
       dalloc(&p->Z_d, 32 * B * (size_t)p->n_wires) != hipSuccess || dalloc(&p->job_out_d, 32 * B * (size_t)(p->n_jobs + p->n_fops)) != hipSuccess ||
@@ -111,6 +111,7 @@ int vz_prover_create_layout(vimz_ctx* ctx, const vimz_circuit* circuit, const vi
     if ((e = hipHostMalloc(&bb.pin, 4 * (size_t)XYZZ_WORDS * MSM_MAX_WINDOWS * B)) != hipSuccess) return fail_free("pinned", e);
     if ((e = hipHostMalloc((void**)&bb.status_host, 4 * B)) != hipSuccess) return fail_free("pinned", e);
   }
+  if ((e = hipStreamSynchronize(nullptr)) != hipSuccess) return fail_free("sync", e);   // the hipMemset fills above ran on the null stream
   p->z_cur.assign(p->len_z, Fe::zero()); p->z0 = p->z_cur;
   *out = p;
   return VIMZ_OK;
