@@ -27,6 +27,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# (GPU_MAX_HW_QUEUES is left at the runtime's default of 4: with 8 the nine streams of three concurrent proofs overlap more —
+#  up to 475 steps/s — but runs become bimodal, 380 or 470; measured in round 1.)
 
 HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MIXED_ADD_PEAK_GOPS = 12.65      # measured ceiling of the XYZZ mixed addition in the 9x29-bit form (profiles/r01_ubench_fp29.txt)

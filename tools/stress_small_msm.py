@@ -21,6 +21,7 @@ def dense(n):
     return a
 
 
+big_host = dense(313000)
 ctx = hip.Context(0)
 B = ctx.bases_generate(_lib.CURVE_BN254_G1, 1 << 19)
 small = [ctx.vec_from_host(_lib.FIELD_BN254_FR, dense(n)) for n in (7586, 7709, 1000, 16000)]
@@ -30,8 +31,6 @@ big_want = ctx.msm_vec(B, _bv)
 stop = False
 
 
-big_host = dense(313000)
-big_want = None
 big_res = []
 
 

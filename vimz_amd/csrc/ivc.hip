@@ -176,11 +176,8 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
       P_TRY(hipMemcpyAsync(Zi + 8 * sw, pin_aug1, 32 * aw1, hipMemcpyHostToDevice, s));
       launch_spmv(p, s, Zi, az, bz, cz, 2);
       P_TRY(hipEventRecord(v->ev_fork, s));
-      { static const int fs = getenv("VIMZ_DEBUG_FORK_SYNC") ? atoi(getenv("VIMZ_DEBUG_FORK_SYNC")) : 0; if (fs & 1) P_TRY(hipStreamSynchronize(s)); }
-      static const int fork_mask = getenv("VIMZ_DEBUG_FORK_MASK") ? atoi(getenv("VIMZ_DEBUG_FORK_MASK")) : 3;
-      hipStream_t sa = (fork_mask & 1) ? v->s2 : s;
-      P_TRY(hipStreamWaitEvent(sa, v->ev_fork, 0));
-      P_TRY(msm_launch<BnG1>(sa, v->ws2, p->ck->d + (size_t)AFFINE_WORDS * (sw - 1), Zi + 8 * sw, aw1 - 2, 1, 0, v->pin, &v->plan_aug, nullptr, 0, nullptr));
+      P_TRY(hipStreamWaitEvent(v->s2, v->ev_fork, 0));
+      P_TRY(msm_launch<BnG1>(v->s2, v->ws2, p->ck->d + (size_t)AFFINE_WORDS * (sw - 1), Zi + 8 * sw, aw1 - 2, 1, 0, v->pin, &v->plan_aug, nullptr, 0, nullptr));
       // ---- 3. NIFS on the primary curve ------------------------------------------------------------------------------------------------
       if (i > 0) {
         hipLaunchKernelGGL(k_cross_term<Fr>, dim3(stream_grid(nc)), dim3(256), 0, s, nc, p->AZ, p->BZ, p->CZ, v->u1_run, az, bz, cz, Fe::one(), p->T);
@@ -262,11 +259,8 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
         P_TRY(hipMemcpyAsync(S.z2, pin_w2, 32 * (size_t)S.n_w, hipMemcpyHostToDevice, s));
         sec_spmv<Fq>(S, s, S.z2, S.az2, S.bz2, S.cz2);
         P_TRY(hipEventRecord(v->ev_fork, s));
-        { static const int fs = getenv("VIMZ_DEBUG_FORK_SYNC") ? atoi(getenv("VIMZ_DEBUG_FORK_SYNC")) : 0; if (fs & 2) P_TRY(hipStreamSynchronize(s)); }
-        static const int fork_mask2 = getenv("VIMZ_DEBUG_FORK_MASK") ? atoi(getenv("VIMZ_DEBUG_FORK_MASK")) : 3;
-        hipStream_t sb2 = (fork_mask2 & 2) ? v->s2 : s;
-        P_TRY(hipStreamWaitEvent(sb2, v->ev_fork, 0));
-        P_TRY(msm_launch<Grumpkin>(sb2, v->ws2, v->ck2->d, S.z2 + 8, S.n_w - 3, 1, 0, v->pin + 2 * v->pin_res, &v->plan_W2, nullptr, 0, nullptr));
+        P_TRY(hipStreamWaitEvent(v->s2, v->ev_fork, 0));
+        P_TRY(msm_launch<Grumpkin>(v->s2, v->ws2, v->ck2->d, S.z2 + 8, S.n_w - 3, 1, 0, v->pin + 2 * v->pin_res, &v->plan_W2, nullptr, 0, nullptr));
         v->sec_T_valid = i > 0;    // U2 is still the zero instance after step 0: its cross term with anything is zero
         if (v->sec_T_valid) {
           hipLaunchKernelGGL(k_cross_term<Fq>, dim3(stream_grid(S.n_c)), dim3(256), 0, s, (size_t)S.n_c, S.AZ, S.BZ, S.CZ, v->u2_run, S.az2, S.bz2, S.cz2, Fq::one(), S.T);
