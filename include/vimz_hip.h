@@ -116,8 +116,8 @@ int vimz_msm_vec_ex(vimz_ctx* ctx, const vimz_bases* bases, size_t base_offset, 
  *      reads at vimz/src/nova_snark_backend/folding.rs:22 and the circom witness generator named by
  *      Config::witness_generator_file(), folding.rs:36).  Host-only: usable without a GPU. -------------------- */
 typedef struct vimz_circuit vimz_circuit;
-/* (crop is built as R1CS + witness program for external / CPU-computed witnesses only: no GPU witness kernels yet, so
- * vimz_prover_fold refuses it and vimz_prover_fold_witness is the way in.)
+/* (all nine step circuits, crop included, have GPU witness programs; circuits loaded from an .r1cs have none and are folded from
+ * supplied witnesses with vimz_prover_fold_witness / vimz_ivc_fold_witness.)
  * transformation ids follow the reference's enum order (vimz/src/transformation.rs:7-18) */
 #define VIMZ_T_BLUR 0
 #define VIMZ_T_BRIGHTNESS 1

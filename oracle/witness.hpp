@@ -199,8 +199,10 @@ static inline int execute(const Program& Pg, const u64* z_in_canon, const u64* p
     }
     return 0;
   };
-  for (int phase = 0; phase < 2; phase++) {
-    if (phase == 1 && run_fops(1)) return 2;
+  const int phase_order[3] = {0, 2, 1};   // row hashes; early field ops, then the chains that use them; the state hashes
+  for (int pi = 0; pi < 3; pi++) {
+    const int phase = phase_order[pi];
+    if (phase == 2 && run_fops(1)) return 2;
     for (size_t c = 0; c < Pg.n_chains; c++) {
       const Chain& C = Pg.chains[c];
       if ((int)C.phase != phase) continue;

@@ -322,8 +322,8 @@ def test_full_image_fold_ends_in_the_references_committed_state(ctx, ck, proof, 
 
 
 def test_crop_steps_fold_from_supplied_witnesses(oracle):
-    """BASELINE config #1 (crop_step HD, 672 k constraints): no GPU witness kernels yet, so the witnesses come from the
-    oracle's executor and go through the external-witness seam; SpMV, both MSMs, folds and verify run on the GPU."""
+    """BASELINE config #1 (crop_step HD, 672 k constraints) through the external-witness seam: the witnesses come from the
+    oracle's executor; SpMV, both MSMs, folds and verify run on the GPU."""
     from tests import _data
     from tests._oracle import T_CROP
     from vimz_amd import hip, image_editor as ie
@@ -341,8 +341,6 @@ def test_crop_steps_fold_from_supplied_witnesses(oracle):
     P = hip.Prover(cx, c, key, max_batch=2)
     try:
         P.reset(z0)
-        with pytest.raises(_lib.VimzError):
-            P.fold(np.stack(o[:1]))                     # refused: no GPU witness program for crop
         P.fold_witness(np.stack(wits))
         assert P.verify() == 0
         inst = P.instance()
@@ -354,6 +352,51 @@ def test_crop_steps_fold_from_supplied_witnesses(oracle):
         assert zz == z
     finally:
         P.close(); key.free(); cx.close()
+
+
+@pytest.mark.parametrize("y", [100, 0])
+def test_crop_witness_and_folds_on_the_gpu(oracle, y):
+    """crop_step on the GPU end to end: its witness needs an ahead-of-time pass (the hash of the cropped row enters the IVC
+    state, and depends on step_in only through the predictable `info` counter).  With y = 100 the rows are outside the crop
+    window (selector 0); with y = 0 they are inside it (selector 1: the cropped-row hash is absorbed).  (The literal circuit
+    increments `info` by one per step, i.e. its x field — SURVEY F6 — so row_index stays 0.)"""
+    from tests import _data
+    from tests._oracle import T_CROP
+    from vimz_amd import hip, image_editor as ie
+    c = Circuit.for_resolution("crop", "HD")
+    fx = _data.rows10("crop")
+    o = ie.hex_to_rows(fx["original"])
+    info = (int(fx["info"]) & 0xFFF) | (y << 12)          # x from the fixture, y as given, row_index 0
+    z0 = [0, 0, info]
+    cx = hip.Context(0)
+    key = cx.bases_generate(_lib.CURVE_BN254_G1, 1 << 20)
+    ck2 = cx.bases_generate(_lib.CURVE_GRUMPKIN, 1 << 13, b"ck-secondary")
+    P = hip.Prover(cx, c, key, max_batch=3)
+    ivc = hip.IVC(cx, c, key, ck2, max_batch=3)
+    try:
+        P.reset(z0)
+        zw, zs, st = P.witness(np.stack(o[:3]))
+        assert not st.any()
+        z = list(z0)
+        for i in range(3):
+            status, want, z_out = witness_execute(oracle, c, z, o[i])
+            assert status == 0 and from_limbs(zs[i]) == z and from_limbs(zs[i + 1]) == z_out
+            diff = np.nonzero((zw[i] != want).any(axis=1))[0]
+            assert diff.size == 0, f"crop row {i}: {diff.size} wires differ, first {diff[:5]}"
+            z = z_out
+        zz = list(z0)
+        for i in range(5):
+            ok, zz = oracle.step_eval(T_CROP, zz, o[i], width=128, width2=64, crop_h=480)
+            assert ok
+        assert (zz[1] != 0) == (y == 0)                    # the cropped rows were (not) absorbed
+        P.reset(z0); P.fold(np.stack(o[:5]))               # two batches: 3 + 2
+        assert P.verify() == 0
+        inst = P.instance()
+        assert inst["steps"] == 5 and from_limbs(inst["z"]) == zz
+        ivc.reset(z0); ivc.fold(np.stack(o[:5]))
+        assert ivc.verify() == 0 and ivc.state() == (zz, 5)
+    finally:
+        ivc.close(); P.close(); key.free(); ck2.free(); cx.close()
 
 
 def test_fold_in_several_calls_equals_one_call(ctx, ck, circuits):

@@ -102,7 +102,7 @@ struct BuilderT {
   std::vector<Chain> chains;
   std::vector<FieldOp> fops;
   std::vector<LcTerm> lc_terms;
-  bool gpu_witness = true;   // false: no GPU witness kernels for this circuit yet (witnesses must be supplied, vimz_prover_fold_witness)
+  bool gpu_witness = true;   // false: a circuit whose witness program the GPU kernels cannot run (none at present)
   std::vector<ZOut> zout;
 
   uint32_t alloc(uint32_t n) { uint32_t b = n_wires; n_wires += n; return b; }

@@ -9,7 +9,7 @@
 //   resize      circuits/src/resize_step.circom:10-112
 //   redact      circuits/src/redact_step.circom:7-26
 // State updates: circuits/src/utils/state.circom:11-79.  IVC state layouts: vimz/src/transformation.rs:25-50.
-//   crop        circuits/src/crop_step.circom:9-120 (R1CS + witness program for the CPU executor; no GPU witness kernels yet)
+//   crop        circuits/src/crop_step.circom:9-120 (literal; its cropped-row hash chain is phase 2: see the T_CROP case)
 #pragma once
 #include "gadgets.hpp"
 
@@ -225,8 +225,9 @@ inline std::unique_ptr<CircuitBuild> build_step_circuit(int t, const StepShape& 
     case T_CROP: {
       // CropHash(widthOrig = w, widthCrop = S.width2, heightCrop = S.crop_height), followed literally
       // (circuits/src/crop_step.circom:9-83, MultiplexerCrop :85-120; SURVEY.md F6: x = info bits 0-11, y = 12-23,
-      // row_index = 24-35, and `step_out.info <== step_in.info + 1`).  No GPU witness kernels yet (b.gpu_witness = false).
-      b.gpu_witness = false;
+      // row_index = 24-35, and `step_out.info <== step_in.info + 1`).  The cropped row's hash depends on step_in only through
+      // `info`, which is predictable (info_0 + i): its chain is phase 2 (after the early field ops, before the state hashes), so
+      // the prover can compute it for all rows ahead of the IVC state chain (prover_internal.hpp, fold_prepare).
       const int wc = S.width2, H = S.crop_height, W10 = 10 * w, C10 = 10 * wc;
       auto d0 = g.decompress_row(P, w);
       // --- CropInfoDecompressor + the row-range test: one lane
@@ -284,13 +285,17 @@ inline std::unique_ptr<CircuitBuild> build_step_circuit(int t, const StepShape& 
         b.fops.push_back(f);
         cropped.push_back(FV{lc, ValRef{REF_FOP, (uint32_t)b.fops.size() - 1}});
       }
-      g.begin_chain(1);
+      g.begin_chain(2);
       FV th = g.array_hash(cropped);
       g.begin_chain(1);
       FV c1 = g.pair_hash(c.zin(1), th);
       FV c0 = c.zin(1);
       b.enforce(c1.lc - c0.lc, s_lc, LC::wire(c.out_wire(1)) - c0.lc);      // Mux1, out is step_out.base.tran_hash
-      { FieldOp f; memset(&f, 0, sizeof(f)); f.op = FOP_MUX; f.wire = c.out_wire(1); f.bound = 1; f.a = ValRef{REF_WIRE, s_wire}; f.b = c0.ref; f.c = c1.ref;
+      // the selector as an (early) field-op value, so that the host's state chain can read it from the ahead-of-time pass
+      ValRef s_ref;
+      { FieldOp f; memset(&f, 0, sizeof(f)); f.op = FOP_LC; f.early = 1; f.a = ValRef{0, (uint32_t)b.lc_terms.size()}; f.b = ValRef{0, 1};
+        b.lc_terms.push_back(LcTerm{s_wire, b.coef_id(Fe::one())}); b.fops.push_back(f); s_ref = ValRef{REF_FOP, (uint32_t)b.fops.size() - 1}; }
+      { FieldOp f; memset(&f, 0, sizeof(f)); f.op = FOP_MUX; f.wire = c.out_wire(1); f.bound = 1; f.a = s_ref; f.b = c0.ref; f.c = c1.ref;
         b.fops.push_back(f); b.zout[1] = ZOut{ValRef{REF_FOP, (uint32_t)b.fops.size() - 1}, 0}; }
       c.head_tail_to_output(c.zin(0), P, w, 0);
       b.enforce(LC::constant(Fe::one()), LC::wire(c.in0 + 2) + LC::constant(Fe::one()), LC::wire(c.out_wire(2)));   // info + 1 (linear)

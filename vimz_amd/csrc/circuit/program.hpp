@@ -72,7 +72,8 @@ struct HashJob {
   uint32_t chain;                    // chain id
   ValRef in[POSEIDON_MAX_T - 1];
 };
-struct Chain { uint32_t job_off, job_cnt, phase, pad; };  // phase 0 = A (row data only), 1 = B (needs step_in)
+struct Chain { uint32_t job_off, job_cnt, phase, pad; };  // phase 0 = A (row data only), 1 = B (needs the hashed state in step_in),
+                                                          // 2 = after the early field ops, before B (may use only the predictable part of step_in)
 
 enum : uint32_t { FOP_ISZERO = 1, FOP_MUX = 2, FOP_LC = 3 };
 struct LcTerm { uint32_t wire; uint32_t coef; };   // coef = index into the R1CS coefficient dictionary

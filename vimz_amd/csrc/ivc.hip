@@ -399,7 +399,7 @@ int vimz_ivc_fold(vimz_ivc* v, const uint64_t* step_inputs, size_t nsteps) {
   if (!v || (!step_inputs && nsteps)) return VIMZ_ERR_INVALID;
   const cb::Builder& b = v->circ1->build->b;
   if (b.zout.empty() && nsteps) return vz_fail(v->ctx, VIMZ_ERR_INVALID, "this circuit was loaded from an .r1cs and has no witness program: use vimz_ivc_fold_witness");
-  if (!b.gpu_witness && nsteps) return vz_fail(v->ctx, VIMZ_ERR_INVALID, "no GPU witness kernels for this step circuit (crop) yet: supply witnesses with vimz_ivc_fold_witness");
+  if (!b.gpu_witness && nsteps) return vz_fail(v->ctx, VIMZ_ERR_INVALID, "no GPU witness kernels for this step circuit: supply witnesses with vimz_ivc_fold_witness");
   try { return ivc_fold_core(v, step_inputs, nullptr, nsteps); } catch (const std::exception& e) { return vz_fail(v->ctx, VIMZ_ERR_INVALID, e.what()); }
 }
 int vimz_ivc_fold_witness(vimz_ivc* v, const uint64_t* witnesses, size_t nsteps) {

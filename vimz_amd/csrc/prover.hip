@@ -74,7 +74,8 @@ int vz_prover_create_layout(vimz_ctx* ctx, const vimz_circuit* circuit, const vi
   }
   WitnessDev& W = p->wd;
   UP(b.decomp, W.decomp); UP(b.lane_groups, W.groups); UP(b.lane_instr, W.instr); UP(b.lane_rows, W.rows);
-  UP(b.jobs, W.jobs); UP(b.chains, W.chains); UP(b.fops, W.fops);
+  UP(b.jobs, W.jobs); UP(b.chains, W.chains); UP(b.fops, W.fops); UP(b.lc_terms, W.lc_terms);
+  W.dict = p->dict;
   W.n_decomp = (uint32_t)b.decomp.size(); W.n_groups = (uint32_t)b.lane_groups.size(); W.n_jobs = p->n_jobs;
   W.n_chains = (uint32_t)b.chains.size(); W.n_fops = p->n_fops; W.n_wires = b.n_wires; W.len_z = b.len_z; W.n_priv = b.n_priv;
   {
@@ -144,74 +145,23 @@ int vimz_prover_reset(vimz_prover* p, const uint64_t* z0) {
   return VIMZ_OK;
 }
 
-// Witness generation for `rows` steps starting from the prover's current IVC state.  Leaves Z_d filled and advances
-// nothing.  zs_host receives the IVC states z_k..z_{k+rows} (canonical, (rows+1) x len_z).  Caller holds the lock.
+// Witness generation for `rows` steps starting from the prover's current IVC state: the stage 0 of a fold (row hashes, the
+// ahead-of-time pass where the circuit needs one, the host's state chain) and the witness kernels of one batch, on the main
+// stream.  Leaves Z_d filled and advances nothing.  Caller holds the lock.
 static int witness_batch_locked(vimz_prover* p, const uint64_t* inputs, size_t rows, std::vector<Fe>& zs) {
   vimz_ctx* ctx = p->ctx;
-  const cb::Builder& b = p->circuit->build->b;
   hipStream_t s = ctx->stream;
-  const WitnessDev& W = p->wd;
+  FoldJob job; job.step_inputs = inputs; job.nsteps = rows;
+  int rc = fold_prepare(p, job);
+  if (rc) return rc;
+  zs = job.zs;
   double t0 = now_s();
-  P_TRY(hipMemcpyAsync(p->priv_d, inputs, 32 * rows * p->n_priv, hipMemcpyHostToDevice, s));
   P_TRY(hipMemsetAsync(p->status_d, 0, 4 * rows, s));
-  const dim3 rows_y(1, (unsigned)rows);
-  for (uint32_t g = 0; g < W.n_decomp; g++) {
-    const uint32_t total = (b.decomp[g].nbits - 1) * b.decomp[g].count;
-    hipLaunchKernelGGL(k_wit_decomp, dim3((total + 255) / 256, (unsigned)rows), dim3(256), 0, s, W, g, p->priv_d, p->Z_d, p->status_d);
-  }
-  // phase-A chains need only the private inputs: run them first so the host can start the state chain
-  uint32_t nA = 0, nB = 0;
-  for (auto& c : b.chains) (c.phase == 0 ? nA : nB)++;
-  // (inputs are read from Z by the chain kernels, so private inputs must be in Z first; z parts are filled later)
-  std::vector<Fe> zs_tmp((rows + 1) * p->len_z, Fe::zero());
-  P_TRY(hipMemsetAsync(p->zs_d, 0, 32 * (rows + 1) * p->len_z, s));
-  hipLaunchKernelGGL(k_wit_inputs, dim3(((1 + 2 * p->len_z + p->n_priv) + 255) / 256, (unsigned)rows), dim3(256), 0, s, W, p->priv_d, p->zs_d, p->Z_d, 0u);
-  if (nA) hipLaunchKernelGGL(k_wit_chains, dim3((nA + 3) / 4, (unsigned)rows), dim3(64), 0, s, W, 0u, p->Z_d, p->job_out_d, (const uint32_t*)nullptr);
-  P_TRY(hipGetLastError());
-  // host: IVC state chain z_k -> z_{k+rows} from the phase-A hash outputs
-  const size_t jstride = p->n_jobs + p->n_fops;
-  std::vector<Fe> jobA(rows * jstride);
-  P_TRY(hipMemcpyAsync(jobA.data(), p->job_out_d, 32 * rows * jstride, hipMemcpyDeviceToHost, s));
-  P_TRY(hipStreamSynchronize(s));
-  p->phase_s[PH_WITNESS] += now_s() - t0; t0 = now_s();
-  zs.assign((rows + 1) * p->len_z, Fe::zero());
-  for (uint32_t i = 0; i < p->len_z; i++) zs[i] = p->z_cur[i];
-  HostEval ev; ev.P = p; ev.b = &b;
-  for (size_t r = 0; r < rows; r++) {
-    ev.priv = inputs + 4 * r * p->n_priv; ev.job_a = jobA.data() + r * jstride; ev.zin = zs.data() + r * p->len_z;
-    ev.job_b.assign(p->n_jobs, Fe::zero()); ev.fop.assign(p->n_fops, Fe::zero());
-    for (auto& c : b.chains) {
-      if (c.phase != 1) continue;
-      for (uint32_t k = 0; k < c.job_cnt; k++) {
-        const HashJob& J = b.jobs[c.job_off + k];
-        Fe in[POSEIDON_MAX_T];
-        for (uint32_t i = 0; i + 1 < J.t; i++) in[i] = ev.value(J.in[i]);
-        ev.job_b[c.job_off + k] = cb::poseidon_hash(in, (int)J.t - 1);
-      }
-    }
-    for (uint32_t f = 0; f < p->n_fops; f++) {
-      const FieldOp& F = b.fops[f];
-      if (F.op == FOP_ISZERO) { Fe in = ev.value(F.a); ev.fop[f] = in.is_zero() ? Fe::one() : Fe::zero(); }
-      else { Fe sv = ev.value(F.a), c0 = ev.value(F.b), c1 = ev.value(F.c); ev.fop[f] = Fe::add(Fe::mul(Fe::sub(c1, c0), sv), c0); }
-    }
-    Fe* zn = zs.data() + (r + 1) * p->len_z;
-    for (uint32_t i = 0; i < p->len_z; i++) zn[i] = Fe::add(ev.value(b.zout[i].ref), cb::fe_from_i64(b.zout[i].add));
-  }
-  std::vector<Fe> zs_canon(zs.size());
-  for (size_t i = 0; i < zs.size(); i++) zs_canon[i] = Fe::from_mont(zs[i]);
-  p->phase_s[PH_ZCHAIN] += now_s() - t0; t0 = now_s();
-  P_TRY(hipMemcpyAsync(p->zs_d, zs_canon.data(), 32 * zs_canon.size(), hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(k_wit_inputs, dim3(((1 + 2 * p->len_z) + 255) / 256, (unsigned)rows), dim3(256), 0, s, W, p->priv_d, p->zs_d, p->Z_d, 0u);
-  for (uint32_t g = 0; g < W.n_groups; g++)
-    hipLaunchKernelGGL(k_wit_lanes, dim3((b.lane_groups[g].lanes + LANE_TB - 1) / LANE_TB, (unsigned)rows), dim3(LANE_TB), 0, s, W, g, p->priv_d, p->zs_d, 0u, p->Z_d, p->status_d);
-  if (nB) hipLaunchKernelGGL(k_wit_chains, dim3((nB + 3) / 4, (unsigned)rows), dim3(64), 0, s, W, 1u, p->Z_d, p->job_out_d, (const uint32_t*)nullptr);
-  if (p->n_fops) hipLaunchKernelGGL(k_wit_fops, dim3(((unsigned)rows + 63) / 64), dim3(64), 0, s, W, p->Z_d, p->job_out_d, (uint32_t)rows);
-  P_TRY(hipGetLastError());
+  if ((rc = launch_witness(p, s, p->Z_d, p->job_out_d, p->status_d, p->priv_all_d, 0, rows, job, false))) return rc;
   p->last_status.assign(rows, 0);
   P_TRY(hipMemcpyAsync(p->last_status.data(), p->status_d, 4 * rows, hipMemcpyDeviceToHost, s));
   P_TRY(hipStreamSynchronize(s));
-  p->phase_s[PH_WITNESS] += now_s() - t0; p->phase_n[PH_WITNESS] += rows; p->phase_n[PH_ZCHAIN] += rows;
-  (void)rows_y;
+  p->phase_s[PH_WITNESS] += now_s() - t0;
   return VIMZ_OK;
 }
 
@@ -282,7 +232,7 @@ static int fold_core(vimz_prover* p, const uint64_t* step_inputs, const uint64_t
 int vimz_prover_fold(vimz_prover* p, const uint64_t* step_inputs, size_t nsteps) {
   if (!p || (!step_inputs && nsteps)) return VIMZ_ERR_INVALID;
   if (p->circuit->build->b.zout.empty() && nsteps) return vz_fail(p->ctx, VIMZ_ERR_INVALID, "this circuit was loaded from an .r1cs and has no witness program: use vimz_prover_fold_witness");
-  if (!p->circuit->build->b.gpu_witness && nsteps) return vz_fail(p->ctx, VIMZ_ERR_INVALID, "no GPU witness kernels for this step circuit (crop) yet: supply witnesses with vimz_prover_fold_witness");
+  if (!p->circuit->build->b.gpu_witness && nsteps) return vz_fail(p->ctx, VIMZ_ERR_INVALID, "no GPU witness kernels for this step circuit: supply witnesses with vimz_prover_fold_witness");
   return fold_core(p, step_inputs, nullptr, nsteps);
 }
 int vimz_prover_fold_witness(vimz_prover* p, const uint64_t* witnesses, size_t nsteps) {

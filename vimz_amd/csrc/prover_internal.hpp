@@ -119,8 +119,8 @@ struct HostEval {
         if (r.idx > b->len_z && r.idx <= 2 * b->len_z) return zin[r.idx - 1 - b->len_z];        // a step_in wire
         if (r.idx >= 1 + 2 * b->len_z && r.idx < 1 + 2 * b->len_z + b->n_priv) return fe_from_canon(priv + 4 * (size_t)(r.idx - (1 + 2 * b->len_z)));
         return Fe::zero();  // the builder never references other wires from phase-B inputs
-      case REF_JOB: return b->chains[b->jobs[r.idx].chain].phase == 0 ? job_a[r.idx] : job_b[r.idx];
-      case REF_FOP: return fop[r.idx];
+      case REF_JOB: return b->chains[b->jobs[r.idx].chain].phase != 1 ? job_a[r.idx] : job_b[r.idx];   // phases 0 and 2: computed on the GPU ahead of the chain
+      case REF_FOP: return b->fops[r.idx].op == FOP_LC ? job_a[b->jobs.size() + r.idx] : fop[r.idx];
       case REF_ZIN: return zin[r.idx];
       default: return Fe::zero();
     }
@@ -170,7 +170,7 @@ static void host_state_chain(const vimz_prover* p, const uint64_t* inputs, size_
     for (uint32_t f = 0; f < p->n_fops; f++) {
       const FieldOp& F = b.fops[f];
       if (F.op == FOP_ISZERO) { Fe in = ev.value(F.a); ev.fop[f] = in.is_zero() ? Fe::one() : Fe::zero(); }
-      else { Fe sv = ev.value(F.a), c0 = ev.value(F.b), c1 = ev.value(F.c); ev.fop[f] = Fe::add(Fe::mul(Fe::sub(c1, c0), sv), c0); }
+      else if (F.op == FOP_MUX) { Fe sv = ev.value(F.a), c0 = ev.value(F.b), c1 = ev.value(F.c); ev.fop[f] = Fe::add(Fe::mul(Fe::sub(c1, c0), sv), c0); }
     }
     Fe* zn = zs.data() + (r + 1) * p->len_z;
     for (uint32_t i = 0; i < p->len_z; i++) zn[i] = Fe::add(ev.value(b.zout[i].ref), cb::fe_from_i64(b.zout[i].add));
@@ -194,10 +194,42 @@ struct FoldJob {
   size_t nsteps = 0;
   std::vector<Fe> zs;                      // (nsteps + 1) x len_z IVC states, Montgomery
   size_t nbatches = 0, Bk = 0;
-  uint32_t nA = 0, nB = 0;                 // Poseidon chains of phase A (row data only) / B (need step_in)
+  uint32_t nA = 0, nB = 0, nE = 0;         // Poseidon chains of phase A (row data only) / B (need the hashed state) / 2 (after the early field ops)
+  bool early_fops = false;
   BaseTables tbl{};
   static constexpr size_t pin_stride = 4 * (size_t)XYZZ_WORDS * MSM_MAX_WINDOWS;
 };
+
+// Witness kernels of `rows` rows starting at global row `first` (program order: decompositions, inputs, lane programs, row
+// hashes, early field ops, the chains that use them, state hashes, late field ops).  ahead = true stops before the state
+// hashes: the ahead-of-time pass of circuits whose IVC state needs values computed from the witness (crop: the hash of the
+// cropped row), run with only the predictable part of step_in filled in.
+static int launch_witness(vimz_prover* p, hipStream_t st, uint32_t* Z, uint32_t* job_out, uint32_t* status, const uint32_t* priv, size_t first, size_t rows,
+                          const FoldJob& J, bool ahead) {
+  vimz_ctx* ctx = p->ctx;
+  const cb::Builder& b = p->circuit->build->b;
+  const WitnessDev& W = p->wd;
+  const unsigned R = (unsigned)rows;
+  for (uint32_t gI = 0; gI < W.n_decomp; gI++) {
+    const uint32_t total = (b.decomp[gI].nbits - 1) * b.decomp[gI].count;
+    hipLaunchKernelGGL(k_wit_decomp, dim3((total + 255) / 256, R), dim3(256), 0, st, W, gI, priv, Z, status);
+  }
+  hipLaunchKernelGGL(k_wit_inputs, dim3(((1 + 2 * p->len_z + p->n_priv) + 255) / 256, R), dim3(256), 0, st, W, priv, (const uint32_t*)p->zs_all_d, Z, (uint32_t)first);
+  for (uint32_t gI = 0; gI < W.n_groups; gI++)
+    hipLaunchKernelGGL(k_wit_lanes, dim3((b.lane_groups[gI].lanes + LANE_TB - 1) / LANE_TB, R), dim3(LANE_TB), 0, st, W, gI, priv, (const uint32_t*)p->zs_all_d, (uint32_t)first, Z, status);
+  if (J.nA && !ahead) hipLaunchKernelGGL(k_wit_chains, dim3((J.nA + 3) / 4, R), dim3(64), 0, st, W, 0u, Z, job_out, (const uint32_t*)nullptr);
+  if (J.early_fops) {
+    hipLaunchKernelGGL(k_wit_fops_lc, dim3(p->n_fops, R), dim3(64), 0, st, W, (const uint32_t*)Z, job_out, 1u);
+    hipLaunchKernelGGL(k_wit_fops, dim3((R + 63) / 64), dim3(64), 0, st, W, Z, job_out, (uint32_t)rows, 1u);
+  }
+  if (J.nE) hipLaunchKernelGGL(k_wit_chains, dim3((J.nE + 3) / 4, R), dim3(64), 0, st, W, 2u, Z, job_out, (const uint32_t*)nullptr);
+  if (!ahead) {
+    if (J.nB) hipLaunchKernelGGL(k_wit_chains, dim3((J.nB + 3) / 4, R), dim3(64), 0, st, W, 1u, Z, job_out, (const uint32_t*)nullptr);
+    if (p->n_fops) hipLaunchKernelGGL(k_wit_fops, dim3((R + 63) / 64), dim3(64), 0, st, W, Z, job_out, (uint32_t)rows, 0u);
+  }
+  P_TRY(hipGetLastError());
+  return VIMZ_OK;
+}
 
 // Stage 0 (caller holds the lock, device set): every private input to HBM; ONE hash-only pass of the phase-A Poseidon chains
 // over ALL rows (they depend on the row data only); the host then runs the whole IVC state chain z_0..z_n and uploads it.
@@ -207,7 +239,8 @@ static int fold_prepare(vimz_prover* p, FoldJob& J) {
   const cb::Builder& b = p->circuit->build->b;
   const WitnessDev& W = p->wd;
   const size_t nsteps = J.nsteps, jstride = p->n_jobs + p->n_fops, B = p->max_batch, sw = p->step_wires;
-  for (auto& c : b.chains) (c.phase == 0 ? J.nA : J.nB)++;
+  for (auto& c : b.chains) (c.phase == 0 ? J.nA : c.phase == 1 ? J.nB : J.nE)++;
+  for (auto& f : b.fops) if (f.early) J.early_fops = true;
   J.zs.assign((nsteps + 1) * p->len_z, Fe::zero());
   std::vector<Fe>& zs = J.zs;
   for (uint32_t i = 0; i < p->len_z; i++) zs[i] = p->z_cur[i];
@@ -236,6 +269,26 @@ static int fold_prepare(vimz_prover* p, FoldJob& J) {
                          (const uint32_t*)(p->priv_all_d + 8 * off * p->n_priv));
     }
     P_TRY(hipGetLastError());
+    if (J.nE || J.early_fops) {
+      // Ahead-of-time pass: the IVC state of these circuits absorbs values computed from the witness (crop: the hash of the cropped
+      // row), which depend on step_in only through its predictable part (state elements that are step_in[j] + constant, e.g. the
+      // row counter).  Fill that part in, run the witness kernels up to the phase-2 chains batch by batch, keep the job outputs.
+      std::vector<Fe> zp((nsteps + 1) * p->len_z, Fe::zero());
+      for (uint32_t i = 0; i < p->len_z; i++) zp[i] = zs[i];
+      for (size_t r = 0; r < nsteps; r++)
+        for (uint32_t i = 0; i < p->len_z; i++)
+          if (b.zout[i].ref.kind == REF_ZIN) zp[(r + 1) * p->len_z + i] = Fe::add(zp[r * p->len_z + b.zout[i].ref.idx], cb::fe_from_i64(b.zout[i].add));
+      std::vector<Fe> zc(zp.size());
+      for (size_t i = 0; i < zp.size(); i++) zc[i] = Fe::from_mont(zp[i]);
+      P_TRY(hipMemcpyAsync(p->zs_all_d, zc.data(), 32 * zc.size(), hipMemcpyHostToDevice, s));
+      P_TRY(hipStreamSynchronize(s));
+      int rc;
+      for (size_t first = 0; first < nsteps; first += B) {
+        const size_t rows = std::min(B, nsteps - first);
+        P_TRY(hipMemsetAsync(p->buf[0].status, 0, 4 * rows, s));
+        if ((rc = launch_witness(p, s, p->buf[0].Z, p->job_all_d + 8 * first * jstride, p->buf[0].status, p->priv_all_d + 8 * first * p->n_priv, first, rows, J, true))) return rc;
+      }
+    }
     std::vector<Fe> jobA(nsteps * jstride);
     P_TRY(hipMemcpyAsync(jobA.data(), p->job_all_d, 32 * nsteps * jstride, hipMemcpyDeviceToHost, s));
     P_TRY(hipStreamSynchronize(s));
@@ -270,17 +323,8 @@ static int fold_issue(vimz_prover* p, const FoldJob& J, size_t k) {
     P_TRY(hipMemcpy2DAsync(bb.Z, 32 * nw, J.witnesses + 4 * first * sw, 32 * sw, 32 * sw, rows, hipMemcpyHostToDevice, sb));
     launch_to_mont<Fr>(sb, bb.Z, rows * nw);
   } else {
-    const uint32_t* priv = p->priv_all_d + 8 * first * p->n_priv;
-    for (uint32_t gI = 0; gI < W.n_decomp; gI++) {
-      const uint32_t total = (b.decomp[gI].nbits - 1) * b.decomp[gI].count;
-      hipLaunchKernelGGL(k_wit_decomp, dim3((total + 255) / 256, (unsigned)rows), dim3(256), 0, sb, W, gI, priv, bb.Z, bb.status);
-    }
-    hipLaunchKernelGGL(k_wit_inputs, dim3(((1 + 2 * p->len_z + p->n_priv) + 255) / 256, (unsigned)rows), dim3(256), 0, sb, W, priv, (const uint32_t*)p->zs_all_d, bb.Z, (uint32_t)first);
-    for (uint32_t gI = 0; gI < W.n_groups; gI++)
-      hipLaunchKernelGGL(k_wit_lanes, dim3((b.lane_groups[gI].lanes + LANE_TB - 1) / LANE_TB, (unsigned)rows), dim3(LANE_TB), 0, sb, W, gI, priv, (const uint32_t*)p->zs_all_d, (uint32_t)first, bb.Z, bb.status);
-    if (J.nA) hipLaunchKernelGGL(k_wit_chains, dim3((J.nA + 3) / 4, (unsigned)rows), dim3(64), 0, sb, W, 0u, bb.Z, bb.job_out, (const uint32_t*)nullptr);
-    if (J.nB) hipLaunchKernelGGL(k_wit_chains, dim3((J.nB + 3) / 4, (unsigned)rows), dim3(64), 0, sb, W, 1u, bb.Z, bb.job_out, (const uint32_t*)nullptr);
-    if (p->n_fops) hipLaunchKernelGGL(k_wit_fops, dim3(((unsigned)rows + 63) / 64), dim3(64), 0, sb, W, bb.Z, bb.job_out, (uint32_t)rows);
+    int rc = launch_witness(p, sb, bb.Z, bb.job_out, bb.status, p->priv_all_d + 8 * first * p->n_priv, first, rows, J, false);
+    if (rc) return rc;
   }
   P_TRY(hipGetLastError());
   P_TRY(hipMemcpyAsync(bb.status_host, bb.status, 4 * rows, hipMemcpyDeviceToHost, sb));

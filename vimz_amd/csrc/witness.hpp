@@ -30,6 +30,7 @@ struct WitnessDev {  // device copies of the program tables
   const HashJob* jobs; uint32_t n_jobs;
   const Chain* chains; uint32_t n_chains;
   const FieldOp* fops; uint32_t n_fops;
+  const LcTerm* lc_terms; const uint32_t* dict;   // FOP_LC: value = sum dict[coef] * Z[wire]   (dictionary in Montgomery form)
   const uint32_t* pc3; const uint32_t* pm3;   // Poseidon constants t=3 (Montgomery): C then M
   const uint32_t* pc9; const uint32_t* pm9;   // t=9
   uint32_t rp3, rp9;
@@ -147,6 +148,22 @@ static __global__ void __launch_bounds__(LANE_TB) k_wit_lanes(WitnessDev P, uint
       case LOP_EMIT:
         store_fe(Z, zrow + G.wire_base + (size_t)I.imm * G.lanes + lane, fr_from_small(regs[I.a][tid]));
         break;
+      case LOP_LANE: regs[I.d][tid] = (long long)x + I.imm; break;
+      case LOP_ANDI: regs[I.d][tid] = regs[I.a][tid] & (long long)I.imm; break;
+      case LOP_SHRI: regs[I.d][tid] = regs[I.a][tid] >> I.imm; break;
+      case LOP_EQ: regs[I.d][tid] = regs[I.a][tid] == regs[I.b][tid] ? 1 : 0; break;
+      case LOP_LDBR: {   // byte (colour 0) of row a at pixel x*imm2 + imm + r[b]; zero outside the row
+        const LaneRow R = P.rows[G.row_off + I.a];
+        const long long px = (long long)x * I.imm2 + I.imm + regs[I.b][tid];
+        long long v = 0;
+        if (px >= 0 && px < (long long)R.count * 10) {
+          const uint32_t* e = prow + 8 * (size_t)(R.src_wire - priv0 + (uint32_t)(px / 10));
+          const int byte = (int)(px % 10) * 3;
+          v = (e[byte >> 2] >> (8 * (byte & 3))) & 0xff;
+        }
+        regs[I.d][tid] = v;
+        break;
+      }
       default: st |= WIT_BAD_INPUT; break;
     }
   }
@@ -275,13 +292,15 @@ static __global__ void __launch_bounds__(64) k_wit_chains(WitnessDev P, uint32_t
   }
 }
 
-static __global__ void __launch_bounds__(64) k_wit_fops(WitnessDev P, uint32_t* __restrict__ Z, uint32_t* __restrict__ job_out, uint32_t rows) {
+// Field ops of one stage (early = before the phase-2 chains, 0 = after every chain), FOP_LC excepted (k_wit_fops_lc).
+static __global__ void __launch_bounds__(64) k_wit_fops(WitnessDev P, uint32_t* __restrict__ Z, uint32_t* __restrict__ job_out, uint32_t rows, uint32_t early) {
   const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= rows) return;
   uint32_t* Zrow = Z + 8 * (size_t)row * P.n_wires;
   uint32_t* jrow = job_out + 8 * (size_t)row * (P.n_jobs + P.n_fops);
   for (uint32_t f = 0; f < P.n_fops; f++) {
     const FieldOp F = P.fops[f];
+    if (F.early != early) continue;
     if (F.op == FOP_ISZERO) {
       const Fr in = wit_value(P, F.a, Zrow, jrow);
       const Fr inv = Fr::pow_pm2(in);                 // 0 -> 0
@@ -295,6 +314,30 @@ static __global__ void __launch_bounds__(64) k_wit_fops(WitnessDev P, uint32_t* 
       store_fe(jrow, P.n_jobs + f, out);
     }
   }
+}
+
+// FOP_LC: the value of a stored linear combination of wires (crop: a packed element of the cropped row = 12.8 k terms, all
+// but ten of them zero).  One wave per (field op, row): lanes stride over the terms, zero wires skip the multiply, shuffle tree.
+static __global__ void __launch_bounds__(64) k_wit_fops_lc(WitnessDev P, const uint32_t* __restrict__ Z, uint32_t* __restrict__ job_out, uint32_t early) {
+  const uint32_t f = blockIdx.x, row = blockIdx.y, lane = threadIdx.x;
+  const FieldOp F = P.fops[f];
+  if (F.op != FOP_LC || F.early != early) return;
+  const size_t zrow = (size_t)row * P.n_wires;
+  Fr acc = Fr::zero();
+  for (uint32_t k = lane; k < F.b.idx; k += 64) {
+    const LcTerm T = P.lc_terms[F.a.idx + k];
+    const Fr v = load_fe<Fr>(Z, zrow + T.wire);
+    if (v.is_zero()) continue;
+    acc = Fr::add(acc, Fr::mul(load_fe<Fr>(P.dict, T.coef), v));
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    Fr o;
+#pragma unroll
+    for (int w = 0; w < 8; w++) o.v[w] = __shfl_xor(acc.v[w], off);
+    acc = Fr::add(acc, o);
+  }
+  if (lane == 0) store_fe(job_out, (size_t)row * (P.n_jobs + P.n_fops) + P.n_jobs + f, acc);
 }
 
 }  // namespace vz
