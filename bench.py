@@ -44,6 +44,8 @@ def build_inputs(transformation, resolution):
     kw = {"factor": 1.4} if transformation in ("contrast", "brightness") else {}
     if transformation == "resize":
         kw["resize_to"] = {"HD": (640, 480), "4K": (1920, 1080), "8K": (3840, 2160)}[resolution]
+    if transformation == "crop":
+        kw.update(x=200, y=100, crop_size="SD")      # the reference's Makefile target (Makefile:23)
     inp = ie.build_input(transformation, img, **kw)
     steps, z0 = folding.prepare_input(transformation, inp, resolution)
     return steps, z0

@@ -378,29 +378,16 @@ int vimz_prover_state_chain(vimz_prover* p, const uint64_t* z_start, const uint6
   vimz_ctx* ctx = p->ctx;
   std::lock_guard<std::mutex> g(ctx->mu);
   P_TRY(hipSetDevice(ctx->device));
-  hipStream_t s = ctx->stream;
-  const cb::Builder& b = p->circuit->build->b;
-  const size_t jstride = p->n_jobs + p->n_fops;
-  uint32_t nA = 0; for (auto& c : b.chains) if (c.phase == 0) nA++;
-  std::vector<Fe> zs((nsteps + 1) * p->len_z, Fe::zero());
-  for (uint32_t i = 0; i < p->len_z; i++) zs[i] = fe_from_canon(z_start + 4 * i);
-  if (nsteps) {
-    P_TRY(grow(&p->priv_all_d, &p->cap_priv_all, 32 * nsteps * (size_t)p->n_priv));
-    P_TRY(grow(&p->job_all_d, &p->cap_job_all, 32 * nsteps * jstride));
-    P_TRY(hipMemcpyAsync(p->priv_all_d, step_inputs, 32 * nsteps * (size_t)p->n_priv, hipMemcpyHostToDevice, s));
-    P_TRY(hipMemsetAsync(p->job_all_d, 0, 32 * nsteps * jstride, s));
-    for (size_t off = 0; off < nsteps && nA; off += 32768) {
-      const unsigned rows = (unsigned)std::min<size_t>(32768, nsteps - off);
-      hipLaunchKernelGGL(k_wit_chains, dim3((nA + 3) / 4, rows), dim3(64), 0, s, p->wd, 0u, (uint32_t*)nullptr, p->job_all_d + 8 * off * jstride,
-                         (const uint32_t*)(p->priv_all_d + 8 * off * p->n_priv));
-    }
-    P_TRY(hipGetLastError());
-    std::vector<Fe> jobA(nsteps * jstride);
-    P_TRY(hipMemcpyAsync(jobA.data(), p->job_all_d, 32 * nsteps * jstride, hipMemcpyDeviceToHost, s));
-    P_TRY(hipStreamSynchronize(s));
-    host_state_chain(p, step_inputs, nsteps, jobA.data(), jstride, zs);
-  }
-  for (size_t i = 0; i < zs.size(); i++) fe_to_canon(zs[i], zs_out + 4 * i);
+  // the stage 0 of a fold (row hashes, the ahead-of-time pass where the circuit needs one, the host's chain), from z_start
+  const std::vector<Fe> keep = p->z_cur;
+  for (uint32_t i = 0; i < p->len_z; i++) p->z_cur[i] = fe_from_canon(z_start + 4 * i);
+  FoldJob job; job.step_inputs = step_inputs; job.nsteps = nsteps;
+  int rc = VIMZ_OK;
+  if (nsteps) rc = fold_prepare(p, job);
+  else job.zs = p->z_cur;
+  p->z_cur = keep;
+  if (rc) return rc;
+  for (size_t i = 0; i < job.zs.size(); i++) fe_to_canon(job.zs[i], zs_out + 4 * i);
   return VIMZ_OK;
 }
 
