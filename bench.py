@@ -177,7 +177,8 @@ def main_ivc(args, rank, world, dist, torch, ctxs, circuit, params, steps_all, g
                        "constraints": n_c, "wires": n_w, "nnz": nnz, "step_circuit_constraints": info["step_constraints"], "step_circuit_wires": info["step_wires"],
                        "secondary_constraints": n_c2, "secondary_wires": n_w2,
                        "rows_per_rank": args.steps, "segments_per_gpu": S, "witness_batch": args.batch,
-                       "parallelism": f"{world * S} independent IVC proofs of contiguous row segments ({S} per GPU, folded concurrently), chained boundary states, no final fold"},
+                       "parallelism": (f"proof set {args.proof_set}: rank r proves proof_set[r % len], {S} IVC segment proofs per GPU; independent proofs, replicas only" if args.proof_set else
+                                       f"{world * S} independent IVC proofs of contiguous row segments ({S} per GPU, folded concurrently), chained boundary states, no final fold")},
             "verified": bool(ok),
             "verify_codes": codes,
             "folded_steps_total": folded,
