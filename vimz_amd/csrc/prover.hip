@@ -1,15 +1,15 @@
-// Folding prover: the body of `fold_input` (vimz/src/nova_snark_backend/folding.rs:27-43), i.e. what
-// nova_scotia::create_recursive_circuit + nova-snark's RecursiveSNARK::prove_step do per image row
-// (SURVEY.md §3.1, §8a), restated as a host loop over HIP kernels with every vector resident in HBM:
+// Folding prover, ACCUMULATOR mode (Nova IVC in full — augmented circuits, secondary curve — is ivc.hip; both share the batch
+// producer in prover_internal.hpp).  The per-row work of `fold_input` (vimz/src/nova_snark_backend/folding.rs:27-43 ->
+// nova_scotia::create_recursive_circuit -> RecursiveSNARK::prove_step) on the step circuit's own
+// instances, as a host loop over HIP kernels with every vector resident in HBM:
 //
 //   per batch of rows   GPU witness generation (witness.hpp)  — replaces one circom child process per step
 //   per step            (A,B,C)·z2  ->  comm_W2 = MSM(ck, W2)  ->  T  ->  comm_T = MSM(ck, T)
 //                       r = RO(...) on the host  ->  one fused fold of W, E and the running Az,Bz,Cz
 //
-// What is NOT here (DESIGN.md "scope"): nova-snark's augmented verifier circuit and the secondary-curve half
-// of prove_step (≈3 % of a step, host-side in the reference design).  The instance
-// folded is the step circuit's R1CS itself with public IO X = (z_{i+1}, z_i); the fold algebra, the
-// commitments and the acceptance check (is_sat_relaxed + commitment openings) are exactly Nova's NIFS.
+// The instance folded is the step circuit's R1CS itself with public IO X = (z_{i+1}, z_i); the fold algebra, the commitments
+// and the acceptance check (is_sat_relaxed + commitment openings) are Nova's NIFS, the transcript is ours.
+// Such accumulators of different row segments merge (vimz_prover_merge*): BASELINE.json north_star's sharding picture.
 #include "prover_internal.hpp"
 
 extern "C" {
