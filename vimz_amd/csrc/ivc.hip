@@ -46,7 +46,7 @@ F rho_element(const uint32_t low[4]) { F c = F::zero(); for (int k = 0; k < 4; k
 
 template <class F>
 void sec_spmv(const SecDev& S, hipStream_t s, const uint32_t* z, uint32_t* az, uint32_t* bz, uint32_t* cz) {
-  hipLaunchKernelGGL(k_spmv3<F>, dim3(stream_grid(S.n_c)), dim3(256), 0, s, S.A, S.B, S.C, S.dict, (size_t)S.n_c, z, az, bz, cz);
+  hipLaunchKernelGGL(k_spmv3<F>, dim3(stream_grid(3 * (size_t)S.n_c)), dim3(256), 0, s, S.A, S.B, S.C, S.dict, (size_t)S.n_c, z, az, bz, cz);
   if (S.n_long) {
     const unsigned blocks = (unsigned)std::min<uint32_t>((S.n_long + 3) / 4, 4096);
     hipLaunchKernelGGL(k_spmv_long<F>, dim3(blocks), dim3(256), 0, s, S.A, S.B, S.C, S.dict, S.long_items, S.n_long, z, az, bz, cz);

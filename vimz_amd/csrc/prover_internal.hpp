@@ -134,7 +134,7 @@ struct HostEval {
 static void launch_spmv(vimz_prover* p, hipStream_t s, const uint32_t* z, uint32_t* az, uint32_t* bz, uint32_t* cz, int part = 0) {
   if (part == 0 || part == 1) {
     const size_t rows = p->step_c;
-    hipLaunchKernelGGL(k_spmv3<Fr>, dim3(stream_grid(rows)), dim3(256), 0, s, p->A, p->B, p->C, p->dict, rows, z, az, bz, cz);
+    hipLaunchKernelGGL(k_spmv3<Fr>, dim3(stream_grid(3 * rows)), dim3(256), 0, s, p->A, p->B, p->C, p->dict, rows, z, az, bz, cz);
     if (p->n_long) {
       const unsigned blocks = (unsigned)std::min<uint32_t>((p->n_long + 3) / 4, 4096);
       hipLaunchKernelGGL(k_spmv_long<Fr>, dim3(blocks), dim3(256), 0, s, p->A, p->B, p->C, p->dict, p->long_items, p->n_long, z, az, bz, cz);
@@ -143,7 +143,7 @@ static void launch_spmv(vimz_prover* p, hipStream_t s, const uint32_t* z, uint32
   if ((part == 0 || part == 2) && p->n_c > p->step_c) {
     const size_t rows = p->n_c - p->step_c, o = p->step_c;
     CsrDev A2{p->A.row_ptr + o, p->A.col, p->A.coef}, B2{p->B.row_ptr + o, p->B.col, p->B.coef}, C2{p->C.row_ptr + o, p->C.col, p->C.coef};
-    hipLaunchKernelGGL(k_spmv3<Fr>, dim3(stream_grid(rows)), dim3(256), 0, s, A2, B2, C2, p->dict, rows, z, az + 8 * o, bz + 8 * o, cz + 8 * o);
+    hipLaunchKernelGGL(k_spmv3<Fr>, dim3(stream_grid(3 * rows)), dim3(256), 0, s, A2, B2, C2, p->dict, rows, z, az + 8 * o, bz + 8 * o, cz + 8 * o);
     if (p->n_long_aug) {
       const unsigned blocks = (unsigned)std::min<uint32_t>((p->n_long_aug + 3) / 4, 4096);
       hipLaunchKernelGGL(k_spmv_long<Fr>, dim3(blocks), dim3(256), 0, s, p->A, p->B, p->C, p->dict, p->long_items_aug, p->n_long_aug, z, az, bz, cz);

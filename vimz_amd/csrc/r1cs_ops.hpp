@@ -15,7 +15,8 @@ namespace vz {
 
 struct CsrDev { const uint32_t* row_ptr; const uint32_t* col; const uint32_t* coef; };
 
-constexpr uint32_t SPMV_LONG = 16;   // (matrix,row) items with more terms than this go to the wave-per-item kernel
+constexpr uint32_t SPMV_LONG = 6;    // (matrix,row) items with more terms than this go to the wave-per-item kernel: the short
+                                     // kernel's duration is its longest serial row (≈1 µs per dependent gather + multiply)
 
 // acc += c * v, skipping the multiply for the values a fresh witness is made of (0 and 1)
 template <class F>
@@ -26,21 +27,21 @@ __device__ __forceinline__ void spmv_term(F& acc, const uint32_t* __restrict__ d
   if (v.eq(F::one())) acc = F::add(acc, c); else acc = F::add(acc, F::mul(c, v));
 }
 
-// One thread per constraint row; rows of a matrix longer than SPMV_LONG are left to k_spmv_long.
+// One thread per (matrix, row), matrix-major so that consecutive lanes read consecutive rows; rows longer than SPMV_LONG are
+// left to k_spmv_long.  (One thread per row looping over A, B, C serialised three dependent gather chains.)
 template <class F>
 __global__ void __launch_bounds__(256) k_spmv3(CsrDev A, CsrDev B, CsrDev C, const uint32_t* __restrict__ dict, size_t nrows,
                                                const uint32_t* __restrict__ z, uint32_t* __restrict__ az, uint32_t* __restrict__ bz, uint32_t* __restrict__ cz) {
-  VZ_GRID_STRIDE(r, nrows) {
-    const CsrDev M[3] = {A, B, C};
-    uint32_t* out[3] = {az, bz, cz};
-#pragma unroll 1
-    for (int m = 0; m < 3; m++) {
-      const uint32_t lo = M[m].row_ptr[r], hi = M[m].row_ptr[r + 1];
-      if (hi - lo > SPMV_LONG) continue;
-      F acc = F::zero();
-      for (uint32_t k = lo; k < hi; k++) spmv_term<F>(acc, dict, M[m].coef[k], z, M[m].col[k]);
-      store_fe(out[m], r, acc);
-    }
+  VZ_GRID_STRIDE(i, 3 * nrows) {
+    const uint32_t m = (uint32_t)(i / nrows);
+    const size_t r = i - (size_t)m * nrows;
+    const CsrDev M = m == 0 ? A : (m == 1 ? B : C);
+    uint32_t* out = m == 0 ? az : (m == 1 ? bz : cz);
+    const uint32_t lo = M.row_ptr[r], hi = M.row_ptr[r + 1];
+    if (hi - lo > SPMV_LONG) continue;
+    F acc = F::zero();
+    for (uint32_t k = lo; k < hi; k++) spmv_term<F>(acc, dict, M.coef[k], z, M.col[k]);
+    store_fe(out, r, acc);
   }
 }
 
