@@ -451,7 +451,7 @@ __global__ void __launch_bounds__(256) k_reduce(const uint32_t* __restrict__ par
 // critical path.  Here one launch does everything: workgroup (w, q) owns window w (c = 7: 37 windows of 64 signed buckets)
 // and point chunk q (<= 1536 points): digits -> counting sort in LDS -> one thread per sub-bucket of <= 8 entries ->
 // segmented tree over a bucket's sub-buckets -> sum_b (b+1)·B_b as the sum of the 64 suffix sums (scan + tree, 12 deep) ->
-// a second tiny kernel adds a window's chunk results.  Depth: 8 + log2(max sub-buckets) + 12 + log2(chunks).
+// the last workgroup of a window to finish adds the chunk results.  Depth: 8 + log2(max sub-buckets) + 12 + log2(chunks).
 constexpr int SMALL_C = 7;
 constexpr uint32_t SMALL_NBW = 1u << (SMALL_C - 1), SMALL_SUB = 8, SMALL_PER_THREAD = 6, SMALL_CHUNK = 256 * SMALL_PER_THREAD, SMALL_MAXQ = 16;
 // (1536 points per workgroup: at most 1536/8 + 64 = 256 sub-buckets, one per thread; 7.6 k points -> 37 x 5 = 185 workgroups,
@@ -471,12 +471,13 @@ __device__ __forceinline__ int signed_digit(const uint32_t* s, int c, int w) {
 template <class S, class F>
 __global__ void __launch_bounds__(256) k_msm_small(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ scalars, uint32_t n, int mont,
                                                    uint32_t Q, uint32_t chunk, uint32_t* __restrict__ chunk_out /* K*Q points */,
+                                                   uint32_t* __restrict__ done /* K counters, zero between launches; nullptr: k_msm_small_sum follows */,
                                                    uint32_t* __restrict__ window_sums) {
   __shared__ XYZZ<F> sh[256];
   __shared__ uint32_t cnt[SMALL_NBW], off[SMALL_NBW + 1], soff[SMALL_NBW + 1], cur[SMALL_NBW];
   __shared__ uint16_t list[SMALL_CHUNK];
   __shared__ uint8_t subb[256];
-  __shared__ uint32_t s_maxm;
+  __shared__ uint32_t s_maxm, s_ticket;
   const uint32_t t = threadIdx.x, w = blockIdx.x, q = blockIdx.y;
   const uint32_t lo = q * chunk, hi = min(n, lo + chunk);
   if (t < SMALL_NBW) { cnt[t] = 0; cur[t] = 0; }
@@ -548,12 +549,37 @@ __global__ void __launch_bounds__(256) k_msm_small(const uint32_t* __restrict__ 
     if (t < d) { XYZZ<F> a = sh[t]; add_full(a, sh[t + d]); sh[t] = a; }
     __syncthreads();
   }
-  if (t == 0) { if (Q == 1) store_xyzz(window_sums, w, sh[0]); else store_xyzz(chunk_out, (size_t)w * Q + q, sh[0]); }
+  if (Q == 1) { if (t == 0) store_xyzz(window_sums, w, sh[0]); return; }
+  if (!done) { if (t == 0) store_xyzz(chunk_out, (size_t)w * Q + q, sh[0]); return; }
+  // The last workgroup of a window to finish adds the window's chunk results (release: stores, fence, agent-scope atomic;
+  // acquire: fence, agent-scope loads that bypass this CU's vector cache).
+  if (t == 0) {
+    store_xyzz(chunk_out, (size_t)w * Q + q, sh[0]);
+    __threadfence();
+    s_ticket = atomicAdd(&done[w], 1u);
+  }
+  __syncthreads();
+  if (s_ticket != Q - 1) return;
+  __threadfence();
+  XYZZ<F> v = XYZZ<F>::identity();
+  if (t < Q) {
+    const uint32_t* src = chunk_out + (size_t)XYZZ_WORDS * ((size_t)w * Q + t);
+    F* f[4] = {&v.X, &v.Y, &v.ZZ, &v.ZZZ};
+    for (int c4 = 0; c4 < 4; c4++) for (int i = 0; i < 9; i++) f[c4]->v[i] = __hip_atomic_load(src + COORD_WORDS * c4 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  sh[t] = v;
+  __syncthreads();
+  for (uint32_t d = SMALL_MAXQ / 2; d > 0; d >>= 1) {
+    if (t < d) { XYZZ<F> a = sh[t]; add_full(a, sh[t + d]); sh[t] = a; }
+    __syncthreads();
+  }
+  if (t == 0) { store_xyzz(window_sums, w, sh[0]); __hip_atomic_store(&done[w], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 }
 
-// window sum = sum of the window's chunk results.  A kernel of its own: the chunk results cross workgroups, which on an
-// 8-XCD part (one L2 per XCD) is only safely ordered by a kernel boundary — an in-kernel "last workgroup sums" variant with
-// fences and agent-scope atomics produced wrong sums under heavy multi-stream load.
+// window sum = sum of the window's chunk results as a kernel of its own (VIMZ_DEBUG_SMALL_SUM_KERNEL=1): the fallback for the
+// in-kernel "last workgroup sums" tail of k_msm_small, whose cross-workgroup hand-off relies on fences and agent-scope atomics
+// across the part's eight L2s.
 template <class F>
 __global__ void __launch_bounds__(64) k_msm_small_sum(const uint32_t* __restrict__ chunk_out, uint32_t Q, uint32_t* __restrict__ window_sums) {
   __shared__ XYZZ<F> sh[SMALL_MAXQ];
@@ -671,9 +697,10 @@ hipError_t msm_launch(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_ba
     uint32_t* done = reinterpret_cast<uint32_t*>(ws.small_buf);
     uint32_t* chunk_out = done + 128;
     if (ev) for (int i = 0; i < 4; i++) VZ_HIP_CHECK(hipEventRecord(ev[i], stream));
+    static const bool sum_kernel = getenv("VIMZ_DEBUG_SMALL_SUM_KERNEL") != nullptr;
     hipLaunchKernelGGL((k_msm_small<S, F>), dim3(ps.K, Q), dim3(256), 0, stream, d_bases, d_scalars, (uint32_t)n, scalars_mont, Q, chunk, chunk_out,
-                       reinterpret_cast<uint32_t*>(ws.window_sums));
-    if (Q > 1) hipLaunchKernelGGL(k_msm_small_sum<F>, dim3(ps.K), dim3(64), 0, stream, chunk_out, Q, reinterpret_cast<uint32_t*>(ws.window_sums));
+                       sum_kernel ? (uint32_t*)nullptr : done, reinterpret_cast<uint32_t*>(ws.window_sums));
+    if (Q > 1 && sum_kernel) hipLaunchKernelGGL(k_msm_small_sum<F>, dim3(ps.K), dim3(64), 0, stream, chunk_out, Q, reinterpret_cast<uint32_t*>(ws.window_sums));
     if (ev) for (int i = 4; i < 7; i++) VZ_HIP_CHECK(hipEventRecord(ev[i], stream));
     VZ_HIP_CHECK(hipGetLastError());
     VZ_HIP_CHECK(hipMemcpyAsync(pinned_dst, ws.window_sums, 4 * (size_t)XYZZ_WORDS * ps.K, hipMemcpyDeviceToHost, stream));

@@ -109,7 +109,9 @@ struct MsmWorkspace {  // device buffers, grown on demand and reused across call
     if (!totals) { VZ_HIP_CHECK(hipMalloc(&totals, 64)); VZ_HIP_CHECK(hipMemset(totals, 0, 64)); VZ_HIP_CHECK(hipStreamSynchronize(nullptr)); }
     if (small_buf) return hipSuccess;
     const size_t bytes = 512 + 4 * (size_t)XYZZ_WORDS * MSM_MAX_WINDOWS * 16;
-    return hipMalloc(&small_buf, bytes);     // chunk results: fully written by every launch before they are read
+    VZ_HIP_CHECK(hipMalloc(&small_buf, bytes));
+    VZ_HIP_CHECK(hipMemset(small_buf, 0, 512));          // the completion counters (the chunk results are written before they are read)
+    return hipStreamSynchronize(nullptr);
   }
   hipError_t reserve_block_hist(size_t words) {
     if (words <= cap_block_hist) return hipSuccess;
