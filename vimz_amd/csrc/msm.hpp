@@ -427,15 +427,25 @@ __global__ void __launch_bounds__(256) k_reduce(const uint32_t* __restrict__ par
     if (counts[g]) { XYZZ<F> B = load_xyzz<F>(partial, sub_off[g]); add_full(run, B); }
     add_full(sum, run);
   }
-  // sum = Σ (j+1)·B_{lo+j}; add lo·run
-  if (lo) {
-    XYZZ<F> acc = XYZZ<F>::identity();
-    for (int bit = 31 - __clz(lo); bit >= 0; bit--) {
-      acc = dbl(acc);
-      if ((lo >> bit) & 1) add_full(acc, run);
-    }
-    add_full(sum, acc);
+  // sum = Σ (j+1)·B_{lo+j}; the chunk's offset contributes lo·run = ch·t·run_t.  Σ_t t·run_t is the sum over s >= 1 of the suffix
+  // sums sfx_s = Σ_{t>=s} run_t, so one suffix scan over the threads' chunk totals replaces a per-thread double-and-add
+  // (≈15 dependent operations for a 10-bit offset):  window sum = Σ_t (sum_t + ch·sfx_t·[t >= 1]).
+  sh[t] = run;
+  __syncthreads();
+  for (uint32_t d = 1; d < T; d <<= 1) {
+    const bool act = t + d < T;
+    XYZZ<F> o = XYZZ<F>::identity();
+    if (act) o = sh[t + d];
+    __syncthreads();
+    if (act) { XYZZ<F> a = sh[t]; add_full(a, o); sh[t] = a; }
+    __syncthreads();
   }
+  if (t >= 1) {
+    XYZZ<F> sfx = sh[t];
+    for (uint32_t k = 1; k < ch; k <<= 1) sfx = dbl(sfx);     // ch is a power of two
+    add_full(sum, sfx);
+  }
+  __syncthreads();
   sh[t] = sum;
   __syncthreads();
   for (uint32_t d = T >> 1; d > 0; d >>= 1) {
