@@ -230,3 +230,32 @@ def test_proof_export_import_verifies_elsewhere_and_resumes(ctx, keys, oracle):
             a.proof_import(blob[:1000])
     finally:
         a.close(); b.close(); ref.close()
+
+
+def test_concurrent_provers_all_verify(oracle):
+    """Four IVC provers on their own contexts fold concurrently from four host threads, several times over from a fresh state
+    (the first step after creation used to be the fragile one: a null-stream fill could land after the first kernel's writes)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from vimz_amd import hip
+    c = Circuit.for_resolution("hash", "HD")
+    z0, inputs = step_inputs("hash")
+    steps = np.stack(inputs)
+    for rep in range(3):
+        ctxs = [hip.Context(0) for _ in range(4)]
+        ck1 = ctxs[0].bases_generate(_lib.CURVE_BN254_G1, 1 << 14)
+        ck2 = ctxs[0].bases_generate(_lib.CURVE_GRUMPKIN, 1 << 13, b"ck-secondary")
+        ivcs = [hip.IVC(cx, c, ck1, ck2, max_batch=4) for cx in ctxs]
+        try:
+            for v in ivcs:
+                v.reset(z0)
+            with ThreadPoolExecutor(4) as ex:
+                list(ex.map(lambda v: v.fold(steps), ivcs))
+            assert [v.verify() for v in ivcs] == [0, 0, 0, 0]
+            ref = ivcs[0].export(0, hip.IX_INSTANCE)
+            assert all((v.export(0, hip.IX_INSTANCE) == ref).all() for v in ivcs)      # same inputs: the very same proof
+        finally:
+            for v in ivcs:
+                v.close()
+            ck1.free(); ck2.free()
+            for cx in ctxs:
+                cx.close()
