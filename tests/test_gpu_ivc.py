@@ -140,15 +140,23 @@ def test_ivc_rejects_a_row_that_violates_the_step_relation(ctx, keys):
     c = Circuit.for_resolution("grayscale", "HD")
     z0, inputs = step_inputs("grayscale")
     steps = np.stack(inputs).copy()
+    good = np.stack(inputs)
     steps[6, 200, 0] ^= np.uint64(0xFF)          # a transformed pixel that is no longer the grayscale of the original
     ivc = hip.IVC(ctx, c, ck1, ck2, max_batch=4)
+    ref = hip.IVC(ctx, c, ck1, ck2, max_batch=4)
     try:
         ivc.reset(z0)
         with pytest.raises(_lib.VimzError) as e:
             ivc.fold(steps)
         assert e.value.code == _lib.ERR_UNSAT
+        # the batch before the bad one (rows 0-3) stays folded and the proof is consistent there: it verifies and can go on
+        assert ivc.state()[1] == 4 and ivc.verify() == 0
+        ivc.fold(good[4:])
+        ref.reset(z0); ref.fold(good)
+        assert ivc.verify() == 0 and ivc.state() == ref.state()
+        assert (ivc.export(0, hip.IX_INSTANCE) == ref.export(0, hip.IX_INSTANCE)).all()
     finally:
-        ivc.close()
+        ivc.close(); ref.close()
 
 
 def test_a_forged_instance_is_caught_by_the_oracle_verifier(ctx, keys, oracle):

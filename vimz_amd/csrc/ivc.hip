@@ -142,6 +142,9 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
     for (size_t r = 0; r < rows; r++) if (bb.status_host[r]) {
       char msg[128]; snprintf(msg, sizeof(msg), "step %llu: the step relation is not satisfiable for these rows", (unsigned long long)(v->i + r));
       hipStreamSynchronize(p->sB);
+      // the batches folded so far stay folded: leave the IVC consistent at that point (state, pending secondary commitments)
+      finish_secondary(v);
+      for (uint32_t q = 0; q < p->len_z; q++) p->z_cur[q] = zs[first * p->len_z + q];
       return vz_fail(ctx, VIMZ_ERR_UNSAT, msg);
     }
     for (size_t r = 0; r < rows; r++) {

@@ -267,6 +267,7 @@ static int fold_core(vimz_prover* p, const uint64_t* step_inputs, const uint64_t
     for (size_t r = 0; r < rows; r++) if (bb.status_host[r]) {
       char msg[128]; snprintf(msg, sizeof(msg), "step %llu: the step relation is not satisfiable for these rows", (unsigned long long)(p->steps + r));
       hipStreamSynchronize(p->sB);
+      for (uint32_t q = 0; q < p->len_z; q++) p->z_cur[q] = zs[first * p->len_z + q];   // the batches folded so far stay folded
       return vz_fail(ctx, VIMZ_ERR_UNSAT, msg);
     }
     // Software-pipelined sequential chain.  While the GPU runs MSM(T) of row r the host finishes the previous row's
