@@ -193,7 +193,7 @@ def main_ivc(args, rank, world, dist, torch, ctxs, circuit, params, steps_all, g
                          "int_utilisation": (adds / (acc_ms * 1e-3) / 1e9 / MIXED_ADD_PEAK_GOPS) if acc_ms else 0.0,
                          "step_algorithmic_bytes": step_bytes, "step_hbm_frac": step_bytes / (dt / max(1, timed_rows)) / 1e9 / HBM_PEAK_GBPS},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # the CPU baseline is timed at N = 1 only
             cores = os.cpu_count() or 1
             ck_host = params.ck.download(0, max(circuit.n_constraints, circuit.n_wires))
             sps, secs, n_cpu = cpu_baseline(circuit, mine, z_rank, ck_host, args.cpu_seconds, cores)
@@ -371,7 +371,7 @@ def main():
                          "int_utilisation": (adds / (acc_ms * 1e-3) / 1e9 / MIXED_ADD_PEAK_GOPS) if acc_ms else 0.0,
                          "step_algorithmic_bytes": step_bytes, "step_hbm_frac": step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBPS},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # the CPU baseline is timed at N = 1 only
             cores = os.cpu_count() or 1
             ck_host = params.ck.download(0, max(n_c, n_w))
             sps, secs, n_cpu = cpu_baseline(circuit, mine, z_start, ck_host, args.cpu_seconds, cores)
