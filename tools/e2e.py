@@ -2,7 +2,7 @@
 """End-to-end run of one transformation on the GPU, the way `vimz -b nova-snark -f <t>` sequences it
 (vimz/src/nova_snark_backend/mod.rs:22-80): prepare input -> prepare folding (circuit + key) -> fold every row -> verify.
 Prints the span times the reference logs ("Prepare input", "Prepare folding", "Fold input", "Verify folded proof").
-usage: e2e.py <transformation> <resolution> [segments] [ivc|accumulator]
+usage: e2e.py <transformation> <resolution> [segments] [ivc|accumulator] [proof file prefix]
 ivc (default): the rows are proven as `segments` Nova IVC proofs of contiguous row segments (chained boundary states);
 accumulator: NIFS accumulators of the segments merged by a final fold."""
 import json
@@ -21,6 +21,7 @@ def main():
     t, res = sys.argv[1], sys.argv[2]
     S = int(sys.argv[3]) if len(sys.argv) > 3 else 2
     mode = sys.argv[4] if len(sys.argv) > 4 else "ivc"
+    save = sys.argv[5] if len(sys.argv) > 5 else None
     spans = {}
     t0 = time.time()
     rows, z0 = bench.build_inputs(t, res)
@@ -44,6 +45,9 @@ def main():
         ok = all(v.verify() == 0 for v in ivcs) and all(segs[i][0].state()[0] == segs[i + 1][2] for i in range(S - 1))
         spans["Verify folded proof"] = time.time() - t0
         n = sum(v.state()[1] for v in ivcs)
+        if save:
+            for k, v in enumerate(ivcs):
+                v.proof_export().tofile(f"{save}.{k}.bin")      # verify elsewhere: tools/verify_proof.py
         print(json.dumps({"config": f"{t}_step_{res}", "mode": "ivc", "steps": n, "segment_proofs": S, "verified": ok, "spans_s": spans,
                           "steps_per_s": n / spans["Fold input"], "total_s": sum(spans.values()),
                           "final_state": [hex(z) for z in ivcs[-1].state()[0]]}))
