@@ -134,6 +134,15 @@ def main_ivc(args, rank, world, dist, torch, ctxs, circuit, params, steps_all, g
     ok = ok and all(ends[i] == segs[i + 1][2] for i in range(S - 1))
     verify_s = time.time() - t_v
     folded = sum(ivc.state()[1] for ivc in ivcs)
+    # for reference: ONE proof folding alone on the GPU (what a single sequential IVC chain reaches), outside the timed region
+    single = None
+    if rank == 0 and S > 1:
+        rows1 = segs[0][1][:64]
+        ctxs[0].sync()
+        t1 = time.time()
+        ivcs[0].fold(rows1)
+        ctxs[0].sync()
+        single = len(rows1) / (time.time() - t1)
     if dist is not None:
         t = torch.tensor([1 if ok else 0, folded, timed_rows], dtype=torch.int64)
         m = t.clone(); dist.all_reduce(m, op=dist.ReduceOp.MIN)
@@ -181,6 +190,7 @@ def main_ivc(args, rank, world, dist, torch, ctxs, circuit, params, steps_all, g
                                        f"{world * S} independent IVC proofs of contiguous row segments ({S} per GPU, folded concurrently), chained boundary states, no final fold")},
             "verified": bool(ok),
             "verify_codes": codes,
+            "single_proof_steps_per_s": single,
             "folded_steps_total": folded,
             "verify_s": verify_s,
             "end_to_end_estimate_s": {"keygen_and_setup": setup_s, "fold_720_steps_one_gpu": 720 * dt / max(1, timed_rows)},
