@@ -14,6 +14,7 @@ from . import _lib
 from .circuit import Circuit, default_shape
 
 DEMO_STEPS = 10  # vimz/src/lib.rs:9
+AUGMENTED_ROOM = 8192   # wires / constraints Nova's verifier circuit adds to a step circuit (vimz_ivc_create)
 
 # vimz/src/transformation.rs:93-123
 ITERATION_COUNT = {"SD": 480, "HD": 720, "FHD": 1080, "4K": 2160, "8K": 4320}
@@ -83,8 +84,8 @@ def prepare_folding(ctx, transformation, resolution="HD", ck_label=b"ck", window
     (optionally with window tables: 16 x the key's size in HBM, 0.67 GB at HD)."""
     t0 = time.time()
     circuit = Circuit(transformation, *default_shape(transformation, resolution))
-    n_aux = circuit.n_wires - 1 - 2 * circuit.len_z
-    n = 1 << (max(n_aux, circuit.n_constraints) - 1).bit_length()   # next power of two, as nova-snark sizes ck
+    # next power of two, as nova-snark sizes ck — of the AUGMENTED circuit: the verifier circuit adds 7 711 wires / 7 712 rows
+    n = 1 << (max(circuit.n_wires, circuit.n_constraints) + AUGMENTED_ROOM - 1).bit_length()
     ck = ctx.bases_generate(_lib.CURVE_BN254_G1, n, ck_label)
     if window_tables:
         ck.precompute()
