@@ -67,7 +67,7 @@ struct vimz_ivc {
   SecDev sec;
   std::vector<void*> owned;
   char* pin = nullptr;                            // pinned: 4 MSM results, then staging for the two host-made witnesses
-  size_t pin_res = 0;
+  size_t pin_res = 0, pin_totals = 0;
   MsmPlan plan_aug{}, plan_T1{}, plan_W2{}, plan_T2{};
   // the witness commitment and the cross-term commitment of one instance are independent: they run side by side
   hipStream_t s2 = nullptr; hipEvent_t ev_fork = nullptr; MsmWorkspace ws2;
@@ -91,10 +91,10 @@ int finish_secondary(vimz_ivc* v) {
   if (!v->pending_sec) return VIMZ_OK;
   vimz_ctx* ctx = v->ctx;
   double t0 = now_s();
-  P_TRY(hipStreamSynchronize(ctx->stream));
   P_TRY(hipStreamSynchronize(v->s2));
+  v->u2.W = msm_finish<Grumpkin>(v->plan_W2, v->pin + 2 * v->pin_res);      // overlaps the rest of MSM(T2)
+  P_TRY(hipStreamSynchronize(ctx->stream));
   v->ph_s[IP_WAIT_SEC] += now_s() - t0; v->ph_n[IP_WAIT_SEC]++;
-  v->u2.W = msm_finish<Grumpkin>(v->plan_W2, v->pin + 2 * v->pin_res);
   if (v->sec_T_valid) v->T2 = msm_finish<Grumpkin>(v->plan_T2, v->pin + 3 * v->pin_res);
   else { v->T2.x = Fe::zero(); v->T2.y = Fe::zero(); }
   static const bool dbg = getenv("VIMZ_DEBUG_CHECK_MSM") != nullptr;
@@ -186,17 +186,17 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
         hipLaunchKernelGGL(k_cross_term<Fr>, dim3(stream_grid(nc)), dim3(256), 0, s, nc, p->AZ, p->BZ, p->CZ, v->u1_run, az, bz, cz, Fe::one(), p->T);
         P_TRY(hipGetLastError());
         P_TRY(msm_launch<BnG1>(s, ctx->msm_ws, p->ck->d, p->T, nc, 1, 0, v->pin + v->pin_res, &v->plan_T1, ctx->profiling ? ctx->ev : nullptr, 0, nullptr));
-        if (ctx->profiling) P_TRY(hipMemcpyAsync(&ctx->last_msm.subs, ctx->msm_ws.totals, 8, hipMemcpyDeviceToHost, s));
+        if (ctx->profiling) P_TRY(hipMemcpyAsync(v->pin + v->pin_totals, ctx->msm_ws.totals, 8, hipMemcpyDeviceToHost, s));   // (pinned: stays asynchronous)
       }
       v->ph_s[IP_LAUNCH] += now_s() - t0;
       t0 = now_s();
       P_TRY(hipEventSynchronize(bb.ev[r]));
       G1Aff cW_step = msm_finish<BnG1>(p->planB, (char*)bb.pin + r * pin_stride);
       P_TRY(hipStreamSynchronize(v->s2));
+      G1Aff cW_aug = msm_finish<BnG1>(v->plan_aug, v->pin);      // the small MSM is back first: its Horner tail overlaps MSM(T1)
       P_TRY(hipStreamSynchronize(s));
       v->ph_s[IP_WAIT_PRI] += now_s() - t0; v->ph_n[IP_WAIT_PRI]++;
       t0 = now_s();
-      G1Aff cW_aug = msm_finish<BnG1>(v->plan_aug, v->pin);
       {
         static const bool dbg = getenv("VIMZ_DEBUG_CHECK_MSM") != nullptr;
         if (dbg) {
@@ -232,6 +232,7 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
       if (i > 0 && ctx->profiling) {       // HIP-event durations of the phases of this MSM(T), accumulated for the roofline figure
         float ms[6];
         for (int q = 0; q < 6; q++) { P_TRY(hipEventElapsedTime(&ms[q], ctx->ev[q], ctx->ev[q + 1])); ctx->last_msm.ms[q] = ms[q]; ctx->msm_tot_ms[q] += ms[q]; }
+        memcpy(&ctx->last_msm.subs, v->pin + v->pin_totals, 8);
         ctx->last_msm.c = v->plan_T1.c; ctx->last_msm.K = v->plan_T1.K;
         ctx->msm_tot_calls++; ctx->msm_tot_points += nc; ctx->msm_tot_entries += ctx->last_msm.entries;
       }
@@ -364,7 +365,8 @@ int vimz_ivc_create(vimz_ctx* ctx, const vimz_circuit* step_circuit, const vimz_
     else if ((e = hipStreamCreateWithPriority(&v->s2, hipStreamNonBlocking, hi)) != hipSuccess) return fail("stream");
     if ((e = hipEventCreateWithFlags(&v->ev_fork, hipEventDisableTiming)) != hipSuccess) return fail("event"); }
   v->pin_res = 4 * (size_t)XYZZ_WORDS * MSM_MAX_WINDOWS;
-  if ((e = hipHostMalloc((void**)&v->pin, 4 * v->pin_res + 32 * (size_t)v->c1->aug_wires() + 32 * (size_t)nw2)) != hipSuccess) return fail("pinned");
+  v->pin_totals = 4 * v->pin_res + 32 * (size_t)v->c1->aug_wires() + 32 * (size_t)nw2;
+  if ((e = hipHostMalloc((void**)&v->pin, v->pin_totals + 64)) != hipSuccess) return fail("pinned");
   if ((e = hipStreamSynchronize(nullptr)) != hipSuccess) return fail("sync");   // the hipMemset fills above ran on the null stream
   v->z0.assign(v->c1->len_z, Fe::zero());
   v->U1 = RelaxedInst<Fq>::zero(); v->U2 = RelaxedInst<Fe>::zero(); v->u2 = FreshInst<Fe>::zero(); v->T2.x = v->T2.y = Fe::zero();

@@ -295,7 +295,8 @@ static int fold_core(vimz_prover* p, const uint64_t* step_inputs, const uint64_t
       P_TRY(hipGetLastError());
       if (!ctx->msm_ws.host_pinned) P_TRY(hipHostMalloc(&ctx->msm_ws.host_pinned, 4 * XYZZ_WORDS * MSM_MAX_WINDOWS));
       P_TRY(msm_launch<BnG1>(s, ctx->msm_ws, p->ck->d, p->T, nc, 1, 0, ctx->msm_ws.host_pinned, &planT, ctx->profiling ? ctx->ev : nullptr, 0, p->ck->tables ? &tbl : nullptr));
-      if (ctx->profiling) P_TRY(hipMemcpyAsync(&ctx->last_msm.subs, ctx->msm_ws.totals, 8, hipMemcpyDeviceToHost, s));
+      if (ctx->profiling)   // into the last (unused) point slot of the pinned result buffer: a pageable destination would make the copy synchronous
+        P_TRY(hipMemcpyAsync((char*)ctx->msm_ws.host_pinned + 4 * (size_t)XYZZ_WORDS * (MSM_MAX_WINDOWS - 1), ctx->msm_ws.totals, 8, hipMemcpyDeviceToHost, s));
       return VIMZ_OK;
     };
     struct Deferred { bool pending = false; G1Aff cW2, cT; Fe r128; } dfr;
@@ -335,6 +336,7 @@ static int fold_core(vimz_prover* p, const uint64_t* step_inputs, const uint64_t
       if (ctx->profiling) {
         float ms[6];
         for (int i = 0; i < 6; i++) { P_TRY(hipEventElapsedTime(&ms[i], ctx->ev[i], ctx->ev[i + 1])); ctx->last_msm.ms[i] = ms[i]; ctx->msm_tot_ms[i] += ms[i]; }
+        memcpy(&ctx->last_msm.subs, (char*)ctx->msm_ws.host_pinned + 4 * (size_t)XYZZ_WORDS * (MSM_MAX_WINDOWS - 1), 8);
         ctx->last_msm.c = planT.c; ctx->last_msm.K = planT.K;
         ctx->msm_tot_calls++; ctx->msm_tot_points += nc; ctx->msm_tot_entries += ctx->last_msm.entries;
       }
