@@ -233,6 +233,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", default="ivc", choices=["ivc", "accumulator"])
+    ap.add_argument("--window-tables", action="store_true", help="precompute 2^(16j)·P_i tables of the primary key (16x its size in HBM): one bucket set, no Horner")
     ap.add_argument("--proof-set", default="", help="comma-separated transformations: rank r proves proof_set[r %% len] (BASELINE config 5: independent proofs, replicas only)")
     args = ap.parse_args()
 
@@ -258,7 +259,7 @@ def main():
     ctxs = [hip.Context(device) for _ in range(S)]
     ctx = ctxs[0]
     t_setup = time.time()
-    circuit, params = folding.prepare_folding(ctx, args.transformation, args.resolution)
+    circuit, params = folding.prepare_folding(ctx, args.transformation, args.resolution, window_tables=args.window_tables)
     steps_all, z0 = build_inputs(args.transformation, args.resolution)
     n_rows = steps_all.shape[0]
     per_rank = args.warmup + args.steps

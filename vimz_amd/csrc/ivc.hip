@@ -185,7 +185,7 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
       if (i > 0) {
         hipLaunchKernelGGL(k_cross_term<Fr>, dim3(stream_grid(nc)), dim3(256), 0, s, nc, p->AZ, p->BZ, p->CZ, v->u1_run, az, bz, cz, Fe::one(), p->T);
         P_TRY(hipGetLastError());
-        P_TRY(msm_launch<BnG1>(s, ctx->msm_ws, p->ck->d, p->T, nc, 1, 0, v->pin + v->pin_res, &v->plan_T1, ctx->profiling ? ctx->ev : nullptr, 0, nullptr));
+        P_TRY(msm_launch<BnG1>(s, ctx->msm_ws, p->ck->d, p->T, nc, 1, 0, v->pin + v->pin_res, &v->plan_T1, ctx->profiling ? ctx->ev : nullptr, 0, p->ck->tables ? &job.tbl : nullptr));
         if (ctx->profiling) P_TRY(hipMemcpyAsync(v->pin + v->pin_totals, ctx->msm_ws.totals, 8, hipMemcpyDeviceToHost, s));   // (pinned: stays asynchronous)
       }
       v->ph_s[IP_LAUNCH] += now_s() - t0;
