@@ -11,7 +11,8 @@
 //   3. k_scatter_lds  counting-sort scatter of (point index | sign) into bucket order, ranks from LDS counters.
 //   4. k_accum     one thread per sub-bucket: gathers its affine bases (80 B each, from L2 / Infinity Cache — the key is
 //                  re-read by every window) and accumulates in XYZZ over the 9x29-bit coordinate field.
-//   5. k_combine (+ k_combine_heavy)  folds the sub-bucket partials of each bucket; hot buckets by a workgroup tree.
+//   5. k_combine (+ k_combine_heavy2) folds the sub-bucket partials of each bucket; hot buckets (listed by k_scan) by workgroup trees
+//                  in the same launch.
 //   6. k_reduce    per window: chunked running sums + LDS tree -> sum_b b*B_b.
 //      (unit scalars, when split: k_ones_partial + k_tree256 -> one extra "window sum")
 //   7. host        Horner over the K window sums (K*c doublings) and one inversion to affine (msm_finish).
@@ -108,7 +109,9 @@ __global__ void k_hist(const uint32_t* __restrict__ scalars, size_t n, int mont,
 template <int SUB>
 __global__ void __launch_bounds__(1024) k_scan(const uint32_t* __restrict__ counts, uint32_t nb,
                                                uint32_t* __restrict__ bucket_off, uint32_t* __restrict__ sub_off,
-                                               uint32_t* __restrict__ totals, uint32_t sub) {
+                                               uint32_t* __restrict__ totals, uint32_t sub,
+                                               uint32_t* __restrict__ heavy /* [0] = count (zeroed by the caller), then ids of buckets with > heavy_min sub-buckets */,
+                                               uint32_t heavy_min, uint32_t heavy_cap) {
   __shared__ uint32_t sh_e[1024], sh_s[1024];
   const uint32_t t = threadIdx.x;
   const uint32_t per = (nb + 1023) / 1024;
@@ -128,7 +131,9 @@ __global__ void __launch_bounds__(1024) k_scan(const uint32_t* __restrict__ coun
   for (uint32_t b = lo; b < hi; b++) {
     uint32_t cnt = counts[b];
     bucket_off[b] = be; sub_off[b] = bs;
-    be += cnt; bs += (cnt + sub - 1) / sub;
+    const uint32_t m = (cnt + sub - 1) / sub;
+    if (m > heavy_min) { const uint32_t slot = atomicAdd(&heavy[0], 1u); if (slot < heavy_cap) heavy[1 + slot] = b; }
+    be += cnt; bs += m;
   }
   if (t == 1023) { bucket_off[nb] = sh_e[1023]; sub_off[nb] = sh_s[1023]; totals[0] = sh_s[1023]; totals[1] = sh_e[1023]; }
 }
@@ -311,50 +316,62 @@ __global__ void __launch_bounds__(256) k_tree256(const uint32_t* __restrict__ in
 
 constexpr uint32_t MSM_HEAVY = 64;   // buckets with more sub-buckets than this are combined by a whole workgroup
 
-// Sixteen lanes per bucket fold the bucket's sub-bucket partials into partial[sub_off[b]]: strided partial sums, then a
-// four-level tree through LDS — the dependent chain is ceil(m/16) + 4 additions instead of m - 1 (one dependent addition
-// costs 6-10 us, and cross-term scalars repeat, so some buckets carry many sub-buckets).  Buckets with more than MSM_HEAVY
-// partials (the few hot buckets of witness-like scalars) are queued for k_combine_heavy instead.
-template <class F>
-__global__ void __launch_bounds__(256) k_combine(uint32_t* __restrict__ partial, const uint32_t* __restrict__ sub_off, uint32_t nb,
-                                                 uint32_t* __restrict__ heavy /* [0] = count, then bucket ids */, uint32_t heavy_cap) {
-  __shared__ XYZZ<F> sh[256];
-  const uint32_t t = threadIdx.x, lane = t & 15u;
-  const uint32_t b = blockIdx.x * 16u + (t >> 4);
-  uint32_t s0 = 0, m = 0;
-  if (b < nb) { s0 = sub_off[b]; m = sub_off[b + 1] - s0; }
-  if (m > MSM_HEAVY) {
-    bool queued = true;
-    if (lane == 0) {
-      const uint32_t slot = atomicAdd(&heavy[0], 1u);
-      if (slot < heavy_cap) heavy[1 + slot] = b; else queued = false;   // list full (cannot happen for heavy_cap >= subs / MSM_HEAVY)
-    }
-    queued = __shfl(queued ? 1 : 0, (int)(t & 48u), 64) != 0;              // lane 0 of this 16-lane group
-    if (queued) m = 0;
-  }
-  XYZZ<F> acc = XYZZ<F>::identity();
-  for (uint32_t k = lane; k < m; k += 16) { XYZZ<F> q = load_xyzz<F>(partial, s0 + k); add_full(acc, q); }
-  sh[t] = acc;
-  __syncthreads();
-  for (uint32_t d = 8; d > 0; d >>= 1) {
-    if (lane < d && lane + d < m) { XYZZ<F> a = sh[t]; add_full(a, sh[t + d]); sh[t] = a; }
-    __syncthreads();
-  }
-  if (lane == 0 && m >= 2) store_xyzz(partial, s0, sh[t]);
-}
-
-// Heavy buckets.  With 254-bit scalars and c = 11 the top window holds one bit plus a carry, so a third of ALL points of a
-// dense MSM meet in one or two buckets (10^4 partials); witness-like scalars add a few hot buckets of small values.  The first
-// MSM_HEAVY_SPLIT queued buckets are therefore folded in two stages — MSM_HEAVY_PARTS workgroups per bucket (strided sums +
-// LDS tree) into a scratch row, then one 32-lane tree per bucket — and any further ones by a single workgroup each.
 constexpr uint32_t MSM_HEAVY_PARTS = 32, MSM_HEAVY_SPLIT = 1024;
 constexpr uint32_t MSM_HEAVY_SPLIT_MIN = 2048;   // buckets with fewer partials than this are left to one workgroup (one tree, no second stage)
+constexpr uint32_t COMBINE_HEAVY_BLOCKS = 512, COMBINE_SPLIT_BLOCKS = 1024;
+
+// ONE launch folds every bucket's sub-bucket partials into partial[sub_off[b]], three kinds of workgroups side by side
+// (they touch disjoint buckets, and run as separate kernels they cost three serial tails of dependent additions):
+//   blocks [0, nbn)                      ordinary buckets (<= MSM_HEAVY partials): 16 lanes per bucket, strided sums + 4-level LDS tree;
+//   next COMBINE_HEAVY_BLOCKS            heavy buckets (list written by k_scan), one workgroup each: strided sums + 8-level tree;
+//   next COMBINE_SPLIT_BLOCKS            very heavy buckets (>= MSM_HEAVY_SPLIT_MIN partials; among the first MSM_HEAVY_SPLIT of the list):
+//                                        stage 1 of a two-stage fold, MSM_HEAVY_PARTS workgroups per bucket into a scratch row
+//                                        (k_combine_heavy2 finishes them).
+// Why buckets get that heavy: with 254-bit scalars and c = 11 the top window holds one bit plus a carry, so a third of ALL points
+// of a dense MSM meet in one or two buckets; repeated cross-term values and the small values of a witness add hot buckets.
 template <class F>
-__global__ void __launch_bounds__(256) k_combine_heavy1(const uint32_t* __restrict__ partial, const uint32_t* __restrict__ sub_off,
-                                                        const uint32_t* __restrict__ heavy, uint32_t heavy_cap, uint32_t* __restrict__ scratch) {
+__global__ void __launch_bounds__(256) k_combine(uint32_t* __restrict__ partial, const uint32_t* __restrict__ sub_off, uint32_t nb, uint32_t nbn,
+                                                 const uint32_t* __restrict__ heavy, uint32_t heavy_cap, uint32_t* __restrict__ scratch) {
   __shared__ XYZZ<F> sh[256];
-  const uint32_t count = min(min(heavy[0], heavy_cap), MSM_HEAVY_SPLIT), t = threadIdx.x;
-  for (uint32_t it = blockIdx.x; it < count * MSM_HEAVY_PARTS; it += gridDim.x) {
+  const uint32_t t = threadIdx.x;
+  if (blockIdx.x < nbn) {
+    const uint32_t lane = t & 15u;
+    const uint32_t b = blockIdx.x * 16u + (t >> 4);
+    uint32_t s0 = 0, m = 0;
+    if (b < nb) { s0 = sub_off[b]; m = sub_off[b + 1] - s0; }
+    if (m > MSM_HEAVY) m = 0;                                 // on k_scan's list: another workgroup of this launch folds it
+    XYZZ<F> acc = XYZZ<F>::identity();
+    for (uint32_t k = lane; k < m; k += 16) { XYZZ<F> q = load_xyzz<F>(partial, s0 + k); add_full(acc, q); }
+    sh[t] = acc;
+    __syncthreads();
+    for (uint32_t d = 8; d > 0; d >>= 1) {
+      if (lane < d && lane + d < m) { XYZZ<F> a = sh[t]; add_full(a, sh[t + d]); sh[t] = a; }
+      __syncthreads();
+    }
+    if (lane == 0 && m >= 2) store_xyzz(partial, s0, sh[t]);
+    return;
+  }
+  const uint32_t count = min(heavy[0], heavy_cap);
+  if (blockIdx.x < nbn + COMBINE_HEAVY_BLOCKS) {
+    for (uint32_t h = blockIdx.x - nbn; h < count; h += COMBINE_HEAVY_BLOCKS) {
+      const uint32_t b = heavy[1 + h];
+      const uint32_t s0 = sub_off[b], m = sub_off[b + 1] - s0;
+      if (h < MSM_HEAVY_SPLIT && m >= MSM_HEAVY_SPLIT_MIN) continue;      // folded in two stages
+      XYZZ<F> acc = XYZZ<F>::identity();
+      for (uint32_t k = t; k < m; k += 256) { XYZZ<F> q = load_xyzz<F>(partial, s0 + k); add_full(acc, q); }
+      __syncthreads();
+      sh[t] = acc;
+      __syncthreads();
+      for (uint32_t d = 128; d > 0; d >>= 1) {
+        if (t < d) { XYZZ<F> a = sh[t]; add_full(a, sh[t + d]); sh[t] = a; }
+        __syncthreads();
+      }
+      if (t == 0) store_xyzz(partial, s0, sh[0]);
+    }
+    return;
+  }
+  const uint32_t nsplit = min(count, MSM_HEAVY_SPLIT);
+  for (uint32_t it = blockIdx.x - nbn - COMBINE_HEAVY_BLOCKS; it < nsplit * MSM_HEAVY_PARTS; it += COMBINE_SPLIT_BLOCKS) {
     const uint32_t b = heavy[1 + it / MSM_HEAVY_PARTS], part = it % MSM_HEAVY_PARTS;
     const uint32_t s0 = sub_off[b], m = sub_off[b + 1] - s0;
     if (m < MSM_HEAVY_SPLIT_MIN) continue;
@@ -371,6 +388,8 @@ __global__ void __launch_bounds__(256) k_combine_heavy1(const uint32_t* __restri
     if (t == 0) store_xyzz(scratch, it, sh[0]);
   }
 }
+
+// stage 2 of the very heavy buckets: one 32-lane tree per bucket over its scratch row
 template <class F>
 __global__ void __launch_bounds__(256) k_combine_heavy2(uint32_t* __restrict__ partial, const uint32_t* __restrict__ sub_off,
                                                         const uint32_t* __restrict__ heavy, uint32_t heavy_cap, const uint32_t* __restrict__ scratch) {
@@ -388,30 +407,6 @@ __global__ void __launch_bounds__(256) k_combine_heavy2(uint32_t* __restrict__ p
   }
   if (lane == 0 && mine) store_xyzz(partial, sub_off[heavy[1 + h]], sh[t]);
 }
-// One workgroup per remaining heavy bucket (moderately heavy ones, and any beyond the first `first` of the list): strided
-// accumulation by 256 threads, then an LDS tree.
-template <class F>
-__global__ void __launch_bounds__(256) k_combine_heavy(uint32_t* __restrict__ partial, const uint32_t* __restrict__ sub_off,
-                                                       const uint32_t* __restrict__ heavy, uint32_t heavy_cap, uint32_t first) {
-  __shared__ XYZZ<F> sh[256];
-  const uint32_t count = min(heavy[0], heavy_cap), t = threadIdx.x;
-  for (uint32_t h = blockIdx.x; h < count; h += gridDim.x) {
-    const uint32_t b = heavy[1 + h];
-    const uint32_t s0 = sub_off[b], m = sub_off[b + 1] - s0;
-    if (h < first && m >= MSM_HEAVY_SPLIT_MIN) continue;      // folded by the two-stage path
-    XYZZ<F> acc = XYZZ<F>::identity();
-    for (uint32_t k = t; k < m; k += 256) { XYZZ<F> q = load_xyzz<F>(partial, s0 + k); add_full(acc, q); }
-    __syncthreads();
-    sh[t] = acc;
-    __syncthreads();
-    for (uint32_t d = 128; d > 0; d >>= 1) {
-      if (t < d) { XYZZ<F> a = sh[t]; add_full(a, sh[t + d]); sh[t] = a; }
-      __syncthreads();
-    }
-    if (t == 0) store_xyzz(partial, s0, sh[0]);
-  }
-}
-
 // grid = K workgroups of T threads (T = min(256, nbw)); window sum = Σ_{idx} (idx+1)·B_idx
 template <class F>
 __global__ void __launch_bounds__(256) k_reduce(const uint32_t* __restrict__ partial, const uint32_t* __restrict__ counts,
@@ -754,7 +749,7 @@ hipError_t msm_launch(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_ba
     hipLaunchKernelGGL(k_hist<S>, dim3(gs), dim3(TB), 0, stream, d_scalars, n, scalars_mont, split_ones, pl.c, pl.K, bstride, ws.counts);
   }
   VZ_EV(1);
-  hipLaunchKernelGGL(k_scan<MSM_SUB>, dim3(1), dim3(1024), 0, stream, ws.counts, pl.nb, ws.bucket_off, ws.sub_off, ws.totals, sub);
+  hipLaunchKernelGGL(k_scan<MSM_SUB>, dim3(1), dim3(1024), 0, stream, ws.counts, pl.nb, ws.bucket_off, ws.sub_off, ws.totals, sub, ws.heavy, MSM_HEAVY, MsmWorkspace::HEAVY_CAP);
   VZ_EV(2);
   if (lds_sort)
     hipLaunchKernelGGL(k_scatter_lds<S>, dim3(SORT_BLOCKS), dim3(SORT_THREADS), pl.nb * 4, stream, d_scalars, n, scalars_mont, split_ones, pl.c, pl.K, bstride, pl.nb,
@@ -768,10 +763,10 @@ hipError_t msm_launch(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_ba
   hipLaunchKernelGGL(k_accum<F>, dim3(ga), dim3(TB), 0, stream, d_bases, ws.sorted, ws.bucket_off, ws.sub_off, pl.nb,
                      ws.totals, partial, sub);
   VZ_EV(4);
-  hipLaunchKernelGGL(k_combine<F>, dim3((pl.nb + 15) / 16), dim3(256), 0, stream, partial, ws.sub_off, pl.nb, ws.heavy, MsmWorkspace::HEAVY_CAP);
-  hipLaunchKernelGGL(k_combine_heavy1<F>, dim3(2048), dim3(256), 0, stream, partial, ws.sub_off, ws.heavy, MsmWorkspace::HEAVY_CAP, ws.heavy_scratch);
+  const unsigned nbn = (pl.nb + 15) / 16;
+  hipLaunchKernelGGL(k_combine<F>, dim3(nbn + COMBINE_HEAVY_BLOCKS + COMBINE_SPLIT_BLOCKS), dim3(256), 0, stream, partial, ws.sub_off, pl.nb, nbn,
+                     (const uint32_t*)ws.heavy, MsmWorkspace::HEAVY_CAP, ws.heavy_scratch);
   hipLaunchKernelGGL(k_combine_heavy2<F>, dim3(MSM_HEAVY_SPLIT / 8), dim3(256), 0, stream, partial, ws.sub_off, ws.heavy, MsmWorkspace::HEAVY_CAP, ws.heavy_scratch);
-  hipLaunchKernelGGL(k_combine_heavy<F>, dim3(1024), dim3(256), 0, stream, partial, ws.sub_off, ws.heavy, MsmWorkspace::HEAVY_CAP, MSM_HEAVY_SPLIT);
   VZ_EV(5);
   const unsigned T = pl.nbw < 256 ? pl.nbw : 256;
   uint32_t* wsum = reinterpret_cast<uint32_t*>(ws.window_sums);
