@@ -80,3 +80,31 @@ def test_fold_external_witnesses_of_loaded_r1cs(oracle, hash_circuit):
             P.fold(np.stack(inputs[:1]))
     finally:
         P.close(); ck.free(); ctx.close()
+
+
+@pytest.mark.gpu
+def test_ivc_over_a_loaded_r1cs_with_external_witnesses(oracle, hash_circuit):
+    """The same seam in IVC mode: a circom-style .r1cs gets Nova's verifier circuit appended (vimz_ivc_create works on any step
+    circuit in the [1 | out | in | ...] layout), its .wtns witnesses are folded with vimz_ivc_fold_witness, the proof verifies."""
+    from vimz_amd import _lib, hip
+    c = hash_circuit
+    loaded = Circuit.from_r1cs(_to_r1cs_bytes(c))
+    z0, inputs = step_inputs("hash")
+    z, wits = list(z0), []
+    for i in range(5):
+        _, w, z = witness_execute(oracle, c, z, inputs[i])
+        wits.append(wtns_load(_iden3.write_wtns(w)))
+    ctx = hip.Context(0)
+    ck1 = ctx.bases_generate(_lib.CURVE_BN254_G1, 1 << 14)
+    ck2 = ctx.bases_generate(_lib.CURVE_GRUMPKIN, 1 << 13, b"ck-secondary")
+    ivc = hip.IVC(ctx, loaded, ck1, ck2, max_batch=2)
+    try:
+        ivc.reset(z0)
+        ivc.fold_witness(np.stack(wits))
+        assert ivc.verify() == 0 and ivc.state() == (z, 5)
+        with pytest.raises(_lib.VimzError):
+            ivc.fold(np.stack(inputs[:1]))               # a loaded circuit has no witness program
+        with pytest.raises(_lib.VimzError):
+            ivc.fold_witness(np.stack([wits[0]]))        # does not continue the chain
+    finally:
+        ivc.close(); ck1.free(); ck2.free(); ctx.close()
