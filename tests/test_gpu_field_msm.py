@@ -92,6 +92,21 @@ def test_msm_small_all_curves(ctx, oracle, cid, n):
     _msm_case(ctx, oracle, cid, n, sc)
 
 
+@pytest.mark.parametrize("n", [1535, 1536, 1537, 7709, 24576, 24577])
+@pytest.mark.parametrize("kind", ["dense", "witness"])
+def test_msm_around_the_fused_kernel_boundaries(ctx, oracle, n, kind):
+    """Sizes at the edges of the single-launch small MSM (1536 points per workgroup chunk, 24 576 points in all) and just past
+    it (general pipeline with short sub-buckets), for dense scalars and for witness-like ones (mostly 0/1 and bytes)."""
+    r = MODULI[CURVE_SCALAR[1]]
+    rng = random.Random(f"{n}-{kind}")
+    if kind == "dense":
+        sc = [rng.randrange(r) for _ in range(n)]
+    else:
+        sc = [rng.choice([0, 1, 1, 1, rng.randrange(256), rng.randrange(r)]) for _ in range(n)]
+        sc[-1] = r - 1
+    _msm_case(ctx, oracle, 1, n, sc)
+
+
 def test_msm_empty(ctx, oracle):
     B = ctx.bases_upload(0, oracle.seq_bases(0, 4))
     assert tuple(from_limbs(ctx.msm(B, np.zeros((0, 4), dtype=np.uint64)))) == (0, 0)
