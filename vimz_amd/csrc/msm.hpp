@@ -314,7 +314,6 @@ __global__ void __launch_bounds__(256) k_tree256(const uint32_t* __restrict__ in
   if (t == 0) store_xyzz(out, blockIdx.x, sh[0]);
 }
 
-constexpr uint32_t MSM_HEAVY = 64;   // buckets with more sub-buckets than this are combined by a whole workgroup
 
 constexpr uint32_t MSM_HEAVY_PARTS = 32, MSM_HEAVY_SPLIT = 1024;
 constexpr uint32_t MSM_HEAVY_SPLIT_MIN = 2048;   // buckets with fewer partials than this are left to one workgroup (one tree, no second stage)
@@ -322,7 +321,7 @@ constexpr uint32_t COMBINE_HEAVY_BLOCKS = 512, COMBINE_SPLIT_BLOCKS = 1024;
 
 // ONE launch folds every bucket's sub-bucket partials into partial[sub_off[b]], three kinds of workgroups side by side
 // (they touch disjoint buckets, and run as separate kernels they cost three serial tails of dependent additions):
-//   blocks [0, nbn)                      ordinary buckets (<= MSM_HEAVY partials): 16 lanes per bucket, strided sums + 4-level LDS tree;
+//   blocks [0, nbn)                      ordinary buckets (<= heavy_min partials): 2..16 lanes per bucket, strided sums + a short LDS tree;
 //   next COMBINE_HEAVY_BLOCKS            heavy buckets (list written by k_scan), one workgroup each: strided sums + 8-level tree;
 //   next COMBINE_SPLIT_BLOCKS            very heavy buckets (>= MSM_HEAVY_SPLIT_MIN partials; among the first MSM_HEAVY_SPLIT of the list):
 //                                        stage 1 of a two-stage fold, MSM_HEAVY_PARTS workgroups per bucket into a scratch row
@@ -331,27 +330,34 @@ constexpr uint32_t COMBINE_HEAVY_BLOCKS = 512, COMBINE_SPLIT_BLOCKS = 1024;
 // of a dense MSM meet in one or two buckets; repeated cross-term values and the small values of a witness add hot buckets.
 template <class F>
 __global__ void __launch_bounds__(256) k_combine(uint32_t* __restrict__ partial, const uint32_t* __restrict__ sub_off, uint32_t nb, uint32_t nbn,
-                                                 const uint32_t* __restrict__ heavy, uint32_t heavy_cap, uint32_t* __restrict__ scratch) {
+                                                 const uint32_t* __restrict__ heavy, uint32_t heavy_cap, uint32_t* __restrict__ scratch,
+                                                 uint32_t lane_bits /* log2 of the lanes per ordinary bucket: 0..4 */, uint32_t heavy_min) {
   __shared__ XYZZ<F> sh[256];
   const uint32_t t = threadIdx.x;
   if (blockIdx.x < nbn) {
-    const uint32_t lane = t & 15u;
-    const uint32_t b = blockIdx.x * 16u + (t >> 4);
+    // The lanes of a bucket are idle for most of an LDS tree (8, 4, 2, 1 of 16 active), and an addition costs the wave the same
+    // whether one lane or all of them take part: the host picks few lanes per bucket (about a third of the mean number of
+    // partials), so the strided sums — where every lane works — carry most of the additions and the tree is short.
+    const uint32_t L = 1u << lane_bits, lane = t & (L - 1u);
+    const uint32_t b = blockIdx.x * (256u >> lane_bits) + (t >> lane_bits);
     uint32_t s0 = 0, m = 0;
     if (b < nb) { s0 = sub_off[b]; m = sub_off[b + 1] - s0; }
-    if (m > MSM_HEAVY) m = 0;                                 // on k_scan's list: another workgroup of this launch folds it
+    if (m > heavy_min && heavy[0] <= heavy_cap) m = 0;        // on k_scan's list: another workgroup of this launch folds it
+                                                              // (a list that overflowed is ignored: every bucket is folded here)
+    if (!__syncthreads_or(m >= 2 ? 1 : 0)) return;            // nothing to fold among this workgroup's buckets
     XYZZ<F> acc = XYZZ<F>::identity();
-    for (uint32_t k = lane; k < m; k += 16) { XYZZ<F> q = load_xyzz<F>(partial, s0 + k); add_full(acc, q); }
+    if (lane < m) acc = load_xyzz<F>(partial, s0 + lane);
+    for (uint32_t k = lane + L; k < m; k += L) { XYZZ<F> q = load_xyzz<F>(partial, s0 + k); add_full(acc, q); }
     sh[t] = acc;
     __syncthreads();
-    for (uint32_t d = 8; d > 0; d >>= 1) {
+    for (uint32_t d = L >> 1; d > 0; d >>= 1) {
       if (lane < d && lane + d < m) { XYZZ<F> a = sh[t]; add_full(a, sh[t + d]); sh[t] = a; }
       __syncthreads();
     }
     if (lane == 0 && m >= 2) store_xyzz(partial, s0, sh[t]);
     return;
   }
-  const uint32_t count = min(heavy[0], heavy_cap);
+  const uint32_t count = heavy[0] <= heavy_cap ? heavy[0] : 0u;
   if (blockIdx.x < nbn + COMBINE_HEAVY_BLOCKS) {
     for (uint32_t h = blockIdx.x - nbn; h < count; h += COMBINE_HEAVY_BLOCKS) {
       const uint32_t b = heavy[1 + h];
@@ -394,7 +400,7 @@ template <class F>
 __global__ void __launch_bounds__(256) k_combine_heavy2(uint32_t* __restrict__ partial, const uint32_t* __restrict__ sub_off,
                                                         const uint32_t* __restrict__ heavy, uint32_t heavy_cap, const uint32_t* __restrict__ scratch) {
   __shared__ XYZZ<F> sh[256];
-  const uint32_t count = min(min(heavy[0], heavy_cap), MSM_HEAVY_SPLIT), t = threadIdx.x, lane = t & 31u;
+  const uint32_t count = heavy[0] <= heavy_cap ? min(heavy[0], MSM_HEAVY_SPLIT) : 0u, t = threadIdx.x, lane = t & 31u;
   const uint32_t h = blockIdx.x * 8u + (t >> 5);
   bool mine = false;
   if (h < count) { const uint32_t b = heavy[1 + h]; mine = sub_off[b + 1] - sub_off[b] >= MSM_HEAVY_SPLIT_MIN; }
@@ -749,7 +755,14 @@ hipError_t msm_launch(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_ba
     hipLaunchKernelGGL(k_hist<S>, dim3(gs), dim3(TB), 0, stream, d_scalars, n, scalars_mont, split_ones, pl.c, pl.K, bstride, ws.counts);
   }
   VZ_EV(1);
-  hipLaunchKernelGGL(k_scan<MSM_SUB>, dim3(1), dim3(1024), 0, stream, ws.counts, pl.nb, ws.bucket_off, ws.sub_off, ws.totals, sub, ws.heavy, MSM_HEAVY, MsmWorkspace::HEAVY_CAP);
+  // lanes per ordinary bucket in k_combine, from the mean number of partials per bucket (upper bound: every digit non-zero): two
+  // lanes up to ~24 partials (measured at 312 k dense points, 19 per bucket: 16 lanes 0.28 ms, 8: 0.155, 4: 0.137, 2: 0.117;
+  // one lane and a heavy list of every bucket: 3.5 ms); buckets above 16 partials per lane go to the heavy list
+  const size_t mean_parts = entries / sub / pl.nb + 1;
+  static const int lane_bits_env = getenv("VIMZ_DEBUG_COMBINE_LANE_BITS") ? atoi(getenv("VIMZ_DEBUG_COMBINE_LANE_BITS")) : -1;
+  const uint32_t lane_bits = lane_bits_env >= 0 ? (uint32_t)lane_bits_env : mean_parts > 96 ? 4u : mean_parts > 48 ? 3u : mean_parts > 24 ? 2u : 1u;
+  const uint32_t heavy_min = 16u << lane_bits;
+  hipLaunchKernelGGL(k_scan<MSM_SUB>, dim3(1), dim3(1024), 0, stream, ws.counts, pl.nb, ws.bucket_off, ws.sub_off, ws.totals, sub, ws.heavy, heavy_min, MsmWorkspace::HEAVY_CAP);
   VZ_EV(2);
   if (lds_sort)
     hipLaunchKernelGGL(k_scatter_lds<S>, dim3(SORT_BLOCKS), dim3(SORT_THREADS), pl.nb * 4, stream, d_scalars, n, scalars_mont, split_ones, pl.c, pl.K, bstride, pl.nb,
@@ -763,9 +776,9 @@ hipError_t msm_launch(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_ba
   hipLaunchKernelGGL(k_accum<F>, dim3(ga), dim3(TB), 0, stream, d_bases, ws.sorted, ws.bucket_off, ws.sub_off, pl.nb,
                      ws.totals, partial, sub);
   VZ_EV(4);
-  const unsigned nbn = (pl.nb + 15) / 16;
+  const unsigned per_wg = 256u >> lane_bits, nbn = (pl.nb + per_wg - 1) / per_wg;
   hipLaunchKernelGGL(k_combine<F>, dim3(nbn + COMBINE_HEAVY_BLOCKS + COMBINE_SPLIT_BLOCKS), dim3(256), 0, stream, partial, ws.sub_off, pl.nb, nbn,
-                     (const uint32_t*)ws.heavy, MsmWorkspace::HEAVY_CAP, ws.heavy_scratch);
+                     (const uint32_t*)ws.heavy, MsmWorkspace::HEAVY_CAP, ws.heavy_scratch, lane_bits, heavy_min);
   hipLaunchKernelGGL(k_combine_heavy2<F>, dim3(MSM_HEAVY_SPLIT / 8), dim3(256), 0, stream, partial, ws.sub_off, ws.heavy, MsmWorkspace::HEAVY_CAP, ws.heavy_scratch);
   VZ_EV(5);
   const unsigned T = pl.nbw < 256 ? pl.nbw : 256;
