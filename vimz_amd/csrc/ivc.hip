@@ -28,7 +28,7 @@ namespace {
 struct SecDev {                    // secondary circuit on the device (field BN254 Fq, commitments on Grumpkin)
   CsrDev A{}, B{}, C{};
   const uint32_t* dict = nullptr;
-  const uint32_t* long_items = nullptr; uint32_t n_long = 0;
+  const uint32_t* long_items = nullptr; uint32_t n_long = 0, n_med = 0;
   uint32_t n_w = 0, n_c = 0;
   uint32_t *Zrun = nullptr, *E = nullptr, *AZ = nullptr, *BZ = nullptr, *CZ = nullptr;   // running instance
   uint32_t *z2 = nullptr, *az2 = nullptr, *bz2 = nullptr, *cz2 = nullptr, *T = nullptr;  // fresh instance, cross term
@@ -48,8 +48,7 @@ template <class F>
 void sec_spmv(const SecDev& S, hipStream_t s, const uint32_t* z, uint32_t* az, uint32_t* bz, uint32_t* cz) {
   hipLaunchKernelGGL(k_spmv3<F>, dim3(stream_grid(3 * (size_t)S.n_c)), dim3(256), 0, s, S.A, S.B, S.C, S.dict, (size_t)S.n_c, z, az, bz, cz);
   if (S.n_long) {
-    const unsigned blocks = (unsigned)std::min<uint32_t>((S.n_long + 3) / 4, 4096);
-    hipLaunchKernelGGL(k_spmv_long<F>, dim3(blocks), dim3(256), 0, s, S.A, S.B, S.C, S.dict, S.long_items, S.n_long, z, az, bz, cz);
+    hipLaunchKernelGGL(k_spmv_long<F>, dim3(spmv_long_blocks(S.n_long, S.n_med)), dim3(256), 0, s, S.A, S.B, S.C, S.dict, S.long_items, S.n_long, S.n_med, z, az, bz, cz);
   }
 }
 
@@ -66,11 +65,16 @@ struct vimz_ivc {
   const vimz_bases *ck1 = nullptr, *ck2 = nullptr;
   SecDev sec;
   std::vector<void*> owned;
-  char* pin = nullptr;                            // pinned: 4 MSM results, then staging for the two host-made witnesses
+  char* pin = nullptr;                            // pinned: 5 MSM results, then staging for the two host-made witnesses
   size_t pin_res = 0, pin_totals = 0;
-  MsmPlan plan_aug{}, plan_T1{}, plan_W2{}, plan_T2{};
+  MsmPlan plan_aug{}, plan_T1{}, plan_T1v{}, plan_W2{}, plan_T2{};
   // the witness commitment and the cross-term commitment of one instance are independent: they run side by side
   hipStream_t s2 = nullptr; hipEvent_t ev_fork = nullptr; MsmWorkspace ws2;
+  // the step rows of the primary cross term need the folded running instance and the producer's products only — not the
+  // verifier circuit of their step: they are queued on a third stream right behind the previous fold and run under the
+  // secondary half of that step and the host's verifier circuit
+  hipStream_t s3 = nullptr; hipEvent_t ev_fold = nullptr; MsmWorkspace ws3;
+  bool t1_step_pending = false;
   // host state of the recursion
   uint64_t i = 0;
   Fe pz1 = Fe::zero(); Fq pz2 = Fq::zero();
@@ -118,7 +122,7 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
   std::lock_guard<std::mutex> g(ctx->mu);
   P_TRY(hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
-  const size_t nw = p->n_wires, nc = p->n_c, sw = p->step_wires;
+  const size_t nw = p->n_wires, nc = p->n_c, sw = p->step_wires, sc = p->step_c;
   const size_t aw1 = v->c1->aug_wires();
   SecDev& S = v->sec;
   int rc;
@@ -127,10 +131,24 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
   if ((rc = fold_prepare(p, job))) return rc;
   const std::vector<Fe>& zs = job.zs;
   const size_t pin_stride = FoldJob::pin_stride;
-  char* pin_aug1 = v->pin + 4 * v->pin_res;
+  char* pin_aug1 = v->pin + 5 * v->pin_res;
   char* pin_w2 = pin_aug1 + 32 * aw1;
   const Fq zero_q = Fq::zero();
 
+  // cross term of the step rows of (running instance, fresh row `row` of batch buffer `b2`) and its commitment, on stream 3
+  // behind everything queued on the main stream so far (the fold that produced the running instance)
+  auto launch_T1_step = [&](decltype(p->buf[0])& b2, size_t row) -> int {
+    P_TRY(hipEventRecord(v->ev_fold, s));
+    P_TRY(hipStreamWaitEvent(v->s3, v->ev_fold, 0));
+    P_TRY(hipStreamWaitEvent(v->s3, b2.ev[row], 0));
+    hipLaunchKernelGGL(k_cross_term<Fr>, dim3(stream_grid(sc)), dim3(256), 0, v->s3, sc, p->AZ, p->BZ, p->CZ, v->u1_run,
+                       b2.az + 8 * row * nc, b2.bz + 8 * row * nc, b2.cz + 8 * row * nc, Fe::one(), p->T);
+    P_TRY(hipGetLastError());
+    P_TRY(msm_launch<BnG1>(v->s3, v->ws3, p->ck->d, p->T, sc, 1, 0, v->pin + v->pin_res, &v->plan_T1, ctx->profiling ? ctx->ev : nullptr, 0, p->ck->tables ? &job.tbl : nullptr));
+    if (ctx->profiling) P_TRY(hipMemcpyAsync(v->pin + v->pin_totals, v->ws3.totals, 8, hipMemcpyDeviceToHost, v->s3));   // (pinned: stays asynchronous)
+    v->t1_step_pending = true;
+    return VIMZ_OK;
+  };
   if ((rc = fold_issue(p, job, 0))) return rc;
   for (size_t k = 0; k < job.nbatches; k++) {
     auto& bb = p->buf[k & 1];
@@ -142,6 +160,7 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
     for (size_t r = 0; r < rows; r++) if (bb.status_host[r]) {
       char msg[128]; snprintf(msg, sizeof(msg), "step %llu: the step relation is not satisfiable for these rows", (unsigned long long)(v->i + r));
       hipStreamSynchronize(p->sB);
+      hipStreamSynchronize(v->s3); v->t1_step_pending = false;     // (the step rows of this batch's first row were queued ahead)
       // the batches folded so far stay folded: leave the IVC consistent at that point (state, pending secondary commitments)
       finish_secondary(v);
       for (uint32_t q = 0; q < p->len_z; q++) p->z_cur[q] = zs[first * p->len_z + q];
@@ -183,10 +202,12 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
       P_TRY(msm_launch<BnG1>(v->s2, v->ws2, p->ck->d + (size_t)AFFINE_WORDS * (sw - 1), Zi + 8 * sw, aw1 - 2, 1, 0, v->pin, &v->plan_aug, nullptr, 0, nullptr));
       // ---- 3. NIFS on the primary curve ------------------------------------------------------------------------------------------------
       if (i > 0) {
-        hipLaunchKernelGGL(k_cross_term<Fr>, dim3(stream_grid(nc)), dim3(256), 0, s, nc, p->AZ, p->BZ, p->CZ, v->u1_run, az, bz, cz, Fe::one(), p->T);
+        if (!v->t1_step_pending && (rc = launch_T1_step(bb, r))) return rc;       // first row of a call: nothing was queued ahead
+        // the verifier rows of the cross term, and their commitment over the matching slice of ck (a small MSM)
+        hipLaunchKernelGGL(k_cross_term<Fr>, dim3(stream_grid(nc - sc)), dim3(256), 0, s, nc - sc, p->AZ + 8 * sc, p->BZ + 8 * sc, p->CZ + 8 * sc, v->u1_run,
+                           az + 8 * sc, bz + 8 * sc, cz + 8 * sc, Fe::one(), p->T + 8 * sc);
         P_TRY(hipGetLastError());
-        P_TRY(msm_launch<BnG1>(s, ctx->msm_ws, p->ck->d, p->T, nc, 1, 0, v->pin + v->pin_res, &v->plan_T1, ctx->profiling ? ctx->ev : nullptr, 0, p->ck->tables ? &job.tbl : nullptr));
-        if (ctx->profiling) P_TRY(hipMemcpyAsync(v->pin + v->pin_totals, ctx->msm_ws.totals, 8, hipMemcpyDeviceToHost, s));   // (pinned: stays asynchronous)
+        P_TRY(msm_launch<BnG1>(s, ctx->msm_ws, p->ck->d + (size_t)AFFINE_WORDS * sc, p->T + 8 * sc, nc - sc, 1, 0, v->pin + 4 * v->pin_res, &v->plan_T1v, nullptr, 0, nullptr));
       }
       v->ph_s[IP_LAUNCH] += now_s() - t0;
       t0 = now_s();
@@ -210,7 +231,17 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
       G1 sum = from_affine(cW_step); add_mixed(sum, cW_aug);
       FreshInst<Fq> u1; u1.W = to_affine(sum); u1.x0 = cross_field<Fq>(o1.x0); u1.x1 = cross_field<Fq>(o1.x1);
       G1Aff T1; T1.x = Fq::zero(); T1.y = Fq::zero();
-      if (i > 0) T1 = msm_finish<BnG1>(v->plan_T1, v->pin + v->pin_res);
+      if (i > 0) {
+        G1Aff Tv = msm_finish<BnG1>(v->plan_T1v, v->pin + 4 * v->pin_res);      // overlaps the rest of the large MSM
+        v->ph_s[IP_SYNTH2] += now_s() - t0;
+        t0 = now_s();
+        P_TRY(hipStreamSynchronize(v->s3));
+        v->ph_s[IP_WAIT_PRI] += now_s() - t0;
+        v->t1_step_pending = false;
+        G1 ts = from_affine(msm_finish<BnG1>(v->plan_T1, v->pin + v->pin_res)); add_mixed(ts, Tv);
+        T1 = to_affine(ts);
+        t0 = now_s();
+      }
       {
         static const bool dbgp = getenv("VIMZ_DEBUG_CHECK_POINTS") != nullptr;
         if (dbgp) {
@@ -234,7 +265,7 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
         for (int q = 0; q < 6; q++) { P_TRY(hipEventElapsedTime(&ms[q], ctx->ev[q], ctx->ev[q + 1])); ctx->last_msm.ms[q] = ms[q]; ctx->msm_tot_ms[q] += ms[q]; }
         memcpy(&ctx->last_msm.subs, v->pin + v->pin_totals, 8);
         ctx->last_msm.c = v->plan_T1.c; ctx->last_msm.K = v->plan_T1.K;
-        ctx->msm_tot_calls++; ctx->msm_tot_points += nc; ctx->msm_tot_entries += ctx->last_msm.entries;
+        ctx->msm_tot_calls++; ctx->msm_tot_points += sc; ctx->msm_tot_entries += ctx->last_msm.entries;
       }
       // ---- 4. secondary verifier circuit on the host: folds (U1, u1) ---------------------------------------------------------------------
       AugIn<BnFq> in2; in2.pz = v->pz2; in2.i = i; in2.U = v->U1; in2.u = u1; in2.T = T1;
@@ -253,6 +284,9 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
         f.x1[4] = p->CZ; f.x2[4] = cz; f.n[4] = nc;
         hipLaunchKernelGGL(k_fold5<Fr>, dim3(2048), dim3(256), 0, s, f, rho1);
         v->u1_run = Fe::add(v->u1_run, rho1);
+        // the next step's large MSM starts here
+        if (r + 1 < rows) { if ((rc = launch_T1_step(bb, r + 1))) return rc; }
+        else if (k + 1 < job.nbatches) { if ((rc = launch_T1_step(p->buf[(k + 1) & 1], 0))) return rc; }
       }
       v->U1 = o2.U_new;
       // fresh secondary instance on the device: [1 | z_out | z_in | verifier wires]
@@ -305,8 +339,10 @@ void vimz_ivc_free(vimz_ivc* v) {
     hipSetDevice(v->ctx->device);
     hipStreamSynchronize(v->ctx->stream);
     if (v->s2 && v->s2 != v->ctx->stream) { hipStreamSynchronize(v->s2); hipStreamDestroy(v->s2); }
+    if (v->s3 && v->s3 != v->ctx->stream) { hipStreamSynchronize(v->s3); hipStreamDestroy(v->s3); }
     if (v->ev_fork) hipEventDestroy(v->ev_fork);
-    v->ws2.release();
+    if (v->ev_fold) hipEventDestroy(v->ev_fold);
+    v->ws2.release(); v->ws3.release();
     for (void* d : v->owned) hipFree(d);
     if (v->pin) hipHostFree(v->pin);
   }
@@ -350,6 +386,7 @@ int vimz_ivc_create(vimz_ctx* ctx, const vimz_circuit* step_circuit, const vimz_
     for (uint32_t m = 0; m < 3; m++)
       for (uint32_t r = 0; r + 1 < Ms[m]->row_ptr.size(); r++)
         if (Ms[m]->row_ptr[r + 1] - Ms[m]->row_ptr[r] > SPMV_LONG) items.push_back((m << 30) | r);
+    S.n_med = spmv_sort_items(items, [&](uint32_t it) { const cb::Csr* M = Ms[it >> 30]; const uint32_t r = it & 0x3fffffffu; return M->row_ptr[r + 1] - M->row_ptr[r]; });
     S.n_long = (uint32_t)items.size();
     UP2(items, S.long_items);
   }
@@ -363,9 +400,12 @@ int vimz_ivc_create(vimz_ctx* ctx, const vimz_circuit* step_circuit, const vimz_
   { int lo = 0, hi = 0; hipDeviceGetStreamPriorityRange(&lo, &hi);
     if (getenv("VIMZ_DEBUG_NO_S2")) v->s2 = ctx->stream;
     else if ((e = hipStreamCreateWithPriority(&v->s2, hipStreamNonBlocking, hi)) != hipSuccess) return fail("stream");
-    if ((e = hipEventCreateWithFlags(&v->ev_fork, hipEventDisableTiming)) != hipSuccess) return fail("event"); }
+    if (getenv("VIMZ_DEBUG_NO_S2")) v->s3 = ctx->stream;
+    else if ((e = hipStreamCreateWithPriority(&v->s3, hipStreamNonBlocking, (lo + hi) / 2)) != hipSuccess) return fail("stream");
+    if ((e = hipEventCreateWithFlags(&v->ev_fork, hipEventDisableTiming)) != hipSuccess) return fail("event");
+    if ((e = hipEventCreateWithFlags(&v->ev_fold, hipEventDisableTiming)) != hipSuccess) return fail("event"); }
   v->pin_res = 4 * (size_t)XYZZ_WORDS * MSM_MAX_WINDOWS;
-  v->pin_totals = 4 * v->pin_res + 32 * (size_t)v->c1->aug_wires() + 32 * (size_t)nw2;
+  v->pin_totals = 5 * v->pin_res + 32 * (size_t)v->c1->aug_wires() + 32 * (size_t)nw2;
   if ((e = hipHostMalloc((void**)&v->pin, v->pin_totals + 64)) != hipSuccess) return fail("pinned");
   if ((e = hipStreamSynchronize(nullptr)) != hipSuccess) return fail("sync");   // the hipMemset fills above ran on the null stream
   v->z0.assign(v->c1->len_z, Fe::zero());
@@ -395,7 +435,7 @@ int vimz_ivc_reset(vimz_ivc* v, const uint64_t* z0) {
   v->pz2 = v->c2.pz(&zq);
   v->U1 = RelaxedInst<Fq>::zero(); v->U2 = RelaxedInst<Fe>::zero(); v->u2 = FreshInst<Fe>::zero(); v->T2.x = v->T2.y = Fe::zero();
   v->u1_run = Fe::zero(); v->u2_run = Fq::zero();
-  v->pending_sec = false; v->sec_T_valid = false;
+  v->pending_sec = false; v->sec_T_valid = false; v->t1_step_pending = false;
   memset(v->ph_s, 0, sizeof(v->ph_s)); memset(v->ph_n, 0, sizeof(v->ph_n));
   return VIMZ_OK;
 }

@@ -69,6 +69,8 @@ int vz_prover_create_layout(vimz_ctx* ctx, const vimz_circuit* circuit, const vi
     for (uint32_t m = 0; m < 3; m++)
       for (uint32_t r = 0; r + 1 < Ms[m]->row_ptr.size(); r++)
         if (Ms[m]->row_ptr[r + 1] - Ms[m]->row_ptr[r] > SPMV_LONG) (r < p->step_c ? items : items_aug).push_back((m << 30) | r);
+    auto terms = [&](uint32_t it) { const cb::Csr* M = Ms[it >> 30]; const uint32_t r = it & 0x3fffffffu; return M->row_ptr[r + 1] - M->row_ptr[r]; };
+    p->n_med = spmv_sort_items(items, terms); p->n_med_aug = spmv_sort_items(items_aug, terms);
     p->n_long = (uint32_t)items.size(); p->n_long_aug = (uint32_t)items_aug.size();
     UP(items, p->long_items); UP(items_aug, p->long_items_aug);
   }

@@ -62,12 +62,12 @@ struct vimz_prover {
   // The batch producer only touches the step part: wires [c0, step_wires) and rows [0, step_c).
   bool ivc = false;
   uint32_t c0 = 0, step_wires = 0, step_c = 0;
-  const uint32_t* long_items_aug = nullptr; uint32_t n_long_aug = 0;   // long (matrix,row) items of the verifier rows
+  const uint32_t* long_items_aug = nullptr; uint32_t n_long_aug = 0, n_med_aug = 0;   // long (matrix,row) items of the verifier rows
   size_t max_batch = 0;
   // device: shape
   CsrDev A{}, B{}, C{};
   const uint32_t* dict = nullptr;
-  const uint32_t* long_items = nullptr; uint32_t n_long = 0;
+  const uint32_t* long_items = nullptr; uint32_t n_long = 0, n_med = 0;   // the first n_med items have <= SPMV_MED terms
   WitnessDev wd{};
   std::vector<void*> owned;   // every device allocation, for cleanup
   // device: batch buffers
@@ -136,8 +136,7 @@ static void launch_spmv(vimz_prover* p, hipStream_t s, const uint32_t* z, uint32
     const size_t rows = p->step_c;
     hipLaunchKernelGGL(k_spmv3<Fr>, dim3(stream_grid(3 * rows)), dim3(256), 0, s, p->A, p->B, p->C, p->dict, rows, z, az, bz, cz);
     if (p->n_long) {
-      const unsigned blocks = (unsigned)std::min<uint32_t>((p->n_long + 3) / 4, 4096);
-      hipLaunchKernelGGL(k_spmv_long<Fr>, dim3(blocks), dim3(256), 0, s, p->A, p->B, p->C, p->dict, p->long_items, p->n_long, z, az, bz, cz);
+      hipLaunchKernelGGL(k_spmv_long<Fr>, dim3(spmv_long_blocks(p->n_long, p->n_med)), dim3(256), 0, s, p->A, p->B, p->C, p->dict, p->long_items, p->n_long, p->n_med, z, az, bz, cz);
     }
   }
   if ((part == 0 || part == 2) && p->n_c > p->step_c) {
@@ -145,8 +144,7 @@ static void launch_spmv(vimz_prover* p, hipStream_t s, const uint32_t* z, uint32
     CsrDev A2{p->A.row_ptr + o, p->A.col, p->A.coef}, B2{p->B.row_ptr + o, p->B.col, p->B.coef}, C2{p->C.row_ptr + o, p->C.col, p->C.coef};
     hipLaunchKernelGGL(k_spmv3<Fr>, dim3(stream_grid(3 * rows)), dim3(256), 0, s, A2, B2, C2, p->dict, rows, z, az + 8 * o, bz + 8 * o, cz + 8 * o);
     if (p->n_long_aug) {
-      const unsigned blocks = (unsigned)std::min<uint32_t>((p->n_long_aug + 3) / 4, 4096);
-      hipLaunchKernelGGL(k_spmv_long<Fr>, dim3(blocks), dim3(256), 0, s, p->A, p->B, p->C, p->dict, p->long_items_aug, p->n_long_aug, z, az, bz, cz);
+      hipLaunchKernelGGL(k_spmv_long<Fr>, dim3(spmv_long_blocks(p->n_long_aug, p->n_med_aug)), dim3(256), 0, s, p->A, p->B, p->C, p->dict, p->long_items_aug, p->n_long_aug, p->n_med_aug, z, az, bz, cz);
     }
   }
 }

@@ -9,6 +9,8 @@
 // All element-wise kernels are HBM streaming kernels: 32 B per element per operand, two 16-byte accesses per lane.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <algorithm>
+#include <vector>
 #include "vecops.hpp"
 
 namespace vz {
@@ -45,31 +47,51 @@ __global__ void __launch_bounds__(256) k_spmv3(CsrDev A, CsrDev B, CsrDev C, con
   }
 }
 
-// One wave per long (matrix,row) item: lanes stride over the terms, then a shuffle tree adds the 64 partial sums.
-// items: packed (matrix << 30 | row).  The long rows are the substituted-bit rows of Num2Bits(240) (240 terms) and
-// the Poseidon partial rounds (up to ~70 terms); with one thread per row they stalled whole waves.
+// Long (matrix,row) items: packed (matrix << 30 | row).  They are the substituted-bit rows of Num2Bits(240) (240 terms), the
+// Poseidon partial rounds (up to ~70 terms) and, nine in ten, rows of 9..32 terms (byte recompositions, full rounds); with one
+// thread per row they stalled whole waves.  The first n_med items (<= SPMV_MED terms, list sorted by the host) get 16 lanes
+// each, four to a wave; the rest one wave each.  Lanes stride over the terms, a shuffle tree adds the partial sums.
+constexpr uint32_t SPMV_MED = 32;
 template <class F>
 __global__ void __launch_bounds__(256) k_spmv_long(CsrDev A, CsrDev B, CsrDev C, const uint32_t* __restrict__ dict, const uint32_t* __restrict__ items,
-                                                   uint32_t n_items, const uint32_t* __restrict__ z, uint32_t* __restrict__ az, uint32_t* __restrict__ bz,
-                                                   uint32_t* __restrict__ cz) {
+                                                   uint32_t n_items, uint32_t n_med, const uint32_t* __restrict__ z, uint32_t* __restrict__ az,
+                                                   uint32_t* __restrict__ bz, uint32_t* __restrict__ cz) {
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
   const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
-  for (uint32_t it = wave; it < n_items; it += nwaves) {
-    const uint32_t packed = items[it], m = packed >> 30, r = packed & 0x3fffffffu;
+  const uint32_t quads = (n_med + 3) >> 2, units = quads + (n_items - n_med);
+  for (uint32_t u = wave; u < units; u += nwaves) {
+    const bool quad = u < quads;
+    const uint32_t it = quad ? 4 * u + (lane >> 4) : n_med + (u - quads);
+    const uint32_t l = quad ? (lane & 15u) : lane, step = quad ? 16u : 64u;
+    const bool live = !quad || it < n_med;
+    const uint32_t packed = live ? items[it] : 0u, m = packed >> 30, r = packed & 0x3fffffffu;
     const CsrDev M = m == 0 ? A : (m == 1 ? B : C);
-    uint32_t* out = m == 0 ? az : (m == 1 ? bz : cz);
-    const uint32_t lo = M.row_ptr[r], hi = M.row_ptr[r + 1];
+    uint32_t lo = 0, hi = 0;
+    if (live) { lo = M.row_ptr[r]; hi = M.row_ptr[r + 1]; }
     F acc = F::zero();
-    for (uint32_t k = lo + lane; k < hi; k += 64) spmv_term<F>(acc, dict, M.coef[k], z, M.col[k]);
+    for (uint32_t k = lo + l; k < hi; k += step) spmv_term<F>(acc, dict, M.coef[k], z, M.col[k]);
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
+      if (quad && off >= 16) continue;                 // (uniform per wave)
       F o;
 #pragma unroll
       for (int w = 0; w < 8; w++) o.v[w] = __shfl_xor(acc.v[w], off);
       acc = F::add(acc, o);
     }
-    if (lane == 0) store_fe(out, r, acc);
+    if (live && l == 0) store_fe(m == 0 ? az : (m == 1 ? bz : cz), r, acc);
   }
+}
+// Host side of the list: items of at most SPMV_MED terms first; returns their number.
+template <class Len>
+inline uint32_t spmv_sort_items(std::vector<uint32_t>& items, Len term_count) {
+  std::vector<uint32_t> med, lng;
+  for (uint32_t it : items) (term_count(it) <= SPMV_MED ? med : lng).push_back(it);
+  items = med; items.insert(items.end(), lng.begin(), lng.end());
+  return (uint32_t)med.size();
+}
+inline unsigned spmv_long_blocks(uint32_t n_items, uint32_t n_med) {
+  const uint32_t units = (n_med + 3) / 4 + (n_items - n_med);
+  return (unsigned)std::min<uint32_t>((units + 3) / 4, 4096);
 }
 
 template <class F>
