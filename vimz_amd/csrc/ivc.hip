@@ -75,6 +75,9 @@ struct vimz_ivc {
   // secondary half of that step and the host's verifier circuit
   hipStream_t s3 = nullptr; hipEvent_t ev_fold = nullptr; MsmWorkspace ws3;
   bool t1_step_pending = false;
+  // window tables (2^(7w)·P_i) of the three base slices the per-step small MSMs run over: verifier wires and verifier rows of
+  // ck1, the head of ck2.  Their window sums only need adding: no 254 doublings on the host per commitment (23 MB each)
+  BaseTables tb_aug{}, tb_T1v{}, tb_ck2{};
   // host state of the recursion
   uint64_t i = 0;
   Fe pz1 = Fe::zero(); Fq pz2 = Fq::zero();
@@ -137,8 +140,8 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
 
   // cross term of the step rows of (running instance, fresh row `row` of batch buffer `b2`) and its commitment, on stream 3
   // behind everything queued on the main stream so far (the fold that produced the running instance)
-  auto launch_T1_step = [&](decltype(p->buf[0])& b2, size_t row) -> int {
-    P_TRY(hipEventRecord(v->ev_fold, s));
+  auto launch_T1_step = [&](decltype(p->buf[0])& b2, size_t row, bool record) -> int {
+    if (record) P_TRY(hipEventRecord(v->ev_fold, s));
     P_TRY(hipStreamWaitEvent(v->s3, v->ev_fold, 0));
     P_TRY(hipStreamWaitEvent(v->s3, b2.ev[row], 0));
     hipLaunchKernelGGL(k_cross_term<Fr>, dim3(stream_grid(sc)), dim3(256), 0, v->s3, sc, p->AZ, p->BZ, p->CZ, v->u1_run,
@@ -196,18 +199,18 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
       memcpy(pin_aug1, aug1.data(), 32 * aw1);
       P_TRY(hipStreamWaitEvent(s, bb.ev[r], 0));
       P_TRY(hipMemcpyAsync(Zi + 8 * sw, pin_aug1, 32 * aw1, hipMemcpyHostToDevice, s));
-      launch_spmv(p, s, Zi, az, bz, cz, 2);
+      // the commitment to the verifier wires needs the upload only: it starts first, on stream 2
       P_TRY(hipEventRecord(v->ev_fork, s));
       P_TRY(hipStreamWaitEvent(v->s2, v->ev_fork, 0));
-      P_TRY(msm_launch<BnG1>(v->s2, v->ws2, p->ck->d + (size_t)AFFINE_WORDS * (sw - 1), Zi + 8 * sw, aw1 - 2, 1, 0, v->pin, &v->plan_aug, nullptr, 0, nullptr));
+      P_TRY(msm_launch<BnG1>(v->s2, v->ws2, p->ck->d + (size_t)AFFINE_WORDS * (sw - 1), Zi + 8 * sw, aw1 - 2, 1, 0, v->pin, &v->plan_aug, nullptr, 0, v->tb_aug.d ? &v->tb_aug : nullptr));
       // ---- 3. NIFS on the primary curve ------------------------------------------------------------------------------------------------
+      // verifier rows: (A,B,C)·z and their part of the cross term in one launch, then its commitment over the matching slice of ck
+      hipLaunchKernelGGL(k_spmv_cross16<Fr>, dim3((unsigned)((16 * (nc - sc) + 255) / 256)), dim3(256), 0, s, p->A, p->B, p->C, p->dict, (uint32_t)sc, (uint32_t)(nc - sc),
+                         Zi, az, bz, cz, i > 0 ? p->AZ : nullptr, p->BZ, p->CZ, v->u1_run, Fe::one(), p->T);
+      P_TRY(hipGetLastError());
       if (i > 0) {
-        if (!v->t1_step_pending && (rc = launch_T1_step(bb, r))) return rc;       // first row of a call: nothing was queued ahead
-        // the verifier rows of the cross term, and their commitment over the matching slice of ck (a small MSM)
-        hipLaunchKernelGGL(k_cross_term<Fr>, dim3(stream_grid(nc - sc)), dim3(256), 0, s, nc - sc, p->AZ + 8 * sc, p->BZ + 8 * sc, p->CZ + 8 * sc, v->u1_run,
-                           az + 8 * sc, bz + 8 * sc, cz + 8 * sc, Fe::one(), p->T + 8 * sc);
-        P_TRY(hipGetLastError());
-        P_TRY(msm_launch<BnG1>(s, ctx->msm_ws, p->ck->d + (size_t)AFFINE_WORDS * sc, p->T + 8 * sc, nc - sc, 1, 0, v->pin + 4 * v->pin_res, &v->plan_T1v, nullptr, 0, nullptr));
+        if (!v->t1_step_pending && (rc = launch_T1_step(bb, r, true))) return rc;       // first row of a call: nothing was queued ahead
+        P_TRY(msm_launch<BnG1>(s, ctx->msm_ws, p->ck->d + (size_t)AFFINE_WORDS * sc, p->T + 8 * sc, nc - sc, 1, 0, v->pin + 4 * v->pin_res, &v->plan_T1v, nullptr, 0, v->tb_T1v.d ? &v->tb_T1v : nullptr));
       }
       v->ph_s[IP_LAUNCH] += now_s() - t0;
       t0 = now_s();
@@ -284,9 +287,7 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
         f.x1[4] = p->CZ; f.x2[4] = cz; f.n[4] = nc;
         hipLaunchKernelGGL(k_fold5<Fr>, dim3(2048), dim3(256), 0, s, f, rho1);
         v->u1_run = Fe::add(v->u1_run, rho1);
-        // the next step's large MSM starts here
-        if (r + 1 < rows) { if ((rc = launch_T1_step(bb, r + 1))) return rc; }
-        else if (k + 1 < job.nbatches) { if ((rc = launch_T1_step(p->buf[(k + 1) & 1], 0))) return rc; }
+        P_TRY(hipEventRecord(v->ev_fold, s));      // the next step's large MSM may start here (queued below, behind the secondary's work)
       }
       v->U1 = o2.U_new;
       // fresh secondary instance on the device: [1 | z_out | z_in | verifier wires]
@@ -295,19 +296,20 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
         w2[0] = Fq::one(); w2[1] = zero_q; w2[2] = zero_q;
         memcpy(w2 + 3, aug2.data(), 32 * aug2.size());
         P_TRY(hipMemcpyAsync(S.z2, pin_w2, 32 * (size_t)S.n_w, hipMemcpyHostToDevice, s));
-        sec_spmv<Fq>(S, s, S.z2, S.az2, S.bz2, S.cz2);
         P_TRY(hipEventRecord(v->ev_fork, s));
         P_TRY(hipStreamWaitEvent(v->s2, v->ev_fork, 0));
-        P_TRY(msm_launch<Grumpkin>(v->s2, v->ws2, v->ck2->d, S.z2 + 8, S.n_w - 3, 1, 0, v->pin + 2 * v->pin_res, &v->plan_W2, nullptr, 0, nullptr));
+        P_TRY(msm_launch<Grumpkin>(v->s2, v->ws2, v->ck2->d, S.z2 + 8, S.n_w - 3, 1, 0, v->pin + 2 * v->pin_res, &v->plan_W2, nullptr, 0, v->tb_ck2.d ? &v->tb_ck2 : nullptr));
         v->sec_T_valid = i > 0;    // U2 is still the zero instance after step 0: its cross term with anything is zero
-        if (v->sec_T_valid) {
-          hipLaunchKernelGGL(k_cross_term<Fq>, dim3(stream_grid(S.n_c)), dim3(256), 0, s, (size_t)S.n_c, S.AZ, S.BZ, S.CZ, v->u2_run, S.az2, S.bz2, S.cz2, Fq::one(), S.T);
-          P_TRY(msm_launch<Grumpkin>(s, ctx->msm_ws, v->ck2->d, S.T, S.n_c, 1, 0, v->pin + 3 * v->pin_res, &v->plan_T2, nullptr, 0, nullptr));
-        }
+        hipLaunchKernelGGL(k_spmv_cross16<Fq>, dim3((unsigned)((16 * (size_t)S.n_c + 255) / 256)), dim3(256), 0, s, S.A, S.B, S.C, S.dict, 0u, S.n_c, S.z2, S.az2, S.bz2, S.cz2,
+                           v->sec_T_valid ? S.AZ : nullptr, S.BZ, S.CZ, v->u2_run, Fq::one(), S.T);
+        if (v->sec_T_valid)
+          P_TRY(msm_launch<Grumpkin>(s, ctx->msm_ws, v->ck2->d, S.T, S.n_c, 1, 0, v->pin + 3 * v->pin_res, &v->plan_T2, nullptr, 0, v->tb_ck2.d ? &v->tb_ck2 : nullptr));
         P_TRY(hipGetLastError());
         v->u2.x0 = cross_field<Fe>(o2.x0); v->u2.x1 = cross_field<Fe>(o2.x1);
         v->pending_sec = true;
       }
+      if (r + 1 < rows) { if ((rc = launch_T1_step(bb, r + 1, false))) return rc; }
+      else if (k + 1 < job.nbatches) { if ((rc = launch_T1_step(p->buf[(k + 1) & 1], 0, false))) return rc; }
       v->ph_s[IP_LAUNCH] += now_s() - t0;
       v->i++; p->steps++;
     }
@@ -404,6 +406,26 @@ int vimz_ivc_create(vimz_ctx* ctx, const vimz_circuit* step_circuit, const vimz_
     else if ((e = hipStreamCreateWithPriority(&v->s3, hipStreamNonBlocking, (lo + hi) / 2)) != hipSuccess) return fail("stream");
     if ((e = hipEventCreateWithFlags(&v->ev_fork, hipEventDisableTiming)) != hipSuccess) return fail("event");
     if ((e = hipEventCreateWithFlags(&v->ev_fold, hipEventDisableTiming)) != hipSuccess) return fail("event"); }
+  if (!getenv("VIMZ_DEBUG_NO_SMALL_TABLES")) {
+    const cb::Builder& b1 = v->circ1->build->b;
+    const size_t sw = v->c1->step_wires, sc = v->c1->step_constraints, aw = v->c1->aug_wires();
+    auto make = [&](auto cv, const uint32_t* bases, size_t n, BaseTables* tb) {
+      typedef decltype(cv) C;
+      const int K = (C::Scalar::Params::BITS + SMALL_C) / SMALL_C;
+      if (!n || n > MSM_SMALL_MAX) return hipSuccess;
+      uint32_t* d = nullptr;
+      hipError_t ee = hipMalloc((void**)&d, 4 * (size_t)AFFINE_WORDS * n * K);
+      if (ee != hipSuccess) return ee;
+      v->owned.push_back(d);
+      if ((ee = build_tables<C>(ctx->stream, bases, n, SMALL_C, K, d)) != hipSuccess) return ee;
+      tb->d = d; tb->n_total = n; tb->offset = 0; tb->c = SMALL_C; tb->K = K;
+      return hipSuccess;
+    };
+    if ((e = make(BnG1{}, ck1->d + (size_t)AFFINE_WORDS * (sw - 1), aw - 2, &v->tb_aug)) != hipSuccess) return fail("window tables");
+    if ((e = make(BnG1{}, ck1->d + (size_t)AFFINE_WORDS * sc, b1.n_constraints() - sc, &v->tb_T1v)) != hipSuccess) return fail("window tables");
+    if ((e = make(Grumpkin{}, ck2->d, std::max<size_t>(nw2 - 3, nc2), &v->tb_ck2)) != hipSuccess) return fail("window tables");
+    if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return fail("window tables");
+  }
   v->pin_res = 4 * (size_t)XYZZ_WORDS * MSM_MAX_WINDOWS;
   v->pin_totals = 5 * v->pin_res + 32 * (size_t)v->c1->aug_wires() + 32 * (size_t)nw2;
   if ((e = hipHostMalloc((void**)&v->pin, v->pin_totals + 64)) != hipSuccess) return fail("pinned");

@@ -463,11 +463,10 @@ __global__ void __launch_bounds__(256) k_reduce(const uint32_t* __restrict__ par
 // and point chunk q (<= 1536 points): digits -> counting sort in LDS -> one thread per sub-bucket of <= 8 entries ->
 // segmented tree over a bucket's sub-buckets -> sum_b (b+1)·B_b as the sum of the 64 suffix sums (scan + tree, 12 deep) ->
 // the last workgroup of a window to finish adds the chunk results.  Depth: 8 + log2(max sub-buckets) + 12 + log2(chunks).
-constexpr int SMALL_C = 7;
-constexpr uint32_t SMALL_NBW = 1u << (SMALL_C - 1), SMALL_SUB = 8, SMALL_PER_THREAD = 6, SMALL_CHUNK = 256 * SMALL_PER_THREAD, SMALL_MAXQ = 16;
+// (SMALL_C, SMALL_CHUNK, SMALL_MAXQ, MSM_SMALL_MAX: msm_api.hpp)
+constexpr uint32_t SMALL_NBW = 1u << (SMALL_C - 1), SMALL_SUB = 8, SMALL_PER_THREAD = SMALL_CHUNK / 256;
 // (1536 points per workgroup: at most 1536/8 + 64 = 256 sub-buckets, one per thread; 7.6 k points -> 37 x 5 = 185 workgroups,
 //  fewer than the 256 CUs, so no two workgroups' single-wave scan phases share a SIMD)
-constexpr size_t MSM_SMALL_MAX = (size_t)SMALL_CHUNK * SMALL_MAXQ;
 
 __device__ __forceinline__ int signed_digit(const uint32_t* s, int c, int w) {
   uint32_t carry = 0, d = 0;
@@ -483,7 +482,8 @@ template <class S, class F>
 __global__ void __launch_bounds__(256) k_msm_small(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ scalars, uint32_t n, int mont,
                                                    uint32_t Q, uint32_t chunk, uint32_t* __restrict__ chunk_out /* K*Q points */,
                                                    uint32_t* __restrict__ done /* K counters, zero between launches; nullptr: k_msm_small_sum follows */,
-                                                   uint32_t* __restrict__ window_sums) {
+                                                   uint32_t* __restrict__ window_sums,
+                                                   const uint32_t* __restrict__ tables /* or nullptr: row w holds 2^(7w)·P_i, row length tstride */, uint32_t tstride) {
   __shared__ XYZZ<F> sh[256];
   __shared__ uint32_t cnt[SMALL_NBW], off[SMALL_NBW + 1], soff[SMALL_NBW + 1], cur[SMALL_NBW];
   __shared__ uint16_t list[SMALL_CHUNK];
@@ -491,6 +491,7 @@ __global__ void __launch_bounds__(256) k_msm_small(const uint32_t* __restrict__ 
   __shared__ uint32_t s_maxm, s_ticket;
   const uint32_t t = threadIdx.x, w = blockIdx.x, q = blockIdx.y;
   const uint32_t lo = q * chunk, hi = min(n, lo + chunk);
+  const uint32_t* __restrict__ wbases = tables ? tables + (size_t)AFFINE_WORDS * ((size_t)w * tstride) : bases;
   if (t < SMALL_NBW) { cnt[t] = 0; cur[t] = 0; }
   __syncthreads();
   int dig[SMALL_PER_THREAD];
@@ -532,7 +533,7 @@ __global__ void __launch_bounds__(256) k_msm_small(const uint32_t* __restrict__ 
     const uint32_t beg = off[b] + kk * SMALL_SUB, end = min(off[b + 1], beg + SMALL_SUB);
     for (uint32_t e = beg; e < end; e++) {
       const uint32_t ent = list[e];
-      Affine<F> pt = load_affine<F>(bases, lo + (ent & 0x7fffu));
+      Affine<F> pt = load_affine<F>(wbases, lo + (ent & 0x7fffu));
       if ((ent & 0x8000u) && !aff_is_identity(pt)) pt.y = F::neg(pt.y);
       add_mixed(acc, pt);
     }
@@ -698,10 +699,13 @@ hipError_t msm_launch(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_ba
   typedef typename C::Coord F;
   typedef typename C::Scalar S;
   if (n == 0 || n >= (1u << 31)) return hipErrorInvalidValue;
-  const bool tabled = tb && tb->d && c_override <= 0;
+  // tables made for the fused small path (window SMALL_C): its window sums then only need adding — no Horner on the host
+  const bool small_tb = tb && tb->d && tb->c == SMALL_C;
+  const bool tabled = tb && tb->d && !small_tb && c_override <= 0;
   static const bool no_small = getenv("VIMZ_DEBUG_NO_SMALL_MSM") != nullptr;
+  if (small_tb && (no_small || c_override > 0 || n > MSM_SMALL_MAX || tb->K != (S::Params::BITS + SMALL_C) / SMALL_C)) return hipErrorInvalidValue;
   if (!no_small && !tabled && c_override <= 0 && n <= MSM_SMALL_MAX) {      // fused single-launch path
-    MsmPlan ps; ps.c = SMALL_C; ps.K = (S::Params::BITS + SMALL_C) / SMALL_C; ps.nbw = SMALL_NBW; ps.nb = SMALL_NBW * (uint32_t)ps.K; ps.split_ones = 0; ps.tabled = 0;
+    MsmPlan ps; ps.c = SMALL_C; ps.K = (S::Params::BITS + SMALL_C) / SMALL_C; ps.nbw = SMALL_NBW; ps.nb = SMALL_NBW * (uint32_t)ps.K; ps.split_ones = 0; ps.tabled = small_tb ? 2 : 0;
     *plan_out = ps;
     VZ_HIP_CHECK(ws.reserve_small());
     const uint32_t Q = (uint32_t)((n + SMALL_CHUNK - 1) / SMALL_CHUNK), chunk = (uint32_t)((n + Q - 1) / Q);
@@ -710,7 +714,8 @@ hipError_t msm_launch(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_ba
     if (ev) for (int i = 0; i < 4; i++) VZ_HIP_CHECK(hipEventRecord(ev[i], stream));
     static const bool sum_kernel = getenv("VIMZ_DEBUG_SMALL_SUM_KERNEL") != nullptr;
     hipLaunchKernelGGL((k_msm_small<S, F>), dim3(ps.K, Q), dim3(256), 0, stream, d_bases, d_scalars, (uint32_t)n, scalars_mont, Q, chunk, chunk_out,
-                       sum_kernel ? (uint32_t*)nullptr : done, reinterpret_cast<uint32_t*>(ws.window_sums));
+                       sum_kernel ? (uint32_t*)nullptr : done, reinterpret_cast<uint32_t*>(ws.window_sums),
+                       small_tb ? tb->d + (size_t)AFFINE_WORDS * tb->offset : (const uint32_t*)nullptr, small_tb ? (uint32_t)tb->n_total : 0u);
     if (Q > 1 && sum_kernel) hipLaunchKernelGGL(k_msm_small_sum<F>, dim3(ps.K), dim3(64), 0, stream, chunk_out, Q, reinterpret_cast<uint32_t*>(ws.window_sums));
     if (ev) for (int i = 4; i < 7; i++) VZ_HIP_CHECK(hipEventRecord(ev[i], stream));
     VZ_HIP_CHECK(hipGetLastError());
@@ -818,7 +823,7 @@ Affine<typename C::Base> msm_finish(const MsmPlan& pl, const void* pinned) {
     return p;
   };
   XYZZ<FS> acc = XYZZ<FS>::identity();
-  const int kout = pl.tabled ? 1 : pl.K;
+  const int kout = pl.tabled == 1 ? 1 : pl.K;      // tabled == 2: K sums of one bucket set each, already weighted
   for (int w = kout - 1; w >= 0; w--) {
     if (!pl.tabled) for (int k = 0; k < pl.c; k++) acc = dbl(acc);
     add_full(acc, host_point(w));

@@ -36,8 +36,13 @@ struct MsmPlan {
   uint32_t nbw;     // buckets per window = 2^(c-1)
   uint32_t nb;      // total buckets
   int split_ones;   // unit scalars summed separately (window_sums[K])
-  int tabled;       // window tables: one bucket set, one window sum, no Horner
+  int tabled;       // 1: window tables, one bucket set, one window sum, no Horner; 2: tables of the fused small path (K sums, no Horner)
 };
+
+// The fused single-launch path for small MSMs (k_msm_small): window, points per workgroup chunk, chunks, size limit.
+constexpr int SMALL_C = 7;
+constexpr uint32_t SMALL_CHUNK = 1536, SMALL_MAXQ = 16;
+constexpr size_t MSM_SMALL_MAX = (size_t)SMALL_CHUNK * SMALL_MAXQ;
 
 // Precomputed window tables of a commitment key: d[j][i] = 2^(c j) * P_i, affine internal form, row length n_total.
 struct BaseTables { const uint32_t* d; size_t n_total; size_t offset; int c, K; };

@@ -94,6 +94,48 @@ inline unsigned spmv_long_blocks(uint32_t n_items, uint32_t n_med) {
   return (unsigned)std::min<uint32_t>((units + 3) / 4, 4096);
 }
 
+// (A,B,C)·z over `nrows` rows starting at `row0` and, in the same pass, the cross term of those rows: for the verifier
+// circuits' 7.6 k rows (both curves) the three launches spmv3 -> spmv_long -> cross_term were three latency-bound hops on the
+// critical path of every step.  16 lanes per row: they stride over the terms of A, B and C in turn, a 4-level shuffle butterfly
+// adds the partial sums, lane 0 stores the products and T.  (T is skipped when az1 is null: step 0 folds into the zero instance.)
+template <class F>
+__global__ void __launch_bounds__(256) k_spmv_cross16(CsrDev A, CsrDev B, CsrDev C, const uint32_t* __restrict__ dict, uint32_t row0, uint32_t nrows,
+                                                      const uint32_t* __restrict__ z, uint32_t* __restrict__ az, uint32_t* __restrict__ bz, uint32_t* __restrict__ cz,
+                                                      const uint32_t* __restrict__ az1, const uint32_t* __restrict__ bz1, const uint32_t* __restrict__ cz1, F u1, F u2,
+                                                      uint32_t* __restrict__ T) {
+  const uint32_t g = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, l = threadIdx.x & 15u;
+  const bool live = g < nrows;
+  const uint32_t r = row0 + (live ? g : 0u);
+  F acc[3];
+#pragma unroll
+  for (int m = 0; m < 3; m++) {
+    const CsrDev M = m == 0 ? A : (m == 1 ? B : C);
+    acc[m] = F::zero();
+    if (live) {
+      const uint32_t lo = M.row_ptr[r], hi = M.row_ptr[r + 1];
+      for (uint32_t k = lo + l; k < hi; k += 16) spmv_term<F>(acc[m], dict, M.coef[k], z, M.col[k]);
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < 3; m++) {
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) {
+      F o;
+#pragma unroll
+      for (int w = 0; w < 8; w++) o.v[w] = __shfl_xor(acc[m].v[w], off);
+      acc[m] = F::add(acc[m], o);
+    }
+  }
+  if (!live || l != 0) return;
+  store_fe(az, r, acc[0]); store_fe(bz, r, acc[1]); store_fe(cz, r, acc[2]);
+  if (!az1) return;
+  F t = F::mul(load_fe<F>(az1, r), acc[1]);
+  t = F::add(t, F::mul(acc[0], load_fe<F>(bz1, r)));
+  t = F::sub(t, F::mul(u1, acc[2]));
+  t = F::sub(t, F::mul(u2, load_fe<F>(cz1, r)));
+  store_fe(T, r, t);
+}
+
 template <class F>
 __global__ void __launch_bounds__(256) k_cross_term(size_t n, const uint32_t* __restrict__ az1, const uint32_t* __restrict__ bz1, const uint32_t* __restrict__ cz1, F u1,
                                                     const uint32_t* __restrict__ az2, const uint32_t* __restrict__ bz2, const uint32_t* __restrict__ cz2, F u2,
