@@ -75,6 +75,7 @@ struct vimz_ivc {
   // secondary half of that step and the host's verifier circuit
   hipStream_t s3 = nullptr; hipEvent_t ev_fold = nullptr; MsmWorkspace ws3;
   bool t1_step_pending = false;
+  hipEvent_t ev_b0 = nullptr, ev_b1 = nullptr;   // profiling: GPU time of the secondary half on the main stream
   // window tables (2^(7w)·P_i) of the three base slices the per-step small MSMs run over: verifier wires and verifier rows of
   // ck1, the head of ck2.  Their window sums only need adding: no 254 doublings on the host per commitment (23 MB each)
   BaseTables tb_aug{}, tb_T1v{}, tb_ck2{};
@@ -102,6 +103,7 @@ int finish_secondary(vimz_ivc* v) {
   v->u2.W = msm_finish<Grumpkin>(v->plan_W2, v->pin + 2 * v->pin_res);      // overlaps the rest of MSM(T2)
   P_TRY(hipStreamSynchronize(ctx->stream));
   v->ph_s[IP_WAIT_SEC] += now_s() - t0; v->ph_n[IP_WAIT_SEC]++;
+  if (ctx->profiling) { float ms = 0; if (hipEventElapsedTime(&ms, v->ev_b0, v->ev_b1) == hipSuccess) { v->ph_s[IP_RESERVED] += ms * 1e-3; v->ph_n[IP_RESERVED]++; } }
   if (v->sec_T_valid) v->T2 = msm_finish<Grumpkin>(v->plan_T2, v->pin + 3 * v->pin_res);
   else { v->T2.x = Fe::zero(); v->T2.y = Fe::zero(); }
   static const bool dbg = getenv("VIMZ_DEBUG_CHECK_MSM") != nullptr;
@@ -205,6 +207,7 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
       P_TRY(msm_launch<BnG1>(v->s2, v->ws2, p->ck->d + (size_t)AFFINE_WORDS * (sw - 1), Zi + 8 * sw, aw1 - 2, 1, 0, v->pin, &v->plan_aug, nullptr, 0, v->tb_aug.d ? &v->tb_aug : nullptr));
       // ---- 3. NIFS on the primary curve ------------------------------------------------------------------------------------------------
       // verifier rows: (A,B,C)·z and their part of the cross term in one launch, then its commitment over the matching slice of ck
+      P_TRY(hipStreamWaitEvent(s, v->ev_fold, 0));          // (the running products come from the previous step's fold on stream 3)
       hipLaunchKernelGGL(k_spmv_cross16<Fr>, dim3((unsigned)((16 * (nc - sc) + 255) / 256)), dim3(256), 0, s, p->A, p->B, p->C, p->dict, (uint32_t)sc, (uint32_t)(nc - sc),
                          Zi, az, bz, cz, i > 0 ? p->AZ : nullptr, p->BZ, p->CZ, v->u1_run, Fe::one(), p->T);
       P_TRY(hipGetLastError());
@@ -285,6 +288,8 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
         f.x1[2] = p->AZ; f.x2[2] = az; f.n[2] = nc;
         f.x1[3] = p->BZ; f.x2[3] = bz; f.n[3] = nc;
         f.x1[4] = p->CZ; f.x2[4] = cz; f.n[4] = nc;
+        // (measured: moving this 145 MB pass to stream 3, out of the secondary half's way, gains that half 45 µs and costs the
+        // large MSM behind it more — it would run at stream 3's lower priority)
         hipLaunchKernelGGL(k_fold5<Fr>, dim3(2048), dim3(256), 0, s, f, rho1);
         v->u1_run = Fe::add(v->u1_run, rho1);
         P_TRY(hipEventRecord(v->ev_fold, s));      // the next step's large MSM may start here (queued below, behind the secondary's work)
@@ -295,6 +300,7 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
         Fq* w2 = (Fq*)pin_w2;
         w2[0] = Fq::one(); w2[1] = zero_q; w2[2] = zero_q;
         memcpy(w2 + 3, aug2.data(), 32 * aug2.size());
+        if (ctx->profiling) P_TRY(hipEventRecord(v->ev_b0, s));
         P_TRY(hipMemcpyAsync(S.z2, pin_w2, 32 * (size_t)S.n_w, hipMemcpyHostToDevice, s));
         P_TRY(hipEventRecord(v->ev_fork, s));
         P_TRY(hipStreamWaitEvent(v->s2, v->ev_fork, 0));
@@ -304,6 +310,7 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
                            v->sec_T_valid ? S.AZ : nullptr, S.BZ, S.CZ, v->u2_run, Fq::one(), S.T);
         if (v->sec_T_valid)
           P_TRY(msm_launch<Grumpkin>(s, ctx->msm_ws, v->ck2->d, S.T, S.n_c, 1, 0, v->pin + 3 * v->pin_res, &v->plan_T2, nullptr, 0, v->tb_ck2.d ? &v->tb_ck2 : nullptr));
+        if (ctx->profiling) P_TRY(hipEventRecord(v->ev_b1, s));
         P_TRY(hipGetLastError());
         v->u2.x0 = cross_field<Fe>(o2.x0); v->u2.x1 = cross_field<Fe>(o2.x1);
         v->pending_sec = true;
@@ -316,9 +323,11 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
     // this buffer is rewritten by batch k+2: the folds that read it must have finished
     P_TRY(hipStreamSynchronize(s));
     P_TRY(hipStreamSynchronize(v->s2));
+    P_TRY(hipEventSynchronize(v->ev_fold));
   }
   if ((rc = finish_secondary(v))) return rc;
   P_TRY(hipStreamSynchronize(p->sB));
+  P_TRY(hipStreamSynchronize(v->s3));
   for (uint32_t k = 0; k < p->len_z; k++) p->z_cur[k] = zs[nsteps * p->len_z + k];
   v->ph_s[IP_TOTAL] += now_s() - t_all; v->ph_n[IP_TOTAL] += nsteps;
   return VIMZ_OK;
@@ -344,6 +353,8 @@ void vimz_ivc_free(vimz_ivc* v) {
     if (v->s3 && v->s3 != v->ctx->stream) { hipStreamSynchronize(v->s3); hipStreamDestroy(v->s3); }
     if (v->ev_fork) hipEventDestroy(v->ev_fork);
     if (v->ev_fold) hipEventDestroy(v->ev_fold);
+    if (v->ev_b0) hipEventDestroy(v->ev_b0);
+    if (v->ev_b1) hipEventDestroy(v->ev_b1);
     v->ws2.release(); v->ws3.release();
     for (void* d : v->owned) hipFree(d);
     if (v->pin) hipHostFree(v->pin);
@@ -405,7 +416,8 @@ int vimz_ivc_create(vimz_ctx* ctx, const vimz_circuit* step_circuit, const vimz_
     if (getenv("VIMZ_DEBUG_NO_S2")) v->s3 = ctx->stream;
     else if ((e = hipStreamCreateWithPriority(&v->s3, hipStreamNonBlocking, (lo + hi) / 2)) != hipSuccess) return fail("stream");
     if ((e = hipEventCreateWithFlags(&v->ev_fork, hipEventDisableTiming)) != hipSuccess) return fail("event");
-    if ((e = hipEventCreateWithFlags(&v->ev_fold, hipEventDisableTiming)) != hipSuccess) return fail("event"); }
+    if ((e = hipEventCreateWithFlags(&v->ev_fold, hipEventDisableTiming)) != hipSuccess) return fail("event");
+    if ((e = hipEventCreate(&v->ev_b0)) != hipSuccess || (e = hipEventCreate(&v->ev_b1)) != hipSuccess) return fail("event"); }
   if (!getenv("VIMZ_DEBUG_NO_SMALL_TABLES")) {
     const cb::Builder& b1 = v->circ1->build->b;
     const size_t sw = v->c1->step_wires, sc = v->c1->step_constraints, aw = v->c1->aug_wires();

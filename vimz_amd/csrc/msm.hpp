@@ -489,6 +489,9 @@ __global__ void __launch_bounds__(256) k_msm_small(const uint32_t* __restrict__ 
   __shared__ uint16_t list[SMALL_CHUNK];
   __shared__ uint8_t subb[256];
   __shared__ uint32_t s_maxm, s_ticket;
+  // These waves sit on the critical path of a folding step while bulk kernels (the large MSM's accumulation, the batch
+  // producer) fill the same SIMDs: raise their issue priority over the resident bulk waves.
+  __builtin_amdgcn_s_setprio(3);
   const uint32_t t = threadIdx.x, w = blockIdx.x, q = blockIdx.y;
   const uint32_t lo = q * chunk, hi = min(n, lo + chunk);
   const uint32_t* __restrict__ wbases = tables ? tables + (size_t)AFFINE_WORDS * ((size_t)w * tstride) : bases;

@@ -98,11 +98,13 @@ inline unsigned spmv_long_blocks(uint32_t n_items, uint32_t n_med) {
 // circuits' 7.6 k rows (both curves) the three launches spmv3 -> spmv_long -> cross_term were three latency-bound hops on the
 // critical path of every step.  16 lanes per row: they stride over the terms of A, B and C in turn, a 4-level shuffle butterfly
 // adds the partial sums, lane 0 stores the products and T.  (T is skipped when az1 is null: step 0 folds into the zero instance.)
+// (One wave per row with 16 lanes per matrix side by side measured slower: 0.81 vs 0.72 ms for the secondary half of a step.)
 template <class F>
 __global__ void __launch_bounds__(256) k_spmv_cross16(CsrDev A, CsrDev B, CsrDev C, const uint32_t* __restrict__ dict, uint32_t row0, uint32_t nrows,
                                                       const uint32_t* __restrict__ z, uint32_t* __restrict__ az, uint32_t* __restrict__ bz, uint32_t* __restrict__ cz,
                                                       const uint32_t* __restrict__ az1, const uint32_t* __restrict__ bz1, const uint32_t* __restrict__ cz1, F u1, F u2,
                                                       uint32_t* __restrict__ T) {
+  __builtin_amdgcn_s_setprio(3);       // critical path of a step, next to bulk kernels on the same SIMDs
   const uint32_t g = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, l = threadIdx.x & 15u;
   const bool live = g < nrows;
   const uint32_t r = row0 + (live ? g : 0u);

@@ -331,7 +331,7 @@ class IVC:
     """vimz_ivc: Nova IVC of one transformation's step circuit with the augmented verifier circuits on the BN254/Grumpkin cycle
     (RecursiveSNARK::new / prove_step / verify; reference entry vimz/src/nova_snark_backend/folding.rs:27-56)."""
     PHASES = ["verifier_circuit_primary_host", "verifier_circuit_secondary_host", "wait_secondary_msm", "wait_primary_msm",
-              "upload_launch", "producer_wait", "reserved", "total"]
+              "upload_launch", "producer_wait", "secondary_gpu", "total"]
 
     def __init__(self, ctx, circuit, ck_primary, ck_secondary, max_batch=16):
         self.ctx, self.circuit = ctx, circuit
