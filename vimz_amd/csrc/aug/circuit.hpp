@@ -75,6 +75,14 @@ struct AugOut {
 
 // FP: the circuit's field; OP: the other field of the cycle.  z_i / z_next: the step circuit's state wires (already in the
 // constraint system).  curve_b, G: the other curve (y^2 = x^3 + b over F) and a fixed finite point on it.
+#ifdef VZ_AUG_TIMING
+extern double g_t[16]; extern const char* g_n[16];
+#define VZ_T(k, name) do { const double _n = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); g_n[k] = name; g_t[k] += _n - _tl; _tl = _n; } while (0)
+#define VZ_T0() double _tl = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count()
+#else
+#define VZ_T(k, name) do {} while (0)
+#define VZ_T0() do {} while (0)
+#endif
 template <class FP, class OP>
 AugOut<FP> synthesize_augmented(CS<FP>& cs, const AugIn<FP>& in, const std::vector<Num<Fp<FP>>>& z_i, const std::vector<Num<Fp<FP>>>& z_next,
                                 bool is_primary, const Fp<FP>& curve_b, const Affine<Fp<FP>>& G, HashCache<Fp<FP>>* cache = nullptr) {
@@ -85,6 +93,7 @@ AugOut<FP> synthesize_augmented(CS<FP>& cs, const AugIn<FP>& in, const std::vect
   typedef NonNative<FP, OP> NN;
   Ec ec(cs, curve_b, G);
   AugOut<FP> out;
+  VZ_T0();
 
   // ---- inputs --------------------------------------------------------------------------------------------------------
   N pz = cs.alloc(in.pz);
@@ -112,6 +121,7 @@ AugOut<FP> synthesize_augmented(CS<FP>& cs, const AugIn<FP>& in, const std::vect
   N nb = cs.one_minus(is_base);
   const bool base = in.i == 0;
 
+  VZ_T(0, "inputs");
   // ---- consistency of the incoming instance with the previous step's output hash ---------------------------------------
   std::vector<N> hin; hin.push_back(pz); hin.push_back(iN);
   hin.insert(hin.end(), z_i.begin(), z_i.end());
@@ -119,13 +129,16 @@ AugOut<FP> synthesize_augmented(CS<FP>& cs, const AugIn<FP>& in, const std::vect
   for (int j = 0; j < 4; j++) hin.push_back(UX0[j]);
   for (int j = 0; j < 4; j++) hin.push_back(UX1[j]);
   N h_chk = cs.hash_cached(hin, cache, nullptr);
+  VZ_T(1, "hash_in");
   std::vector<N> hb = cs.bits(h_chk, FP::BITS);
   N h250 = cs.pack(hb, 0, 250);
   cs.enforce(nb, cs.sub(h250, ux0), cs.zero());
   if (!base && !h250.v.eq(ux0.v)) cs.bad = true;
 
+  VZ_T(2, "bits_in");
   // ---- challenge ----------------------------------------------------------------------------------------------------------
   N hr = cs.hash({h_chk, uW.x, uW.y, ux0, ux1, T.x, T.y});
+  VZ_T(3, "hash_rho");
   std::vector<N> rb = cs.bits(hr, FP::BITS);
   N rho0 = cs.pack(rb, 0, 64), rho1 = cs.pack(rb, 64, 128);
   { F c = F::from_mont(hr.v); for (int k = 0; k < 4; k++) out.rho_low[k] = c.v[k]; }
@@ -143,17 +156,22 @@ AugOut<FP> synthesize_augmented(CS<FP>& cs, const AugIn<FP>& in, const std::vect
 
   std::vector<N> xb0 = cs.bits(ux0, 250), xb1 = cs.bits(ux1, 250);
 
+  VZ_T(4, "select_bits");
   std::vector<Affine<F>> ops = {Ec::scalar_operand(in.u.W, G), Ec::scalar_operand(in.T, G)};
   std::vector<typename Ec::ChainHints> hints;
   Ec::chain_hints_parallel(ops, out.rho_low, 128, hints, cs.worker);
+  VZ_T(5, "chain_hints");
   Pt rW = ec.scalar_mul(uW, rb, 128, hints[0]);
   Pt rT = ec.scalar_mul(T, rb, 128, hints[1]);
+  VZ_T(6, "scalar_mul_gadget");
   Pt Wn = ec.add(We, rW), En = ec.add(Ee, rT);
+  VZ_T(7, "ec_add");
   N un = cs.add(ue, rho);
   N X0n[4], X1n[4]; U256w X0nv, X1nv;
   NN::fold(cs, X0e, X0v, rho0, rho1, out.rho_low, xb0, to_u256(in.u.x0), X0n, X0nv);
   NN::fold(cs, X1e, X1v, rho0, rho1, out.rho_low, xb1, to_u256(in.u.x1), X1n, X1nv);
 
+  VZ_T(8, "nonnative");
   // ---- the primary's base case outputs the zero instance (its incoming fresh instance is a dummy) -----------------------------
   Pt Wo = Wn, Eo = En; N uo = un;
   if (is_primary) {
@@ -172,7 +190,9 @@ AugOut<FP> synthesize_augmented(CS<FP>& cs, const AugIn<FP>& in, const std::vect
   hout.push_back(Wo.x); hout.push_back(Wo.y); hout.push_back(Eo.x); hout.push_back(Eo.y); hout.push_back(uo);
   for (int j = 0; j < 4; j++) hout.push_back(X0n[j]);
   for (int j = 0; j < 4; j++) hout.push_back(X1n[j]);
+  VZ_T(9, "sel_out");
   N h_new = cs.hash_cached(hout, nullptr, cache);
+  VZ_T(10, "hash_out");
   std::vector<N> hnb = cs.bits(h_new, FP::BITS);
   N hn250 = cs.pack(hnb, 0, 250);
 
@@ -182,6 +202,7 @@ AugOut<FP> synthesize_augmented(CS<FP>& cs, const AugIn<FP>& in, const std::vect
   cs.enforce_equal(p1, hn250);
   out.x0 = p0.v; out.x1 = p1.v;
   out.x0_wire = cs.base + (uint32_t)cs.w.size() - 2; out.x1_wire = out.x0_wire + 1;
+  VZ_T(11, "tail");
   return out;
 }
 

@@ -164,8 +164,13 @@ inline void poseidon_permute(Fp<FP>* s, int t, bool lane0_const, std::vector<Fp<
   const PoseidonSparseT<F>& S = poseidon_sparse_t<FP>(t);
   F u[POSEIDON_MAX_T];
   auto sbox = [&](F& x, bool emit) { const F x2 = F::sqr(x), x4 = F::sqr(x2), x5 = F::mul(x4, x); if (wires && emit) { wires->push_back(x2); wires->push_back(x4); wires->push_back(x5); } x = x5; };
+  auto dot = [](const F* a, const F* b, int n) {      // F::dot takes at most 12 terms
+    F acc = F::dot(a, b, n < 12 ? n : 12);
+    for (int k = 12; k < n; k += 12) acc = F::add(acc, F::dot(a + k, b + k, n - k < 12 ? n - k : 12));
+    return acc;
+  };
   auto mix = [&]() {
-    for (int i = 0; i < t; i++) { F acc = F::zero(); for (int j = 0; j < t; j++) acc = F::add(acc, F::mul(P.M[(size_t)i * t + j], s[j])); u[i] = acc; }
+    for (int i = 0; i < t; i++) u[i] = dot(&P.M[(size_t)i * t], s, t);
     for (int i = 0; i < t; i++) s[i] = u[i];
   };
   const int half = P.rf / 2;
@@ -179,12 +184,11 @@ inline void poseidon_permute(Fp<FP>* s, int t, bool lane0_const, std::vector<Fp<
     const F* ct = &S.ctil[(size_t)r * t]; const F* row = &S.row[(size_t)r * t]; const F* col = &S.col[(size_t)r * m];
     for (int i = 0; i < t; i++) s[i] = F::add(s[i], ct[i]);
     sbox(s[0], true);
-    F n0 = F::mul(row[0], s[0]);
-    for (int i = 1; i < t; i++) n0 = F::add(n0, F::mul(row[i], s[i]));
+    const F n0 = dot(row, s, t);
     for (int i = 1; i < t; i++) s[i] = F::add(s[i], F::mul(col[i - 1], s[0]));
     s[0] = n0;
   }
-  for (int i = 0; i < m; i++) { F acc = F::zero(); for (int k = 0; k < m; k++) acc = F::add(acc, F::mul(S.Pfin[(size_t)i * m + k], s[1 + k])); u[i] = acc; }
+  for (int i = 0; i < m; i++) u[i] = dot(&S.Pfin[(size_t)i * m], s + 1, m);
   for (int i = 0; i < m; i++) s[1 + i] = u[i];
   for (int r = half + P.rp; r < P.rf + P.rp; r++) {
     for (int i = 0; i < t; i++) s[i] = F::add(s[i], P.C[(size_t)r * t + i]);

@@ -104,7 +104,9 @@ struct Fp {
       for (int i = 0; i < 4; i++) { c += (u128)A[i] + B[i]; t[i] = (uint64_t)c; c >>= 64; }
       uint64_t br = 0;
       for (int i = 0; i < 4; i++) { u128 d = (u128)t[i] - M[i] - br; s[i] = (uint64_t)d; br = (uint64_t)(d >> 64) & 1; }
-      Fp r; __builtin_memcpy(r.v, br ? t : s, 32);
+      const uint64_t keep = (uint64_t)0 - br;      // branch-free select: the borrow is a coin flip on random data
+      for (int i = 0; i < 4; i++) s[i] = (t[i] & keep) | (s[i] & ~keep);
+      Fp r; __builtin_memcpy(r.v, s, 32);
       return r;
     }
 #endif
@@ -121,7 +123,7 @@ struct Fp {
       __builtin_memcpy(A, a.v, 32); __builtin_memcpy(B, b.v, 32); __builtin_memcpy(M, P::MOD.w, 32);
       uint64_t br = 0;
       for (int i = 0; i < 4; i++) { u128 d = (u128)A[i] - B[i] - br; t[i] = (uint64_t)d; br = (uint64_t)(d >> 64) & 1; }
-      const uint64_t mask = br ? ~(uint64_t)0 : 0;
+      const uint64_t mask = (uint64_t)0 - br;
       u128 c = 0;
       for (int i = 0; i < 4; i++) { c += (u128)t[i] + (M[i] & mask); t[i] = (uint64_t)c; c >>= 64; }
       Fp r; __builtin_memcpy(r.v, t, 32);
@@ -172,7 +174,9 @@ struct Fp {
       uint64_t t[4] = {t0, t1, t2, t3}, s[4];
       uint64_t br = 0;
       for (int i = 0; i < 4; i++) { u128 d = (u128)t[i] - M[i] - br; s[i] = (uint64_t)d; br = (uint64_t)(d >> 64) & 1; }
-      Fp r; __builtin_memcpy(r.v, br ? t : s, 32);
+      const uint64_t keep = (uint64_t)0 - br;
+      for (int i = 0; i < 4; i++) s[i] = (t[i] & keep) | (s[i] & ~keep);
+      Fp r; __builtin_memcpy(r.v, s, 32);
       return r;
     }
 #else
@@ -195,6 +199,49 @@ struct Fp {
 #endif
   }
   static VZ_HD Fp sqr(const Fp& a) { return mul(a, a); }
+
+  // sum_k a[k]*b[k] (Montgomery), n <= 12.  Host pass: the 512-bit products are accumulated unreduced and reduced once — the
+  // Poseidon matrix rows of the verifier circuits' witnesses are dot products of 9, and a reduction costs as much as a product.
+  // (12 p^2 < 2^512 for p < 2^254.2, which covers the four fields here; the reduced value is below 12 p (p / 2^256) + p < 5 p,
+  // brought under p by conditional subtractions.)
+  static VZ_HD Fp dot(const Fp* a, const Fp* b, int n) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+    typedef unsigned __int128 u128;
+    uint64_t acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, M[4];
+    __builtin_memcpy(M, P::MOD.w, 32);
+    for (int k = 0; k < n; k++) {
+      uint64_t A[4], B[4];
+      __builtin_memcpy(A, a[k].v, 32); __builtin_memcpy(B, b[k].v, 32);
+      for (int i = 0; i < 4; i++) {
+        u128 c = 0;
+        for (int j = 0; j < 4; j++) { c += (u128)A[j] * B[i] + acc[i + j]; acc[i + j] = (uint64_t)c; c >>= 64; }
+        for (int j = i + 4; j < 9 && c; j++) { c += acc[j]; acc[j] = (uint64_t)c; c >>= 64; }
+      }
+    }
+    for (int i = 0; i < 4; i++) {
+      const uint64_t m = acc[i] * P::N0_64;
+      u128 c = 0;
+      for (int j = 0; j < 4; j++) { c += (u128)m * M[j] + acc[i + j]; acc[i + j] = (uint64_t)c; c >>= 64; }
+      for (int j = i + 4; j < 9; j++) { c += acc[j]; acc[j] = (uint64_t)c; c >>= 64; }
+    }
+    uint64_t r[4] = {acc[4], acc[5], acc[6], acc[7]};      // < 5 p < 2^257: acc[8] carries at most one bit
+    uint64_t top = acc[8];
+    for (int round = 0; round < 4; round++) {              // subtract p while the value is >= p (at most four times)
+      uint64_t d[4], br = 0;
+      for (int i = 0; i < 4; i++) { u128 x = (u128)r[i] - M[i] - br; d[i] = (uint64_t)x; br = (uint64_t)(x >> 64) & 1; }
+      const uint64_t ge = top | (br ^ 1);                  // value >= p
+      const uint64_t take = (uint64_t)0 - (ge ? 1 : 0);
+      top = top - ((top && br) ? 1 : 0);                   // the borrow comes out of the top bit
+      for (int i = 0; i < 4; i++) r[i] = (d[i] & take) | (r[i] & ~take);
+    }
+    Fp o; __builtin_memcpy(o.v, r, 32);
+    return o;
+#else
+    Fp acc = zero();
+    for (int k = 0; k < n; k++) acc = add(acc, mul(a[k], b[k]));
+    return acc;
+#endif
+  }
 
   // canonical <-> Montgomery
   static VZ_HD Fp to_mont(const Fp& canon) { return mul(canon, r2()); }
