@@ -86,6 +86,18 @@ int vz_prover_create_layout(vimz_ctx* ctx, const vimz_circuit* circuit, const vi
     UP(t3.C, d); W.pc3 = (const uint32_t*)d; UP(t3.M, d); W.pm3 = (const uint32_t*)d;
     UP(t9.C, d); W.pc9 = (const uint32_t*)d; UP(t9.M, d); W.pm9 = (const uint32_t*)d;
     W.rp3 = (uint32_t)t3.rp; W.rp9 = (uint32_t)t9.rp;
+    for (int t : {3, 9}) {
+      const auto& S = cb::poseidon_sparse_t<BnFr>(t);
+      const int rp = t == 3 ? t3.rp : t9.rp;
+      std::vector<Fe> packed((size_t)rp * t * 3);
+      for (int r = 0; r < rp; r++)
+        for (int i = 0; i < t; i++) {
+          Fe* q = &packed[3 * ((size_t)r * t + i)];
+          q[0] = S.ctil[(size_t)r * t + i]; q[1] = S.row[(size_t)r * t + i]; q[2] = i ? S.col[(size_t)r * (t - 1) + i - 1] : Fe::zero();
+        }
+      UP(packed, d); (t == 3 ? W.ps3 : W.ps9) = (const uint32_t*)d;
+      UP(S.Pfin, d); (t == 3 ? W.pf3 : W.pf9) = (const uint32_t*)d;
+    }
   }
 #undef UP
   auto dalloc = [&](uint32_t** dst, size_t bytes) { e = hipMalloc((void**)dst, bytes ? bytes : 32); if (e == hipSuccess) { p->owned.push_back(*dst); e = hipMemset(*dst, 0, bytes ? bytes : 32); } return e; };   // (null-stream fills: synchronised below)

@@ -33,6 +33,10 @@ struct WitnessDev {  // device copies of the program tables
   const LcTerm* lc_terms; const uint32_t* dict;   // FOP_LC: value = sum dict[coef] * Z[wire]   (dictionary in Montgomery form)
   const uint32_t* pc3; const uint32_t* pm3;   // Poseidon constants t=3 (Montgomery): C then M
   const uint32_t* pc9; const uint32_t* pm9;   // t=9
+  // partial rounds in sparse form (circuit/poseidon_params.hpp: poseidon_sparse_t): per (round, lane) the triple
+  // (transformed round constant, first-row entry, first-column entry [0 for lane 0]); then the (t-1)^2 basis change
+  const uint32_t* ps3; const uint32_t* pf3;
+  const uint32_t* ps9; const uint32_t* pf9;
   uint32_t rp3, rp9;
   uint32_t n_wires, len_z, n_priv;
 };
@@ -199,6 +203,8 @@ __device__ __forceinline__ Fr poseidon_group(const WitnessDev& P, const HashJob&
                                              uint32_t* __restrict__ Zrow) {   // Zrow == nullptr: compute the hash only, write no wires
   const uint32_t* PC = T == 3 ? P.pc3 : P.pc9;
   const uint32_t* PM = T == 3 ? P.pm3 : P.pm9;
+  const uint32_t* PS = T == 3 ? P.ps3 : P.ps9;
+  const uint32_t* PF = T == 3 ? P.pf3 : P.pf9;
   const uint32_t rp = T == 3 ? P.rp3 : P.rp9;
   const uint32_t R = 8 + rp;
   const bool mine = li < (uint32_t)T;
@@ -212,23 +218,24 @@ __device__ __forceinline__ Fr poseidon_group(const WitnessDev& P, const HashJob&
   const uint32_t nf0 = __popc(grp_mask16);
   const uint32_t elim_slot = 3 * (nf0 + 3 * T + rp + 3 * T) + 2;  // x5 of (last round, lane 0)
   const bool bound = J.out_wire != 0;
-  for (uint32_t r = 0; r < R; r++) {
-    const bool full = r < 4 || r >= 4 + rp;
+  auto emit = [&](uint32_t index, const Fr& x2, const Fr& x4, const Fr& x5) {
+    const uint32_t slot = 3 * index;
+    auto wire_of = [&](uint32_t sl) { return J.wire_base + sl - ((bound && sl > elim_slot) ? 1u : 0u); };
+    store_fe(Zrow, wire_of(slot), x2);
+    store_fe(Zrow, wire_of(slot + 1), x4);
+    if (!(bound && slot + 2 == elim_slot)) store_fe(Zrow, wire_of(slot + 2), x5);
+  };
+  auto full_round = [&](uint32_t r) {
     if (mine) s = Fr::add(s, load_fe<Fr>(PC, (size_t)r * T + li));
-    if (mine && (full || li == 0)) {
+    if (mine) {
       const Fr x2 = Fr::sqr(s), x4 = Fr::sqr(x2), x5 = Fr::mul(x4, s);
       const bool folded = r == 0 && in_const;
       if (live && !folded && Zrow) {
         uint32_t index;
         if (r == 0) index = nf_before;
         else if (r < 4) index = nf0 + (r - 1) * T + li;
-        else if (r < 4 + rp) index = nf0 + 3 * T + (r - 4);
         else index = nf0 + 3 * T + rp + (r - 4 - rp) * T + li;
-        const uint32_t slot = 3 * index;
-        auto wire_of = [&](uint32_t sl) { return J.wire_base + sl - ((bound && sl > elim_slot) ? 1u : 0u); };
-        store_fe(Zrow, wire_of(slot), x2);
-        store_fe(Zrow, wire_of(slot + 1), x4);
-        if (!(bound && slot + 2 == elim_slot)) store_fe(Zrow, wire_of(slot + 2), x5);
+        emit(index, x2, x4, x5);
       }
       s = x5;
     }
@@ -241,7 +248,45 @@ __device__ __forceinline__ Fr poseidon_group(const WitnessDev& P, const HashJob&
 #pragma unroll
       for (int j = 0; j + stride < T; j += 2 * stride) prod[j] = Fr::add(prod[j], prod[j + stride]);
     s = prod[0];
+  };
+  for (uint32_t r = 0; r < 4; r++) full_round(r);
+  // Partial rounds in sparse form: only lane 0 goes through the S-box, and its value is the one the dense form has; the other
+  // lanes live in a changed basis (undone by PF below).  Four multiplication slots per round instead of twelve:
+  //   [x2 on lane 0 | row_i·s_i on the others]  [x4]  [x5]  [row_0·x5 on lane 0 | col_i·x5 on the others],
+  // then the lanes' row products are added by a shuffle butterfly.
+  const bool l0 = li == 0;
+  Fr ct = Fr::zero(), rw = Fr::zero(), cl = Fr::zero();
+  if (mine) { const size_t q = 3 * (size_t)li; ct = load_fe<Fr>(PS, q); rw = load_fe<Fr>(PS, q + 1); cl = load_fe<Fr>(PS, q + 2); }
+  for (uint32_t r = 0; r < rp; r++) {
+    Fr ctn = Fr::zero(), rwn = Fr::zero(), cln = Fr::zero();       // next round's constants: in flight during this round
+    if (mine && r + 1 < rp) { const size_t q = 3 * ((size_t)(r + 1) * T + li); ctn = load_fe<Fr>(PS, q); rwn = load_fe<Fr>(PS, q + 1); cln = load_fe<Fr>(PS, q + 2); }
+    s = Fr::add(s, ct);
+    const Fr m1 = Fr::mul(l0 ? s : rw, s);                         // lane 0: x2; lane i: row_i·s_i
+    Fr x4 = Fr::zero(), x5 = Fr::zero();
+    if (l0) { x4 = Fr::sqr(m1); x5 = Fr::mul(x4, s); if (live && Zrow) emit(nf0 + 3 * T + r, m1, x4, x5); }
+    const Fr s0 = shfl_fe(x5, lane_base);
+    const Fr m2 = Fr::mul(l0 ? rw : cl, s0);                       // lane 0: row_0·x5; lane i: col_i·x5
+    Fr p = l0 ? m2 : (mine ? m1 : Fr::zero());
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) {
+      Fr o;
+#pragma unroll
+      for (int k = 0; k < 8; k++) o.v[k] = __shfl_xor(p.v[k], off);
+      p = Fr::add(p, o);
+    }
+    s = l0 ? p : (mine ? Fr::add(s, m2) : s);
+    ct = ctn; rw = rwn; cl = cln;
   }
+  {  // back to the standard basis on lanes 1..T-1
+    Fr acc = Fr::zero();
+#pragma unroll
+    for (int j = 0; j < T - 1; j++) {
+      const Fr sj = shfl_fe(s, lane_base + 1 + j);
+      if (mine && !l0) acc = Fr::add(acc, Fr::mul(load_fe<Fr>(PF, (size_t)(li - 1) * (T - 1) + j), sj));
+    }
+    if (mine && !l0) s = acc;
+  }
+  for (uint32_t r = 4 + rp; r < R; r++) full_round(r);
   return s;
 }
 
