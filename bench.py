@@ -109,7 +109,7 @@ def main_ivc(args, rank, world, dist, torch, ctxs, circuit, params, steps_all, g
     fold_concurrently([(ivc, rows[:w_each]) for ivc, rows, z in segs])
     timed_rows = sum(len(rows) - min(w_each, len(rows)) for _, rows, _ in segs)
     for c in ctxs:
-        c.set_profiling(True)              # HIP events around every kernel of the primary MSM(T) launches on each context's stream
+        c.set_profiling(True)              # HIP events around every kernel of the primary MSM(T) launches (step rows) on the stream they run on
         c.msm_profile_totals(reset=True)
     prof0 = [ivc.profile() for ivc in ivcs]
     sync_all()
@@ -196,7 +196,7 @@ def main_ivc(args, rank, world, dist, torch, ctxs, circuit, params, steps_all, g
             "end_to_end_estimate_s": {"keygen_and_setup": setup_s, "fold_720_steps_one_gpu": 720 * dt / max(1, timed_rows)},
             "published_reference": {"contrast_HD_steps_per_s_cpu_server": 1.94, "source": "README.md:52 (720 steps / 371.7 s)"},
             "phase_ms_per_step_per_proof": phases,
-            "roofline": {"bound": "hbm", "kernel": "k_accum (bucket accumulation) of the primary MSM(T) launches in the timed region", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": "k_accum (bucket accumulation) of the primary MSM(T) launches over the step circuit's rows in the timed region (they run on a third stream under the rest of the step, so their duration includes that contention)", "achieved": achieved,
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": acc_ms, "launches": tot["calls"], "msm_gpu_ms": msm_ms,
                          "mixed_adds_per_launch": adds, "msm_phase_ms": {k: v / calls for k, v in tot["ms"].items()},
