@@ -162,7 +162,7 @@ __global__ void k_scatter(const uint32_t* __restrict__ scalars, size_t n, int mo
 // Here each workgroup histograms its own contiguous chunk of scalars in LDS (all buckets fit: 24 x 1024 counters = 96 KiB),
 // a scan kernel turns the per-workgroup histograms into global bucket sizes and per-workgroup offsets, and the scatter
 // ranks its entries with LDS atomics again.  No global atomic is issued at all.
-constexpr uint32_t SORT_BLOCKS = 256;      // one workgroup per CU
+constexpr uint32_t SORT_BLOCKS = 256;      // at most one workgroup per CU (msm_launch picks fewer for small inputs)
 constexpr uint32_t SORT_THREADS = 1024;
 
 template <class S>
@@ -171,7 +171,7 @@ __global__ void __launch_bounds__(SORT_THREADS) k_hist_lds(const uint32_t* __res
   extern __shared__ uint32_t lds_cnt[];
   for (uint32_t g = threadIdx.x; g < nb; g += SORT_THREADS) lds_cnt[g] = 0;
   __syncthreads();
-  const size_t chunk = (n + SORT_BLOCKS - 1) / SORT_BLOCKS;
+  const size_t chunk = (n + gridDim.x - 1) / gridDim.x;
   const size_t lo = blockIdx.x * chunk, hi = lo + chunk < n ? lo + chunk : n;
   for (size_t i = lo + threadIdx.x; i < hi; i += SORT_THREADS) {
     uint32_t s[8];
@@ -185,11 +185,13 @@ __global__ void __launch_bounds__(SORT_THREADS) k_hist_lds(const uint32_t* __res
 
 // per bucket: total over workgroups -> counts[g]; block_hist[blk][g] becomes the exclusive prefix over workgroups
 template <int DUMMY>
-__global__ void __launch_bounds__(256) k_block_prefix(uint32_t* __restrict__ block_hist, uint32_t nb, uint32_t* __restrict__ counts) {
+__global__ void __launch_bounds__(256) k_block_prefix(uint32_t* __restrict__ block_hist, uint32_t nb, uint32_t* __restrict__ counts, uint32_t nblocks,
+                                                      uint32_t* __restrict__ heavy) {
   const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g == 0) heavy[0] = 0;                       // k_scan's heavy-bucket list starts empty (saves a fill launch per MSM)
   if (g >= nb) return;
   uint32_t run = 0;
-  for (uint32_t blk = 0; blk < SORT_BLOCKS; blk++) {
+  for (uint32_t blk = 0; blk < nblocks; blk++) {
     const size_t idx = (size_t)blk * nb + g;
     const uint32_t v = block_hist[idx];
     block_hist[idx] = run;
@@ -206,7 +208,7 @@ __global__ void __launch_bounds__(SORT_THREADS) k_scatter_lds(const uint32_t* __
   const uint32_t* mine = block_hist + (size_t)blockIdx.x * nb;
   for (uint32_t g = threadIdx.x; g < nb; g += SORT_THREADS) lds_pos[g] = bucket_off[g] + mine[g];
   __syncthreads();
-  const size_t chunk = (n + SORT_BLOCKS - 1) / SORT_BLOCKS;
+  const size_t chunk = (n + gridDim.x - 1) / gridDim.x;
   const size_t lo = blockIdx.x * chunk, hi = lo + chunk < n ? lo + chunk : n;
   for (size_t i = lo + threadIdx.x; i < hi; i += SORT_THREADS) {
     uint32_t s[8];
@@ -739,15 +741,23 @@ hipError_t msm_launch(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_ba
   const uint32_t sub = n < (1u << 15) ? 8u : (uint32_t)MSM_SUB;   // MSM_SUB for everything large
   const size_t max_subs = entries / sub + pl.nb + 1;
   VZ_HIP_CHECK(ws.reserve(pl.nb, entries, max_subs));
-  VZ_HIP_CHECK(hipMemsetAsync(ws.counts, 0, 4 * (size_t)pl.nb, stream));
-  VZ_HIP_CHECK(hipMemsetAsync(ws.cursor, 0, 4 * (size_t)pl.nb, stream));
-  VZ_HIP_CHECK(hipMemsetAsync(ws.heavy, 0, 4, stream));
   const int TB = 256;
 #define VZ_EV(i) do { if (ev) VZ_HIP_CHECK(hipEventRecord(ev[i], stream)); } while (0)
   VZ_EV(0);
   const unsigned gs = (unsigned)std::min<size_t>((n + TB - 1) / TB, 256 * 16);
   // all buckets' counters fit in one workgroup's LDS at the default window (24 x 1024 x 4 B = 96 KiB): contention-free sort
   const bool lds_sort = (size_t)pl.nb * 4 <= 144 * 1024;
+  if (!lds_sort) {      // (the LDS sort writes every counter itself and needs no cursors; each fill is a launch of its own)
+    VZ_HIP_CHECK(hipMemsetAsync(ws.counts, 0, 4 * (size_t)pl.nb, stream));
+    VZ_HIP_CHECK(hipMemsetAsync(ws.cursor, 0, 4 * (size_t)pl.nb, stream));
+    VZ_HIP_CHECK(hipMemsetAsync(ws.heavy, 0, 4, stream));
+  }
+  static const int sort_blocks_env = getenv("VIMZ_DEBUG_SORT_BLOCKS") ? atoi(getenv("VIMZ_DEBUG_SORT_BLOCKS")) : 0;
+  // every sort workgroup zeroes, writes out and later re-reads all nb counters (96 KiB at the default window): with one workgroup
+  // per CU at 305 k points each handled 1.2 k scalars for 24.5 k counters, and k_block_prefix walked 256 rows — fixed costs.
+  // About 4 k scalars per workgroup (75 workgroups here) measured best: one proof 384 -> 394 steps/s, three 599 -> 614.
+  const uint32_t sort_blocks = sort_blocks_env > 0 && sort_blocks_env <= (int)SORT_BLOCKS ? (uint32_t)sort_blocks_env
+                                                                                           : (uint32_t)std::min<size_t>(SORT_BLOCKS, std::max<size_t>(32, n / 4096));
   const uint32_t bstride = tabled ? 0u : pl.nbw, pstride = tabled ? (uint32_t)tb->n_total : 0u;
   if (lds_sort) {
     VZ_HIP_CHECK(ws.reserve_block_hist((size_t)SORT_BLOCKS * pl.nb));
@@ -757,8 +767,8 @@ hipError_t msm_launch(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_ba
       hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_lds<S>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       attr_set = true;
     }
-    hipLaunchKernelGGL(k_hist_lds<S>, dim3(SORT_BLOCKS), dim3(SORT_THREADS), pl.nb * 4, stream, d_scalars, n, scalars_mont, split_ones, pl.c, pl.K, bstride, pl.nb, ws.block_hist);
-    hipLaunchKernelGGL(k_block_prefix<0>, dim3((pl.nb + 255) / 256), dim3(256), 0, stream, ws.block_hist, pl.nb, ws.counts);
+    hipLaunchKernelGGL(k_hist_lds<S>, dim3(sort_blocks), dim3(SORT_THREADS), pl.nb * 4, stream, d_scalars, n, scalars_mont, split_ones, pl.c, pl.K, bstride, pl.nb, ws.block_hist);
+    hipLaunchKernelGGL(k_block_prefix<0>, dim3((pl.nb + 255) / 256), dim3(256), 0, stream, ws.block_hist, pl.nb, ws.counts, sort_blocks, ws.heavy);
   } else {
     hipLaunchKernelGGL(k_hist<S>, dim3(gs), dim3(TB), 0, stream, d_scalars, n, scalars_mont, split_ones, pl.c, pl.K, bstride, ws.counts);
   }
@@ -773,7 +783,7 @@ hipError_t msm_launch(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_ba
   hipLaunchKernelGGL(k_scan<MSM_SUB>, dim3(1), dim3(1024), 0, stream, ws.counts, pl.nb, ws.bucket_off, ws.sub_off, ws.totals, sub, ws.heavy, heavy_min, MsmWorkspace::HEAVY_CAP);
   VZ_EV(2);
   if (lds_sort)
-    hipLaunchKernelGGL(k_scatter_lds<S>, dim3(SORT_BLOCKS), dim3(SORT_THREADS), pl.nb * 4, stream, d_scalars, n, scalars_mont, split_ones, pl.c, pl.K, bstride, pl.nb,
+    hipLaunchKernelGGL(k_scatter_lds<S>, dim3(sort_blocks), dim3(SORT_THREADS), pl.nb * 4, stream, d_scalars, n, scalars_mont, split_ones, pl.c, pl.K, bstride, pl.nb,
                        pstride, ws.bucket_off, ws.block_hist, ws.sorted);
   else
     hipLaunchKernelGGL(k_scatter<S>, dim3(gs), dim3(TB), 0, stream, d_scalars, n, scalars_mont, split_ones, pl.c, pl.K, bstride, pstride,
