@@ -705,10 +705,11 @@ hipError_t msm_launch(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_ba
   typedef typename C::Scalar S;
   if (n == 0 || n >= (1u << 31)) return hipErrorInvalidValue;
   // tables made for the fused small path (window SMALL_C): its window sums then only need adding — no Horner on the host
-  const bool small_tb = tb && tb->d && tb->c == SMALL_C;
-  const bool tabled = tb && tb->d && !small_tb && c_override <= 0;
   static const bool no_small = getenv("VIMZ_DEBUG_NO_SMALL_MSM") != nullptr;
-  if (small_tb && (no_small || c_override > 0 || n > MSM_SMALL_MAX || tb->K != (S::Params::BITS + SMALL_C) / SMALL_C)) return hipErrorInvalidValue;
+  const bool small_fmt = tb && tb->d && tb->c == SMALL_C;             // (ignored, not an error, when the fused path is switched off)
+  const bool small_tb = small_fmt && !no_small && c_override <= 0;
+  const bool tabled = tb && tb->d && !small_fmt && c_override <= 0;
+  if (small_tb && (n > MSM_SMALL_MAX || tb->K != (S::Params::BITS + SMALL_C) / SMALL_C)) return hipErrorInvalidValue;
   if (!no_small && !tabled && c_override <= 0 && n <= MSM_SMALL_MAX) {      // fused single-launch path
     MsmPlan ps; ps.c = SMALL_C; ps.K = (S::Params::BITS + SMALL_C) / SMALL_C; ps.nbw = SMALL_NBW; ps.nb = SMALL_NBW * (uint32_t)ps.K; ps.split_ones = 0; ps.tabled = small_tb ? 2 : 0;
     *plan_out = ps;
