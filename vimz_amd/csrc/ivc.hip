@@ -76,6 +76,7 @@ struct vimz_ivc {
   hipStream_t s3 = nullptr; hipEvent_t ev_fold = nullptr; MsmWorkspace ws3;
   bool t1_step_pending = false;
   hipEvent_t ev_b0 = nullptr, ev_b1 = nullptr;   // profiling: GPU time of the secondary half on the main stream
+  hipEvent_t ev_a = nullptr;                      // the primary half's results on the main stream are back
   // window tables (2^(7w)·P_i) of the three base slices the per-step small MSMs run over: verifier wires and verifier rows of
   // ck1, the head of ck2.  Their window sums only need adding: no 254 doublings on the host per commitment (23 MB each)
   BaseTables tb_aug{}, tb_T1v{}, tb_ck2{};
@@ -185,17 +186,6 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
       if (bad) return vz_fail(ctx, VIMZ_ERR_UNSAT, "primary verifier circuit: inconsistent incoming instance");
       v->ph_s[IP_SYNTH1] += now_s() - t0; v->ph_n[IP_SYNTH1]++;
       t0 = now_s();
-      if (i > 0) {   // the same fold on the witness vectors
-        const Fq rho2 = rho_element<Fq>(o1.rho_low);
-        Fold5 f;
-        f.x1[0] = S.Zrun; f.x2[0] = S.z2; f.n[0] = S.n_w;
-        f.x1[1] = v->sec_T_valid ? S.E : nullptr; f.x2[1] = S.T; f.n[1] = S.n_c;
-        f.x1[2] = S.AZ; f.x2[2] = S.az2; f.n[2] = S.n_c;
-        f.x1[3] = S.BZ; f.x2[3] = S.bz2; f.n[3] = S.n_c;
-        f.x1[4] = S.CZ; f.x2[4] = S.cz2; f.n[4] = S.n_c;
-        hipLaunchKernelGGL(k_fold5<Fq>, dim3(256), dim3(256), 0, s, f, rho2);
-        v->u2_run = Fq::add(v->u2_run, rho2);
-      }
       v->U2 = o1.U_new;
       // ---- fresh primary instance: upload the verifier wires, finish (A,B,C)·z and the commitment ---------------------------------
       memcpy(pin_aug1, aug1.data(), 32 * aw1);
@@ -215,13 +205,26 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
         if (!v->t1_step_pending && (rc = launch_T1_step(bb, r, true))) return rc;       // first row of a call: nothing was queued ahead
         P_TRY(msm_launch<BnG1>(s, ctx->msm_ws, p->ck->d + (size_t)AFFINE_WORDS * sc, p->T + 8 * sc, nc - sc, 1, 0, v->pin + 4 * v->pin_res, &v->plan_T1v, nullptr, 0, v->tb_T1v.d ? &v->tb_T1v : nullptr));
       }
+      P_TRY(hipEventRecord(v->ev_a, s));
+      if (i > 0) {   // the same fold on the secondary's witness vectors: nothing in this half of the step reads them, so it is queued
+                     // behind the verifier rows' work (it used to open the half: 50-160 µs under load before the upload could start)
+        const Fq rho2 = rho_element<Fq>(o1.rho_low);
+        Fold5 f;
+        f.x1[0] = S.Zrun; f.x2[0] = S.z2; f.n[0] = S.n_w;
+        f.x1[1] = v->sec_T_valid ? S.E : nullptr; f.x2[1] = S.T; f.n[1] = S.n_c;
+        f.x1[2] = S.AZ; f.x2[2] = S.az2; f.n[2] = S.n_c;
+        f.x1[3] = S.BZ; f.x2[3] = S.bz2; f.n[3] = S.n_c;
+        f.x1[4] = S.CZ; f.x2[4] = S.cz2; f.n[4] = S.n_c;
+        hipLaunchKernelGGL(k_fold5<Fq>, dim3(256), dim3(256), 0, s, f, rho2);
+        v->u2_run = Fq::add(v->u2_run, rho2);
+      }
       v->ph_s[IP_LAUNCH] += now_s() - t0;
       t0 = now_s();
       P_TRY(hipEventSynchronize(bb.ev[r]));
       G1Aff cW_step = msm_finish<BnG1>(p->planB, (char*)bb.pin + r * pin_stride);
       P_TRY(hipStreamSynchronize(v->s2));
-      G1Aff cW_aug = msm_finish<BnG1>(v->plan_aug, v->pin);      // the small MSM is back first: its Horner tail overlaps MSM(T1)
-      P_TRY(hipStreamSynchronize(s));
+      G1Aff cW_aug = msm_finish<BnG1>(v->plan_aug, v->pin);      // the small MSM is back first: its tail overlaps the other one
+      P_TRY(hipEventSynchronize(v->ev_a));
       v->ph_s[IP_WAIT_PRI] += now_s() - t0; v->ph_n[IP_WAIT_PRI]++;
       t0 = now_s();
       {
@@ -288,11 +291,13 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
         f.x1[2] = p->AZ; f.x2[2] = az; f.n[2] = nc;
         f.x1[3] = p->BZ; f.x2[3] = bz; f.n[3] = nc;
         f.x1[4] = p->CZ; f.x2[4] = cz; f.n[4] = nc;
-        // (measured: moving this 145 MB pass to stream 3, out of the secondary half's way, gains that half 45 µs and costs the
-        // large MSM behind it more — it would run at stream 3's lower priority)
-        hipLaunchKernelGGL(k_fold5<Fr>, dim3(2048), dim3(256), 0, s, f, rho1);
+        // (measured: on stream 3, where the large MSM follows, it runs at that stream's lower priority and delays the MSM by more
+        // than the secondary half gains)
+        // on stream 2, idle until the secondary witness is uploaded: this 145 MB pass overlaps that upload instead of preceding it
+        // (everything it reads is complete — the host has waited for all three streams)
+        hipLaunchKernelGGL(k_fold5<Fr>, dim3(2048), dim3(256), 0, v->s2, f, rho1);
         v->u1_run = Fe::add(v->u1_run, rho1);
-        P_TRY(hipEventRecord(v->ev_fold, s));      // the next step's large MSM may start here (queued below, behind the secondary's work)
+        P_TRY(hipEventRecord(v->ev_fold, v->s2));  // the next step's large MSM may start here (queued below, behind the secondary's work)
       }
       v->U1 = o2.U_new;
       // fresh secondary instance on the device: [1 | z_out | z_in | verifier wires]
@@ -355,6 +360,7 @@ void vimz_ivc_free(vimz_ivc* v) {
     if (v->ev_fold) hipEventDestroy(v->ev_fold);
     if (v->ev_b0) hipEventDestroy(v->ev_b0);
     if (v->ev_b1) hipEventDestroy(v->ev_b1);
+    if (v->ev_a) hipEventDestroy(v->ev_a);
     v->ws2.release(); v->ws3.release();
     for (void* d : v->owned) hipFree(d);
     if (v->pin) hipHostFree(v->pin);
@@ -417,7 +423,8 @@ int vimz_ivc_create(vimz_ctx* ctx, const vimz_circuit* step_circuit, const vimz_
     else if ((e = hipStreamCreateWithPriority(&v->s3, hipStreamNonBlocking, (lo + hi) / 2)) != hipSuccess) return fail("stream");
     if ((e = hipEventCreateWithFlags(&v->ev_fork, hipEventDisableTiming)) != hipSuccess) return fail("event");
     if ((e = hipEventCreateWithFlags(&v->ev_fold, hipEventDisableTiming)) != hipSuccess) return fail("event");
-    if ((e = hipEventCreate(&v->ev_b0)) != hipSuccess || (e = hipEventCreate(&v->ev_b1)) != hipSuccess) return fail("event"); }
+    if ((e = hipEventCreate(&v->ev_b0)) != hipSuccess || (e = hipEventCreate(&v->ev_b1)) != hipSuccess) return fail("event");
+    if ((e = hipEventCreateWithFlags(&v->ev_a, hipEventDisableTiming)) != hipSuccess) return fail("event"); }
   if (!getenv("VIMZ_DEBUG_NO_SMALL_TABLES")) {
     const cb::Builder& b1 = v->circ1->build->b;
     const size_t sw = v->c1->step_wires, sc = v->c1->step_constraints, aw = v->c1->aug_wires();
