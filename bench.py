@@ -156,9 +156,25 @@ def main_ivc(args, rank, world, dist, torch, ctxs, circuit, params, steps_all, g
         calls = max(1, tot["calls"])
         acc_ms = tot["ms"]["accumulate"] / calls
         msm_ms = sum(tot["ms"].values()) / calls
-        alg_bytes = 96.0 * n_c
+        alg_bytes = 96.0 * tot["points"] / calls       # 32 B scalar + 64 B base per point of the launch (the step circuit's rows)
         achieved = alg_bytes / (acc_ms * 1e-3) / 1e9 if acc_ms else 0.0
         adds = tot["entries"] / calls
+        # for reference, outside the timed region: the same kernel over the same kind of data (the running error vector of the first
+        # proof, which has the cross terms' zero and repetition structure) with nothing else on the GPU
+        alone_ms = None
+        try:
+            E = np.ascontiguousarray(ivcs[0].export(0, hip.IX_RUNNING_E))[:info["step_constraints"]]
+            vec = ctxs[0].vec_from_host(_lib.FIELD_BN254_FR, E)
+            ctxs[0].set_profiling(True)
+            ms = []
+            for _ in range(7):
+                ctxs[0].msm_vec(params.ck, vec)
+                ms.append(ctxs[0].msm_last_profile()["ms"]["accumulate"])
+            ctxs[0].set_profiling(False)
+            vec.free()
+            alone_ms = sorted(ms[1:])[len(ms[1:]) // 2]
+        except Exception as e:                          # informational only
+            print(f"[bench] isolated k_accum measurement skipped: {e}", file=sys.stderr)
         traffic = None
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fp:
@@ -201,6 +217,8 @@ def main_ivc(args, rank, world, dist, torch, ctxs, circuit, params, steps_all, g
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": acc_ms, "launches": tot["calls"], "msm_gpu_ms": msm_ms,
                          "mixed_adds_per_launch": adds, "msm_phase_ms": {k: v / calls for k, v in tot["ms"].items()},
                          "int_utilisation": (adds / (acc_ms * 1e-3) / 1e9 / MIXED_ADD_PEAK_GOPS) if acc_ms else 0.0,
+                         "kernel_ms_alone_on_gpu": alone_ms,
+                         "frac_alone_on_gpu": (alg_bytes / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if alone_ms else None,
                          "step_algorithmic_bytes": step_bytes, "step_hbm_frac": step_bytes / (dt / max(1, timed_rows)) / 1e9 / HBM_PEAK_GBPS},
         }
         if not args.no_cpu_baseline and world == 1:      # the CPU baseline is timed at N = 1 only
