@@ -72,7 +72,7 @@ int vimz_timer_stop(vimz_ctx* ctx, float* ms_out);
 int vimz_set_profiling(vimz_ctx* ctx, int enabled);
 /* ms[6] = {hist, scan, scatter, accumulate, combine, reduce}; info[4] = {window bits, windows, sub-buckets, entries} */
 int vimz_msm_last_profile(vimz_ctx* ctx, float ms[6], uint32_t info[4]);
-/* sums over every profiled MSM issued on the context's stream since the last reset (the MSM(T) launches of a fold):
+/* sums over every profiled MSM of the context since the last reset (the large MSM(T) launches of a fold, on the stream they run on):
  * ms[6] as above; counts[3] = {MSM calls, points, bucket entries (= mixed additions)} */
 int vimz_msm_profile_totals(vimz_ctx* ctx, double ms[6], uint64_t counts[3], int reset);
 
@@ -235,7 +235,7 @@ int vimz_ivc_state(const vimz_ivc* v, uint64_t* z_current /* len_z x 4 */, uint6
 /* IVC state chain only (as vimz_prover_state_chain): where a row segment proven by another IVC starts */
 int vimz_ivc_state_chain(vimz_ivc* v, const uint64_t* z_start, const uint64_t* step_inputs, size_t nsteps, uint64_t* zs_out);
 /* seconds[8]/counts[8]: verifier-circuit witness primary (host), secondary (host), wait for secondary MSMs, wait for primary MSMs,
- * uploads+launches, producer wait, reserved, total */
+ * uploads+launches, producer wait, GPU time of the secondary half on the main stream (only while profiling is on), total */
 int vimz_ivc_profile(const vimz_ivc* v, double seconds[8], uint64_t counts[8]);
 /* The proof as an object of its own (RecursiveSNARK serialisation; checkpoint / resume): everything vimz_ivc_verify reads and the
  * next vimz_ivc_fold needs.  Import into a vimz_ivc created for the same step circuit and keys, then verify or keep folding. */

@@ -267,3 +267,26 @@ def test_concurrent_provers_all_verify(oracle):
             ck1.free(); ck2.free()
             for cx in ctxs:
                 cx.close()
+
+
+@pytest.mark.gpu
+def test_proof_does_not_depend_on_the_schedule():
+    """The same rows give the same proof (running instances, fresh instance, state) whichever way the step's work is spread over
+    streams and kernels: default (three streams, fused small MSMs over window tables, large MSM queued ahead) against the
+    debugging switches that serialise or replace each of those pieces.  Each variant runs in a process of its own (the switches
+    are read once)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    variants = [{}, {"VIMZ_DEBUG_NO_S2": "1"}, {"VIMZ_DEBUG_NO_SMALL_TABLES": "1"}, {"VIMZ_DEBUG_NO_SMALL_MSM": "1"},
+                {"VIMZ_DEBUG_SMALL_SUM_KERNEL": "1", "VIMZ_AUG_NO_THREADS": "1"}, {"VIMZ_DEBUG_SORT_BLOCKS": "256", "VIMZ_DEBUG_COMBINE_LANE_BITS": "4"}]
+    lines = []
+    for env in variants:
+        out = subprocess.run([sys.executable, os.path.join(root, "tools", "ivc_digest.py"), "grayscale", "2"], capture_output=True, text=True,
+                             timeout=600, env={**os.environ, **env})
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+        line = [l for l in out.stdout.splitlines() if l.startswith("digest ")][-1]
+        assert " verify 0 " in line, (env, line)
+        lines.append(line)
+    assert len(set(lines)) == 1, list(zip(variants, lines))
