@@ -135,6 +135,9 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
   const double t_all = now_s();
   FoldJob job; job.step_inputs = step_inputs; job.witnesses = witnesses; job.nsteps = nsteps;
   if ((rc = fold_prepare(p, job))) return rc;
+  static const bool dbg_timing = getenv("VIMZ_DEBUG_TIMING") != nullptr;
+  const double t_prep = now_s() - t_all;
+  double t_first = 0, t_wait0 = 0;
   const std::vector<Fe>& zs = job.zs;
   const size_t pin_stride = FoldJob::pin_stride;
   char* pin_aug1 = v->pin + 5 * v->pin_res;
@@ -163,6 +166,7 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
     double t0 = now_s();
     P_TRY(hipEventSynchronize(bb.wit_done));
     v->ph_s[IP_PRODUCER] += now_s() - t0;
+    if (k == 0) { t_wait0 = now_s() - t0; t_first = now_s() - t_all; }
     for (size_t r = 0; r < rows; r++) if (bb.status_host[r]) {
       char msg[128]; snprintf(msg, sizeof(msg), "step %llu: the step relation is not satisfiable for these rows", (unsigned long long)(v->i + r));
       hipStreamSynchronize(p->sB);
@@ -335,6 +339,7 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
   P_TRY(hipStreamSynchronize(v->s3));
   for (uint32_t k = 0; k < p->len_z; k++) p->z_cur[k] = zs[nsteps * p->len_z + k];
   v->ph_s[IP_TOTAL] += now_s() - t_all; v->ph_n[IP_TOTAL] += nsteps;
+  if (dbg_timing) fprintf(stderr, "[timing] fold of %zu steps: %.1f ms (prepare %.1f, first batch ready at %.1f after waiting %.1f)\n", nsteps, 1e3 * (now_s() - t_all), 1e3 * t_prep, 1e3 * t_first, 1e3 * t_wait0);
   return VIMZ_OK;
 }
 

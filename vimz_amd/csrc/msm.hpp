@@ -552,8 +552,38 @@ __global__ void __launch_bounds__(256) k_msm_small(const uint32_t* __restrict__ 
   XYZZ<F> bk = XYZZ<F>::identity();
   if (t < SMALL_NBW && cnt[t]) bk = sh[soff[t]];
   __syncthreads();
-  if (t < SMALL_NBW) sh[t] = bk;
-  __syncthreads();
+  if (Q > 1 && done) {
+    // The chunks of a window share its buckets: publish this chunk's 64 bucket sums; the last workgroup of the window to arrive
+    // adds them bucket by bucket and alone runs the weighted bucket reduction below (it used to run in every chunk's workgroup,
+    // twelve dependent additions on one wave each, followed by a tree over the chunk results: same depth, a fifth of the
+    // instructions at five chunks).  Release: stores, fence, barrier, agent-scope atomic ticket; acquire: fence, agent-scope
+    // loads that bypass this CU's vector cache.
+    if (t < SMALL_NBW) store_xyzz(chunk_out, ((size_t)w * Q + q) * SMALL_NBW + t, bk);
+    __threadfence();
+    __syncthreads();
+    if (t == 0) s_ticket = atomicAdd(&done[w], 1u);
+    __syncthreads();
+    if (s_ticket != Q - 1) return;
+    __threadfence();
+    const uint32_t b = t & (SMALL_NBW - 1), g = t / SMALL_NBW;          // 256 threads: four partial sums per bucket
+    XYZZ<F> acc = XYZZ<F>::identity();
+    for (uint32_t qq = g; qq < Q; qq += 256 / SMALL_NBW) {
+      const uint32_t* src = chunk_out + (size_t)XYZZ_WORDS * (((size_t)w * Q + qq) * SMALL_NBW + b);
+      XYZZ<F> v; F* f[4] = {&v.X, &v.Y, &v.ZZ, &v.ZZZ};
+      for (int c4 = 0; c4 < 4; c4++) for (int i = 0; i < 9; i++) f[c4]->v[i] = __hip_atomic_load(src + COORD_WORDS * c4 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      add_full(acc, v);
+    }
+    sh[t] = acc;
+    __syncthreads();
+    for (uint32_t d = 128; d >= SMALL_NBW; d >>= 1) {
+      if (t < d) { XYZZ<F> a = sh[t]; add_full(a, sh[t + d]); sh[t] = a; }
+      __syncthreads();
+    }
+    if (t == 0) __hip_atomic_store(&done[w], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    if (t < SMALL_NBW) sh[t] = bk;
+    __syncthreads();
+  }
   for (uint32_t d = 1; d < SMALL_NBW; d <<= 1) {    // inclusive suffix sums of the buckets
     const bool act = t + d < SMALL_NBW;
     XYZZ<F> o = XYZZ<F>::identity();
@@ -566,32 +596,8 @@ __global__ void __launch_bounds__(256) k_msm_small(const uint32_t* __restrict__ 
     if (t < d) { XYZZ<F> a = sh[t]; add_full(a, sh[t + d]); sh[t] = a; }
     __syncthreads();
   }
-  if (Q == 1) { if (t == 0) store_xyzz(window_sums, w, sh[0]); return; }
-  if (!done) { if (t == 0) store_xyzz(chunk_out, (size_t)w * Q + q, sh[0]); return; }
-  // The last workgroup of a window to finish adds the window's chunk results (release: stores, fence, agent-scope atomic;
-  // acquire: fence, agent-scope loads that bypass this CU's vector cache).
-  if (t == 0) {
-    store_xyzz(chunk_out, (size_t)w * Q + q, sh[0]);
-    __threadfence();
-    s_ticket = atomicAdd(&done[w], 1u);
-  }
-  __syncthreads();
-  if (s_ticket != Q - 1) return;
-  __threadfence();
-  XYZZ<F> v = XYZZ<F>::identity();
-  if (t < Q) {
-    const uint32_t* src = chunk_out + (size_t)XYZZ_WORDS * ((size_t)w * Q + t);
-    F* f[4] = {&v.X, &v.Y, &v.ZZ, &v.ZZZ};
-    for (int c4 = 0; c4 < 4; c4++) for (int i = 0; i < 9; i++) f[c4]->v[i] = __hip_atomic_load(src + COORD_WORDS * c4 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  __syncthreads();
-  sh[t] = v;
-  __syncthreads();
-  for (uint32_t d = SMALL_MAXQ / 2; d > 0; d >>= 1) {
-    if (t < d) { XYZZ<F> a = sh[t]; add_full(a, sh[t + d]); sh[t] = a; }
-    __syncthreads();
-  }
-  if (t == 0) { store_xyzz(window_sums, w, sh[0]); __hip_atomic_store(&done[w], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  if (Q == 1 || done) { if (t == 0) store_xyzz(window_sums, w, sh[0]); return; }
+  if (t == 0) store_xyzz(chunk_out, (size_t)w * Q + q, sh[0]);          // k_msm_small_sum follows (VIMZ_DEBUG_SMALL_SUM_KERNEL)
 }
 
 // window sum = sum of the window's chunk results as a kernel of its own (VIMZ_DEBUG_SMALL_SUM_KERNEL=1): the fallback for the

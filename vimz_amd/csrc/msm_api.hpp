@@ -104,7 +104,7 @@ struct MsmWorkspace {  // device buffers, grown on demand and reused across call
     if (!host_pinned) VZ_HIP_CHECK(hipHostMalloc(&host_pinned, 4 * XYZZ_WORDS * MSM_MAX_WINDOWS));
     return hipSuccess;
   }
-  void* small_buf = nullptr;       // fused small MSM: 128 completion counters, then MSM_MAX_WINDOWS x 16 chunk results
+  void* small_buf = nullptr;       // fused small MSM: 128 completion counters, then MSM_MAX_WINDOWS x 16 chunks x 64 bucket sums
   hipError_t reserve_small() {
     if (!window_sums) VZ_HIP_CHECK(hipMalloc(&window_sums, 4 * XYZZ_WORDS * MSM_MAX_WINDOWS));
     if (!host_pinned) VZ_HIP_CHECK(hipHostMalloc(&host_pinned, 4 * XYZZ_WORDS * MSM_MAX_WINDOWS));
@@ -113,7 +113,7 @@ struct MsmWorkspace {  // device buffers, grown on demand and reused across call
     // writes cost a day: it zeroed chunk results of the very first small MSM of a prover, only under heavy multi-stream load).
     if (!totals) { VZ_HIP_CHECK(hipMalloc(&totals, 64)); VZ_HIP_CHECK(hipMemset(totals, 0, 64)); VZ_HIP_CHECK(hipStreamSynchronize(nullptr)); }
     if (small_buf) return hipSuccess;
-    const size_t bytes = 512 + 4 * (size_t)XYZZ_WORDS * MSM_MAX_WINDOWS * 16;
+    const size_t bytes = 512 + 4 * (size_t)XYZZ_WORDS * MSM_MAX_WINDOWS * SMALL_MAXQ * (1u << (SMALL_C - 1));
     VZ_HIP_CHECK(hipMalloc(&small_buf, bytes));
     VZ_HIP_CHECK(hipMemset(small_buf, 0, 512));          // the completion counters (the chunk results are written before they are read)
     return hipStreamSynchronize(nullptr);

@@ -29,6 +29,7 @@ void vimz_prover_free(vimz_prover* p) {
     }
     p->wsB.release();
     hipFree(p->priv_all_d); hipFree(p->zs_all_d); hipFree(p->job_all_d);
+    for (void* d : p->retired) hipFree(d);
     for (void* d : p->owned) hipFree(d);
   }
   delete p;
