@@ -134,7 +134,7 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
   int rc;
   const double t_all = now_s();
   FoldJob job; job.step_inputs = step_inputs; job.witnesses = witnesses; job.nsteps = nsteps;
-  if ((rc = fold_prepare(p, job))) return rc;
+  if ((rc = fold_prepare(p, job, true))) return rc;
   static const bool dbg_timing = getenv("VIMZ_DEBUG_TIMING") != nullptr;
   const double t_prep = now_s() - t_all;
   double t_first = 0, t_wait0 = 0;

@@ -266,7 +266,7 @@ static int fold_core(vimz_prover* p, const uint64_t* step_inputs, const uint64_t
   int rc;
   double t0;
   FoldJob job; job.step_inputs = step_inputs; job.witnesses = witnesses; job.nsteps = nsteps;
-  if ((rc = fold_prepare(p, job))) return rc;
+  if ((rc = fold_prepare(p, job, true))) return rc;
   const std::vector<Fe>& zs = job.zs;
   const BaseTables& tbl = job.tbl;
   const size_t pin_stride = FoldJob::pin_stride, nbatches = job.nbatches, Bk = job.Bk;

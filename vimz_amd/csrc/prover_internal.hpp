@@ -195,6 +195,7 @@ int vz_prover_create_layout(vimz_ctx* ctx, const vimz_circuit* circuit, const vi
 
 // One call of vimz_prover_fold / vimz_ivc_fold: the inputs, the IVC state chain and the batch schedule.
 struct FoldJob {
+  bool batch0_started = false;     // fold_prepare already ran the state-independent part of batch 0's witness (see there)
   const uint64_t* step_inputs = nullptr;   // nsteps x n_priv canonical, or
   const uint64_t* witnesses = nullptr;     // nsteps x step_wires canonical (circom .wtns order)
   size_t nsteps = 0;
@@ -210,20 +211,28 @@ struct FoldJob {
 // hashes, early field ops, the chains that use them, state hashes, late field ops).  ahead = true stops before the state
 // hashes: the ahead-of-time pass of circuits whose IVC state needs values computed from the witness (crop: the hash of the
 // cropped row), run with only the predictable part of step_in filled in.
+// part: 0 = everything; 1 = only what does not depend on the IVC state (bit decompositions, input wires, the row-hash chains
+// with their wires); 2 = the rest, after part 1 (the input wires are rewritten: the state ones were not known in part 1).
 static int launch_witness(vimz_prover* p, hipStream_t st, uint32_t* Z, uint32_t* job_out, uint32_t* status, const uint32_t* priv, size_t first, size_t rows,
-                          const FoldJob& J, bool ahead) {
+                          const FoldJob& J, bool ahead, int part = 0) {
   vimz_ctx* ctx = p->ctx;
   const cb::Builder& b = p->circuit->build->b;
   const WitnessDev& W = p->wd;
   const unsigned R = (unsigned)rows;
-  for (uint32_t gI = 0; gI < W.n_decomp; gI++) {
-    const uint32_t total = (b.decomp[gI].nbits - 1) * b.decomp[gI].count;
-    hipLaunchKernelGGL(k_wit_decomp, dim3((total + 255) / 256, R), dim3(256), 0, st, W, gI, priv, Z, status);
-  }
+  if (part != 2)
+    for (uint32_t gI = 0; gI < W.n_decomp; gI++) {
+      const uint32_t total = (b.decomp[gI].nbits - 1) * b.decomp[gI].count;
+      hipLaunchKernelGGL(k_wit_decomp, dim3((total + 255) / 256, R), dim3(256), 0, st, W, gI, priv, Z, status);
+    }
   hipLaunchKernelGGL(k_wit_inputs, dim3(((1 + 2 * p->len_z + p->n_priv) + 255) / 256, R), dim3(256), 0, st, W, priv, (const uint32_t*)p->zs_all_d, Z, (uint32_t)first);
+  if (part == 1) {
+    hipLaunchKernelGGL(k_wit_chains, dim3((J.nA + 3) / 4, R), dim3(64), 0, st, W, 0u, Z, job_out, (const uint32_t*)nullptr);
+    P_TRY(hipGetLastError());
+    return VIMZ_OK;
+  }
   for (uint32_t gI = 0; gI < W.n_groups; gI++)
     hipLaunchKernelGGL(k_wit_lanes, dim3((b.lane_groups[gI].lanes + LANE_TB - 1) / LANE_TB, R), dim3(LANE_TB), 0, st, W, gI, priv, (const uint32_t*)p->zs_all_d, (uint32_t)first, Z, status);
-  if (J.nA && !ahead) hipLaunchKernelGGL(k_wit_chains, dim3((J.nA + 3) / 4, R), dim3(64), 0, st, W, 0u, Z, job_out, (const uint32_t*)nullptr);
+  if (J.nA && !ahead && part != 2) hipLaunchKernelGGL(k_wit_chains, dim3((J.nA + 3) / 4, R), dim3(64), 0, st, W, 0u, Z, job_out, (const uint32_t*)nullptr);
   if (J.early_fops) {
     hipLaunchKernelGGL(k_wit_fops_lc, dim3(p->n_fops, R), dim3(64), 0, st, W, (const uint32_t*)Z, job_out, 1u);
     hipLaunchKernelGGL(k_wit_fops, dim3((R + 63) / 64), dim3(64), 0, st, W, Z, job_out, (uint32_t)rows, 1u);
@@ -239,7 +248,7 @@ static int launch_witness(vimz_prover* p, hipStream_t st, uint32_t* Z, uint32_t*
 
 // Stage 0 (caller holds the lock, device set): every private input to HBM; ONE hash-only pass of the phase-A Poseidon chains
 // over ALL rows (they depend on the row data only); the host then runs the whole IVC state chain z_0..z_n and uploads it.
-static int fold_prepare(vimz_prover* p, FoldJob& J) {
+static int fold_prepare(vimz_prover* p, FoldJob& J, bool start_batch0 = false) {
   vimz_ctx* ctx = p->ctx;
   hipStream_t s = ctx->stream;
   const cb::Builder& b = p->circuit->build->b;
@@ -269,7 +278,24 @@ static int fold_prepare(vimz_prover* p, FoldJob& J) {
     P_TRY(grow(p->retired, &p->job_all_d, &p->cap_job_all, 32 * nsteps * jstride, 32 * 1024 * jstride));
     P_TRY(hipMemcpyAsync(p->priv_all_d, J.step_inputs, 32 * nsteps * (size_t)p->n_priv, hipMemcpyHostToDevice, s));
     P_TRY(hipMemsetAsync(p->job_all_d, 0, 32 * nsteps * jstride, s));
-    for (size_t off = 0; off < nsteps && J.nA; off += 32768) {
+    // Both this pass and the first witness batch are one Poseidon-chain latency long (≈10 ms, whatever the row count), and the
+    // first fold waits for both.  For the first batch's rows the chains therefore run once, with their wires, into the batch
+    // buffer on the producer's stream, side by side with the hash-only pass of the remaining rows; fold_issue(0) adds the rest.
+    size_t rows0 = 0;
+    if (start_batch0 && J.nA && !J.nE && !J.early_fops) {
+      const size_t nb0 = (nsteps + B - 1) / B;
+      rows0 = std::min((nsteps + nb0 - 1) / nb0, nsteps);
+      auto& b0 = p->buf[0];
+      P_TRY(hipEventRecord(b0.wit_done, s));
+      P_TRY(hipStreamWaitEvent(p->sB, b0.wit_done, 0));
+      P_TRY(hipMemsetAsync(b0.status, 0, 4 * rows0, p->sB));
+      int rc = launch_witness(p, p->sB, b0.Z, b0.job_out, b0.status, p->priv_all_d, 0, rows0, J, false, 1);
+      if (rc) return rc;
+      P_TRY(hipMemcpyAsync(p->job_all_d, b0.job_out, 32 * rows0 * jstride, hipMemcpyDeviceToDevice, p->sB));
+      P_TRY(hipEventRecord(b0.wit_done, p->sB));
+      J.batch0_started = true;
+    }
+    for (size_t off = rows0; off < nsteps && J.nA; off += 32768) {
       const unsigned rows = (unsigned)std::min<size_t>(32768, nsteps - off);
       hipLaunchKernelGGL(k_wit_chains, dim3((J.nA + 3) / 4, rows), dim3(64), 0, s, W, 0u, (uint32_t*)nullptr, p->job_all_d + 8 * off * jstride,
                          (const uint32_t*)(p->priv_all_d + 8 * off * p->n_priv));
@@ -296,6 +322,7 @@ static int fold_prepare(vimz_prover* p, FoldJob& J) {
       }
     }
     std::vector<Fe> jobA(nsteps * jstride);
+    if (J.batch0_started) P_TRY(hipStreamWaitEvent(s, p->buf[0].wit_done, 0));
     P_TRY(hipMemcpyAsync(jobA.data(), p->job_all_d, 32 * nsteps * jstride, hipMemcpyDeviceToHost, s));
     P_TRY(hipStreamSynchronize(s));
     p->phase_s[PH_WITNESS] += now_s() - t0; t0 = now_s();
@@ -324,12 +351,13 @@ static int fold_issue(vimz_prover* p, const FoldJob& J, size_t k) {
   auto& bb = p->buf[k & 1];
   const size_t first = k * J.Bk, rows = std::min(J.Bk, J.nsteps - first);
   hipStream_t sb = p->sB;
-  P_TRY(hipMemsetAsync(bb.status, 0, 4 * rows, sb));
+  const bool started = k == 0 && J.batch0_started;      // (its status words already hold the decompositions' range checks)
+  if (!started) P_TRY(hipMemsetAsync(bb.status, 0, 4 * rows, sb));
   if (J.witnesses) {
     P_TRY(hipMemcpy2DAsync(bb.Z, 32 * nw, J.witnesses + 4 * first * sw, 32 * sw, 32 * sw, rows, hipMemcpyHostToDevice, sb));
     launch_to_mont<Fr>(sb, bb.Z, rows * nw);
   } else {
-    int rc = launch_witness(p, sb, bb.Z, bb.job_out, bb.status, p->priv_all_d + 8 * first * p->n_priv, first, rows, J, false);
+    int rc = launch_witness(p, sb, bb.Z, bb.job_out, bb.status, p->priv_all_d + 8 * first * p->n_priv, first, rows, J, false, started ? 2 : 0);
     if (rc) return rc;
   }
   P_TRY(hipGetLastError());
