@@ -425,7 +425,7 @@ int vimz_ivc_create(vimz_ctx* ctx, const vimz_circuit* step_circuit, const vimz_
     if (getenv("VIMZ_DEBUG_NO_S2")) v->s2 = ctx->stream;
     else if ((e = hipStreamCreateWithPriority(&v->s2, hipStreamNonBlocking, hi)) != hipSuccess) return fail("stream");
     if (getenv("VIMZ_DEBUG_NO_S2")) v->s3 = ctx->stream;
-    else if ((e = hipStreamCreateWithPriority(&v->s3, hipStreamNonBlocking, (lo + hi) / 2)) != hipSuccess) return fail("stream");
+    else if ((e = hipStreamCreateWithPriority(&v->s3, hipStreamNonBlocking, getenv("VIMZ_DEBUG_S3_PRIO") ? atoi(getenv("VIMZ_DEBUG_S3_PRIO")) : (lo + hi) / 2)) != hipSuccess) return fail("stream");
     if ((e = hipEventCreateWithFlags(&v->ev_fork, hipEventDisableTiming)) != hipSuccess) return fail("event");
     if ((e = hipEventCreateWithFlags(&v->ev_fold, hipEventDisableTiming)) != hipSuccess) return fail("event");
     if ((e = hipEventCreate(&v->ev_b0)) != hipSuccess || (e = hipEventCreate(&v->ev_b1)) != hipSuccess) return fail("event");

@@ -113,7 +113,7 @@ int vz_prover_create_layout(vimz_ctx* ctx, const vimz_circuit* circuit, const vi
       dalloc(&p->bad_d, 64) != hipSuccess)
     return fail_free("device allocation", e);
   { int lo = 0, hi = 0; hipDeviceGetStreamPriorityRange(&lo, &hi);
-    if ((e = hipStreamCreateWithPriority(&p->sB, hipStreamNonBlocking, lo)) != hipSuccess) return fail_free("stream", e); }
+    if ((e = hipStreamCreateWithPriority(&p->sB, hipStreamNonBlocking, getenv("VIMZ_DEBUG_SB_PRIO") ? atoi(getenv("VIMZ_DEBUG_SB_PRIO")) : lo)) != hipSuccess) return fail_free("stream", e); }
   for (int k = 0; k < 2; k++) {
     auto& bb = p->buf[k];
     if (k == 0) { bb.Z = p->Z_d; bb.job_out = p->job_out_d; bb.status = p->status_d; }   // buffer 0 is shared with the witness hook
