@@ -5,7 +5,7 @@ import collections
 import csv
 import sys
 
-steps = float(sys.argv[2])
+steps = float(sys.argv[2])   # rows folded by the run: warm-up + timed + the single-proof probe (count k_fold5<Fr> launches)
 counter = sys.argv[3] if len(sys.argv) > 3 else "SQ_INSTS_VALU"
 acc, calls = collections.Counter(), collections.Counter()
 for r in csv.DictReader(open(sys.argv[1])):
