@@ -545,6 +545,8 @@ __global__ void __launch_bounds__(256) k_msm_small(const uint32_t* __restrict__ 
   }
   sh[t] = acc;
   __syncthreads();
+  // (Compacting a level's scattered pairs onto the first threads — two waves, then one, instead of all four — saves a fifth of this
+  // kernel's instructions and measured 406 vs 397 steps/s for one proof but 665 vs 685 for three: left as it is.)
   for (uint32_t d = 1; d < s_maxm; d <<= 1) {       // a bucket's sub-buckets are contiguous: stride-doubling tree inside each segment
     if (t < nsubs && (kk & (2 * d - 1)) == 0 && kk + d < mb) { XYZZ<F> a = sh[t]; add_full(a, sh[t + d]); sh[t] = a; }
     __syncthreads();
