@@ -1,7 +1,8 @@
 #!/bin/bash
 # Regenerates the measurement set under gpurun_out/refresh/ on the GPU box (copy what is to be judged into profiles/):
 #   bench lines (IVC default, accumulator), rocprofv3 kernel stats + the k_accum split of the same command, and the
-#   FETCH_SIZE / WRITE_SIZE counter passes (separate runs, counters only) summarised per kernel.
+#   FETCH_SIZE / WRITE_SIZE counter passes (separate runs, counters only) summarised per kernel, whole-image runs and the
+#   bench windows of the other configurations.
 set -u
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/refresh; rm -rf $O; mkdir -p $O
@@ -18,4 +19,19 @@ for mode in ivc accumulator; do
   python3 tools/pmc_summary.py $(find $O/pf -name "*counter_collection.csv" | head -1) $(find $O/pw -name "*counter_collection.csv" | head -1) $O/pmc_summary_$mode.json
   rm -rf $O/pf $O/pw
 done
+# whole images the way `vimz -b nova-snark -f <t>` sequences them (-> profiles/r01_e2e.jsonl)
+: > $O/e2e.jsonl
+for cfg in "contrast HD 3 ivc" "grayscale HD 3 ivc" "blur HD 3 ivc" "crop HD 3 ivc" "contrast 4K 3 ivc" "resize 8K 3 ivc" "contrast HD 2 accumulator" "contrast HD 1 ivc"; do
+  timeout 600 python3 tools/e2e.py $cfg 2>/dev/null | tail -1 >> $O/e2e.jsonl
+done
+# bench windows of the other BASELINE.json configurations (-> profiles/r01_configs.jsonl)
+: > $O/configs.jsonl
+run() { timeout 900 python3 bench.py --no-cpu-baseline "$@" 2>/dev/null | tail -1 >> $O/configs.jsonl; }
+run --transformation grayscale --resolution HD
+run --transformation crop --resolution HD --steps 192
+run --transformation contrast --resolution 4K --steps 192
+run --transformation resize --resolution 8K --steps 192
+run --transformation brightness --resolution 4K --steps 96
+run --transformation sharpness --resolution 4K --steps 96
+run --transformation blur --resolution 4K --steps 96
 ls -la $O
