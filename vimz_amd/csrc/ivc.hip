@@ -226,8 +226,22 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
       t0 = now_s();
       P_TRY(hipEventSynchronize(bb.ev[r]));
       G1Aff cW_step = msm_finish<BnG1>(p->planB, (char*)bb.pin + r * pin_stride);
+      // the large MSM's host tail (Horner over 24 window sums, ≈0.1 ms) is taken whenever its stream turns out to be done:
+      // before the small ones if it already is, so that it overlaps what is still running
+      G1Aff T1_step; bool t1_step_done = false;
+      auto take_T1_step = [&](bool wait) {
+        if (t1_step_done || i == 0) return hipSuccess;
+        hipError_t q = wait ? hipStreamSynchronize(v->s3) : hipStreamQuery(v->s3);
+        if (q == hipErrorNotReady) return hipSuccess;
+        if (q != hipSuccess) return q;
+        T1_step = msm_finish<BnG1>(v->plan_T1, v->pin + v->pin_res);
+        t1_step_done = true; v->t1_step_pending = false;
+        return hipSuccess;
+      };
+      P_TRY(take_T1_step(false));
       P_TRY(hipStreamSynchronize(v->s2));
       G1Aff cW_aug = msm_finish<BnG1>(v->plan_aug, v->pin);      // the small MSM is back first: its tail overlaps the other one
+      P_TRY(take_T1_step(false));
       P_TRY(hipEventSynchronize(v->ev_a));
       v->ph_s[IP_WAIT_PRI] += now_s() - t0; v->ph_n[IP_WAIT_PRI]++;
       t0 = now_s();
@@ -248,10 +262,9 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
         G1Aff Tv = msm_finish<BnG1>(v->plan_T1v, v->pin + 4 * v->pin_res);      // overlaps the rest of the large MSM
         v->ph_s[IP_SYNTH2] += now_s() - t0;
         t0 = now_s();
-        P_TRY(hipStreamSynchronize(v->s3));
+        P_TRY(take_T1_step(true));
         v->ph_s[IP_WAIT_PRI] += now_s() - t0;
-        v->t1_step_pending = false;
-        G1 ts = from_affine(msm_finish<BnG1>(v->plan_T1, v->pin + v->pin_res)); add_mixed(ts, Tv);
+        G1 ts = from_affine(T1_step); add_mixed(ts, Tv);
         T1 = to_affine(ts);
         t0 = now_s();
       }
