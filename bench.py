@@ -128,7 +128,7 @@ def main_ivc(args, rank, world, dist, torch, ctxs, circuit, params, steps_all, g
         dt = float(t[0])
     # acceptance (outside the timed region): every segment proof verifies, and the segments' boundary states chain
     t_v = time.time()
-    codes = [ivc.verify() for ivc in ivcs]
+    codes = [ivc.verify(len(rows), z) for ivc, rows, z in segs]
     ok = all(c == 0 for c in codes)
     ends = [ivc.state()[0] for ivc in ivcs]
     ok = ok and all(ends[i] == segs[i + 1][2] for i in range(S - 1))

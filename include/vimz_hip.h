@@ -168,8 +168,9 @@ int64_t vimz_circuit_export(const vimz_circuit* c, int what, void* buf, size_t c
 
 /* ---- folding prover: the body of `fold_input` (vimz/src/nova_snark_backend/folding.rs:27-43), i.e. the per-row loop of
  *      nova_scotia::create_recursive_circuit around nova-snark's RecursiveSNARK::prove_step, with W, E and the running
- *      (A,B,C)·Z resident in HBM.  The instance folded is the step circuit's R1CS with X = (z_{i+1}, z_i); nova-snark's
- *      augmented verifier circuit and secondary curve are not part of this round. ------------------------ */
+ *      (A,B,C)·Z resident in HBM.  This is the NIFS *accumulator* over the step circuit's own instances, X = (z_{i+1}, z_i):
+ *      accumulators of different row segments merge (vimz_prover_merge), which is the multi-GPU sharding of BASELINE.json's
+ *      north_star.  RecursiveSNARK::prove_step in full — augmented verifier circuits on both curves — is vimz_ivc_* below. ------------------------ */
 typedef struct vimz_prover vimz_prover;
 /* ck must be on BN254 G1 with at least max(wires, constraints) generators; max_batch = rows whose witnesses are
  * generated together (memory: max_batch * wires * 32 bytes). */
@@ -222,12 +223,14 @@ int vimz_ivc_reset(vimz_ivc* v, const uint64_t* z0);
 /* same inputs as vimz_prover_fold / vimz_prover_fold_witness */
 int vimz_ivc_fold(vimz_ivc* v, const uint64_t* step_inputs, size_t nsteps);
 int vimz_ivc_fold_witness(vimz_ivc* v, const uint64_t* witnesses, size_t nsteps);
-/* RecursiveSNARK::verify: both output hashes, is_sat_relaxed of both running instances, is_sat of the last secondary instance,
- * every commitment re-opened.  result: 0 = accepted; bit 0/1 hash of the primary/secondary chain; bit 2 primary relaxed relation;
+/* RecursiveSNARK::verify(pp, num_steps, z0_primary, z0_secondary) (reached from folding.rs:53-55): the proof must be about exactly
+ * `num_steps` steps from the initial state `z0` (len_z canonical elements; the secondary's z0 is the constant [0]); both output
+ * hashes (recomputed from the CLAIMED z0), is_sat_relaxed of both running instances, is_sat of the last secondary instance,
+ * every commitment re-opened.  result: 0 = accepted; bit 12 the proof's step count or initial state differ from the claimed ones; bit 0/1 hash of the primary/secondary chain; bit 2 primary relaxed relation;
  * bit 3 primary comm_W; bit 4 primary comm_E; bit 5 secondary relaxed relation; bit 6/7 secondary comm_W/comm_E; bit 8 last
  * secondary instance's relation; bit 9 its comm_W; bit 10 instance scalars differ from the witness vectors; bit 11 the running products (A,B,C)·Z kept for the next
  * fold violate the relation (prover-side bookkeeping, not part of the proof). */
-int vimz_ivc_verify(vimz_ivc* v, uint32_t* result);
+int vimz_ivc_verify(vimz_ivc* v, uint64_t num_steps, const uint64_t* z0, uint32_t* result);
 /* info[0..11]: steps, primary wires, primary constraints, step wires, step constraints, secondary wires, secondary constraints,
  * len_z, verifier-circuit wires (primary), nnz(A+B+C) primary, nnz secondary, reserved */
 int vimz_ivc_info(const vimz_ivc* v, uint64_t info[12]);
@@ -253,11 +256,11 @@ int vimz_ivc_proof_import(vimz_ivc* v, const uint8_t* blob, size_t len);
                                    commitment curve's base field, u/X in this side's scalar field) */
 #define VIMZ_IX_FRESH_INSTANCE 104  /* side 1 only: comm_W.x, comm_W.y, x0, x1 */
 #define VIMZ_IX_INFO 106        /* u64[4]: wires, constraints, step wires, step constraints */
-#define VIMZ_IX_PARAMS 105      /* digest, pz, z0..., z_i...  (2 + 2 len_z elements of this side's field; secondary len_z = 1) */
+#define VIMZ_IX_PARAMS 105      /* digest, z0..., z_i...  (1 + 2 len_z elements of this side's field; secondary len_z = 1) */
 int64_t vimz_ivc_export(vimz_ivc* v, int side, int what, void* buf, size_t cap);
 /* Host-only hooks for the parity tests of the verifier circuit itself (no GPU): build the augmented circuit of one side over a
  * trivial step circuit (z_out = z_in, arity 1), export it, and run its witness generator on given inputs.
- *   inputs (canonical elements): pz, i, z_i, U = (W.x, W.y, E.x, E.y, u, X0, X1), u = (W.x, W.y, x0, x1), T = (x, y)   -> 16 elements
+ *   inputs (canonical elements): digest, i, z_0, z_i, U = (W.x, W.y, E.x, E.y, u, X0, X1), u = (W.x, W.y, x0, x1), T = (x, y)   -> 17 elements
  *   wires_out: n_wires elements (the full witness incl. the constant and the trivial step)
  *   outputs: U_new (7), rho (1), x0, x1 (2), flag (1: 1 = some range check failed)                                      -> 11 elements */
 typedef struct vimz_augcircuit vimz_augcircuit;

@@ -48,15 +48,15 @@ template <class F> static void store_relaxed(const NovaRelaxed<F>& r, u64* U) {
   memcpy(U + 20, r.X0, 32); memcpy(U + 24, r.X1, 32);
 }
 template <class Cv, class G>
-static int nova_step_c(int is_primary, const u64* pz, u64 i, const u64* z_i, const u64* z_next, int len_z, const u64* U, const u64* u, const u64* T,
+static int nova_step_c(int is_primary, const u64* pz, u64 i, const u64* z_0, const u64* z_i, const u64* z_next, int len_z, const u64* U, const u64* u, const u64* T,
                        u64* U_new, u64* rho, u64* x1) {
   typedef typename Cv::Base F;
-  std::vector<F> zi(len_z), zn(len_z);
-  for (int k = 0; k < len_z; k++) { zi[k] = F::from_canonical(z_i + 4 * k); zn[k] = F::from_canonical(z_next + 4 * k); }
+  std::vector<F> z0(len_z), zi(len_z), zn(len_z);
+  for (int k = 0; k < len_z; k++) { z0[k] = F::from_canonical(z_0 + 4 * k); zi[k] = F::from_canonical(z_i + 4 * k); zn[k] = F::from_canonical(z_next + 4 * k); }
   NovaFresh<F> uf; uf.W.x = F::from_canonical(u); uf.W.y = F::from_canonical(u + 4); uf.x0 = F::from_canonical(u + 8); uf.x1 = F::from_canonical(u + 12);
   Affine<F> Tp; Tp.x = F::from_canonical(T); Tp.y = F::from_canonical(T + 4);
   NovaRelaxed<F> R; F x1f;
-  if (!nova_step<Cv, G>(is_primary != 0, F::from_canonical(pz), i, zi, zn, load_relaxed<F>(U), uf, Tp, R, rho, x1f)) return 0;
+  if (!nova_step<Cv, G>(is_primary != 0, F::from_canonical(pz), i, z0, zi, zn, load_relaxed<F>(U), uf, Tp, R, rho, x1f)) return 0;
   store_relaxed(R, U_new); x1f.to_canonical(x1);
   return 1;
 }
@@ -283,19 +283,19 @@ long orc_r1cs_check(size_t nrows, size_t ncols, const uint32_t* const* row_ptr, 
 void orc_nova_hash(int fid, const u64* in, int n, u64* out) {
   FIELD_SWITCH(fid, { std::vector<F> v(n); for (int i = 0; i < n; i++) v[i] = F::from_canonical(in + 4 * i); nova_hash<F>(v).to_canonical(out); });
 }
-// trunc250(H(pz, i, z, U)); U = 7 canonical elements (W.x, W.y, E.x, E.y, u, X0, X1)
-void orc_nova_instance_hash(int fid, const u64* pz, u64 i, const u64* z, int len_z, const u64* U, u64* out) {
+// trunc250(H(digest, i, z_0, z, U)); U = 7 canonical elements (W.x, W.y, E.x, E.y, u, X0, X1)
+void orc_nova_instance_hash(int fid, const u64* pz, u64 i, const u64* z_0, const u64* z, int len_z, const u64* U, u64* out) {
   FIELD_SWITCH(fid, {
-    std::vector<F> zz(len_z); for (int k = 0; k < len_z; k++) zz[k] = F::from_canonical(z + 4 * k);
-    low_bits(nova_instance_hash_full<F>(F::from_canonical(pz), i, zz, load_relaxed<F>(U)), 250).to_canonical(out);
+    std::vector<F> z0(len_z), zz(len_z); for (int k = 0; k < len_z; k++) { z0[k] = F::from_canonical(z_0 + 4 * k); zz[k] = F::from_canonical(z + 4 * k); }
+    low_bits(nova_instance_hash_full<F>(F::from_canonical(pz), i, z0, zz, load_relaxed<F>(U)), 250).to_canonical(out);
   });
 }
 // side 0: circuit over Fr folding Grumpkin commitments; side 1: circuit over Fq folding BN254-G1 commitments.
 // Returns 1 when the relation holds (incoming hash matches or base case), 0 otherwise.
-int orc_nova_step(int side, int is_primary, const u64* pz, u64 i, const u64* z_i, const u64* z_next, int len_z, const u64* U, const u64* u, const u64* T,
+int orc_nova_step(int side, int is_primary, const u64* pz, u64 i, const u64* z_0, const u64* z_i, const u64* z_next, int len_z, const u64* U, const u64* u, const u64* T,
                   u64* U_new, u64* rho, u64* x1) {
-  return side == 0 ? nova_step_c<Grumpkin, BnFq>(is_primary, pz, i, z_i, z_next, len_z, U, u, T, U_new, rho, x1)
-                   : nova_step_c<BnG1, BnFr>(is_primary, pz, i, z_i, z_next, len_z, U, u, T, U_new, rho, x1);
+  return side == 0 ? nova_step_c<Grumpkin, BnFq>(is_primary, pz, i, z_0, z_i, z_next, len_z, U, u, T, U_new, rho, x1)
+                   : nova_step_c<BnG1, BnFr>(is_primary, pz, i, z_0, z_i, z_next, len_z, U, u, T, U_new, rho, x1);
 }
 // Relaxed R1CS over field fid with dictionary-compressed CSR: first row where Az∘Bz != u·Cz + E (E may be NULL), or -1.
 long orc_r1cs_check_relaxed(int fid, size_t nrows, size_t ncols, const uint32_t* const* row_ptr, const uint32_t* const* col, const uint32_t* const* coef,

@@ -9,8 +9,10 @@
 // paper leaves open are the product's documented choices restated here from that description:
 //   * hash: circomlib-construction Poseidon over the circuit's own field, parameters from the Poseidon reference
 //     Grain LFSR for that prime; arbitrary-length input absorbed 8 elements first, then (running hash + 7) per call;
-//   * instance hash trunc250(H(pz, i, z, U)) with U = (W.x, W.y, E.x, E.y, u, X0 limbs[4], X1 limbs[4]), 64-bit limbs;
-//   * challenge rho = 2^128 + low128(H(H_full(pz,i,z,U), u.W.x, u.W.y, u.x0, u.x1, T.x, T.y));
+//   * instance hash trunc250(H(digest, i, z_0, z_i, U)) with U = (W.x, W.y, E.x, E.y, u, X0 limbs[4], X1 limbs[4]), 64-bit limbs
+//     (the shape digest and the initial state are absorbed by every hash, as in Nova Fig. 4: "hash(vk, i, z_0, z_i, U_i)");
+//   * base case: z_i must equal z_0;
+//   * challenge rho = 2^128 + low128(H(H_full(digest,i,z_0,z_i,U), u.W.x, u.W.y, u.x0, u.x1, T.x, T.y));
 //   * NIFS.V: W' = W + rho·w, E' = E + rho·T, u' = u + rho, X' = X + rho·x mod (other field's prime).
 #pragma once
 #include <vector>
@@ -87,8 +89,9 @@ template <class F> struct NovaRelaxed { Affine<F> W, E; F u; u64 X0[4], X1[4]; }
 template <class F> struct NovaFresh { Affine<F> W; F x0, x1; };
 
 template <class F>
-static F nova_instance_hash_full(const F& pz, u64 i, const std::vector<F>& z, const NovaRelaxed<F>& U) {
-  std::vector<F> in = {pz, F::from_u64(i)};
+static F nova_instance_hash_full(const F& digest, u64 i, const std::vector<F>& z0, const std::vector<F>& z, const NovaRelaxed<F>& U) {
+  std::vector<F> in = {digest, F::from_u64(i)};
+  in.insert(in.end(), z0.begin(), z0.end());
   in.insert(in.end(), z.begin(), z.end());
   in.push_back(U.W.x); in.push_back(U.W.y); in.push_back(U.E.x); in.push_back(U.E.y); in.push_back(U.u);
   for (int k = 0; k < 4; k++) in.push_back(F::from_u64(U.X0[k]));
@@ -97,14 +100,17 @@ static F nova_instance_hash_full(const F& pz, u64 i, const std::vector<F>& z, co
 }
 
 // One run of the augmented circuit's relation.  C: the curve whose points are being folded (coordinates in F = C::Base);
-// G: the other field (the folded instances' scalar field).  Returns false when the incoming hash does not match.
+// G: the other field (the folded instances' scalar field).  Returns false when the incoming hash does not match, or when the base
+// case does not start from z_0.
 template <class C, class G>
-static bool nova_step(bool is_primary, const typename C::Base& pz, u64 i, const std::vector<typename C::Base>& z_i, const std::vector<typename C::Base>& z_next,
+static bool nova_step(bool is_primary, const typename C::Base& digest, u64 i, const std::vector<typename C::Base>& z_0,
+                      const std::vector<typename C::Base>& z_i, const std::vector<typename C::Base>& z_next,
                       const NovaRelaxed<typename C::Base>& U_in, const NovaFresh<typename C::Base>& u, const Affine<typename C::Base>& T,
                       NovaRelaxed<typename C::Base>& U_new, u64 rho_out[4], typename C::Base& x1_out) {
   typedef typename C::Base F;
   const bool base = i == 0;
-  const F h_full = nova_instance_hash_full<F>(pz, i, z_i, U_in);
+  if (base) for (size_t k = 0; k < z_i.size(); k++) if (z_i[k] != z_0[k]) return false;      // the chain starts from the claimed state
+  const F h_full = nova_instance_hash_full<F>(digest, i, z_0, z_i, U_in);
   if (!base && low_bits(h_full, 250) != u.x0) return false;
   std::vector<F> rin = {h_full, u.W.x, u.W.y, u.x0, u.x1, T.x, T.y};
   const F hr = nova_hash<F>(rin);
@@ -122,7 +128,7 @@ static bool nova_step(bool is_primary, const typename C::Base& pz, u64 i, const 
   (G::from_canonical(U.X1) + rg * G::from_canonical(x1c)).to_canonical(R.X1);
   if (is_primary && base) { R.W.x = R.W.y = R.E.x = R.E.y = R.u = F::zero(); memset(R.X0, 0, 32); memset(R.X1, 0, 32); }
   U_new = R;
-  x1_out = low_bits(nova_instance_hash_full<F>(pz, i + 1, z_next, R), 250);
+  x1_out = low_bits(nova_instance_hash_full<F>(digest, i + 1, z_0, z_next, R), 250);
   return true;
 }
 

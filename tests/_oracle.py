@@ -129,17 +129,18 @@ class Oracle:
         self.lib.orc_nova_hash(fid, _p(to_limbs(inputs)), len(inputs), _p(o))
         return from_limbs(o)[0]
 
-    def nova_instance_hash(self, fid, pz, i, z, U):
-        """trunc250(H(pz, i, z, U)); U = [W.x, W.y, E.x, E.y, u, X0, X1]."""
+    def nova_instance_hash(self, fid, digest, i, z0, z, U):
+        """trunc250(H(digest, i, z0, z, U)); U = [W.x, W.y, E.x, E.y, u, X0, X1]."""
+        assert len(z0) == len(z)
         o = np.zeros(4, dtype=np.uint64)
-        self.lib.orc_nova_instance_hash(fid, _p(to_limbs([pz])), C.c_uint64(i), _p(to_limbs(z)), len(z), _p(to_limbs(U)), _p(o))
+        self.lib.orc_nova_instance_hash(fid, _p(to_limbs([digest])), C.c_uint64(i), _p(to_limbs(z0)), _p(to_limbs(z)), len(z), _p(to_limbs(U)), _p(o))
         return from_limbs(o)[0]
 
-    def nova_step(self, side, is_primary, pz, i, z_i, z_next, U, u, T):
-        """The augmented circuit's relation, natively: returns None if the incoming hash does not match,
-        else (U_new[7], rho, x1)."""
+    def nova_step(self, side, is_primary, digest, i, z0, z_i, z_next, U, u, T):
+        """The augmented circuit's relation, natively: returns None if the incoming hash does not match (or the base case does
+        not start from z0), else (U_new[7], rho, x1)."""
         Un, rho, x1 = np.zeros((7, 4), dtype=np.uint64), np.zeros(4, dtype=np.uint64), np.zeros(4, dtype=np.uint64)
-        ok = self.lib.orc_nova_step(side, int(is_primary), _p(to_limbs([pz])), C.c_uint64(i), _p(to_limbs(z_i)), _p(to_limbs(z_next)), len(z_i),
+        ok = self.lib.orc_nova_step(side, int(is_primary), _p(to_limbs([digest])), C.c_uint64(i), _p(to_limbs(z0)), _p(to_limbs(z_i)), _p(to_limbs(z_next)), len(z_i),
                                     _p(to_limbs(U)), _p(to_limbs(u)), _p(to_limbs(T)), _p(Un), _p(rho), _p(x1))
         if not ok:
             return None

@@ -80,6 +80,8 @@ class OracleProver:
         d = pickle.loads(np.asarray(blob, dtype=np.uint8).tobytes())
         if d["steps"] == 0:
             return
+        if list(d["z0"]) != list(self.z):
+            raise ValueError("merge: the incoming segment does not start at the state this accumulator ends in")
         if self.steps == 0:
             for k, v in d.items():
                 setattr(self, k, v)

@@ -29,7 +29,8 @@ def _pt(oracle, cid, k):
 def _case(oracle, side, name, rng):
     fid, cid, gid = SIDES[side]
     p_other = oracle.modulus[gid]
-    pz, z = rng.randrange(1 << 250), rng.randrange(1 << 200)
+    pz, z = rng.randrange(1 << 250), rng.randrange(1 << 200)       # pz: the shape digest the hashes absorb
+    z0 = z if name == "base" else rng.randrange(1 << 200)
     r250 = lambda: rng.randrange(1 << 250)
     if name == "base":
         i = 0
@@ -52,8 +53,8 @@ def _case(oracle, side, name, rng):
         u = [*_pt(oracle, cid, rng.randrange(1, 1 << 64)), 0, r250()]
         T = _pt(oracle, cid, rng.randrange(1, 1 << 64))
     if i > 0:
-        u[2] = oracle.nova_instance_hash(fid, pz, i, [z], U)
-    return pz, i, z, U, u, T
+        u[2] = oracle.nova_instance_hash(fid, pz, i, [z0], [z], U)
+    return pz, i, z0, z, U, u, T
 
 
 @pytest.mark.parametrize("side", [0, 1])
@@ -72,11 +73,11 @@ def test_witness_satisfies_r1cs_and_equals_native_relation(oracle, circuits, sid
     c = cs[side]
     fid = SIDES[side][0]
     rng = random.Random(f"{side}-{name}")
-    pz, i, z, U, u, T = _case(oracle, side, name, rng)
-    wires, out = c.witness([pz, i, z, *U, *u, *T])
+    pz, i, z0, z, U, u, T = _case(oracle, side, name, rng)
+    wires, out = c.witness([pz, i, z0, z, *U, *u, *T])
     assert out[10] == 0, "range flag"
     assert oracle.r1cs_check_relaxed(fid, tabs[side], c.n_wires, wires) == -1
-    want = oracle.nova_step(side, side == 0, pz, i, [z], [z], U, u, T)
+    want = oracle.nova_step(side, side == 0, pz, i, [z0], [z], [z], U, u, T)
     assert want is not None
     U_new, rho, x1 = want
     assert out[0:7] == U_new and out[7] == rho and out[9] == x1 and out[8] == u[3]
@@ -90,12 +91,38 @@ def test_wrong_incoming_hash_is_rejected(oracle, circuits, side):
     cs, tabs = circuits
     c = cs[side]
     fid = SIDES[side][0]
-    pz, i, z, U, u, T = _case(oracle, side, "generic", random.Random(7))
+    pz, i, z0, z, U, u, T = _case(oracle, side, "generic", random.Random(7))
     u[2] ^= 1
-    assert oracle.nova_step(side, side == 0, pz, i, [z], [z], U, u, T) is None
-    wires, out = c.witness([pz, i, z, *U, *u, *T])
+    assert oracle.nova_step(side, side == 0, pz, i, [z0], [z], [z], U, u, T) is None
+    wires, out = c.witness([pz, i, z0, z, *U, *u, *T])
     assert out[10] == 1
     assert oracle.r1cs_check_relaxed(fid, tabs[side], c.n_wires, wires) >= 0
+
+
+@pytest.mark.parametrize("side", [0, 1])
+def test_base_case_must_start_from_z0(oracle, circuits, side):
+    """A chain that claims z_0 but feeds the first step another state is not satisfiable (without this the IVC
+    proved only that SOME start state leads to z_n), and z_0 reaches every later hash: changing it changes the output hash."""
+    cs, tabs = circuits
+    c = cs[side]
+    fid = SIDES[side][0]
+    pz, i, z0, z, U, u, T = _case(oracle, side, "base", random.Random(3))
+    assert i == 0 and z0 == z
+    wires, out = c.witness([pz, i, z0, z, *U, *u, *T])
+    assert out[10] == 0 and oracle.r1cs_check_relaxed(fid, tabs[side], c.n_wires, wires) == -1
+    x1_good = out[9]
+    assert oracle.nova_step(side, side == 0, pz, 0, [z0 + 1], [z], [z], U, u, T) is None
+    wires, out = c.witness([pz, i, z0 + 1, z, *U, *u, *T])
+    assert out[10] == 1
+    assert oracle.r1cs_check_relaxed(fid, tabs[side], c.n_wires, wires) >= 0
+    # later steps: z_0 is free to differ from z_i but is bound by the hashes
+    pz, i, z0, z, U, u, T = _case(oracle, side, "generic", random.Random(4))
+    _, out_a = c.witness([pz, i, z0, z, *U, *u, *T])
+    u_b = list(u); u_b[2] = oracle.nova_instance_hash(fid, pz, i, [z0 + 1], [z], U)
+    _, out_b = c.witness([pz, i, z0 + 1, z, *U, *u_b, *T])
+    assert out_a[10] == 0 and out_b[10] == 0 and out_a[9] != out_b[9] and x1_good != out_a[9]
+    wires, out = c.witness([pz, i, z0 + 1, z, *U, *u, *T])          # the old hash with another z_0: rejected
+    assert out[10] == 1 and oracle.r1cs_check_relaxed(fid, tabs[side], c.n_wires, wires) >= 0
 
 
 @pytest.mark.parametrize("side", [0, 1])
@@ -105,8 +132,8 @@ def test_tampered_witness_and_off_curve_points_are_rejected(oracle, circuits, si
     fid = SIDES[side][0]
     p = oracle.modulus[fid]
     rng = random.Random(11 + side)
-    pz, i, z, U, u, T = _case(oracle, side, "generic", rng)
-    wires, out = c.witness([pz, i, z, *U, *u, *T])
+    pz, i, z0, z, U, u, T = _case(oracle, side, "generic", rng)
+    wires, out = c.witness([pz, i, z0, z, *U, *u, *T])
     assert oracle.r1cs_check_relaxed(fid, tabs[side], c.n_wires, wires) == -1
     for k in rng.sample(range(1, c.n_wires), 1500):
         w = wires.copy()
@@ -115,10 +142,10 @@ def test_tampered_witness_and_off_curve_points_are_rejected(oracle, circuits, si
     # a fresh commitment that is not on the curve
     bad_u = list(u); bad_u[1] = (bad_u[1] + 1) % p
     bad_u[2] = u[2]
-    wires, out = c.witness([pz, i, z, *U, *bad_u, *T])
+    wires, out = c.witness([pz, i, z0, z, *U, *bad_u, *T])
     assert oracle.r1cs_check_relaxed(fid, tabs[side], c.n_wires, wires) >= 0
     bad_T = (T[0], (T[1] + 1) % p)
-    wires, out = c.witness([pz, i, z, *U, *u, *bad_T])
+    wires, out = c.witness([pz, i, z0, z, *U, *u, *bad_T])
     assert oracle.r1cs_check_relaxed(fid, tabs[side], c.n_wires, wires) >= 0
 
 

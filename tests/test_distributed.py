@@ -80,6 +80,10 @@ def test_merge_of_oracle_provers_satisfies_relaxed_r1cs(oracle):
     a, b = OracleProver(oracle, c, key), OracleProver(oracle, c, key)
     a.reset(z0); a.fold(inputs[:3])
     b.reset(a.z); b.fold(inputs[3:4])
+    with pytest.raises(ValueError):          # segments merge only in row order and only when adjacent
+        b.merge(a.export())
+    with pytest.raises(ValueError):
+        a.merge(a.export())
     a.merge(b.export())
     assert a.verify() == 0 and a.steps == 4
     a.E[0, 0] ^= np.uint64(1)

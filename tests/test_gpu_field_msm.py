@@ -227,6 +227,40 @@ def test_msm_large_dense(ctx, oracle):
     B.free()
 
 
+def test_msm_2_19_dense_and_real_error_vector(ctx, oracle):
+    """The headline launches are 305 k / 313 k points over a 2^19 key: oracle parity at n = 2^19 on (a) uniform 254-bit scalars and
+    (b) a REAL running error vector E exported from a contrast-HD IVC after eight folds (41 % zeros, repeated values, heavy
+    buckets — the structure DESIGN.md §9 describes), zero-padded to 2^19."""
+    from tests.test_circuits import step_inputs
+    from vimz_amd import hip
+    from vimz_amd.circuit import Circuit
+    n = 1 << 19
+    rs = np.random.default_rng(19)
+    raw = rs.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64)
+    raw[:, 3] &= np.uint64((1 << 60) - 1)
+    ck = ctx.bases_generate(_lib.CURVE_BN254_G1, n)
+    bases = ck.download(0, n)
+    assert tuple(from_limbs(ctx.msm(ck, raw))) == oracle.msm(0, bases, raw, threads=8)
+    c = Circuit.for_resolution("contrast", "HD")
+    ck2 = ctx.bases_generate(_lib.CURVE_GRUMPKIN, 1 << 13, b"ck-secondary")
+    ivc = hip.IVC(ctx, c, ck, ck2, max_batch=4)
+    try:
+        z0, inputs = step_inputs("contrast")
+        ivc.reset(z0); ivc.fold(np.stack(inputs[:8]))
+        E = np.ascontiguousarray(ivc.export(0, hip.IX_RUNNING_E))
+        inst = from_limbs(ivc.export(0, hip.IX_INSTANCE))
+    finally:
+        ivc.close(); ck2.free()
+    assert (E == 0).all(axis=1).mean() > 0.2                    # it IS the structured vector, not a dense one
+    want = oracle.msm(0, bases[:len(E)], E, threads=8)
+    assert want == (inst[2], inst[3])                           # the prover's comm_E is the oracle's commitment to E
+    pad = np.zeros((n, 4), dtype=np.uint64); pad[:len(E)] = E
+    assert tuple(from_limbs(ctx.msm(ck, pad))) == want
+    v = ctx.vec_from_host(_lib.FIELD_BN254_FR, E)
+    assert tuple(from_limbs(ctx.msm_vec(ck, v))) == want
+    v.free(); ck.free()
+
+
 @pytest.mark.parametrize("cid", [0, 1, 2, 3])
 def test_commitment_key_derivation(ctx, oracle, cid):
     """GPU SHAKE256 try-and-increment generators == Python hashlib restatement; all on the curve."""

@@ -64,8 +64,9 @@ def test_witness_matches_oracle_executor(ctx, ck, oracle, circuits, op):
         P.close()
 
 
-@pytest.mark.parametrize("op", ["grayscale", "sharpness"])
+@pytest.mark.parametrize("op", ["grayscale", "sharpness", "contrast"])
 def test_spmv_matches_oracle(ctx, ck, oracle, circuits, op):
+    """(A,B,C)·z on the shapes the bench runs (contrast = the headline workload), on a real witness and on dense random z."""
     from vimz_amd import hip
     c = circuits[op]
     z0, inputs = step_inputs(op)
@@ -210,7 +211,15 @@ def test_segment_merge_matches_oracle_prover(ctx, ck, oracle, circuits):
         A.reset(z0); A.fold(rows[:3])
         B.reset(z_mid); B.fold(rows[3:])
         assert A.verify() == 0 and B.verify() == 0
-        A.merge(B.export())
+        blob_a, blob_b = A.export(), B.export()
+        # segments must be adjacent and in row order: B after B, A after A, A after B are all refused and leave B untouched
+        for bad in (blob_b, blob_a):
+            with pytest.raises(_lib.VimzError):
+                B.merge(bad)
+        with pytest.raises(_lib.VimzError):
+            A.merge(blob_a)
+        assert B.instance()["steps"] == 2 and A.instance()["steps"] == 3
+        A.merge(blob_b)
         assert A.verify() == 0
         inst = A.instance()
         z_run, E_run = A.running()
@@ -394,7 +403,7 @@ def test_crop_witness_and_folds_on_the_gpu(oracle, y):
         inst = P.instance()
         assert inst["steps"] == 5 and from_limbs(inst["z"]) == zz
         ivc.reset(z0); ivc.fold(np.stack(o[:5]))
-        assert ivc.verify() == 0 and ivc.state() == (zz, 5)
+        assert ivc.verify(5, z0) == 0 and ivc.state() == (zz, 5)
     finally:
         ivc.close(); P.close(); key.free(); ck2.free(); cx.close()
 

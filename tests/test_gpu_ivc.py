@@ -53,16 +53,18 @@ def oracle_verify(oracle, ivc, ck1, ck2, n_steps, z0, check_commitments=True):
     info = ivc.info()
     par1, par2 = from_limbs(ivc.export(0, hip.IX_PARAMS)), from_limbs(ivc.export(1, hip.IX_PARAMS))
     len_z = info["len_z"]
-    digest1, pz1, z0_x, z_n = par1[0], par1[1], par1[2:2 + len_z], par1[2 + len_z:]
-    digest2, pz2 = par2[0], par2[1]
+    digest1, z0_x, z_n = par1[0], par1[1:1 + len_z], par1[1 + len_z:]
+    digest2 = par2[0]
     if z0_x != list(z0): failed.append("z0")
-    if digest1 != _shape_digest(ivc, 0) or digest2 != _shape_digest(ivc, 1): failed.append("shape digest")
-    if pz1 != oracle.nova_hash(0, [digest1, *z0]) or pz2 != oracle.nova_hash(1, [digest2, 0]): failed.append("pz")
+    if info["steps"] != n_steps: failed.append("step count")
+    # the verifier's OWN digests and the CLAIMED z0 go into the hashes below, never the proof's copies
+    digest1, digest2 = _shape_digest(ivc, 0), _shape_digest(ivc, 1)
+    if (digest1, digest2) != (par1[0], par2[0]): failed.append("shape digest")
     U1, U2 = from_limbs(ivc.export(0, hip.IX_INSTANCE)), from_limbs(ivc.export(1, hip.IX_INSTANCE))
     u2 = from_limbs(ivc.export(1, hip.IX_FRESH_INSTANCE))
     # the two hashes the last secondary instance carries
-    if oracle.nova_instance_hash(0, pz1, n_steps, z_n, U2) != u2[2]: failed.append("hash of the primary chain")
-    if oracle.nova_instance_hash(1, pz2, n_steps, [0], U1) != u2[3]: failed.append("hash of the secondary chain")
+    if oracle.nova_instance_hash(0, digest1, n_steps, list(z0), z_n, U2) != u2[2]: failed.append("hash of the primary chain")
+    if oracle.nova_instance_hash(1, digest2, n_steps, [0], [0], U1) != u2[3]: failed.append("hash of the secondary chain")
     for side, U, ck, cid, fid in ((0, U1, ck1, 0, 0), (1, U2, ck2, 1, 1)):
         tabs = ivc.r1cs(side)
         Z, E = ivc.export(side, hip.IX_RUNNING_Z), ivc.export(side, hip.IX_RUNNING_E)
@@ -95,7 +97,8 @@ def test_ivc_verifies_and_the_oracle_verifier_accepts(ctx, keys, oracle, op):
     try:
         ivc.reset(z0)
         ivc.fold(steps)
-        assert ivc.verify() == 0
+        assert ivc.verify(10, z0) == 0
+        assert ivc.verify(9, z0) & 4096 and ivc.verify(10, [x + 1 for x in z0]) & (4096 | 1) == (4096 | 1)     # the statement is part of the check
         z_n, n = ivc.state()
         assert n == 10
         acc.reset(z0); acc.fold(steps)
@@ -120,13 +123,13 @@ def test_ivc_in_several_calls_equals_one_call_and_reset_restarts(ctx, keys, orac
         a.reset(z0); b.reset(z0)
         a.fold(steps[:1]); a.fold(steps[1:4]); a.fold(steps[4:])
         b.fold(steps)
-        assert a.verify() == 0 and b.verify() == 0
+        assert a.verify(10, z0) == 0 and b.verify(10, z0) == 0
         for side in (0, 1):
             assert (a.export(side, hip.IX_INSTANCE) == b.export(side, hip.IX_INSTANCE)).all()
             assert (a.export(side, hip.IX_RUNNING_Z) == b.export(side, hip.IX_RUNNING_Z)).all()
         assert (a.export(1, hip.IX_FRESH_INSTANCE) == b.export(1, hip.IX_FRESH_INSTANCE)).all()
         # verification in the middle of a run does not disturb it
-        a.reset(z0); a.fold(steps[:5]); assert a.verify() == 0; a.fold(steps[5:]); assert a.verify() == 0
+        a.reset(z0); a.fold(steps[:5]); assert a.verify(5, z0) == 0; a.fold(steps[5:]); assert a.verify(10, z0) == 0
         assert (a.export(0, hip.IX_INSTANCE) == b.export(0, hip.IX_INSTANCE)).all()
         failed, _ = oracle_verify(oracle, a, ck1, ck2, 10, z0)
         assert failed == []
@@ -150,10 +153,10 @@ def test_ivc_rejects_a_row_that_violates_the_step_relation(ctx, keys):
             ivc.fold(steps)
         assert e.value.code == _lib.ERR_UNSAT
         # the batch before the bad one (rows 0-3) stays folded and the proof is consistent there: it verifies and can go on
-        assert ivc.state()[1] == 4 and ivc.verify() == 0
+        assert ivc.state()[1] == 4 and ivc.verify(4, z0) == 0
         ivc.fold(good[4:])
         ref.reset(z0); ref.fold(good)
-        assert ivc.verify() == 0 and ivc.state() == ref.state()
+        assert ivc.verify(10, z0) == 0 and ivc.state() == ref.state()
         assert (ivc.export(0, hip.IX_INSTANCE) == ref.export(0, hip.IX_INSTANCE)).all()
     finally:
         ivc.close(); ref.close()
@@ -194,7 +197,8 @@ def test_full_image_as_two_ivc_proofs_ends_in_the_references_committed_state(ctx
         for v, r, z in segs:
             v.reset(z)
         fold_concurrently([(v, r) for v, r, z in segs])
-        assert [v.verify() for v in ivcs] == [0, 0]
+        assert [v.verify(360, z) for v, r, z in segs] == [0, 0]
+        assert segs[0][2] == [int(x) for x in z0]
         assert ivcs[0].state() == (segs[1][2], 360)
         assert ivcs[1].state() == ([int(x) for x in P["z_final"]], 360)
     finally:
@@ -216,10 +220,10 @@ def test_proof_export_import_verifies_elsewhere_and_resumes(ctx, keys, oracle):
         a.reset(z0); a.fold(steps[:6])
         blob = a.proof_export()
         b.proof_import(blob)
-        assert b.verify() == 0 and b.state() == a.state()
+        assert b.verify(6, z0) == 0 and b.state() == a.state()
         b.fold(steps[6:])
         ref.reset(z0); ref.fold(steps)
-        assert b.verify() == 0
+        assert b.verify(10, z0) == 0
         for side in (0, 1):
             assert (b.export(side, hip.IX_INSTANCE) == ref.export(side, hip.IX_INSTANCE)).all()
             assert (b.export(side, hip.IX_RUNNING_Z) == ref.export(side, hip.IX_RUNNING_Z)).all()
@@ -233,7 +237,15 @@ def test_proof_export_import_verifies_elsewhere_and_resumes(ctx, keys, oracle):
             bad = blob.copy()
             bad[where] ^= 1
             a.proof_import(bad)
-            assert a.verify() != 0, where
+            assert a.verify(6, z0) != 0, where
+        # limbs that are not below the modulus are refused before anything of the importing IVC changes
+        b_state = b.state()
+        for where in (len(blob) // 2, len(blob) - 16):
+            bad = blob.copy()
+            bad[where - where % 32: where - where % 32 + 32] = 0xFF
+            with pytest.raises(_lib.VimzError):
+                b.proof_import(bad)
+        assert b.state() == b_state and b.verify(10, z0) == 0
         with pytest.raises(_lib.VimzError):
             a.proof_import(blob[:1000])
     finally:
@@ -258,7 +270,7 @@ def test_concurrent_provers_all_verify(oracle):
                 v.reset(z0)
             with ThreadPoolExecutor(4) as ex:
                 list(ex.map(lambda v: v.fold(steps), ivcs))
-            assert [v.verify() for v in ivcs] == [0, 0, 0, 0]
+            assert [v.verify(10, z0) for v in ivcs] == [0, 0, 0, 0]
             ref = ivcs[0].export(0, hip.IX_INSTANCE)
             assert all((v.export(0, hip.IX_INSTANCE) == ref).all() for v in ivcs)      # same inputs: the very same proof
         finally:

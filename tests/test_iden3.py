@@ -101,7 +101,7 @@ def test_ivc_over_a_loaded_r1cs_with_external_witnesses(oracle, hash_circuit):
     try:
         ivc.reset(z0)
         ivc.fold_witness(np.stack(wits))
-        assert ivc.verify() == 0 and ivc.state() == (z, 5)
+        assert ivc.verify(5, z0) == 0 and ivc.state() == (z, 5)
         with pytest.raises(_lib.VimzError):
             ivc.fold(np.stack(inputs[:1]))               # a loaded circuit has no witness program
         with pytest.raises(_lib.VimzError):

@@ -42,7 +42,7 @@ def main():
             c.sync()
         spans["Fold input"] = time.time() - t0
         t0 = time.time()
-        ok = all(v.verify() == 0 for v in ivcs) and all(segs[i][0].state()[0] == segs[i + 1][2] for i in range(S - 1))
+        ok = all(v.verify(len(r), z) == 0 for v, r, z in segs) and segs[0][2] == list(z0)
         spans["Verify folded proof"] = time.time() - t0
         n = sum(v.state()[1] for v in ivcs)
         if save:

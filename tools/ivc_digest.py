@@ -31,7 +31,7 @@ def main():
     ivc.reset(z0)
     ivc.fold(rows[:7])          # two calls: the second starts without a queued large MSM
     ivc.fold(rows[7:])
-    code = ivc.verify()
+    code = ivc.verify(len(rows), z0)
     h = hashlib.sha256()
     for side in (0, 1):
         h.update(np.ascontiguousarray(ivc.export(side, hip.IX_INSTANCE)).tobytes())

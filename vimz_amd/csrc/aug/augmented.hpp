@@ -82,7 +82,7 @@ struct AugCircuit {
     primary = is_primary;
     len_z = b.len_z; step_wires = b.n_wires; step_constraints = b.n_constraints();
     CS<FP> cs; cs.b = &b; cs.base = b.n_wires;
-    AugIn<FP> in; in.pz = F::zero(); in.i = 0; in.U = RelaxedInst<F>::zero(); in.u = FreshInst<F>::zero(); in.T.x = in.T.y = F::zero();
+    AugIn<FP> in; in.digest = F::zero(); in.i = 0; in.U = RelaxedInst<F>::zero(); in.u = FreshInst<F>::zero(); in.T.x = in.T.y = F::zero();
     std::vector<Num<F>> zi, zn;
     for (uint32_t k = 0; k < len_z; k++) { zi.push_back(cs.wire(1 + len_z + k, F::zero())); zn.push_back(cs.wire(1 + k, F::zero())); }
     synthesize_augmented<FP, OP>(cs, in, zi, zn, primary, CycleSide<FP>::b(), CycleSide<FP>::G());
@@ -111,12 +111,6 @@ struct AugCircuit {
     return o;
   }
 
-  // pz = H(digest, z_0): the constant the circuit hashes in place of (params, z_0)
-  F pz(const F* z0) const {
-    std::vector<F> in; in.push_back(digest);
-    for (uint32_t k = 0; k < len_z; k++) in.push_back(z0[k]);
-    return hash_native<FP>(in);
-  }
 };
 
 }  // namespace aug

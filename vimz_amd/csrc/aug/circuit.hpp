@@ -7,14 +7,17 @@
 // One instance of the circuit, over field F (native), does for the OTHER circuit's instances (commitments = points with
 // coordinates in F, public IO = elements of the other field):
 //     is_base = (i == 0)
-//     check   u.x0 == trunc250(H(pz, i, z_i, U))                       unless is_base
-//     rho     = 2^128 + low128(H(H(pz, i, z_i, U), u.W, u.x0, u.x1, T))      Fiat–Shamir challenge, leading one explicit
+//     check   z_i == z_0                                                if is_base (the chain starts from the claimed state)
+//     check   u.x0 == trunc250(H(digest, i, z_0, z_i, U))              unless is_base
+//     rho     = 2^128 + low128(H(H(digest, i, z_0, z_i, U), u.W, u.x0, u.x1, T))      Fiat–Shamir challenge, leading one explicit
 //     U'      = NIFS.V(U or the zero instance if is_base, u, T, rho):
 //               W' = W + rho·u.W,  E' = E + rho·T,  u' = u + rho,  X' = X + rho·x (mod the other field's prime)
 //     U_new   = primary and is_base ? zero instance : U'
 //     z_{i+1} = F(z_i)                                                  (the step circuit; identity on the secondary)
-//     public IO  X0 = u.x1 (passed through),  X1 = trunc250(H(pz, i+1, z_{i+1}, U_new))
-// pz = H(shape digest, z_0) is computed by prover and verifier outside the circuit: z_0 is only ever hashed.
+//     public IO  X0 = u.x1 (passed through),  X1 = trunc250(H(digest, i+1, z_0, z_{i+1}, U_new))
+// digest (of the shape) and z_0 are witness wires that every hash absorbs, as in nova-snark's circuit: the verifier recomputes the
+// final hash with the true digest and the claimed z_0, and the chain of hash checks carries both back to step 0, where z_i is
+// tied to z_0.
 #pragma once
 #include "cs.hpp"
 
@@ -46,11 +49,12 @@ inline void absorb_relaxed(const RelaxedInst<F>& U, std::vector<F>& out) {
   for (int j = 0; j < 4; j++) out.push_back(cb::f_from_u64<F>(U.X0.w[j]));
   for (int j = 0; j < 4; j++) out.push_back(cb::f_from_u64<F>(U.X1.w[j]));
 }
-// trunc250(H(pz, i, z, U)) outside any circuit (verifier; also the prover's bookkeeping)
+// trunc250(H(digest, i, z_0, z, U)) outside any circuit (verifier; also the prover's bookkeeping)
 template <class FP>
-inline Fp<FP> instance_hash_native(const Fp<FP>& pz, uint64_t i, const std::vector<Fp<FP>>& z, const RelaxedInst<Fp<FP>>& U, Fp<FP>* full = nullptr) {
+inline Fp<FP> instance_hash_native(const Fp<FP>& digest, uint64_t i, const std::vector<Fp<FP>>& z0, const std::vector<Fp<FP>>& z, const RelaxedInst<Fp<FP>>& U, Fp<FP>* full = nullptr) {
   typedef Fp<FP> F;
-  std::vector<F> in; in.push_back(pz); in.push_back(cb::f_from_u64<F>(i));
+  std::vector<F> in; in.push_back(digest); in.push_back(cb::f_from_u64<F>(i));
+  in.insert(in.end(), z0.begin(), z0.end());
   in.insert(in.end(), z.begin(), z.end());
   absorb_relaxed(U, in);
   F h = hash_native<FP>(in);
@@ -61,7 +65,8 @@ inline Fp<FP> instance_hash_native(const Fp<FP>& pz, uint64_t i, const std::vect
 template <class FP>
 struct AugIn {
   typedef Fp<FP> F;
-  F pz; uint64_t i = 0;
+  F digest; uint64_t i = 0;
+  std::vector<F> z0;       // the initial state the chain claims to start from (len_z elements; empty = zeros)
   RelaxedInst<F> U; FreshInst<F> u; Affine<F> T;
 };
 template <class FP>
@@ -96,7 +101,9 @@ AugOut<FP> synthesize_augmented(CS<FP>& cs, const AugIn<FP>& in, const std::vect
   VZ_T0();
 
   // ---- inputs --------------------------------------------------------------------------------------------------------
-  N pz = cs.alloc(in.pz);
+  N dg = cs.alloc(in.digest);
+  std::vector<N> z0(z_i.size());
+  for (size_t k = 0; k < z_i.size(); k++) z0[k] = cs.alloc(k < in.z0.size() ? in.z0[k] : F::zero());
   N iN = cs.alloc(cb::f_from_u64<F>(in.i));
   std::vector<F> inv = {iN.v, in.U.W.y, in.U.E.y, in.u.W.y, in.T.y};
   batch_inv(inv);
@@ -120,10 +127,16 @@ AugOut<FP> synthesize_augmented(CS<FP>& cs, const AugIn<FP>& in, const std::vect
   N is_base = cs.is_zero(iN, &inv[0]);
   N nb = cs.one_minus(is_base);
   const bool base = in.i == 0;
+  // the base case starts from the claimed initial state: is_base·(z_i − z_0) = 0
+  for (size_t k = 0; k < z_i.size(); k++) {
+    cs.enforce(is_base, cs.sub(z_i[k], z0[k]), cs.zero());
+    if (base && !z_i[k].v.eq(z0[k].v)) cs.bad = true;
+  }
 
   VZ_T(0, "inputs");
   // ---- consistency of the incoming instance with the previous step's output hash ---------------------------------------
-  std::vector<N> hin; hin.push_back(pz); hin.push_back(iN);
+  std::vector<N> hin; hin.push_back(dg); hin.push_back(iN);
+  hin.insert(hin.end(), z0.begin(), z0.end());
   hin.insert(hin.end(), z_i.begin(), z_i.end());
   hin.push_back(UW.x); hin.push_back(UW.y); hin.push_back(UE.x); hin.push_back(UE.y); hin.push_back(Uu);
   for (int j = 0; j < 4; j++) hin.push_back(UX0[j]);
@@ -185,7 +198,8 @@ AugOut<FP> synthesize_augmented(CS<FP>& cs, const AugIn<FP>& in, const std::vect
   out.U_new.X0 = X0nv; out.U_new.X1 = X1nv;
 
   // ---- output hash ----------------------------------------------------------------------------------------------------------
-  std::vector<N> hout; hout.push_back(pz); hout.push_back(cs.addc(iN, F::one()));
+  std::vector<N> hout; hout.push_back(dg); hout.push_back(cs.addc(iN, F::one()));
+  hout.insert(hout.end(), z0.begin(), z0.end());
   hout.insert(hout.end(), z_next.begin(), z_next.end());
   hout.push_back(Wo.x); hout.push_back(Wo.y); hout.push_back(Eo.x); hout.push_back(Eo.y); hout.push_back(uo);
   for (int j = 0; j < 4; j++) hout.push_back(X0n[j]);

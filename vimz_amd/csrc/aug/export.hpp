@@ -46,11 +46,12 @@ inline int witness_flat(const AugCircuit<FP>& c, const uint64_t* in, uint64_t* w
   auto fe = [&](int k) { F x; memcpy(x.v, in + 4 * k, 32); return F::to_mont(x); };
   auto u256 = [&](int k) { U256w x; memcpy(x.w, in + 4 * k, 32); return x; };
   AugIn<FP> a;
-  a.pz = fe(0); a.i = in[4];
-  F zi = fe(2);
-  a.U.W.x = fe(3); a.U.W.y = fe(4); a.U.E.x = fe(5); a.U.E.y = fe(6); a.U.u = fe(7); a.U.X0 = u256(8); a.U.X1 = u256(9);
-  a.u.W.x = fe(10); a.u.W.y = fe(11); a.u.x0 = fe(12); a.u.x1 = fe(13);
-  a.T.x = fe(14); a.T.y = fe(15);
+  a.digest = fe(0); a.i = in[4];
+  a.z0.push_back(fe(2));
+  F zi = fe(3);
+  a.U.W.x = fe(4); a.U.W.y = fe(5); a.U.E.x = fe(6); a.U.E.y = fe(7); a.U.u = fe(8); a.U.X0 = u256(9); a.U.X1 = u256(10);
+  a.u.W.x = fe(11); a.u.W.y = fe(12); a.u.x0 = fe(13); a.u.x1 = fe(14);
+  a.T.x = fe(15); a.T.y = fe(16);
   std::vector<F> aug; bool bad = false;
   AugOut<FP> o = c.witness(a, &zi, &zi, aug, &bad);
   auto put = [&](uint64_t* dst, const F& m) { F x = F::from_mont(m); memcpy(dst, x.v, 32); };

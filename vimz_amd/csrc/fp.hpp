@@ -82,6 +82,12 @@ struct Fp {
   static VZ_HD Fp r2() { Fp r; for (int i = 0; i < 8; i++) r.v[i] = P::R2.w[i]; return r; }
   VZ_HD bool is_zero() const { uint32_t o = 0; for (int i = 0; i < 8; i++) o |= v[i]; return o == 0; }
   VZ_HD bool eq(const Fp& b) const { uint32_t o = 0; for (int i = 0; i < 8; i++) o |= v[i] ^ b.v[i]; return o == 0; }
+  // limbs < p: the invariant every operation here assumes of its operands (data from outside is checked with this)
+  VZ_HD bool is_reduced() const {
+    uint64_t br = 0;
+    for (int i = 0; i < 8; i++) { uint64_t d = (uint64_t)v[i] - P::MOD.w[i] - br; br = (d >> 32) & 1; }
+    return br != 0;
+  }
 
   // r = a - p if a >= p  (a < 2p)
   static VZ_HD Fp reduce_once(const uint32_t* t) {

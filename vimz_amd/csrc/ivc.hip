@@ -82,8 +82,8 @@ struct vimz_ivc {
   BaseTables tb_aug{}, tb_T1v{}, tb_ck2{};
   // host state of the recursion
   uint64_t i = 0;
-  Fe pz1 = Fe::zero(); Fq pz2 = Fq::zero();
-  std::vector<Fe> z0;
+  std::vector<Fe> z0;                             // the initial state the chain starts from (absorbed by every instance hash)
+  std::vector<Fq> z0_sec{Fq::zero()};             // the secondary's trivial step circuit starts from [0]
   RelaxedInst<Fe> U2;       // running secondary instance (commitments on Grumpkin), as the primary circuit sees it
   RelaxedInst<Fq> U1;       // running primary instance (commitments on BN254 G1), as the secondary circuit sees it
   FreshInst<Fe> u2;         // last fresh secondary instance
@@ -184,7 +184,7 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
       if ((rc = finish_secondary(v))) return rc;
       // ---- 2. primary verifier circuit on the host: folds (U2, u2) and hashes the result ----------------------------------------
       t0 = now_s();
-      AugIn<BnFr> in1; in1.pz = v->pz1; in1.i = i; in1.U = v->U2; in1.u = v->u2; in1.T = v->T2;
+      AugIn<BnFr> in1; in1.digest = v->c1->digest; in1.z0 = v->z0; in1.i = i; in1.U = v->U2; in1.u = v->u2; in1.T = v->T2;
       std::vector<Fe> aug1; bool bad = false;
       AugOut<BnFr> o1 = v->c1->witness(in1, zs.data() + (first + r) * p->len_z, zs.data() + (first + r + 1) * p->len_z, aug1, &bad);
       if (bad) return vz_fail(ctx, VIMZ_ERR_UNSAT, "primary verifier circuit: inconsistent incoming instance");
@@ -294,7 +294,7 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
         ctx->msm_tot_calls++; ctx->msm_tot_points += sc; ctx->msm_tot_entries += ctx->last_msm.entries;
       }
       // ---- 4. secondary verifier circuit on the host: folds (U1, u1) ---------------------------------------------------------------------
-      AugIn<BnFq> in2; in2.pz = v->pz2; in2.i = i; in2.U = v->U1; in2.u = u1; in2.T = T1;
+      AugIn<BnFq> in2; in2.digest = v->c2.digest; in2.z0 = v->z0_sec; in2.i = i; in2.U = v->U1; in2.u = u1; in2.T = T1;
       std::vector<Fq> aug2;
       AugOut<BnFq> o2 = v->c2.witness(in2, &zero_q, &zero_q, aug2, &bad);
       if (bad) return vz_fail(ctx, VIMZ_ERR_UNSAT, "secondary verifier circuit: inconsistent incoming instance");
@@ -489,9 +489,6 @@ int vimz_ivc_reset(vimz_ivc* v, const uint64_t* z0) {
   P_TRY(hipStreamSynchronize(s));
   v->i = 0;
   for (uint32_t k = 0; k < v->c1->len_z; k++) v->z0[k] = v->pri->z_cur[k];
-  v->pz1 = v->c1->pz(v->z0.data());
-  const Fq zq = Fq::zero();
-  v->pz2 = v->c2.pz(&zq);
   v->U1 = RelaxedInst<Fq>::zero(); v->U2 = RelaxedInst<Fe>::zero(); v->u2 = FreshInst<Fe>::zero(); v->T2.x = v->T2.y = Fe::zero();
   v->u1_run = Fe::zero(); v->u2_run = Fq::zero();
   v->pending_sec = false; v->sec_T_valid = false; v->t1_step_pending = false;
@@ -536,8 +533,8 @@ int vimz_ivc_profile(const vimz_ivc* v, double seconds[8], uint64_t counts[8]) {
   return VIMZ_OK;
 }
 
-int vimz_ivc_verify(vimz_ivc* v, uint32_t* result) {
-  if (!v || !result) return VIMZ_ERR_INVALID;
+int vimz_ivc_verify(vimz_ivc* v, uint64_t num_steps, const uint64_t* z0, uint32_t* result) {
+  if (!v || !result || !z0) return VIMZ_ERR_INVALID;
   vimz_ctx* ctx = v->ctx;
   vimz_prover* p = v->pri;
   std::lock_guard<std::mutex> g(ctx->mu);
@@ -545,13 +542,26 @@ int vimz_ivc_verify(vimz_ivc* v, uint32_t* result) {
   hipStream_t s = ctx->stream;
   SecDev& S = v->sec;
   uint32_t res = 0;
-  if (v->i == 0) { *result = 0; return VIMZ_OK; }
-  // 1. the two hashes carried by the last fresh secondary instance
+  // 0. the statement: the proof must be about the claimed number of steps from the claimed initial state
+  //    (RecursiveSNARK::verify(pp, num_steps, z0_primary, z0_secondary), reached from folding.rs:53-55)
+  std::vector<Fe> z0c(p->len_z);
+  for (uint32_t k = 0; k < p->len_z; k++) {
+    Fe c; memcpy(c.v, z0 + 4 * k, 32);
+    if (!c.is_reduced()) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_ivc_verify: z0 element not below the modulus");
+    z0c[k] = Fe::to_mont(c);
+  }
+  if (v->i != num_steps) res |= 4096;
+  for (uint32_t k = 0; k < p->len_z; k++) if (!z0c[k].eq(v->z0[k])) res |= 4096;
+  if (v->i == 0) {       // zero steps: the "proof" is the initial state itself
+    for (uint32_t k = 0; k < p->len_z; k++) if (!p->z_cur[k].eq(z0c[k])) res |= 4096;
+    *result = res; return VIMZ_OK;
+  }
+  // 1. the two hashes carried by the last fresh secondary instance, recomputed from the CLAIMED z0
   {
-    Fe h1 = instance_hash_native<BnFr>(v->pz1, v->i, p->z_cur, v->U2);
+    Fe h1 = instance_hash_native<BnFr>(v->c1->digest, v->i, z0c, p->z_cur, v->U2);
     if (!h1.eq(v->u2.x0)) res |= 1;
     std::vector<Fq> zq = {Fq::zero()};
-    Fq h2 = instance_hash_native<BnFq>(v->pz2, v->i, zq, v->U1);
+    Fq h2 = instance_hash_native<BnFq>(v->c2.digest, v->i, v->z0_sec, zq, v->U1);
     if (!cross_field<Fe>(h2).eq(v->u2.x1)) res |= 2;
   }
   const uint32_t init[2] = {0, 0xffffffffu};
@@ -641,8 +651,8 @@ int64_t vimz_ivc_export(vimz_ivc* v, int side, int what, void* buf, size_t cap) 
       if (side != 1) return VIMZ_ERR_INVALID;
       push(v->u2.W.x); push(v->u2.W.y); push(v->u2.x0); push(v->u2.x1);
     } else {
-      if (side == 0) { push(v->c1->digest); push(v->pz1); for (auto& z : v->z0) push(z); for (auto& z : p->z_cur) push(z); }
-      else { push(v->c2.digest); push(v->pz2); push(Fq::zero()); push(Fq::zero()); }
+      if (side == 0) { push(v->c1->digest); for (auto& z : v->z0) push(z); for (auto& z : p->z_cur) push(z); }
+      else { push(v->c2.digest); push(Fq::zero()); push(Fq::zero()); }
     }
     const size_t bytes = o.size() * 8;
     if (buf && cap >= bytes) memcpy(buf, o.data(), bytes);
@@ -672,9 +682,9 @@ int64_t vimz_ivc_export(vimz_ivc* v, int side, int what, void* buf, size_t cap) 
 // same step circuit and keys) or folding can resume after a restart.
 namespace {
 struct ProofHeader { uint64_t magic, steps, n_w1, n_c1, n_w2, n_c2, len_z, flags; };
-const uint64_t PROOF_MAGIC = 0x3143564956ull;   // "VIVC1"
+const uint64_t PROOF_MAGIC = 0x3243564956ull;   // "VIVC2"
 struct ProofHost {
-  Fe pz1; Fq pz2; RelaxedInst<Fe> U2; RelaxedInst<Fq> U1; FreshInst<Fe> u2; G2Aff T2; Fe u1_run; Fq u2_run; Fe digest1; Fq digest2;
+  RelaxedInst<Fe> U2; RelaxedInst<Fq> U1; FreshInst<Fe> u2; G2Aff T2; Fe u1_run; Fq u2_run; Fe digest1; Fq digest2;
 };
 size_t proof_vec_bytes(const vimz_ivc* v) {
   const size_t nw1 = v->pri->n_wires, nc1 = v->pri->n_c, nw2 = v->sec.n_w, nc2 = v->sec.n_c;
@@ -695,7 +705,7 @@ int vimz_ivc_proof_export(vimz_ivc* v, uint8_t* blob, size_t cap) {
   hipStream_t s = ctx->stream;
   ProofHeader h{PROOF_MAGIC, v->i, p->n_wires, p->n_c, S.n_w, S.n_c, p->len_z, (uint64_t)(v->sec_T_valid ? 1 : 0)};
   ProofHost hs; memset(&hs, 0, sizeof(hs));
-  hs.pz1 = v->pz1; hs.pz2 = v->pz2; hs.U2 = v->U2; hs.U1 = v->U1; hs.u2 = v->u2; hs.T2 = v->T2; hs.u1_run = v->u1_run; hs.u2_run = v->u2_run;
+  hs.U2 = v->U2; hs.U1 = v->U1; hs.u2 = v->u2; hs.T2 = v->T2; hs.u1_run = v->u1_run; hs.u2_run = v->u2_run;
   hs.digest1 = v->c1->digest; hs.digest2 = v->c2.digest;
   uint8_t* o = blob;
   memcpy(o, &h, sizeof(h)); o += sizeof(h);
@@ -717,23 +727,52 @@ int vimz_ivc_proof_import(vimz_ivc* v, const uint8_t* blob, size_t len) {
     return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_ivc_proof_import: the blob does not match this IVC's circuits");
   ProofHost hs; memcpy(&hs, blob + sizeof(h), sizeof(hs));
   if (!hs.digest1.eq(v->c1->digest) || !hs.digest2.eq(v->c2.digest)) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_ivc_proof_import: shape digest differs");
+  // The blob is untrusted: every field element in it must be below its modulus BEFORE anything of this IVC changes (the Montgomery
+  // arithmetic and the raw-limb comparisons of vimz_ivc_verify assume reduced operands).
+  {
+    bool ok = hs.U2.W.x.is_reduced() && hs.U2.W.y.is_reduced() && hs.U2.E.x.is_reduced() && hs.U2.E.y.is_reduced() && hs.U2.u.is_reduced() &&
+              hs.U1.W.x.is_reduced() && hs.U1.W.y.is_reduced() && hs.U1.E.x.is_reduced() && hs.U1.E.y.is_reduced() && hs.U1.u.is_reduced() &&
+              hs.u2.W.x.is_reduced() && hs.u2.W.y.is_reduced() && hs.u2.x0.is_reduced() && hs.u2.x1.is_reduced() &&
+              hs.T2.x.is_reduced() && hs.T2.y.is_reduced() && hs.u1_run.is_reduced() && hs.u2_run.is_reduced();
+    const uint8_t* zp = blob + sizeof(h) + sizeof(hs);
+    for (uint32_t k = 0; k < 2 * p->len_z && ok; k++) { Fe z; memcpy(z.v, zp + 32 * k, 32); ok = z.is_reduced(); }
+    if (!ok) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_ivc_proof_import: a field element of the blob is not below its modulus");
+  }
   std::lock_guard<std::mutex> g(ctx->mu);
   P_TRY(hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
-  const uint8_t* o = blob + sizeof(h) + sizeof(hs);
-  memcpy(v->z0.data(), o, 32 * p->len_z); o += 32 * p->len_z;
-  memcpy(p->z_cur.data(), o, 32 * p->len_z); o += 32 * p->len_z;
-  p->z0 = v->z0;
-  uint32_t* dst[] = {p->Zrun, p->E, p->AZ, p->BZ, p->CZ, S.Zrun, S.z2, S.E, S.AZ, S.BZ, S.CZ, S.az2, S.bz2, S.cz2, S.T};
+  const uint8_t* o = blob + sizeof(h) + sizeof(hs) + 64 * (size_t)p->len_z;
+  // device vectors: staged, range-checked on the GPU, and only then copied over the IVC's own
   const size_t ln[] = {p->n_wires, p->n_c, p->n_c, p->n_c, p->n_c, S.n_w, S.n_w, S.n_c, S.n_c, S.n_c, S.n_c, S.n_c, S.n_c, S.n_c, S.n_c};
-  for (int k = 0; k < 15; k++) { P_TRY(hipMemcpyAsync(dst[k], o, 32 * ln[k], hipMemcpyHostToDevice, s)); o += 32 * ln[k]; }
+  const size_t vec_bytes = proof_vec_bytes(v);
+  int rc = vz_ensure_scratch(ctx, vec_bytes + 64); if (rc) return rc;
+  uint32_t* stage = (uint32_t*)ctx->scratch;
+  uint32_t* badc = stage + vec_bytes / 4;
+  P_TRY(hipMemcpyAsync(stage, o, vec_bytes, hipMemcpyHostToDevice, s));
+  P_TRY(hipMemsetAsync(badc, 0, 8, s));
+  {
+    size_t off = 0;
+    for (int k = 0; k < 15; k++) {
+      if (k < 5) hipLaunchKernelGGL(k_count_unreduced<Fr>, dim3(stream_grid(ln[k])), dim3(256), 0, s, ln[k], (const uint32_t*)(stage + off), badc);
+      else hipLaunchKernelGGL(k_count_unreduced<Fq>, dim3(stream_grid(ln[k])), dim3(256), 0, s, ln[k], (const uint32_t*)(stage + off), badc);
+      off += 8 * ln[k];
+    }
+  }
+  uint32_t nbad = 0;
+  P_TRY(hipMemcpyAsync(&nbad, badc, 4, hipMemcpyDeviceToHost, s));
   P_TRY(hipStreamSynchronize(s));
+  if (nbad) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_ivc_proof_import: a vector element of the blob is not below its modulus");
+  // commit
+  uint32_t* dst[] = {p->Zrun, p->E, p->AZ, p->BZ, p->CZ, S.Zrun, S.z2, S.E, S.AZ, S.BZ, S.CZ, S.az2, S.bz2, S.cz2, S.T};
+  { size_t off = 0; for (int k = 0; k < 15; k++) { P_TRY(hipMemcpyAsync(dst[k], stage + off, 32 * ln[k], hipMemcpyDeviceToDevice, s)); off += 8 * ln[k]; } }
+  P_TRY(hipStreamSynchronize(s));
+  const uint8_t* zp = blob + sizeof(h) + sizeof(hs);
+  memcpy(v->z0.data(), zp, 32 * p->len_z);
+  memcpy(p->z_cur.data(), zp + 32 * p->len_z, 32 * p->len_z);
+  p->z0 = v->z0;
   v->i = h.steps; p->steps = h.steps;
-  v->pz1 = hs.pz1; v->pz2 = hs.pz2; v->U2 = hs.U2; v->U1 = hs.U1; v->u2 = hs.u2; v->T2 = hs.T2; v->u1_run = hs.u1_run; v->u2_run = hs.u2_run;
-  v->sec_T_valid = (h.flags & 1) != 0; v->pending_sec = false;
-  // pz must be what this IVC derives from its own digests and the blob's z0 (a forged pz would make the hashes unverifiable anyway)
-  const Fq zq = Fq::zero();
-  if (!v->pz1.eq(v->c1->pz(v->z0.data())) || !v->pz2.eq(v->c2.pz(&zq))) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_ivc_proof_import: pz does not match z0");
+  v->U2 = hs.U2; v->U1 = hs.U1; v->u2 = hs.u2; v->T2 = hs.T2; v->u1_run = hs.u1_run; v->u2_run = hs.u2_run;
+  v->sec_T_valid = (h.flags & 1) != 0; v->pending_sec = false; v->t1_step_pending = false;
   v->c1->cache.valid = false; v->c2.cache.valid = false;
   return VIMZ_OK;
 }

@@ -21,6 +21,7 @@
 // bit-identical run to run and to the CPU oracle.
 #pragma once
 #include <cstdlib>
+#include <mutex>
 #include "msm_api.hpp"
 
 namespace vz {
@@ -770,11 +771,17 @@ hipError_t msm_launch(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_ba
   const uint32_t bstride = tabled ? 0u : pl.nbw, pstride = tabled ? (uint32_t)tb->n_total : 0u;
   if (lds_sort) {
     VZ_HIP_CHECK(ws.reserve_block_hist((size_t)SORT_BLOCKS * pl.nb));
-    static bool attr_set = false;
-    if (!attr_set) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&k_hist_lds<S>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_lds<S>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr_set = true;
+    {   // the >64 KiB dynamic-LDS opt-in is per device and per kernel instantiation; contexts fold from several host threads
+      static std::mutex attr_mu;
+      static uint64_t attr_devices = 0;
+      int dev = 0;
+      VZ_HIP_CHECK(hipGetDevice(&dev));
+      std::lock_guard<std::mutex> g(attr_mu);
+      if (!((attr_devices >> (dev & 63)) & 1ull)) {
+        VZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_hist_lds<S>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        VZ_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_scatter_lds<S>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_devices |= 1ull << (dev & 63);
+      }
     }
     hipLaunchKernelGGL(k_hist_lds<S>, dim3(sort_blocks), dim3(SORT_THREADS), pl.nb * 4, stream, d_scalars, n, scalars_mont, split_ones, pl.c, pl.K, bstride, pl.nb, ws.block_hist);
     hipLaunchKernelGGL(k_block_prefix<0>, dim3((pl.nb + 255) / 256), dim3(256), 0, stream, ws.block_hist, pl.nb, ws.counts, sort_blocks, ws.heavy);

@@ -462,6 +462,10 @@ static int merge_core(vimz_prover* p, const OtherInstance& o) {
   hipStream_t s = ctx->stream;
   const size_t nw = p->n_wires, nc = p->n_c;
   if (o.steps == 0) return VIMZ_OK;
+  // Segments are merged in row order and must be ADJACENT: the incoming segment starts at the state this one ends in.  Without this
+  // check segments that are out of order, duplicated or from another image merge into an accumulator that still "verifies".
+  for (uint32_t k = 0; k < p->len_z; k++)
+    if (!o.z0[k].eq(p->z_cur[k])) return vz_fail(ctx, VIMZ_ERR_INVALID, "merge: the incoming segment does not start at the state this accumulator ends in");
   if (p->steps == 0) {   // this prover is empty: adopt the other instance
     P_TRY(hipMemcpyAsync(p->Zrun, o.Z, 32 * nw, hipMemcpyDeviceToDevice, s)); P_TRY(hipMemcpyAsync(p->E, o.E, 32 * nc, hipMemcpyDeviceToDevice, s));
     P_TRY(hipMemcpyAsync(p->AZ, o.AZ, 32 * nc, hipMemcpyDeviceToDevice, s)); P_TRY(hipMemcpyAsync(p->BZ, o.BZ, 32 * nc, hipMemcpyDeviceToDevice, s));
@@ -508,6 +512,8 @@ int vimz_prover_merge(vimz_prover* p, const uint8_t* blob, size_t len) {
   BlobHeader h; memcpy(&h, blob, sizeof(h));
   if (h.magic != BLOB_MAGIC || h.n_wires != p->n_wires || h.n_c != p->n_c || h.len_z != p->len_z || len < vimz_prover_export_size(p))
     return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_prover_merge: blob does not match this prover's circuit");
+  if (h.transformation != (uint64_t)p->circuit->transformation || h.width != (uint64_t)p->circuit->shape.width)
+    return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_prover_merge: blob is of another transformation or row width");
   std::lock_guard<std::mutex> g(ctx->mu);
   P_TRY(hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
@@ -520,6 +526,12 @@ int vimz_prover_merge(vimz_prover* p, const uint8_t* blob, size_t len) {
   oi.z_cur.resize(p->len_z); oi.z0.resize(p->len_z);
   memcpy(oi.z_cur.data(), o, 32 * p->len_z); o += 32 * p->len_z; memcpy(oi.z0.data(), o, 32 * p->len_z); o += 32 * p->len_z;
   if (h.steps == 0) return VIMZ_OK;
+  {   // untrusted host state: limbs must be below the modulus (the vectors are range-checked on the device below)
+    bool ok = oi.u.is_reduced() && oi.ro.is_reduced() && oi.zdigest.is_reduced() && oi.cW.x.is_reduced() && oi.cW.y.is_reduced() && oi.cE.x.is_reduced() && oi.cE.y.is_reduced();
+    for (auto& z : oi.z_cur) ok = ok && z.is_reduced();
+    for (auto& z : oi.z0) ok = ok && z.is_reduced();
+    if (!ok) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_prover_merge: a field element of the blob is not below its modulus");
+  }
   // stage the other instance's vectors in the (idle) batch buffer 0: Z | E | AZ | BZ | CZ
   auto& bb = p->buf[0];
   uint32_t *Z2 = bb.Z, *E2 = p->az2, *AZ2 = bb.az, *BZ2 = bb.bz, *CZ2 = bb.cz;
@@ -528,6 +540,16 @@ int vimz_prover_merge(vimz_prover* p, const uint8_t* blob, size_t len) {
   P_TRY(hipMemcpyAsync(AZ2, o, 32 * nc, hipMemcpyHostToDevice, s)); o += 32 * nc;
   P_TRY(hipMemcpyAsync(BZ2, o, 32 * nc, hipMemcpyHostToDevice, s)); o += 32 * nc;
   P_TRY(hipMemcpyAsync(CZ2, o, 32 * nc, hipMemcpyHostToDevice, s)); o += 32 * nc;
+  {
+    const uint32_t zero2[2] = {0, 0};
+    P_TRY(hipMemcpyAsync(p->bad_d, zero2, 8, hipMemcpyHostToDevice, s));
+    const uint32_t* vs[5] = {Z2, E2, AZ2, BZ2, CZ2}; const size_t ns[5] = {nw, nc, nc, nc, nc};
+    for (int k = 0; k < 5; k++) hipLaunchKernelGGL(k_count_unreduced<Fr>, dim3(stream_grid(ns[k])), dim3(256), 0, s, ns[k], vs[k], p->bad_d);
+    uint32_t nbad = 0;
+    P_TRY(hipMemcpyAsync(&nbad, p->bad_d, 4, hipMemcpyDeviceToHost, s));
+    P_TRY(hipStreamSynchronize(s));
+    if (nbad) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_prover_merge: a vector element of the blob is not below its modulus");
+  }
   oi.Z = Z2; oi.E = E2; oi.AZ = AZ2; oi.BZ = BZ2; oi.CZ = CZ2;
   return merge_core(p, oi);
 }

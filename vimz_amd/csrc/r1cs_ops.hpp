@@ -189,4 +189,13 @@ static __global__ void __launch_bounds__(256) k_count_diff(size_t n, const uint3
   }
 }
 
+// counts elements whose limbs are not below the modulus (data imported from outside)
+template <class F>
+__global__ void __launch_bounds__(256) k_count_unreduced(size_t n, const uint32_t* __restrict__ a, uint32_t* __restrict__ bad) {
+  VZ_GRID_STRIDE(i, n) {
+    F x = load_fe<F>(a, i);
+    if (!x.is_reduced()) atomicAdd(&bad[0], 1u);
+  }
+}
+
 }  // namespace vz

@@ -15,6 +15,7 @@ from .circuit import Circuit, default_shape
 
 DEMO_STEPS = 10  # vimz/src/lib.rs:9
 AUGMENTED_ROOM = 8192   # wires / constraints Nova's verifier circuit adds to a step circuit (vimz_ivc_create)
+SECONDARY_KEY_LEN = 1 << 13   # generators of the secondary (Grumpkin) key: the secondary circuit has 7.6 k wires / rows
 
 # vimz/src/transformation.rs:93-123
 ITERATION_COUNT = {"SD": 480, "HD": 720, "FHD": 1080, "4K": 2160, "8K": 4320}
@@ -73,10 +74,22 @@ def prepare_input(transformation, inp, resolution="HD", demo=False):
 
 
 class FoldingParams:
-    """The analogue of nova-snark's PublicParams: R1CS shape + commitment key, resident on one GPU."""
+    """The analogue of nova-snark's PublicParams: R1CS shape + both commitment keys (BN254 G1 for the primary circuit, Grumpkin for
+    the secondary), resident on one GPU."""
 
-    def __init__(self, ctx, circuit, ck, keygen_seconds):
-        self.ctx, self.circuit, self.ck, self.keygen_seconds = ctx, circuit, ck, keygen_seconds
+    def __init__(self, ctx, circuit, ck, keygen_seconds, ck_secondary=None):
+        self.ctx, self.circuit, self.ck, self.keygen_seconds, self.ck_secondary = ctx, circuit, ck, keygen_seconds, ck_secondary
+
+    def secondary_key(self):
+        if self.ck_secondary is None:
+            self.ck_secondary = self.ctx.bases_generate(_lib.CURVE_GRUMPKIN, SECONDARY_KEY_LEN, b"ck-secondary")
+        return self.ck_secondary
+
+    def free(self):
+        if self.ck_secondary is not None:
+            self.ck_secondary.free()
+            self.ck_secondary = None
+        self.ck.free()
 
 
 def prepare_folding(ctx, transformation, resolution="HD", ck_label=b"ck", window_tables=False):
@@ -84,7 +97,7 @@ def prepare_folding(ctx, transformation, resolution="HD", ck_label=b"ck", window
     (optionally with window tables: 16 x the key's size in HBM, 0.67 GB at HD)."""
     t0 = time.time()
     circuit = Circuit(transformation, *default_shape(transformation, resolution))
-    # next power of two, as nova-snark sizes ck — of the AUGMENTED circuit: the verifier circuit adds 7 711 wires / 7 712 rows
+    # next power of two, as nova-snark sizes ck — of the AUGMENTED circuit: the verifier circuit adds 7.7 k wires / rows
     n = 1 << (max(circuit.n_wires, circuit.n_constraints) + AUGMENTED_ROOM - 1).bit_length()
     ck = ctx.bases_generate(_lib.CURVE_BN254_G1, n, ck_label)
     if window_tables:
@@ -93,24 +106,50 @@ def prepare_folding(ctx, transformation, resolution="HD", ck_label=b"ck", window
 
 
 class FoldingProof:
-    def __init__(self, prover, steps, z0):
-        self.prover, self.steps, self.z0 = prover, steps, z0
+    """FoldingProof (folding.rs:17): the RecursiveSNARK (mode "ivc": a vimz_ivc) or, in accumulator mode, the NIFS accumulator of
+    the step circuit's own instances (a vimz_prover; mergeable across row segments, not a RecursiveSNARK)."""
+
+    def __init__(self, prover, steps, z0, mode):
+        self.prover, self.steps, self.z0, self.mode = prover, steps, z0, mode
 
     def instance(self):
         return self.prover.instance()
 
+    def state(self):
+        """The final IVC state z_n as integers."""
+        if self.mode == "ivc":
+            return self.prover.state()[0]
+        return _limbs_to_ints(self.prover.instance()["z"])
 
-def fold_input(params, ivc_step_inputs, initial_state, max_batch=16, prover=None):
-    """fold_input (folding.rs:27-43).  Raises VimzError (the reference panics with "Failed to fold input")."""
-    from .hip import Prover
-    p = prover or Prover(params.ctx, params.circuit, params.ck, max_batch=max_batch)
+
+def _limbs_to_ints(a):
+    return [sum(int(x[k]) << (64 * k) for k in range(4)) for x in np.asarray(a).reshape(-1, 4)]
+
+
+def fold_input(params, ivc_step_inputs, initial_state, max_batch=16, prover=None, mode="ivc"):
+    """fold_input (folding.rs:27-43): one RecursiveSNARK over all steps (mode "ivc", what the reference produces), or the NIFS
+    accumulator (mode "accumulator").  Raises VimzError (the reference panics with "Failed to fold input")."""
+    from .hip import IVC, Prover
+    if prover is not None:
+        p = prover
+        mode = "ivc" if isinstance(prover, IVC) else "accumulator"
+    elif mode == "ivc":
+        p = IVC(params.ctx, params.circuit, params.ck, params.secondary_key(), max_batch=max_batch)
+    else:
+        p = Prover(params.ctx, params.circuit, params.ck, max_batch=max_batch)
     p.reset(initial_state)
     p.fold(ivc_step_inputs)
-    return FoldingProof(p, len(ivc_step_inputs), list(initial_state))
+    return FoldingProof(p, len(ivc_step_inputs), list(initial_state), mode)
 
 
 def verify_folded_proof(proof, params, num_steps, initial_state):
-    """verify_folded_proof (folding.rs:45-56); raises like the reference's expect("Failed to verify folded proof")."""
+    """verify_folded_proof (folding.rs:45-56: RecursiveSNARK::verify(pp, num_steps, z0, [0])); raises like the reference's
+    expect("Failed to verify folded proof")."""
+    if proof.mode == "ivc":
+        r = proof.prover.verify(num_steps, initial_state)
+        if r != 0:
+            raise _lib.VimzError(_lib.ERR_UNSAT, f"Failed to verify folded proof (flags {r:#x})")
+        return
     inst = proof.prover.instance()
     if inst["steps"] != num_steps or list(initial_state) != list(proof.z0):
         raise _lib.VimzError(_lib.ERR_INVALID, "Failed to verify folded proof: step count / initial state mismatch")

@@ -343,7 +343,7 @@ class IVC:
         lib.vimz_ivc_reset.argtypes = [vp, vp]
         lib.vimz_ivc_fold.argtypes = [vp, vp, sz]
         lib.vimz_ivc_fold_witness.argtypes = [vp, vp, sz]
-        lib.vimz_ivc_verify.argtypes = [vp, C.POINTER(C.c_uint32)]
+        lib.vimz_ivc_verify.argtypes = [vp, C.c_uint64, vp, C.POINTER(C.c_uint32)]
         lib.vimz_ivc_info.argtypes = [vp, vp]
         lib.vimz_ivc_state.argtypes = [vp, vp, C.POINTER(C.c_uint64)]
         lib.vimz_ivc_profile.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
@@ -373,9 +373,14 @@ class IVC:
         a = _u64(witnesses).reshape(-1, self.circuit.n_wires, 4)
         self.ctx._chk(self.ctx.lib.vimz_ivc_fold_witness(self.h, _ptr(a), a.shape[0]))
 
-    def verify(self):
+    def verify(self, num_steps, z0):
+        """RecursiveSNARK::verify(pp, num_steps, z0): 0 = accepted (bit 12: not a proof of `num_steps` steps from `z0`)."""
+        z = np.zeros((self.circuit.len_z, 4), dtype=np.uint64)
+        for i, v in enumerate(z0):
+            for k in range(4):
+                z[i, k] = (int(v) >> (64 * k)) & 0xFFFFFFFFFFFFFFFF
         r = C.c_uint32()
-        self.ctx._chk(self.ctx.lib.vimz_ivc_verify(self.h, C.byref(r)))
+        self.ctx._chk(self.ctx.lib.vimz_ivc_verify(self.h, int(num_steps), _ptr(z), C.byref(r)))
         return r.value
 
     def info(self):
@@ -465,8 +470,9 @@ class AugCircuit:
         return _r1cs_tables(self.lib.vimz_augcircuit_export, self.h)
 
     def witness(self, inputs):
-        """inputs: 16 integers (pz, i, z, U[7], u[4], T[2]).  Returns (wires[n_wires] ints as (n,4) u64, outputs: list of 11 ints)."""
-        a = np.zeros((16, 4), dtype=np.uint64)
+        """inputs: 17 integers (digest, i, z0, z, U[7], u[4], T[2]).  Returns (wires[n_wires] ints as (n,4) u64, outputs: list of 11 ints)."""
+        a = np.zeros((17, 4), dtype=np.uint64)
+        assert len(inputs) == 17
         for i, v in enumerate(inputs):
             for k in range(4):
                 a[i, k] = (int(v) >> (64 * k)) & 0xFFFFFFFFFFFFFFFF
