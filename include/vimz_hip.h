@@ -112,6 +112,27 @@ int vimz_msm_vec(vimz_ctx* ctx, const vimz_bases* bases, size_t base_offset, con
 int vimz_msm_vec_ex(vimz_ctx* ctx, const vimz_bases* bases, size_t base_offset, const vimz_vec* v, size_t offset,
                     size_t n, int window_bits, int flags, uint64_t out_xy[8], int out_form);
 
+/* ---- sparse R1CS mat-vec and the cross-term commitment for a CALLER-SUPPLIED shape (SURVEY.md §8b seam 2): replaces
+ *      `R1CSShape::multiply_vec(&self, z) -> (Az, Bz, Cz)` and `R1CSShape::commit_T(ck, U1, W1, U2, W2) -> (T, comm_T)` of
+ *      nova-snark 0.23.0, reached from NIFS::prove / is_sat* inside RecursiveSNARK::{prove_step, verify}
+ *      (vimz/src/nova_snark_backend/folding.rs:35-41, 53-55).  The matrices are handed over as nova-snark holds them: three lists
+ *      of (row, col, value) triplets, in any order; they stay resident behind the handle (CSR + coefficient dictionary). ------- */
+typedef struct vimz_r1cs vimz_r1cs;
+typedef struct { const uint32_t* row; const uint32_t* col; const uint64_t* val /* nnz x 4 limbs */; size_t nnz; } vimz_coo;
+/* field: the shape's scalar field (VIMZ_FIELD_*); ncols = length of z = [W, u, X] as the caller orders it */
+int vimz_r1cs_upload(vimz_ctx* ctx, int field, size_t nrows, size_t ncols, const vimz_coo* A, const vimz_coo* B, const vimz_coo* C, int form,
+                     vimz_r1cs** out);
+void vimz_r1cs_free(vimz_ctx* ctx, vimz_r1cs* shape);
+/* info = {rows, cols, nnz A, nnz B, nnz C, distinct coefficients, long rows, field} */
+int vimz_r1cs_info(const vimz_r1cs* shape, uint64_t info[8]);
+/* (Az, Bz, Cz) = (A, B, C)·z; every vector a vimz_vec of the shape's field (z: >= ncols elements, outputs: >= nrows) */
+int vimz_spmv3(vimz_ctx* ctx, const vimz_r1cs* shape, const vimz_vec* z, vimz_vec* az, vimz_vec* bz, vimz_vec* cz);
+/* T = AZ1∘BZ2 + AZ2∘BZ1 − u1·CZ2 − u2·CZ1 (written to T_out, nrows elements) and comm_T = Σ T_i·ck_i (affine, out_form).
+ * z1 / z2: the full assignment vectors of the two instances (running and fresh); u1 / u2: their relaxation scalars in `form`
+ * (u2 = 1 for a fresh instance).  ck: at least nrows generators on the curve whose scalar field is the shape's field. */
+int vimz_commit_T(vimz_ctx* ctx, const vimz_r1cs* shape, const vimz_bases* ck, const vimz_vec* z1, const uint64_t u1[4], const vimz_vec* z2,
+                  const uint64_t u2[4], int form, vimz_vec* T_out, uint64_t comm_T[8], int out_form);
+
 /* ---- step circuits: R1CS shape + witness program (replaces the `.r1cs` that nova_scotia::circom::reader::load_r1cs
  *      reads at vimz/src/nova_snark_backend/folding.rs:22 and the circom witness generator named by
  *      Config::witness_generator_file(), folding.rs:36).  Host-only: usable without a GPU. -------------------- */

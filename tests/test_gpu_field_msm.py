@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 from tests._oracle import CURVE_BASE, CURVE_SCALAR, GENERATORS, from_limbs, to_limbs
+from vimz_amd import _lib
 
 pytestmark = pytest.mark.gpu
 

@@ -1,0 +1,84 @@
+"""The standalone SpMV / commit_T seam (include/vimz_hip.h: vimz_r1cs_upload, vimz_spmv3, vimz_commit_T):
+a caller-supplied shape as COO triplets — what nova-snark's R1CSShape holds — against the oracle's spmv / cross_term / msm."""
+import numpy as np
+import pytest
+
+from tests._oracle import from_limbs, r1cs_check, to_limbs, witness_execute
+from tests.test_circuits import step_inputs
+from vimz_amd import _lib
+from vimz_amd.circuit import Circuit
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from vimz_amd import hip
+    c = hip.Context(0)
+    yield c
+    c.close()
+
+
+def _coo_from_circuit(c, rng):
+    """The step circuit's matrices as shuffled (row, col, value) triplets with explicit canonical coefficients."""
+    dict_canon = c.export("DICT_CANON", np.uint64).reshape(-1, 4)
+    out = []
+    for m in "ABC":
+        rp, col, coef = c.csr(m)
+        rows = np.repeat(np.arange(len(rp) - 1, dtype=np.uint32), np.diff(rp).astype(np.int64))
+        vals = dict_canon[coef]
+        perm = rng.permutation(len(rows))
+        out.append((rows[perm], col[perm], vals[perm]))
+    return out
+
+
+@pytest.mark.parametrize("op", ["hash", "grayscale"])
+def test_multiply_vec_and_commit_T_match_the_oracle(ctx, oracle, op):
+    from vimz_amd import hip
+    c = Circuit.for_resolution(op, "HD")
+    rng = np.random.default_rng(5)
+    A, B, Cm = _coo_from_circuit(c, rng)
+    S = hip.R1CSShape(ctx, _lib.FIELD_BN254_FR, c.n_constraints, c.n_wires, A, B, Cm)
+    ck = ctx.bases_generate(_lib.CURVE_BN254_G1, c.n_constraints)
+    try:
+        z0, inputs = step_inputs(op)
+        _, w_fresh, _ = witness_execute(oracle, c, z0, inputs[0])
+        dense = rng.integers(0, 1 << 62, size=w_fresh.shape, dtype=np.uint64)
+        dense[:, 3] &= np.uint64((1 << 58) - 1)
+        prods = {}
+        for name, z in (("fresh", w_fresh), ("running", dense)):
+            zd = ctx.vec_from_host(_lib.FIELD_BN254_FR, z)
+            got = S.multiply_vec(zd)
+            _, want = r1cs_check(oracle, c, z, want_products=True)
+            for g, w in zip(got, want):
+                assert np.array_equal(g.download(), w), f"{op}: (A,B,C)·z differs on the {name} vector"
+                g.free()
+            prods[name] = (zd, want)
+        u1 = int(rng.integers(1, 1 << 62)) << 64 | 12345          # a running instance's relaxation scalar
+        (z1, (a1, b1, c1)), (z2, (a2, b2, c2)) = prods["running"], prods["fresh"]
+        T, comm = S.commit_T(ck, z1, u1, z2, 1)
+        want_T = oracle.cross_term(0, a1, b1, c1, u1, a2, b2, c2, 1)
+        assert np.array_equal(T.download(), want_T)
+        bases = ck.download(0, c.n_constraints)
+        assert tuple(from_limbs(comm)) == oracle.msm(0, bases, want_T, threads=8)
+        T.free(); z1.free(); z2.free()
+    finally:
+        S.free(); ck.free()
+
+
+def test_upload_rejects_bad_shapes(ctx):
+    from vimz_amd import hip
+    one = to_limbs([1])
+    rows, cols = np.array([0], dtype=np.uint32), np.array([0], dtype=np.uint32)
+    ok = (rows, cols, one)
+    with pytest.raises(_lib.VimzError):
+        hip.R1CSShape(ctx, _lib.FIELD_BN254_FR, 1, 1, (np.array([1], dtype=np.uint32), cols, one), ok, ok)         # row outside the shape
+    with pytest.raises(_lib.VimzError):
+        hip.R1CSShape(ctx, _lib.FIELD_BN254_FR, 1, 1, ok, (rows, cols, np.full((1, 4), 2**64 - 1, dtype=np.uint64)), ok)   # coefficient >= p
+    S = hip.R1CSShape(ctx, _lib.FIELD_BN254_FR, 1, 1, ok, ok, ok)
+    z = ctx.vec_from_host(_lib.FIELD_BN254_FR, to_limbs([7]))
+    az, bz, cz = S.multiply_vec(z)
+    assert from_limbs(az.download()) == [7]
+    for v in (az, bz, cz, z):
+        v.free()
+    S.free()

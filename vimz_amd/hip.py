@@ -482,3 +482,52 @@ class AugCircuit:
         if rc:
             raise L.VimzError(rc, "vimz_augcircuit_witness")
         return wires, [sum(int(out[i, k]) << (64 * k) for k in range(4)) for i in range(11)]
+
+
+class _Coo(C.Structure):
+    _fields_ = [("row", C.c_void_p), ("col", C.c_void_p), ("val", C.c_void_p), ("nnz", C.c_size_t)]
+
+
+class R1CSShape:
+    """vimz_r1cs: a caller-supplied R1CS shape resident on the GPU — the `R1CSShape` of nova-snark 0.23.0 behind the C ABI
+    (multiply_vec -> spmv3, commit_T -> commit_T).  Matrices are COO triplets (row, col, value) in any order, like the crate's."""
+
+    def __init__(self, ctx, field, nrows, ncols, A, B, Cm, form=L.FORM_CANONICAL):
+        """A, B, Cm: (rows uint32[nnz], cols uint32[nnz], vals (nnz, 4) uint64)."""
+        self.ctx, self.field, self.nrows, self.ncols = ctx, field, nrows, ncols
+        lib = ctx.lib
+        vp = C.c_void_p
+        lib.vimz_r1cs_upload.argtypes = [vp, C.c_int, C.c_size_t, C.c_size_t, C.POINTER(_Coo), C.POINTER(_Coo), C.POINTER(_Coo), C.c_int, C.POINTER(vp)]
+        lib.vimz_r1cs_free.argtypes = [vp, vp]
+        lib.vimz_r1cs_free.restype = None
+        lib.vimz_spmv3.argtypes = [vp, vp, vp, vp, vp, vp]
+        lib.vimz_commit_T.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp, C.c_int]
+        keep, coos = [], []
+        for rows, cols, vals in (A, B, Cm):
+            r, c = np.ascontiguousarray(rows, dtype=np.uint32), np.ascontiguousarray(cols, dtype=np.uint32)
+            v = _u64(vals)
+            keep += [r, c, v]
+            coos.append(_Coo(r.ctypes.data, c.ctypes.data, v.ctypes.data, r.size))
+        h = vp()
+        ctx._chk(lib.vimz_r1cs_upload(ctx.h, field, nrows, ncols, C.byref(coos[0]), C.byref(coos[1]), C.byref(coos[2]), form, C.byref(h)))
+        self.h = h
+
+    def free(self):
+        if self.h:
+            self.ctx.lib.vimz_r1cs_free(self.ctx.h, self.h)
+            self.h = None
+
+    def multiply_vec(self, z):
+        """R1CSShape::multiply_vec: z a DeviceVec of ncols elements -> (Az, Bz, Cz) as new DeviceVecs."""
+        out = [self.ctx.vec_alloc(self.field, self.nrows) for _ in range(3)]
+        self.ctx._chk(self.ctx.lib.vimz_spmv3(self.ctx.h, self.h, z.h, out[0].h, out[1].h, out[2].h))
+        return out
+
+    def commit_T(self, ck, z1, u1, z2, u2=1):
+        """R1CSShape::commit_T: returns (T DeviceVec of nrows elements, comm_T as (8,) uint64 canonical affine)."""
+        T = self.ctx.vec_alloc(self.field, self.nrows)
+        lim = lambda x: np.array([(int(x) >> (64 * k)) & 0xFFFFFFFFFFFFFFFF for k in range(4)], dtype=np.uint64)
+        a, b = lim(u1), lim(u2)
+        out = np.zeros(8, dtype=np.uint64)
+        self.ctx._chk(self.ctx.lib.vimz_commit_T(self.ctx.h, self.h, ck.h, z1.h, _ptr(a), z2.h, _ptr(b), L.FORM_CANONICAL, T.h, _ptr(out), L.FORM_CANONICAL))
+        return T, out
