@@ -29,18 +29,23 @@ VZ_HD XYZZ<F> from_affine(const Affine<F>& a) {
   return r;
 }
 
+// ---- bounds (multiples of p) the lazily reduced coordinate field Fp29 relies on ------------------------------------------------
+// Every XYZZ point these formulas produce or consume satisfies   X < 5.3 p,  Y < 3.4 p,  ZZ, ZZZ < 1.5 p;   affine operands are
+// canonical (< p).  A product needs Bx·By <= 64 and is < (Bx·By/128 + 1) p; sub<K>(a, b) = a − b + K p needs b < K p.  The bound of
+// every intermediate is noted on its line.  For the canonical Fp<P> (host) the same code is ordinary modular arithmetic.
+
 // 2 * affine point (mdbl-2008-s-1); caller guarantees the point is not the identity.
 template <class F>
 VZ_HD XYZZ<F> dbl_affine(const Affine<F>& a) {
   XYZZ<F> r;
-  F U = F::dbl(a.y);
-  F V = F::sqr(U);
-  F W = F::mul(U, V);
-  F S = F::mul(a.x, V);
-  F X2 = F::sqr(a.x);
-  F M = F::add(F::dbl(X2), X2);
-  r.X = F::sub(F::sqr(M), F::dbl(S));
-  r.Y = F::sub(F::mul(M, F::sub(S, r.X)), F::mul(W, a.y));
+  F U = F::dbl(a.y);                                   // 2
+  F V = F::sqr(U);                                     // 1.04
+  F W = F::mul(U, V);                                  // 1.02
+  F S = F::mul(a.x, V);                                // 1.01
+  F X2 = F::sqr(a.x);                                  // 1.01
+  F M = F::add(F::dbl(X2), X2);                        // 3.1
+  r.X = F::template sub<4>(F::sqr(M), F::dbl(S));      // 1.08 − 2.02 + 4 = 5.08
+  r.Y = F::template sub<2>(F::mul(M, F::template sub<6>(S, r.X)), F::mul(W, a.y));     // 3.1·7.01 -> 1.17;  1.17 − 1.01 + 2 = 3.17
   r.ZZ = V; r.ZZZ = W;
   return r;
 }
@@ -50,14 +55,14 @@ template <class F>
 VZ_HD XYZZ<F> dbl(const XYZZ<F>& p) {
   if (p.is_identity()) return p;
   XYZZ<F> r;
-  F U = F::dbl(p.Y);
-  F V = F::sqr(U);
-  F W = F::mul(U, V);
-  F S = F::mul(p.X, V);
-  F X2 = F::sqr(p.X);
-  F M = F::add(F::dbl(X2), X2);
-  r.X = F::sub(F::sqr(M), F::dbl(S));
-  r.Y = F::sub(F::mul(M, F::sub(S, r.X)), F::mul(W, p.Y));
+  F U = F::dbl(p.Y);                                   // 6.8
+  F V = F::sqr(U);                                     // 46.3 -> 1.37
+  F W = F::mul(U, V);                                  // 9.3 -> 1.08
+  F S = F::mul(p.X, V);                                // 7.3 -> 1.06
+  F X2 = F::sqr(p.X);                                  // 28.1 -> 1.22
+  F M = F::add(F::dbl(X2), X2);                        // 3.66
+  r.X = F::template sub<4>(F::sqr(M), F::dbl(S));      // 1.11 − 2.12 + 4 = 5.11
+  r.Y = F::template sub<2>(F::mul(M, F::template sub<6>(S, r.X)), F::mul(W, p.Y));     // 3.66·7.06 -> 1.21;  W·Y: 3.7 -> 1.03;  3.21
   r.ZZ = F::mul(V, p.ZZ);
   r.ZZZ = F::mul(W, p.ZZZ);
   return r;
@@ -68,21 +73,21 @@ template <class F>
 VZ_HD void add_mixed(XYZZ<F>& acc, const Affine<F>& q) {
   if (aff_is_identity(q)) return;
   if (acc.is_identity()) { acc.X = q.x; acc.Y = q.y; acc.ZZ = F::one(); acc.ZZZ = F::one(); return; }
-  F U2 = F::mul(q.x, acc.ZZ);
-  F S2 = F::mul(q.y, acc.ZZZ);
-  F Pv = F::sub(U2, acc.X);
-  F R = F::sub(S2, acc.Y);
-  if (Pv.is_zero()) {
-    if (R.is_zero()) acc = dbl_affine(q); else acc = XYZZ<F>::identity();
+  F U2 = F::mul(q.x, acc.ZZ);                          // 1.02
+  F S2 = F::mul(q.y, acc.ZZZ);                         // 1.02
+  F Pv = F::template sub<6>(U2, acc.X);                // 1.02 − X + 6 < 7.1
+  F R = F::template sub<4>(S2, acc.Y);                 // 1.02 − Y + 4 < 5.1
+  if (Pv.is_zero_mod()) {
+    if (R.is_zero_mod()) acc = dbl_affine(q); else acc = XYZZ<F>::identity();
     return;
   }
-  F PP = F::sqr(Pv);
-  F PPP = F::mul(Pv, PP);
-  F Q = F::mul(acc.X, PP);
-  F X3 = F::sub(F::sub(F::sqr(R), PPP), F::dbl(Q));
-  F Y3 = F::sub(F::mul(R, F::sub(Q, X3)), F::mul(acc.Y, PPP));
+  F PP = F::sqr(Pv);                                   // 50.4 -> 1.40
+  F PPP = F::mul(Pv, PP);                              // 9.9 -> 1.08
+  F Q = F::mul(acc.X, PP);                             // 7.4 -> 1.06
+  F X3 = F::template sub<4>(F::sqr(R), F::add(PPP, F::dbl(Q)));     // R²: 26 -> 1.21;  PPP + 2Q < 3.2;  1.21 + 4 = 5.21
+  F Y3 = F::template sub<2>(F::mul(R, F::template sub<6>(Q, X3)), F::mul(acc.Y, PPP));   // 5.1·7.06 -> 1.29;  Y·PPP: 3.7 -> 1.03;  3.29
   acc.X = X3; acc.Y = Y3;
-  acc.ZZ = F::mul(acc.ZZ, PP);
+  acc.ZZ = F::mul(acc.ZZ, PP);                         // 2.1 -> 1.02
   acc.ZZZ = F::mul(acc.ZZZ, PPP);
 }
 
@@ -91,34 +96,34 @@ template <class F>
 VZ_HD void add_full(XYZZ<F>& acc, const XYZZ<F>& q) {
   if (q.is_identity()) return;
   if (acc.is_identity()) { acc = q; return; }
-  F U1 = F::mul(acc.X, q.ZZ);
-  F U2 = F::mul(q.X, acc.ZZ);
-  F S1 = F::mul(acc.Y, q.ZZZ);
-  F S2 = F::mul(q.Y, acc.ZZZ);
-  F Pv = F::sub(U2, U1);
-  F R = F::sub(S2, S1);
-  if (Pv.is_zero()) {
-    if (R.is_zero()) acc = dbl(acc); else acc = XYZZ<F>::identity();
+  F U1 = F::mul(acc.X, q.ZZ);                          // 5.3·1.5 -> 1.07
+  F U2 = F::mul(q.X, acc.ZZ);                          // 1.07
+  F S1 = F::mul(acc.Y, q.ZZZ);                         // 3.4·1.5 -> 1.04
+  F S2 = F::mul(q.Y, acc.ZZZ);                         // 1.04
+  F Pv = F::template sub<2>(U2, U1);                   // 3.07
+  F R = F::template sub<2>(S2, S1);                    // 3.04
+  if (Pv.is_zero_mod()) {
+    if (R.is_zero_mod()) acc = dbl(acc); else acc = XYZZ<F>::identity();
     return;
   }
-  F PP = F::sqr(Pv);
-  F PPP = F::mul(Pv, PP);
-  F Q = F::mul(U1, PP);
-  F X3 = F::sub(F::sub(F::sqr(R), PPP), F::dbl(Q));
-  F Y3 = F::sub(F::mul(R, F::sub(Q, X3)), F::mul(S1, PPP));
+  F PP = F::sqr(Pv);                                   // 9.5 -> 1.08
+  F PPP = F::mul(Pv, PP);                              // 1.03
+  F Q = F::mul(U1, PP);                                // 1.01
+  F X3 = F::template sub<4>(F::sqr(R), F::add(PPP, F::dbl(Q)));     // 1.08 + 4 = 5.08   (PPP + 2Q < 3.1)
+  F Y3 = F::template sub<2>(F::mul(R, F::template sub<6>(Q, X3)), F::mul(S1, PPP));     // 3.04·7.01 -> 1.17;  3.17
   acc.X = X3; acc.Y = Y3;
   acc.ZZ = F::mul(F::mul(acc.ZZ, q.ZZ), PP);
   acc.ZZZ = F::mul(F::mul(acc.ZZZ, q.ZZZ), PPP);
 }
 
 template <class F>
-VZ_HD Affine<F> to_affine(const XYZZ<F>& p) {  // one inversion; identity -> (0,0)
+VZ_HD Affine<F> to_affine(const XYZZ<F>& p) {  // one inversion; identity -> (0,0); coordinates canonical
   Affine<F> a;
   if (p.is_identity()) { a.x = F::zero(); a.y = F::zero(); return a; }
   F zi3 = F::pow_pm2(p.ZZZ);                 // 1/ZZZ
   F zi2 = F::sqr(F::mul(zi3, p.ZZ));       // (ZZ/ZZZ)^2 = 1/ZZ   (ZZ^3 = ZZZ^2)
-  a.x = F::mul(p.X, zi2);
-  a.y = F::mul(p.Y, zi3);
+  a.x = F::mul(p.X, zi2).canon();
+  a.y = F::mul(p.Y, zi3).canon();
   return a;
 }
 

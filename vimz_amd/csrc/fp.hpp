@@ -147,6 +147,12 @@ struct Fp {
   }
   static VZ_HD Fp neg(const Fp& a) { return sub(zero(), a); }
   static VZ_HD Fp dbl(const Fp& a) { return add(a, a); }
+  // The interface the curve formulas (ec.hpp) are written against, shared with the lazily reduced Fp29: there sub<K> is
+  // a − b + K·p without a reduction; here every value is canonical and K is irrelevant.
+  static constexpr bool LAZY = false;
+  template <int K> static VZ_HD Fp sub(const Fp& a, const Fp& b) { return sub(a, b); }
+  VZ_HD bool is_zero_mod() const { return is_zero(); }
+  VZ_HD Fp canon() const { return *this; }
 
   // CIOS Montgomery product a*b/R mod p.
   static VZ_HD Fp mul(const Fp& a, const Fp& b) {

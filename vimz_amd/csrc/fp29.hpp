@@ -29,7 +29,20 @@ constexpr L29x9 ct_split29(const U256& x) {
   }
   return r;
 }
+constexpr L29x9 ct_times29(const L29x9& x, uint32_t k) {      // k·x in 29-bit limbs (k·x < 2^261)
+  L29x9 r{}; uint64_t c = 0;
+  for (int i = 0; i < 9; i++) { c += (uint64_t)x.l[i] * k; r.l[i] = (uint32_t)(c & 0x1fffffffu); c >>= 29; }
+  return r;
+}
 
+// LAZY REDUCTION.  Nine 29-bit limbs hold integers below 2^261 = 128·2^254 > 128 p, seven bits more than a residue needs, and
+// the Montgomery product of x < Bx·p and y < By·p is below (Bx·By/128 + 1)·p (p/R' < 2^-7).  So values are kept as normalised
+// limbs (each < 2^29) of ANY representative below 128 p: `mul`/`sqr` never subtract p at the end (operand bounds must satisfy
+// Bx·By <= 64: result < 1.5 p), `add` only propagates carries, `sub<K>` computes a − b + K·p for a caller-stated K·p >= b.
+// Every formula in ec.hpp carries its bounds in comments.  `canon()` brings a value below 8 p to [0, p) — needed only where
+// limbs are compared or leave this representation (to_std, table entries, equality) — and `is_zero_mod()` tests ≡ 0 (mod p)
+// of a value below 8 p in three instructions on the common path (k = v0·p^-1 mod 2^29 must be < 8 for v = k·p).
+// Measured: the conditional subtractions were 14 % of a mixed addition's issue slots (profiles/r02_ubench_fp29.txt).
 template <class P>
 struct Fp29 {
   typedef P Params;
@@ -39,45 +52,82 @@ struct Fp29 {
   static constexpr L29x9 MOD29 = ct_split29(P::MOD);
   static constexpr L29x9 ONE29 = ct_split29(ct_pow2_mod(261, P::MOD));
   static constexpr L29x9 R2_29 = ct_split29(ct_pow2_mod(522, P::MOD));
-  static constexpr uint32_t N0_29 = P::N0 & MASK;   // -p^-1 mod 2^29
+  static constexpr uint32_t N0_29 = P::N0 & MASK;            // -p^-1 mod 2^29
+  static constexpr uint32_t PINV_29 = (0u - P::N0) & MASK;   //  p^-1 mod 2^29
+  static constexpr bool LAZY = true;
 
   uint32_t v[9];
 
   static VZ_HD Fp29 zero() { Fp29 r; for (int i = 0; i < 9; i++) r.v[i] = 0; return r; }
   static VZ_HD Fp29 one() { Fp29 r; for (int i = 0; i < 9; i++) r.v[i] = ONE29.l[i]; return r; }
-  VZ_HD bool is_zero() const { uint32_t o = 0; for (int i = 0; i < 9; i++) o |= v[i]; return o == 0; }
-  VZ_HD bool eq(const Fp29& b) const { uint32_t o = 0; for (int i = 0; i < 9; i++) o |= v[i] ^ b.v[i]; return o == 0; }
+  VZ_HD bool is_zero() const { uint32_t o = 0; for (int i = 0; i < 9; i++) o |= v[i]; return o == 0; }    // the integer 0 (identity markers)
+  VZ_HD bool eq(const Fp29& b) const { uint32_t o = 0; for (int i = 0; i < 9; i++) o |= v[i] ^ b.v[i]; return o == 0; }   // same limbs: canon() first
 
-  // t (limbs < 2^29, value < 2p) -> t mod p
-  static VZ_HD Fp29 reduce_once(const uint32_t* t) {
+  // ≡ 0 (mod p) for a value below 8 p
+  VZ_HD bool is_zero_mod() const {
+    const uint32_t k = (v[0] * PINV_29) & MASK;
+    if (k >= 8u) return false;
+    uint64_t c = 0; uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) { c += (uint64_t)MOD29.l[i] * k; o |= v[i] ^ ((uint32_t)c & MASK); c >>= 29; }
+    return o == 0;
+  }
+  // t (limbs < 2^29) -> t - p if t >= p
+  static VZ_HD Fp29 cond_sub(const uint32_t* t, const L29x9& m) {
     uint32_t s[9]; uint32_t br = 0;
 #pragma unroll
-    for (int i = 0; i < 9; i++) { uint32_t d = t[i] - MOD29.l[i] - br; br = d >> 31; s[i] = d & MASK; }
+    for (int i = 0; i < 9; i++) { uint32_t d = t[i] - m.l[i] - br; br = d >> 31; s[i] = d & MASK; }
     Fp29 r;
 #pragma unroll
     for (int i = 0; i < 9; i++) r.v[i] = br ? t[i] : s[i];
     return r;
   }
-  static VZ_HD Fp29 add(const Fp29& a, const Fp29& b) {
-    uint32_t t[9]; uint32_t c = 0;
-#pragma unroll
-    for (int i = 0; i < 9; i++) { uint32_t x = a.v[i] + b.v[i] + c; c = x >> 29; t[i] = x & MASK; }
-    return reduce_once(t);
+  static VZ_HD Fp29 reduce_once(const uint32_t* t) { return cond_sub(t, MOD29); }
+  // value < 8 p -> [0, p)
+  VZ_HD Fp29 canon() const {
+    constexpr L29x9 P4 = ct_times29(MOD29, 4), P2 = ct_times29(MOD29, 2);
+    Fp29 r = cond_sub(v, P4);
+    r = cond_sub(r.v, P2);
+    return cond_sub(r.v, MOD29);
   }
-  static VZ_HD Fp29 sub(const Fp29& a, const Fp29& b) {
-    uint32_t t[9]; uint32_t br = 0;
-#pragma unroll
-    for (int i = 0; i < 9; i++) { uint32_t d = a.v[i] - b.v[i] - br; br = d >> 31; t[i] = d & MASK; }
-    const uint32_t m = br ? 0xffffffffu : 0u;
+  // a + b (no reduction): bound Ba + Bb
+  static VZ_HD Fp29 add(const Fp29& a, const Fp29& b) {
     Fp29 r; uint32_t c = 0;
 #pragma unroll
-    for (int i = 0; i < 9; i++) { uint32_t x = t[i] + (MOD29.l[i] & m) + c; c = x >> 29; r.v[i] = x & MASK; }
+    for (int i = 0; i < 9; i++) { uint32_t x = a.v[i] + b.v[i] + c; c = x >> 29; r.v[i] = x & MASK; }
     return r;
   }
-  static VZ_HD Fp29 neg(const Fp29& a) { return sub(zero(), a); }
+  // a − b + K·p, for b < K·p: bound Ba + K
+  template <int K>
+  static VZ_HD Fp29 sub(const Fp29& a, const Fp29& b) {
+    constexpr L29x9 KP = ct_times29(MOD29, K);
+    Fp29 r; int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) { int32_t x = (int32_t)(a.v[i] + KP.l[i]) - (int32_t)b.v[i] + c; c = x >> 29; r.v[i] = (uint32_t)x & MASK; }
+    return r;
+  }
+  static VZ_HD Fp29 neg(const Fp29& a) { return sub<1>(zero(), a); }      // a <= p (canonical operands: the affine bases)
   static VZ_HD Fp29 dbl(const Fp29& a) { return add(a, a); }
 
-  // Montgomery product a*b / 2^261 mod p: column-wise product, then word-by-word reduction.
+  // Montgomery reduction of the 18 product columns: result < (column value)/2^261 + p, limbs normalised, NO final subtraction
+  static VZ_HD Fp29 redc(uint64_t* acc) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      const uint32_t m = ((uint32_t)acc[i] * N0_29) & MASK;
+#pragma unroll
+      for (int j = 0; j < 9; j++) acc[i + j] += (uint64_t)m * MOD29.l[j];
+      acc[i + 1] += acc[i] >> 29;   // low 29 bits of acc[i] are now zero
+    }
+    Fp29 r;
+#pragma unroll
+    for (int k = 9; k < 18; k++) {
+      r.v[k - 9] = (uint32_t)acc[k] & MASK;
+      if (k < 17) acc[k + 1] += acc[k] >> 29;
+    }
+    return r;
+  }
+  // Montgomery product a*b / 2^261: column-wise product (a column of 9 + 9 products of 29-bit limbs fits 64 bits), then the
+  // word-by-word reduction.  Operand bounds Ba·Bb <= 64 -> result < 1.5 p.
   static VZ_HD Fp29 mul(const Fp29& a, const Fp29& b) {
     uint64_t acc[18];
 #pragma unroll
@@ -86,24 +136,27 @@ struct Fp29 {
     for (int i = 0; i < 9; i++)
 #pragma unroll
       for (int j = 0; j < 9; j++) acc[i + j] += (uint64_t)a.v[i] * b.v[j];
+    return redc(acc);
+  }
+  // a^2: 45 products instead of 81 (cross terms against the doubled limbs, 2a_j < 2^30: a column holds at most four such
+  // products, one square and nine reduction products: < 2^62.4)
+  static VZ_HD Fp29 sqr(const Fp29& a) {
+    uint64_t acc[18];
+    uint32_t d[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) d[i] = a.v[i] << 1;
+#pragma unroll
+    for (int k = 0; k < 18; k++) acc[k] = 0;
 #pragma unroll
     for (int i = 0; i < 9; i++) {
-      const uint32_t m = ((uint32_t)acc[i] * N0_29) & MASK;
+      acc[2 * i] += (uint64_t)a.v[i] * a.v[i];
 #pragma unroll
-      for (int j = 0; j < 9; j++) acc[i + j] += (uint64_t)m * MOD29.l[j];
-      acc[i + 1] += acc[i] >> 29;   // low 29 bits of acc[i] are now zero
+      for (int j = i + 1; j < 9; j++) acc[i + j] += (uint64_t)a.v[i] * d[j];
     }
-    uint32_t t[9];
-#pragma unroll
-    for (int k = 9; k < 18; k++) {
-      t[k - 9] = (uint32_t)acc[k] & MASK;
-      if (k < 17) acc[k + 1] += acc[k] >> 29;
-    }
-    return reduce_once(t);
+    return redc(acc);
   }
-  static VZ_HD Fp29 sqr(const Fp29& a) { return mul(a, a); }
 
-  static VZ_HD Fp29 pow_pm2(const Fp29& a) {  // a^(p-2)
+  static VZ_HD Fp29 pow_pm2(const Fp29& a) {  // a^(p-2)   (a < 8 p; result < 1.5 p)
     uint32_t e[8]; uint64_t br = 2;
     for (int i = 0; i < 8; i++) { uint64_t d = (uint64_t)P::MOD.w[i] - br; e[i] = (uint32_t)d; br = (d >> 32) & 1; }
     Fp29 acc = one();
@@ -126,7 +179,7 @@ struct Fp29 {
     }
     return r;
   }
-  VZ_HD void unpack(uint32_t* w8) const {        // 29-bit limbs -> 256-bit integer
+  VZ_HD void unpack(uint32_t* w8) const {        // 29-bit limbs (value < 2^256) -> 256-bit integer
     uint64_t buf = 0; int have = 0, o = 0;
 #pragma unroll
     for (int i = 0; i < 9; i++) {
@@ -135,16 +188,17 @@ struct Fp29 {
     }
     if (o < 8) w8[o] = (uint32_t)buf;
   }
-  // y = x*2^256 (standard Montgomery)  ->  x*2^261
+  // y = x*2^256 (standard Montgomery)  ->  x*2^261, canonical
   static VZ_HD Fp29 from_std(const Fp<P>& y) {
     Fp<P> t = y;
 #pragma unroll
     for (int k = 0; k < 5; k++) t = Fp<P>::dbl(t);
     return pack(t.v);
   }
-  // x*2^261 -> x*2^256: five modular halvings
+  // x*2^261 (any representative below 8 p) -> x*2^256: canonicalise, then five modular halvings
   VZ_HD Fp<P> to_std() const {
-    uint32_t w[8]; unpack(w);
+    const Fp29 cn = canon();
+    uint32_t w[8]; cn.unpack(w);
     for (int k = 0; k < 5; k++) {
       uint64_t c = 0;
       if (w[0] & 1) { for (int i = 0; i < 8; i++) { c += (uint64_t)w[i] + P::MOD.w[i]; w[i] = (uint32_t)c; c >>= 32; } }
