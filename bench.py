@@ -5,17 +5,22 @@
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 A "step" is one folding step = one image row through witness generation -> (A,B,C)·z -> MSM(W) -> cross term ->
-MSM(T) -> challenge -> fold.  Two modes:
+MSM(T) -> challenge -> fold, on both curves of the cycle.  Workload: contrast_step at HD (the configuration the reference's
+headline number is quoted on: 720 steps in 371.7 s = 1.94 steps/s, README.md:52), rows of the reference's sample image
+(tests/golden/img2.png, contrast factor 1.4).
+
   --mode ivc (default)   RecursiveSNARK::prove_step in full: Nova IVC with the augmented verifier circuits on the BN254/Grumpkin
-                         cycle (vimz_ivc_*; SURVEY.md §8a incl. rows S1/S2).  A rank proves its rows as `--segments` independent
-                         IVC proofs of contiguous row segments (IVC chains cannot be merged), folded concurrently.
+                         cycle (vimz_ivc_*; SURVEY.md §8a incl. rows S1/S2).  `value` is ONE proof per GPU — the object the
+                         reference's fold_input returns (vimz/src/nova_snark_backend/folding.rs:27-43): W untimed rows, then
+                         EXACTLY K timed rows of the same chain, HIP-event profiling off.  A second pass of K more rows of the
+                         same chain with per-kernel HIP events gives the roofline figure; the proof of all W + 2K rows is
+                         verified for (steps, z0).  `--segments S` (S > 1) folds S proofs of contiguous row segments per GPU
+                         concurrently (an IVC chain cannot be merged: the result is a list of S proofs); at N = 1 the default
+                         run also reports that aggregate as an extra key.
   --mode accumulator     the NIFS accumulator over the step circuit's own instances (vimz_prover_*): row segments fold
                          independently and are merged by a host-side final fold (BASELINE.json north_star's sharding picture).
-Workload at any N: contrast_step at HD (the configuration the reference's headline
-number is quoted on: 720 steps in 371.7 s = 1.94 steps/s, README.md:52), rows of the reference's sample image
-(tests/golden/img2.png, contrast factor 1.4).  Every rank folds its own contiguous row segment of W+K rows into its own
-running instance (independent row-folds, weak scaling, no data-path collective); after the timed region rank 0 gathers
-the exported instances and performs the host-side sequential final fold, then verifies.  Prints ONE JSON line on rank 0.
+N > 1: every rank folds its own rows (independent row-folds, weak scaling, no data-path collective).  Prints ONE JSON line on
+rank 0.
 """
 import argparse
 import json
@@ -31,7 +36,7 @@ sys.path.insert(0, ROOT)
 #  up to 475 steps/s — but runs become bimodal, 380 or 470; measured in round 1.)
 
 HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-MIXED_ADD_PEAK_GOPS = 12.65      # measured ceiling of the XYZZ mixed addition in the 9x29-bit form (profiles/r01_ubench_fp29.txt)
+MIXED_ADD_PEAK_GOPS = 15.47      # measured ceiling of the XYZZ mixed addition in the lazily reduced 9x29-bit form (profiles/r02_ubench_fp29.txt)
 
 
 def build_inputs(transformation, resolution):
@@ -53,48 +58,74 @@ def build_inputs(transformation, resolution):
 
 def cpu_baseline(circuit, steps, z0, ck_host, budget_s, threads):
     """The oracle (CPU restatement, kind "port") timed on the same workload for about `budget_s` seconds: witness,
-    (A,B,C)·z, MSM(W), cross term, MSM(T), folds.  Reported beside the GPU number; never the thing measured as `value`."""
+    (A,B,C)·z, MSM(W), cross term, MSM(T), folds.  Reported beside the GPU number; never the thing measured as `value`.
+    Returns (steps/s, seconds, steps, per-phase seconds per step)."""
     from tests import _oracle
     orc = _oracle.load()
     aux0 = 1 + 2 * circuit.len_z
     key_m = orc.to_mont(1, ck_host.reshape(-1, 4)).reshape(-1, 8)      # Montgomery bases, as the product keeps them
     z = list(z0)
+    ph = {"witness_1_thread": 0.0, "spmv": 0.0, "msm_w": 0.0, "cross_term": 0.0, "msm_t": 0.0, "folds": 0.0}
     t0 = time.time()
     run, n = None, 0
     while n < len(steps) and (n < 2 or time.time() - t0 < budget_s):
+        t = time.time()
         st, w, z = _oracle.witness_execute(orc, circuit, z, steps[n])
+        ph["witness_1_thread"] += time.time() - t; t = time.time()
         bad, (a2, b2, c2) = _oracle.r1cs_check(orc, circuit, w, want_products=True, threads=threads)
         assert st == 0 and bad == -1
+        ph["spmv"] += time.time() - t; t = time.time()
         _, cW = orc.msm_mont_timed(0, key_m, np.ascontiguousarray(w[aux0:]), threads)
+        ph["msm_w"] += time.time() - t
         n += 1
         if run is None:
             run = [w, a2, b2, c2, np.zeros_like(a2), 1]
             continue
+        t = time.time()
         T = orc.cross_term(0, run[1], run[2], run[3], run[5], a2, b2, c2, 1)
+        ph["cross_term"] += time.time() - t; t = time.time()
         _, cT = orc.msm_mont_timed(0, key_m, T, threads)
+        ph["msm_t"] += time.time() - t; t = time.time()
         r = (cT[0] ^ cW[0]) & ((1 << 128) - 1)        # any 128-bit challenge: the arithmetic cost does not depend on it
         run = [orc.axpy(0, run[0], r, w), orc.axpy(0, run[1], r, a2), orc.axpy(0, run[2], r, b2), orc.axpy(0, run[3], r, c2),
                orc.axpy(0, run[4], r, T), (run[5] + r) % orc.modulus[0]]
+        ph["folds"] += time.time() - t
     dt = time.time() - t0
-    return n / dt, dt, n
+    return n / dt, dt, n, {k: v / max(1, n) for k, v in ph.items()}
+
+
+def _ints(limbs):
+    return [int(a[0]) | int(a[1]) << 64 | int(a[2]) << 128 | int(a[3]) << 192 for a in limbs]
+
+
+def _pmc_traffic(key):
+    """HBM bytes per launch of the roofline kernel from SEPARATE rocprofv3 --pmc passes of this command (the counters cannot be
+    read from inside the process): profiles/pmc_traffic.json, refreshed by tools/refresh_profiles.sh; the entry names its run."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fp:
+            e = json.load(fp).get(key, {})
+        return e.get("hbm_bytes_per_launch"), e.get("source")
+    except OSError:
+        return None, None
 
 
 def main_ivc(args, rank, world, dist, torch, ctxs, circuit, params, steps_all, glob, lo, hi, mine, z0, t_setup):
-    """Nova IVC (the default mode).  The rank's W+K rows are cut into S contiguous segments; segment s is one IVC proof on its own
-    context, warmed up with its first W/S rows and timed on the rest.  All S proofs of all ranks must verify."""
+    """Nova IVC (the default mode).  Every proof of this rank folds w warm-up rows, k timed rows and k more rows under per-kernel
+    HIP events; S = 1 by default: one proof per GPU."""
     from vimz_amd import _lib, hip
-    from vimz_amd.distributed import fold_concurrently, ivc_segments
-    ctx = ctxs[0]
+    from vimz_amd.distributed import fold_concurrently
     S = len(ctxs)
-    ck2 = ctx.bases_generate(_lib.CURVE_GRUMPKIN, 1 << 13, b"ck-secondary")
+    w_each, k_each = -(-args.warmup // S), -(-args.steps // S)
+    per_proof = w_each + 2 * k_each
+    ck2 = params.secondary_key()
     ivcs = [hip.IVC(c, circuit, params.ck, ck2, max_batch=args.batch) for c in ctxs]
-    z_rank = list(z0)
-    if lo:
-        zs = ivcs[0].state_chain(z0, steps_all[glob[:lo]])
-        z_rank = [int(a[0]) | int(a[1]) << 64 | int(a[2]) << 128 | int(a[3]) << 192 for a in zs[-1]]
-    segs = ivc_segments(ivcs, mine, z_rank)
+    # state at which each proof's row segment starts (hash-only chain over the rows before it)
+    starts = []
+    for s_ in range(S):
+        before = lo + s_ * per_proof
+        starts.append(_ints(ivcs[0].state_chain(z0, steps_all[glob[:before]])[-1]) if before else list(z0))
+    segs = [(ivcs[s_], mine[s_ * per_proof:(s_ + 1) * per_proof], starts[s_]) for s_ in range(S)]
     setup_s = time.time() - t_setup
-    w_each = args.warmup // S
 
     def sync_all():
         for c in ctxs:
@@ -107,42 +138,45 @@ def main_ivc(args, rank, world, dist, torch, ctxs, circuit, params, steps_all, g
     for ivc, rows, z in segs:
         ivc.reset(z)
     fold_concurrently([(ivc, rows[:w_each]) for ivc, rows, z in segs])
-    timed_rows = sum(len(rows) - min(w_each, len(rows)) for _, rows, _ in segs)
-    for c in ctxs:
-        c.set_profiling(True)              # HIP events around every kernel of the primary MSM(T) launches (step rows) on the stream they run on
-        c.msm_profile_totals(reset=True)
     prof0 = [ivc.profile() for ivc in ivcs]
+    timed_rows = S * k_each
     sync_all()
     t0 = time.time()
-    fold_concurrently([(ivc, rows[w_each:]) for ivc, rows, z in segs])
+    if rank > 0:
+        # a rank's segment of a real image starts at the state after all rows before it: that hash-only chain over the lower
+        # ranks' timed rows is a cost of the sharded scheme and is paid inside the timed region
+        ivcs[0].state_chain(z0, np.concatenate([mine[w_each:w_each + k_each]] * (rank * S))[:rank * timed_rows])
+    fold_concurrently([(ivc, rows[w_each:w_each + k_each]) for ivc, rows, z in segs])
     sync_all()
     dt = time.time() - t0
+    prof1 = [ivc.profile() for ivc in ivcs]
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0])
+    # second pass, outside the timed region: k more rows per proof (the chain continues), with HIP events around every kernel of
+    # the primary MSM(T) launches on the stream they run on -> the roofline figure
+    for c in ctxs:
+        c.set_profiling(True)
+        c.msm_profile_totals(reset=True)
+    t1 = time.time()
+    fold_concurrently([(ivc, rows[w_each + k_each:]) for ivc, rows, z in segs])
+    for c in ctxs:
+        c.sync()
+    dt_prof = time.time() - t1
     tots = [c.msm_profile_totals() for c in ctxs]
     tot = {"ms": {k: sum(t["ms"][k] for t in tots) for k in tots[0]["ms"]}, "calls": sum(t["calls"] for t in tots),
            "points": sum(t["points"] for t in tots), "entries": sum(t["entries"] for t in tots)}
     for c in ctxs:
         c.set_profiling(False)
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t[0])
-    # acceptance (outside the timed region): every segment proof verifies, and the segments' boundary states chain
+    # acceptance: every proof verifies for exactly (its rows, its start state); the first starts at the transformation's z0
     t_v = time.time()
-    codes = [ivc.verify(len(rows), z) for ivc, rows, z in segs]
-    ok = all(c == 0 for c in codes)
+    codes = [ivc.verify(per_proof, z) for ivc, rows, z in segs]
+    ok = all(c == 0 for c in codes) and (lo > 0 or segs[0][2] == [int(x) for x in z0])
     ends = [ivc.state()[0] for ivc in ivcs]
     ok = ok and all(ends[i] == segs[i + 1][2] for i in range(S - 1))
     verify_s = time.time() - t_v
     folded = sum(ivc.state()[1] for ivc in ivcs)
-    # for reference: ONE proof folding alone on the GPU (what a single sequential IVC chain reaches), outside the timed region
-    single = None
-    if rank == 0 and S > 1:
-        rows1 = segs[0][1][:64]
-        ctxs[0].sync()
-        t1 = time.time()
-        ivcs[0].fold(rows1)
-        ctxs[0].sync()
-        single = len(rows1) / (time.time() - t1)
     if dist is not None:
         t = torch.tensor([1 if ok else 0, folded, timed_rows], dtype=torch.int64)
         m = t.clone(); dist.all_reduce(m, op=dist.ReduceOp.MIN)
@@ -159,8 +193,8 @@ def main_ivc(args, rank, world, dist, torch, ctxs, circuit, params, steps_all, g
         alg_bytes = 96.0 * tot["points"] / calls       # 32 B scalar + 64 B base per point of the launch (the step circuit's rows)
         achieved = alg_bytes / (acc_ms * 1e-3) / 1e9 if acc_ms else 0.0
         adds = tot["entries"] / calls
-        # for reference, outside the timed region: the same kernel over the same kind of data (the running error vector of the first
-        # proof, which has the cross terms' zero and repetition structure) with nothing else on the GPU
+        # for reference: the same kernel over the same kind of data (the running error vector of the first proof, which has the
+        # cross terms' zero and repetition structure) with nothing else on the GPU
         alone_ms = None
         try:
             E = np.ascontiguousarray(ivcs[0].export(0, hip.IX_RUNNING_E))[:info["step_constraints"]]
@@ -175,23 +209,49 @@ def main_ivc(args, rank, world, dist, torch, ctxs, circuit, params, steps_all, g
             alone_ms = sorted(ms[1:])[len(ms[1:]) // 2]
         except Exception as e:                          # informational only
             print(f"[bench] isolated k_accum measurement skipped: {e}", file=sys.stderr)
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fp:
-                traffic = json.load(fp).get(f"{args.transformation}_step_{args.resolution}_ivc", {}).get("hbm_bytes_per_launch")
-        except OSError:
-            pass
+        traffic, traffic_src = _pmc_traffic(f"{args.transformation}_step_{args.resolution}_ivc")
         n_w2, n_c2, nnz2 = info["secondary_wires"], info["secondary_constraints"], info["secondary_nnz"]
         step_bytes = sum(96 * w + 96 * c + 8 * z + 32 * w + 96 * c + 7 * 32 * c + 3 * 32 * w + 12 * 32 * c for w, c, z in ((n_w, n_c, nnz), (n_w2, n_c2, nnz2)))
-        prof1 = [ivc.profile() for ivc in ivcs]
         phases = {k: 1e3 * sum(p1[k][0] - p0[k][0] for p0, p1 in zip(prof0, prof1)) / max(1, timed_rows) for k in prof1[0]}
+        # extra (N = 1, one proof per GPU): the aggregate of three proofs of contiguous row segments folded concurrently — a list
+        # of three proofs, not the reference's object; measured after everything else
+        three = None
+        if world == 1 and S == 1 and not args.no_extras:
+            try:
+                cx = [hip.Context(ctxs[0].device) for _ in range(2)]
+                more = [hip.IVC(c, circuit, params.ck, ck2, max_batch=args.batch) for c in cx]
+                trio = [ivcs[0]] + more
+                blk = w_each + k_each
+                rows3 = [np.ascontiguousarray(steps_all[[i % len(steps_all) for i in range(j * blk, (j + 1) * blk)]]) for j in range(3)]
+                z3 = [list(z0)]
+                for j in range(2):
+                    z3.append(_ints(ivcs[0].state_chain(z3[-1], rows3[j])[-1]))
+                for v, z in zip(trio, z3):
+                    v.reset(z)
+                fold_concurrently([(v, r[:w_each]) for v, r in zip(trio, rows3)])
+                for c in [ctxs[0]] + cx:
+                    c.sync()
+                t3 = time.time()
+                fold_concurrently([(v, r[w_each:]) for v, r in zip(trio, rows3)])
+                for c in [ctxs[0]] + cx:
+                    c.sync()
+                d3 = time.time() - t3
+                ok3 = all(v.verify(blk, z) == 0 for v, z in zip(trio, z3)) and all(trio[j].state()[0] == z3[j + 1] for j in range(2))
+                three = {"steps_per_s": 3 * k_each / d3, "proofs": 3, "rows_each": k_each, "verified": bool(ok3),
+                         "note": "three IVC proofs of contiguous row segments folded concurrently on this GPU (boundary states chain); a list of proofs, not one RecursiveSNARK"}
+                for v in more:
+                    v.close()
+                for c in cx:
+                    c.close()
+            except Exception as e:
+                print(f"[bench] three-proof extra skipped: {e}", file=sys.stderr)
         out = {
             "metric": "nova_folding_steps_per_sec",
             "value": timed_total / dt,
             "unit": "steps/s",
             "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
+            "steps": timed_rows,
+            "warmup": S * w_each,
             "ms_per_step": dt / max(1, timed_rows) * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
@@ -201,19 +261,22 @@ def main_ivc(args, rank, world, dist, torch, ctxs, circuit, params, steps_all, g
             "config": {"workload": f"{args.transformation}_step_{args.resolution}", "mode": "ivc (augmented circuits on BN254/Grumpkin: RecursiveSNARK::prove_step in full)",
                        "constraints": n_c, "wires": n_w, "nnz": nnz, "step_circuit_constraints": info["step_constraints"], "step_circuit_wires": info["step_wires"],
                        "secondary_constraints": n_c2, "secondary_wires": n_w2,
-                       "rows_per_rank": args.steps, "segments_per_gpu": S, "witness_batch": args.batch,
-                       "parallelism": (f"proof set {args.proof_set}: rank r proves proof_set[r % len], {S} IVC segment proofs per GPU; independent proofs, replicas only" if args.proof_set else
-                                       f"{world * S} independent IVC proofs of contiguous row segments ({S} per GPU, folded concurrently), chained boundary states, no final fold")},
+                       "rows_per_rank": timed_rows, "proofs_per_gpu": S, "witness_batch": args.batch,
+                       "parallelism": (f"proof set {args.proof_set}: rank r proves proof_set[r % len]; independent proofs, replicas only" if args.proof_set else
+                                       ("one IVC proof per GPU" if S == 1 else f"{S} IVC proofs of contiguous row segments per GPU, folded concurrently") +
+                                       ("" if world == 1 else f"; {world} GPUs prove {world * S} contiguous row segments of the image independently (boundary states chain), no data-path collective"))},
             "verified": bool(ok),
             "verify_codes": codes,
-            "single_proof_steps_per_s": single,
             "folded_steps_total": folded,
             "verify_s": verify_s,
-            "end_to_end_estimate_s": {"keygen_and_setup": setup_s, "fold_720_steps_one_gpu": 720 * dt / max(1, timed_rows)},
+            "three_concurrent_proofs": three,
+            "end_to_end_estimate_s": {"keygen_and_setup": setup_s, "fold_720_steps_one_gpu": 720 * dt / max(1, timed_rows), "compress": None},
             "published_reference": {"contrast_HD_steps_per_s_cpu_server": 1.94, "source": "README.md:52 (720 steps / 371.7 s)"},
             "phase_ms_per_step_per_proof": phases,
-            "roofline": {"bound": "hbm", "kernel": "k_accum (bucket accumulation) of the primary MSM(T) launches over the step circuit's rows in the timed region (they run on a third stream under the rest of the step, so their duration includes that contention)", "achieved": achieved,
-                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+            "roofline": {"bound": "hbm", "kernel": "k_accum (bucket accumulation) of the primary MSM(T) launches over the step circuit's rows",
+                         "measured": f"HIP events on the kernel's own stream over a second pass of {timed_rows} rows of the same chain(s) right after the timed region (events off while `value` is timed); that pass ran at {timed_rows / dt_prof:.1f} steps/s",
+                         "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": acc_ms, "launches": tot["calls"], "msm_gpu_ms": msm_ms,
                          "mixed_adds_per_launch": adds, "msm_phase_ms": {k: v / calls for k, v in tot["ms"].items()},
                          "int_utilisation": (adds / (acc_ms * 1e-3) / 1e9 / MIXED_ADD_PEAK_GOPS) if acc_ms else 0.0,
@@ -224,14 +287,15 @@ def main_ivc(args, rank, world, dist, torch, ctxs, circuit, params, steps_all, g
         if not args.no_cpu_baseline and world == 1:      # the CPU baseline is timed at N = 1 only
             cores = os.cpu_count() or 1
             ck_host = params.ck.download(0, max(circuit.n_constraints, circuit.n_wires))
-            sps, secs, n_cpu = cpu_baseline(circuit, mine, z_rank, ck_host, args.cpu_seconds, cores)
+            sps, secs, n_cpu, cph = cpu_baseline(circuit, mine, starts[0], ck_host, args.cpu_seconds, cores)
             out["cpu_baseline"] = {"value": sps, "unit": "steps/s", "cores": cores, "kind": "port",
-                                   "sample": f"{n_cpu} folding steps of the step circuit's instances with the CPU oracle (C++ restatement, std::thread over all cores; not the Rust binary; "
-                                             f"without the augmented circuits, i.e. less work per step than the GPU number), {secs:.1f} s"}
+                                   "sample": f"{n_cpu} folding steps of the step circuit's instances with the CPU oracle (C++ restatement, std::thread over all cores for SpMV / MSM / vector ops, "
+                                             f"witness executor single-threaded; not the Rust binary; without the augmented circuits, i.e. less work per step than the GPU number), {secs:.1f} s",
+                                   "seconds_per_step_by_phase": cph}
         print(json.dumps(out), flush=True)
     for v in ivcs:
         v.close()
-    params.ck.free(); ck2.free()
+    params.free()
     for c in ctxs:
         c.close()
     if dist is not None:
@@ -243,13 +307,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=256)
-    ap.add_argument("--warmup", type=int, default=96)      # 32 rows per concurrent proof: repeated runs spread 452-461 instead of 416-465 with 16
+    ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--transformation", default="contrast")
     ap.add_argument("--resolution", default="HD")
     ap.add_argument("--batch", type=int, default=64)
-    ap.add_argument("--segments", type=int, default=0, help="row segments folded concurrently on each GPU, own context + streams each (default: 3 IVC proofs, 2 accumulators)")
+    ap.add_argument("--segments", type=int, default=0, help="proofs / row segments folded concurrently on each GPU, own context + streams each (default: 1 IVC proof, 2 accumulators)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the three-concurrent-proofs extra of the default IVC run")
     ap.add_argument("--mode", default="ivc", choices=["ivc", "accumulator"])
     ap.add_argument("--window-tables", action="store_true", help="precompute 2^(16j)·P_i tables of the primary key (16x its size in HBM): one bucket set, no Horner")
     ap.add_argument("--proof-set", default="", help="comma-separated transformations: rank r proves proof_set[r %% len] (BASELINE config 5: independent proofs, replicas only)")
@@ -271,16 +336,19 @@ def main():
     if torch.cuda.is_available():
         torch.cuda.set_device(device)
 
-    from vimz_amd import _lib, folding, hip
+    from vimz_amd import folding, hip
     from vimz_amd.distributed import segment_bounds
-    S = args.segments if args.segments > 0 else (3 if args.mode == "ivc" else 2)
+    S = args.segments if args.segments > 0 else (1 if args.mode == "ivc" else 2)
     ctxs = [hip.Context(device) for _ in range(S)]
     ctx = ctxs[0]
     t_setup = time.time()
     circuit, params = folding.prepare_folding(ctx, args.transformation, args.resolution, window_tables=args.window_tables)
     steps_all, z0 = build_inputs(args.transformation, args.resolution)
     n_rows = steps_all.shape[0]
-    per_rank = args.warmup + args.steps
+    if args.mode == "ivc":
+        per_rank = S * (-(-args.warmup // S) + 2 * -(-args.steps // S))
+    else:
+        per_rank = args.warmup + args.steps
     # global row list = concatenation of the ranks' segments; rank r folds rows [r*per_rank, (r+1)*per_rank) of it
     # (image rows are reused cyclically when the list is longer than the image)
     glob = [i % n_rows for i in range(world * per_rank)]
@@ -291,11 +359,7 @@ def main():
     provers = [hip.Prover(c, circuit, params.ck, max_batch=args.batch) for c in ctxs]   # the key and the shape are shared, read-only
     prover = provers[0]
     # IVC state at which this rank's segment starts (hash-only chain over the rows before it)
-    if lo:
-        zs = prover.state_chain(z0, steps_all[glob[:lo]])
-        z_start = [int(a[0]) | int(a[1]) << 64 | int(a[2]) << 128 | int(a[3]) << 192 for a in zs[-1]]
-    else:
-        z_start = list(z0)
+    z_start = _ints(prover.state_chain(z0, steps_all[glob[:lo]])[-1]) if lo else list(z0)
     setup_s = time.time() - t_setup
 
     from vimz_amd.distributed import fold_local_segments
@@ -311,7 +375,7 @@ def main():
     # warm-up: the rank's first W rows, folded with the same local segmentation and merged, exactly like the timed part
     if args.warmup:
         fold_local_segments(provers, mine[:args.warmup], z_start)
-        z_timed = [int(a[0]) | int(a[1]) << 64 | int(a[2]) << 128 | int(a[3]) << 192 for a in prover.instance()["z"]]
+        z_timed = _ints(prover.instance()["z"])
     else:
         z_timed = z_start
     warm_blob = prover.export() if args.warmup else None
@@ -365,12 +429,7 @@ def main():
         alg_bytes = 96.0 * n_c                                     # 32 B scalar + 64 B affine base per point
         achieved = alg_bytes / (acc_ms * 1e-3) / 1e9 if acc_ms else 0.0
         adds = tot["entries"] / calls
-        traffic = None          # HBM bytes per launch of the roofline kernel from PMC passes of this same command (profiles/)
-        try:
-            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fp:
-                traffic = json.load(fp).get(f"{args.transformation}_step_{args.resolution}", {}).get("hbm_bytes_per_launch")
-        except OSError:
-            pass
+        traffic, traffic_src = _pmc_traffic(f"{args.transformation}_step_{args.resolution}")
         step_bytes = 96 * n_w + 96 * n_c + 8 * nnz + 32 * n_w + 96 * n_c + 7 * 32 * n_c + 3 * 32 * n_w + 12 * 32 * n_c
         out = {
             "metric": "nova_folding_steps_per_sec",
@@ -394,7 +453,7 @@ def main():
             "published_reference": {"contrast_HD_steps_per_s_cpu_server": 1.94, "source": "README.md:52 (720 steps / 371.7 s)"},
             "phase_ms_per_step": {k: 1e3 * v["seconds"] / max(1, (args.steps + args.warmup)) for k, v in prof.items()},
             "roofline": {"bound": "hbm", "kernel": "k_accum (bucket accumulation) of the MSM(T) launches in the timed region", "achieved": achieved,
-                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": acc_ms, "launches": tot["calls"], "msm_gpu_ms": msm_ms,
                          "mixed_adds_per_launch": adds, "msm_phase_ms": {k: v / calls for k, v in tot["ms"].items()},
                          "int_utilisation": (adds / (acc_ms * 1e-3) / 1e9 / MIXED_ADD_PEAK_GOPS) if acc_ms else 0.0,
@@ -403,13 +462,14 @@ def main():
         if not args.no_cpu_baseline and world == 1:      # the CPU baseline is timed at N = 1 only
             cores = os.cpu_count() or 1
             ck_host = params.ck.download(0, max(n_c, n_w))
-            sps, secs, n_cpu = cpu_baseline(circuit, mine, z_start, ck_host, args.cpu_seconds, cores)
+            sps, secs, n_cpu, cph = cpu_baseline(circuit, mine, z_start, ck_host, args.cpu_seconds, cores)
             out["cpu_baseline"] = {"value": sps, "unit": "steps/s", "cores": cores, "kind": "port",
-                                   "sample": f"{n_cpu} folding steps of the same workload with the CPU oracle (C++ restatement, std::thread over all cores; not the Rust binary), {secs:.1f} s"}
+                                   "sample": f"{n_cpu} folding steps of the same workload with the CPU oracle (C++ restatement, std::thread over all cores; not the Rust binary), {secs:.1f} s",
+                                   "seconds_per_step_by_phase": cph}
         print(json.dumps(out), flush=True)
     for p_ in provers:
         p_.close()
-    params.ck.free()
+    params.free()
     for c in ctxs:
         c.close()
     if dist is not None:

@@ -197,6 +197,55 @@ inline void poseidon_permute(Fp<FP>* s, int t, bool lane0_const, std::vector<Fp<
   }
 }
 
+// One HashJob of a step circuit's witness program on the host, with the wires the GPU kernel (witness.hpp: poseidon_group) writes:
+// x^2, x^4, x^5 of every S-box in (round, lane) order; round-0 S-boxes of lane 0 (state 0 + C) and of lanes whose input is the
+// constant zero (bit i of fold_mask0 set for lane i) are folded into constants and emit nothing; when the output is bound to a
+// public-output wire (`bound`) the x^5 of (last round, lane 0) is the substituted signal and is not a wire either.
+// state: s[0..t) in, permuted in place (s[0] = the hash); returns the number of wires written.
+template <class FP>
+inline uint32_t poseidon_job_wires(Fp<FP>* s, int t, uint32_t fold_mask0, bool bound, Fp<FP>* wires) {
+  typedef Fp<FP> F;
+  const PoseidonTableT<F>& P = poseidon_table_t<FP>(t);
+  const PoseidonSparseT<F>& S = poseidon_sparse_t<FP>(t);
+  F u[POSEIDON_MAX_T];
+  uint32_t n = 0;
+  auto sbox = [&](F& x, bool emit, bool skip_x5) {
+    const F x2 = F::sqr(x), x4 = F::sqr(x2), x5 = F::mul(x4, x);
+    if (emit) { wires[n++] = x2; wires[n++] = x4; if (!skip_x5) wires[n++] = x5; }
+    x = x5;
+  };
+  auto dot = [](const F* a, const F* b, int k) { return F::dot(a, b, k); };      // t <= 9 terms
+  auto mix = [&]() {
+    for (int i = 0; i < t; i++) u[i] = dot(&P.M[(size_t)i * t], s, t);
+    for (int i = 0; i < t; i++) s[i] = u[i];
+  };
+  const int half = P.rf / 2, R = P.rf + P.rp;
+  for (int r = 0; r < half; r++) {
+    for (int i = 0; i < t; i++) s[i] = F::add(s[i], P.C[(size_t)r * t + i]);
+    for (int i = 0; i < t; i++) sbox(s[i], !(r == 0 && (i == 0 || ((fold_mask0 >> i) & 1u))), false);
+    mix();
+  }
+  const int m = t - 1;
+  for (int r = 0; r < P.rp; r++) {
+    const F* ct = &S.ctil[(size_t)r * t]; const F* row = &S.row[(size_t)r * t]; const F* col = &S.col[(size_t)r * m];
+    for (int i = 0; i < t; i++) s[i] = F::add(s[i], ct[i]);
+    sbox(s[0], true, false);
+    const F n0 = dot(row, s, t);
+    for (int i = 1; i < t; i++) s[i] = F::add(s[i], F::mul(col[i - 1], s[0]));
+    s[0] = n0;
+  }
+  for (int i = 0; i < m; i++) u[i] = dot(&S.Pfin[(size_t)i * m], s + 1, m);
+  for (int i = 0; i < m; i++) s[1 + i] = u[i];
+  for (int r = half + P.rp; r < R; r++) {
+    for (int i = 0; i < t; i++) s[i] = F::add(s[i], P.C[(size_t)r * t + i]);
+    for (int i = 0; i < t; i++) sbox(s[i], true, bound && r == R - 1 && i == 0);
+    mix();
+  }
+  return n;
+}
+// wires a job of width t writes, given the number of its non-constant inputs
+inline uint32_t poseidon_job_wire_count(int t, int rp, uint32_t nonconst_inputs, bool bound) { return 3u * (nonconst_inputs + 3u * t + rp + 4u * t) - (bound ? 1u : 0u); }
+
 // Numeric hash on the host (IVC state chain, transcript, instance hashes).
 template <class FP>
 inline Fp<FP> poseidon_hash_t(const Fp<FP>* in, int n) {

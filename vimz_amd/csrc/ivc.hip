@@ -158,12 +158,12 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
     v->t1_step_pending = true;
     return VIMZ_OK;
   };
-  if ((rc = fold_issue(p, job, 0))) return rc;
   for (size_t k = 0; k < job.nbatches; k++) {
     auto& bb = p->buf[k & 1];
-    const size_t first = k * job.Bk, rows = std::min(job.Bk, nsteps - first);
-    if (k + 1 < job.nbatches && (rc = fold_issue(p, job, k + 1))) return rc;
+    const size_t first = job.first(k), rows = job.rows(k);
     double t0 = now_s();
+    if ((rc = fold_issue_when_ready(p, job, k, true))) return rc;            // (batch 0 of a head-batch call is already out)
+    if ((rc = fold_issue_when_ready(p, job, k + 1, false))) return rc;       // the next batch is produced while this one is folded
     P_TRY(hipEventSynchronize(bb.wit_done));
     v->ph_s[IP_PRODUCER] += now_s() - t0;
     if (k == 0) { t_wait0 = now_s() - t0; t_first = now_s() - t_all; }
@@ -178,6 +178,7 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
     }
     for (size_t r = 0; r < rows; r++) {
       const uint64_t i = v->i;
+      if ((rc = fold_issue_when_ready(p, job, k + 1, false))) return rc;
       uint32_t* Zi = bb.Z + 8 * r * nw;
       uint32_t *az = bb.az + 8 * r * nc, *bz = bb.bz + 8 * r * nc, *cz = bb.cz + 8 * r * nc;
       // ---- 1. the previous fresh secondary instance is complete once its two MSMs are back -------------------------------------
@@ -338,7 +339,10 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
         v->pending_sec = true;
       }
       if (r + 1 < rows) { if ((rc = launch_T1_step(bb, r + 1, false))) return rc; }
-      else if (k + 1 < job.nbatches) { if ((rc = launch_T1_step(p->buf[(k + 1) & 1], 0, false))) return rc; }
+      else if (k + 1 < job.nbatches) {
+        if ((rc = fold_issue_when_ready(p, job, k + 1, true))) return rc;      // its per-row events must have been recorded in this call
+        if ((rc = launch_T1_step(p->buf[(k + 1) & 1], 0, false))) return rc;
+      }
       v->ph_s[IP_LAUNCH] += now_s() - t0;
       v->i++; p->steps++;
     }

@@ -21,6 +21,15 @@ void vimz_prover_free(vimz_prover* p) {
     hipSetDevice(p->ctx->device);
     hipStreamSynchronize(p->ctx->stream);
     if (p->sB) { hipStreamSynchronize(p->sB); hipStreamDestroy(p->sB); }
+    if (p->sH) { hipStreamSynchronize(p->sH); hipStreamDestroy(p->sH); }
+    if (p->ev_head) hipEventDestroy(p->ev_head);
+    if (p->ev_hash) hipEventDestroy(p->ev_hash);
+    p->pool.reset();
+    p->wsH.release();
+    if (p->stage_host) hipHostFree(p->stage_host);
+    if (p->jobvals_host) hipHostFree(p->jobvals_host);
+    if (p->zs_host) hipHostFree(p->zs_host);
+    hipFree(p->stage_d); hipFree(p->jobvals_d);
     for (auto& bb : p->buf) {
       for (auto e : bb.ev) hipEventDestroy(e);
       if (bb.wit_done) hipEventDestroy(bb.wit_done);
@@ -134,6 +143,26 @@ int vz_prover_create_layout(vimz_ctx* ctx, const vimz_circuit* circuit, const vi
     if ((e = hipEventCreateWithFlags(&bb.wit_done, hipEventDisableTiming)) != hipSuccess) return fail_free("event", e);
     if ((e = hipHostMalloc(&bb.pin, 4 * (size_t)XYZZ_WORDS * MSM_MAX_WINDOWS * B)) != hipSuccess) return fail_free("pinned", e);
     if ((e = hipHostMalloc((void**)&bb.status_host, 4 * B)) != hipSuccess) return fail_free("pinned", e);
+  }
+  {   // head batch of a fold call (prover_internal.hpp: fold_head_batch): staging layout of the Poseidon jobs' wires, its stream
+    int lo = 0, hi = 0; hipDeviceGetStreamPriorityRange(&lo, &hi);
+    if ((e = hipStreamCreateWithPriority(&p->sH, hipStreamNonBlocking, lo)) != hipSuccess) return fail_free("stream", e);
+    if ((e = hipEventCreateWithFlags(&p->ev_head, hipEventDisableTiming)) != hipSuccess || (e = hipEventCreateWithFlags(&p->ev_hash, hipEventDisableTiming)) != hipSuccess)
+      return fail_free("event", e);
+    const cb::PoseidonTable& t3 = cb::poseidon_table(3); const cb::PoseidonTable& t9 = cb::poseidon_table(9);
+    p->job_stage_off.assign(1, 0); p->job_fold_mask.clear();
+    for (auto& J : b.jobs) {
+      uint32_t mask = 0, nonconst = 0;
+      for (uint32_t i = 0; i + 1 < J.t; i++) { if (J.in[i].kind == REF_CONST_ZERO) mask |= 1u << (i + 1); else nonconst++; }
+      p->job_fold_mask.push_back(mask);
+      p->job_stage_off.push_back(p->job_stage_off.back() + cb::poseidon_job_wire_count((int)J.t, J.t == 3 ? t3.rp : t9.rp, nonconst, J.out_wire != 0));
+    }
+    e = upload(p->job_stage_off, &p->job_stage_off_d); if (p->job_stage_off_d) p->owned.push_back((void*)p->job_stage_off_d);
+    if (e != hipSuccess) return fail_free("upload job layout", e);
+    bool ok = !b.jobs.empty() && b.gpu_witness && !b.zout.empty();
+    for (auto& c : b.chains) ok = ok && c.phase <= 1;
+    for (auto& f : b.fops) ok = ok && !f.early && f.op != FOP_LC;
+    p->head_eligible = ok;
   }
   if ((e = hipStreamSynchronize(nullptr)) != hipSuccess) return fail_free("sync", e);   // the hipMemset fills above ran on the null stream
   p->z_cur.assign(p->len_z, Fe::zero()); p->z0 = p->z_cur;
@@ -277,15 +306,14 @@ static int fold_core(vimz_prover* p, const uint64_t* step_inputs, const uint64_t
   if ((rc = fold_prepare(p, job, true))) return rc;
   const std::vector<Fe>& zs = job.zs;
   const BaseTables& tbl = job.tbl;
-  const size_t pin_stride = FoldJob::pin_stride, nbatches = job.nbatches, Bk = job.Bk;
-  auto issue = [&](size_t k) -> int { return fold_issue(p, job, k); };
+  const size_t pin_stride = FoldJob::pin_stride, nbatches = job.nbatches;
 
   // ---- 2. consumer: the sequential chain on stream A ------------------------------------------------------------
-  if ((rc = issue(0))) return rc;
   for (size_t k = 0; k < nbatches; k++) {
     auto& bb = p->buf[k & 1];
-    const size_t first = k * Bk, rows = std::min(Bk, nsteps - first);
-    if (k + 1 < nbatches && (rc = issue(k + 1))) return rc;
+    const size_t first = job.first(k), rows = job.rows(k);
+    if ((rc = fold_issue_when_ready(p, job, k, true))) return rc;            // (batch 0 of a head-batch call is already out)
+    if ((rc = fold_issue_when_ready(p, job, k + 1, false))) return rc;       // the next batch is produced while this one is folded
     P_TRY(hipEventSynchronize(bb.wit_done));
     for (size_t r = 0; r < rows; r++) if (bb.status_host[r]) {
       char msg[128]; snprintf(msg, sizeof(msg), "step %llu: the step relation is not satisfiable for these rows", (unsigned long long)(p->steps + r));
@@ -352,6 +380,7 @@ static int fold_core(vimz_prover* p, const uint64_t* step_inputs, const uint64_t
     for (size_t r = r0; r < rows; r++) {
       // host work hidden behind MSM(T) of row r
       flush_deferred();
+      if ((rc = fold_issue_when_ready(p, job, k + 1, false))) return rc;
       if (r + 1 < rows && (rc = do_prep(r + 1))) return rc;
       t0 = now_s();
       P_TRY(hipStreamSynchronize(s));

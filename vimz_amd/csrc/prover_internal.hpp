@@ -4,8 +4,14 @@
 // Both use the same batch producer (witness kernels, per-row SpMV, witness-commitment MSM on a low-priority stream).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
+#include <memory>
+#include <string>
+#include <thread>
 #include <vector>
 #include <algorithm>
 
@@ -49,6 +55,47 @@ G1 scalar_mul(const G1Aff& p, const uint32_t* k, int bits) {
 
 }  // namespace
 
+// A few host threads per prover for the head batch's Poseidon chains (fold_head_batch).  run(n, f) executes f(0..n-1) on the
+// workers and the calling thread and returns when all are done.
+struct HostPool {
+  std::vector<std::thread> th;
+  std::mutex m; std::condition_variable cv, cv_done;
+  std::function<void(size_t)> fn; size_t n = 0; std::atomic<size_t> next{0}; size_t done = 0, active = 0; uint64_t gen = 0; bool stop = false;
+  explicit HostPool(unsigned workers) { for (unsigned i = 0; i < workers; i++) th.emplace_back([this] { loop(); }); }
+  ~HostPool() { { std::lock_guard<std::mutex> g(m); stop = true; } cv.notify_all(); for (auto& t : th) t.join(); }
+  void drain() {
+    for (;;) {
+      const size_t i = next.fetch_add(1);
+      if (i >= n) break;
+      fn(i);
+      std::lock_guard<std::mutex> g(m);
+      if (++done == n) cv_done.notify_all();
+    }
+  }
+  void loop() {
+    uint64_t seen = 0;
+    std::unique_lock<std::mutex> lk(m);
+    for (;;) {
+      cv.wait(lk, [&] { return stop || gen != seen; });
+      if (stop) return;
+      seen = gen; active++;
+      lk.unlock(); drain(); lk.lock();
+      if (--active == 0) cv_done.notify_all();
+    }
+  }
+  void run(size_t count, std::function<void(size_t)> f) {
+    if (!count) return;
+    std::unique_lock<std::mutex> lk(m);
+    cv_done.wait(lk, [&] { return active == 0; });      // stragglers of the previous call have left drain(): fn / n may change
+    fn = std::move(f); n = count; next = 0; done = 0; gen++;
+    lk.unlock();
+    cv.notify_all();
+    drain();
+    lk.lock();
+    cv_done.wait(lk, [&] { return done == n; });
+  }
+};
+
 enum { PH_WITNESS = 0, PH_ZCHAIN, PH_SPMV, PH_MSM_W, PH_CROSS, PH_MSM_T, PH_RO, PH_FOLD, PH_HOST_EC, PH_COUNT };
 
 struct vimz_prover {
@@ -87,6 +134,17 @@ struct vimz_prover {
   } buf[2];
   MsmWorkspace wsB;
   MsmPlan planB{};
+  // head batch of a fold call: Poseidon jobs evaluated on the host, everything else on a stream of its own (fold_head_batch)
+  hipStream_t sH = nullptr; hipEvent_t ev_head = nullptr, ev_hash = nullptr;
+  MsmWorkspace wsH;
+  std::vector<uint32_t> job_stage_off;     // [n_jobs + 1] wire offsets of the jobs inside a staging row
+  std::vector<uint32_t> job_fold_mask;     // per job: lanes whose round-0 S-box is folded (constant-zero inputs)
+  const uint32_t* job_stage_off_d = nullptr;
+  Fe* stage_host = nullptr; Fe* jobvals_host = nullptr; Fe* zs_host = nullptr;   // pinned
+  uint32_t *stage_d = nullptr, *jobvals_d = nullptr;
+  size_t head_rows_cap = 0;
+  std::unique_ptr<HostPool> pool;
+  bool head_eligible = false;
   // per fold call: all private inputs, all IVC states and all row hashes resident
   uint32_t *priv_all_d = nullptr, *zs_all_d = nullptr, *job_all_d = nullptr;
   size_t cap_priv_all = 0, cap_zs_all = 0, cap_job_all = 0;
@@ -151,19 +209,31 @@ static void launch_spmv(vimz_prover* p, hipStream_t s, const uint32_t* z, uint32
 }
 
 // Host IVC-state chain for `rows` rows: zs[(r+1)] from zs[r] and the row hashes (phase-A job outputs) of row r.
-static void host_state_chain(const vimz_prover* p, const uint64_t* inputs, size_t rows, const Fe* jobA, size_t jstride, std::vector<Fe>& zs) {
+// stage / jobvals (optional, head batch): also emit the wires of the state-dependent (phase-B) jobs into the row's staging area and
+// their outputs into the row's job values, so that no Poseidon work of these rows is left for the GPU.
+static void host_state_chain(const vimz_prover* p, const uint64_t* inputs, size_t rows, const Fe* jobA, size_t jstride, std::vector<Fe>& zs, size_t zs_row0 = 0,
+                             Fe* stage = nullptr, size_t stage_row = 0, Fe* jobvals = nullptr) {
   const cb::Builder& b = p->circuit->build->b;
   HostEval ev; ev.P = p; ev.b = &b;
   for (size_t r = 0; r < rows; r++) {
-    ev.priv = inputs + 4 * r * p->n_priv; ev.job_a = jobA + r * jstride; ev.zin = zs.data() + r * p->len_z;
+    ev.priv = inputs + 4 * r * p->n_priv; ev.job_a = jobA + r * jstride; ev.zin = zs.data() + (zs_row0 + r) * p->len_z;
     ev.job_b.assign(p->n_jobs, Fe::zero()); ev.fop.assign(p->n_fops, Fe::zero());
     for (auto& c : b.chains) {
       if (c.phase != 1) continue;
       for (uint32_t k = 0; k < c.job_cnt; k++) {
-        const HashJob& J = b.jobs[c.job_off + k];
-        Fe in[POSEIDON_MAX_T];
-        for (uint32_t i = 0; i + 1 < J.t; i++) in[i] = ev.value(J.in[i]);
-        ev.job_b[c.job_off + k] = cb::poseidon_hash(in, (int)J.t - 1);
+        const uint32_t j = c.job_off + k;
+        const HashJob& J = b.jobs[j];
+        if (stage) {
+          Fe st[POSEIDON_MAX_T]; st[0] = Fe::zero();
+          for (uint32_t i = 0; i + 1 < J.t; i++) st[1 + i] = ev.value(J.in[i]);
+          cb::poseidon_job_wires<BnFr>(st, (int)J.t, p->job_fold_mask[j], J.out_wire != 0, stage + r * stage_row + p->job_stage_off[j]);
+          ev.job_b[j] = st[0];
+          jobvals[r * jstride + j] = st[0];
+        } else {
+          Fe in[POSEIDON_MAX_T];
+          for (uint32_t i = 0; i + 1 < J.t; i++) in[i] = ev.value(J.in[i]);
+          ev.job_b[j] = cb::poseidon_hash(in, (int)J.t - 1);
+        }
       }
     }
     for (uint32_t f = 0; f < p->n_fops; f++) {
@@ -171,7 +241,7 @@ static void host_state_chain(const vimz_prover* p, const uint64_t* inputs, size_
       if (F.op == FOP_ISZERO) { Fe in = ev.value(F.a); ev.fop[f] = in.is_zero() ? Fe::one() : Fe::zero(); }
       else if (F.op == FOP_MUX) { Fe sv = ev.value(F.a), c0 = ev.value(F.b), c1 = ev.value(F.c); ev.fop[f] = Fe::add(Fe::mul(Fe::sub(c1, c0), sv), c0); }
     }
-    Fe* zn = zs.data() + (r + 1) * p->len_z;
+    Fe* zn = zs.data() + (zs_row0 + r + 1) * p->len_z;
     for (uint32_t i = 0; i < p->len_z; i++) zn[i] = Fe::add(ev.value(b.zout[i].ref), cb::fe_from_i64(b.zout[i].add));
   }
 }
@@ -195,15 +265,26 @@ int vz_prover_create_layout(vimz_ctx* ctx, const vimz_circuit* circuit, const vi
 
 // One call of vimz_prover_fold / vimz_ivc_fold: the inputs, the IVC state chain and the batch schedule.
 struct FoldJob {
-  bool batch0_started = false;     // fold_prepare already ran the state-independent part of batch 0's witness (see there)
+  int started_batch = -1;          // fold_prepare already ran the state-independent part of this batch's witness (see there)
   const uint64_t* step_inputs = nullptr;   // nsteps x n_priv canonical, or
   const uint64_t* witnesses = nullptr;     // nsteps x step_wires canonical (circom .wtns order)
   size_t nsteps = 0;
   std::vector<Fe> zs;                      // (nsteps + 1) x len_z IVC states, Montgomery
-  size_t nbatches = 0, Bk = 0;
+  size_t nbatches = 0;
+  std::vector<size_t> bfirst, brows;       // batch k = rows [bfirst[k], bfirst[k] + brows[k]); buffer k & 1
+  size_t first(size_t k) const { return bfirst[k]; }
+  size_t rows(size_t k) const { return brows[k]; }
   uint32_t nA = 0, nB = 0, nE = 0;         // Poseidon chains of phase A (row data only) / B (need the hashed state) / 2 (after the early field ops)
   bool early_fops = false;
   BaseTables tbl{};
+  // head batch on the host (fold_head_batch): batch 0 is already issued when fold_prepare returns, and the IVC states of the rows
+  // after it arrive later, from a helper thread (the hash-only pass over those rows takes one Poseidon-chain latency on the GPU)
+  bool head = false;
+  size_t next_issue = 0;                   // first batch not yet handed to fold_issue
+  std::thread helper; std::atomic<size_t> states_upto{0};   // rows whose IVC states (zs, on host and device) exist
+  std::atomic<int> helper_done{1}; int helper_rc = VIMZ_OK; std::string helper_err;
+  std::vector<Fe> jobA_rest;
+  ~FoldJob() { if (helper.joinable()) helper.join(); }
   static constexpr size_t pin_stride = 4 * (size_t)XYZZ_WORDS * MSM_MAX_WINDOWS;
 };
 
@@ -246,8 +327,116 @@ static int launch_witness(vimz_prover* p, hipStream_t st, uint32_t* Z, uint32_t*
   return VIMZ_OK;
 }
 
-// Stage 0 (caller holds the lock, device set): every private input to HBM; ONE hash-only pass of the phase-A Poseidon chains
-// over ALL rows (they depend on the row data only); the host then runs the whole IVC state chain z_0..z_n and uploads it.
+// Even split of rows [first, first + n) into batches of at most B rows, appended to the job's batch table
+// (85 rows -> 43 + 42, not 64 + 21: no short tail batch).
+static void plan_batches(FoldJob& J, size_t first, size_t n, size_t B) {
+  if (!n) return;
+  const size_t nb = (n + B - 1) / B, per = (n + nb - 1) / nb;
+  for (size_t off = 0; off < n; off += per) { J.bfirst.push_back(first + off); J.brows.push_back(std::min(per, n - off)); }
+}
+
+static int fold_issue(vimz_prover* p, const FoldJob& J, size_t k);
+
+// Rows of a call whose Poseidon jobs are evaluated on the host (VIMZ_HEAD_ROWS overrides; 0 switches the head batch off).
+static size_t head_rows_wanted() {
+  static const long v = getenv("VIMZ_HEAD_ROWS") ? atol(getenv("VIMZ_HEAD_ROWS")) : 8;
+  return v < 0 ? 0 : (size_t)v;
+}
+
+// HEAD BATCH.  A fold call cannot start folding before the first rows' witnesses exist, and those contain the row-hash Poseidon
+// chains: 17 dependent permutations, 10 ms on the GPU whatever the row count (one wave per chain, ~0.6 ms per permutation) but
+// 1.1 ms on a CPU core (66 µs per permutation).  So the Poseidon jobs of the first few rows of a call are evaluated on host
+// threads — outputs for the IVC state chain and every S-box wire — while the GPU does the rest of those rows' witnesses (bit
+// decompositions, lane programs, field ops) on a stream of its own and, on the producer's stream, already runs the chains of the
+// NEXT batch.  The first fold of a call starts after ~3 ms instead of ~20 ms (VIMZ_DEBUG_TIMING=1 prints it).
+// Leaves batch 0 fully issued (events bb.wit_done, bb.ev[r] recorded on p->sH) and the IVC states zs[0..rows] filled in.
+static int fold_head_batch(vimz_prover* p, FoldJob& J, size_t rows) {
+  vimz_ctx* ctx = p->ctx;
+  const cb::Builder& b = p->circuit->build->b;
+  const WitnessDev& W = p->wd;
+  const size_t jstride = p->n_jobs + p->n_fops, stage_row = p->job_stage_off.back(), nw = p->n_wires, nc = p->n_c, sw = p->step_wires;
+  if (rows > p->head_rows_cap) {       // (first use: pinned + device staging for the largest head this prover can see, kept —
+                                       //  pinned allocations take milliseconds and must not recur in later calls)
+    const size_t cap_rows = std::max(rows, std::min(head_rows_wanted(), p->max_batch));
+    if (p->stage_host) { hipHostFree(p->stage_host); hipHostFree(p->jobvals_host); hipHostFree(p->zs_host); p->retired.push_back(p->stage_d); p->retired.push_back(p->jobvals_d); }
+    p->stage_host = nullptr; p->jobvals_host = nullptr; p->zs_host = nullptr; p->stage_d = nullptr; p->jobvals_d = nullptr; p->head_rows_cap = 0;
+    P_TRY(hipHostMalloc((void**)&p->stage_host, 32 * cap_rows * stage_row));
+    P_TRY(hipHostMalloc((void**)&p->jobvals_host, 32 * cap_rows * jstride));
+    P_TRY(hipHostMalloc((void**)&p->zs_host, 32 * (cap_rows + 1) * (size_t)p->len_z));
+    P_TRY(hipMalloc((void**)&p->stage_d, 32 * cap_rows * stage_row));
+    P_TRY(hipMalloc((void**)&p->jobvals_d, 32 * cap_rows * jstride));
+    p->head_rows_cap = cap_rows;
+  }
+  if (!p->pool) {
+    const unsigned hw = std::thread::hardware_concurrency();
+    p->pool.reset(new HostPool(hw > 2 ? std::min(15u, hw - 2) : 0u));
+  }
+  auto& bb = p->buf[0];
+  hipStream_t sh = p->sH;
+  // the state-independent GPU part of these rows starts now, under the host's Poseidon work
+  P_TRY(hipStreamWaitEvent(sh, bb.wit_done, 0));          // (recorded by the caller behind the upload of the private inputs)
+  P_TRY(hipMemsetAsync(bb.status, 0, 4 * rows, sh));
+  for (uint32_t gI = 0; gI < W.n_decomp; gI++) {
+    const uint32_t total = (b.decomp[gI].nbits - 1) * b.decomp[gI].count;
+    hipLaunchKernelGGL(k_wit_decomp, dim3((total + 255) / 256, (unsigned)rows), dim3(256), 0, sh, W, gI, (const uint32_t*)p->priv_all_d, bb.Z, bb.status);
+  }
+  // 1. row-hash chains (phase A) of every head row, one task per (row, chain)
+  std::vector<uint32_t> chainsA;
+  for (uint32_t c = 0; c < b.chains.size(); c++) if (b.chains[c].phase == 0) chainsA.push_back(c);
+  Fe* stage = p->stage_host; Fe* jobvals = p->jobvals_host;
+  memset(jobvals, 0, 32 * rows * jstride);
+  const uint64_t* inputs = J.step_inputs;
+  const uint32_t priv0 = 1 + 2 * b.len_z;
+  p->pool->run(rows * chainsA.size(), [&](size_t task) {
+    const size_t r = task / chainsA.size();
+    const Chain& C = b.chains[chainsA[task % chainsA.size()]];
+    Fe prev = Fe::zero();
+    for (uint32_t k = 0; k < C.job_cnt; k++) {
+      const uint32_t j = C.job_off + k;
+      const HashJob& Jb = b.jobs[j];
+      Fe st[POSEIDON_MAX_T]; st[0] = Fe::zero();
+      for (uint32_t i = 0; i + 1 < Jb.t; i++) {
+        const ValRef& ref = Jb.in[i];
+        if (ref.kind == REF_WIRE) st[1 + i] = fe_from_canon(inputs + 4 * (r * p->n_priv + (ref.idx - priv0)));
+        else if (ref.kind == REF_JOB) st[1 + i] = ref.idx + 1 == j ? prev : jobvals[r * jstride + ref.idx];
+        else st[1 + i] = Fe::zero();
+      }
+      cb::poseidon_job_wires<BnFr>(st, (int)Jb.t, p->job_fold_mask[j], Jb.out_wire != 0, stage + r * stage_row + p->job_stage_off[j]);
+      prev = st[0];
+      jobvals[r * jstride + j] = st[0];
+    }
+  });
+  // 2. the IVC state chain of these rows, with the wires of the state hashes
+  host_state_chain(p, inputs, rows, jobvals, jstride, J.zs, 0, stage, stage_row, jobvals);
+  for (size_t i = 0; i < (rows + 1) * (size_t)p->len_z; i++) p->zs_host[i] = Fe::from_mont(J.zs[i]);
+  // 3. upload, scatter, the rest of the witness, then per row (A,B,C)·z and the witness commitment
+  P_TRY(hipMemcpyAsync(p->zs_all_d, p->zs_host, 32 * (rows + 1) * (size_t)p->len_z, hipMemcpyHostToDevice, sh));
+  P_TRY(hipMemcpyAsync(p->stage_d, stage, 32 * rows * stage_row, hipMemcpyHostToDevice, sh));
+  P_TRY(hipMemcpyAsync(p->jobvals_d, jobvals, 32 * rows * jstride, hipMemcpyHostToDevice, sh));
+  const unsigned R = (unsigned)rows;
+  hipLaunchKernelGGL(k_wit_inputs, dim3(((1 + 2 * p->len_z + p->n_priv) + 255) / 256, R), dim3(256), 0, sh, W, (const uint32_t*)p->priv_all_d, (const uint32_t*)p->zs_all_d, bb.Z, 0u);
+  for (uint32_t gI = 0; gI < W.n_groups; gI++)
+    hipLaunchKernelGGL(k_wit_lanes, dim3((b.lane_groups[gI].lanes + LANE_TB - 1) / LANE_TB, R), dim3(LANE_TB), 0, sh, W, gI, (const uint32_t*)p->priv_all_d, (const uint32_t*)p->zs_all_d, 0u, bb.Z, bb.status);
+  if (p->n_jobs) hipLaunchKernelGGL(k_wit_scatter, dim3(p->n_jobs, R), dim3(128), 0, sh, W, p->job_stage_off_d, (const uint32_t*)p->stage_d, (uint32_t)stage_row, (const uint32_t*)p->jobvals_d, bb.Z, bb.job_out);
+  if (p->n_fops) hipLaunchKernelGGL(k_wit_fops, dim3((R + 63) / 64), dim3(64), 0, sh, W, bb.Z, bb.job_out, (uint32_t)rows, 0u);
+  P_TRY(hipGetLastError());
+  P_TRY(hipMemcpyAsync(bb.status_host, bb.status, 4 * rows, hipMemcpyDeviceToHost, sh));
+  P_TRY(hipEventRecord(bb.wit_done, sh));
+  for (size_t r = 0; r < rows; r++) {
+    const uint32_t* Zi = bb.Z + 8 * r * nw;
+    launch_spmv(p, sh, Zi, bb.az + 8 * r * nc, bb.bz + 8 * r * nc, bb.cz + 8 * r * nc, 1);
+    P_TRY(msm_launch<BnG1>(sh, p->wsH, p->ck->d, Zi + 8 * (size_t)p->c0, sw - p->c0, 1, 0, (char*)bb.pin + r * FoldJob::pin_stride, &p->planB, nullptr, 1, p->ck->tables ? &J.tbl : nullptr));
+    P_TRY(hipEventRecord(bb.ev[r], sh));
+  }
+  P_TRY(hipEventRecord(p->ev_head, sh));
+  return VIMZ_OK;
+}
+
+// Stage 0 (caller holds the lock, device set): every private input to HBM; the row hashes (phase-A Poseidon chains) of ALL rows
+// — they depend on the row data only —; the host then runs the IVC state chain z_0..z_n and uploads it.
+// start_batch0 (the fold calls): the first batch is issued from here — as a host-evaluated head batch where the circuit allows it
+// (fold_head_batch), in which case the states of the remaining rows are finished by a helper thread (fold_states_wait) —, else
+// with its state-independent part started ahead.
 static int fold_prepare(vimz_prover* p, FoldJob& J, bool start_batch0 = false) {
   vimz_ctx* ctx = p->ctx;
   hipStream_t s = ctx->stream;
@@ -259,6 +448,7 @@ static int fold_prepare(vimz_prover* p, FoldJob& J, bool start_batch0 = false) {
   J.zs.assign((nsteps + 1) * p->len_z, Fe::zero());
   std::vector<Fe>& zs = J.zs;
   for (uint32_t i = 0; i < p->len_z; i++) zs[i] = p->z_cur[i];
+  J.tbl = p->ck->tb(0);
   double t0 = now_s();
   if (J.witnesses) {
     // external witnesses: the state chain is read off their public wires, and checked for continuity
@@ -272,72 +462,155 @@ static int fold_prepare(vimz_prover* p, FoldJob& J, bool start_batch0 = false) {
         zs[(r + 1) * p->len_z + i] = fe_from_canon(w + 4 * (1 + i));
       }
     }
-  } else {
-    P_TRY(grow(p->retired, &p->priv_all_d, &p->cap_priv_all, 32 * nsteps * (size_t)p->n_priv, 32 * 1024 * (size_t)p->n_priv));
-    P_TRY(grow(p->retired, &p->zs_all_d, &p->cap_zs_all, 32 * (nsteps + 1) * (size_t)p->len_z, 32 * 1025 * (size_t)p->len_z));
-    P_TRY(grow(p->retired, &p->job_all_d, &p->cap_job_all, 32 * nsteps * jstride, 32 * 1024 * jstride));
-    P_TRY(hipMemcpyAsync(p->priv_all_d, J.step_inputs, 32 * nsteps * (size_t)p->n_priv, hipMemcpyHostToDevice, s));
-    P_TRY(hipMemsetAsync(p->job_all_d, 0, 32 * nsteps * jstride, s));
-    // Both this pass and the first witness batch are one Poseidon-chain latency long (≈10 ms, whatever the row count), and the
-    // first fold waits for both.  For the first batch's rows the chains therefore run once, with their wires, into the batch
-    // buffer on the producer's stream, side by side with the hash-only pass of the remaining rows; fold_issue(0) adds the rest.
-    size_t rows0 = 0;
-    if (start_batch0 && J.nA && !J.nE && !J.early_fops) {
-      const size_t nb0 = (nsteps + B - 1) / B;
-      rows0 = std::min((nsteps + nb0 - 1) / nb0, nsteps);
-      auto& b0 = p->buf[0];
-      P_TRY(hipEventRecord(b0.wit_done, s));
-      P_TRY(hipStreamWaitEvent(p->sB, b0.wit_done, 0));
-      P_TRY(hipMemsetAsync(b0.status, 0, 4 * rows0, p->sB));
-      int rc = launch_witness(p, p->sB, b0.Z, b0.job_out, b0.status, p->priv_all_d, 0, rows0, J, false, 1);
-      if (rc) return rc;
-      P_TRY(hipMemcpyAsync(p->job_all_d, b0.job_out, 32 * rows0 * jstride, hipMemcpyDeviceToDevice, p->sB));
-      P_TRY(hipEventRecord(b0.wit_done, p->sB));
-      J.batch0_started = true;
-    }
-    for (size_t off = rows0; off < nsteps && J.nA; off += 32768) {
-      const unsigned rows = (unsigned)std::min<size_t>(32768, nsteps - off);
-      hipLaunchKernelGGL(k_wit_chains, dim3((J.nA + 3) / 4, rows), dim3(64), 0, s, W, 0u, (uint32_t*)nullptr, p->job_all_d + 8 * off * jstride,
-                         (const uint32_t*)(p->priv_all_d + 8 * off * p->n_priv));
-    }
-    P_TRY(hipGetLastError());
-    if (J.nE || J.early_fops) {
-      // Ahead-of-time pass: the IVC state of these circuits absorbs values computed from the witness (crop: the hash of the cropped
-      // row), which depend on step_in only through its predictable part (state elements that are step_in[j] + constant, e.g. the
-      // row counter).  Fill that part in, run the witness kernels up to the phase-2 chains batch by batch, keep the job outputs.
-      std::vector<Fe> zp((nsteps + 1) * p->len_z, Fe::zero());
-      for (uint32_t i = 0; i < p->len_z; i++) zp[i] = zs[i];
-      for (size_t r = 0; r < nsteps; r++)
-        for (uint32_t i = 0; i < p->len_z; i++)
-          if (b.zout[i].ref.kind == REF_ZIN) zp[(r + 1) * p->len_z + i] = Fe::add(zp[r * p->len_z + b.zout[i].ref.idx], cb::fe_from_i64(b.zout[i].add));
-      std::vector<Fe> zc(zp.size());
-      for (size_t i = 0; i < zp.size(); i++) zc[i] = Fe::from_mont(zp[i]);
-      P_TRY(hipMemcpyAsync(p->zs_all_d, zc.data(), 32 * zc.size(), hipMemcpyHostToDevice, s));
-      P_TRY(hipStreamSynchronize(s));
-      int rc;
-      for (size_t first = 0; first < nsteps; first += B) {
-        const size_t rows = std::min(B, nsteps - first);
-        P_TRY(hipMemsetAsync(p->buf[0].status, 0, 4 * rows, s));
-        if ((rc = launch_witness(p, s, p->buf[0].Z, p->job_all_d + 8 * first * jstride, p->buf[0].status, p->priv_all_d + 8 * first * p->n_priv, first, rows, J, true))) return rc;
-      }
-    }
-    std::vector<Fe> jobA(nsteps * jstride);
-    if (J.batch0_started) P_TRY(hipStreamWaitEvent(s, p->buf[0].wit_done, 0));
-    P_TRY(hipMemcpyAsync(jobA.data(), p->job_all_d, 32 * nsteps * jstride, hipMemcpyDeviceToHost, s));
-    P_TRY(hipStreamSynchronize(s));
-    p->phase_s[PH_WITNESS] += now_s() - t0; t0 = now_s();
-    host_state_chain(p, J.step_inputs, nsteps, jobA.data(), jstride, zs);
-    {
-      std::vector<Fe> zc(zs.size());
-      for (size_t i = 0; i < zs.size(); i++) zc[i] = Fe::from_mont(zs[i]);
-      P_TRY(hipMemcpyAsync(p->zs_all_d, zc.data(), 32 * zc.size(), hipMemcpyHostToDevice, s));
-      P_TRY(hipStreamSynchronize(s));
-    }
-    p->phase_s[PH_ZCHAIN] += now_s() - t0; p->phase_n[PH_ZCHAIN] += nsteps; p->phase_n[PH_WITNESS] += nsteps;
+    plan_batches(J, 0, nsteps, B);
+    J.nbatches = J.bfirst.size();
+    J.states_upto = nsteps;
+    return VIMZ_OK;
   }
-  J.tbl = p->ck->tb(0);
-  J.nbatches = (nsteps + B - 1) / B;
-  J.Bk = (nsteps + J.nbatches - 1) / J.nbatches;     // even batches (85 rows -> 43 + 42, not 64 + 21): no short tail batch
+  P_TRY(grow(p->retired, &p->priv_all_d, &p->cap_priv_all, 32 * nsteps * (size_t)p->n_priv, 32 * 1024 * (size_t)p->n_priv));
+  P_TRY(grow(p->retired, &p->zs_all_d, &p->cap_zs_all, 32 * (nsteps + 1) * (size_t)p->len_z, 32 * 1025 * (size_t)p->len_z));
+  P_TRY(grow(p->retired, &p->job_all_d, &p->cap_job_all, 32 * nsteps * jstride, 32 * 1024 * jstride));
+  P_TRY(hipMemcpyAsync(p->priv_all_d, J.step_inputs, 32 * nsteps * (size_t)p->n_priv, hipMemcpyHostToDevice, s));
+  P_TRY(hipMemsetAsync(p->job_all_d, 0, 32 * nsteps * jstride, s));
+  const bool plain = J.nA && !J.nE && !J.early_fops;           // no ahead-of-time witness pass needed (everything but crop)
+  const size_t head = start_batch0 && plain && p->head_eligible ? std::min(std::min(head_rows_wanted(), B), nsteps) : 0;
+  if (head) {
+    J.head = true;
+    plan_batches(J, 0, head, B);
+    plan_batches(J, head, nsteps - head, B);
+  } else plan_batches(J, 0, nsteps, B);
+  J.nbatches = J.bfirst.size();
+  // Both the hash-only pass and a batch's witness are one Poseidon-chain latency long (≈10 ms, whatever the row count).  For one
+  // batch — the first GPU-produced one — the chains therefore run once, WITH their wires, into its batch buffer on the producer's
+  // stream, side by side with the hash-only pass of the rows after it; fold_issue adds the rest of that batch's witness.
+  size_t hashed_from = 0;             // rows before this one get their row hashes elsewhere (host / started batch)
+  if (start_batch0 && plain) {
+    const size_t kb = head ? 1 : 0;
+    if (kb < J.nbatches) {
+      auto& bk = p->buf[kb & 1];
+      const size_t f = J.first(kb), n = J.rows(kb);
+      P_TRY(hipEventRecord(bk.wit_done, s));
+      P_TRY(hipStreamWaitEvent(p->sB, bk.wit_done, 0));
+      P_TRY(hipMemsetAsync(bk.status, 0, 4 * n, p->sB));
+      int rc = launch_witness(p, p->sB, bk.Z, bk.job_out, bk.status, p->priv_all_d + 8 * f * p->n_priv, f, n, J, false, 1);
+      if (rc) return rc;
+      P_TRY(hipMemcpyAsync(p->job_all_d + 8 * f * jstride, bk.job_out, 32 * n * jstride, hipMemcpyDeviceToDevice, p->sB));
+      P_TRY(hipEventRecord(bk.wit_done, p->sB));
+      J.started_batch = (int)kb;
+      hashed_from = f + n;
+    } else hashed_from = nsteps;
+    if (head) P_TRY(hipEventRecord(p->buf[0].wit_done, s));      // the head batch's GPU work waits for the upload of the inputs
+  }
+  // hash-only pass over the remaining rows: behind the started batch's chains on the producer's stream when there is a head batch
+  // (the main stream must stay free for the first folds), on the main stream otherwise
+  hipStream_t sh = head ? p->sB : s;
+  for (size_t off = hashed_from; off < nsteps && J.nA; off += 32768) {
+    const unsigned rows = (unsigned)std::min<size_t>(32768, nsteps - off);
+    hipLaunchKernelGGL(k_wit_chains, dim3((J.nA + 3) / 4, rows), dim3(64), 0, sh, W, 0u, (uint32_t*)nullptr, p->job_all_d + 8 * off * jstride,
+                       (const uint32_t*)(p->priv_all_d + 8 * off * p->n_priv));
+  }
+  P_TRY(hipGetLastError());
+  if (head) {
+    int rc = fold_head_batch(p, J, head);
+    if (rc) return rc;
+    J.next_issue = 1;
+    p->phase_s[PH_WITNESS] += now_s() - t0; p->phase_n[PH_WITNESS] += head;
+    J.states_upto = head;
+    if (head == nsteps) return VIMZ_OK;
+    // the states of the remaining rows: a helper thread waits for their row hashes (first those of the started batch, ready one
+    // chain latency earlier than the rest), runs the host chain and uploads the states; fold_issue_when_ready() looks at
+    // states_upto before a GPU-produced batch is issued.  (Every blocking call — the pageable download above all — lives in the
+    // helper: issued from here it held up the first fold by a whole chain latency.)
+    J.states_upto = head;
+    const size_t mid = hashed_from;           // rows [head, mid): hashed by the started batch (ev_head2); [mid, nsteps): by the hash-only pass
+    P_TRY(hipEventRecord(p->ev_hash, p->sB));
+    J.jobA_rest.resize((nsteps - head) * jstride);
+    J.helper_done = 0;
+    hipEvent_t ev_mid = J.started_batch >= 0 ? p->buf[J.started_batch & 1].wit_done : p->ev_hash;
+    J.helper = std::thread([p, &J, head, mid, nsteps, jstride, ev_mid] {
+      vimz_ctx* ctx = p->ctx;
+      auto failed = [&](const char* what, hipError_t e) { J.helper_rc = VIMZ_ERR_HIP; J.helper_err = std::string(what) + ": " + hipGetErrorString(e); J.helper_done = 1; };
+      hipError_t e = hipSetDevice(ctx->device);
+      if (e != hipSuccess) return failed("helper: hipSetDevice", e);
+      hipStream_t sx = nullptr;            // own stream: nothing of the fold is queued behind these copies
+      if ((e = hipStreamCreateWithFlags(&sx, hipStreamNonBlocking)) != hipSuccess) return failed("helper: stream", e);
+      const size_t cuts[3] = {head, mid, nsteps};
+      hipEvent_t evs[2] = {ev_mid, p->ev_hash};
+      for (int part = 0; part < 2; part++) {
+        const size_t lo = cuts[part], hi = cuts[part + 1];
+        if (hi <= lo) continue;
+        if ((e = hipEventSynchronize(evs[part])) != hipSuccess) { hipStreamDestroy(sx); return failed("helper: row hashes", e); }
+        const double t1 = now_s();
+        Fe* ja = J.jobA_rest.data() + (lo - head) * jstride;
+        if ((e = hipMemcpyAsync(ja, p->job_all_d + 8 * lo * jstride, 32 * (hi - lo) * jstride, hipMemcpyDeviceToHost, sx)) != hipSuccess ||
+            (e = hipStreamSynchronize(sx)) != hipSuccess) { hipStreamDestroy(sx); return failed("helper: download", e); }
+        host_state_chain(p, J.step_inputs + 4 * lo * (size_t)p->n_priv, hi - lo, ja, jstride, J.zs, lo);
+        std::vector<Fe> zc((hi - lo) * (size_t)p->len_z);
+        for (size_t i = 0; i < zc.size(); i++) zc[i] = Fe::from_mont(J.zs[(lo + 1) * p->len_z + i]);
+        if ((e = hipMemcpyAsync(p->zs_all_d + 8 * (lo + 1) * (size_t)p->len_z, zc.data(), 32 * zc.size(), hipMemcpyHostToDevice, sx)) != hipSuccess ||
+            (e = hipStreamSynchronize(sx)) != hipSuccess) { hipStreamDestroy(sx); return failed("helper: upload", e); }
+        p->phase_s[PH_ZCHAIN] += now_s() - t1; p->phase_n[PH_ZCHAIN] += hi - lo;
+        J.states_upto.store(hi, std::memory_order_release);
+      }
+      hipStreamDestroy(sx);
+      J.helper_done = 1;
+    });
+    return VIMZ_OK;
+  }
+  if (J.nE || J.early_fops) {
+    // Ahead-of-time pass: the IVC state of these circuits absorbs values computed from the witness (crop: the hash of the cropped
+    // row), which depend on step_in only through its predictable part (state elements that are step_in[j] + constant, e.g. the
+    // row counter).  Fill that part in, run the witness kernels up to the phase-2 chains batch by batch, keep the job outputs.
+    std::vector<Fe> zp((nsteps + 1) * p->len_z, Fe::zero());
+    for (uint32_t i = 0; i < p->len_z; i++) zp[i] = zs[i];
+    for (size_t r = 0; r < nsteps; r++)
+      for (uint32_t i = 0; i < p->len_z; i++)
+        if (b.zout[i].ref.kind == REF_ZIN) zp[(r + 1) * p->len_z + i] = Fe::add(zp[r * p->len_z + b.zout[i].ref.idx], cb::fe_from_i64(b.zout[i].add));
+    std::vector<Fe> zc(zp.size());
+    for (size_t i = 0; i < zp.size(); i++) zc[i] = Fe::from_mont(zp[i]);
+    P_TRY(hipMemcpyAsync(p->zs_all_d, zc.data(), 32 * zc.size(), hipMemcpyHostToDevice, s));
+    P_TRY(hipStreamSynchronize(s));
+    int rc;
+    for (size_t first = 0; first < nsteps; first += B) {
+      const size_t rows = std::min(B, nsteps - first);
+      P_TRY(hipMemsetAsync(p->buf[0].status, 0, 4 * rows, s));
+      if ((rc = launch_witness(p, s, p->buf[0].Z, p->job_all_d + 8 * first * jstride, p->buf[0].status, p->priv_all_d + 8 * first * p->n_priv, first, rows, J, true))) return rc;
+    }
+  }
+  std::vector<Fe> jobA(nsteps * jstride);
+  if (J.started_batch >= 0) P_TRY(hipStreamWaitEvent(s, p->buf[J.started_batch & 1].wit_done, 0));
+  P_TRY(hipMemcpyAsync(jobA.data(), p->job_all_d, 32 * nsteps * jstride, hipMemcpyDeviceToHost, s));
+  P_TRY(hipStreamSynchronize(s));
+  p->phase_s[PH_WITNESS] += now_s() - t0; t0 = now_s();
+  host_state_chain(p, J.step_inputs, nsteps, jobA.data(), jstride, zs);
+  {
+    std::vector<Fe> zc(zs.size());
+    for (size_t i = 0; i < zs.size(); i++) zc[i] = Fe::from_mont(zs[i]);
+    P_TRY(hipMemcpyAsync(p->zs_all_d, zc.data(), 32 * zc.size(), hipMemcpyHostToDevice, s));
+    P_TRY(hipStreamSynchronize(s));
+  }
+  p->phase_s[PH_ZCHAIN] += now_s() - t0; p->phase_n[PH_ZCHAIN] += nsteps; p->phase_n[PH_WITNESS] += nsteps;
+  J.states_upto = nsteps;
+  return VIMZ_OK;
+}
+
+// Hand batch k to the producer as soon as the IVC states of its rows exist (called at the top of batch k-1 and then once per row
+// until it has happened; wait = true before batch k is consumed).
+static int fold_issue_when_ready(vimz_prover* p, FoldJob& J, size_t k, bool wait) {
+  if (k >= J.nbatches || J.next_issue > k) return VIMZ_OK;
+  const size_t need = J.first(k) + J.rows(k);
+  while (J.states_upto.load(std::memory_order_acquire) < need) {
+    if (J.helper_done.load() && J.states_upto.load() < need) {       // the helper stopped early
+      if (J.helper.joinable()) J.helper.join();
+      p->ctx->err = J.helper_err.empty() ? std::string("fold: the state chain helper stopped early") : J.helper_err;
+      return J.helper_rc ? J.helper_rc : VIMZ_ERR_HIP;
+    }
+    if (!wait) return VIMZ_OK;
+    std::this_thread::yield();
+  }
+  int rc = fold_issue(p, J, k);
+  if (rc) return rc;
+  J.next_issue = k + 1;
   return VIMZ_OK;
 }
 
@@ -345,13 +618,12 @@ static int fold_prepare(vimz_prover* p, FoldJob& J, bool start_batch0 = false) {
 // (A,B,C)·z and the commitment to the step circuit's wires.  Records bb.wit_done and one event per row.
 static int fold_issue(vimz_prover* p, const FoldJob& J, size_t k) {
   vimz_ctx* ctx = p->ctx;
-  const cb::Builder& b = p->circuit->build->b;
-  const WitnessDev& W = p->wd;
   const size_t nw = p->n_wires, nc = p->n_c, sw = p->step_wires;
   auto& bb = p->buf[k & 1];
-  const size_t first = k * J.Bk, rows = std::min(J.Bk, J.nsteps - first);
+  const size_t first = J.first(k), rows = J.rows(k);
   hipStream_t sb = p->sB;
-  const bool started = k == 0 && J.batch0_started;      // (its status words already hold the decompositions' range checks)
+  if (J.head && k == 1) P_TRY(hipStreamWaitEvent(sb, p->ev_head, 0));      // (orders the two MSM workspaces' users; the head batch is long done)
+  const bool started = (int)k == J.started_batch;      // (its status words already hold the decompositions' range checks)
   if (!started) P_TRY(hipMemsetAsync(bb.status, 0, 4 * rows, sb));
   if (J.witnesses) {
     P_TRY(hipMemcpy2DAsync(bb.Z, 32 * nw, J.witnesses + 4 * first * sw, 32 * sw, 32 * sw, rows, hipMemcpyHostToDevice, sb));

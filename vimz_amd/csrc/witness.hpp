@@ -337,6 +337,25 @@ static __global__ void __launch_bounds__(64) k_wit_chains(WitnessDev P, uint32_t
   }
 }
 
+// Head batch of a fold call (prover_internal.hpp: fold_head_batch): its Poseidon jobs were evaluated on the host — a sequential
+// chain of 17 permutations is 1.1 ms on a CPU core and 10 ms on one wave — and arrive as one staging row per witness row
+// (job j's wires at [job_off[j], job_off[j+1])) plus the job outputs.  grid (jobs, rows): copy them to their wires.
+static __global__ void __launch_bounds__(128) k_wit_scatter(WitnessDev P, const uint32_t* __restrict__ job_off, const uint32_t* __restrict__ stage, uint32_t stage_row,
+                                                             const uint32_t* __restrict__ jobvals, uint32_t* __restrict__ Z, uint32_t* __restrict__ job_out) {
+  const uint32_t j = blockIdx.x, row = blockIdx.y;
+  const HashJob& J = P.jobs[j];
+  const uint32_t lo = job_off[j], cnt = job_off[j + 1] - lo;
+  const uint32_t* src = stage + 8 * ((size_t)row * stage_row + lo);
+  uint32_t* dst = Z + 8 * ((size_t)row * P.n_wires + J.wire_base);
+  for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) store_fe(dst, i, load_fe<Fr>(src, i));
+  if (threadIdx.x == 0) {
+    const size_t jr = (size_t)row * (P.n_jobs + P.n_fops) + j;
+    const Fr out = load_fe<Fr>(jobvals, jr);
+    store_fe(job_out, jr, out);
+    if (J.out_wire) store_fe(Z, (size_t)row * P.n_wires + J.out_wire, out);
+  }
+}
+
 // Field ops of one stage (early = before the phase-2 chains, 0 = after every chain), FOP_LC excepted (k_wit_fops_lc).
 static __global__ void __launch_bounds__(64) k_wit_fops(WitnessDev P, uint32_t* __restrict__ Z, uint32_t* __restrict__ job_out, uint32_t rows, uint32_t early) {
   const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;

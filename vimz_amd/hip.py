@@ -68,6 +68,7 @@ class Context:
         if rc != L.OK:
             raise L.VimzError(rc, self.lib.vimz_last_error(None).decode())
         self.h = h
+        self.device = device
 
     def _chk(self, rc):
         if rc != L.OK:
