@@ -330,7 +330,14 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="gloo")      # timing barrier / max / final gather only: the data path has no collective
+        # (gloo's C++ side prints its connection banner on stdout: keep stdout for the ONE JSON line)
+        sys.stdout.flush()
+        keep = os.dup(1); os.dup2(2, 1)
+        try:
+            dist.init_process_group(backend="gloo")      # timing barrier / max / final gather only: the data path has no collective
+            dist.barrier()
+        finally:
+            sys.stdout.flush(); os.dup2(keep, 1); os.close(keep)
     ndev = torch.cuda.device_count() if torch.cuda.is_available() else 1
     device = local_rank % max(1, ndev)            # (several ranks may share a GPU when the node has fewer GPUs than ranks)
     if torch.cuda.is_available():

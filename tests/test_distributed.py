@@ -46,6 +46,59 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _gpu_worker(rank, world, port, q):
+    """The same driver over the GPU prover (two ranks share the one GPU of the test box: own context, own streams each)."""
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from tests._oracle import from_limbs
+    from tests.test_circuits import step_inputs
+    from vimz_amd import _lib, hip
+    from vimz_amd.circuit import Circuit
+    from vimz_amd.distributed import fold_sharded
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ctx = hip.Context(0)
+    c = Circuit.for_resolution("hash", "HD")
+    ck = ctx.bases_generate(_lib.CURVE_BN254_G1, 1 << 13)
+    z0, inputs = step_inputs("hash")
+    rows = np.stack(inputs[:7])
+    p = hip.Prover(ctx, c, ck, max_batch=2)
+    res = fold_sharded(p, rows, z0, rank=rank, world=world, dist=dist)
+    if rank == 0:
+        inst = p.instance()
+        q.put((res, from_limbs(inst["z"]), inst["steps"], p.verify()))
+    dist.barrier()
+    p.close(); ck.free(); ctx.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_rank_fold_on_the_gpu_prover(oracle):
+    """world_size 2 over gloo with the GPU prover behind the driver: rank 1's segment starts at the hash-only state chain's
+    state, rank 0 gathers its exported accumulator, merges (host-side final fold) and verifies; the merged chain ends in the
+    oracle's state after all seven rows."""
+    import torch.multiprocessing as mp
+    from tests._oracle import T_HASH
+    from tests.test_circuits import step_inputs
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gpu_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res, z_final, steps, vflags = q.get(timeout=900)
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    assert res["verified"] and res["steps"] == 7 and steps == 7 and vflags == 0
+    z0, inputs = step_inputs("hash")
+    z = list(z0)
+    for i in range(7):
+        ok, z = oracle.step_eval(T_HASH, z, inputs[i])
+    assert z_final == z
+
+
 def test_two_rank_fold_merges_and_verifies(oracle):
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
