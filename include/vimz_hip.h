@@ -266,6 +266,18 @@ int vimz_ivc_profile(const vimz_ivc* v, double seconds[8], uint64_t counts[8]);
 size_t vimz_ivc_proof_size(const vimz_ivc* v);
 int vimz_ivc_proof_export(vimz_ivc* v, uint8_t* blob, size_t cap);
 int vimz_ivc_proof_import(vimz_ivc* v, const uint8_t* blob, size_t len);
+/* ---- CompressedSNARK::{setup, prove, verify} (vimz/src/nova_snark_backend/mod.rs:52-67: Spartan relaxed-R1CS SNARK with
+ *      inner-product-argument openings over both curves; README.md:196 counts it into the total proof time).  Our own statement of
+ *      the construction (vimz_amd/csrc/spartan.hip), NOT byte-compatible with nova-snark's proof object.  The proof covers the two
+ *      running instances and the last fresh secondary instance of the IVC and carries (steps, z_0, z_n). ---------------------------- */
+size_t vimz_ivc_compressed_size(vimz_ivc* v);                    /* bytes of a compressed proof for this IVC's shapes */
+/* prove: blob receives vimz_ivc_compressed_size(v) bytes; seconds (optional) = {setup (first call only), prove} */
+int vimz_ivc_compress(vimz_ivc* v, uint8_t* blob, size_t cap, double seconds[2]);
+/* verify(vk, num_steps, z0): `v` supplies the verifier key — any vimz_ivc created for the same step circuit and commitment keys;
+ * its folding state is neither read nor changed.  result: 0 = accepted; bit 0 / 1 primary / secondary chain hash; bit 2 / 3 / 4 the
+ * argument for the primary running / secondary running / last fresh secondary instance; bit 12 statement mismatch; bit 13 malformed. */
+int vimz_ivc_verify_compressed(vimz_ivc* v, const uint8_t* blob, size_t len, uint64_t num_steps, const uint64_t* z0, uint32_t* result);
+
 /* Everything an independent verifier needs, canonical little-endian 4 x u64 per element (the parity tests hand these to the
  * CPU oracle's verifier).  side 0 = primary (BN254 Fr / G1), 1 = secondary (BN254 Fq / Grumpkin).
  *   what = VIMZ_CX_{A,B,C}_{ROWPTR,COL,COEF}, VIMZ_CX_DICT_CANON : the augmented circuit's R1CS

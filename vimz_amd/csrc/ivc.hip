@@ -13,85 +13,7 @@
 //      MSM(T2) on the GPU with the same kernels instantiated for Fq / Grumpkin.
 // The challenges are the ones the circuits derive (rho = 2^128 + low 128 bits of a Poseidon hash), so the folded instances
 // the prover holds are exactly the ones the circuits compute: vimz_ivc_verify checks that.
-#include "prover_internal.hpp"
-#include <type_traits>
-#include <cstdio>
-#include <cstdlib>
-#include "aug/export.hpp"
-
-using namespace vz::aug;
-typedef Affine<Fe> G2Aff;          // Grumpkin point: coordinates in BN254 Fr
-typedef XYZZ<Fe> G2;
-
-namespace {
-
-struct SecDev {                    // secondary circuit on the device (field BN254 Fq, commitments on Grumpkin)
-  CsrDev A{}, B{}, C{};
-  const uint32_t* dict = nullptr;
-  const uint32_t* long_items = nullptr; uint32_t n_long = 0, n_med = 0;
-  uint32_t n_w = 0, n_c = 0;
-  uint32_t *Zrun = nullptr, *E = nullptr, *AZ = nullptr, *BZ = nullptr, *CZ = nullptr;   // running instance
-  uint32_t *z2 = nullptr, *az2 = nullptr, *bz2 = nullptr, *cz2 = nullptr, *T = nullptr;  // fresh instance, cross term
-  uint32_t* bad = nullptr;
-};
-
-template <class To, class From>
-To cross_field(const From& m) {     // the same integer (< both primes) as an element of the other field
-  From c = From::from_mont(m);
-  To t; for (int k = 0; k < 8; k++) t.v[k] = c.v[k];
-  return To::to_mont(t);
-}
-template <class F>
-F rho_element(const uint32_t low[4]) { F c = F::zero(); for (int k = 0; k < 4; k++) c.v[k] = low[k]; c.v[4] = 1; return F::to_mont(c); }
-
-template <class F>
-void sec_spmv(const SecDev& S, hipStream_t s, const uint32_t* z, uint32_t* az, uint32_t* bz, uint32_t* cz) {
-  hipLaunchKernelGGL(k_spmv3<F>, dim3(stream_grid(3 * (size_t)S.n_c)), dim3(256), 0, s, S.A, S.B, S.C, S.dict, (size_t)S.n_c, z, az, bz, cz);
-  if (S.n_long) {
-    hipLaunchKernelGGL(k_spmv_long<F>, dim3(spmv_long_blocks(S.n_long, S.n_med)), dim3(256), 0, s, S.A, S.B, S.C, S.dict, S.long_items, S.n_long, S.n_med, z, az, bz, cz);
-  }
-}
-
-}  // namespace
-
-enum { IP_SYNTH1 = 0, IP_SYNTH2, IP_WAIT_SEC, IP_WAIT_PRI, IP_LAUNCH, IP_PRODUCER, IP_RESERVED, IP_TOTAL, IP_COUNT };
-
-struct vimz_ivc {
-  vimz_ctx* ctx = nullptr;
-  std::unique_ptr<vimz_circuit> circ1;            // the step circuit's copy, with the verifier circuit appended
-  std::unique_ptr<AugCircuit<BnFr>> c1;
-  AugCircuit<BnFq> c2;
-  vimz_prover* pri = nullptr;
-  const vimz_bases *ck1 = nullptr, *ck2 = nullptr;
-  SecDev sec;
-  std::vector<void*> owned;
-  char* pin = nullptr;                            // pinned: 5 MSM results, then staging for the two host-made witnesses
-  size_t pin_res = 0, pin_totals = 0;
-  MsmPlan plan_aug{}, plan_T1{}, plan_T1v{}, plan_W2{}, plan_T2{};
-  // the witness commitment and the cross-term commitment of one instance are independent: they run side by side
-  hipStream_t s2 = nullptr; hipEvent_t ev_fork = nullptr; MsmWorkspace ws2;
-  // the step rows of the primary cross term need the folded running instance and the producer's products only — not the
-  // verifier circuit of their step: they are queued on a third stream right behind the previous fold and run under the
-  // secondary half of that step and the host's verifier circuit
-  hipStream_t s3 = nullptr; hipEvent_t ev_fold = nullptr; MsmWorkspace ws3;
-  bool t1_step_pending = false;
-  hipEvent_t ev_b0 = nullptr, ev_b1 = nullptr;   // profiling: GPU time of the secondary half on the main stream
-  hipEvent_t ev_a = nullptr;                      // the primary half's results on the main stream are back
-  // window tables (2^(7w)·P_i) of the three base slices the per-step small MSMs run over: verifier wires and verifier rows of
-  // ck1, the head of ck2.  Their window sums only need adding: no 254 doublings on the host per commitment (23 MB each)
-  BaseTables tb_aug{}, tb_T1v{}, tb_ck2{};
-  // host state of the recursion
-  uint64_t i = 0;
-  std::vector<Fe> z0;                             // the initial state the chain starts from (absorbed by every instance hash)
-  std::vector<Fq> z0_sec{Fq::zero()};             // the secondary's trivial step circuit starts from [0]
-  RelaxedInst<Fe> U2;       // running secondary instance (commitments on Grumpkin), as the primary circuit sees it
-  RelaxedInst<Fq> U1;       // running primary instance (commitments on BN254 G1), as the secondary circuit sees it
-  FreshInst<Fe> u2;         // last fresh secondary instance
-  G2Aff T2;                 // commitment to the cross term of (U2, u2)
-  Fe u1_run = Fe::zero(); Fq u2_run = Fq::zero();   // the running scalars in the fields their vectors live in
-  bool pending_sec = false, sec_T_valid = false;
-  double ph_s[IP_COUNT] = {}; uint64_t ph_n[IP_COUNT] = {};
-};
+#include "ivc_internal.hpp"
 
 namespace {
 
@@ -371,6 +293,7 @@ extern "C" {
 
 void vimz_ivc_free(vimz_ivc* v) {
   if (!v) return;
+  if (v->spartan_free) v->spartan_free(v);
   if (v->pri) vimz_prover_free(v->pri);
   if (v->ctx) {
     std::lock_guard<std::mutex> g(v->ctx->mu);

@@ -5,6 +5,7 @@ same function names, argument meaning and error behaviour, driving the GPU throu
     prepare_folding (folding.rs:20-25)  load_r1cs + create_public_params -> (circuit, FoldingParams)
     fold_input      (folding.rs:27-43)  create_recursive_circuit -> FoldingProof
     verify_folded_proof (folding.rs:45-56)
+    compress_proof / verify_compressed_proof (mod.rs:52-67)  CompressedSNARK::{setup, prove, verify}
 """
 import time
 
@@ -156,3 +157,19 @@ def verify_folded_proof(proof, params, num_steps, initial_state):
     r = proof.prover.verify()
     if r != 0:
         raise _lib.VimzError(_lib.ERR_UNSAT, f"Failed to verify folded proof (flags {r:#x})")
+
+
+def compress_proof(params, proof):
+    """CompressedSNARK::setup + prove (vimz/src/nova_snark_backend/mod.rs:52-59; spans "Prepare compression" / "Compress proof").
+    Returns (proof bytes, timings)."""
+    if proof.mode != "ivc":
+        raise _lib.VimzError(_lib.ERR_INVALID, "Failed to compress proof: only a RecursiveSNARK (mode \"ivc\") can be compressed")
+    return proof.prover.compress()
+
+
+def verify_compressed_proof(verifier_key, compressed, num_steps, initial_state):
+    """compressed_proof.verify(&vk, num_steps, initial_state, secondary_initial_state) (mod.rs:63-67).  verifier_key: an IVC object
+    created for the same step circuit and keys (e.g. proof.prover, or a fresh hip.IVC in another process)."""
+    r = verifier_key.verify_compressed(compressed, num_steps, initial_state)
+    if r != 0:
+        raise _lib.VimzError(_lib.ERR_UNSAT, f"Failed to verify proof (flags {r:#x})")

@@ -433,6 +433,31 @@ class IVC:
         b = np.ascontiguousarray(blob, dtype=np.uint8)
         self.ctx._chk(lib.vimz_ivc_proof_import(self.h, _ptr(b), b.size))
 
+    def compress(self):
+        """CompressedSNARK::prove: returns (proof bytes as uint8 array, {"setup_s", "prove_s"})."""
+        lib = self.ctx.lib
+        lib.vimz_ivc_compressed_size.argtypes = [C.c_void_p]
+        lib.vimz_ivc_compressed_size.restype = C.c_size_t
+        lib.vimz_ivc_compress.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_double)]
+        n = lib.vimz_ivc_compressed_size(self.h)
+        buf = np.zeros(n, dtype=np.uint8)
+        sec = (C.c_double * 2)()
+        self.ctx._chk(lib.vimz_ivc_compress(self.h, _ptr(buf), n, sec))
+        return buf, {"setup_s": sec[0], "prove_s": sec[1]}
+
+    def verify_compressed(self, blob, num_steps, z0):
+        """CompressedSNARK::verify(vk, num_steps, z0): 0 = accepted.  This IVC object only supplies the verifier key."""
+        lib = self.ctx.lib
+        lib.vimz_ivc_verify_compressed.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint32)]
+        b = np.ascontiguousarray(blob, dtype=np.uint8)
+        z = np.zeros((self.circuit.len_z, 4), dtype=np.uint64)
+        for i, v in enumerate(z0):
+            for k in range(4):
+                z[i, k] = (int(v) >> (64 * k)) & 0xFFFFFFFFFFFFFFFF
+        r = C.c_uint32()
+        self.ctx._chk(lib.vimz_ivc_verify_compressed(self.h, _ptr(b), b.size, int(num_steps), _ptr(z), C.byref(r)))
+        return r.value
+
     def export(self, side, what):
         """(n, 4) uint64 canonical elements."""
         return _export(self.ctx.lib.vimz_ivc_export, self.h, side, what).view(np.uint64).reshape(-1, 4)
