@@ -7,6 +7,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <cstdio>
 #include <cstring>
 #include <functional>
 #include <memory>
@@ -92,7 +93,8 @@ struct HostPool {
     cv.notify_all();
     drain();
     lk.lock();
-    cv_done.wait(lk, [&] { return done == n; });
+    while (!cv_done.wait_for(lk, std::chrono::seconds(10), [&] { return done == n; }))
+      fprintf(stderr, "[vimz] host pool: %zu of %zu tasks done after 10 s (next %zu, active workers %zu)\n", done, n, next.load(), active);
   }
 };
 
@@ -599,6 +601,7 @@ static int fold_prepare(vimz_prover* p, FoldJob& J, bool start_batch0 = false) {
 static int fold_issue_when_ready(vimz_prover* p, FoldJob& J, size_t k, bool wait) {
   if (k >= J.nbatches || J.next_issue > k) return VIMZ_OK;
   const size_t need = J.first(k) + J.rows(k);
+  const double t_wait = now_s(); uint64_t spins = 0;
   while (J.states_upto.load(std::memory_order_acquire) < need) {
     if (J.helper_done.load() && J.states_upto.load() < need) {       // the helper stopped early
       if (J.helper.joinable()) J.helper.join();
@@ -607,6 +610,11 @@ static int fold_issue_when_ready(vimz_prover* p, FoldJob& J, size_t k, bool wait
     }
     if (!wait) return VIMZ_OK;
     std::this_thread::yield();
+    if ((++spins & 0xfffff) == 0 && now_s() - t_wait > 10.0) {      // a stuck helper must not hang the caller silently
+      fprintf(stderr, "[vimz] fold: waiting for the IVC states of batch %zu for %.0f s (states for %zu rows, need %zu, helper done %d)\n", k, now_s() - t_wait,
+              J.states_upto.load(), need, J.helper_done.load());
+      if (now_s() - t_wait > 120.0) return vz_fail(p->ctx, VIMZ_ERR_HIP, "fold: the state chain helper did not finish within 120 s");
+    }
   }
   int rc = fold_issue(p, J, k);
   if (rc) return rc;
