@@ -45,11 +45,19 @@ def main():
         ok = all(v.verify(len(r), z) == 0 for v, r, z in segs) and segs[0][2] == list(z0)
         spans["Verify folded proof"] = time.time() - t0
         n = sum(v.state()[1] for v in ivcs)
+        if S == 1:      # the reference's remaining spans (vimz/src/nova_snark_backend/mod.rs:52-67): one RecursiveSNARK -> CompressedSNARK
+            blob, tc = ivcs[0].compress()
+            spans["Prepare compression"] = tc["setup_s"]
+            spans["Compress proof"] = tc["prove_s"]
+            t0 = time.time()
+            ok = ok and ivcs[0].verify_compressed(blob, len(rows), z0) == 0
+            spans["Verify compressed proof"] = time.time() - t0
+            spans["compressed proof bytes"] = int(len(blob))
         if save:
             for k, v in enumerate(ivcs):
                 v.proof_export().tofile(f"{save}.{k}.bin")      # verify elsewhere: tools/verify_proof.py
         print(json.dumps({"config": f"{t}_step_{res}", "mode": "ivc", "steps": n, "segment_proofs": S, "verified": ok, "spans_s": spans,
-                          "steps_per_s": n / spans["Fold input"], "total_s": sum(spans.values()),
+                          "steps_per_s": n / spans["Fold input"], "total_s": sum(v for k, v in spans.items() if not k.endswith("bytes")),
                           "final_state": [hex(z) for z in ivcs[-1].state()[0]]}))
         return
     provers = [hip.Prover(c, circuit, params.ck, max_batch=64 if res == "HD" else 32) for c in ctxs]
