@@ -11,7 +11,7 @@ namespace vz { namespace aug { double g_t[16]; const char* g_n[16]; } }
 int main() {
   typedef BnFq FP; typedef Fp<FP> F;
   AugCircuit<FP> c; c.init_trivial_step(); c.finish(false);
-  AugIn<FP> in; in.pz = f_from_u64<F>(5); in.i = 0;
+  AugIn<FP> in; in.digest = f_from_u64<F>(5); in.z0.push_back(F::zero()); in.i = 0;
   in.U = RelaxedInst<F>::zero(); in.u = FreshInst<F>::zero(); in.T.x = in.T.y = F::zero();
   // fresh instance: some point on G1 (commitments the secondary folds live on BN254 G1: y^2 = x^3 + 3): use G = (1,2)
   in.u.W.x = f_from_u64<F>(1); in.u.W.y = f_from_u64<F>(2);
