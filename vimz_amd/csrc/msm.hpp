@@ -223,7 +223,7 @@ __global__ void __launch_bounds__(SORT_THREADS) k_scatter_lds(const uint32_t* __
 }
 
 template <class F>
-__global__ void __launch_bounds__(256) k_accum(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
+__global__ void __launch_bounds__(256, 3) k_accum(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
                                                const uint32_t* __restrict__ bucket_off, const uint32_t* __restrict__ sub_off,
                                                uint32_t nb, const uint32_t* __restrict__ totals,
                                                uint32_t* __restrict__ partial, uint32_t sub) {
