@@ -90,6 +90,14 @@ int vimz_bases_precompute(vimz_ctx* ctx, vimz_bases* b, int window_bits);
 size_t vimz_bases_len(const vimz_bases* b);
 void vimz_bases_free(vimz_ctx* ctx, vimz_bases* b);
 
+/* ---- input pipeline: pixel packing on the device (replaces pyvimz's compress_by_rows / compress_by_blocks,
+ *      pyvimz/pyvimz/img/ops.py:4-70, whose hex strings `VIMzInput` carries, vimz/src/input.rs:9-62).  pixels: height x width x
+ *      channels bytes (channels 3 = RGB, 1 = grey).  block = 0: one output row of ceil(width/10) elements per image row;
+ *      block = 40: 40 x 40 blocks of 160 elements, blocks row-major (the redact input).  out: vimz_pack_count(...) canonical
+ *      elements (4 x u64 each). ---------------------------------------------------------------------------------------------- */
+size_t vimz_pack_count(size_t height, size_t width, int block);
+int vimz_pack_pixels(vimz_ctx* ctx, const uint8_t* pixels, size_t height, size_t width, int channels, int block, uint64_t* out);
+
 /* ---- device vectors -------------------------------------------------------------------------------- */
 int vimz_vec_alloc(vimz_ctx* ctx, int field, size_t n, vimz_vec** out); /* zero-filled */
 int vimz_vec_upload(vimz_ctx* ctx, vimz_vec* v, size_t offset, const uint64_t* host, size_t n, int form);

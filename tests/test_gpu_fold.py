@@ -455,3 +455,19 @@ def test_largest_single_gpu_config_contrast_4k(oracle):
         assert from_limbs(P.instance()["z"]) == z
     finally:
         P.close(); key.free(); cx.close()
+
+
+def test_pixel_packing_on_the_device_matches_the_image_editor(ctx):
+    """vimz_pack_pixels == our restatement of pyvimz's compress_by_rows / compress_by_blocks (itself pinned on fixtures minted by
+    importing pyvimz, tests/test_oracle_golden.py) on the reference's sample images, RGB and grey, incl. a width that is not a
+    multiple of ten."""
+    from tests import _data
+    from vimz_amd import image_editor as ie
+    img = _data.load_image("img1")
+    assert np.array_equal(ctx.pack_pixels(img), ie.compress_by_rows(img))
+    grey = ie.convert_to_grayscale(img)
+    assert np.array_equal(ctx.pack_pixels(grey), ie.compress_by_rows(grey))
+    odd = img[:37, :1003]
+    assert np.array_equal(ctx.pack_pixels(odd), ie.compress_by_rows(odd))
+    assert np.array_equal(ctx.pack_pixels(img, block=40), ie.compress_by_blocks(img))
+    assert ctx.pack_pixels(img).shape == (720, 128, 4)

@@ -101,6 +101,38 @@ static int msm_device(vimz_ctx* c, const vimz_bases* bases, size_t base_offset, 
   return vz::vz_msm_device(c, bases, base_offset, d_scalars, n, scalars_mont, window_bits, out_xy, out_form);
 }
 
+// Input pipeline: packing of pixels into field elements on the device — ten pixels per element, pixel k in
+// bits [24k, 24k + 24) with R in the low byte (a grey value alone in the low byte), rows padded with zero pixels: what
+// pyvimz/pyvimz/img/ops.py:4-33 (compress_by_rows) and :36-70 (compress_by_blocks, 40 x 40 blocks -> 160 elements) produce as hex
+// strings.  One thread per packed element; the output is canonical little-endian limbs, i.e. the 30 pixel bytes followed by two zeros.
+static __global__ void __launch_bounds__(256) k_pack_pixels(const uint8_t* __restrict__ px, uint32_t h, uint32_t w, uint32_t ch, uint32_t block,
+                                                            uint32_t n_out, uint32_t* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_out) return;
+  uint32_t row, col0, run;       // first pixel of this element and how many pixels of the row / block row are left
+  if (!block) {
+    const uint32_t per = (w + 9) / 10;
+    row = i / per; col0 = (i % per) * 10; run = w - col0;
+  } else {
+    const uint32_t bw = (w + block - 1) / block, per_row = (block + 9) / 10, per_blk = block * per_row;
+    const uint32_t b = i / per_blk, e = i % per_blk, br = b / bw, bc = b % bw, r = e / per_row, c = e % per_row;
+    row = br * block + r; col0 = bc * block + c * 10;
+    const uint32_t end = min(w, (bc + 1) * block);
+    run = row < h && col0 < end ? end - col0 : 0;
+  }
+  uint32_t words[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const uint32_t np = run < 10 ? run : 10;
+  for (uint32_t k = 0; k < np; k++)
+    for (uint32_t c = 0; c < 3; c++) {
+      const uint32_t v = c < ch ? px[((size_t)row * w + col0 + k) * ch + c] : 0u;
+      const uint32_t byte = 3 * k + c;
+      words[byte >> 2] |= v << (8 * (byte & 3));
+    }
+  uint4* o = reinterpret_cast<uint4*>(out + 8 * (size_t)i);
+  o[0] = make_uint4(words[0], words[1], words[2], words[3]);
+  o[1] = make_uint4(words[4], words[5], words[6], words[7]);
+}
+
 extern "C" {
 
 const char* vimz_version(void) { return "vimz-hip 0.1 (gfx950)"; }
@@ -148,6 +180,29 @@ int vimz_device_info(vimz_ctx* c, char* name, size_t name_len, int* cus, uint64_
   if (name && name_len) { snprintf(name, name_len, "%s (%s)", p.name, p.gcnArchName); }
   if (cus) *cus = p.multiProcessorCount;
   if (hbm_bytes) *hbm_bytes = p.totalGlobalMem;
+  return VIMZ_OK;
+}
+
+size_t vimz_pack_count(size_t height, size_t width, int block) {
+  if (!block) return height * ((width + 9) / 10);
+  const size_t b = (size_t)block;
+  return ((height + b - 1) / b) * ((width + b - 1) / b) * b * ((b + 9) / 10);
+}
+int vimz_pack_pixels(vimz_ctx* c, const uint8_t* pixels, size_t height, size_t width, int channels, int block, uint64_t* out) {
+  if (!c || !pixels || !out || !height || !width || (channels != 1 && channels != 3) || block < 0 || height * width > (1ull << 31))
+    return fail(c, VIMZ_ERR_INVALID, "vimz_pack_pixels: bad argument");
+  const size_t n = vimz_pack_count(height, width, block), in_bytes = height * width * (size_t)channels;
+  std::lock_guard<std::mutex> g(c->mu);
+  HIP_TRY(c, hipSetDevice(c->device));
+  int rc = ensure_scratch(c, 32 * n + in_bytes + 64);
+  if (rc) return rc;
+  uint8_t* d_in = (uint8_t*)c->scratch + 32 * n;
+  HIP_TRY(c, hipMemcpyAsync(d_in, pixels, in_bytes, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_pack_pixels, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const uint8_t*)d_in, (uint32_t)height, (uint32_t)width,
+                     (uint32_t)channels, (uint32_t)block, (uint32_t)n, (uint32_t*)c->scratch);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(out, c->scratch, 32 * n, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
   return VIMZ_OK;
 }
 

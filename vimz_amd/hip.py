@@ -143,6 +143,27 @@ class Context:
         v = self.vec_alloc(field, host.size // 4)
         return v.upload(host, 0, form)
 
+    # ---- input pipeline
+    def pack_pixels(self, image, block=0):
+        """compress_by_rows (block = 0) / compress_by_blocks (block = 40) of pyvimz on the device: (H, W[, 3]) uint8 ->
+        (H, ceil(W/10), 4) or (blocks, block*block/10, 4) uint64 limbs."""
+        img = np.ascontiguousarray(image, dtype=np.uint8)
+        if img.ndim == 3 and img.shape[2] > 3:
+            img = np.ascontiguousarray(img[:, :, :3])
+        h, w = img.shape[:2]
+        ch = 1 if img.ndim == 2 else 3
+        lib = self.lib
+        lib.vimz_pack_count.argtypes = [C.c_size_t, C.c_size_t, C.c_int]
+        lib.vimz_pack_count.restype = C.c_size_t
+        lib.vimz_pack_pixels.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
+        n = lib.vimz_pack_count(h, w, block)
+        out = np.zeros((n, 4), dtype=np.uint64)
+        self._chk(lib.vimz_pack_pixels(self.h, _ptr(img), h, w, ch, block, _ptr(out)))
+        if block:
+            per = block * ((block + 9) // 10)
+            return out.reshape(-1, per, 4)
+        return out.reshape(h, -1, 4)
+
     # ---- MSM
     def msm(self, bases, scalars, form=L.FORM_CANONICAL, window_bits=0, out_form=L.FORM_CANONICAL):
         scalars = _u64(scalars)
