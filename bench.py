@@ -119,6 +119,14 @@ def main_ivc(args, rank, world, dist, torch, ctxs, circuit, params, steps_all, g
     per_proof = w_each + 2 * k_each
     ck2 = params.secondary_key()
     ivcs = [hip.IVC(c, circuit, params.ck, ck2, max_batch=args.batch) for c in ctxs]
+    helper_ctxs, helper_keys = [], []
+    for hidx in range(args.msm_helpers):      # one proof on several GPUs — the large MSM(T) split by base range
+        ndev = max(1, torch.cuda.device_count())
+        dev = (ctxs[0].device + 1 + hidx) % ndev
+        hc = hip.Context(dev)
+        hk = params.ck if dev == ctxs[0].device else hc.bases_generate(_lib.CURVE_BN254_G1, params.ck.n)
+        ivcs[0].add_msm_helper(hc, hk)
+        helper_ctxs.append(hc); helper_keys.append(hk)
     # state at which each proof's row segment starts (hash-only chain over the rows before it)
     starts = []
     for s_ in range(S):
@@ -272,7 +280,7 @@ def main_ivc(args, rank, world, dist, torch, ctxs, circuit, params, steps_all, g
             "config": {"workload": f"{args.transformation}_step_{args.resolution}", "mode": "ivc (augmented circuits on BN254/Grumpkin: RecursiveSNARK::prove_step in full)",
                        "constraints": n_c, "wires": n_w, "nnz": nnz, "step_circuit_constraints": info["step_constraints"], "step_circuit_wires": info["step_wires"],
                        "secondary_constraints": n_c2, "secondary_wires": n_w2,
-                       "rows_per_rank": timed_rows, "proofs_per_gpu": S, "witness_batch": args.batch,
+                       "rows_per_rank": timed_rows, "proofs_per_gpu": S, "witness_batch": args.batch, "msm_helper_contexts": args.msm_helpers,
                        "parallelism": (f"proof set {args.proof_set}: rank r proves proof_set[r % len]; independent proofs, replicas only" if args.proof_set else
                                        ("one IVC proof per GPU" if S == 1 else f"{S} IVC proofs of contiguous row segments per GPU, folded concurrently") +
                                        ("" if world == 1 else f"; {world} GPUs prove {world * S} contiguous row segments of the image independently (boundary states chain), no data-path collective"))},
@@ -329,6 +337,8 @@ def main():
     ap.add_argument("--segments", type=int, default=0, help="proofs / row segments folded concurrently on each GPU, own context + streams each (default: 1 IVC proof, 2 accumulators)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--msm-helpers", type=int, default=0, help="IVC mode: split every step's large MSM(T) by base range over this many helper contexts "
+                    "(devices after this rank's, wrapping around; on a one-GPU box they share the device): one proof on several GPUs, SURVEY.md §8e")
     ap.add_argument("--no-compress", action="store_true", help="skip CompressedSNARK::prove / verify of the folded proof")
     ap.add_argument("--no-extras", action="store_true", help="skip the three-concurrent-proofs extra of the default IVC run")
     ap.add_argument("--mode", default="ivc", choices=["ivc", "accumulator"])

@@ -249,6 +249,10 @@ int vimz_ivc_create(vimz_ctx* ctx, const vimz_circuit* step_circuit, const vimz_
                     size_t max_batch, vimz_ivc** out);
 void vimz_ivc_free(vimz_ivc* v);
 int vimz_ivc_reset(vimz_ivc* v, const uint64_t* z0);
+/* One proof on several GPUs: every step's large cross-term commitment MSM(T) is split by base range between this
+ * IVC's GPU and the registered helpers (at most 7); each returns one partial point, the host adds them.  helper_ctx: a context on
+ * another device; ck_on_helper: a replica of ck_primary resident there (same generators).  The proof is unchanged. */
+int vimz_ivc_add_msm_helper(vimz_ivc* v, vimz_ctx* helper_ctx, const vimz_bases* ck_on_helper);
 /* same inputs as vimz_prover_fold / vimz_prover_fold_witness */
 int vimz_ivc_fold(vimz_ivc* v, const uint64_t* step_inputs, size_t nsteps);
 int vimz_ivc_fold_witness(vimz_ivc* v, const uint64_t* witnesses, size_t nsteps);

@@ -252,6 +252,32 @@ def test_proof_export_import_verifies_elsewhere_and_resumes(ctx, keys, oracle):
         a.close(); b.close(); ref.close()
 
 
+def test_large_msm_split_over_helper_contexts_gives_the_same_proof(ctx, keys):
+    """SURVEY.md §8e single-proof multi-GPU: the step's large MSM(T) split by base range over two helper contexts (on a one-GPU box:
+    two more contexts of the same device, each with its own stream and workspace; on a node: other devices with key replicas) —
+    partial commitments added on the host.  The proof is bit-identical to the unsplit one."""
+    from vimz_amd import hip
+    ck1, ck2 = keys
+    c = Circuit.for_resolution("grayscale", "HD")
+    z0, inputs = step_inputs("grayscale")
+    steps = np.stack(inputs)
+    helpers = [hip.Context(0), hip.Context(0)]
+    a, b = hip.IVC(ctx, c, ck1, ck2, max_batch=4), hip.IVC(ctx, c, ck1, ck2, max_batch=4)
+    try:
+        for h in helpers:
+            b.add_msm_helper(h, ck1)
+        a.reset(z0); a.fold(steps)
+        b.reset(z0); b.fold(steps[:4]); b.fold(steps[4:])
+        assert a.verify(10, z0) == 0 and b.verify(10, z0) == 0
+        for side in (0, 1):
+            assert (a.export(side, hip.IX_INSTANCE) == b.export(side, hip.IX_INSTANCE)).all()
+        assert (a.export(1, hip.IX_FRESH_INSTANCE) == b.export(1, hip.IX_FRESH_INSTANCE)).all()
+    finally:
+        a.close(); b.close()
+        for h in helpers:
+            h.close()
+
+
 def test_concurrent_provers_all_verify(oracle):
     """Four IVC provers on their own contexts fold concurrently from four host threads, several times over from a fresh state
     (the first step after creation used to be the fragile one: a null-stream fill could land after the first kernel's writes)."""

@@ -75,7 +75,24 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
     hipLaunchKernelGGL(k_cross_term<Fr>, dim3(stream_grid(sc)), dim3(256), 0, v->s3, sc, p->AZ, p->BZ, p->CZ, v->u1_run,
                        b2.az + 8 * row * nc, b2.bz + 8 * row * nc, b2.cz + 8 * row * nc, Fe::one(), p->T);
     P_TRY(hipGetLastError());
-    P_TRY(msm_launch<BnG1>(v->s3, v->ws3, p->ck->d, p->T, sc, 1, 0, v->pin + v->pin_res, &v->plan_T1, ctx->profiling ? ctx->ev : nullptr, 0, p->ck->tables ? &job.tbl : nullptr));
+    // base-range split: the first share stays here, helper h commits to rows [off_h, off_h + n_h) with its replica of the key
+    const size_t parts = v->helpers.size() + 1, share = (sc + parts - 1) / parts;
+    v->t1_main_n = std::min(share, sc);
+    if (!v->helpers.empty()) {
+      P_TRY(hipEventRecord(v->ev_T, v->s3));
+      size_t off = v->t1_main_n;
+      for (auto& h : v->helpers) {
+        h.off = off; h.n = off < sc ? std::min(share, sc - off) : 0; off += h.n;
+        if (!h.n) continue;
+        P_TRY(hipSetDevice(h.ctx->device));
+        P_TRY(hipStreamWaitEvent(h.s, v->ev_T, 0));
+        P_TRY(hipMemcpyAsync(h.T, p->T + 8 * h.off, 32 * h.n, hipMemcpyDefault, h.s));
+        P_TRY(msm_launch<BnG1>(h.s, h.ws, h.ck->d + (size_t)AFFINE_WORDS * h.off, h.T, h.n, 1, 0, h.pin, &h.plan, nullptr, 0, nullptr));
+      }
+      P_TRY(hipSetDevice(ctx->device));
+    }
+    P_TRY(msm_launch<BnG1>(v->s3, v->ws3, p->ck->d, p->T, v->t1_main_n, 1, 0, v->pin + v->pin_res, &v->plan_T1, ctx->profiling ? ctx->ev : nullptr, 0,
+                           p->ck->tables && v->helpers.empty() ? &job.tbl : nullptr));
     if (ctx->profiling) P_TRY(hipMemcpyAsync(v->pin + v->pin_totals, v->ws3.totals, 8, hipMemcpyDeviceToHost, v->s3));   // (pinned: stays asynchronous)
     v->t1_step_pending = true;
     return VIMZ_OK;
@@ -157,7 +174,18 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
         hipError_t q = wait ? hipStreamSynchronize(v->s3) : hipStreamQuery(v->s3);
         if (q == hipErrorNotReady) return hipSuccess;
         if (q != hipSuccess) return q;
+        for (auto& h : v->helpers) {
+          if (!h.n) continue;
+          q = wait ? hipStreamSynchronize(h.s) : hipStreamQuery(h.s);
+          if (q == hipErrorNotReady) return hipSuccess;
+          if (q != hipSuccess) return q;
+        }
         T1_step = msm_finish<BnG1>(v->plan_T1, v->pin + v->pin_res);
+        if (!v->helpers.empty()) {                      // host-side sum of the partial commitments (<= 8 points)
+          G1 acc = from_affine(T1_step);
+          for (auto& h : v->helpers) if (h.n) { const G1Aff part = msm_finish<BnG1>(h.plan, h.pin); add_mixed(acc, part); }
+          T1_step = to_affine(acc);
+        }
         t1_step_done = true; v->t1_step_pending = false;
         return hipSuccess;
       };
@@ -214,7 +242,7 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
         for (int q = 0; q < 6; q++) { P_TRY(hipEventElapsedTime(&ms[q], ctx->ev[q], ctx->ev[q + 1])); ctx->last_msm.ms[q] = ms[q]; ctx->msm_tot_ms[q] += ms[q]; }
         memcpy(&ctx->last_msm.subs, v->pin + v->pin_totals, 8);
         ctx->last_msm.c = v->plan_T1.c; ctx->last_msm.K = v->plan_T1.K;
-        ctx->msm_tot_calls++; ctx->msm_tot_points += sc; ctx->msm_tot_entries += ctx->last_msm.entries;
+        ctx->msm_tot_calls++; ctx->msm_tot_points += v->t1_main_n; ctx->msm_tot_entries += ctx->last_msm.entries;
       }
       // ---- 4. secondary verifier circuit on the host: folds (U1, u1) ---------------------------------------------------------------------
       AugIn<BnFq> in2; in2.digest = v->c2.digest; in2.z0 = v->z0_sec; in2.i = i; in2.U = v->U1; in2.u = u1; in2.T = T1;
@@ -306,6 +334,15 @@ void vimz_ivc_free(vimz_ivc* v) {
     if (v->ev_b0) hipEventDestroy(v->ev_b0);
     if (v->ev_b1) hipEventDestroy(v->ev_b1);
     if (v->ev_a) hipEventDestroy(v->ev_a);
+    if (v->ev_T) hipEventDestroy(v->ev_T);
+    for (auto& h : v->helpers) {
+      hipSetDevice(h.ctx->device);
+      if (h.s) { hipStreamSynchronize(h.s); hipStreamDestroy(h.s); }
+      h.ws.release();
+      hipFree(h.T);
+      if (h.pin) hipHostFree(h.pin);
+    }
+    hipSetDevice(v->ctx->device);
     v->ws2.release(); v->ws3.release();
     for (void* d : v->owned) hipFree(d);
     if (v->pin) hipHostFree(v->pin);
@@ -397,6 +434,27 @@ int vimz_ivc_create(vimz_ctx* ctx, const vimz_circuit* step_circuit, const vimz_
   v->z0.assign(v->c1->len_z, Fe::zero());
   v->U1 = RelaxedInst<Fq>::zero(); v->U2 = RelaxedInst<Fe>::zero(); v->u2 = FreshInst<Fe>::zero(); v->T2.x = v->T2.y = Fe::zero();
   *out = v.release();
+  return VIMZ_OK;
+}
+
+// A helper GPU for the large cross-term commitment of every step.  helper_ctx: a context on another device (or,
+// for tests on a one-GPU box, a second context on the same device); ck_on_helper: a replica of ck_primary resident there.
+int vimz_ivc_add_msm_helper(vimz_ivc* v, vimz_ctx* helper_ctx, const vimz_bases* ck_on_helper) {
+  if (!v || !helper_ctx || !ck_on_helper) return VIMZ_ERR_INVALID;
+  vimz_ctx* ctx = v->ctx;
+  if (ck_on_helper->curve != VIMZ_CURVE_BN254_G1 || ck_on_helper->n < v->ck1->n) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_ivc_add_msm_helper: the helper's key must be a replica of ck_primary");
+  if (v->helpers.size() >= 7) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_ivc_add_msm_helper: at most seven helpers");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  vimz_ivc::MsmHelper h; h.ctx = helper_ctx; h.ck = ck_on_helper;
+  P_TRY(hipSetDevice(helper_ctx->device));
+  int lo = 0, hi = 0; hipDeviceGetStreamPriorityRange(&lo, &hi);
+  P_TRY(hipStreamCreateWithPriority(&h.s, hipStreamNonBlocking, (lo + hi) / 2));
+  P_TRY(hipMalloc((void**)&h.T, 32 * (size_t)v->pri->step_c));
+  P_TRY(hipHostMalloc(&h.pin, 4 * (size_t)XYZZ_WORDS * MSM_MAX_WINDOWS));
+  if (helper_ctx->device != ctx->device) { int can = 0; hipDeviceCanAccessPeer(&can, helper_ctx->device, ctx->device); if (can) hipDeviceEnablePeerAccess(ctx->device, 0); }
+  P_TRY(hipSetDevice(ctx->device));
+  if (!v->ev_T) P_TRY(hipEventCreateWithFlags(&v->ev_T, hipEventDisableTiming));
+  v->helpers.push_back(std::move(h));
   return VIMZ_OK;
 }
 

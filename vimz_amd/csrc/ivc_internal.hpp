@@ -75,6 +75,11 @@ struct vimz_ivc {
   Fe u1_run = Fe::zero(); Fq u2_run = Fq::zero();   // the running scalars in the fields their vectors live in
   bool pending_sec = false, sec_T_valid = false;
   double ph_s[IP_COUNT] = {}; uint64_t ph_n[IP_COUNT] = {};
+  // Helper GPUs for the one large MSM of a step ("the per-step dense MSM(T) is split by base range across the G GPUs ...
+  // each returns one partial point, host adds"): helper h holds a replica of ck_primary, receives its slice of the cross term
+  // (device-to-device copy on its own stream) and commits to it; the host adds the partial commitments (vimz_ivc_add_msm_helper).
+  struct MsmHelper { vimz_ctx* ctx = nullptr; const vimz_bases* ck = nullptr; hipStream_t s = nullptr; MsmWorkspace ws; uint32_t* T = nullptr; void* pin = nullptr; MsmPlan plan{}; size_t off = 0, n = 0; };
+  std::vector<MsmHelper> helpers; hipEvent_t ev_T = nullptr; size_t t1_main_n = 0;
   // CompressedSNARK (spartan.hip): transposed shapes, scratch — built on first use, released with the IVC
   void* spartan_cache = nullptr; void (*spartan_free)(vimz_ivc*) = nullptr;
 };

@@ -387,6 +387,12 @@ class IVC:
                 z[i, k] = (int(v) >> (64 * k)) & 0xFFFFFFFFFFFFFFFF
         self.ctx._chk(self.ctx.lib.vimz_ivc_reset(self.h, _ptr(z)))
 
+    def add_msm_helper(self, helper_ctx, ck_on_helper):
+        """vimz_ivc_add_msm_helper: another GPU (context) takes a base range of every step's large MSM(T)."""
+        lib = self.ctx.lib
+        lib.vimz_ivc_add_msm_helper.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        self.ctx._chk(lib.vimz_ivc_add_msm_helper(self.h, helper_ctx.h, ck_on_helper.h))
+
     def fold(self, step_inputs):
         a = _u64(step_inputs).reshape(-1, self.circuit.n_priv, 4)
         self.ctx._chk(self.ctx.lib.vimz_ivc_fold(self.h, _ptr(a), a.shape[0]))
