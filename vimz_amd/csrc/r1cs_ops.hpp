@@ -115,7 +115,21 @@ __global__ void __launch_bounds__(256) k_spmv_cross16(CsrDev A, CsrDev B, CsrDev
     acc[m] = F::zero();
     if (live) {
       const uint32_t lo = M.row_ptr[r], hi = M.row_ptr[r + 1];
-      for (uint32_t k = lo + l; k < hi; k += 16) spmv_term<F>(acc[m], dict, M.coef[k], z, M.col[k]);
+      // four terms of this lane at a time: their index loads, then their value / coefficient gathers, are in flight together (one
+      // term per iteration made every term two dependent memory latencies: the 254-term rows of a bit decomposition cost 16 of them)
+      for (uint32_t k0 = lo + l; k0 < hi; k0 += 64) {
+        uint32_t col[4], cf[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) { const uint32_t kk = k0 + 16u * j; const bool on = kk < hi; col[j] = on ? M.col[kk] : 0xffffffffu; cf[j] = on ? M.coef[kk] : 0u; }
+        F v[4], c[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) { v[j] = col[j] != 0xffffffffu ? load_fe<F>(z, col[j]) : F::zero(); c[j] = load_fe<F>(dict, cf[j]); }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          if (v[j].is_zero()) continue;
+          acc[m] = v[j].eq(F::one()) ? F::add(acc[m], c[j]) : F::add(acc[m], F::mul(c[j], v[j]));
+        }
+      }
     }
   }
 #pragma unroll
