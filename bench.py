@@ -342,7 +342,7 @@ def main():
     ap.add_argument("--no-compress", action="store_true", help="skip CompressedSNARK::prove / verify of the folded proof")
     ap.add_argument("--no-extras", action="store_true", help="skip the three-concurrent-proofs extra of the default IVC run")
     ap.add_argument("--mode", default="ivc", choices=["ivc", "accumulator"])
-    ap.add_argument("--window-tables", action="store_true", help="precompute 2^(16j)·P_i tables of the primary key (16x its size in HBM): one bucket set, no Horner")
+    ap.add_argument("--window-tables", type=int, default=0, help="window tables of the primary key in HBM (vimz_bases_precompute): 11 = per-window buckets, no host Horner; 13..16 = one shared bucket set; 0 = none")
     ap.add_argument("--proof-set", default="", help="comma-separated transformations: rank r proves proof_set[r %% len] (BASELINE config 5: independent proofs, replicas only)")
     args = ap.parse_args()
 

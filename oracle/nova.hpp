@@ -90,9 +90,11 @@ template <class F> struct NovaFresh { Affine<F> W; F x0, x1; };
 
 template <class F>
 static F nova_instance_hash_full(const F& digest, u64 i, const std::vector<F>& z0, const std::vector<F>& z, const NovaRelaxed<F>& U) {
-  std::vector<F> in = {digest, F::from_u64(i)};
-  in.insert(in.end(), z0.begin(), z0.end());
-  in.insert(in.end(), z.begin(), z.end());
+  // two levels: the statement part (digest, i, z_0, z_i) is hashed on its own, then absorbed with the instance
+  std::vector<F> st = {digest, F::from_u64(i)};
+  st.insert(st.end(), z0.begin(), z0.end());
+  st.insert(st.end(), z.begin(), z.end());
+  std::vector<F> in = {nova_hash<F>(st)};
   in.push_back(U.W.x); in.push_back(U.W.y); in.push_back(U.E.x); in.push_back(U.E.y); in.push_back(U.u);
   for (int k = 0; k < 4; k++) in.push_back(F::from_u64(U.X0[k]));
   for (int k = 0; k < 4; k++) in.push_back(F::from_u64(U.X1[k]));

@@ -308,3 +308,31 @@ def test_msm_with_window_tables(ctx, oracle, cid):
             v.free()
     finally:
         B.free()
+
+
+@pytest.mark.gpu
+def test_msm_with_per_window_tables(ctx, oracle):
+    """Tables of the large-MSM window (11 bits) keep the per-window bucket sets and only spare the host its Horner: same points as the
+    oracle on dense and witness-like scalars (unit split), on a sub-range with a base offset, and on an MSM too small for that window
+    (which ignores the tables)."""
+    cid = 0
+    r = MODULI[CURVE_SCALAR[cid]]
+    n = 1 << 15
+    rng = random.Random(77)
+    bases = oracle.seq_bases(cid, n)
+    bases[5] = 0
+    dense = [rng.randrange(r) for _ in range(n)]
+    dense[:6] = [0, 1, r - 1, 1 << 200, 65535, 65536]
+    wit = [rng.choice([0, 1, 1, rng.randrange(256), rng.randrange(r)]) for _ in range(n)]
+    B = ctx.bases_upload(cid, bases).precompute(11)
+    try:
+        for sc, split in ((dense, False), (wit, True)):
+            v = ctx.vec_from_host(CURVE_SCALAR[cid], to_limbs(sc))
+            assert tuple(from_limbs(ctx.msm_vec(B, v, split_ones=split))) == oracle.msm(cid, bases, to_limbs(sc), threads=8)
+            assert tuple(from_limbs(ctx.msm_vec(B, v, n=n - 64, offset=32, base_offset=17, split_ones=split))) == \
+                oracle.msm(cid, bases[17:17 + n - 64], to_limbs(sc[32:n - 32]), threads=8)
+            assert tuple(from_limbs(ctx.msm_vec(B, v, n=30000, split_ones=split))) == oracle.msm(cid, bases[:30000], to_limbs(sc[:30000]), threads=8)
+            v.free()
+    finally:
+        B.free()
+

@@ -61,7 +61,7 @@ struct AugCircuit {
   explicit AugCircuit(cb::BuilderT<F>& ext) : b(ext) {}
   uint32_t len_z = 0, step_wires = 0, step_constraints = 0;
   F digest;                 // SHA3-256 of the shape, truncated to 250 bits
-  mutable HashCache<F> cache;                 // the output hash of the last witness() call, replayed by the next (cs.hpp)
+  mutable AugCache<F> cache;                  // the output hashes of the last witness() call, replayed by the next (cs.hpp)
   mutable std::unique_ptr<Worker> worker;     // helper thread for the scalar-multiplication chains (created on first use)
   bool use_worker = std::thread::hardware_concurrency() > 1 && !getenv("VIMZ_AUG_NO_THREADS");
 
@@ -109,6 +109,16 @@ struct AugCircuit {
     if (bad) *bad = cs.bad;
     aug.swap(cs.w);
     return o;
+  }
+  // The statement part H(digest, i + 1, z_0, z_next) of the output hash of step i, with its wires: nothing in it depends on the
+  // commitments step i's witness() waits for, so the prover calls this while they are computed.  (A stale or missing entry only
+  // costs witness() the permutation: the cache is keyed on the inputs.)
+  void precompute_statement(uint64_t i_next, const std::vector<F>& z0, const F* z_next) const {
+    CS<FP> cs;
+    std::vector<Num<F>> in(2 + 2 * (size_t)len_z);
+    in[0].v = digest; in[1].v = cb::f_from_u64<F>(i_next);
+    for (uint32_t k = 0; k < len_z; k++) { in[2 + k].v = k < z0.size() ? z0[k] : F::zero(); in[2 + len_z + k].v = z_next[k]; }
+    cs.hash_cached(in, nullptr, &cache.next_pre);
   }
 
 };

@@ -53,9 +53,12 @@ inline void absorb_relaxed(const RelaxedInst<F>& U, std::vector<F>& out) {
 template <class FP>
 inline Fp<FP> instance_hash_native(const Fp<FP>& digest, uint64_t i, const std::vector<Fp<FP>>& z0, const std::vector<Fp<FP>>& z, const RelaxedInst<Fp<FP>>& U, Fp<FP>* full = nullptr) {
   typedef Fp<FP> F;
-  std::vector<F> in; in.push_back(digest); in.push_back(cb::f_from_u64<F>(i));
-  in.insert(in.end(), z0.begin(), z0.end());
-  in.insert(in.end(), z.begin(), z.end());
+  // two levels: H(H(digest, i, z_0, z_i), U) — the statement part does not depend on the folding challenge, so the prover has it
+  // (and its S-box wires) ready before the commitments a step waits for arrive (AugCache::next_pre)
+  std::vector<F> st; st.push_back(digest); st.push_back(cb::f_from_u64<F>(i));
+  st.insert(st.end(), z0.begin(), z0.end());
+  st.insert(st.end(), z.begin(), z.end());
+  std::vector<F> in; in.push_back(hash_native<FP>(st));
   absorb_relaxed(U, in);
   F h = hash_native<FP>(in);
   if (full) *full = h;
@@ -90,7 +93,7 @@ extern double g_t[16]; extern const char* g_n[16];
 #endif
 template <class FP, class OP>
 AugOut<FP> synthesize_augmented(CS<FP>& cs, const AugIn<FP>& in, const std::vector<Num<Fp<FP>>>& z_i, const std::vector<Num<Fp<FP>>>& z_next,
-                                bool is_primary, const Fp<FP>& curve_b, const Affine<Fp<FP>>& G, HashCache<Fp<FP>>* cache = nullptr) {
+                                bool is_primary, const Fp<FP>& curve_b, const Affine<Fp<FP>>& G, AugCache<Fp<FP>>* cache = nullptr) {
   typedef Fp<FP> F;
   typedef Num<F> N;
   typedef EcGadgets<FP> Ec;
@@ -135,13 +138,14 @@ AugOut<FP> synthesize_augmented(CS<FP>& cs, const AugIn<FP>& in, const std::vect
 
   VZ_T(0, "inputs");
   // ---- consistency of the incoming instance with the previous step's output hash ---------------------------------------
-  std::vector<N> hin; hin.push_back(dg); hin.push_back(iN);
-  hin.insert(hin.end(), z0.begin(), z0.end());
-  hin.insert(hin.end(), z_i.begin(), z_i.end());
+  std::vector<N> hst; hst.push_back(dg); hst.push_back(iN);
+  hst.insert(hst.end(), z0.begin(), z0.end());
+  hst.insert(hst.end(), z_i.begin(), z_i.end());
+  std::vector<N> hin; hin.push_back(cs.hash_cached(hst, cache ? &cache->pre : nullptr, nullptr));
   hin.push_back(UW.x); hin.push_back(UW.y); hin.push_back(UE.x); hin.push_back(UE.y); hin.push_back(Uu);
   for (int j = 0; j < 4; j++) hin.push_back(UX0[j]);
   for (int j = 0; j < 4; j++) hin.push_back(UX1[j]);
-  N h_chk = cs.hash_cached(hin, cache, nullptr);
+  N h_chk = cs.hash_cached(hin, cache ? &cache->rest : nullptr, nullptr);
   VZ_T(1, "hash_in");
   std::vector<N> hb = cs.bits(h_chk, FP::BITS);
   N h250 = cs.pack(hb, 0, 250);
@@ -198,14 +202,15 @@ AugOut<FP> synthesize_augmented(CS<FP>& cs, const AugIn<FP>& in, const std::vect
   out.U_new.X0 = X0nv; out.U_new.X1 = X1nv;
 
   // ---- output hash ----------------------------------------------------------------------------------------------------------
-  std::vector<N> hout; hout.push_back(dg); hout.push_back(cs.addc(iN, F::one()));
-  hout.insert(hout.end(), z0.begin(), z0.end());
-  hout.insert(hout.end(), z_next.begin(), z_next.end());
+  std::vector<N> host; host.push_back(dg); host.push_back(cs.addc(iN, F::one()));
+  host.insert(host.end(), z0.begin(), z0.end());
+  host.insert(host.end(), z_next.begin(), z_next.end());
+  std::vector<N> hout; hout.push_back(cs.hash_cached(host, cache ? &cache->next_pre : nullptr, cache ? &cache->pre : nullptr));
   hout.push_back(Wo.x); hout.push_back(Wo.y); hout.push_back(Eo.x); hout.push_back(Eo.y); hout.push_back(uo);
   for (int j = 0; j < 4; j++) hout.push_back(X0n[j]);
   for (int j = 0; j < 4; j++) hout.push_back(X1n[j]);
   VZ_T(9, "sel_out");
-  N h_new = cs.hash_cached(hout, nullptr, cache);
+  N h_new = cs.hash_cached(hout, nullptr, cache ? &cache->rest : nullptr);
   VZ_T(10, "hash_out");
   std::vector<N> hnb = cs.bits(h_new, FP::BITS);
   N hn250 = cs.pack(hnb, 0, 250);

@@ -75,6 +75,11 @@ struct Worker {
 // step's circuit recomputes to check its incoming instance, so its S-box wires are kept and replayed.
 template <class F>
 struct HashCache { std::vector<F> in, wires; F out; bool valid = false; };
+// The instance hash is H(H(digest, i, z_0, z_i), U):  `pre` / `rest` hold the two hashes a step's circuit ends with, replayed as the
+// incoming-hash check of the next step;  `next_pre` is the statement part of THIS step's output hash, which the prover may compute
+// ahead (AugCircuit::precompute_statement) while it waits for the commitments the rest of the circuit needs.
+template <class F>
+struct AugCache { HashCache<F> pre, rest, next_pre; };
 
 // Montgomery batch inversion; zeros are left as zero.
 template <class F>
@@ -222,7 +227,7 @@ struct CS {
     if (read && read->valid && read->in.size() == in.size()) {
       bool same = true;
       for (size_t i = 0; i < in.size() && same; i++) same = read->in[i].eq(in[i].v);
-      if (same) { w.insert(w.end(), read->wires.begin(), read->wires.end()); N r; r.v = read->out; return r; }
+      if (same) { w.insert(w.end(), read->wires.begin(), read->wires.end()); N r; r.v = read->out; if (write && write != read) *write = *read; return r; }
     }
     const size_t w0 = w.size();
     N h = hash(in);

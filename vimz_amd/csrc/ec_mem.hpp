@@ -35,4 +35,92 @@ __device__ __forceinline__ XYZZ<F> load_xyzz(const uint32_t* __restrict__ base, 
   XYZZ<F> p; load_words20(d, p.X, p.Y); load_words20(d + AFFINE_WORDS, p.ZZ, p.ZZZ); return p;
 }
 
+// ---- four lanes, one full addition ---------------------------------------------------------------------------------------------------
+// The tails of a bucket reduction (suffix scans, trees) are chains of DEPENDENT full additions with few of them per level: one lane
+// per addition leaves three of a CU's four SIMDs idle and takes 14 sequential field multiplications (≈7 µs).  The 14 products of
+// add-2008-s fall into four dependency levels of at most four independent products:
+//     U1 = X1·ZZ2, U2 = X2·ZZ1, S1 = Y1·ZZZ2, S2 = Y2·ZZZ1   |   PP = P², RR = R², Z12 = ZZ1·ZZ2, Z123 = ZZZ1·ZZZ2
+//     PPP = P·PP, Q = U1·PP, ZZ3 = Z12·PP                     |   Ya = R·(Q − X3), Yb = S1·PPP, ZZZ3 = Z123·PPP
+// so a quad of consecutive lanes (q = lane & 3) computes one addition in four multiplication levels, exchanging 9-word field
+// elements by wave shuffles (63 words in all).  Operands and result live in LDS (sh[]): quad_add_compute reads them and returns what
+// this lane will write; the caller puts a barrier between it and quad_add_store (other quads may still read the destination).
+// Identity operands and the doubling / cancellation case (P ≡ 0; lane 0 of the quad then runs the scalar formula) keep add_full's
+// semantics.  Same bounds as add_full (ec.hpp).  Every lane of the wave must call both functions (shuffles are wave-wide).
+template <class F> struct QuadRes { F c0, c1; XYZZ<F> full; uint32_t mode; };       // mode 0: nothing to store; 1: copy of b; 2: sum; 3: lane 0 holds `full`
+template <class F>
+__device__ __forceinline__ F quad_shfl(const F& v, int src_lane) {
+  F r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.v[i] = __shfl(v.v[i], src_lane);
+  return r;
+}
+template <class F>
+__device__ __forceinline__ QuadRes<F> quad_add_compute(const XYZZ<F>* __restrict__ sh, uint32_t ia, uint32_t ib, bool active) {
+  const int lane = (int)(threadIdx.x & 63u), q = lane & 3, base = lane & ~3;
+  QuadRes<F> out; out.mode = 0;
+  const XYZZ<F>& A = sh[ia]; const XYZZ<F>& B = sh[ib];
+  const bool a_id = A.ZZ.is_zero(), b_id = B.ZZ.is_zero();
+  // (operands are selected per lane, then ONE multiplication is issued per level: a select between four products would make every
+  //  lane compute all four)
+  auto sel = [](bool c, const F& x, const F& y) { F r; for (int i = 0; i < 9; i++) r.v[i] = c ? x.v[i] : y.v[i]; return r; };
+  // level 1: U1 = X1·ZZ2 | U2 = X2·ZZ1 | S1 = Y1·ZZZ2 | S2 = Y2·ZZZ1
+  const F* px = q == 0 ? &A.X : q == 1 ? &B.X : q == 2 ? &A.Y : &B.Y;
+  const F* py = q == 0 ? &B.ZZ : q == 1 ? &A.ZZ : q == 2 ? &B.ZZZ : &A.ZZZ;
+  const F m1 = F::mul(*px, *py);
+  F o1;
+#pragma unroll
+  for (int i = 0; i < 9; i++) o1.v[i] = __shfl_xor(m1.v[i], 1);
+  // q0,q1: P = U2 − U1;  q2,q3: R = S2 − S1   (the even lane of a pair holds the "1" operand)
+  const F lo = sel(q & 1, o1, m1), hi = sel(q & 1, m1, o1);
+  const F PR = F::template sub<2>(hi, lo);
+  const int pz = __shfl((q == 0 && PR.is_zero_mod()) ? 1 : 0, base);
+  // level 2: PP = P² | Z12 = ZZ1·ZZ2 | RR = R² | Z123 = ZZZ1·ZZZ2
+  const F* pa = q == 1 ? &A.ZZ : &A.ZZZ; const F* pb = q == 1 ? &B.ZZ : &B.ZZZ;
+  const F za = *pa, zb = *pb;
+  const F m2 = F::mul(sel(q & 1, za, PR), sel(q & 1, zb, PR));
+  const F PP = quad_shfl(m2, base);
+  const F Z12 = quad_shfl(m2, base + 1);
+  // level 3: PPP = P·PP | Q = U1·PP | — | ZZ3 = Z12·PP
+  const F m3 = F::mul(sel(q == 0, PR, sel(q == 1, lo, Z12)), PP);
+  const F PPP = quad_shfl(m3, base);
+  const F Qv = quad_shfl(m3, base + 1);
+  const F S1 = quad_shfl(lo, base + 2);              // lane 2's `lo` is S1
+  // X3 and Q − X3 (meaningful on lane 2, whose m2 is RR)
+  const F X3 = F::template sub<4>(m2, F::add(PPP, F::dbl(Qv)));
+  const F D = F::template sub<6>(Qv, X3);
+  // level 4: Yb = S1·PPP | — | Ya = R·(Q − X3) | ZZZ3 = Z123·PPP
+  const F m4 = F::mul(sel(q == 0, S1, sel(q == 2, PR, m2)), sel(q == 2, D, PPP));
+  const F Yb = quad_shfl(m4, base);
+  if (!active || b_id) return out;
+  if (a_id) { out.mode = 1; out.c0 = q == 0 ? B.X : q == 1 ? B.Y : q == 2 ? B.ZZ : B.ZZZ; return out; }
+  if (pz) {                                          // same x: doubling or cancellation — rare, the scalar formula on lane 0
+    out.mode = 3;
+    if (q == 0) { XYZZ<F> a = A; add_full(a, B); out.full = a; }
+    return out;
+  }
+  out.mode = 2;
+  if (q == 2) { out.c0 = X3; out.c1 = F::template sub<2>(m4, Yb); }
+  if (q == 3) { out.c0 = m3; out.c1 = m4; }
+  return out;
+}
+template <class F>
+__device__ __forceinline__ void quad_add_store(XYZZ<F>* __restrict__ sh, uint32_t ia, const QuadRes<F>& r) {
+  const int q = (int)(threadIdx.x & 3u);
+  XYZZ<F>& A = sh[ia];
+  if (r.mode == 1) { if (q == 0) A.X = r.c0; else if (q == 1) A.Y = r.c0; else if (q == 2) A.ZZ = r.c0; else A.ZZZ = r.c0; }
+  else if (r.mode == 2) { if (q == 2) { A.X = r.c0; A.Y = r.c1; } else if (q == 3) { A.ZZ = r.c0; A.ZZZ = r.c1; } }
+  else if (r.mode == 3 && q == 0) A = r.full;
+}
+// One level of `count` (<= 64) additions sh[dst(e)] += sh[src(e)] by a 256-thread workgroup, four lanes each.
+template <class F, class Fd, class Fs>
+__device__ __forceinline__ void quad_level(XYZZ<F>* __restrict__ sh, uint32_t count, Fd dst, Fs src) {
+  const uint32_t e = threadIdx.x >> 2;
+  const bool active = e < count;
+  const uint32_t ia = active ? dst(e) : 0u, ib = active ? src(e) : 0u;
+  const QuadRes<F> r = quad_add_compute<F>(sh, ia, ib, active);
+  __syncthreads();
+  quad_add_store<F>(sh, ia, r);
+  __syncthreads();
+}
+
 }  // namespace vz

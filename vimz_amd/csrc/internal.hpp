@@ -25,7 +25,7 @@ struct vimz_ctx {
 struct vimz_bases {
   int curve; size_t n; uint32_t* d;
   uint32_t* tables = nullptr; int table_c = 0, table_K = 0;   // optional window tables (vimz_bases_precompute)
-  vz::BaseTables tb(size_t offset) const { return vz::BaseTables{tables, n, offset, table_c, table_K}; }
+  vz::BaseTables tb(size_t offset) const { return vz::BaseTables{tables, n, offset, table_c, table_K, table_c == 11}; }
 };
 struct vimz_vec { int field; size_t n; uint32_t* d; };
 

@@ -121,6 +121,8 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
       uint32_t* Zi = bb.Z + 8 * r * nw;
       uint32_t *az = bb.az + 8 * r * nc, *bz = bb.bz + 8 * r * nc, *cz = bb.cz + 8 * r * nc;
       // ---- 1. the previous fresh secondary instance is complete once its two MSMs are back -------------------------------------
+      // (while they run: the statement part of this step's output hash, which depends on nothing they produce)
+      v->c1->precompute_statement(i + 1, v->z0, zs.data() + (first + r + 1) * p->len_z);
       if ((rc = finish_secondary(v))) return rc;
       // ---- 2. primary verifier circuit on the host: folds (U2, u2) and hashes the result ----------------------------------------
       t0 = now_s();
@@ -164,6 +166,7 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
       }
       v->ph_s[IP_LAUNCH] += now_s() - t0;
       t0 = now_s();
+      v->c2.precompute_statement(i + 1, v->z0_sec, &zero_q);      // likewise for the secondary circuit, under the primary half's MSMs
       P_TRY(hipEventSynchronize(bb.ev[r]));
       G1Aff cW_step = msm_finish<BnG1>(p->planB, (char*)bb.pin + r * pin_stride);
       // the large MSM's host tail (Horner over 24 window sums, ≈0.1 ms) is taken whenever its stream turns out to be done:
@@ -758,7 +761,7 @@ int vimz_ivc_proof_import(vimz_ivc* v, const uint8_t* blob, size_t len) {
   v->i = h.steps; p->steps = h.steps;
   v->U2 = hs.U2; v->U1 = hs.U1; v->u2 = hs.u2; v->T2 = hs.T2; v->u1_run = hs.u1_run; v->u2_run = hs.u2_run;
   v->sec_T_valid = (h.flags & 1) != 0; v->pending_sec = false; v->t1_step_pending = false;
-  v->c1->cache.valid = false; v->c2.cache.valid = false;
+  v->c1->cache = aug::AugCache<Fe>(); v->c2.cache = aug::AugCache<Fq>();
   return VIMZ_OK;
 }
 

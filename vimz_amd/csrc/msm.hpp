@@ -463,7 +463,7 @@ __global__ void __launch_bounds__(256) k_msm_small(const uint32_t* __restrict__ 
   __shared__ uint32_t cnt[SMALL_NBW], off[SMALL_NBW + 1], soff[SMALL_NBW + 1], cur[SMALL_NBW];
   __shared__ uint16_t list[SMALL_CHUNK];
   __shared__ uint8_t subb[256];
-  __shared__ uint32_t s_maxm, s_ticket;
+  __shared__ uint32_t s_maxm, s_ticket, wcnt[4];
   // These waves sit on the critical path of a folding step while bulk kernels (the large MSM's accumulation, the batch
   // producer) fill the same SIMDs: raise their issue priority over the resident bulk waves.
   __builtin_amdgcn_s_setprio(3);
@@ -518,11 +518,19 @@ __global__ void __launch_bounds__(256) k_msm_small(const uint32_t* __restrict__ 
   }
   sh[t] = acc;
   __syncthreads();
-  // (Compacting a level's scattered pairs onto the first threads — two waves, then one, instead of all four — saves a fifth of this
-  // kernel's instructions and measured 406 vs 397 steps/s for one proof but 665 vs 685 for three: left as it is.)
-  for (uint32_t d = 1; d < s_maxm; d <<= 1) {       // a bucket's sub-buckets are contiguous: stride-doubling tree inside each segment
-    if (t < nsubs && (kk & (2 * d - 1)) == 0 && kk + d < mb) { XYZZ<F> a = sh[t]; add_full(a, sh[t + d]); sh[t] = a; }
+  // A bucket's sub-buckets are contiguous: stride-doubling tree inside each segment.  A level's scattered pairs are compacted
+  // (ballot + popcount) into `list`, free by now, and added four lanes per addition (ec_mem.hpp: quad_level), 64 pairs a round.
+  for (uint32_t d = 1; d < s_maxm; d <<= 1) {
+    const bool act = t < nsubs && (kk & (2 * d - 1)) == 0 && kk + d < mb;
+    const uint64_t bal = __ballot(act);
+    if ((t & 63) == 0) wcnt[t >> 6] = (uint32_t)__popcll(bal);
     __syncthreads();
+    uint32_t before = 0, total = 0;
+    for (uint32_t wv = 0; wv < 4; wv++) { before += wv < (t >> 6) ? wcnt[wv] : 0u; total += wcnt[wv]; }
+    if (act) list[before + (uint32_t)__popcll(bal & ((1ull << (t & 63)) - 1ull))] = (uint16_t)t;
+    __syncthreads();
+    for (uint32_t base = 0; base < total; base += 64)
+      quad_level<F>(sh, min(64u, total - base), [&](uint32_t e) { return (uint32_t)list[base + e]; }, [&](uint32_t e) { return (uint32_t)list[base + e] + d; });
   }
   XYZZ<F> bk = XYZZ<F>::identity();
   if (t < SMALL_NBW && cnt[t]) bk = sh[soff[t]];
@@ -540,37 +548,33 @@ __global__ void __launch_bounds__(256) k_msm_small(const uint32_t* __restrict__ 
     __syncthreads();
     if (s_ticket != Q - 1) return;
     __threadfence();
-    const uint32_t b = t & (SMALL_NBW - 1), g = t / SMALL_NBW;          // 256 threads: four partial sums per bucket
-    XYZZ<F> acc = XYZZ<F>::identity();
-    for (uint32_t qq = g; qq < Q; qq += 256 / SMALL_NBW) {
-      const uint32_t* src = chunk_out + (size_t)XYZZ_WORDS * (((size_t)w * Q + qq) * SMALL_NBW + b);
-      XYZZ<F> v; F* f[4] = {&v.X, &v.Y, &v.ZZ, &v.ZZZ};
-      for (int c4 = 0; c4 < 4; c4++) for (int i = 0; i < 9; i++) f[c4]->v[i] = __hip_atomic_load(src + COORD_WORDS * c4 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      add_full(acc, v);
-    }
-    sh[t] = acc;
-    __syncthreads();
-    for (uint32_t d = 128; d >= SMALL_NBW; d >>= 1) {
-      if (t < d) { XYZZ<F> a = sh[t]; add_full(a, sh[t + d]); sh[t] = a; }
+    // sh = four slots of 64 buckets; slot 0 accumulates, the chunks arrive four (then three) at a time and every addition
+    // is a four-lane one: (0 += 1, 2 += 3), 0 += 2
+    const uint32_t b = t & (SMALL_NBW - 1), sl = t / SMALL_NBW;
+    for (uint32_t loaded = 0; loaded < Q;) {
+      const uint32_t slot0 = loaded ? 1u : 0u, k = min(Q - loaded, 4u - slot0), m = slot0 + k;
+      if (sl >= slot0 && sl < m) {
+        const uint32_t* src = chunk_out + (size_t)XYZZ_WORDS * (((size_t)w * Q + loaded + sl - slot0) * SMALL_NBW + b);
+        XYZZ<F> v; F* f[4] = {&v.X, &v.Y, &v.ZZ, &v.ZZZ};
+        for (int c4 = 0; c4 < 4; c4++) for (int i = 0; i < 9; i++) f[c4]->v[i] = __hip_atomic_load(src + COORD_WORDS * c4 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sh[t] = v;
+      }
       __syncthreads();
+      if (m >= 2) quad_level<F>(sh, SMALL_NBW, [](uint32_t e) { return e; }, [](uint32_t e) { return e + SMALL_NBW; });
+      if (m == 4) quad_level<F>(sh, SMALL_NBW, [](uint32_t e) { return e + 2 * SMALL_NBW; }, [](uint32_t e) { return e + 3 * SMALL_NBW; });
+      if (m >= 3) quad_level<F>(sh, SMALL_NBW, [](uint32_t e) { return e; }, [](uint32_t e) { return e + 2 * SMALL_NBW; });
+      loaded += k;
     }
     if (t == 0) __hip_atomic_store(&done[w], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   } else {
     if (t < SMALL_NBW) sh[t] = bk;
     __syncthreads();
   }
-  for (uint32_t d = 1; d < SMALL_NBW; d <<= 1) {    // inclusive suffix sums of the buckets
-    const bool act = t + d < SMALL_NBW;
-    XYZZ<F> o = XYZZ<F>::identity();
-    if (act) o = sh[t + d];
-    __syncthreads();
-    if (act) { XYZZ<F> a = sh[t]; add_full(a, o); sh[t] = a; }
-    __syncthreads();
-  }
-  for (uint32_t d = SMALL_NBW / 2; d > 0; d >>= 1) {   // sum_b (b+1)·B_b = sum of the suffix sums
-    if (t < d) { XYZZ<F> a = sh[t]; add_full(a, sh[t + d]); sh[t] = a; }
-    __syncthreads();
-  }
+  // The rest is twelve levels of at most 64 dependent additions: four lanes per addition (ec_mem.hpp: quad_level), all four waves busy.
+  for (uint32_t d = 1; d < SMALL_NBW; d <<= 1)      // inclusive suffix sums of the buckets
+    quad_level<F>(sh, SMALL_NBW - d, [](uint32_t e) { return e; }, [d](uint32_t e) { return e + d; });
+  for (uint32_t d = SMALL_NBW / 2; d > 0; d >>= 1)  // sum_b (b+1)·B_b = sum of the suffix sums
+    quad_level<F>(sh, d, [](uint32_t e) { return e; }, [d](uint32_t e) { return e + d; });
   if (Q == 1 || done) { if (t == 0) store_xyzz(window_sums, w, sh[0]); return; }
   if (t == 0) store_xyzz(chunk_out, (size_t)w * Q + q, sh[0]);          // k_msm_small_sum follows (VIMZ_DEBUG_SMALL_SUM_KERNEL)
 }
@@ -689,7 +693,10 @@ hipError_t msm_launch(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_ba
   static const bool no_small = getenv("VIMZ_DEBUG_NO_SMALL_MSM") != nullptr;
   const bool small_fmt = tb && tb->d && tb->c == SMALL_C;             // (ignored, not an error, when the fused path is switched off)
   const bool small_tb = small_fmt && !no_small && c_override <= 0;
-  const bool tabled = tb && tb->d && !small_fmt && c_override <= 0;
+  bool tabled = tb && tb->d && !small_fmt && c_override <= 0;
+  // tables with per-window bucket sets only fit the window this size would get anyway; otherwise they are not used
+  if (tabled && tb->own && tb->c != msm_plan(n, S::Params::BITS, 0).c) tabled = false;
+  const bool own = tabled && tb->own;
   if (small_tb && (n > MSM_SMALL_MAX || tb->K != (S::Params::BITS + SMALL_C) / SMALL_C)) return hipErrorInvalidValue;
   if (!no_small && !tabled && c_override <= 0 && n <= MSM_SMALL_MAX) {      // fused single-launch path
     MsmPlan ps; ps.c = SMALL_C; ps.K = (S::Params::BITS + SMALL_C) / SMALL_C; ps.nbw = SMALL_NBW; ps.nb = SMALL_NBW * (uint32_t)ps.K; ps.split_ones = 0; ps.tabled = small_tb ? 2 : 0;
@@ -710,9 +717,9 @@ hipError_t msm_launch(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_ba
     return hipSuccess;
   }
   MsmPlan pl = msm_plan(n, S::Params::BITS, tabled ? tb->c : c_override);
-  if (tabled) {            // one bucket set shared by all windows
+  if (tabled) {            // one bucket set shared by all windows — or (own) the usual ones, whose sums then need no Horner
     if (tb->K != pl.K || pl.nbw < 256 || (size_t)tb->K * tb->n_total >= (1u << 31)) return hipErrorInvalidValue;
-    pl.nb = pl.nbw; pl.tabled = 1;
+    if (own) pl.tabled = 3; else { pl.nb = pl.nbw; pl.tabled = 1; }
     d_bases = tb->d + (size_t)AFFINE_WORDS * tb->offset;
   }
   if (pl.K + 1 > MSM_MAX_WINDOWS || pl.c > 16 || pl.c < 2) return hipErrorInvalidValue;
@@ -740,7 +747,7 @@ hipError_t msm_launch(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_ba
   // About 4 k scalars per workgroup (75 workgroups here) measured best: one proof 384 -> 394 steps/s, three 599 -> 614.
   const uint32_t sort_blocks = sort_blocks_env > 0 && sort_blocks_env <= (int)SORT_BLOCKS ? (uint32_t)sort_blocks_env
                                                                                            : (uint32_t)std::min<size_t>(SORT_BLOCKS, std::max<size_t>(32, n / 4096));
-  const uint32_t bstride = tabled ? 0u : pl.nbw, pstride = tabled ? (uint32_t)tb->n_total : 0u;
+  const uint32_t bstride = tabled && !own ? 0u : pl.nbw, pstride = tabled ? (uint32_t)tb->n_total : 0u;
   if (lds_sort) {
     VZ_HIP_CHECK(ws.reserve_block_hist((size_t)SORT_BLOCKS * pl.nb));
     {   // the >64 KiB dynamic-LDS opt-in is per device and per kernel instantiation; contexts fold from several host threads
@@ -789,8 +796,8 @@ hipError_t msm_launch(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_ba
   VZ_EV(5);
   const unsigned T = pl.nbw < 256 ? pl.nbw : 256;
   uint32_t* wsum = reinterpret_cast<uint32_t*>(ws.window_sums);
-  const int kout = tabled ? 1 : pl.K;     // window sums produced
-  if (tabled) {
+  const int kout = tabled && !own ? 1 : pl.K;     // window sums produced
+  if (tabled && !own) {
     uint32_t* rs = reinterpret_cast<uint32_t*>(ws.ones_partial);   // scratch: 2 x (nbw/256) points (<= 2 x 128 of the 16448)
     hipLaunchKernelGGL(k_reduce_big1<F>, dim3(pl.nbw / 256), dim3(256), 0, stream, partial, ws.counts, ws.sub_off, rs + (size_t)XYZZ_WORDS * 16448);
     hipLaunchKernelGGL(k_reduce_big2<F>, dim3(1), dim3(256), 0, stream, rs + (size_t)XYZZ_WORDS * 16448, pl.nbw / 256, wsum);
@@ -824,7 +831,7 @@ Affine<typename C::Base> msm_finish(const MsmPlan& pl, const void* pinned) {
     return p;
   };
   XYZZ<FS> acc = XYZZ<FS>::identity();
-  const int kout = pl.tabled == 1 ? 1 : pl.K;      // tabled == 2: K sums of one bucket set each, already weighted
+  const int kout = pl.tabled == 1 ? 1 : pl.K;      // tabled == 2, 3: K sums of one bucket set each, already weighted
   for (int w = kout - 1; w >= 0; w--) {
     if (!pl.tabled) for (int k = 0; k < pl.c; k++) acc = dbl(acc);
     add_full(acc, host_point(w));

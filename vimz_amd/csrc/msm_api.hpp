@@ -45,7 +45,9 @@ constexpr uint32_t SMALL_CHUNK = 1536, SMALL_MAXQ = 16;
 constexpr size_t MSM_SMALL_MAX = (size_t)SMALL_CHUNK * SMALL_MAXQ;
 
 // Precomputed window tables of a commitment key: d[j][i] = 2^(c j) * P_i, affine internal form, row length n_total.
-struct BaseTables { const uint32_t* d; size_t n_total; size_t offset; int c, K; };
+// own != 0: every window keeps its own bucket set, as without tables — the tables only spare the host the Horner over the window sums
+// (the large-MSM default window, c = 11); own == 0: one bucket set shared by all windows (c = 13..16: fewer entries, deeper reduce).
+struct BaseTables { const uint32_t* d; size_t n_total; size_t offset; int c, K; int own = 0; };
 
 static inline MsmPlan msm_plan(size_t n, int scalar_bits, int c_override) {
   MsmPlan p;

@@ -93,16 +93,17 @@ class FoldingParams:
         self.ck.free()
 
 
-def prepare_folding(ctx, transformation, resolution="HD", ck_label=b"ck", window_tables=False):
-    """prepare_folding (folding.rs:20-25): build the step circuit and derive the commitment key on the GPU
-    (optionally with window tables: 16 x the key's size in HBM, 0.67 GB at HD)."""
+def prepare_folding(ctx, transformation, resolution="HD", ck_label=b"ck", window_tables=0):
+    """prepare_folding (folding.rs:20-25): build the step circuit and derive the commitment key on the GPU.
+    window_tables: 0 = none; 11 = tables 2^(11j)·P_i with the usual per-window buckets (24 x the key in HBM, 1 GB at HD: the
+    window sums need no Horner on the host); 13..16 = one bucket set shared by all windows (vimz_bases_precompute)."""
     t0 = time.time()
     circuit = Circuit(transformation, *default_shape(transformation, resolution))
     # next power of two, as nova-snark sizes ck — of the AUGMENTED circuit: the verifier circuit adds 7.7 k wires / rows
     n = 1 << (max(circuit.n_wires, circuit.n_constraints) + AUGMENTED_ROOM - 1).bit_length()
     ck = ctx.bases_generate(_lib.CURVE_BN254_G1, n, ck_label)
     if window_tables:
-        ck.precompute()
+        ck.precompute(16 if window_tables is True else int(window_tables))
     return circuit, FoldingParams(ctx, circuit, ck, time.time() - t0)
 
 
