@@ -123,4 +123,13 @@ __device__ __forceinline__ void quad_level(XYZZ<F>* __restrict__ sh, uint32_t co
   __syncthreads();
 }
 
+// sh[0] = sum of sh[0..256) by a 256-thread workgroup: eight levels, every addition a four-lane one (two rounds for the 128 pairs
+// of the first level).  Ends with a barrier.
+template <class F>
+__device__ __forceinline__ void quad_tree256(XYZZ<F>* __restrict__ sh) {
+  quad_level<F>(sh, 64, [](uint32_t e) { return e; }, [](uint32_t e) { return e + 128; });
+  quad_level<F>(sh, 64, [](uint32_t e) { return e + 64; }, [](uint32_t e) { return e + 192; });
+  for (uint32_t d = 64; d > 0; d >>= 1) quad_level<F>(sh, d, [](uint32_t e) { return e; }, [d](uint32_t e) { return e + d; });
+}
+
 }  // namespace vz

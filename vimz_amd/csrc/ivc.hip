@@ -68,10 +68,20 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
 
   // cross term of the step rows of (running instance, fresh row `row` of batch buffer `b2`) and its commitment, on stream 3
   // behind everything queued on the main stream so far (the fold that produced the running instance)
-  auto launch_T1_step = [&](decltype(p->buf[0])& b2, size_t row, bool record) -> int {
+  // With `fuse` (the row just folded, its challenge): the fold of the step rows' running products and error vector rides in the same
+  // pass (k_fold_cross) and nothing is waited for but the next row's products.
+  struct FusedFold { const uint32_t *az, *bz, *cz; Fe rho; bool fold_E; };
+  static const bool no_fuse = getenv("VIMZ_DEBUG_NO_FUSED_FOLD") != nullptr;
+  static const bool use_launcher = std::thread::hardware_concurrency() > 2 && !getenv("VIMZ_DEBUG_NO_LAUNCHER");
+  auto launch_T1_step = [&](decltype(p->buf[0])& b2, size_t row, bool record, const FusedFold* fuse) -> int {
     if (record) P_TRY(hipEventRecord(v->ev_fold, s));
-    P_TRY(hipStreamWaitEvent(v->s3, v->ev_fold, 0));
+    if (!fuse) P_TRY(hipStreamWaitEvent(v->s3, v->ev_fold, 0));
     P_TRY(hipStreamWaitEvent(v->s3, b2.ev[row], 0));
+    if (fuse) {
+      hipLaunchKernelGGL(k_fold_cross<Fr>, dim3(stream_grid(sc)), dim3(256), 0, v->s3, sc, p->AZ, p->BZ, p->CZ, p->E, p->T, fuse->fold_E ? 1 : 0, fuse->rho, v->u1_run,
+                         fuse->az, fuse->bz, fuse->cz, b2.az + 8 * row * nc, b2.bz + 8 * row * nc, b2.cz + 8 * row * nc, Fe::one());
+      P_TRY(hipEventRecord(v->ev_fused, v->s3)); v->fused_recorded = true;
+    } else
     hipLaunchKernelGGL(k_cross_term<Fr>, dim3(stream_grid(sc)), dim3(256), 0, v->s3, sc, p->AZ, p->BZ, p->CZ, v->u1_run,
                        b2.az + 8 * row * nc, b2.bz + 8 * row * nc, b2.cz + 8 * row * nc, Fe::one(), p->T);
     P_TRY(hipGetLastError());
@@ -148,7 +158,7 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
                          Zi, az, bz, cz, i > 0 ? p->AZ : nullptr, p->BZ, p->CZ, v->u1_run, Fe::one(), p->T);
       P_TRY(hipGetLastError());
       if (i > 0) {
-        if (!v->t1_step_pending && (rc = launch_T1_step(bb, r, true))) return rc;       // first row of a call: nothing was queued ahead
+        if (!v->t1_step_pending && (rc = launch_T1_step(bb, r, true, nullptr))) return rc;       // first row of a call: nothing was queued ahead
         P_TRY(msm_launch<BnG1>(s, ctx->msm_ws, p->ck->d + (size_t)AFFINE_WORDS * sc, p->T + 8 * sc, nc - sc, 1, 0, v->pin + 4 * v->pin_res, &v->plan_T1v, nullptr, 0, v->tb_T1v.d ? &v->tb_T1v : nullptr));
       }
       P_TRY(hipEventRecord(v->ev_a, s));
@@ -254,21 +264,44 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
       if (bad) return vz_fail(ctx, VIMZ_ERR_UNSAT, "secondary verifier circuit: inconsistent incoming instance");
       v->ph_s[IP_SYNTH2] += now_s() - t0; v->ph_n[IP_SYNTH2]++;
       t0 = now_s();
+      bool t1_queued = false; int launcher_rc = VIMZ_OK; FusedFold ff{};
+      struct WaitGuard { aug::Worker* w = nullptr; ~WaitGuard() { if (w) w->wait(); } } launching;      // (an early return must not leave the helper with this frame)
       {
         const Fe rho1 = rho_element<Fe>(o2.rho_low);
+        // the row whose step rows' cross term is wanted next (none after the last row of a call)
+        decltype(&bb) nb = nullptr; size_t nrow = 0;
+        if (r + 1 < rows) { nb = &bb; nrow = r + 1; }
+        else if (k + 1 < job.nbatches) {
+          if ((rc = fold_issue_when_ready(p, job, k + 1, true))) return rc;      // its per-row events must have been recorded in this call
+          nb = &p->buf[(k + 1) & 1]; nrow = 0;
+        }
+        const bool fuse = nb && !no_fuse;
+        const size_t lo = fuse ? sc : 0;       // fused: the step rows of E, AZ, BZ, CZ are folded by k_fold_cross on stream 3
         Fold5 f;
         f.x1[0] = p->Zrun; f.x2[0] = Zi; f.n[0] = nw;
-        f.x1[1] = i > 0 ? p->E : nullptr; f.x2[1] = p->T; f.n[1] = nc;
-        f.x1[2] = p->AZ; f.x2[2] = az; f.n[2] = nc;
-        f.x1[3] = p->BZ; f.x2[3] = bz; f.n[3] = nc;
-        f.x1[4] = p->CZ; f.x2[4] = cz; f.n[4] = nc;
+        f.x1[1] = i > 0 ? p->E + 8 * lo : nullptr; f.x2[1] = p->T + 8 * lo; f.n[1] = nc - lo;
+        f.x1[2] = p->AZ + 8 * lo; f.x2[2] = az + 8 * lo; f.n[2] = nc - lo;
+        f.x1[3] = p->BZ + 8 * lo; f.x2[3] = bz + 8 * lo; f.n[3] = nc - lo;
+        f.x1[4] = p->CZ + 8 * lo; f.x2[4] = cz + 8 * lo; f.n[4] = nc - lo;
+        v->u1_run = Fe::add(v->u1_run, rho1);
+        if (fuse) {
+          // the next step's large MSM is the longest dependent chain of a step: it is queued at once, on stream 3 — by a helper
+          // thread (a dozen launches, 40-60 µs of host time), while this one queues the secondary half
+          ff = FusedFold{az, bz, cz, rho1, i > 0};
+          if (use_launcher) {
+            if (!v->launcher) v->launcher.reset(new aug::Worker());
+            launcher_rc = VIMZ_OK;
+            v->launcher->start([&, nb, nrow] { if (hipSetDevice(ctx->device) != hipSuccess) { launcher_rc = VIMZ_ERR_HIP; return; } launcher_rc = launch_T1_step(*nb, nrow, false, &ff); });
+            launching.w = v->launcher.get();
+          } else if ((rc = launch_T1_step(*nb, nrow, false, &ff))) return rc;
+          t1_queued = true;
+        }
         // (measured: on stream 3, where the large MSM follows, it runs at that stream's lower priority and delays the MSM by more
         // than the secondary half gains)
-        // on stream 2, idle until the secondary witness is uploaded: this 145 MB pass overlaps that upload instead of preceding it
+        // on stream 2, idle until the secondary witness is uploaded: this pass overlaps that upload instead of preceding it
         // (everything it reads is complete — the host has waited for all three streams)
-        hipLaunchKernelGGL(k_fold5<Fr>, dim3(2048), dim3(256), 0, v->s2, f, rho1);
-        v->u1_run = Fe::add(v->u1_run, rho1);
-        P_TRY(hipEventRecord(v->ev_fold, v->s2));  // the next step's large MSM may start here (queued below, behind the secondary's work)
+        hipLaunchKernelGGL(k_fold5<Fr>, dim3(fuse ? 512 : 2048), dim3(256), 0, v->s2, f, rho1);
+        P_TRY(hipEventRecord(v->ev_fold, v->s2));  // the verifier rows of the next step (and, unfused, its large MSM) may start here
       }
       v->U1 = o2.U_new;
       // fresh secondary instance on the device: [1 | z_out | z_in | verifier wires]
@@ -291,10 +324,10 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
         v->u2.x0 = cross_field<Fe>(o2.x0); v->u2.x1 = cross_field<Fe>(o2.x1);
         v->pending_sec = true;
       }
-      if (r + 1 < rows) { if ((rc = launch_T1_step(bb, r + 1, false))) return rc; }
-      else if (k + 1 < job.nbatches) {
-        if ((rc = fold_issue_when_ready(p, job, k + 1, true))) return rc;      // its per-row events must have been recorded in this call
-        if ((rc = launch_T1_step(p->buf[(k + 1) & 1], 0, false))) return rc;
+      if (launching.w) { launching.w->wait(); launching.w = nullptr; if (launcher_rc) return launcher_rc; }
+      if (!t1_queued) {
+        if (r + 1 < rows) { if ((rc = launch_T1_step(bb, r + 1, false, nullptr))) return rc; }
+        else if (k + 1 < job.nbatches) { if ((rc = launch_T1_step(p->buf[(k + 1) & 1], 0, false, nullptr))) return rc; }
       }
       v->ph_s[IP_LAUNCH] += now_s() - t0;
       v->i++; p->steps++;
@@ -303,6 +336,7 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
     P_TRY(hipStreamSynchronize(s));
     P_TRY(hipStreamSynchronize(v->s2));
     P_TRY(hipEventSynchronize(v->ev_fold));
+    if (v->fused_recorded) P_TRY(hipEventSynchronize(v->ev_fused));
   }
   if ((rc = finish_secondary(v))) return rc;
   P_TRY(hipStreamSynchronize(p->sB));
@@ -334,6 +368,7 @@ void vimz_ivc_free(vimz_ivc* v) {
     if (v->s3 && v->s3 != v->ctx->stream) { hipStreamSynchronize(v->s3); hipStreamDestroy(v->s3); }
     if (v->ev_fork) hipEventDestroy(v->ev_fork);
     if (v->ev_fold) hipEventDestroy(v->ev_fold);
+    if (v->ev_fused) hipEventDestroy(v->ev_fused);
     if (v->ev_b0) hipEventDestroy(v->ev_b0);
     if (v->ev_b1) hipEventDestroy(v->ev_b1);
     if (v->ev_a) hipEventDestroy(v->ev_a);
@@ -408,6 +443,7 @@ int vimz_ivc_create(vimz_ctx* ctx, const vimz_circuit* step_circuit, const vimz_
     else if ((e = hipStreamCreateWithPriority(&v->s3, hipStreamNonBlocking, getenv("VIMZ_DEBUG_S3_PRIO") ? atoi(getenv("VIMZ_DEBUG_S3_PRIO")) : (lo + hi) / 2)) != hipSuccess) return fail("stream");
     if ((e = hipEventCreateWithFlags(&v->ev_fork, hipEventDisableTiming)) != hipSuccess) return fail("event");
     if ((e = hipEventCreateWithFlags(&v->ev_fold, hipEventDisableTiming)) != hipSuccess) return fail("event");
+    if ((e = hipEventCreateWithFlags(&v->ev_fused, hipEventDisableTiming)) != hipSuccess) return fail("event");
     if ((e = hipEventCreate(&v->ev_b0)) != hipSuccess || (e = hipEventCreate(&v->ev_b1)) != hipSuccess) return fail("event");
     if ((e = hipEventCreateWithFlags(&v->ev_a, hipEventDisableTiming)) != hipSuccess) return fail("event"); }
   if (!getenv("VIMZ_DEBUG_NO_SMALL_TABLES")) {

@@ -1,6 +1,7 @@
 // Internals of the Nova IVC object shared by ivc.hip (RecursiveSNARK::{new, prove_step, verify}) and spartan.hip
 // (CompressedSNARK::{prove, verify}).
 #pragma once
+#include <memory>
 #include "prover_internal.hpp"
 #include <type_traits>
 #include <cstdio>
@@ -59,6 +60,8 @@ struct vimz_ivc {
   // secondary half of that step and the host's verifier circuit
   hipStream_t s3 = nullptr; hipEvent_t ev_fold = nullptr; MsmWorkspace ws3;
   bool t1_step_pending = false;
+  hipEvent_t ev_fused = nullptr; bool fused_recorded = false;      // the fused fold + cross term of the step rows on stream 3 (k_fold_cross)
+  std::unique_ptr<aug::Worker> launcher;                           // queues the large MSM (a dozen launches) while the main thread queues the secondary half
   hipEvent_t ev_b0 = nullptr, ev_b1 = nullptr;   // profiling: GPU time of the secondary half on the main stream
   hipEvent_t ev_a = nullptr;                      // the primary half's results on the main stream are back
   // window tables (2^(7w)·P_i) of the three base slices the per-step small MSMs run over: verifier wires and verifier rows of

@@ -282,10 +282,7 @@ __global__ void __launch_bounds__(256) k_tree256(const uint32_t* __restrict__ in
   const uint32_t t = threadIdx.x, i = blockIdx.x * 256 + t;
   sh[t] = i < m ? load_xyzz<F>(in, i) : XYZZ<F>::identity();
   __syncthreads();
-  for (uint32_t d = 128; d > 0; d >>= 1) {
-    if (t < d) { XYZZ<F> a = sh[t]; add_full(a, sh[t + d]); sh[t] = a; }
-    __syncthreads();
-  }
+  quad_tree256<F>(sh);
   if (t == 0) store_xyzz(out, blockIdx.x, sh[0]);
 }
 
@@ -343,10 +340,7 @@ __global__ void __launch_bounds__(256) k_combine(uint32_t* __restrict__ partial,
       __syncthreads();
       sh[t] = acc;
       __syncthreads();
-      for (uint32_t d = 128; d > 0; d >>= 1) {
-        if (t < d) { XYZZ<F> a = sh[t]; add_full(a, sh[t + d]); sh[t] = a; }
-        __syncthreads();
-      }
+      quad_tree256<F>(sh);
       if (t == 0) store_xyzz(partial, s0, sh[0]);
     }
     return;
@@ -362,10 +356,7 @@ __global__ void __launch_bounds__(256) k_combine(uint32_t* __restrict__ partial,
     __syncthreads();
     sh[t] = acc;
     __syncthreads();
-    for (uint32_t d = 128; d > 0; d >>= 1) {
-      if (t < d) { XYZZ<F> a = sh[t]; add_full(a, sh[t + d]); sh[t] = a; }
-      __syncthreads();
-    }
+    quad_tree256<F>(sh);
     if (t == 0) store_xyzz(scratch, it, sh[0]);
   }
 }
@@ -382,9 +373,11 @@ __global__ void __launch_bounds__(256) k_combine_heavy2(uint32_t* __restrict__ p
   if (!__syncthreads_or(mine ? 1 : 0)) return;       // nothing split among this workgroup's eight buckets
   sh[t] = mine ? load_xyzz<F>(scratch, h * MSM_HEAVY_PARTS + lane) : XYZZ<F>::identity();
   __syncthreads();
+  // eight 32-lane trees side by side, four lanes per addition: 128 pairs (two rounds), then 64, 32, 16, 8
   for (uint32_t d = 16; d > 0; d >>= 1) {
-    if (lane < d) { XYZZ<F> a = sh[t]; add_full(a, sh[t + d]); sh[t] = a; }
-    __syncthreads();
+    const uint32_t pairs = 8 * d;
+    for (uint32_t base = 0; base < pairs; base += 64)
+      quad_level<F>(sh, min(64u, pairs - base), [=](uint32_t e) { return 32u * ((base + e) / d) + (base + e) % d; }, [=](uint32_t e) { return 32u * ((base + e) / d) + (base + e) % d + d; });
   }
   if (lane == 0 && mine) store_xyzz(partial, sub_off[heavy[1 + h]], sh[t]);
 }
@@ -424,7 +417,8 @@ __global__ void __launch_bounds__(256) k_reduce(const uint32_t* __restrict__ par
   __syncthreads();
   sh[t] = sum;
   __syncthreads();
-  for (uint32_t d = T >> 1; d > 0; d >>= 1) {
+  if (T == 256) quad_tree256<F>(sh);
+  else for (uint32_t d = T >> 1; d > 0; d >>= 1) {
     if (t < d) { XYZZ<F> a = sh[t]; add_full(a, sh[t + d]); sh[t] = a; }
     __syncthreads();
   }
@@ -596,6 +590,7 @@ __global__ void __launch_bounds__(64) k_msm_small_sum(const uint32_t* __restrict
 }
 
 // ---- host driver ---------------------------------------------------------------------------------
+
 
 // ---- window tables: one bucket set for all windows ---------------------------------------------------------------------
 // With T_j[i] = 2^(c·j)·P_i precomputed (the commitment key is fixed for the whole proof and HBM is plentiful), digit j of

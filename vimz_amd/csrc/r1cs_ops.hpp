@@ -165,6 +165,30 @@ __global__ void __launch_bounds__(256) k_cross_term(size_t n, const uint32_t* __
   }
 }
 
+// The step rows of a primary fold and of the next cross term in ONE pass, queued the moment a step's challenge r is known:
+//   (AZ, BZ, CZ) += r·(az, bz, cz) of the row just folded;  E += r·T (T: that row's cross term);
+//   T <- cross term of the folded products with the NEXT row's (az', bz', cz').
+// Everything is element-wise on row i, so the large MSM of the next step starts one 150 MB pass earlier than with k_fold5 followed by
+// k_cross_term (the error vector is not folded at step 0: there is no cross term yet).
+template <class F>
+__global__ void __launch_bounds__(256) k_fold_cross(size_t n, uint32_t* __restrict__ AZ, uint32_t* __restrict__ BZ, uint32_t* __restrict__ CZ, uint32_t* __restrict__ E,
+                                                    uint32_t* __restrict__ T, int fold_E, F r, F u1_new,
+                                                    const uint32_t* __restrict__ az, const uint32_t* __restrict__ bz, const uint32_t* __restrict__ cz,
+                                                    const uint32_t* __restrict__ azn, const uint32_t* __restrict__ bzn, const uint32_t* __restrict__ czn, F u2) {
+  VZ_GRID_STRIDE(i, n) {
+    const F a = F::add(load_fe<F>(AZ, i), F::mul(r, load_fe<F>(az, i)));
+    const F b = F::add(load_fe<F>(BZ, i), F::mul(r, load_fe<F>(bz, i)));
+    const F c = F::add(load_fe<F>(CZ, i), F::mul(r, load_fe<F>(cz, i)));
+    store_fe(AZ, i, a); store_fe(BZ, i, b); store_fe(CZ, i, c);
+    if (fold_E) store_fe(E, i, F::add(load_fe<F>(E, i), F::mul(r, load_fe<F>(T, i))));
+    F t = F::mul(a, load_fe<F>(bzn, i));
+    t = F::add(t, F::mul(load_fe<F>(azn, i), b));
+    t = F::sub(t, F::mul(u1_new, load_fe<F>(czn, i)));
+    t = F::sub(t, F::mul(u2, c));
+    store_fe(T, i, t);
+  }
+}
+
 // x1[i] += r * x2[i]
 template <class F>
 __global__ void __launch_bounds__(256) k_axpy_inplace(size_t n, uint32_t* __restrict__ x1, F r, const uint32_t* __restrict__ x2) {
