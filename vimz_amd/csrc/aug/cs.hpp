@@ -334,7 +334,9 @@ struct EcGadgets {
 
   // Native double-and-add chains of (2^nbits + k)·P for several (P, same k) at once, then every slope by two batched
   // inversions.  bits: the low nbits of the scalar (canonical words), the leading one is implicit.
-  struct ChainHints { std::vector<F> lam_d, lam_a; };
+  // wires: the 9·nbits values scalar_mul allocates inside its loop, in its order (x², λ_d, 2P, λ_a, 2P + P, the two selects'
+  // products) — the chain has them all at hand, so in witness mode the gadget only appends them;  last: the final accumulator
+  struct ChainHints { std::vector<F> lam_d, lam_a, wires; Affine<F> last; };
   static void chain_hints(const std::vector<Affine<F>>& Ps, const uint32_t* k, int nbits, std::vector<ChainHints>& out) {
     const size_t m = Ps.size();
     out.assign(m, ChainHints());
@@ -369,12 +371,21 @@ struct EcGadgets {
     batch_inv(den);
     for (size_t j = 0; j < m; j++) {
       out[j].lam_d.resize(nbits); out[j].lam_a.resize(nbits);
+      std::vector<F>& w = out[j].wires;
+      w.resize(9 * (size_t)nbits);
+      size_t o = 0;
       for (int i = nbits - 1; i >= 0; i--) {
         const size_t ix = j * nbits + i;
         const F xx = F::sqr(accs[ix].x);
         out[j].lam_d[i] = F::mul(F::add(F::dbl(xx), xx), den[2 * ix]);
         out[j].lam_a[i] = F::mul(F::sub(Ps[j].y, Da[ix].y), den[2 * ix + 1]);
+        const bool bit = (k[i >> 5] >> (i & 31)) & 1u;
+        w[o++] = xx; w[o++] = out[j].lam_d[i]; w[o++] = Da[ix].x; w[o++] = Da[ix].y;
+        w[o++] = out[j].lam_a[i]; w[o++] = Aa[ix].x; w[o++] = Aa[ix].y;
+        w[o++] = bit ? F::sub(Aa[ix].x, Da[ix].x) : F::zero();
+        w[o++] = bit ? F::sub(Aa[ix].y, Da[ix].y) : F::zero();
       }
+      out[j].last = (k[0] & 1u) ? Aa[j * nbits] : Da[j * nbits];
     }
   }
 
@@ -395,6 +406,10 @@ struct EcGadgets {
   Pt scalar_mul(const Pt& P, const std::vector<N>& bits, int nbits, const ChainHints& h) {
     XY Pe; Pe.x = cs.select(P.inf, cs.constant(G.x), P.x); Pe.y = cs.select(P.inf, cs.constant(G.y), P.y);
     XY acc = Pe;
+    if (!cs.b && h.wires.size() == 9 * (size_t)nbits) {       // witness mode: the chain's values, as computed with the slopes
+      cs.w.insert(cs.w.end(), h.wires.begin(), h.wires.end());
+      acc.x.v = h.last.x; acc.y.v = h.last.y; acc.x.konst = acc.y.konst = false;
+    } else
     for (int i = nbits - 1; i >= 0; i--) {
       XY d = dbl(acc, h.lam_d[i]);
       XY a = add_distinct(d, Pe, h.lam_a[i]);
