@@ -722,7 +722,8 @@ hipError_t msm_launch(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_ba
   *plan_out = pl;
   const size_t entries = (size_t)pl.K * n;
   // small MSMs are latency-bound (one dependent addition ~ 6-10 us): shorter chains per thread, more threads
-  const uint32_t sub = n < (1u << 15) ? 8u : (uint32_t)MSM_SUB;   // MSM_SUB for everything large
+  static const int sub_env = getenv("VIMZ_DEBUG_MSM_SUB") ? atoi(getenv("VIMZ_DEBUG_MSM_SUB")) : 0;
+  const uint32_t sub = n < (1u << 15) ? 8u : sub_env >= 4 && sub_env <= 64 ? (uint32_t)sub_env : (uint32_t)MSM_SUB;   // MSM_SUB for everything large
   const size_t max_subs = entries / sub + pl.nb + 1;
   VZ_HIP_CHECK(ws.reserve(pl.nb, entries, max_subs));
   const int TB = 256;
