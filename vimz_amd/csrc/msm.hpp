@@ -433,7 +433,12 @@ __global__ void __launch_bounds__(256) k_reduce(const uint32_t* __restrict__ par
 // segmented tree over a bucket's sub-buckets -> sum_b (b+1)·B_b as the sum of the 64 suffix sums (scan + tree, 12 deep) ->
 // the last workgroup of a window to finish adds the chunk results.  Depth: 8 + log2(max sub-buckets) + 12 + log2(chunks).
 // (SMALL_C, SMALL_CHUNK, SMALL_MAXQ, MSM_SMALL_MAX: msm_api.hpp)
-constexpr uint32_t SMALL_NBW = 1u << (SMALL_C - 1), SMALL_SUB = 8, SMALL_PER_THREAD = SMALL_CHUNK / 256;
+// 256 threads, one wave per SIMD.  (512 threads on half-length sub-buckets — two waves per SIMD, 210 VGPRs, no spills — measured
+// SLOWER: 0.251 vs 0.187 ms at 7.7 k points, 0.167 vs 0.145 ms for one chunk: the accumulation phase does not get shorter with a second
+// wave per SIMD, and the segment tree grows.)
+constexpr uint32_t SMALL_THREADS = 256;
+constexpr uint32_t SMALL_NBW = 1u << (SMALL_C - 1), SMALL_SUB = 8, SMALL_PER_THREAD = SMALL_CHUNK / SMALL_THREADS;
+static_assert(SMALL_CHUNK / SMALL_SUB + SMALL_NBW <= SMALL_THREADS, "one thread per sub-bucket");
 // (1536 points per workgroup: at most 1536/8 + 64 = 256 sub-buckets, one per thread; 7.6 k points -> 37 x 5 = 185 workgroups,
 //  fewer than the 256 CUs, so no two workgroups' single-wave scan phases share a SIMD)
 
@@ -448,16 +453,16 @@ __device__ __forceinline__ int signed_digit(const uint32_t* s, int c, int w) {
 }
 
 template <class S, class F>
-__global__ void __launch_bounds__(256) k_msm_small(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ scalars, uint32_t n, int mont,
+__global__ void __launch_bounds__(SMALL_THREADS) k_msm_small(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ scalars, uint32_t n, int mont,
                                                    uint32_t Q, uint32_t chunk, uint32_t* __restrict__ chunk_out /* K*Q points */,
                                                    uint32_t* __restrict__ done /* K counters, zero between launches; nullptr: k_msm_small_sum follows */,
                                                    uint32_t* __restrict__ window_sums,
                                                    const uint32_t* __restrict__ tables /* or nullptr: row w holds 2^(7w)·P_i, row length tstride */, uint32_t tstride) {
-  __shared__ XYZZ<F> sh[256];
+  __shared__ XYZZ<F> sh[SMALL_THREADS];
   __shared__ uint32_t cnt[SMALL_NBW], off[SMALL_NBW + 1], soff[SMALL_NBW + 1], cur[SMALL_NBW];
   __shared__ uint16_t list[SMALL_CHUNK];
-  __shared__ uint8_t subb[256];
-  __shared__ uint32_t s_maxm, s_ticket, wcnt[4];
+  __shared__ uint8_t subb[SMALL_THREADS];
+  __shared__ uint32_t s_maxm, s_ticket, wcnt[SMALL_THREADS / 64];
   // These waves sit on the critical path of a folding step while bulk kernels (the large MSM's accumulation, the batch
   // producer) fill the same SIMDs: raise their issue priority over the resident bulk waves.
   __builtin_amdgcn_s_setprio(3);
@@ -470,7 +475,7 @@ __global__ void __launch_bounds__(256) k_msm_small(const uint32_t* __restrict__ 
 #pragma unroll
   for (int k = 0; k < (int)SMALL_PER_THREAD; k++) {
     dig[k] = 0;
-    const uint32_t i = lo + t + 256u * k;
+    const uint32_t i = lo + t + SMALL_THREADS * k;
     if (i < hi) {
       uint32_t sc[8];
       if (load_scalar<S>(scalars, i, mont, 0, sc)) {
@@ -491,7 +496,7 @@ __global__ void __launch_bounds__(256) k_msm_small(const uint32_t* __restrict__ 
     if (dig[k]) {
       const uint32_t b = (uint32_t)(dig[k] < 0 ? -dig[k] : dig[k]) - 1;
       const uint32_t pos = atomicAdd(&cur[b], 1u);
-      list[off[b] + pos] = (uint16_t)((t + 256u * k) | (dig[k] < 0 ? 0x8000u : 0u));
+      list[off[b] + pos] = (uint16_t)((t + SMALL_THREADS * k) | (dig[k] < 0 ? 0x8000u : 0u));
     }
   }
   if (t < SMALL_NBW) for (uint32_t sb = soff[t]; sb < soff[t + 1]; sb++) subb[sb] = (uint8_t)t;
@@ -503,11 +508,15 @@ __global__ void __launch_bounds__(256) k_msm_small(const uint32_t* __restrict__ 
     const uint32_t b = subb[t];
     kk = t - soff[b]; mb = soff[b + 1] - soff[b];
     const uint32_t beg = off[b] + kk * SMALL_SUB, end = min(off[b + 1], beg + SMALL_SUB);
+    // (one wave per SIMD: nothing else hides the gather of an 80-byte table entry, so entry e+1 is in flight while e is added)
+    uint32_t ent = beg < end ? list[beg] : 0u;
+    Affine<F> pt = load_affine<F>(wbases, lo + (ent & 0x7fffu));
     for (uint32_t e = beg; e < end; e++) {
-      const uint32_t ent = list[e];
-      Affine<F> pt = load_affine<F>(wbases, lo + (ent & 0x7fffu));
+      const uint32_t ent_n = e + 1 < end ? list[e + 1] : ent;
+      const Affine<F> pt_n = load_affine<F>(wbases, lo + (ent_n & 0x7fffu));
       if ((ent & 0x8000u) && !aff_is_identity(pt)) pt.y = F::neg(pt.y);
       add_mixed(acc, pt);
+      ent = ent_n; pt = pt_n;
     }
   }
   sh[t] = acc;
@@ -520,7 +529,7 @@ __global__ void __launch_bounds__(256) k_msm_small(const uint32_t* __restrict__ 
     if ((t & 63) == 0) wcnt[t >> 6] = (uint32_t)__popcll(bal);
     __syncthreads();
     uint32_t before = 0, total = 0;
-    for (uint32_t wv = 0; wv < 4; wv++) { before += wv < (t >> 6) ? wcnt[wv] : 0u; total += wcnt[wv]; }
+    for (uint32_t wv = 0; wv < SMALL_THREADS / 64; wv++) { before += wv < (t >> 6) ? wcnt[wv] : 0u; total += wcnt[wv]; }
     if (act) list[before + (uint32_t)__popcll(bal & ((1ull << (t & 63)) - 1ull))] = (uint16_t)t;
     __syncthreads();
     for (uint32_t base = 0; base < total; base += 64)
@@ -702,7 +711,7 @@ hipError_t msm_launch(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_ba
     uint32_t* chunk_out = done + 128;
     if (ev) for (int i = 0; i < 4; i++) VZ_HIP_CHECK(hipEventRecord(ev[i], stream));
     static const bool sum_kernel = getenv("VIMZ_DEBUG_SMALL_SUM_KERNEL") != nullptr;
-    hipLaunchKernelGGL((k_msm_small<S, F>), dim3(ps.K, Q), dim3(256), 0, stream, d_bases, d_scalars, (uint32_t)n, scalars_mont, Q, chunk, chunk_out,
+    hipLaunchKernelGGL((k_msm_small<S, F>), dim3(ps.K, Q), dim3(SMALL_THREADS), 0, stream, d_bases, d_scalars, (uint32_t)n, scalars_mont, Q, chunk, chunk_out,
                        sum_kernel ? (uint32_t*)nullptr : done, reinterpret_cast<uint32_t*>(ws.window_sums),
                        small_tb ? tb->d + (size_t)AFFINE_WORDS * tb->offset : (const uint32_t*)nullptr, small_tb ? (uint32_t)tb->n_total : 0u);
     if (Q > 1 && sum_kernel) hipLaunchKernelGGL(k_msm_small_sum<F>, dim3(ps.K), dim3(64), 0, stream, chunk_out, Q, reinterpret_cast<uint32_t*>(ws.window_sums));
