@@ -310,16 +310,18 @@ def test_concurrent_provers_all_verify(oracle):
 @pytest.mark.gpu
 def test_proof_does_not_depend_on_the_schedule():
     """The same rows give the same proof (running instances, fresh instance, state) whichever way the step's work is spread over
-    streams, kernels and the host: default (three streams, fused small MSMs over window tables, large MSM queued ahead, the
+    streams, kernels and the host: default (three streams, fused small MSMs over window tables, large MSM queued behind the fused fold, the
     Poseidon jobs of a call's first eight rows evaluated on host threads) against no / a shorter host-evaluated head batch and the
-    debugging switches that serialise or replace each of those pieces.  Each variant runs in a process of its own (the switches
+    debugging switches that serialise or replace each of those pieces, and the lookahead schedule (the large MSM's cross term taken one
+    step ahead against the previous running instance and completed by the producer's fresh x fresh commitment).  Each variant runs in a process of its own (the switches
     are read once)."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     variants = [{}, {"VIMZ_HEAD_ROWS": "0"}, {"VIMZ_HEAD_ROWS": "3"}, {"VIMZ_DEBUG_NO_S2": "1"}, {"VIMZ_DEBUG_NO_SMALL_TABLES": "1"}, {"VIMZ_DEBUG_NO_SMALL_MSM": "1"},
-                {"VIMZ_DEBUG_SMALL_SUM_KERNEL": "1", "VIMZ_AUG_NO_THREADS": "1"}, {"VIMZ_DEBUG_SORT_BLOCKS": "256", "VIMZ_DEBUG_COMBINE_LANE_BITS": "4"}]
+                {"VIMZ_DEBUG_SMALL_SUM_KERNEL": "1", "VIMZ_AUG_NO_THREADS": "1"}, {"VIMZ_DEBUG_SORT_BLOCKS": "256", "VIMZ_DEBUG_COMBINE_LANE_BITS": "4"},
+                {"VIMZ_IVC_LOOKAHEAD": "1"}, {"VIMZ_DEBUG_NO_LAUNCHER": "1", "VIMZ_DEBUG_MSM_SUB": "8"}]
     lines = []
     for env in variants:
         out = subprocess.run([sys.executable, os.path.join(root, "tools", "ivc_digest.py"), "grayscale", "2"], capture_output=True, text=True,

@@ -66,26 +66,13 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
   char* pin_w2 = pin_aug1 + 32 * aw1;
   const Fq zero_q = Fq::zero();
 
-  // cross term of the step rows of (running instance, fresh row `row` of batch buffer `b2`) and its commitment, on stream 3
-  // behind everything queued on the main stream so far (the fold that produced the running instance)
-  // With `fuse` (the row just folded, its challenge): the fold of the step rows' running products and error vector rides in the same
-  // pass (k_fold_cross) and nothing is waited for but the next row's products.
-  struct FusedFold { const uint32_t *az, *bz, *cz; Fe rho; bool fold_E; };
-  static const bool no_fuse = getenv("VIMZ_DEBUG_NO_FUSED_FOLD") != nullptr;
+  // ---- the step rows' cross term and its commitment (the one large MSM of a step), on stream 3 ------------------------------------
   static const bool use_launcher = std::thread::hardware_concurrency() > 2 && !getenv("VIMZ_DEBUG_NO_LAUNCHER");
-  auto launch_T1_step = [&](decltype(p->buf[0])& b2, size_t row, bool record, const FusedFold* fuse) -> int {
-    if (record) P_TRY(hipEventRecord(v->ev_fold, s));
-    if (!fuse) P_TRY(hipStreamWaitEvent(v->s3, v->ev_fold, 0));
-    P_TRY(hipStreamWaitEvent(v->s3, b2.ev[row], 0));
-    if (fuse) {
-      hipLaunchKernelGGL(k_fold_cross<Fr>, dim3(stream_grid(sc)), dim3(256), 0, v->s3, sc, p->AZ, p->BZ, p->CZ, p->E, p->T, fuse->fold_E ? 1 : 0, fuse->rho, v->u1_run,
-                         fuse->az, fuse->bz, fuse->cz, b2.az + 8 * row * nc, b2.bz + 8 * row * nc, b2.cz + 8 * row * nc, Fe::one());
-      P_TRY(hipEventRecord(v->ev_fused, v->s3)); v->fused_recorded = true;
-    } else
-    hipLaunchKernelGGL(k_cross_term<Fr>, dim3(stream_grid(sc)), dim3(256), 0, v->s3, sc, p->AZ, p->BZ, p->CZ, v->u1_run,
-                       b2.az + 8 * row * nc, b2.bz + 8 * row * nc, b2.cz + 8 * row * nc, Fe::one(), p->T);
-    P_TRY(hipGetLastError());
-    // base-range split: the first share stays here, helper h commits to rows [off_h, off_h + n_h) with its replica of the key
+  typedef vimz_prover::BatchBuf BufRef;
+  // commitment to the vector of slot `par` (base-range split: the first share stays here, helper h commits to rows [off_h, off_h + n_h)
+  // with its replica of the key)
+  auto queue_msm = [&](int par) -> int {
+    auto& S = v->t1[par];
     const size_t parts = v->helpers.size() + 1, share = (sc + parts - 1) / parts;
     v->t1_main_n = std::min(share, sc);
     if (!v->helpers.empty()) {
@@ -96,30 +83,104 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
         if (!h.n) continue;
         P_TRY(hipSetDevice(h.ctx->device));
         P_TRY(hipStreamWaitEvent(h.s, v->ev_T, 0));
-        P_TRY(hipMemcpyAsync(h.T, p->T + 8 * h.off, 32 * h.n, hipMemcpyDefault, h.s));
+        P_TRY(hipMemcpyAsync(h.T, S.buf + 8 * h.off, 32 * h.n, hipMemcpyDefault, h.s));
         P_TRY(msm_launch<BnG1>(h.s, h.ws, h.ck->d + (size_t)AFFINE_WORDS * h.off, h.T, h.n, 1, 0, h.pin, &h.plan, nullptr, 0, nullptr));
       }
       P_TRY(hipSetDevice(ctx->device));
     }
-    P_TRY(msm_launch<BnG1>(v->s3, v->ws3, p->ck->d, p->T, v->t1_main_n, 1, 0, v->pin + v->pin_res, &v->plan_T1, ctx->profiling ? ctx->ev : nullptr, 0,
+    P_TRY(msm_launch<BnG1>(v->s3, v->ws3, p->ck->d, S.buf, v->t1_main_n, 1, 0, S.pin, &S.plan, ctx->profiling ? S.ev : nullptr, 0,
                            p->ck->tables && v->helpers.empty() ? &job.tbl : nullptr));
-    if (ctx->profiling) P_TRY(hipMemcpyAsync(v->pin + v->pin_totals, v->ws3.totals, 8, hipMemcpyDeviceToHost, v->s3));   // (pinned: stays asynchronous)
-    v->t1_step_pending = true;
+    if (ctx->profiling) P_TRY(hipMemcpyAsync(S.pin + v->pin_res, v->ws3.totals, 8, hipMemcpyDeviceToHost, v->s3));   // (pinned: stays asynchronous)
+    P_TRY(hipEventRecord(S.done, v->s3));
+    return VIMZ_OK;
+  };
+  // the cross term of step `step` = row `row` of `b2` against the running instance as it is now (first row of a call)
+  auto launch_direct = [&](BufRef& b2, size_t row, uint64_t step) -> int {
+    auto& S = v->t1[step & 1];
+    P_TRY(hipEventRecord(v->ev_fold, s));
+    P_TRY(hipStreamWaitEvent(v->s3, v->ev_fold, 0));
+    P_TRY(hipStreamWaitEvent(v->s3, b2.ev[row], 0));
+    hipLaunchKernelGGL(k_cross_term<Fr>, dim3(stream_grid(sc)), dim3(256), 0, v->s3, sc, p->AZ, p->BZ, p->CZ, v->u1_run,
+                       b2.az + 8 * row * nc, b2.bz + 8 * row * nc, b2.cz + 8 * row * nc, Fe::one(), S.buf);
+    P_TRY(hipGetLastError());
+    S.step = (int64_t)step; S.hasB = false;
+    return queue_msm((int)(step & 1));
+  };
+  // When step i's challenge is known: k_fold_cross folds the step rows (running products, error vector) and writes the cross term(s)
+  // that come next —  `next1` (row i+1, against the running instance it will meet: needed unless a lookahead produced it already)
+  // and/or `next2` (row i+2 against the running instance of step i+1: the lookahead, completed by −rho_{i+1}·negB_{i+2} when used).
+  struct RowAt { BufRef* b; size_t row; };
+  struct FoldArgs { uint64_t i; BufRef* cur; size_t r; Fe rho; bool need1; RowAt next1; bool look; RowAt next2; };
+  auto launch_fold_and_cross = [&](const FoldArgs& a) -> int {
+    const int par = (int)(a.i & 1);
+    auto& Scur = v->t1[par]; auto& Soth = v->t1[par ^ 1];
+    const bool fold_E = a.i > 0, hasB = fold_E && Scur.hasB;
+    const uint32_t *az = a.cur->az + 8 * a.r * nc, *bz = a.cur->bz + 8 * a.r * nc, *cz = a.cur->cz + 8 * a.r * nc;
+    if (hasB) P_TRY(hipStreamWaitEvent(v->s3, a.cur->ev_d[a.r], 0));
+    // first output of the pass: next1 into the other slot if it is needed, else the lookahead into this slot (read, then overwritten)
+    const RowAt* t = a.need1 ? &a.next1 : a.look ? &a.next2 : nullptr;
+    uint32_t* out = a.need1 ? Soth.buf : a.look ? Scur.buf : nullptr;
+    if (t) P_TRY(hipStreamWaitEvent(v->s3, t->b->ev[t->row], 0));
+    hipLaunchKernelGGL(k_fold_cross<Fr>, dim3(stream_grid(sc)), dim3(256), 0, v->s3, sc, p->AZ, p->BZ, p->CZ, p->E, (const uint32_t*)Scur.buf, fold_E ? 1 : 0, a.rho,
+                       hasB ? 1 : 0, v->rho_prev, hasB ? (const uint32_t*)(a.cur->d + 8 * a.r * sc) : (const uint32_t*)nullptr, v->u1_run, az, bz, cz,
+                       out, t ? t->b->az + 8 * t->row * nc : nullptr, t ? t->b->bz + 8 * t->row * nc : nullptr, t ? t->b->cz + 8 * t->row * nc : nullptr, Fe::one());
+    P_TRY(hipGetLastError());
+    if (a.need1 && a.look) {      // both (the first step of a call): the lookahead as a pass of its own, after this slot's vector was read
+      P_TRY(hipStreamWaitEvent(v->s3, a.next2.b->ev[a.next2.row], 0));
+      hipLaunchKernelGGL(k_cross_term<Fr>, dim3(stream_grid(sc)), dim3(256), 0, v->s3, sc, p->AZ, p->BZ, p->CZ, v->u1_run,
+                         a.next2.b->az + 8 * a.next2.row * nc, a.next2.b->bz + 8 * a.next2.row * nc, a.next2.b->cz + 8 * a.next2.row * nc, Fe::one(), Scur.buf);
+      P_TRY(hipGetLastError());
+    }
+    P_TRY(hipEventRecord(v->ev_fused, v->s3)); v->fused_recorded = true;
+    if (a.need1) { Soth.step = (int64_t)a.i + 1; Soth.hasB = false; int rc2 = queue_msm(par ^ 1); if (rc2) return rc2; }
+    if (a.look) { Scur.step = (int64_t)a.i + 2; Scur.hasB = true; int rc2 = queue_msm(par); if (rc2) return rc2; }
+    return VIMZ_OK;
+  };
+  // ---- the batch producer's launches (some forty per row, sixty with the lookahead's commitment) come from a thread of their own: issued
+  // from this one, a whole batch at a time, they held every step up by 0.15-0.23 ms on average.  Batch b may be issued once its IVC
+  // states exist and this thread allows it (`allowed` > b: the buffer it overwrites has been folded and the streams told to wait).
+  std::atomic<size_t> allowed{0}, issued{job.next_issue};
+  std::atomic<int> issuer_rc{VIMZ_OK};
+  std::atomic<bool> issuer_stop{false};
+  std::thread issuer([&, b0 = job.next_issue] {
+    if (hipSetDevice(ctx->device) != hipSuccess) { issuer_rc = VIMZ_ERR_HIP; return; }
+    for (size_t b = b0; b < job.nbatches; b++) {
+      const size_t need = job.first(b) + job.rows(b);
+      while (allowed.load(std::memory_order_acquire) <= b || job.states_upto.load(std::memory_order_acquire) < need) {
+        if (issuer_stop.load()) return;
+        if (job.helper_done.load() && job.states_upto.load() < need) { issuer_rc = job.helper_rc ? job.helper_rc : VIMZ_ERR_HIP; return; }
+        std::this_thread::yield();
+      }
+      const int rc2 = fold_issue(p, job, b);
+      if (rc2) { issuer_rc = rc2; return; }
+      issued.store(b + 1, std::memory_order_release);
+    }
+  });
+  struct IssuerJoin { std::thread& t; std::atomic<bool>& stop; ~IssuerJoin() { stop = true; if (t.joinable()) t.join(); } } issuer_join{issuer, issuer_stop};
+  auto wait_issued = [&](size_t b) -> int {
+    const double t_wait = now_s(); uint64_t spins = 0;
+    while (issued.load(std::memory_order_acquire) <= b) {
+      const int irc = issuer_rc.load();
+      if (irc) { if (ctx->err.empty()) ctx->err = job.helper_err.empty() ? std::string("fold: the batch producer stopped early") : job.helper_err; return irc; }
+      std::this_thread::yield();
+      if ((++spins & 0xfffff) == 0 && now_s() - t_wait > 120.0) return vz_fail(ctx, VIMZ_ERR_HIP, "fold: batch not issued within 120 s");
+    }
     return VIMZ_OK;
   };
   for (size_t k = 0; k < job.nbatches; k++) {
     auto& bb = p->buf[k & 1];
     const size_t first = job.first(k), rows = job.rows(k);
     double t0 = now_s();
-    if ((rc = fold_issue_when_ready(p, job, k, true))) return rc;            // (batch 0 of a head-batch call is already out)
-    if ((rc = fold_issue_when_ready(p, job, k + 1, false))) return rc;       // the next batch is produced while this one is folded
+    allowed.store(k + 2, std::memory_order_release);       // the next batch is produced while this one is folded
+    if ((rc = wait_issued(k))) return rc;                  // (batch 0 of a head-batch call is already out)
     P_TRY(hipEventSynchronize(bb.wit_done));
     v->ph_s[IP_PRODUCER] += now_s() - t0;
     if (k == 0) { t_wait0 = now_s() - t0; t_first = now_s() - t_all; }
     for (size_t r = 0; r < rows; r++) if (bb.status_host[r]) {
       char msg[128]; snprintf(msg, sizeof(msg), "step %llu: the step relation is not satisfiable for these rows", (unsigned long long)(v->i + r));
       hipStreamSynchronize(p->sB);
-      hipStreamSynchronize(v->s3); v->t1_step_pending = false;     // (the step rows of this batch's first row were queued ahead)
+      if (p->sD) hipStreamSynchronize(p->sD);
+      hipStreamSynchronize(v->s3); v->t1[0].step = v->t1[1].step = -1;     // (cross terms of this batch's rows were queued ahead)
       // the batches folded so far stay folded: leave the IVC consistent at that point (state, pending secondary commitments)
       finish_secondary(v);
       for (uint32_t q = 0; q < p->len_z; q++) p->z_cur[q] = zs[first * p->len_z + q];
@@ -127,7 +188,6 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
     }
     for (size_t r = 0; r < rows; r++) {
       const uint64_t i = v->i;
-      if ((rc = fold_issue_when_ready(p, job, k + 1, false))) return rc;
       uint32_t* Zi = bb.Z + 8 * r * nw;
       uint32_t *az = bb.az + 8 * r * nc, *bz = bb.bz + 8 * r * nc, *cz = bb.cz + 8 * r * nc;
       // ---- 1. the previous fresh secondary instance is complete once its two MSMs are back -------------------------------------
@@ -158,7 +218,7 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
                          Zi, az, bz, cz, i > 0 ? p->AZ : nullptr, p->BZ, p->CZ, v->u1_run, Fe::one(), p->T);
       P_TRY(hipGetLastError());
       if (i > 0) {
-        if (!v->t1_step_pending && (rc = launch_T1_step(bb, r, true, nullptr))) return rc;       // first row of a call: nothing was queued ahead
+        if (v->t1[i & 1].step != (int64_t)i && (rc = launch_direct(bb, r, i))) return rc;       // first row of a call: nothing was queued ahead
         P_TRY(msm_launch<BnG1>(s, ctx->msm_ws, p->ck->d + (size_t)AFFINE_WORDS * sc, p->T + 8 * sc, nc - sc, 1, 0, v->pin + 4 * v->pin_res, &v->plan_T1v, nullptr, 0, v->tb_T1v.d ? &v->tb_T1v : nullptr));
       }
       P_TRY(hipEventRecord(v->ev_a, s));
@@ -182,9 +242,12 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
       // the large MSM's host tail (Horner over 24 window sums, ≈0.1 ms) is taken whenever its stream turns out to be done:
       // before the small ones if it already is, so that it overlaps what is still running
       G1Aff T1_step; bool t1_step_done = false;
+      auto& slot = v->t1[i & 1];
       auto take_T1_step = [&](bool wait) {
         if (t1_step_done || i == 0) return hipSuccess;
-        hipError_t q = wait ? hipStreamSynchronize(v->s3) : hipStreamQuery(v->s3);
+        // (polled: hipEventSynchronize on this event — recorded by the launcher thread, no timing — returned 0.3 ms late)
+        hipError_t q = hipEventQuery(slot.done);
+        if (wait) while (q == hipErrorNotReady) { std::this_thread::yield(); q = hipEventQuery(slot.done); }
         if (q == hipErrorNotReady) return hipSuccess;
         if (q != hipSuccess) return q;
         for (auto& h : v->helpers) {
@@ -193,15 +256,28 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
           if (q == hipErrorNotReady) return hipSuccess;
           if (q != hipSuccess) return q;
         }
-        T1_step = msm_finish<BnG1>(v->plan_T1, v->pin + v->pin_res);
+        T1_step = msm_finish<BnG1>(slot.plan, slot.pin);
         if (!v->helpers.empty()) {                      // host-side sum of the partial commitments (<= 8 points)
           G1 acc = from_affine(T1_step);
           for (auto& h : v->helpers) if (h.n) { const G1Aff part = msm_finish<BnG1>(h.plan, h.pin); add_mixed(acc, part); }
           T1_step = to_affine(acc);
         }
-        t1_step_done = true; v->t1_step_pending = false;
+        t1_step_done = true;
         return hipSuccess;
       };
+      // A lookahead cross term was taken against the running instance one step back: the commitment is completed by
+      // rho_{i-1}·comm(T(u_{i-1}, u_i)) = −rho_{i-1}·comm(negB_i) — one 129-bit scalar multiplication on the host, done here, while
+      // the device works on the verifier rows (the producer committed to negB_i long ago)
+      G1 lookB = G1::identity();
+      if (i > 0 && slot.hasB) {
+        P_TRY(hipEventSynchronize(bb.ev_d[r]));
+        const G1Aff cD = msm_finish<BnG1>(p->planD, (char*)bb.pin_d + r * pin_stride);
+        if (!aff_is_identity(cD)) {
+          G1 acc = from_affine(cD);                       // the leading one of rho = 2^128 + low
+          for (int bit = 127; bit >= 0; bit--) { acc = dbl(acc); if ((v->rho_prev_low[bit >> 5] >> (bit & 31)) & 1u) add_mixed(acc, cD); }
+          lookB = acc;
+        }
+      }
       P_TRY(take_T1_step(false));
       P_TRY(hipStreamSynchronize(v->s2));
       G1Aff cW_aug = msm_finish<BnG1>(v->plan_aug, v->pin);      // the small MSM is back first: its tail overlaps the other one
@@ -229,6 +305,7 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
         P_TRY(take_T1_step(true));
         v->ph_s[IP_WAIT_PRI] += now_s() - t0;
         G1 ts = from_affine(T1_step); add_mixed(ts, Tv);
+        if (slot.hasB) { G1 nb = lookB; if (!nb.is_identity()) nb.Y = Fq::neg(nb.Y); add_full(ts, nb); }
         T1 = to_affine(ts);
         t0 = now_s();
       }
@@ -252,9 +329,9 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
       }
       if (i > 0 && ctx->profiling) {       // HIP-event durations of the phases of this MSM(T), accumulated for the roofline figure
         float ms[6];
-        for (int q = 0; q < 6; q++) { P_TRY(hipEventElapsedTime(&ms[q], ctx->ev[q], ctx->ev[q + 1])); ctx->last_msm.ms[q] = ms[q]; ctx->msm_tot_ms[q] += ms[q]; }
-        memcpy(&ctx->last_msm.subs, v->pin + v->pin_totals, 8);
-        ctx->last_msm.c = v->plan_T1.c; ctx->last_msm.K = v->plan_T1.K;
+        for (int q = 0; q < 6; q++) { P_TRY(hipEventElapsedTime(&ms[q], slot.ev[q], slot.ev[q + 1])); ctx->last_msm.ms[q] = ms[q]; ctx->msm_tot_ms[q] += ms[q]; }
+        memcpy(&ctx->last_msm.subs, slot.pin + v->pin_res, 8);
+        ctx->last_msm.c = slot.plan.c; ctx->last_msm.K = slot.plan.K;
         ctx->msm_tot_calls++; ctx->msm_tot_points += v->t1_main_n; ctx->msm_tot_entries += ctx->last_msm.entries;
       }
       // ---- 4. secondary verifier circuit on the host: folds (U1, u1) ---------------------------------------------------------------------
@@ -264,44 +341,48 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
       if (bad) return vz_fail(ctx, VIMZ_ERR_UNSAT, "secondary verifier circuit: inconsistent incoming instance");
       v->ph_s[IP_SYNTH2] += now_s() - t0; v->ph_n[IP_SYNTH2]++;
       t0 = now_s();
-      bool t1_queued = false; int launcher_rc = VIMZ_OK; FusedFold ff{};
+      int launcher_rc = VIMZ_OK; FoldArgs fa{};
       struct WaitGuard { aug::Worker* w = nullptr; ~WaitGuard() { if (w) w->wait(); } } launching;      // (an early return must not leave the helper with this frame)
       {
         const Fe rho1 = rho_element<Fe>(o2.rho_low);
-        // the row whose step rows' cross term is wanted next (none after the last row of a call)
-        decltype(&bb) nb = nullptr; size_t nrow = 0;
-        if (r + 1 < rows) { nb = &bb; nrow = r + 1; }
-        else if (k + 1 < job.nbatches) {
-          if ((rc = fold_issue_when_ready(p, job, k + 1, true))) return rc;      // its per-row events must have been recorded in this call
-          nb = &p->buf[(k + 1) & 1]; nrow = 0;
+        // the rows whose step rows' cross terms come next: row i+1 (unless a lookahead produced its cross term already) and, one whole
+        // step ahead, row i+2 — if its batch is out and the producer differenced it against row i+1 (fold_issue_d)
+        auto row_at = [&](size_t ahead, RowAt* out) -> int {
+          out->b = nullptr; out->row = 0;
+          if (r + ahead < rows) { out->b = &bb; out->row = r + ahead; return VIMZ_OK; }
+          if (k + 1 >= job.nbatches || r + ahead - rows >= job.rows(k + 1)) return VIMZ_OK;
+          int rc2 = wait_issued(k + 1);      // its per-row events must have been recorded
+          if (rc2) return rc2;
+          out->b = &p->buf[(k + 1) & 1]; out->row = r + ahead - rows;
+          return VIMZ_OK;
+        };
+        fa.i = i; fa.cur = &bb; fa.r = r; fa.rho = rho1;
+        if ((rc = row_at(1, &fa.next1))) return rc;
+        fa.need1 = fa.next1.b && v->t1[(i + 1) & 1].step != (int64_t)i + 1;
+        fa.look = false;
+        if (fa.next1.b && v->lookahead && v->helpers.empty() && p->want_d) {
+          if ((rc = row_at(2, &fa.next2))) return rc;
+          fa.look = fa.next2.b && fa.next2.b->has_d[fa.next2.row];
         }
-        const bool fuse = nb && !no_fuse;
-        const size_t lo = fuse ? sc : 0;       // fused: the step rows of E, AZ, BZ, CZ are folded by k_fold_cross on stream 3
+        // the witness and the verifier rows (everything k_fold_cross does not touch)
         Fold5 f;
         f.x1[0] = p->Zrun; f.x2[0] = Zi; f.n[0] = nw;
-        f.x1[1] = i > 0 ? p->E + 8 * lo : nullptr; f.x2[1] = p->T + 8 * lo; f.n[1] = nc - lo;
-        f.x1[2] = p->AZ + 8 * lo; f.x2[2] = az + 8 * lo; f.n[2] = nc - lo;
-        f.x1[3] = p->BZ + 8 * lo; f.x2[3] = bz + 8 * lo; f.n[3] = nc - lo;
-        f.x1[4] = p->CZ + 8 * lo; f.x2[4] = cz + 8 * lo; f.n[4] = nc - lo;
+        f.x1[1] = i > 0 ? p->E + 8 * sc : nullptr; f.x2[1] = p->T + 8 * sc; f.n[1] = nc - sc;
+        f.x1[2] = p->AZ + 8 * sc; f.x2[2] = az + 8 * sc; f.n[2] = nc - sc;
+        f.x1[3] = p->BZ + 8 * sc; f.x2[3] = bz + 8 * sc; f.n[3] = nc - sc;
+        f.x1[4] = p->CZ + 8 * sc; f.x2[4] = cz + 8 * sc; f.n[4] = nc - sc;
         v->u1_run = Fe::add(v->u1_run, rho1);
-        if (fuse) {
-          // the next step's large MSM is the longest dependent chain of a step: it is queued at once, on stream 3 — by a helper
-          // thread (a dozen launches, 40-60 µs of host time), while this one queues the secondary half
-          ff = FusedFold{az, bz, cz, rho1, i > 0};
-          if (use_launcher) {
-            if (!v->launcher) v->launcher.reset(new aug::Worker());
-            launcher_rc = VIMZ_OK;
-            v->launcher->start([&, nb, nrow] { if (hipSetDevice(ctx->device) != hipSuccess) { launcher_rc = VIMZ_ERR_HIP; return; } launcher_rc = launch_T1_step(*nb, nrow, false, &ff); });
-            launching.w = v->launcher.get();
-          } else if ((rc = launch_T1_step(*nb, nrow, false, &ff))) return rc;
-          t1_queued = true;
-        }
-        // (measured: on stream 3, where the large MSM follows, it runs at that stream's lower priority and delays the MSM by more
-        // than the secondary half gains)
+        // the large MSM(s) that follow are queued at once, on stream 3 — by a helper thread (a dozen launches, 40-60 µs of host time),
+        // while this one queues the secondary half
+        if (use_launcher) {
+          if (!v->launcher) v->launcher.reset(new aug::Worker());
+          v->launcher->start([&] { if (hipSetDevice(ctx->device) != hipSuccess) { launcher_rc = VIMZ_ERR_HIP; return; } launcher_rc = launch_fold_and_cross(fa); });
+          launching.w = v->launcher.get();
+        } else if ((rc = launch_fold_and_cross(fa))) return rc;
         // on stream 2, idle until the secondary witness is uploaded: this pass overlaps that upload instead of preceding it
         // (everything it reads is complete — the host has waited for all three streams)
-        hipLaunchKernelGGL(k_fold5<Fr>, dim3(fuse ? 512 : 2048), dim3(256), 0, v->s2, f, rho1);
-        P_TRY(hipEventRecord(v->ev_fold, v->s2));  // the verifier rows of the next step (and, unfused, its large MSM) may start here
+        hipLaunchKernelGGL(k_fold5<Fr>, dim3(512), dim3(256), 0, v->s2, f, rho1);
+        P_TRY(hipEventRecord(v->ev_fold, v->s2));  // the verifier rows of the next step may start here
       }
       v->U1 = o2.U_new;
       // fresh secondary instance on the device: [1 | z_out | z_in | verifier wires]
@@ -325,10 +406,7 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
         v->pending_sec = true;
       }
       if (launching.w) { launching.w->wait(); launching.w = nullptr; if (launcher_rc) return launcher_rc; }
-      if (!t1_queued) {
-        if (r + 1 < rows) { if ((rc = launch_T1_step(bb, r + 1, false, nullptr))) return rc; }
-        else if (k + 1 < job.nbatches) { if ((rc = launch_T1_step(p->buf[(k + 1) & 1], 0, false, nullptr))) return rc; }
-      }
+      v->rho_prev = rho_element<Fe>(o2.rho_low); memcpy(v->rho_prev_low, o2.rho_low, sizeof(v->rho_prev_low));
       v->ph_s[IP_LAUNCH] += now_s() - t0;
       v->i++; p->steps++;
     }
@@ -336,11 +414,14 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
     P_TRY(hipStreamSynchronize(s));
     P_TRY(hipStreamSynchronize(v->s2));
     P_TRY(hipEventSynchronize(v->ev_fold));
-    if (v->fused_recorded) P_TRY(hipEventSynchronize(v->ev_fused));
+    // (the fused fold of the last row sits on stream 3 behind up to two large MSMs: the producers wait for it, not the host)
+    if (v->fused_recorded) { P_TRY(hipStreamWaitEvent(p->sB, v->ev_fused, 0)); P_TRY(hipStreamWaitEvent(p->sH, v->ev_fused, 0)); }
   }
   if ((rc = finish_secondary(v))) return rc;
   P_TRY(hipStreamSynchronize(p->sB));
+  if (p->sD) P_TRY(hipStreamSynchronize(p->sD));
   P_TRY(hipStreamSynchronize(v->s3));
+  v->t1[0].step = v->t1[1].step = -1;
   for (uint32_t k = 0; k < p->len_z; k++) p->z_cur[k] = zs[nsteps * p->len_z + k];
   v->ph_s[IP_TOTAL] += now_s() - t_all; v->ph_n[IP_TOTAL] += nsteps;
   if (dbg_timing) fprintf(stderr, "[timing] fold of %zu steps: %.1f ms (prepare %.1f, first batch ready at %.1f after waiting %.1f)\n", nsteps, 1e3 * (now_s() - t_all), 1e3 * t_prep, 1e3 * t_first, 1e3 * t_wait0);
@@ -369,6 +450,9 @@ void vimz_ivc_free(vimz_ivc* v) {
     if (v->ev_fork) hipEventDestroy(v->ev_fork);
     if (v->ev_fold) hipEventDestroy(v->ev_fold);
     if (v->ev_fused) hipEventDestroy(v->ev_fused);
+    for (int q = 0; q < 2; q++) if (v->t1[q].done) hipEventDestroy(v->t1[q].done);
+    for (int q = 0; q < 7; q++) if (v->ev_alt[q]) hipEventDestroy(v->ev_alt[q]);
+    if (v->pin_t1b) hipHostFree(v->pin_t1b);
     if (v->ev_b0) hipEventDestroy(v->ev_b0);
     if (v->ev_b1) hipEventDestroy(v->ev_b1);
     if (v->ev_a) hipEventDestroy(v->ev_a);
@@ -469,6 +553,17 @@ int vimz_ivc_create(vimz_ctx* ctx, const vimz_circuit* step_circuit, const vimz_
   v->pin_res = 4 * (size_t)XYZZ_WORDS * MSM_MAX_WINDOWS;
   v->pin_totals = 5 * v->pin_res + 32 * (size_t)v->c1->aug_wires() + 32 * (size_t)nw2;
   if ((e = hipHostMalloc((void**)&v->pin, v->pin_totals + 64)) != hipSuccess) return fail("pinned");
+  // the two slots of the step rows' cross term (T1Slot): vector, pinned window sums + totals, events
+  if ((e = hipHostMalloc((void**)&v->pin_t1b, 2 * (v->pin_res + 64))) != hipSuccess) return fail("pinned");
+  for (int q = 0; q < 2; q++) {
+    if (dalloc(&v->t1[q].buf, 32 * (size_t)v->c1->step_constraints) != hipSuccess) return fail("device allocation");
+    if ((e = hipEventCreateWithFlags(&v->t1[q].done, hipEventDisableTiming)) != hipSuccess) return fail("event");
+    v->t1[q].pin = v->pin_t1b + q * (v->pin_res + 64);
+  }
+  for (int q = 0; q < 7; q++) if ((e = hipEventCreate(&v->ev_alt[q])) != hipSuccess) return fail("event");
+  v->t1[0].ev = ctx->ev; v->t1[1].ev = v->ev_alt;
+  v->lookahead = ivc_lookahead_enabled();
+  v->pri->want_d = v->lookahead;
   if ((e = hipStreamSynchronize(nullptr)) != hipSuccess) return fail("sync");   // the hipMemset fills above ran on the null stream
   v->z0.assign(v->c1->len_z, Fe::zero());
   v->U1 = RelaxedInst<Fq>::zero(); v->U2 = RelaxedInst<Fe>::zero(); v->u2 = FreshInst<Fe>::zero(); v->T2.x = v->T2.y = Fe::zero();
@@ -515,7 +610,7 @@ int vimz_ivc_reset(vimz_ivc* v, const uint64_t* z0) {
   for (uint32_t k = 0; k < v->c1->len_z; k++) v->z0[k] = v->pri->z_cur[k];
   v->U1 = RelaxedInst<Fq>::zero(); v->U2 = RelaxedInst<Fe>::zero(); v->u2 = FreshInst<Fe>::zero(); v->T2.x = v->T2.y = Fe::zero();
   v->u1_run = Fe::zero(); v->u2_run = Fq::zero();
-  v->pending_sec = false; v->sec_T_valid = false; v->t1_step_pending = false;
+  v->pending_sec = false; v->sec_T_valid = false; v->t1[0].step = v->t1[1].step = -1;
   memset(v->ph_s, 0, sizeof(v->ph_s)); memset(v->ph_n, 0, sizeof(v->ph_n));
   return VIMZ_OK;
 }
@@ -796,7 +891,7 @@ int vimz_ivc_proof_import(vimz_ivc* v, const uint8_t* blob, size_t len) {
   p->z0 = v->z0;
   v->i = h.steps; p->steps = h.steps;
   v->U2 = hs.U2; v->U1 = hs.U1; v->u2 = hs.u2; v->T2 = hs.T2; v->u1_run = hs.u1_run; v->u2_run = hs.u2_run;
-  v->sec_T_valid = (h.flags & 1) != 0; v->pending_sec = false; v->t1_step_pending = false;
+  v->sec_T_valid = (h.flags & 1) != 0; v->pending_sec = false; v->t1[0].step = v->t1[1].step = -1;
   v->c1->cache = aug::AugCache<Fe>(); v->c2.cache = aug::AugCache<Fq>();
   return VIMZ_OK;
 }

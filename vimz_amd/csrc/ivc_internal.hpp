@@ -52,14 +52,21 @@ struct vimz_ivc {
   std::vector<void*> owned;
   char* pin = nullptr;                            // pinned: 5 MSM results, then staging for the two host-made witnesses
   size_t pin_res = 0, pin_totals = 0;
-  MsmPlan plan_aug{}, plan_T1{}, plan_T1v{}, plan_W2{}, plan_T2{};
+  MsmPlan plan_aug{}, plan_T1v{}, plan_W2{}, plan_T2{};
   // the witness commitment and the cross-term commitment of one instance are independent: they run side by side
   hipStream_t s2 = nullptr; hipEvent_t ev_fork = nullptr; MsmWorkspace ws2;
   // the step rows of the primary cross term need the folded running instance and the producer's products only — not the
   // verifier circuit of their step: they are queued on a third stream right behind the previous fold and run under the
   // secondary half of that step and the host's verifier circuit
   hipStream_t s3 = nullptr; hipEvent_t ev_fold = nullptr; MsmWorkspace ws3;
-  bool t1_step_pending = false;
+  // The step rows' cross term of step i (against the running instance of step i, or — lookahead — of step i-1) lives in slot i & 1:
+  // its vector, the pinned window sums and plan of its commitment, the events of that MSM.  step = the step it belongs to (-1: none).
+  struct T1Slot { int64_t step = -1; bool hasB = false; uint32_t* buf = nullptr; char* pin = nullptr; MsmPlan plan{}; hipEvent_t done = nullptr; hipEvent_t* ev = nullptr; };
+  T1Slot t1[2];
+  hipEvent_t ev_alt[7] = {};       // profiling events of slot 1 (slot 0 uses the context's)
+  char* pin_t1b = nullptr;         // pinned window sums (+ totals) of slot 1
+  bool lookahead = false;          // step i+2's cross term against the running instance of step i+1 (VIMZ_IVC_LOOKAHEAD=1); off with MSM helpers
+  Fe rho_prev = Fe::zero(); uint32_t rho_prev_low[4] = {};      // the previous step's folding challenge
   hipEvent_t ev_fused = nullptr; bool fused_recorded = false;      // the fused fold + cross term of the step rows on stream 3 (k_fold_cross)
   std::unique_ptr<aug::Worker> launcher;                           // queues the large MSM (a dozen launches) while the main thread queues the secondary half
   hipEvent_t ev_b0 = nullptr, ev_b1 = nullptr;   // profiling: GPU time of the secondary half on the main stream

@@ -133,7 +133,15 @@ struct vimz_prover {
     uint32_t* status_host = nullptr;      // pinned
     std::vector<hipEvent_t> ev;           // per row: fresh-instance work done
     hipEvent_t wit_done = nullptr;
+    // IVC lookahead (want_d): per row minus the fresh x fresh cross term with the row before it, and its commitment (fold_issue_d)
+    uint32_t* d = nullptr; void* pin_d = nullptr;
+    std::vector<hipEvent_t> ev_p, ev_d;   // per row: (A,B,C)·z done on the producer's stream; the commitment to d done on stream sD
+    std::vector<uint8_t> has_d;
   } buf[2];
+  bool want_d = false;
+  hipStream_t sD = nullptr;      // = sH, the head batch's stream, idle for the rest of a call (a stream of its own — a sixth — shifted the
+                                 // streams' hardware queues and cost one proof 10 %, with nothing ever queued on it)
+  MsmWorkspace wsD; MsmPlan planD{};
   MsmWorkspace wsB;
   MsmPlan planB{};
   // head batch of a fold call: Poseidon jobs evaluated on the host, everything else on a stream of its own (fold_head_batch)
@@ -345,6 +353,36 @@ static size_t head_rows_wanted() {
   return v < 0 ? 0 : (size_t)v;
 }
 
+// The IVC's lookahead schedule (ivc.hip) is an option: VIMZ_IVC_LOOKAHEAD=1 (read once).  It takes the large MSM off a
+// step's dependent chains at the price of one more (cheap) commitment per row from the producer; measured 563 against 607 steps/s for
+// one proof at contrast HD — the producer's two low-priority streams then run at the pace of the folds and the proof waits for rows.
+static bool ivc_lookahead_enabled() { static const bool v = getenv("VIMZ_IVC_LOOKAHEAD") && atoi(getenv("VIMZ_IVC_LOOKAHEAD")) != 0; return v; }
+
+// IVC lookahead: row r of batch k gets negB = −T(previous row, this row) over the step rows and its commitment, on stream sD behind
+// the row's (A,B,C)·z (`sp`: the stream that just computed them).  The previous row is the one before it in the batch, or the last
+// row of the batch before (the other buffer — still intact: it is rewritten by batch k+1, whose producer waits for this).
+static int fold_issue_d(vimz_prover* p, const FoldJob& J, size_t k, size_t r, hipStream_t sp) {
+  vimz_ctx* ctx = p->ctx;
+  auto& bb = p->buf[k & 1];
+  bb.has_d[r] = 0;
+  if (!p->want_d) return VIMZ_OK;
+  const size_t nc = p->n_c, sc = p->step_c;
+  const uint32_t *az0, *bz0, *cz0;
+  if (r > 0) { az0 = bb.az + 8 * (r - 1) * nc; bz0 = bb.bz + 8 * (r - 1) * nc; cz0 = bb.cz + 8 * (r - 1) * nc; }
+  else if (k > 0) { auto& ob = p->buf[(k - 1) & 1]; const size_t lr = J.rows(k - 1) - 1; az0 = ob.az + 8 * lr * nc; bz0 = ob.bz + 8 * lr * nc; cz0 = ob.cz + 8 * lr * nc; }
+  else return VIMZ_OK;        // first row of a call: its cross term is computed against the running instance directly
+  P_TRY(hipEventRecord(bb.ev_p[r], sp));
+  P_TRY(hipStreamWaitEvent(p->sD, bb.ev_p[r], 0));
+  uint32_t* d = bb.d + 8 * r * sc;
+  hipLaunchKernelGGL(k_fresh_cross_neg<Fr>, dim3(stream_grid(sc)), dim3(256), 0, p->sD, sc, az0, bz0, cz0, bb.az + 8 * r * nc, bb.bz + 8 * r * nc, bb.cz + 8 * r * nc, d);
+  P_TRY(hipGetLastError());
+  P_TRY(msm_launch<BnG1>(p->sD, p->wsD, p->ck->d, d, sc, 1, 0, (char*)bb.pin_d + r * FoldJob::pin_stride, &p->planD, nullptr, 1, nullptr));
+  P_TRY(hipEventRecord(bb.ev_d[r], p->sD));
+  bb.has_d[r] = 1;
+  return VIMZ_OK;
+}
+
+
 // HEAD BATCH.  A fold call cannot start folding before the first rows' witnesses exist, and those contain the row-hash Poseidon
 // chains: 17 dependent permutations, 10 ms on the GPU whatever the row count (one wave per chain, ~0.6 ms per permutation) but
 // 1.1 ms on a CPU core (66 µs per permutation).  So the Poseidon jobs of the first few rows of a call are evaluated on host
@@ -427,6 +465,7 @@ static int fold_head_batch(vimz_prover* p, FoldJob& J, size_t rows) {
   for (size_t r = 0; r < rows; r++) {
     const uint32_t* Zi = bb.Z + 8 * r * nw;
     launch_spmv(p, sh, Zi, bb.az + 8 * r * nc, bb.bz + 8 * r * nc, bb.cz + 8 * r * nc, 1);
+    { int rc = fold_issue_d(p, J, 0, r, sh); if (rc) return rc; }
     P_TRY(msm_launch<BnG1>(sh, p->wsH, p->ck->d, Zi + 8 * (size_t)p->c0, sw - p->c0, 1, 0, (char*)bb.pin + r * FoldJob::pin_stride, &p->planB, nullptr, 1, p->ck->tables ? &J.tbl : nullptr));
     P_TRY(hipEventRecord(bb.ev[r], sh));
   }
@@ -631,6 +670,8 @@ static int fold_issue(vimz_prover* p, const FoldJob& J, size_t k) {
   const size_t first = J.first(k), rows = J.rows(k);
   hipStream_t sb = p->sB;
   if (J.head && k == 1) P_TRY(hipStreamWaitEvent(sb, p->ev_head, 0));      // (orders the two MSM workspaces' users; the head batch is long done)
+  // this batch overwrites the buffer of batch k-2, whose last row the first row of batch k-1 was differenced against (fold_issue_d)
+  if (p->want_d && k >= 1 && p->buf[(k - 1) & 1].has_d[0]) P_TRY(hipStreamWaitEvent(sb, p->buf[(k - 1) & 1].ev_d[0], 0));
   const bool started = (int)k == J.started_batch;      // (its status words already hold the decompositions' range checks)
   if (!started) P_TRY(hipMemsetAsync(bb.status, 0, 4 * rows, sb));
   if (J.witnesses) {
@@ -646,6 +687,7 @@ static int fold_issue(vimz_prover* p, const FoldJob& J, size_t k) {
   for (size_t r = 0; r < rows; r++) {
     const uint32_t* Zi = bb.Z + 8 * r * nw;
     launch_spmv(p, sb, Zi, bb.az + 8 * r * nc, bb.bz + 8 * r * nc, bb.cz + 8 * r * nc, 1);
+    { int rc = fold_issue_d(p, J, k, r, sb); if (rc) return rc; }
     P_TRY(msm_launch<BnG1>(sb, p->wsB, p->ck->d, Zi + 8 * (size_t)p->c0, sw - p->c0, 1, 0, (char*)bb.pin + r * FoldJob::pin_stride, &p->planB, nullptr, 1, p->ck->tables ? &J.tbl : nullptr));
     P_TRY(hipEventRecord(bb.ev[r], sb));
   }

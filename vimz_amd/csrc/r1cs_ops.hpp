@@ -165,27 +165,49 @@ __global__ void __launch_bounds__(256) k_cross_term(size_t n, const uint32_t* __
   }
 }
 
-// The step rows of a primary fold and of the next cross term in ONE pass, queued the moment a step's challenge r is known:
-//   (AZ, BZ, CZ) += r·(az, bz, cz) of the row just folded;  E += r·T (T: that row's cross term);
-//   T <- cross term of the folded products with the NEXT row's (az', bz', cz').
-// Everything is element-wise on row i, so the large MSM of the next step starts one 150 MB pass earlier than with k_fold5 followed by
-// k_cross_term (the error vector is not folded at step 0: there is no cross term yet).
+// The step rows of a primary fold and of a later cross term in ONE pass, queued the moment a step's challenge r is known:
+//   (AZ, BZ, CZ) += r·(az, bz, cz) of the row just folded;
+//   E += r·T,  T = Tin − hasB·r_prev·negB the cross term of that row (see below; no error vector is folded at step 0);
+//   out <- cross term of the folded products with a coming row's (az', bz', cz')      (out may be Tin: element-wise, read first).
+// Lookahead (ivc.hip): the cross term of step i+2 is computed against the running instance of step i+1, one whole step early —
+// T(U + r·u, u') = T(U, u') + r·T(u, u') — so the vector actually folded into E is Tin + r_prev·T(u_prev, u) = Tin − r_prev·negB.
 template <class F>
 __global__ void __launch_bounds__(256) k_fold_cross(size_t n, uint32_t* __restrict__ AZ, uint32_t* __restrict__ BZ, uint32_t* __restrict__ CZ, uint32_t* __restrict__ E,
-                                                    uint32_t* __restrict__ T, int fold_E, F r, F u1_new,
+                                                    const uint32_t* Tin, int fold_E, F r, int hasB, F r_prev, const uint32_t* __restrict__ negB, F u1_new,
                                                     const uint32_t* __restrict__ az, const uint32_t* __restrict__ bz, const uint32_t* __restrict__ cz,
-                                                    const uint32_t* __restrict__ azn, const uint32_t* __restrict__ bzn, const uint32_t* __restrict__ czn, F u2) {
+                                                    uint32_t* out, const uint32_t* __restrict__ azn, const uint32_t* __restrict__ bzn, const uint32_t* __restrict__ czn, F u2) {
   VZ_GRID_STRIDE(i, n) {
     const F a = F::add(load_fe<F>(AZ, i), F::mul(r, load_fe<F>(az, i)));
     const F b = F::add(load_fe<F>(BZ, i), F::mul(r, load_fe<F>(bz, i)));
     const F c = F::add(load_fe<F>(CZ, i), F::mul(r, load_fe<F>(cz, i)));
     store_fe(AZ, i, a); store_fe(BZ, i, b); store_fe(CZ, i, c);
-    if (fold_E) store_fe(E, i, F::add(load_fe<F>(E, i), F::mul(r, load_fe<F>(T, i))));
-    F t = F::mul(a, load_fe<F>(bzn, i));
-    t = F::add(t, F::mul(load_fe<F>(azn, i), b));
-    t = F::sub(t, F::mul(u1_new, load_fe<F>(czn, i)));
-    t = F::sub(t, F::mul(u2, c));
-    store_fe(T, i, t);
+    if (fold_E) {
+      F t = load_fe<F>(Tin, i);
+      if (hasB) t = F::sub(t, F::mul(r_prev, load_fe<F>(negB, i)));
+      store_fe(E, i, F::add(load_fe<F>(E, i), F::mul(r, t)));
+    }
+    if (out) {
+      F t = F::mul(a, load_fe<F>(bzn, i));
+      t = F::add(t, F::mul(load_fe<F>(azn, i), b));
+      t = F::sub(t, F::mul(u1_new, load_fe<F>(czn, i)));
+      t = F::sub(t, F::mul(u2, c));
+      store_fe(out, i, t);
+    }
+  }
+}
+
+// MINUS the cross term of two fresh instances (u = 1 both):  negB = c0 + c1 − a0·b1 − a1·b0.  For satisfied rows (c = a·b) this is
+// (a1 − a0)·(b1 − b0): between two consecutive image rows 80 % zeros, 15 % ones and the 13 k Poseidon rows (measured on the sample
+// image) — a vector whose commitment costs a twentieth of a dense one (the unit scalars are summed directly, MSM `split_ones`).
+template <class F>
+__global__ void __launch_bounds__(256) k_fresh_cross_neg(size_t n, const uint32_t* __restrict__ az0, const uint32_t* __restrict__ bz0, const uint32_t* __restrict__ cz0,
+                                                         const uint32_t* __restrict__ az1, const uint32_t* __restrict__ bz1, const uint32_t* __restrict__ cz1,
+                                                         uint32_t* __restrict__ out) {
+  VZ_GRID_STRIDE(i, n) {
+    F t = F::add(load_fe<F>(cz0, i), load_fe<F>(cz1, i));
+    t = F::sub(t, F::mul(load_fe<F>(az0, i), load_fe<F>(bz1, i)));
+    t = F::sub(t, F::mul(load_fe<F>(az1, i), load_fe<F>(bz0, i)));
+    store_fe(out, i, t);
   }
 }
 
