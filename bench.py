@@ -82,13 +82,13 @@ def cpu_baseline(circuit, steps, z0, ck_host, budget_s, threads):
             run = [w, a2, b2, c2, np.zeros_like(a2), 1]
             continue
         t = time.time()
-        T = orc.cross_term(0, run[1], run[2], run[3], run[5], a2, b2, c2, 1)
+        T = orc.cross_term(0, run[1], run[2], run[3], run[5], a2, b2, c2, 1, threads=threads)
         ph["cross_term"] += time.time() - t; t = time.time()
         _, cT = orc.msm_mont_timed(0, key_m, T, threads)
         ph["msm_t"] += time.time() - t; t = time.time()
         r = (cT[0] ^ cW[0]) & ((1 << 128) - 1)        # any 128-bit challenge: the arithmetic cost does not depend on it
-        run = [orc.axpy(0, run[0], r, w), orc.axpy(0, run[1], r, a2), orc.axpy(0, run[2], r, b2), orc.axpy(0, run[3], r, c2),
-               orc.axpy(0, run[4], r, T), (run[5] + r) % orc.modulus[0]]
+        run = [orc.axpy(0, run[0], r, w, threads), orc.axpy(0, run[1], r, a2, threads), orc.axpy(0, run[2], r, b2, threads), orc.axpy(0, run[3], r, c2, threads),
+               orc.axpy(0, run[4], r, T, threads), (run[5] + r) % orc.modulus[0]]
         ph["folds"] += time.time() - t
     dt = time.time() - t0
     return n / dt, dt, n, {k: v / max(1, n) for k, v in ph.items()}

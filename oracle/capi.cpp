@@ -85,6 +85,15 @@ static long r1cs_check_relaxed_t(size_t nrows, size_t ncols, const uint32_t* con
   return -1;
 }
 
+template <class Fn>
+static void par_chunks(size_t n, int threads, Fn fn) {
+  const size_t T = threads > 1 ? (size_t)threads : 1, chunk = (n + T - 1) / T;
+  if (T == 1) { fn((size_t)0, n); return; }
+  std::vector<std::thread> th;
+  for (size_t t = 0; t < T; t++) { const size_t lo = std::min(n, t * chunk), hi = std::min(n, lo + chunk); if (lo < hi) th.emplace_back(fn, lo, hi); }
+  for (auto& x : th) x.join();
+}
+
 extern "C" {
 
 // ---------------- fields ----------------
@@ -209,6 +218,30 @@ void orc_cross_term(int fid, size_t n, const u64* az1, const u64* bz1, const u64
 }
 void orc_axpy(int fid, size_t n, const u64* a, const u64* r, const u64* b, u64* out) {
   FIELD_SWITCH(fid, { VEC(F, aa, a, n); VEC(F, bb, b, n); std::vector<F> o(n); axpy<F>(n, aa.data(), F::from_canonical(r), bb.data(), o.data()); OUT(o, out); });
+}
+// The same two vector operations over `threads` host threads, conversions included (the CPU baseline of bench.py times them on all
+// cores; the single-threaded forms above are what the parity tests call).
+void orc_cross_term_mt(int fid, size_t n, const u64* az1, const u64* bz1, const u64* cz1, const u64* u1,
+                       const u64* az2, const u64* bz2, const u64* cz2, const u64* u2, u64* T, int threads) {
+  FIELD_SWITCH(fid, {
+    const F U1 = F::from_canonical(u1); const F U2 = F::from_canonical(u2);
+    par_chunks(n, threads, [&](size_t lo, size_t hi) {
+      for (size_t i = lo; i < hi; i++) {
+        const F a1 = F::from_canonical(az1 + 4 * i); const F b1 = F::from_canonical(bz1 + 4 * i); const F c1 = F::from_canonical(cz1 + 4 * i);
+        const F a2 = F::from_canonical(az2 + 4 * i); const F b2 = F::from_canonical(bz2 + 4 * i); const F c2 = F::from_canonical(cz2 + 4 * i);
+        F t; cross_term<F>(1, &a1, &b1, &c1, U1, &a2, &b2, &c2, U2, &t);
+        t.to_canonical(T + 4 * i);
+      }
+    });
+  });
+}
+void orc_axpy_mt(int fid, size_t n, const u64* a, const u64* r, const u64* b, u64* out, int threads) {
+  FIELD_SWITCH(fid, {
+    const F R = F::from_canonical(r);
+    par_chunks(n, threads, [&](size_t lo, size_t hi) {
+      for (size_t i = lo; i < hi; i++) { const F x = F::from_canonical(a + 4 * i); const F y = F::from_canonical(b + 4 * i); F o; axpy<F>(1, &x, R, &y, &o); o.to_canonical(out + 4 * i); }
+    });
+  });
 }
 // returns -1 if Az∘Bz == u·Cz + E for every row, else the first failing row.  E may be NULL (= 0).
 long orc_first_unsat(int fid, size_t n, const u64* az, const u64* bz, const u64* cz, const u64* u, const u64* E) {

@@ -209,17 +209,24 @@ class Oracle:
                           _p(np.ascontiguousarray(z, dtype=np.uint64)), _p(out), threads)
         return out
 
-    def cross_term(self, fid, az1, bz1, cz1, u1, az2, bz2, cz2, u2):
+    def cross_term(self, fid, az1, bz1, cz1, u1, az2, bz2, cz2, u2, threads=1):
         n = az1.size // 4
         T = np.zeros((n, 4), dtype=np.uint64)
         c = lambda a: _p(np.ascontiguousarray(a, dtype=np.uint64))
-        self.lib.orc_cross_term(fid, C.c_size_t(n), c(az1), c(bz1), c(cz1), _p(to_limbs([u1])), c(az2), c(bz2), c(cz2), _p(to_limbs([u2])), _p(T))
+        if threads > 1:
+            self.lib.orc_cross_term_mt(fid, C.c_size_t(n), c(az1), c(bz1), c(cz1), _p(to_limbs([u1])), c(az2), c(bz2), c(cz2), _p(to_limbs([u2])), _p(T), threads)
+        else:
+            self.lib.orc_cross_term(fid, C.c_size_t(n), c(az1), c(bz1), c(cz1), _p(to_limbs([u1])), c(az2), c(bz2), c(cz2), _p(to_limbs([u2])), _p(T))
         return T
 
-    def axpy(self, fid, a, r, b):
+    def axpy(self, fid, a, r, b, threads=1):
         n = a.size // 4
         o = np.zeros((n, 4), dtype=np.uint64)
-        self.lib.orc_axpy(fid, C.c_size_t(n), _p(np.ascontiguousarray(a, dtype=np.uint64)), _p(to_limbs([r])), _p(np.ascontiguousarray(b, dtype=np.uint64)), _p(o))
+        args = (fid, C.c_size_t(n), _p(np.ascontiguousarray(a, dtype=np.uint64)), _p(to_limbs([r])), _p(np.ascontiguousarray(b, dtype=np.uint64)), _p(o))
+        if threads > 1:
+            self.lib.orc_axpy_mt(*args, threads)
+        else:
+            self.lib.orc_axpy(*args)
         return o
 
     def first_unsat(self, fid, az, bz, cz, u=1, E=None):
