@@ -311,7 +311,7 @@ def test_concurrent_provers_all_verify(oracle):
 def test_proof_does_not_depend_on_the_schedule():
     """The same rows give the same proof (running instances, fresh instance, state) whichever way the step's work is spread over
     streams, kernels and the host: default (three streams, fused small MSMs over window tables, large MSM queued behind the fused fold, the
-    Poseidon jobs of a call's first eight rows evaluated on host threads) against no / a shorter host-evaluated head batch and the
+    Poseidon jobs of a call's first 24 rows evaluated on host threads) against no / a shorter host-evaluated head batch and the
     debugging switches that serialise or replace each of those pieces, and the lookahead schedule (the large MSM's cross term taken one
     step ahead against the previous running instance and completed by the producer's fresh x fresh commitment).  Each variant runs in a process of its own (the switches
     are read once)."""

@@ -151,7 +151,9 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
         if (job.helper_done.load() && job.states_upto.load() < need) { issuer_rc = job.helper_rc ? job.helper_rc : VIMZ_ERR_HIP; return; }
         std::this_thread::yield();
       }
+      const double _ti = now_s();
       const int rc2 = fold_issue(p, job, b);
+      if (dbg_timing) fprintf(stderr, "[timing] producer: batch %zu (%zu rows): ready at %.1f ms, issue took %.1f ms\n", b, job.rows(b), 1e3 * (_ti - t_all), 1e3 * (now_s() - _ti));
       if (rc2) { issuer_rc = rc2; return; }
       issued.store(b + 1, std::memory_order_release);
     }

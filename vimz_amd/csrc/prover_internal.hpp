@@ -348,8 +348,11 @@ static void plan_batches(FoldJob& J, size_t first, size_t n, size_t B) {
 static int fold_issue(vimz_prover* p, const FoldJob& J, size_t k);
 
 // Rows of a call whose Poseidon jobs are evaluated on the host (VIMZ_HEAD_ROWS overrides; 0 switches the head batch off).
+// 24: the first GPU-produced batch needs one Poseidon-chain latency on the low-priority producer stream — 10 ms alone, 16-18 ms
+// next to the first folds — and 8 head rows were folded after 14 ms (driver window of 20 rows: 530 steps/s with 8, 580-594 with 20-24,
+// 513-596 with 32-48; 256-row window 609 -> 628).
 static size_t head_rows_wanted() {
-  static const long v = getenv("VIMZ_HEAD_ROWS") ? atol(getenv("VIMZ_HEAD_ROWS")) : 8;
+  static const long v = getenv("VIMZ_HEAD_ROWS") ? atol(getenv("VIMZ_HEAD_ROWS")) : 24;
   return v < 0 ? 0 : (size_t)v;
 }
 
