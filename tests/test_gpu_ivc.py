@@ -322,9 +322,14 @@ def test_proof_does_not_depend_on_the_schedule():
     variants = [{}, {"VIMZ_HEAD_ROWS": "0"}, {"VIMZ_HEAD_ROWS": "3"}, {"VIMZ_DEBUG_NO_S2": "1"}, {"VIMZ_DEBUG_NO_SMALL_TABLES": "1"}, {"VIMZ_DEBUG_NO_SMALL_MSM": "1"},
                 {"VIMZ_DEBUG_SMALL_SUM_KERNEL": "1", "VIMZ_AUG_NO_THREADS": "1"}, {"VIMZ_DEBUG_SORT_BLOCKS": "256", "VIMZ_DEBUG_COMBINE_LANE_BITS": "4"},
                 {"VIMZ_IVC_LOOKAHEAD": "1"}, {"VIMZ_DEBUG_NO_LAUNCHER": "1", "VIMZ_DEBUG_MSM_SUB": "8"}]
+    # (the lookahead also with batches of two and three rows and no host-evaluated head: every way a row two steps ahead can fall into
+    #  the same batch, the next one, or not exist)
+    variants += [{"VIMZ_IVC_LOOKAHEAD": "1", "VIMZ_HEAD_ROWS": "0", "_batch": "2"}, {"VIMZ_IVC_LOOKAHEAD": "1", "VIMZ_HEAD_ROWS": "0", "_batch": "3"}]
     lines = []
     for env in variants:
-        out = subprocess.run([sys.executable, os.path.join(root, "tools", "ivc_digest.py"), "grayscale", "2"], capture_output=True, text=True,
+        env = dict(env)
+        batch = env.pop("_batch", "8")
+        out = subprocess.run([sys.executable, os.path.join(root, "tools", "ivc_digest.py"), "grayscale", "2", batch], capture_output=True, text=True,
                              timeout=600, env={**os.environ, **env})
         assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
         line = [l for l in out.stdout.splitlines() if l.startswith("digest ")][-1]

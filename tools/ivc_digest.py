@@ -3,7 +3,7 @@
 proof consists of (both running instances, the last fresh secondary instance, the state), plus the verification code.
 The proof is a deterministic function of the inputs, whatever the schedule: tests/test_gpu_ivc.py runs this under the
 library's debugging switches (serial streams, no fused small MSM, no window tables, ...) and compares the lines.
-usage: ivc_digest.py [transformation] [repeats]"""
+usage: ivc_digest.py [transformation] [repeats] [max_batch]"""
 import hashlib
 import sys
 
@@ -18,6 +18,7 @@ from vimz_amd.circuit import Circuit  # noqa: E402
 def main():
     t = sys.argv[1] if len(sys.argv) > 1 else "hash"
     rep = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+    max_batch = int(sys.argv[3]) if len(sys.argv) > 3 else 8
     z0, inputs = step_inputs(t)
     rows = np.concatenate([np.stack(inputs)] * rep)
     ctx = hip.Context(0)
@@ -27,7 +28,7 @@ def main():
         n *= 2
     ck = ctx.bases_generate(L.CURVE_BN254_G1, n)
     ck2 = ctx.bases_generate(L.CURVE_GRUMPKIN, 8192, b"ck-secondary")
-    ivc = hip.IVC(ctx, c, ck, ck2, max_batch=8)
+    ivc = hip.IVC(ctx, c, ck, ck2, max_batch=max_batch)
     ivc.reset(z0)
     ivc.fold(rows[:7])          # two calls: the second starts without a queued large MSM
     ivc.fold(rows[7:])
