@@ -94,6 +94,27 @@ def cpu_baseline(circuit, steps, z0, ck_host, budget_s, threads):
     return n / dt, dt, n, {k: v / max(1, n) for k, v in ph.items()}
 
 
+def usable_cores():
+    """Host cores this process may actually use: the CPU affinity mask capped by the cgroup's CPU quota (the GPU boxes show 256 logical
+    CPUs and grant 16: threads beyond the quota only get the whole group throttled)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            quota, period = open(path).read().split()[:2]
+            if quota != "max":
+                n = min(n, max(1, int(quota) // int(period)))
+        except (OSError, ValueError):
+            pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            n = min(n, max(1, q // per))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def _ints(limbs):
     return [int(a[0]) | int(a[1]) << 64 | int(a[2]) << 128 | int(a[3]) << 192 for a in limbs]
 
@@ -308,11 +329,11 @@ def main_ivc(args, rank, world, dist, torch, ctxs, circuit, params, steps_all, g
                          "step_algorithmic_bytes": step_bytes, "step_hbm_frac": step_bytes / (dt / max(1, timed_rows)) / 1e9 / HBM_PEAK_GBPS},
         }
         if not args.no_cpu_baseline and world == 1:      # the CPU baseline is timed at N = 1 only
-            cores = os.cpu_count() or 1
+            cores = usable_cores()
             ck_host = params.ck.download(0, max(circuit.n_constraints, circuit.n_wires))
             sps, secs, n_cpu, cph = cpu_baseline(circuit, mine, starts[0], ck_host, args.cpu_seconds, cores)
             out["cpu_baseline"] = {"value": sps, "unit": "steps/s", "cores": cores, "kind": "port",
-                                   "sample": f"{n_cpu} folding steps of the step circuit's instances with the CPU oracle (C++ restatement, std::thread over all cores for SpMV / MSM / vector ops, "
+                                   "sample": f"{n_cpu} folding steps of the step circuit's instances with the CPU oracle (C++ restatement, std::thread over the usable cores (affinity and cgroup quota) for SpMV / MSM / vector ops, "
                                              f"witness executor single-threaded; not the Rust binary; without the augmented circuits, i.e. less work per step than the GPU number), {secs:.1f} s",
                                    "seconds_per_step_by_phase": cph}
         print(json.dumps(out), flush=True)
@@ -493,11 +514,11 @@ def main():
                          "step_algorithmic_bytes": step_bytes, "step_hbm_frac": step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBPS},
         }
         if not args.no_cpu_baseline and world == 1:      # the CPU baseline is timed at N = 1 only
-            cores = os.cpu_count() or 1
+            cores = usable_cores()
             ck_host = params.ck.download(0, max(n_c, n_w))
             sps, secs, n_cpu, cph = cpu_baseline(circuit, mine, z_start, ck_host, args.cpu_seconds, cores)
             out["cpu_baseline"] = {"value": sps, "unit": "steps/s", "cores": cores, "kind": "port",
-                                   "sample": f"{n_cpu} folding steps of the same workload with the CPU oracle (C++ restatement, std::thread over all cores; not the Rust binary), {secs:.1f} s",
+                                   "sample": f"{n_cpu} folding steps of the same workload with the CPU oracle (C++ restatement, std::thread over the usable cores (affinity and cgroup quota); not the Rust binary), {secs:.1f} s",
                                    "seconds_per_step_by_phase": cph}
         print(json.dumps(out), flush=True)
     for p_ in provers:

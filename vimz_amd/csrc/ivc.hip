@@ -67,7 +67,8 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
   const Fq zero_q = Fq::zero();
 
   // ---- the step rows' cross term and its commitment (the one large MSM of a step), on stream 3 ------------------------------------
-  static const bool use_launcher = std::thread::hardware_concurrency() > 2 && !getenv("VIMZ_DEBUG_NO_LAUNCHER");
+  // (a helper thread for these launches measured no gain once the producer had its issuer thread, and costs a spinning core)
+  static const bool use_launcher = getenv("VIMZ_DEBUG_LAUNCHER") != nullptr;
   typedef vimz_prover::BatchBuf BufRef;
   // commitment to the vector of slot `par` (base-range split: the first share stays here, helper h commits to rows [off_h, off_h + n_h)
   // with its replica of the key)
@@ -149,7 +150,9 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
       while (allowed.load(std::memory_order_acquire) <= b || job.states_upto.load(std::memory_order_acquire) < need) {
         if (issuer_stop.load()) return;
         if (job.helper_done.load() && job.states_upto.load() < need) { issuer_rc = job.helper_rc ? job.helper_rc : VIMZ_ERR_HIP; return; }
-        std::this_thread::yield();
+        // (a batch is wanted a whole batch of folds after it may be issued: sleeping polls, not a spinning core — the GPU boxes
+        // grant a process 16 CPUs and throttle the whole group beyond that)
+        std::this_thread::sleep_for(std::chrono::microseconds(100));
       }
       const double _ti = now_s();
       const int rc2 = fold_issue(p, job, b);
