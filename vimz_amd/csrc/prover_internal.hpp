@@ -347,6 +347,27 @@ static void plan_batches(FoldJob& J, size_t first, size_t n, size_t B) {
 
 static int fold_issue(vimz_prover* p, const FoldJob& J, size_t k);
 
+// Host CPUs this process can really use: what the OS shows, capped by the cgroup's CPU quota (cpu.max / cfs_quota_us).  A GPU box shows
+// 256 logical CPUs and grants 16; threads beyond the quota get the whole process throttled for the rest of a 100 ms period.
+static unsigned usable_cpus() {
+  static const unsigned v = [] {
+    unsigned n = std::max(1u, std::thread::hardware_concurrency());
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+      char q[32] = {0}; long per = 0;
+      if (fscanf(f, "%31s %ld", q, &per) == 2 && strcmp(q, "max") != 0 && per > 0) { const long k = atol(q) / per; if (k >= 1) n = std::min<unsigned>(n, (unsigned)k); }
+      fclose(f);
+    } else if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+      long quota = -1, per = 100000;
+      if (fscanf(g, "%ld", &quota) != 1) quota = -1;
+      fclose(g);
+      if (FILE* h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(h, "%ld", &per) != 1) per = 100000; fclose(h); }
+      if (quota > 0 && per > 0 && quota / per >= 1) n = std::min<unsigned>(n, (unsigned)(quota / per));
+    }
+    return n;
+  }();
+  return v;
+}
+
 // Rows of a call whose Poseidon jobs are evaluated on the host (VIMZ_HEAD_ROWS overrides; 0 switches the head batch off).
 // 24: the first GPU-produced batch needs one Poseidon-chain latency on the low-priority producer stream — 10 ms alone, 16-18 ms
 // next to the first folds — and 8 head rows were folded after 14 ms (driver window of 20 rows: 530 steps/s with 8, 580-594 with 20-24,
@@ -411,7 +432,7 @@ static int fold_head_batch(vimz_prover* p, FoldJob& J, size_t rows) {
     p->head_rows_cap = cap_rows;
   }
   if (!p->pool) {
-    const unsigned hw = std::thread::hardware_concurrency();
+    const unsigned hw = usable_cpus();
     p->pool.reset(new HostPool(hw > 2 ? std::min(15u, hw - 2) : 0u));
   }
   auto& bb = p->buf[0];
