@@ -95,9 +95,10 @@ static F nova_instance_hash_full(const F& digest, u64 i, const std::vector<F>& z
   st.insert(st.end(), z0.begin(), z0.end());
   st.insert(st.end(), z.begin(), z.end());
   std::vector<F> in = {nova_hash<F>(st)};
-  in.push_back(U.W.x); in.push_back(U.W.y); in.push_back(U.E.x); in.push_back(U.E.y); in.push_back(U.u);
+  in.push_back(U.u);
   for (int k = 0; k < 4; k++) in.push_back(F::from_u64(U.X0[k]));
   for (int k = 0; k < 4; k++) in.push_back(F::from_u64(U.X1[k]));
+  in.push_back(U.W.x); in.push_back(U.W.y); in.push_back(U.E.x); in.push_back(U.E.y);
   return nova_hash<F>(in);
 }
 

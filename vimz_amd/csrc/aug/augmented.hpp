@@ -62,7 +62,8 @@ struct AugCircuit {
   uint32_t len_z = 0, step_wires = 0, step_constraints = 0;
   F digest;                 // SHA3-256 of the shape, truncated to 250 bits
   mutable AugCache<F> cache;                  // the output hashes of the last witness() call, replayed by the next (cs.hpp)
-  mutable std::unique_ptr<Worker> worker;     // helper thread for the scalar-multiplication chains (created on first use)
+  mutable std::unique_ptr<Worker> worker, worker2;     // helper threads for the two scalar-multiplication chains (created on first use)
+  Worker *shared_w = nullptr, *shared_w2 = nullptr;    // ... or the owner's (an IVC hands both of its circuits the same two)
   bool use_worker = std::thread::hardware_concurrency() > 1 && !getenv("VIMZ_AUG_NO_THREADS");
 
   uint32_t n_wires() const { return b.n_wires; }
@@ -101,7 +102,10 @@ struct AugCircuit {
   AugOut<FP> witness(const AugIn<FP>& in, const F* z_i, const F* z_next, std::vector<F>& aug, bool* bad) const {
     CS<FP> cs; cs.base = step_wires;
     cs.w.reserve(aug_wires());
-    if (use_worker) { if (!worker) worker.reset(new Worker()); cs.worker = worker.get(); }
+    if (use_worker) {
+      if (shared_w) { cs.worker = shared_w; cs.worker2 = shared_w2; }
+      else { if (!worker) worker.reset(new Worker()); if (!worker2) worker2.reset(new Worker()); cs.worker = worker.get(); cs.worker2 = worker2.get(); }
+    }
     std::vector<Num<F>> zi(len_z), zn(len_z);
     for (uint32_t k = 0; k < len_z; k++) { zi[k].v = z_i[k]; zn[k].v = z_next[k]; }
     AugOut<FP> o = synthesize_augmented<FP, OP>(cs, in, zi, zn, primary, CycleSide<FP>::b(), CycleSide<FP>::G(), &cache);

@@ -44,10 +44,13 @@ template <class F> inline F trunc250(const F& mont) { F c = F::from_mont(mont); 
 
 // The elements a relaxed instance contributes to the hashes, in order.
 template <class F>
+// (u and the IO limbs first: they only need the folding challenge, so the permutation that absorbs them — the first of the two — runs
+//  while the commitments are still being folded; the commitments go into the second)
 inline void absorb_relaxed(const RelaxedInst<F>& U, std::vector<F>& out) {
-  out.push_back(U.W.x); out.push_back(U.W.y); out.push_back(U.E.x); out.push_back(U.E.y); out.push_back(U.u);
+  out.push_back(U.u);
   for (int j = 0; j < 4; j++) out.push_back(cb::f_from_u64<F>(U.X0.w[j]));
   for (int j = 0; j < 4; j++) out.push_back(cb::f_from_u64<F>(U.X1.w[j]));
+  out.push_back(U.W.x); out.push_back(U.W.y); out.push_back(U.E.x); out.push_back(U.E.y);
 }
 // trunc250(H(digest, i, z_0, z, U)) outside any circuit (verifier; also the prover's bookkeeping)
 template <class FP>
@@ -142,9 +145,10 @@ AugOut<FP> synthesize_augmented(CS<FP>& cs, const AugIn<FP>& in, const std::vect
   hst.insert(hst.end(), z0.begin(), z0.end());
   hst.insert(hst.end(), z_i.begin(), z_i.end());
   std::vector<N> hin; hin.push_back(cs.hash_cached(hst, cache ? &cache->pre : nullptr, nullptr));
-  hin.push_back(UW.x); hin.push_back(UW.y); hin.push_back(UE.x); hin.push_back(UE.y); hin.push_back(Uu);
+  hin.push_back(Uu);
   for (int j = 0; j < 4; j++) hin.push_back(UX0[j]);
   for (int j = 0; j < 4; j++) hin.push_back(UX1[j]);
+  hin.push_back(UW.x); hin.push_back(UW.y); hin.push_back(UE.x); hin.push_back(UE.y);
   N h_chk = cs.hash_cached(hin, cache ? &cache->rest : nullptr, nullptr);
   VZ_T(1, "hash_in");
   std::vector<N> hb = cs.bits(h_chk, FP::BITS);
@@ -162,6 +166,10 @@ AugOut<FP> synthesize_augmented(CS<FP>& cs, const AugIn<FP>& in, const std::vect
   N rho = cs.add(cs.add(rho0, cs.scale(rho1, cb::f_pow2<F>(64))), cs.constant(cb::f_pow2<F>(128)));
 
   // ---- NIFS.V --------------------------------------------------------------------------------------------------------------
+  // The two 128-step scalar multiplications are the long pole of the witness: their chains (cs.hpp: chain_hints) start now, on
+  // helper threads, and everything below that only needs the challenge is evaluated under them.
+  typename Ec::ChainJob chains;
+  chains.start(Ec::scalar_operand(in.u.W, G), Ec::scalar_operand(in.T, G), out.rho_low, 128, cs.worker, cs.worker2);
   Pt We, Ee;   // the running instance, or the zero instance in the base case
   We.x = cs.mul(nb, UW.x); We.y = cs.mul(nb, UW.y); We.inf = cs.add(UW.inf, cs.mul(is_base, cs.one_minus(UW.inf)));
   Ee.x = cs.mul(nb, UE.x); Ee.y = cs.mul(nb, UE.y); Ee.inf = cs.add(UE.inf, cs.mul(is_base, cs.one_minus(UE.inf)));
@@ -172,46 +180,65 @@ AugOut<FP> synthesize_augmented(CS<FP>& cs, const AugIn<FP>& in, const std::vect
   if (base) for (int j = 0; j < 4; j++) X0v.w[j] = X1v.w[j] = 0;
 
   std::vector<N> xb0 = cs.bits(ux0, 250), xb1 = cs.bits(ux1, 250);
-
   VZ_T(4, "select_bits");
-  std::vector<Affine<F>> ops = {Ec::scalar_operand(in.u.W, G), Ec::scalar_operand(in.T, G)};
+  N un = cs.add(ue, rho);
+  N X0n[4], X1n[4]; U256w X0nv, X1nv;
+  NN::fold(cs, X0e, X0v, rho0, rho1, out.rho_low, xb0, to_u256(in.u.x0), X0n, X0nv);
+  NN::fold(cs, X1e, X1v, rho0, rho1, out.rho_low, xb1, to_u256(in.u.x1), X1n, X1nv);
+  VZ_T(8, "nonnative");
+  // the primary's base case outputs the zero instance (its incoming fresh instance is a dummy)
+  N uo = un;
+  if (is_primary) {
+    uo = cs.mul(nb, un);
+    for (int j = 0; j < 4; j++) { X0n[j] = cs.mul(nb, X0n[j]); X1n[j] = cs.mul(nb, X1n[j]); }
+    if (base) for (int j = 0; j < 4; j++) X0nv.w[j] = X1nv.w[j] = 0;
+  }
+  // ---- output hash, first part: the statement (computed ahead, AugCache::next_pre) and the permutation that absorbs u and the IO limbs
+  std::vector<N> host; host.push_back(dg); host.push_back(cs.addc(iN, F::one()));
+  host.insert(host.end(), z0.begin(), z0.end());
+  host.insert(host.end(), z_next.begin(), z_next.end());
+  std::vector<N> hout; hout.push_back(cs.hash_cached(host, cache ? &cache->next_pre : nullptr, cache ? &cache->pre : nullptr));
+  hout.push_back(uo);
+  for (int j = 0; j < 4; j++) hout.push_back(X0n[j]);
+  for (int j = 0; j < 4; j++) hout.push_back(X1n[j]);
+  VZ_T(9, "sel_out");
+  const size_t w_h1 = cs.w.size();
+  N h1 = cs.poseidon(std::vector<N>(hout.begin(), hout.begin() + 8));      // (hash() of the 14 elements = this, then h1 with the other six)
+  const size_t w_h1_end = cs.w.size();
+  VZ_T(10, "hash_out_1");
+
+  // ---- the folded commitments ------------------------------------------------------------------------------------------------------
   std::vector<typename Ec::ChainHints> hints;
-  Ec::chain_hints_parallel(ops, out.rho_low, 128, hints, cs.worker);
+  chains.wait(hints);
   VZ_T(5, "chain_hints");
   Pt rW = ec.scalar_mul(uW, rb, 128, hints[0]);
   Pt rT = ec.scalar_mul(T, rb, 128, hints[1]);
   VZ_T(6, "scalar_mul_gadget");
   Pt Wn = ec.add(We, rW), En = ec.add(Ee, rT);
   VZ_T(7, "ec_add");
-  N un = cs.add(ue, rho);
-  N X0n[4], X1n[4]; U256w X0nv, X1nv;
-  NN::fold(cs, X0e, X0v, rho0, rho1, out.rho_low, xb0, to_u256(in.u.x0), X0n, X0nv);
-  NN::fold(cs, X1e, X1v, rho0, rho1, out.rho_low, xb1, to_u256(in.u.x1), X1n, X1nv);
-
-  VZ_T(8, "nonnative");
-  // ---- the primary's base case outputs the zero instance (its incoming fresh instance is a dummy) -----------------------------
-  Pt Wo = Wn, Eo = En; N uo = un;
+  Pt Wo = Wn, Eo = En;
   if (is_primary) {
     Wo.x = cs.mul(nb, Wn.x); Wo.y = cs.mul(nb, Wn.y);
     Eo.x = cs.mul(nb, En.x); Eo.y = cs.mul(nb, En.y);
-    uo = cs.mul(nb, un);
-    for (int j = 0; j < 4; j++) { X0n[j] = cs.mul(nb, X0n[j]); X1n[j] = cs.mul(nb, X1n[j]); }
-    if (base) for (int j = 0; j < 4; j++) X0nv.w[j] = X1nv.w[j] = 0;
   }
   out.U_new.W.x = Wo.x.v; out.U_new.W.y = Wo.y.v; out.U_new.E.x = Eo.x.v; out.U_new.E.y = Eo.y.v; out.U_new.u = uo.v;
   out.U_new.X0 = X0nv; out.U_new.X1 = X1nv;
 
-  // ---- output hash ----------------------------------------------------------------------------------------------------------
-  std::vector<N> host; host.push_back(dg); host.push_back(cs.addc(iN, F::one()));
-  host.insert(host.end(), z0.begin(), z0.end());
-  host.insert(host.end(), z_next.begin(), z_next.end());
-  std::vector<N> hout; hout.push_back(cs.hash_cached(host, cache ? &cache->next_pre : nullptr, cache ? &cache->pre : nullptr));
-  hout.push_back(Wo.x); hout.push_back(Wo.y); hout.push_back(Eo.x); hout.push_back(Eo.y); hout.push_back(uo);
-  for (int j = 0; j < 4; j++) hout.push_back(X0n[j]);
-  for (int j = 0; j < 4; j++) hout.push_back(X1n[j]);
-  VZ_T(9, "sel_out");
-  N h_new = cs.hash_cached(hout, nullptr, cache ? &cache->rest : nullptr);
-  VZ_T(10, "hash_out");
+  // ---- output hash, second part ---------------------------------------------------------------------------------------------------------
+  hout.push_back(Wo.x); hout.push_back(Wo.y); hout.push_back(Eo.x); hout.push_back(Eo.y);
+  const size_t w_h2 = cs.w.size();
+  std::vector<N> h2in; h2in.push_back(h1);
+  h2in.insert(h2in.end(), hout.begin() + 8, hout.end());
+  N h_new = cs.poseidon(h2in);
+  if (cache && !cs.b) {      // kept for the next step's incoming-hash check: inputs, the two permutations' wires in order, the value
+    HashCache<F>& hc = cache->rest;
+    hc.in.resize(hout.size());
+    for (size_t k = 0; k < hout.size(); k++) hc.in[k] = hout[k].v;
+    hc.wires.assign(cs.w.begin() + w_h1, cs.w.begin() + w_h1_end);
+    hc.wires.insert(hc.wires.end(), cs.w.begin() + w_h2, cs.w.end());
+    hc.out = h_new.v; hc.valid = true;
+  }
+  VZ_T(11, "hash_out_2");
   std::vector<N> hnb = cs.bits(h_new, FP::BITS);
   N hn250 = cs.pack(hnb, 0, 250);
 
@@ -221,7 +248,7 @@ AugOut<FP> synthesize_augmented(CS<FP>& cs, const AugIn<FP>& in, const std::vect
   cs.enforce_equal(p1, hn250);
   out.x0 = p0.v; out.x1 = p1.v;
   out.x0_wire = cs.base + (uint32_t)cs.w.size() - 2; out.x1_wire = out.x0_wire + 1;
-  VZ_T(11, "tail");
+  VZ_T(12, "tail");
   return out;
 }
 

@@ -108,7 +108,8 @@ struct CS {
   uint32_t base = 0;              // index of the first wire this synthesis allocates
   std::vector<F> w;               // values of the wires allocated by this synthesis, in order
   bool bad = false;               // witness mode: some value did not fit its range (the witness will not satisfy)
-  Worker* worker = nullptr;       // witness mode: optional helper thread
+  Worker* worker = nullptr;       // witness mode: optional helper threads for the two scalar-multiplication chains
+  Worker* worker2 = nullptr;
 
   bool shape() const { return b != nullptr; }
 
@@ -389,17 +390,20 @@ struct EcGadgets {
     }
   }
 
-  // the same with the operands split between the calling thread and a helper
-  static void chain_hints_parallel(const std::vector<Affine<F>>& Ps, const uint32_t* k, int nbits, std::vector<ChainHints>& out, Worker* wk) {
-    if (!wk || Ps.size() != 2) { chain_hints(Ps, k, nbits, out); return; }
-    std::vector<ChainHints> o1;
-    const std::vector<Affine<F>> p1 = {Ps[1]};
-    wk->start([&] { chain_hints(p1, k, nbits, o1); });
-    std::vector<ChainHints> o0;
-    chain_hints(std::vector<Affine<F>>{Ps[0]}, k, nbits, o0);
-    wk->wait();
-    out.clear(); out.push_back(std::move(o0[0])); out.push_back(std::move(o1[0]));
-  }
+  // Both chains on helper threads (one each), started as soon as the challenge is known: the calling thread goes on with the part of
+  // the circuit that needs the challenge only (non-native folds, the first permutation of the output hash) and collects them after.
+  // Without helpers (or with one) the missing chains are computed at wait().
+  struct ChainJob {
+    std::vector<Affine<F>> ps[2]; std::vector<ChainHints> o[2]; const uint32_t* k = nullptr; int nbits = 0; Worker* w[2] = {nullptr, nullptr};
+    void start(const Affine<F>& p0, const Affine<F>& p1, const uint32_t* k_, int nbits_, Worker* w0, Worker* w1) {
+      ps[0] = {p0}; ps[1] = {p1}; k = k_; nbits = nbits_; w[0] = w0; w[1] = w1;
+      for (int j = 0; j < 2; j++) if (w[j]) w[j]->start([this, j] { chain_hints(ps[j], k, nbits, o[j]); });
+    }
+    void wait(std::vector<ChainHints>& out) {
+      for (int j = 0; j < 2; j++) { if (w[j]) w[j]->wait(); else chain_hints(ps[j], k, nbits, o[j]); }
+      out.clear(); out.push_back(std::move(o[0][0])); out.push_back(std::move(o[1][0]));
+    }
+  };
 
   // (2^nbits + sum bits[i] 2^i) · P.  An identity P gives the identity.  9 constraints per bit.
   // The accumulator is an even multiple >= 2 of P when P is added, so the two x-coordinates always differ.

@@ -567,6 +567,10 @@ int vimz_ivc_create(vimz_ctx* ctx, const vimz_circuit* step_circuit, const vimz_
   }
   for (int q = 0; q < 7; q++) if ((e = hipEventCreate(&v->ev_alt[q])) != hipSuccess) return fail("event");
   v->t1[0].ev = ctx->ev; v->t1[1].ev = v->ev_alt;
+  if (v->c2.use_worker) {       // one pair of helper threads for both circuits
+    for (auto& w : v->chain_w) w.reset(new aug::Worker());
+    v->c1->shared_w = v->c2.shared_w = v->chain_w[0].get(); v->c1->shared_w2 = v->c2.shared_w2 = v->chain_w[1].get();
+  }
   v->lookahead = ivc_lookahead_enabled();
   v->pri->want_d = v->lookahead;
   if ((e = hipStreamSynchronize(nullptr)) != hipSuccess) return fail("sync");   // the hipMemset fills above ran on the null stream
