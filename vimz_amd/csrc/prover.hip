@@ -22,7 +22,6 @@ void vimz_prover_free(vimz_prover* p) {
     hipStreamSynchronize(p->ctx->stream);
     if (p->sB) { hipStreamSynchronize(p->sB); hipStreamDestroy(p->sB); }
     if (p->sH) { hipStreamSynchronize(p->sH); hipStreamDestroy(p->sH); }
-    p->wsD.release();
     if (p->ev_head) hipEventDestroy(p->ev_head);
     if (p->ev_hash) hipEventDestroy(p->ev_hash);
     p->pool.reset();
@@ -148,12 +147,15 @@ int vz_prover_create_layout(vimz_ctx* ctx, const vimz_circuit* circuit, const vi
     if ((e = hipHostMalloc(&bb.pin, 4 * (size_t)XYZZ_WORDS * MSM_MAX_WINDOWS * B)) != hipSuccess) return fail_free("pinned", e);
     if ((e = hipHostMalloc((void**)&bb.status_host, 4 * B)) != hipSuccess) return fail_free("pinned", e);
     bb.has_d.assign(B, 0);
+    if (p->ivc) {        // per row: (A,B,C)·z done (the rows of a batch alternate between two producer streams)
+      bb.ev_p.resize(B);
+      for (size_t i = 0; i < B; i++) if ((e = hipEventCreateWithFlags(&bb.ev_p[i], hipEventDisableTiming)) != hipSuccess) return fail_free("event", e);
+    }
     if (p->ivc && ivc_lookahead_enabled()) {     // lookahead of the IVC's large MSM (fold_issue_d)
       if (dalloc(&bb.d, 32 * B * (size_t)p->step_c) != hipSuccess) return fail_free("device allocation", e);
       if ((e = hipHostMalloc(&bb.pin_d, 4 * (size_t)XYZZ_WORDS * MSM_MAX_WINDOWS * B)) != hipSuccess) return fail_free("pinned", e);
-      bb.ev_p.resize(B); bb.ev_d.resize(B);
-      for (size_t i = 0; i < B; i++)
-        if ((e = hipEventCreateWithFlags(&bb.ev_p[i], hipEventDisableTiming)) != hipSuccess || (e = hipEventCreateWithFlags(&bb.ev_d[i], hipEventDisableTiming)) != hipSuccess) return fail_free("event", e);
+      bb.ev_d.resize(B);
+      for (size_t i = 0; i < B; i++) if ((e = hipEventCreateWithFlags(&bb.ev_d[i], hipEventDisableTiming)) != hipSuccess) return fail_free("event", e);
     }
   }
   {   // head batch of a fold call (prover_internal.hpp: fold_head_batch): staging layout of the Poseidon jobs' wires, its stream

@@ -139,9 +139,9 @@ struct vimz_prover {
     std::vector<uint8_t> has_d;
   } buf[2];
   bool want_d = false;
-  hipStream_t sD = nullptr;      // = sH, the head batch's stream, idle for the rest of a call (a stream of its own — a sixth — shifted the
-                                 // streams' hardware queues and cost one proof 10 %, with nothing ever queued on it)
-  MsmWorkspace wsD; MsmPlan planD{};
+  hipStream_t sD = nullptr;      // = sH (a stream of its own for the lookahead's commitments — a sixth — shifted the streams' hardware
+                                 // queues and cost one proof 10 %, with nothing ever queued on it)
+  MsmPlan planD{};
   MsmWorkspace wsB;
   MsmPlan planB{};
   // head batch of a fold call: Poseidon jobs evaluated on the host, everything else on a stream of its own (fold_head_batch)
@@ -349,6 +349,13 @@ static int fold_issue(vimz_prover* p, const FoldJob& J, size_t k);
 
 // Host CPUs this process can really use: what the OS shows, capped by the cgroup's CPU quota (cpu.max / cfs_quota_us).  A GPU box shows
 // 256 logical CPUs and grants 16; threads beyond the quota get the whole process throttled for the rest of a 100 ms period.
+static bool getenv_once(const char* name) {      // (debugging switches are read once; each call site has its own name)
+  static std::mutex m; static std::vector<std::pair<std::string, bool>> seen;
+  std::lock_guard<std::mutex> g(m);
+  for (auto& e : seen) if (e.first == name) return e.second;
+  seen.emplace_back(name, getenv(name) != nullptr);
+  return seen.back().second;
+}
 static unsigned usable_cpus() {
   static const unsigned v = [] {
     unsigned n = std::max(1u, std::thread::hardware_concurrency());
@@ -382,26 +389,26 @@ static size_t head_rows_wanted() {
 // one proof at contrast HD — the producer's two low-priority streams then run at the pace of the folds and the proof waits for rows.
 static bool ivc_lookahead_enabled() { static const bool v = getenv("VIMZ_IVC_LOOKAHEAD") && atoi(getenv("VIMZ_IVC_LOOKAHEAD")) != 0; return v; }
 
-// IVC lookahead: row r of batch k gets negB = −T(previous row, this row) over the step rows and its commitment, on stream sD behind
-// the row's (A,B,C)·z (`sp`: the stream that just computed them).  The previous row is the one before it in the batch, or the last
-// row of the batch before (the other buffer — still intact: it is rewritten by batch k+1, whose producer waits for this).
-static int fold_issue_d(vimz_prover* p, const FoldJob& J, size_t k, size_t r, hipStream_t sp) {
+// IVC lookahead: row r of batch k gets negB = −T(previous row, this row) over the step rows and its commitment, on the row's own
+// producer stream `sp` behind its commitment to the witness (same workspace, used one after the other).  The previous row is the one
+// before it in the batch, or the last row of the batch before (the other buffer — still intact: it is rewritten by batch k+1, whose
+// producer waits for this); its products may come from the other producer stream: ev_p.
+static int fold_issue_d(vimz_prover* p, const FoldJob& J, size_t k, size_t r, hipStream_t sp, MsmWorkspace& ws) {
   vimz_ctx* ctx = p->ctx;
   auto& bb = p->buf[k & 1];
   bb.has_d[r] = 0;
   if (!p->want_d) return VIMZ_OK;
   const size_t nc = p->n_c, sc = p->step_c;
-  const uint32_t *az0, *bz0, *cz0;
-  if (r > 0) { az0 = bb.az + 8 * (r - 1) * nc; bz0 = bb.bz + 8 * (r - 1) * nc; cz0 = bb.cz + 8 * (r - 1) * nc; }
-  else if (k > 0) { auto& ob = p->buf[(k - 1) & 1]; const size_t lr = J.rows(k - 1) - 1; az0 = ob.az + 8 * lr * nc; bz0 = ob.bz + 8 * lr * nc; cz0 = ob.cz + 8 * lr * nc; }
+  const uint32_t *az0, *bz0, *cz0; hipEvent_t prev;
+  if (r > 0) { az0 = bb.az + 8 * (r - 1) * nc; bz0 = bb.bz + 8 * (r - 1) * nc; cz0 = bb.cz + 8 * (r - 1) * nc; prev = bb.ev_p[r - 1]; }
+  else if (k > 0) { auto& ob = p->buf[(k - 1) & 1]; const size_t lr = J.rows(k - 1) - 1; az0 = ob.az + 8 * lr * nc; bz0 = ob.bz + 8 * lr * nc; cz0 = ob.cz + 8 * lr * nc; prev = ob.ev_p[lr]; }
   else return VIMZ_OK;        // first row of a call: its cross term is computed against the running instance directly
-  P_TRY(hipEventRecord(bb.ev_p[r], sp));
-  P_TRY(hipStreamWaitEvent(p->sD, bb.ev_p[r], 0));
+  P_TRY(hipStreamWaitEvent(sp, prev, 0));      // (the previous row's (A,B,C)·z may come from the other producer stream)
   uint32_t* d = bb.d + 8 * r * sc;
-  hipLaunchKernelGGL(k_fresh_cross_neg<Fr>, dim3(stream_grid(sc)), dim3(256), 0, p->sD, sc, az0, bz0, cz0, bb.az + 8 * r * nc, bb.bz + 8 * r * nc, bb.cz + 8 * r * nc, d);
+  hipLaunchKernelGGL(k_fresh_cross_neg<Fr>, dim3(stream_grid(sc)), dim3(256), 0, sp, sc, az0, bz0, cz0, bb.az + 8 * r * nc, bb.bz + 8 * r * nc, bb.cz + 8 * r * nc, d);
   P_TRY(hipGetLastError());
-  P_TRY(msm_launch<BnG1>(p->sD, p->wsD, p->ck->d, d, sc, 1, 0, (char*)bb.pin_d + r * FoldJob::pin_stride, &p->planD, nullptr, 1, nullptr));
-  P_TRY(hipEventRecord(bb.ev_d[r], p->sD));
+  P_TRY(msm_launch<BnG1>(sp, ws, p->ck->d, d, sc, 1, 0, (char*)bb.pin_d + r * FoldJob::pin_stride, &p->planD, nullptr, 1, nullptr));
+  P_TRY(hipEventRecord(bb.ev_d[r], sp));
   bb.has_d[r] = 1;
   return VIMZ_OK;
 }
@@ -489,9 +496,10 @@ static int fold_head_batch(vimz_prover* p, FoldJob& J, size_t rows) {
   for (size_t r = 0; r < rows; r++) {
     const uint32_t* Zi = bb.Z + 8 * r * nw;
     launch_spmv(p, sh, Zi, bb.az + 8 * r * nc, bb.bz + 8 * r * nc, bb.cz + 8 * r * nc, 1);
-    { int rc = fold_issue_d(p, J, 0, r, sh); if (rc) return rc; }
+    if (p->ivc) P_TRY(hipEventRecord(bb.ev_p[r], sh));
     P_TRY(msm_launch<BnG1>(sh, p->wsH, p->ck->d, Zi + 8 * (size_t)p->c0, sw - p->c0, 1, 0, (char*)bb.pin + r * FoldJob::pin_stride, &p->planB, nullptr, 1, p->ck->tables ? &J.tbl : nullptr));
     P_TRY(hipEventRecord(bb.ev[r], sh));
+    { int rc = fold_issue_d(p, J, 0, r, sh, p->wsH); if (rc) return rc; }
   }
   P_TRY(hipEventRecord(p->ev_head, sh));
   return VIMZ_OK;
@@ -695,7 +703,7 @@ static int fold_issue(vimz_prover* p, const FoldJob& J, size_t k) {
   hipStream_t sb = p->sB;
   if (J.head && k == 1) P_TRY(hipStreamWaitEvent(sb, p->ev_head, 0));      // (orders the two MSM workspaces' users; the head batch is long done)
   // this batch overwrites the buffer of batch k-2, whose last row the first row of batch k-1 was differenced against (fold_issue_d)
-  if (p->want_d && k >= 1 && p->buf[(k - 1) & 1].has_d[0]) P_TRY(hipStreamWaitEvent(sb, p->buf[(k - 1) & 1].ev_d[0], 0));
+  if (p->want_d && k >= 1 && p->buf[(k - 1) & 1].has_d[0]) { P_TRY(hipStreamWaitEvent(sb, p->buf[(k - 1) & 1].ev_d[0], 0)); P_TRY(hipStreamWaitEvent(p->sH, p->buf[(k - 1) & 1].ev_d[0], 0)); }
   const bool started = (int)k == J.started_batch;      // (its status words already hold the decompositions' range checks)
   if (!started) P_TRY(hipMemsetAsync(bb.status, 0, 4 * rows, sb));
   if (J.witnesses) {
@@ -708,12 +716,20 @@ static int fold_issue(vimz_prover* p, const FoldJob& J, size_t k) {
   P_TRY(hipGetLastError());
   P_TRY(hipMemcpyAsync(bb.status_host, bb.status, 4 * rows, hipMemcpyDeviceToHost, sb));
   P_TRY(hipEventRecord(bb.wit_done, sb));
+  // Per row: the step rows of (A,B,C)·z, the commitment to the witness and (lookahead) the fresh x fresh commitment — a chain of some
+  // twenty-five dependent launches, ≈1 ms (1.6 ms with the lookahead's) whatever the GPU has free.  In IVC mode the rows alternate
+  // between the producer's stream and the head batch's (idle after the first rows of a call), each with its own MSM workspace.
+  const bool two = p->ivc && p->sH && p->sH != sb && !getenv_once("VIMZ_DEBUG_ONE_PRODUCER_STREAM");
+  if (two) P_TRY(hipStreamWaitEvent(p->sH, bb.wit_done, 0));
   for (size_t r = 0; r < rows; r++) {
     const uint32_t* Zi = bb.Z + 8 * r * nw;
-    launch_spmv(p, sb, Zi, bb.az + 8 * r * nc, bb.bz + 8 * r * nc, bb.cz + 8 * r * nc, 1);
-    { int rc = fold_issue_d(p, J, k, r, sb); if (rc) return rc; }
-    P_TRY(msm_launch<BnG1>(sb, p->wsB, p->ck->d, Zi + 8 * (size_t)p->c0, sw - p->c0, 1, 0, (char*)bb.pin + r * FoldJob::pin_stride, &p->planB, nullptr, 1, p->ck->tables ? &J.tbl : nullptr));
-    P_TRY(hipEventRecord(bb.ev[r], sb));
+    hipStream_t st = two && (r & 1) ? p->sH : sb;
+    MsmWorkspace& ws = two && (r & 1) ? p->wsH : p->wsB;
+    launch_spmv(p, st, Zi, bb.az + 8 * r * nc, bb.bz + 8 * r * nc, bb.cz + 8 * r * nc, 1);
+    if (p->ivc) P_TRY(hipEventRecord(bb.ev_p[r], st));
+    P_TRY(msm_launch<BnG1>(st, ws, p->ck->d, Zi + 8 * (size_t)p->c0, sw - p->c0, 1, 0, (char*)bb.pin + r * FoldJob::pin_stride, &p->planB, nullptr, 1, p->ck->tables ? &J.tbl : nullptr));
+    P_TRY(hipEventRecord(bb.ev[r], st));
+    { int rc = fold_issue_d(p, J, k, r, st, ws); if (rc) return rc; }
   }
   return VIMZ_OK;
 }
