@@ -385,7 +385,7 @@ static size_t head_rows_wanted() {
 }
 
 // The IVC's lookahead schedule (ivc.hip) is an option: VIMZ_IVC_LOOKAHEAD=1 (read once).  It takes the large MSM off a
-// step's dependent chains at the price of one more (cheap) commitment per row from the producer; measured 563 against 607 steps/s for
+// step's dependent chains at the price of one more (cheap) commitment per row from the producer; measured 572 against 651 steps/s for
 // one proof at contrast HD — the producer's two low-priority streams then run at the pace of the folds and the proof waits for rows.
 static bool ivc_lookahead_enabled() { static const bool v = getenv("VIMZ_IVC_LOOKAHEAD") && atoi(getenv("VIMZ_IVC_LOOKAHEAD")) != 0; return v; }
 
