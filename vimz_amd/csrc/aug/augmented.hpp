@@ -63,6 +63,7 @@ struct AugCircuit {
   F digest;                 // SHA3-256 of the shape, truncated to 250 bits
   mutable AugCache<F> cache;                  // the output hashes of the last witness() call, replayed by the next (cs.hpp)
   mutable std::unique_ptr<Worker> worker, worker2;     // helper threads for the two scalar-multiplication chains (created on first use)
+  mutable std::function<void(const uint32_t*)> on_challenge;      // witness(): called with the challenge once the parts of the circuit that only need it are done
   Worker *shared_w = nullptr, *shared_w2 = nullptr;    // ... or the owner's (an IVC hands both of its circuits the same two)
   bool use_worker = std::thread::hardware_concurrency() > 1 && !getenv("VIMZ_AUG_NO_THREADS");
 
@@ -106,6 +107,7 @@ struct AugCircuit {
       if (shared_w) { cs.worker = shared_w; cs.worker2 = shared_w2; }
       else { if (!worker) worker.reset(new Worker()); if (!worker2) worker2.reset(new Worker()); cs.worker = worker.get(); cs.worker2 = worker2.get(); }
     }
+    cs.on_challenge = &on_challenge;
     std::vector<Num<F>> zi(len_z), zn(len_z);
     for (uint32_t k = 0; k < len_z; k++) { zi[k].v = z_i[k]; zn[k].v = z_next[k]; }
     AugOut<FP> o = synthesize_augmented<FP, OP>(cs, in, zi, zn, primary, CycleSide<FP>::b(), CycleSide<FP>::G(), &cache);

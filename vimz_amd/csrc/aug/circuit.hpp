@@ -208,6 +208,10 @@ AugOut<FP> synthesize_augmented(CS<FP>& cs, const AugIn<FP>& in, const std::vect
   VZ_T(10, "hash_out_1");
 
   // ---- the folded commitments ------------------------------------------------------------------------------------------------------
+  // (the prover's hook: what only waits for the challenge on the device — the folds, the next cross term and its commitment — is
+  //  queued here, in the time this thread would otherwise spend waiting for the chains.  Right after the chains' start instead: the
+  //  large MSM begins 60 µs earlier still, its accumulation lands on the secondary half — 659 against 677 steps/s)
+  if (cs.on_challenge && *cs.on_challenge) (*cs.on_challenge)(out.rho_low);
   std::vector<typename Ec::ChainHints> hints;
   chains.wait(hints);
   VZ_T(5, "chain_hints");

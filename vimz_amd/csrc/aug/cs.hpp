@@ -110,6 +110,7 @@ struct CS {
   bool bad = false;               // witness mode: some value did not fit its range (the witness will not satisfy)
   Worker* worker = nullptr;       // witness mode: optional helper threads for the two scalar-multiplication chains
   Worker* worker2 = nullptr;
+  std::function<void(const uint32_t*)>* on_challenge = nullptr;   // witness mode: called once with the challenge's low 128 bits (see circuit.hpp)
 
   bool shape() const { return b != nullptr; }
 

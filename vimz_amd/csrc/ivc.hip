@@ -46,6 +46,7 @@ int finish_secondary(vimz_ivc* v) {
 int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witnesses, size_t nsteps) {
   if (!nsteps) return VIMZ_OK;
   vimz_ctx* ctx = v->ctx;
+  if (v->broken) return vz_fail(ctx, VIMZ_ERR_INVALID, "this IVC failed in the middle of a step and cannot be folded any further");
   vimz_prover* p = v->pri;
   std::lock_guard<std::mutex> g(ctx->mu);
   P_TRY(hipSetDevice(ctx->device));
@@ -341,15 +342,14 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
       }
       // ---- 4. secondary verifier circuit on the host: folds (U1, u1) ---------------------------------------------------------------------
       AugIn<BnFq> in2; in2.digest = v->c2.digest; in2.z0 = v->z0_sec; in2.i = i; in2.U = v->U1; in2.u = u1; in2.T = T1;
-      std::vector<Fq> aug2;
-      AugOut<BnFq> o2 = v->c2.witness(in2, &zero_q, &zero_q, aug2, &bad);
-      if (bad) return vz_fail(ctx, VIMZ_ERR_UNSAT, "secondary verifier circuit: inconsistent incoming instance");
-      v->ph_s[IP_SYNTH2] += now_s() - t0; v->ph_n[IP_SYNTH2]++;
-      t0 = now_s();
-      int launcher_rc = VIMZ_OK; FoldArgs fa{};
+      // What only waits for this step's challenge on the device — the fold of the running instance, the next step's cross term over the
+      // step rows and its commitment: the longest dependent chain of a step — is queued from INSIDE the circuit's evaluation, when the
+      // challenge and everything that depends on nothing else are done and the thread would wait for the two scalar-multiplication
+      // chains (AugCircuit::on_challenge): the large MSM starts ≈0.1 ms earlier than after witness() returns.
+      int launcher_rc = VIMZ_OK, hook_rc = VIMZ_OK; bool hook_ran = false; FoldArgs fa{};
       struct WaitGuard { aug::Worker* w = nullptr; ~WaitGuard() { if (w) w->wait(); } } launching;      // (an early return must not leave the helper with this frame)
-      {
-        const Fe rho1 = rho_element<Fe>(o2.rho_low);
+      auto queue_folds = [&](const uint32_t* rho_low) -> int {
+        const Fe rho1 = rho_element<Fe>(rho_low);
         // the rows whose step rows' cross terms come next: row i+1 (unless a lookahead produced its cross term already) and, one whole
         // step ahead, row i+2 — if its batch is out and the producer differenced it against row i+1 (fold_issue_d)
         auto row_at = [&](size_t ahead, RowAt* out) -> int {
@@ -361,12 +361,13 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
           out->b = &p->buf[(k + 1) & 1]; out->row = r + ahead - rows;
           return VIMZ_OK;
         };
+        int rc2;
         fa.i = i; fa.cur = &bb; fa.r = r; fa.rho = rho1;
-        if ((rc = row_at(1, &fa.next1))) return rc;
+        if ((rc2 = row_at(1, &fa.next1))) return rc2;
         fa.need1 = fa.next1.b && v->t1[(i + 1) & 1].step != (int64_t)i + 1;
         fa.look = false;
         if (fa.next1.b && v->lookahead && v->helpers.empty() && p->want_d) {
-          if ((rc = row_at(2, &fa.next2))) return rc;
+          if ((rc2 = row_at(2, &fa.next2))) return rc2;
           fa.look = fa.next2.b && fa.next2.b->has_d[fa.next2.row];
         }
         // the witness and the verifier rows (everything k_fold_cross does not touch)
@@ -377,18 +378,30 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
         f.x1[3] = p->BZ + 8 * sc; f.x2[3] = bz + 8 * sc; f.n[3] = nc - sc;
         f.x1[4] = p->CZ + 8 * sc; f.x2[4] = cz + 8 * sc; f.n[4] = nc - sc;
         v->u1_run = Fe::add(v->u1_run, rho1);
-        // the large MSM(s) that follow are queued at once, on stream 3 — by a helper thread (a dozen launches, 40-60 µs of host time),
-        // while this one queues the secondary half
         if (use_launcher) {
           if (!v->launcher) v->launcher.reset(new aug::Worker());
           v->launcher->start([&] { if (hipSetDevice(ctx->device) != hipSuccess) { launcher_rc = VIMZ_ERR_HIP; return; } launcher_rc = launch_fold_and_cross(fa); });
           launching.w = v->launcher.get();
-        } else if ((rc = launch_fold_and_cross(fa))) return rc;
+        } else if ((rc2 = launch_fold_and_cross(fa))) return rc2;
         // on stream 2, idle until the secondary witness is uploaded: this pass overlaps that upload instead of preceding it
         // (everything it reads is complete — the host has waited for all three streams)
         hipLaunchKernelGGL(k_fold5<Fr>, dim3(512), dim3(256), 0, v->s2, f, rho1);
         P_TRY(hipEventRecord(v->ev_fold, v->s2));  // the verifier rows of the next step may start here
+        return VIMZ_OK;
+      };
+      static const bool early_folds = getenv("VIMZ_DEBUG_LATE_FOLDS") == nullptr;
+      if (early_folds) v->c2.on_challenge = [&](const uint32_t* rho_low) { hook_ran = true; hook_rc = queue_folds(rho_low); };
+      std::vector<Fq> aug2;
+      AugOut<BnFq> o2 = v->c2.witness(in2, &zero_q, &zero_q, aug2, &bad);
+      v->c2.on_challenge = nullptr;
+      if (hook_ran && (bad || hook_rc)) {
+        v->broken = true;       // the folds with this challenge are queued already: the running instance cannot be used any further
+        return hook_rc ? hook_rc : vz_fail(ctx, VIMZ_ERR_UNSAT, "secondary verifier circuit: inconsistent incoming instance");
       }
+      if (bad) return vz_fail(ctx, VIMZ_ERR_UNSAT, "secondary verifier circuit: inconsistent incoming instance");
+      v->ph_s[IP_SYNTH2] += now_s() - t0; v->ph_n[IP_SYNTH2]++;
+      t0 = now_s();
+      if (!hook_ran && (rc = queue_folds(o2.rho_low))) return rc;
       v->U1 = o2.U_new;
       // fresh secondary instance on the device: [1 | z_out | z_in | verifier wires]
       {
@@ -619,7 +632,7 @@ int vimz_ivc_reset(vimz_ivc* v, const uint64_t* z0) {
   for (uint32_t k = 0; k < v->c1->len_z; k++) v->z0[k] = v->pri->z_cur[k];
   v->U1 = RelaxedInst<Fq>::zero(); v->U2 = RelaxedInst<Fe>::zero(); v->u2 = FreshInst<Fe>::zero(); v->T2.x = v->T2.y = Fe::zero();
   v->u1_run = Fe::zero(); v->u2_run = Fq::zero();
-  v->pending_sec = false; v->sec_T_valid = false; v->t1[0].step = v->t1[1].step = -1;
+  v->pending_sec = false; v->sec_T_valid = false; v->t1[0].step = v->t1[1].step = -1; v->broken = false;
   memset(v->ph_s, 0, sizeof(v->ph_s)); memset(v->ph_n, 0, sizeof(v->ph_n));
   return VIMZ_OK;
 }
@@ -900,7 +913,7 @@ int vimz_ivc_proof_import(vimz_ivc* v, const uint8_t* blob, size_t len) {
   p->z0 = v->z0;
   v->i = h.steps; p->steps = h.steps;
   v->U2 = hs.U2; v->U1 = hs.U1; v->u2 = hs.u2; v->T2 = hs.T2; v->u1_run = hs.u1_run; v->u2_run = hs.u2_run;
-  v->sec_T_valid = (h.flags & 1) != 0; v->pending_sec = false; v->t1[0].step = v->t1[1].step = -1;
+  v->sec_T_valid = (h.flags & 1) != 0; v->pending_sec = false; v->t1[0].step = v->t1[1].step = -1; v->broken = false;
   v->c1->cache = aug::AugCache<Fe>(); v->c2.cache = aug::AugCache<Fq>();
   return VIMZ_OK;
 }

@@ -67,6 +67,7 @@ struct vimz_ivc {
   char* pin_t1b = nullptr;         // pinned window sums (+ totals) of slot 1
   bool lookahead = false;          // step i+2's cross term against the running instance of step i+1 (VIMZ_IVC_LOOKAHEAD=1); off with MSM helpers
   Fe rho_prev = Fe::zero(); uint32_t rho_prev_low[4] = {};      // the previous step's folding challenge
+  bool broken = false;             // a step failed after its folds were queued (cannot happen with an honest witness): no further folds
   hipEvent_t ev_fused = nullptr; bool fused_recorded = false;      // the fused fold + cross term of the step rows on stream 3 (k_fold_cross)
   std::unique_ptr<aug::Worker> chain_w[2];                         // the two circuits' scalar-multiplication chains (they never run at the same time)
   std::unique_ptr<aug::Worker> launcher;                           // queues the large MSM (a dozen launches) while the main thread queues the secondary half
