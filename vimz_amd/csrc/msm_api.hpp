@@ -26,8 +26,8 @@ namespace vz {
 
 #define VZ_HIP_CHECK(x) do { hipError_t _e = (x); if (_e != hipSuccess) return _e; } while (0)
 
-constexpr int MSM_SUB = 12;          // max entries one thread accumulates in k_accum: the chain of dependent additions per thread;
-                                     // the partials of a bucket are then folded by k_combine.  8 / 12 / 16 / 24 give the same steps/s
+constexpr int MSM_SUB = 16;          // max entries one thread accumulates in k_accum: the chain of dependent additions per thread;
+                                     // the partials of a bucket are then folded by k_combine.  8 / 12 / 16 / 24 give the same steps/s within the run-to-run noise
                                      // (shorter pieces: k_accum wastes fewer lanes at its end, k_combine has more partials to fold —
                                      // in the bench 0.27 + 0.31, 0.29 + 0.25, 0.32 + 0.25, 0.53 + 0.19 ms)
 constexpr int MSM_MAX_WINDOWS = 96;
