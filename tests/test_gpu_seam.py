@@ -66,6 +66,64 @@ def test_multiply_vec_and_commit_T_match_the_oracle(ctx, oracle, op):
         S.free(); ck.free()
 
 
+def _random_coo(rng, nrows, ncols, modulus, long_rows=()):
+    """Random sparse matrix as shuffled triplets (no duplicate positions): 1-4 terms per row, a few long rows, coefficients that are
+    small, negative-small or full-width."""
+    rows, cols, vals = [], [], []
+    for r in range(nrows):
+        k = 120 if r in long_rows else int(rng.integers(1, 5))
+        for c in rng.choice(ncols, size=k, replace=False):
+            kind = int(rng.integers(0, 4))
+            v = 1 if kind == 0 else int(rng.integers(2, 1 << 16)) if kind == 1 else modulus - int(rng.integers(1, 1 << 16)) if kind == 2 else int.from_bytes(rng.bytes(32), "little") % modulus
+            rows.append(r); cols.append(int(c)); vals.append(v)
+    perm = rng.permutation(len(rows))
+    return np.asarray(rows, dtype=np.uint32)[perm], np.asarray(cols, dtype=np.uint32)[perm], to_limbs([vals[i] for i in perm])
+
+
+def _csr(rows, cols, vals, nrows):
+    order = np.argsort(rows, kind="stable")
+    rp = np.zeros(nrows + 1, dtype=np.uint32)
+    np.add.at(rp, rows.astype(np.int64) + 1, 1)
+    return np.cumsum(rp).astype(np.uint32), cols[order], vals[order]
+
+
+@pytest.mark.parametrize("curve", [_lib.CURVE_PALLAS, _lib.CURVE_VESTA])
+def test_seam_over_the_pasta_fields(ctx, oracle, curve):
+    """north_star names the Pasta cycle: (A,B,C)·z and commit_T for a caller-supplied shape over Pallas' / Vesta's scalar field, with the
+    commitment on that curve, against the oracle's spmv / cross_term / msm in the same field."""
+    from vimz_amd import hip
+    fid = _lib.CURVE_SCALAR_FIELD[curve]
+    q = oracle.modulus[fid]
+    rng = np.random.default_rng(40 + curve)
+    nrows, ncols = 6000, 5000
+    mats = [_random_coo(rng, nrows, ncols, q, long_rows=(7, 4100)) for _ in range(3)]
+    S = hip.R1CSShape(ctx, fid, nrows, ncols, *mats)
+    ck = ctx.bases_upload(curve, oracle.seq_bases(curve, nrows))
+    try:
+        zs = []
+        for _ in range(2):
+            z = to_limbs([int.from_bytes(rng.bytes(32), "little") % q for _ in range(ncols)])
+            zs.append((ctx.vec_from_host(fid, z), z))
+        prods = []
+        for zd, z in zs:
+            got = S.multiply_vec(zd)
+            want = [oracle.spmv(fid, nrows, ncols, *_csr(*m, nrows), z) for m in mats]
+            for g, w in zip(got, want):
+                assert np.array_equal(g.download(), w)
+                g.free()
+            prods.append(want)
+        u1 = int.from_bytes(rng.bytes(31), "little")
+        T, comm = S.commit_T(ck, zs[0][0], u1, zs[1][0], 1)
+        want_T = oracle.cross_term(fid, *prods[0], u1, *prods[1], 1)
+        assert np.array_equal(T.download(), want_T)
+        assert tuple(from_limbs(comm)) == oracle.msm(curve, oracle.seq_bases(curve, nrows), want_T, threads=8)
+        T.free()
+        for zd, _ in zs:
+            zd.free()
+    finally:
+        S.free(); ck.free()
+
+
 def test_upload_rejects_bad_shapes(ctx):
     from vimz_amd import hip
     one = to_limbs([1])
