@@ -143,6 +143,9 @@ int vimz_spmv3(vimz_ctx* ctx, const vimz_r1cs* shape, const vimz_vec* z, vimz_ve
  * (u2 = 1 for a fresh instance).  ck: at least nrows generators on the curve whose scalar field is the shape's field. */
 int vimz_commit_T(vimz_ctx* ctx, const vimz_r1cs* shape, const vimz_bases* ck, const vimz_vec* z1, const uint64_t u1[4], const vimz_vec* z2,
                   const uint64_t u2[4], int form, vimz_vec* T_out, uint64_t comm_T[8], int out_form);
+/* x1 <- x1 + r * x2 over the first n elements (r in `form`): the fold of a resident vector — RelaxedR1CSWitness::fold for W and E,
+ * nova-snark 0.23.0 (reached from NIFS::prove, folding.rs:35-41).  Both vectors of the same field, x1 != x2. */
+int vimz_vec_axpy(vimz_ctx* ctx, vimz_vec* x1, const uint64_t r[4], int form, const vimz_vec* x2, size_t n);
 
 /* ---- step circuits: R1CS shape + witness program (replaces the `.r1cs` that nova_scotia::circom::reader::load_r1cs
  *      reads at vimz/src/nova_snark_backend/folding.rs:22 and the circom witness generator named by

@@ -124,6 +124,30 @@ def test_seam_over_the_pasta_fields(ctx, oracle, curve):
         S.free(); ck.free()
 
 
+@pytest.mark.parametrize("fid", [_lib.FIELD_BN254_FR, _lib.FIELD_BN254_FQ, _lib.FIELD_PALLAS_FP, _lib.FIELD_VESTA_FQ])
+def test_vec_axpy_matches_the_oracle(ctx, oracle, fid):
+    """The fold of a resident vector (RelaxedR1CSWitness::fold) in all four fields: x1 + r·x2 on a prefix, the rest untouched."""
+    from vimz_amd import hip
+    q = oracle.modulus[fid]
+    rng = np.random.default_rng(90 + fid)
+    n = 10_000
+    a = to_limbs([int.from_bytes(rng.bytes(32), "little") % q for _ in range(n)])
+    b = to_limbs([int.from_bytes(rng.bytes(32), "little") % q for _ in range(n)])
+    r = int.from_bytes(rng.bytes(16), "little") | 1 << 128
+    x1, x2 = ctx.vec_from_host(fid, a), ctx.vec_from_host(fid, b)
+    try:
+        hip.vec_axpy(ctx, x1, r, x2, n=n - 7)
+        got = x1.download()
+        assert np.array_equal(got[: n - 7], oracle.axpy(fid, a[: n - 7], r, b[: n - 7]))
+        assert np.array_equal(got[n - 7:], a[n - 7:])
+        with pytest.raises(_lib.VimzError):
+            hip.vec_axpy(ctx, x1, q, x2)                  # r not reduced
+        with pytest.raises(_lib.VimzError):
+            hip.vec_axpy(ctx, x1, 3, x1)
+    finally:
+        x1.free(); x2.free()
+
+
 def test_upload_rejects_bad_shapes(ctx):
     from vimz_amd import hip
     one = to_limbs([1])

@@ -206,4 +206,25 @@ int vimz_commit_T(vimz_ctx* ctx, const vimz_r1cs* S, const vimz_bases* ck, const
   return vz_msm_device(ctx, ck, 0, T_out->d, nr, 1, 0, comm_T, out_form);
 }
 
+// x1 <- x1 + r * x2 over the first n elements: RelaxedR1CSWitness::fold (W and E) / the fold of any resident vector.
+int vimz_vec_axpy(vimz_ctx* ctx, vimz_vec* x1, const uint64_t r[4], int form, const vimz_vec* x2, size_t n) {
+  if (!ctx || !x1 || !x2 || !r) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_vec_axpy: bad argument");
+  if (x1->field != x2->field || n > x1->n || n > x2->n) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_vec_axpy: fields differ or a vector is shorter than n");
+  if (x1 == x2) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_vec_axpy: x1 and x2 must be different vectors");
+  if (!n) return VIMZ_OK;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  R_TRY(hipSetDevice(ctx->device));
+  int rc = field_dispatch(x1->field, [&](auto f) {
+    typedef decltype(f) F;
+    F a; memcpy(a.v, r, 32);
+    if (!a.is_reduced()) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_vec_axpy: r not below the modulus");
+    if (form == VIMZ_FORM_CANONICAL) a = F::to_mont(a);
+    hipLaunchKernelGGL(k_axpy_inplace<F>, dim3(stream_grid(n)), dim3(256), 0, ctx->stream, n, x1->d, a, (const uint32_t*)x2->d);
+    return VIMZ_OK;
+  });
+  if (rc) return rc;
+  R_TRY(hipGetLastError());
+  return VIMZ_OK;
+}
+
 }  // extern "C"

@@ -541,6 +541,14 @@ class _Coo(C.Structure):
     _fields_ = [("row", C.c_void_p), ("col", C.c_void_p), ("val", C.c_void_p), ("nnz", C.c_size_t)]
 
 
+def vec_axpy(ctx, x1, r, x2, n=None, form=L.FORM_CANONICAL):
+    """x1 <- x1 + r * x2 (vimz_vec_axpy): RelaxedR1CSWitness::fold of a resident vector; r an int (canonical) or 4 limbs in `form`."""
+    lib = ctx.lib
+    lib.vimz_vec_axpy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+    rl = _u64([(int(r) >> (64 * i)) & ((1 << 64) - 1) for i in range(4)]) if isinstance(r, int) else _u64(r)
+    ctx._chk(lib.vimz_vec_axpy(ctx.h, x1.h, rl.ctypes.data, form, x2.h, x1.n if n is None else n))
+
+
 class R1CSShape:
     """vimz_r1cs: a caller-supplied R1CS shape resident on the GPU — the `R1CSShape` of nova-snark 0.23.0 behind the C ABI
     (multiply_vec -> spmv3, commit_T -> commit_T).  Matrices are COO triplets (row, col, value) in any order, like the crate's."""
