@@ -124,6 +124,81 @@ def test_seam_over_the_pasta_fields(ctx, oracle, curve):
         S.free(); ck.free()
 
 
+def _toy_circuit(rng, q, n_in, n_mul, n_lin):
+    """A satisfiable R1CS over GF(q) in the layout z = [W | u | x0, x1]: input wires, products of earlier wires (one constraint each),
+    linear combinations (lin · u = w, so they stay consistent in relaxed form), and two public outputs.  Returns the three matrices as
+    triplet lists and a witness generator."""
+    m = n_in + n_mul + n_lin                       # witness wires; u at column m, X at m+1, m+2
+    A, B, Cm, ops = [], [], [], []
+    row = 0
+    for k in range(n_in, m):
+        a, b = int(rng.integers(0, k)), int(rng.integers(0, k))
+        ca, cb = int(rng.integers(1, 1 << 20)), q - int(rng.integers(1, 1 << 20))
+        if k < n_in + n_mul:
+            A.append((row, a, ca)); B.append((row, b, cb)); Cm.append((row, k, 1)); ops.append(("mul", k, a, b, ca, cb))
+        else:
+            A.append((row, a, ca)); A.append((row, b, cb) if b != a else (row, (a + 1) % k, cb)); B.append((row, m, 1)); Cm.append((row, k, 1))
+            ops.append(("lin", k, a, b if b != a else (a + 1) % k, ca, cb))
+        row += 1
+    for j, src in enumerate((m - 1, m - 2)):       # public outputs: w_src · u = x_j
+        A.append((row, src, 1)); B.append((row, m, 1)); Cm.append((row, m + 1 + j, 1)); row += 1
+
+    def witness():
+        w = [int.from_bytes(rng.bytes(32), "little") % q for _ in range(n_in)] + [0] * (m - n_in)
+        for kind, k, a, b, ca, cb in ops:
+            w[k] = (ca * w[a] % q) * (cb * w[b] % q) % q if kind == "mul" else (ca * w[a] + cb * w[b]) % q
+        return w, [w[m - 1], w[m - 2]]
+
+    def coo(T):
+        return (np.asarray([t[0] for t in T], dtype=np.uint32), np.asarray([t[1] for t in T], dtype=np.uint32), to_limbs([t[2] for t in T]))
+    return row, m + 3, m, coo(A), coo(B), coo(Cm), witness
+
+
+@pytest.mark.parametrize("curve", [_lib.CURVE_PALLAS, _lib.CURVE_VESTA])
+def test_nifs_over_the_pasta_cycle_through_the_seam(ctx, oracle, curve):
+    """Nova's non-interactive folding (NIFS::prove as RecursiveSNARK::prove_step runs it, folding.rs:35-41) over Pallas / Vesta with
+    nothing but the C-ABI seam: commitments (vimz_msm_vec), cross term and its commitment (vimz_commit_T), the folds of W and E
+    (vimz_vec_axpy); the folded commitments and scalars on the host.  Five fresh instances of a satisfiable toy circuit are folded;
+    the oracle then checks that the running instance satisfies the relaxed relation and that its two commitments open to W and E."""
+    from vimz_amd import hip
+    fid = _lib.CURVE_SCALAR_FIELD[curve]
+    q = oracle.modulus[fid]
+    rng = np.random.default_rng(1000 + curve)
+    nrows, ncols, m, A, B, Cm, witness = _toy_circuit(rng, q, n_in=64, n_mul=3000, n_lin=500)
+    S = hip.R1CSShape(ctx, fid, nrows, ncols, A, B, Cm)
+    nk = max(nrows, m)
+    bases = oracle.seq_bases(curve, nk)
+    ck = ctx.bases_upload(curve, bases)
+    zrun = ctx.vec_alloc(fid, ncols)              # running instance: z = [W | u | X], all zero to begin with
+    E = ctx.vec_alloc(fid, nrows)
+    u_run, X_run, cW_run, cE_run = 0, [0, 0], (0, 0), (0, 0)
+    try:
+        for step in range(5):
+            w, X = witness()
+            z2 = ctx.vec_from_host(fid, to_limbs(w + [1] + X))
+            cW2 = tuple(from_limbs(ctx.msm_vec(ck, z2, n=m)))
+            T, cT = S.commit_T(ck, zrun, u_run, z2, 1)
+            cT = tuple(from_limbs(cT))
+            r = (int.from_bytes(rng.bytes(16), "little") | 1 << 127) % q       # any challenge: the transcript is the caller's business
+            hip.vec_axpy(ctx, zrun, r, z2)                                     # W, u and X in one pass (z holds all three)
+            hip.vec_axpy(ctx, E, r, T)
+            u_run = (u_run + r) % q
+            X_run = [(a + r * b) % q for a, b in zip(X_run, X)]
+            cW_run = oracle.curve_add(curve, cW_run, oracle.curve_mul(curve, cW2, r))
+            cE_run = oracle.curve_add(curve, cE_run, oracle.curve_mul(curve, cT, r))
+            T.free(); z2.free()
+        zh, Eh = zrun.download(), E.download()
+        assert from_limbs(zh[m]) == [u_run] and from_limbs(zh[m + 1:]) == X_run
+        prods = [oracle.spmv(fid, nrows, ncols, *_csr(*M, nrows), zh) for M in (A, B, Cm)]
+        assert oracle.first_unsat(fid, *prods, u=u_run, E=Eh) == -1           # Az∘Bz = u·Cz + E
+        assert oracle.msm(curve, bases[:m], zh[:m], threads=8) == cW_run
+        assert oracle.msm(curve, bases[:nrows], Eh, threads=8) == cE_run
+        bad = Eh.copy(); bad[5, 0] ^= np.uint64(1)
+        assert oracle.first_unsat(fid, *prods, u=u_run, E=bad) == 5
+    finally:
+        S.free(); ck.free(); zrun.free(); E.free()
+
+
 @pytest.mark.parametrize("fid", [_lib.FIELD_BN254_FR, _lib.FIELD_BN254_FQ, _lib.FIELD_PALLAS_FP, _lib.FIELD_VESTA_FQ])
 def test_vec_axpy_matches_the_oracle(ctx, oracle, fid):
     """The fold of a resident vector (RelaxedR1CSWitness::fold) in all four fields: x1 + r·x2 on a prefix, the rest untouched."""
