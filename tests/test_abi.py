@@ -39,3 +39,15 @@ def test_no_cpu_fallback_without_gpu():
     with pytest.raises(_lib.VimzError) as e:
         hip.Context(0)
     assert e.value.code == _lib.ERR_NO_DEVICE
+
+
+def test_bench_sizes_its_cpu_baseline_by_the_usable_cores():
+    """bench.py's CPU baseline uses as many threads as the process may really run (affinity mask capped by the cgroup quota): at least
+    one, never more than the machine shows."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    n = bench.usable_cores()
+    assert 1 <= n <= (os.cpu_count() or 1)
