@@ -143,6 +143,11 @@ int vimz_spmv3(vimz_ctx* ctx, const vimz_r1cs* shape, const vimz_vec* z, vimz_ve
  * (u2 = 1 for a fresh instance).  ck: at least nrows generators on the curve whose scalar field is the shape's field. */
 int vimz_commit_T(vimz_ctx* ctx, const vimz_r1cs* shape, const vimz_bases* ck, const vimz_vec* z1, const uint64_t u1[4], const vimz_vec* z2,
                   const uint64_t u2[4], int form, vimz_vec* T_out, uint64_t comm_T[8], int out_form);
+/* R1CSShape::is_sat_relaxed for a resident assignment z = [W, u-slot, X] with relaxation scalar u (in `form`) and error vector E (NULL = 0):
+ * bad_rows = number of rows with (A·z)∘(B·z) != u·(C·z) + E, first_bad = the first of them (all ones if none).  nova-snark 0.23.0,
+ * reached from RecursiveSNARK::verify (folding.rs:53-55). */
+int vimz_r1cs_check_relaxed(vimz_ctx* ctx, const vimz_r1cs* shape, const vimz_vec* z, const uint64_t u[4], int form, const vimz_vec* E,
+                            uint64_t* bad_rows, uint64_t* first_bad);
 /* x1 <- x1 + r * x2 over the first n elements (r in `form`): the fold of a resident vector — RelaxedR1CSWitness::fold for W and E,
  * nova-snark 0.23.0 (reached from NIFS::prove, folding.rs:35-41).  Both vectors of the same field, x1 != x2. */
 int vimz_vec_axpy(vimz_ctx* ctx, vimz_vec* x1, const uint64_t r[4], int form, const vimz_vec* x2, size_t n);

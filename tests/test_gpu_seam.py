@@ -199,6 +199,47 @@ def test_nifs_over_the_pasta_cycle_through_the_seam(ctx, oracle, curve):
         S.free(); ck.free(); zrun.free(); E.free()
 
 
+@pytest.mark.parametrize("curve", [_lib.CURVE_PALLAS, _lib.CURVE_VESTA, _lib.CURVE_BN254_G1])
+def test_relaxed_accumulator_over_the_seam(ctx, oracle, curve):
+    """vimz_amd.nifs.RelaxedAccumulator (the product's NIFS over a caller-supplied shape, device calls only) against the oracle: after
+    six folds its own verify() passes, the oracle agrees on the relaxed relation and on both openings and re-derives the folded
+    commitments from the per-step values with its own curve arithmetic; a tampered error vector or witness is rejected."""
+    from vimz_amd import hip, nifs
+    fid = _lib.CURVE_SCALAR_FIELD[curve]
+    q = oracle.modulus[fid]
+    rng = np.random.default_rng(2000 + curve)
+    nrows, ncols, m, A, B, Cm, witness = _toy_circuit(rng, q, n_in=32, n_mul=2500, n_lin=300)
+    acc = nifs.RelaxedAccumulator(ctx, curve, nrows, m, 2, A, B, Cm, q)
+    try:
+        cW, cE = (0, 0), (0, 0)
+        for _ in range(6):
+            w, X = witness()
+            r, cW2, cT = acc.fold(w, X)
+            cW = oracle.curve_add(curve, cW, oracle.curve_mul(curve, tuple(from_limbs(cW2)), r))
+            cE = oracle.curve_add(curve, cE, oracle.curve_mul(curve, tuple(from_limbs(cT)), r))
+        assert acc.verify() == 0
+        inst = acc.instance()
+        assert tuple(from_limbs(inst["comm_W"])) == cW and tuple(from_limbs(inst["comm_E"])) == cE and inst["steps"] == 6
+        zh, Eh = acc.z.download(), acc.E.download()
+        bases = acc.ck.download(0, max(m, nrows))
+        prods = [oracle.spmv(fid, nrows, ncols, *_csr(*M, nrows), zh) for M in (A, B, Cm)]
+        assert oracle.first_unsat(fid, *prods, u=inst["u"], E=Eh) == -1
+        assert oracle.msm(curve, bases[:m], zh[:m], threads=8) == cW
+        assert oracle.msm(curve, bases[:nrows], Eh, threads=8) == cE
+        # a flipped bit in E: relation and opening fail; in W: relation (some row), opening of W
+        bad = Eh.copy(); bad[11, 0] ^= np.uint64(1)
+        acc.E.upload(bad)
+        assert acc.verify() & 5 == 5 and acc.shape.check_relaxed(acc.z, inst["u"], acc.E)[1] == 11
+        acc.E.upload(Eh)
+        badz = zh.copy(); badz[3, 0] ^= np.uint64(1)
+        acc.z.upload(badz)
+        assert acc.verify() & 2
+        acc.z.upload(zh)
+        assert acc.verify() == 0
+    finally:
+        acc.free()
+
+
 @pytest.mark.parametrize("fid", [_lib.FIELD_BN254_FR, _lib.FIELD_BN254_FQ, _lib.FIELD_PALLAS_FP, _lib.FIELD_VESTA_FQ])
 def test_vec_axpy_matches_the_oracle(ctx, oracle, fid):
     """The fold of a resident vector (RelaxedR1CSWitness::fold) in all four fields: x1 + r·x2 on a prefix, the rest untouched."""

@@ -206,6 +206,39 @@ int vimz_commit_T(vimz_ctx* ctx, const vimz_r1cs* S, const vimz_bases* ck, const
   return vz_msm_device(ctx, ck, 0, T_out->d, nr, 1, 0, comm_T, out_form);
 }
 
+// is_sat_relaxed of a resident assignment: the number of rows with (A·z)∘(B·z) != u·(C·z) + E and the first of them.
+int vimz_r1cs_check_relaxed(vimz_ctx* ctx, const vimz_r1cs* S, const vimz_vec* z, const uint64_t u[4], int form, const vimz_vec* E, uint64_t* bad_rows, uint64_t* first_bad) {
+  if (!ctx || !S || !z || !u || !bad_rows) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_r1cs_check_relaxed: bad argument");
+  if (z->field != S->field || z->n < S->ncols || (E && (E->field != S->field || E->n < S->nrows)))
+    return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_r1cs_check_relaxed: field or length of a vector does not fit the shape");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  R_TRY(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  const size_t nr = S->nrows;
+  uint32_t* w = S->scratch;
+  uint32_t* bad_d = w + 8 * 3 * nr;              // (the second half of the scratch is free here)
+  const uint32_t init[2] = {0, 0xffffffffu};
+  R_TRY(hipMemcpyAsync(bad_d, init, 8, hipMemcpyHostToDevice, s));
+  int rc = field_dispatch(S->field, [&](auto f) {
+    typedef decltype(f) F;
+    F a; memcpy(a.v, u, 32);
+    if (!a.is_reduced()) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_r1cs_check_relaxed: u not below the modulus");
+    if (form == VIMZ_FORM_CANONICAL) a = F::to_mont(a);
+    spmv3<F>(S, s, z->d, w, w + 8 * nr, w + 16 * nr);
+    hipLaunchKernelGGL(k_check_relaxed<F>, dim3(stream_grid(nr)), dim3(256), 0, s, nr, (const uint32_t*)w, (const uint32_t*)(w + 8 * nr), (const uint32_t*)(w + 16 * nr), a,
+                       E ? (const uint32_t*)E->d : (const uint32_t*)nullptr, bad_d);
+    return VIMZ_OK;
+  });
+  if (rc) return rc;
+  R_TRY(hipGetLastError());
+  uint32_t bad[2];
+  R_TRY(hipMemcpyAsync(bad, bad_d, 8, hipMemcpyDeviceToHost, s));
+  R_TRY(hipStreamSynchronize(s));
+  *bad_rows = bad[0];
+  if (first_bad) *first_bad = bad[0] ? bad[1] : ~0ull;
+  return VIMZ_OK;
+}
+
 // x1 <- x1 + r * x2 over the first n elements: RelaxedR1CSWitness::fold (W and E) / the fold of any resident vector.
 int vimz_vec_axpy(vimz_ctx* ctx, vimz_vec* x1, const uint64_t r[4], int form, const vimz_vec* x2, size_t n) {
   if (!ctx || !x1 || !x2 || !r) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_vec_axpy: bad argument");

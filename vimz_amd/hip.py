@@ -573,6 +573,15 @@ class R1CSShape:
         ctx._chk(lib.vimz_r1cs_upload(ctx.h, field, nrows, ncols, C.byref(coos[0]), C.byref(coos[1]), C.byref(coos[2]), form, C.byref(h)))
         self.h = h
 
+    def check_relaxed(self, z, u, E=None, form=L.FORM_CANONICAL):
+        """is_sat_relaxed (vimz_r1cs_check_relaxed): (number of unsatisfied rows, first of them or None)."""
+        lib = self.ctx.lib
+        lib.vimz_r1cs_check_relaxed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        ul = _u64([(int(u) >> (64 * i)) & ((1 << 64) - 1) for i in range(4)]) if isinstance(u, int) else _u64(u)
+        bad, first = C.c_uint64(), C.c_uint64()
+        self.ctx._chk(lib.vimz_r1cs_check_relaxed(self.ctx.h, self.h, z.h, ul.ctypes.data, form, E.h if E is not None else None, C.byref(bad), C.byref(first)))
+        return int(bad.value), (int(first.value) if bad.value else None)
+
     def free(self):
         if self.h:
             self.ctx.lib.vimz_r1cs_free(self.ctx.h, self.h)
