@@ -11,11 +11,11 @@ def _section(t, payload):
     return struct.pack("<IQ", t, len(payload)) + payload
 
 
-def write_r1cs(n_wires, n_pub_out, n_pub_in, n_prv, csr_abc, dict_canon):
+def write_r1cs(n_wires, n_pub_out, n_pub_in, n_prv, csr_abc, dict_canon, prime=PRIME):
     """csr_abc: three (row_ptr, col, coef) uint32 triples; dict_canon: (n,4) uint64 coefficient dictionary."""
     ncon = len(csr_abc[0][0]) - 1
     dict_bytes = [bytes(np.ascontiguousarray(d)) for d in dict_canon]
-    hdr = struct.pack("<I", 32) + PRIME.to_bytes(32, "little") + struct.pack("<IIIIQI", n_wires, n_pub_out, n_pub_in, n_prv, n_wires, ncon)
+    hdr = struct.pack("<I", 32) + prime.to_bytes(32, "little") + struct.pack("<IIIIQI", n_wires, n_pub_out, n_pub_in, n_prv, n_wires, ncon)
     body = bytearray()
     for k in range(ncon):
         for rp, col, coef in csr_abc:
@@ -27,7 +27,7 @@ def write_r1cs(n_wires, n_pub_out, n_pub_in, n_prv, csr_abc, dict_canon):
     return b"r1cs" + struct.pack("<II", 1, 3) + _section(1, hdr) + _section(2, bytes(body)) + _section(3, labels)
 
 
-def write_wtns(witness_limbs):
+def write_wtns(witness_limbs, prime=PRIME):
     w = np.ascontiguousarray(witness_limbs, dtype=np.uint64).reshape(-1, 4)
-    hdr = struct.pack("<I", 32) + PRIME.to_bytes(32, "little") + struct.pack("<I", w.shape[0])
+    hdr = struct.pack("<I", 32) + prime.to_bytes(32, "little") + struct.pack("<I", w.shape[0])
     return b"wtns" + struct.pack("<II", 2, 2) + _section(1, hdr) + _section(2, w.tobytes())

@@ -240,6 +240,59 @@ def test_relaxed_accumulator_over_the_seam(ctx, oracle, curve):
         acc.free()
 
 
+def _circom_files(rng, q, n_in, n_mul, n_lin, n_witnesses):
+    """The toy circuit as circom would emit it for the prime q — `.r1cs` bytes in circom's wire order [1 | outputs | private] and a few
+    `.wtns` — written with the test-side iden3 writers."""
+    from tests import _iden3
+    nrows, ncols, m, A, B, Cm, witness = _toy_circuit(rng, q, n_in, n_mul, n_lin)
+    n_pub = 2
+    def wire(col):          # nova column -> circom wire
+        return np.where(col == m, 0, np.where(col > m, col - m, col + n_pub + 1)).astype(np.uint32)
+    vals_all = np.concatenate([M[2] for M in (A, B, Cm)])
+    dict_canon, inv = np.unique(vals_all, axis=0, return_inverse=True)
+    csr, off = [], 0
+    for rows, cols, vals in (A, B, Cm):
+        order = np.argsort(rows, kind="stable")
+        rp = np.zeros(nrows + 1, dtype=np.uint32); np.add.at(rp, rows.astype(np.int64) + 1, 1)
+        csr.append((np.cumsum(rp).astype(np.uint32), wire(cols.astype(np.int64))[order], inv.reshape(-1)[off:off + len(rows)][order].astype(np.uint32)))
+        off += len(rows)
+    r1cs_bytes = _iden3.write_r1cs(1 + n_pub + m, n_pub, 0, m, csr, dict_canon, prime=q)
+    wtns = []
+    for _ in range(n_witnesses):
+        w, X = witness()
+        wtns.append(_iden3.write_wtns(to_limbs([1] + X + w), prime=q))
+    return r1cs_bytes, wtns, (nrows, m)
+
+
+@pytest.mark.parametrize("curve", [_lib.CURVE_PALLAS, _lib.CURVE_VESTA])
+def test_circom_artefacts_for_a_pasta_prime_fold_through_the_seam(ctx, oracle, curve):
+    """`.r1cs` / `.wtns` as circom writes them for a Pasta prime (vimz_amd.iden3 reads them) folded with RelaxedAccumulator.from_r1cs —
+    the nova-scotia flow (load_r1cs, one witness per step) on the cycle north_star names; verify() and the oracle accept."""
+    from vimz_amd import iden3, nifs
+    fid = _lib.CURVE_SCALAR_FIELD[curve]
+    q = oracle.modulus[fid]
+    rng = np.random.default_rng(3000 + curve)
+    r1cs_bytes, wtns, (nrows, m) = _circom_files(rng, q, 16, 1200, 200, 4)
+    r1cs = iden3.read_r1cs(r1cs_bytes)
+    assert r1cs["prime"] == q and r1cs["n_constraints"] == nrows and r1cs["n_wires"] == m + 3
+    acc = nifs.RelaxedAccumulator.from_r1cs(ctx, curve, r1cs)
+    try:
+        for blob in wtns:
+            prime, vals = iden3.read_wtns(blob)
+            assert prime == q
+            acc.fold(*iden3.split_witness(r1cs, vals))
+        assert acc.verify() == 0 and acc.steps == 4
+        n_w, n_pub, A, B, Cm = iden3.to_nova_columns(r1cs)
+        zh, Eh = acc.z.download(), acc.E.download()
+        prods = [oracle.spmv(fid, nrows, n_w + 1 + n_pub, *_csr(*M, nrows), zh) for M in (A, B, Cm)]
+        assert oracle.first_unsat(fid, *prods, u=acc.u, E=Eh) == -1
+        assert oracle.msm(curve, acc.ck.download(0, n_w), zh[:n_w], threads=8) == tuple(from_limbs(acc.comm_W))
+        with pytest.raises(ValueError):
+            iden3.split_witness(r1cs, iden3.read_wtns(wtns[0])[1][:-1])
+    finally:
+        acc.free()
+
+
 @pytest.mark.parametrize("fid", [_lib.FIELD_BN254_FR, _lib.FIELD_BN254_FQ, _lib.FIELD_PALLAS_FP, _lib.FIELD_VESTA_FQ])
 def test_vec_axpy_matches_the_oracle(ctx, oracle, fid):
     """The fold of a resident vector (RelaxedR1CSWitness::fold) in all four fields: x1 + r·x2 on a prefix, the rest untouched."""

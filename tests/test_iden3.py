@@ -108,3 +108,29 @@ def test_ivc_over_a_loaded_r1cs_with_external_witnesses(oracle, hash_circuit):
             ivc.fold_witness(np.stack([wits[0]]))        # does not continue the chain
     finally:
         ivc.close(); ck1.free(); ck2.free(); ctx.close()
+
+
+def test_python_reader_handles_any_prime():
+    """vimz_amd.iden3 (the reader that feeds the seam-based accumulator) on files written for the Pallas base field: header, triplets in
+    circom's wire numbering, the move to nova-snark's column order, witnesses."""
+    import numpy as np
+    from tests import _iden3
+    from tests._oracle import Q_VESTA, to_limbs
+    from vimz_amd import iden3
+    # two constraints over wires [1 | out | in | a, b]:  a*b = out ;  (in + 3)*1 = a
+    dict_canon = to_limbs([1, 3, Q_VESTA - 1])
+    A = (np.array([0, 1, 3], dtype=np.uint32), np.array([3, 2, 0], dtype=np.uint32), np.array([0, 0, 1], dtype=np.uint32))
+    B = (np.array([0, 1, 2], dtype=np.uint32), np.array([4, 0], dtype=np.uint32), np.array([0, 0], dtype=np.uint32))
+    C = (np.array([0, 1, 2], dtype=np.uint32), np.array([1, 3], dtype=np.uint32), np.array([0, 0], dtype=np.uint32))
+    blob = _iden3.write_r1cs(5, 1, 1, 2, [A, B, C], dict_canon, prime=Q_VESTA)
+    r = iden3.read_r1cs(blob)
+    assert (r["prime"], r["n_wires"], r["n_pub_out"], r["n_pub_in"], r["n_prv"], r["n_constraints"]) == (Q_VESTA, 5, 1, 1, 2, 2)
+    assert r["A"][0].tolist() == [0, 1, 1] and r["A"][1].tolist() == [3, 2, 0] and r["A"][2][2].tolist() == [3, 0, 0, 0]
+    n_w, n_pub, An, Bn, Cn = iden3.to_nova_columns(r)
+    assert (n_w, n_pub) == (2, 2)
+    assert An[1].tolist() == [0, 4, 2] and Bn[1].tolist() == [1, 2] and Cn[1].tolist() == [3, 0]      # W = [a, b], u at 2, X = [out, in] at 3, 4
+    wt = _iden3.write_wtns(to_limbs([1, 35, 4, 7, 5]), prime=Q_VESTA)
+    prime, vals = iden3.read_wtns(wt)
+    assert prime == Q_VESTA
+    W, X = iden3.split_witness(r, vals)
+    assert W[:, 0].tolist() == [7, 5] and X == [35, 4]

@@ -45,6 +45,13 @@ class RelaxedAccumulator:
         self.comm_E = np.zeros(8, dtype=np.uint64)
         self.steps = 0
 
+    @classmethod
+    def from_r1cs(cls, ctx, curve, r1cs, ck=None):
+        """From a parsed circom `.r1cs` (vimz_amd.iden3.read_r1cs) whose prime is `curve`'s scalar field."""
+        from . import iden3
+        n_w, n_pub, A, B, Cm = iden3.to_nova_columns(r1cs)
+        return cls(ctx, curve, r1cs["n_constraints"], n_w, n_pub, A, B, Cm, r1cs["prime"], ck=ck)
+
     # ---- host-side pieces ------------------------------------------------------------------------------------------------------------
     def _scalar_mul(self, point, k):
         """k·P for one affine point, as an MSM of one term over a throw-away key (vimz_msm)."""
