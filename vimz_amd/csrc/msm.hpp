@@ -114,30 +114,33 @@ __global__ void __launch_bounds__(1024) k_scan(const uint32_t* __restrict__ coun
                                                uint32_t* __restrict__ totals, uint32_t sub,
                                                uint32_t* __restrict__ heavy /* [0] = count (zeroed by the caller), then ids of buckets with > heavy_min sub-buckets */,
                                                uint32_t heavy_min, uint32_t heavy_cap) {
-  __shared__ uint32_t sh_e[1024], sh_s[1024];
-  const uint32_t t = threadIdx.x;
-  const uint32_t per = (nb + 1023) / 1024;
-  const uint32_t lo = min(nb, t * per), hi = min(nb, lo + per);
-  uint32_t e = 0, s = 0;
-  for (uint32_t b = lo; b < hi; b++) { uint32_t cnt = counts[b]; e += cnt; s += (cnt + sub - 1) / sub; }
-  sh_e[t] = e; sh_s[t] = s;
-  __syncthreads();
-  for (uint32_t d = 1; d < 1024; d <<= 1) {  // Hillis-Steele inclusive scan
-    uint32_t ve = 0, vs = 0;
-    if (t >= d) { ve = sh_e[t - d]; vs = sh_s[t - d]; }
+  // One pass, coalesced: the buckets are taken 1024 at a time (thread t: bucket base + t); each block is scanned inside its waves
+  // by shuffles and across the 16 wave totals through LDS (one barrier per block, the totals double-buffered), carrying the running
+  // totals along.  (This kernel sits between the two sort passes of every MSM, on a step's dependent chain.  The first version gave
+  // every thread 24 consecutive buckets — two strided passes over the counters and a twenty-barrier Hillis-Steele scan: 50 µs.)
+  __shared__ uint32_t wv_e[2][16], wv_s[2][16];
+  const uint32_t t = threadIdx.x, lane = t & 63u, wv = t >> 6;
+  uint32_t carry_e = 0, carry_s = 0;
+  for (uint32_t base = 0, it = 0; base < nb; base += 1024, it++) {
+    const uint32_t b = base + t;
+    const uint32_t cnt = b < nb ? counts[b] : 0u, m = (cnt + sub - 1) / sub;
+    uint32_t ie = cnt, is = m;
+#pragma unroll
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+      const uint32_t ve = __shfl_up(ie, d), vs = __shfl_up(is, d);
+      if (lane >= d) { ie += ve; is += vs; }
+    }
+    if (lane == 63) { wv_e[it & 1][wv] = ie; wv_s[it & 1][wv] = is; }
     __syncthreads();
-    sh_e[t] += ve; sh_s[t] += vs;
-    __syncthreads();
+    uint32_t oe = 0, os = 0, te = 0, ts = 0;
+    for (uint32_t q = 0; q < 16; q++) { const uint32_t xe = wv_e[it & 1][q], xs = wv_s[it & 1][q]; if (q < wv) { oe += xe; os += xs; } te += xe; ts += xs; }
+    if (b < nb) {
+      bucket_off[b] = carry_e + oe + ie - cnt; sub_off[b] = carry_s + os + is - m;
+      if (m > heavy_min) { const uint32_t slot = atomicAdd(&heavy[0], 1u); if (slot < heavy_cap) heavy[1 + slot] = b; }
+    }
+    carry_e += te; carry_s += ts;
   }
-  uint32_t be = sh_e[t] - e, bs = sh_s[t] - s;
-  for (uint32_t b = lo; b < hi; b++) {
-    uint32_t cnt = counts[b];
-    bucket_off[b] = be; sub_off[b] = bs;
-    const uint32_t m = (cnt + sub - 1) / sub;
-    if (m > heavy_min) { const uint32_t slot = atomicAdd(&heavy[0], 1u); if (slot < heavy_cap) heavy[1 + slot] = b; }
-    be += cnt; bs += m;
-  }
-  if (t == 1023) { bucket_off[nb] = sh_e[1023]; sub_off[nb] = sh_s[1023]; totals[0] = sh_s[1023]; totals[1] = sh_e[1023]; }
+  if (t == 0) { bucket_off[nb] = carry_e; sub_off[nb] = carry_s; totals[0] = carry_s; totals[1] = carry_e; }
 }
 
 template <class S>
