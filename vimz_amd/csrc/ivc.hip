@@ -13,6 +13,11 @@
 //      MSM(T2) on the GPU with the same kernels instantiated for Fq / Grumpkin.
 // The challenges are the ones the circuits derive (rho = 2^128 + low 128 bits of a Poseidon hash), so the folded instances
 // the prover holds are exactly the ones the circuits compute: vimz_ivc_verify checks that.
+//
+// Schedule: streams 1 and 2 (high priority) carry the two halves of a step, stream 3 the one large MSM — the step
+// rows' cross term, written by k_fold_cross together with the fold of the step rows and queued from INSIDE the secondary circuit's
+// evaluation (AugCircuit::on_challenge) —, two low-priority streams the batch producer, whose launches come from an issuer thread.
+// Option VIMZ_IVC_LOOKAHEAD=1: the cross term of step i+2 against the running instance of step i+1 (T1Slot, fold_issue_d).
 #include "ivc_internal.hpp"
 
 namespace {
