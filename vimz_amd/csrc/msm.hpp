@@ -696,6 +696,9 @@ hipError_t msm_launch(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_ba
   typedef typename C::Coord F;
   typedef typename C::Scalar S;
   if (n == 0 || n >= (1u << 31)) return hipErrorInvalidValue;
+  // The window sums go straight into the caller's pinned buffer (host memory the device can write): the copy that used to follow —
+  // a launch and a dependent hop between the last kernel and the host's wake-up — is gone.  (VIMZ_DEBUG_COPY_SUMS: the copy.)
+  static const bool direct = getenv("VIMZ_DEBUG_COPY_SUMS") == nullptr;
   // tables made for the fused small path (window SMALL_C): its window sums then only need adding — no Horner on the host
   static const bool no_small = getenv("VIMZ_DEBUG_NO_SMALL_MSM") != nullptr;
   const bool small_fmt = tb && tb->d && tb->c == SMALL_C;             // (ignored, not an error, when the fused path is switched off)
@@ -715,12 +718,12 @@ hipError_t msm_launch(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_ba
     if (ev) for (int i = 0; i < 4; i++) VZ_HIP_CHECK(hipEventRecord(ev[i], stream));
     static const bool sum_kernel = getenv("VIMZ_DEBUG_SMALL_SUM_KERNEL") != nullptr;
     hipLaunchKernelGGL((k_msm_small<S, F>), dim3(ps.K, Q), dim3(SMALL_THREADS), 0, stream, d_bases, d_scalars, (uint32_t)n, scalars_mont, Q, chunk, chunk_out,
-                       sum_kernel ? (uint32_t*)nullptr : done, reinterpret_cast<uint32_t*>(ws.window_sums),
+                       sum_kernel ? (uint32_t*)nullptr : done, direct ? reinterpret_cast<uint32_t*>(pinned_dst) : reinterpret_cast<uint32_t*>(ws.window_sums),
                        small_tb ? tb->d + (size_t)AFFINE_WORDS * tb->offset : (const uint32_t*)nullptr, small_tb ? (uint32_t)tb->n_total : 0u);
-    if (Q > 1 && sum_kernel) hipLaunchKernelGGL(k_msm_small_sum<F>, dim3(ps.K), dim3(64), 0, stream, chunk_out, Q, reinterpret_cast<uint32_t*>(ws.window_sums));
+    if (Q > 1 && sum_kernel) hipLaunchKernelGGL(k_msm_small_sum<F>, dim3(ps.K), dim3(64), 0, stream, chunk_out, Q, direct ? reinterpret_cast<uint32_t*>(pinned_dst) : reinterpret_cast<uint32_t*>(ws.window_sums));
     if (ev) for (int i = 4; i < 7; i++) VZ_HIP_CHECK(hipEventRecord(ev[i], stream));
     VZ_HIP_CHECK(hipGetLastError());
-    VZ_HIP_CHECK(hipMemcpyAsync(pinned_dst, ws.window_sums, 4 * (size_t)XYZZ_WORDS * ps.K, hipMemcpyDeviceToHost, stream));
+    if (!direct) VZ_HIP_CHECK(hipMemcpyAsync(pinned_dst, ws.window_sums, 4 * (size_t)XYZZ_WORDS * ps.K, hipMemcpyDeviceToHost, stream));
     return hipSuccess;
   }
   MsmPlan pl = msm_plan(n, S::Params::BITS, tabled ? tb->c : c_override);
@@ -803,7 +806,7 @@ hipError_t msm_launch(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_ba
   hipLaunchKernelGGL(k_combine_heavy2<F>, dim3(MSM_HEAVY_SPLIT / 8), dim3(256), 0, stream, partial, ws.sub_off, ws.heavy, MsmWorkspace::HEAVY_CAP, ws.heavy_scratch);
   VZ_EV(5);
   const unsigned T = pl.nbw < 256 ? pl.nbw : 256;
-  uint32_t* wsum = reinterpret_cast<uint32_t*>(ws.window_sums);
+  uint32_t* wsum = direct ? reinterpret_cast<uint32_t*>(pinned_dst) : reinterpret_cast<uint32_t*>(ws.window_sums);
   const int kout = tabled && !own ? 1 : pl.K;     // window sums produced
   if (tabled && !own) {
     uint32_t* rs = reinterpret_cast<uint32_t*>(ws.ones_partial);   // scratch: 2 x (nbw/256) points (<= 2 x 128 of the 16448)
@@ -821,7 +824,7 @@ hipError_t msm_launch(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_ba
     hipLaunchKernelGGL(k_tree256<F>, dim3(1), dim3(256), 0, stream, lvl1, ONES_THREADS / 256, wsum + (size_t)XYZZ_WORDS * kout);
   }
   VZ_HIP_CHECK(hipGetLastError());
-  VZ_HIP_CHECK(hipMemcpyAsync(pinned_dst, wsum, 4 * (size_t)XYZZ_WORDS * (kout + (split_ones ? 1 : 0)), hipMemcpyDeviceToHost, stream));
+  if (!direct) VZ_HIP_CHECK(hipMemcpyAsync(pinned_dst, wsum, 4 * (size_t)XYZZ_WORDS * (kout + (split_ones ? 1 : 0)), hipMemcpyDeviceToHost, stream));
   return hipSuccess;
 }
 
