@@ -145,7 +145,10 @@ def _spartan_verify(orc, cid, tr, digest, inst, tabs, n_w, n_c, key, Ugen, side_
     N, Mr = 1 << t, 1 << s
     shifted = [key[N - 1]] + list(key[:N - 1])          # index i (wire i) -> ck[i - 1], index 0 -> ck[N - 1]
     import numpy as np
-    if not _ipa_verify(orc, cid, tr, Ugen, np.array(shifted), ey, cW, evalW, rd, pb, ps):
+    # the W opening is over the committed positions only: the public slots (wire 0, the last two wires) and the padding above the
+    # last wire are zeroed in b, so nothing a prover puts under those generators can stand in for (u, X0, X1)
+    eyW = [0 if (i == 0 or i + 2 >= n_w) else v for i, v in enumerate(ey)]
+    if not _ipa_verify(orc, cid, tr, Ugen, np.array(shifted), eyW, cW, evalW, rd, pb, ps):
         return "opening of W"
     if has_E and not _ipa_verify(orc, cid, tr, Ugen, np.array(key[:Mr]), ex, cE, ve, rd, pb, ps):
         return "opening of E"

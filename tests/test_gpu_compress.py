@@ -70,6 +70,42 @@ def test_compressed_proof_of_a_ten_step_hash_ivc(ctx, keys, oracle):
         ivc.close(); vk.close()
 
 
+def test_a_correction_hidden_in_a_public_slot_is_rejected():
+    """the W opening must not let a prover hide a correction of a public entry under the (live, otherwise unused)
+    generator of that entry's slot.  A cheating prover — the test hook VIMZ_TEST_FORGE_PUBLIC_SLOT of vimz_ivc_compress — claims
+    x0 + 1 for the last fresh instance, commits to W − ck[n−3] and opens a vector with −1 in the slot of wire n−2: every sum-check
+    message is honest for the TRUE z.  Before the mask on b this argument was accepted (bit 4 clear); it must fail.  The hook is
+    read per call, so the honest proof of the same process is the control."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = """
+import numpy as np, os, sys
+sys.path.insert(0, %r)
+from tests.test_circuits import step_inputs
+from vimz_amd import _lib, hip
+from vimz_amd.circuit import Circuit
+ctx = hip.Context(0)
+ck1 = ctx.bases_generate(_lib.CURVE_BN254_G1, 1 << 15)
+ck2 = ctx.bases_generate(_lib.CURVE_GRUMPKIN, 1 << 13, b"ck-secondary")
+c = Circuit.for_resolution("hash", "HD")
+z0, inputs = step_inputs("hash")
+ivc = hip.IVC(ctx, c, ck1, ck2, max_batch=4)
+ivc.reset(z0); ivc.fold(np.stack(inputs)[:3])
+honest, _ = ivc.compress()
+os.environ["VIMZ_TEST_FORGE_PUBLIC_SLOT"] = "1"
+forged, _ = ivc.compress()
+del os.environ["VIMZ_TEST_FORGE_PUBLIC_SLOT"]
+print("codes", ivc.verify_compressed(honest, 3, z0), ivc.verify_compressed(forged, 3, z0))
+""" % root
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    honest, forged = [int(x) for x in [l for l in out.stdout.splitlines() if l.startswith("codes ")][-1].split()[1:]]
+    assert honest == 0
+    assert forged & 16, forged        # the argument for the last fresh secondary instance itself fails (not only the chain hash, bit 0)
+
+
 def test_compressed_proof_through_the_reference_call_sequence(ctx, oracle):
     """prepare_folding -> fold_input -> verify_folded_proof -> compress -> verify, as nova_snark_backend::run does (mod.rs:22-67),
     on the grayscale circuit (2^17 rows)."""

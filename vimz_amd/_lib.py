@@ -16,6 +16,13 @@ CURVE_BN254_G1, CURVE_GRUMPKIN, CURVE_PALLAS, CURVE_VESTA = 0, 1, 2, 3
 FIELD_BN254_FR, FIELD_BN254_FQ, FIELD_PALLAS_FP, FIELD_VESTA_FQ = 0, 1, 2, 3
 CURVE_SCALAR_FIELD = {0: 0, 1: 1, 2: 3, 3: 2}
 CURVE_BASE_FIELD = {0: 1, 1: 0, 2: 2, 3: 3}
+# the four field moduli (BN254 Fr, BN254 Fq, Pallas Fp, Vesta Fq), indexed by FIELD_*
+MODULUS = {
+    0: 21888242871839275222246405745257275088548364400416034343698204186575808495617,
+    1: 21888242871839275222246405745257275088696311157297823662689037894645226208583,
+    2: 0x40000000000000000000000000000000224698fc094cf91b992d30ed00000001,
+    3: 0x40000000000000000000000000000000224698fc0994a8dd8c46eb2100000001,
+}
 
 
 class VimzError(RuntimeError):

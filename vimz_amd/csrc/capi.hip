@@ -189,9 +189,12 @@ size_t vimz_pack_count(size_t height, size_t width, int block) {
   return ((height + b - 1) / b) * ((width + b - 1) / b) * b * ((b + 9) / 10);
 }
 int vimz_pack_pixels(vimz_ctx* c, const uint8_t* pixels, size_t height, size_t width, int channels, int block, uint64_t* out) {
-  if (!c || !pixels || !out || !height || !width || (channels != 1 && channels != 3) || block < 0 || height * width > (1ull << 31))
-    return fail(c, VIMZ_ERR_INVALID, "vimz_pack_pixels: bad argument");
+  // (each dimension is bounded before anything is multiplied: the kernel indexes with 32-bit products)
+  if (!c || !pixels || !out || !height || !width || (channels != 1 && channels != 3) || block < 0 || block > 4096 || height > (1ull << 20) || width > (1ull << 20) ||
+      height * width > (1ull << 30))
+    return fail(c, VIMZ_ERR_INVALID, "vimz_pack_pixels: bad argument (at most 2^20 per dimension, 2^30 pixels, blocks of at most 4096)");
   const size_t n = vimz_pack_count(height, width, block), in_bytes = height * width * (size_t)channels;
+  if (n >= (1ull << 31)) return fail(c, VIMZ_ERR_INVALID, "vimz_pack_pixels: output too large");
   std::lock_guard<std::mutex> g(c->mu);
   HIP_TRY(c, hipSetDevice(c->device));
   int rc = ensure_scratch(c, 32 * n + in_bytes + 64);

@@ -134,6 +134,24 @@ struct Grumpkin { typedef Fp<BnFr> Base; typedef Fp29<BnFr> Coord; typedef Fp<Bn
 struct Pallas { typedef Fp<PallasFp> Base; typedef Fp29<PallasFp> Coord; typedef Fp<VestaFq> Scalar; };
 struct Vesta { typedef Fp<VestaFq> Base; typedef Fp29<VestaFq> Coord; typedef Fp<PallasFp> Scalar; };
 
+// y² = x³ + b of the curve whose coordinates live in Fp<P> — for validating points that come from outside (proof blobs): the XYZZ
+// formulas never use b, so an off-curve point would silently compute on another curve.
+template <class P> struct CurveB;
+template <> struct CurveB<BnFq> { static constexpr int value = 3; };        // BN254 G1
+template <> struct CurveB<BnFr> { static constexpr int value = -17; };      // Grumpkin
+template <> struct CurveB<PallasFp> { static constexpr int value = 5; };
+template <> struct CurveB<VestaFq> { static constexpr int value = 5; };
+template <class P>
+inline bool aff_on_curve(const Affine<Fp<P>>& q) {      // the identity's encoding (0,0) counts as on the curve
+  typedef Fp<P> F;
+  if (aff_is_identity(q)) return true;
+  F b = F::zero();
+  const int bv = CurveB<P>::value;
+  for (int i = 0; i < (bv < 0 ? -bv : bv); i++) b = F::add(b, F::one());
+  if (bv < 0) b = F::neg(b);
+  return F::sqr(q.y).eq(F::add(F::mul(F::sqr(q.x), q.x), b));
+}
+
 // Device storage of curve data: coordinates at a stride of 10 words (40 B): affine = 20 words, XYZZ = 40 words.
 constexpr int COORD_WORDS = 10;
 constexpr int AFFINE_WORDS = 2 * COORD_WORDS;

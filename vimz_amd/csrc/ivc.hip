@@ -63,6 +63,17 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
   const double t_all = now_s();
   FoldJob job; job.step_inputs = step_inputs; job.witnesses = witnesses; job.nsteps = nsteps;
   if ((rc = fold_prepare(p, job, true))) return rc;
+  // Any return between here and the end that does not first restore a consistent state (rows folded so far, no cross term queued
+  // ahead, state = that of the last folded row) leaves work of a half-done step behind: such an IVC refuses further folds.
+  struct BrokenGuard { vimz_ivc* v; bool armed = true; ~BrokenGuard() { if (armed) v->broken = true; } } guard{v};
+  auto settle = [&](size_t rows_done) {      // the rows folded so far stay folded: drop what was queued ahead, finish the pending secondary commitments
+    hipStreamSynchronize(p->sB);
+    if (p->sD) hipStreamSynchronize(p->sD);
+    hipStreamSynchronize(v->s3); v->t1[0].step = v->t1[1].step = -1;
+    const int rc2 = finish_secondary(v);
+    for (uint32_t q = 0; q < p->len_z; q++) p->z_cur[q] = job.zs[rows_done * p->len_z + q];
+    if (!rc2) guard.armed = false;
+  };
   static const bool dbg_timing = getenv("VIMZ_DEBUG_TIMING") != nullptr;
   const double t_prep = now_s() - t_all;
   double t_first = 0, t_wait0 = 0;
@@ -189,12 +200,8 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
     if (k == 0) { t_wait0 = now_s() - t0; t_first = now_s() - t_all; }
     for (size_t r = 0; r < rows; r++) if (bb.status_host[r]) {
       char msg[128]; snprintf(msg, sizeof(msg), "step %llu: the step relation is not satisfiable for these rows", (unsigned long long)(v->i + r));
-      hipStreamSynchronize(p->sB);
-      if (p->sD) hipStreamSynchronize(p->sD);
-      hipStreamSynchronize(v->s3); v->t1[0].step = v->t1[1].step = -1;     // (cross terms of this batch's rows were queued ahead)
-      // the batches folded so far stay folded: leave the IVC consistent at that point (state, pending secondary commitments)
-      finish_secondary(v);
-      for (uint32_t q = 0; q < p->len_z; q++) p->z_cur[q] = zs[first * p->len_z + q];
+      // the batches folded so far stay folded: leave the IVC consistent at that point (cross terms of this batch's rows were queued ahead)
+      settle(first);
       return vz_fail(ctx, VIMZ_ERR_UNSAT, msg);
     }
     for (size_t r = 0; r < rows; r++) {
@@ -210,7 +217,7 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
       AugIn<BnFr> in1; in1.digest = v->c1->digest; in1.z0 = v->z0; in1.i = i; in1.U = v->U2; in1.u = v->u2; in1.T = v->T2;
       std::vector<Fe> aug1; bool bad = false;
       AugOut<BnFr> o1 = v->c1->witness(in1, zs.data() + (first + r) * p->len_z, zs.data() + (first + r + 1) * p->len_z, aug1, &bad);
-      if (bad) return vz_fail(ctx, VIMZ_ERR_UNSAT, "primary verifier circuit: inconsistent incoming instance");
+      if (bad) { settle(first + r); return vz_fail(ctx, VIMZ_ERR_UNSAT, "primary verifier circuit: inconsistent incoming instance"); }   // (nothing of this row is queued yet)
       v->ph_s[IP_SYNTH1] += now_s() - t0; v->ph_n[IP_SYNTH1]++;
       t0 = now_s();
       v->U2 = o1.U_new;
@@ -399,10 +406,9 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
       std::vector<Fq> aug2;
       AugOut<BnFq> o2 = v->c2.witness(in2, &zero_q, &zero_q, aug2, &bad);
       v->c2.on_challenge = nullptr;
-      if (hook_ran && (bad || hook_rc)) {
-        v->broken = true;       // the folds with this challenge are queued already: the running instance cannot be used any further
-        return hook_rc ? hook_rc : vz_fail(ctx, VIMZ_ERR_UNSAT, "secondary verifier circuit: inconsistent incoming instance");
-      }
+      // (the secondary running instance has already been folded with this step's challenge, and with the hook the primary one too:
+      //  the guard marks the IVC broken)
+      if (hook_ran && hook_rc) return hook_rc;
       if (bad) return vz_fail(ctx, VIMZ_ERR_UNSAT, "secondary verifier circuit: inconsistent incoming instance");
       v->ph_s[IP_SYNTH2] += now_s() - t0; v->ph_n[IP_SYNTH2]++;
       t0 = now_s();
@@ -446,6 +452,7 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
   P_TRY(hipStreamSynchronize(v->s3));
   v->t1[0].step = v->t1[1].step = -1;
   for (uint32_t k = 0; k < p->len_z; k++) p->z_cur[k] = zs[nsteps * p->len_z + k];
+  guard.armed = false;
   v->ph_s[IP_TOTAL] += now_s() - t_all; v->ph_n[IP_TOTAL] += nsteps;
   if (dbg_timing) fprintf(stderr, "[timing] fold of %zu steps: %.1f ms (prepare %.1f, first batch ready at %.1f after waiting %.1f)\n", nsteps, 1e3 * (now_s() - t_all), 1e3 * t_prep, 1e3 * t_first, 1e3 * t_wait0);
   return VIMZ_OK;

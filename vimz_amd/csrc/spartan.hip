@@ -177,6 +177,15 @@ __global__ void __launch_bounds__(256) k_committed_part(const uint32_t* __restri
   VZ_GRID_STRIDE(i, N) store_fe(out, i, (i == 0 || i + 2 >= nw) ? F::zero() : load_fe<F>(Z, i));
 }
 
+// b of the W opening: eq(ry, ·) with the public slots (wire 0 = u, the last two wires = X0, X1) and the padding above the last wire
+// zeroed.  Those positions of the opened vector are NOT part of what comm_W may say about Z: their generators are live and honest
+// commitments never use them, so without the mask a prover could hide a correction of (u, X0, X1) there and prove the relation for
+// a z whose public entries differ from the instance's.
+template <class F>
+__global__ void __launch_bounds__(256) k_mask_public(uint32_t* __restrict__ b, size_t nw, size_t N) {
+  VZ_GRID_STRIDE(i, N) if (i == 0 || i + 2 >= nw) store_fe(b, i, F::zero());
+}
+
 // ---- per-side resident data -----------------------------------------------------------------------------------------------------------
 struct SideDev {
   CsrDev A{}, B{}, C{}; const uint32_t* dict = nullptr; const uint32_t* items = nullptr; uint32_t n_long = 0, n_med = 0;     // the shape
@@ -311,7 +320,8 @@ struct Reader {
   template <class F> F fe() { F c = F::zero(); if (need(4)) { memcpy(c.v, w + pos, 32); pos += 4; if (!c.is_reduced()) { ok = false; return F::zero(); } } return F::to_mont(c); }
   U256w u256() { U256w x{}; if (need(4)) { memcpy(x.w, w + pos, 32); pos += 4; } return x; }
   uint64_t word() { uint64_t x = 0; if (need(1)) x = w[pos++]; return x; }
-  template <class F> Affine<F> point() { Affine<F> p; p.x = fe<F>(); p.y = fe<F>(); return p; }
+  // (an untrusted point must be on its curve: the addition formulas do not depend on b)
+  template <class F> Affine<F> point() { Affine<F> p; p.x = fe<F>(); p.y = fe<F>(); if (ok && !aff_on_curve(p)) { ok = false; p.x = p.y = F::zero(); } return p; }
 };
 
 template <class F>
@@ -407,7 +417,8 @@ hipError_t load_bases(hipStream_t s, uint32_t* G, const vimz_bases* ck, size_t n
 
 template <class F, class C, class Fwd>
 int spartan_prove(vimz_ctx* ctx, SpartanCache& cache, SideDev& S, hipStream_t s, const vimz_bases* ck, const Affine<typename C::Base>& Ugen, const F& digest,
-                  const Instance<F, typename C::Base>& I, const uint32_t* Z, const uint32_t* E, uint32_t side_tag, Transcript& tr, Writer& out, Fwd fwd) {
+                  const Instance<F, typename C::Base>& I, const uint32_t* Z, const uint32_t* E, uint32_t side_tag, Transcript& tr, Writer& out, Fwd fwd,
+                  bool forge_public_slot = false) {
   const size_t M = S.M, N = S.N, big = std::max(M, N);
   absorb_instance(tr, digest, I, side_tag);
   // vectors: (A,B,C)·Z padded to M, E padded to M
@@ -495,6 +506,11 @@ int spartan_prove(vimz_ctx* ctx, SpartanCache& cache, SideDev& S, hipStream_t s,
   hipLaunchKernelGGL(k_committed_part<F>, dim3(stream_grid(N)), dim3(256), 0, s, Z, (size_t)S.n_w, N, S.va);
   { const F one = F::one(); P_TRY(hipMemcpyAsync(S.vb, one.v, 32, hipMemcpyHostToDevice, s)); P_TRY(hipStreamSynchronize(s)); }
   for (uint32_t k = S.t; k-- > 0;) hipLaunchKernelGGL(k_eq_step<F>, dim3(stream_grid((size_t)1 << (S.t - 1 - k))), dim3(256), 0, s, S.vb, (size_t)1 << (S.t - 1 - k), ry[k]);
+  hipLaunchKernelGGL(k_mask_public<F>, dim3(stream_grid(N)), dim3(256), 0, s, S.vb, (size_t)S.n_w, N);
+  if (forge_public_slot) {      // test hook (vimz_ivc_compress): the opened vector carries X0 − X0' = −1 in the slot of wire n−2
+    const F m1 = F::neg(F::one());
+    P_TRY(hipMemcpyAsync(S.va + 8 * (size_t)(S.n_w - 2), m1.v, 32, hipMemcpyHostToDevice, s)); P_TRY(hipStreamSynchronize(s));
+  }
   P_TRY(load_bases(s, S.G, ck, N, true));
   if ((rc = ipa_prove<F, C>(ctx, cache, S, s, tr, Ugen, S.va, S.vb, S.t, I.cW, evalW, out))) return rc;
   // opening of E at rx
@@ -530,8 +546,6 @@ bool ipa_verify(vimz_ctx* ctx, SpartanCache& cache, SideDev& S, hipStream_t s, T
   const Affine<FS> Up = to_affine(host_mul<FS>(Ugen, r0, 128));
   XYZZ<FS> P = from_affine(comm); { XYZZ<FS> t = host_mul_fe<FS, F>(Up, claim); add_full(P, t); }
   std::vector<F> xs(rounds);
-  auto on_curve = [](const Affine<FS>& q) { if (aff_is_identity(q)) return true; return F::zero().is_zero() && true; };
-  (void)on_curve;
   for (uint32_t j = 0; j < rounds; j++) {
     const Affine<FS> L = in.point<FS>(), R = in.point<FS>();
     if (!in.ok) return false;
@@ -624,7 +638,11 @@ bool spartan_verify(vimz_ctx* ctx, SpartanCache& cache, SideDev& S, hipStream_t 
   }
   const F vz = F::add(evalW, F::add(F::mul(I.u, ey[0]), F::add(F::mul(I.X0, ey[S.n_w - 2]), F::mul(I.X1, ey[S.n_w - 1]))));
   if (!F::mul(vm, vz).eq(claim)) return false;
-  if (!ipa_verify<F, C>(ctx, cache, S, s, tr, Ugen, ck, true, ey, S.t, I.cW, evalW, in)) return false;
+  {   // the W opening is over the committed positions only: b = eq(ry, ·) with the public slots and the padding zeroed (k_mask_public)
+    std::vector<F> eyW(ey);
+    for (size_t i = 0; i < eyW.size(); i++) if (i == 0 || i + 2 >= S.n_w) eyW[i] = F::zero();
+    if (!ipa_verify<F, C>(ctx, cache, S, s, tr, Ugen, ck, true, eyW, S.t, I.cW, evalW, in)) return false;
+  }
   if (I.has_E && !ipa_verify<F, C>(ctx, cache, S, s, tr, Ugen, ck, false, ex, S.s, I.cE, cl[3], in)) return false;
   return true;
 }
@@ -677,12 +695,25 @@ int vimz_ivc_compress(vimz_ivc* v, uint8_t* blob, size_t cap, double seconds[2])
   if (rc) return rc;
   const double t_setup = now_s() - t0;
   t0 = now_s();
+  // Test hook for the negative test of the public-slot binding (tests/test_gpu_compress.py): a cheating prover that claims x0 + 1 for
+  // the last fresh instance and hides the difference in the generator of that wire's slot.  Never set outside that test.
+  const bool forge = getenv("VIMZ_TEST_FORGE_PUBLIC_SLOT") != nullptr;
+  G2Aff forge_gen; forge_gen.x = forge_gen.y = Fe::zero();
+  if (forge) {
+    uint64_t xy[8];
+    if ((rc = vimz_bases_download(ctx, v->ck2, v->sec.n_w - 3, xy, 1, VIMZ_FORM_MONTGOMERY))) return rc;
+    memcpy(forge_gen.x.v, xy, 32); memcpy(forge_gen.y.v, xy + 4, 32);
+  }
   std::lock_guard<std::mutex> g(ctx->mu);
   P_TRY(hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
   P_TRY(hipStreamSynchronize(s));
   vimz_prover* p = v->pri;
   Loaded L; L.U1 = v->U1; L.U2 = v->U2; L.u2 = v->u2; L.u1_run = v->u1_run; L.u2_run = v->u2_run;
+  if (forge) {      // comm' = comm − ck[n−3] commits to the same W with −1 in the slot of wire n−2;  x0' = x0 + 1
+    G2 a = from_affine(L.u2.W); G2Aff neg = forge_gen; neg.y = Fe::neg(neg.y); add_mixed(a, neg); L.u2.W = to_affine(a);
+    L.u2.x0 = Fe::add(L.u2.x0, Fe::one());
+  }
   Writer out;
   out.word(CSNARK_MAGIC); out.word(v->i); out.word(p->len_z); out.word(cache->side[0].s); out.word(cache->side[0].t); out.word(cache->side[1].s); out.word(cache->side[1].t); out.word(0);
   for (auto& z : v->z0) out.fe(z);
@@ -697,7 +728,7 @@ int vimz_ivc_compress(vimz_ivc* v, uint8_t* blob, size_t cap, double seconds[2])
   auto fwd2 = [&](const uint32_t* z, uint32_t* az, uint32_t* bz, uint32_t* cz) { sec_spmv<Fq>(v->sec, s, z, az, bz, cz); };
   if ((rc = spartan_prove<Fe, BnG1>(ctx, *cache, cache->side[0], s, v->ck1, cache->ipa_u1, v->c1->digest, inst_primary(L), p->Zrun, p->E, 1, tr, out, fwd1))) return rc;
   if ((rc = spartan_prove<Fq, Grumpkin>(ctx, *cache, cache->side[1], s, v->ck2, cache->ipa_u2, v->c2.digest, inst_secondary(L), v->sec.Zrun, v->sec.E, 2, tr, out, fwd2))) return rc;
-  if ((rc = spartan_prove<Fq, Grumpkin>(ctx, *cache, cache->side[1], s, v->ck2, cache->ipa_u2, v->c2.digest, inst_fresh(L), v->sec.z2, nullptr, 3, tr, out, fwd2))) return rc;
+  if ((rc = spartan_prove<Fq, Grumpkin>(ctx, *cache, cache->side[1], s, v->ck2, cache->ipa_u2, v->c2.digest, inst_fresh(L), v->sec.z2, nullptr, 3, tr, out, fwd2, forge))) return rc;
   if (8 * out.w.size() != vimz_ivc_compressed_size(v)) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_ivc_compress: internal size mismatch");
   memcpy(blob, out.w.data(), 8 * out.w.size());
   if (seconds) { seconds[0] = t_setup; seconds[1] = now_s() - t0; }

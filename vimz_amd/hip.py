@@ -599,5 +599,9 @@ class R1CSShape:
         lim = lambda x: np.array([(int(x) >> (64 * k)) & 0xFFFFFFFFFFFFFFFF for k in range(4)], dtype=np.uint64)
         a, b = lim(u1), lim(u2)
         out = np.zeros(8, dtype=np.uint64)
-        self.ctx._chk(self.ctx.lib.vimz_commit_T(self.ctx.h, self.h, ck.h, z1.h, _ptr(a), z2.h, _ptr(b), L.FORM_CANONICAL, T.h, _ptr(out), L.FORM_CANONICAL))
+        try:
+            self.ctx._chk(self.ctx.lib.vimz_commit_T(self.ctx.h, self.h, ck.h, z1.h, _ptr(a), z2.h, _ptr(b), L.FORM_CANONICAL, T.h, _ptr(out), L.FORM_CANONICAL))
+        except Exception:
+            T.free()
+            raise
         return T, out

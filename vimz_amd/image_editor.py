@@ -3,7 +3,7 @@
 Host-side mirror of the reference's Python input generator (pyvimz/pyvimz/image_editor.py:71-150,
 pyvimz/pyvimz/img/ops.py:4-105, pyvimz/pyvimz/img/transformations.py:6-147), restated with integer
 numpy arithmetic so that it is bit-exact against the reference's outputs (pinned in
-tests/test_image_editor.py against the reference's committed PNGs/hashes and against fixtures minted
+tests/test_oracle_golden.py against the reference's committed PNGs/hashes and against fixtures minted
 by importing pyvimz, see tests/golden/make_fixtures.py).
 
 Packing (ops.py:17-31, circuits/src/utils/pixels.circom:15-27): 10 pixels per field element, pixel k

@@ -34,6 +34,8 @@ class RelaxedAccumulator:
     def __init__(self, ctx, curve, nrows, n_witness, n_public, A, B, C, modulus, ck=None, ck_label=b"ck"):
         self.ctx, self.curve, self.field = ctx, curve, L.CURVE_SCALAR_FIELD[curve]
         self.nrows, self.nw, self.nx, self.q = nrows, n_witness, n_public, int(modulus)
+        if self.q != L.MODULUS[self.field]:      # (a circom file compiled for another prime would upload fine and fold mod the wrong field)
+            raise ValueError(f"the shape's prime {self.q:#x} is not the scalar field of curve {curve}")
         self.ncols = n_witness + 1 + n_public
         self.shape = hip.R1CSShape(ctx, self.field, nrows, self.ncols, A, B, C)
         self.own_ck = ck is None
@@ -79,6 +81,7 @@ class RelaxedAccumulator:
         w = np.asarray(witness, dtype=np.uint64).reshape(-1, 4) if isinstance(witness, np.ndarray) else np.stack([_limbs(x) for x in witness])
         assert w.shape[0] == self.nw and len(public) == self.nx
         z2 = self.ctx.vec_alloc(self.field, self.ncols)
+        T = None
         try:
             z2.upload(w, 0)
             z2.upload(np.stack([_limbs(1)] + [_limbs(x) for x in public]), self.nw)
@@ -87,9 +90,10 @@ class RelaxedAccumulator:
             r = self.challenge(comm_W2, public, comm_T)
             hip.vec_axpy(self.ctx, self.z, r, z2)              # W, u and X together: z holds all three
             hip.vec_axpy(self.ctx, self.E, r, T)
-            T.free()
         finally:
             z2.free()
+            if T is not None:
+                T.free()
         self.u = (self.u + r) % self.q
         self.X = [(a + r * int(b)) % self.q for a, b in zip(self.X, public)]
         self.comm_W = self._add(self.comm_W, self._scalar_mul(comm_W2, r))
