@@ -301,6 +301,48 @@ int vimz_ivc_compress(vimz_ivc* v, uint8_t* blob, size_t cap, double seconds[2])
  * argument for the primary running / secondary running / last fresh secondary instance; bit 12 statement mismatch; bit 13 malformed. */
 int vimz_ivc_verify_compressed(vimz_ivc* v, const uint8_t* blob, size_t len, uint64_t num_steps, const uint64_t* z0, uint32_t* result);
 
+/* ---- ONE proof object out of several row segments: the "host-side sequential final fold" of BASELINE.json's north_star for IVC proofs.
+ *      fold_input returns ONE RecursiveSNARK (vimz/src/nova_snark_backend/folding.rs:27-43); row segments of an image folded
+ *      concurrently (S proofs on one GPU, or one per GPU) are merged into one verifiable object by out-of-circuit NIFS on both curves —
+ *      the final fold CompressedSNARK::prove performs on the last fresh secondary instance (mod.rs:56-59), extended to S segments
+ *      (protocol: vimz_amd/csrc/merge_internal.hpp; ours, like the augmented circuits).  The verifier replays the
+ *      segments' hash checks, their adjacency and the fold tree from the records, then checks ONE primary and ONE secondary relaxed
+ *      instance (or one compressed argument each).  The cross terms, their commitments and the vector folds run on the GPU. -------- */
+typedef struct vimz_ivc_merged vimz_ivc_merged;
+/* the merged proof of one segment; `segment` is left unchanged, supplies shapes / keys / context and must outlive the object */
+int vimz_ivc_merged_create(vimz_ivc* segment, vimz_ivc_merged** out);
+void vimz_ivc_merged_free(vimz_ivc_merged* m);
+/* fold the proof of the NEXT row segment in (same device; read in place, left unchanged): it must start at the state m ends in */
+int vimz_ivc_merge(vimz_ivc_merged* m, vimz_ivc* next_segment);
+/* the same for two merged proofs of adjacent runs of segments (e.g. one per GPU, brought over with vimz_ivc_merged_save / _load) */
+int vimz_ivc_merge_merged(vimz_ivc_merged* m, vimz_ivc_merged* next);
+/* RecursiveSNARK::verify(pp, num_steps, z0) for the merged object.  result: 0 = accepted; bit 0 / 1 a segment's primary / secondary chain
+ * hash; bit 2 primary relaxed relation; bit 3 / 4 primary comm_W / comm_E; bit 5 secondary relation; bit 6 / 7 secondary comm_W / comm_E;
+ * bit 10 public entries of a witness vector differ from the instance; bit 11 kept running products (bookkeeping for further merges);
+ * bit 12 statement (total steps, initial state, or segments not adjacent); bit 13 malformed. */
+int vimz_ivc_merged_verify(vimz_ivc_merged* m, uint64_t num_steps, const uint64_t* z0, uint32_t* result);
+/* info = {steps, segments, ops, len_z, primary wires, primary constraints, secondary wires, secondary constraints} */
+int vimz_ivc_merged_info(const vimz_ivc_merged* m, uint64_t info[8]);
+int vimz_ivc_merged_state(const vimz_ivc_merged* m, uint64_t* z_start, uint64_t* z_end, uint64_t* steps);
+/* seconds = {leaf work, wait for the cross-term commitments, folds + host instance arithmetic, total} */
+int vimz_ivc_merged_profile(const vimz_ivc_merged* m, double seconds[4]);
+/* The proof as bytes: records ‖ folded witnesses.  vimz_ivc_merged_load takes `vk` = any vimz_ivc created for the same step circuit
+ * and keys (neither read nor changed; must outlive the object); the blob is untrusted (range and curve checks; instances recomputed). */
+size_t vimz_ivc_merged_size(const vimz_ivc_merged* m);
+int vimz_ivc_merged_save(vimz_ivc_merged* m, uint8_t* blob, size_t cap);
+int vimz_ivc_merged_load(vimz_ivc* vk, const uint8_t* blob, size_t len, vimz_ivc_merged** out);
+/* what an independent verifier replays: header {magic, segments, ops, len_z, n_w1, n_c1, n_w2, n_c2}, per segment {n, z_start, z_end,
+ * U1 (W, E, u, X0, X1), U2, u2 (W, x0, x1), T}, per op {kind, leaf [, T_p, T_q]} — canonical little-endian words; returns the byte size */
+int64_t vimz_ivc_merged_records(const vimz_ivc_merged* m, void* buf, size_t cap);
+/* side 0 / 1; what = VIMZ_IX_RUNNING_Z, VIMZ_IX_RUNNING_E (canonical), VIMZ_IX_INSTANCE (comm_W, comm_E, u, X0, X1 of the folded instance) */
+int64_t vimz_ivc_merged_export(vimz_ivc_merged* m, int side, int what, void* buf, size_t cap);
+/* CompressedSNARK::{prove, verify} for the merged object: one argument for the folded primary and one for the folded secondary
+ * instance (vimz_amd/csrc/spartan.hip); the blob carries the records.  result bits as vimz_ivc_verify_compressed, bit 2 / 3 = the
+ * primary / secondary argument. */
+size_t vimz_ivc_merged_compressed_size(const vimz_ivc_merged* m);
+int vimz_ivc_merged_compress(vimz_ivc_merged* m, uint8_t* blob, size_t cap, double seconds[2]);
+int vimz_ivc_verify_merged_compressed(vimz_ivc* vk, const uint8_t* blob, size_t len, uint64_t num_steps, const uint64_t* z0, uint32_t* result);
+
 /* Everything an independent verifier needs, canonical little-endian 4 x u64 per element (the parity tests hand these to the
  * CPU oracle's verifier).  side 0 = primary (BN254 Fr / G1), 1 = secondary (BN254 Fq / Grumpkin).
  *   what = VIMZ_CX_{A,B,C}_{ROWPTR,COL,COEF}, VIMZ_CX_DICT_CANON : the augmented circuit's R1CS

@@ -27,29 +27,10 @@
 // of the fold (msm.hpp) and a per-point double-and-add kernel for the generator folding.
 #include "ivc_internal.hpp"
 #include "ec_mem.hpp"
+#include "proof_io.hpp"
+#include "merge_internal.hpp"
 
 namespace {
-
-// ---- transcript: SHA3-256 chain ---------------------------------------------------------------------------------------------------
-struct Transcript {
-  uint8_t st[32];
-  explicit Transcript(const char* label) { memset(st, 0, 32); absorb_bytes("init", label, strlen(label)); }
-  void absorb_bytes(const char* tag, const void* data, size_t n) {
-    Sha3 h; h.update(st, 32);
-    uint8_t t[8] = {0}; for (int i = 0; i < 8 && tag[i]; i++) t[i] = (uint8_t)tag[i];
-    h.update(t, 8);
-    const uint64_t len = n; h.update(&len, 8);
-    if (n) h.update(data, n);
-    h.finish(st);
-  }
-  void absorb_words(const char* tag, const uint64_t* w, size_t nwords) { absorb_bytes(tag, w, 8 * nwords); }
-  template <class F> void absorb_fe(const char* tag, const F& mont) { F c = F::from_mont(mont); absorb_bytes(tag, c.v, 32); }
-  void challenge(uint32_t out[4]) {               // 128 bits
-    Sha3 h; h.update(st, 32); const uint8_t c = 'c'; h.update(&c, 1); h.finish(st);
-    memcpy(out, st, 16);
-  }
-  template <class F> F challenge_fe() { uint32_t w[4]; challenge(w); F c = F::zero(); for (int i = 0; i < 4; i++) c.v[i] = w[i]; return F::to_mont(c); }
-};
 
 // ---- kernels -------------------------------------------------------------------------------------------------------------------------
 template <class F, int K>
@@ -306,24 +287,6 @@ int spartan_setup(vimz_ivc* v, SpartanCache** out) {
   return VIMZ_OK;
 }
 
-// ---- serialisation helpers -------------------------------------------------------------------------------------------------------------
-struct Writer {
-  std::vector<uint64_t> w;
-  template <class F> void fe(const F& mont) { F c = F::from_mont(mont); const size_t o = w.size(); w.resize(o + 4); memcpy(&w[o], c.v, 32); }
-  void u256(const U256w& x) { w.insert(w.end(), x.w, x.w + 4); }
-  void word(uint64_t x) { w.push_back(x); }
-  template <class F> void point(const Affine<F>& p) { fe(p.x); fe(p.y); }
-};
-struct Reader {
-  const uint64_t* w; size_t n, pos = 0; bool ok = true;
-  bool need(size_t k) { if (pos + k > n) ok = false; return ok; }
-  template <class F> F fe() { F c = F::zero(); if (need(4)) { memcpy(c.v, w + pos, 32); pos += 4; if (!c.is_reduced()) { ok = false; return F::zero(); } } return F::to_mont(c); }
-  U256w u256() { U256w x{}; if (need(4)) { memcpy(x.w, w + pos, 32); pos += 4; } return x; }
-  uint64_t word() { uint64_t x = 0; if (need(1)) x = w[pos++]; return x; }
-  // (an untrusted point must be on its curve: the addition formulas do not depend on b)
-  template <class F> Affine<F> point() { Affine<F> p; p.x = fe<F>(); p.y = fe<F>(); if (ok && !aff_on_curve(p)) { ok = false; p.x = p.y = F::zero(); } return p; }
-};
-
 template <class F>
 F interp_cubic(const F& s0, const F& s1, const F& s2, const F& s3, const F& r) {     // Lagrange through t = 0, 1, 2, 3
   const F one = F::one(), two = F::dbl(one), three = F::add(two, one);
@@ -342,16 +305,6 @@ F interp_quad(const F& s0, const F& s1, const F& s2, const F& r) {              
   const F l0 = F::mul(F::mul(r1, r2), inv2), l1 = F::neg(F::mul(r, r2)), l2 = F::mul(F::mul(r, r1), inv2);
   return F::add(F::add(F::mul(l0, s0), F::mul(l1, s1)), F::mul(l2, s2));
 }
-
-// host scalar·point on curve C (scalar: canonical little-endian words)
-template <class FS>
-XYZZ<FS> host_mul(const Affine<FS>& p, const uint32_t* k, int bits) {
-  XYZZ<FS> acc = XYZZ<FS>::identity();
-  for (int i = bits - 1; i >= 0; i--) { acc = dbl(acc); if ((k[i >> 5] >> (i & 31)) & 1) add_mixed(acc, p); }
-  return acc;
-}
-template <class FS, class F>
-XYZZ<FS> host_mul_fe(const Affine<FS>& p, const F& k_mont) { F c = F::from_mont(k_mont); return host_mul<FS>(p, c.v, 256); }
 
 // One relaxed instance of one side, as the prover and the verifier see it.
 template <class F, class FS>
@@ -789,6 +742,100 @@ int vimz_ivc_verify_compressed(vimz_ivc* v, const uint8_t* blob, size_t len, uin
   if (ok1 && !ok2) res |= 8;
   if (ok1 && ok2 && !ok3) res |= 16;
   if (!in.ok || (ok3 && in.pos != in.n)) res |= 8192;
+  *result = res;
+  return VIMZ_OK;
+}
+
+// ---- CompressedSNARK for a merged proof (merge.hip): one argument for the folded primary instance, one for the folded secondary one.
+// Blob: {magic, words of the records} ‖ records (segments' statements and instances, the fold tree's cross-term commitments) ‖ the two
+// arguments.  The verifier replays the records (every segment's hash checks, adjacency, the folds) and verifies the arguments for the
+// instances IT computed.
+static const uint64_t CMERGED_MAGIC = 0x31474d43565aull;   // "ZVCMG1"
+
+static size_t arg_words(size_t s, size_t t, bool e) { return 4 * (3 * s + 4 + 2 * t + 1) + 4 * (4 * t + 1) + (e ? 4 * (4 * s + 1) : 0); }
+
+size_t vimz_ivc_merged_compressed_size(const vimz_ivc_merged* m) {
+  if (!m) return 0;
+  const vimz_ivc* v = m->vk;
+  const uint32_t s1 = ceil_log2(v->pri->n_c), t1 = ceil_log2(v->pri->n_wires), s2 = ceil_log2(v->sec.n_c), t2 = ceil_log2(v->sec.n_w);
+  return 8 * (2 + records_words(m) + arg_words(s1, t1, true) + arg_words(s2, t2, true));
+}
+
+int vimz_ivc_merged_compress(vimz_ivc_merged* m, uint8_t* blob, size_t cap, double seconds[2]) {
+  if (!m || !blob) return VIMZ_ERR_INVALID;
+  vimz_ivc* v = m->vk; vimz_ctx* ctx = v->ctx;
+  if (cap < vimz_ivc_merged_compressed_size(m)) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_ivc_merged_compress: buffer too small");
+  double t0 = now_s();
+  SpartanCache* cache = nullptr;
+  int rc = spartan_setup(v, &cache);
+  if (rc) return rc;
+  const double t_setup = now_s() - t0;
+  t0 = now_s();
+  std::lock_guard<std::mutex> g(ctx->mu);
+  P_TRY(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  P_TRY(hipStreamSynchronize(s));
+  vimz_prover* p = v->pri;
+  Writer out;
+  out.word(CMERGED_MAGIC); out.word(records_words(m));
+  write_records(m, out);
+  Transcript tr("vimz-merged-compressed-v1");
+  tr.absorb_words("records", out.w.data() + 2, out.w.size() - 2);
+  Instance<Fe, Fq> I1; I1.cW = m->acc.P.cW; I1.cE = m->acc.P.cE; I1.u = m->acc.P.u; I1.X0 = m->acc.P.X0; I1.X1 = m->acc.P.X1; I1.has_E = true;
+  Instance<Fq, Fe> I2; I2.cW = m->acc.Q.cW; I2.cE = m->acc.Q.cE; I2.u = m->acc.Q.u; I2.X0 = m->acc.Q.X0; I2.X1 = m->acc.Q.X1; I2.has_E = true;
+  auto fwd1 = [&](const uint32_t* z, uint32_t* az, uint32_t* bz, uint32_t* cz) { launch_spmv(p, s, z, az, bz, cz, 0); };
+  auto fwd2 = [&](const uint32_t* z, uint32_t* az, uint32_t* bz, uint32_t* cz) { sec_spmv<Fq>(v->sec, s, z, az, bz, cz); };
+  if ((rc = spartan_prove<Fe, BnG1>(ctx, *cache, cache->side[0], s, v->ck1, cache->ipa_u1, v->c1->digest, I1, m->Zp, m->Ep, 1, tr, out, fwd1))) return rc;
+  if ((rc = spartan_prove<Fq, Grumpkin>(ctx, *cache, cache->side[1], s, v->ck2, cache->ipa_u2, v->c2.digest, I2, m->Zq, m->Eq, 2, tr, out, fwd2))) return rc;
+  if (8 * out.w.size() != vimz_ivc_merged_compressed_size(m)) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_ivc_merged_compress: internal size mismatch");
+  memcpy(blob, out.w.data(), 8 * out.w.size());
+  if (seconds) { seconds[0] = t_setup; seconds[1] = now_s() - t0; }
+  return VIMZ_OK;
+}
+
+// verify(vk, num_steps, z0) of a compressed merged proof.  result: 0 = accepted; bit 0 / 1 a segment's primary / secondary chain hash;
+// bit 2 / 3 the argument for the folded primary / secondary instance; bit 12 statement (steps, z0, adjacency); bit 13 malformed.
+int vimz_ivc_verify_merged_compressed(vimz_ivc* v, const uint8_t* blob, size_t len, uint64_t num_steps, const uint64_t* z0, uint32_t* result) {
+  if (!v || !blob || !z0 || !result) return VIMZ_ERR_INVALID;
+  vimz_ctx* ctx = v->ctx;
+  SpartanCache* cache = nullptr;
+  int rc = spartan_setup(v, &cache);
+  if (rc) return rc;
+  if ((len & 7) || len < 16) { *result = 8192; return VIMZ_OK; }
+  std::vector<uint64_t> words(len / 8); memcpy(words.data(), blob, len);
+  Reader in{words.data(), words.size()};
+  const uint64_t magic = in.word(), rw = in.word();
+  if (magic != CMERGED_MAGIC || rw > words.size() - 2) { *result = 8192; return VIMZ_OK; }
+  std::vector<MSeg> segs; std::vector<MOp> ops;
+  if (!read_records(in, v, segs, ops) || in.pos != 2 + rw) { *result = 8192; return VIMZ_OK; }
+  const uint32_t s1 = cache->side[0].s, t1 = cache->side[0].t, s2 = cache->side[1].s, t2 = cache->side[1].t;
+  if (words.size() != 2 + rw + arg_words(s1, t1, true) + arg_words(s2, t2, true)) { *result = 8192; return VIMZ_OK; }
+  uint32_t res = 0;
+  MAcc R;
+  if (!merged_replay(v, segs, ops, &R, &res)) { *result = res | 8192; return VIMZ_OK; }
+  vimz_prover* p = v->pri;
+  if (R.n != num_steps) res |= 4096;
+  for (uint32_t k = 0; k < p->len_z; k++) {
+    Fe c; memcpy(c.v, z0 + 4 * k, 32);
+    if (!c.is_reduced()) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_ivc_verify_merged_compressed: z0 element not below the modulus");
+    if (!Fe::to_mont(c).eq(R.zs[k])) res |= 4096;
+  }
+  std::lock_guard<std::mutex> g(ctx->mu);
+  P_TRY(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  Transcript tr("vimz-merged-compressed-v1");
+  tr.absorb_words("records", words.data() + 2, rw);
+  Instance<Fe, Fq> I1; I1.cW = R.P.cW; I1.cE = R.P.cE; I1.u = R.P.u; I1.X0 = R.P.X0; I1.X1 = R.P.X1; I1.has_E = true;
+  Instance<Fq, Fe> I2; I2.cW = R.Q.cW; I2.cE = R.Q.cE; I2.u = R.Q.u; I2.X0 = R.Q.X0; I2.X1 = R.Q.X1; I2.has_E = true;
+  const cb::Builder& b1 = v->circ1->build->b; const cb::BuilderT<Fq>& b2 = v->c2.b;
+  bool ok1 = false, ok2 = false;
+  try {
+    ok1 = spartan_verify<Fe, BnG1>(ctx, *cache, cache->side[0], s, v->ck1, cache->ipa_u1, v->c1->digest, I1, b1, 1, tr, in);
+    ok2 = ok1 && spartan_verify<Fq, Grumpkin>(ctx, *cache, cache->side[1], s, v->ck2, cache->ipa_u2, v->c2.digest, I2, b2, 2, tr, in);
+  } catch (const std::exception& e) { return vz_fail(ctx, VIMZ_ERR_INVALID, e.what()); }
+  if (!ok1) res |= 4;
+  if (ok1 && !ok2) res |= 8;
+  if (!in.ok || (ok2 && in.pos != in.n)) res |= 8192;
   *result = res;
   return VIMZ_OK;
 }

@@ -79,9 +79,9 @@ def fold_local_segments(provers, step_inputs, z0, merge=True):
 
 def ivc_segments(ivcs, step_inputs, z0):
     """Split `step_inputs` into len(ivcs) contiguous row segments and return [(ivc, rows, z_start)], where z_start is the IVC
-    state at which the segment begins (hash-only chain over the rows before it).  In IVC mode (vimz_amd.hip.IVC) two running
-    instances cannot be merged — Nova IVC is a chain — so an image proven on several streams / GPUs is a LIST of IVC proofs,
-    one per row segment, whose boundary states chain: z_end of segment j = z_start of segment j+1 (checked by the caller)."""
+    state at which the segment begins (hash-only chain over the rows before it).  An image proven on several streams / GPUs is a
+    list of IVC proofs, one per row segment, whose boundary states chain (z_end of segment j = z_start of segment j+1); they become
+    ONE proof object by vimz_amd.hip.MergedProof.of(ivcs) (vimz_ivc_merge: the host-side sequential final fold)."""
     n, S = len(step_inputs), len(ivcs)
     bounds = segment_bounds(n, S)
     starts = [list(z0)]

@@ -121,17 +121,48 @@ class FoldingProof:
         """The final IVC state z_n as integers."""
         if self.mode == "ivc":
             return self.prover.state()[0]
+        if self.mode == "merged":
+            return self.prover.state()[1]
         return _limbs_to_ints(self.prover.instance()["z"])
+
+    def close(self):
+        """Release the proof and, for a merged proof, the segment provers and contexts fold_input created for it."""
+        self.prover.close()
+        for o in getattr(self, "_owned", []):
+            o.close()
+        self._owned = []
 
 
 def _limbs_to_ints(a):
     return [sum(int(x[k]) << (64 * k) for k in range(4)) for x in np.asarray(a).reshape(-1, 4)]
 
 
-def fold_input(params, ivc_step_inputs, initial_state, max_batch=16, prover=None, mode="ivc"):
+def fold_input(params, ivc_step_inputs, initial_state, max_batch=16, prover=None, mode="ivc", segments=1):
     """fold_input (folding.rs:27-43): one RecursiveSNARK over all steps (mode "ivc", what the reference produces), or the NIFS
-    accumulator (mode "accumulator").  Raises VimzError (the reference panics with "Failed to fold input")."""
-    from .hip import IVC, Prover
+    accumulator (mode "accumulator").  Raises VimzError (the reference panics with "Failed to fold input").
+    segments = S > 1 (mode "ivc"): the rows are proven as S contiguous segments folded CONCURRENTLY on this GPU (one IVC each, own
+    context and streams) and merged into ONE proof object (vimz_ivc_merge; FoldingProof.mode == "merged") — a single chain leaves a
+    quarter of an MI355X idle."""
+    from .hip import IVC, Context, MergedProof, Prover
+    if prover is None and mode == "ivc" and segments > 1 and len(ivc_step_inputs) >= segments:
+        from .distributed import fold_concurrently, ivc_segments
+        ctxs = [params.ctx] + [Context(params.ctx.device) for _ in range(segments - 1)]
+        ck2 = params.secondary_key()
+        ivcs = [IVC(c, params.circuit, params.ck, ck2, max_batch=max_batch) for c in ctxs]
+        try:
+            segs = ivc_segments(ivcs, ivc_step_inputs, initial_state)
+            for v, rows, z in segs:
+                v.reset(z)
+            fold_concurrently([(v, rows) for v, rows, z in segs])
+            merged = MergedProof.of(ivcs)
+        except Exception:
+            for o in ivcs + ctxs[1:]:
+                o.close()
+            raise
+        proof = FoldingProof(merged, len(ivc_step_inputs), list(initial_state), "merged")
+        proof._owned = ivcs + ctxs[1:]          # (the first IVC is the merged proof's verifier key: released after it)
+        proof.verifier_key = ivcs[0]
+        return proof
     if prover is not None:
         p = prover
         mode = "ivc" if isinstance(prover, IVC) else "accumulator"
@@ -147,7 +178,7 @@ def fold_input(params, ivc_step_inputs, initial_state, max_batch=16, prover=None
 def verify_folded_proof(proof, params, num_steps, initial_state):
     """verify_folded_proof (folding.rs:45-56: RecursiveSNARK::verify(pp, num_steps, z0, [0])); raises like the reference's
     expect("Failed to verify folded proof")."""
-    if proof.mode == "ivc":
+    if proof.mode in ("ivc", "merged"):
         r = proof.prover.verify(num_steps, initial_state)
         if r != 0:
             raise _lib.VimzError(_lib.ERR_UNSAT, f"Failed to verify folded proof (flags {r:#x})")
@@ -163,14 +194,19 @@ def verify_folded_proof(proof, params, num_steps, initial_state):
 def compress_proof(params, proof):
     """CompressedSNARK::setup + prove (vimz/src/nova_snark_backend/mod.rs:52-59; spans "Prepare compression" / "Compress proof").
     Returns (proof bytes, timings)."""
-    if proof.mode != "ivc":
-        raise _lib.VimzError(_lib.ERR_INVALID, "Failed to compress proof: only a RecursiveSNARK (mode \"ivc\") can be compressed")
+    if proof.mode not in ("ivc", "merged"):
+        raise _lib.VimzError(_lib.ERR_INVALID, "Failed to compress proof: only a RecursiveSNARK (mode \"ivc\", or merged segments) can be compressed")
     return proof.prover.compress()
 
 
 def verify_compressed_proof(verifier_key, compressed, num_steps, initial_state):
     """compressed_proof.verify(&vk, num_steps, initial_state, secondary_initial_state) (mod.rs:63-67).  verifier_key: an IVC object
     created for the same step circuit and keys (e.g. proof.prover, or a fresh hip.IVC in another process)."""
-    r = verifier_key.verify_compressed(compressed, num_steps, initial_state)
+    words = np.frombuffer(np.ascontiguousarray(compressed, dtype=np.uint8)[:8].tobytes(), dtype=np.uint64)
+    if len(words) and int(words[0]) == 0x31474D43565A:      # a compressed MERGED proof (vimz_ivc_merged_compress)
+        from .hip import MergedProof
+        r = MergedProof.verify_compressed(verifier_key, compressed, num_steps, initial_state)
+    else:
+        r = verifier_key.verify_compressed(compressed, num_steps, initial_state)
     if r != 0:
         raise _lib.VimzError(_lib.ERR_UNSAT, f"Failed to verify proof (flags {r:#x})")

@@ -493,6 +493,140 @@ class IVC:
         return _r1cs_tables(self.ctx.lib.vimz_ivc_export, self.h, side)
 
 
+def _zlimbs(z0, len_z):
+    z = np.zeros((len_z, 4), dtype=np.uint64)
+    for i, v in enumerate(z0):
+        for k in range(4):
+            z[i, k] = (int(v) >> (64 * k)) & 0xFFFFFFFFFFFFFFFF
+    return z
+
+
+class MergedProof:
+    """vimz_ivc_merged: ONE proof object out of the IVC proofs of contiguous row segments (the host-side sequential final fold of
+    BASELINE.json's north_star; the reference's fold_input returns one RecursiveSNARK, vimz/src/nova_snark_backend/folding.rs:27-43).
+    `first`: the IVC of the first segment (left unchanged; supplies shapes, keys and context and must stay open)."""
+    PHASES = ["leaf", "wait_cross_term_msm", "folds_and_host", "total"]
+
+    def __init__(self, first=None, _handle=None, _vk=None):
+        self.vk = first if first is not None else _vk
+        self.ctx = self.vk.ctx
+        lib = self.ctx.lib
+        vp, sz = C.c_void_p, C.c_size_t
+        lib.vimz_ivc_merged_create.argtypes = [vp, C.POINTER(vp)]
+        lib.vimz_ivc_merged_free.argtypes = [vp]
+        lib.vimz_ivc_merged_free.restype = None
+        lib.vimz_ivc_merge.argtypes = [vp, vp]
+        lib.vimz_ivc_merge_merged.argtypes = [vp, vp]
+        lib.vimz_ivc_merged_verify.argtypes = [vp, C.c_uint64, vp, C.POINTER(C.c_uint32)]
+        lib.vimz_ivc_merged_info.argtypes = [vp, vp]
+        lib.vimz_ivc_merged_state.argtypes = [vp, vp, vp, C.POINTER(C.c_uint64)]
+        lib.vimz_ivc_merged_profile.argtypes = [vp, C.POINTER(C.c_double)]
+        lib.vimz_ivc_merged_size.argtypes = [vp]
+        lib.vimz_ivc_merged_size.restype = sz
+        lib.vimz_ivc_merged_save.argtypes = [vp, vp, sz]
+        lib.vimz_ivc_merged_load.argtypes = [vp, vp, sz, C.POINTER(vp)]
+        lib.vimz_ivc_merged_records.argtypes = [vp, vp, sz]
+        lib.vimz_ivc_merged_records.restype = C.c_int64
+        lib.vimz_ivc_merged_export.argtypes = [vp, C.c_int, C.c_int, vp, sz]
+        lib.vimz_ivc_merged_export.restype = C.c_int64
+        lib.vimz_ivc_merged_compressed_size.argtypes = [vp]
+        lib.vimz_ivc_merged_compressed_size.restype = sz
+        lib.vimz_ivc_merged_compress.argtypes = [vp, vp, sz, C.POINTER(C.c_double)]
+        lib.vimz_ivc_verify_merged_compressed.argtypes = [vp, vp, sz, C.c_uint64, vp, C.POINTER(C.c_uint32)]
+        if _handle is not None:
+            self.h = _handle
+        else:
+            h = vp()
+            self.ctx._chk(lib.vimz_ivc_merged_create(first.h, C.byref(h)))
+            self.h = h
+
+    @classmethod
+    def of(cls, ivcs):
+        """The merged proof of the segments' IVCs, in row order."""
+        m = cls(ivcs[0])
+        for v in ivcs[1:]:
+            m.merge(v)
+        return m
+
+    @classmethod
+    def load(cls, vk, blob):
+        """vimz_ivc_merged_load: `vk` = an IVC for the same step circuit and keys (its state is not touched)."""
+        b = np.ascontiguousarray(blob, dtype=np.uint8)
+        m = cls.__new__(cls)
+        cls.__init__(m, _handle=C.c_void_p(0), _vk=vk)
+        h = C.c_void_p()
+        vk.ctx._chk(vk.ctx.lib.vimz_ivc_merged_load(vk.h, _ptr(b), b.size, C.byref(h)))
+        m.h = h
+        return m
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.vimz_ivc_merged_free(self.h)
+            self.h = None
+
+    def merge(self, nxt):
+        """Fold the next row segment in: an IVC (vimz_ivc_merge) or another merged proof (vimz_ivc_merge_merged)."""
+        if isinstance(nxt, MergedProof):
+            self.ctx._chk(self.ctx.lib.vimz_ivc_merge_merged(self.h, nxt.h))
+        else:
+            self.ctx._chk(self.ctx.lib.vimz_ivc_merge(self.h, nxt.h))
+
+    def verify(self, num_steps, z0):
+        r = C.c_uint32()
+        self.ctx._chk(self.ctx.lib.vimz_ivc_merged_verify(self.h, int(num_steps), _ptr(_zlimbs(z0, self.vk.circuit.len_z)), C.byref(r)))
+        return r.value
+
+    def info(self):
+        a = np.zeros(8, dtype=np.uint64)
+        self.ctx._chk(self.ctx.lib.vimz_ivc_merged_info(self.h, _ptr(a)))
+        keys = ["steps", "segments", "ops", "len_z", "primary_wires", "primary_constraints", "secondary_wires", "secondary_constraints"]
+        return {k: int(a[i]) for i, k in enumerate(keys)}
+
+    def state(self):
+        """(z_start, z_end, steps)"""
+        lz = self.vk.circuit.len_z
+        a, b = np.zeros((lz, 4), dtype=np.uint64), np.zeros((lz, 4), dtype=np.uint64)
+        n = C.c_uint64()
+        self.ctx._chk(self.ctx.lib.vimz_ivc_merged_state(self.h, _ptr(a), _ptr(b), C.byref(n)))
+        ints = lambda z: [sum(int(z[i, k]) << (64 * k) for k in range(4)) for i in range(lz)]
+        return ints(a), ints(b), n.value
+
+    def profile(self):
+        s = (C.c_double * 4)()
+        self.ctx._chk(self.ctx.lib.vimz_ivc_merged_profile(self.h, s))
+        return {k: s[i] for i, k in enumerate(self.PHASES)}
+
+    def save(self):
+        n = self.ctx.lib.vimz_ivc_merged_size(self.h)
+        buf = np.zeros(n, dtype=np.uint8)
+        self.ctx._chk(self.ctx.lib.vimz_ivc_merged_save(self.h, _ptr(buf), n))
+        return buf
+
+    def records(self):
+        """The statement part as uint64 words (header, segment records, ops): what an independent verifier replays."""
+        return _export(self.ctx.lib.vimz_ivc_merged_records, self.h).view(np.uint64)
+
+    def export(self, side, what):
+        return _export(self.ctx.lib.vimz_ivc_merged_export, self.h, side, what).view(np.uint64).reshape(-1, 4)
+
+    def compress(self):
+        lib = self.ctx.lib
+        n = lib.vimz_ivc_merged_compressed_size(self.h)
+        buf = np.zeros(n, dtype=np.uint8)
+        sec = (C.c_double * 2)()
+        self.ctx._chk(lib.vimz_ivc_merged_compress(self.h, _ptr(buf), n, sec))
+        return buf, {"setup_s": sec[0], "prove_s": sec[1]}
+
+    @staticmethod
+    def verify_compressed(vk, blob, num_steps, z0):
+        lib = vk.ctx.lib
+        lib.vimz_ivc_verify_merged_compressed.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint32)]
+        b = np.ascontiguousarray(blob, dtype=np.uint8)
+        r = C.c_uint32()
+        vk.ctx._chk(lib.vimz_ivc_verify_merged_compressed(vk.h, _ptr(b), b.size, int(num_steps), _ptr(_zlimbs(z0, vk.circuit.len_z)), C.byref(r)))
+        return r.value
+
+
 class AugCircuit:
     """vimz_augcircuit: one side's verifier circuit over a trivial step circuit — host-only hook for the circuit's own tests."""
 
