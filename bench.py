@@ -10,13 +10,14 @@ headline number is quoted on: 720 steps in 371.7 s = 1.94 steps/s, README.md:52)
 (tests/golden/img2.png, contrast factor 1.4).
 
   --mode ivc (default)   RecursiveSNARK::prove_step in full: Nova IVC with the augmented verifier circuits on the BN254/Grumpkin
-                         cycle (vimz_ivc_*; SURVEY.md §8a incl. rows S1/S2).  `value` is ONE proof per GPU — the object the
-                         reference's fold_input returns (vimz/src/nova_snark_backend/folding.rs:27-43): W untimed rows, then
-                         EXACTLY K timed rows of the same chain, HIP-event profiling off.  A second pass of K more rows of the
-                         same chain with per-kernel HIP events gives the roofline figure; the proof of all W + 2K rows is
-                         verified for (steps, z0).  `--segments S` (S > 1) folds S proofs of contiguous row segments per GPU
-                         concurrently (an IVC chain cannot be merged: the result is a list of S proofs); at N = 1 the default
-                         run also reports that aggregate as an extra key.
+                         cycle (vimz_ivc_*; SURVEY.md §8a incl. rows S1/S2).  `value` is ONE proof object — what the reference's
+                         fold_input returns (vimz/src/nova_snark_backend/folding.rs:27-43) — of EXACTLY K timed rows per GPU from the
+                         transformation's z0, after a warm-up proof of W rows made the same way; HIP-event profiling off.  The rows
+                         are proven as `--segments S` (default 3) contiguous row segments folded concurrently on the GPU and merged
+                         into one object (vimz_ivc_merge: out-of-circuit NIFS on both curves); the segments' start states
+                         (hash-only chains), the merges and, at N > 1, rank 0's final fold of the ranks' merged proofs are inside the
+                         timed region.  The object is verified for exactly (world x K steps, z0) and compressed.  `--segments 1`:
+                         one IVC chain.  A second proof of K rows with per-kernel HIP events gives the roofline figure.
   --mode accumulator     the NIFS accumulator over the step circuit's own instances (vimz_prover_*): row segments fold
                          independently and are merged by a host-side final fold (BASELINE.json north_star's sharding picture).
 N > 1: every rank folds its own rows (independent row-folds, weak scaling, no data-path collective).  Prints ONE JSON line on
@@ -131,13 +132,14 @@ def _pmc_traffic(key):
 
 
 def main_ivc(args, rank, world, dist, torch, ctxs, circuit, params, steps_all, glob, lo, hi, mine, z0, t_setup):
-    """Nova IVC (the default mode).  Every proof of this rank folds w warm-up rows, k timed rows and k more rows under per-kernel
-    HIP events; S = 1 by default: one proof per GPU."""
+    """Nova IVC (the default mode).  `value`: ONE proof object of world x K rows from the transformation's z0.  Every rank proves its K
+    rows as S contiguous segments folded concurrently (S = 3 by default: one chain leaves a quarter of an MI355X idle) and merged
+    (vimz_ivc_merge); at N > 1 rank 0 then performs the host-side sequential final fold of the ranks' merged proofs.  The segment
+    start states (hash-only chains), the merges and the final fold are all inside the timed region."""
     from vimz_amd import _lib, hip
-    from vimz_amd.distributed import fold_concurrently
+    from vimz_amd.distributed import fold_segments_merged, prove_sharded
     S = len(ctxs)
-    w_each, k_each = -(-args.warmup // S), -(-args.steps // S)
-    per_proof = w_each + 2 * k_each
+    W, K = args.warmup, args.steps
     ck2 = params.secondary_key()
     ivcs = [hip.IVC(c, circuit, params.ck, ck2, max_batch=args.batch) for c in ctxs]
     helper_ctxs, helper_keys = [], []
@@ -148,13 +150,9 @@ def main_ivc(args, rank, world, dist, torch, ctxs, circuit, params, steps_all, g
         hk = params.ck if dev == ctxs[0].device else hc.bases_generate(_lib.CURVE_BN254_G1, params.ck.n)
         ivcs[0].add_msm_helper(hc, hk)
         helper_ctxs.append(hc); helper_keys.append(hk)
-    # state at which each proof's row segment starts (hash-only chain over the rows before it)
-    starts = []
-    for s_ in range(S):
-        before = lo + s_ * per_proof
-        starts.append(_ints(ivcs[0].state_chain(z0, steps_all[glob[:before]])[-1]) if before else list(z0))
-    segs = [(ivcs[s_], mine[s_ * per_proof:(s_ + 1) * per_proof], starts[s_]) for s_ in range(S)]
     setup_s = time.time() - t_setup
+    z0 = [int(x) for x in z0]
+    rows_warm, rows_timed, rows_prof = mine[:W], mine[W:W + K], mine[W + K:W + 2 * K]
 
     def sync_all():
         for c in ctxs:
@@ -164,77 +162,92 @@ def main_ivc(args, rank, world, dist, torch, ctxs, circuit, params, steps_all, g
         if dist is not None:
             dist.barrier()
 
-    for ivc, rows, z in segs:
-        ivc.reset(z)
-    fold_concurrently([(ivc, rows[:w_each]) for ivc, rows, z in segs])
-    prof0 = [ivc.profile() for ivc in ivcs]
-    timed_rows = S * k_each
+    def prove(rows, z_start, timings=None):
+        """one proof object of `rows` from z_start on this rank"""
+        return fold_segments_merged(ivcs, rows, z_start, timings)
+
+    # warm-up: a proof of W rows, made and dropped exactly like the timed one (first-call allocations, pinned buffers, thread pools)
+    if W:
+        prove(rows_warm, z0).close()
+    shm = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp", f"vimz_bench_{os.environ.get('MASTER_PORT', '0')}_r")
+    tm = {}
     sync_all()
     t0 = time.time()
-    if rank > 0:
-        # a rank's segment of a real image starts at the state after all rows before it: that hash-only chain over the lower
-        # ranks' timed rows is a cost of the sharded scheme and is paid inside the timed region
-        ivcs[0].state_chain(z0, np.concatenate([mine[w_each:w_each + k_each]] * (rank * S))[:rank * timed_rows])
-    fold_concurrently([(ivc, rows[w_each:w_each + k_each]) for ivc, rows, z in segs])
+    # the timed job: ONE proof of world x K rows from z0 (proof sets: every rank its own proof of K rows).  Rank r's rows start at the
+    # state after the r·K rows of the ranks before it: rank 0 runs that hash-only chain once and hands every rank its start state;
+    # the ranks' merged proofs go to rank 0 through node-local shared memory and are folded in row order
+    if world > 1 and not args.proof_set:
+        timed_all = np.ascontiguousarray(steps_all[[glob[r * (W + 2 * K) + W + i] for r in range(world) for i in range(K)]])
+        proof = prove_sharded(ivcs, timed_all, z0, rank, world, dist, tm, shm_prefix=shm)
+    else:
+        proof = prove(rows_timed, z0, tm)
     sync_all()
     dt = time.time() - t0
+    t_fold = dt - tm.get("final_fold_s", 0.0)
+    state_chain_s, final_fold_s = tm.get("state_chain_s", 0.0), tm.get("final_fold_s", 0.0)
     prof1 = [ivc.profile() for ivc in ivcs]
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64)
+        t = torch.tensor([dt, t_fold], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t[0])
-    # second pass, outside the timed region: k more rows per proof (the chain continues), with HIP events around every kernel of
-    # the primary MSM(T) launches on the stream they run on -> the roofline figure
+        dt, t_fold = float(t[0]), float(t[1])
+    timed_rows = K
+    timed_total = K * world
+    # acceptance: the ONE object verifies for exactly (world x K steps, z0)   [proof sets: every rank's own proof for (K, z0)]
+    t_v = time.time()
+    ok, codes = True, []
+    if proof is not None:
+        n_claim = K if (args.proof_set or world == 1) else world * K
+        code = proof.verify(n_claim, z0)
+        codes = [code]
+        ok = code == 0 and proof.verify(n_claim + 1, z0) != 0
+    verify_s = time.time() - t_v
+    merged_info = proof.info() if proof is not None else None
+    merge_prof = proof.profile() if proof is not None else None
+    # CompressedSNARK::prove / verify of the merged proof (mod.rs:52-67; README.md:196 counts it into the total proof time)
+    compress = None
+    if rank == 0 and proof is not None and not args.no_compress:
+        try:
+            blob, tc = proof.compress()
+            t_cv = time.time()
+            code_c = hip.MergedProof.verify_compressed(ivcs[0], blob, merged_info["steps"], z0)
+            compress = {"setup_s": tc["setup_s"], "prove_s": tc["prove_s"], "verify_s": time.time() - t_cv, "proof_bytes": int(len(blob)), "verified": code_c == 0,
+                        "arguments": "one for the folded primary and one for the folded secondary instance of the merged proof"}
+            ok = ok and code_c == 0
+        except Exception as e:
+            print(f"[bench] compression skipped: {e}", file=sys.stderr)
+    if proof is not None:
+        proof.close()
+    # second pass, outside the timed region: the same K rows proven again with HIP events around every kernel of the primary MSM(T)
+    # launches on the stream they run on -> the roofline figure
     for c in ctxs:
         c.set_profiling(True)
         c.msm_profile_totals(reset=True)
     t1 = time.time()
-    fold_concurrently([(ivc, rows[w_each + k_each:]) for ivc, rows, z in segs])
+    p2 = prove(rows_prof if len(rows_prof) == K else rows_timed, z0)
     for c in ctxs:
         c.sync()
     dt_prof = time.time() - t1
+    p2.close()
     tots = [c.msm_profile_totals() for c in ctxs]
     tot = {"ms": {k: sum(t["ms"][k] for t in tots) for k in tots[0]["ms"]}, "calls": sum(t["calls"] for t in tots),
            "points": sum(t["points"] for t in tots), "entries": sum(t["entries"] for t in tots)}
     for c in ctxs:
         c.set_profiling(False)
-    # acceptance: every proof verifies for exactly (its rows, its start state); the first starts at the transformation's z0
-    t_v = time.time()
-    codes = [ivc.verify(per_proof, z) for ivc, rows, z in segs]
-    ok = all(c == 0 for c in codes) and (lo > 0 or segs[0][2] == [int(x) for x in z0])
-    ends = [ivc.state()[0] for ivc in ivcs]
-    ok = ok and all(ends[i] == segs[i + 1][2] for i in range(S - 1))
-    verify_s = time.time() - t_v
-    folded = sum(ivc.state()[1] for ivc in ivcs)
-    # CompressedSNARK::prove / verify of the first proof (mod.rs:52-67; README.md:196 counts it into the total proof time)
-    compress = None
-    if rank == 0 and not args.no_compress:
-        try:
-            blob, tc = ivcs[0].compress()
-            t_cv = time.time()
-            code_c = ivcs[0].verify_compressed(blob, per_proof, segs[0][2])
-            compress = {"setup_s": tc["setup_s"], "prove_s": tc["prove_s"], "verify_s": time.time() - t_cv, "proof_bytes": int(len(blob)), "verified": code_c == 0}
-            ok = ok and code_c == 0
-        except Exception as e:
-            print(f"[bench] compression skipped: {e}", file=sys.stderr)
     if dist is not None:
-        t = torch.tensor([1 if ok else 0, folded, timed_rows], dtype=torch.int64)
-        m = t.clone(); dist.all_reduce(m, op=dist.ReduceOp.MIN)
-        a = t.clone(); dist.all_reduce(a, op=dist.ReduceOp.SUM)
-        ok, folded, timed_total = bool(int(m[0])), int(a[1]), int(a[2])
-    else:
-        timed_total = timed_rows
+        t = torch.tensor([1 if ok else 0], dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        ok = bool(int(t[0]))
     if rank == 0:
         info = ivcs[0].info()
         n_w, n_c, nnz = info["primary_wires"], info["primary_constraints"], info["primary_nnz"]
         calls = max(1, tot["calls"])
         acc_ms = tot["ms"]["accumulate"] / calls
         msm_ms = sum(tot["ms"].values()) / calls
-        alg_bytes = 96.0 * tot["points"] / calls       # 32 B scalar + 64 B base per point of the launch (the step circuit's rows)
+        alg_bytes = 96.0 * tot["points"] / calls       # 32 B scalar + 64 B base per point of the launch
         achieved = alg_bytes / (acc_ms * 1e-3) / 1e9 if acc_ms else 0.0
         adds = tot["entries"] / calls
-        # for reference: the same kernel over the same kind of data (the running error vector of the first proof, which has the
-        # cross terms' zero and repetition structure) with nothing else on the GPU
+        # for reference: the same kernel over the same kind of data (the running error vector of the first segment's proof, which has
+        # the cross terms' zero and repetition structure) with nothing else on the GPU
         alone_ms = None
         try:
             E = np.ascontiguousarray(ivcs[0].export(0, hip.IX_RUNNING_E))[:info["step_constraints"]]
@@ -252,46 +265,28 @@ def main_ivc(args, rank, world, dist, torch, ctxs, circuit, params, steps_all, g
         traffic, traffic_src = _pmc_traffic(f"{args.transformation}_step_{args.resolution}_ivc")
         n_w2, n_c2, nnz2 = info["secondary_wires"], info["secondary_constraints"], info["secondary_nnz"]
         step_bytes = sum(96 * w + 96 * c + 8 * z + 32 * w + 96 * c + 7 * 32 * c + 3 * 32 * w + 12 * 32 * c for w, c, z in ((n_w, n_c, nnz), (n_w2, n_c2, nnz2)))
-        phases = {k: 1e3 * sum(p1[k][0] - p0[k][0] for p0, p1 in zip(prof0, prof1)) / max(1, timed_rows) for k in prof1[0]}
-        # extra (N = 1, one proof per GPU): the aggregate of three proofs of contiguous row segments folded concurrently — a list
-        # of three proofs, not the reference's object; measured after everything else
-        three = None
-        if world == 1 and S == 1 and not args.no_extras:
+        phases = {k: 1e3 * sum(p1[k][0] for p1 in prof1) / max(1, timed_rows) for k in prof1[0]}      # (reset() at the start of the timed proof zeroed the counters)
+        # extra (N = 1): the same K rows as ONE chain (one IVC, no segments, no merge) — what a single sequential prove_step loop reaches
+        one_chain = None
+        if world == 1 and S > 1 and not args.no_extras:
             try:
-                cx = [hip.Context(ctxs[0].device) for _ in range(2)]
-                more = [hip.IVC(c, circuit, params.ck, ck2, max_batch=args.batch) for c in cx]
-                trio = [ivcs[0]] + more
-                blk = w_each + k_each
-                rows3 = [np.ascontiguousarray(steps_all[[i % len(steps_all) for i in range(j * blk, (j + 1) * blk)]]) for j in range(3)]
-                z3 = [list(z0)]
-                for j in range(2):
-                    z3.append(_ints(ivcs[0].state_chain(z3[-1], rows3[j])[-1]))
-                for v, z in zip(trio, z3):
-                    v.reset(z)
-                fold_concurrently([(v, r[:w_each]) for v, r in zip(trio, rows3)])
-                for c in [ctxs[0]] + cx:
-                    c.sync()
+                ivcs[0].reset(z0)
+                ctxs[0].sync()
                 t3 = time.time()
-                fold_concurrently([(v, r[w_each:]) for v, r in zip(trio, rows3)])
-                for c in [ctxs[0]] + cx:
-                    c.sync()
+                ivcs[0].fold(rows_timed)
+                ctxs[0].sync()
                 d3 = time.time() - t3
-                ok3 = all(v.verify(blk, z) == 0 for v, z in zip(trio, z3)) and all(trio[j].state()[0] == z3[j + 1] for j in range(2))
-                three = {"steps_per_s": 3 * k_each / d3, "proofs": 3, "rows_each": k_each, "verified": bool(ok3),
-                         "note": "three IVC proofs of contiguous row segments folded concurrently on this GPU (boundary states chain); a list of proofs, not one RecursiveSNARK"}
-                for v in more:
-                    v.close()
-                for c in cx:
-                    c.close()
+                one_chain = {"steps_per_s": K / d3, "verified": ivcs[0].verify(K, z0) == 0,
+                             "note": "the same rows as one IVC chain on one set of streams (bench.py --segments 1)"}
             except Exception as e:
-                print(f"[bench] three-proof extra skipped: {e}", file=sys.stderr)
+                print(f"[bench] one-chain extra skipped: {e}", file=sys.stderr)
         out = {
             "metric": "nova_folding_steps_per_sec",
             "value": timed_total / dt,
             "unit": "steps/s",
             "n_gpus": world,
             "steps": timed_rows,
-            "warmup": S * w_each,
+            "warmup": W,
             "ms_per_step": dt / max(1, timed_rows) * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
@@ -301,24 +296,30 @@ def main_ivc(args, rank, world, dist, torch, ctxs, circuit, params, steps_all, g
             "config": {"workload": f"{args.transformation}_step_{args.resolution}", "mode": "ivc (augmented circuits on BN254/Grumpkin: RecursiveSNARK::prove_step in full)",
                        "constraints": n_c, "wires": n_w, "nnz": nnz, "step_circuit_constraints": info["step_constraints"], "step_circuit_wires": info["step_wires"],
                        "secondary_constraints": n_c2, "secondary_wires": n_w2,
-                       "rows_per_rank": timed_rows, "proofs_per_gpu": S, "witness_batch": args.batch, "msm_helper_contexts": args.msm_helpers,
+                       "rows_per_rank": timed_rows, "segments_per_gpu": S, "witness_batch": args.batch, "msm_helper_contexts": args.msm_helpers,
                        "parallelism": (f"proof set {args.proof_set}: rank r proves proof_set[r % len]; independent proofs, replicas only" if args.proof_set else
-                                       ("one IVC proof per GPU" if S == 1 else f"{S} IVC proofs of contiguous row segments per GPU, folded concurrently") +
-                                       ("" if world == 1 else f"; {world} GPUs prove {world * S} contiguous row segments of the image independently (boundary states chain), no data-path collective"))},
+                                       (f"ONE proof object: {S} contiguous row segments per GPU folded concurrently as Nova IVCs and merged (vimz_ivc_merge)" if S > 1 else "one IVC chain per GPU") +
+                                       ("" if world == 1 else f"; {world} GPUs prove {world} contiguous runs of rows, rank 0 folds their merged proofs into ONE object (host-side sequential final fold); no data-path collective"))},
             "verified": bool(ok),
             "verify_codes": codes,
-            "folded_steps_total": folded,
+            "proof_object": merged_info,
+            "folded_steps_total": merged_info["steps"] if merged_info else None,
             "verify_s": verify_s,
-            "three_concurrent_proofs": three,
+            "state_chain_s": state_chain_s,
+            "merge_s": tm.get("merge_s", 0.0),
+            "final_fold_s": final_fold_s,
+            "fold_s": t_fold,
+            "merge_profile_s": merge_prof,
+            "one_chain": one_chain,
             "compressed_snark": compress,
-            "end_to_end_estimate_s": {"keygen_and_setup": setup_s, "fold_720_steps_one_gpu": 720 * dt / max(1, timed_rows),
+            "end_to_end_estimate_s": {"keygen_and_setup": setup_s, "fold_720_steps_one_gpu": 720 * dt / max(1, timed_total),
                                       "compress": (compress["setup_s"] + compress["prove_s"]) if compress else None,
-                                      "total_720_steps": (setup_s + 720 * dt / max(1, timed_rows) + compress["setup_s"] + compress["prove_s"]) if compress else None,
+                                      "total_720_steps": (setup_s + 720 * dt / max(1, timed_total) + compress["setup_s"] + compress["prove_s"]) if compress else None,
                                       "reference_cpu_server": {"keygen_s": 6.5, "fold_s": 371.7, "compress_s_sample_run": 13.0, "source": "README.md:52, sample-output.png"}},
             "published_reference": {"contrast_HD_steps_per_s_cpu_server": 1.94, "source": "README.md:52 (720 steps / 371.7 s)"},
             "phase_ms_per_step_per_proof": phases,
             "roofline": {"bound": "hbm", "kernel": "k_accum (bucket accumulation) of the primary MSM(T) launches over the step circuit's rows",
-                         "measured": f"HIP events on the kernel's own stream over a second pass of {timed_rows} rows of the same chain(s) right after the timed region (events off while `value` is timed); that pass ran at {timed_rows / dt_prof:.1f} steps/s",
+                         "measured": f"HIP events on the kernel's own stream over a second proof of {timed_rows} rows made the same way right after the timed region (events off while `value` is timed); that pass ran at {timed_rows / dt_prof:.1f} steps/s",
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": acc_ms, "launches": tot["calls"], "msm_gpu_ms": msm_ms,
@@ -331,7 +332,7 @@ def main_ivc(args, rank, world, dist, torch, ctxs, circuit, params, steps_all, g
         if not args.no_cpu_baseline and world == 1:      # the CPU baseline is timed at N = 1 only
             cores = usable_cores()
             ck_host = params.ck.download(0, max(circuit.n_constraints, circuit.n_wires))
-            sps, secs, n_cpu, cph = cpu_baseline(circuit, mine, starts[0], ck_host, args.cpu_seconds, cores)
+            sps, secs, n_cpu, cph = cpu_baseline(circuit, mine, z0, ck_host, args.cpu_seconds, cores)
             out["cpu_baseline"] = {"value": sps, "unit": "steps/s", "cores": cores, "kind": "port",
                                    "sample": f"{n_cpu} folding steps of the step circuit's instances with the CPU oracle (C++ restatement, std::thread over the usable cores (affinity and cgroup quota) for SpMV / MSM / vector ops, "
                                              f"witness executor single-threaded; not the Rust binary; without the augmented circuits, i.e. less work per step than the GPU number), {secs:.1f} s",
@@ -355,13 +356,13 @@ def main():
     ap.add_argument("--transformation", default="contrast")
     ap.add_argument("--resolution", default="HD")
     ap.add_argument("--batch", type=int, default=64)
-    ap.add_argument("--segments", type=int, default=0, help="proofs / row segments folded concurrently on each GPU, own context + streams each (default: 1 IVC proof, 2 accumulators)")
+    ap.add_argument("--segments", type=int, default=0, help="row segments folded concurrently on each GPU, own context + streams each, and merged into one proof (default: 3 in IVC mode, 2 accumulators)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--msm-helpers", type=int, default=0, help="IVC mode: split every step's large MSM(T) by base range over this many helper contexts "
                     "(devices after this rank's, wrapping around; on a one-GPU box they share the device): one proof on several GPUs, SURVEY.md §8e")
     ap.add_argument("--no-compress", action="store_true", help="skip CompressedSNARK::prove / verify of the folded proof")
-    ap.add_argument("--no-extras", action="store_true", help="skip the three-concurrent-proofs extra of the default IVC run")
+    ap.add_argument("--no-extras", action="store_true", help="skip the one-chain extra of the default IVC run")
     ap.add_argument("--mode", default="ivc", choices=["ivc", "accumulator"])
     ap.add_argument("--window-tables", type=int, default=0, help="window tables of the primary key in HBM (vimz_bases_precompute): 11 = per-window buckets, no host Horner; 13..16 = one shared bucket set; 0 = none")
     ap.add_argument("--proof-set", default="", help="comma-separated transformations: rank r proves proof_set[r %% len] (BASELINE config 5: independent proofs, replicas only)")
@@ -392,17 +393,14 @@ def main():
 
     from vimz_amd import folding, hip
     from vimz_amd.distributed import segment_bounds
-    S = args.segments if args.segments > 0 else (1 if args.mode == "ivc" else 2)
+    S = args.segments if args.segments > 0 else (3 if args.mode == "ivc" else 2)
     ctxs = [hip.Context(device) for _ in range(S)]
     ctx = ctxs[0]
     t_setup = time.time()
     circuit, params = folding.prepare_folding(ctx, args.transformation, args.resolution, window_tables=args.window_tables)
     steps_all, z0 = build_inputs(args.transformation, args.resolution)
     n_rows = steps_all.shape[0]
-    if args.mode == "ivc":
-        per_rank = S * (-(-args.warmup // S) + 2 * -(-args.steps // S))
-    else:
-        per_rank = args.warmup + args.steps
+    per_rank = args.warmup + (2 if args.mode == "ivc" else 1) * args.steps
     # global row list = concatenation of the ranks' segments; rank r folds rows [r*per_rank, (r+1)*per_rank) of it
     # (image rows are reused cyclically when the list is longer than the image)
     glob = [i % n_rows for i in range(world * per_rank)]

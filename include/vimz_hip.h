@@ -88,6 +88,8 @@ int vimz_bases_download(vimz_ctx* ctx, const vimz_bases* b, size_t offset, uint6
  *   window_bits 12..16: ONE bucket set shared by all windows — fewer digits per scalar, one bucket reduction, no Horner;
  *   window_bits 11 (the window a large MSM uses anyway): the usual per-window bucket sets, whose sums the host then only adds
  *   (no Horner: ~0.1 ms less on the host per MSM).  MSMs too small for that window ignore such tables.
+ *   window_bits 7 (keys of at most 24576 points): EVERY multiple m·2^(7w)·P_i, m = 1..64 (189 KB per point): a digit selects its point,
+ *   the MSM is one sum without buckets — what the per-step commitments over the verifier circuits' fixed key slices use.
  * Results are unchanged. */
 int vimz_bases_precompute(vimz_ctx* ctx, vimz_bases* b, int window_bits);
 size_t vimz_bases_len(const vimz_bases* b);

@@ -179,3 +179,170 @@ def test_ivc_segments_chain_their_boundary_states(oracle):
         assert segs[i][0].z == segs[i + 1][2]            # z_end of segment i = z_start of segment i+1
     single = Stub(); single.reset(z0); single.fold(rows)
     assert segs[2][0].z == single.z and sum(s.n for s in stubs) == 10
+
+
+# ---- ONE proof object over ranks (prove_sharded): the host logic on CPU over stand-ins, the real thing with two ranks on one GPU --------
+class _StubIVC:
+    """state_chain / reset / fold over the oracle's step relation (what vimz_amd.hip.IVC offers the sharding driver)."""
+
+    def __init__(self, oracle):
+        self.o, self.z, self.z0, self.n = oracle, None, None, 0
+
+    def state_chain(self, z_start, rws):
+        from tests._oracle import T_HASH, to_limbs
+        zs, z = [list(z_start)], list(z_start)
+        for r in rws:
+            ok, z = self.o.step_eval(T_HASH, z, r)
+            assert ok
+            zs.append(list(z))
+        return np.stack([to_limbs(s) for s in zs])
+
+    def reset(self, z):
+        self.z, self.z0, self.n = list(z), list(z), 0
+
+    def fold(self, rws):
+        from tests._oracle import T_HASH
+        for r in rws:
+            ok, self.z = self.o.step_eval(T_HASH, self.z, r)
+            assert ok
+            self.n += 1
+
+
+class _StubMerged:
+    """What vimz_amd.hip.MergedProof offers: created from the first segment, merge() of the adjacent next one (an IVC or another
+    merged proof), save / load as bytes."""
+
+    def __init__(self, first):
+        self.zs, self.ze, self.n, self.segments = list(first.z0), list(first.z), first.n, 1
+
+    def merge(self, nxt):
+        zs, ze, n, k = (nxt.zs, nxt.ze, nxt.n, nxt.segments) if isinstance(nxt, _StubMerged) else (nxt.z0, nxt.z, nxt.n, 1)
+        if list(zs) != self.ze:
+            raise ValueError("segments not adjacent")
+        self.ze, self.n, self.segments = list(ze), self.n + n, self.segments + k
+
+    def save(self):
+        import pickle
+        return np.frombuffer(pickle.dumps((self.zs, self.ze, self.n, self.segments)), dtype=np.uint8)
+
+    @classmethod
+    def load(cls, vk, blob):
+        import pickle
+        m = cls.__new__(cls)
+        m.zs, m.ze, m.n, m.segments = pickle.loads(np.asarray(blob, dtype=np.uint8).tobytes())
+        return m
+
+    def close(self):
+        pass
+
+
+def _sharded_worker(rank, world, port, q, shm):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from tests import _oracle
+    from tests.test_circuits import step_inputs
+    from vimz_amd.distributed import prove_sharded
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    orc = _oracle.load()
+    z0, inputs = step_inputs("hash")
+    rows = np.stack(inputs[:9])
+    tm = {}
+    proof = prove_sharded([_StubIVC(orc) for _ in range(2)], rows, z0, rank, world, dist, tm, merged_cls=_StubMerged,
+                          shm_prefix=(f"/tmp/vimz_test_{port}_" if shm else None))
+    if rank == 0:
+        q.put((proof.zs, proof.ze, proof.n, proof.segments, sorted(tm)))
+    else:
+        assert proof is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("shm", [False, True])
+def test_two_ranks_with_two_segments_each_end_in_one_proof_object(oracle, shm):
+    """prove_sharded over gloo, world size 2, two local segments per rank (stand-ins over the oracle's step relation): rank 0's chain
+    gives rank 1 its start state, every rank's segments merge locally, rank 0 folds rank 1's merged proof in — one object about all
+    nine rows from z0 that ends where a single chain ends; both ways of moving the bytes."""
+    import torch.multiprocessing as mp
+    from tests._oracle import T_HASH
+    from tests.test_circuits import step_inputs
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q, shm)) for r in range(2)]
+    for p in procs:
+        p.start()
+    zs, ze, n, segments, keys = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    z0, inputs = step_inputs("hash")
+    z = list(z0)
+    for i in range(9):
+        ok, z = oracle.step_eval(T_HASH, z, inputs[i])
+    assert (zs, ze, n, segments) == (list(z0), z, 9, 4)
+    assert keys == ["final_fold_s", "merge_s", "state_chain_s"]
+
+
+def test_fold_segments_merged_handles_fewer_rows_than_segments(oracle):
+    from tests.test_circuits import step_inputs
+    from vimz_amd.distributed import fold_segments_merged
+    z0, inputs = step_inputs("hash")
+    m = fold_segments_merged([_StubIVC(oracle) for _ in range(3)], np.stack(inputs[:2]), z0, merged_cls=_StubMerged)
+    assert (m.n, m.segments, m.zs) == (2, 2, list(z0))
+
+
+def _gpu_sharded_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from tests.test_circuits import step_inputs
+    from vimz_amd import _lib, hip
+    from vimz_amd.circuit import Circuit
+    from vimz_amd.distributed import prove_sharded
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ctxs = [hip.Context(0), hip.Context(0)]
+    c = Circuit.for_resolution("hash", "HD")
+    ck1 = ctxs[0].bases_generate(_lib.CURVE_BN254_G1, 1 << 14)
+    ck2 = ctxs[0].bases_generate(_lib.CURVE_GRUMPKIN, 1 << 13, b"ck-secondary")
+    z0, inputs = step_inputs("hash")
+    rows = np.stack(inputs[:9])
+    ivcs = [hip.IVC(cx, c, ck1, ck2, max_batch=2) for cx in ctxs]
+    proof = prove_sharded(ivcs, rows, z0, rank, world, dist, shm_prefix=f"/tmp/vimz_test_{port}_")
+    if rank == 0:
+        q.put((proof.verify(9, z0), proof.verify(8, z0), proof.state(), proof.info()["segments"]))
+        proof.close()
+    dist.barrier()
+    for v in ivcs:
+        v.close()
+    ck1.free(); ck2.free()
+    for cx in ctxs:
+        cx.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_the_gpu_end_in_one_verified_proof_object(oracle):
+    """world_size 2 over gloo with the GPU provers (both ranks share the one GPU of the box): 2 x 2 IVC segments -> two merged proofs
+    -> rank 0's final fold -> ONE object that verifies for (9 steps, z0) and for nothing else."""
+    import torch.multiprocessing as mp
+    from tests._oracle import T_HASH
+    from tests.test_circuits import step_inputs
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gpu_sharded_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    ok9, ok8, state, segments = q.get(timeout=900)
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    z0, inputs = step_inputs("hash")
+    z = list(z0)
+    for i in range(9):
+        ok, z = oracle.step_eval(T_HASH, z, inputs[i])
+    assert ok9 == 0 and ok8 != 0 and segments == 4
+    assert state == ([int(x) for x in z0], z, 9)

@@ -3,7 +3,8 @@
 (vimz/src/nova_snark_backend/mod.rs:22-80): prepare input -> prepare folding (circuit + key) -> fold every row -> verify.
 Prints the span times the reference logs ("Prepare input", "Prepare folding", "Fold input", "Verify folded proof").
 usage: e2e.py <transformation> <resolution> [segments] [ivc|accumulator] [proof file prefix]
-ivc (default): the rows are proven as `segments` Nova IVC proofs of contiguous row segments (chained boundary states);
+ivc (default): ONE proof object — the rows are proven as `segments` Nova IVCs of contiguous row segments folded concurrently and
+merged (vimz_ivc_merge), then compressed;
 accumulator: NIFS accumulators of the segments merged by a final fold."""
 import json
 import sys
@@ -14,12 +15,12 @@ import numpy as np
 sys.path.insert(0, __file__.rsplit("/tools/", 1)[0])
 import bench  # noqa: E402
 from vimz_amd import _lib, folding, hip  # noqa: E402
-from vimz_amd.distributed import fold_concurrently, fold_local_segments, ivc_segments  # noqa: E402
+from vimz_amd.distributed import fold_local_segments, fold_segments_merged  # noqa: E402
 
 
 def main():
     t, res = sys.argv[1], sys.argv[2]
-    S = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+    S = int(sys.argv[3]) if len(sys.argv) > 3 else 3
     mode = sys.argv[4] if len(sys.argv) > 4 else "ivc"
     save = sys.argv[5] if len(sys.argv) > 5 else None
     spans = {}
@@ -30,35 +31,33 @@ def main():
     ctxs = [hip.Context(0) for _ in range(S)]
     circuit, params = folding.prepare_folding(ctxs[0], t, res)
     if mode == "ivc":
-        ck2 = ctxs[0].bases_generate(_lib.CURVE_GRUMPKIN, 1 << 13, b"ck-secondary")
+        ck2 = params.secondary_key()
         ivcs = [hip.IVC(c, circuit, params.ck, ck2, max_batch=64 if res == "HD" else 32) for c in ctxs]
         spans["Prepare folding"] = time.time() - t0
         t0 = time.time()
-        segs = ivc_segments(ivcs, rows, z0)
-        for v, r, z in segs:
-            v.reset(z)
-        fold_concurrently([(v, r) for v, r, z in segs])
+        tm = {}
+        proof = fold_segments_merged(ivcs, rows, z0, tm)      # ONE proof object: S concurrent segments + merge (S = 1: one chain)
         for c in ctxs:
             c.sync()
         spans["Fold input"] = time.time() - t0
         t0 = time.time()
-        ok = all(v.verify(len(r), z) == 0 for v, r, z in segs) and segs[0][2] == list(z0)
+        ok = proof.verify(len(rows), z0) == 0
         spans["Verify folded proof"] = time.time() - t0
-        n = sum(v.state()[1] for v in ivcs)
-        if S == 1:      # the reference's remaining spans (vimz/src/nova_snark_backend/mod.rs:52-67): one RecursiveSNARK -> CompressedSNARK
-            blob, tc = ivcs[0].compress()
-            spans["Prepare compression"] = tc["setup_s"]
-            spans["Compress proof"] = tc["prove_s"]
-            t0 = time.time()
-            ok = ok and ivcs[0].verify_compressed(blob, len(rows), z0) == 0
-            spans["Verify compressed proof"] = time.time() - t0
-            spans["compressed proof bytes"] = int(len(blob))
+        zs, ze, n = proof.state()
+        # the reference's remaining spans (vimz/src/nova_snark_backend/mod.rs:52-67): RecursiveSNARK -> CompressedSNARK
+        blob, tc = proof.compress()
+        spans["Prepare compression"] = tc["setup_s"]
+        spans["Compress proof"] = tc["prove_s"]
+        t0 = time.time()
+        ok = ok and hip.MergedProof.verify_compressed(ivcs[0], blob, len(rows), z0) == 0
+        spans["Verify compressed proof"] = time.time() - t0
+        spans["compressed proof bytes"] = int(len(blob))
         if save:
-            for k, v in enumerate(ivcs):
-                v.proof_export().tofile(f"{save}.{k}.bin")      # verify elsewhere: tools/verify_proof.py
-        print(json.dumps({"config": f"{t}_step_{res}", "mode": "ivc", "steps": n, "segment_proofs": S, "verified": ok, "spans_s": spans,
+            proof.save().tofile(f"{save}.merged.bin")       # verify elsewhere: tools/verify_proof.py
+        print(json.dumps({"config": f"{t}_step_{res}", "mode": "ivc", "steps": n, "segments": S, "proof_objects": 1, "verified": ok, "spans_s": spans,
+                          "state_chain_s": tm.get("state_chain_s"), "merge_s": tm.get("merge_s"),
                           "steps_per_s": n / spans["Fold input"], "total_s": sum(v for k, v in spans.items() if not k.endswith("bytes")),
-                          "final_state": [hex(z) for z in ivcs[-1].state()[0]]}))
+                          "final_state": [hex(z) for z in ze]}))
         return
     provers = [hip.Prover(c, circuit, params.ck, max_batch=64 if res == "HD" else 32) for c in ctxs]
     spans["Prepare folding"] = time.time() - t0

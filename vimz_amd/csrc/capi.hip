@@ -82,9 +82,16 @@ int vz_msm_device(vimz_ctx* c, const vimz_bases* bases, size_t base_offset, cons
     typedef decltype(cv) C;
     typedef typename C::Base F;
     Affine<F> r;
-    const BaseTables tb = bases->tb(base_offset);
+    BaseTables tb = bases->tb(base_offset);
+    bool have_tb = bases->tables != nullptr;
+    if (n <= MSM_SMALL_MAX && window_bits <= 0 && !split_ones) {      // a fixed slice with small-MSM tables (vimz_bases_precompute(7), or an IVC's slices)
+      vimz_bases* bm = const_cast<vimz_bases*>(bases);
+      std::lock_guard<std::mutex> g(bm->small_mu);
+      for (auto& t : bm->small)
+        if (t.offset <= base_offset && base_offset + n <= t.offset + t.n) { tb = BaseTables{t.rows, t.n, base_offset - t.offset, t.c, t.K, 0, t.mult}; have_tb = true; break; }
+    }
     hipError_t e = msm_run<C>(c->stream, c->msm_ws, bases->d + (size_t)AFFINE_WORDS * base_offset, d_scalars, n, scalars_mont, window_bits, &r,
-                              &c->last_msm, c->profiling ? c->ev : nullptr, split_ones, bases->tables ? &tb : nullptr);
+                              &c->last_msm, c->profiling ? c->ev : nullptr, split_ones, have_tb ? &tb : nullptr);
     if (e != hipSuccess) return vz_fail(c, VIMZ_ERR_HIP, "msm", e);
     if (c->profiling && n) {
       for (int i = 0; i < 6; i++) c->msm_tot_ms[i] += c->last_msm.ms[i];
@@ -92,6 +99,33 @@ int vz_msm_device(vimz_ctx* c, const vimz_bases* bases, size_t base_offset, cons
     }
     if (out_form == VIMZ_FORM_CANONICAL) { r.x = F::from_mont(r.x); r.y = F::from_mont(r.y); }
     memcpy(out_xy, r.x.v, 32); memcpy(out_xy + 4, r.y.v, 32);
+    return VIMZ_OK;
+  });
+}
+int vz_small_tables(vimz_ctx* c, vimz_bases* b, size_t offset, size_t n, bool with_mult, BaseTables* out) {
+  *out = BaseTables{nullptr, 0, 0, 0, 0};
+  if (!n || n > MSM_SMALL_MAX || offset + n > b->n) return VIMZ_OK;
+  std::lock_guard<std::mutex> g(b->small_mu);
+  vimz_small_tables* t = nullptr;
+  for (auto& e : b->small) if (e.offset == offset && e.n == n) t = &e;
+  return curve_dispatch(b->curve, [&](auto cv) {
+    typedef decltype(cv) C;
+    const int K = (C::Scalar::Params::BITS + SMALL_C) / SMALL_C;
+    hipError_t e = hipSuccess;
+    if (!t) {
+      vimz_small_tables nt; nt.offset = offset; nt.n = n; nt.c = SMALL_C; nt.K = K;
+      if ((e = hipMalloc((void**)&nt.rows, 4 * (size_t)AFFINE_WORDS * n * K)) != hipSuccess) return vz_fail(c, VIMZ_ERR_HIP, "small-MSM window tables", e);
+      if ((e = build_tables<C>(c->stream, b->d + (size_t)AFFINE_WORDS * offset, n, SMALL_C, K, nt.rows)) != hipSuccess) { hipFree(nt.rows); return vz_fail(c, VIMZ_ERR_HIP, "small-MSM window tables", e); }
+      b->small.push_back(nt);
+      t = &b->small.back();
+    }
+    if (with_mult && !t->mult) {
+      const size_t nm = (size_t)1 << (SMALL_C - 1);
+      if ((e = hipMalloc((void**)&t->mult, 4 * (size_t)AFFINE_WORDS * n * K * nm)) != hipSuccess) return vz_fail(c, VIMZ_ERR_HIP, "small-MSM multiples tables (1.5 GB per 7.7 k points)", e);
+      if ((e = build_multiples<C>(c->stream, t->rows, n, SMALL_C, K, t->mult)) != hipSuccess) { hipFree(t->mult); t->mult = nullptr; return vz_fail(c, VIMZ_ERR_HIP, "small-MSM multiples tables", e); }
+    }
+    if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return vz_fail(c, VIMZ_ERR_HIP, "small-MSM tables", e);
+    out->d = t->rows; out->n_total = n; out->offset = 0; out->c = SMALL_C; out->K = K; out->mult = with_mult ? t->mult : nullptr;
     return VIMZ_OK;
   });
 }
@@ -306,7 +340,12 @@ int vimz_bases_download(vimz_ctx* c, const vimz_bases* b, size_t offset, uint64_
 size_t vimz_bases_len(const vimz_bases* b) { return b ? b->n : 0; }
 void vimz_bases_free(vimz_ctx* c, vimz_bases* b) {
   if (!b) return;
-  if (c) { std::lock_guard<std::mutex> g(c->mu); hipSetDevice(c->device); hipStreamSynchronize(c->stream); if (b->d) hipFree(b->d); if (b->tables) hipFree(b->tables); }
+  if (c) {
+    std::lock_guard<std::mutex> g(c->mu); hipSetDevice(c->device); hipStreamSynchronize(c->stream);
+    if (b->d) hipFree(b->d);
+    if (b->tables) hipFree(b->tables);
+    for (auto& t : b->small) { if (t.rows) hipFree(t.rows); if (t.mult) hipFree(t.mult); }
+  }
   delete b;
 }
 // Window tables T_j[i] = 2^(c j) P_i for the whole key (c = window_bits, 0 -> 16): K x the key's size in HBM
@@ -314,7 +353,14 @@ void vimz_bases_free(vimz_ctx* c, vimz_bases* b) {
 int vimz_bases_precompute(vimz_ctx* c, vimz_bases* b, int window_bits) {
   if (!c || !b) return fail(c, VIMZ_ERR_INVALID, "vimz_bases_precompute: bad argument");
   const int cw = window_bits > 0 ? window_bits : 16;
-  if (cw < 10 || cw > 16) return fail(c, VIMZ_ERR_INVALID, "vimz_bases_precompute: window_bits must be in [10, 16]");
+  if (cw == SMALL_C) {       // the small-MSM form: rows 2^(7w)·P_i and every multiple of them (keys of at most MSM_SMALL_MAX points)
+    if (b->n > MSM_SMALL_MAX) return fail(c, VIMZ_ERR_INVALID, "vimz_bases_precompute: window_bits 7 (tables of multiples) is for keys of at most 24576 points");
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(c, hipSetDevice(c->device));
+    BaseTables t;
+    return vz_small_tables(c, b, 0, b->n, true, &t);
+  }
+  if (cw < 10 || cw > 16) return fail(c, VIMZ_ERR_INVALID, "vimz_bases_precompute: window_bits must be 7 or in [10, 16]");
   std::lock_guard<std::mutex> g(c->mu);
   HIP_TRY(c, hipSetDevice(c->device));
   if (b->tables) { hipFree(b->tables); b->tables = nullptr; }

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <mutex>
 #include <string>
+#include <vector>
 #include "../../include/vimz_hip.h"
 #include "ec.hpp"
 #include "msm_api.hpp"
@@ -22,8 +23,13 @@ struct vimz_ctx {
   void* scratch = nullptr;  // device staging for host-scalar MSM / probes
   size_t scratch_bytes = 0;
 };
+// Tables of a fixed slice [offset, offset + n) of a key for the fused small MSMs (the four per-step MSMs of an IVC run over fixed
+// slices): rows 2^(7w)·P_i and every multiple m·2^(7w)·P_i, m = 1..64 (msm_api.hpp: BaseTables).  Built once per key and slice,
+// shared by every IVC created over the key, released with the key.
+struct vimz_small_tables { size_t offset = 0, n = 0; uint32_t* rows = nullptr; uint32_t* mult = nullptr; int c = 0, K = 0; };
 struct vimz_bases {
   int curve; size_t n; uint32_t* d;
+  std::mutex small_mu; std::vector<vimz_small_tables> small;
   uint32_t* tables = nullptr; int table_c = 0, table_K = 0;   // optional window tables (vimz_bases_precompute)
   vz::BaseTables tb(size_t offset) const { return vz::BaseTables{tables, n, offset, table_c, table_K, table_c == 11}; }
 };
@@ -33,6 +39,9 @@ struct vimz_vec { int field; size_t n; uint32_t* d; };
 namespace vz {
 int vz_fail(vimz_ctx* c, int code, const char* what, hipError_t e = hipSuccess);
 int vz_ensure_scratch(vimz_ctx* c, size_t bytes);
+// tables of the slice [offset, offset + n) of `b` for the fused small MSMs (built on first use on the context's stream; caller holds
+// c->mu and has set the device).  with_mult: also every multiple (64 x the rows' footprint).  out->d == nullptr: n too large.
+int vz_small_tables(vimz_ctx* c, vimz_bases* b, size_t offset, size_t n, bool with_mult, BaseTables* out);
 // MSM over device-resident scalars on the context's stream (caller holds c->mu and has set the device)
 int vz_msm_device(vimz_ctx* c, const vimz_bases* bases, size_t base_offset, const uint32_t* d_scalars, size_t n,
                   int scalars_mont, int window_bits, uint64_t out_xy[8], int out_form, int split_ones = 0);

@@ -561,24 +561,16 @@ int vimz_ivc_create(vimz_ctx* ctx, const vimz_circuit* step_circuit, const vimz_
     if ((e = hipEventCreate(&v->ev_b0)) != hipSuccess || (e = hipEventCreate(&v->ev_b1)) != hipSuccess) return fail("event");
     if ((e = hipEventCreateWithFlags(&v->ev_a, hipEventDisableTiming)) != hipSuccess) return fail("event"); }
   if (!getenv("VIMZ_DEBUG_NO_SMALL_TABLES")) {
+    // tables of the three fixed slices the per-step small MSMs run over (verifier wires and verifier rows of ck1, the head of ck2):
+    // rows 2^(7w)·P_i and every multiple of them, shared by all IVCs over these keys (vz_small_tables)
     const cb::Builder& b1 = v->circ1->build->b;
     const size_t sw = v->c1->step_wires, sc = v->c1->step_constraints, aw = v->c1->aug_wires();
-    auto make = [&](auto cv, const uint32_t* bases, size_t n, BaseTables* tb) {
-      typedef decltype(cv) C;
-      const int K = (C::Scalar::Params::BITS + SMALL_C) / SMALL_C;
-      if (!n || n > MSM_SMALL_MAX) return hipSuccess;
-      uint32_t* d = nullptr;
-      hipError_t ee = hipMalloc((void**)&d, 4 * (size_t)AFFINE_WORDS * n * K);
-      if (ee != hipSuccess) return ee;
-      v->owned.push_back(d);
-      if ((ee = build_tables<C>(ctx->stream, bases, n, SMALL_C, K, d)) != hipSuccess) return ee;
-      tb->d = d; tb->n_total = n; tb->offset = 0; tb->c = SMALL_C; tb->K = K;
-      return hipSuccess;
-    };
-    if ((e = make(BnG1{}, ck1->d + (size_t)AFFINE_WORDS * (sw - 1), aw - 2, &v->tb_aug)) != hipSuccess) return fail("window tables");
-    if ((e = make(BnG1{}, ck1->d + (size_t)AFFINE_WORDS * sc, b1.n_constraints() - sc, &v->tb_T1v)) != hipSuccess) return fail("window tables");
-    if ((e = make(Grumpkin{}, ck2->d, std::max<size_t>(nw2 - 3, nc2), &v->tb_ck2)) != hipSuccess) return fail("window tables");
-    if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return fail("window tables");
+    // (every multiple resident — k_msm_fixed, 1.46 GB per slice — is 18-40 % faster alone and SLOWER in a fold: its gathers sweep
+    //  the caches the large MSM's accumulation lives in; option VIMZ_IVC_MULT_TABLES=1)
+    const bool mult = getenv("VIMZ_IVC_MULT_TABLES") != nullptr && atoi(getenv("VIMZ_IVC_MULT_TABLES")) != 0;
+    if ((rc = vz_small_tables(ctx, const_cast<vimz_bases*>(ck1), sw - 1, aw - 2, mult, &v->tb_aug))) { lk.unlock(); vimz_ivc_free(v.release()); return rc; }
+    if ((rc = vz_small_tables(ctx, const_cast<vimz_bases*>(ck1), sc, b1.n_constraints() - sc, mult, &v->tb_T1v))) { lk.unlock(); vimz_ivc_free(v.release()); return rc; }
+    if ((rc = vz_small_tables(ctx, const_cast<vimz_bases*>(ck2), 0, std::max<size_t>(nw2 - 3, nc2), mult, &v->tb_ck2))) { lk.unlock(); vimz_ivc_free(v.release()); return rc; }
   }
   v->pin_res = 4 * (size_t)XYZZ_WORDS * MSM_MAX_WINDOWS;
   v->pin_totals = 5 * v->pin_res + 32 * (size_t)v->c1->aug_wires() + 32 * (size_t)nw2;

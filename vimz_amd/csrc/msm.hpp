@@ -601,6 +601,123 @@ __global__ void __launch_bounds__(64) k_msm_small_sum(const uint32_t* __restrict
   if (t == 0) store_xyzz(window_sums, w, sh[0]);
 }
 
+// ---- fixed-base small MSM: precomputed multiples, no buckets ---------------------------------------------------------------------------
+// The four small MSMs of an IVC step run over FIXED slices of the keys, and an MI355X has 288 GB: with every multiple
+// m·2^(7w)·P_i (m = 1..64) of a slice resident (1.46 GB per 7.7 k points) a signed digit selects its point and the MSM is the plain sum
+// of n·37 points — no digit sort, no bucket accumulation chains, no weighted bucket reduction (twelve dependent additions).  Depth:
+// three mixed additions per thread (four points each), the 256-leaf tree of a workgroup (nine four-lane rounds), the tree over a
+// window's ≤ 32 workgroup sums by the last workgroup of the window to arrive; the host adds the 37 window sums as before.
+constexpr uint32_t FIXED_PER_THREAD = 4, FIXED_CHUNK = 256 * FIXED_PER_THREAD, FIXED_MAXQ = 32;
+static_assert(MSM_SMALL_MAX <= (size_t)FIXED_CHUNK * FIXED_MAXQ, "a window's workgroup sums fit one tree");
+
+template <class F>
+__global__ void __launch_bounds__(256) k_build_multiples(const uint32_t* __restrict__ tables, size_t n, int K, uint32_t nm, uint32_t* __restrict__ mult) {
+  const size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x;       // (w, i)
+  if (g >= n * (size_t)K) return;
+  const Affine<F> B = load_affine<F>(tables, (uint32_t)g);
+  XYZZ<F> acc = from_affine(B);
+  uint32_t* dst = mult + (size_t)AFFINE_WORDS * (g * nm);
+  for (uint32_t m = 0; m < nm; m++) {
+    const Affine<F> a = to_affine(acc);
+    store_words20(dst + (size_t)AFFINE_WORDS * m, a.x, a.y);
+    add_mixed(acc, B);
+  }
+}
+template <class C>
+hipError_t build_multiples(hipStream_t stream, const uint32_t* d_tables, size_t n, int c, int K, uint32_t* d_mult) {
+  typedef typename C::Coord F;
+  if (!n) return hipSuccess;
+  if (n * (size_t)K >= (1u << 31)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_build_multiples<F>, dim3((unsigned)((n * (size_t)K + 255) / 256)), dim3(256), 0, stream, d_tables, n, K, 1u << (c - 1), d_mult);
+  return hipGetLastError();
+}
+
+// grid (Q, K): workgroup (q, w) sums the points selected by window w's digits of scalars [q·FIXED_CHUNK, (q+1)·FIXED_CHUNK).
+// A quad-lane level whose additions all sit in the lower waves is skipped by the waves above them (the shuffles are wave-wide, the
+// barriers workgroup-wide): the last five levels of a 256-leaf tree issue on one wave instead of four.
+template <class F, class Fd, class Fs>
+__device__ __forceinline__ void quad_level_lazy(XYZZ<F>* __restrict__ sh, uint32_t count, Fd dst, Fs src) {
+  const uint32_t e = threadIdx.x >> 2;
+  const bool active = e < count;
+  QuadRes<F> r; r.mode = 0;
+  uint32_t ia = 0;
+  if ((threadIdx.x & ~63u) < 4u * count) {            // wave-uniform
+    ia = active ? dst(e) : 0u;
+    const uint32_t ib = active ? src(e) : 0u;
+    r = quad_add_compute<F>(sh, ia, ib, active);
+  }
+  __syncthreads();
+  quad_add_store<F>(sh, ia, r);
+  __syncthreads();
+}
+
+template <class S, class F>
+__global__ void __launch_bounds__(256) k_msm_fixed(const uint32_t* __restrict__ mult, uint32_t tstride, const uint32_t* __restrict__ scalars, uint32_t n, int mont,
+                                                   uint32_t Q, uint32_t* __restrict__ partial /* K x Q */, uint32_t* __restrict__ done /* K counters */,
+                                                   uint32_t* __restrict__ window_sums) {
+  __shared__ XYZZ<F> sh[256];
+  __shared__ uint32_t s_ticket;
+  __builtin_amdgcn_s_setprio(3);
+  const uint32_t t = threadIdx.x, q = blockIdx.x, w = blockIdx.y;
+  constexpr uint32_t NM = SMALL_NBW;
+  // the four table entries of this thread are requested before the first of them is needed
+  Affine<F> pt[FIXED_PER_THREAD];
+  bool neg[FIXED_PER_THREAD], have[FIXED_PER_THREAD];
+#pragma unroll
+  for (int k = 0; k < (int)FIXED_PER_THREAD; k++) {
+    const uint32_t i = q * FIXED_CHUNK + t + 256u * k;
+    have[k] = false; neg[k] = false;
+    if (i < n) {
+      uint32_t sc[8];
+      if (load_scalar<S>(scalars, i, mont, 0, sc)) {
+        const int d = signed_digit(sc, SMALL_C, (int)w);
+        if (d) {
+          have[k] = true; neg[k] = d < 0;
+          const uint32_t m = (uint32_t)(d < 0 ? -d : d) - 1u;
+          const uint32_t* src = mult + (size_t)AFFINE_WORDS * (((size_t)w * tstride + i) * NM + m);
+          load_words20(src, pt[k].x, pt[k].y);
+        }
+      }
+    }
+  }
+  XYZZ<F> acc = XYZZ<F>::identity();
+#pragma unroll
+  for (int k = 0; k < (int)FIXED_PER_THREAD; k++) {
+    if (have[k]) {
+      if (neg[k] && !aff_is_identity(pt[k])) pt[k].y = F::neg(pt[k].y);
+      add_mixed(acc, pt[k]);
+    }
+  }
+  sh[t] = acc;
+  __syncthreads();
+  quad_level_lazy<F>(sh, 64, [](uint32_t e) { return e; }, [](uint32_t e) { return e + 128; });
+  quad_level_lazy<F>(sh, 64, [](uint32_t e) { return e + 64; }, [](uint32_t e) { return e + 192; });
+  for (uint32_t d = 64; d > 0; d >>= 1) quad_level_lazy<F>(sh, d, [](uint32_t e) { return e; }, [d](uint32_t e) { return e + d; });
+  if (Q == 1) { if (t == 0) store_xyzz(window_sums, w, sh[0]); return; }
+  // publish; the last workgroup of the window to arrive sums the Q workgroup sums (release: store, fence, barrier, agent-scope
+  // ticket; acquire: fence, agent-scope loads — as k_msm_small's chunk merge)
+  if (t == 0) store_xyzz(partial, (size_t)w * Q + q, sh[0]);
+  __threadfence();
+  __syncthreads();
+  if (t == 0) s_ticket = atomicAdd(&done[w], 1u);
+  __syncthreads();
+  if (s_ticket != Q - 1) return;
+  __threadfence();
+  if (t < FIXED_MAXQ) {
+    XYZZ<F> v = XYZZ<F>::identity();
+    if (t < Q) {
+      const uint32_t* src = partial + (size_t)XYZZ_WORDS * ((size_t)w * Q + t);
+      F* f[4] = {&v.X, &v.Y, &v.ZZ, &v.ZZZ};
+      for (int c4 = 0; c4 < 4; c4++) for (int i = 0; i < 9; i++) f[c4]->v[i] = __hip_atomic_load(src + COORD_WORDS * c4 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    sh[t] = v;
+  }
+  __syncthreads();
+  uint32_t top = 1; while (top < Q) top <<= 1;
+  for (uint32_t d = top >> 1; d > 0; d >>= 1) quad_level_lazy<F>(sh, d, [](uint32_t e) { return e; }, [d](uint32_t e) { return e + d; });
+  if (t == 0) { store_xyzz(window_sums, w, sh[0]); __hip_atomic_store(&done[w], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+}
+
 // ---- host driver ---------------------------------------------------------------------------------
 
 
@@ -715,6 +832,16 @@ hipError_t msm_launch(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_ba
     const uint32_t Q = (uint32_t)((n + SMALL_CHUNK - 1) / SMALL_CHUNK), chunk = (uint32_t)((n + Q - 1) / Q);
     uint32_t* done = reinterpret_cast<uint32_t*>(ws.small_buf);
     uint32_t* chunk_out = done + 128;
+    if (small_tb && tb->mult) {      // every multiple resident: the digits select their points (k_msm_fixed)
+      const uint32_t Qf = (uint32_t)((n + FIXED_CHUNK - 1) / FIXED_CHUNK);
+      if (ev) for (int i = 0; i < 4; i++) VZ_HIP_CHECK(hipEventRecord(ev[i], stream));
+      hipLaunchKernelGGL((k_msm_fixed<S, F>), dim3(Qf, ps.K), dim3(256), 0, stream, tb->mult + (size_t)AFFINE_WORDS * SMALL_NBW * tb->offset, (uint32_t)tb->n_total, d_scalars, (uint32_t)n,
+                         scalars_mont, Qf, chunk_out, done, direct ? reinterpret_cast<uint32_t*>(pinned_dst) : reinterpret_cast<uint32_t*>(ws.window_sums));
+      if (ev) for (int i = 4; i < 7; i++) VZ_HIP_CHECK(hipEventRecord(ev[i], stream));
+      VZ_HIP_CHECK(hipGetLastError());
+      if (!direct) VZ_HIP_CHECK(hipMemcpyAsync(pinned_dst, ws.window_sums, 4 * (size_t)XYZZ_WORDS * ps.K, hipMemcpyDeviceToHost, stream));
+      return hipSuccess;
+    }
     if (ev) for (int i = 0; i < 4; i++) VZ_HIP_CHECK(hipEventRecord(ev[i], stream));
     static const bool sum_kernel = getenv("VIMZ_DEBUG_SMALL_SUM_KERNEL") != nullptr;
     hipLaunchKernelGGL((k_msm_small<S, F>), dim3(ps.K, Q), dim3(SMALL_THREADS), 0, stream, d_bases, d_scalars, (uint32_t)n, scalars_mont, Q, chunk, chunk_out,

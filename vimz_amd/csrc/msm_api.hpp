@@ -49,7 +49,12 @@ constexpr size_t MSM_SMALL_MAX = (size_t)SMALL_CHUNK * SMALL_MAXQ;
 // Precomputed window tables of a commitment key: d[j][i] = 2^(c j) * P_i, affine internal form, row length n_total.
 // own != 0: every window keeps its own bucket set, as without tables — the tables only spare the host the Horner over the window sums
 // (the large-MSM default window, c = 11); own == 0: one bucket set shared by all windows (c = 13..16: fewer entries, deeper reduce).
-struct BaseTables { const uint32_t* d; size_t n_total; size_t offset; int c, K; int own = 0; };
+struct BaseTables {
+  const uint32_t* d; size_t n_total; size_t offset; int c, K; int own = 0;
+  // fused small path only: every multiple of the table rows — mult[(w·n_total + i)·2^(c−1) + (m−1)] = m·2^(c·w)·P_i, m = 1..2^(c−1) —
+  // so that a digit SELECTS its point: no buckets, no sort, the MSM is one sum (k_msm_fixed).  189 KB per base point at c = 7.
+  const uint32_t* mult = nullptr;
+};
 
 static inline MsmPlan msm_plan(size_t n, int scalar_bits, int c_override) {
   MsmPlan p;
@@ -146,6 +151,9 @@ hipError_t msm_launch(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_ba
                       const BaseTables* tb = nullptr);
 template <class C>
 hipError_t build_tables(hipStream_t stream, const uint32_t* d_bases, size_t n, int c, int K, uint32_t* d_tables);
+// d_mult[(w·n + i)·2^(c−1) + (m−1)] = m·d_tables[w][i] for m = 1..2^(c−1)  (n·K·2^(c−1) affine points)
+template <class C>
+hipError_t build_multiples(hipStream_t stream, const uint32_t* d_tables, size_t n, int c, int K, uint32_t* d_mult);
 template <class C>
 Affine<typename C::Base> msm_finish(const MsmPlan& pl, const void* pinned);
 template <class C>

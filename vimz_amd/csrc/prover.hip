@@ -12,6 +12,12 @@
 // Such accumulators of different row segments merge (vimz_prover_merge*): BASELINE.json north_star's sharding picture.
 #include "prover_internal.hpp"
 
+// (leaked on purpose: worker threads must not be joined from a static destructor while the library is being unloaded)
+HostPool& vz_shared_pool() {
+  static HostPool* pool = [] { const unsigned hw = usable_cpus(); return new HostPool(hw > 2 ? std::min(15u, hw - 2) : 0u); }();
+  return *pool;
+}
+
 extern "C" {
 
 void vimz_prover_free(vimz_prover* p) {
@@ -24,7 +30,6 @@ void vimz_prover_free(vimz_prover* p) {
     if (p->sH) { hipStreamSynchronize(p->sH); hipStreamDestroy(p->sH); }
     if (p->ev_head) hipEventDestroy(p->ev_head);
     if (p->ev_hash) hipEventDestroy(p->ev_hash);
-    p->pool.reset();
     p->wsH.release();
     if (p->stage_host) hipHostFree(p->stage_host);
     if (p->jobvals_host) hipHostFree(p->jobvals_host);
@@ -453,7 +458,41 @@ int vimz_prover_state_chain(vimz_prover* p, const uint64_t* z_start, const uint6
   for (uint32_t i = 0; i < p->len_z; i++) p->z_cur[i] = fe_from_canon(z_start + 4 * i);
   FoldJob job; job.step_inputs = step_inputs; job.nsteps = nsteps;
   int rc = VIMZ_OK;
-  if (nsteps) rc = fold_prepare(p, job);
+  // Short inputs: the row-hash chains on the host's thread pool (0.4 ms per chain of 17 permutations and core) instead of one
+  // Poseidon-chain latency of the GPU (≈10 ms whatever the row count) — the start states of a few short row segments that are
+  // about to be folded concurrently must not cost as much as folding them.
+  const cb::Builder& b = p->circuit->build->b;
+  size_t nA = 0, nE = 0; bool early = false;
+  for (auto& c : b.chains) { if (c.phase == 0) nA++; else if (c.phase != 1) nE++; }
+  for (auto& f : b.fops) if (f.early) early = true;
+  if (nsteps && nsteps <= 96 && p->head_eligible && nA && !nE && !early && head_rows_wanted()) {
+    const size_t jstride = p->n_jobs + p->n_fops;
+    std::vector<uint32_t> chainsA;
+    for (uint32_t c = 0; c < b.chains.size(); c++) if (b.chains[c].phase == 0) chainsA.push_back(c);
+    std::vector<Fe> jobvals(nsteps * jstride, Fe::zero());
+    const uint32_t priv0 = 1 + 2 * b.len_z;
+    vz_shared_pool().run(nsteps * chainsA.size(), [&](size_t task) {
+      const size_t r = task / chainsA.size();
+      const Chain& C = b.chains[chainsA[task % chainsA.size()]];
+      Fe prev = Fe::zero();
+      for (uint32_t k = 0; k < C.job_cnt; k++) {
+        const uint32_t j = C.job_off + k;
+        const HashJob& Jb = b.jobs[j];
+        Fe in[POSEIDON_MAX_T];
+        for (uint32_t i = 0; i + 1 < Jb.t; i++) {
+          const ValRef& ref = Jb.in[i];
+          if (ref.kind == REF_WIRE) in[i] = fe_from_canon(step_inputs + 4 * (r * p->n_priv + (ref.idx - priv0)));
+          else if (ref.kind == REF_JOB) in[i] = ref.idx + 1 == j ? prev : jobvals[r * jstride + ref.idx];
+          else in[i] = Fe::zero();
+        }
+        prev = cb::poseidon_hash(in, (int)Jb.t - 1);
+        jobvals[r * jstride + j] = prev;
+      }
+    });
+    job.zs.assign((nsteps + 1) * p->len_z, Fe::zero());
+    for (uint32_t i = 0; i < p->len_z; i++) job.zs[i] = p->z_cur[i];
+    host_state_chain(p, step_inputs, nsteps, jobvals.data(), jstride, job.zs);
+  } else if (nsteps) rc = fold_prepare(p, job);
   else job.zs = p->z_cur;
   p->z_cur = keep;
   if (rc) return rc;

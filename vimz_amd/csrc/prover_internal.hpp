@@ -84,8 +84,10 @@ struct HostPool {
       if (--active == 0) cv_done.notify_all();
     }
   }
+  std::mutex run_mu;       // one run at a time: callers of different provers queue up instead of oversubscribing the host's cores
   void run(size_t count, std::function<void(size_t)> f) {
     if (!count) return;
+    std::lock_guard<std::mutex> one(run_mu);
     std::unique_lock<std::mutex> lk(m);
     cv_done.wait(lk, [&] { return active == 0; });      // stragglers of the previous call have left drain(): fn / n may change
     fn = std::move(f); n = count; next = 0; done = 0; gen++;
@@ -97,6 +99,11 @@ struct HostPool {
       fprintf(stderr, "[vimz] host pool: %zu of %zu tasks done after 10 s (next %zu, active workers %zu)\n", done, n, next.load(), active);
   }
 };
+
+// ONE pool per process (defined in prover.hip), shared by every prover: the GPU boxes grant a process 16 CPUs, every IVC keeps about
+// three threads busy while it folds, and three concurrent segments with a pool of fourteen workers each — all evaluating head
+// batches at once in a short fold call — got the whole process throttled (20-row windows: 550 to 780 steps/s from run to run).
+HostPool& vz_shared_pool();
 
 enum { PH_WITNESS = 0, PH_ZCHAIN, PH_SPMV, PH_MSM_W, PH_CROSS, PH_MSM_T, PH_RO, PH_FOLD, PH_HOST_EC, PH_COUNT };
 
@@ -153,7 +160,6 @@ struct vimz_prover {
   Fe* stage_host = nullptr; Fe* jobvals_host = nullptr; Fe* zs_host = nullptr;   // pinned
   uint32_t *stage_d = nullptr, *jobvals_d = nullptr;
   size_t head_rows_cap = 0;
-  std::unique_ptr<HostPool> pool;
   bool head_eligible = false;
   // per fold call: all private inputs, all IVC states and all row hashes resident
   uint32_t *priv_all_d = nullptr, *zs_all_d = nullptr, *job_all_d = nullptr;
@@ -438,10 +444,6 @@ static int fold_head_batch(vimz_prover* p, FoldJob& J, size_t rows) {
     P_TRY(hipMalloc((void**)&p->jobvals_d, 32 * cap_rows * jstride));
     p->head_rows_cap = cap_rows;
   }
-  if (!p->pool) {
-    const unsigned hw = usable_cpus();
-    p->pool.reset(new HostPool(hw > 2 ? std::min(15u, hw - 2) : 0u));
-  }
   auto& bb = p->buf[0];
   hipStream_t sh = p->sH;
   // the state-independent GPU part of these rows starts now, under the host's Poseidon work
@@ -458,7 +460,7 @@ static int fold_head_batch(vimz_prover* p, FoldJob& J, size_t rows) {
   memset(jobvals, 0, 32 * rows * jstride);
   const uint64_t* inputs = J.step_inputs;
   const uint32_t priv0 = 1 + 2 * b.len_z;
-  p->pool->run(rows * chainsA.size(), [&](size_t task) {
+  vz_shared_pool().run(rows * chainsA.size(), [&](size_t task) {
     const size_t r = task / chainsA.size();
     const Chain& C = b.chains[chainsA[task % chainsA.size()]];
     Fe prev = Fe::zero();

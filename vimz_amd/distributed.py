@@ -91,6 +91,125 @@ def ivc_segments(ivcs, step_inputs, z0):
     return [(ivcs[i], step_inputs[bounds[i][0]:bounds[i][1]], starts[i]) for i in range(S)]
 
 
+def _ints(limbs):
+    return [int(a[0]) | int(a[1]) << 64 | int(a[2]) << 128 | int(a[3]) << 192 for a in np.asarray(limbs)]
+
+
+def fold_segments_merged(ivcs, step_inputs, z0, timings=None, merged_cls=None):
+    """ONE proof of all rows from state z0 on one GPU: len(ivcs) contiguous row segments, each folded as a Nova IVC by its own prover
+    (own context = own streams, own host thread), then merged in row order (vimz_ivc_merge: out-of-circuit NIFS on both curves).
+    Segment j starts at the state segment j-1 ends in; that state comes from the hash-only chain over segment j-1's rows, computed by
+    prover j on ITS context while the earlier segments are already folding (so the chains cost a staggered start, not a serial
+    prologue).  Returns the MergedProof (its verifier key is ivcs[0]: keep the IVCs open while it is in use).
+    timings (optional dict): state_chain_s (host view, summed), merge_s."""
+    import time
+    from concurrent.futures import ThreadPoolExecutor
+    if merged_cls is None:
+        from .hip import MergedProof as merged_cls
+    MergedProof = merged_cls
+    n = len(step_inputs)
+    used = [j for j, (lo, hi) in enumerate(segment_bounds(n, len(ivcs))) if hi > lo]
+    bounds = segment_bounds(n, len(used))
+    t_chain = 0.0
+    z = [int(x) for x in z0]
+    with ThreadPoolExecutor(max(1, len(used))) as ex:
+        futs = []
+        for k, j in enumerate(used):
+            lo, hi = bounds[k]
+            if k > 0:
+                t0 = time.time()
+                plo, phi = bounds[k - 1]
+                z = _ints(ivcs[j].state_chain(z, step_inputs[plo:phi])[-1])
+                t_chain += time.time() - t0
+            ivcs[j].reset(z)
+            futs.append(ex.submit(ivcs[j].fold, step_inputs[lo:hi]))
+        for f in futs:
+            f.result()
+    # (merging segment k while later segments still fold measured worse: the merge's allocations and its large MSM on a
+    #  high-priority stream stall the chains that are still running — 575-680 against 780 steps/s in a 20-row window)
+    t0 = time.time()
+    merged = MergedProof(ivcs[used[0]])
+    try:
+        for j in used[1:]:
+            merged.merge(ivcs[j])
+    except Exception:
+        merged.close()
+        raise
+    t_merge = time.time() - t0
+    if timings is not None:
+        timings["state_chain_s"] = timings.get("state_chain_s", 0.0) + t_chain
+        timings["merge_s"] = timings.get("merge_s", 0.0) + t_merge
+    return merged
+
+
+def prove_sharded(ivcs, step_inputs, z0, rank=0, world=1, dist=None, timings=None, merged_cls=None, shm_prefix=None):
+    """ONE proof object of all rows from z0 over `world` ranks (one process per GPU; BASELINE.json north_star: "independent row-folds
+    shard embarrassingly across the 8 GPUs ... host-side sequential final fold; no RCCL collectives needed").  Rank r proves the r-th
+    contiguous run of rows with fold_segments_merged (len(ivcs) concurrent segments on its GPU); the runs' start states come from ONE
+    hash-only chain on rank 0, scattered; the ranks' merged proofs travel as bytes (gloo gather, or node-local shared memory when
+    shm_prefix is given) and rank 0 folds them in row order (vimz_ivc_merge_merged).  Returns the proof on rank 0, None elsewhere.
+    timings: state_chain_s (rank 0's chain + scatter, plus the local segments' chains), merge_s, final_fold_s."""
+    import os
+    import time
+    if merged_cls is None:
+        from .hip import MergedProof as merged_cls
+    n = len(step_inputs)
+    bounds = segment_bounds(n, world)
+    z_start = [int(x) for x in z0]
+    if world > 1:
+        t0 = time.time()
+        starts = [None] * world
+        if rank == 0:
+            z = starts[0] = z_start
+            for r in range(1, world):
+                lo, hi = bounds[r - 1]
+                if hi > lo:
+                    z = _ints(ivcs[0].state_chain(z, step_inputs[lo:hi])[-1])
+                starts[r] = z
+        out = [None]
+        dist.scatter_object_list(out, starts if rank == 0 else None, src=0)
+        z_start = out[0]
+        if timings is not None:
+            timings["state_chain_s"] = timings.get("state_chain_s", 0.0) + time.time() - t0
+    lo, hi = bounds[rank]
+    proof = fold_segments_merged(ivcs, step_inputs[lo:hi], z_start, timings, merged_cls) if hi > lo else None
+    if world == 1:
+        return proof
+    dist.barrier()                      # (every rank has its proof: what follows is the final fold alone, not the wait for the slowest rank)
+    t0 = time.time()
+    blob = np.asarray(proof.save()) if (proof is not None and rank > 0) else None
+    if shm_prefix:
+        if blob is not None:
+            blob.tofile(f"{shm_prefix}{rank}")
+        dist.barrier()
+        blobs = [None] + [np.fromfile(f"{shm_prefix}{r}", dtype=np.uint8) if os.path.exists(f"{shm_prefix}{r}") else None for r in range(1, world)] if rank == 0 else None
+    else:
+        blobs = [None] * world if rank == 0 else None
+        dist.gather_object(blob.tobytes() if blob is not None else None, blobs, dst=0)
+    if rank != 0:
+        if proof is not None:
+            proof.close()
+        if shm_prefix:
+            dist.barrier()              # (rank 0 has read the files)
+            if blob is not None:
+                os.unlink(f"{shm_prefix}{rank}")
+        return None
+    for r in range(1, world):           # host-side sequential final fold, in row order
+        if blobs[r] is None:
+            continue
+        other = merged_cls.load(ivcs[0], np.frombuffer(blobs[r], dtype=np.uint8) if isinstance(blobs[r], (bytes, bytearray)) else blobs[r])
+        if proof is None:
+            proof = other
+        else:
+            proof.merge(other)
+            other.close()
+    if shm_prefix:
+        dist.barrier()
+    if timings is not None:
+        timings["final_fold_s"] = timings.get("final_fold_s", 0.0) + time.time() - t0
+    return proof
+
+
 def fold_concurrently(jobs):
     """jobs: [(ivc, rows)] folded from one host thread each (ctypes releases the GIL; every IVC has its own context = streams).
     A single IVC alternates between host work (the verifier circuits' witnesses) and GPU work; several of them interleave."""
