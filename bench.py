@@ -120,15 +120,27 @@ def _ints(limbs):
     return [int(a[0]) | int(a[1]) << 64 | int(a[2]) << 128 | int(a[3]) << 192 for a in limbs]
 
 
+def _kernel_source_sha():
+    """sha256[:16] of the MSM kernels' source: profiles/pmc_traffic.json records it with every entry, so a counter figure measured on
+    other kernel code is flagged stale instead of being quoted as current."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("msm.hpp", "ec.hpp", "fp29.hpp"):
+        with open(os.path.join(ROOT, "vimz_amd", "csrc", f), "rb") as fp:
+            h.update(fp.read())
+    return h.hexdigest()[:16]
+
+
 def _pmc_traffic(key):
     """HBM bytes per launch of the roofline kernel from SEPARATE rocprofv3 --pmc passes of this command (the counters cannot be
-    read from inside the process): profiles/pmc_traffic.json, refreshed by tools/refresh_profiles.sh; the entry names its run."""
+    read from inside the process): profiles/pmc_traffic.json, written by tools/update_pmc_traffic.py from tools/refresh_profiles.sh's
+    passes; the entry names its run.  Returns (bytes, source, stale): stale = the kernels' source has changed since the passes."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fp:
             e = json.load(fp).get(key, {})
-        return e.get("hbm_bytes_per_launch"), e.get("source")
+        return e.get("hbm_bytes_per_launch"), e.get("source"), (e.get("kernel_source_sha") != _kernel_source_sha()) if e else None
     except OSError:
-        return None, None
+        return None, None, None
 
 
 def main_ivc(args, rank, world, dist, torch, ctxs, circuit, params, steps_all, glob, lo, hi, mine, z0, t_setup):
@@ -262,7 +274,31 @@ def main_ivc(args, rank, world, dist, torch, ctxs, circuit, params, steps_all, g
             alone_ms = sorted(ms[1:])[len(ms[1:]) // 2]
         except Exception as e:                          # informational only
             print(f"[bench] isolated k_accum measurement skipped: {e}", file=sys.stderr)
-        traffic, traffic_src = _pmc_traffic(f"{args.transformation}_step_{args.resolution}_ivc")
+        # the kernel on a step's CRITICAL chain: the fused small MSM (four per step over the verifier circuits' 7.7 k wires / rows),
+        # alone on the GPU over dense scalars of that size (in a fold it runs under the bulk kernels: profiles/ has the in-bench trace)
+        small = None
+        try:
+            n_s = info["verifier_wires"] - 2
+            rs = np.random.default_rng(5)
+            dense = rs.integers(0, 1 << 63, size=(n_s, 4), dtype=np.uint64); dense[:, 3] &= np.uint64((1 << 60) - 1)
+            vec = ctxs[0].vec_from_host(_lib.FIELD_BN254_FR, dense)
+            ctxs[0].set_profiling(True)
+            ms = []
+            for _ in range(9):
+                ctxs[0].msm_vec(params.ck, vec, base_offset=info["step_wires"] - 1)
+                ms.append(ctxs[0].msm_last_profile()["ms"]["accumulate"])
+            ctxs[0].set_profiling(False)
+            vec.free()
+            sm = sorted(ms[1:])[len(ms[1:]) // 2]
+            k_win = 37
+            small = {"kernel": "k_msm_small (one launch: digits, LDS counting sort, sub-bucket sums, segment tree, chunk merge, weighted bucket reduction)",
+                     "points": n_s, "windows": k_win, "algorithmic_bytes_per_launch": 96.0 * n_s, "kernel_ms_alone_on_gpu": sm,
+                     "achieved": 96.0 * n_s / (sm * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": 96.0 * n_s / (sm * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                     "bucket_additions": n_s * k_win, "int_utilisation": n_s * k_win / (sm * 1e-3) / 1e9 / MIXED_ADD_PEAK_GOPS,
+                     "bound": "latency: ~25 dependent point additions at ~6 us a level on one wave per SIMD (DESIGN.md §4); four launches per step, two of them in series"}
+        except Exception as e:
+            print(f"[bench] isolated k_msm_small measurement skipped: {e}", file=sys.stderr)
+        traffic, traffic_src, traffic_stale = _pmc_traffic(f"{args.transformation}_step_{args.resolution}_ivc")
         n_w2, n_c2, nnz2 = info["secondary_wires"], info["secondary_constraints"], info["secondary_nnz"]
         step_bytes = sum(96 * w + 96 * c + 8 * z + 32 * w + 96 * c + 7 * 32 * c + 3 * 32 * w + 12 * 32 * c for w, c, z in ((n_w, n_c, nnz), (n_w2, n_c2, nnz2)))
         phases = {k: 1e3 * sum(p1[k][0] for p1 in prof1) / max(1, timed_rows) for k in prof1[0]}      # (reset() at the start of the timed proof zeroed the counters)
@@ -318,10 +354,11 @@ def main_ivc(args, rank, world, dist, torch, ctxs, circuit, params, steps_all, g
                                       "reference_cpu_server": {"keygen_s": 6.5, "fold_s": 371.7, "compress_s_sample_run": 13.0, "source": "README.md:52, sample-output.png"}},
             "published_reference": {"contrast_HD_steps_per_s_cpu_server": 1.94, "source": "README.md:52 (720 steps / 371.7 s)"},
             "phase_ms_per_step_per_proof": phases,
+            "roofline_critical_chain_kernel": small,
             "roofline": {"bound": "hbm", "kernel": "k_accum (bucket accumulation) of the primary MSM(T) launches over the step circuit's rows",
                          "measured": f"HIP events on the kernel's own stream over a second proof of {timed_rows} rows made the same way right after the timed region (events off while `value` is timed); that pass ran at {timed_rows / dt_prof:.1f} steps/s",
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": traffic_stale,
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": acc_ms, "launches": tot["calls"], "msm_gpu_ms": msm_ms,
                          "mixed_adds_per_launch": adds, "msm_phase_ms": {k: v / calls for k, v in tot["ms"].items()},
                          "int_utilisation": (adds / (acc_ms * 1e-3) / 1e9 / MIXED_ADD_PEAK_GOPS) if acc_ms else 0.0,
@@ -481,7 +518,7 @@ def main():
         alg_bytes = 96.0 * n_c                                     # 32 B scalar + 64 B affine base per point
         achieved = alg_bytes / (acc_ms * 1e-3) / 1e9 if acc_ms else 0.0
         adds = tot["entries"] / calls
-        traffic, traffic_src = _pmc_traffic(f"{args.transformation}_step_{args.resolution}")
+        traffic, traffic_src, traffic_stale = _pmc_traffic(f"{args.transformation}_step_{args.resolution}")
         step_bytes = 96 * n_w + 96 * n_c + 8 * nnz + 32 * n_w + 96 * n_c + 7 * 32 * n_c + 3 * 32 * n_w + 12 * 32 * n_c
         out = {
             "metric": "nova_folding_steps_per_sec",
@@ -505,7 +542,7 @@ def main():
             "published_reference": {"contrast_HD_steps_per_s_cpu_server": 1.94, "source": "README.md:52 (720 steps / 371.7 s)"},
             "phase_ms_per_step": {k: 1e3 * v["seconds"] / max(1, (args.steps + args.warmup)) for k, v in prof.items()},
             "roofline": {"bound": "hbm", "kernel": "k_accum (bucket accumulation) of the MSM(T) launches in the timed region", "achieved": achieved,
-                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
+                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": traffic_stale,
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": acc_ms, "launches": tot["calls"], "msm_gpu_ms": msm_ms,
                          "mixed_adds_per_launch": adds, "msm_phase_ms": {k: v / calls for k, v in tot["ms"].items()},
                          "int_utilisation": (adds / (acc_ms * 1e-3) / 1e9 / MIXED_ADD_PEAK_GOPS) if acc_ms else 0.0,

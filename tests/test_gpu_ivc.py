@@ -320,8 +320,8 @@ def test_proof_does_not_depend_on_the_schedule():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     variants = [{}, {"VIMZ_HEAD_ROWS": "0"}, {"VIMZ_HEAD_ROWS": "3"}, {"VIMZ_DEBUG_NO_S2": "1"}, {"VIMZ_DEBUG_NO_SMALL_TABLES": "1"}, {"VIMZ_IVC_MULT_TABLES": "1"}, {"VIMZ_DEBUG_NO_SMALL_MSM": "1"},
-                {"VIMZ_DEBUG_SMALL_SUM_KERNEL": "1", "VIMZ_AUG_NO_THREADS": "1"}, {"VIMZ_DEBUG_SORT_BLOCKS": "256", "VIMZ_DEBUG_COMBINE_LANE_BITS": "4"},
-                {"VIMZ_IVC_LOOKAHEAD": "1"}, {"VIMZ_DEBUG_LAUNCHER": "1", "VIMZ_DEBUG_MSM_SUB": "8"}, {"VIMZ_DEBUG_COPY_SUMS": "1", "VIMZ_DEBUG_LATE_FOLDS": "1"}]
+                {"VIMZ_DEBUG_SMALL_SUM_KERNEL": "1", "VIMZ_AUG_NO_THREADS": "1"}, {"VIMZ_TUNE": "sort_blocks=256,combine_lane_bits=4"},
+                {"VIMZ_IVC_LOOKAHEAD": "1"}, {"VIMZ_TUNE": "sort_blocks=40,combine_lane_bits=2", "VIMZ_DEBUG_CHECK_MSM": "1"}]
     # (the lookahead also with batches of two and three rows and no host-evaluated head: every way a row two steps ahead can fall into
     #  the same batch, the next one, or not exist)
     variants += [{"VIMZ_IVC_LOOKAHEAD": "1", "VIMZ_HEAD_ROWS": "0", "_batch": "2"}, {"VIMZ_IVC_LOOKAHEAD": "1", "VIMZ_HEAD_ROWS": "0", "_batch": "3"}]

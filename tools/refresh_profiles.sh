@@ -1,41 +1,73 @@
 #!/bin/bash
 # Regenerates the measurement set under gpurun_out/refresh/ on the GPU box (copy what is to be judged into profiles/):
 #   the driver-style bench line and the long-window one, rocprofv3 kernel stats + the k_accum split of the same command, the
-#   FETCH_SIZE / WRITE_SIZE counter passes (separate runs, counters only) summarised per kernel, whole-image runs and the bench
-#   windows of the other configurations.   usage: tools/refresh_profiles.sh [round tag, default r02]
+#   FETCH_SIZE / WRITE_SIZE counter passes (separate runs, counters only) summarised per kernel — for the HD headline and for the
+#   4K / 8K shapes —, whole-image runs, the bench windows of the other configurations, the N > 1 lines on the one GPU of the box.
+#   usage: tools/refresh_profiles.sh [round tag, default r03] [parts: all | bench | rocprof | pmc | e2e | configs | ranks]
 set -u
-R=${1:-r02}
+R=${1:-r03}
+PARTS=${2:-all}
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/refresh; rm -rf $O; mkdir -p $O
-T="timeout 600"
-$T python3 bench.py --steps 20 --warmup 5 > $O/${R}_bench_driver_window.json 2> $O/bench.err
-$T python3 bench.py > $O/${R}_bench.json 2>> $O/bench.err
-$T python3 bench.py --mode accumulator > $O/${R}_bench_accumulator.json 2>> $O/bench.err
-$T rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python3 bench.py --no-cpu-baseline --no-extras > $O/${R}_bench_under_rocprof.json 2> $O/rocprof.err
-cp $(find $O/kt -name "*kernel_stats.csv" | head -1) $O/${R}_bench_kernel_stats.csv
-python3 tools/split_kernel_trace.py $(find $O/kt -name "*kernel_trace.csv" | head -1) k_accum > $O/${R}_k_accum_split.txt
-python3 tools/trace_busy.py $(find $O/kt -name "*kernel_trace.csv" | head -1) > $O/${R}_trace_busy.txt 2>/dev/null
-rm -rf $O/kt
-for mode in ivc accumulator; do
-  extra=""; [ $mode = accumulator ] && extra="--mode accumulator"
-  $T rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pf -o pf -- python3 bench.py --no-cpu-baseline --no-extras --no-compress --steps 96 $extra > /dev/null 2>> $O/rocprof.err
-  $T rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pw -o pw -- python3 bench.py --no-cpu-baseline --no-extras --no-compress --steps 96 $extra > /dev/null 2>> $O/rocprof.err
-  python3 tools/pmc_summary.py $(find $O/pf -name "*counter_collection.csv" | head -1) $(find $O/pw -name "*counter_collection.csv" | head -1) $O/${R}_pmc_summary_$mode.json > $O/${R}_pmc_summary_$mode.txt
+O=gpurun_out/refresh; mkdir -p $O
+T="timeout 900"
+want() { [ "$PARTS" = all ] || echo "$PARTS" | grep -q "$1"; }
+if want bench; then
+  $T python3 bench.py --steps 20 --warmup 5 > $O/${R}_bench_driver_window.json 2> $O/bench.err
+  $T python3 bench.py > $O/${R}_bench.json 2>> $O/bench.err
+  $T python3 bench.py --segments 1 --no-cpu-baseline > $O/${R}_bench_one_chain.json 2>> $O/bench.err
+  $T python3 bench.py --mode accumulator --no-cpu-baseline > $O/${R}_bench_accumulator.json 2>> $O/bench.err
+  (python3 tools/small_msm_bench.py plain; python3 tools/small_msm_bench.py mult) > $O/${R}_small_msm.txt 2>/dev/null
+fi
+kstats() {   # kstats <tag> <bench args...>: rocprofv3 kernel trace + stats of one bench command
+  local tag=$1; shift
+  $T rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python3 bench.py --no-cpu-baseline --no-extras --no-compress "$@" > $O/${R}_bench_under_rocprof_$tag.json 2> $O/rocprof.err
+  cp $(find $O/kt -name "*kernel_stats.csv" | head -1) $O/${R}_kernel_stats_$tag.csv
+  python3 tools/split_kernel_trace.py $(find $O/kt -name "*kernel_trace.csv" | head -1) k_accum > $O/${R}_k_accum_split_$tag.txt
+  python3 tools/split_kernel_trace.py $(find $O/kt -name "*kernel_trace.csv" | head -1) k_msm_small > $O/${R}_k_msm_small_split_$tag.txt
+  python3 tools/trace_busy.py $(find $O/kt -name "*kernel_trace.csv" | head -1) > $O/${R}_trace_busy_$tag.txt 2>/dev/null
+  rm -rf $O/kt
+}
+if want rocprof; then
+  kstats HD
+  kstats HD_one_chain --segments 1
+  kstats 4K --transformation contrast --resolution 4K --steps 96 --warmup 12
+  kstats 8K --transformation resize --resolution 8K --steps 96 --warmup 12
+fi
+pmc() {      # pmc <tag> <bench args...>: FETCH_SIZE and WRITE_SIZE in separate passes (counters only)
+  local tag=$1; shift
+  $T rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pf -o pf -- python3 bench.py --no-cpu-baseline --no-extras --no-compress "$@" > /dev/null 2>> $O/rocprof.err
+  $T rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pw -o pw -- python3 bench.py --no-cpu-baseline --no-extras --no-compress "$@" > /dev/null 2>> $O/rocprof.err
+  python3 tools/pmc_summary.py $(find $O/pf -name "*counter_collection.csv" | head -1) $(find $O/pw -name "*counter_collection.csv" | head -1) $O/${R}_pmc_summary_$tag.json > $O/${R}_pmc_summary_$tag.txt
   rm -rf $O/pf $O/pw
-done
-# whole images the way `vimz -b nova-snark -f <t>` sequences them
-: > $O/${R}_e2e.jsonl
-for cfg in "contrast HD 1 ivc" "grayscale HD 1 ivc" "blur HD 1 ivc" "crop HD 1 ivc" "contrast 4K 1 ivc" "resize 8K 1 ivc" "contrast HD 3 ivc" "contrast HD 2 accumulator"; do
-  timeout 600 python3 tools/e2e.py $cfg 2>/dev/null | tail -1 >> $O/${R}_e2e.jsonl
-done
-# bench windows of the other BASELINE.json configurations
-: > $O/${R}_configs.jsonl
-run() { timeout 900 python3 bench.py --no-cpu-baseline --no-extras "$@" 2>/dev/null | tail -1 >> $O/${R}_configs.jsonl; }
-run --transformation grayscale --resolution HD
-run --transformation crop --resolution HD --steps 192
-run --transformation contrast --resolution 4K --steps 192
-run --transformation resize --resolution 8K --steps 192
-run --transformation brightness --resolution 4K --steps 96
-run --transformation sharpness --resolution 4K --steps 96
-run --transformation blur --resolution 4K --steps 96
+}
+if want pmc; then
+  pmc ivc --steps 96
+  pmc accumulator --steps 96 --mode accumulator
+  pmc ivc_4K --transformation contrast --resolution 4K --steps 48 --warmup 12
+  pmc ivc_8K --transformation resize --resolution 8K --steps 48 --warmup 12
+fi
+if want e2e; then      # whole images the way `vimz -b nova-snark -f <t>` sequences them
+  : > $O/${R}_e2e.jsonl
+  for cfg in "contrast HD 3 ivc" "contrast HD 1 ivc" "grayscale HD 3 ivc" "blur HD 3 ivc" "crop HD 3 ivc" "contrast 4K 3 ivc" "contrast 4K 1 ivc" "resize 8K 3 ivc" "resize 8K 1 ivc" "contrast HD 2 accumulator"; do
+    timeout 900 python3 tools/e2e.py $cfg 2>/dev/null | tail -1 >> $O/${R}_e2e.jsonl
+  done
+fi
+if want configs; then  # bench windows of the other BASELINE.json configurations
+  : > $O/${R}_configs.jsonl
+  run() { timeout 900 python3 bench.py --no-cpu-baseline --no-extras "$@" 2>/dev/null | tail -1 >> $O/${R}_configs.jsonl; }
+  run --transformation grayscale --resolution HD
+  run --transformation crop --resolution HD --steps 192
+  run --transformation contrast --resolution 4K --steps 192
+  run --transformation resize --resolution 8K --steps 192
+  run --transformation brightness --resolution 4K --steps 96
+  run --transformation sharpness --resolution 4K --steps 96
+  run --transformation blur --resolution 4K --steps 96
+fi
+if want ranks; then    # N > 1 on the one GPU of the box: ONE object out of two ranks' segments; the proof set of BASELINE config 5
+  TR="timeout 1200 python3 -m torch.distributed.run --nnodes=1 --master-addr 127.0.0.1"
+  $TR --nproc-per-node 2 --master-port 29621 bench.py --gpus 2 --no-cpu-baseline > $O/${R}_bench_2ranks_on_1gpu_ivc.json 2> $O/ranks.err
+  $TR --nproc-per-node 2 --master-port 29622 bench.py --gpus 2 --no-cpu-baseline --segments 1 > $O/${R}_bench_2ranks_on_1gpu_ivc_one_chain_each.json 2>> $O/ranks.err
+  $TR --nproc-per-node 2 --master-port 29623 bench.py --gpus 2 --no-cpu-baseline --mode accumulator > $O/${R}_bench_2ranks_on_1gpu_accumulator.json 2>> $O/ranks.err
+  $TR --nproc-per-node 4 --master-port 29624 bench.py --gpus 4 --no-cpu-baseline --no-compress --proof-set contrast,brightness,sharpness,blur --resolution 4K --steps 48 --warmup 8 --segments 1 > $O/${R}_bench_proof_set_4K_4ranks_on_1gpu.json 2>> $O/ranks.err
+fi
 ls -la $O

@@ -85,7 +85,6 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
 
   // ---- the step rows' cross term and its commitment (the one large MSM of a step), on stream 3 ------------------------------------
   // (a helper thread for these launches measured no gain once the producer had its issuer thread, and costs a spinning core)
-  static const bool use_launcher = getenv("VIMZ_DEBUG_LAUNCHER") != nullptr;
   typedef vimz_prover::BatchBuf BufRef;
   // commitment to the vector of slot `par` (base-range split: the first share stays here, helper h commits to rows [off_h, off_h + n_h)
   // with its replica of the key)
@@ -224,7 +223,7 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
       // ---- fresh primary instance: upload the verifier wires, finish (A,B,C)·z and the commitment ---------------------------------
       memcpy(pin_aug1, aug1.data(), 32 * aw1);
       P_TRY(hipStreamWaitEvent(s, bb.ev[r], 0));
-      P_TRY(hipMemcpyAsync(Zi + 8 * sw, pin_aug1, 32 * aw1, hipMemcpyHostToDevice, s));
+      P_TRY(upload_pinned(s, Zi + 8 * sw, pin_aug1, 32 * aw1));
       // the commitment to the verifier wires needs the upload only: it starts first, on stream 2
       P_TRY(hipEventRecord(v->ev_fork, s));
       P_TRY(hipStreamWaitEvent(v->s2, v->ev_fork, 0));
@@ -358,8 +357,7 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
       // step rows and its commitment: the longest dependent chain of a step — is queued from INSIDE the circuit's evaluation, when the
       // challenge and everything that depends on nothing else are done and the thread would wait for the two scalar-multiplication
       // chains (AugCircuit::on_challenge): the large MSM starts ≈0.1 ms earlier than after witness() returns.
-      int launcher_rc = VIMZ_OK, hook_rc = VIMZ_OK; bool hook_ran = false; FoldArgs fa{};
-      struct WaitGuard { aug::Worker* w = nullptr; ~WaitGuard() { if (w) w->wait(); } } launching;      // (an early return must not leave the helper with this frame)
+      int hook_rc = VIMZ_OK; bool hook_ran = false; FoldArgs fa{};
       auto queue_folds = [&](const uint32_t* rho_low) -> int {
         const Fe rho1 = rho_element<Fe>(rho_low);
         // the rows whose step rows' cross terms come next: row i+1 (unless a lookahead produced its cross term already) and, one whole
@@ -390,19 +388,14 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
         f.x1[3] = p->BZ + 8 * sc; f.x2[3] = bz + 8 * sc; f.n[3] = nc - sc;
         f.x1[4] = p->CZ + 8 * sc; f.x2[4] = cz + 8 * sc; f.n[4] = nc - sc;
         v->u1_run = Fe::add(v->u1_run, rho1);
-        if (use_launcher) {
-          if (!v->launcher) v->launcher.reset(new aug::Worker());
-          v->launcher->start([&] { if (hipSetDevice(ctx->device) != hipSuccess) { launcher_rc = VIMZ_ERR_HIP; return; } launcher_rc = launch_fold_and_cross(fa); });
-          launching.w = v->launcher.get();
-        } else if ((rc2 = launch_fold_and_cross(fa))) return rc2;
+        if ((rc2 = launch_fold_and_cross(fa))) return rc2;
         // on stream 2, idle until the secondary witness is uploaded: this pass overlaps that upload instead of preceding it
         // (everything it reads is complete — the host has waited for all three streams)
         hipLaunchKernelGGL(k_fold5<Fr>, dim3(512), dim3(256), 0, v->s2, f, rho1);
         P_TRY(hipEventRecord(v->ev_fold, v->s2));  // the verifier rows of the next step may start here
         return VIMZ_OK;
       };
-      static const bool early_folds = getenv("VIMZ_DEBUG_LATE_FOLDS") == nullptr;
-      if (early_folds) v->c2.on_challenge = [&](const uint32_t* rho_low) { hook_ran = true; hook_rc = queue_folds(rho_low); };
+      v->c2.on_challenge = [&](const uint32_t* rho_low) { hook_ran = true; hook_rc = queue_folds(rho_low); };
       std::vector<Fq> aug2;
       AugOut<BnFq> o2 = v->c2.witness(in2, &zero_q, &zero_q, aug2, &bad);
       v->c2.on_challenge = nullptr;
@@ -420,7 +413,7 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
         w2[0] = Fq::one(); w2[1] = zero_q; w2[2] = zero_q;
         memcpy(w2 + 3, aug2.data(), 32 * aug2.size());
         if (ctx->profiling) P_TRY(hipEventRecord(v->ev_b0, s));
-        P_TRY(hipMemcpyAsync(S.z2, pin_w2, 32 * (size_t)S.n_w, hipMemcpyHostToDevice, s));
+        P_TRY(upload_pinned(s, S.z2, pin_w2, 32 * (size_t)S.n_w));
         P_TRY(hipEventRecord(v->ev_fork, s));
         P_TRY(hipStreamWaitEvent(v->s2, v->ev_fork, 0));
         P_TRY(msm_launch<Grumpkin>(v->s2, v->ws2, v->ck2->d, S.z2 + 8, S.n_w - 3, 1, 0, v->pin + 2 * v->pin_res, &v->plan_W2, nullptr, 0, v->tb_ck2.d ? &v->tb_ck2 : nullptr));
@@ -434,7 +427,6 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
         v->u2.x0 = cross_field<Fe>(o2.x0); v->u2.x1 = cross_field<Fe>(o2.x1);
         v->pending_sec = true;
       }
-      if (launching.w) { launching.w->wait(); launching.w = nullptr; if (launcher_rc) return launcher_rc; }
       v->rho_prev = rho_element<Fe>(o2.rho_low); memcpy(v->rho_prev_low, o2.rho_low, sizeof(v->rho_prev_low));
       v->ph_s[IP_LAUNCH] += now_s() - t0;
       v->i++; p->steps++;
@@ -554,7 +546,7 @@ int vimz_ivc_create(vimz_ctx* ctx, const vimz_circuit* step_circuit, const vimz_
     if (getenv("VIMZ_DEBUG_NO_S2")) v->s2 = ctx->stream;
     else if ((e = hipStreamCreateWithPriority(&v->s2, hipStreamNonBlocking, hi)) != hipSuccess) return fail("stream");
     if (getenv("VIMZ_DEBUG_NO_S2")) v->s3 = ctx->stream;
-    else if ((e = hipStreamCreateWithPriority(&v->s3, hipStreamNonBlocking, getenv("VIMZ_DEBUG_S3_PRIO") ? atoi(getenv("VIMZ_DEBUG_S3_PRIO")) : (lo + hi) / 2)) != hipSuccess) return fail("stream");
+    else if ((e = hipStreamCreateWithPriority(&v->s3, hipStreamNonBlocking, (lo + hi) / 2)) != hipSuccess) return fail("stream");
     if ((e = hipEventCreateWithFlags(&v->ev_fork, hipEventDisableTiming)) != hipSuccess) return fail("event");
     if ((e = hipEventCreateWithFlags(&v->ev_fold, hipEventDisableTiming)) != hipSuccess) return fail("event");
     if ((e = hipEventCreateWithFlags(&v->ev_fused, hipEventDisableTiming)) != hipSuccess) return fail("event");

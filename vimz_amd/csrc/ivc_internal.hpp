@@ -70,7 +70,6 @@ struct vimz_ivc {
   bool broken = false;             // a step failed after its folds were queued (cannot happen with an honest witness): no further folds
   hipEvent_t ev_fused = nullptr; bool fused_recorded = false;      // the fused fold + cross term of the step rows on stream 3 (k_fold_cross)
   std::unique_ptr<aug::Worker> chain_w[2];                         // the two circuits' scalar-multiplication chains (they never run at the same time)
-  std::unique_ptr<aug::Worker> launcher;                           // queues the large MSM (a dozen launches) while the main thread queues the secondary half
   hipEvent_t ev_b0 = nullptr, ev_b1 = nullptr;   // profiling: GPU time of the secondary half on the main stream
   hipEvent_t ev_a = nullptr;                      // the primary half's results on the main stream are back
   // window tables (2^(7w)·P_i) of the three base slices the per-step small MSMs run over: verifier wires and verifier rows of

@@ -21,11 +21,30 @@
 // bit-identical run to run and to the CPU oracle.
 #pragma once
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include "msm_api.hpp"
 #include "ec_mem.hpp"
 
 namespace vz {
+
+// The two shape parameters of the large-MSM pipeline that are chosen from the input size can be pinned from the environment, ONE
+// variable read once:  VIMZ_TUNE="sort_blocks=256,combine_lane_bits=4"  (workgroups of the LDS counting sort; log2 of the lanes per
+// bucket in k_combine).  Results never depend on them — tests/test_gpu_ivc.py folds the same rows under other values and requires
+// the identical proof.  (The switches of rounds 1-2 whose A/B is settled — launcher thread, copied window sums, CU masks, stream
+// priorities, sub-bucket length, late folds, one producer stream — are gone; DESIGN.md §9 keeps what they measured.)
+struct MsmTuning { int sort_blocks = 0, combine_lane_bits = -1; };
+inline const MsmTuning& msm_tuning() {
+  static const MsmTuning t = [] {
+    MsmTuning r;
+    if (const char* e = getenv("VIMZ_TUNE")) {
+      if (const char* q = strstr(e, "sort_blocks=")) r.sort_blocks = atoi(q + 12);
+      if (const char* q = strstr(e, "combine_lane_bits=")) r.combine_lane_bits = atoi(q + 18);
+    }
+    return r;
+  }();
+  return t;
+}
 
 // ---- device helpers --------------------------------------------------------------------------
 
@@ -814,8 +833,8 @@ hipError_t msm_launch(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_ba
   typedef typename C::Scalar S;
   if (n == 0 || n >= (1u << 31)) return hipErrorInvalidValue;
   // The window sums go straight into the caller's pinned buffer (host memory the device can write): the copy that used to follow —
-  // a launch and a dependent hop between the last kernel and the host's wake-up — is gone.  (VIMZ_DEBUG_COPY_SUMS: the copy.)
-  static const bool direct = getenv("VIMZ_DEBUG_COPY_SUMS") == nullptr;
+  // a launch and a dependent hop between the last kernel and the host's wake-up — is gone.
+  constexpr bool direct = true;
   // tables made for the fused small path (window SMALL_C): its window sums then only need adding — no Horner on the host
   static const bool no_small = getenv("VIMZ_DEBUG_NO_SMALL_MSM") != nullptr;
   const bool small_fmt = tb && tb->d && tb->c == SMALL_C;             // (ignored, not an error, when the fused path is switched off)
@@ -864,8 +883,7 @@ hipError_t msm_launch(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_ba
   *plan_out = pl;
   const size_t entries = (size_t)pl.K * n;
   // small MSMs are latency-bound (one dependent addition ~ 6-10 us): shorter chains per thread, more threads
-  static const int sub_env = getenv("VIMZ_DEBUG_MSM_SUB") ? atoi(getenv("VIMZ_DEBUG_MSM_SUB")) : 0;
-  const uint32_t sub = n < (1u << 15) ? 8u : sub_env >= 4 && sub_env <= 64 ? (uint32_t)sub_env : (uint32_t)MSM_SUB;   // MSM_SUB for everything large
+  const uint32_t sub = n < (1u << 15) ? 8u : (uint32_t)MSM_SUB;   // MSM_SUB for everything large
   const size_t max_subs = entries / sub + pl.nb + 1;
   VZ_HIP_CHECK(ws.reserve(pl.nb, entries, max_subs));
   const int TB = 256;
@@ -879,7 +897,7 @@ hipError_t msm_launch(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_ba
     VZ_HIP_CHECK(hipMemsetAsync(ws.cursor, 0, 4 * (size_t)pl.nb, stream));
     VZ_HIP_CHECK(hipMemsetAsync(ws.heavy, 0, 4, stream));
   }
-  static const int sort_blocks_env = getenv("VIMZ_DEBUG_SORT_BLOCKS") ? atoi(getenv("VIMZ_DEBUG_SORT_BLOCKS")) : 0;
+  const int sort_blocks_env = msm_tuning().sort_blocks;
   // every sort workgroup zeroes, writes out and later re-reads all nb counters (96 KiB at the default window): with one workgroup
   // per CU at 305 k points each handled 1.2 k scalars for 24.5 k counters, and k_block_prefix walked 256 rows — fixed costs.
   // About 4 k scalars per workgroup (75 workgroups here) measured best: one proof 384 -> 394 steps/s, three 599 -> 614.
@@ -910,7 +928,7 @@ hipError_t msm_launch(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_ba
   // lanes up to ~24 partials (measured at 312 k dense points, 19 per bucket: 16 lanes 0.28 ms, 8: 0.155, 4: 0.137, 2: 0.117;
   // one lane and a heavy list of every bucket: 3.5 ms); buckets above 16 partials per lane go to the heavy list
   const size_t mean_parts = entries / sub / pl.nb + 1;
-  static const int lane_bits_env = getenv("VIMZ_DEBUG_COMBINE_LANE_BITS") ? atoi(getenv("VIMZ_DEBUG_COMBINE_LANE_BITS")) : -1;
+  const int lane_bits_env = msm_tuning().combine_lane_bits;
   const uint32_t lane_bits = lane_bits_env >= 0 ? (uint32_t)lane_bits_env : mean_parts > 96 ? 4u : mean_parts > 48 ? 3u : mean_parts > 24 ? 2u : 1u;
   const uint32_t heavy_min = 16u << lane_bits;
   hipLaunchKernelGGL(k_scan<MSM_SUB>, dim3(1), dim3(1024), 0, stream, ws.counts, pl.nb, ws.bucket_off, ws.sub_off, ws.totals, sub, ws.heavy, heavy_min, MsmWorkspace::HEAVY_CAP);

@@ -130,15 +130,8 @@ int vz_prover_create_layout(vimz_ctx* ctx, const vimz_circuit* circuit, const vi
       dalloc(&p->bad_d, 64) != hipSuccess)
     return fail_free("device allocation", e);
   { int lo = 0, hi = 0; hipDeviceGetStreamPriorityRange(&lo, &hi);
-    // experiment: VIMZ_DEBUG_SB_CUS=n restricts the producer's stream to n compute units (mask bits 0..n-1); such a stream has the
-    // default priority, so pair it with VIMZ_DEBUG_S3_PRIO=1
-    const int cus = getenv("VIMZ_DEBUG_SB_CUS") ? atoi(getenv("VIMZ_DEBUG_SB_CUS")) : 0;
-    if (cus > 0 && cus < 1024) {
-      uint32_t mask[32] = {};
-      for (int i = 0; i < cus; i++) mask[i >> 5] |= 1u << (i & 31);
-      if ((e = hipExtStreamCreateWithCUMask(&p->sB, 32, mask)) != hipSuccess) return fail_free("stream (CU mask)", e);
-    } else
-    if ((e = hipStreamCreateWithPriority(&p->sB, hipStreamNonBlocking, getenv("VIMZ_DEBUG_SB_PRIO") ? atoi(getenv("VIMZ_DEBUG_SB_PRIO")) : lo)) != hipSuccess) return fail_free("stream", e); }
+    // (the producer sits on the lowest of HIP's three priority levels; confining it to a CU mask instead measured no better: DESIGN.md §9)
+    if ((e = hipStreamCreateWithPriority(&p->sB, hipStreamNonBlocking, lo)) != hipSuccess) return fail_free("stream", e); }
   for (int k = 0; k < 2; k++) {
     auto& bb = p->buf[k];
     if (k == 0) { bb.Z = p->Z_d; bb.job_out = p->job_out_d; bb.status = p->status_d; }   // buffer 0 is shared with the witness hook

@@ -446,6 +446,8 @@ static int fold_head_batch(vimz_prover* p, FoldJob& J, size_t rows) {
   }
   auto& bb = p->buf[0];
   hipStream_t sh = p->sH;
+  static const bool dbg_t = getenv("VIMZ_DEBUG_TIMING") != nullptr;
+  const double th0 = now_s();
   // the state-independent GPU part of these rows starts now, under the host's Poseidon work
   P_TRY(hipStreamWaitEvent(sh, bb.wit_done, 0));          // (recorded by the caller behind the upload of the private inputs)
   P_TRY(hipMemsetAsync(bb.status, 0, 4 * rows, sh));
@@ -479,13 +481,16 @@ static int fold_head_batch(vimz_prover* p, FoldJob& J, size_t rows) {
       jobvals[r * jstride + j] = st[0];
     }
   });
+  const double th1 = now_s();
   // 2. the IVC state chain of these rows, with the wires of the state hashes
   host_state_chain(p, inputs, rows, jobvals, jstride, J.zs, 0, stage, stage_row, jobvals);
+  const double th2 = now_s();
   for (size_t i = 0; i < (rows + 1) * (size_t)p->len_z; i++) p->zs_host[i] = Fe::from_mont(J.zs[i]);
   // 3. upload, scatter, the rest of the witness, then per row (A,B,C)·z and the witness commitment
-  P_TRY(hipMemcpyAsync(p->zs_all_d, p->zs_host, 32 * (rows + 1) * (size_t)p->len_z, hipMemcpyHostToDevice, sh));
-  P_TRY(hipMemcpyAsync(p->stage_d, stage, 32 * rows * stage_row, hipMemcpyHostToDevice, sh));
-  P_TRY(hipMemcpyAsync(p->jobvals_d, jobvals, 32 * rows * jstride, hipMemcpyHostToDevice, sh));
+  P_TRY(upload_pinned(sh, p->zs_all_d, p->zs_host, 32 * (rows + 1) * (size_t)p->len_z));
+  P_TRY(upload_pinned(sh, p->stage_d, stage, 32 * rows * stage_row));
+  P_TRY(upload_pinned(sh, p->jobvals_d, jobvals, 32 * rows * jstride));
+  const double th3 = now_s();
   const unsigned R = (unsigned)rows;
   hipLaunchKernelGGL(k_wit_inputs, dim3(((1 + 2 * p->len_z + p->n_priv) + 255) / 256, R), dim3(256), 0, sh, W, (const uint32_t*)p->priv_all_d, (const uint32_t*)p->zs_all_d, bb.Z, 0u);
   for (uint32_t gI = 0; gI < W.n_groups; gI++)
@@ -493,8 +498,10 @@ static int fold_head_batch(vimz_prover* p, FoldJob& J, size_t rows) {
   if (p->n_jobs) hipLaunchKernelGGL(k_wit_scatter, dim3(p->n_jobs, R), dim3(128), 0, sh, W, p->job_stage_off_d, (const uint32_t*)p->stage_d, (uint32_t)stage_row, (const uint32_t*)p->jobvals_d, bb.Z, bb.job_out);
   if (p->n_fops) hipLaunchKernelGGL(k_wit_fops, dim3((R + 63) / 64), dim3(64), 0, sh, W, bb.Z, bb.job_out, (uint32_t)rows, 0u);
   P_TRY(hipGetLastError());
-  P_TRY(hipMemcpyAsync(bb.status_host, bb.status, 4 * rows, hipMemcpyDeviceToHost, sh));
+  const double th4 = now_s();
+  P_TRY(copy_pinned(sh, bb.status_host, bb.status, 4 * rows));
   P_TRY(hipEventRecord(bb.wit_done, sh));
+  const double th5 = now_s();
   for (size_t r = 0; r < rows; r++) {
     const uint32_t* Zi = bb.Z + 8 * r * nw;
     launch_spmv(p, sh, Zi, bb.az + 8 * r * nc, bb.bz + 8 * r * nc, bb.cz + 8 * r * nc, 1);
@@ -504,6 +511,7 @@ static int fold_head_batch(vimz_prover* p, FoldJob& J, size_t rows) {
     { int rc = fold_issue_d(p, J, 0, r, sh, p->wsH); if (rc) return rc; }
   }
   P_TRY(hipEventRecord(p->ev_head, sh));
+  if (dbg_t) fprintf(stderr, "[timing] head batch of %zu rows: launches + row-hash chains on the pool %.2f ms, state chain %.2f ms, uploads %.2f, witness launches %.2f, status copy + event %.2f, per-row spmv + msm launches %.2f ms\n", rows, 1e3 * (th1 - th0), 1e3 * (th2 - th1), 1e3 * (th3 - th2), 1e3 * (th4 - th3), 1e3 * (th5 - th4), 1e3 * (now_s() - th5));
   return VIMZ_OK;
 }
 
@@ -547,6 +555,7 @@ static int fold_prepare(vimz_prover* p, FoldJob& J, bool start_batch0 = false) {
   P_TRY(grow(p->retired, &p->job_all_d, &p->cap_job_all, 32 * nsteps * jstride, 32 * 1024 * jstride));
   P_TRY(hipMemcpyAsync(p->priv_all_d, J.step_inputs, 32 * nsteps * (size_t)p->n_priv, hipMemcpyHostToDevice, s));
   P_TRY(hipMemsetAsync(p->job_all_d, 0, 32 * nsteps * jstride, s));
+  { static const bool dbg_t = getenv("VIMZ_DEBUG_TIMING") != nullptr; if (dbg_t) fprintf(stderr, "[timing] prepare: buffers + upload of the inputs %.2f ms\n", 1e3 * (now_s() - t0)); }
   const bool plain = J.nA && !J.nE && !J.early_fops;           // no ahead-of-time witness pass needed (everything but crop)
   const size_t head = start_batch0 && plain && p->head_eligible ? std::min(std::min(head_rows_wanted(), B), nsteps) : 0;
   if (head) {
@@ -716,12 +725,12 @@ static int fold_issue(vimz_prover* p, const FoldJob& J, size_t k) {
     if (rc) return rc;
   }
   P_TRY(hipGetLastError());
-  P_TRY(hipMemcpyAsync(bb.status_host, bb.status, 4 * rows, hipMemcpyDeviceToHost, sb));
+  P_TRY(copy_pinned(sb, bb.status_host, bb.status, 4 * rows));
   P_TRY(hipEventRecord(bb.wit_done, sb));
   // Per row: the step rows of (A,B,C)·z, the commitment to the witness and (lookahead) the fresh x fresh commitment — a chain of some
   // twenty-five dependent launches, ≈1 ms (1.6 ms with the lookahead's) whatever the GPU has free.  In IVC mode the rows alternate
   // between the producer's stream and the head batch's (idle after the first rows of a call), each with its own MSM workspace.
-  const bool two = p->ivc && p->sH && p->sH != sb && !getenv_once("VIMZ_DEBUG_ONE_PRODUCER_STREAM");
+  const bool two = p->ivc && p->sH && p->sH != sb;
   if (two) P_TRY(hipStreamWaitEvent(p->sH, bb.wit_done, 0));
   for (size_t r = 0; r < rows; r++) {
     const uint32_t* Zi = bb.Z + 8 * r * nw;

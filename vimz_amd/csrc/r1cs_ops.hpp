@@ -217,6 +217,30 @@ __global__ void __launch_bounds__(256) k_axpy_inplace(size_t n, uint32_t* __rest
   VZ_GRID_STRIDE(i, n) store_fe(x1, i, F::add(load_fe<F>(x1, i), F::mul(r, load_fe<F>(x2, i))));
 }
 
+// Upload from PINNED host memory by a kernel that reads the host buffer over the link itself.  hipMemcpyAsync(pinned -> device) is
+// asynchronous on paper; with several contexts of one process folding at once the call itself was seen to block for 6-7 ms now and
+// then (the copy path's own queue), which in a 20-row window decides between 560 and 750 steps/s.  A kernel launch never takes that
+// path.  bytes must be a multiple of 16; the host buffer must stay unchanged until the stream has passed this point (as for a copy).
+static __global__ void __launch_bounds__(256) k_copy16(uint4* __restrict__ dst, const uint4* __restrict__ src, size_t n16) {
+  VZ_GRID_STRIDE(i, n16) dst[i] = src[i];
+}
+static __global__ void __launch_bounds__(256) k_copy4(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, size_t n4) {
+  VZ_GRID_STRIDE(i, n4) dst[i] = src[i];
+}
+// either direction: one side is device memory, the other pinned host memory (bytes a multiple of 4)
+static inline hipError_t copy_pinned(hipStream_t s, void* dst, const void* src, size_t bytes) {
+  if (!bytes) return hipSuccess;
+  if ((bytes & 15) || (((uintptr_t)dst | (uintptr_t)src) & 15)) {
+    if (bytes & 3) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_copy4, dim3((unsigned)std::min<size_t>(1024, (bytes / 4 + 255) / 256)), dim3(256), 0, s, (uint32_t*)dst, (const uint32_t*)src, bytes / 4);
+    return hipGetLastError();
+  }
+  const size_t n16 = bytes / 16;
+  hipLaunchKernelGGL(k_copy16, dim3((unsigned)std::min<size_t>(1024, (n16 + 255) / 256)), dim3(256), 0, s, (uint4*)dst, (const uint4*)src, n16);
+  return hipGetLastError();
+}
+static inline hipError_t upload_pinned(hipStream_t s, void* dst, const void* src_pinned, size_t bytes) { return copy_pinned(s, dst, src_pinned, bytes); }
+
 struct Fold5 { uint32_t* x1[5]; const uint32_t* x2[5]; size_t n[5]; };
 template <class F>
 __global__ void __launch_bounds__(256) k_fold5(Fold5 a, F r) {
