@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """profiles/pmc_traffic.json from the per-kernel summaries of tools/refresh_profiles.sh's counter passes: for each workload the
-k_accum launch class with the largest grid (the primary MSM(T) launches), its HBM bytes per launch, the command and the sha of the
+k_accum launch class that moves the most bytes (the per-step primary MSM(T) launches), its HBM bytes per launch, the command and the sha of the
 kernels' source at the time of the passes (bench.py flags the figure stale when that source changes).
 usage: update_pmc_traffic.py <round tag> <summary dir>      (e.g. r03 profiles)"""
 import json
@@ -29,7 +29,8 @@ def main():
         acc = {k: v for k, v in summ.items() if k.startswith("k_accum") and "grid=" in k}
         if not acc:
             continue
-        k = max(acc, key=lambda x: int(x.split("grid=")[1].rstrip("]")))
+        # the per-step MSM(T) launches: the launch class that moves the most bytes in all (the few larger launches are the merges')
+        k = max(acc, key=lambda x: acc[x]["launches"] * acc[x]["hbm_bytes_per_launch"])
         out[key] = {"kernel": k, "hbm_bytes_per_launch": acc[k]["hbm_bytes_per_launch"], "launches": acc[k]["launches"],
                     "method": f"rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `bench.py --no-cpu-baseline --no-extras --no-compress {cmd}` "
                               f"(tools/refresh_profiles.sh, round {tag}); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE halving, MI355X_MICROARCH.md §HBM); "
