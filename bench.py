@@ -392,7 +392,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--transformation", default="contrast")
     ap.add_argument("--resolution", default="HD")
-    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--batch", type=int, default=0, help="rows whose witnesses are generated together (0: folding.default_batch — 64 at HD, 128 for the 4K / 8K widths)")
     ap.add_argument("--segments", type=int, default=0, help="row segments folded concurrently on each GPU, own context + streams each, and merged into one proof (default: 3 in IVC mode, 2 accumulators)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -435,6 +435,8 @@ def main():
     ctx = ctxs[0]
     t_setup = time.time()
     circuit, params = folding.prepare_folding(ctx, args.transformation, args.resolution, window_tables=args.window_tables)
+    if args.batch <= 0:
+        args.batch = folding.default_batch(circuit)
     steps_all, z0 = build_inputs(args.transformation, args.resolution)
     n_rows = steps_all.shape[0]
     per_rank = args.warmup + (2 if args.mode == "ivc" else 1) * args.steps

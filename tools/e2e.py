@@ -2,7 +2,7 @@
 """End-to-end run of one transformation on the GPU, the way `vimz -b nova-snark -f <t>` sequences it
 (vimz/src/nova_snark_backend/mod.rs:22-80): prepare input -> prepare folding (circuit + key) -> fold every row -> verify.
 Prints the span times the reference logs ("Prepare input", "Prepare folding", "Fold input", "Verify folded proof").
-usage: e2e.py <transformation> <resolution> [segments] [ivc|accumulator] [proof file prefix]
+usage: e2e.py <transformation> <resolution> [segments] [ivc|accumulator] [proof file prefix or -] [witness batch]
 ivc (default): ONE proof object — the rows are proven as `segments` Nova IVCs of contiguous row segments folded concurrently and
 merged (vimz_ivc_merge), then compressed;
 accumulator: NIFS accumulators of the segments merged by a final fold."""
@@ -22,7 +22,8 @@ def main():
     t, res = sys.argv[1], sys.argv[2]
     S = int(sys.argv[3]) if len(sys.argv) > 3 else 3
     mode = sys.argv[4] if len(sys.argv) > 4 else "ivc"
-    save = sys.argv[5] if len(sys.argv) > 5 else None
+    save = sys.argv[5] if len(sys.argv) > 5 and sys.argv[5] != "-" else None
+    batch = int(sys.argv[6]) if len(sys.argv) > 6 else 0            # rows whose witnesses are generated together (0: folding.default_batch)
     spans = {}
     t0 = time.time()
     rows, z0 = bench.build_inputs(t, res)
@@ -30,9 +31,10 @@ def main():
     t0 = time.time()
     ctxs = [hip.Context(0) for _ in range(S)]
     circuit, params = folding.prepare_folding(ctxs[0], t, res)
+    batch = batch or folding.default_batch(circuit)
     if mode == "ivc":
         ck2 = params.secondary_key()
-        ivcs = [hip.IVC(c, circuit, params.ck, ck2, max_batch=64 if res == "HD" else 32) for c in ctxs]
+        ivcs = [hip.IVC(c, circuit, params.ck, ck2, max_batch=batch) for c in ctxs]
         spans["Prepare folding"] = time.time() - t0
         t0 = time.time()
         tm = {}
@@ -54,12 +56,12 @@ def main():
         spans["compressed proof bytes"] = int(len(blob))
         if save:
             proof.save().tofile(f"{save}.merged.bin")       # verify elsewhere: tools/verify_proof.py
-        print(json.dumps({"config": f"{t}_step_{res}", "mode": "ivc", "steps": n, "segments": S, "proof_objects": 1, "verified": ok, "spans_s": spans,
+        print(json.dumps({"config": f"{t}_step_{res}", "mode": "ivc", "steps": n, "segments": S, "witness_batch": batch, "proof_objects": 1, "verified": ok, "spans_s": spans,
                           "state_chain_s": tm.get("state_chain_s"), "merge_s": tm.get("merge_s"),
                           "steps_per_s": n / spans["Fold input"], "total_s": sum(v for k, v in spans.items() if not k.endswith("bytes")),
                           "final_state": [hex(z) for z in ze]}))
         return
-    provers = [hip.Prover(c, circuit, params.ck, max_batch=64 if res == "HD" else 32) for c in ctxs]
+    provers = [hip.Prover(c, circuit, params.ck, max_batch=batch) for c in ctxs]
     spans["Prepare folding"] = time.time() - t0
     t0 = time.time()
     merged = fold_local_segments(provers, rows, z0)

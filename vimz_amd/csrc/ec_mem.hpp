@@ -111,13 +111,21 @@ __device__ __forceinline__ void quad_add_store(XYZZ<F>* __restrict__ sh, uint32_
   else if (r.mode == 2) { if (q == 2) { A.X = r.c0; A.Y = r.c1; } else if (q == 3) { A.ZZ = r.c0; A.ZZZ = r.c1; } }
   else if (r.mode == 3 && q == 0) A = r.full;
 }
-// One level of `count` (<= 64) additions sh[dst(e)] += sh[src(e)] by a 256-thread workgroup, four lanes each.
+// One level of `count` (<= 64) additions sh[dst(e)] += sh[src(e)] by a 256-thread workgroup, four lanes each.  A wave none of whose
+// quads has an addition at this level skips the arithmetic (the shuffles are wave-wide, the barriers workgroup-wide): the last five
+// levels of a 256-leaf tree issue on one wave instead of four — the tails are issue-bound per SIMD and, with three proofs sharing
+// the GPU, every slot a waiting wave does not burn goes to another kernel.
 template <class F, class Fd, class Fs>
 __device__ __forceinline__ void quad_level(XYZZ<F>* __restrict__ sh, uint32_t count, Fd dst, Fs src) {
   const uint32_t e = threadIdx.x >> 2;
   const bool active = e < count;
-  const uint32_t ia = active ? dst(e) : 0u, ib = active ? src(e) : 0u;
-  const QuadRes<F> r = quad_add_compute<F>(sh, ia, ib, active);
+  QuadRes<F> r; r.mode = 0;
+  uint32_t ia = 0;
+  if ((threadIdx.x & ~63u) < 4u * count) {            // wave-uniform: this wave holds at least one active quad
+    ia = active ? dst(e) : 0u;
+    const uint32_t ib = active ? src(e) : 0u;
+    r = quad_add_compute<F>(sh, ia, ib, active);
+  }
   __syncthreads();
   quad_add_store<F>(sh, ia, r);
   __syncthreads();

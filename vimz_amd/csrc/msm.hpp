@@ -652,24 +652,6 @@ hipError_t build_multiples(hipStream_t stream, const uint32_t* d_tables, size_t 
 }
 
 // grid (Q, K): workgroup (q, w) sums the points selected by window w's digits of scalars [q·FIXED_CHUNK, (q+1)·FIXED_CHUNK).
-// A quad-lane level whose additions all sit in the lower waves is skipped by the waves above them (the shuffles are wave-wide, the
-// barriers workgroup-wide): the last five levels of a 256-leaf tree issue on one wave instead of four.
-template <class F, class Fd, class Fs>
-__device__ __forceinline__ void quad_level_lazy(XYZZ<F>* __restrict__ sh, uint32_t count, Fd dst, Fs src) {
-  const uint32_t e = threadIdx.x >> 2;
-  const bool active = e < count;
-  QuadRes<F> r; r.mode = 0;
-  uint32_t ia = 0;
-  if ((threadIdx.x & ~63u) < 4u * count) {            // wave-uniform
-    ia = active ? dst(e) : 0u;
-    const uint32_t ib = active ? src(e) : 0u;
-    r = quad_add_compute<F>(sh, ia, ib, active);
-  }
-  __syncthreads();
-  quad_add_store<F>(sh, ia, r);
-  __syncthreads();
-}
-
 template <class S, class F>
 __global__ void __launch_bounds__(256) k_msm_fixed(const uint32_t* __restrict__ mult, uint32_t tstride, const uint32_t* __restrict__ scalars, uint32_t n, int mont,
                                                    uint32_t Q, uint32_t* __restrict__ partial /* K x Q */, uint32_t* __restrict__ done /* K counters */,
@@ -709,9 +691,9 @@ __global__ void __launch_bounds__(256) k_msm_fixed(const uint32_t* __restrict__ 
   }
   sh[t] = acc;
   __syncthreads();
-  quad_level_lazy<F>(sh, 64, [](uint32_t e) { return e; }, [](uint32_t e) { return e + 128; });
-  quad_level_lazy<F>(sh, 64, [](uint32_t e) { return e + 64; }, [](uint32_t e) { return e + 192; });
-  for (uint32_t d = 64; d > 0; d >>= 1) quad_level_lazy<F>(sh, d, [](uint32_t e) { return e; }, [d](uint32_t e) { return e + d; });
+  quad_level<F>(sh, 64, [](uint32_t e) { return e; }, [](uint32_t e) { return e + 128; });
+  quad_level<F>(sh, 64, [](uint32_t e) { return e + 64; }, [](uint32_t e) { return e + 192; });
+  for (uint32_t d = 64; d > 0; d >>= 1) quad_level<F>(sh, d, [](uint32_t e) { return e; }, [d](uint32_t e) { return e + d; });
   if (Q == 1) { if (t == 0) store_xyzz(window_sums, w, sh[0]); return; }
   // publish; the last workgroup of the window to arrive sums the Q workgroup sums (release: store, fence, barrier, agent-scope
   // ticket; acquire: fence, agent-scope loads — as k_msm_small's chunk merge)
@@ -733,7 +715,7 @@ __global__ void __launch_bounds__(256) k_msm_fixed(const uint32_t* __restrict__ 
   }
   __syncthreads();
   uint32_t top = 1; while (top < Q) top <<= 1;
-  for (uint32_t d = top >> 1; d > 0; d >>= 1) quad_level_lazy<F>(sh, d, [](uint32_t e) { return e; }, [d](uint32_t e) { return e + d; });
+  for (uint32_t d = top >> 1; d > 0; d >>= 1) quad_level<F>(sh, d, [](uint32_t e) { return e; }, [d](uint32_t e) { return e + d; });
   if (t == 0) { store_xyzz(window_sums, w, sh[0]); __hip_atomic_store(&done[w], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 }
 

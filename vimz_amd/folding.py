@@ -107,6 +107,14 @@ def prepare_folding(ctx, transformation, resolution="HD", ck_label=b"ck", window
     return circuit, FoldingParams(ctx, circuit, ck, time.time() - t0)
 
 
+def default_batch(circuit):
+    """Rows whose witnesses are generated together (and whose (A,B,C)·z and commitments the producer keeps ahead of the folds).  A batch
+    costs one Poseidon-chain latency whatever its size, so wide circuits want large batches — 288 GB of HBM is what allows them: at 4K /
+    8K whole images run at 370 / 284 steps/s with 32 rows, 408 / 359 with 64, 420 / 381 with 128, 427 / 398 with 256 (which is 54 GB per
+    prover, and three provers share a GPU); at HD the size does not matter (742-768 from 64 to 256).  (profiles/r03_batch_sweep.txt)"""
+    return 64 if circuit.n_wires < 500_000 else 128
+
+
 class FoldingProof:
     """FoldingProof (folding.rs:17): the RecursiveSNARK (mode "ivc": a vimz_ivc) or, in accumulator mode, the NIFS accumulator of
     the step circuit's own instances (a vimz_prover; mergeable across row segments, not a RecursiveSNARK)."""
@@ -137,13 +145,15 @@ def _limbs_to_ints(a):
     return [sum(int(x[k]) << (64 * k) for k in range(4)) for x in np.asarray(a).reshape(-1, 4)]
 
 
-def fold_input(params, ivc_step_inputs, initial_state, max_batch=16, prover=None, mode="ivc", segments=1):
+def fold_input(params, ivc_step_inputs, initial_state, max_batch=None, prover=None, mode="ivc", segments=1):
     """fold_input (folding.rs:27-43): one RecursiveSNARK over all steps (mode "ivc", what the reference produces), or the NIFS
     accumulator (mode "accumulator").  Raises VimzError (the reference panics with "Failed to fold input").
     segments = S > 1 (mode "ivc"): the rows are proven as S contiguous segments folded CONCURRENTLY on this GPU (one IVC each, own
     context and streams) and merged into ONE proof object (vimz_ivc_merge; FoldingProof.mode == "merged") — a single chain leaves a
     quarter of an MI355X idle."""
     from .hip import IVC, Context, MergedProof, Prover
+    if max_batch is None:
+        max_batch = default_batch(params.circuit)
     if prover is None and mode == "ivc" and segments > 1 and len(ivc_step_inputs) >= segments:
         from .distributed import fold_concurrently, ivc_segments
         ctxs = [params.ctx] + [Context(params.ctx.device) for _ in range(segments - 1)]
