@@ -86,7 +86,11 @@ size_t merged_words(const vimz_ivc* v) {      // 32-byte elements of the one dev
   return nw1 + 4 * nc1 + 2 * (nw2 + 4 * nc2) + nc2;
 }
 
-int merged_alloc(vimz_ivc* vk, std::unique_ptr<vimz_ivc_merged>& m) {
+// (an object that is dropped on an error path gives its device and pinned memory back; the caller holds the context's lock)
+struct MergedDrop { void operator()(vimz_ivc_merged* m) const { if (!m) return; if (m->dev) hipFree(m->dev); if (m->pin) hipHostFree(m->pin); delete m; } };
+typedef std::unique_ptr<vimz_ivc_merged, MergedDrop> MergedPtr;
+
+int merged_alloc(vimz_ivc* vk, MergedPtr& m) {
   vimz_ctx* ctx = vk->ctx;
   m.reset(new vimz_ivc_merged());
   m->vk = vk;
@@ -113,11 +117,11 @@ MSeg record_of(const vimz_ivc* v) {
 }
 
 // Z, E, AZ, BZ, CZ of  U2 + r·u2  of the IVC `v` into dst[0..5)  (the secondary half of Leaf(v)), on stream s
-void leaf_fold_secondary(const vimz_ivc* v, const uint32_t r[4], uint32_t* const dst[5], hipStream_t s) {
+hipError_t leaf_fold_secondary(const vimz_ivc* v, const uint32_t r[4], uint32_t* const dst[5], hipStream_t s) {
   const SecDev& S = v->sec;
   const uint32_t* run[5] = {S.Zrun, S.E, S.AZ, S.BZ, S.CZ};
   const size_t len[5] = {S.n_w, S.n_c, S.n_c, S.n_c, S.n_c};
-  for (int k = 0; k < 5; k++) hipMemcpyAsync(dst[k], run[k], 32 * len[k], hipMemcpyDeviceToDevice, s);
+  for (int k = 0; k < 5; k++) { const hipError_t e = hipMemcpyAsync(dst[k], run[k], 32 * len[k], hipMemcpyDeviceToDevice, s); if (e != hipSuccess) return e; }
   Fold5 f;
   f.x1[0] = dst[0]; f.x2[0] = S.z2; f.n[0] = S.n_w;
   f.x1[1] = v->sec_T_valid ? dst[1] : nullptr; f.x2[1] = S.T; f.n[1] = S.n_c;      // (after one step U2 is still the zero instance: T = 0)
@@ -125,6 +129,7 @@ void leaf_fold_secondary(const vimz_ivc* v, const uint32_t r[4], uint32_t* const
   f.x1[3] = dst[3]; f.x2[3] = S.bz2; f.n[3] = S.n_c;
   f.x1[4] = dst[4]; f.x2[4] = S.cz2; f.n[4] = S.n_c;
   hipLaunchKernelGGL(k_fold5<Fq>, dim3(64), dim3(256), 0, s, f, fe128<Fq>(r));
+  return hipGetLastError();
 }
 
 // Node(m, B) on the device and the host: m absorbs the accumulator B whose vectors sit at `bv`.  Caller holds the lock of m's context.
@@ -132,8 +137,12 @@ int node_merge(vimz_ivc_merged* m, const MAcc& B, const DevAcc& bv) {
   vimz_ivc* vk = m->vk; vimz_ctx* ctx = vk->ctx; vimz_prover* p = vk->pri;
   hipStream_t s = ctx->stream, s2 = vk->s2;
   const size_t nw1 = p->n_wires, nc1 = p->n_c, nw2 = vk->sec.n_w, nc2 = vk->sec.n_c;
+  if (m->broken) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_ivc_merge: this merged proof failed in the middle of an earlier merge and cannot be used");
   if (!same_state(m->acc.ze, B.zs)) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_ivc_merge: the incoming segment does not start at the state the merged proof ends in");
+  if (m->acc.n + B.n < m->acc.n) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_ivc_merge: step count overflow");
   const double t0 = now_s();
+  // (from here on a failure leaves the vectors half folded: the guard marks the object unusable)
+  struct Poison { vimz_ivc_merged* m; bool armed = true; ~Poison() { if (armed) m->broken = true; } } poison{m};
   // cross terms and their commitments: the primary one (the only large MSM of a merge) on the context's stream, the secondary one beside it
   hipLaunchKernelGGL(k_cross_term<Fr>, dim3(stream_grid(nc1)), dim3(256), 0, s, nc1, (const uint32_t*)m->AZp, (const uint32_t*)m->BZp, (const uint32_t*)m->CZp, m->acc.P.u,
                      bv.AZp, bv.BZp, bv.CZp, B.P.u, p->T);
@@ -185,6 +194,7 @@ int node_merge(vimz_ivc_merged* m, const MAcc& B, const DevAcc& bv) {
   P_TRY(hipStreamSynchronize(s));
   const double t2 = now_s();
   m->seconds[1] += t1 - t0; m->seconds[2] += t2 - t1; m->seconds[3] += t2 - t0;
+  poison.armed = false;
   return VIMZ_OK;
 }
 
@@ -226,7 +236,7 @@ bool merged_replay(const vimz_ivc* vk, const std::vector<MSeg>& segs, const std:
       if (st.size() < 2) { *flags = fl | 8192; return false; }
       MAcc B = std::move(st.back()); st.pop_back();
       MAcc A = std::move(st.back()); st.pop_back();
-      if (!same_state(A.ze, B.zs)) fl |= 4096;
+      if (!same_state(A.ze, B.zs) || A.n + B.n < A.n) fl |= 4096;
       uint32_t rp[4], rq[4];
       st.push_back(node_acc(A, B, o.Tp, o.Tq, rp, rq));
     } else { *flags = fl | 8192; return false; }
@@ -262,9 +272,9 @@ int vimz_ivc_merged_create(vimz_ivc* v, vimz_ivc_merged** out) {
   std::lock_guard<std::mutex> g(ctx->mu);
   P_TRY(hipSetDevice(ctx->device));
   const double t0 = now_s();
-  std::unique_ptr<vimz_ivc_merged> m;
+  MergedPtr m;
   int rc = merged_alloc(v, m);
-  if (rc) { if (m) { hipFree(m->dev); if (m->pin) hipHostFree(m->pin); } return rc; }
+  if (rc) return rc;
   hipStream_t s = ctx->stream;
   vimz_prover* p = v->pri;
   const uint32_t* src[5] = {p->Zrun, p->E, p->AZ, p->BZ, p->CZ}; uint32_t* dst[5] = {m->Zp, m->Ep, m->AZp, m->BZp, m->CZp};
@@ -274,7 +284,7 @@ int vimz_ivc_merged_create(vimz_ivc* v, vimz_ivc_merged** out) {
   uint32_t r[4];
   m->acc = leaf_acc(v, m->segs[0], r);
   uint32_t* q[5] = {m->Zq, m->Eq, m->AZq, m->BZq, m->CZq};
-  leaf_fold_secondary(v, r, q, s);
+  P_TRY(leaf_fold_secondary(v, r, q, s));
   MOp op; op.kind = 0; op.leaf = 0; op.Tp.x = op.Tp.y = Fq::zero(); op.Tq.x = op.Tq.y = Fe::zero();
   m->ops.push_back(op);
   P_TRY(hipGetLastError());
@@ -297,9 +307,9 @@ int vimz_ivc_merge(vimz_ivc_merged* m, vimz_ivc* next) {
   MSeg rec = record_of(next);
   if (!same_state(m->acc.ze, rec.zs)) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_ivc_merge: the incoming segment does not start at the state the merged proof ends in");
   uint32_t r[4];
+  if (m->broken) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_ivc_merge: this merged proof failed in the middle of an earlier merge and cannot be used");
   const MAcc B = leaf_acc(vk, rec, r);
-  leaf_fold_secondary(next, r, m->leaf_q, ctx->stream);
-  P_TRY(hipGetLastError());
+  P_TRY(leaf_fold_secondary(next, r, m->leaf_q, ctx->stream));
   vimz_prover* np = next->pri;
   const DevAcc bv{np->Zrun, np->E, np->AZ, np->BZ, np->CZ, m->leaf_q[0], m->leaf_q[1], m->leaf_q[2], m->leaf_q[3], m->leaf_q[4]};
   m->seconds[0] += now_s() - t0;
@@ -331,12 +341,14 @@ int vimz_ivc_merge_merged(vimz_ivc_merged* m, vimz_ivc_merged* other) {
 int vimz_ivc_merged_info(const vimz_ivc_merged* m, uint64_t info[8]) {
   if (!m || !info) return VIMZ_ERR_INVALID;
   const vimz_ivc* vk = m->vk;
+  std::lock_guard<std::mutex> g(vk->ctx->mu);
   info[0] = m->acc.n; info[1] = m->segs.size(); info[2] = m->ops.size(); info[3] = vk->pri->len_z;
   info[4] = vk->pri->n_wires; info[5] = vk->pri->n_c; info[6] = vk->sec.n_w; info[7] = vk->sec.n_c;
   return VIMZ_OK;
 }
 int vimz_ivc_merged_state(const vimz_ivc_merged* m, uint64_t* z_start, uint64_t* z_end, uint64_t* steps) {
   if (!m) return VIMZ_ERR_INVALID;
+  std::lock_guard<std::mutex> g(m->vk->ctx->mu);
   const uint32_t lz = m->vk->pri->len_z;
   if (z_start) for (uint32_t k = 0; k < lz; k++) fe_to_canon(m->acc.zs[k], z_start + 4 * k);
   if (z_end) for (uint32_t k = 0; k < lz; k++) fe_to_canon(m->acc.ze[k], z_end + 4 * k);
@@ -353,6 +365,7 @@ int vimz_ivc_merged_profile(const vimz_ivc_merged* m, double seconds[4]) {
 // what a verifier replays.  Returns the size in bytes (copies when buf is large enough).
 int64_t vimz_ivc_merged_records(const vimz_ivc_merged* m, void* buf, size_t cap) {
   if (!m) return VIMZ_ERR_INVALID;
+  std::lock_guard<std::mutex> g(m->vk->ctx->mu);        // (a merge on another thread grows the records)
   const size_t bytes = 8 * records_words(m);
   if (buf && cap >= bytes) { Writer w; write_records(m, w); if (8 * w.w.size() != bytes) return VIMZ_ERR_INVALID; memcpy(buf, w.w.data(), bytes); }
   return (int64_t)bytes;
@@ -423,10 +436,10 @@ int vimz_ivc_merged_load(vimz_ivc* vk, const uint8_t* blob, size_t len, vimz_ivc
   if (!merged_replay(vk, segs, ops, &acc, &fl)) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_ivc_merged_load: malformed op sequence");
   std::lock_guard<std::mutex> g(ctx->mu);
   P_TRY(hipSetDevice(ctx->device));
-  std::unique_ptr<vimz_ivc_merged> m;
+  MergedPtr m;
   int rc = merged_alloc(vk, m);
-  auto drop = [&]() { if (m) { if (m->dev) hipFree(m->dev); if (m->pin) hipHostFree(m->pin); } };
-  if (rc) { drop(); return rc; }
+  auto drop = [] {};        // (MergedDrop releases the buffers on every early return)
+  if (rc) return rc;
   hipStream_t s = ctx->stream;
   const uint8_t* o = blob + 8 * in.pos;
   uint32_t* dst[4] = {m->Zp, m->Ep, m->Zq, m->Eq}; const size_t ln[4] = {nw1, nc1, nw2, nc2};
@@ -467,6 +480,7 @@ int vimz_ivc_merged_verify(vimz_ivc_merged* m, uint64_t num_steps, const uint64_
   vimz_ivc* vk = m->vk; vimz_ctx* ctx = vk->ctx; vimz_prover* p = vk->pri;
   const SecDev& S = vk->sec;
   uint32_t res = 0;
+  if (m->broken) { *result = 8192; return VIMZ_OK; }
   MAcc R;
   if (!merged_replay(vk, m->segs, m->ops, &R, &res)) { *result = res | 8192; return VIMZ_OK; }
   if (R.n != num_steps) res |= 4096;

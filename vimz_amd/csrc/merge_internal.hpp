@@ -38,6 +38,7 @@ struct vimz_ivc_merged {
   uint32_t* Tq = nullptr;                 // secondary cross term
   void* pin = nullptr;                    // pinned window sums of the secondary cross-term commitment
   double seconds[4] = {};                 // leaf work, node GPU wait, node host, total
+  bool broken = false;                    // a merge failed after its folds were queued: the vectors no longer match the records
 };
 
 namespace {
@@ -75,7 +76,7 @@ bool read_records(Reader& in, const vimz_ivc* vk, std::vector<MSeg>& segs, std::
   const vimz_prover* p = vk->pri;
   const size_t lz = p->len_z;
   const uint64_t magic = in.word(), S = in.word(), n_ops = in.word(), lzb = in.word(), nw1 = in.word(), nc1 = in.word(), nw2 = in.word(), nc2 = in.word();
-  if (!in.ok || magic != MERGED_MAGIC || lzb != lz || nw1 != p->n_wires || nc1 != p->n_c || nw2 != vk->sec.n_w || nc2 != vk->sec.n_c || S == 0 || S > 65536 || n_ops != 2 * S - 1) return false;
+  if (!in.ok || magic != MERGED_MAGIC || lzb != lz || nw1 != p->n_wires || nc1 != p->n_c || nw2 != vk->sec.n_w || nc2 != vk->sec.n_c || S == 0 || S > 4096 || n_ops != 2 * S - 1) return false;
   segs.assign(S, MSeg()); ops.assign(n_ops, MOp());
   for (auto& s : segs) {
     s.n = in.word();
