@@ -488,6 +488,8 @@ void vimz_ivc_free(vimz_ivc* v) {
     }
     hipSetDevice(v->ctx->device);
     v->ws2.release(); v->ws3.release();
+    if (v->merged_spare_dev) hipFree(v->merged_spare_dev);
+    if (v->merged_spare_pin) hipHostFree(v->merged_spare_pin);
     for (void* d : v->owned) hipFree(d);
     if (v->pin) hipHostFree(v->pin);
   }

@@ -91,6 +91,9 @@ struct vimz_ivc {
   // (device-to-device copy on its own stream) and commits to it; the host adds the partial commitments (vimz_ivc_add_msm_helper).
   struct MsmHelper { vimz_ctx* ctx = nullptr; const vimz_bases* ck = nullptr; hipStream_t s = nullptr; MsmWorkspace ws; uint32_t* T = nullptr; void* pin = nullptr; MsmPlan plan{}; size_t off = 0, n = 0; };
   std::vector<MsmHelper> helpers; hipEvent_t ev_T = nullptr; size_t t1_main_n = 0;
+  // one set of a merged proof's buffers (merge.hip) kept from the last one that was freed: the next vimz_ivc_merged_create over this
+  // IVC needs no allocation (device + pinned: 0.5-2 ms next to running kernels, inside a timed fold_input)
+  uint32_t* merged_spare_dev = nullptr; void* merged_spare_pin = nullptr;
   // CompressedSNARK (spartan.hip): transposed shapes, scratch — built on first use, released with the IVC
   void* spartan_cache = nullptr; void (*spartan_free)(vimz_ivc*) = nullptr;
 };

@@ -87,7 +87,14 @@ size_t merged_words(const vimz_ivc* v) {      // 32-byte elements of the one dev
 }
 
 // (an object that is dropped on an error path gives its device and pinned memory back; the caller holds the context's lock)
-struct MergedDrop { void operator()(vimz_ivc_merged* m) const { if (!m) return; if (m->dev) hipFree(m->dev); if (m->pin) hipHostFree(m->pin); delete m; } };
+// (its buffers go back to the verifier-key IVC as the spare set when that has none)
+void release_buffers(vimz_ivc_merged* m) {
+  vimz_ivc* vk = m->vk;
+  if (vk && m->dev && m->pin && !vk->merged_spare_dev) { vk->merged_spare_dev = m->dev; vk->merged_spare_pin = m->pin; }
+  else { if (m->dev) hipFree(m->dev); if (m->pin) hipHostFree(m->pin); }
+  m->dev = nullptr; m->pin = nullptr;
+}
+struct MergedDrop { void operator()(vimz_ivc_merged* m) const { if (!m) return; release_buffers(m); delete m; } };
 typedef std::unique_ptr<vimz_ivc_merged, MergedDrop> MergedPtr;
 
 int merged_alloc(vimz_ivc* vk, MergedPtr& m) {
@@ -95,14 +102,15 @@ int merged_alloc(vimz_ivc* vk, MergedPtr& m) {
   m.reset(new vimz_ivc_merged());
   m->vk = vk;
   const size_t nw1 = vk->pri->n_wires, nc1 = vk->pri->n_c, nw2 = vk->sec.n_w, nc2 = vk->sec.n_c;
-  P_TRY(hipMalloc((void**)&m->dev, 32 * merged_words(vk)));
+  if (vk->merged_spare_dev) { m->dev = vk->merged_spare_dev; m->pin = vk->merged_spare_pin; vk->merged_spare_dev = nullptr; vk->merged_spare_pin = nullptr; }
+  else P_TRY(hipMalloc((void**)&m->dev, 32 * merged_words(vk)));
   uint32_t* d = m->dev;
   auto take = [&](size_t n) { uint32_t* r = d; d += 8 * n; return r; };
   m->Zp = take(nw1); m->Ep = take(nc1); m->AZp = take(nc1); m->BZp = take(nc1); m->CZp = take(nc1);
   m->Zq = take(nw2); m->Eq = take(nc2); m->AZq = take(nc2); m->BZq = take(nc2); m->CZq = take(nc2);
   m->leaf_q[0] = take(nw2); for (int k = 1; k < 5; k++) m->leaf_q[k] = take(nc2);
   m->Tq = take(nc2);
-  P_TRY(hipHostMalloc(&m->pin, 4 * (size_t)XYZZ_WORDS * MSM_MAX_WINDOWS));
+  if (!m->pin) P_TRY(hipHostMalloc(&m->pin, 4 * (size_t)XYZZ_WORDS * MSM_MAX_WINDOWS));
   return VIMZ_OK;
 }
 
@@ -257,8 +265,8 @@ void vimz_ivc_merged_free(vimz_ivc_merged* m) {
     std::lock_guard<std::mutex> g(m->vk->ctx->mu);
     hipSetDevice(m->vk->ctx->device);
     hipStreamSynchronize(m->vk->ctx->stream);
-    if (m->dev) hipFree(m->dev);
-    if (m->pin) hipHostFree(m->pin);
+    if (m->vk->s2) hipStreamSynchronize(m->vk->s2);
+    release_buffers(m);
   }
   delete m;
 }
