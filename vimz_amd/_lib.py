@@ -6,6 +6,11 @@ an error (surfaced as VimzError) when no MI355X is visible.
 import ctypes as C
 import os
 
+# Hardware queues of the HIP runtime: the default of 4 makes the streams of several concurrent provers of one process wait for each
+# other (three segments: 785 steps/s against 885 with 8).  Read by the runtime when it initialises, so it only takes
+# effect if this module is imported before anything touches the GPU; an explicit setting wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(HERE, "libvimz_hip.so")
 
