@@ -307,6 +307,7 @@ inline std::unique_ptr<CircuitBuild> build_step_circuit(int t, const StepShape& 
     default:
       throw std::runtime_error("unknown transformation");
   }
+  group_boolean_rows_first(b);
   return cbp;
 }
 
