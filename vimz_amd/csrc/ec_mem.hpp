@@ -121,7 +121,10 @@ __device__ __forceinline__ void quad_level(XYZZ<F>* __restrict__ sh, uint32_t co
   const bool active = e < count;
   QuadRes<F> r; r.mode = 0;
   uint32_t ia = 0;
-  if ((threadIdx.x & ~63u) < 4u * count) {            // wave-uniform: this wave holds at least one active quad
+  // (the wave index through readfirstlane: a condition the compiler KNOWS to be scalar becomes a branch; a per-lane one was
+  //  flattened into predicated code that the idle waves still issued — same instruction count as before)
+  const uint32_t wave0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63u));
+  if (wave0 < 4u * count) {                            // this wave holds at least one active quad
     ia = active ? dst(e) : 0u;
     const uint32_t ib = active ? src(e) : 0u;
     r = quad_add_compute<F>(sh, ia, ib, active);
