@@ -34,10 +34,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # Hardware queues of the HIP runtime (read once, when the runtime initialises: set before torch or the library touch the GPU).  The
-# default of 4 serialises the fifteen streams of three concurrent segments more than the GPU requires: 8 and more give 880-890 instead
-# of 784-788 steps/s over 256 rows (profiles/r03_hw_queues.txt; one chain and the 20-row window are unchanged).  vimz_amd/_lib.py
-# sets the same default for every user of the library; an explicit setting in the environment wins.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# default of 4 serialises the fifteen streams of three concurrent segments more than the GPU requires: 8 give 880-890 instead of 784-788
+# steps/s over 256 rows — but 8 per process with TWO processes on one GPU collapse to 63 (profiles/r03_hw_queues.txt).  vimz_amd/_lib.py
+# picks 8 when a rank has its GPU to itself and the runtime's 4 when ranks share one (LOCAL_WORLD_SIZE over the visible devices); an explicit setting in the environment wins.
+from vimz_amd import _lib as _vimz_lib  # noqa: E402,F401  (sets GPU_MAX_HW_QUEUES; touches neither torch nor the GPU)
 
 HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MIXED_ADD_PEAK_GOPS = 15.47      # measured ceiling of the XYZZ mixed addition in the lazily reduced 9x29-bit form (profiles/r02_ubench_fp29.txt)

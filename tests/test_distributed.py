@@ -49,6 +49,7 @@ def _worker(rank, world, port, q):
 def _gpu_worker(rank, world, port, q):
     """The same driver over the GPU prover (two ranks share the one GPU of the test box: own context, own streams each)."""
     sys.path.insert(0, ROOT)
+    os.environ["LOCAL_WORLD_SIZE"] = str(world)      # (both ranks share the one GPU: half the hardware queues per process)
     import torch.distributed as dist
     from tests._oracle import from_limbs
     from tests.test_circuits import step_inputs
@@ -295,6 +296,7 @@ def test_fold_segments_merged_handles_fewer_rows_than_segments(oracle):
 
 def _gpu_sharded_worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
+    os.environ["LOCAL_WORLD_SIZE"] = str(world)      # (both ranks share the one GPU: vimz_amd/_lib.py halves the hardware queues per process)
     import torch.distributed as dist
     from tests.test_circuits import step_inputs
     from vimz_amd import _lib, hip

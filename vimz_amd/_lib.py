@@ -6,10 +6,29 @@ an error (surfaced as VimzError) when no MI355X is visible.
 import ctypes as C
 import os
 
-# Hardware queues of the HIP runtime: the default of 4 makes the streams of several concurrent provers of one process wait for each
-# other (three segments: 785 steps/s against 885 with 8).  Read by the runtime when it initialises, so it only takes
-# effect if this module is imported before anything touches the GPU; an explicit setting wins.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# Hardware queues of the HIP runtime.  Its default of 4 makes the streams of several concurrent provers of ONE process wait for each
+# other (three segments: 785 steps/s against 885 with 8; more than 8 changes nothing) — but the GPU has about eight in all: two
+# processes with 8 each on one GPU collapse to 63 steps/s, four with 2 each to 67, while 4 each is fine for two and for four
+# processes (profiles/r03_hw_queues.txt).  So: 8 when this process has its GPU to itself, the runtime's 4 when ranks share one, as
+# far as a launcher's environment tells (LOCAL_WORLD_SIZE / visible devices); callers that know
+# better set GPU_MAX_HW_QUEUES themselves (an explicit setting wins).  The runtime reads the variable when it initialises: this only
+# takes effect if the module is imported before anything touches the GPU.
+def default_hw_queues(n_devices=None):
+    local = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")) or 1)
+    if n_devices is None:
+        vis = os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("ROCR_VISIBLE_DEVICES", ""))
+        n_devices = len([x for x in vis.split(",") if x.strip()]) if vis else None
+    if n_devices is None:
+        try:
+            n_devices = len([d for d in os.listdir("/sys/class/kfd/kfd/topology/nodes")
+                             if int(open(f"/sys/class/kfd/kfd/topology/nodes/{d}/simd_count").read() or 0) > 0])
+        except (OSError, ValueError):
+            n_devices = 1
+    per_gpu = -(-local // max(1, n_devices))
+    return 8 if per_gpu <= 1 else 4
+
+
+os.environ.setdefault("GPU_MAX_HW_QUEUES", str(default_hw_queues()))
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(HERE, "libvimz_hip.so")

@@ -167,11 +167,6 @@ static __global__ void __launch_bounds__(256) k_pack_pixels(const uint8_t* __res
   o[1] = make_uint4(words[4], words[5], words[6], words[7]);
 }
 
-// Hardware queues of the HIP runtime.  Its default of 4 makes the streams of several provers of one process share queues and wait for
-// each other (three concurrent segments: 785 steps/s against 885 with 8, profiles/r03_hw_queues.txt).  The runtime reads the variable when
-// it initialises — after this library is loaded unless the process has used the GPU before —; an explicit setting wins.
-__attribute__((constructor)) static void vimz_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
-
 extern "C" {
 
 const char* vimz_version(void) { return "vimz-hip 0.1 (gfx950)"; }
