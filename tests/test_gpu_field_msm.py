@@ -401,3 +401,34 @@ def test_msm_general_pipeline_on_the_255_bit_curves_at_2_17(ctx, oracle, cid):
         assert oracle.curve_add(cid, want, tuple(from_limbs(ctx.msm(B, neg)))) == (0, 0)
     finally:
         B.free()
+
+
+@pytest.mark.gpu
+def test_kzg_style_commitment_over_an_uploaded_srs_has_the_closed_form_value(ctx, oracle):
+    """The Sonobe backend commits with KZG over BN254 G1 (vimz/src/sonobe_backend/folding.rs:22: `KZG<'static, Bn254>`): an MSM over
+    the SRS's powers [tau^i]G, handed to this library as an ordinary key (`vimz_bases_upload`).  With a test SRS whose tau is known the
+    commitment has a closed form that needs no other MSM to check it:  sum_i c_i·[tau^i]G = p(tau)·G.  Dense coefficients, 2^14
+    powers, and a sub-range (a polynomial of lower degree times a power of tau)."""
+    r = MODULI[0]
+    n = 1 << 14
+    tau = 0x1234567890ABCDEF1234567890ABCDEF1234567890ABCDEF % r
+    G = GENERATORS[0]
+    powers, t = [], 1
+    for _ in range(n):
+        powers.append(t)
+        t = t * tau % r
+    srs = np.zeros((n, 8), dtype=np.uint64)
+    for i, k in enumerate(powers):
+        srs[i] = to_limbs(list(oracle.curve_mul(0, G, k))).reshape(-1)
+    B = ctx.bases_upload(0, srs)
+    try:
+        rng = random.Random(2718)
+        coeffs = [rng.randrange(r) for _ in range(n)]
+        p_tau = sum(c * k for c, k in zip(coeffs, powers)) % r
+        assert tuple(from_limbs(ctx.msm(B, to_limbs(coeffs)))) == oracle.curve_mul(0, G, p_tau)
+        v = ctx.vec_from_host(0, to_limbs(coeffs))
+        q_tau = sum(c * k for c, k in zip(coeffs[100:5100], powers[300:5300])) % r
+        assert tuple(from_limbs(ctx.msm_vec(B, v, n=5000, offset=100, base_offset=300))) == oracle.curve_mul(0, G, q_tau)
+        v.free()
+    finally:
+        B.free()
