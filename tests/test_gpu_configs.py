@@ -116,3 +116,42 @@ def test_config5_proof_set_4k_four_ivcs_side_by_side(keys, oracle):
             v.close()
         for cx in ctxs:
             cx.close()
+
+
+@pytest.mark.parametrize("op,res", [("resize", "8K"), ("contrast", "4K")])
+def test_config_rows_sharded_into_three_segments_are_one_proof_object(keys, oracle, op, res):
+    """BASELINE config 4's shape ("row-batches sharded ..., host-side final fold") on the one GPU of the box: six rows of the 8K
+    resize circuit (and of the 4K contrast circuit) proven as THREE concurrent segments on three contexts and merged into ONE object
+    (vimz_ivc_merge); the product's verifier and the oracle-side verifier (tests/_merge.py: replay of the records, relaxed relation of
+    both folded instances over the 0.8-0.9 M-row shapes) accept it for (6 steps, z0), and it ends in the oracle's state."""
+    from tests import _merge
+    from tests.test_circuits import ORC_T
+    from tests.test_gpu_ivc import _shape_digest
+    from vimz_amd import hip
+    from vimz_amd.distributed import fold_segments_merged
+    ck1, ck2 = keys
+    n = 6
+    c = Circuit.for_resolution(op, res)
+    rows, z0 = _data.config_rows(op, res, n)
+    ctxs = [hip.Context(0) for _ in range(3)]
+    ivcs = [hip.IVC(cx, c, ck1, ck2, max_batch=2) for cx in ctxs]
+    m = None
+    try:
+        tm = {}
+        m = fold_segments_merged(ivcs, rows, z0, tm)
+        assert m.verify(n, z0) == 0 and m.verify(n - 1, z0) != 0
+        z = list(z0)
+        for i in range(n):
+            ok, z = oracle.step_eval(ORC_T[op], z, rows[i], **({"width": 384} if res == "4K" else {"width": 768, "width2": 384, "rows_in": 2, "rows_out": 1}))
+            assert ok
+        zs, ze, steps = m.state()
+        assert (zs, ze, steps) == ([int(x) for x in z0], z, n) and m.info()["segments"] == 3
+        failed, acc = _merge.verify_merged(oracle, m, ivcs[0], ck1, ck2, n, z0, _shape_digest(ivcs[0], 0), _shape_digest(ivcs[0], 1), check_commitments=False)
+        assert failed == [] and acc["ze"] == z
+    finally:
+        if m:
+            m.close()
+        for v in ivcs:
+            v.close()
+        for cx in ctxs:
+            cx.close()
