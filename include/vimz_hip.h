@@ -233,6 +233,13 @@ int vimz_prover_running(vimz_prover* p, uint64_t* z_run, uint64_t* E);
 /* IVC state chain only: zs_out = (nsteps+1) x len_z canonical elements starting at z_start (one hash-only GPU pass over the
  * rows + the host pair-hash chain).  Lets a multi-GPU driver find the state at which each row segment starts. */
 int vimz_prover_state_chain(vimz_prover* p, const uint64_t* z_start, const uint64_t* step_inputs, size_t nsteps, uint64_t* zs_out);
+/* The chain in its two parts, for proofs sharded over GPUs: (1) the ROW DIGESTS (the state-independent row hashes: the expensive part,
+ * one GPU pass) of any run of rows — every rank hashes its own rows side by side —, (2) the serial chain over rows whose digests are
+ * known (host only, ≈ 12-25 µs per row).  stride = elements per row of the digests (opaque Montgomery limbs); 0 for a circuit whose
+ * digests depend on the state (crop): use vimz_prover_state_chain there. */
+size_t vimz_prover_digest_stride(const vimz_prover* p);
+int vimz_prover_row_digests(vimz_prover* p, const uint64_t* step_inputs, size_t nsteps, uint64_t* digests_out /* nsteps x stride x 4 */);
+int vimz_prover_chain_from_digests(vimz_prover* p, const uint64_t* z_start, const uint64_t* step_inputs, const uint64_t* digests, size_t nsteps, uint64_t* zs_out);
 /* Host-side final fold of row segments folded on different GPUs (north_star: "host-side sequential final fold"):
  * export one prover's running relaxed instance as a byte blob, merge it into another's (NIFS for two relaxed instances). */
 size_t vimz_prover_export_size(const vimz_prover* p);
@@ -283,6 +290,10 @@ int vimz_ivc_info(const vimz_ivc* v, uint64_t info[12]);
 int vimz_ivc_state(const vimz_ivc* v, uint64_t* z_current /* len_z x 4 */, uint64_t* steps);
 /* IVC state chain only (as vimz_prover_state_chain): where a row segment proven by another IVC starts */
 int vimz_ivc_state_chain(vimz_ivc* v, const uint64_t* z_start, const uint64_t* step_inputs, size_t nsteps, uint64_t* zs_out);
+/* the same in its two parts (see vimz_prover_row_digests): what vimz_amd/distributed.py::prove_sharded uses across ranks */
+size_t vimz_ivc_digest_stride(const vimz_ivc* v);
+int vimz_ivc_row_digests(vimz_ivc* v, const uint64_t* step_inputs, size_t nsteps, uint64_t* digests_out);
+int vimz_ivc_chain_from_digests(vimz_ivc* v, const uint64_t* z_start, const uint64_t* step_inputs, const uint64_t* digests, size_t nsteps, uint64_t* zs_out);
 /* seconds[8]/counts[8]: verifier-circuit witness primary (host), secondary (host), wait for secondary MSMs, wait for primary MSMs,
  * uploads+launches, producer wait, GPU time of the secondary half on the main stream (only while profiling is on), total */
 int vimz_ivc_profile(const vimz_ivc* v, double seconds[8], uint64_t counts[8]);

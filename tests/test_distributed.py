@@ -209,6 +209,21 @@ class _StubIVC:
             self.n += 1
 
 
+class _StubIVCDigests(_StubIVC):
+    """The same with the chain in its two parts (row digests computed by any rank, serial chain over known digests): the stand-in's
+    "digest" of a row is the row itself."""
+
+    def digest_stride(self):
+        return 128
+
+    def row_digests(self, rws):
+        return np.ascontiguousarray(rws, dtype=np.uint64).reshape(len(rws), -1, 4)[:, :128]
+
+    def chain_from_digests(self, z_start, rws, digests):
+        assert (np.asarray(digests).reshape(len(rws), -1, 4) == np.asarray(rws).reshape(len(rws), -1, 4)[:, :128]).all()
+        return self.state_chain(z_start, rws)
+
+
 class _StubMerged:
     """What vimz_amd.hip.MergedProof offers: created from the first segment, merge() of the adjacent next one (an IVC or another
     merged proof), save / load as bytes."""
@@ -237,7 +252,7 @@ class _StubMerged:
         pass
 
 
-def _sharded_worker(rank, world, port, q, shm):
+def _sharded_worker(rank, world, port, q, shm, digests=False):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     from tests import _oracle
@@ -250,7 +265,7 @@ def _sharded_worker(rank, world, port, q, shm):
     z0, inputs = step_inputs("hash")
     rows = np.stack(inputs[:9])
     tm = {}
-    proof = prove_sharded([_StubIVC(orc) for _ in range(2)], rows, z0, rank, world, dist, tm, merged_cls=_StubMerged,
+    proof = prove_sharded([(_StubIVCDigests if digests else _StubIVC)(orc) for _ in range(2)], rows, z0, rank, world, dist, tm, merged_cls=_StubMerged,
                           shm_prefix=(f"/tmp/vimz_test_{port}_" if shm else None))
     if rank == 0:
         q.put((proof.zs, proof.ze, proof.n, proof.segments, sorted(tm)))
@@ -260,10 +275,10 @@ def _sharded_worker(rank, world, port, q, shm):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("shm", [False, True])
-def test_two_ranks_with_two_segments_each_end_in_one_proof_object(oracle, shm):
+@pytest.mark.parametrize("shm,digests", [(False, False), (True, False), (True, True)])
+def test_two_ranks_with_two_segments_each_end_in_one_proof_object(oracle, shm, digests):
     """prove_sharded over gloo, world size 2, two local segments per rank (stand-ins over the oracle's step relation): rank 0's chain
-    gives rank 1 its start state, every rank's segments merge locally, rank 0 folds rank 1's merged proof in — one object about all
+    (or, with the chain in its two parts, every rank's own row digests, all-gathered) gives rank 1 its start state, every rank's segments merge locally, rank 0 folds rank 1's merged proof in — one object about all
     nine rows from z0 that ends where a single chain ends; both ways of moving the bytes."""
     import torch.multiprocessing as mp
     from tests._oracle import T_HASH
@@ -271,7 +286,7 @@ def test_two_ranks_with_two_segments_each_end_in_one_proof_object(oracle, shm):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q, shm)) for r in range(2)]
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q, shm, digests)) for r in range(2)]
     for p in procs:
         p.start()
     zs, ze, n, segments, keys = q.get(timeout=600)

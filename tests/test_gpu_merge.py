@@ -258,3 +258,44 @@ def test_full_image_as_three_concurrent_segments_is_one_proof_ending_in_the_refe
         params.free()
         for c_ in cx[1:]:
             c_.close()
+
+
+@pytest.mark.parametrize("op,n", [("contrast", 10), ("blur", 10), ("resize", 10), ("hash", 10)])
+def test_state_chain_in_two_parts_equals_the_one_call_chain(ctx, op, n):
+    """vimz_ivc_row_digests (any rank can hash any rows) + vimz_ivc_chain_from_digests (the serial part, host only) give the states
+    vimz_ivc_state_chain gives, for a run of rows cut in two at any point — what lets the ranks of a sharded proof hash their own
+    rows side by side (prove_sharded); the GPU hash pass and the host pool path (short inputs) both; crop reports stride 0."""
+    from vimz_amd import folding, hip
+    c, params = folding.prepare_folding(ctx, op, "HD")
+    ck1, ck2 = params.ck, params.secondary_key()
+    z0, inputs = step_inputs(op)
+    rows = np.stack(inputs)[:n]
+    a, b = hip.IVC(ctx, c, ck1, ck2, max_batch=4), hip.IVC(ctx, c, ck1, ck2, max_batch=4)
+    try:
+        want = a.state_chain(z0, rows)
+        assert a.digest_stride() > 0
+        d1, d2 = a.row_digests(rows[:4]), b.row_digests(rows[4:])            # "two ranks"
+        z_mid = a.chain_from_digests(z0, rows[:4], d1)
+        assert (z_mid == want[:5]).all()
+        z_end = b.chain_from_digests(_ints(z_mid[-1]), rows[4:], d2)
+        assert (z_end == want[4:]).all()
+        big = np.concatenate([rows] * 12)[:100]                               # > 96 rows: the GPU hash pass
+        wb = a.state_chain(z0, big)
+        assert (a.chain_from_digests(z0, big, a.row_digests(big)) == wb).all()
+        bad = d1.copy(); bad[0, 0] = 0xFFFFFFFFFFFFFFFF                       # an unreduced digest element is refused
+        with pytest.raises(_lib.VimzError):
+            a.chain_from_digests(z0, rows[:4], bad)
+    finally:
+        a.close(); b.close(); params.free()
+
+
+def test_crop_has_no_state_independent_digests(ctx):
+    from vimz_amd import folding, hip
+    circuit, params = folding.prepare_folding(ctx, "crop", "HD")
+    v = hip.IVC(ctx, circuit, params.ck, params.secondary_key(), max_batch=2)
+    try:
+        assert v.digest_stride() == 0
+        with pytest.raises(_lib.VimzError):
+            v.row_digests(np.zeros((1, circuit.n_priv, 4), dtype=np.uint64))
+    finally:
+        v.close(); params.free()

@@ -665,6 +665,15 @@ int vimz_ivc_state_chain(vimz_ivc* v, const uint64_t* z_start, const uint64_t* s
   if (!v) return VIMZ_ERR_INVALID;
   return vimz_prover_state_chain(v->pri, z_start, step_inputs, nsteps, zs_out);
 }
+size_t vimz_ivc_digest_stride(const vimz_ivc* v) { return v ? vimz_prover_digest_stride(v->pri) : 0; }
+int vimz_ivc_row_digests(vimz_ivc* v, const uint64_t* step_inputs, size_t nsteps, uint64_t* digests_out) {
+  if (!v) return VIMZ_ERR_INVALID;
+  return vimz_prover_row_digests(v->pri, step_inputs, nsteps, digests_out);
+}
+int vimz_ivc_chain_from_digests(vimz_ivc* v, const uint64_t* z_start, const uint64_t* step_inputs, const uint64_t* digests, size_t nsteps, uint64_t* zs_out) {
+  if (!v) return VIMZ_ERR_INVALID;
+  return vimz_prover_chain_from_digests(v->pri, z_start, step_inputs, digests, nsteps, zs_out);
+}
 int vimz_ivc_profile(const vimz_ivc* v, double seconds[8], uint64_t counts[8]) {
   if (!v) return VIMZ_ERR_INVALID;
   if (seconds) memcpy(seconds, v->ph_s, sizeof(double) * IP_COUNT);

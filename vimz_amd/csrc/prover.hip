@@ -438,31 +438,31 @@ static int fold_core(vimz_prover* p, const uint64_t* step_inputs, const uint64_t
   return VIMZ_OK;
 }
 
-extern "C" {
-// IVC state chain only (no folding): zs_out[(nsteps+1) x len_z] canonical, starting from z_start.  One hash-only GPU pass
-// over the rows + the host pair-hash chain.  A multi-GPU driver uses it to find the state at which a row segment starts.
-int vimz_prover_state_chain(vimz_prover* p, const uint64_t* z_start, const uint64_t* step_inputs, size_t nsteps, uint64_t* zs_out) {
-  if (!p || !z_start || !zs_out || (!step_inputs && nsteps)) return VIMZ_ERR_INVALID;
-  vimz_ctx* ctx = p->ctx;
-  std::lock_guard<std::mutex> g(ctx->mu);
-  P_TRY(hipSetDevice(ctx->device));
-  // the stage 0 of a fold (row hashes, the ahead-of-time pass where the circuit needs one, the host's chain), from z_start
-  const std::vector<Fe> keep = p->z_cur;
-  for (uint32_t i = 0; i < p->len_z; i++) p->z_cur[i] = fe_from_canon(z_start + 4 * i);
-  FoldJob job; job.step_inputs = step_inputs; job.nsteps = nsteps;
-  int rc = VIMZ_OK;
-  // Short inputs: the row-hash chains on the host's thread pool (0.4 ms per chain of 17 permutations and core) instead of one
-  // Poseidon-chain latency of the GPU (≈10 ms whatever the row count) — the start states of a few short row segments that are
-  // about to be folded concurrently must not cost as much as folding them.
+// ---- the IVC state chain in its two parts -------------------------------------------------------------------------------------------
+// (1) the ROW DIGESTS — the outputs of the state-independent Poseidon chains of every row (the row hashes) —, which depend on the
+//     row data only and are the expensive part (34 permutations per row at contrast HD, ≈ 150 at 8K): any GPU can compute them for
+//     any rows, so the ranks of a sharded proof each hash their own rows side by side;
+// (2) the serial chain z_i -> z_{i+1} over those digests: two or three small permutations per row on the host (≈ 12-25 µs).
+// Plain circuits only (no Poseidon work that depends on step_in other than through the state hashes: everything but crop).
+static bool chain_is_plain(const vimz_prover* p) {
   const cb::Builder& b = p->circuit->build->b;
-  size_t nA = 0, nE = 0; bool early = false;
+  size_t nA = 0, nE = 0;
   for (auto& c : b.chains) { if (c.phase == 0) nA++; else if (c.phase != 1) nE++; }
-  for (auto& f : b.fops) if (f.early) early = true;
-  if (nsteps && nsteps <= 96 && p->head_eligible && nA && !nE && !early && head_rows_wanted()) {
-    const size_t jstride = p->n_jobs + p->n_fops;
-    std::vector<uint32_t> chainsA;
-    for (uint32_t c = 0; c < b.chains.size(); c++) if (b.chains[c].phase == 0) chainsA.push_back(c);
-    std::vector<Fe> jobvals(nsteps * jstride, Fe::zero());
+  for (auto& f : b.fops) if (f.early) return false;
+  return nA > 0 && nE == 0;
+}
+// caller holds the lock and has set the device; out: nsteps x (n_jobs + n_fops) elements (Montgomery)
+static int compute_row_digests(vimz_prover* p, const uint64_t* step_inputs, size_t nsteps, Fe* out) {
+  vimz_ctx* ctx = p->ctx;
+  const cb::Builder& b = p->circuit->build->b;
+  const size_t jstride = p->n_jobs + p->n_fops;
+  std::vector<uint32_t> chainsA;
+  for (uint32_t c = 0; c < b.chains.size(); c++) if (b.chains[c].phase == 0) chainsA.push_back(c);
+  if (nsteps <= 96 && p->head_eligible && head_rows_wanted()) {
+    // Short inputs: the row-hash chains on the host's thread pool (0.4 ms per chain of 17 permutations and core) instead of one
+    // Poseidon-chain latency of the GPU (≈10 ms whatever the row count) — the start states of a few short row segments that are
+    // about to be folded concurrently must not cost as much as folding them.
+    for (size_t i = 0; i < nsteps * jstride; i++) out[i] = Fe::zero();
     const uint32_t priv0 = 1 + 2 * b.len_z;
     vz_shared_pool().run(nsteps * chainsA.size(), [&](size_t task) {
       const size_t r = task / chainsA.size();
@@ -475,17 +475,80 @@ int vimz_prover_state_chain(vimz_prover* p, const uint64_t* z_start, const uint6
         for (uint32_t i = 0; i + 1 < Jb.t; i++) {
           const ValRef& ref = Jb.in[i];
           if (ref.kind == REF_WIRE) in[i] = fe_from_canon(step_inputs + 4 * (r * p->n_priv + (ref.idx - priv0)));
-          else if (ref.kind == REF_JOB) in[i] = ref.idx + 1 == j ? prev : jobvals[r * jstride + ref.idx];
+          else if (ref.kind == REF_JOB) in[i] = ref.idx + 1 == j ? prev : out[r * jstride + ref.idx];
           else in[i] = Fe::zero();
         }
         prev = cb::poseidon_hash(in, (int)Jb.t - 1);
-        jobvals[r * jstride + j] = prev;
+        out[r * jstride + j] = prev;
       }
     });
-    job.zs.assign((nsteps + 1) * p->len_z, Fe::zero());
-    for (uint32_t i = 0; i < p->len_z; i++) job.zs[i] = p->z_cur[i];
-    host_state_chain(p, step_inputs, nsteps, jobvals.data(), jstride, job.zs);
-  } else if (nsteps) rc = fold_prepare(p, job);
+    return VIMZ_OK;
+  }
+  hipStream_t s = ctx->stream;
+  P_TRY(grow(p->retired, &p->priv_all_d, &p->cap_priv_all, 32 * nsteps * (size_t)p->n_priv, 32 * 1024 * (size_t)p->n_priv));
+  P_TRY(grow(p->retired, &p->job_all_d, &p->cap_job_all, 32 * nsteps * jstride, 32 * 1024 * jstride));
+  P_TRY(hipMemcpyAsync(p->priv_all_d, step_inputs, 32 * nsteps * (size_t)p->n_priv, hipMemcpyHostToDevice, s));
+  P_TRY(hipMemsetAsync(p->job_all_d, 0, 32 * nsteps * jstride, s));
+  for (size_t off = 0; off < nsteps; off += 32768) {
+    const unsigned rows = (unsigned)std::min<size_t>(32768, nsteps - off);
+    hipLaunchKernelGGL(k_wit_chains, dim3((chainsA.size() + 3) / 4, rows), dim3(64), 0, s, p->wd, 0u, (uint32_t*)nullptr, p->job_all_d + 8 * off * jstride,
+                       (const uint32_t*)(p->priv_all_d + 8 * off * p->n_priv));
+  }
+  P_TRY(hipGetLastError());
+  P_TRY(hipMemcpyAsync(out, p->job_all_d, 32 * nsteps * jstride, hipMemcpyDeviceToHost, s));
+  P_TRY(hipStreamSynchronize(s));
+  return VIMZ_OK;
+}
+
+extern "C" {
+// elements per row of vimz_prover_row_digests' output (0: this circuit's digests depend on the state — crop —, use vimz_prover_state_chain)
+size_t vimz_prover_digest_stride(const vimz_prover* p) { return p && chain_is_plain(p) ? (size_t)p->n_jobs + p->n_fops : 0; }
+// part (1): digests_out = nsteps x stride elements (4 x u64 each, Montgomery limbs: opaque to the caller)
+int vimz_prover_row_digests(vimz_prover* p, const uint64_t* step_inputs, size_t nsteps, uint64_t* digests_out) {
+  if (!p || !digests_out || (!step_inputs && nsteps)) return VIMZ_ERR_INVALID;
+  vimz_ctx* ctx = p->ctx;
+  if (!chain_is_plain(p)) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_prover_row_digests: this circuit's row digests depend on the IVC state: use vimz_prover_state_chain");
+  if (!nsteps) return VIMZ_OK;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  P_TRY(hipSetDevice(ctx->device));
+  return compute_row_digests(p, step_inputs, nsteps, reinterpret_cast<Fe*>(digests_out));
+}
+// part (2): zs_out[(nsteps+1) x len_z] canonical from z_start, the rows' private inputs and their digests (host only)
+int vimz_prover_chain_from_digests(vimz_prover* p, const uint64_t* z_start, const uint64_t* step_inputs, const uint64_t* digests, size_t nsteps, uint64_t* zs_out) {
+  if (!p || !z_start || !zs_out || ((!step_inputs || !digests) && nsteps)) return VIMZ_ERR_INVALID;
+  if (!chain_is_plain(p)) return vz_fail(p->ctx, VIMZ_ERR_INVALID, "vimz_prover_chain_from_digests: use vimz_prover_state_chain for this circuit");
+  const size_t jstride = p->n_jobs + p->n_fops;
+  const Fe* dg = reinterpret_cast<const Fe*>(digests);
+  for (size_t i = 0; i < nsteps * jstride; i++) if (!dg[i].is_reduced()) return vz_fail(p->ctx, VIMZ_ERR_INVALID, "vimz_prover_chain_from_digests: a digest element is not below the modulus");
+  std::vector<Fe> zs((nsteps + 1) * p->len_z, Fe::zero());
+  for (uint32_t i = 0; i < p->len_z; i++) { Fe c; memcpy(c.v, z_start + 4 * i, 32); if (!c.is_reduced()) return vz_fail(p->ctx, VIMZ_ERR_INVALID, "z_start element not below the modulus"); zs[i] = Fe::to_mont(c); }
+  if (nsteps) host_state_chain(p, step_inputs, nsteps, dg, jstride, zs);
+  for (size_t i = 0; i < zs.size(); i++) fe_to_canon(zs[i], zs_out + 4 * i);
+  return VIMZ_OK;
+}
+
+// IVC state chain only (no folding): zs_out[(nsteps+1) x len_z] canonical, starting from z_start.  Both parts on this GPU: the row
+// digests (one hash-only GPU pass, or the host pool for short inputs), then the host's chain.  A multi-GPU driver uses it — or the
+// two parts separately — to find the state at which a row segment starts.
+int vimz_prover_state_chain(vimz_prover* p, const uint64_t* z_start, const uint64_t* step_inputs, size_t nsteps, uint64_t* zs_out) {
+  if (!p || !z_start || !zs_out || (!step_inputs && nsteps)) return VIMZ_ERR_INVALID;
+  vimz_ctx* ctx = p->ctx;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  P_TRY(hipSetDevice(ctx->device));
+  const std::vector<Fe> keep = p->z_cur;
+  for (uint32_t i = 0; i < p->len_z; i++) p->z_cur[i] = fe_from_canon(z_start + 4 * i);
+  FoldJob job; job.step_inputs = step_inputs; job.nsteps = nsteps;
+  int rc = VIMZ_OK;
+  if (nsteps && chain_is_plain(p)) {
+    const size_t jstride = p->n_jobs + p->n_fops;
+    std::vector<Fe> dg(nsteps * jstride);
+    rc = compute_row_digests(p, step_inputs, nsteps, dg.data());
+    if (!rc) {
+      job.zs.assign((nsteps + 1) * p->len_z, Fe::zero());
+      for (uint32_t i = 0; i < p->len_z; i++) job.zs[i] = p->z_cur[i];
+      host_state_chain(p, step_inputs, nsteps, dg.data(), jstride, job.zs);
+    }
+  } else if (nsteps) rc = fold_prepare(p, job);      // (the stage 0 of a fold, with the ahead-of-time witness pass crop needs)
   else job.zs = p->z_cur;
   p->z_cur = keep;
   if (rc) return rc;

@@ -225,11 +225,102 @@ static void launch_spmv(vimz_prover* p, hipStream_t s, const uint32_t* z, uint32
 }
 
 // Host IVC-state chain for `rows` rows: zs[(r+1)] from zs[r] and the row hashes (phase-A job outputs) of row r.
+// The IVC state chain is the one strictly serial part of a fold (and what a sharded proof's later segments wait for): two Poseidon
+// permutations per row at contrast, ≈ 50 µs.  Most circuits' state elements are INDEPENDENT chains (contrast: the hash chain of the
+// original rows, the hash chain of the transformed rows, the constant factor): the value-only chain (no wires wanted) runs every
+// independent component on a thread of its own.  plan: components of the graph  state element i — state element k  when z_out[i]
+// reads z_in[k]; per component the phase-B jobs and field ops its outputs need, in evaluation order.
+struct ChainPlan { std::vector<std::vector<uint32_t>> outs, jobs, fops; };
+static ChainPlan chain_plan(const cb::Builder& b) {
+  const uint32_t L = b.len_z, nj = (uint32_t)b.jobs.size(), nf = (uint32_t)b.fops.size();
+  std::vector<uint32_t> dep_job(nj, 0), dep_fop(nf, 0);
+  std::vector<int> done_job(nj, 0), done_fop(nf, 0);
+  std::function<uint32_t(const ValRef&)> deps = [&](const ValRef& r) -> uint32_t {
+    switch (r.kind) {
+      case REF_ZIN: return r.idx < 32 ? 1u << r.idx : 0xffffffffu;
+      case REF_WIRE: return (r.idx > L && r.idx <= 2 * L) ? 1u << (r.idx - 1 - L) : 0u;
+      case REF_JOB: {
+        if (r.idx >= nj || b.chains[b.jobs[r.idx].chain].phase != 1) return 0u;
+        if (!done_job[r.idx]) { done_job[r.idx] = 1; uint32_t d = 0; for (uint32_t i = 0; i + 1 < b.jobs[r.idx].t; i++) d |= deps(b.jobs[r.idx].in[i]); dep_job[r.idx] = d; }
+        return dep_job[r.idx];
+      }
+      case REF_FOP: {
+        if (r.idx >= nf || b.fops[r.idx].op == FOP_LC) return 0u;
+        if (!done_fop[r.idx]) { done_fop[r.idx] = 1; const FieldOp& F = b.fops[r.idx]; uint32_t d = deps(F.a); if (F.op == FOP_MUX) d |= deps(F.b) | deps(F.c); dep_fop[r.idx] = d; }
+        return dep_fop[r.idx];
+      }
+      default: return 0u;
+    }
+  };
+  std::vector<uint32_t> parent(L);
+  for (uint32_t i = 0; i < L; i++) parent[i] = i;
+  std::function<uint32_t(uint32_t)> find = [&](uint32_t x) { return parent[x] == x ? x : parent[x] = find(parent[x]); };
+  for (uint32_t i = 0; i < L; i++) { const uint32_t d = deps(b.zout[i].ref); for (uint32_t k = 0; k < L && k < 32; k++) if ((d >> k) & 1u) parent[find(i)] = find(k); }
+  ChainPlan P;
+  std::vector<int> comp_of(L, -1);
+  for (uint32_t i = 0; i < L; i++) {
+    const uint32_t root = find(i);
+    if (comp_of[root] < 0) { comp_of[root] = (int)P.outs.size(); P.outs.emplace_back(); P.jobs.emplace_back(); P.fops.emplace_back(); }
+    P.outs[comp_of[root]].push_back(i);
+  }
+  for (size_t c = 0; c < P.outs.size(); c++) {
+    std::vector<uint8_t> need_job(nj, 0), need_fop(nf, 0);
+    std::function<void(const ValRef&)> mark = [&](const ValRef& r) {
+      if (r.kind == REF_JOB && r.idx < nj && b.chains[b.jobs[r.idx].chain].phase == 1 && !need_job[r.idx]) {
+        need_job[r.idx] = 1; for (uint32_t i = 0; i + 1 < b.jobs[r.idx].t; i++) mark(b.jobs[r.idx].in[i]);
+      } else if (r.kind == REF_FOP && r.idx < nf && b.fops[r.idx].op != FOP_LC && !need_fop[r.idx]) {
+        need_fop[r.idx] = 1; const FieldOp& F = b.fops[r.idx]; mark(F.a); if (F.op == FOP_MUX) { mark(F.b); mark(F.c); }
+      }
+    };
+    for (uint32_t i : P.outs[c]) mark(b.zout[i].ref);
+    for (auto& ch : b.chains) if (ch.phase == 1) for (uint32_t k = 0; k < ch.job_cnt; k++) if (need_job[ch.job_off + k]) P.jobs[c].push_back(ch.job_off + k);
+    for (uint32_t f = 0; f < nf; f++) if (need_fop[f]) P.fops[c].push_back(f);
+  }
+  return P;
+}
+
 // stage / jobvals (optional, head batch): also emit the wires of the state-dependent (phase-B) jobs into the row's staging area and
 // their outputs into the row's job values, so that no Poseidon work of these rows is left for the GPU.
 static void host_state_chain(const vimz_prover* p, const uint64_t* inputs, size_t rows, const Fe* jobA, size_t jstride, std::vector<Fe>& zs, size_t zs_row0 = 0,
                              Fe* stage = nullptr, size_t stage_row = 0, Fe* jobvals = nullptr) {
   const cb::Builder& b = p->circuit->build->b;
+  if (!stage && rows >= 16) {       // value-only chain: one thread per independent component that has Poseidon work
+    const ChainPlan P = chain_plan(b);
+    size_t heavy = 0;
+    for (auto& j : P.jobs) if (!j.empty()) heavy++;
+    if (heavy >= 2) {
+      auto run = [&](size_t c) {
+        HostEval ev; ev.P = p; ev.b = &b;
+        ev.job_b.assign(p->n_jobs, Fe::zero()); ev.fop.assign(p->n_fops, Fe::zero());
+        for (size_t r = 0; r < rows; r++) {
+          ev.priv = inputs + 4 * r * p->n_priv; ev.job_a = jobA + r * jstride; ev.zin = zs.data() + (zs_row0 + r) * p->len_z;
+          for (uint32_t j : P.jobs[c]) {
+            const HashJob& J = b.jobs[j];
+            Fe in[POSEIDON_MAX_T];
+            for (uint32_t i = 0; i + 1 < J.t; i++) in[i] = ev.value(J.in[i]);
+            ev.job_b[j] = cb::poseidon_hash(in, (int)J.t - 1);
+          }
+          for (uint32_t f : P.fops[c]) {
+            const FieldOp& F = b.fops[f];
+            if (F.op == FOP_ISZERO) { Fe in = ev.value(F.a); ev.fop[f] = in.is_zero() ? Fe::one() : Fe::zero(); }
+            else if (F.op == FOP_MUX) { Fe sv = ev.value(F.a), c0 = ev.value(F.b), c1 = ev.value(F.c); ev.fop[f] = Fe::add(Fe::mul(Fe::sub(c1, c0), sv), c0); }
+          }
+          Fe* zn = zs.data() + (zs_row0 + r + 1) * p->len_z;
+          for (uint32_t i : P.outs[c]) zn[i] = Fe::add(ev.value(b.zout[i].ref), cb::fe_from_i64(b.zout[i].add));
+        }
+      };
+      std::vector<std::thread> th;
+      size_t mine = P.outs.size();                   // the calling thread takes the first heavy component and all light ones
+      for (size_t c = 0; c < P.outs.size(); c++) {
+        if (P.jobs[c].empty()) continue;
+        if (mine == P.outs.size()) { mine = c; continue; }
+        th.emplace_back(run, c);
+      }
+      for (size_t c = 0; c < P.outs.size(); c++) if (P.jobs[c].empty() || c == mine) run(c);
+      for (auto& t : th) t.join();
+      return;
+    }
+  }
   HostEval ev; ev.P = p; ev.b = &b;
   for (size_t r = 0; r < rows; r++) {
     ev.priv = inputs + 4 * r * p->n_priv; ev.job_a = jobA + r * jstride; ev.zin = zs.data() + (zs_row0 + r) * p->len_z;

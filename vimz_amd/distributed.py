@@ -145,8 +145,9 @@ def fold_segments_merged(ivcs, step_inputs, z0, timings=None, merged_cls=None):
 def prove_sharded(ivcs, step_inputs, z0, rank=0, world=1, dist=None, timings=None, merged_cls=None, shm_prefix=None):
     """ONE proof object of all rows from z0 over `world` ranks (one process per GPU; BASELINE.json north_star: "independent row-folds
     shard embarrassingly across the 8 GPUs ... host-side sequential final fold; no RCCL collectives needed").  Rank r proves the r-th
-    contiguous run of rows with fold_segments_merged (len(ivcs) concurrent segments on its GPU); the runs' start states come from ONE
-    hash-only chain on rank 0, scattered; the ranks' merged proofs travel as bytes (gloo gather, or node-local shared memory when
+    contiguous run of rows with fold_segments_merged (len(ivcs) concurrent segments on its GPU); the runs' start states: every rank
+    hashes its own rows, the digests are all-gathered, each rank chains over the rows before it (circuits whose digests depend on
+    the state: one chain on rank 0, scattered); the ranks' merged proofs travel as bytes (gloo gather, or node-local shared memory when
     shm_prefix is given) and rank 0 folds them in row order (vimz_ivc_merge_merged).  Returns the proof on rank 0, None elsewhere.
     timings: state_chain_s (rank 0's chain + scatter, plus the local segments' chains), merge_s, final_fold_s."""
     import os
@@ -158,17 +159,33 @@ def prove_sharded(ivcs, step_inputs, z0, rank=0, world=1, dist=None, timings=Non
     z_start = [int(x) for x in z0]
     if world > 1:
         t0 = time.time()
-        starts = [None] * world
-        if rank == 0:
-            z = starts[0] = z_start
-            for r in range(1, world):
-                lo, hi = bounds[r - 1]
-                if hi > lo:
-                    z = _ints(ivcs[0].state_chain(z, step_inputs[lo:hi])[-1])
-                starts[r] = z
-        out = [None]
-        dist.scatter_object_list(out, starts if rank == 0 else None, src=0)
-        z_start = out[0]
+        stride = ivcs[0].digest_stride() if hasattr(ivcs[0], "digest_stride") else 0
+        if stride:
+            # the chain in its two parts: every rank hashes ITS rows (the expensive, state-independent part: one GPU pass, side by
+            # side on all GPUs), the digests are exchanged (a few hundred KB), and rank r runs the serial part — two or three small
+            # permutations per row on the host — over the rows of the ranks before it.  (Rank 0 hashing everybody's rows on its GPU
+            # cost 138 µs per row at 8K: 260 ms before the last of eight ranks could start a 650 ms fold.)
+            lo, hi = bounds[rank]
+            mine = np.ascontiguousarray(ivcs[0].row_digests(step_inputs[lo:hi])) if hi > lo else np.zeros((0, stride, 4), dtype=np.uint64)
+            allg = [None] * world
+            dist.all_gather_object(allg, mine.tobytes())
+            for r in range(rank):
+                plo, phi = bounds[r]
+                if phi > plo:
+                    dg = np.frombuffer(allg[r], dtype=np.uint64).reshape(phi - plo, stride, 4)
+                    z_start = _ints(ivcs[0].chain_from_digests(z_start, step_inputs[plo:phi], dg)[-1])
+        else:
+            starts = [None] * world
+            if rank == 0:
+                z = starts[0] = z_start
+                for r in range(1, world):
+                    lo, hi = bounds[r - 1]
+                    if hi > lo:
+                        z = _ints(ivcs[0].state_chain(z, step_inputs[lo:hi])[-1])
+                    starts[r] = z
+            out = [None]
+            dist.scatter_object_list(out, starts if rank == 0 else None, src=0)
+            z_start = out[0]
         if timings is not None:
             timings["state_chain_s"] = timings.get("state_chain_s", 0.0) + time.time() - t0
     lo, hi = bounds[rank]

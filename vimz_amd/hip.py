@@ -437,6 +437,33 @@ class IVC:
         self.ctx._chk(lib.vimz_ivc_state_chain(self.h, _ptr(z), _ptr(a), n, _ptr(out)))
         return out
 
+    def digest_stride(self):
+        """Elements per row of row_digests' output; 0 when this circuit's digests depend on the state (crop)."""
+        lib = self.ctx.lib
+        lib.vimz_ivc_digest_stride.argtypes = [C.c_void_p]
+        lib.vimz_ivc_digest_stride.restype = C.c_size_t
+        return int(lib.vimz_ivc_digest_stride(self.h))
+
+    def row_digests(self, inputs):
+        """Part (1) of the state chain: the state-independent row hashes of `inputs` ((n, stride, 4) uint64, opaque).  Any GPU can
+        compute them for any rows: the ranks of a sharded proof hash their own rows side by side."""
+        a = _u64(inputs).reshape(-1, self.circuit.n_priv, 4)
+        out = np.zeros((a.shape[0], self.digest_stride(), 4), dtype=np.uint64)
+        lib = self.ctx.lib
+        lib.vimz_ivc_row_digests.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        self.ctx._chk(lib.vimz_ivc_row_digests(self.h, _ptr(a), a.shape[0], _ptr(out)))
+        return out
+
+    def chain_from_digests(self, z_start, inputs, digests):
+        """Part (2): the serial chain over rows whose digests are known (host only); returns (n + 1, len_z, 4) states."""
+        a = _u64(inputs).reshape(-1, self.circuit.n_priv, 4)
+        d = np.ascontiguousarray(digests, dtype=np.uint64).reshape(a.shape[0], -1, 4)
+        out = np.zeros((a.shape[0] + 1, self.circuit.len_z, 4), dtype=np.uint64)
+        lib = self.ctx.lib
+        lib.vimz_ivc_chain_from_digests.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        self.ctx._chk(lib.vimz_ivc_chain_from_digests(self.h, _ptr(_zlimbs(z_start, self.circuit.len_z)), _ptr(a), _ptr(d), a.shape[0], _ptr(out)))
+        return out
+
     def profile(self):
         s = (C.c_double * 8)()
         n = (C.c_uint64 * 8)()
