@@ -98,9 +98,9 @@ def _ints(limbs):
 def fold_segments_merged(ivcs, step_inputs, z0, timings=None, merged_cls=None):
     """ONE proof of all rows from state z0 on one GPU: len(ivcs) contiguous row segments, each folded as a Nova IVC by its own prover
     (own context = own streams, own host thread), then merged in row order (vimz_ivc_merge: out-of-circuit NIFS on both curves).
-    Segment j starts at the state segment j-1 ends in; that state comes from the hash-only chain over segment j-1's rows, computed by
-    prover j on ITS context while the earlier segments are already folding (so the chains cost a staggered start, not a serial
-    prologue).  Returns the MergedProof (its verifier key is ivcs[0]: keep the IVCs open while it is in use).
+    Segment j starts at the state segment j-1 ends in; that state comes from the hash-only chain over segment j-1's rows: the row
+    digests of all but the last segment are computed at once, each by its successor's prover on ITS context, while segment 0
+    already folds; only the short host chains over them are serial (a staggered start, not a serial prologue).  Returns the MergedProof (its verifier key is ivcs[0]: keep the IVCs open while it is in use).
     timings (optional dict): state_chain_s (host view, summed), merge_s."""
     import time
     from concurrent.futures import ThreadPoolExecutor
@@ -112,14 +112,22 @@ def fold_segments_merged(ivcs, step_inputs, z0, timings=None, merged_cls=None):
     bounds = segment_bounds(n, len(used))
     t_chain = 0.0
     z = [int(x) for x in z0]
-    with ThreadPoolExecutor(max(1, len(used))) as ex:
-        futs = []
+    two_part = len(used) > 1 and all(hasattr(ivcs[j], "digest_stride") for j in used) and ivcs[used[0]].digest_stride() > 0
+    with ThreadPoolExecutor(2 * max(1, len(used))) as ex:
+        futs, dig = [], {}
+        if two_part:      # the row hashes of segments 0 .. S-2, each on its successor's context, all at once: only the chains are serial
+            for k in range(len(used) - 1):
+                lo, hi = bounds[k]
+                dig[k] = ex.submit(ivcs[used[k + 1]].row_digests, step_inputs[lo:hi])
         for k, j in enumerate(used):
             lo, hi = bounds[k]
             if k > 0:
                 t0 = time.time()
                 plo, phi = bounds[k - 1]
-                z = _ints(ivcs[j].state_chain(z, step_inputs[plo:phi])[-1])
+                if two_part:
+                    z = _ints(ivcs[j].chain_from_digests(z, step_inputs[plo:phi], dig[k - 1].result())[-1])
+                else:
+                    z = _ints(ivcs[j].state_chain(z, step_inputs[plo:phi])[-1])
                 t_chain += time.time() - t0
             ivcs[j].reset(z)
             futs.append(ex.submit(ivcs[j].fold, step_inputs[lo:hi]))
