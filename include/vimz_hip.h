@@ -329,6 +329,13 @@ void vimz_ivc_merged_free(vimz_ivc_merged* m);
 int vimz_ivc_merge(vimz_ivc_merged* m, vimz_ivc* next_segment);
 /* the same for two merged proofs of adjacent runs of segments (e.g. one per GPU, brought over with vimz_ivc_merged_save / _load) */
 int vimz_ivc_merge_merged(vimz_ivc_merged* m, vimz_ivc_merged* next);
+/* fold_input in ONE call (folding.rs:27-43): `nsteps` rows from state z0 proven as n_segments contiguous segments — segment k by
+ * segments[k]: IVCs of the same circuits, each on a context of its own on one device; they are reset by this call —, folded concurrently
+ * (a host thread each) and merged into one object.  The segments' start states come from the state chain in its two parts: the row
+ * digests of all but the last segment at once, each on its successor's context, then short serial host chains.
+ * seconds (optional) = {waiting for start states, merge, total}. */
+int vimz_ivc_fold_segments(vimz_ivc* const* segments, size_t n_segments, const uint64_t* z0, const uint64_t* step_inputs, size_t nsteps,
+                           vimz_ivc_merged** out, double seconds[3]);
 /* RecursiveSNARK::verify(pp, num_steps, z0) for the merged object.  result: 0 = accepted; bit 0 / 1 a segment's primary / secondary chain
  * hash; bit 2 primary relaxed relation; bit 3 / 4 primary comm_W / comm_E; bit 5 secondary relation; bit 6 / 7 secondary comm_W / comm_E;
  * bit 10 public entries of a witness vector differ from the instance; bit 11 kept running products (bookkeeping for further merges);

@@ -3,6 +3,7 @@
 // BASELINE.json's north_star shards a proof by row segments with a "host-side sequential final fold": this is that fold for IVC
 // proofs — relaxed + relaxed NIFS on both curves of the cycle, the cross terms and the folds of the witness vectors on the GPU
 // (k_cross_term, the Pippenger MSM, k_fold5), the instance arithmetic and the SHA3 hash tree on the host.
+#include <thread>
 #include "ivc_internal.hpp"
 #include "proof_io.hpp"
 #include "merge_internal.hpp"
@@ -554,6 +555,68 @@ int vimz_ivc_merged_verify(vimz_ivc_merged* m, uint64_t num_steps, const uint64_
     if (!e[0].eq(R.Q.u) || !e[1].eq(R.Q.X0) || !e[2].eq(R.Q.X1)) res |= 1024;
   }
   *result = res;
+  return VIMZ_OK;
+}
+
+// fold_input in ONE call (vimz/src/nova_snark_backend/folding.rs:27-43): the rows are proven as n_seg contiguous segments — segment k
+// by segs[k], IVCs of the same circuits on their own contexts of one device, reset by this call —, folded concurrently from a thread
+// each and merged into ONE object.  Segment k starts at the state segment k−1 ends in: the row digests of all but the last segment
+// are computed at once (each on its successor's context) while segment 0 already folds; only the short host chains are serial.
+// seconds (optional) = {waiting for start states, merge, total}.  Segments that get no rows (nsteps < n_seg) are left out.
+int vimz_ivc_fold_segments(vimz_ivc* const* segs, size_t n_seg, const uint64_t* z0, const uint64_t* step_inputs, size_t nsteps, vimz_ivc_merged** out, double seconds[3]) {
+  if (!segs || !n_seg || !z0 || !out || !step_inputs || !nsteps) return VIMZ_ERR_INVALID;
+  for (size_t k = 0; k < n_seg; k++) if (!segs[k]) return VIMZ_ERR_INVALID;
+  vimz_ctx* ctx = segs[0]->ctx;
+  for (size_t k = 1; k < n_seg; k++) {
+    if (!same_shapes(segs[0], segs[k])) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_ivc_fold_segments: the segments' IVCs must be of the same circuits and on the same device");
+    for (size_t j = 0; j < k; j++) if (segs[j]->ctx == segs[k]->ctx) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_ivc_fold_segments: every segment needs a context of its own");
+  }
+  const double t_all = now_s();
+  const size_t S = std::min(n_seg, nsteps), base = nsteps / S, rem = nsteps % S;
+  std::vector<size_t> lo(S), hi(S);
+  for (size_t k = 0, at = 0; k < S; k++) { lo[k] = at; at += base + (k < rem ? 1 : 0); hi[k] = at; }
+  const size_t n_priv = segs[0]->pri->n_priv, lz = segs[0]->pri->len_z;
+  const size_t stride = vimz_ivc_digest_stride(segs[0]);
+  std::vector<int> rc_fold(S, VIMZ_OK), rc_dig(S, VIMZ_OK);
+  std::vector<std::vector<uint64_t>> dig(S);
+  std::vector<std::thread> th_dig, th_fold;
+  if (stride && S > 1)
+    for (size_t k = 0; k + 1 < S; k++) {
+      dig[k].resize(4 * stride * (hi[k] - lo[k]));
+      th_dig.emplace_back([&, k] { rc_dig[k] = vimz_ivc_row_digests(segs[k + 1], step_inputs + 4 * n_priv * lo[k], hi[k] - lo[k], dig[k].data()); });
+    }
+  std::vector<uint64_t> z(z0, z0 + 4 * lz), zs;
+  double t_chain = 0;
+  int rc = VIMZ_OK;
+  size_t started = 0;
+  for (size_t k = 0; k < S && !rc; k++) {
+    if (k > 0) {
+      const double t0 = now_s();
+      const size_t n = hi[k - 1] - lo[k - 1];
+      zs.assign(4 * lz * (n + 1), 0);
+      if (stride) {
+        th_dig[k - 1].join();
+        rc = rc_dig[k - 1];
+        if (!rc) rc = vimz_ivc_chain_from_digests(segs[k], z.data(), step_inputs + 4 * n_priv * lo[k - 1], dig[k - 1].data(), n, zs.data());
+      } else rc = vimz_ivc_state_chain(segs[k], z.data(), step_inputs + 4 * n_priv * lo[k - 1], n, zs.data());
+      if (rc) { if (segs[k]->ctx != ctx) ctx->err = segs[k]->ctx->err; break; }
+      z.assign(zs.end() - 4 * lz, zs.end());
+      t_chain += now_s() - t0;
+    }
+    if ((rc = vimz_ivc_reset(segs[k], z.data()))) break;
+    th_fold.emplace_back([&, k] { rc_fold[k] = vimz_ivc_fold(segs[k], step_inputs + 4 * n_priv * lo[k], hi[k] - lo[k]); });
+    started = k + 1;
+  }
+  for (auto& t : th_fold) t.join();
+  for (size_t k = 0; k < th_dig.size(); k++) if (th_dig[k].joinable()) th_dig[k].join();
+  for (size_t k = 0; k < started && !rc; k++) if (rc_fold[k]) { rc = rc_fold[k]; if (segs[k]->ctx != ctx) ctx->err = segs[k]->ctx->err; }
+  if (rc) return rc;
+  const double t_m = now_s();
+  vimz_ivc_merged* m = nullptr;
+  if ((rc = vimz_ivc_merged_create(segs[0], &m))) return rc;
+  for (size_t k = 1; k < S; k++) if ((rc = vimz_ivc_merge(m, segs[k]))) { vimz_ivc_merged_free(m); return rc; }
+  if (seconds) { seconds[0] = t_chain; seconds[1] = now_s() - t_m; seconds[2] = now_s() - t_all; }
+  *out = m;
   return VIMZ_OK;
 }
 

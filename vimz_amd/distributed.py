@@ -106,6 +106,12 @@ def fold_segments_merged(ivcs, step_inputs, z0, timings=None, merged_cls=None):
     from concurrent.futures import ThreadPoolExecutor
     if merged_cls is None:
         from .hip import MergedProof as merged_cls
+        if len(step_inputs) and all(hasattr(v, "h") for v in ivcs):       # the library's own fold_input: the same sequence in one C call
+            merged, t = merged_cls.fold_segments(ivcs, step_inputs, z0)
+            if timings is not None:
+                timings["state_chain_s"] = timings.get("state_chain_s", 0.0) + t["state_chain_s"]
+                timings["merge_s"] = timings.get("merge_s", 0.0) + t["merge_s"]
+            return merged
     MergedProof = merged_cls
     n = len(step_inputs)
     used = [j for j, (lo, hi) in enumerate(segment_bounds(n, len(ivcs))) if hi > lo]

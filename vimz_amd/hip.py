@@ -576,6 +576,22 @@ class MergedProof:
         return m
 
     @classmethod
+    def fold_segments(cls, ivcs, step_inputs, z0):
+        """vimz_ivc_fold_segments: fold_input in one call — the rows as len(ivcs) concurrent segments (own context each), merged.
+        Returns (MergedProof, {"state_chain_s", "merge_s", "total_s"}); its verifier key is ivcs[0]."""
+        vk = ivcs[0]
+        lib = vk.ctx.lib
+        lib.vimz_ivc_fold_segments.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_double)]
+        a = _u64(step_inputs).reshape(-1, vk.circuit.n_priv, 4)
+        arr = (C.c_void_p * len(ivcs))(*[v.h for v in ivcs])
+        h = C.c_void_p()
+        sec = (C.c_double * 3)()
+        vk.ctx._chk(lib.vimz_ivc_fold_segments(arr, len(ivcs), _ptr(_zlimbs(z0, vk.circuit.len_z)), _ptr(a), a.shape[0], C.byref(h), sec))
+        m = cls.__new__(cls)
+        cls.__init__(m, _handle=h, _vk=vk)
+        return m, {"state_chain_s": sec[0], "merge_s": sec[1], "total_s": sec[2]}
+
+    @classmethod
     def load(cls, vk, blob):
         """vimz_ivc_merged_load: `vk` = an IVC for the same step circuit and keys (its state is not touched)."""
         b = np.ascontiguousarray(blob, dtype=np.uint8)
