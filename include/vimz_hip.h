@@ -322,7 +322,8 @@ int vimz_ivc_verify_compressed(vimz_ivc* v, const uint8_t* blob, size_t len, uin
  *      segments' hash checks, their adjacency and the fold tree from the records, then checks ONE primary and ONE secondary relaxed
  *      instance (or one compressed argument each).  The cross terms, their commitments and the vector folds run on the GPU. -------- */
 typedef struct vimz_ivc_merged vimz_ivc_merged;
-/* the merged proof of one segment; `segment` is left unchanged, supplies shapes / keys / context and must outlive the object */
+/* the merged proof of one segment; `segment` is left unchanged and supplies shapes / keys / context: keep it alive while the object is
+ * in use (freeing it first orphans the object: its buffers are released, every later call on it fails, freeing it stays safe) */
 int vimz_ivc_merged_create(vimz_ivc* segment, vimz_ivc_merged** out);
 void vimz_ivc_merged_free(vimz_ivc_merged* m);
 /* fold the proof of the NEXT row segment in (same device; read in place, left unchanged): it must start at the state m ends in */

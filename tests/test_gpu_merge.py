@@ -299,3 +299,50 @@ def test_crop_has_no_state_independent_digests(ctx):
             v.row_digests(np.zeros((1, circuit.n_priv, 4), dtype=np.uint64))
     finally:
         v.close(); params.free()
+
+
+def test_fold_segments_in_one_call_edge_cases(ctx, keys, oracle):
+    """vimz_ivc_fold_segments: fewer rows than segments (the spare IVCs are left out), the same object as the hand-made sequence
+    (state chain, reset, fold, create, merge) gives, two segments on one context refused, an unsatisfiable row reported as such and
+    no object returned."""
+    from vimz_amd import hip
+    ck1, ck2 = keys
+    c = Circuit.for_resolution("grayscale", "HD")
+    z0, inputs = step_inputs("grayscale")
+    rows = np.stack(inputs)
+    cx = [ctx, hip.Context(0), hip.Context(0)]
+    ivcs = [hip.IVC(c_, c, ck1, ck2, max_batch=4) for c_ in cx]
+    objs = []
+    try:
+        m2, t = hip.MergedProof.fold_segments(ivcs, rows[:2], z0); objs.append(m2)
+        assert m2.info()["segments"] == 2 and m2.verify(2, z0) == 0 and set(t) == {"state_chain_s", "merge_s", "total_s"}
+        m, _ = hip.MergedProof.fold_segments(ivcs, rows, z0); objs.append(m)
+        assert m.verify(10, z0) == 0 and m.info()["segments"] == 3
+        # the same by hand
+        hand = [hip.IVC(c_, c, ck1, ck2, max_batch=4) for c_ in cx]
+        z, cuts = list(z0), [0, 4, 7, 10]
+        for k, v in enumerate(hand):
+            v.reset(z); v.fold(rows[cuts[k]:cuts[k + 1]]); z = v.state()[0]
+        mh = hip.MergedProof.of(hand); objs.append(mh)
+        assert (mh.records() == m.records()).all()                     # same segments, same commitments, same challenges
+        for v in hand:
+            v.close()
+        # its verifier key (hand[0]) is gone: the object is orphaned — calls on it fail cleanly, closing it is safe
+        with pytest.raises(_lib.VimzError):
+            mh.info()
+        assert mh.verify(10, z0) == 8192
+        with pytest.raises(_lib.VimzError):
+            hip.MergedProof.fold_segments([ivcs[0], ivcs[0]], rows, z0)
+        bad = rows.copy(); bad[8, 200, 0] ^= np.uint64(0xFF)
+        with pytest.raises(_lib.VimzError) as e:
+            hip.MergedProof.fold_segments(ivcs, bad, z0)
+        assert e.value.code == _lib.ERR_UNSAT
+        m3, _ = hip.MergedProof.fold_segments(ivcs, rows, z0); objs.append(m3)       # the provers are usable afterwards
+        assert m3.verify(10, z0) == 0
+    finally:
+        for o in objs:
+            o.close()
+        for v in ivcs:
+            v.close()
+        for c_ in cx[1:]:
+            c_.close()

@@ -461,6 +461,7 @@ extern "C" {
 
 void vimz_ivc_free(vimz_ivc* v) {
   if (!v) return;
+  if (v->orphan_merged) v->orphan_merged(v);
   if (v->spartan_free) v->spartan_free(v);
   if (v->pri) vimz_prover_free(v->pri);
   if (v->ctx) {

@@ -94,6 +94,10 @@ struct vimz_ivc {
   // one set of a merged proof's buffers (merge.hip) kept from the last one that was freed: the next vimz_ivc_merged_create over this
   // IVC needs no allocation (device + pinned: 0.5-2 ms next to running kernels, inside a timed fold_input)
   uint32_t* merged_spare_dev = nullptr; void* merged_spare_pin = nullptr;
+  // the merged proofs that use this IVC as their verifier key: freeing the IVC first orphans them (their buffers are released, every
+  // later call on them fails cleanly) instead of leaving them with a dangling pointer
+  std::vector<struct vimz_ivc_merged*> merged_dependents;
+  void (*orphan_merged)(vimz_ivc*) = nullptr;
   // CompressedSNARK (spartan.hip): transposed shapes, scratch — built on first use, released with the IVC
   void* spartan_cache = nullptr; void (*spartan_free)(vimz_ivc*) = nullptr;
 };

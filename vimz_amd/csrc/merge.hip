@@ -95,13 +95,31 @@ void release_buffers(vimz_ivc_merged* m) {
   else { if (m->dev) hipFree(m->dev); if (m->pin) hipHostFree(m->pin); }
   m->dev = nullptr; m->pin = nullptr;
 }
-struct MergedDrop { void operator()(vimz_ivc_merged* m) const { if (!m) return; release_buffers(m); delete m; } };
+void unregister_merged(vimz_ivc_merged* m) {
+  if (!m->vk) return;
+  auto& d = m->vk->merged_dependents;
+  d.erase(std::remove(d.begin(), d.end(), m), d.end());
+}
+// vimz_ivc_free of a verifier key that still has merged proofs: they lose their buffers and their key (every later call fails cleanly)
+void orphan_dependents(vimz_ivc* v) {
+  std::lock_guard<std::mutex> g(v->ctx->mu);
+  hipSetDevice(v->ctx->device);
+  hipStreamSynchronize(v->ctx->stream);
+  for (vimz_ivc_merged* m : v->merged_dependents) {
+    if (m->dev) hipFree(m->dev);
+    if (m->pin) hipHostFree(m->pin);
+    m->dev = nullptr; m->pin = nullptr; m->vk = nullptr; m->broken = true;
+  }
+  v->merged_dependents.clear();
+}
+struct MergedDrop { void operator()(vimz_ivc_merged* m) const { if (!m) return; unregister_merged(m); release_buffers(m); delete m; } };
 typedef std::unique_ptr<vimz_ivc_merged, MergedDrop> MergedPtr;
 
 int merged_alloc(vimz_ivc* vk, MergedPtr& m) {
   vimz_ctx* ctx = vk->ctx;
   m.reset(new vimz_ivc_merged());
   m->vk = vk;
+  vk->merged_dependents.push_back(m.get()); vk->orphan_merged = orphan_dependents;
   const size_t nw1 = vk->pri->n_wires, nc1 = vk->pri->n_c, nw2 = vk->sec.n_w, nc2 = vk->sec.n_c;
   if (vk->merged_spare_dev) { m->dev = vk->merged_spare_dev; m->pin = vk->merged_spare_pin; vk->merged_spare_dev = nullptr; vk->merged_spare_pin = nullptr; }
   else P_TRY(hipMalloc((void**)&m->dev, 32 * merged_words(vk)));
@@ -264,6 +282,7 @@ void vimz_ivc_merged_free(vimz_ivc_merged* m) {
   if (!m) return;
   if (m->vk && m->vk->ctx) {
     std::lock_guard<std::mutex> g(m->vk->ctx->mu);
+    unregister_merged(m);
     hipSetDevice(m->vk->ctx->device);
     hipStreamSynchronize(m->vk->ctx->stream);
     if (m->vk->s2) hipStreamSynchronize(m->vk->s2);
@@ -306,7 +325,7 @@ int vimz_ivc_merged_create(vimz_ivc* v, vimz_ivc_merged** out) {
 // Node(m, Leaf(next)): the proof of the next row segment is folded into the merged proof.  `next` is read in place and left unchanged
 // (it may go on folding); it must start at the state the merged proof ends in, be of the same circuits and sit on the same device.
 int vimz_ivc_merge(vimz_ivc_merged* m, vimz_ivc* next) {
-  if (!m || !next) return VIMZ_ERR_INVALID;
+  if (!m || !next || !m->vk) return VIMZ_ERR_INVALID;
   vimz_ivc* vk = m->vk; vimz_ctx* ctx = vk->ctx;
   if (!same_shapes(vk, next)) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_ivc_merge: the segment is of other circuits or on another device (export it and use vimz_ivc_merged_load there)");
   if (next->i == 0 || next->broken || next->pending_sec) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_ivc_merge: the incoming IVC has folded nothing or is not at rest");
@@ -332,7 +351,7 @@ int vimz_ivc_merge(vimz_ivc_merged* m, vimz_ivc* next) {
 
 // Node(m, other): two merged proofs (of adjacent runs of segments) become one.  `other` is left unchanged.
 int vimz_ivc_merge_merged(vimz_ivc_merged* m, vimz_ivc_merged* other) {
-  if (!m || !other || m == other) return VIMZ_ERR_INVALID;
+  if (!m || !other || m == other || !m->vk || !other->vk) return VIMZ_ERR_INVALID;
   vimz_ivc* vk = m->vk; vimz_ctx* ctx = vk->ctx;
   if (!same_shapes(vk, other->vk)) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_ivc_merge_merged: the proofs are of other circuits or on another device");
   TwoLocks lk(ctx, other->vk->ctx);
@@ -348,7 +367,7 @@ int vimz_ivc_merge_merged(vimz_ivc_merged* m, vimz_ivc_merged* other) {
 
 // info: steps, segments, ops, len_z, primary wires, primary constraints, secondary wires, secondary constraints
 int vimz_ivc_merged_info(const vimz_ivc_merged* m, uint64_t info[8]) {
-  if (!m || !info) return VIMZ_ERR_INVALID;
+  if (!m || !info || !m->vk) return VIMZ_ERR_INVALID;
   const vimz_ivc* vk = m->vk;
   std::lock_guard<std::mutex> g(vk->ctx->mu);
   info[0] = m->acc.n; info[1] = m->segs.size(); info[2] = m->ops.size(); info[3] = vk->pri->len_z;
@@ -356,7 +375,7 @@ int vimz_ivc_merged_info(const vimz_ivc_merged* m, uint64_t info[8]) {
   return VIMZ_OK;
 }
 int vimz_ivc_merged_state(const vimz_ivc_merged* m, uint64_t* z_start, uint64_t* z_end, uint64_t* steps) {
-  if (!m) return VIMZ_ERR_INVALID;
+  if (!m || !m->vk) return VIMZ_ERR_INVALID;
   std::lock_guard<std::mutex> g(m->vk->ctx->mu);
   const uint32_t lz = m->vk->pri->len_z;
   if (z_start) for (uint32_t k = 0; k < lz; k++) fe_to_canon(m->acc.zs[k], z_start + 4 * k);
@@ -373,7 +392,7 @@ int vimz_ivc_merged_profile(const vimz_ivc_merged* m, double seconds[4]) {
 // The statement part of the proof — header, segment records, ops (with the cross-term commitments) — as canonical little-endian words:
 // what a verifier replays.  Returns the size in bytes (copies when buf is large enough).
 int64_t vimz_ivc_merged_records(const vimz_ivc_merged* m, void* buf, size_t cap) {
-  if (!m) return VIMZ_ERR_INVALID;
+  if (!m || !m->vk) return VIMZ_ERR_INVALID;
   std::lock_guard<std::mutex> g(m->vk->ctx->mu);        // (a merge on another thread grows the records)
   const size_t bytes = 8 * records_words(m);
   if (buf && cap >= bytes) { Writer w; write_records(m, w); if (8 * w.w.size() != bytes) return VIMZ_ERR_INVALID; memcpy(buf, w.w.data(), bytes); }
@@ -382,7 +401,7 @@ int64_t vimz_ivc_merged_records(const vimz_ivc_merged* m, void* buf, size_t cap)
 
 // side 0 / 1; what = VIMZ_IX_RUNNING_Z, VIMZ_IX_RUNNING_E (canonical vectors), VIMZ_IX_INSTANCE (comm_W, comm_E, u, X0, X1: 7 canonical elements)
 int64_t vimz_ivc_merged_export(vimz_ivc_merged* m, int side, int what, void* buf, size_t cap) {
-  if (!m || (side != 0 && side != 1)) return VIMZ_ERR_INVALID;
+  if (!m || !m->vk || (side != 0 && side != 1)) return VIMZ_ERR_INVALID;
   vimz_ivc* vk = m->vk; vimz_ctx* ctx = vk->ctx;
   if (what == VIMZ_IX_INSTANCE) {
     Writer w;
@@ -408,12 +427,13 @@ int64_t vimz_ivc_merged_export(vimz_ivc_merged* m, int side, int what, void* buf
 
 // The proof as bytes (for a verifier or a merging rank in another process): records ‖ Zp ‖ Ep ‖ Zq ‖ Eq (vectors as Montgomery limbs).
 size_t vimz_ivc_merged_size(const vimz_ivc_merged* m) {
-  if (!m) return 0;
+  if (!m || !m->vk) return 0;
   const vimz_ivc* vk = m->vk;
   return 8 * records_words(m) + 32 * ((size_t)vk->pri->n_wires + vk->pri->n_c + vk->sec.n_w + vk->sec.n_c);
 }
 int vimz_ivc_merged_save(vimz_ivc_merged* m, uint8_t* blob, size_t cap) {
-  if (!m || !blob || cap < vimz_ivc_merged_size(m)) return vz_fail(m ? m->vk->ctx : nullptr, VIMZ_ERR_INVALID, "vimz_ivc_merged_save: buffer too small");
+  if (!m || !m->vk) return VIMZ_ERR_INVALID;
+  if (!blob || cap < vimz_ivc_merged_size(m)) return vz_fail(m->vk->ctx, VIMZ_ERR_INVALID, "vimz_ivc_merged_save: buffer too small");
   vimz_ivc* vk = m->vk; vimz_ctx* ctx = vk->ctx;
   Writer w; write_records(m, w);
   memcpy(blob, w.w.data(), 8 * w.w.size());
@@ -486,6 +506,7 @@ int vimz_ivc_merged_load(vimz_ivc* vk, const uint8_t* blob, size_t len, vimz_ivc
 // the proof); bit 12 the statement: total steps, initial state, or segments not adjacent; bit 13 malformed.
 int vimz_ivc_merged_verify(vimz_ivc_merged* m, uint64_t num_steps, const uint64_t* z0, uint32_t* result) {
   if (!m || !z0 || !result) return VIMZ_ERR_INVALID;
+  if (!m->vk) { *result = 8192; return VIMZ_OK; }      // its verifier key was freed: nothing left to check against
   vimz_ivc* vk = m->vk; vimz_ctx* ctx = vk->ctx; vimz_prover* p = vk->pri;
   const SecDev& S = vk->sec;
   uint32_t res = 0;

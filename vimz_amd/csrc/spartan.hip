@@ -755,14 +755,14 @@ static const uint64_t CMERGED_MAGIC = 0x31474d43565aull;   // "ZVCMG1"
 static size_t arg_words(size_t s, size_t t, bool e) { return 4 * (3 * s + 4 + 2 * t + 1) + 4 * (4 * t + 1) + (e ? 4 * (4 * s + 1) : 0); }
 
 size_t vimz_ivc_merged_compressed_size(const vimz_ivc_merged* m) {
-  if (!m) return 0;
+  if (!m || !m->vk) return 0;
   const vimz_ivc* v = m->vk;
   const uint32_t s1 = ceil_log2(v->pri->n_c), t1 = ceil_log2(v->pri->n_wires), s2 = ceil_log2(v->sec.n_c), t2 = ceil_log2(v->sec.n_w);
   return 8 * (2 + records_words(m) + arg_words(s1, t1, true) + arg_words(s2, t2, true));
 }
 
 int vimz_ivc_merged_compress(vimz_ivc_merged* m, uint8_t* blob, size_t cap, double seconds[2]) {
-  if (!m || !blob) return VIMZ_ERR_INVALID;
+  if (!m || !blob || !m->vk || m->broken) return VIMZ_ERR_INVALID;
   vimz_ivc* v = m->vk; vimz_ctx* ctx = v->ctx;
   if (cap < vimz_ivc_merged_compressed_size(m)) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_ivc_merged_compress: buffer too small");
   double t0 = now_s();
