@@ -459,19 +459,35 @@ __global__ void __launch_bounds__(256) k_reduce(const uint32_t* __restrict__ par
 // SLOWER: 0.251 vs 0.187 ms at 7.7 k points, 0.167 vs 0.145 ms for one chunk: the accumulation phase does not get shorter with a second
 // wave per SIMD, and the segment tree grows.)
 constexpr uint32_t SMALL_THREADS = 256;
-constexpr uint32_t SMALL_NBW = 1u << (SMALL_C - 1), SMALL_SUB = 8, SMALL_PER_THREAD = SMALL_CHUNK / SMALL_THREADS;
+constexpr uint32_t SMALL_NBW = 1u << (SMALL_C - 1), SMALL_SUB = 8 /* longest sub-bucket */, SMALL_PER_THREAD = SMALL_CHUNK / SMALL_THREADS;
 static_assert(SMALL_CHUNK / SMALL_SUB + SMALL_NBW <= SMALL_THREADS, "one thread per sub-bucket");
+static_assert(SMALL_NBW == 64, "k_msm_small scans the buckets of a window with one wave");
 // (1536 points per workgroup: at most 1536/8 + 64 = 256 sub-buckets, one per thread; 7.6 k points -> 37 x 5 = 185 workgroups,
 //  fewer than the 256 CUs, so no two workgroups' single-wave scan phases share a SIMD)
 
-__device__ __forceinline__ int signed_digit(const uint32_t* s, int c, int w) {
-  uint32_t carry = 0, d = 0;
-  const uint32_t half = 1u << (c - 1);
-  for (int j = 0; j <= w; j++) {
-    d = window_bits(s, j * c, c) + carry;
-    carry = d > half;
+// Signed digit w of a scalar WITHOUT walking the carries of the windows below it (a workgroup of the fused kernels owns one window):
+// the recoding's digits lie in [-(half-1), half], so the carry into window w is 1 exactly when the low c·w bits exceed what w digits
+// can hold without one,  T_w = Σ_{j<w} half·2^(cj)  (bit c-1 of every lower window) — one masked 256-bit comparison.
+// (The walk cost ~1 µs per window below w: the top windows of k_msm_small started their accumulation 40 µs after window 0.)
+template <int C>
+struct DigitThreshold {
+  uint32_t w[8];
+  constexpr DigitThreshold() : w{} { for (int p = C - 1; p < 256; p += C) w[p >> 5] |= 1u << (p & 31); }
+};
+template <int C>
+__device__ __forceinline__ int signed_digit(const uint32_t* s, int w) {
+  constexpr DigitThreshold<C> T{};
+  const int lo = C * w;
+  uint32_t br = 0;                                       // borrow of T_w − (s mod 2^lo)
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const int nb = lo - 32 * i;
+    const uint32_t m = nb >= 32 ? 0xffffffffu : nb <= 0 ? 0u : (1u << nb) - 1u;
+    const uint64_t d = (uint64_t)(T.w[i] & m) - (uint64_t)(s[i] & m) - br;
+    br = (uint32_t)(d >> 63);
   }
-  return d > half ? (int)d - (1 << c) : (int)d;
+  const uint32_t d = window_bits(s, lo, C) + br;
+  return d > (1u << (C - 1)) ? (int)d - (1 << C) : (int)d;
 }
 
 template <class S, class F>
@@ -501,16 +517,29 @@ __global__ void __launch_bounds__(SMALL_THREADS) k_msm_small(const uint32_t* __r
     if (i < hi) {
       uint32_t sc[8];
       if (load_scalar<S>(scalars, i, mont, 0, sc)) {
-        dig[k] = signed_digit(sc, SMALL_C, (int)w);
+        dig[k] = signed_digit<SMALL_C>(sc, (int)w);
         if (dig[k]) atomicAdd(&cnt[(dig[k] < 0 ? -dig[k] : dig[k]) - 1], 1u);
       }
     }
   }
   __syncthreads();
-  if (t == 0) {
-    uint32_t e = 0, sb = 0, mx = 0;
-    for (uint32_t b = 0; b < SMALL_NBW; b++) { off[b] = e; soff[b] = sb; const uint32_t m = (cnt[b] + SMALL_SUB - 1) / SMALL_SUB; e += cnt[b]; sb += m; mx = m > mx ? m : mx; }
-    off[SMALL_NBW] = e; soff[SMALL_NBW] = sb; s_maxm = mx;
+  if (t < 64) {
+    // Wave 0, one lane per bucket: the sub-bucket length is the SHORTEST (4..8) whose sub-buckets still get a thread each — the
+    // accumulation below is that many dependent mixed additions on every wave of the workgroup (≈4.7 µs each) — and a bucket's
+    // entries are spread evenly over its sub-buckets.  (8 always fits: SMALL_CHUNK/8 + 64 = 256.)
+    const uint32_t c0 = cnt[t];
+    uint32_t m4 = (c0 + 3) / 4, m5 = (c0 + 4) / 5, m6 = (c0 + 5) / 6, m7 = (c0 + 6) / 7;
+    for (int o = 32; o > 0; o >>= 1) { m4 += __shfl_xor(m4, o); m5 += __shfl_xor(m5, o); m6 += __shfl_xor(m6, o); m7 += __shfl_xor(m7, o); }
+    const uint32_t sub = m4 <= SMALL_THREADS ? 4u : m5 <= SMALL_THREADS ? 5u : m6 <= SMALL_THREADS ? 6u : m7 <= SMALL_THREADS ? 7u : 8u;
+    const uint32_t m = (c0 + sub - 1) / sub;
+    uint32_t ic = c0, im = m, mx = m;                       // inclusive scans over the 64 lanes
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t uc = __shfl_up(ic, o), um = __shfl_up(im, o);
+      if ((int)t >= o) { ic += uc; im += um; }
+    }
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor(mx, o));
+    off[t] = ic - c0; soff[t] = im - m;
+    if (t == 63) { off[SMALL_NBW] = ic; soff[SMALL_NBW] = im; s_maxm = mx; }
   }
   __syncthreads();
 #pragma unroll
@@ -529,7 +558,8 @@ __global__ void __launch_bounds__(SMALL_THREADS) k_msm_small(const uint32_t* __r
   if (t < nsubs) {
     const uint32_t b = subb[t];
     kk = t - soff[b]; mb = soff[b + 1] - soff[b];
-    const uint32_t beg = off[b] + kk * SMALL_SUB, end = min(off[b + 1], beg + SMALL_SUB);
+    const uint32_t cb = off[b + 1] - off[b];
+    const uint32_t beg = off[b] + kk * cb / mb, end = off[b] + (kk + 1) * cb / mb;
     // (one wave per SIMD: nothing else hides the gather of an 80-byte table entry, so entry e+1 is in flight while e is added)
     uint32_t ent = beg < end ? list[beg] : 0u;
     Affine<F> pt = load_affine<F>(wbases, lo + (ent & 0x7fffu));
@@ -564,25 +594,27 @@ __global__ void __launch_bounds__(SMALL_THREADS) k_msm_small(const uint32_t* __r
     // The chunks of a window share its buckets: publish this chunk's 64 bucket sums; the last workgroup of the window to arrive
     // adds them bucket by bucket and alone runs the weighted bucket reduction below (it used to run in every chunk's workgroup,
     // twelve dependent additions on one wave each, followed by a tree over the chunk results: same depth, a fifth of the
-    // instructions at five chunks).  Release: stores, fence, barrier, agent-scope atomic ticket; acquire: fence, agent-scope
-    // loads that bypass this CU's vector cache.
-    if (t < SMALL_NBW) store_xyzz(chunk_out, ((size_t)w * Q + q) * SMALL_NBW + t, bk);
-    __threadfence();
-    __syncthreads();
-    if (t == 0) s_ticket = atomicAdd(&done[w], 1u);
+    // instructions at five chunks).  Release: stores, fence, agent-scope atomic ticket — all by the publishing wave; acquire: fence
+    // (invalidates this CU's vector cache and the L2's non-local lines), then plain 16-byte loads.  (Per-word agent-scope atomic
+    // loads here were issued one at a time: 72 serial round trips to another XCD's data, 40 µs.)
+    // (the publishing wave alone runs the release fence: it writes this XCD's L2 back, and with every wave of the launch's 222
+    //  workgroups doing so at the same moment the write-backs queued for ~25 µs)
+    if (t < SMALL_NBW) {
+      store_xyzz(chunk_out, ((size_t)w * Q + q) * SMALL_NBW + t, bk);
+      __threadfence();
+      if (t == 0) s_ticket = atomicAdd(&done[w], 1u);
+    }
     __syncthreads();
     if (s_ticket != Q - 1) return;
     __threadfence();
+
     // sh = four slots of 64 buckets; slot 0 accumulates, the chunks arrive four (then three) at a time and every addition
     // is a four-lane one: (0 += 1, 2 += 3), 0 += 2
     const uint32_t b = t & (SMALL_NBW - 1), sl = t / SMALL_NBW;
     for (uint32_t loaded = 0; loaded < Q;) {
       const uint32_t slot0 = loaded ? 1u : 0u, k = min(Q - loaded, 4u - slot0), m = slot0 + k;
       if (sl >= slot0 && sl < m) {
-        const uint32_t* src = chunk_out + (size_t)XYZZ_WORDS * (((size_t)w * Q + loaded + sl - slot0) * SMALL_NBW + b);
-        XYZZ<F> v; F* f[4] = {&v.X, &v.Y, &v.ZZ, &v.ZZZ};
-        for (int c4 = 0; c4 < 4; c4++) for (int i = 0; i < 9; i++) f[c4]->v[i] = __hip_atomic_load(src + COORD_WORDS * c4 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        sh[t] = v;
+        sh[t] = load_xyzz<F>(chunk_out, ((size_t)w * Q + loaded + sl - slot0) * SMALL_NBW + b);
       }
       __syncthreads();
       if (m >= 2) quad_level<F>(sh, SMALL_NBW, [](uint32_t e) { return e; }, [](uint32_t e) { return e + SMALL_NBW; });
@@ -671,7 +703,7 @@ __global__ void __launch_bounds__(256) k_msm_fixed(const uint32_t* __restrict__ 
     if (i < n) {
       uint32_t sc[8];
       if (load_scalar<S>(scalars, i, mont, 0, sc)) {
-        const int d = signed_digit(sc, SMALL_C, (int)w);
+        const int d = signed_digit<SMALL_C>(sc, (int)w);
         if (d) {
           have[k] = true; neg[k] = d < 0;
           const uint32_t m = (uint32_t)(d < 0 ? -d : d) - 1u;
@@ -695,21 +727,20 @@ __global__ void __launch_bounds__(256) k_msm_fixed(const uint32_t* __restrict__ 
   quad_level<F>(sh, 64, [](uint32_t e) { return e + 64; }, [](uint32_t e) { return e + 192; });
   for (uint32_t d = 64; d > 0; d >>= 1) quad_level<F>(sh, d, [](uint32_t e) { return e; }, [d](uint32_t e) { return e + d; });
   if (Q == 1) { if (t == 0) store_xyzz(window_sums, w, sh[0]); return; }
-  // publish; the last workgroup of the window to arrive sums the Q workgroup sums (release: store, fence, barrier, agent-scope
-  // ticket; acquire: fence, agent-scope loads — as k_msm_small's chunk merge)
-  if (t == 0) store_xyzz(partial, (size_t)w * Q + q, sh[0]);
-  __threadfence();
-  __syncthreads();
-  if (t == 0) s_ticket = atomicAdd(&done[w], 1u);
+  // publish; the last workgroup of the window to arrive sums the Q workgroup sums (release: store, fence, agent-scope ticket — by
+  // the one publishing wave; acquire: fence, then plain loads — as k_msm_small's chunk merge)
+  if (t < 64) {
+    if (t == 0) store_xyzz(partial, (size_t)w * Q + q, sh[0]);
+    __threadfence();
+    if (t == 0) s_ticket = atomicAdd(&done[w], 1u);
+  }
   __syncthreads();
   if (s_ticket != Q - 1) return;
   __threadfence();
   if (t < FIXED_MAXQ) {
     XYZZ<F> v = XYZZ<F>::identity();
     if (t < Q) {
-      const uint32_t* src = partial + (size_t)XYZZ_WORDS * ((size_t)w * Q + t);
-      F* f[4] = {&v.X, &v.Y, &v.ZZ, &v.ZZZ};
-      for (int c4 = 0; c4 < 4; c4++) for (int i = 0; i < 9; i++) f[c4]->v[i] = __hip_atomic_load(src + COORD_WORDS * c4 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      v = load_xyzz<F>(partial, (size_t)w * Q + t);
     }
     sh[t] = v;
   }
