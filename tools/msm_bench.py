@@ -29,7 +29,7 @@ def main():
         wit[full] = dense[full]
         for name, sc in (("dense", dense), ("witness", wit)):
             v = ctx.vec_from_host(_lib.FIELD_BN254_FR, sc)
-            for c in ([0, 10, 12, 13] if name == "dense" else [0, 8, 13]):
+            for c in ([0, 12, 13, 14, 15] if name == "dense" else [0, 12, 13, 14]):
                 ctx.set_profiling(False)
                 ctx.msm_vec(B, v, window_bits=c)  # warm
                 ctx.set_profiling(True)

@@ -68,6 +68,14 @@ VZ_HD XYZZ<F> dbl(const XYZZ<F>& p) {
   return r;
 }
 
+// a·b − c·d for c < K·p.  The lazily reduced device form sums both products' columns and reduces ONCE (fp29.hpp: mul_add2 — 81 of a
+// mixed addition's 1 390 multiply instructions and one of its nine reductions); the canonical form multiplies twice.
+template <int K, class F>
+VZ_HD F diff_of_products(const F& a, const F& b, const F& c, const F& d) {
+  if constexpr (F::LAZY) return F::mul_add2(a, b, F::template sub<K>(F::zero(), c), d);
+  else return F::template sub<2>(F::mul(a, b), F::mul(c, d));
+}
+
 // acc += q (affine), madd-2008-s.  Handles identity on either side, doubling and cancellation.
 template <class F>
 VZ_HD void add_mixed(XYZZ<F>& acc, const Affine<F>& q) {
@@ -85,7 +93,7 @@ VZ_HD void add_mixed(XYZZ<F>& acc, const Affine<F>& q) {
   F PPP = F::mul(Pv, PP);                              // 9.9 -> 1.08
   F Q = F::mul(acc.X, PP);                             // 7.4 -> 1.06
   F X3 = F::template sub<4>(F::sqr(R), F::add(PPP, F::dbl(Q)));     // R²: 26 -> 1.21;  PPP + 2Q < 3.2;  1.21 + 4 = 5.21
-  F Y3 = F::template sub<2>(F::mul(R, F::template sub<6>(Q, X3)), F::mul(acc.Y, PPP));   // 5.1·7.06 -> 1.29;  Y·PPP: 3.7 -> 1.03;  3.29
+  F Y3 = diff_of_products<4>(R, F::template sub<6>(Q, X3), acc.Y, PPP);   // 5.1·7.06 + 4·1.08 = 40.4 -> 1.32   (two reductions: 3.29)
   acc.X = X3; acc.Y = Y3;
   acc.ZZ = F::mul(acc.ZZ, PP);                         // 2.1 -> 1.02
   acc.ZZZ = F::mul(acc.ZZZ, PPP);
@@ -110,7 +118,7 @@ VZ_HD void add_full(XYZZ<F>& acc, const XYZZ<F>& q) {
   F PPP = F::mul(Pv, PP);                              // 1.03
   F Q = F::mul(U1, PP);                                // 1.01
   F X3 = F::template sub<4>(F::sqr(R), F::add(PPP, F::dbl(Q)));     // 1.08 + 4 = 5.08   (PPP + 2Q < 3.1)
-  F Y3 = F::template sub<2>(F::mul(R, F::template sub<6>(Q, X3)), F::mul(S1, PPP));     // 3.04·7.01 -> 1.17;  3.17
+  F Y3 = diff_of_products<2>(R, F::template sub<6>(Q, X3), S1, PPP);     // 3.04·7.01 + 2·1.03 = 23.4 -> 1.19   (two reductions: 3.17)
   acc.X = X3; acc.Y = Y3;
   acc.ZZ = F::mul(F::mul(acc.ZZ, q.ZZ), PP);
   acc.ZZZ = F::mul(F::mul(acc.ZZZ, q.ZZZ), PPP);

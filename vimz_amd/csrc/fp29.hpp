@@ -138,6 +138,22 @@ struct Fp29 {
       for (int j = 0; j < 9; j++) acc[i + j] += (uint64_t)a.v[i] * b.v[j];
     return redc(acc);
   }
+  // (a*b + c*d) / 2^261 with ONE reduction: a column then holds 18 + 9 products of 29-bit limbs, < 2^62.8.  Operand bounds
+  // Ba·Bb + Bc·Bd <= 64 -> result < 1.5 p.
+  static VZ_HD Fp29 mul_add2(const Fp29& a, const Fp29& b, const Fp29& c, const Fp29& d) {
+    uint64_t acc[18];
+#pragma unroll
+    for (int k = 0; k < 18; k++) acc[k] = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++)
+#pragma unroll
+      for (int j = 0; j < 9; j++) acc[i + j] += (uint64_t)a.v[i] * b.v[j];
+#pragma unroll
+    for (int i = 0; i < 9; i++)
+#pragma unroll
+      for (int j = 0; j < 9; j++) acc[i + j] += (uint64_t)c.v[i] * d.v[j];
+    return redc(acc);
+  }
   // a^2: 45 products instead of 81 (cross terms against the doubled limbs, 2a_j < 2^30: a column holds at most four such
   // products, one square and nine reduction products: < 2^62.4)
   static VZ_HD Fp29 sqr(const Fp29& a) {
