@@ -314,6 +314,41 @@ int vimz_ivc_compress(vimz_ivc* v, uint8_t* blob, size_t cap, double seconds[2])
  * argument for the primary running / secondary running / last fresh secondary instance; bit 12 statement mismatch; bit 13 malformed. */
 int vimz_ivc_verify_compressed(vimz_ivc* v, const uint8_t* blob, size_t len, uint64_t num_steps, const uint64_t* z0, uint32_t* result);
 
+/* ---- Nova + CycleFold IVC: the `prove_step` loop of the reference's Sonobe backend (vimz/src/sonobe_backend/folding.rs:52-66; scheme
+ *      `Nova<G1, G2, C, KZG<Bn254>, Pedersen<G2>, false>`, folding.rs:22) — SURVEY.md §8 row N1.  The main circuit F' (step circuit + our
+ *      statement of CycleFold's augmented circuit, vimz_amd/csrc/aug/cyclefold.hpp) is committed on BN254 G1 — ck_main may be a KZG SRS's
+ *      G1 powers (vimz_bases_upload) or any other generators —, the CycleFold circuit (1.4 k constraints over Fq) on Grumpkin.  Sonobe is
+ *      not vendored with the reference: NOT byte-compatible with its proof object, and the decider (Groth16 + KZG, decider.rs:13-21) is
+ *      not built; the calldata layout of its output is vimz_amd/calldata.py.  One proof = (U_n, W_n), (u_n, w_n), (cfU_n, cfW_n). ---------- */
+typedef struct vimz_cf vimz_cf;
+int vimz_cf_create(vimz_ctx* ctx, const vimz_circuit* step_circuit, const vimz_bases* ck_main, const vimz_bases* ck_cyclefold, size_t max_batch, vimz_cf** out);
+void vimz_cf_free(vimz_cf* v);
+int vimz_cf_reset(vimz_cf* v, const uint64_t* z0);
+/* Folding::prove_step for every row (same inputs as vimz_ivc_fold) */
+int vimz_cf_fold(vimz_cf* v, const uint64_t* step_inputs, size_t nsteps);
+/* Folding::verify(vp, ivc_proof) (folding.rs:69-75) for the claimed statement: 0 = accepted; bit 0 / 1 the hash of the main / CycleFold running
+ * instance carried by the last instance of F'; bit 2 main relaxed relation; bit 3 / 4 main comm_W / comm_E; bit 5 CycleFold relaxed relation;
+ * bit 6 / 7 its comm_W / comm_E; bit 8 the last instance of F' (strict); bit 9 its comm_W; bit 10 instance scalars differ from the witness
+ * vectors; bit 11 prover-side running products; bit 12 the proof's step count or initial state differ from the claimed ones. */
+int vimz_cf_verify(vimz_cf* v, uint64_t num_steps, const uint64_t* z0, uint32_t* result);
+/* info[0..12): steps, main wires, main constraints, step wires, step constraints, CycleFold wires, CycleFold constraints, len_z,
+ * F' wires, nnz main, nnz CycleFold, public elements of a CycleFold instance */
+int vimz_cf_info(const vimz_cf* v, uint64_t info[12]);
+int vimz_cf_state(const vimz_cf* v, uint64_t* z_current, uint64_t* steps);
+/* seconds[8]/counts[8]: cross term + MSM(T), the two CycleFold instances, F' on the host, fresh instance (upload, verifier rows,
+ * commitment), producer wait, total, reserved x2 */
+int vimz_cf_profile(const vimz_cf* v, double seconds[8], uint64_t counts[8]);
+/* side 0 = main circuit, 1 = CycleFold circuit; what = VIMZ_CX_* (R1CS tables), VIMZ_IX_INFO, VIMZ_IX_INSTANCE (side 0: comm_W.x, comm_W.y,
+ * comm_E.x, comm_E.y, u, x0, x1; side 1: comm_W.x, comm_W.y, comm_E.x, comm_E.y, u, x[0..7)), VIMZ_IX_FRESH_INSTANCE (side 0: comm_W.x,
+ * comm_W.y, x0, x1), VIMZ_IX_PARAMS (side 0: digest, z0..., z_i...), VIMZ_IX_RUNNING_Z, VIMZ_IX_RUNNING_E, VIMZ_IX_FRESH_Z (side 0) */
+int64_t vimz_cf_export(vimz_cf* v, int side, int what, void* buf, size_t cap);
+/* test hooks.  poke: overwrite one element (canonical) of a witness vector on the device — which = 0 running main Z, 1 last fresh main Z,
+ * 2 running CycleFold Z, 3 running main E, 4 running CycleFold E.  selfcheck: host only, no GPU — `steps` steps over the trivial step
+ * circuit with made-up commitments, every witness checked against its R1CS and every in-circuit fold against field / curve arithmetic
+ * (result 0 = good; counts: F' wires, constraints, CycleFold wires, constraints). */
+int vimz_cf_poke(vimz_cf* v, int which, size_t index, const uint64_t value[4]);
+int vimz_cf_selfcheck(int steps, uint32_t* result, uint64_t counts[4]);
+
 /* ---- ONE proof object out of several row segments: the "host-side sequential final fold" of BASELINE.json's north_star for IVC proofs.
  *      fold_input returns ONE RecursiveSNARK (vimz/src/nova_snark_backend/folding.rs:27-43); row segments of an image folded
  *      concurrently (S proofs on one GPU, or one per GPU) are merged into one verifiable object by out-of-circuit NIFS on both curves —

@@ -1,0 +1,100 @@
+"""Independent verifier of a Nova + CycleFold IVC proof (vimz_cf_*, vimz_amd/csrc/aug/cyclefold.hpp): Sonobe's Nova::verify restated
+with the CPU oracle — the oracle's Poseidon hash (oracle/nova.hpp: nova_hash over Fr), its generic relaxed-R1CS check and its MSM over the
+exported shapes, instances and witness vectors — plus the in-circuit folding relation of one step in Python integers / oracle curve
+arithmetic.  Test infrastructure only: nothing of the product imports this."""
+import hashlib
+import struct
+
+import numpy as np
+
+from tests._oracle import from_limbs
+
+CF_IO = 7
+
+
+def limbs64(v):
+    return [(int(v) >> (64 * k)) & 0xFFFFFFFFFFFFFFFF for k in range(4)]
+
+
+def shape_digest(cf):
+    """SHA3-256 of both shapes as CfMainCircuit::finish serialises them, truncated to 250 bits."""
+    from vimz_amd import hip
+    ex = lambda side, code: hip._export(cf.ctx.lib.vimz_cf_export, cf.h, side, code)
+    info0, info1 = ex(0, hip.IX_INFO).view(np.uint64), ex(1, hip.IX_INFO).view(np.uint64)
+    h = hashlib.sha3_256()
+    h.update(struct.pack("<6Q", 0x31306d6663, int(info0[0]), int(info0[1]), cf.circuit.len_z, int(info0[2]), int(info1[0])))
+    for side in (0, 1):
+        for code in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9):
+            a = ex(side, code)
+            elem = 32 if code == 9 else 4
+            h.update(struct.pack("<Q", len(a) // elem))
+            h.update(a.tobytes())
+    return int.from_bytes(h.digest(), "little") & ((1 << 250) - 1)
+
+
+def hash_main(orc, dg, i, z0, z, U):
+    """U = (W.x, W.y, E.x, E.y, u, x0, x1): H(H(dg, i, z0, z), u, x0, x1, limbs of W, limbs of E)"""
+    st = orc.nova_hash(0, [dg, i] + list(z0) + list(z))
+    return orc.nova_hash(0, [st, U[4], U[5], U[6]] + limbs64(U[0]) + limbs64(U[1]) + limbs64(U[2]) + limbs64(U[3]))
+
+
+def hash_cf(orc, dg, cfU):
+    """cfU = (W.x, W.y, E.x, E.y, u, x[0..7))"""
+    lim = []
+    for x in cfU[5:5 + CF_IO]:
+        lim += limbs64(x)
+    return orc.nova_hash(0, [dg, cfU[4]] + lim + list(cfU[0:4]))
+
+
+def chal(h):
+    return (1 << 128) + (int(h) & ((1 << 128) - 1))
+
+
+def verify(orc, cf, ck1, ck2, n_steps, z0, check_commitments=True):
+    """Nova::verify of Sonobe's IVC proof, restated; returns (failed checks, final state)."""
+    from vimz_amd import hip
+    failed = []
+    info = cf.info()
+    len_z = info["len_z"]
+    par = from_limbs(cf.export(0, hip.IX_PARAMS))
+    z0_x, z_n = par[1:1 + len_z], par[1 + len_z:]
+    if z0_x != list(z0): failed.append("z0")
+    if info["steps"] != n_steps: failed.append("step count")
+    dg = shape_digest(cf)
+    if dg != par[0]: failed.append("shape digest")
+    U, cfU = from_limbs(cf.export(0, hip.IX_INSTANCE)), from_limbs(cf.export(1, hip.IX_INSTANCE))
+    u = from_limbs(cf.export(0, hip.IX_FRESH_INSTANCE))
+    if hash_main(orc, dg, n_steps, list(z0), z_n, U) != u[2]: failed.append("hash of the main running instance")
+    if hash_cf(orc, dg, cfU) != u[3]: failed.append("hash of the CycleFold running instance")
+    # running main pair
+    tabs = cf.r1cs(0)
+    Z, E = cf.export(0, hip.IX_RUNNING_Z), cf.export(0, hip.IX_RUNNING_E)
+    nw = len(Z)
+    if from_limbs(Z[0:1])[0] != U[4] or from_limbs(Z[-2:]) != U[5:7]: failed.append("main: instance scalars")
+    if orc.r1cs_check_relaxed(0, tabs, nw, Z, u=U[4], E=E) != -1: failed.append("main: relaxed relation")
+    # the last instance of F'
+    z = cf.export(0, hip.IX_FRESH_Z)
+    if from_limbs(z[0:1])[0] != 1 or from_limbs(z[-2:]) != u[2:4]: failed.append("fresh: instance scalars")
+    if orc.r1cs_check_relaxed(0, tabs, nw, z) != -1: failed.append("fresh: relation")
+    if check_commitments:
+        bases = ck1.download(0, max(nw - 3, len(E)))
+        if orc.msm(0, bases[:nw - 3], Z[1:nw - 2]) != (U[0], U[1]): failed.append("main: comm_W")
+        if orc.msm(0, bases[:len(E)], E) != (U[2], U[3]): failed.append("main: comm_E")
+        if orc.msm(0, bases[:nw - 3], z[1:nw - 2]) != (u[0], u[1]): failed.append("fresh: comm_W")
+    # running CycleFold pair (over Fq, committed on Grumpkin)
+    tabs2 = cf.r1cs(1)
+    Z2, E2 = cf.export(1, hip.IX_RUNNING_Z), cf.export(1, hip.IX_RUNNING_E)
+    n2 = len(Z2)
+    if from_limbs(Z2[0:1])[0] != cfU[4] or from_limbs(Z2[-CF_IO:]) != cfU[5:5 + CF_IO]: failed.append("cyclefold: instance scalars")
+    if orc.r1cs_check_relaxed(1, tabs2, n2, Z2, u=cfU[4], E=E2) != -1: failed.append("cyclefold: relaxed relation")
+    if check_commitments:
+        bases2 = ck2.download(0, max(n2 - 1 - CF_IO, len(E2)))
+        if orc.msm(1, bases2[:n2 - 1 - CF_IO], Z2[1:n2 - CF_IO]) != (cfU[0], cfU[1]): failed.append("cyclefold: comm_W")
+        if orc.msm(1, bases2[:len(E2)], E2) != (cfU[2], cfU[3]): failed.append("cyclefold: comm_E")
+    return failed, z_n
+
+
+def cyclefold_relation(orc, x):
+    """The CycleFold circuit's statement for one instance's public elements x = (r, P1, P2, P3): P3 == P1 + r·P2 on BN254 G1."""
+    r, p1, p2, p3 = x[0], (x[1], x[2]), (x[3], x[4]), (x[5], x[6])
+    return orc.curve_add(0, p1, orc.curve_mul(0, p2, r)) == p3

@@ -1,0 +1,105 @@
+"""Nova + CycleFold IVC on the GPU (vimz_cf_*, SURVEY.md §8 row N1: the prove_step loop of the reference's Sonobe backend,
+vimz/src/sonobe_backend/folding.rs:52-66).  The product's verifier must accept, and so must the independent verifier assembled from the
+CPU oracle (tests/_cyclefold.py) over the exported proof; states must equal the Nova IVC's and the oracle executor's."""
+import numpy as np
+import pytest
+
+from tests import _cyclefold as cfo
+from tests._oracle import from_limbs
+from tests.test_circuits import step_inputs
+from vimz_amd import _lib
+from vimz_amd.circuit import Circuit
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from vimz_amd import hip
+    c = hip.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def keys(ctx):
+    ck1 = ctx.bases_generate(_lib.CURVE_BN254_G1, 1 << 19)
+    ck2 = ctx.bases_generate(_lib.CURVE_GRUMPKIN, 1 << 13, b"ck-cyclefold")
+    yield ck1, ck2
+    ck1.free(); ck2.free()
+
+
+@pytest.mark.parametrize("op", ["contrast", "grayscale", "hash"])
+def test_cyclefold_ivc_verifies_and_the_oracle_verifier_accepts(ctx, keys, oracle, op):
+    from vimz_amd import hip
+    ck1, ck2 = keys
+    c = Circuit.for_resolution(op, "HD")
+    z0, inputs = step_inputs(op)
+    steps = np.stack(inputs)
+    cf = hip.CycleFoldIVC(ctx, c, ck1, ck2, max_batch=4)
+    ivc = hip.IVC(ctx, c, ck1, ck2, max_batch=4)
+    try:
+        cf.reset(z0)
+        cf.fold(steps)                                  # 10 steps: three batches (4, 4, 2)
+        assert cf.verify(10, z0) == 0
+        assert cf.verify(9, z0) == 4096 and cf.verify(10, [z0[0] + 1] + list(z0[1:])) & 4096
+        failed, z_n = cfo.verify(oracle, cf, ck1, ck2, 10, z0, check_commitments=(op == "contrast"))
+        assert failed == []
+        # the same ten rows as a Nova IVC end in the same state
+        ivc.reset(z0); ivc.fold(steps)
+        assert cf.state() == ivc.state() and cf.state()[0] == z_n
+        # every CycleFold instance the running one absorbed spoke about a true statement: the running instance's public elements are
+        # random combinations — spot-check the relation the circuit enforces on a fresh run of one step instead (below); here: the
+        # proof stays valid when folding goes on in a second call
+        cf.fold(steps[:3])
+        assert cf.verify(13, z0) == 0
+        failed, _ = cfo.verify(oracle, cf, ck1, ck2, 13, z0, check_commitments=False)
+        assert failed == []
+    finally:
+        cf.close(); ivc.close()
+
+
+def test_cyclefold_verifiers_reject_tampering(ctx, keys, oracle):
+    from vimz_amd import hip
+    ck1, ck2 = keys
+    c = Circuit.for_resolution("contrast", "HD")
+    z0, inputs = step_inputs("contrast")
+    steps = np.stack(inputs)
+    cf = hip.CycleFoldIVC(ctx, c, ck1, ck2, max_batch=4)
+    try:
+        cf.reset(z0)
+        cf.fold(steps[:5])
+        assert cf.verify(5, z0) == 0
+        info = cf.info()
+        rs = np.random.default_rng(3)
+        # one wrong element in any of the five vectors: both verifiers reject
+        for which, n, side, what in ((0, info["main_wires"], 0, hip.IX_RUNNING_Z), (1, info["main_wires"], 0, hip.IX_FRESH_Z), (2, info["cyclefold_wires"], 1, hip.IX_RUNNING_Z),
+                                     (3, info["main_constraints"], 0, hip.IX_RUNNING_E), (4, info["cyclefold_constraints"], 1, hip.IX_RUNNING_E)):
+            vec = from_limbs(cf.export(side, what))
+            for idx in sorted(set([1, n - 1] + [int(x) for x in rs.integers(1, n, size=3)])):
+                old = vec[idx]
+                cf.poke(which, idx, (old + 1) % _lib.MODULUS[side])
+                assert cf.verify(5, z0) != 0, (which, idx)
+                if idx in (1, n - 1):
+                    failed, _ = cfo.verify(oracle, cf, ck1, ck2, 5, z0, check_commitments=False)
+                    assert failed, (which, idx)
+                cf.poke(which, idx, old)
+        assert cf.verify(5, z0) == 0
+        # an unsatisfiable row is refused and leaves the proof where it was
+        bad = steps[5:7].copy(); bad[1, 200, 0] ^= np.uint64(0xFF)      # a transformed pixel that is no longer the contrast of the original
+        with pytest.raises(_lib.VimzError) as e:
+            cf.fold(bad)
+        assert e.value.code == _lib.ERR_UNSAT
+        assert cf.state()[1] == 5 and cf.verify(5, z0) == 0
+        cf.fold(steps[5:])
+        assert cf.verify(10, z0) == 0
+    finally:
+        cf.close()
+
+
+def test_cyclefold_instance_statement(oracle):
+    """The statement a CycleFold instance makes, on the host circuit: P3 = P1 + r·P2 for the public elements the witness ends in."""
+    g = (1, 2)
+    p1, p2 = oracle.curve_mul(0, g, 12345), oracle.curve_mul(0, g, 67890)
+    r = (1 << 128) + 0x1234567890abcdef1234567890abcdef
+    assert cfo.cyclefold_relation(oracle, [r, p1[0], p1[1], p2[0], p2[1], *oracle.curve_add(0, p1, oracle.curve_mul(0, p2, r))])

@@ -529,6 +529,56 @@ struct NonNative {
       carry_in = c_signed;
     }
   }
+
+  // The same integer identity for an x that is ANY element of the other field, given as four 64-bit limbs (CycleFold: the coordinates
+  // of the points a CycleFold instance speaks about; the caller range-checks the limbs or takes them from a checked hash).
+  // rho·x < 2^129·2^256, so the quotient k may need 131 bits: three limbs k0, k1, k2 (k2 < 8).
+  static void fold_limbs(Cs& cs, const N X[4], const U256w& Xv, const N& rho0, const N& rho1, const uint32_t rho_low128[4],
+                         const N xl[4], const U256w& xv, N out[4], U256w& outv) {
+    typedef unsigned __int128 u128;
+    const U256w m = modulus();
+    outv = fold_value(Xv, rho_low128, xv);
+    // k = (X + rho·x − X') / m exactly and k < 2^192: from the low 192 bits alone, with m^{-1} mod 2^192
+    auto mul_lo3 = [](const uint64_t* a, const uint64_t* b, uint64_t* o) {
+      uint64_t r[3] = {0, 0, 0};
+      for (int i = 0; i < 3; i++) { u128 carry = 0; for (int j = 0; i + j < 3; j++) { const u128 cur = (u128)a[i] * b[j] + r[i + j] + carry; r[i + j] = (uint64_t)cur; carry = cur >> 64; } }
+      o[0] = r[0]; o[1] = r[1]; o[2] = r[2];
+    };
+    auto add3 = [](const uint64_t* a, const uint64_t* b, uint64_t* o) { u128 c = 0; for (int i = 0; i < 3; i++) { c += (u128)a[i] + b[i]; o[i] = (uint64_t)c; c >>= 64; } };
+    auto sub3 = [](const uint64_t* a, const uint64_t* b, uint64_t* o) { uint64_t br = 0; for (int i = 0; i < 3; i++) { const u128 d = (u128)a[i] - b[i] - br; o[i] = (uint64_t)d; br = (uint64_t)(d >> 64) & 1; } };
+    const uint64_t rl[3] = {(uint64_t)rho_low128[0] | ((uint64_t)rho_low128[1] << 32), (uint64_t)rho_low128[2] | ((uint64_t)rho_low128[3] << 32), 1};
+    uint64_t minv[3] = {1, 0, 0};
+    for (int it = 0; it < 8; it++) {      // Newton: inverse of the odd m modulo 2^192
+      uint64_t t[3], two[3] = {2, 0, 0};
+      mul_lo3(m.w, minv, t); sub3(two, t, t); mul_lo3(minv, t, minv);
+    }
+    uint64_t sl[3], kq[3];
+    mul_lo3(rl, xv.w, sl); add3(sl, Xv.w, sl); sub3(sl, outv.w, sl); mul_lo3(sl, minv, kq);
+    if (kq[2] >= 8) cs.bad = true;
+    F kf = F::zero();
+    for (int i = 0; i < 3; i++) { kf.v[2 * i] = (uint32_t)kq[i]; kf.v[2 * i + 1] = (uint32_t)(kq[i] >> 32); }
+    N kN = cs.alloc(F::to_mont(kf));
+    std::vector<N> kb = cs.bits(kN, 131);
+    N k0 = cs.pack(kb, 0, 64), k1 = cs.pack(kb, 64, 128), k2 = cs.pack(kb, 128, 131);
+    for (int j = 0; j < 4; j++) { out[j] = cs.alloc(from_u64(outv.w[j])); cs.bits(out[j], 64); }
+    N p0[4], p1[4];
+    for (int c = 0; c < 4; c++) { p0[c] = cs.mul(rho0, xl[c]); p1[c] = cs.mul(rho1, xl[c]); }
+    const F two64 = cb::f_pow2<F>(64), off = cb::f_pow2<F>(68);
+    static const F inv_two64 = F::pow_pm2(cb::f_pow2<F>(64));
+    N carry_in = cs.zero();
+    for (int j = 0; j < 6; j++) {
+      N t = carry_in;
+      if (j < 4) { t = cs.add(t, cs.sub(X[j], out[j])); t = cs.add(t, p0[j]); t = cs.sub(t, cs.scale(k0, from_u64(m.w[j]))); }
+      if (j >= 1 && j - 1 < 4) { t = cs.add(t, p1[j - 1]); t = cs.sub(t, cs.scale(k1, from_u64(m.w[j - 1]))); }
+      if (j >= 2 && j - 2 < 4) { t = cs.add(t, xl[j - 2]); t = cs.sub(t, cs.scale(k2, from_u64(m.w[j - 2]))); }
+      if (j == 5) { cs.enforce_zero(t); if (!t.v.is_zero()) cs.bad = true; break; }
+      N cN = cs.alloc(F::add(F::mul(t.v, inv_two64), off));   // c_j + 2^68 in [0, 2^69)
+      cs.bits(cN, 69);
+      N c_signed = cs.addc(cN, F::neg(off));
+      cs.enforce_zero(cs.sub(t, cs.scale(c_signed, two64)));
+      carry_in = c_signed;
+    }
+  }
 };
 
 }  // namespace aug

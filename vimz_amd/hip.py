@@ -520,6 +520,90 @@ class IVC:
         return _r1cs_tables(self.ctx.lib.vimz_ivc_export, self.h, side)
 
 
+class CycleFoldIVC:
+    """vimz_cf: Nova + CycleFold IVC of one transformation's step circuit (the reference's Sonobe backend: Folding::prove_step / verify,
+    vimz/src/sonobe_backend/folding.rs:52-75).  ck_main on BN254 G1 (e.g. a KZG SRS's powers), ck_cyclefold on Grumpkin."""
+    PHASES = ["cross_term_msm", "cyclefold_instances", "main_circuit_host", "fresh_instance", "producer_wait", "total"]
+
+    def __init__(self, ctx, circuit, ck_main, ck_cyclefold, max_batch=16):
+        self.ctx, self.circuit = ctx, circuit
+        lib = ctx.lib
+        vp, sz = C.c_void_p, C.c_size_t
+        lib.vimz_cf_create.argtypes = [vp, vp, vp, vp, sz, C.POINTER(vp)]
+        lib.vimz_cf_free.argtypes = [vp]
+        lib.vimz_cf_free.restype = None
+        lib.vimz_cf_reset.argtypes = [vp, vp]
+        lib.vimz_cf_fold.argtypes = [vp, vp, sz]
+        lib.vimz_cf_verify.argtypes = [vp, C.c_uint64, vp, C.POINTER(C.c_uint32)]
+        lib.vimz_cf_info.argtypes = [vp, vp]
+        lib.vimz_cf_state.argtypes = [vp, vp, C.POINTER(C.c_uint64)]
+        lib.vimz_cf_profile.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+        lib.vimz_cf_export.argtypes = [vp, C.c_int, C.c_int, vp, sz]
+        lib.vimz_cf_export.restype = C.c_int64
+        lib.vimz_cf_poke.argtypes = [vp, C.c_int, sz, vp]
+        h = vp()
+        ctx._chk(lib.vimz_cf_create(ctx.h, circuit.h, ck_main.h, ck_cyclefold.h, max_batch, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.vimz_cf_free(self.h)
+            self.h = None
+
+    def reset(self, z0):
+        self.ctx._chk(self.ctx.lib.vimz_cf_reset(self.h, _ptr(_zlimbs(z0, self.circuit.len_z))))
+
+    def fold(self, step_inputs):
+        a = _u64(step_inputs).reshape(-1, self.circuit.n_priv, 4)
+        self.ctx._chk(self.ctx.lib.vimz_cf_fold(self.h, _ptr(a), a.shape[0]))
+
+    def verify(self, num_steps, z0):
+        r = C.c_uint32()
+        self.ctx._chk(self.ctx.lib.vimz_cf_verify(self.h, int(num_steps), _ptr(_zlimbs(z0, self.circuit.len_z)), C.byref(r)))
+        return r.value
+
+    def info(self):
+        a = np.zeros(12, dtype=np.uint64)
+        self.ctx._chk(self.ctx.lib.vimz_cf_info(self.h, _ptr(a)))
+        keys = ["steps", "main_wires", "main_constraints", "step_wires", "step_constraints", "cyclefold_wires", "cyclefold_constraints",
+                "len_z", "verifier_wires", "main_nnz", "cyclefold_nnz", "cyclefold_io"]
+        return {k: int(a[i]) for i, k in enumerate(keys)}
+
+    def state(self):
+        z = np.zeros((self.circuit.len_z, 4), dtype=np.uint64)
+        steps = C.c_uint64()
+        self.ctx._chk(self.ctx.lib.vimz_cf_state(self.h, _ptr(z), C.byref(steps)))
+        return [sum(int(z[i, k]) << (64 * k) for k in range(4)) for i in range(self.circuit.len_z)], steps.value
+
+    def profile(self):
+        s = (C.c_double * 8)()
+        n = (C.c_uint64 * 8)()
+        self.ctx._chk(self.ctx.lib.vimz_cf_profile(self.h, s, n))
+        return {k: (s[i], n[i]) for i, k in enumerate(self.PHASES)}
+
+    def export(self, side, what):
+        return _export(self.ctx.lib.vimz_cf_export, self.h, side, what).view(np.uint64).reshape(-1, 4)
+
+    def r1cs(self, side):
+        return _r1cs_tables(self.ctx.lib.vimz_cf_export, self.h, side)
+
+    def poke(self, which, index, value):
+        self.ctx._chk(self.ctx.lib.vimz_cf_poke(self.h, which, index, _ptr(_zlimbs([value], 1))))
+
+
+def cyclefold_selfcheck(steps=4):
+    """vimz_cf_selfcheck (host only, no GPU): (result bits, {"main_wires", "main_constraints", "cyclefold_wires", "cyclefold_constraints"})."""
+    from . import _lib
+    lib = _lib.lib()
+    lib.vimz_cf_selfcheck.argtypes = [C.c_int, C.POINTER(C.c_uint32), C.c_void_p]
+    r = C.c_uint32()
+    counts = np.zeros(4, dtype=np.uint64)
+    rc = lib.vimz_cf_selfcheck(int(steps), C.byref(r), _ptr(counts))
+    if rc:
+        raise _lib.VimzError(rc, "vimz_cf_selfcheck")
+    return r.value, dict(zip(["main_wires", "main_constraints", "cyclefold_wires", "cyclefold_constraints"], (int(x) for x in counts)))
+
+
 def _zlimbs(z0, len_z):
     z = np.zeros((len_z, 4), dtype=np.uint64)
     for i, v in enumerate(z0):
