@@ -6,7 +6,7 @@ import pytest
 
 from tests import _cyclefold as cfo
 from tests._oracle import from_limbs
-from tests.test_circuits import step_inputs
+from tests.test_circuits import ORC_T, step_inputs
 from vimz_amd import _lib
 from vimz_amd.circuit import Circuit
 
@@ -103,3 +103,26 @@ def test_cyclefold_instance_statement(oracle):
     p1, p2 = oracle.curve_mul(0, g, 12345), oracle.curve_mul(0, g, 67890)
     r = (1 << 128) + 0x1234567890abcdef1234567890abcdef
     assert cfo.cyclefold_relation(oracle, [r, p1[0], p1[1], p2[0], p2[1], *oracle.curve_add(0, p1, oracle.curve_mul(0, p2, r))])
+
+
+def test_fold_input_with_the_sonobe_backend(ctx, oracle):
+    """folding.fold_input(mode="cyclefold") / verify_folded_proof: the Sonobe backend's fold_input and verify_folding
+    (vimz/src/sonobe_backend/folding.rs:52-75) over ten rows of the sample image; the final state is the image-hash pair the reference checks
+    (verify_final_state_arkworks, folding.rs:77-131)."""
+    from vimz_amd import folding
+    z0, inputs = step_inputs("grayscale")
+    steps = np.stack(inputs)
+    circuit, params = folding.prepare_folding(ctx, "grayscale", "HD", backend="sonobe")
+    try:
+        proof = folding.fold_input(params, steps, z0, mode="cyclefold")
+        folding.verify_folded_proof(proof, params, 10, z0)
+        with pytest.raises(_lib.VimzError):
+            folding.verify_folded_proof(proof, params, 9, z0)
+        z = list(z0)
+        for i in range(10):
+            ok, z = oracle.step_eval(ORC_T["grayscale"], z, steps[i])
+            assert ok
+        assert proof.state() == z
+        proof.close()
+    finally:
+        params.free()

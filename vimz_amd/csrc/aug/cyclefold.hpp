@@ -103,7 +103,11 @@ struct CfMainOut {
   CfFr x0, x1;
 };
 
-inline CfMainOut synthesize_cf_main(CS<BnFr>& cs, const CfMainIn& in, const std::vector<Num<CfFr>>& z_i, const std::vector<Num<CfFr>>& z_next) {
+// The four hashes a step ends with are the ones the next step's circuit recomputes to check its incoming instance: their wires are kept
+// and replayed (cs.hpp: HashCache) — st = H(dg, i, z_0, z), U = the main instance's, cf_pre / cf_fin = the CycleFold instance's in two parts
+// (the first 29 elements — u and the limbs — end on a block boundary of the sponge; the last block absorbs the commitments).
+struct CfHashCache { HashCache<CfFr> st, U, cf_pre, cf_fin; };
+inline CfMainOut synthesize_cf_main(CS<BnFr>& cs, const CfMainIn& in, const std::vector<Num<CfFr>>& z_i, const std::vector<Num<CfFr>>& z_next, CfHashCache* cache = nullptr) {
   typedef CfFr F;
   typedef Num<F> N;
   typedef EcGadgets<BnFr> Ec;
@@ -159,15 +163,16 @@ inline CfMainOut synthesize_cf_main(CS<BnFr>& cs, const CfMainIn& in, const std:
   std::vector<N> hst = {dg, iN};
   hst.insert(hst.end(), z0.begin(), z0.end());
   hst.insert(hst.end(), z_i.begin(), z_i.end());
-  std::vector<N> hin = {cs.hash(hst), Uu, Ux0, Ux1};
+  std::vector<N> hin = {cs.hash_cached(hst, cache ? &cache->st : nullptr, nullptr), Uu, Ux0, Ux1};
   push_nn(hin, UW); push_nn(hin, UE);
-  N h_U = cs.hash(hin);
+  N h_U = cs.hash_cached(hin, cache ? &cache->U : nullptr, nullptr);
   cs.enforce(nb, cs.sub(h_U, ux0), cs.zero());
   if (!base && !h_U.v.eq(ux0.v)) cs.bad = true;
   std::vector<N> hcin = {dg, cu};
   for (int k = 0; k < CF_IO; k++) for (int j = 0; j < 4; j++) hcin.push_back(cx[k][j]);
-  hcin.push_back(cW.x); hcin.push_back(cW.y); hcin.push_back(cE.x); hcin.push_back(cE.y);
-  N h_cf = cs.hash(hcin);
+  static_assert(2 + 4 * CF_IO == 30, "the sponge absorbs 8 + 7 + 7 + 7 = 29 elements in four blocks; the rest and the commitments go into the fifth");
+  N h_cf_pre = cs.hash_cached(std::vector<N>(hcin.begin(), hcin.begin() + 29), cache ? &cache->cf_pre : nullptr, nullptr);
+  N h_cf = cs.hash_cached({h_cf_pre, hcin[29], cW.x, cW.y, cE.x, cE.y}, cache ? &cache->cf_fin : nullptr, nullptr);
   cs.enforce(nb, cs.sub(h_cf, ux1), cs.zero());
   if (!base && !h_cf.v.eq(ux1.v)) cs.bad = true;
 
@@ -216,35 +221,42 @@ inline CfMainOut synthesize_cf_main(CS<BnFr>& cs, const CfMainIn& in, const std:
   N ue = cs.mul(nb, cu);
   N xe[CF_IO][4]; U256w xev[CF_IO];
   for (int k = 0; k < CF_IO; k++) { for (int j = 0; j < 4; j++) xe[k][j] = cs.mul(nb, cx[k][j]); xev[k] = in.cfU.x[k]; if (base) for (int j = 0; j < 4; j++) xev[k].w[j] = 0; }
-  std::vector<Ec::ChainHints> hints;
-  { Ec::ChainJob job; job.start(Ec::scalar_operand(in.cf1W, ec.G), Ec::scalar_operand(in.cf1T, ec.G), out.r1, 128, cs.worker, cs.worker2); job.wait(hints); }
-  Pt W1 = ec.add(We, ec.scalar_mul(c1W, r1b, 128, hints[0])), E1 = ec.add(Ee, ec.scalar_mul(c1T, r1b, 128, hints[1]));
-  N u1 = cs.add(ue, r1);
+  // The four 128-step scalar multiplications are the long pole of the witness: both pairs' chains (cs.hpp: chain_hints, one batch per
+  // pair) start now, on the two helper threads; the non-native folds and the hashes that do not need the folded commitments run under them.
+  struct PairJob {
+    std::vector<Affine<F>> ps; std::vector<Ec::ChainHints> o; const uint32_t* k = nullptr; Worker* w = nullptr;
+    void start(const Affine<F>& a, const Affine<F>& b2, const uint32_t* k_, Worker* w_) { ps = {a, b2}; k = k_; w = w_; if (w) w->start([this] { Ec::chain_hints(ps, k, 128, o); }); }
+    void wait() { if (w) w->wait(); else Ec::chain_hints(ps, k, 128, o); }
+  } job1, job2;
+  job1.start(Ec::scalar_operand(in.cf1W, ec.G), Ec::scalar_operand(in.cf1T, ec.G), out.r1, cs.worker);
+  job2.start(Ec::scalar_operand(in.cf2W, ec.G), Ec::scalar_operand(in.cf2T, ec.G), out.r2, cs.worker2);
+  N u1 = cs.add(ue, r1), u2 = cs.add(u1, r2);
   N x1v[CF_IO][4]; U256w x1vv[CF_IO];
   for (int k = 0; k < CF_IO; k++) NN::fold_limbs(cs, xe[k], xev[k], r1_0, r1_1, out.r1, cf1x[k].l, cf1x[k].v, x1v[k], x1vv[k]);
-  { Ec::ChainJob job; job.start(Ec::scalar_operand(in.cf2W, ec.G), Ec::scalar_operand(in.cf2T, ec.G), out.r2, 128, cs.worker, cs.worker2); job.wait(hints); }
-  Pt W2 = ec.add(W1, ec.scalar_mul(c2W, r2b, 128, hints[0])), E2 = ec.add(E1, ec.scalar_mul(c2T, r2b, 128, hints[1]));
-  N u2 = cs.add(u1, r2);
   N x2v[CF_IO][4]; U256w x2vv[CF_IO];
   for (int k = 0; k < CF_IO; k++) NN::fold_limbs(cs, x1v[k], x1vv[k], r2_0, r2_1, out.r2, cf2x[k].l, cf2x[k].v, x2v[k], x2vv[k]);
-  // masked by the base case
-  N oWx = cs.mul(nb, W2.x), oWy = cs.mul(nb, W2.y), oEx = cs.mul(nb, E2.x), oEy = cs.mul(nb, E2.y), ou = cs.mul(nb, u2);
+  N ou = cs.mul(nb, u2);
   N ox[CF_IO][4];
   for (int k = 0; k < CF_IO; k++) for (int j = 0; j < 4; j++) { ox[k][j] = cs.mul(nb, x2v[k][j]); if (base) x2vv[k].w[j] = 0; }
-  out.cfU_new.W.x = oWx.v; out.cfU_new.W.y = oWy.v; out.cfU_new.E.x = oEx.v; out.cfU_new.E.y = oEy.v; out.cfU_new.u = ou.v;
-  for (int k = 0; k < CF_IO; k++) out.cfU_new.x[k] = x2vv[k];
-
-  // ---- public IO: the hashes of the two new running instances --------------------------------------------------------------------------------------
+  // public IO, the parts that do not wait for the chains: the hash of the new main instance, four of the five blocks of the CycleFold one
   std::vector<N> host = {dg, cs.addc(iN, F::one())};
   host.insert(host.end(), z0.begin(), z0.end());
   host.insert(host.end(), z_next.begin(), z_next.end());
-  std::vector<N> hout = {cs.hash(host), un, x0n, x1n};
+  std::vector<N> hout = {cs.hash_cached(host, nullptr, cache ? &cache->st : nullptr), un, x0n, x1n};
   push_nn(hout, Wn); push_nn(hout, En);
-  N hU_new = cs.hash(hout);
+  N hU_new = cs.hash_cached(hout, nullptr, cache ? &cache->U : nullptr);
   std::vector<N> hcout = {dg, ou};
   for (int k = 0; k < CF_IO; k++) for (int j = 0; j < 4; j++) hcout.push_back(ox[k][j]);
-  hcout.push_back(oWx); hcout.push_back(oWy); hcout.push_back(oEx); hcout.push_back(oEy);
-  N hcf_new = cs.hash(hcout);
+  N hcf_pre = cs.hash_cached(std::vector<N>(hcout.begin(), hcout.begin() + 29), nullptr, cache ? &cache->cf_pre : nullptr);
+  // the folded commitments
+  job1.wait(); job2.wait();
+  Pt W1 = ec.add(We, ec.scalar_mul(c1W, r1b, 128, job1.o[0])), E1 = ec.add(Ee, ec.scalar_mul(c1T, r1b, 128, job1.o[1]));
+  Pt W2 = ec.add(W1, ec.scalar_mul(c2W, r2b, 128, job2.o[0])), E2 = ec.add(E1, ec.scalar_mul(c2T, r2b, 128, job2.o[1]));
+  // masked by the base case
+  N oWx = cs.mul(nb, W2.x), oWy = cs.mul(nb, W2.y), oEx = cs.mul(nb, E2.x), oEy = cs.mul(nb, E2.y);
+  out.cfU_new.W.x = oWx.v; out.cfU_new.W.y = oWy.v; out.cfU_new.E.x = oEx.v; out.cfU_new.E.y = oEy.v; out.cfU_new.u = ou.v;
+  for (int k = 0; k < CF_IO; k++) out.cfU_new.x[k] = x2vv[k];
+  N hcf_new = cs.hash_cached({hcf_pre, hcout[29], oWx, oWy, oEx, oEy}, nullptr, cache ? &cache->cf_fin : nullptr);
   N p0 = cs.alloc(hU_new.v), p1 = cs.alloc(hcf_new.v);
   cs.enforce_equal(p0, hU_new);
   cs.enforce_equal(p1, hcf_new);
@@ -306,6 +318,7 @@ struct CfMainCircuit {
   uint32_t len_z = 0, step_wires = 0, step_constraints = 0;
   CfFr digest;                 // SHA3-256 of both shapes, truncated to 250 bits
   mutable std::unique_ptr<Worker> worker, worker2;
+  mutable CfHashCache cache;            // the output hashes of the last witness() call, replayed by the next
   bool use_worker = std::thread::hardware_concurrency() > 1 && !getenv("VIMZ_AUG_NO_THREADS");
   uint32_t n_wires() const { return b.n_wires; }
   uint32_t n_constraints() const { return b.n_constraints(); }
@@ -333,7 +346,7 @@ struct CfMainCircuit {
     if (use_worker) { if (!worker) worker.reset(new Worker()); if (!worker2) worker2.reset(new Worker()); cs.worker = worker.get(); cs.worker2 = worker2.get(); }
     std::vector<Num<CfFr>> zi(len_z), zn(len_z);
     for (uint32_t k = 0; k < len_z; k++) { zi[k].v = z_i[k]; zn[k].v = z_next[k]; }
-    CfMainOut o = synthesize_cf_main(cs, in, zi, zn);
+    CfMainOut o = synthesize_cf_main(cs, in, zi, zn, &cache);
     if (cs.w.size() != aug_wires()) throw std::runtime_error("cyclefold main circuit: witness length differs from the shape");
     if (bad) *bad = cs.bad;
     aug.swap(cs.w);

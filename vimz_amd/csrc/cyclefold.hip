@@ -32,6 +32,14 @@ struct vimz_cf {
   char* pin = nullptr; size_t pin_res = 0;         // pinned: 4 MSM results, then staging for the two host-made witnesses
   hipStream_t s2 = nullptr; hipEvent_t ev_fork = nullptr; MsmWorkspace ws2;
   MsmPlan plan_T{}, plan_aug{}, plan_cfW{}, plan_cfT{};
+  // The step rows of the NEXT step's cross term need the running pair as folded by this step and the producer's products of this row
+  // only — not F' of this step: they are queued on a third stream right behind the fold and run, with their commitment (the one large
+  // MSM of a step), under the CycleFold instances and F' on the host.  The verifier rows' share follows F' (k_spmv_cross16 writes it
+  // with the products).  *_for = the step a kept result belongs to (-1: none; never kept across calls).
+  hipStream_t s3 = nullptr; hipEvent_t ev_fold = nullptr, ev_ts = nullptr; MsmWorkspace ws3; char* pin_ts = nullptr;
+  MsmPlan plan_Ts{}, plan_Tv{};
+  int64_t t_step_for = -1, t_ver_for = -1;
+  BaseTables tb_ck2{};            // window tables of the head of ck_cyclefold: the CycleFold instances' small MSMs only add window sums
   uint32_t *Zl = nullptr, *azl = nullptr, *bzl = nullptr, *czl = nullptr;   // the last fresh main instance's vectors (the incoming pair of the next step)
   // host state of the recursion
   uint64_t i = 0;
@@ -64,25 +72,24 @@ bool fetch(hipStream_t s, const uint32_t* d, size_t idx, size_t n, F* out) {
 }
 
 // One CycleFold instance: witness, commitments, challenge, fold into the running CycleFold instance.  which = 1 / 2.
-int run_cyclefold(vimz_cf* v, int which, const uint32_t r_low[4], const G1Aff& P1, const G1Aff& P2, const G1Aff& want, CfChallenges& ch, const NnPoint& hint,
-                  G2Aff* cW_out, G2Aff* cT_out) {
+struct CfWitness { std::vector<Fq> wires; G1Aff P3; bool bad = false; };
+int run_cyclefold(vimz_cf* v, int which, const CfWitness& w, const G1Aff& want, CfChallenges& ch, const NnPoint& hint, G2Aff* cW_out, G2Aff* cT_out) {
   vimz_ctx* ctx = v->ctx;
   hipStream_t s = ctx->stream;
   SecDev& S = v->sec;
-  std::vector<Fq> wires; bool bad = false;
-  const G1Aff P3 = v->cf.witness(r_low, P1, P2, wires, &bad);
-  if (bad || !P3.x.eq(want.x) || !P3.y.eq(want.y)) return vz_fail(ctx, VIMZ_ERR_UNSAT, "cyclefold circuit: its result differs from the folded commitment");
+  const std::vector<Fq>& wires = w.wires;
+  if (w.bad || !w.P3.x.eq(want.x) || !w.P3.y.eq(want.y)) return vz_fail(ctx, VIMZ_ERR_UNSAT, "cyclefold circuit: its result differs from the folded commitment");
   char* pin_cf = v->pin + 4 * v->pin_res;
   memcpy(pin_cf, wires.data(), 32 * (size_t)S.n_w);
   P_TRY(upload_pinned(s, S.z2, pin_cf, 32 * (size_t)S.n_w));
   P_TRY(hipEventRecord(v->ev_fork, s));
   P_TRY(hipStreamWaitEvent(v->s2, v->ev_fork, 0));
-  P_TRY(msm_launch<Grumpkin>(v->s2, v->ws2, v->ck2->d, S.z2 + 8, S.n_w - 1 - CF_IO, 1, 0, v->pin + 2 * v->pin_res, &v->plan_cfW, nullptr, 0, nullptr));
+  P_TRY(msm_launch<Grumpkin>(v->s2, v->ws2, v->ck2->d, S.z2 + 8, S.n_w - 1 - CF_IO, 1, 0, v->pin + 2 * v->pin_res, &v->plan_cfW, nullptr, 0, v->tb_ck2.d ? &v->tb_ck2 : nullptr));
   const bool have_run = !v->cf_u_run.is_zero();        // the running instance is the zero instance until the first fold: no cross term
   hipLaunchKernelGGL(k_spmv_cross16<Fq>, dim3((unsigned)((16 * (size_t)S.n_c + 255) / 256)), dim3(256), 0, s, S.A, S.B, S.C, S.dict, 0u, S.n_c, S.z2, S.az2, S.bz2, S.cz2,
                      have_run ? S.AZ : nullptr, S.BZ, S.CZ, v->cf_u_run, Fq::one(), S.T);
   P_TRY(hipGetLastError());
-  if (have_run) P_TRY(msm_launch<Grumpkin>(s, ctx->msm_ws, v->ck2->d, S.T, S.n_c, 1, 0, v->pin + 3 * v->pin_res, &v->plan_cfT, nullptr, 0, nullptr));
+  if (have_run) P_TRY(msm_launch<Grumpkin>(s, ctx->msm_ws, v->ck2->d, S.T, S.n_c, 1, 0, v->pin + 3 * v->pin_res, &v->plan_cfT, nullptr, 0, v->tb_ck2.d ? &v->tb_ck2 : nullptr));
   P_TRY(hipStreamSynchronize(v->s2));
   const G2Aff cW = msm_finish<Grumpkin>(v->plan_cfW, v->pin + 2 * v->pin_res);
   P_TRY(hipStreamSynchronize(s));
@@ -117,6 +124,7 @@ int cf_fold_core(vimz_cf* v, const uint64_t* step_inputs, size_t nsteps) {
   FoldJob job; job.step_inputs = step_inputs; job.nsteps = nsteps;
   if ((rc = fold_prepare(p, job, true))) return rc;
   struct BrokenGuard { vimz_cf* v; bool armed = true; ~BrokenGuard() { if (armed) v->broken = true; } } guard{v};
+  struct Ahead { vimz_cf* v; ~Ahead() { hipStreamSynchronize(v->s3); v->t_step_for = v->t_ver_for = -1; } } ahead{v};      // nothing queued ahead survives the call
   const std::vector<Fe>& zs = job.zs;
   const size_t pin_stride = FoldJob::pin_stride;
   char* pin_aug = v->pin + 4 * v->pin_res + 32 * (size_t)v->sec.n_w;
@@ -145,8 +153,9 @@ int cf_fold_core(vimz_cf* v, const uint64_t* step_inputs, size_t nsteps) {
       CfMainIn in = CfMainIn::zero();
       in.digest = v->c1->digest; in.i = i; in.z0 = v->z0; in.U = v->U; in.u = v->u; in.cfU = v->cfU;
       CfChallenges ch;
-      ch.h_U = cf_hash_main(in.digest, i, v->z0, z_i, v->U);
-      ch.h_cf = cf_hash_cf(in.digest, v->cfU);
+      // (the hashes of the two running instances are the public IO of the incoming instance — F' of the previous step computed them)
+      ch.h_U = i > 0 ? v->u.x0 : cf_hash_main(in.digest, i, v->z0, z_i, v->U);
+      ch.h_cf = i > 0 ? v->u.x1 : cf_hash_cf(in.digest, v->cfU);
       G1Aff Wn = g1_identity(), En = g1_identity();
       if (i > 0) {
         // ---- 1. cross term of the running and the incoming pair, and its commitment ------------------------------------------------
@@ -155,13 +164,23 @@ int cf_fold_core(vimz_cf* v, const uint64_t* step_inputs, size_t nsteps) {
                        *pcz = r ? bb.cz + 8 * (r - 1) * nc : v->czl;
         const bool have_run = !v->u_run.is_zero();       // step 1 folds into the zero instance: no cross term
         G1Aff cT = g1_identity();
-        if (have_run) {
+        if (have_run && v->t_step_for == (int64_t)i && v->t_ver_for == (int64_t)i) {      // both shares were queued by the previous step
+          P_TRY(hipEventSynchronize(v->ev_ts));
+          const G1Aff c_step = msm_finish<BnG1>(v->plan_Ts, v->pin_ts);
+          P_TRY(hipStreamSynchronize(s));
+          const G1Aff c_ver = msm_finish<BnG1>(v->plan_Tv, v->pin + v->pin_res);
+          G1 sum = aff_is_identity(c_step) ? G1::identity() : from_affine(c_step);
+          add_mixed(sum, c_ver);
+          cT = to_affine(sum);
+        } else if (have_run) {                                                                 // first row of a call: all rows at once
+          P_TRY(hipStreamSynchronize(v->s3));
           hipLaunchKernelGGL(k_cross_term<Fr>, dim3(stream_grid(nc)), dim3(256), 0, s, nc, p->AZ, p->BZ, p->CZ, v->u_run, paz, pbz, pcz, Fe::one(), p->T);
           P_TRY(hipGetLastError());
           P_TRY(msm_launch<BnG1>(s, ctx->msm_ws, p->ck->d, p->T, nc, 1, 0, ctx->msm_ws.host_pinned, &v->plan_T, nullptr, 0, p->ck->tables ? &job.tbl : nullptr));
           P_TRY(hipStreamSynchronize(s));
           cT = msm_finish<BnG1>(v->plan_T, ctx->msm_ws.host_pinned);
         }
+        v->t_step_for = v->t_ver_for = -1;
         v->ph_s[CP_CROSS_MSM] += now_s() - t0; v->ph_n[CP_CROSS_MSM]++;
         // ---- 2. challenge, fold of the main pair -------------------------------------------------------------------------------------
         t0 = now_s();
@@ -177,12 +196,30 @@ int cf_fold_core(vimz_cf* v, const uint64_t* step_inputs, size_t nsteps) {
         hipLaunchKernelGGL(k_fold5<Fr>, dim3(2048), dim3(256), 0, s, f, rho);
         P_TRY(hipGetLastError());
         v->u_run = Fe::add(v->u_run, rho);
+        // the next step folds THIS row's instance: the step rows of that cross term and their commitment start now, on stream 3
+        P_TRY(hipEventRecord(v->ev_fold, s));
+        P_TRY(hipStreamWaitEvent(v->s3, v->ev_fold, 0));
+        P_TRY(hipStreamWaitEvent(v->s3, bb.ev[r], 0));
+        hipLaunchKernelGGL(k_cross_term<Fr>, dim3(stream_grid(sc)), dim3(256), 0, v->s3, sc, p->AZ, p->BZ, p->CZ, v->u_run, az, bz, cz, Fe::one(), p->T);
+        P_TRY(hipGetLastError());
+        P_TRY(msm_launch<BnG1>(v->s3, v->ws3, p->ck->d, p->T, sc, 1, 0, v->pin_ts, &v->plan_Ts, nullptr, 0, p->ck->tables ? &job.tbl : nullptr));
+        P_TRY(hipEventRecord(v->ev_ts, v->s3));
+        v->t_step_for = (int64_t)i + 1;
         Wn = g1_fold(v->UW, ch.r, v->uW);
         En = g1_fold(v->UE, ch.r, cT);
         in.Wn = nn_point(Wn); in.En = nn_point(En);
         // ---- 3. the two CycleFold instances -------------------------------------------------------------------------------------------
-        if ((rc = run_cyclefold(v, 1, ch.r, v->UW, v->uW, Wn, ch, in.Wn, &in.cf1W, &in.cf1T))) return rc;
-        if ((rc = run_cyclefold(v, 2, ch.r, v->UE, cT, En, ch, in.En, &in.cf2W, &in.cf2T))) return rc;
+        // (both witnesses need the challenge only: the second is computed on a helper thread while the first instance is on the GPU)
+        CfWitness w1, w2;
+        aug::Worker* helper = v->c1->use_worker ? v->c1->worker.get() : nullptr;
+        const G1Aff UE_now = v->UE;
+        auto make2 = [&] { w2.P3 = v->cf.witness(ch.r, UE_now, cT, w2.wires, &w2.bad); };
+        if (helper) helper->start(make2);
+        w1.P3 = v->cf.witness(ch.r, v->UW, v->uW, w1.wires, &w1.bad);
+        rc = run_cyclefold(v, 1, w1, Wn, ch, in.Wn, &in.cf1W, &in.cf1T);
+        if (helper) helper->wait(); else make2();
+        if (rc) return rc;
+        if ((rc = run_cyclefold(v, 2, w2, En, ch, in.En, &in.cf2W, &in.cf2T))) return rc;
         v->ph_s[CP_CF] += now_s() - t0; v->ph_n[CP_CF]++;
       }
       // ---- 4. F' of this step on the host ---------------------------------------------------------------------------------------------------
@@ -203,14 +240,20 @@ int cf_fold_core(vimz_cf* v, const uint64_t* step_inputs, size_t nsteps) {
       P_TRY(hipEventRecord(v->ev_fork, s));
       P_TRY(hipStreamWaitEvent(v->s2, v->ev_fork, 0));
       P_TRY(msm_launch<BnG1>(v->s2, v->ws2, p->ck->d + (size_t)AFFINE_WORDS * (sw - 1), Zi + 8 * sw, aw - 2, 1, 0, v->pin, &v->plan_aug, nullptr, 0, nullptr));
+      // (the verifier rows' products, and with them those rows' share of the next step's cross term and its commitment)
+      const bool cross_ahead = v->t_step_for == (int64_t)i + 1;
       hipLaunchKernelGGL(k_spmv_cross16<Fr>, dim3((unsigned)((16 * (nc - sc) + 255) / 256)), dim3(256), 0, s, p->A, p->B, p->C, p->dict, (uint32_t)sc, (uint32_t)(nc - sc),
-                         Zi, az, bz, cz, (const uint32_t*)nullptr, p->BZ, p->CZ, v->u_run, Fe::one(), p->T);
+                         Zi, az, bz, cz, cross_ahead ? (const uint32_t*)p->AZ : (const uint32_t*)nullptr, p->BZ, p->CZ, v->u_run, Fe::one(), p->T);
       P_TRY(hipGetLastError());
       P_TRY(hipEventSynchronize(bb.ev[r]));
       const G1Aff cW_step = msm_finish<BnG1>(p->planB, (char*)bb.pin + r * pin_stride);
       P_TRY(hipStreamSynchronize(v->s2));
       const G1Aff cW_aug = msm_finish<BnG1>(v->plan_aug, v->pin);
       P_TRY(hipStreamSynchronize(s));
+      if (cross_ahead) {
+        P_TRY(msm_launch<BnG1>(s, ctx->msm_ws, p->ck->d + (size_t)AFFINE_WORDS * sc, p->T + 8 * sc, nc - sc, 1, 0, v->pin + v->pin_res, &v->plan_Tv, nullptr, 0, nullptr));
+        v->t_ver_for = (int64_t)i + 1;
+      }
       G1 sum = from_affine(cW_step); if (aff_is_identity(cW_step)) sum = G1::identity();
       add_mixed(sum, cW_aug);
       v->uW = to_affine(sum);
@@ -276,8 +319,12 @@ void vimz_cf_free(vimz_cf* v) {
     hipSetDevice(v->ctx->device);
     hipStreamSynchronize(v->ctx->stream);
     if (v->s2) { hipStreamSynchronize(v->s2); hipStreamDestroy(v->s2); }
+    if (v->s3) { hipStreamSynchronize(v->s3); hipStreamDestroy(v->s3); }
     if (v->ev_fork) hipEventDestroy(v->ev_fork);
-    v->ws2.release();
+    if (v->ev_fold) hipEventDestroy(v->ev_fold);
+    if (v->ev_ts) hipEventDestroy(v->ev_ts);
+    if (v->pin_ts) hipHostFree(v->pin_ts);
+    v->ws2.release(); v->ws3.release();
     for (void* d : v->owned) hipFree(d);
     if (v->pin) hipHostFree(v->pin);
   }
@@ -297,6 +344,7 @@ int vimz_cf_create(vimz_ctx* ctx, const vimz_circuit* step_circuit, const vimz_b
     v->circ->build->b = step_circuit->build->b;
     v->c1.reset(new CfMainCircuit(v->circ->build->b));
     v->c1->finish(v->cf);
+    if (v->c1->use_worker) { v->c1->worker.reset(new aug::Worker()); v->c1->worker2.reset(new aug::Worker()); }
   } catch (const std::exception& e) { return vz_fail(ctx, VIMZ_ERR_INVALID, e.what()); }
   const uint32_t nw2 = v->cf.n_wires(), nc2 = v->cf.n_constraints();
   if (ck2->n < nw2 || ck2->n < nc2) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_cf_create: CycleFold commitment key shorter than the CycleFold circuit");
@@ -336,7 +384,12 @@ int vimz_cf_create(vimz_ctx* ctx, const vimz_circuit* step_circuit, const vimz_b
   for (auto d : {&v->azl, &v->bzl, &v->czl}) if (dalloc(d, 32 * nc) != hipSuccess) return fail("device allocation");
   { int lo = 0, hi = 0; hipDeviceGetStreamPriorityRange(&lo, &hi);
     if ((e = hipStreamCreateWithPriority(&v->s2, hipStreamNonBlocking, hi)) != hipSuccess) return fail("stream");
-    if ((e = hipEventCreateWithFlags(&v->ev_fork, hipEventDisableTiming)) != hipSuccess) return fail("event"); }
+    if ((e = hipStreamCreateWithPriority(&v->s3, hipStreamNonBlocking, (lo + hi) / 2)) != hipSuccess) return fail("stream");
+    if ((e = hipEventCreateWithFlags(&v->ev_fork, hipEventDisableTiming)) != hipSuccess) return fail("event");
+    if ((e = hipEventCreateWithFlags(&v->ev_fold, hipEventDisableTiming)) != hipSuccess) return fail("event");
+    if ((e = hipEventCreateWithFlags(&v->ev_ts, hipEventDisableTiming)) != hipSuccess) return fail("event"); }
+  if ((e = hipHostMalloc((void**)&v->pin_ts, 4 * (size_t)XYZZ_WORDS * MSM_MAX_WINDOWS)) != hipSuccess) return fail("pinned");
+  if ((rc = vz_small_tables(ctx, const_cast<vimz_bases*>(ck2), 0, std::max<size_t>(nw2 - 1 - CF_IO, nc2), false, &v->tb_ck2))) { lk.unlock(); vimz_cf_free(v.release()); return rc; }
   v->pin_res = 4 * (size_t)XYZZ_WORDS * MSM_MAX_WINDOWS;
   if ((e = hipHostMalloc((void**)&v->pin, 4 * v->pin_res + 32 * (size_t)nw2 + 32 * (size_t)v->c1->aug_wires() + 64)) != hipSuccess) return fail("pinned");
   if ((e = hipStreamSynchronize(nullptr)) != hipSuccess) return fail("sync");
@@ -367,7 +420,7 @@ int vimz_cf_reset(vimz_cf* v, const uint64_t* z0) {
   for (uint32_t k = 0; k < v->c1->len_z; k++) v->z0[k] = v->pri->z_cur[k];
   v->U = CfMainRelaxed::zero(); v->u = CfMainFresh::zero(); v->cfU = CfRelaxed::zero();
   v->UW = v->UE = v->uW = g1_identity();
-  v->u_run = Fe::zero(); v->cf_u_run = Fq::zero(); v->broken = false;
+  v->u_run = Fe::zero(); v->cf_u_run = Fq::zero(); v->broken = false; v->t_step_for = v->t_ver_for = -1;
   memset(v->ph_s, 0, sizeof(v->ph_s)); memset(v->ph_n, 0, sizeof(v->ph_n));
   return VIMZ_OK;
 }

@@ -16,6 +16,7 @@ from .circuit import Circuit, default_shape
 
 DEMO_STEPS = 10  # vimz/src/lib.rs:9
 AUGMENTED_ROOM = 8192   # wires / constraints Nova's verifier circuit adds to a step circuit (vimz_ivc_create)
+CYCLEFOLD_ROOM = 28672  # ... and Nova + CycleFold's main circuit F' (vimz_cf_create: 27.5 k — non-native folds of two CycleFold instances per step)
 SECONDARY_KEY_LEN = 1 << 13   # generators of the secondary (Grumpkin) key: the secondary circuit has 7.6 k wires / rows
 
 # vimz/src/transformation.rs:93-123
@@ -93,14 +94,16 @@ class FoldingParams:
         self.ck.free()
 
 
-def prepare_folding(ctx, transformation, resolution="HD", ck_label=b"ck", window_tables=0):
+def prepare_folding(ctx, transformation, resolution="HD", ck_label=b"ck", window_tables=0, backend="nova-snark"):
     """prepare_folding (folding.rs:20-25): build the step circuit and derive the commitment key on the GPU.
     window_tables: 0 = none; 11 = tables 2^(11j)·P_i with the usual per-window buckets (24 x the key in HBM, 1 GB at HD: the
-    window sums need no Horner on the host); 13..16 = one bucket set shared by all windows (vimz_bases_precompute)."""
+    window sums need no Horner on the host); 13..16 = one bucket set shared by all windows (vimz_bases_precompute).
+    backend: "nova-snark" (vimz/src/nova_snark_backend) or "sonobe" (vimz/src/sonobe_backend: Nova + CycleFold, fold_input(mode="cyclefold"));
+    it only sizes the key (the reference's two backends size theirs the same way: for the augmented circuit)."""
     t0 = time.time()
     circuit = Circuit(transformation, *default_shape(transformation, resolution))
     # next power of two, as nova-snark sizes ck — of the AUGMENTED circuit: the verifier circuit adds 7.7 k wires / rows
-    n = 1 << (max(circuit.n_wires, circuit.n_constraints) + AUGMENTED_ROOM - 1).bit_length()
+    n = 1 << (max(circuit.n_wires, circuit.n_constraints) + (CYCLEFOLD_ROOM if backend == "sonobe" else AUGMENTED_ROOM) - 1).bit_length()
     ck = ctx.bases_generate(_lib.CURVE_BN254_G1, n, ck_label)
     if window_tables:
         ck.precompute(16 if window_tables is True else int(window_tables))
@@ -127,7 +130,7 @@ class FoldingProof:
 
     def state(self):
         """The final IVC state z_n as integers."""
-        if self.mode == "ivc":
+        if self.mode in ("ivc", "cyclefold"):
             return self.prover.state()[0]
         if self.mode == "merged":
             return self.prover.state()[1]
@@ -151,9 +154,14 @@ def fold_input(params, ivc_step_inputs, initial_state, max_batch=None, prover=No
     segments = S > 1 (mode "ivc"): the rows are proven as S contiguous segments folded CONCURRENTLY on this GPU (one IVC each, own
     context and streams) and merged into ONE proof object (vimz_ivc_merge; FoldingProof.mode == "merged") — a single chain leaves a
     quarter of an MI355X idle."""
-    from .hip import IVC, Context, MergedProof, Prover
+    from .hip import IVC, Context, CycleFoldIVC, MergedProof, Prover
     if max_batch is None:
         max_batch = default_batch(params.circuit)
+    if mode == "cyclefold":        # the Sonobe backend's fold_input (vimz/src/sonobe_backend/folding.rs:52-66): Nova + CycleFold prove_step per row
+        p = prover if prover is not None else CycleFoldIVC(params.ctx, params.circuit, params.ck, params.secondary_key(), max_batch=max_batch)
+        p.reset(initial_state)
+        p.fold(ivc_step_inputs)
+        return FoldingProof(p, len(ivc_step_inputs), list(initial_state), "cyclefold")
     if prover is None and mode == "ivc" and segments > 1 and len(ivc_step_inputs) >= segments:
         from .distributed import fold_concurrently, ivc_segments
         ctxs = [params.ctx] + [Context(params.ctx.device) for _ in range(segments - 1)]
@@ -188,7 +196,7 @@ def fold_input(params, ivc_step_inputs, initial_state, max_batch=None, prover=No
 def verify_folded_proof(proof, params, num_steps, initial_state):
     """verify_folded_proof (folding.rs:45-56: RecursiveSNARK::verify(pp, num_steps, z0, [0])); raises like the reference's
     expect("Failed to verify folded proof")."""
-    if proof.mode in ("ivc", "merged"):
+    if proof.mode in ("ivc", "merged", "cyclefold"):      # (cyclefold: verify_folding, vimz/src/sonobe_backend/folding.rs:69-75)
         r = proof.prover.verify(num_steps, initial_state)
         if r != 0:
             raise _lib.VimzError(_lib.ERR_UNSAT, f"Failed to verify folded proof (flags {r:#x})")
