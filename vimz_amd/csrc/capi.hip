@@ -354,7 +354,7 @@ int vimz_bases_precompute(vimz_ctx* c, vimz_bases* b, int window_bits) {
   if (!c || !b) return fail(c, VIMZ_ERR_INVALID, "vimz_bases_precompute: bad argument");
   const int cw = window_bits > 0 ? window_bits : 16;
   if (cw == SMALL_C) {       // the small-MSM form: rows 2^(7w)·P_i and every multiple of them (keys of at most MSM_SMALL_MAX points)
-    if (b->n > MSM_SMALL_MAX) return fail(c, VIMZ_ERR_INVALID, "vimz_bases_precompute: window_bits 7 (tables of multiples) is for keys of at most 24576 points");
+    if (b->n > MSM_SMALL_MAX) return fail(c, VIMZ_ERR_INVALID, "vimz_bases_precompute: window_bits 7 (tables of multiples) is for keys of at most 30720 points");
     std::lock_guard<std::mutex> g(c->mu);
     HIP_TRY(c, hipSetDevice(c->device));
     BaseTables t;

@@ -41,6 +41,8 @@ struct vimz_cf {
   int64_t t_step_for = -1, t_ver_for = -1;
   BaseTables tb_ck2{};            // window tables of the head of ck_cyclefold: the CycleFold instances' small MSMs only add window sums
   uint32_t *Zl = nullptr, *azl = nullptr, *bzl = nullptr, *czl = nullptr;   // the last fresh main instance's vectors (the incoming pair of the next step)
+  uint32_t *z3 = nullptr, *az3 = nullptr, *bz3 = nullptr, *cz3 = nullptr;   // the second CycleFold instance of a step (the first uses sec.z2, ...)
+  MsmPlan plan_cfW2{}; hipStream_t s4 = nullptr; MsmWorkspace ws4; hipEvent_t ev_z3 = nullptr; char* pin_w2 = nullptr;   // ... and commits to its witness on a stream of its own
   // host state of the recursion
   uint64_t i = 0;
   std::vector<Fe> z0;
@@ -73,39 +75,67 @@ bool fetch(hipStream_t s, const uint32_t* d, size_t idx, size_t n, F* out) {
 
 // One CycleFold instance: witness, commitments, challenge, fold into the running CycleFold instance.  which = 1 / 2.
 struct CfWitness { std::vector<Fq> wires; G1Aff P3; bool bad = false; };
-int run_cyclefold(vimz_cf* v, int which, const CfWitness& w, const G1Aff& want, CfChallenges& ch, const NnPoint& hint, G2Aff* cW_out, G2Aff* cT_out) {
+// The two CycleFold instances of a step: commitments, (A,B,C)·z, cross terms against the running CycleFold instance, challenges, folds.
+// Both witness commitments run side by side on stream 2; on the main stream the chain is cross term 1 -> commitment -> challenge -> fold ->
+// cross term 2 (against the folded instance) -> commitment -> challenge -> fold.  second(): blocks until the second witness exists.
+template <class WaitSecond>
+int run_cyclefold_pair(vimz_cf* v, const CfWitness& w1, const CfWitness& w2, WaitSecond second, CfChallenges& ch, CfMainIn& in) {
   vimz_ctx* ctx = v->ctx;
   hipStream_t s = ctx->stream;
   SecDev& S = v->sec;
-  const std::vector<Fq>& wires = w.wires;
-  if (w.bad || !w.P3.x.eq(want.x) || !w.P3.y.eq(want.y)) return vz_fail(ctx, VIMZ_ERR_UNSAT, "cyclefold circuit: its result differs from the folded commitment");
+  if (w1.bad) return vz_fail(ctx, VIMZ_ERR_UNSAT, "cyclefold circuit: a commitment to fold is not on the curve");
   char* pin_cf = v->pin + 4 * v->pin_res;
-  memcpy(pin_cf, wires.data(), 32 * (size_t)S.n_w);
+  char* pin_cf2 = pin_cf + 32 * (size_t)S.n_w;
+  const size_t nwit = S.n_w - 1 - CF_IO;
+  const BaseTables* tb = v->tb_ck2.d ? &v->tb_ck2 : nullptr;
+  auto cross = [&](const uint32_t* z, uint32_t* az, uint32_t* bz, uint32_t* cz, bool have_run) {
+    hipLaunchKernelGGL(k_spmv_cross16<Fq>, dim3((unsigned)((16 * (size_t)S.n_c + 255) / 256)), dim3(256), 0, s, S.A, S.B, S.C, S.dict, 0u, S.n_c, z, az, bz, cz,
+                       have_run ? S.AZ : nullptr, S.BZ, S.CZ, v->cf_u_run, Fq::one(), S.T);
+  };
+  auto fold = [&](const uint32_t* z, const uint32_t* az, const uint32_t* bz, const uint32_t* cz, bool have_run, const Fq& rq) {
+    Fold5 f;
+    f.x1[0] = S.Zrun; f.x2[0] = z; f.n[0] = S.n_w;
+    f.x1[1] = have_run ? S.E : nullptr; f.x2[1] = S.T; f.n[1] = S.n_c;
+    f.x1[2] = S.AZ; f.x2[2] = az; f.n[2] = S.n_c;
+    f.x1[3] = S.BZ; f.x2[3] = bz; f.n[3] = S.n_c;
+    f.x1[4] = S.CZ; f.x2[4] = cz; f.n[4] = S.n_c;
+    hipLaunchKernelGGL(k_fold5<Fq>, dim3(64), dim3(256), 0, s, f, rq);
+    v->cf_u_run = Fq::add(v->cf_u_run, rq);
+  };
+  // first instance
+  memcpy(pin_cf, w1.wires.data(), 32 * (size_t)S.n_w);
   P_TRY(upload_pinned(s, S.z2, pin_cf, 32 * (size_t)S.n_w));
   P_TRY(hipEventRecord(v->ev_fork, s));
   P_TRY(hipStreamWaitEvent(v->s2, v->ev_fork, 0));
-  P_TRY(msm_launch<Grumpkin>(v->s2, v->ws2, v->ck2->d, S.z2 + 8, S.n_w - 1 - CF_IO, 1, 0, v->pin + 2 * v->pin_res, &v->plan_cfW, nullptr, 0, v->tb_ck2.d ? &v->tb_ck2 : nullptr));
-  const bool have_run = !v->cf_u_run.is_zero();        // the running instance is the zero instance until the first fold: no cross term
-  hipLaunchKernelGGL(k_spmv_cross16<Fq>, dim3((unsigned)((16 * (size_t)S.n_c + 255) / 256)), dim3(256), 0, s, S.A, S.B, S.C, S.dict, 0u, S.n_c, S.z2, S.az2, S.bz2, S.cz2,
-                     have_run ? S.AZ : nullptr, S.BZ, S.CZ, v->cf_u_run, Fq::one(), S.T);
+  P_TRY(msm_launch<Grumpkin>(v->s2, v->ws2, v->ck2->d, S.z2 + 8, nwit, 1, 0, v->pin + 2 * v->pin_res, &v->plan_cfW, nullptr, 0, tb));
+  const bool run1 = !v->cf_u_run.is_zero();        // the running instance is the zero instance until the first fold: no cross term
+  cross(S.z2, S.az2, S.bz2, S.cz2, run1);
   P_TRY(hipGetLastError());
-  if (have_run) P_TRY(msm_launch<Grumpkin>(s, ctx->msm_ws, v->ck2->d, S.T, S.n_c, 1, 0, v->pin + 3 * v->pin_res, &v->plan_cfT, nullptr, 0, v->tb_ck2.d ? &v->tb_ck2 : nullptr));
+  if (run1) P_TRY(msm_launch<Grumpkin>(s, ctx->msm_ws, v->ck2->d, S.T, S.n_c, 1, 0, v->pin + 3 * v->pin_res, &v->plan_cfT, nullptr, 0, tb));
+  // second instance: its witness commitment needs the upload only — on its own stream, next to the first one's
+  second();
+  if (w2.bad) return vz_fail(ctx, VIMZ_ERR_UNSAT, "cyclefold circuit: a commitment to fold is not on the curve");
+  memcpy(pin_cf2, w2.wires.data(), 32 * (size_t)S.n_w);
+  P_TRY(upload_pinned(v->s4, v->z3, pin_cf2, 32 * (size_t)S.n_w));
+  P_TRY(hipEventRecord(v->ev_z3, v->s4));
+  P_TRY(msm_launch<Grumpkin>(v->s4, v->ws4, v->ck2->d, v->z3 + 8, nwit, 1, 0, v->pin_w2, &v->plan_cfW2, nullptr, 0, tb));
   P_TRY(hipStreamSynchronize(v->s2));
-  const G2Aff cW = msm_finish<Grumpkin>(v->plan_cfW, v->pin + 2 * v->pin_res);
+  in.cf1W = msm_finish<Grumpkin>(v->plan_cfW, v->pin + 2 * v->pin_res);
   P_TRY(hipStreamSynchronize(s));
-  const G2Aff cT = have_run ? msm_finish<Grumpkin>(v->plan_cfT, v->pin + 3 * v->pin_res) : g2_identity();
-  if (which == 1) cf_challenge_cf1(ch, cW, hint, cT); else cf_challenge_cf2(ch, cW, hint, cT);
-  const Fq rq = rho_element<Fq>(which == 1 ? ch.r1 : ch.r2);
-  Fold5 f;
-  f.x1[0] = S.Zrun; f.x2[0] = S.z2; f.n[0] = S.n_w;
-  f.x1[1] = have_run ? S.E : nullptr; f.x2[1] = S.T; f.n[1] = S.n_c;
-  f.x1[2] = S.AZ; f.x2[2] = S.az2; f.n[2] = S.n_c;
-  f.x1[3] = S.BZ; f.x2[3] = S.bz2; f.n[3] = S.n_c;
-  f.x1[4] = S.CZ; f.x2[4] = S.cz2; f.n[4] = S.n_c;
-  hipLaunchKernelGGL(k_fold5<Fq>, dim3(64), dim3(256), 0, s, f, rq);
+  in.cf1T = run1 ? msm_finish<Grumpkin>(v->plan_cfT, v->pin + 3 * v->pin_res) : g2_identity();
+  cf_challenge_cf1(ch, in.cf1W, in.Wn, in.cf1T);
+  fold(S.z2, S.az2, S.bz2, S.cz2, run1, rho_element<Fq>(ch.r1));
+  P_TRY(hipStreamWaitEvent(s, v->ev_z3, 0));
+  cross(v->z3, v->az3, v->bz3, v->cz3, true);
   P_TRY(hipGetLastError());
-  v->cf_u_run = Fq::add(v->cf_u_run, rq);
-  *cW_out = cW; *cT_out = cT;
+  P_TRY(msm_launch<Grumpkin>(s, ctx->msm_ws, v->ck2->d, S.T, S.n_c, 1, 0, v->pin + 3 * v->pin_res, &v->plan_cfT, nullptr, 0, tb));
+  P_TRY(hipStreamSynchronize(v->s4));
+  in.cf2W = msm_finish<Grumpkin>(v->plan_cfW2, v->pin_w2);
+  P_TRY(hipStreamSynchronize(s));
+  in.cf2T = msm_finish<Grumpkin>(v->plan_cfT, v->pin + 3 * v->pin_res);
+  cf_challenge_cf2(ch, in.cf2W, in.En, in.cf2T);
+  fold(v->z3, v->az3, v->bz3, v->cz3, true, rho_element<Fq>(ch.r2));
+  P_TRY(hipGetLastError());
   return VIMZ_OK;
 }
 
@@ -127,7 +157,7 @@ int cf_fold_core(vimz_cf* v, const uint64_t* step_inputs, size_t nsteps) {
   struct Ahead { vimz_cf* v; ~Ahead() { hipStreamSynchronize(v->s3); v->t_step_for = v->t_ver_for = -1; } } ahead{v};      // nothing queued ahead survives the call
   const std::vector<Fe>& zs = job.zs;
   const size_t pin_stride = FoldJob::pin_stride;
-  char* pin_aug = v->pin + 4 * v->pin_res + 32 * (size_t)v->sec.n_w;
+  char* pin_aug = v->pin + 4 * v->pin_res + 64 * (size_t)v->sec.n_w;
   if (!ctx->msm_ws.host_pinned) P_TRY(hipHostMalloc(&ctx->msm_ws.host_pinned, 4 * XYZZ_WORDS * MSM_MAX_WINDOWS));
   for (size_t k = 0; k < job.nbatches; k++) {
     auto& bb = p->buf[k & 1];
@@ -205,9 +235,6 @@ int cf_fold_core(vimz_cf* v, const uint64_t* step_inputs, size_t nsteps) {
         P_TRY(msm_launch<BnG1>(v->s3, v->ws3, p->ck->d, p->T, sc, 1, 0, v->pin_ts, &v->plan_Ts, nullptr, 0, p->ck->tables ? &job.tbl : nullptr));
         P_TRY(hipEventRecord(v->ev_ts, v->s3));
         v->t_step_for = (int64_t)i + 1;
-        Wn = g1_fold(v->UW, ch.r, v->uW);
-        En = g1_fold(v->UE, ch.r, cT);
-        in.Wn = nn_point(Wn); in.En = nn_point(En);
         // ---- 3. the two CycleFold instances -------------------------------------------------------------------------------------------
         // (both witnesses need the challenge only: the second is computed on a helper thread while the first instance is on the GPU)
         CfWitness w1, w2;
@@ -216,10 +243,13 @@ int cf_fold_core(vimz_cf* v, const uint64_t* step_inputs, size_t nsteps) {
         auto make2 = [&] { w2.P3 = v->cf.witness(ch.r, UE_now, cT, w2.wires, &w2.bad); };
         if (helper) helper->start(make2);
         w1.P3 = v->cf.witness(ch.r, v->UW, v->uW, w1.wires, &w1.bad);
-        rc = run_cyclefold(v, 1, w1, Wn, ch, in.Wn, &in.cf1W, &in.cf1T);
-        if (helper) helper->wait(); else make2();
+        // (the folded commitments W' = W + r·W_in and E' = E + r·cmT are what the two witnesses end in: no second scalar multiplication)
+        Wn = w1.P3; in.Wn = nn_point(Wn);
+        bool waited = false;
+        auto second = [&] { if (waited) return; waited = true; if (helper) helper->wait(); else make2(); En = w2.P3; in.En = nn_point(En); };
+        rc = run_cyclefold_pair(v, w1, w2, second, ch, in);
+        second();                                        // (an early error return must not leave the helper running on this frame)
         if (rc) return rc;
-        if ((rc = run_cyclefold(v, 2, w2, En, ch, in.En, &in.cf2W, &in.cf2T))) return rc;
         v->ph_s[CP_CF] += now_s() - t0; v->ph_n[CP_CF]++;
       }
       // ---- 4. F' of this step on the host ---------------------------------------------------------------------------------------------------
@@ -245,15 +275,14 @@ int cf_fold_core(vimz_cf* v, const uint64_t* step_inputs, size_t nsteps) {
       hipLaunchKernelGGL(k_spmv_cross16<Fr>, dim3((unsigned)((16 * (nc - sc) + 255) / 256)), dim3(256), 0, s, p->A, p->B, p->C, p->dict, (uint32_t)sc, (uint32_t)(nc - sc),
                          Zi, az, bz, cz, cross_ahead ? (const uint32_t*)p->AZ : (const uint32_t*)nullptr, p->BZ, p->CZ, v->u_run, Fe::one(), p->T);
       P_TRY(hipGetLastError());
+      if (cross_ahead) {      // (same stream: it follows the kernel that writes its scalars; read back at the start of the next step)
+        P_TRY(msm_launch<BnG1>(s, ctx->msm_ws, p->ck->d + (size_t)AFFINE_WORDS * sc, p->T + 8 * sc, nc - sc, 1, 0, v->pin + v->pin_res, &v->plan_Tv, nullptr, 0, nullptr));
+        v->t_ver_for = (int64_t)i + 1;
+      }
       P_TRY(hipEventSynchronize(bb.ev[r]));
       const G1Aff cW_step = msm_finish<BnG1>(p->planB, (char*)bb.pin + r * pin_stride);
       P_TRY(hipStreamSynchronize(v->s2));
       const G1Aff cW_aug = msm_finish<BnG1>(v->plan_aug, v->pin);
-      P_TRY(hipStreamSynchronize(s));
-      if (cross_ahead) {
-        P_TRY(msm_launch<BnG1>(s, ctx->msm_ws, p->ck->d + (size_t)AFFINE_WORDS * sc, p->T + 8 * sc, nc - sc, 1, 0, v->pin + v->pin_res, &v->plan_Tv, nullptr, 0, nullptr));
-        v->t_ver_for = (int64_t)i + 1;
-      }
       G1 sum = from_affine(cW_step); if (aff_is_identity(cW_step)) sum = G1::identity();
       add_mixed(sum, cW_aug);
       v->uW = to_affine(sum);
@@ -320,6 +349,10 @@ void vimz_cf_free(vimz_cf* v) {
     hipStreamSynchronize(v->ctx->stream);
     if (v->s2) { hipStreamSynchronize(v->s2); hipStreamDestroy(v->s2); }
     if (v->s3) { hipStreamSynchronize(v->s3); hipStreamDestroy(v->s3); }
+    if (v->s4) { hipStreamSynchronize(v->s4); hipStreamDestroy(v->s4); }
+    if (v->ev_z3) hipEventDestroy(v->ev_z3);
+    if (v->pin_w2) hipHostFree(v->pin_w2);
+    v->ws4.release();
     if (v->ev_fork) hipEventDestroy(v->ev_fork);
     if (v->ev_fold) hipEventDestroy(v->ev_fold);
     if (v->ev_ts) hipEventDestroy(v->ev_ts);
@@ -382,16 +415,21 @@ int vimz_cf_create(vimz_ctx* ctx, const vimz_circuit* step_circuit, const vimz_b
   const size_t nw = v->circ->build->b.n_wires, nc = v->circ->build->b.n_constraints();
   if (dalloc(&v->Zl, 32 * nw) != hipSuccess) return fail("device allocation");
   for (auto d : {&v->azl, &v->bzl, &v->czl}) if (dalloc(d, 32 * nc) != hipSuccess) return fail("device allocation");
+  if (dalloc(&v->z3, 32 * (size_t)nw2) != hipSuccess) return fail("device allocation");
+  for (auto d : {&v->az3, &v->bz3, &v->cz3}) if (dalloc(d, 32 * (size_t)nc2) != hipSuccess) return fail("device allocation");
   { int lo = 0, hi = 0; hipDeviceGetStreamPriorityRange(&lo, &hi);
     if ((e = hipStreamCreateWithPriority(&v->s2, hipStreamNonBlocking, hi)) != hipSuccess) return fail("stream");
     if ((e = hipStreamCreateWithPriority(&v->s3, hipStreamNonBlocking, (lo + hi) / 2)) != hipSuccess) return fail("stream");
+    if ((e = hipStreamCreateWithPriority(&v->s4, hipStreamNonBlocking, hi)) != hipSuccess) return fail("stream");
+    if ((e = hipEventCreateWithFlags(&v->ev_z3, hipEventDisableTiming)) != hipSuccess) return fail("event");
     if ((e = hipEventCreateWithFlags(&v->ev_fork, hipEventDisableTiming)) != hipSuccess) return fail("event");
     if ((e = hipEventCreateWithFlags(&v->ev_fold, hipEventDisableTiming)) != hipSuccess) return fail("event");
     if ((e = hipEventCreateWithFlags(&v->ev_ts, hipEventDisableTiming)) != hipSuccess) return fail("event"); }
   if ((e = hipHostMalloc((void**)&v->pin_ts, 4 * (size_t)XYZZ_WORDS * MSM_MAX_WINDOWS)) != hipSuccess) return fail("pinned");
+  if ((e = hipHostMalloc((void**)&v->pin_w2, 4 * (size_t)XYZZ_WORDS * MSM_MAX_WINDOWS)) != hipSuccess) return fail("pinned");
   if ((rc = vz_small_tables(ctx, const_cast<vimz_bases*>(ck2), 0, std::max<size_t>(nw2 - 1 - CF_IO, nc2), false, &v->tb_ck2))) { lk.unlock(); vimz_cf_free(v.release()); return rc; }
   v->pin_res = 4 * (size_t)XYZZ_WORDS * MSM_MAX_WINDOWS;
-  if ((e = hipHostMalloc((void**)&v->pin, 4 * v->pin_res + 32 * (size_t)nw2 + 32 * (size_t)v->c1->aug_wires() + 64)) != hipSuccess) return fail("pinned");
+  if ((e = hipHostMalloc((void**)&v->pin, 4 * v->pin_res + 64 * (size_t)nw2 + 32 * (size_t)v->c1->aug_wires() + 64)) != hipSuccess) return fail("pinned");
   if ((e = hipStreamSynchronize(nullptr)) != hipSuccess) return fail("sync");
   v->z0.assign(v->c1->len_z, Fe::zero());
   v->U = CfMainRelaxed::zero(); v->u = CfMainFresh::zero(); v->cfU = CfRelaxed::zero();

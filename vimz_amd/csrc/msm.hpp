@@ -658,7 +658,7 @@ __global__ void __launch_bounds__(64) k_msm_small_sum(const uint32_t* __restrict
 // of n·37 points — no digit sort, no bucket accumulation chains, no weighted bucket reduction (twelve dependent additions).  Depth:
 // three mixed additions per thread (four points each), the 256-leaf tree of a workgroup (nine four-lane rounds), the tree over a
 // window's ≤ 32 workgroup sums by the last workgroup of the window to arrive; the host adds the 37 window sums as before.
-constexpr uint32_t FIXED_PER_THREAD = 4, FIXED_CHUNK = 256 * FIXED_PER_THREAD, FIXED_MAXQ = 32;
+constexpr uint32_t FIXED_PER_THREAD = 4, FIXED_CHUNK = 256 * FIXED_PER_THREAD, FIXED_MAXQ = 64;
 static_assert(MSM_SMALL_MAX <= (size_t)FIXED_CHUNK * FIXED_MAXQ, "a window's workgroup sums fit one tree");
 
 template <class F>

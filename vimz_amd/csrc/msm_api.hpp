@@ -43,8 +43,11 @@ struct MsmPlan {
 
 // The fused single-launch path for small MSMs (k_msm_small): window, points per workgroup chunk, chunks, size limit.
 constexpr int SMALL_C = 7;
-constexpr uint32_t SMALL_CHUNK = 1536, SMALL_MAXQ = 16;
-constexpr size_t MSM_SMALL_MAX = (size_t)SMALL_CHUNK * SMALL_MAXQ;
+constexpr uint32_t SMALL_CHUNK = 1536, SMALL_MAXQ = 32;
+// (measured on MI355X, dense scalars, tools/small_msm_crossover.py: fused 0.22 / 0.29 / 0.31 / 0.35 / 0.45 ms at 16 k / 24.6 k / 27.7 k / 32.8 k / 49 k
+//  points against 0.28 / 0.34 / 0.35 / 0.34 / 0.42 ms through the general pipeline: the hand-over is at 20 chunks)
+constexpr size_t MSM_SMALL_MAX = (size_t)SMALL_CHUNK * 20;
+static_assert(MSM_SMALL_MAX <= (size_t)SMALL_CHUNK * SMALL_MAXQ, "chunk results of a window fit the workspace");
 
 // Precomputed window tables of a commitment key: d[j][i] = 2^(c j) * P_i, affine internal form, row length n_total.
 // own != 0: every window keeps its own bucket set, as without tables — the tables only spare the host the Horner over the window sums
