@@ -2,10 +2,12 @@
 """End-to-end run of one transformation on the GPU, the way `vimz -b nova-snark -f <t>` sequences it
 (vimz/src/nova_snark_backend/mod.rs:22-80): prepare input -> prepare folding (circuit + key) -> fold every row -> verify.
 Prints the span times the reference logs ("Prepare input", "Prepare folding", "Fold input", "Verify folded proof").
-usage: e2e.py <transformation> <resolution> [segments] [ivc|accumulator] [proof file prefix or -] [witness batch]
+usage: e2e.py <transformation> <resolution> [segments] [ivc|accumulator|cyclefold] [proof file prefix or -] [witness batch]
 ivc (default): ONE proof object — the rows are proven as `segments` Nova IVCs of contiguous row segments folded concurrently and
 merged (vimz_ivc_merge), then compressed;
-accumulator: NIFS accumulators of the segments merged by a final fold."""
+accumulator: NIFS accumulators of the segments merged by a final fold;
+cyclefold: the Sonobe backend's sequence (vimz/src/sonobe_backend/mod.rs:52-95: prepare folding, fold input, verify folded proof) with Nova +
+CycleFold on one chain (the decider is not built)."""
 import json
 import sys
 import time
@@ -60,6 +62,24 @@ def main():
                           "state_chain_s": tm.get("state_chain_s"), "merge_s": tm.get("merge_s"),
                           "steps_per_s": n / spans["Fold input"], "total_s": sum(v for k, v in spans.items() if not k.endswith("bytes")),
                           "final_state": [hex(z) for z in ze]}))
+        return
+    if mode == "cyclefold":
+        for c in ctxs[1:]:
+            c.close()
+        params.free()
+        t0 = time.time()
+        circuit, params = folding.prepare_folding(ctxs[0], t, res, backend="sonobe")
+        cf = hip.CycleFoldIVC(ctxs[0], circuit, params.ck, params.secondary_key(), max_batch=batch)
+        spans["Prepare folding"] = time.time() - t0
+        t0 = time.time()
+        cf.reset(z0); cf.fold(np.stack(rows))
+        spans["Fold input"] = time.time() - t0
+        t0 = time.time()
+        ok = cf.verify(len(rows), z0) == 0
+        spans["Verify folded proof"] = time.time() - t0
+        print(json.dumps({"config": f"{t}_step_{res}", "mode": "cyclefold", "steps": len(rows), "segments": 1, "witness_batch": batch, "proof_objects": 1, "verified": ok, "spans_s": spans,
+                          "info": cf.info(), "ms_per_step": {k: 1e3 * sec / len(rows) for k, (sec, n) in cf.profile().items()},
+                          "steps_per_s": len(rows) / spans["Fold input"], "total_s": sum(spans.values()), "final_state": [hex(z) for z in cf.state()[0]]}))
         return
     provers = [hip.Prover(c, circuit, params.ck, max_batch=batch) for c in ctxs]
     spans["Prepare folding"] = time.time() - t0

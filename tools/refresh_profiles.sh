@@ -3,7 +3,7 @@
 #   the driver-style bench line and the long-window one, rocprofv3 kernel stats + the k_accum split of the same command, the
 #   FETCH_SIZE / WRITE_SIZE counter passes (separate runs, counters only) summarised per kernel — for the HD headline and for the
 #   4K / 8K shapes —, whole-image runs, the bench windows of the other configurations, the N > 1 lines on the one GPU of the box.
-#   usage: tools/refresh_profiles.sh [round tag, default r03] [parts: all | bench | rocprof | pmc | e2e | configs | ranks]
+#   usage: tools/refresh_profiles.sh [round tag, default r03] [parts: all | bench | rocprof | pmc | e2e | configs | ranks | cyclefold]
 set -u
 R=${1:-r03}
 PARTS=${2:-all}
@@ -69,5 +69,17 @@ if want ranks; then    # N > 1 on the one GPU of the box: ONE object out of two 
   $TR --nproc-per-node 2 --master-port 29622 bench.py --gpus 2 --no-cpu-baseline --segments 1 > $O/${R}_bench_2ranks_on_1gpu_ivc_one_chain_each.json 2>> $O/ranks.err
   $TR --nproc-per-node 2 --master-port 29623 bench.py --gpus 2 --no-cpu-baseline --mode accumulator > $O/${R}_bench_2ranks_on_1gpu_accumulator.json 2>> $O/ranks.err
   $TR --nproc-per-node 4 --master-port 29624 bench.py --gpus 4 --no-cpu-baseline --no-compress --proof-set contrast,brightness,sharpness,blur --resolution 4K --steps 48 --warmup 8 --segments 1 > $O/${R}_bench_proof_set_4K_4ranks_on_1gpu.json 2>> $O/ranks.err
+fi
+if want cyclefold; then  # the Sonobe backend's path: Nova + CycleFold on one chain
+  : > $O/${R}_cyclefold.jsonl
+  timeout 900 python3 tools/cyclefold_bench.py contrast HD 256 2>/dev/null | tail -1 >> $O/${R}_cyclefold.jsonl
+  for cfg in "contrast HD" "grayscale HD" "contrast 4K"; do
+    timeout 900 python3 tools/e2e.py $cfg 1 cyclefold 2>/dev/null | tail -1 >> $O/${R}_cyclefold.jsonl
+  done
+  $T rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python3 tools/cyclefold_bench.py contrast HD 128 > $O/${R}_cyclefold_under_rocprof.json 2> $O/rocprof.err
+  cp $(find $O/kt -name "*kernel_stats.csv" | head -1) $O/${R}_kernel_stats_cyclefold_HD.csv
+  python3 tools/trace_busy.py $(find $O/kt -name "*kernel_trace.csv" | head -1) > $O/${R}_trace_busy_cyclefold_HD.txt 2>/dev/null
+  rm -rf $O/kt
+  python3 tools/small_msm_crossover.py > $O/${R}_small_msm_crossover.txt 2>/dev/null
 fi
 ls -la $O
