@@ -298,7 +298,7 @@ def main_ivc(args, rank, world, dist, torch, ctxs, circuit, params, steps_all, g
                      "points": n_s, "windows": k_win, "algorithmic_bytes_per_launch": 96.0 * n_s, "kernel_ms_alone_on_gpu": sm,
                      "achieved": 96.0 * n_s / (sm * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": 96.0 * n_s / (sm * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                      "bucket_additions": n_s * k_win, "int_utilisation": n_s * k_win / (sm * 1e-3) / 1e9 / MIXED_ADD_PEAK_GOPS,
-                     "bound": "latency: ~25 dependent point additions at ~6 us a level on one wave per SIMD (DESIGN.md §4); four launches per step, two of them in series"}
+                     "bound": "latency: 6 dependent mixed additions, then 19 four-lane levels of dependent additions at ~3.6 us on one wave per SIMD (DESIGN.md §4, §9c); four launches per step, two of them in series"}
         except Exception as e:
             print(f"[bench] isolated k_msm_small measurement skipped: {e}", file=sys.stderr)
         traffic, traffic_src, traffic_stale = _pmc_traffic(f"{args.transformation}_step_{args.resolution}_ivc")
@@ -319,6 +319,29 @@ def main_ivc(args, rank, world, dist, torch, ctxs, circuit, params, steps_all, g
                              "note": "the same rows as one IVC chain on one set of streams (bench.py --segments 1)"}
             except Exception as e:
                 print(f"[bench] one-chain extra skipped: {e}", file=sys.stderr)
+        # extra (N = 1): the reference's second backend on the same rows — Nova + CycleFold, one chain (vimz_cf_*)
+        sonobe = None
+        if world == 1 and not args.no_extras and not args.proof_set:
+            try:
+                from vimz_amd.hip import CycleFoldIVC
+                n_cf = min(K, 64)
+                cf = CycleFoldIVC(ctxs[0], circuit, params.ck, params.secondary_key(), max_batch=min(args.batch, 32))
+                try:
+                    cf.reset(z0); cf.fold(rows_timed[:min(8, n_cf)])          # first-call allocations
+                    cf.reset(z0)
+                    ctxs[0].sync()
+                    t4 = time.time()
+                    cf.fold(rows_timed[:n_cf])
+                    d4 = time.time() - t4
+                    ci = cf.info()
+                    sonobe = {"steps_per_s": n_cf / d4, "steps": n_cf, "verified": cf.verify(n_cf, z0) == 0,
+                              "main_constraints": ci["main_constraints"], "cyclefold_constraints": ci["cyclefold_constraints"],
+                              "ms_per_step": {k: 1e3 * sec / n_cf for k, (sec, n) in cf.profile().items()},
+                              "note": "Nova + CycleFold IVC (the Sonobe backend's prove_step loop, vimz/src/sonobe_backend/folding.rs:52-66), one chain, same kernels"}
+                finally:
+                    cf.close()
+            except Exception as e:
+                print(f"[bench] sonobe-backend extra skipped: {e}", file=sys.stderr)
         out = {
             "metric": "nova_folding_steps_per_sec",
             "value": timed_total / dt,
@@ -350,6 +373,7 @@ def main_ivc(args, rank, world, dist, torch, ctxs, circuit, params, steps_all, g
             "fold_s": t_fold,
             "merge_profile_s": merge_prof,
             "one_chain": one_chain,
+            "sonobe_backend": sonobe,
             "compressed_snark": compress,
             "end_to_end_estimate_s": {"keygen_and_setup": setup_s, "fold_720_steps_one_gpu": 720 * dt / max(1, timed_total),
                                       "compress": (compress["setup_s"] + compress["prove_s"]) if compress else None,
@@ -402,7 +426,7 @@ def main():
     ap.add_argument("--msm-helpers", type=int, default=0, help="IVC mode: split every step's large MSM(T) by base range over this many helper contexts "
                     "(devices after this rank's, wrapping around; on a one-GPU box they share the device): one proof on several GPUs, SURVEY.md §8e")
     ap.add_argument("--no-compress", action="store_true", help="skip CompressedSNARK::prove / verify of the folded proof")
-    ap.add_argument("--no-extras", action="store_true", help="skip the one-chain extra of the default IVC run")
+    ap.add_argument("--no-extras", action="store_true", help="skip the one-chain and Sonobe-backend extras of the default IVC run")
     ap.add_argument("--mode", default="ivc", choices=["ivc", "accumulator"])
     ap.add_argument("--window-tables", type=int, default=0, help="window tables of the primary key in HBM (vimz_bases_precompute): 11 = per-window buckets, no host Horner; 13..16 = one shared bucket set; 0 = none")
     ap.add_argument("--proof-set", default="", help="comma-separated transformations: rank r proves proof_set[r %% len] (BASELINE config 5: independent proofs, replicas only)")

@@ -88,7 +88,7 @@ int vimz_bases_download(vimz_ctx* ctx, const vimz_bases* b, size_t offset, uint6
  *   window_bits 12..16: ONE bucket set shared by all windows — fewer digits per scalar, one bucket reduction, no Horner;
  *   window_bits 11 (the window a large MSM uses anyway): the usual per-window bucket sets, whose sums the host then only adds
  *   (no Horner: ~0.1 ms less on the host per MSM).  MSMs too small for that window ignore such tables.
- *   window_bits 7 (keys of at most 24576 points): EVERY multiple m·2^(7w)·P_i, m = 1..64 (189 KB per point): a digit selects its point,
+ *   window_bits 7 (keys of at most 30720 points): EVERY multiple m·2^(7w)·P_i, m = 1..64 (189 KB per point): a digit selects its point,
  *   the MSM is one sum without buckets — what the per-step commitments over the verifier circuits' fixed key slices use.
  * Results are unchanged. */
 int vimz_bases_precompute(vimz_ctx* ctx, vimz_bases* b, int window_bits);
@@ -342,6 +342,11 @@ int vimz_cf_profile(const vimz_cf* v, double seconds[8], uint64_t counts[8]);
  * comm_E.x, comm_E.y, u, x0, x1; side 1: comm_W.x, comm_W.y, comm_E.x, comm_E.y, u, x[0..7)), VIMZ_IX_FRESH_INSTANCE (side 0: comm_W.x,
  * comm_W.y, x0, x1), VIMZ_IX_PARAMS (side 0: digest, z0..., z_i...), VIMZ_IX_RUNNING_Z, VIMZ_IX_RUNNING_E, VIMZ_IX_FRESH_Z (side 0) */
 int64_t vimz_cf_export(vimz_cf* v, int side, int what, void* buf, size_t cap);
+/* The proof as an object of its own (Sonobe's `ivc_proof()` / `from_ivc_proof`; checkpoint / resume): everything vimz_cf_verify reads and the
+ * next vimz_cf_fold needs.  Import into a vimz_cf created for the same step circuit and keys, then verify or keep folding. */
+size_t vimz_cf_proof_size(const vimz_cf* v);
+int vimz_cf_proof_export(vimz_cf* v, uint8_t* blob, size_t cap);
+int vimz_cf_proof_import(vimz_cf* v, const uint8_t* blob, size_t len);
 /* test hooks.  poke: overwrite one element (canonical) of a witness vector on the device — which = 0 running main Z, 1 last fresh main Z,
  * 2 running CycleFold Z, 3 running main E, 4 running CycleFold E.  selfcheck: host only, no GPU — `steps` steps over the trivial step
  * circuit with made-up commitments, every witness checked against its R1CS and every in-circuit fold against field / curve arithmetic

@@ -126,3 +126,43 @@ def test_fold_input_with_the_sonobe_backend(ctx, oracle):
         proof.close()
     finally:
         params.free()
+
+
+def test_cyclefold_proof_export_import_and_resume(ctx, keys):
+    """The proof as bytes (Sonobe's ivc_proof / from_ivc_proof): another prover object verifies it and keeps folding; the result equals
+    the uninterrupted run; malformed blobs are refused and leave the importer untouched."""
+    from vimz_amd import hip
+    ck1, ck2 = keys
+    c = Circuit.for_resolution("contrast", "HD")
+    z0, inputs = step_inputs("contrast")
+    steps = np.stack(inputs)
+    a = hip.CycleFoldIVC(ctx, c, ck1, ck2, max_batch=4)
+    b = hip.CycleFoldIVC(ctx, c, ck1, ck2, max_batch=4)
+    try:
+        a.reset(z0); a.fold(steps[:6])
+        blob = a.proof_export()
+        b.reset(z0)
+        b.proof_import(blob)
+        assert b.verify(6, z0) == 0 and b.state() == a.state()
+        a.fold(steps[6:]); b.fold(steps[6:])
+        assert a.verify(10, z0) == 0 and b.verify(10, z0) == 0
+        for side in (0, 1):
+            assert (a.export(side, hip.IX_INSTANCE) == b.export(side, hip.IX_INSTANCE)).all()
+        assert (a.export(0, hip.IX_FRESH_INSTANCE) == b.export(0, hip.IX_FRESH_INSTANCE)).all()
+        # refused: truncated, wrong magic, an element above the modulus, a point off its curve
+        for bad in (blob[:1000], np.concatenate([np.frombuffer(b"\x00" * 8, dtype=np.uint8), blob[8:]])):
+            with pytest.raises(_lib.VimzError):
+                b.proof_import(bad)
+        t = blob.copy(); t[-32:] = 0xFF
+        with pytest.raises(_lib.VimzError):
+            b.proof_import(t)
+        t = blob.copy(); t[64 + 8 * 4 * 4 + 8 * 4 * 3] ^= 1          # (inside the header's host state: a coordinate of a commitment)
+        try:
+            b.proof_import(t)
+            assert b.verify(6, z0) != 0                               # a change the range / curve checks cannot see is caught by verification
+            b.proof_import(blob)
+        except _lib.VimzError:
+            pass
+        assert b.verify(10, z0) == 0 or b.verify(6, z0) == 0          # the importer still holds a valid proof
+    finally:
+        a.close(); b.close()

@@ -93,10 +93,10 @@ def test_msm_small_all_curves(ctx, oracle, cid, n):
     _msm_case(ctx, oracle, cid, n, sc)
 
 
-@pytest.mark.parametrize("n", [1535, 1536, 1537, 7709, 24576, 24577])
+@pytest.mark.parametrize("n", [1535, 1536, 1537, 7709, 24576, 24577, 30720, 30721])
 @pytest.mark.parametrize("kind", ["dense", "witness"])
 def test_msm_around_the_fused_kernel_boundaries(ctx, oracle, n, kind):
-    """Sizes at the edges of the single-launch small MSM (1536 points per workgroup chunk, 24 576 points in all) and just past
+    """Sizes at the edges of the single-launch small MSM (1536 points per workgroup chunk, 30 720 points — twenty chunks — in all; 24 576 was the limit until round 3) and just past
     it (general pipeline with short sub-buckets), for dense scalars and for witness-like ones (mostly 0/1 and bytes)."""
     r = MODULI[CURVE_SCALAR[1]]
     rng = random.Random(f"{n}-{kind}")

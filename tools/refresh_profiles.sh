@@ -3,7 +3,7 @@
 #   the driver-style bench line and the long-window one, rocprofv3 kernel stats + the k_accum split of the same command, the
 #   FETCH_SIZE / WRITE_SIZE counter passes (separate runs, counters only) summarised per kernel — for the HD headline and for the
 #   4K / 8K shapes —, whole-image runs, the bench windows of the other configurations, the N > 1 lines on the one GPU of the box.
-#   usage: tools/refresh_profiles.sh [round tag, default r03] [parts: all | bench | rocprof | pmc | e2e | configs | ranks | cyclefold]
+#   usage: tools/refresh_profiles.sh [round tag, default r03] [parts: all | bench | rocprof | pmc | valu | e2e | configs | ranks | cyclefold]
 set -u
 R=${1:-r03}
 PARTS=${2:-all}
@@ -45,6 +45,11 @@ if want pmc; then
   pmc accumulator --steps 96 --mode accumulator
   pmc ivc_4K --transformation contrast --resolution 4K --steps 48 --warmup 12
   pmc ivc_8K --transformation resize --resolution 8K --steps 48 --warmup 12
+fi
+if want valu; then     # vector instructions per step and kernel (the instruction budget of DESIGN.md §8)
+  $T rocprofv3 --pmc SQ_INSTS_VALU --output-format csv -d $O/pv -o pv -- python3 bench.py --no-cpu-baseline --no-extras --no-compress --steps 96 > /dev/null 2>> $O/rocprof.err
+  python3 tools/valu_budget.py $(find $O/pv -name "*counter_collection.csv" | head -1) 224 > $O/${R}_valu_budget.txt
+  rm -rf $O/pv
 fi
 if want e2e; then      # whole images the way `vimz -b nova-snark -f <t>` sequences them
   : > $O/${R}_e2e.jsonl

@@ -637,6 +637,104 @@ int64_t vimz_cf_export(vimz_cf* v, int side, int what, void* buf, size_t cap) {
   return (int64_t)bytes;
 }
 
+// ---- the proof as an object of its own (Sonobe's `ivc_proof()` / `from_ivc_proof`; checkpoint / resume): everything vimz_cf_verify reads and
+// the next vimz_cf_fold needs.  Blob = header | host state | device vectors (Montgomery limbs as they sit in HBM).
+namespace {
+struct CfProofHeader { uint64_t magic, steps, n_w1, n_c1, n_w2, n_c2, len_z, flags; };
+const uint64_t CF_PROOF_MAGIC = 0x3146435a56ull;   // "VZCF1"
+struct CfProofHost { CfMainRelaxed U; G1Aff UW, UE; CfMainFresh u; G1Aff uW; CfRelaxed cfU; Fe u_run; Fq cf_u_run; Fe digest; };
+size_t cf_vec_bytes(const vimz_cf* v) {
+  const size_t nw1 = v->pri->n_wires, nc1 = v->pri->n_c, nw2 = v->sec.n_w, nc2 = v->sec.n_c;
+  return 32 * (2 * nw1 + 7 * nc1 + nw2 + 4 * nc2);
+}
+}  // namespace
+
+size_t vimz_cf_proof_size(const vimz_cf* v) {
+  if (!v) return 0;
+  return sizeof(CfProofHeader) + sizeof(CfProofHost) + 64 * (size_t)v->pri->len_z + cf_vec_bytes(v);
+}
+
+int vimz_cf_proof_export(vimz_cf* v, uint8_t* blob, size_t cap) {
+  if (!v || !blob || cap < vimz_cf_proof_size(v)) return vz_fail(v ? v->ctx : nullptr, VIMZ_ERR_INVALID, "vimz_cf_proof_export: buffer too small");
+  if (v->broken) return vz_fail(v->ctx, VIMZ_ERR_INVALID, "vimz_cf_proof_export: this IVC failed in the middle of a step");
+  vimz_ctx* ctx = v->ctx; vimz_prover* p = v->pri; SecDev& S = v->sec;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  P_TRY(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  CfProofHeader h{CF_PROOF_MAGIC, v->i, p->n_wires, p->n_c, S.n_w, S.n_c, p->len_z, 0};
+  CfProofHost hs; memset((void*)&hs, 0, sizeof(hs));
+  hs.U = v->U; hs.UW = v->UW; hs.UE = v->UE; hs.u = v->u; hs.uW = v->uW; hs.cfU = v->cfU; hs.u_run = v->u_run; hs.cf_u_run = v->cf_u_run; hs.digest = v->c1->digest;
+  uint8_t* o = blob;
+  memcpy(o, &h, sizeof(h)); o += sizeof(h);
+  memcpy(o, (const void*)&hs, sizeof(hs)); o += sizeof(hs);
+  memcpy(o, v->z0.data(), 32 * p->len_z); o += 32 * p->len_z;
+  memcpy(o, p->z_cur.data(), 32 * p->len_z); o += 32 * p->len_z;
+  const uint32_t* src[] = {p->Zrun, p->E, p->AZ, p->BZ, p->CZ, v->Zl, v->azl, v->bzl, v->czl, S.Zrun, S.E, S.AZ, S.BZ, S.CZ};
+  const size_t len[] = {p->n_wires, p->n_c, p->n_c, p->n_c, p->n_c, p->n_wires, p->n_c, p->n_c, p->n_c, S.n_w, S.n_c, S.n_c, S.n_c, S.n_c};
+  for (int k = 0; k < 14; k++) { P_TRY(hipMemcpyAsync(o, src[k], 32 * len[k], hipMemcpyDeviceToHost, s)); o += 32 * len[k]; }
+  P_TRY(hipStreamSynchronize(s));
+  return VIMZ_OK;
+}
+
+int vimz_cf_proof_import(vimz_cf* v, const uint8_t* blob, size_t len) {
+  if (!v || !blob || len < sizeof(CfProofHeader)) return VIMZ_ERR_INVALID;
+  vimz_ctx* ctx = v->ctx; vimz_prover* p = v->pri; SecDev& S = v->sec;
+  CfProofHeader h; memcpy(&h, blob, sizeof(h));
+  if (h.magic != CF_PROOF_MAGIC || h.n_w1 != p->n_wires || h.n_c1 != p->n_c || h.n_w2 != S.n_w || h.n_c2 != S.n_c || h.len_z != p->len_z || len < vimz_cf_proof_size(v))
+    return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_cf_proof_import: the blob does not match this IVC's circuits");
+  CfProofHost hs; memcpy((void*)&hs, blob + sizeof(h), sizeof(hs));
+  if (!hs.digest.eq(v->c1->digest)) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_cf_proof_import: shape digest differs");
+  // The blob is untrusted: every field element must be below its modulus and every point on its curve BEFORE anything of this IVC changes.
+  {
+    auto q_ok = [](const U256w& x) { Fq c; for (int i = 0; i < 4; i++) { c.v[2 * i] = (uint32_t)x.w[i]; c.v[2 * i + 1] = (uint32_t)(x.w[i] >> 32); } return c.is_reduced(); };
+    auto g1_ok = [](const G1Aff& P) { return P.x.is_reduced() && P.y.is_reduced() && aff_on_curve(P); };
+    auto g2_ok = [](const G2Aff& P) { return P.x.is_reduced() && P.y.is_reduced() && aff_on_curve(P); };
+    auto same = [](const G1Aff& P, const NnPoint& n) { const NnPoint m = nn_point(P); return !memcmp(&m, &n, sizeof(m)); };
+    bool ok = g1_ok(hs.UW) && g1_ok(hs.UE) && g1_ok(hs.uW) && same(hs.UW, hs.U.W) && same(hs.UE, hs.U.E) && same(hs.uW, hs.u.W) &&
+              hs.U.u.is_reduced() && hs.U.x0.is_reduced() && hs.U.x1.is_reduced() && hs.u.x0.is_reduced() && hs.u.x1.is_reduced() &&
+              g2_ok(hs.cfU.W) && g2_ok(hs.cfU.E) && hs.cfU.u.is_reduced() && hs.u_run.is_reduced() && hs.cf_u_run.is_reduced();
+    for (int k = 0; k < CF_IO && ok; k++) ok = q_ok(hs.cfU.x[k]);
+    const uint8_t* zp = blob + sizeof(h) + sizeof(hs);
+    for (uint32_t k = 0; k < 2 * p->len_z && ok; k++) { Fe z; memcpy(z.v, zp + 32 * k, 32); ok = z.is_reduced(); }
+    if (!ok) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_cf_proof_import: a field element of the blob is not below its modulus, or a point is not on its curve");
+  }
+  std::lock_guard<std::mutex> g(ctx->mu);
+  P_TRY(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  const uint8_t* o = blob + sizeof(h) + sizeof(hs) + 64 * (size_t)p->len_z;
+  const size_t ln[] = {p->n_wires, p->n_c, p->n_c, p->n_c, p->n_c, p->n_wires, p->n_c, p->n_c, p->n_c, S.n_w, S.n_c, S.n_c, S.n_c, S.n_c};
+  const size_t vec_bytes = cf_vec_bytes(v);
+  int rc = vz_ensure_scratch(ctx, vec_bytes + 64); if (rc) return rc;
+  uint32_t* stage = (uint32_t*)ctx->scratch;
+  uint32_t* badc = stage + vec_bytes / 4;
+  P_TRY(hipMemcpyAsync(stage, o, vec_bytes, hipMemcpyHostToDevice, s));
+  P_TRY(hipMemsetAsync(badc, 0, 8, s));
+  {
+    size_t off = 0;
+    for (int k = 0; k < 14; k++) {
+      if (k < 9) hipLaunchKernelGGL(k_count_unreduced<Fr>, dim3(stream_grid(ln[k])), dim3(256), 0, s, ln[k], (const uint32_t*)(stage + off), badc);
+      else hipLaunchKernelGGL(k_count_unreduced<Fq>, dim3(stream_grid(ln[k])), dim3(256), 0, s, ln[k], (const uint32_t*)(stage + off), badc);
+      off += 8 * ln[k];
+    }
+  }
+  uint32_t nbad = 0;
+  P_TRY(hipMemcpyAsync(&nbad, badc, 4, hipMemcpyDeviceToHost, s));
+  P_TRY(hipStreamSynchronize(s));
+  if (nbad) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_cf_proof_import: a vector element of the blob is not below its modulus");
+  uint32_t* dst[] = {p->Zrun, p->E, p->AZ, p->BZ, p->CZ, v->Zl, v->azl, v->bzl, v->czl, S.Zrun, S.E, S.AZ, S.BZ, S.CZ};
+  { size_t off = 0; for (int k = 0; k < 14; k++) { P_TRY(hipMemcpyAsync(dst[k], stage + off, 32 * ln[k], hipMemcpyDeviceToDevice, s)); off += 8 * ln[k]; } }
+  P_TRY(hipStreamSynchronize(s));
+  const uint8_t* zp = blob + sizeof(h) + sizeof(hs);
+  memcpy(v->z0.data(), zp, 32 * p->len_z);
+  memcpy(p->z_cur.data(), zp + 32 * p->len_z, 32 * p->len_z);
+  p->z0 = v->z0;
+  v->i = h.steps; p->steps = h.steps;
+  v->U = hs.U; v->UW = hs.UW; v->UE = hs.UE; v->u = hs.u; v->uW = hs.uW; v->cfU = hs.cfU; v->u_run = hs.u_run; v->cf_u_run = hs.cf_u_run;
+  v->t_step_for = v->t_ver_for = -1; v->broken = false;
+  v->c1->cache = CfHashCache();
+  return VIMZ_OK;
+}
+
 // test hook: overwrite one element of a witness vector on the device (soundness tests flip wires and expect vimz_cf_verify / the
 // oracle verifier to reject).  which: 0 running main Z, 1 last fresh main Z, 2 running CycleFold Z, 3 running main E, 4 running CycleFold E.
 int vimz_cf_poke(vimz_cf* v, int which, size_t index, const uint64_t value[4]) {

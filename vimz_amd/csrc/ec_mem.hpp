@@ -42,21 +42,23 @@ __device__ __forceinline__ XYZZ<F> load_xyzz(const uint32_t* __restrict__ base, 
 //     U1 = X1·ZZ2, U2 = X2·ZZ1, S1 = Y1·ZZZ2, S2 = Y2·ZZZ1   |   PP = P², RR = R², Z12 = ZZ1·ZZ2, Z123 = ZZZ1·ZZZ2
 //     PPP = P·PP, Q = U1·PP, ZZ3 = Z12·PP                     |   Ya = R·(Q − X3), Yb = S1·PPP, ZZZ3 = Z123·PPP
 // so a quad of consecutive lanes (q = lane & 3) computes one addition in four multiplication levels, exchanging 9-word field
-// elements by wave shuffles (63 words in all).  Operands and result live in LDS (sh[]): quad_add_compute reads them and returns what
+// elements inside the quad by DPP moves (63 words in all).  Operands and result live in LDS (sh[]): quad_add_compute reads them and returns what
 // this lane will write; the caller puts a barrier between it and quad_add_store (other quads may still read the destination).
 // Identity operands and the doubling / cancellation case (P ≡ 0; lane 0 of the quad then runs the scalar formula) keep add_full's
 // semantics.  Same bounds as add_full (ec.hpp).  Every lane of the wave must call both functions (shuffles are wave-wide).
 template <class F> struct QuadRes { F c0, c1; XYZZ<F> full; uint32_t mode; };       // mode 0: nothing to store; 1: copy of b; 2: sum; 3: lane 0 holds `full`
-template <class F>
-__device__ __forceinline__ F quad_shfl(const F& v, int src_lane) {
+// lane K of every quad to the quad's four lanes: a DPP quad_perm move (one VALU instruction per word; __shfl with a runtime lane goes
+// through ds_bpermute — the LDS crossbar and its latency, exposed with one wave per SIMD)
+template <int K, class F>
+__device__ __forceinline__ F quad_bcast(const F& v) {
   F r;
 #pragma unroll
-  for (int i = 0; i < 9; i++) r.v[i] = __shfl(v.v[i], src_lane);
+  for (int i = 0; i < 9; i++) r.v[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.v[i], K * 0x55, 0xf, 0xf, true);
   return r;
 }
 template <class F>
 __device__ __forceinline__ QuadRes<F> quad_add_compute(const XYZZ<F>* __restrict__ sh, uint32_t ia, uint32_t ib, bool active) {
-  const int lane = (int)(threadIdx.x & 63u), q = lane & 3, base = lane & ~3;
+  const int q = (int)(threadIdx.x & 3u);
   QuadRes<F> out; out.mode = 0;
   const XYZZ<F>& A = sh[ia]; const XYZZ<F>& B = sh[ib];
   const bool a_id = A.ZZ.is_zero(), b_id = B.ZZ.is_zero();
@@ -69,28 +71,28 @@ __device__ __forceinline__ QuadRes<F> quad_add_compute(const XYZZ<F>* __restrict
   const F m1 = F::mul(*px, *py);
   F o1;
 #pragma unroll
-  for (int i = 0; i < 9; i++) o1.v[i] = __shfl_xor(m1.v[i], 1);
+  for (int i = 0; i < 9; i++) o1.v[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m1.v[i], 0xB1, 0xf, 0xf, true);      // quad_perm [1,0,3,2]
   // q0,q1: P = U2 − U1;  q2,q3: R = S2 − S1   (the even lane of a pair holds the "1" operand)
   const F lo = sel(q & 1, o1, m1), hi = sel(q & 1, m1, o1);
   const F PR = F::template sub<2>(hi, lo);
-  const int pz = __shfl((q == 0 && PR.is_zero_mod()) ? 1 : 0, base);
+  const int pz = __builtin_amdgcn_update_dpp(0, (q == 0 && PR.is_zero_mod()) ? 1 : 0, 0x00, 0xf, 0xf, true);
   // level 2: PP = P² | Z12 = ZZ1·ZZ2 | RR = R² | Z123 = ZZZ1·ZZZ2
   const F* pa = q == 1 ? &A.ZZ : &A.ZZZ; const F* pb = q == 1 ? &B.ZZ : &B.ZZZ;
   const F za = *pa, zb = *pb;
   const F m2 = F::mul(sel(q & 1, za, PR), sel(q & 1, zb, PR));
-  const F PP = quad_shfl(m2, base);
-  const F Z12 = quad_shfl(m2, base + 1);
+  const F PP = quad_bcast<0>(m2);
+  const F Z12 = quad_bcast<1>(m2);
   // level 3: PPP = P·PP | Q = U1·PP | — | ZZ3 = Z12·PP
   const F m3 = F::mul(sel(q == 0, PR, sel(q == 1, lo, Z12)), PP);
-  const F PPP = quad_shfl(m3, base);
-  const F Qv = quad_shfl(m3, base + 1);
-  const F S1 = quad_shfl(lo, base + 2);              // lane 2's `lo` is S1
+  const F PPP = quad_bcast<0>(m3);
+  const F Qv = quad_bcast<1>(m3);
+  const F S1 = quad_bcast<2>(lo);              // lane 2's `lo` is S1
   // X3 and Q − X3 (meaningful on lane 2, whose m2 is RR)
   const F X3 = F::template sub<4>(m2, F::add(PPP, F::dbl(Qv)));
   const F D = F::template sub<6>(Qv, X3);
   // level 4: Yb = S1·PPP | — | Ya = R·(Q − X3) | ZZZ3 = Z123·PPP
   const F m4 = F::mul(sel(q == 0, S1, sel(q == 2, PR, m2)), sel(q == 2, D, PPP));
-  const F Yb = quad_shfl(m4, base);
+  const F Yb = quad_bcast<0>(m4);
   if (!active || b_id) return out;
   if (a_id) { out.mode = 1; out.c0 = q == 0 ? B.X : q == 1 ? B.Y : q == 2 ? B.ZZ : B.ZZZ; return out; }
   if (pz) {                                          // same x: doubling or cancellation — rare, the scalar formula on lane 0

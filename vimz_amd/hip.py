@@ -590,6 +590,23 @@ class CycleFoldIVC:
     def poke(self, which, index, value):
         self.ctx._chk(self.ctx.lib.vimz_cf_poke(self.h, which, index, _ptr(_zlimbs([value], 1))))
 
+    def proof_export(self):
+        """The proof (and resume state) as bytes: vimz_cf_proof_export."""
+        lib = self.ctx.lib
+        lib.vimz_cf_proof_size.argtypes = [C.c_void_p]
+        lib.vimz_cf_proof_size.restype = C.c_size_t
+        lib.vimz_cf_proof_export.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        n = lib.vimz_cf_proof_size(self.h)
+        buf = np.zeros(n, dtype=np.uint8)
+        self.ctx._chk(lib.vimz_cf_proof_export(self.h, _ptr(buf), n))
+        return buf
+
+    def proof_import(self, blob):
+        lib = self.ctx.lib
+        lib.vimz_cf_proof_import.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        b = np.ascontiguousarray(blob, dtype=np.uint8)
+        self.ctx._chk(lib.vimz_cf_proof_import(self.h, _ptr(b), b.size))
+
 
 def cyclefold_selfcheck(steps=4):
     """vimz_cf_selfcheck (host only, no GPU): (result bits, {"main_wires", "main_constraints", "cyclefold_wires", "cyclefold_constraints"})."""
