@@ -347,6 +347,31 @@ int64_t vimz_cf_export(vimz_cf* v, int side, int what, void* buf, size_t cap);
 size_t vimz_cf_proof_size(const vimz_cf* v);
 int vimz_cf_proof_export(vimz_cf* v, uint8_t* blob, size_t cap);
 int vimz_cf_proof_import(vimz_cf* v, const uint8_t* blob, size_t len);
+/* ONE proof object out of several row segments' CycleFold proofs (the north_star's "host-side sequential final fold" for this scheme; what
+ * vimz_ivc_merge* is for the Nova IVC): segments folded concurrently — each a vimz_cf of its own on the same device — are folded in row order
+ * by out-of-circuit NIFS: the running main instances pairwise (two relaxed instances), each segment's last instance of F' (strict), the
+ * running CycleFold instances pairwise on Grumpkin.  The verifier replays the segment records (hashes from each segment's statement,
+ * adjacency, folds of the instances) and checks ONE main and ONE CycleFold relaxed instance.  Protocol: vimz_amd/csrc/cyclefold.hip, ours. */
+typedef struct vimz_cf_merged vimz_cf_merged;
+/* the merged proof of one segment; `first` is left unchanged, supplies shapes / keys / context and must outlive the object */
+int vimz_cf_merged_create(vimz_cf* first, vimz_cf_merged** out);
+void vimz_cf_merged_free(vimz_cf_merged* m);
+/* fold the proof of the NEXT row segment in (same device; read in place, left unchanged): it must start at the state m ends in */
+int vimz_cf_merge(vimz_cf_merged* m, vimz_cf* next_segment);
+/* result: 0 = accepted; bit 0 / 1 a segment's main / CycleFold hash; bit 2 / 3 / 4 main relaxed relation / comm_W / comm_E; bit 5 / 6 / 7 the
+ * same of the CycleFold instance; bit 10 instance scalars differ from the vectors; bit 12 statement (step count, initial state, adjacency);
+ * bit 13 the stored folded instances differ from the replay of the records */
+int vimz_cf_merged_verify(vimz_cf_merged* m, uint64_t num_steps, const uint64_t* z0, uint32_t* result);
+/* info[0..8): steps, segments, len_z, main wires, main constraints, CycleFold wires, CycleFold constraints, broken */
+int vimz_cf_merged_info(const vimz_cf_merged* m, uint64_t info[8]);
+int vimz_cf_merged_state(const vimz_cf_merged* m, uint64_t* z_start, uint64_t* z_end, uint64_t* steps);
+int vimz_cf_merged_profile(const vimz_cf_merged* m, double seconds[4]);   /* cross terms + commitments, folds, host, total */
+/* the statement part as canonical little-endian 64-bit words (layout: cyclefold.hip); returns the byte size */
+int64_t vimz_cf_merged_records(const vimz_cf_merged* m, void* buf, size_t cap);
+/* side 0 / 1; what = VIMZ_IX_RUNNING_Z, VIMZ_IX_RUNNING_E, VIMZ_IX_INSTANCE (side 0: 7 elements, side 1: 12 — as vimz_cf_export) of the folded instances */
+int64_t vimz_cf_merged_export(vimz_cf_merged* m, int side, int what, void* buf, size_t cap);
+/* IVC state chain only (as vimz_ivc_state_chain): the state at which a row segment proven by another vimz_cf starts */
+int vimz_cf_state_chain(vimz_cf* v, const uint64_t* z_start, const uint64_t* step_inputs, size_t nsteps, uint64_t* zs_out);
 /* test hooks.  poke: overwrite one element (canonical) of a witness vector on the device — which = 0 running main Z, 1 last fresh main Z,
  * 2 running CycleFold Z, 3 running main E, 4 running CycleFold E.  selfcheck: host only, no GPU — `steps` steps over the trivial step
  * circuit with made-up commitments, every witness checked against its R1CS and every in-circuit fold against field / curve arithmetic

@@ -98,3 +98,108 @@ def cyclefold_relation(orc, x):
     """The CycleFold circuit's statement for one instance's public elements x = (r, P1, P2, P3): P3 == P1 + r·P2 on BN254 G1."""
     r, p1, p2, p3 = x[0], (x[1], x[2]), (x[3], x[4]), (x[5], x[6])
     return orc.curve_add(0, p1, orc.curve_mul(0, p2, r)) == p3
+
+
+# ---- merged proofs (vimz_cf_merge): replay of the segment records with hashlib, Python integers and the oracle's curve arithmetic -------------
+MERGED_MAGIC = 0x31474d46435a56
+
+
+def parse_merged_records(words, len_z):
+    w = [int(x) for x in words]
+    magic, S, lz, nw1, nc1, nw2, nc2, _ = w[:8]
+    assert magic == MERGED_MAGIC and lz == len_z
+    pos = 8
+
+    def el():
+        nonlocal pos
+        v = sum(w[pos + k] << (64 * k) for k in range(4))
+        pos += 4
+        return v
+    segs = []
+    for _ in range(S):
+        s = {"n": w[pos]}
+        pos += 1
+        s["zs"] = [el() for _ in range(lz)]
+        s["ze"] = [el() for _ in range(lz)]
+        s["U"] = [el() for _ in range(7)]
+        s["u"] = [el() for _ in range(4)]
+        s["cfU"] = [el() for _ in range(5 + CF_IO)]
+        s["T1"], s["T2"], s["Tc"] = (el(), el()), (el(), el()), (el(), el())
+        segs.append(s)
+    assert pos == len(w)
+    return {"shape": (nw1, nc1, nw2, nc2), "segs": segs}
+
+
+def _b32(x):
+    return int(x).to_bytes(32, "little")
+
+
+def replay_merged(orc, rec, dg, len_z):
+    """Returns (failed checks, accumulator dict: n, zs, ze, P = (cW, cE, u, x0, x1), Q = (qW, qE, qu, qx[7]))."""
+    import hashlib
+    sha = lambda b: hashlib.sha3_256(b).digest()
+    chal = lambda h, tag, extra: int.from_bytes(sha(h + tag + extra)[:16], "little")
+    pr, pq = orc.modulus[0], orc.modulus[1]
+    axpy = lambda cid, a, r, b: orc.curve_add(cid, a, orc.curve_mul(cid, b, r))
+    failed = []
+    h_prev = sha(b"vimz-cf-merge-v1" + _b32(dg) + len_z.to_bytes(8, "little"))
+    acc = None
+    for j, s in enumerate(rec["segs"]):
+        U, u, cfU = s["U"], s["u"], s["cfU"]
+        if s["n"] == 0: failed.append(f"segment {j}: empty")
+        if hash_main(orc, dg, s["n"], s["zs"], s["ze"], U) != u[2]: failed.append(f"segment {j}: hash of the main running instance")
+        if hash_cf(orc, dg, cfU) != u[3]: failed.append(f"segment {j}: hash of the CycleFold running instance")
+        if acc is not None and acc["ze"] != s["zs"]: failed.append(f"segment {j}: not adjacent")
+        m = h_prev + s["n"].to_bytes(8, "little") + b"".join(_b32(x) for x in s["zs"] + s["ze"] + U + u + cfU)
+        h = sha(m)
+        t1, t2, tc = _b32(s["T1"][0]) + _b32(s["T1"][1]), _b32(s["T2"][0]) + _b32(s["T2"][1]), _b32(s["Tc"][0]) + _b32(s["Tc"][1])
+        r1, r2, rc = chal(h, b"a", t1), chal(h, b"b", t1 + t2), chal(h, b"c", tc)
+        h_prev = sha(h + b"n" + t1 + t2 + tc)
+        if acc is None:
+            acc = {"n": 0, "zs": s["zs"], "P": [(U[0], U[1]), (U[2], U[3]), U[4], U[5], U[6]], "Q": [(cfU[0], cfU[1]), (cfU[2], cfU[3]), cfU[4] % pq, [x % pq for x in cfU[5:]]]}
+        else:
+            P, Q = acc["P"], acc["Q"]
+            P[0] = axpy(0, P[0], r1, (U[0], U[1]))
+            P[1] = axpy(0, P[1], r1, axpy(0, s["T1"], r1, (U[2], U[3])))
+            P[2], P[3], P[4] = (P[2] + r1 * U[4]) % pr, (P[3] + r1 * U[5]) % pr, (P[4] + r1 * U[6]) % pr
+            Q[0] = axpy(1, Q[0], rc, (cfU[0], cfU[1]))
+            Q[1] = axpy(1, Q[1], rc, axpy(1, s["Tc"], rc, (cfU[2], cfU[3])))
+            Q[2] = (Q[2] + rc * cfU[4]) % pq
+            Q[3] = [(a + rc * b) % pq for a, b in zip(Q[3], cfU[5:])]
+        P = acc["P"]
+        P[0] = axpy(0, P[0], r2, (u[0], u[1]))
+        P[1] = axpy(0, P[1], r2, s["T2"])
+        P[2], P[3], P[4] = (P[2] + r2) % pr, (P[3] + r2 * u[2]) % pr, (P[4] + r2 * u[3]) % pr
+        acc["n"] += s["n"]
+        acc["ze"] = s["ze"]
+    return failed, acc
+
+
+def verify_merged(orc, merged, cf, ck1, ck2, num_steps, z0, check_commitments=True):
+    """verify(vk, num_steps, z0) of a merged CycleFold proof, restated; returns the list of failed checks."""
+    from vimz_amd import hip
+    len_z = cf.circuit.len_z
+    dg = shape_digest(cf)
+    rec = parse_merged_records(merged.records(), len_z)
+    failed, acc = replay_merged(orc, rec, dg, len_z)
+    if acc["n"] != num_steps: failed.append("step count")
+    if acc["zs"] != [int(x) for x in z0]: failed.append("z0")
+    P, Q = acc["P"], acc["Q"]
+    tabs = cf.r1cs(0)
+    Z, E = merged.export(0, hip.IX_RUNNING_Z), merged.export(0, hip.IX_RUNNING_E)
+    nw = len(Z)
+    if from_limbs(Z[0:1])[0] != P[2] or from_limbs(Z[-2:]) != [P[3], P[4]]: failed.append("main: instance scalars")
+    if orc.r1cs_check_relaxed(0, tabs, nw, Z, u=P[2], E=E) != -1: failed.append("main: relaxed relation")
+    tabs2 = cf.r1cs(1)
+    Z2, E2 = merged.export(1, hip.IX_RUNNING_Z), merged.export(1, hip.IX_RUNNING_E)
+    n2 = len(Z2)
+    if from_limbs(Z2[0:1])[0] != Q[2] or from_limbs(Z2[-CF_IO:]) != Q[3]: failed.append("cyclefold: instance scalars")
+    if orc.r1cs_check_relaxed(1, tabs2, n2, Z2, u=Q[2], E=E2) != -1: failed.append("cyclefold: relaxed relation")
+    if check_commitments:
+        bases = ck1.download(0, max(nw - 3, len(E)))
+        if orc.msm(0, bases[:nw - 3], Z[1:nw - 2]) != tuple(P[0]): failed.append("main: comm_W")
+        if orc.msm(0, bases[:len(E)], E) != tuple(P[1]): failed.append("main: comm_E")
+        bases2 = ck2.download(0, max(n2 - 1 - CF_IO, len(E2)))
+        if orc.msm(1, bases2[:n2 - 1 - CF_IO], Z2[1:n2 - CF_IO]) != tuple(Q[0]): failed.append("cyclefold: comm_W")
+        if orc.msm(1, bases2[:len(E2)], E2) != tuple(Q[1]): failed.append("cyclefold: comm_E")
+    return failed, acc

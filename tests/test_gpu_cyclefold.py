@@ -166,3 +166,75 @@ def test_cyclefold_proof_export_import_and_resume(ctx, keys):
         assert b.verify(10, z0) == 0 or b.verify(6, z0) == 0          # the importer still holds a valid proof
     finally:
         a.close(); b.close()
+
+
+def test_merged_cyclefold_proof_of_three_segments(ctx, keys, oracle):
+    """ONE proof object out of three row segments' CycleFold proofs (vimz_cf_merge): the product verifier and the oracle-side replay accept
+    it for (all rows, z0) and for nothing else; segments in the wrong order are refused; a wrong vector element is rejected."""
+    from vimz_amd import hip
+    ck1, ck2 = keys
+    c = Circuit.for_resolution("contrast", "HD")
+    z0, inputs = step_inputs("contrast")
+    steps = np.stack(inputs)
+    ctxs = [ctx, hip.Context(0), hip.Context(0)]
+    cfs = [hip.CycleFoldIVC(cx, c, ck1, ck2, max_batch=4) for cx in ctxs]
+    m = None
+    try:
+        bounds = [(0, 4), (4, 7), (7, 10)]
+        z = list(z0)
+        for v, (lo, hi) in zip(cfs, bounds):
+            v.reset(z)
+            zs = v.state_chain(z, steps[lo:hi])
+            v.fold(steps[lo:hi])
+            z = [sum(int(a[k]) << (64 * k) for k in range(4)) for a in zs[-1]]
+            assert v.state()[0] == z and v.verify(hi - lo, v_z0(v)) == 0
+        with pytest.raises(_lib.VimzError):
+            hip.CycleFoldMerged.of([cfs[0], cfs[2]])                 # not adjacent
+        m = hip.CycleFoldMerged.of(cfs)
+        assert m.info()["segments"] == 3 and m.info()["steps"] == 10
+        assert m.verify(10, z0) == 0
+        assert m.verify(9, z0) & 4096 and m.verify(10, [z0[0] + 1] + list(z0[1:])) & 4096
+        assert m.state() == (list(z0), z, 10)
+        failed, acc = cfo.verify_merged(oracle, m, cfs[0], ck1, ck2, 10, z0)
+        assert failed == []
+        # the same rows as one chain end in the same state
+        one = hip.CycleFoldIVC(ctx, c, ck1, ck2, max_batch=4)
+        try:
+            one.reset(z0); one.fold(steps)
+            assert one.state()[0] == z
+        finally:
+            one.close()
+    finally:
+        if m is not None:
+            m.close()
+        for v in cfs:
+            v.close()
+        for cx in ctxs[1:]:
+            cx.close()
+
+
+def v_z0(v):
+    """the initial state a prover was reset to (its proof's own statement)"""
+    from vimz_amd import hip
+    par = from_limbs(v.export(0, hip.IX_PARAMS))
+    return par[1:1 + v.circuit.len_z]
+
+
+def test_fold_input_cyclefold_in_segments(ctx, oracle):
+    from vimz_amd import folding
+    z0, inputs = step_inputs("grayscale")
+    steps = np.stack(inputs)
+    circuit, params = folding.prepare_folding(ctx, "grayscale", "HD", backend="sonobe")
+    try:
+        proof = folding.fold_input(params, steps, z0, mode="cyclefold", segments=3)
+        assert proof.mode == "cyclefold-merged"
+        folding.verify_folded_proof(proof, params, 10, z0)
+        with pytest.raises(_lib.VimzError):
+            folding.verify_folded_proof(proof, params, 10, [1] + list(z0[1:]))
+        z = list(z0)
+        for i in range(10):
+            ok, z = oracle.step_eval(ORC_T["grayscale"], z, steps[i])
+        assert proof.state() == z
+        proof.close()
+    finally:
+        params.free()

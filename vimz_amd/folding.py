@@ -132,7 +132,7 @@ class FoldingProof:
         """The final IVC state z_n as integers."""
         if self.mode in ("ivc", "cyclefold"):
             return self.prover.state()[0]
-        if self.mode == "merged":
+        if self.mode in ("merged", "cyclefold-merged"):
             return self.prover.state()[1]
         return _limbs_to_ints(self.prover.instance()["z"])
 
@@ -157,6 +157,27 @@ def fold_input(params, ivc_step_inputs, initial_state, max_batch=None, prover=No
     from .hip import IVC, Context, CycleFoldIVC, MergedProof, Prover
     if max_batch is None:
         max_batch = default_batch(params.circuit)
+    if mode == "cyclefold" and prover is None and segments > 1 and len(ivc_step_inputs) >= segments:
+        # S contiguous row segments folded concurrently (one CycleFold prover each, own context and streams) and merged into ONE object
+        from .distributed import fold_concurrently, ivc_segments
+        from .hip import CycleFoldMerged
+        ctxs = [params.ctx] + [Context(params.ctx.device) for _ in range(segments - 1)]
+        ck2 = params.secondary_key()
+        cfs = [CycleFoldIVC(c, params.circuit, params.ck, ck2, max_batch=max_batch) for c in ctxs]
+        try:
+            segs = ivc_segments(cfs, ivc_step_inputs, initial_state)
+            for v, rows, z in segs:
+                v.reset(z)
+            fold_concurrently([(v, rows) for v, rows, z in segs])
+            merged = CycleFoldMerged.of(cfs)
+        except Exception:
+            for o in cfs + ctxs[1:]:
+                o.close()
+            raise
+        proof = FoldingProof(merged, len(ivc_step_inputs), list(initial_state), "cyclefold-merged")
+        proof._owned = cfs + ctxs[1:]
+        proof.verifier_key = cfs[0]
+        return proof
     if mode == "cyclefold":        # the Sonobe backend's fold_input (vimz/src/sonobe_backend/folding.rs:52-66): Nova + CycleFold prove_step per row
         p = prover if prover is not None else CycleFoldIVC(params.ctx, params.circuit, params.ck, params.secondary_key(), max_batch=max_batch)
         p.reset(initial_state)
@@ -196,7 +217,7 @@ def fold_input(params, ivc_step_inputs, initial_state, max_batch=None, prover=No
 def verify_folded_proof(proof, params, num_steps, initial_state):
     """verify_folded_proof (folding.rs:45-56: RecursiveSNARK::verify(pp, num_steps, z0, [0])); raises like the reference's
     expect("Failed to verify folded proof")."""
-    if proof.mode in ("ivc", "merged", "cyclefold"):      # (cyclefold: verify_folding, vimz/src/sonobe_backend/folding.rs:69-75)
+    if proof.mode in ("ivc", "merged", "cyclefold", "cyclefold-merged"):      # (cyclefold: verify_folding, vimz/src/sonobe_backend/folding.rs:69-75)
         r = proof.prover.verify(num_steps, initial_state)
         if r != 0:
             raise _lib.VimzError(_lib.ERR_UNSAT, f"Failed to verify folded proof (flags {r:#x})")

@@ -590,6 +590,14 @@ class CycleFoldIVC:
     def poke(self, which, index, value):
         self.ctx._chk(self.ctx.lib.vimz_cf_poke(self.h, which, index, _ptr(_zlimbs([value], 1))))
 
+    def state_chain(self, z_start, inputs):
+        a = _u64(inputs).reshape(-1, self.circuit.n_priv, 4)
+        out = np.zeros((a.shape[0] + 1, self.circuit.len_z, 4), dtype=np.uint64)
+        lib = self.ctx.lib
+        lib.vimz_cf_state_chain.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        self.ctx._chk(lib.vimz_cf_state_chain(self.h, _ptr(_zlimbs(z_start, self.circuit.len_z)), _ptr(a), a.shape[0], _ptr(out)))
+        return out
+
     def proof_export(self):
         """The proof (and resume state) as bytes: vimz_cf_proof_export."""
         lib = self.ctx.lib
@@ -606,6 +614,85 @@ class CycleFoldIVC:
         lib.vimz_cf_proof_import.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         b = np.ascontiguousarray(blob, dtype=np.uint8)
         self.ctx._chk(lib.vimz_cf_proof_import(self.h, _ptr(b), b.size))
+
+
+class CycleFoldMerged:
+    """vimz_cf_merged: ONE proof object out of the CycleFold proofs of contiguous row segments (vimz_cf_merge).  `first`: the prover of the
+    first segment (left unchanged; supplies shapes, keys and context and must stay open)."""
+    PHASES = ["cross_terms_and_commitments", "folds", "host", "total"]
+
+    def __init__(self, first):
+        self.vk, self.ctx = first, first.ctx
+        lib = self.ctx.lib
+        vp, sz = C.c_void_p, C.c_size_t
+        lib.vimz_cf_merged_create.argtypes = [vp, C.POINTER(vp)]
+        lib.vimz_cf_merged_free.argtypes = [vp]
+        lib.vimz_cf_merged_free.restype = None
+        lib.vimz_cf_merge.argtypes = [vp, vp]
+        lib.vimz_cf_merged_verify.argtypes = [vp, C.c_uint64, vp, C.POINTER(C.c_uint32)]
+        lib.vimz_cf_merged_info.argtypes = [vp, vp]
+        lib.vimz_cf_merged_state.argtypes = [vp, vp, vp, C.POINTER(C.c_uint64)]
+        lib.vimz_cf_merged_profile.argtypes = [vp, C.POINTER(C.c_double)]
+        lib.vimz_cf_merged_records.argtypes = [vp, vp, sz]
+        lib.vimz_cf_merged_records.restype = C.c_int64
+        lib.vimz_cf_merged_export.argtypes = [vp, C.c_int, C.c_int, vp, sz]
+        lib.vimz_cf_merged_export.restype = C.c_int64
+        h = vp()
+        self.ctx._chk(lib.vimz_cf_merged_create(first.h, C.byref(h)))
+        self.h = h
+
+    @classmethod
+    def of(cls, provers):
+        """The merged proof of segments proven by `provers`, in row order."""
+        m = cls(provers[0])
+        try:
+            for v in provers[1:]:
+                m.merge(v)
+        except Exception:
+            m.close()
+            raise
+        return m
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.vimz_cf_merged_free(self.h)
+            self.h = None
+
+    def merge(self, nxt):
+        self.ctx._chk(self.ctx.lib.vimz_cf_merge(self.h, nxt.h))
+
+    def verify(self, num_steps, z0):
+        r = C.c_uint32()
+        self.ctx._chk(self.ctx.lib.vimz_cf_merged_verify(self.h, int(num_steps), _ptr(_zlimbs(z0, self.vk.circuit.len_z)), C.byref(r)))
+        return r.value
+
+    def info(self):
+        a = np.zeros(8, dtype=np.uint64)
+        self.ctx._chk(self.ctx.lib.vimz_cf_merged_info(self.h, _ptr(a)))
+        return dict(zip(["steps", "segments", "len_z", "main_wires", "main_constraints", "cyclefold_wires", "cyclefold_constraints", "broken"], (int(x) for x in a)))
+
+    def state(self):
+        """(z_start, z_end, steps)"""
+        lz = self.vk.circuit.len_z
+        zs, ze = np.zeros((lz, 4), dtype=np.uint64), np.zeros((lz, 4), dtype=np.uint64)
+        steps = C.c_uint64()
+        self.ctx._chk(self.ctx.lib.vimz_cf_merged_state(self.h, _ptr(zs), _ptr(ze), C.byref(steps)))
+        ints = lambda a: [sum(int(a[i, k]) << (64 * k) for k in range(4)) for i in range(lz)]
+        return ints(zs), ints(ze), steps.value
+
+    def profile(self):
+        s = (C.c_double * 4)()
+        self.ctx._chk(self.ctx.lib.vimz_cf_merged_profile(self.h, s))
+        return dict(zip(self.PHASES, s))
+
+    def records(self):
+        n = self.ctx.lib.vimz_cf_merged_records(self.h, None, 0)
+        buf = np.zeros(n // 8, dtype=np.uint64)
+        assert self.ctx.lib.vimz_cf_merged_records(self.h, _ptr(buf), n) == n
+        return buf
+
+    def export(self, side, what):
+        return _export(self.ctx.lib.vimz_cf_merged_export, self.h, side, what).view(np.uint64).reshape(-1, 4)
 
 
 def cyclefold_selfcheck(steps=4):
