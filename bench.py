@@ -319,27 +319,30 @@ def main_ivc(args, rank, world, dist, torch, ctxs, circuit, params, steps_all, g
                              "note": "the same rows as one IVC chain on one set of streams (bench.py --segments 1)"}
             except Exception as e:
                 print(f"[bench] one-chain extra skipped: {e}", file=sys.stderr)
-        # extra (N = 1): the reference's second backend on the same rows — Nova + CycleFold, one chain (vimz_cf_*)
+        # extra (N = 1): the reference's second backend on the same image — Nova + CycleFold (vimz_cf_*): the whole image as one
+        # chain and as ONE merged proof of S concurrent segments (vimz_cf_merge), each in a process of its own the way `vimz -b sonobe` would run
+        # (tools/e2e.py; a child process, started the ordinary way — this one keeps its GPU state)
         sonobe = None
-        if world == 1 and not args.no_extras and not args.proof_set:
+        if world == 1 and not args.no_extras and not args.proof_set and args.resolution == "HD":
             try:
-                from vimz_amd.hip import CycleFoldIVC
-                n_cf = min(K, 64)
-                cf = CycleFoldIVC(ctxs[0], circuit, params.ck, params.secondary_key(), max_batch=min(args.batch, 32))
-                try:
-                    cf.reset(z0); cf.fold(rows_timed[:min(8, n_cf)])          # first-call allocations
-                    cf.reset(z0)
-                    ctxs[0].sync()
-                    t4 = time.time()
-                    cf.fold(rows_timed[:n_cf])
-                    d4 = time.time() - t4
-                    ci = cf.info()
-                    sonobe = {"steps_per_s": n_cf / d4, "steps": n_cf, "verified": cf.verify(n_cf, z0) == 0,
-                              "main_constraints": ci["main_constraints"], "cyclefold_constraints": ci["cyclefold_constraints"],
-                              "ms_per_step": {k: 1e3 * sec / n_cf for k, (sec, n) in cf.profile().items()},
-                              "note": "Nova + CycleFold IVC (the Sonobe backend's prove_step loop, vimz/src/sonobe_backend/folding.rs:52-66), one chain, same kernels"}
-                finally:
-                    cf.close()
+                import subprocess
+                runs = {}
+                for segs in sorted({1, S}):
+                    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "e2e.py"), args.transformation, args.resolution, str(segs), "cyclefold"],
+                                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+                    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+                    if r.returncode != 0 or not line:
+                        raise RuntimeError(f"tools/e2e.py exited with {r.returncode}: {r.stderr[-300:]}")
+                    runs[segs] = json.loads(line[-1])
+                one = runs[1]
+                sonobe = {"one_chain_steps_per_s": one["steps_per_s"], "steps": one["steps"], "verified": bool(one["verified"]), "fold_s": one["spans_s"]["Fold input"],
+                          "main_constraints": one["info"]["main_constraints"], "cyclefold_constraints": one["info"]["cyclefold_constraints"],
+                          "one_chain_ms_per_step": one["ms_per_step_first_segment"],
+                          "note": "Nova + CycleFold IVC (the Sonobe backend's prove_step loop, vimz/src/sonobe_backend/folding.rs:52-66) over the whole image, same kernels; own process"}
+                if S > 1:
+                    mg = runs[S]
+                    sonobe.update({"merged_steps_per_s": mg["steps_per_s"], "segments": S, "merged_verified": bool(mg["verified"]), "merged_fold_s": mg["spans_s"]["Fold input"],
+                                   "state_chain_s": mg["state_chain_s"], "merge_s": mg["merge_s"]})
             except Exception as e:
                 print(f"[bench] sonobe-backend extra skipped: {e}", file=sys.stderr)
         out = {

@@ -64,22 +64,32 @@ def main():
                           "final_state": [hex(z) for z in ze]}))
         return
     if mode == "cyclefold":
-        for c in ctxs[1:]:
-            c.close()
+        from vimz_amd.distributed import fold_concurrently, ivc_segments
         params.free()
         t0 = time.time()
         circuit, params = folding.prepare_folding(ctxs[0], t, res, backend="sonobe")
-        cf = hip.CycleFoldIVC(ctxs[0], circuit, params.ck, params.secondary_key(), max_batch=batch)
+        ck2 = params.secondary_key()
+        cfs = [hip.CycleFoldIVC(c, circuit, params.ck, ck2, max_batch=batch) for c in ctxs]
         spans["Prepare folding"] = time.time() - t0
         t0 = time.time()
-        cf.reset(z0); cf.fold(np.stack(rows))
+        rows_a = np.stack(rows)
+        segs = ivc_segments(cfs, rows_a, z0)
+        t_chain = time.time() - t0
+        for v, r, z in segs:
+            v.reset(z)
+        fold_concurrently([(v, r) for v, r, z in segs])
+        t1 = time.time()
+        proof = hip.CycleFoldMerged.of(cfs) if S > 1 else cfs[0]
+        t_merge = time.time() - t1
         spans["Fold input"] = time.time() - t0
         t0 = time.time()
-        ok = cf.verify(len(rows), z0) == 0
+        ok = proof.verify(len(rows), z0) == 0
         spans["Verify folded proof"] = time.time() - t0
-        print(json.dumps({"config": f"{t}_step_{res}", "mode": "cyclefold", "steps": len(rows), "segments": 1, "witness_batch": batch, "proof_objects": 1, "verified": ok, "spans_s": spans,
-                          "info": cf.info(), "ms_per_step": {k: 1e3 * sec / len(rows) for k, (sec, n) in cf.profile().items()},
-                          "steps_per_s": len(rows) / spans["Fold input"], "total_s": sum(spans.values()), "final_state": [hex(z) for z in cf.state()[0]]}))
+        ze = proof.state()[1] if S > 1 else proof.state()[0]
+        print(json.dumps({"config": f"{t}_step_{res}", "mode": "cyclefold", "steps": len(rows), "segments": S, "witness_batch": batch, "proof_objects": 1, "verified": ok, "spans_s": spans,
+                          "state_chain_s": t_chain, "merge_s": t_merge, "info": cfs[0].info(),
+                          "ms_per_step_first_segment": {k: 1e3 * sec / max(1, cfs[0].info()["steps"]) for k, (sec, n) in cfs[0].profile().items()},
+                          "steps_per_s": len(rows) / spans["Fold input"], "total_s": sum(spans.values()), "final_state": [hex(z) for z in ze]}))
         return
     provers = [hip.Prover(c, circuit, params.ck, max_batch=batch) for c in ctxs]
     spans["Prepare folding"] = time.time() - t0
