@@ -238,3 +238,21 @@ def test_fold_input_cyclefold_in_segments(ctx, oracle):
         proof.close()
     finally:
         params.free()
+
+
+def test_merged_cyclefold_proof_outlives_nothing_it_should_not(ctx, keys):
+    """Freeing the verifier-key prover first orphans the merged proof: later calls fail cleanly, freeing it stays safe."""
+    from vimz_amd import hip
+    ck1, ck2 = keys
+    c = Circuit.for_resolution("hash", "HD")
+    z0, inputs = step_inputs("hash")
+    v = hip.CycleFoldIVC(ctx, c, ck1, ck2, max_batch=2)
+    v.reset(z0); v.fold(np.stack(inputs[:2]))
+    m = hip.CycleFoldMerged(v)
+    assert m.verify(2, z0) == 0
+    v.close()
+    with pytest.raises(_lib.VimzError):
+        m.verify(2, z0)
+    with pytest.raises(_lib.VimzError):
+        m.info()
+    m.close()

@@ -201,6 +201,7 @@ void vimz_ctx_destroy(vimz_ctx* c) {
   if (c->scratch) hipFree(c->scratch);
   for (int i = 0; i < 7; i++) if (c->ev[i]) hipEventDestroy(c->ev[i]);
   hipEventDestroy(c->t0); hipEventDestroy(c->t1);
+  for (auto& ps : c->spare_streams) hipStreamDestroy(ps.second);
   hipStreamDestroy(c->stream);
   delete c;
 }

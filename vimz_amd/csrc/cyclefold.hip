@@ -52,6 +52,9 @@ struct vimz_cf {
   Fe u_run = Fe::zero(); Fq cf_u_run = Fq::zero();
   bool broken = false;
   double ph_s[CP_COUNT] = {}; uint64_t ph_n[CP_COUNT] = {};
+  // merged proofs that use this prover as their verifier key: freeing it first orphans them (buffers released, later calls fail cleanly)
+  std::vector<struct vimz_cf_merged*> merged_dependents;
+  void (*orphan_merged)(vimz_cf*) = nullptr;
 };
 
 namespace {
@@ -342,14 +345,14 @@ extern "C" {
 
 void vimz_cf_free(vimz_cf* v) {
   if (!v) return;
+  if (v->orphan_merged) v->orphan_merged(v);
   if (v->pri) vimz_prover_free(v->pri);
   if (v->ctx) {
     std::lock_guard<std::mutex> g(v->ctx->mu);
     hipSetDevice(v->ctx->device);
     hipStreamSynchronize(v->ctx->stream);
-    if (v->s2) { hipStreamSynchronize(v->s2); hipStreamDestroy(v->s2); }
-    if (v->s3) { hipStreamSynchronize(v->s3); hipStreamDestroy(v->s3); }
-    if (v->s4) { hipStreamSynchronize(v->s4); hipStreamDestroy(v->s4); }
+    { int lo = 0, hi = 0; hipDeviceGetStreamPriorityRange(&lo, &hi);
+      vz_stream_release(v->ctx, hi, v->s2); vz_stream_release(v->ctx, (lo + hi) / 2, v->s3); vz_stream_release(v->ctx, hi, v->s4); }
     if (v->ev_z3) hipEventDestroy(v->ev_z3);
     if (v->pin_w2) hipHostFree(v->pin_w2);
     v->ws4.release();
@@ -418,9 +421,9 @@ int vimz_cf_create(vimz_ctx* ctx, const vimz_circuit* step_circuit, const vimz_b
   if (dalloc(&v->z3, 32 * (size_t)nw2) != hipSuccess) return fail("device allocation");
   for (auto d : {&v->az3, &v->bz3, &v->cz3}) if (dalloc(d, 32 * (size_t)nc2) != hipSuccess) return fail("device allocation");
   { int lo = 0, hi = 0; hipDeviceGetStreamPriorityRange(&lo, &hi);
-    if ((e = hipStreamCreateWithPriority(&v->s2, hipStreamNonBlocking, hi)) != hipSuccess) return fail("stream");
-    if ((e = hipStreamCreateWithPriority(&v->s3, hipStreamNonBlocking, (lo + hi) / 2)) != hipSuccess) return fail("stream");
-    if ((e = hipStreamCreateWithPriority(&v->s4, hipStreamNonBlocking, hi)) != hipSuccess) return fail("stream");
+    if ((e = vz_stream_acquire(ctx, hi, &v->s2)) != hipSuccess) return fail("stream");
+    if ((e = vz_stream_acquire(ctx, (lo + hi) / 2, &v->s3)) != hipSuccess) return fail("stream");
+    if ((e = vz_stream_acquire(ctx, hi, &v->s4)) != hipSuccess) return fail("stream");
     if ((e = hipEventCreateWithFlags(&v->ev_z3, hipEventDisableTiming)) != hipSuccess) return fail("event");
     if ((e = hipEventCreateWithFlags(&v->ev_fork, hipEventDisableTiming)) != hipSuccess) return fail("event");
     if ((e = hipEventCreateWithFlags(&v->ev_fold, hipEventDisableTiming)) != hipSuccess) return fail("event");
@@ -942,6 +945,13 @@ int cfm_merge_locked(vimz_cf_merged* m, vimz_cf* next) {
   m->seconds[2] += now_s() - t0; m->seconds[3] += now_s() - t_all;
   return VIMZ_OK;
 }
+void cfm_orphan_dependents(vimz_cf* v) {
+  std::lock_guard<std::mutex> g(v->ctx->mu);
+  hipSetDevice(v->ctx->device);
+  hipStreamSynchronize(v->ctx->stream);
+  for (vimz_cf_merged* m : v->merged_dependents) { if (m->dev) hipFree(m->dev); m->dev = nullptr; m->vk = nullptr; m->broken = true; }
+  v->merged_dependents.clear();
+}
 bool cfm_same_shapes(const vimz_cf* a, const vimz_cf* b) {
   return a->ctx->device == b->ctx->device && a->ck1 == b->ck1 && a->ck2 == b->ck2 && a->pri->n_wires == b->pri->n_wires && a->pri->n_c == b->pri->n_c &&
          a->c1->digest.eq(b->c1->digest);
@@ -952,7 +962,12 @@ extern "C" {
 
 void vimz_cf_merged_free(vimz_cf_merged* m) {
   if (!m) return;
-  if (m->dev && m->vk) { std::lock_guard<std::mutex> g(m->vk->ctx->mu); hipSetDevice(m->vk->ctx->device); hipStreamSynchronize(m->vk->ctx->stream); hipFree(m->dev); }
+  if (m->vk) {
+    std::lock_guard<std::mutex> g(m->vk->ctx->mu);
+    auto& d = m->vk->merged_dependents;
+    d.erase(std::remove(d.begin(), d.end(), m), d.end());
+    if (m->dev) { hipSetDevice(m->vk->ctx->device); hipStreamSynchronize(m->vk->ctx->stream); hipFree(m->dev); }
+  }
   delete m;
 }
 // the merged proof of one segment; `first` is left unchanged, supplies shapes / keys / context and must outlive the object
@@ -970,6 +985,7 @@ int vimz_cf_merged_create(vimz_cf* first, vimz_cf_merged** out) {
   m->Zq = q; q += 8 * nw2; m->Eq = q; q += 8 * nc2; m->AZq = q; q += 8 * nc2; m->BZq = q; q += 8 * nc2; m->CZq = q; q += 8 * nc2; m->Tq = q;
   int rc = cfm_merge_locked(m.get(), first);
   if (rc) { hipFree(m->dev); m->dev = nullptr; return rc; }
+  first->merged_dependents.push_back(m.get()); first->orphan_merged = cfm_orphan_dependents;
   *out = m.release();
   return VIMZ_OK;
 }
@@ -987,7 +1003,7 @@ int vimz_cf_merge(vimz_cf_merged* m, vimz_cf* next) {
   return cfm_merge_locked(m, next);
 }
 int vimz_cf_merged_info(const vimz_cf_merged* m, uint64_t info[8]) {
-  if (!m || !info) return VIMZ_ERR_INVALID;
+  if (!m || !info || !m->vk) return VIMZ_ERR_INVALID;
   info[0] = m->acc.n; info[1] = m->segs.size(); info[2] = m->vk->pri->len_z; info[3] = m->vk->pri->n_wires; info[4] = m->vk->pri->n_c;
   info[5] = m->vk->sec.n_w; info[6] = m->vk->sec.n_c; info[7] = m->broken ? 1 : 0;
   return VIMZ_OK;
@@ -1007,7 +1023,7 @@ int vimz_cf_merged_profile(const vimz_cf_merged* m, double seconds[4]) {
 // CycleFold constraints, 0), then per segment: n; z_start; z_end; U = comm_W.x, .y, comm_E.x, .y, u, x0, x1; u = comm_W.x, .y, x0, x1;
 // cfU = comm_W.x, .y, comm_E.x, .y, u, x[0..7); T1.x, .y; T2.x, .y; Tc.x, .y  (every element four words).
 int64_t vimz_cf_merged_records(const vimz_cf_merged* m, void* buf, size_t cap) {
-  if (!m) return VIMZ_ERR_INVALID;
+  if (!m || !m->vk) return VIMZ_ERR_INVALID;
   std::vector<uint64_t> o = {CF_MERGED_MAGIC, m->segs.size(), m->vk->pri->len_z, m->vk->pri->n_wires, m->vk->pri->n_c, m->vk->sec.n_w, m->vk->sec.n_c, 0};
   auto push = [&](const auto& v) { auto x = std::decay_t<decltype(v)>::from_mont(v); o.resize(o.size() + 4); memcpy(o.data() + o.size() - 4, x.v, 32); };
   auto push_u = [&](const U256w& x) { o.insert(o.end(), x.w, x.w + 4); };

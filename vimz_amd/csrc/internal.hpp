@@ -22,7 +22,28 @@ struct vimz_ctx {
   std::string err;
   void* scratch = nullptr;  // device staging for host-scalar MSM / probes
   size_t scratch_bytes = 0;
+  // Streams of provers that were freed, kept for the provers created next (vz_stream_acquire / vz_stream_release): no stream is created and
+  // destroyed per fold call (the state-chain helper's) or per prover, and a context's later provers sit on the streams its first ones had.
+  // (Tried as a cure for the slow concurrent folds of provers created after others were destroyed, DESIGN.md §5c: it is not one.)
+  std::mutex stream_mu;
+  std::vector<std::pair<int, hipStream_t>> spare_streams;     // (priority, stream)
 };
+// a non-blocking stream of the given priority on c's device (caller has set the device): a recycled one if there is one
+static inline hipError_t vz_stream_acquire(vimz_ctx* c, int priority, hipStream_t* out) {
+  {
+    std::lock_guard<std::mutex> g(c->stream_mu);
+    for (size_t i = 0; i < c->spare_streams.size(); i++)
+      if (c->spare_streams[i].first == priority) { *out = c->spare_streams[i].second; c->spare_streams.erase(c->spare_streams.begin() + i); return hipSuccess; }
+  }
+  return hipStreamCreateWithPriority(out, hipStreamNonBlocking, priority);
+}
+// hand a stream back (synchronised first); destroyed with the context
+static inline void vz_stream_release(vimz_ctx* c, int priority, hipStream_t s) {
+  if (!s) return;
+  hipStreamSynchronize(s);
+  std::lock_guard<std::mutex> g(c->stream_mu);
+  c->spare_streams.emplace_back(priority, s);
+}
 // Tables of a fixed slice [offset, offset + n) of a key for the fused small MSMs (the four per-step MSMs of an IVC run over fixed
 // slices): rows 2^(7w)·P_i and every multiple m·2^(7w)·P_i, m = 1..64 (msm_api.hpp: BaseTables).  Built once per key and slice,
 // shared by every IVC created over the key, released with the key.

@@ -468,8 +468,9 @@ void vimz_ivc_free(vimz_ivc* v) {
     std::lock_guard<std::mutex> g(v->ctx->mu);
     hipSetDevice(v->ctx->device);
     hipStreamSynchronize(v->ctx->stream);
-    if (v->s2 && v->s2 != v->ctx->stream) { hipStreamSynchronize(v->s2); hipStreamDestroy(v->s2); }
-    if (v->s3 && v->s3 != v->ctx->stream) { hipStreamSynchronize(v->s3); hipStreamDestroy(v->s3); }
+    { int lo = 0, hi = 0; hipDeviceGetStreamPriorityRange(&lo, &hi);
+      if (v->s2 && v->s2 != v->ctx->stream) vz_stream_release(v->ctx, hi, v->s2);
+      if (v->s3 && v->s3 != v->ctx->stream) vz_stream_release(v->ctx, (lo + hi) / 2, v->s3); }
     if (v->ev_fork) hipEventDestroy(v->ev_fork);
     if (v->ev_fold) hipEventDestroy(v->ev_fold);
     if (v->ev_fused) hipEventDestroy(v->ev_fused);
@@ -547,9 +548,9 @@ int vimz_ivc_create(vimz_ctx* ctx, const vimz_circuit* step_circuit, const vimz_
   if (dalloc(&S.bad, 64) != hipSuccess) return fail("device allocation");
   { int lo = 0, hi = 0; hipDeviceGetStreamPriorityRange(&lo, &hi);
     if (getenv("VIMZ_DEBUG_NO_S2")) v->s2 = ctx->stream;
-    else if ((e = hipStreamCreateWithPriority(&v->s2, hipStreamNonBlocking, hi)) != hipSuccess) return fail("stream");
+    else if ((e = vz_stream_acquire(ctx, hi, &v->s2)) != hipSuccess) return fail("stream");
     if (getenv("VIMZ_DEBUG_NO_S2")) v->s3 = ctx->stream;
-    else if ((e = hipStreamCreateWithPriority(&v->s3, hipStreamNonBlocking, (lo + hi) / 2)) != hipSuccess) return fail("stream");
+    else if ((e = vz_stream_acquire(ctx, (lo + hi) / 2, &v->s3)) != hipSuccess) return fail("stream");
     if ((e = hipEventCreateWithFlags(&v->ev_fork, hipEventDisableTiming)) != hipSuccess) return fail("event");
     if ((e = hipEventCreateWithFlags(&v->ev_fold, hipEventDisableTiming)) != hipSuccess) return fail("event");
     if ((e = hipEventCreateWithFlags(&v->ev_fused, hipEventDisableTiming)) != hipSuccess) return fail("event");

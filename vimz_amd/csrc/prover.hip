@@ -26,8 +26,7 @@ void vimz_prover_free(vimz_prover* p) {
     std::lock_guard<std::mutex> g(p->ctx->mu);
     hipSetDevice(p->ctx->device);
     hipStreamSynchronize(p->ctx->stream);
-    if (p->sB) { hipStreamSynchronize(p->sB); hipStreamDestroy(p->sB); }
-    if (p->sH) { hipStreamSynchronize(p->sH); hipStreamDestroy(p->sH); }
+    { int lo = 0, hi = 0; hipDeviceGetStreamPriorityRange(&lo, &hi); vz_stream_release(p->ctx, lo, p->sB); vz_stream_release(p->ctx, lo, p->sH); }
     if (p->ev_head) hipEventDestroy(p->ev_head);
     if (p->ev_hash) hipEventDestroy(p->ev_hash);
     p->wsH.release();
@@ -131,7 +130,7 @@ int vz_prover_create_layout(vimz_ctx* ctx, const vimz_circuit* circuit, const vi
     return fail_free("device allocation", e);
   { int lo = 0, hi = 0; hipDeviceGetStreamPriorityRange(&lo, &hi);
     // (the producer sits on the lowest of HIP's three priority levels; confining it to a CU mask instead measured no better: DESIGN.md §9)
-    if ((e = hipStreamCreateWithPriority(&p->sB, hipStreamNonBlocking, lo)) != hipSuccess) return fail_free("stream", e); }
+    if ((e = vz_stream_acquire(ctx, lo, &p->sB)) != hipSuccess) return fail_free("stream", e); }
   for (int k = 0; k < 2; k++) {
     auto& bb = p->buf[k];
     if (k == 0) { bb.Z = p->Z_d; bb.job_out = p->job_out_d; bb.status = p->status_d; }   // buffer 0 is shared with the witness hook
@@ -158,7 +157,7 @@ int vz_prover_create_layout(vimz_ctx* ctx, const vimz_circuit* circuit, const vi
   }
   {   // head batch of a fold call (prover_internal.hpp: fold_head_batch): staging layout of the Poseidon jobs' wires, its stream
     int lo = 0, hi = 0; hipDeviceGetStreamPriorityRange(&lo, &hi);
-    if ((e = hipStreamCreateWithPriority(&p->sH, hipStreamNonBlocking, lo)) != hipSuccess) return fail_free("stream", e);
+    if ((e = vz_stream_acquire(ctx, lo, &p->sH)) != hipSuccess) return fail_free("stream", e);
     p->sD = p->sH;
     if ((e = hipEventCreateWithFlags(&p->ev_head, hipEventDisableTiming)) != hipSuccess || (e = hipEventCreateWithFlags(&p->ev_hash, hipEventDisableTiming)) != hipSuccess)
       return fail_free("event", e);

@@ -708,26 +708,27 @@ static int fold_prepare(vimz_prover* p, FoldJob& J, bool start_batch0 = false) {
       hipError_t e = hipSetDevice(ctx->device);
       if (e != hipSuccess) return failed("helper: hipSetDevice", e);
       hipStream_t sx = nullptr;            // own stream: nothing of the fold is queued behind these copies
-      if ((e = hipStreamCreateWithFlags(&sx, hipStreamNonBlocking)) != hipSuccess) return failed("helper: stream", e);
+      int plo = 0, phi = 0; hipDeviceGetStreamPriorityRange(&plo, &phi); const int pmid = (plo + phi) / 2;
+      if ((e = vz_stream_acquire(ctx, pmid, &sx)) != hipSuccess) return failed("helper: stream", e);      // (recycled: no stream churn per fold call)
       const size_t cuts[3] = {head, mid, nsteps};
       hipEvent_t evs[2] = {ev_mid, p->ev_hash};
       for (int part = 0; part < 2; part++) {
         const size_t lo = cuts[part], hi = cuts[part + 1];
         if (hi <= lo) continue;
-        if ((e = hipEventSynchronize(evs[part])) != hipSuccess) { hipStreamDestroy(sx); return failed("helper: row hashes", e); }
+        if ((e = hipEventSynchronize(evs[part])) != hipSuccess) { vz_stream_release(ctx, pmid, sx); return failed("helper: row hashes", e); }
         const double t1 = now_s();
         Fe* ja = J.jobA_rest.data() + (lo - head) * jstride;
         if ((e = hipMemcpyAsync(ja, p->job_all_d + 8 * lo * jstride, 32 * (hi - lo) * jstride, hipMemcpyDeviceToHost, sx)) != hipSuccess ||
-            (e = hipStreamSynchronize(sx)) != hipSuccess) { hipStreamDestroy(sx); return failed("helper: download", e); }
+            (e = hipStreamSynchronize(sx)) != hipSuccess) { vz_stream_release(ctx, pmid, sx); return failed("helper: download", e); }
         host_state_chain(p, J.step_inputs + 4 * lo * (size_t)p->n_priv, hi - lo, ja, jstride, J.zs, lo);
         std::vector<Fe> zc((hi - lo) * (size_t)p->len_z);
         for (size_t i = 0; i < zc.size(); i++) zc[i] = Fe::from_mont(J.zs[(lo + 1) * p->len_z + i]);
         if ((e = hipMemcpyAsync(p->zs_all_d + 8 * (lo + 1) * (size_t)p->len_z, zc.data(), 32 * zc.size(), hipMemcpyHostToDevice, sx)) != hipSuccess ||
-            (e = hipStreamSynchronize(sx)) != hipSuccess) { hipStreamDestroy(sx); return failed("helper: upload", e); }
+            (e = hipStreamSynchronize(sx)) != hipSuccess) { vz_stream_release(ctx, pmid, sx); return failed("helper: upload", e); }
         p->phase_s[PH_ZCHAIN] += now_s() - t1; p->phase_n[PH_ZCHAIN] += hi - lo;
         J.states_upto.store(hi, std::memory_order_release);
       }
-      hipStreamDestroy(sx);
+      vz_stream_release(ctx, pmid, sx);
       J.helper_done = 1;
     });
     return VIMZ_OK;
