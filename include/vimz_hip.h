@@ -336,7 +336,7 @@ int vimz_cf_verify(vimz_cf* v, uint64_t num_steps, const uint64_t* z0, uint32_t*
 int vimz_cf_info(const vimz_cf* v, uint64_t info[12]);
 int vimz_cf_state(const vimz_cf* v, uint64_t* z_current, uint64_t* steps);
 /* seconds[8]/counts[8]: cross term + MSM(T), the two CycleFold instances, F' on the host, fresh instance (upload, verifier rows,
- * commitment), producer wait, total, reserved x2 */
+ * commitment), producer wait, total, and — parts of the fresh-instance phase — the wait for the producer's row, for the verifier wires' commitment */
 int vimz_cf_profile(const vimz_cf* v, double seconds[8], uint64_t counts[8]);
 /* side 0 = main circuit, 1 = CycleFold circuit; what = VIMZ_CX_* (R1CS tables), VIMZ_IX_INFO, VIMZ_IX_INSTANCE (side 0: comm_W.x, comm_W.y,
  * comm_E.x, comm_E.y, u, x0, x1; side 1: comm_W.x, comm_W.y, comm_E.x, comm_E.y, u, x[0..7)), VIMZ_IX_FRESH_INSTANCE (side 0: comm_W.x,

@@ -282,9 +282,11 @@ int cf_fold_core(vimz_cf* v, const uint64_t* step_inputs, size_t nsteps) {
         P_TRY(msm_launch<BnG1>(s, ctx->msm_ws, p->ck->d + (size_t)AFFINE_WORDS * sc, p->T + 8 * sc, nc - sc, 1, 0, v->pin + v->pin_res, &v->plan_Tv, nullptr, 0, nullptr));
         v->t_ver_for = (int64_t)i + 1;
       }
-      P_TRY(hipEventSynchronize(bb.ev[r]));
+      { const double tw = now_s();
+        P_TRY(hipEventSynchronize(bb.ev[r]));      // (polling hipEventQuery instead measured worse: three provers' threads spinning on the runtime)
+        v->ph_s[6] += now_s() - tw; }
       const G1Aff cW_step = msm_finish<BnG1>(p->planB, (char*)bb.pin + r * pin_stride);
-      P_TRY(hipStreamSynchronize(v->s2));
+      { const double tw = now_s(); P_TRY(hipStreamSynchronize(v->s2)); v->ph_s[7] += now_s() - tw; }
       const G1Aff cW_aug = msm_finish<BnG1>(v->plan_aug, v->pin);
       G1 sum = from_affine(cW_step); if (aff_is_identity(cW_step)) sum = G1::identity();
       add_mixed(sum, cW_aug);

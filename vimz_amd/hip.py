@@ -523,7 +523,7 @@ class IVC:
 class CycleFoldIVC:
     """vimz_cf: Nova + CycleFold IVC of one transformation's step circuit (the reference's Sonobe backend: Folding::prove_step / verify,
     vimz/src/sonobe_backend/folding.rs:52-75).  ck_main on BN254 G1 (e.g. a KZG SRS's powers), ck_cyclefold on Grumpkin."""
-    PHASES = ["cross_term_msm", "cyclefold_instances", "main_circuit_host", "fresh_instance", "producer_wait", "total"]
+    PHASES = ["cross_term_msm", "cyclefold_instances", "main_circuit_host", "fresh_instance", "producer_wait", "total", "wait_row_event", "wait_verifier_commitment"]
 
     def __init__(self, ctx, circuit, ck_main, ck_cyclefold, max_batch=16):
         self.ctx, self.circuit = ctx, circuit
