@@ -375,9 +375,10 @@ int vimz_cf_state_chain(vimz_cf* v, const uint64_t* z_start, const uint64_t* ste
 /* test hooks.  poke: overwrite one element (canonical) of a witness vector on the device — which = 0 running main Z, 1 last fresh main Z,
  * 2 running CycleFold Z, 3 running main E, 4 running CycleFold E.  selfcheck: host only, no GPU — `steps` steps over the trivial step
  * circuit with made-up commitments, every witness checked against its R1CS and every in-circuit fold against field / curve arithmetic
- * (result 0 = good; counts: F' wires, constraints, CycleFold wires, constraints). */
+ * (result 0 = good; counts: F' wires, constraints, CycleFold wires, constraints, then of the last step's
+ * flip test — every wire incremented by one must violate a row — wires of F' flipped, unnoticed, wires of the CycleFold circuit flipped, unnoticed). */
 int vimz_cf_poke(vimz_cf* v, int which, size_t index, const uint64_t value[4]);
-int vimz_cf_selfcheck(int steps, uint32_t* result, uint64_t counts[4]);
+int vimz_cf_selfcheck(int steps, uint32_t* result, uint64_t counts[8]);
 
 /* ---- ONE proof object out of several row segments: the "host-side sequential final fold" of BASELINE.json's north_star for IVC proofs.
  *      fold_input returns ONE RecursiveSNARK (vimz/src/nova_snark_backend/folding.rs:27-43); row segments of an image folded

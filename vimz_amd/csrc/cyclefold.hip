@@ -1165,8 +1165,10 @@ int vimz_cf_poke(vimz_cf* v, int which, size_t index, const uint64_t value[4]) {
 // R1CS, every in-circuit fold against the same fold in field / curve arithmetic.  result: 0 = all good; bit 0 a CycleFold witness
 // violates its shape, bit 1 its result is wrong, bit 2 an F' witness violates its shape, bit 3 F' flagged its inputs, bit 4 a folded
 // CycleFold public element differs from x + r·x_in mod q, bit 5 the folded scalars of the main instance differ, bit 6 the output
-// hashes differ from the verifier's, bit 7 a flipped wire of F' went unnoticed.  counts (optional): F' wires / constraints, CycleFold wires / constraints.
-int vimz_cf_selfcheck(int steps, uint32_t* result, uint64_t counts[4]) {
+// hashes differ from the verifier's, bit 7 more flipped wires than the allowed handful went unnoticed.  counts (optional, 8 words): F' wires /
+// constraints, CycleFold wires / constraints, then the flip test of the last step: wires of F + F' flipped, unnoticed, wires of the CycleFold
+// circuit flipped, unnoticed.
+int vimz_cf_selfcheck(int steps, uint32_t* result, uint64_t counts[8]) {
   if (!result || steps < 1 || steps > 64) return VIMZ_ERR_INVALID;
   try {
     CfCircuit cf; cf.finish();
@@ -1186,6 +1188,31 @@ int vimz_cf_selfcheck(int steps, uint32_t* result, uint64_t counts[4]) {
       }
       return true;
     };
+    // number of wires from `from` on whose increment by one leaves every row that mentions them satisfied
+    auto flips_unnoticed = [](const auto& bld, const auto& z0v, size_t from) -> uint64_t {
+      typedef std::decay_t<decltype(z0v[0])> F;
+      const cb::Csr* Ms[3] = {&bld.A, &bld.B, &bld.C};
+      const uint32_t nr = bld.n_constraints();
+      std::vector<std::vector<uint32_t>> rows_of(z0v.size());
+      for (int m = 0; m < 3; m++) for (uint32_t r = 0; r < nr; r++) for (uint32_t k = Ms[m]->row_ptr[r]; k < Ms[m]->row_ptr[r + 1]; k++) {
+        auto& v = rows_of[Ms[m]->col[k]]; if (v.empty() || v.back() != r) v.push_back(r);
+      }
+      auto z = z0v;
+      uint64_t un = 0;
+      for (size_t w = from; w < z.size(); w++) {
+        const F keep = z[w]; z[w] = F::add(keep, F::one());
+        bool noticed = false;
+        for (uint32_t r : rows_of[w]) {
+          F acc[3];
+          for (int m = 0; m < 3; m++) { acc[m] = F::zero(); for (uint32_t k = Ms[m]->row_ptr[r]; k < Ms[m]->row_ptr[r + 1]; k++) acc[m] = F::add(acc[m], F::mul(bld.dict[Ms[m]->coef[k]], z[Ms[m]->col[k]])); }
+          if (!F::mul(acc[0], acc[1]).eq(acc[2])) { noticed = true; break; }
+        }
+        if (!noticed) { un++; if (getenv("VIMZ_CF_SELFCHECK_VERBOSE")) fprintf(stderr, "[selfcheck] wire %zu of %zu: +1 unnoticed (%zu rows mention it)\n", w, z.size(), rows_of[w].size()); }
+        z[w] = keep;
+      }
+      return un;
+    };
+    uint64_t flips_buf[4] = {0, 0, 0, 0}; uint64_t* flips_out = flips_buf;
     uint32_t res = 0;
     const G1Aff g1 = CycleSide<BnFq>::G(); const G2Aff g2 = CycleSide<BnFr>::G();
     auto fake1 = [&](uint64_t k) { const uint32_t w[2] = {(uint32_t)k, (uint32_t)(k >> 32)}; return to_affine(scalar_mul(g1, w, 64)); };
@@ -1213,6 +1240,7 @@ int vimz_cf_selfcheck(int steps, uint32_t* result, uint64_t counts[4]) {
           std::vector<Q> wires; bool bad = false;
           const G1Aff P3 = cf.witness(ch.r, P1s[c], P2s[c], wires, &bad);
           if (bad || !sat(cf.b, wires)) res |= 1;
+          else if (i == steps - 1 && c == 0) { const uint64_t un = flips_unnoticed(cf.b, wires, 1); if (flips_out) { flips_out[2] = wires.size() - 1; flips_out[3] = un; } if (un > 4) res |= 128; }
           if (!P3.x.eq(P3s[c].x) || !P3.y.eq(P3s[c].y)) res |= 2;
         }
         in.cf1W = fake2(0x2000 + i); in.cf1T = i > 1 ? fake2(0x3000 + i) : g2_identity();
@@ -1231,8 +1259,12 @@ int vimz_cf_selfcheck(int steps, uint32_t* result, uint64_t counts[4]) {
       std::vector<Fe> z = {Fe::one(), z0[0], z0[0]};
       z.insert(z.end(), aug.begin(), aug.end());
       if (!sat(b, z)) res |= 4;
-      else if (i == steps - 1)      // the check itself must notice a wrong wire: flip a few of F's and expect every one to violate some row
-        for (size_t w : {(size_t)3, z.size() / 3, z.size() / 2, z.size() - 1}) { std::vector<Fe> zz = z; zz[w] = Fe::add(zz[w], Fe::one()); if (sat(b, zz)) res |= 128; }
+      else if (i == steps - 1) {    // EVERY wire of F' matters: adding one to it must violate a row that mentions it (a wire no row notices is
+                                    // unconstrained — the only ones allowed are the inverse hints of is-zero tests whose argument IS zero)
+        uint64_t unnoticed = flips_unnoticed(b, z, 3);
+        if (flips_out) { flips_out[0] = z.size() - 3; flips_out[1] = unnoticed; }
+        if (unnoticed > 8) res |= 128;
+      }
       if (i > 0) {
         if (memcmp(o.r, ch.r, 16) || memcmp(o.r1, ch.r1, 16) || memcmp(o.r2, ch.r2, 16)) res |= 64;
         for (int k = 0; k < CF_IO; k++) if (memcmp(o.cfU_new.x[k].w, want_x[k].w, 32)) res |= 16;
@@ -1253,6 +1285,7 @@ int vimz_cf_selfcheck(int steps, uint32_t* result, uint64_t counts[4]) {
       if (!cf_hash_main(c1.digest, i + 1, z0, z0.data(), U).eq(o.x0) || !cf_hash_cf(c1.digest, cfU).eq(o.x1)) res |= 64;
       uW = fake1(0x6000 + i); u.W = nn_point(uW); u.x0 = o.x0; u.x1 = o.x1;
     }
+    if (counts) { counts[4] = flips_buf[0]; counts[5] = flips_buf[1]; counts[6] = flips_buf[2]; counts[7] = flips_buf[3]; }
     *result = res;
     return VIMZ_OK;
   } catch (const std::exception& e) { return vz_fail(nullptr, VIMZ_ERR_INVALID, e.what()); }

@@ -701,11 +701,12 @@ def cyclefold_selfcheck(steps=4):
     lib = _lib.lib()
     lib.vimz_cf_selfcheck.argtypes = [C.c_int, C.POINTER(C.c_uint32), C.c_void_p]
     r = C.c_uint32()
-    counts = np.zeros(4, dtype=np.uint64)
+    counts = np.zeros(8, dtype=np.uint64)
     rc = lib.vimz_cf_selfcheck(int(steps), C.byref(r), _ptr(counts))
     if rc:
         raise _lib.VimzError(rc, "vimz_cf_selfcheck")
-    return r.value, dict(zip(["main_wires", "main_constraints", "cyclefold_wires", "cyclefold_constraints"], (int(x) for x in counts)))
+    return r.value, dict(zip(["main_wires", "main_constraints", "cyclefold_wires", "cyclefold_constraints", "main_flipped", "main_unnoticed", "cyclefold_flipped", "cyclefold_unnoticed"],
+                             (int(x) for x in counts)))
 
 
 def _zlimbs(z0, len_z):
