@@ -314,6 +314,13 @@ int vimz_ivc_compress(vimz_ivc* v, uint8_t* blob, size_t cap, double seconds[2])
  * argument for the primary running / secondary running / last fresh secondary instance; bit 12 statement mismatch; bit 13 malformed. */
 int vimz_ivc_verify_compressed(vimz_ivc* v, const uint8_t* blob, size_t len, uint64_t num_steps, const uint64_t* z0, uint32_t* result);
 
+/* KZG opening of a committed, device-resident vector (the `KZG::prove` of Sonobe's decider for the final commitments, reached from
+ * vimz/src/sonobe_backend/decider.rs:13-21; calldata words kzg_*: vimz_amd/calldata.py): `srs` = the SRS's G1 powers [τ^i]G as bases
+ * (vimz_bases_upload), so that vimz_msm_vec over them commits to p(X) = Σ v_i X^i.  eval_out = p(z); proof_xy = the commitment to
+ * (p(X) − p(z)) / (X − z) (affine, `form`; the identity as zeros).  z and eval_out in `form`.  The pairing check belongs to the verifier. */
+int vimz_kzg_open(vimz_ctx* ctx, const vimz_bases* srs, size_t base_offset, const vimz_vec* v, size_t offset, size_t n, const uint64_t z[4], int form,
+                  uint64_t eval_out[4], uint64_t proof_xy[8]);
+
 /* ---- Nova + CycleFold IVC: the `prove_step` loop of the reference's Sonobe backend (vimz/src/sonobe_backend/folding.rs:52-66; scheme
  *      `Nova<G1, G2, C, KZG<Bn254>, Pedersen<G2>, false>`, folding.rs:22) — SURVEY.md §8 row N1.  The main circuit F' (step circuit + our
  *      statement of CycleFold's augmented circuit, vimz_amd/csrc/aug/cyclefold.hpp) is committed on BN254 G1 — ck_main may be a KZG SRS's
@@ -342,6 +349,9 @@ int vimz_cf_profile(const vimz_cf* v, double seconds[8], uint64_t counts[8]);
  * comm_E.x, comm_E.y, u, x0, x1; side 1: comm_W.x, comm_W.y, comm_E.x, comm_E.y, u, x[0..7)), VIMZ_IX_FRESH_INSTANCE (side 0: comm_W.x,
  * comm_W.y, x0, x1), VIMZ_IX_PARAMS (side 0: digest, z0..., z_i...), VIMZ_IX_RUNNING_Z, VIMZ_IX_RUNNING_E, VIMZ_IX_FRESH_Z (side 0) */
 int64_t vimz_cf_export(vimz_cf* v, int side, int what, void* buf, size_t cap);
+/* KZG openings of the running main instance's commitments at z (vimz_kzg_open over ck_main as the SRS): which = 0 comm_W (coefficients = the witness
+ * wires [1, wires - 2) of the running vector), 1 comm_E.  Canonical in and out. */
+int vimz_cf_kzg_open(vimz_cf* v, int which, const uint64_t z[4], uint64_t eval_out[4], uint64_t proof_xy[8]);
 /* The proof as an object of its own (Sonobe's `ivc_proof()` / `from_ivc_proof`; checkpoint / resume): everything vimz_cf_verify reads and the
  * next vimz_cf_fold needs.  Import into a vimz_cf created for the same step circuit and keys, then verify or keep folding. */
 size_t vimz_cf_proof_size(const vimz_cf* v);

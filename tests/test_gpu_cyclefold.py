@@ -256,3 +256,37 @@ def test_merged_cyclefold_proof_outlives_nothing_it_should_not(ctx, keys):
     with pytest.raises(_lib.VimzError):
         m.info()
     m.close()
+
+
+def test_kzg_openings_of_a_cyclefold_proof_over_an_srs(ctx, oracle):
+    """The Sonobe backend commits the main instances with KZG (folding.rs:22) and its decider opens the final commitments (decider.rs:13-21).
+    With the powers [tau^i]G of a test SRS (tau known) uploaded as ck_main, a CycleFold IVC folds and verifies as with any key, and the KZG
+    openings of its running comm_W / comm_E (vimz_cf_kzg_open) satisfy the pairing equation's G1 form (tau - z)·proof == comm - eval·G."""
+    from tests._oracle import to_limbs
+    from vimz_amd import hip
+    r = _lib.MODULUS[0]
+    c = Circuit.for_resolution("hash", "HD")
+    n = 36000                                               # >= max(wires, constraints) of F + F' for this step circuit (34.3 k)
+    tau = 0x2718281828459045235360287471352662497757247093699959574966967627 % r
+    G = (1, 2)
+    srs, t = np.zeros((n, 8), dtype=np.uint64), 1
+    for i in range(n):
+        srs[i] = to_limbs(list(oracle.curve_mul(0, G, t))).reshape(-1)
+        t = t * tau % r
+    B = ctx.bases_upload(0, srs)
+    ck2 = ctx.bases_generate(_lib.CURVE_GRUMPKIN, 1 << 13, b"ck-cyclefold")
+    z0, inputs = step_inputs("hash")
+    cf = hip.CycleFoldIVC(ctx, c, B, ck2, max_batch=2)
+    try:
+        cf.reset(z0); cf.fold(np.stack(inputs[:4]))
+        assert cf.verify(4, z0) == 0
+        U = from_limbs(cf.export(0, hip.IX_INSTANCE))
+        rs = np.random.default_rng(11)
+        for which, comm in ((0, (U[0], U[1])), (1, (U[2], U[3]))):
+            for z in (3, int(rs.integers(1, 1 << 62)) * int(rs.integers(1, 1 << 62)) % r):
+                ev, proof = cf.kzg_open(which, z)
+                lhs = oracle.curve_mul(0, proof, (tau - z) % r)
+                rhs = oracle.curve_add(0, comm, oracle.curve_mul(0, G, (r - ev) % r))
+                assert lhs == rhs, (which, z)
+    finally:
+        cf.close(); B.free(); ck2.free()

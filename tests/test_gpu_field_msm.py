@@ -429,6 +429,26 @@ def test_kzg_style_commitment_over_an_uploaded_srs_has_the_closed_form_value(ctx
         v = ctx.vec_from_host(0, to_limbs(coeffs))
         q_tau = sum(c * k for c, k in zip(coeffs[100:5100], powers[300:5300])) % r
         assert tuple(from_limbs(ctx.msm_vec(B, v, n=5000, offset=100, base_offset=300))) == oracle.curve_mul(0, G, q_tau)
+        # KZG openings (vimz_kzg_open: what Sonobe's decider produces for the final commitments, decider.rs:13-21): eval = p(z) and
+        # proof = commit((p(X) - p(z)) / (X - z)); with tau known the proof has the closed form ((p(tau) - p(z)) / (tau - z))·G, and the
+        # pairing equation e(proof, [tau - z]H) = e(comm - eval·G, H) becomes (tau - z)·proof == comm - eval·G in G1
+        for z in (5, rng.randrange(r), tau + 1, 0):
+            ev, proof = ctx.kzg_open(B, v, z)
+            p_z = sum(c * pow(z, i, r) for i, c in enumerate(coeffs)) % r
+            assert ev == p_z
+            want = (p_tau - p_z) * pow((tau - z) % r, -1, r) % r
+            assert proof == oracle.curve_mul(0, G, want)
+            comm = oracle.curve_mul(0, G, p_tau)
+            lhs = oracle.curve_mul(0, proof, (tau - z) % r)
+            rhs = oracle.curve_add(0, comm, oracle.curve_mul(0, G, (r - p_z) % r))
+            assert lhs == rhs
+        # a sub-range of the vector over the low powers, and a constant
+        ev, proof = ctx.kzg_open(B, v, 7, n=3000, offset=200)
+        sub = coeffs[200:3200]
+        p7, pt = sum(c * pow(7, i, r) for i, c in enumerate(sub)) % r, sum(c * k for c, k in zip(sub, powers)) % r
+        assert ev == p7 and proof == oracle.curve_mul(0, G, (pt - p7) * pow((tau - 7) % r, -1, r) % r)
+        ev, proof = ctx.kzg_open(B, v, 9, n=1, offset=3)
+        assert ev == coeffs[3] and proof == (0, 0)
         v.free()
     finally:
         B.free()

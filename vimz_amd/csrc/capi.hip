@@ -102,6 +102,33 @@ int vz_msm_device(vimz_ctx* c, const vimz_bases* bases, size_t base_offset, cons
     return VIMZ_OK;
   });
 }
+
+// core of vimz_kzg_open on a device-resident vector of Montgomery elements (caller holds c->mu and has set the device)
+int vz_kzg_open_device(vimz_ctx* c, const vimz_bases* srs, size_t base_offset, int field, const uint32_t* d_vec, size_t n, const uint64_t z[4], int form,
+                       uint64_t eval_out[4], uint64_t proof_xy[8]) {
+  if (n == 0 || base_offset + n > srs->n) return vz_fail(c, VIMZ_ERR_INVALID, "kzg open: the SRS is shorter than the vector");
+  std::vector<uint32_t> host(8 * n);
+  hipError_t e;
+  if ((e = hipMemcpyAsync(host.data(), d_vec, 32 * n, hipMemcpyDeviceToHost, c->stream)) != hipSuccess || (e = hipStreamSynchronize(c->stream)) != hipSuccess)
+    return vz_fail(c, VIMZ_ERR_HIP, "kzg open: download", e);
+  int rc = field_dispatch(field, [&](auto f) {
+    typedef decltype(f) F;
+    F zz; memcpy(zz.v, z, 32);
+    if (!zz.is_reduced()) return vz_fail(c, VIMZ_ERR_INVALID, "kzg open: z not below the modulus");
+    if (form == VIMZ_FORM_CANONICAL) zz = F::to_mont(zz);
+    F* a = reinterpret_cast<F*>(host.data());       // Montgomery, as resident
+    F carry = F::zero();                              // q_i, walking down; the last carry is p(z)
+    for (size_t i = n; i-- > 0;) { const F cur = F::add(a[i], F::mul(zz, carry)); a[i] = carry; carry = cur; }      // a[i] <- q_i  (q_{n-1} = 0)
+    const F ev = form == VIMZ_FORM_CANONICAL ? F::from_mont(carry) : carry;
+    memcpy(eval_out, ev.v, 32);
+    return VIMZ_OK;
+  });
+  if (rc) return rc;
+  if (n == 1) { memset(proof_xy, 0, 64); return VIMZ_OK; }      // a constant: the quotient is zero, its commitment the identity
+  rc = vz_ensure_scratch(c, 32 * (n - 1)); if (rc) return rc;
+  if ((e = hipMemcpyAsync(c->scratch, host.data(), 32 * (n - 1), hipMemcpyHostToDevice, c->stream)) != hipSuccess) return vz_fail(c, VIMZ_ERR_HIP, "kzg open: upload", e);
+  return vz_msm_device(c, srs, base_offset, (const uint32_t*)c->scratch, n - 1, 1, 0, proof_xy, form);
+}
 int vz_small_tables(vimz_ctx* c, vimz_bases* b, size_t offset, size_t n, bool with_mult, BaseTables* out) {
   *out = BaseTables{nullptr, 0, 0, 0, 0};
   if (!n || n > MSM_SMALL_MAX || offset + n > b->n) return VIMZ_OK;
@@ -459,6 +486,20 @@ int vimz_msm_vec_ex(vimz_ctx* c, const vimz_bases* bases, size_t base_offset, co
   std::lock_guard<std::mutex> g(c->mu);
   HIP_TRY(c, hipSetDevice(c->device));
   return vz::vz_msm_device(c, bases, base_offset, v->d + 8 * offset, n, 1, window_bits, out_xy, out_form, (flags & VIMZ_MSM_SPLIT_ONES) ? 1 : 0);
+}
+
+// KZG opening of a committed vector at a point (the `KZG::prove` the Sonobe decider calls for the final commitments, reached from
+// vimz/src/sonobe_backend/decider.rs:13-21): with the SRS's G1 powers as bases, comm = Σ v_i·[τ^i]G commits to p(X) = Σ v_i X^i;
+// the opening at z is  eval = p(z)  and  proof = commit((p(X) − p(z)) / (X − z)) — the quotient's coefficients by synthetic division
+// (q_{n-2} = v_{n-1}, q_{i-1} = v_i + z·q_i; a serial recurrence of n multiplications: host, ≈ 10 ms at 3·10^5), then the same MSM as the
+// commitment, one point shorter.  The pairing check e(proof, [τ − z]H) = e(comm − eval·G, H) is the on-chain verifier's (no G2 arithmetic here).
+int vimz_kzg_open(vimz_ctx* c, const vimz_bases* srs, size_t base_offset, const vimz_vec* v, size_t offset, size_t n, const uint64_t z[4], int form,
+                  uint64_t eval_out[4], uint64_t proof_xy[8]) {
+  if (!c || !srs || !v || !z || !eval_out || !proof_xy || n == 0 || offset + n > v->n || base_offset + n > srs->n) return fail(c, VIMZ_ERR_INVALID, "vimz_kzg_open: bad argument");
+  if (v->field != curve_scalar_field(srs->curve)) return fail(c, VIMZ_ERR_INVALID, "vimz_kzg_open: vector is not over the curve's scalar field");
+  std::lock_guard<std::mutex> g(c->mu);
+  HIP_TRY(c, hipSetDevice(c->device));
+  return vz::vz_kzg_open_device(c, srs, base_offset, v->field, v->d + 8 * offset, n, z, form, eval_out, proof_xy);
 }
 
 // ---- probes ------------------------------------------------------------------------------------------

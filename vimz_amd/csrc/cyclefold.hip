@@ -1133,6 +1133,18 @@ int vimz_cf_state_chain(vimz_cf* v, const uint64_t* z_start, const uint64_t* ste
   return vimz_prover_state_chain(v->pri, z_start, step_inputs, nsteps, zs_out);
 }
 
+// KZG openings of the running main instance's two commitments (what Sonobe's decider adds to the proof for the on-chain verifier, decider.rs:13-21;
+// calldata words kzg_*): with ck_main = the SRS's G1 powers, comm_W commits to the polynomial whose coefficients are the witness wires
+// [1, wires - 2) of the running vector, comm_E to the error vector's.  which = 0: W, 1: E.  z, eval_out canonical; proof_xy canonical affine.
+int vimz_cf_kzg_open(vimz_cf* v, int which, const uint64_t z[4], uint64_t eval_out[4], uint64_t proof_xy[8]) {
+  if (!v || !z || !eval_out || !proof_xy || (which != 0 && which != 1)) return VIMZ_ERR_INVALID;
+  vimz_ctx* ctx = v->ctx; vimz_prover* p = v->pri;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  P_TRY(hipSetDevice(ctx->device));
+  return which == 0 ? vz_kzg_open_device(ctx, p->ck, 0, VIMZ_FIELD_BN254_FR, p->Zrun + 8, p->n_wires - 3, z, VIMZ_FORM_CANONICAL, eval_out, proof_xy)
+                    : vz_kzg_open_device(ctx, p->ck, 0, VIMZ_FIELD_BN254_FR, p->E, p->n_c, z, VIMZ_FORM_CANONICAL, eval_out, proof_xy);
+}
+
 // test hook: overwrite one element of a witness vector on the device (soundness tests flip wires and expect vimz_cf_verify / the
 // oracle verifier to reject).  which: 0 running main Z, 1 last fresh main Z, 2 running CycleFold Z, 3 running main E, 4 running CycleFold E.
 int vimz_cf_poke(vimz_cf* v, int which, size_t index, const uint64_t value[4]) {

@@ -66,4 +66,7 @@ int vz_small_tables(vimz_ctx* c, vimz_bases* b, size_t offset, size_t n, bool wi
 // MSM over device-resident scalars on the context's stream (caller holds c->mu and has set the device)
 int vz_msm_device(vimz_ctx* c, const vimz_bases* bases, size_t base_offset, const uint32_t* d_scalars, size_t n,
                   int scalars_mont, int window_bits, uint64_t out_xy[8], int out_form, int split_ones = 0);
+// KZG opening (vimz_kzg_open) of a device-resident vector of Montgomery elements of field `field` (caller holds c->mu and has set the device)
+int vz_kzg_open_device(vimz_ctx* c, const vimz_bases* srs, size_t base_offset, int field, const uint32_t* d_vec, size_t n, const uint64_t z[4], int form,
+                       uint64_t eval_out[4], uint64_t proof_xy[8]);
 }

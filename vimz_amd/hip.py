@@ -180,6 +180,16 @@ class Context:
             self._chk(self.lib.vimz_msm_vec(self.h, bases.h, base_offset, vec.h, offset, n, window_bits, _ptr(out), out_form))
         return out
 
+    def kzg_open(self, srs, vec, z, n=None, offset=0, base_offset=0):
+        """vimz_kzg_open: (p(z), proof point) for p(X) = sum_i vec[offset + i] X^i over the SRS powers `srs`; canonical integers."""
+        n = vec.n - offset if n is None else n
+        lib = self.lib
+        lib.vimz_kzg_open.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        ev, pr = np.zeros(4, dtype=np.uint64), np.zeros(8, dtype=np.uint64)
+        self._chk(lib.vimz_kzg_open(self.h, srs.h, base_offset, vec.h, offset, n, _ptr(_zlimbs([z], 1)), L.FORM_CANONICAL, _ptr(ev), _ptr(pr)))
+        ints = lambda a: sum(int(a[k]) << (64 * k) for k in range(4))
+        return ints(ev), (ints(pr[:4]), ints(pr[4:]))
+
     # ---- probes
     def field_op(self, field, op, a, b=None):
         a = _u64(a)
@@ -597,6 +607,15 @@ class CycleFoldIVC:
         lib.vimz_cf_state_chain.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         self.ctx._chk(lib.vimz_cf_state_chain(self.h, _ptr(_zlimbs(z_start, self.circuit.len_z)), _ptr(a), a.shape[0], _ptr(out)))
         return out
+
+    def kzg_open(self, which, z):
+        """vimz_cf_kzg_open: (eval, proof point) of the running main instance's comm_W (which = 0) or comm_E (1) at z."""
+        lib = self.ctx.lib
+        lib.vimz_cf_kzg_open.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        ev, pr = np.zeros(4, dtype=np.uint64), np.zeros(8, dtype=np.uint64)
+        self.ctx._chk(lib.vimz_cf_kzg_open(self.h, which, _ptr(_zlimbs([z], 1)), _ptr(ev), _ptr(pr)))
+        ints = lambda a: sum(int(a[k]) << (64 * k) for k in range(4))
+        return ints(ev), (ints(pr[:4]), ints(pr[4:]))
 
     def proof_export(self):
         """The proof (and resume state) as bytes: vimz_cf_proof_export."""
