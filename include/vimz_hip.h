@@ -382,6 +382,10 @@ int64_t vimz_cf_merged_records(const vimz_cf_merged* m, void* buf, size_t cap);
 int64_t vimz_cf_merged_export(vimz_cf_merged* m, int side, int what, void* buf, size_t cap);
 /* IVC state chain only (as vimz_ivc_state_chain): the state at which a row segment proven by another vimz_cf starts */
 int vimz_cf_state_chain(vimz_cf* v, const uint64_t* z_start, const uint64_t* step_inputs, size_t nsteps, uint64_t* zs_out);
+/* ... in its two parts, as vimz_ivc_row_digests / vimz_ivc_chain_from_digests */
+size_t vimz_cf_digest_stride(const vimz_cf* v);
+int vimz_cf_row_digests(vimz_cf* v, const uint64_t* step_inputs, size_t nsteps, uint64_t* digests_out);
+int vimz_cf_chain_from_digests(vimz_cf* v, const uint64_t* z_start, const uint64_t* step_inputs, const uint64_t* digests, size_t nsteps, uint64_t* zs_out);
 /* test hooks.  poke: overwrite one element (canonical) of a witness vector on the device — which = 0 running main Z, 1 last fresh main Z,
  * 2 running CycleFold Z, 3 running main E, 4 running CycleFold E.  selfcheck: host only, no GPU — `steps` steps over the trivial step
  * circuit with made-up commitments, every witness checked against its R1CS and every in-circuit fold against field / curve arithmetic

@@ -73,14 +73,13 @@ def main():
         spans["Prepare folding"] = time.time() - t0
         t0 = time.time()
         rows_a = np.stack(rows)
-        segs = ivc_segments(cfs, rows_a, z0)
-        t_chain = time.time() - t0
-        for v, r, z in segs:
-            v.reset(z)
-        fold_concurrently([(v, r) for v, r, z in segs])
-        t1 = time.time()
-        proof = hip.CycleFoldMerged.of(cfs) if S > 1 else cfs[0]
-        t_merge = time.time() - t1
+        tm = {}
+        if S > 1:      # segments' start states staggered under the folds (row digests of all but the last segment at once), then the merge
+            proof = fold_segments_merged(cfs, rows_a, z0, tm, merged_cls=hip.CycleFoldMerged)
+        else:
+            cfs[0].reset(z0); cfs[0].fold(rows_a)
+            proof = cfs[0]
+        t_chain, t_merge = tm.get("state_chain_s", 0.0), tm.get("merge_s", 0.0)
         spans["Fold input"] = time.time() - t0
         t0 = time.time()
         ok = proof.verify(len(rows), z0) == 0

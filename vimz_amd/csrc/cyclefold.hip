@@ -1132,6 +1132,16 @@ int vimz_cf_state_chain(vimz_cf* v, const uint64_t* z_start, const uint64_t* ste
   if (!v) return VIMZ_ERR_INVALID;
   return vimz_prover_state_chain(v->pri, z_start, step_inputs, nsteps, zs_out);
 }
+/* the same in its two parts (see vimz_prover_row_digests): the row digests of any run of rows on any prover's GPU, then the serial host chain */
+size_t vimz_cf_digest_stride(const vimz_cf* v) { return v ? vimz_prover_digest_stride(v->pri) : 0; }
+int vimz_cf_row_digests(vimz_cf* v, const uint64_t* step_inputs, size_t nsteps, uint64_t* digests_out) {
+  if (!v) return VIMZ_ERR_INVALID;
+  return vimz_prover_row_digests(v->pri, step_inputs, nsteps, digests_out);
+}
+int vimz_cf_chain_from_digests(vimz_cf* v, const uint64_t* z_start, const uint64_t* step_inputs, const uint64_t* digests, size_t nsteps, uint64_t* zs_out) {
+  if (!v) return VIMZ_ERR_INVALID;
+  return vimz_prover_chain_from_digests(v->pri, z_start, step_inputs, digests, nsteps, zs_out);
+}
 
 // KZG openings of the running main instance's two commitments (what Sonobe's decider adds to the proof for the on-chain verifier, decider.rs:13-21;
 // calldata words kzg_*): with ck_main = the SRS's G1 powers, comm_W commits to the polynomial whose coefficients are the witness wires

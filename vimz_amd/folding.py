@@ -165,11 +165,8 @@ def fold_input(params, ivc_step_inputs, initial_state, max_batch=None, prover=No
         ck2 = params.secondary_key()
         cfs = [CycleFoldIVC(c, params.circuit, params.ck, ck2, max_batch=max_batch) for c in ctxs]
         try:
-            segs = ivc_segments(cfs, ivc_step_inputs, initial_state)
-            for v, rows, z in segs:
-                v.reset(z)
-            fold_concurrently([(v, rows) for v, rows, z in segs])
-            merged = CycleFoldMerged.of(cfs)
+            from .distributed import fold_segments_merged
+            merged = fold_segments_merged(cfs, ivc_step_inputs, initial_state, None, merged_cls=CycleFoldMerged)      # (start states staggered under the folds)
         except Exception:
             for o in cfs + ctxs[1:]:
                 o.close()

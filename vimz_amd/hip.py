@@ -617,6 +617,29 @@ class CycleFoldIVC:
         ints = lambda a: sum(int(a[k]) << (64 * k) for k in range(4))
         return ints(ev), (ints(pr[:4]), ints(pr[4:]))
 
+    def digest_stride(self):
+        lib = self.ctx.lib
+        lib.vimz_cf_digest_stride.argtypes = [C.c_void_p]
+        lib.vimz_cf_digest_stride.restype = C.c_size_t
+        return int(lib.vimz_cf_digest_stride(self.h))
+
+    def row_digests(self, inputs):
+        a = _u64(inputs).reshape(-1, self.circuit.n_priv, 4)
+        out = np.zeros((a.shape[0], self.digest_stride(), 4), dtype=np.uint64)
+        lib = self.ctx.lib
+        lib.vimz_cf_row_digests.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        self.ctx._chk(lib.vimz_cf_row_digests(self.h, _ptr(a), a.shape[0], _ptr(out)))
+        return out
+
+    def chain_from_digests(self, z_start, inputs, digests):
+        a = _u64(inputs).reshape(-1, self.circuit.n_priv, 4)
+        d = np.ascontiguousarray(digests, dtype=np.uint64).reshape(a.shape[0], -1, 4)
+        out = np.zeros((a.shape[0] + 1, self.circuit.len_z, 4), dtype=np.uint64)
+        lib = self.ctx.lib
+        lib.vimz_cf_chain_from_digests.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        self.ctx._chk(lib.vimz_cf_chain_from_digests(self.h, _ptr(_zlimbs(z_start, self.circuit.len_z)), _ptr(a), _ptr(d), a.shape[0], _ptr(out)))
+        return out
+
     def proof_export(self):
         """The proof (and resume state) as bytes: vimz_cf_proof_export."""
         lib = self.ctx.lib
