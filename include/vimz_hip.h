@@ -368,6 +368,14 @@ int vimz_cf_merged_create(vimz_cf* first, vimz_cf_merged** out);
 void vimz_cf_merged_free(vimz_cf_merged* m);
 /* fold the proof of the NEXT row segment in (same device; read in place, left unchanged): it must start at the state m ends in */
 int vimz_cf_merge(vimz_cf_merged* m, vimz_cf* next_segment);
+/* fold another merged object — ONE run of segments, e.g. what another GPU made of its rows (north_star's sharding) — in, as a whole: two relaxed
+ * accumulators on each side.  It must start at the state m ends in; read in place, left unchanged; afterwards m takes no more single segments. */
+int vimz_cf_merge_merged(vimz_cf_merged* m, vimz_cf_merged* other);
+/* the object as bytes (records + the folded witnesses and running products), and back — into the context of `vk`, any vimz_cf for the same step
+ * circuit and keys; untrusted input: ranges, curve membership, the accumulator recomputed from the records */
+size_t vimz_cf_merged_size(const vimz_cf_merged* m);
+int vimz_cf_merged_save(vimz_cf_merged* m, uint8_t* blob, size_t cap);
+int vimz_cf_merged_load(vimz_cf* vk, const uint8_t* blob, size_t len, vimz_cf_merged** out);
 /* result: 0 = accepted; bit 0 / 1 a segment's main / CycleFold hash; bit 2 / 3 / 4 main relaxed relation / comm_W / comm_E; bit 5 / 6 / 7 the
  * same of the CycleFold instance; bit 10 instance scalars differ from the vectors; bit 12 statement (step count, initial state, adjacency);
  * bit 13 the stored folded instances differ from the replay of the records */

@@ -101,14 +101,16 @@ def cyclefold_relation(orc, x):
 
 
 # ---- merged proofs (vimz_cf_merge): replay of the segment records with hashlib, Python integers and the oracle's curve arithmetic -------------
-MERGED_MAGIC = 0x31474d46435a56
+MERGED_MAGIC = 0x32474d46435a56
 
 
 def parse_merged_records(words, len_z):
     w = [int(x) for x in words]
-    magic, S, lz, nw1, nc1, nw2, nc2, _ = w[:8]
-    assert magic == MERGED_MAGIC and lz == len_z
-    pos = 8
+    magic, S, lz, nw1, nc1, nw2, nc2, R = w[:8]
+    assert magic == MERGED_MAGIC and lz == len_z and 1 <= R <= S
+    run_start = w[8:8 + R]
+    assert run_start[0] == 0 and all(a < b for a, b in zip(run_start, run_start[1:])) and run_start[-1] < S
+    pos = 8 + R
 
     def el():
         nonlocal pos
@@ -126,8 +128,9 @@ def parse_merged_records(words, len_z):
         s["cfU"] = [el() for _ in range(5 + CF_IO)]
         s["T1"], s["T2"], s["Tc"] = (el(), el()), (el(), el()), (el(), el())
         segs.append(s)
+    junctions = [((el(), el()), (el(), el())) for _ in range(R - 1)]
     assert pos == len(w)
-    return {"shape": (nw1, nc1, nw2, nc2), "segs": segs}
+    return {"shape": (nw1, nc1, nw2, nc2), "segs": segs, "run_start": run_start, "junctions": junctions}
 
 
 def _b32(x):
@@ -142,9 +145,34 @@ def replay_merged(orc, rec, dg, len_z):
     pr, pq = orc.modulus[0], orc.modulus[1]
     axpy = lambda cid, a, r, b: orc.curve_add(cid, a, orc.curve_mul(cid, b, r))
     failed = []
+    runs = rec.get("run_start", [0])
+    bounds = list(zip(runs, runs[1:] + [len(rec["segs"])]))
+    total = None
+    for k, (lo, hi) in enumerate(bounds):
+        f, acc = _replay_run(orc, rec["segs"][lo:hi], dg, len_z, sha, chal, axpy, pr, pq, lo)
+        failed += f
+        if total is None:
+            total = acc
+            continue
+        Tp, Tq = rec["junctions"][k - 1]
+        if total["ze"] != acc["zs"]: failed.append(f"run {k}: not adjacent")
+        h = sha(b"vimz-cf-merge-node-v1" + total["h"] + acc["h"] + _b32(Tp[0]) + _b32(Tp[1]) + _b32(Tq[0]) + _b32(Tq[1]))
+        rp, rq = chal(h, b"p", b""), chal(h, b"q", b"")
+        P, Q, Pb, Qb = total["P"], total["Q"], acc["P"], acc["Q"]
+        P[0] = axpy(0, P[0], rp, Pb[0]); P[1] = axpy(0, P[1], rp, axpy(0, Tp, rp, Pb[1]))
+        P[2], P[3], P[4] = (P[2] + rp * Pb[2]) % pr, (P[3] + rp * Pb[3]) % pr, (P[4] + rp * Pb[4]) % pr
+        Q[0] = axpy(1, Q[0], rq, Qb[0]); Q[1] = axpy(1, Q[1], rq, axpy(1, Tq, rq, Qb[1]))
+        Q[2] = (Q[2] + rq * Qb[2]) % pq
+        Q[3] = [(a + rq * b) % pq for a, b in zip(Q[3], Qb[3])]
+        total["n"] += acc["n"]; total["ze"] = acc["ze"]; total["h"] = h
+    return failed, total
+
+
+def _replay_run(orc, segs, dg, len_z, sha, chal, axpy, pr, pq, first_index):
+    failed = []
     h_prev = sha(b"vimz-cf-merge-v1" + _b32(dg) + len_z.to_bytes(8, "little"))
     acc = None
-    for j, s in enumerate(rec["segs"]):
+    for j, s in enumerate(segs, start=first_index):
         U, u, cfU = s["U"], s["u"], s["cfU"]
         if s["n"] == 0: failed.append(f"segment {j}: empty")
         if hash_main(orc, dg, s["n"], s["zs"], s["ze"], U) != u[2]: failed.append(f"segment {j}: hash of the main running instance")
@@ -172,6 +200,7 @@ def replay_merged(orc, rec, dg, len_z):
         P[2], P[3], P[4] = (P[2] + r2) % pr, (P[3] + r2 * u[2]) % pr, (P[4] + r2 * u[3]) % pr
         acc["n"] += s["n"]
         acc["ze"] = s["ze"]
+        acc["h"] = h_prev
     return failed, acc
 
 

@@ -340,6 +340,62 @@ def _gpu_sharded_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _gpu_sharded_cyclefold_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["LOCAL_WORLD_SIZE"] = str(world)
+    import torch.distributed as dist
+    from tests.test_circuits import step_inputs
+    from vimz_amd import _lib, hip
+    from vimz_amd.circuit import Circuit
+    from vimz_amd.distributed import prove_sharded
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ctxs = [hip.Context(0), hip.Context(0)]
+    c = Circuit.for_resolution("hash", "HD")
+    ck1 = ctxs[0].bases_generate(_lib.CURVE_BN254_G1, 1 << 16)
+    ck2 = ctxs[0].bases_generate(_lib.CURVE_GRUMPKIN, 1 << 13, b"ck-cyclefold")
+    z0, inputs = step_inputs("hash")
+    rows = np.stack(inputs[:9])
+    cfs = [hip.CycleFoldIVC(cx, c, ck1, ck2, max_batch=2) for cx in ctxs]
+    proof = prove_sharded(cfs, rows, z0, rank, world, dist, merged_cls=hip.CycleFoldMerged, shm_prefix=f"/tmp/vimz_test_cf_{port}_")
+    if rank == 0:
+        q.put((proof.verify(9, z0), proof.verify(8, z0), proof.state(), proof.info()["segments"]))
+        proof.close()
+    dist.barrier()
+    for v in cfs:
+        v.close()
+    ck1.free(); ck2.free()
+    for cx in ctxs:
+        cx.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_the_gpu_end_in_one_verified_cyclefold_proof_object(oracle):
+    """The same sharding for the Sonobe backend's scheme: 2 ranks x 2 CycleFold segments -> two merged objects (one run each) -> rank 0's
+    final fold (vimz_cf_merge_merged) -> ONE object that verifies for (9 steps, z0) and for nothing else."""
+    import torch.multiprocessing as mp
+    from tests._oracle import T_HASH
+    from tests.test_circuits import step_inputs
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gpu_sharded_cyclefold_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    ok9, ok8, state, segments = q.get(timeout=900)
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    z0, inputs = step_inputs("hash")
+    z = list(z0)
+    for i in range(9):
+        ok, z = oracle.step_eval(T_HASH, z, inputs[i])
+    assert ok9 == 0 and ok8 != 0 and segments == 4
+    assert state == ([int(x) for x in z0], z, 9)
+
+
 @pytest.mark.gpu
 def test_two_ranks_on_the_gpu_end_in_one_verified_proof_object(oracle):
     """world_size 2 over gloo with the GPU provers (both ranks share the one GPU of the box): 2 x 2 IVC segments -> two merged proofs

@@ -290,3 +290,62 @@ def test_kzg_openings_of_a_cyclefold_proof_over_an_srs(ctx, oracle):
                 assert lhs == rhs, (which, z)
     finally:
         cf.close(); B.free(); ck2.free()
+
+
+def test_merged_cyclefold_runs_save_load_and_fold_into_one_object(ctx, keys, oracle):
+    """Two merged objects — one run of segments each, as two GPUs of a sharded proof would make them — travel as bytes, are loaded into
+    another prover's context and folded into ONE object (vimz_cf_merge_merged): product verifier and oracle-side replay accept it for
+    (all rows, z0) only; runs in the wrong order and tampered blobs are refused."""
+    from vimz_amd import hip
+    ck1, ck2 = keys
+    c = Circuit.for_resolution("contrast", "HD")
+    z0, inputs = step_inputs("contrast")
+    steps = np.stack(inputs)
+    ctxs = [ctx, hip.Context(0), hip.Context(0)]
+    cfs = [hip.CycleFoldIVC(cx, c, ck1, ck2, max_batch=4) for cx in ctxs]
+    objs = []
+    try:
+        bounds = [(0, 3), (3, 6), (6, 10)]
+        z = list(z0)
+        for v, (lo, hi) in zip(cfs, bounds):
+            v.reset(z); v.fold(steps[lo:hi])
+            z = v.state()[0]
+        a = hip.CycleFoldMerged.of(cfs[:2]); objs.append(a)          # run A: segments 0, 1
+        b = hip.CycleFoldMerged(cfs[2]); objs.append(b)             # run B: segment 2
+        blob_a, blob_b = a.save(), b.save()
+        # loaded elsewhere (here: the third prover's context supplies shapes and keys)
+        la = hip.CycleFoldMerged.load(cfs[2], blob_a); objs.append(la)
+        lb = hip.CycleFoldMerged.load(cfs[2], blob_b); objs.append(lb)
+        assert la.verify(6, z0) == 0 and la.state()[2] == 6
+        with pytest.raises(_lib.VimzError):
+            lb.merge(la)                                             # wrong order: B does not end where A starts
+        la.merge(lb)
+        assert la.info()["segments"] == 3 and la.verify(10, z0) == 0 and la.verify(9, z0) & 4096
+        assert la.state() == (list(z0), z, 10)
+        failed, acc = cfo.verify_merged(oracle, la, cfs[2], ck1, ck2, 10, z0, check_commitments=False)
+        assert failed == []
+        with pytest.raises(_lib.VimzError):
+            la.merge(cfs[0])                                         # an object of several runs takes no more single segments
+        # the whole thing once more through bytes
+        again = hip.CycleFoldMerged.load(cfs[0], la.save()); objs.append(again)
+        assert again.verify(10, z0) == 0
+        # refused or rejected: truncated, an element above the modulus, a changed statement word
+        for bad in (blob_a[:4096], ):
+            with pytest.raises(_lib.VimzError):
+                hip.CycleFoldMerged.load(cfs[2], bad)
+        t = blob_a.copy(); t[-32:] = 0xFF
+        with pytest.raises(_lib.VimzError):
+            hip.CycleFoldMerged.load(cfs[2], t)
+        t = blob_a.copy(); t[8 * (8 + 1)] ^= 1                       # n of the first segment
+        try:
+            x = hip.CycleFoldMerged.load(cfs[2], t); objs.append(x)
+            assert x.verify(6, z0) != 0 and x.verify(7, z0) != 0
+        except _lib.VimzError:
+            pass
+    finally:
+        for o in objs:
+            o.close()
+        for v in cfs:
+            v.close()
+        for cx in ctxs[1:]:
+            cx.close()

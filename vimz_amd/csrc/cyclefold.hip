@@ -754,12 +754,21 @@ int vimz_cf_proof_import(vimz_cf* v, const uint8_t* blob, size_t len) {
 // little-endian integer —; h_j = SHA3(h ‖ 'n' ‖ T1 ‖ T2 ‖ Tc).  The verifier replays the records (for every segment: the two hashes its
 // last instance carries, recomputed from (n_j, z_start_j, z_end_j); z_end_{j-1} = z_start_j; the folds of the instances), obtains
 // (n = Σ n_j, z_start_1, z_end_S, acc, cfacc) and checks ONE main and ONE CycleFold relaxed instance against their witnesses.
+// Several such objects — one RUN of segments each, e.g. one per GPU — are folded left to right (vimz_cf_merge_merged): Node(A, B) requires
+// A.z_end = B.z_start;  h = SHA3("vimz-cf-merge-node-v1" ‖ A.h ‖ B.h ‖ T_p ‖ T_q), r_p = chal(h ‖ 'p'), r_q = chal(h ‖ 'q');  both pairs of
+// relaxed accumulators fold with E += r·T + r²·E_B.  The verifier recomputes every run's accumulator from its records on its own.
 // Ours, like the circuits.
 struct CfSegRec { uint64_t n = 0; std::vector<Fe> zs, ze; CfMainRelaxed U; G1Aff UW, UE; CfMainFresh u; G1Aff uW; CfRelaxed cfU; G1Aff T1, T2; G2Aff Tc; };
 struct CfAcc { uint8_t h[32] = {}; uint64_t n = 0; std::vector<Fe> zs, ze; G1Aff cW, cE; Fe u, x0, x1; G2Aff qW, qE; Fq qu; Fq qx[CF_IO]; };
+struct CfJunction { G1Aff Tp; G2Aff Tq; };
 struct vimz_cf_merged {
   vimz_cf* vk = nullptr;                  // shapes, keys, context: must outlive this object
   std::vector<CfSegRec> segs;
+  // RUNS: segs[run_start[k] .. run_start[k+1]) were folded in row order by vimz_cf_merge on one GPU (one run per GPU of a sharded proof);
+  // run k > 0 was folded into the runs before it as a whole (vimz_cf_merge_merged: two relaxed accumulators), junction k-1 holds that fold's
+  // two cross-term commitments
+  std::vector<uint32_t> run_start{0};
+  std::vector<CfJunction> junctions;
   CfAcc acc;
   uint32_t* dev = nullptr;                // one allocation
   uint32_t *Zp = nullptr, *Ep = nullptr, *AZp = nullptr, *BZp = nullptr, *CZp = nullptr, *Tp = nullptr;
@@ -769,7 +778,7 @@ struct vimz_cf_merged {
 };
 
 namespace {
-const uint64_t CF_MERGED_MAGIC = 0x31474d46435a56ull;      // "VZCFMG1"
+const uint64_t CF_MERGED_MAGIC = 0x32474d46435a56ull;      // "VZCFMG2"
 template <class F> void cfm_fe(Sha3& h, const F& m) { const F c = F::from_mont(m); h.update(c.v, 32); }
 template <class F> void cfm_pt(Sha3& h, const Affine<F>& p) { cfm_fe(h, p.x); cfm_fe(h, p.y); }
 void cfm_chal(const uint8_t h[32], char tag, const uint8_t* extra, size_t n, uint32_t out[4]) {
@@ -852,6 +861,40 @@ void cfm_absorb(const vimz_cf* vk, CfAcc& acc, const CfSegRec& s, bool first, ui
   acc.u = Fe::add(acc.u, r2); acc.x0 = Fe::add(acc.x0, Fe::mul(r2, s.u.x0)); acc.x1 = Fe::add(acc.x1, Fe::mul(r2, s.u.x1));
   acc.n += s.n; acc.ze = s.ze;
 }
+// Node(A, B): the statement-side fold of two runs' accumulators (flags bit 2: not adjacent); A becomes the result
+void cfm_node(CfAcc& A, const CfAcc& B, const CfJunction& J, uint32_t* flags, uint32_t rp_out[4], uint32_t rq_out[4]) {
+  if (A.ze.size() != B.zs.size()) *flags |= 4;
+  else for (size_t k = 0; k < B.zs.size(); k++) if (!A.ze[k].eq(B.zs[k])) *flags |= 4;
+  Sha3 hh; const char* tag = "vimz-cf-merge-node-v1"; hh.update(tag, strlen(tag)); hh.update(A.h, 32); hh.update(B.h, 32);
+  cfm_pt(hh, J.Tp); cfm_pt(hh, J.Tq);
+  uint8_t h[32]; hh.finish(h);
+  uint32_t rp[4], rq[4];
+  cfm_chal(h, 'p', nullptr, 0, rp); cfm_chal(h, 'q', nullptr, 0, rq);
+  if (rp_out) memcpy(rp_out, rp, 16);
+  if (rq_out) memcpy(rq_out, rq, 16);
+  const Fe rpf = cfm_fe128<Fe>(rp); const Fq rqf = cfm_fe128<Fq>(rq);
+  A.cW = cfm_axpy(A.cW, rp, B.cW);
+  A.cE = cfm_axpy(A.cE, rp, cfm_axpy(J.Tp, rp, B.cE));
+  A.u = Fe::add(A.u, Fe::mul(rpf, B.u)); A.x0 = Fe::add(A.x0, Fe::mul(rpf, B.x0)); A.x1 = Fe::add(A.x1, Fe::mul(rpf, B.x1));
+  A.qW = cfm_axpy(A.qW, rq, B.qW);
+  A.qE = cfm_axpy(A.qE, rq, cfm_axpy(J.Tq, rq, B.qE));
+  A.qu = Fq::add(A.qu, Fq::mul(rqf, B.qu));
+  for (int k = 0; k < CF_IO; k++) A.qx[k] = Fq::add(A.qx[k], Fq::mul(rqf, B.qx[k]));
+  A.n += B.n; A.ze = B.ze;
+  memcpy(A.h, h, 32);
+}
+// the whole statement side: every run from its records, the runs folded left to right
+bool cfm_replay(const vimz_cf* vk, const std::vector<CfSegRec>& segs, const std::vector<uint32_t>& run_start, const std::vector<CfJunction>& junctions, CfAcc& out, uint32_t* flags) {
+  if (segs.empty() || run_start.empty() || run_start[0] != 0 || junctions.size() + 1 != run_start.size()) return false;
+  for (size_t k = 0; k < run_start.size(); k++) {
+    const size_t lo = run_start[k], hi = k + 1 < run_start.size() ? run_start[k + 1] : segs.size();
+    if (hi <= lo || hi > segs.size()) return false;
+    CfAcc a;
+    for (size_t j = lo; j < hi; j++) cfm_absorb(vk, a, segs[j], j == lo, flags, nullptr);
+    if (k == 0) out = a; else cfm_node(out, a, junctions[k - 1], flags, nullptr, nullptr);
+  }
+  return true;
+}
 CfSegRec cfm_record_of(const vimz_cf* v) {
   CfSegRec s; s.n = v->i; s.zs = v->z0; s.ze = v->pri->z_cur;
   s.U = v->U; s.UW = v->UW; s.UE = v->UE; s.u = v->u; s.uW = v->uW; s.cfU = v->cfU;
@@ -882,6 +925,7 @@ int cfm_merge_locked(vimz_cf_merged* m, vimz_cf* next) {
   const SecDev& Sn = next->sec;
   const bool first = m->segs.empty();
   const double t_all = now_s();
+  if (m->run_start.size() > 1) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_cf_merge: this object already holds several runs (vimz_cf_merge_merged): segments are folded into a single run");
   if (next->i == 0) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_cf_merge: the segment has no steps");
   if (next->broken) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_cf_merge: the segment's IVC failed in the middle of a step");
   if (!first) { for (uint32_t k = 0; k < p->len_z; k++) if (!m->acc.ze[k].eq(next->z0[k])) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_cf_merge: the segment does not start at the state the merged proof ends in"); }
@@ -1004,6 +1048,145 @@ int vimz_cf_merge(vimz_cf_merged* m, vimz_cf* next) {
   P_TRY(hipSetDevice(ctx->device));
   return cfm_merge_locked(m, next);
 }
+// fold another merged object — ONE run, e.g. what another GPU made of its rows — in: it must start at the state m ends in.  `other` is read in
+// place and left unchanged (same device).
+int vimz_cf_merge_merged(vimz_cf_merged* m, vimz_cf_merged* other) {
+  if (!m || !other || m == other || !m->vk || !other->vk) return VIMZ_ERR_INVALID;
+  vimz_cf* vk = m->vk; vimz_ctx* ctx = vk->ctx;
+  if (m->broken || other->broken) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_cf_merge_merged: one of the objects failed in the middle of a merge");
+  if (!cfm_same_shapes(vk, other->vk)) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_cf_merge_merged: the objects are about different circuits, keys or devices");
+  if (other->run_start.size() != 1 || m->segs.empty() || other->segs.empty()) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_cf_merge_merged: the object to fold in must hold exactly one run");
+  std::mutex* a = &ctx->mu; std::mutex* b = &other->vk->ctx->mu;
+  std::unique_lock<std::mutex> l1, l2;
+  if (a == b) l1 = std::unique_lock<std::mutex>(*a);
+  else { if (b < a) std::swap(a, b); l1 = std::unique_lock<std::mutex>(*a); l2 = std::unique_lock<std::mutex>(*b); }
+  P_TRY(hipSetDevice(ctx->device));
+  for (size_t k = 0; k < m->acc.ze.size(); k++) if (!m->acc.ze[k].eq(other->acc.zs[k])) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_cf_merge_merged: the object does not start at the state this one ends in");
+  hipStream_t s = ctx->stream;
+  vimz_prover* p = vk->pri; const size_t nw = p->n_wires, nc = p->n_c, nw2 = vk->sec.n_w, nc2 = vk->sec.n_c;
+  P_TRY(hipStreamSynchronize(other->vk->ctx->stream));
+  const double t0 = now_s();
+  CfJunction J; uint64_t pt[8]; int rc;
+  hipLaunchKernelGGL(k_cross_term<Fr>, dim3(stream_grid(nc)), dim3(256), 0, s, nc, m->AZp, m->BZp, m->CZp, m->acc.u, other->AZp, other->BZp, other->CZp, other->acc.u, m->Tp);
+  P_TRY(hipGetLastError());
+  if ((rc = vz_msm_device(ctx, p->ck, 0, m->Tp, nc, 1, 0, pt, VIMZ_FORM_MONTGOMERY))) return rc;
+  memcpy(J.Tp.x.v, pt, 32); memcpy(J.Tp.y.v, pt + 4, 32);
+  hipLaunchKernelGGL(k_cross_term<Fq>, dim3(stream_grid(nc2)), dim3(256), 0, s, nc2, m->AZq, m->BZq, m->CZq, m->acc.qu, other->AZq, other->BZq, other->CZq, other->acc.qu, m->Tq);
+  P_TRY(hipGetLastError());
+  if ((rc = vz_msm_device(ctx, vk->ck2, 0, m->Tq, nc2, 1, 0, pt, VIMZ_FORM_MONTGOMERY))) return rc;
+  memcpy(J.Tq.x.v, pt, 32); memcpy(J.Tq.y.v, pt + 4, 32);
+  m->seconds[0] += now_s() - t0;
+  const double t1 = now_s();
+  CfAcc A = m->acc; uint32_t fl = 0, rp[4], rq[4];
+  cfm_node(A, other->acc, J, &fl, rp, rq);
+  if (fl) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_cf_merge_merged: the objects are not adjacent");
+  struct Poison { vimz_cf_merged* m; bool armed = true; ~Poison() { if (armed) m->broken = true; } } poison{m};
+  cfm_fold<Fr>(s, m->Zp, m->Ep, m->AZp, m->BZp, m->CZp, nw, nc, other->Zp, m->Tp, other->AZp, other->BZp, other->CZp, other->Ep, cfm_fe128<Fe>(rp));
+  cfm_fold<Fq>(s, m->Zq, m->Eq, m->AZq, m->BZq, m->CZq, nw2, nc2, other->Zq, m->Tq, other->AZq, other->BZq, other->CZq, other->Eq, cfm_fe128<Fq>(rq));
+  P_TRY(hipGetLastError());
+  P_TRY(hipStreamSynchronize(s));
+  m->run_start.push_back((uint32_t)m->segs.size());
+  m->segs.insert(m->segs.end(), other->segs.begin(), other->segs.end());
+  m->junctions.push_back(J);
+  m->acc = A;
+  poison.armed = false;
+  m->seconds[1] += now_s() - t1; m->seconds[3] += now_s() - t0;
+  return VIMZ_OK;
+}
+
+// The object as bytes (a GPU's run on its way to the rank that folds the runs; a proof on disk): the records, then the folded witnesses and
+// running products of both sides as they sit in HBM.  load: into the context of `vk` (a vimz_cf for the same step circuit and keys); every
+// element range-checked, every point checked to be on its curve, the accumulator recomputed from the records.
+size_t vimz_cf_merged_size(const vimz_cf_merged* m) {
+  if (!m || !m->vk) return 0;
+  const size_t nw = m->vk->pri->n_wires, nc = m->vk->pri->n_c, nw2 = m->vk->sec.n_w, nc2 = m->vk->sec.n_c;
+  return (size_t)vimz_cf_merged_records(m, nullptr, 0) + 32 * (nw + 4 * nc + nw2 + 4 * nc2);
+}
+int vimz_cf_merged_save(vimz_cf_merged* m, uint8_t* blob, size_t cap) {
+  if (!m || !m->vk || !blob) return VIMZ_ERR_INVALID;
+  vimz_ctx* ctx = m->vk->ctx;
+  if (m->broken) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_cf_merged_save: this object failed in the middle of a merge");
+  if (cap < vimz_cf_merged_size(m)) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_cf_merged_save: buffer too small");
+  const int64_t rb = vimz_cf_merged_records(m, blob, cap);
+  if (rb < 0) return (int)rb;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  P_TRY(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  const size_t nw = m->vk->pri->n_wires, nc = m->vk->pri->n_c, nw2 = m->vk->sec.n_w, nc2 = m->vk->sec.n_c;
+  const uint32_t* src[] = {m->Zp, m->Ep, m->AZp, m->BZp, m->CZp, m->Zq, m->Eq, m->AZq, m->BZq, m->CZq};
+  const size_t len[] = {nw, nc, nc, nc, nc, nw2, nc2, nc2, nc2, nc2};
+  uint8_t* o = blob + rb;
+  for (int k = 0; k < 10; k++) { P_TRY(hipMemcpyAsync(o, src[k], 32 * len[k], hipMemcpyDeviceToHost, s)); o += 32 * len[k]; }
+  P_TRY(hipStreamSynchronize(s));
+  return VIMZ_OK;
+}
+int vimz_cf_merged_load(vimz_cf* vk, const uint8_t* blob, size_t len, vimz_cf_merged** out) {
+  if (!vk || !blob || !out || len < 64) return VIMZ_ERR_INVALID;
+  vimz_ctx* ctx = vk->ctx; vimz_prover* p = vk->pri;
+  const size_t lz = p->len_z, nw = p->n_wires, nc = p->n_c, nw2 = vk->sec.n_w, nc2 = vk->sec.n_c;
+  const uint64_t* w = reinterpret_cast<const uint64_t*>(blob);      // (blobs come from numpy / malloc: 8-byte aligned)
+  if ((uintptr_t)blob % 8) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_cf_merged_load: blob not 8-byte aligned");
+  const uint64_t S = w[1], R = w[7];
+  if (w[0] != CF_MERGED_MAGIC || w[2] != lz || w[3] != nw || w[4] != nc || w[5] != nw2 || w[6] != nc2 || S == 0 || S > 4096 || R == 0 || R > S)
+    return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_cf_merged_load: the blob does not match this prover's circuits");
+  const size_t seg_words = 1 + 4 * (2 * lz + 7 + 4 + 5 + CF_IO + 6);
+  const size_t rec_words = 8 + R + S * seg_words + (R - 1) * 16;
+  if (len < 8 * rec_words + 32 * (nw + 4 * nc + nw2 + 4 * nc2)) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_cf_merged_load: blob too short");
+  std::unique_ptr<vimz_cf_merged> m(new vimz_cf_merged());
+  m->vk = vk;
+  m->run_start.clear();
+  size_t pos = 8;
+  for (uint64_t k = 0; k < R; k++) { if (w[pos] >= S || (k && w[pos] <= m->run_start.back())) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_cf_merged_load: malformed runs"); m->run_start.push_back((uint32_t)w[pos++]); }
+  if (m->run_start[0] != 0) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_cf_merged_load: malformed runs");
+  bool ok = true;
+  auto fe = [&](auto* dst) { typedef std::decay_t<decltype(*dst)> F; F c; memcpy(c.v, w + pos, 32); pos += 4; if (!c.is_reduced()) ok = false; *dst = F::to_mont(c); };
+  auto u256 = [&](U256w* dst) { memcpy(dst->w, w + pos, 32); pos += 4; Fq c; memcpy(c.v, dst->w, 32); if (!c.is_reduced()) ok = false; };
+  auto g1 = [&](G1Aff* P) { fe(&P->x); fe(&P->y); if (ok && !aff_on_curve(*P)) ok = false; };
+  auto g2 = [&](G2Aff* P) { fe(&P->x); fe(&P->y); if (ok && !aff_on_curve(*P)) ok = false; };
+  m->segs.assign(S, CfSegRec());
+  for (auto& sg : m->segs) {
+    sg.n = w[pos++];
+    sg.zs.resize(lz); sg.ze.resize(lz);
+    for (auto& z : sg.zs) fe(&z);
+    for (auto& z : sg.ze) fe(&z);
+    g1(&sg.UW); g1(&sg.UE); fe(&sg.U.u); fe(&sg.U.x0); fe(&sg.U.x1); sg.U.W = nn_point(sg.UW); sg.U.E = nn_point(sg.UE);
+    g1(&sg.uW); fe(&sg.u.x0); fe(&sg.u.x1); sg.u.W = nn_point(sg.uW);
+    g2(&sg.cfU.W); g2(&sg.cfU.E); fe(&sg.cfU.u); for (auto& e : sg.cfU.x) u256(&e);
+    g1(&sg.T1); g1(&sg.T2); g2(&sg.Tc);
+  }
+  m->junctions.assign(R - 1, CfJunction());
+  for (auto& j : m->junctions) { g1(&j.Tp); g2(&j.Tq); }
+  if (!ok || pos != rec_words) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_cf_merged_load: an element of the records is not below its modulus, or a point is not on its curve");
+  uint32_t fl = 0;
+  if (!cfm_replay(vk, m->segs, m->run_start, m->junctions, m->acc, &fl)) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_cf_merged_load: malformed records");
+  // (hash / adjacency failures of the replay are the verifier's to report: the object loads and vimz_cf_merged_verify rejects it)
+  std::lock_guard<std::mutex> g(ctx->mu);
+  P_TRY(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  P_TRY(hipMalloc((void**)&m->dev, 32 * (nw + 5 * nc + nw2 + 5 * nc2)));
+  uint32_t* q = m->dev;
+  m->Zp = q; q += 8 * nw; m->Ep = q; q += 8 * nc; m->AZp = q; q += 8 * nc; m->BZp = q; q += 8 * nc; m->CZp = q; q += 8 * nc; m->Tp = q; q += 8 * nc;
+  m->Zq = q; q += 8 * nw2; m->Eq = q; q += 8 * nc2; m->AZq = q; q += 8 * nc2; m->BZq = q; q += 8 * nc2; m->CZq = q; q += 8 * nc2; m->Tq = q;
+  uint32_t* dst[] = {m->Zp, m->Ep, m->AZp, m->BZp, m->CZp, m->Zq, m->Eq, m->AZq, m->BZq, m->CZq};
+  const size_t ln[] = {nw, nc, nc, nc, nc, nw2, nc2, nc2, nc2, nc2};
+  const uint8_t* o = blob + 8 * rec_words;
+  uint32_t* badc = m->Tp;      // (scratch until the first merge)
+  hipError_t e = hipMemsetAsync(badc, 0, 8, s);
+  for (int k = 0; k < 10 && e == hipSuccess; k++) {
+    e = hipMemcpyAsync(dst[k], o, 32 * ln[k], hipMemcpyHostToDevice, s); o += 32 * ln[k];
+    if (e != hipSuccess) break;
+    if (k < 5) hipLaunchKernelGGL(k_count_unreduced<Fr>, dim3(stream_grid(ln[k])), dim3(256), 0, s, ln[k], (const uint32_t*)dst[k], badc);
+    else hipLaunchKernelGGL(k_count_unreduced<Fq>, dim3(stream_grid(ln[k])), dim3(256), 0, s, ln[k], (const uint32_t*)dst[k], badc);
+  }
+  uint32_t nbad = 0;
+  if (e == hipSuccess) e = hipMemcpyAsync(&nbad, badc, 4, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (e != hipSuccess || nbad) { hipFree(m->dev); m->dev = nullptr; return e != hipSuccess ? vz_fail(ctx, VIMZ_ERR_HIP, "vimz_cf_merged_load: upload", e) : vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_cf_merged_load: a vector element is not below its modulus"); }
+  vk->merged_dependents.push_back(m.get()); vk->orphan_merged = cfm_orphan_dependents;
+  *out = m.release();
+  return VIMZ_OK;
+}
+
 int vimz_cf_merged_info(const vimz_cf_merged* m, uint64_t info[8]) {
   if (!m || !info || !m->vk) return VIMZ_ERR_INVALID;
   info[0] = m->acc.n; info[1] = m->segs.size(); info[2] = m->vk->pri->len_z; info[3] = m->vk->pri->n_wires; info[4] = m->vk->pri->n_c;
@@ -1022,11 +1205,12 @@ int vimz_cf_merged_profile(const vimz_cf_merged* m, double seconds[4]) {
   return VIMZ_OK;
 }
 // The statement part as canonical little-endian words: header (magic, segments, len_z, main wires, main constraints, CycleFold wires,
-// CycleFold constraints, 0), then per segment: n; z_start; z_end; U = comm_W.x, .y, comm_E.x, .y, u, x0, x1; u = comm_W.x, .y, x0, x1;
-// cfU = comm_W.x, .y, comm_E.x, .y, u, x[0..7); T1.x, .y; T2.x, .y; Tc.x, .y  (every element four words).
+// CycleFold constraints, runs), the first segment of every run, then per segment: n; z_start; z_end; U = comm_W.x, .y, comm_E.x, .y, u, x0, x1; u = comm_W.x, .y, x0, x1;
+// cfU = comm_W.x, .y, comm_E.x, .y, u, x[0..7); T1.x, .y; T2.x, .y; Tc.x, .y  (every element four words); then per junction T_p.x, .y, T_q.x, .y.
 int64_t vimz_cf_merged_records(const vimz_cf_merged* m, void* buf, size_t cap) {
   if (!m || !m->vk) return VIMZ_ERR_INVALID;
-  std::vector<uint64_t> o = {CF_MERGED_MAGIC, m->segs.size(), m->vk->pri->len_z, m->vk->pri->n_wires, m->vk->pri->n_c, m->vk->sec.n_w, m->vk->sec.n_c, 0};
+  std::vector<uint64_t> o = {CF_MERGED_MAGIC, m->segs.size(), m->vk->pri->len_z, m->vk->pri->n_wires, m->vk->pri->n_c, m->vk->sec.n_w, m->vk->sec.n_c, m->run_start.size()};
+  for (uint32_t r0 : m->run_start) o.push_back(r0);
   auto push = [&](const auto& v) { auto x = std::decay_t<decltype(v)>::from_mont(v); o.resize(o.size() + 4); memcpy(o.data() + o.size() - 4, x.v, 32); };
   auto push_u = [&](const U256w& x) { o.insert(o.end(), x.w, x.w + 4); };
   for (auto& s : m->segs) {
@@ -1038,6 +1222,7 @@ int64_t vimz_cf_merged_records(const vimz_cf_merged* m, void* buf, size_t cap) {
     push(s.cfU.W.x); push(s.cfU.W.y); push(s.cfU.E.x); push(s.cfU.E.y); push(s.cfU.u); for (auto& e : s.cfU.x) push_u(e);
     push(s.T1.x); push(s.T1.y); push(s.T2.x); push(s.T2.y); push(s.Tc.x); push(s.Tc.y);
   }
+  for (auto& j : m->junctions) { push(j.Tp.x); push(j.Tp.y); push(j.Tq.x); push(j.Tq.y); }
   const size_t bytes = o.size() * 8;
   if (buf && cap >= bytes) memcpy(buf, o.data(), bytes);
   return (int64_t)bytes;
@@ -1080,7 +1265,7 @@ int vimz_cf_merged_verify(vimz_cf_merged* m, uint64_t num_steps, const uint64_t*
   vimz_cf* vk = m->vk; vimz_ctx* ctx = vk->ctx; vimz_prover* p = vk->pri; SecDev& S = vk->sec;
   uint32_t res = m->broken ? 8192 : 0;
   CfAcc R; uint32_t fl = 0;
-  for (size_t j = 0; j < m->segs.size(); j++) cfm_absorb(vk, R, m->segs[j], j == 0, &fl, nullptr);
+  if (!m->segs.empty() && !cfm_replay(vk, m->segs, m->run_start, m->junctions, R, &fl)) fl |= 4;
   if (fl & 1) res |= 1;
   if (fl & 2) res |= 2;
   if (fl & 4) res |= 4096;

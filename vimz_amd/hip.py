@@ -663,10 +663,16 @@ class CycleFoldMerged:
     first segment (left unchanged; supplies shapes, keys and context and must stay open)."""
     PHASES = ["cross_terms_and_commitments", "folds", "host", "total"]
 
-    def __init__(self, first):
-        self.vk, self.ctx = first, first.ctx
+    def __init__(self, first=None, _handle=None, _vk=None):
+        self.vk = first if first is not None else _vk
+        self.ctx = self.vk.ctx
         lib = self.ctx.lib
         vp, sz = C.c_void_p, C.c_size_t
+        lib.vimz_cf_merge_merged.argtypes = [vp, vp]
+        lib.vimz_cf_merged_size.argtypes = [vp]
+        lib.vimz_cf_merged_size.restype = sz
+        lib.vimz_cf_merged_save.argtypes = [vp, vp, sz]
+        lib.vimz_cf_merged_load.argtypes = [vp, vp, sz, C.POINTER(vp)]
         lib.vimz_cf_merged_create.argtypes = [vp, C.POINTER(vp)]
         lib.vimz_cf_merged_free.argtypes = [vp]
         lib.vimz_cf_merged_free.restype = None
@@ -679,9 +685,31 @@ class CycleFoldMerged:
         lib.vimz_cf_merged_records.restype = C.c_int64
         lib.vimz_cf_merged_export.argtypes = [vp, C.c_int, C.c_int, vp, sz]
         lib.vimz_cf_merged_export.restype = C.c_int64
+        if _handle is not None:
+            self.h = _handle
+            return
         h = vp()
         self.ctx._chk(lib.vimz_cf_merged_create(first.h, C.byref(h)))
         self.h = h
+
+    @classmethod
+    def load(cls, vk, blob):
+        """vimz_cf_merged_load: a merged proof from bytes, into the context of `vk` (a CycleFoldIVC for the same step circuit and keys)."""
+        lib = vk.ctx.lib
+        lib.vimz_cf_merged_load.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+        b = np.ascontiguousarray(blob, dtype=np.uint8)
+        if b.ctypes.data % 8:
+            b = np.frombuffer(bytearray(b.tobytes()) + bytearray(8), dtype=np.uint8)[:b.size].copy()
+        h = C.c_void_p()
+        vk.ctx._chk(lib.vimz_cf_merged_load(vk.h, _ptr(b), b.size, C.byref(h)))
+        return cls(_handle=h, _vk=vk)
+
+    def save(self):
+        """vimz_cf_merged_save: the object as bytes (records + folded vectors)."""
+        n = self.ctx.lib.vimz_cf_merged_size(self.h)
+        buf = np.zeros(n, dtype=np.uint8)
+        self.ctx._chk(self.ctx.lib.vimz_cf_merged_save(self.h, _ptr(buf), n))
+        return buf
 
     @classmethod
     def of(cls, provers):
@@ -701,7 +729,11 @@ class CycleFoldMerged:
             self.h = None
 
     def merge(self, nxt):
-        self.ctx._chk(self.ctx.lib.vimz_cf_merge(self.h, nxt.h))
+        """Fold the next row segment's proof in (a CycleFoldIVC), or another merged object holding one run (vimz_cf_merge_merged)."""
+        if isinstance(nxt, CycleFoldMerged):
+            self.ctx._chk(self.ctx.lib.vimz_cf_merge_merged(self.h, nxt.h))
+        else:
+            self.ctx._chk(self.ctx.lib.vimz_cf_merge(self.h, nxt.h))
 
     def verify(self, num_steps, z0):
         r = C.c_uint32()
