@@ -388,6 +388,9 @@ int vimz_cf_merged_profile(const vimz_cf_merged* m, double seconds[4]);   /* cro
 int64_t vimz_cf_merged_records(const vimz_cf_merged* m, void* buf, size_t cap);
 /* side 0 / 1; what = VIMZ_IX_RUNNING_Z, VIMZ_IX_RUNNING_E, VIMZ_IX_INSTANCE (side 0: 7 elements, side 1: 12 — as vimz_cf_export) of the folded instances */
 int64_t vimz_cf_merged_export(vimz_cf_merged* m, int side, int what, void* buf, size_t cap);
+/* KZG openings (vimz_kzg_open over ck_main as the SRS) of the FOLDED main instance: which = 0 comm_W, 1 comm_E.  For a merged proof of one segment the
+ * folded instance is U_{i+1} = NIFS(U_i, u_i), the one Sonobe's decider opens (decider.rs:13-21).  Canonical in and out. */
+int vimz_cf_merged_kzg_open(vimz_cf_merged* m, int which, const uint64_t z[4], uint64_t eval_out[4], uint64_t proof_xy[8]);
 /* IVC state chain only (as vimz_ivc_state_chain): the state at which a row segment proven by another vimz_cf starts */
 int vimz_cf_state_chain(vimz_cf* v, const uint64_t* z_start, const uint64_t* step_inputs, size_t nsteps, uint64_t* zs_out);
 /* ... in its two parts, as vimz_ivc_row_digests / vimz_ivc_chain_from_digests */

@@ -15,7 +15,9 @@ What this module is and is not.  The statement part — selector, steps, z_0, z_
 on marketplace/proofs).  The 25 proof words are Sonobe's Nova+CycleFold instance commitments over a KZG SRS drawn from
 `StdRng::from_seed([41; 32])` (sonobe_backend/mod.rs:54) and a Groth16 decider proof: they cannot be produced without that SRS and
 the decider circuit's proving key, neither of which exists in this repository or image.  So `encode` takes the 25 words from the
-caller; this library's own proofs (vimz_ivc_*, vimz_ivc_merge*) are NOT accepted by those contracts.
+caller; this library's own proofs (vimz_ivc_*, vimz_ivc_merge*, vimz_cf_*) are NOT accepted by those contracts.  `decider_words` fills the 17
+words that do not come from the Groth16 prover for a proof of this library's Nova + CycleFold scheme: what of
+`Decider::prove` the GPU pipeline covers — the final fold and the KZG openings —, in our protocol's values.
 """
 
 MASK64 = (1 << 64) - 1
@@ -70,6 +72,49 @@ WORD_NAMES = ["U_i.cmW.x", "U_i.cmW.y", "U_i.cmE.x", "U_i.cmE.y", "u_i.cmW.x", "
               "groth16.A.x", "groth16.A.y", "groth16.B.x1", "groth16.B.x0", "groth16.B.y1", "groth16.B.y0", "groth16.C.x", "groth16.C.y",
               "kzg.challenge_W", "kzg.challenge_E", "kzg.eval_W", "kzg.eval_E", "kzg.proof_W.x", "kzg.proof_W.y", "kzg.proof_E.x", "kzg.proof_E.y"]
 G1_POINTS = [(0, 1), (2, 3), (4, 5), (6, 7), (9, 10), (15, 16), (21, 22), (23, 24)]      # word indices of the BN254 G1 points
+
+
+GROTH16_WORDS = list(range(9, 17))      # the eight words of the decider's Groth16 proof: not produced here
+
+
+def decider_words(cf_prover):
+    """The 17 of the 25 proof words that do not come out of the Groth16 prover, for a Nova + CycleFold proof made by `cf_prover`
+    (vimz_amd.hip.CycleFoldIVC, its commitment key being the KZG SRS's powers) — in THIS library's protocol, so a statement of
+    what the GPU pipeline covers of `Decider::prove` (vimz/src/sonobe_backend/decider.rs:13-21), not bytes a contract generated for Sonobe accepts:
+        U_i.cmW, U_i.cmE, u_i.cmW                       the running and the last instance's commitments
+        cmT, r                                          the decider's final fold U_{i+1} = NIFS(U_i, u_i): cross-term commitment and challenge
+        kzg.challenge / eval / proof (W, E)             openings of U_{i+1}'s two commitments at challenges derived from them
+    Returns a list of 25 entries (ints; None in the Groth16 slots) and the folded commitments (U_{i+1}.cmW, U_{i+1}.cmE)."""
+    import hashlib
+    import numpy as np
+    from . import _lib
+    from .hip import CycleFoldMerged, IX_INSTANCE
+    r_mod = _lib.MODULUS[0]
+    m = CycleFoldMerged(cf_prover)              # one segment: acc = U_i (+) u_i
+    try:
+        w = [int(x) for x in m.records()]
+        lz = w[2]
+        pos = 8 + w[7] + 1 + 8 * lz               # header, run starts, n, z_start, z_end
+        el = lambda k: sum(w[pos + 4 * k + q] << (64 * q) for q in range(4))
+        U, u = [el(k) for k in range(7)], [el(7 + k) for k in range(4)]
+        T2 = (el(7 + 4 + 12 + 2), el(7 + 4 + 12 + 3))
+        folded = [sum(int(a[q]) << (64 * q) for q in range(4)) for a in np.asarray(m.export(0, IX_INSTANCE))]
+        # r as the merge derives it: recomputed by the verifier from the records (cyclefold.hip: cfm_challenges); taken from u' - U.u here
+        r = (folded[4] - U[4]) % r_mod
+        words = [None] * PROOF_WORDS
+        words[0:4] = U[0:4]
+        words[4:6] = u[0:2]
+        words[6:8] = list(T2)
+        words[8] = r
+        for k, which in enumerate((0, 1)):
+            comm = (folded[2 * which], folded[2 * which + 1])
+            ch = int.from_bytes(hashlib.sha3_256(b"vimz-kzg-challenge" + comm[0].to_bytes(32, "little") + comm[1].to_bytes(32, "little")).digest(), "little") % r_mod
+            ev, proof = m.kzg_open(which, ch)
+            words[17 + k], words[19 + k] = ch, ev
+            words[21 + 2 * k], words[22 + 2 * k] = proof
+        return words, ((folded[0], folded[1]), (folded[2], folded[3]))
+    finally:
+        m.close()
 
 
 def selector(len_z):

@@ -1312,6 +1312,17 @@ int vimz_cf_merged_verify(vimz_cf_merged* m, uint64_t num_steps, const uint64_t*
   *result = res;
   return VIMZ_OK;
 }
+// KZG openings of the FOLDED main instance of a merged object (vimz_cf_kzg_open for a merged proof).  For a merged proof of ONE segment that is
+// U_{i+1} = NIFS(U_i, u_i): the instance Sonobe's decider opens (decider.rs:13-21).  which = 0: comm_W, 1: comm_E; canonical in and out.
+int vimz_cf_merged_kzg_open(vimz_cf_merged* m, int which, const uint64_t z[4], uint64_t eval_out[4], uint64_t proof_xy[8]) {
+  if (!m || !m->vk || !z || !eval_out || !proof_xy || (which != 0 && which != 1)) return VIMZ_ERR_INVALID;
+  vimz_ctx* ctx = m->vk->ctx; vimz_prover* p = m->vk->pri;
+  if (m->broken) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_cf_merged_kzg_open: this object failed in the middle of a merge");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  P_TRY(hipSetDevice(ctx->device));
+  return which == 0 ? vz_kzg_open_device(ctx, p->ck, 0, VIMZ_FIELD_BN254_FR, m->Zp + 8, p->n_wires - 3, z, VIMZ_FORM_CANONICAL, eval_out, proof_xy)
+                    : vz_kzg_open_device(ctx, p->ck, 0, VIMZ_FIELD_BN254_FR, m->Ep, p->n_c, z, VIMZ_FORM_CANONICAL, eval_out, proof_xy);
+}
 /* IVC state chain only (as vimz_ivc_state_chain): where a row segment proven by another vimz_cf starts */
 int vimz_cf_state_chain(vimz_cf* v, const uint64_t* z_start, const uint64_t* step_inputs, size_t nsteps, uint64_t* zs_out) {
   if (!v) return VIMZ_ERR_INVALID;

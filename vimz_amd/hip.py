@@ -759,6 +759,15 @@ class CycleFoldMerged:
         self.ctx._chk(self.ctx.lib.vimz_cf_merged_profile(self.h, s))
         return dict(zip(self.PHASES, s))
 
+    def kzg_open(self, which, z):
+        """vimz_cf_merged_kzg_open: (eval, proof point) of the folded main instance's comm_W (which = 0) or comm_E (1) at z."""
+        lib = self.ctx.lib
+        lib.vimz_cf_merged_kzg_open.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        ev, pr = np.zeros(4, dtype=np.uint64), np.zeros(8, dtype=np.uint64)
+        self.ctx._chk(lib.vimz_cf_merged_kzg_open(self.h, which, _ptr(_zlimbs([z], 1)), _ptr(ev), _ptr(pr)))
+        ints = lambda a: sum(int(a[k]) << (64 * k) for k in range(4))
+        return ints(ev), (ints(pr[:4]), ints(pr[4:]))
+
     def records(self):
         n = self.ctx.lib.vimz_cf_merged_records(self.h, None, 0)
         buf = np.zeros(n // 8, dtype=np.uint64)
