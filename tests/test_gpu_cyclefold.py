@@ -362,3 +362,26 @@ def test_merged_cyclefold_runs_save_load_and_fold_into_one_object(ctx, keys, ora
             v.close()
         for cx in ctxs[1:]:
             cx.close()
+
+
+def test_full_image_with_the_sonobe_scheme_ends_in_the_references_committed_state(ctx):
+    """All 720 rows of the reference's sample image (img2, contrast 1.4) through fold_input(mode="cyclefold", segments=3): ONE merged Nova +
+    CycleFold proof that verifies for (720 steps, the transformation's z0) and whose final state is the one inside the proof the reference
+    committed for this image — which its Sonobe backend produced (marketplace/proofs/img2-contrast.proof via tests/golden/kat.json)."""
+    from tests import _data
+    from vimz_amd import folding, image_editor as ie
+    P = _data.kat()["proofs"]["img2-contrast"]
+    inp = ie.build_input("contrast", _data.load_image("img2"), factor=1.4)
+    rows, z0 = folding.prepare_input("contrast", inp, "HD")
+    circuit, params = folding.prepare_folding(ctx, "contrast", "HD", backend="sonobe")
+    try:
+        proof = folding.fold_input(params, rows, z0, max_batch=32, mode="cyclefold", segments=3)
+        try:
+            folding.verify_folded_proof(proof, params, 720, z0)
+            assert proof.state() == [int(x) for x in P["z_final"]]
+            with pytest.raises(_lib.VimzError):
+                folding.verify_folded_proof(proof, params, 719, z0)
+        finally:
+            proof.close()
+    finally:
+        params.free()

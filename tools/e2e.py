@@ -85,6 +85,8 @@ def main():
         ok = proof.verify(len(rows), z0) == 0
         spans["Verify folded proof"] = time.time() - t0
         ze = proof.state()[1] if S > 1 else proof.state()[0]
+        if save and S > 1:
+            proof.save().tofile(f"{save}.cfmerged.bin")       # verify elsewhere: tools/verify_proof.py
         print(json.dumps({"config": f"{t}_step_{res}", "mode": "cyclefold", "steps": len(rows), "segments": S, "witness_batch": batch, "proof_objects": 1, "verified": ok, "spans_s": spans,
                           "state_chain_s": t_chain, "merge_s": t_merge, "info": cfs[0].info(),
                           "ms_per_step_first_segment": {k: 1e3 * sec / max(1, cfs[0].info()["steps"]) for k, (sec, n) in cfs[0].profile().items()},

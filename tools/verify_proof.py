@@ -4,8 +4,9 @@ vimz/src/nova_snark_backend/folding.rs:45-56): rebuilds the public parameters (s
 transformation name and resolution, loads the merged proof (vimz_ivc_merged_load: one object for all row segments of the image) and
 runs vimz_ivc_merged_verify.  The statement verified is the reference's and the VERIFIER's: iteration_count(transformation,
 resolution) steps starting from Transformation::ivc_initial_state (factor / info given on the command line) — never the blob's.
-usage: verify_proof.py <transformation> <resolution> <factor-or-info> <proof.merged.bin>
-(write proofs with: tools/e2e.py <transformation> <resolution> <segments> ivc <prefix>  ->  <prefix>.merged.bin)"""
+usage: verify_proof.py <transformation> <resolution> <factor-or-info> <proof.merged.bin | proof.cfmerged.bin>
+(write proofs with: tools/e2e.py <transformation> <resolution> <segments> ivc|cyclefold <prefix>  ->  <prefix>.merged.bin / <prefix>.cfmerged.bin;
+ a merged Nova + CycleFold proof — the Sonobe backend's scheme — is recognised by its magic and verified by vimz_cf_merged_verify)"""
 import sys
 
 import numpy as np
@@ -19,9 +20,15 @@ def main():
     z_first = folding.ivc_initial_state(t, {"factor": extra, "info": extra})
     want_steps = folding.iteration_count(t, res)
     ctx = hip.Context(0)
-    circuit, params = folding.prepare_folding(ctx, t, res)
-    vk = hip.IVC(ctx, circuit, params.ck, params.secondary_key(), max_batch=1)
-    proof = hip.MergedProof.load(vk, np.fromfile(path, dtype=np.uint8))
+    blob = np.fromfile(path, dtype=np.uint8)
+    cyclefold = int.from_bytes(blob[:8].tobytes(), "little") == 0x32474d46435a56      # "VZCFMG2": a merged Nova + CycleFold proof (vimz_cf_merged_save)
+    circuit, params = folding.prepare_folding(ctx, t, res, backend="sonobe" if cyclefold else "nova-snark")
+    if cyclefold:
+        vk = hip.CycleFoldIVC(ctx, circuit, params.ck, params.secondary_key(), max_batch=1)
+        proof = hip.CycleFoldMerged.load(vk, blob)
+    else:
+        vk = hip.IVC(ctx, circuit, params.ck, params.secondary_key(), max_batch=1)
+        proof = hip.MergedProof.load(vk, blob)
     code = proof.verify(want_steps, z_first)
     zs, ze, n = proof.state()
     print(f"{path}: {proof.info()['segments']} segments, {n} steps, verify code {code} for ({want_steps} steps from the transformation's initial state)")
