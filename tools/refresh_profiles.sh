@@ -78,7 +78,7 @@ fi
 if want cyclefold; then  # the Sonobe backend's path: Nova + CycleFold on one chain
   : > $O/${R}_cyclefold.jsonl
   timeout 900 python3 tools/cyclefold_bench.py contrast HD 256 2>/dev/null | tail -1 >> $O/${R}_cyclefold.jsonl
-  for cfg in "contrast HD 1" "contrast HD 3" "grayscale HD 3" "contrast 4K 1" "contrast 4K 3"; do
+  for cfg in "contrast HD 1" "contrast HD 3" "grayscale HD 3" "crop HD 3" "contrast 4K 1" "contrast 4K 3" "resize 8K 3"; do
     timeout 900 python3 tools/e2e.py $cfg cyclefold 2>/dev/null | tail -1 >> $O/${R}_cyclefold.jsonl
   done
   $T rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python3 tools/cyclefold_bench.py contrast HD 128 > $O/${R}_cyclefold_under_rocprof.json 2> $O/rocprof.err
