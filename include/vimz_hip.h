@@ -361,7 +361,7 @@ int vimz_cf_proof_import(vimz_cf* v, const uint8_t* blob, size_t len);
  * vimz_ivc_merge* is for the Nova IVC): segments folded concurrently — each a vimz_cf of its own on the same device — are folded in row order
  * by out-of-circuit NIFS: the running main instances pairwise (two relaxed instances), each segment's last instance of F' (strict), the
  * running CycleFold instances pairwise on Grumpkin.  The verifier replays the segment records (hashes from each segment's statement,
- * adjacency, folds of the instances) and checks ONE main and ONE CycleFold relaxed instance.  Protocol: vimz_amd/csrc/cyclefold.hip, ours. */
+ * adjacency, folds of the instances) and checks ONE main and ONE CycleFold relaxed instance.  Protocol: vimz_amd/csrc/cyclefold_merge.hip, ours. */
 typedef struct vimz_cf_merged vimz_cf_merged;
 /* the merged proof of one segment; `first` is left unchanged, supplies shapes / keys / context and must outlive the object */
 int vimz_cf_merged_create(vimz_cf* first, vimz_cf_merged** out);
@@ -384,7 +384,7 @@ int vimz_cf_merged_verify(vimz_cf_merged* m, uint64_t num_steps, const uint64_t*
 int vimz_cf_merged_info(const vimz_cf_merged* m, uint64_t info[8]);
 int vimz_cf_merged_state(const vimz_cf_merged* m, uint64_t* z_start, uint64_t* z_end, uint64_t* steps);
 int vimz_cf_merged_profile(const vimz_cf_merged* m, double seconds[4]);   /* cross terms + commitments, folds, host, total */
-/* the statement part as canonical little-endian 64-bit words (layout: cyclefold.hip); returns the byte size */
+/* the statement part as canonical little-endian 64-bit words (layout: cyclefold_merge.hip); returns the byte size */
 int64_t vimz_cf_merged_records(const vimz_cf_merged* m, void* buf, size_t cap);
 /* side 0 / 1; what = VIMZ_IX_RUNNING_Z, VIMZ_IX_RUNNING_E, VIMZ_IX_INSTANCE (side 0: 7 elements, side 1: 12 — as vimz_cf_export) of the folded instances */
 int64_t vimz_cf_merged_export(vimz_cf_merged* m, int side, int what, void* buf, size_t cap);

@@ -99,7 +99,7 @@ def decider_words(cf_prover):
         U, u = [el(k) for k in range(7)], [el(7 + k) for k in range(4)]
         T2 = (el(7 + 4 + 12 + 2), el(7 + 4 + 12 + 3))
         folded = [sum(int(a[q]) << (64 * q) for q in range(4)) for a in np.asarray(m.export(0, IX_INSTANCE))]
-        # r as the merge derives it: recomputed by the verifier from the records (cyclefold.hip: cfm_challenges); taken from u' - U.u here
+        # r as the merge derives it: recomputed by the verifier from the records (cyclefold_merge.hip: cfm_challenges); taken from u' - U.u here
         r = (folded[4] - U[4]) % r_mod
         words = [None] * PROOF_WORDS
         words[0:4] = U[0:4]
