@@ -347,7 +347,8 @@ int vimz_cf_state(const vimz_cf* v, uint64_t* z_current, uint64_t* steps);
 int vimz_cf_profile(const vimz_cf* v, double seconds[8], uint64_t counts[8]);
 /* side 0 = main circuit, 1 = CycleFold circuit; what = VIMZ_CX_* (R1CS tables), VIMZ_IX_INFO, VIMZ_IX_INSTANCE (side 0: comm_W.x, comm_W.y,
  * comm_E.x, comm_E.y, u, x0, x1; side 1: comm_W.x, comm_W.y, comm_E.x, comm_E.y, u, x[0..7)), VIMZ_IX_FRESH_INSTANCE (side 0: comm_W.x,
- * comm_W.y, x0, x1), VIMZ_IX_PARAMS (side 0: digest, z0..., z_i...), VIMZ_IX_RUNNING_Z, VIMZ_IX_RUNNING_E, VIMZ_IX_FRESH_Z (side 0) */
+ * comm_W.y, x0, x1), VIMZ_IX_PARAMS (side 0: digest, z0..., z_i...), VIMZ_IX_RUNNING_Z, VIMZ_IX_RUNNING_E, VIMZ_IX_FRESH_Z (side 0),
+ * VIMZ_IX_LAST_STEP (side 0: inputs and outputs of the last step's F', for an independent restatement of the step relation) */
 int64_t vimz_cf_export(vimz_cf* v, int side, int what, void* buf, size_t cap);
 /* KZG openings of the running main instance's commitments at z (vimz_kzg_open over ck_main as the SRS): which = 0 comm_W (coefficients = the witness
  * wires [1, wires - 2) of the running vector), 1 comm_E.  Canonical in and out. */
@@ -465,6 +466,7 @@ int vimz_ivc_verify_merged_compressed(vimz_ivc* vk, const uint8_t* blob, size_t 
 #define VIMZ_IX_INSTANCE 103    /* running instance: comm_W.x, comm_W.y, comm_E.x, comm_E.y, u, X0, X1  (7 elements; coordinates in the
                                    commitment curve's base field, u/X in this side's scalar field) */
 #define VIMZ_IX_FRESH_INSTANCE 104  /* side 1 only: comm_W.x, comm_W.y, x0, x1 */
+#define VIMZ_IX_LAST_STEP 107   /* vimz_cf_export, side 0: what the last step's F' was given and returned (layout: cyclefold.hip) */
 #define VIMZ_IX_INFO 106        /* u64[4]: wires, constraints, step wires, step constraints */
 #define VIMZ_IX_PARAMS 105      /* digest, z0..., z_i...  (1 + 2 len_z elements of this side's field; secondary len_z = 1) */
 int64_t vimz_ivc_export(vimz_ivc* v, int side, int what, void* buf, size_t cap);

@@ -232,3 +232,57 @@ def verify_merged(orc, merged, cf, ck1, ck2, num_steps, z0, check_commitments=Tr
         if orc.msm(1, bases2[:n2 - 1 - CF_IO], Z2[1:n2 - CF_IO]) != tuple(Q[0]): failed.append("cyclefold: comm_W")
         if orc.msm(1, bases2[:len(E2)], E2) != tuple(Q[1]): failed.append("cyclefold: comm_E")
     return failed, acc
+
+
+# ---- the relation F' enforces in one step, restated natively (the counterpart of oracle/nova.hpp's nova_step for this scheme): from what the
+# last step's circuit was given (vimz_cf_export VIMZ_IX_LAST_STEP) to what it must have returned ----------------------------------------------
+def parse_last_step(words, len_z):
+    w = [int(x) for x in np.asarray(words).reshape(-1)]
+    pos = 0
+
+    def el():
+        nonlocal pos
+        v = sum(w[pos + k] << (64 * k) for k in range(4))
+        pos += 4
+        return v
+    r = {"i": el(), "z_i": [el() for _ in range(len_z)], "z_next": [el() for _ in range(len_z)], "U": [el() for _ in range(7)], "u": [el() for _ in range(4)],
+         "T": (el(), el()), "Wn": (el(), el()), "En": (el(), el()), "cfU": [el() for _ in range(5 + CF_IO)]}
+    r["cf1W"], r["cf1T"], r["cf2W"], r["cf2T"] = (el(), el()), (el(), el()), (el(), el()), (el(), el())
+    r["U_new"], r["cfU_new"], r["x0"], r["x1"] = [el() for _ in range(7)], [el() for _ in range(5 + CF_IO)], el(), el()
+    r["r"], r["r1"], r["r2"] = el(), el(), el()
+    assert pos == len(w)
+    return r
+
+
+def step_relation(orc, dg, z0, s):
+    """What F' must return for the inputs `s` (aug/cyclefold.hpp, header comment): (failed checks, U', cfU', x0, x1, challenges)."""
+    pr, pq = orc.modulus[0], orc.modulus[1]
+    failed = []
+    base = s["i"] == 0
+    U, u, cfU = s["U"], s["u"], s["cfU"]
+    if base and s["z_i"] != list(z0): failed.append("base case does not start from z0")
+    h_U, h_cf = hash_main(orc, dg, s["i"], z0, s["z_i"], U), hash_cf(orc, dg, cfU)
+    if not base and (h_U != u[2] or h_cf != u[3]): failed.append("incoming hashes")
+    hr = orc.nova_hash(0, [h_U] + limbs64(u[0]) + limbs64(u[1]) + [u[2], u[3]] + limbs64(s["T"][0]) + limbs64(s["T"][1]))
+    r = chal(hr)
+    h1 = orc.nova_hash(0, [h_cf, hr, s["cf1W"][0], s["cf1W"][1]] + limbs64(s["Wn"][0]) + limbs64(s["Wn"][1]) + [s["cf1T"][0], s["cf1T"][1]])
+    r1 = chal(h1)
+    h2 = orc.nova_hash(0, [h1, s["cf2W"][0], s["cf2W"][1]] + limbs64(s["En"][0]) + limbs64(s["En"][1]) + [s["cf2T"][0], s["cf2T"][1]])
+    r2 = chal(h2)
+    if base:
+        Un, cn = [0] * 7, [0] * (5 + CF_IO)
+        if s["Wn"] != (0, 0) or s["En"] != (0, 0): failed.append("base case hints")
+    else:
+        axpy = lambda cid, a, k, b: orc.curve_add(cid, a, orc.curve_mul(cid, b, k))
+        # the hinted commitments are what the two CycleFold instances speak about: W' = W + r·W_in, E' = E + r·cmT on BN254 G1
+        if axpy(0, (U[0], U[1]), r, (u[0], u[1])) != s["Wn"]: failed.append("hint W'")
+        if axpy(0, (U[2], U[3]), r, s["T"]) != s["En"]: failed.append("hint E'")
+        Un = [s["Wn"][0], s["Wn"][1], s["En"][0], s["En"][1], (U[4] + r) % pr, (U[5] + r * u[2]) % pr, (U[6] + r * u[3]) % pr]
+        cf1x = [r, U[0], U[1], u[0], u[1], s["Wn"][0], s["Wn"][1]]
+        cf2x = [r, U[2], U[3], s["T"][0], s["T"][1], s["En"][0], s["En"][1]]
+        W = axpy(1, axpy(1, (cfU[0], cfU[1]), r1, s["cf1W"]), r2, s["cf2W"])
+        E = axpy(1, axpy(1, (cfU[2], cfU[3]), r1, s["cf1T"]), r2, s["cf2T"])
+        cn = [W[0], W[1], E[0], E[1], (cfU[4] + r1 + r2) % pr] + [(x + r1 * a + r2 * b) % pq for x, a, b in zip(cfU[5:], cf1x, cf2x)]
+    x0 = hash_main(orc, dg, s["i"] + 1, z0, s["z_next"], Un)
+    x1 = hash_cf(orc, dg, cn)
+    return failed, Un, cn, x0, x1, (r, r1, r2)

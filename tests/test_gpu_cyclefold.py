@@ -385,3 +385,31 @@ def test_full_image_with_the_sonobe_scheme_ends_in_the_references_committed_stat
             proof.close()
     finally:
         params.free()
+
+
+@pytest.mark.parametrize("n_steps", [1, 2, 5])
+def test_step_relation_restated_natively(ctx, keys, oracle, n_steps):
+    """What the last step's F' returned equals the native restatement of its relation (tests/_cyclefold.py::step_relation: oracle Poseidon,
+    Python integers, oracle curve arithmetic on both curves) applied to what it was given — the base case (1 step), the first fold into
+    the zero instances (2) and a general step (5)."""
+    from vimz_amd import hip
+    ck1, ck2 = keys
+    c = Circuit.for_resolution("grayscale", "HD")
+    z0, inputs = step_inputs("grayscale")
+    cf = hip.CycleFoldIVC(ctx, c, ck1, ck2, max_batch=4)
+    try:
+        cf.reset(z0); cf.fold(np.stack(inputs[:n_steps]))
+        assert cf.verify(n_steps, z0) == 0
+        s = cfo.parse_last_step(cf.export(0, hip.IX_LAST_STEP), c.len_z)
+        dg = cfo.shape_digest(cf)
+        assert s["i"] == n_steps - 1
+        failed, Un, cn, x0, x1, (r, r1, r2) = cfo.step_relation(oracle, dg, list(z0), s)
+        assert failed == []
+        assert (Un, cn, x0, x1) == (s["U_new"], s["cfU_new"], s["x0"], s["x1"])
+        mask = (1 << 128) - 1
+        assert (r & mask, r1 & mask, r2 & mask) == (s["r"], s["r1"], s["r2"])
+        # ... and they are what the prover now holds
+        assert from_limbs(cf.export(0, hip.IX_INSTANCE)) == Un and from_limbs(cf.export(1, hip.IX_INSTANCE)) == cn
+        assert from_limbs(cf.export(0, hip.IX_FRESH_INSTANCE))[2:4] == [x0, x1]
+    finally:
+        cf.close()

@@ -205,6 +205,7 @@ int cf_fold_core(vimz_cf* v, const uint64_t* step_inputs, size_t nsteps) {
         return vz_fail(ctx, VIMZ_ERR_INVALID, "cyclefold main circuit: its challenges differ from the prover's");
       v->ph_s[CP_SYNTH] += now_s() - t0; v->ph_n[CP_SYNTH]++;
       t0 = now_s();
+      v->last_in = in; v->last_out = o; v->last_zi.assign(z_i, z_i + p->len_z); v->last_zn.assign(z_n, z_n + p->len_z); v->have_last = true;
       v->U = o.U_new; v->UW = i > 0 ? Wn : g1_identity(); v->UE = i > 0 ? En : g1_identity();
       v->cfU = o.cfU_new;
       // ---- fresh main instance: verifier wires behind the step circuit's, verifier rows of (A,B,C)·z, commitment ---------------------------
@@ -547,11 +548,29 @@ int64_t vimz_cf_export(vimz_cf* v, int side, int what, void* buf, size_t cap) {
   vimz_ctx* ctx = v->ctx;
   vimz_prover* p = v->pri;
   SecDev& S = v->sec;
-  if (what == VIMZ_IX_INSTANCE || what == VIMZ_IX_FRESH_INSTANCE || what == VIMZ_IX_PARAMS) {
+  if (what == VIMZ_IX_INSTANCE || what == VIMZ_IX_FRESH_INSTANCE || what == VIMZ_IX_PARAMS || what == VIMZ_IX_LAST_STEP) {
     std::vector<uint64_t> o;
     auto push = [&](const auto& m) { auto x = std::decay_t<decltype(m)>::from_mont(m); o.resize(o.size() + 4); memcpy(o.data() + o.size() - 4, x.v, 32); };
     auto push_u = [&](const U256w& x) { o.insert(o.end(), x.w, x.w + 4); };
-    if (what == VIMZ_IX_INSTANCE) {
+    if (what == VIMZ_IX_LAST_STEP) {
+      // the last step's F': i (one element), z_i, z_{i+1}, U (7), u (4), cmT (2), the hinted W', E' (4), cfU (12), cf1.W, cf1.T, cf2.W, cf2.T (8),
+      // then what it returned: U' (7), cfU' (12), x0, x1, and the three challenges' low 128 bits (3)
+      if (side != 0 || !v->have_last) return VIMZ_ERR_INVALID;
+      const CfMainIn& L = v->last_in; const CfMainOut& O = v->last_out;
+      auto push_i = [&](uint64_t x) { o.push_back(x); o.push_back(0); o.push_back(0); o.push_back(0); };
+      auto push_low = [&](const uint32_t* r) { o.push_back((uint64_t)r[0] | ((uint64_t)r[1] << 32)); o.push_back((uint64_t)r[2] | ((uint64_t)r[3] << 32)); o.push_back(0); o.push_back(0); };
+      auto push_main = [&](const CfMainRelaxed& U) { push_u(U.W.x); push_u(U.W.y); push_u(U.E.x); push_u(U.E.y); push(U.u); push(U.x0); push(U.x1); };
+      auto push_cf = [&](const CfRelaxed& U) { push(U.W.x); push(U.W.y); push(U.E.x); push(U.E.y); push(U.u); for (auto& e : U.x) push_u(e); };
+      push_i(L.i);
+      for (auto& z : v->last_zi) push(z);
+      for (auto& z : v->last_zn) push(z);
+      push_main(L.U); push_u(L.u.W.x); push_u(L.u.W.y); push(L.u.x0); push(L.u.x1);
+      push_u(L.T.x); push_u(L.T.y); push_u(L.Wn.x); push_u(L.Wn.y); push_u(L.En.x); push_u(L.En.y);
+      push_cf(L.cfU);
+      for (const G2Aff* P : {&L.cf1W, &L.cf1T, &L.cf2W, &L.cf2T}) { push(P->x); push(P->y); }
+      push_main(O.U_new); push_cf(O.cfU_new); push(O.x0); push(O.x1);
+      push_low(O.r); push_low(O.r1); push_low(O.r2);
+    } else if (what == VIMZ_IX_INSTANCE) {
       if (side == 0) { push_u(v->U.W.x); push_u(v->U.W.y); push_u(v->U.E.x); push_u(v->U.E.y); push(v->U.u); push(v->U.x0); push(v->U.x1); }
       else { push(v->cfU.W.x); push(v->cfU.W.y); push(v->cfU.E.x); push(v->cfU.E.y); push(v->cfU.u); for (auto& e : v->cfU.x) push_u(e); }
     } else if (what == VIMZ_IX_FRESH_INSTANCE) {

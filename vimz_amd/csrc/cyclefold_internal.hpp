@@ -39,6 +39,8 @@ struct vimz_cf {
   Fe u_run = Fe::zero(); Fq cf_u_run = Fq::zero();
   bool broken = false;
   double ph_s[CP_COUNT] = {}; uint64_t ph_n[CP_COUNT] = {};
+  // what the last step's F' was given and what it returned (VIMZ_IX_LAST_STEP: the oracle-side restatement of the step relation replays it)
+  CfMainIn last_in = CfMainIn::zero(); CfMainOut last_out{}; std::vector<Fe> last_zi, last_zn; bool have_last = false;
   // merged proofs that use this prover as their verifier key: freeing it first orphans them (buffers released, later calls fail cleanly)
   std::vector<struct vimz_cf_merged*> merged_dependents;
   void (*orphan_merged)(vimz_cf*) = nullptr;

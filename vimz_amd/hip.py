@@ -336,7 +336,7 @@ class Prover:
 # ---- Nova IVC (include/vimz_hip.h: vimz_ivc_*) --------------------------------------------------------------------------
 CX_R1CS = {"A_rowptr": 0, "A_col": 1, "A_coef": 2, "B_rowptr": 3, "B_col": 4, "B_coef": 5, "C_rowptr": 6, "C_col": 7, "C_coef": 8,
            "dict_canon": 10}
-IX_RUNNING_Z, IX_RUNNING_E, IX_FRESH_Z, IX_INSTANCE, IX_FRESH_INSTANCE, IX_PARAMS, IX_INFO = 100, 101, 102, 103, 104, 105, 106
+IX_RUNNING_Z, IX_RUNNING_E, IX_FRESH_Z, IX_INSTANCE, IX_FRESH_INSTANCE, IX_PARAMS, IX_INFO, IX_LAST_STEP = 100, 101, 102, 103, 104, 105, 106, 107
 
 
 def _export(fn, *args):
