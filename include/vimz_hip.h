@@ -405,6 +405,9 @@ int vimz_cf_chain_from_digests(vimz_cf* v, const uint64_t* z_start, const uint64
  * flip test — every wire incremented by one must violate a row — wires of F' flipped, unnoticed, wires of the CycleFold circuit flipped, unnoticed). */
 int vimz_cf_poke(vimz_cf* v, int which, size_t index, const uint64_t value[4]);
 int vimz_cf_selfcheck(int steps, uint32_t* result, uint64_t counts[8]);
+/* the LAST step of the same host-only run, for an outside restatement of the relation F' enforces: digest, z_0 (one element), then the words of
+ * VIMZ_IX_LAST_STEP.  Returns the byte size (copies when buf is large enough); negative on error or when the self-check itself fails. */
+int64_t vimz_cf_selfcheck_last_step(int steps, void* buf, size_t cap);
 
 /* ---- ONE proof object out of several row segments: the "host-side sequential final fold" of BASELINE.json's north_star for IVC proofs.
  *      fold_input returns ONE RecursiveSNARK (vimz/src/nova_snark_backend/folding.rs:27-43); row segments of an image folded

@@ -253,6 +253,27 @@ int cf_fold_core(vimz_cf* v, const uint64_t* step_inputs, size_t nsteps) {
   return VIMZ_OK;
 }
 
+// the words of VIMZ_IX_LAST_STEP: what a step's F' was given and what it returned
+std::vector<uint64_t> last_step_words(const CfMainIn& L, const CfMainOut& O, const std::vector<Fe>& zi, const std::vector<Fe>& zn) {
+  std::vector<uint64_t> o;
+  auto push = [&](const auto& m) { auto x = std::decay_t<decltype(m)>::from_mont(m); o.resize(o.size() + 4); memcpy(o.data() + o.size() - 4, x.v, 32); };
+  auto push_u = [&](const U256w& x) { o.insert(o.end(), x.w, x.w + 4); };
+  auto push_i = [&](uint64_t x) { o.push_back(x); o.push_back(0); o.push_back(0); o.push_back(0); };
+  auto push_low = [&](const uint32_t* r) { o.push_back((uint64_t)r[0] | ((uint64_t)r[1] << 32)); o.push_back((uint64_t)r[2] | ((uint64_t)r[3] << 32)); o.push_back(0); o.push_back(0); };
+  auto push_main = [&](const CfMainRelaxed& U) { push_u(U.W.x); push_u(U.W.y); push_u(U.E.x); push_u(U.E.y); push(U.u); push(U.x0); push(U.x1); };
+  auto push_cf = [&](const CfRelaxed& U) { push(U.W.x); push(U.W.y); push(U.E.x); push(U.E.y); push(U.u); for (auto& e : U.x) push_u(e); };
+  push_i(L.i);
+  for (auto& z : zi) push(z);
+  for (auto& z : zn) push(z);
+  push_main(L.U); push_u(L.u.W.x); push_u(L.u.W.y); push(L.u.x0); push(L.u.x1);
+  push_u(L.T.x); push_u(L.T.y); push_u(L.Wn.x); push_u(L.Wn.y); push_u(L.En.x); push_u(L.En.y);
+  push_cf(L.cfU);
+  for (const G2Aff* P : {&L.cf1W, &L.cf1T, &L.cf2W, &L.cf2T}) { push(P->x); push(P->y); }
+  push_main(O.U_new); push_cf(O.cfU_new); push(O.x0); push(O.x1);
+  push_low(O.r); push_low(O.r1); push_low(O.r2);
+  return o;
+}
+
 template <class F>
 int64_t export_builder(const cb::BuilderT<F>& b, uint32_t step_wires, uint32_t step_c, int what, void* buf, size_t cap) {
   const void* src = nullptr; size_t bytes = 0;
@@ -556,20 +577,7 @@ int64_t vimz_cf_export(vimz_cf* v, int side, int what, void* buf, size_t cap) {
       // the last step's F': i (one element), z_i, z_{i+1}, U (7), u (4), cmT (2), the hinted W', E' (4), cfU (12), cf1.W, cf1.T, cf2.W, cf2.T (8),
       // then what it returned: U' (7), cfU' (12), x0, x1, and the three challenges' low 128 bits (3)
       if (side != 0 || !v->have_last) return VIMZ_ERR_INVALID;
-      const CfMainIn& L = v->last_in; const CfMainOut& O = v->last_out;
-      auto push_i = [&](uint64_t x) { o.push_back(x); o.push_back(0); o.push_back(0); o.push_back(0); };
-      auto push_low = [&](const uint32_t* r) { o.push_back((uint64_t)r[0] | ((uint64_t)r[1] << 32)); o.push_back((uint64_t)r[2] | ((uint64_t)r[3] << 32)); o.push_back(0); o.push_back(0); };
-      auto push_main = [&](const CfMainRelaxed& U) { push_u(U.W.x); push_u(U.W.y); push_u(U.E.x); push_u(U.E.y); push(U.u); push(U.x0); push(U.x1); };
-      auto push_cf = [&](const CfRelaxed& U) { push(U.W.x); push(U.W.y); push(U.E.x); push(U.E.y); push(U.u); for (auto& e : U.x) push_u(e); };
-      push_i(L.i);
-      for (auto& z : v->last_zi) push(z);
-      for (auto& z : v->last_zn) push(z);
-      push_main(L.U); push_u(L.u.W.x); push_u(L.u.W.y); push(L.u.x0); push(L.u.x1);
-      push_u(L.T.x); push_u(L.T.y); push_u(L.Wn.x); push_u(L.Wn.y); push_u(L.En.x); push_u(L.En.y);
-      push_cf(L.cfU);
-      for (const G2Aff* P : {&L.cf1W, &L.cf1T, &L.cf2W, &L.cf2T}) { push(P->x); push(P->y); }
-      push_main(O.U_new); push_cf(O.cfU_new); push(O.x0); push(O.x1);
-      push_low(O.r); push_low(O.r1); push_low(O.r2);
+      o = last_step_words(v->last_in, v->last_out, v->last_zi, v->last_zn);
     } else if (what == VIMZ_IX_INSTANCE) {
       if (side == 0) { push_u(v->U.W.x); push_u(v->U.W.y); push_u(v->U.E.x); push_u(v->U.E.y); push(v->U.u); push(v->U.x0); push(v->U.x1); }
       else { push(v->cfU.W.x); push(v->cfU.W.y); push(v->cfU.E.x); push(v->cfU.E.y); push(v->cfU.u); for (auto& e : v->cfU.x) push_u(e); }
@@ -763,7 +771,7 @@ int vimz_cf_poke(vimz_cf* v, int which, size_t index, const uint64_t value[4]) {
 // hashes differ from the verifier's, bit 7 more flipped wires than the allowed handful went unnoticed.  counts (optional, 8 words): F' wires /
 // constraints, CycleFold wires / constraints, then the flip test of the last step: wires of F + F' flipped, unnoticed, wires of the CycleFold
 // circuit flipped, unnoticed.
-int vimz_cf_selfcheck(int steps, uint32_t* result, uint64_t counts[8]) {
+static int cf_selfcheck_core(int steps, uint32_t* result, uint64_t counts[8], std::vector<uint64_t>* record) {
   if (!result || steps < 1 || steps > 64) return VIMZ_ERR_INVALID;
   try {
     CfCircuit cf; cf.finish();
@@ -876,6 +884,13 @@ int vimz_cf_selfcheck(int steps, uint32_t* result, uint64_t counts[8]) {
         const G2Aff Wc = fold2(cfU.W, in.cf1W, in.cf2W), Ec = fold2(cfU.E, in.cf1T, in.cf2T);
         if (!Wc.x.eq(o.cfU_new.W.x) || !Wc.y.eq(o.cfU_new.W.y) || !Ec.x.eq(o.cfU_new.E.x) || !Ec.y.eq(o.cfU_new.E.y)) res |= 16;
       }
+      if (record && i == steps - 1) {      // digest, z_0, then the VIMZ_IX_LAST_STEP words of this step
+        record->clear();
+        auto put = [&](const Fe& m) { const Fe x = Fe::from_mont(m); record->resize(record->size() + 4); memcpy(record->data() + record->size() - 4, x.v, 32); };
+        put(c1.digest); put(z0[0]);
+        const std::vector<uint64_t> w = last_step_words(in, o, z0, z0);
+        record->insert(record->end(), w.begin(), w.end());
+      }
       U = o.U_new; UW = i > 0 ? Wn : g1_identity(); UE = i > 0 ? En : g1_identity(); cfU = o.cfU_new;
       if (!cf_hash_main(c1.digest, i + 1, z0, z0.data(), U).eq(o.x0) || !cf_hash_cf(c1.digest, cfU).eq(o.x1)) res |= 64;
       uW = fake1(0x6000 + i); u.W = nn_point(uW); u.x0 = o.x0; u.x1 = o.x1;
@@ -884,6 +899,18 @@ int vimz_cf_selfcheck(int steps, uint32_t* result, uint64_t counts[8]) {
     *result = res;
     return VIMZ_OK;
   } catch (const std::exception& e) { return vz_fail(nullptr, VIMZ_ERR_INVALID, e.what()); }
+}
+int vimz_cf_selfcheck(int steps, uint32_t* result, uint64_t counts[8]) { return cf_selfcheck_core(steps, result, counts, nullptr); }
+// the same run's LAST step for an outside restatement of the relation (tests/_cyclefold.py::step_relation, on the CPU): digest, z_0 (one element:
+// the trivial step circuit's state), then the words of VIMZ_IX_LAST_STEP.  Returns the byte size (copies when buf is large enough).
+int64_t vimz_cf_selfcheck_last_step(int steps, void* buf, size_t cap) {
+  uint32_t res = 0; std::vector<uint64_t> rec;
+  const int rc = cf_selfcheck_core(steps, &res, nullptr, &rec);
+  if (rc) return rc;
+  if (res) return VIMZ_ERR_UNSAT;
+  const size_t bytes = 8 * rec.size();
+  if (buf && cap >= bytes) memcpy(buf, rec.data(), bytes);
+  return (int64_t)bytes;
 }
 
 }  // extern "C"

@@ -658,6 +658,21 @@ class CycleFoldIVC:
         self.ctx._chk(lib.vimz_cf_proof_import(self.h, _ptr(b), b.size))
 
 
+def cyclefold_selfcheck_last_step(steps=4):
+    """vimz_cf_selfcheck_last_step (host only): (digest, z_0, uint64 words of the last step's VIMZ_IX_LAST_STEP record)."""
+    from . import _lib
+    lib = _lib.lib()
+    lib.vimz_cf_selfcheck_last_step.argtypes = [C.c_int, C.c_void_p, C.c_size_t]
+    lib.vimz_cf_selfcheck_last_step.restype = C.c_int64
+    n = lib.vimz_cf_selfcheck_last_step(int(steps), None, 0)
+    if n < 0:
+        raise _lib.VimzError(int(n), "vimz_cf_selfcheck_last_step")
+    buf = np.zeros(n // 8, dtype=np.uint64)
+    assert lib.vimz_cf_selfcheck_last_step(int(steps), _ptr(buf), n) == n
+    ints = lambda a: sum(int(a[k]) << (64 * k) for k in range(4))
+    return ints(buf[0:4]), ints(buf[4:8]), buf[8:]
+
+
 class CycleFoldMerged:
     """vimz_cf_merged: ONE proof object out of the CycleFold proofs of contiguous row segments (vimz_cf_merge).  `first`: the prover of the
     first segment (left unchanged; supplies shapes, keys and context and must stay open)."""
