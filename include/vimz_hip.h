@@ -392,6 +392,9 @@ int64_t vimz_cf_merged_export(vimz_cf_merged* m, int side, int what, void* buf, 
 /* KZG openings (vimz_kzg_open over ck_main as the SRS) of the FOLDED main instance: which = 0 comm_W, 1 comm_E.  For a merged proof of one segment the
  * folded instance is U_{i+1} = NIFS(U_i, u_i), the one Sonobe's decider opens (decider.rs:13-21).  Canonical in and out. */
 int vimz_cf_merged_kzg_open(vimz_cf_merged* m, int which, const uint64_t z[4], uint64_t eval_out[4], uint64_t proof_xy[8]);
+/* test hook, host only (no GPU): two runs of made-up, self-consistent segment records replayed by the library; output = digest, word count + records,
+ * the accumulator arrived at (layout: cyclefold_merge.hip) — for an outside replay of the merge transcript in the CPU suite.  Returns the byte size. */
+int64_t vimz_cf_selfcheck_merge(int segs_run0, int segs_run1, void* buf, size_t cap);
 /* IVC state chain only (as vimz_ivc_state_chain): the state at which a row segment proven by another vimz_cf starts */
 int vimz_cf_state_chain(vimz_cf* v, const uint64_t* z_start, const uint64_t* step_inputs, size_t nsteps, uint64_t* zs_out);
 /* ... in its two parts, as vimz_ivc_row_digests / vimz_ivc_chain_from_digests */

@@ -28,3 +28,23 @@ def test_step_relation_of_the_main_circuit_restated_with_the_oracle(oracle):
         assert (Un, cn, x0, x1) == (s["U_new"], s["cfU_new"], s["x0"], s["x1"]), steps
         mask = (1 << 128) - 1
         assert (r & mask, r1 & mask, r2 & mask) == (s["r"], s["r1"], s["r2"])
+
+
+def test_merge_transcript_replayed_with_the_oracle(oracle):
+    """The statement side of merged CycleFold proofs (segment hashes, adjacency, SHA3 transcript, folds of the instances on both curves, runs
+    and their junctions): the library's replay of made-up, self-consistent records and the outside replay (tests/_cyclefold.py: hashlib,
+    Python integers, the oracle's Poseidon and curve arithmetic) arrive at the same accumulator.  No GPU."""
+    from tests import _cyclefold as cfo
+    for run0, run1 in ((1, 0), (3, 0), (2, 2)):
+        dg, rec_words, acc = hip.cyclefold_selfcheck_merge(run0, run1)
+        rec = cfo.parse_merged_records(rec_words, 1)
+        assert len(rec["segs"]) == run0 + run1 and len(rec["junctions"]) == (1 if run1 else 0)
+        failed, got = cfo.replay_merged(oracle, rec, dg, 1)
+        assert failed == [], failed
+        assert got["n"] == acc["n"] and got["zs"] == acc["zs"] and got["ze"] == acc["ze"]
+        assert [tuple(got["P"][0]), tuple(got["P"][1])] + list(got["P"][2:]) == [acc["P"][0], acc["P"][1]] + acc["P"][2:]
+        assert [tuple(got["Q"][0]), tuple(got["Q"][1]), got["Q"][2], list(got["Q"][3])] == [acc["Q"][0], acc["Q"][1], acc["Q"][2], list(acc["Q"][3])]
+        # a changed record is noticed by the outside replay
+        bad = rec_words.copy(); bad[8 + len(rec["run_start"])] += 1             # n of the first segment
+        f2, _ = cfo.replay_merged(oracle, cfo.parse_merged_records(bad, 1), dg, 1)
+        assert f2

@@ -467,13 +467,13 @@ int vimz_cf_merged_profile(const vimz_cf_merged* m, double seconds[4]) {
 // The statement part as canonical little-endian words: header (magic, segments, len_z, main wires, main constraints, CycleFold wires,
 // CycleFold constraints, runs), the first segment of every run, then per segment: n; z_start; z_end; U = comm_W.x, .y, comm_E.x, .y, u, x0, x1; u = comm_W.x, .y, x0, x1;
 // cfU = comm_W.x, .y, comm_E.x, .y, u, x[0..7); T1.x, .y; T2.x, .y; Tc.x, .y  (every element four words); then per junction T_p.x, .y, T_q.x, .y.
-int64_t vimz_cf_merged_records(const vimz_cf_merged* m, void* buf, size_t cap) {
-  if (!m || !m->vk) return VIMZ_ERR_INVALID;
-  std::vector<uint64_t> o = {CF_MERGED_MAGIC, m->segs.size(), m->vk->pri->len_z, m->vk->pri->n_wires, m->vk->pri->n_c, m->vk->sec.n_w, m->vk->sec.n_c, m->run_start.size()};
-  for (uint32_t r0 : m->run_start) o.push_back(r0);
+static std::vector<uint64_t> cfm_records_words(const uint64_t shape[5] /* len_z, main wires, main constraints, CycleFold wires, CycleFold constraints */,
+                                               const std::vector<CfSegRec>& segs, const std::vector<uint32_t>& run_start, const std::vector<CfJunction>& junctions) {
+  std::vector<uint64_t> o = {CF_MERGED_MAGIC, segs.size(), shape[0], shape[1], shape[2], shape[3], shape[4], run_start.size()};
+  for (uint32_t r0 : run_start) o.push_back(r0);
   auto push = [&](const auto& v) { auto x = std::decay_t<decltype(v)>::from_mont(v); o.resize(o.size() + 4); memcpy(o.data() + o.size() - 4, x.v, 32); };
   auto push_u = [&](const U256w& x) { o.insert(o.end(), x.w, x.w + 4); };
-  for (auto& s : m->segs) {
+  for (auto& s : segs) {
     o.push_back(s.n);
     for (auto& z : s.zs) push(z);
     for (auto& z : s.ze) push(z);
@@ -482,10 +482,71 @@ int64_t vimz_cf_merged_records(const vimz_cf_merged* m, void* buf, size_t cap) {
     push(s.cfU.W.x); push(s.cfU.W.y); push(s.cfU.E.x); push(s.cfU.E.y); push(s.cfU.u); for (auto& e : s.cfU.x) push_u(e);
     push(s.T1.x); push(s.T1.y); push(s.T2.x); push(s.T2.y); push(s.Tc.x); push(s.Tc.y);
   }
-  for (auto& j : m->junctions) { push(j.Tp.x); push(j.Tp.y); push(j.Tq.x); push(j.Tq.y); }
+  for (auto& j : junctions) { push(j.Tp.x); push(j.Tp.y); push(j.Tq.x); push(j.Tq.y); }
+  return o;
+}
+int64_t vimz_cf_merged_records(const vimz_cf_merged* m, void* buf, size_t cap) {
+  if (!m || !m->vk) return VIMZ_ERR_INVALID;
+  const uint64_t shape[5] = {m->vk->pri->len_z, m->vk->pri->n_wires, m->vk->pri->n_c, m->vk->sec.n_w, m->vk->sec.n_c};
+  const std::vector<uint64_t> o = cfm_records_words(shape, m->segs, m->run_start, m->junctions);
   const size_t bytes = o.size() * 8;
   if (buf && cap >= bytes) memcpy(buf, o.data(), bytes);
   return (int64_t)bytes;
+}
+// Host only, no GPU (test hook for the CPU suite): two runs of made-up segment records — commitments are multiples of the generators, the hashes
+// each segment's last instance carries are the true ones of its made-up statement — replayed by cfm_replay.  Output: digest (4 words), the records
+// (vimz_cf_merged_records' layout, len_z = 1), then the accumulator the replay arrives at: n, z_start, z_end (one element each), comm_W.x, .y, comm_E.x,
+// .y, u, x0, x1 of the main side, comm_W.x, .y, comm_E.x, .y, u, x[0..7) of the CycleFold side.  An outside replay (tests/_cyclefold.py) must agree.
+int64_t vimz_cf_selfcheck_merge(int segs_run0, int segs_run1, void* buf, size_t cap) {
+  if (segs_run0 < 1 || segs_run0 > 8 || segs_run1 < 0 || segs_run1 > 8) return VIMZ_ERR_INVALID;
+  try {
+    CfCircuit cfc; cfc.finish();
+    cb::BuilderT<Fe> b;
+    b.len_z = 1; b.n_priv = 0; b.n_wires = 3;
+    b.enforce(cb::LCT<Fe>::constant(Fe::one()), cb::LCT<Fe>::wire(2), cb::LCT<Fe>::wire(1));
+    b.n_linear = 1;
+    vimz_cf vk;
+    vk.c1.reset(new CfMainCircuit(b)); vk.c1->use_worker = false; vk.c1->finish(cfc);
+    const Fe dg = vk.c1->digest;
+    const G1Aff g1 = CycleSide<BnFq>::G(); const G2Aff g2 = CycleSide<BnFr>::G();
+    uint64_t ctr = 0x9e3779b97f4a7c15ull;
+    auto next = [&] { ctr = ctr * 6364136223846793005ull + 1442695040888963407ull; return ctr >> 8; };
+    auto p1 = [&] { const uint64_t k = next(); const uint32_t w[2] = {(uint32_t)k, (uint32_t)(k >> 32)}; return to_affine(scalar_mul(g1, w, 56)); };
+    auto p2 = [&] { const uint64_t k = next(); const uint32_t w[2] = {(uint32_t)k, (uint32_t)(k >> 32)}; return to_affine(host_mul<Fe>(g2, w, 56)); };
+    auto fe = [&] { return Fe::mul(cb::f_from_u64<Fe>(next()), cb::f_from_u64<Fe>(next())); };
+    const int S = segs_run0 + segs_run1;
+    std::vector<CfSegRec> segs((size_t)S);
+    Fe z = cb::f_from_u64<Fe>(5);
+    for (int j = 0; j < S; j++) {
+      CfSegRec& s = segs[(size_t)j];
+      s.n = 1 + (uint64_t)(next() % 7);
+      s.zs = {z}; z = fe(); s.ze = {z};
+      s.UW = p1(); s.UE = p1(); s.U.W = nn_point(s.UW); s.U.E = nn_point(s.UE); s.U.u = fe(); s.U.x0 = fe(); s.U.x1 = fe();
+      s.cfU.W = p2(); s.cfU.E = p2(); s.cfU.u = cb::f_from_u64<Fe>(next());
+      for (auto& e : s.cfU.x) e = to_u256(Fq::mul(cb::f_from_u64<Fq>(next()), cb::f_from_u64<Fq>(next())));
+      s.uW = p1(); s.u.W = nn_point(s.uW);
+      s.u.x0 = cf_hash_main(dg, s.n, s.zs, s.ze.data(), s.U); s.u.x1 = cf_hash_cf(dg, s.cfU);
+      const bool first_of_run = j == 0 || j == segs_run0;
+      s.T1 = first_of_run ? g1_identity() : p1(); s.T2 = p1(); s.Tc = first_of_run ? g2_identity() : p2();
+    }
+    std::vector<uint32_t> run_start = {0};
+    std::vector<CfJunction> junctions;
+    if (segs_run1) { run_start.push_back((uint32_t)segs_run0); CfJunction J; J.Tp = p1(); J.Tq = p2(); junctions.push_back(J); }
+    CfAcc acc; uint32_t fl = 0;
+    if (!cfm_replay(&vk, segs, run_start, junctions, acc, &fl) || fl) return VIMZ_ERR_UNSAT;
+    std::vector<uint64_t> o;
+    auto push = [&](const auto& v) { auto x = std::decay_t<decltype(v)>::from_mont(v); o.resize(o.size() + 4); memcpy(o.data() + o.size() - 4, x.v, 32); };
+    push(dg);
+    const uint64_t shape[5] = {1, b.n_wires, b.n_constraints(), cfc.n_wires(), cfc.n_constraints()};
+    const std::vector<uint64_t> rec = cfm_records_words(shape, segs, run_start, junctions);
+    o.push_back(rec.size()); o.insert(o.end(), rec.begin(), rec.end());
+    o.push_back(acc.n); push(acc.zs[0]); push(acc.ze[0]);
+    push(acc.cW.x); push(acc.cW.y); push(acc.cE.x); push(acc.cE.y); push(acc.u); push(acc.x0); push(acc.x1);
+    push(acc.qW.x); push(acc.qW.y); push(acc.qE.x); push(acc.qE.y); push(acc.qu); for (auto& e : acc.qx) push(e);
+    const size_t bytes = 8 * o.size();
+    if (buf && cap >= bytes) memcpy(buf, o.data(), bytes);
+    return (int64_t)bytes;
+  } catch (const std::exception& e) { return vz_fail(nullptr, VIMZ_ERR_INVALID, e.what()); }
 }
 // side 0 / 1 = main / CycleFold; what = VIMZ_IX_RUNNING_Z, VIMZ_IX_RUNNING_E (canonical), VIMZ_IX_INSTANCE (side 0: comm_W.x, .y, comm_E.x, .y,
 // u, x0, x1; side 1: comm_W.x, .y, comm_E.x, .y, u, x[0..7)) of the folded instances

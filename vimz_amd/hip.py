@@ -673,6 +673,30 @@ def cyclefold_selfcheck_last_step(steps=4):
     return ints(buf[0:4]), ints(buf[4:8]), buf[8:]
 
 
+def cyclefold_selfcheck_merge(segs_run0=3, segs_run1=2):
+    """vimz_cf_selfcheck_merge (host only): (digest, record words, accumulator dict) of made-up segment records replayed by the library."""
+    from . import _lib
+    lib = _lib.lib()
+    lib.vimz_cf_selfcheck_merge.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+    lib.vimz_cf_selfcheck_merge.restype = C.c_int64
+    n = lib.vimz_cf_selfcheck_merge(segs_run0, segs_run1, None, 0)
+    if n < 0:
+        raise _lib.VimzError(int(n), "vimz_cf_selfcheck_merge")
+    buf = np.zeros(n // 8, dtype=np.uint64)
+    assert lib.vimz_cf_selfcheck_merge(segs_run0, segs_run1, _ptr(buf), n) == n
+    w = [int(x) for x in buf]
+    el = lambda pos: sum(w[pos + k] << (64 * k) for k in range(4))
+    dg, nrec = el(0), w[4]
+    rec = buf[5:5 + nrec]
+    pos = 5 + nrec
+    acc = {"n": w[pos], "zs": [el(pos + 1)], "ze": [el(pos + 5)]}
+    pos += 9
+    vals = [el(pos + 4 * k) for k in range(7 + 12)]
+    acc["P"] = [(vals[0], vals[1]), (vals[2], vals[3]), vals[4], vals[5], vals[6]]
+    acc["Q"] = [(vals[7], vals[8]), (vals[9], vals[10]), vals[11], vals[12:19]]
+    return dg, rec, acc
+
+
 class CycleFoldMerged:
     """vimz_cf_merged: ONE proof object out of the CycleFold proofs of contiguous row segments (vimz_cf_merge).  `first`: the prover of the
     first segment (left unchanged; supplies shapes, keys and context and must stay open)."""
