@@ -411,6 +411,9 @@ int vimz_cf_selfcheck(int steps, uint32_t* result, uint64_t counts[8]);
 /* the LAST step of the same host-only run, for an outside restatement of the relation F' enforces: digest, z_0 (one element), then the words of
  * VIMZ_IX_LAST_STEP.  Returns the byte size (copies when buf is large enough); negative on error or when the self-check itself fails. */
 int64_t vimz_cf_selfcheck_last_step(int steps, void* buf, size_t cap);
+/* test hook, host only: `jobs` trivial jobs posted to and awaited from one helper thread of the verifier circuits' witness generators; returns how many
+ * ran.  With VIMZ_WORKER_SPIN_US=0 the helper sleeps between jobs, so that every post is a wake-up. */
+int64_t vimz_worker_selftest(int jobs);
 
 /* ---- ONE proof object out of several row segments: the "host-side sequential final fold" of BASELINE.json's north_star for IVC proofs.
  *      fold_input returns ONE RecursiveSNARK (vimz/src/nova_snark_backend/folding.rs:27-43); row segments of an image folded

@@ -48,3 +48,20 @@ def test_merge_transcript_replayed_with_the_oracle(oracle):
         bad = rec_words.copy(); bad[8 + len(rec["run_start"])] += 1             # n of the first segment
         f2, _ = cfo.replay_merged(oracle, cfo.parse_merged_records(bad, 1), dg, 1)
         assert f2
+
+
+def test_helper_thread_wake_ups_are_not_lost():
+    """The helper threads of the verifier circuits' witness generators spin for a while after a job and then sleep; posting a job to a helper that
+    is just going to sleep must wake it (a release-ordered post could be passed by the read of the helper's `sleeping` flag: seen as a hang of a
+    whole fold once the spin window was shortened).  200 000 post / wait pairs with the helper sleeping between all of them, in a process of its
+    own with a time limit."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import ctypes, sys; sys.path.insert(0, %r); from vimz_amd import _lib; L = _lib.lib(); L.vimz_worker_selftest.restype = ctypes.c_int64; "
+            "print(L.vimz_worker_selftest(200000))" % root)
+    for spin in ("0", "3"):
+        env = dict(os.environ, VIMZ_WORKER_SPIN_US=spin)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and r.stdout.strip().splitlines()[-1] == "200000", (spin, r.stdout[-200:], r.stderr[-300:])

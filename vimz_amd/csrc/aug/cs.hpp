@@ -10,6 +10,7 @@
 // combinations are built, inversions are batched (Montgomery's trick) by the gadgets that need many.
 #pragma once
 #include <stdint.h>
+#include <cstdlib>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -41,6 +42,10 @@ struct Worker {
   std::function<void()> job;
   std::atomic<int> state{0};          // 0 idle, 1 job posted, 2 job done
   std::atomic<bool> sleeping{false}, stop{false};
+  // how long an idle helper spins before it sleeps (VIMZ_WORKER_SPIN_US, default 100 µs).  It used to be 20 ms — "waking a sleeping thread costs more
+  // than the job saves" was measured with the lost wake-up above still in place; without it 0 / 200 / 2 000 / 20 000 µs give the same steps/s (one chain
+  // 753-755, CycleFold 452-457 / 820-833), and idle helpers that do not burn a core each are what a process under a CPU quota needs
+  static long spin_us() { static const long v = [] { const char* e = getenv("VIMZ_WORKER_SPIN_US"); const long x = e ? atol(e) : 100; return x < 0 ? 0 : x; }(); return v; }
   Worker() { th = std::thread([this] { loop(); }); }
   ~Worker() { stop = true; { std::lock_guard<std::mutex> g(m); } cv.notify_all(); th.join(); }
   void loop() {
@@ -50,10 +55,10 @@ struct Worker {
       while (state.load(std::memory_order_acquire) != 1) {
         if (stop) return;
         std::this_thread::yield();      // free on an idle core; hands the core over when there is only one
-        if ((++spins & 63) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) {
+        if ((++spins & 63) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(spin_us())) {
           std::unique_lock<std::mutex> lk(m);
-          sleeping = true;
-          cv.wait(lk, [this] { return state.load() == 1 || stop; });
+          sleeping.store(true, std::memory_order_seq_cst);
+          cv.wait(lk, [this] { return state.load(std::memory_order_seq_cst) == 1 || stop; });
           sleeping = false;
           if (stop) return;
           break;
@@ -65,8 +70,10 @@ struct Worker {
   }
   void start(std::function<void()> f) {
     job = std::move(f);
-    state.store(1, std::memory_order_release);
-    if (sleeping.load()) { { std::lock_guard<std::mutex> g(m); } cv.notify_all(); }
+    // (sequentially consistent, like the helper's `sleeping = true` and its re-check of `state` under the lock: with a release store the read of
+    //  `sleeping` below could pass it — the helper goes to sleep, nobody wakes it, wait() spins for ever.  Seen as a hang once the spin window was short.)
+    state.store(1, std::memory_order_seq_cst);
+    if (sleeping.load(std::memory_order_seq_cst)) { { std::lock_guard<std::mutex> g(m); } cv.notify_all(); }
   }
   void wait() { while (state.load(std::memory_order_acquire) != 2) std::this_thread::yield(); state.store(0, std::memory_order_relaxed); }
 };

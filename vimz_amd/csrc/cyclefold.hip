@@ -901,6 +901,15 @@ static int cf_selfcheck_core(int steps, uint32_t* result, uint64_t counts[8], st
   } catch (const std::exception& e) { return vz_fail(nullptr, VIMZ_ERR_INVALID, e.what()); }
 }
 int vimz_cf_selfcheck(int steps, uint32_t* result, uint64_t counts[8]) { return cf_selfcheck_core(steps, result, counts, nullptr); }
+// test hook, host only: `jobs` trivial jobs through one helper thread (aug::Worker), each posted and waited for; returns how many ran.  With
+// VIMZ_WORKER_SPIN_US=0 the helper sleeps between jobs: every post is a wake-up (a lost one would hang this call).
+int64_t vimz_worker_selftest(int jobs) {
+  if (jobs < 0) return VIMZ_ERR_INVALID;
+  aug::Worker w;
+  std::atomic<int64_t> ran{0};
+  for (int i = 0; i < jobs; i++) { w.start([&] { ran.fetch_add(1, std::memory_order_relaxed); }); w.wait(); }
+  return ran.load();
+}
 // the same run's LAST step for an outside restatement of the relation (tests/_cyclefold.py::step_relation, on the CPU): digest, z_0 (one element:
 // the trivial step circuit's state), then the words of VIMZ_IX_LAST_STEP.  Returns the byte size (copies when buf is large enough).
 int64_t vimz_cf_selfcheck_last_step(int steps, void* buf, size_t cap) {
