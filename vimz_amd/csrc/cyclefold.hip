@@ -173,7 +173,7 @@ int cf_fold_core(vimz_cf* v, const uint64_t* step_inputs, size_t nsteps) {
         // the next step folds THIS row's instance: the step rows of that cross term and their commitment start now, on stream 3
         P_TRY(hipEventRecord(v->ev_fold, s));
         P_TRY(hipStreamWaitEvent(v->s3, v->ev_fold, 0));
-        P_TRY(hipStreamWaitEvent(v->s3, bb.ev[r], 0));
+        { const double tw = now_s(); P_TRY(wait_row_flag(bb, r, bb.ev[r])); v->ph_s[6] += now_s() - tw; }
         hipLaunchKernelGGL(k_cross_term<Fr>, dim3(stream_grid(sc)), dim3(256), 0, v->s3, sc, p->AZ, p->BZ, p->CZ, v->u_run, az, bz, cz, Fe::one(), p->T);
         P_TRY(hipGetLastError());
         P_TRY(msm_launch<BnG1>(v->s3, v->ws3, p->ck->d, p->T, sc, 1, 0, v->pin_ts, &v->plan_Ts, nullptr, 0, p->ck->tables ? &job.tbl : nullptr));
@@ -210,7 +210,8 @@ int cf_fold_core(vimz_cf* v, const uint64_t* step_inputs, size_t nsteps) {
       v->cfU = o.cfU_new;
       // ---- fresh main instance: verifier wires behind the step circuit's, verifier rows of (A,B,C)·z, commitment ---------------------------
       memcpy(pin_aug, aug.data(), 32 * aw);
-      P_TRY(hipStreamWaitEvent(s, bb.ev[r], 0));
+      // (waited for on the HOST, not by a barrier on this stream: ivc.hip)
+      { const double tw = now_s(); P_TRY(wait_row_flag(bb, r, bb.ev[r])); v->ph_s[6] += now_s() - tw; }
       P_TRY(upload_pinned(s, Zi + 8 * sw, pin_aug, 32 * aw));
       P_TRY(hipEventRecord(v->ev_fork, s));
       P_TRY(hipStreamWaitEvent(v->s2, v->ev_fork, 0));
@@ -225,7 +226,7 @@ int cf_fold_core(vimz_cf* v, const uint64_t* step_inputs, size_t nsteps) {
         v->t_ver_for = (int64_t)i + 1;
       }
       { const double tw = now_s();
-        P_TRY(hipEventSynchronize(bb.ev[r]));      // (polling hipEventQuery instead measured worse: three provers' threads spinning on the runtime)
+        P_TRY(wait_row_flag(bb, r, bb.ev[r]));      // (a pinned word, not the producer's event: prover_internal.hpp)
         v->ph_s[6] += now_s() - tw; }
       const G1Aff cW_step = msm_finish<BnG1>(p->planB, (char*)bb.pin + r * pin_stride);
       { const double tw = now_s(); P_TRY(hipStreamSynchronize(v->s2)); v->ph_s[7] += now_s() - tw; }

@@ -24,7 +24,8 @@ struct vimz_ctx {
   size_t scratch_bytes = 0;
   // Streams of provers that were freed, kept for the provers created next (vz_stream_acquire / vz_stream_release): no stream is created and
   // destroyed per fold call (the state-chain helper's) or per prover, and a context's later provers sit on the streams its first ones had.
-  // (Tried as a cure for the slow concurrent folds of provers created after others were destroyed, DESIGN.md §5c: it is not one.)
+  // (Not the cure for the slow folds of provers created after others had folded on the context — that was a priority inversion between
+  // the streams, prover_internal.hpp: wait_row_flag — but kept: no stream creation per fold call.)
   std::mutex stream_mu;
   std::vector<std::pair<int, hipStream_t>> spare_streams;     // (priority, stream)
 };

@@ -116,7 +116,7 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
     auto& S = v->t1[step & 1];
     P_TRY(hipEventRecord(v->ev_fold, s));
     P_TRY(hipStreamWaitEvent(v->s3, v->ev_fold, 0));
-    P_TRY(hipStreamWaitEvent(v->s3, b2.ev[row], 0));
+    P_TRY(wait_row_flag(b2, row, b2.ev[row]));      // (on the host: prover_internal.hpp, wait_row_flag)
     hipLaunchKernelGGL(k_cross_term<Fr>, dim3(stream_grid(sc)), dim3(256), 0, v->s3, sc, p->AZ, p->BZ, p->CZ, v->u1_run,
                        b2.az + 8 * row * nc, b2.bz + 8 * row * nc, b2.cz + 8 * row * nc, Fe::one(), S.buf);
     P_TRY(hipGetLastError());
@@ -133,17 +133,17 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
     auto& Scur = v->t1[par]; auto& Soth = v->t1[par ^ 1];
     const bool fold_E = a.i > 0, hasB = fold_E && Scur.hasB;
     const uint32_t *az = a.cur->az + 8 * a.r * nc, *bz = a.cur->bz + 8 * a.r * nc, *cz = a.cur->cz + 8 * a.r * nc;
-    if (hasB) P_TRY(hipStreamWaitEvent(v->s3, a.cur->ev_d[a.r], 0));
+    if (hasB) P_TRY(wait_row_flag(*a.cur, a.cur->flag_rows + a.r, a.cur->ev_d[a.r]));
     // first output of the pass: next1 into the other slot if it is needed, else the lookahead into this slot (read, then overwritten)
     const RowAt* t = a.need1 ? &a.next1 : a.look ? &a.next2 : nullptr;
     uint32_t* out = a.need1 ? Soth.buf : a.look ? Scur.buf : nullptr;
-    if (t) P_TRY(hipStreamWaitEvent(v->s3, t->b->ev[t->row], 0));
+    if (t) P_TRY(wait_row_flag(*t->b, t->row, t->b->ev[t->row]));      // (the producer is a batch ahead: no wait in the steady state)
     hipLaunchKernelGGL(k_fold_cross<Fr>, dim3(stream_grid(sc)), dim3(256), 0, v->s3, sc, p->AZ, p->BZ, p->CZ, p->E, (const uint32_t*)Scur.buf, fold_E ? 1 : 0, a.rho,
                        hasB ? 1 : 0, v->rho_prev, hasB ? (const uint32_t*)(a.cur->d + 8 * a.r * sc) : (const uint32_t*)nullptr, v->u1_run, az, bz, cz,
                        out, t ? t->b->az + 8 * t->row * nc : nullptr, t ? t->b->bz + 8 * t->row * nc : nullptr, t ? t->b->cz + 8 * t->row * nc : nullptr, Fe::one());
     P_TRY(hipGetLastError());
     if (a.need1 && a.look) {      // both (the first step of a call): the lookahead as a pass of its own, after this slot's vector was read
-      P_TRY(hipStreamWaitEvent(v->s3, a.next2.b->ev[a.next2.row], 0));
+      P_TRY(wait_row_flag(*a.next2.b, a.next2.row, a.next2.b->ev[a.next2.row]));
       hipLaunchKernelGGL(k_cross_term<Fr>, dim3(stream_grid(sc)), dim3(256), 0, v->s3, sc, p->AZ, p->BZ, p->CZ, v->u1_run,
                          a.next2.b->az + 8 * a.next2.row * nc, a.next2.b->bz + 8 * a.next2.row * nc, a.next2.b->cz + 8 * a.next2.row * nc, Fe::one(), Scur.buf);
       P_TRY(hipGetLastError());
@@ -222,7 +222,9 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
       v->U2 = o1.U_new;
       // ---- fresh primary instance: upload the verifier wires, finish (A,B,C)·z and the commitment ---------------------------------
       memcpy(pin_aug1, aug1.data(), 32 * aw1);
-      P_TRY(hipStreamWaitEvent(s, bb.ev[r], 0));
+      // (waited for on the HOST, not by a barrier on this stream: a high-priority queue stalled behind the producer's event keeps the
+      //  producer's low-priority queues from being served — once a producer fell behind it stayed behind, 10× slower: DESIGN.md §5c)
+      P_TRY(wait_row_flag(bb, r, bb.ev[r]));
       P_TRY(upload_pinned(s, Zi + 8 * sw, pin_aug1, 32 * aw1));
       // the commitment to the verifier wires needs the upload only: it starts first, on stream 2
       P_TRY(hipEventRecord(v->ev_fork, s));
@@ -254,7 +256,6 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
       v->ph_s[IP_LAUNCH] += now_s() - t0;
       t0 = now_s();
       v->c2.precompute_statement(i + 1, v->z0_sec, &zero_q);      // likewise for the secondary circuit, under the primary half's MSMs
-      P_TRY(hipEventSynchronize(bb.ev[r]));
       G1Aff cW_step = msm_finish<BnG1>(p->planB, (char*)bb.pin + r * pin_stride);
       // the large MSM's host tail (Horner over 24 window sums, ≈0.1 ms) is taken whenever its stream turns out to be done:
       // before the small ones if it already is, so that it overlaps what is still running
@@ -287,7 +288,7 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
       // the device works on the verifier rows (the producer committed to negB_i long ago)
       G1 lookB = G1::identity();
       if (i > 0 && slot.hasB) {
-        P_TRY(hipEventSynchronize(bb.ev_d[r]));
+        P_TRY(wait_row_flag(bb, bb.flag_rows + r, bb.ev_d[r]));
         const G1Aff cD = msm_finish<BnG1>(p->planD, (char*)bb.pin_d + r * pin_stride);
         if (!aff_is_identity(cD)) {
           G1 acc = from_affine(cD);                       // the leading one of rho = 2^128 + low

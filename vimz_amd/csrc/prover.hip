@@ -42,6 +42,7 @@ void vimz_prover_free(vimz_prover* p) {
       if (bb.pin_d) hipHostFree(bb.pin_d);
       if (bb.pin) hipHostFree(bb.pin);
       if (bb.status_host) hipHostFree(bb.status_host);
+      if (bb.row_flag) hipHostFree(bb.row_flag);
     }
     p->wsB.release();
     hipFree(p->priv_all_d); hipFree(p->zs_all_d); hipFree(p->job_all_d);
@@ -143,6 +144,8 @@ int vz_prover_create_layout(vimz_ctx* ctx, const vimz_circuit* circuit, const vi
     if ((e = hipEventCreateWithFlags(&bb.wit_done, hipEventDisableTiming)) != hipSuccess) return fail_free("event", e);
     if ((e = hipHostMalloc(&bb.pin, 4 * (size_t)XYZZ_WORDS * MSM_MAX_WINDOWS * B)) != hipSuccess) return fail_free("pinned", e);
     if ((e = hipHostMalloc((void**)&bb.status_host, 4 * B)) != hipSuccess) return fail_free("pinned", e);
+    if ((e = hipHostMalloc((void**)&bb.row_flag, 8 * B)) != hipSuccess) return fail_free("pinned", e);
+    memset(bb.row_flag, 0, 8 * B); bb.flag_rows = B;
     bb.has_d.assign(B, 0);
     if (p->ivc) {        // per row: (A,B,C)·z done (the rows of a batch alternate between two producer streams)
       bb.ev_p.resize(B);
@@ -341,7 +344,7 @@ static int fold_core(vimz_prover* p, const uint64_t* step_inputs, const uint64_t
     std::vector<Prep> prep(rows);
     auto do_prep = [&](size_t r) -> int {          // host side of the fresh instance of row r
       double tp = now_s();
-      P_TRY(hipEventSynchronize(bb.ev[r]));
+      P_TRY(wait_row_flag(bb, r, bb.ev[r]));
       prep[r].cW2 = msm_finish<BnG1>(p->planB, (char*)bb.pin + r * pin_stride);
       Fe zd = r == 0 ? p->zdigest : prep[r - 1].zdig;
       const Fe* znext = zs.data() + (first + r + 1) * p->len_z;
@@ -352,7 +355,7 @@ static int fold_core(vimz_prover* p, const uint64_t* step_inputs, const uint64_t
     };
     MsmPlan planT{};
     auto launch_T = [&](size_t r) -> int {         // cross term + MSM(T) of row r, asynchronous on stream A
-      P_TRY(hipStreamWaitEvent(s, bb.ev[r], 0));
+      P_TRY(wait_row_flag(bb, r, bb.ev[r]));      // (on the host, not by a barrier on this high-priority stream: prover_internal.hpp)
       hipLaunchKernelGGL(k_cross_term<Fr>, dim3(stream_grid(nc)), dim3(256), 0, s, nc, p->AZ, p->BZ, p->CZ, p->u,
                          bb.az + 8 * r * nc, bb.bz + 8 * r * nc, bb.cz + 8 * r * nc, Fe::one(), p->T);
       P_TRY(hipGetLastError());
@@ -375,7 +378,7 @@ static int fold_core(vimz_prover* p, const uint64_t* step_inputs, const uint64_t
     if ((rc = do_prep(0))) return rc;
     if (p->steps == 0) {
       // base case: the running instance IS the first fresh instance (u = 1, E = 0), as RecursiveSNARK::new does
-      P_TRY(hipStreamWaitEvent(s, bb.ev[0], 0));
+      P_TRY(wait_row_flag(bb, 0, bb.ev[0]));
       P_TRY(hipMemcpyAsync(p->Zrun, bb.Z, 32 * nw, hipMemcpyDeviceToDevice, s));
       P_TRY(hipMemcpyAsync(p->AZ, bb.az, 32 * nc, hipMemcpyDeviceToDevice, s));
       P_TRY(hipMemcpyAsync(p->BZ, bb.bz, 32 * nc, hipMemcpyDeviceToDevice, s));

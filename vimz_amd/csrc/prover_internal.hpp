@@ -144,6 +144,10 @@ struct vimz_prover {
     uint32_t* d = nullptr; void* pin_d = nullptr;
     std::vector<hipEvent_t> ev_p, ev_d;   // per row: (A,B,C)·z done on the producer's stream; the commitment to d done on stream sD
     std::vector<uint8_t> has_d;
+    // Host-side hand-over of a row: behind the row's last kernel the producer's stream stores this filling's generation into a pinned
+    // word (k_row_flag) and the fold thread reads that word (wait_row_flag) — no runtime call on the producer's event from another
+    // thread.  [0, B): the fresh instance's work (beside ev[r]); [B, 2B): the lookahead's commitment (beside ev_d[r]).
+    uint32_t* row_flag = nullptr; uint32_t gen = 0; size_t flag_rows = 0;
   } buf[2];
   bool want_d = false;
   hipStream_t sD = nullptr;      // = sH (a stream of its own for the lookahead's commitments — a sixth — shifted the streams' hardware
@@ -442,6 +446,36 @@ static void plan_batches(FoldJob& J, size_t first, size_t n, size_t B) {
   for (size_t off = 0; off < n; off += per) { J.bfirst.push_back(first + off); J.brows.push_back(std::min(per, n - off)); }
 }
 
+template <int DUMMY>
+__global__ void k_row_flag(uint32_t* flag, uint32_t v) { __hip_atomic_store(flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+static inline hipError_t mark_row(hipStream_t st, vimz_prover::BatchBuf& bb, size_t idx) {
+  hipLaunchKernelGGL(k_row_flag<0>, dim3(1), dim3(1), 0, st, bb.row_flag + idx, bb.gen);
+  return hipGetLastError();
+}
+// The fold thread's wait for row idx of a batch that has been issued (the word is written in stream order behind the row's results, which
+// went to pinned memory too), and the ONLY way the fold's streams depend on the producer's: what they launch for a row is launched after
+// this returned, never behind a hipStreamWaitEvent on the producer's event.  The producer's streams have the lowest priority, the fold's
+// the highest; a high-priority queue stalled in a barrier behind a producer's event still counts as having work, so the producer's queues
+// were served in leftovers exactly when the fold was waiting for them: a producer that once fell behind stayed behind, and provers
+// created after others had folded on the same context ran 10× slower (20–250 steps/s instead of 800–930: DESIGN.md §5c).  Nor is the
+// event synchronised on from this thread (that goes through the runtime's lock of the producer's stream, which the producer's
+// thread needs for every launch); it is looked at now and then, for a device error, and ends the wait if it completed.
+static inline hipError_t wait_row_flag(const vimz_prover::BatchBuf& bb, size_t idx, hipEvent_t ev) {
+  const uint32_t want = bb.gen;
+  const uint32_t* f = bb.row_flag + idx;
+  double t_start = 0;
+  for (uint32_t spins = 1; __atomic_load_n(f, __ATOMIC_ACQUIRE) != want; spins++) {
+    if (spins & 31) continue;
+    std::this_thread::yield();
+    if ((spins & 0x3ffff) == 0) {
+      const hipError_t q = hipEventQuery(ev);
+      if (q == hipSuccess) break;                     // (recorded behind the word's kernel)
+      if (q != hipErrorNotReady) return q;
+      if (t_start == 0) t_start = now_s(); else if (now_s() - t_start > 120.0) return hipErrorNotReady;      // fails loudly instead of hanging
+    }
+  }
+  return hipSuccess;
+}
 static int fold_issue(vimz_prover* p, const FoldJob& J, size_t k);
 
 // Host CPUs this process can really use: what the OS shows, capped by the cgroup's CPU quota (cpu.max / cfs_quota_us).  A GPU box shows
@@ -505,6 +539,7 @@ static int fold_issue_d(vimz_prover* p, const FoldJob& J, size_t k, size_t r, hi
   hipLaunchKernelGGL(k_fresh_cross_neg<Fr>, dim3(stream_grid(sc)), dim3(256), 0, sp, sc, az0, bz0, cz0, bb.az + 8 * r * nc, bb.bz + 8 * r * nc, bb.cz + 8 * r * nc, d);
   P_TRY(hipGetLastError());
   P_TRY(msm_launch<BnG1>(sp, ws, p->ck->d, d, sc, 1, 0, (char*)bb.pin_d + r * FoldJob::pin_stride, &p->planD, nullptr, 1, nullptr));
+  P_TRY(mark_row(sp, bb, bb.flag_rows + r));
   P_TRY(hipEventRecord(bb.ev_d[r], sp));
   bb.has_d[r] = 1;
   return VIMZ_OK;
@@ -536,6 +571,7 @@ static int fold_head_batch(vimz_prover* p, FoldJob& J, size_t rows) {
     p->head_rows_cap = cap_rows;
   }
   auto& bb = p->buf[0];
+  bb.gen++;      // (row flags of this filling: wait_row_flag)
   hipStream_t sh = p->sH;
   static const bool dbg_t = getenv("VIMZ_DEBUG_TIMING") != nullptr;
   const double th0 = now_s();
@@ -598,6 +634,7 @@ static int fold_head_batch(vimz_prover* p, FoldJob& J, size_t rows) {
     launch_spmv(p, sh, Zi, bb.az + 8 * r * nc, bb.bz + 8 * r * nc, bb.cz + 8 * r * nc, 1);
     if (p->ivc) P_TRY(hipEventRecord(bb.ev_p[r], sh));
     P_TRY(msm_launch<BnG1>(sh, p->wsH, p->ck->d, Zi + 8 * (size_t)p->c0, sw - p->c0, 1, 0, (char*)bb.pin + r * FoldJob::pin_stride, &p->planB, nullptr, 1, p->ck->tables ? &J.tbl : nullptr));
+    P_TRY(mark_row(sh, bb, r));
     P_TRY(hipEventRecord(bb.ev[r], sh));
     { int rc = fold_issue_d(p, J, 0, r, sh, p->wsH); if (rc) return rc; }
   }
@@ -802,6 +839,7 @@ static int fold_issue(vimz_prover* p, const FoldJob& J, size_t k) {
   vimz_ctx* ctx = p->ctx;
   const size_t nw = p->n_wires, nc = p->n_c, sw = p->step_wires;
   auto& bb = p->buf[k & 1];
+  bb.gen++;      // (row flags of this filling: wait_row_flag)
   const size_t first = J.first(k), rows = J.rows(k);
   hipStream_t sb = p->sB;
   if (J.head && k == 1) P_TRY(hipStreamWaitEvent(sb, p->ev_head, 0));      // (orders the two MSM workspaces' users; the head batch is long done)
@@ -831,6 +869,7 @@ static int fold_issue(vimz_prover* p, const FoldJob& J, size_t k) {
     launch_spmv(p, st, Zi, bb.az + 8 * r * nc, bb.bz + 8 * r * nc, bb.cz + 8 * r * nc, 1);
     if (p->ivc) P_TRY(hipEventRecord(bb.ev_p[r], st));
     P_TRY(msm_launch<BnG1>(st, ws, p->ck->d, Zi + 8 * (size_t)p->c0, sw - p->c0, 1, 0, (char*)bb.pin + r * FoldJob::pin_stride, &p->planB, nullptr, 1, p->ck->tables ? &J.tbl : nullptr));
+    P_TRY(mark_row(st, bb, r));
     P_TRY(hipEventRecord(bb.ev[r], st));
     { int rc = fold_issue_d(p, J, k, r, st, ws); if (rc) return rc; }
   }
