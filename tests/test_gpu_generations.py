@@ -44,5 +44,6 @@ def test_later_generations_of_provers_on_the_same_contexts_fold_as_fast_as_the_f
         for c in ctxs:
             c.close()
     # measured: 920 / 810–840 / 680–720 / 920 steps/s; before the cure the second and third generations ran at 20–250
-    assert second > 0.6 * first and fourth > 0.6 * first, (first, second, third, fourth)
-    assert third > 0.45 * first, (first, second, third, fourth)
+    # (thresholds well below what is measured and well above the 0.03–0.25 of the old behaviour: a timing test must not be a flaky one)
+    assert second > 0.45 * first and fourth > 0.45 * first, (first, second, third, fourth)
+    assert third > 0.35 * first, (first, second, third, fourth)
