@@ -48,6 +48,7 @@ if not skip_nova:
         print(f"nova merged fold {rep}: {96/dt:.0f} steps/s; throttled periods +{c1['nr_throttled']-c0['nr_throttled']}, throttled {1e-6*(c1['throttled_usec']-c0['throttled_usec']):.2f} s, cpu {1e-6*(c1['usage_usec']-c0['usage_usec']):.2f} s in {dt:.2f} s wall; threads {nthreads()}", flush=True)
         assert p.verify(96, z0) == 0
         p.close()
+        print("   prover 0 phases, ms:", {k: round(1e3 * v[0], 1) for k, v in ivcs[0].profile().items()}, flush=True)
     if mode != 'keep':
         for i in ivcs: i.close()
         params.free()
