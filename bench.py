@@ -98,6 +98,21 @@ def cpu_baseline(circuit, steps, z0, ck_host, budget_s, threads):
     return n / dt, dt, n, {k: v / max(1, n) for k, v in ph.items()}
 
 
+def memory_now(torch, device, dist=None):
+    """The peak-memory column of the reference's table (README.md:48-56; benchmark.sh:4-8 reads it from /usr/bin/time): device memory in
+    use on this rank's GPU right after the timed job (the provers keep every buffer they ever needed until they are closed, so in use
+    now = peak; all processes on the device count) and this process's peak resident set."""
+    import resource
+    dev = None
+    try:
+        free, total = torch.cuda.mem_get_info(device)
+        dev = int(total - free)
+    except Exception:
+        pass
+    rss = int(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss) * 1024
+    return {"device_bytes": dev, "host_rss_bytes": rss, "note": "rank 0's GPU and process; device: in use right after the timed job (buffers are kept until close, other processes on the GPU included); host: ru_maxrss"}
+
+
 def usable_cores():
     """Host cores this process may actually use: the CPU affinity mask capped by the cgroup's CPU quota (the GPU boxes show 256 logical
     CPUs and grant 16: threads beyond the quota only get the whole group throttled)."""
@@ -182,29 +197,46 @@ def main_ivc(args, rank, world, dist, torch, ctxs, circuit, params, steps_all, g
         return fold_segments_merged(ivcs, rows, z_start, timings)
 
     # warm-up: a proof of W rows, made and dropped exactly like the timed one (first-call allocations, pinned buffers, thread pools)
-    if W:
-        prove(rows_warm, z0).close()
-    shm = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp", f"vimz_bench_{os.environ.get('MASTER_PORT', '0')}_r")
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"      # (only used where the ranks cannot hand their proofs over by HIP IPC)
+    sharded = world > 1 and not args.proof_set
+    if W:      # (N > 1: through the same sharded path — digests exchange, tree of hand-overs — so that connections and mappings exist)
+        if sharded:
+            warm_all = np.ascontiguousarray(steps_all[[glob[r * (W + 2 * K) + i] for r in range(world) for i in range(W)]])
+            pw = prove_sharded(ivcs, warm_all, z0, rank, world, dist, shm_dir=shm)
+        else:
+            pw = prove(rows_warm, z0)
+        if pw is not None:
+            pw.close()
     tm = {}
     sync_all()
     t0 = time.time()
     # the timed job: ONE proof of world x K rows from z0 (proof sets: every rank its own proof of K rows).  Rank r's rows start at the
     # state after the r·K rows of the ranks before it: rank 0 runs that hash-only chain once and hands every rank its start state;
     # the ranks' merged proofs go to rank 0 through node-local shared memory and are folded in row order
-    if world > 1 and not args.proof_set:
+    if sharded:
         timed_all = np.ascontiguousarray(steps_all[[glob[r * (W + 2 * K) + W + i] for r in range(world) for i in range(K)]])
-        proof = prove_sharded(ivcs, timed_all, z0, rank, world, dist, tm, shm_prefix=shm)
+        proof = prove_sharded(ivcs, timed_all, z0, rank, world, dist, tm, shm_dir=shm)
     else:
         proof = prove(rows_timed, z0, tm)
+        tm["t_ready"] = tm["t_done"] = time.time()
     sync_all()
     dt = time.time() - t0
-    t_fold = dt - tm.get("final_fold_s", 0.0)
+    mem = memory_now(torch, ctxs[0].device)
     state_chain_s, final_fold_s = tm.get("state_chain_s", 0.0), tm.get("final_fold_s", 0.0)
     prof1 = [ivc.profile() for ivc in ivcs]
+    # the tail the ranks' final fold adds to the job: from the moment the LAST rank has its own proof to the moment rank 0 holds the one
+    # object (the ranks of a node share the wall clock); the prologue: from the start to the moment the LAST rank knows its start state
+    t_ready_max, t_done_0, prologue_max = tm["t_ready"], tm["t_done"], tm.get("state_chain_s", 0.0)
+    tree = None
     if dist is not None:
-        t = torch.tensor([dt, t_fold], dtype=torch.float64)
+        t = torch.tensor([dt, tm["t_ready"], prologue_max, tm.get("digests_s", 0.0), tm.get("allgather_s", 0.0), tm.get("chain_s", 0.0),
+                          tm.get("final_fold_s", 0.0), tm.get("final_fold_wait_s", 0.0)], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt, t_fold = float(t[0]), float(t[1])
+        dt, t_ready_max, prologue_max = float(t[0]), float(t[1]), float(t[2])
+        tree = {"hand_overs_to_rank0": tm.get("hand_overs"), "digests_s_max": float(t[3]), "allgather_s_max": float(t[4]), "chain_s_max": float(t[5]), "merging_s_max_over_ranks": float(t[6]),
+                "waiting_for_partner_s_max_over_ranks": float(t[7])}
+    final_tail_s = max(0.0, t_done_0 - t_ready_max) if world > 1 else 0.0
+    t_fold = dt - final_tail_s
     timed_rows = K
     timed_total = K * world
     # acceptance: the ONE object verifies for exactly (world x K steps, z0)   [proof sets: every rank's own proof for (K, z0)]
@@ -372,8 +404,13 @@ def main_ivc(args, rank, world, dist, torch, ctxs, circuit, params, steps_all, g
             "verify_s": verify_s,
             "state_chain_s": state_chain_s,
             "merge_s": tm.get("merge_s", 0.0),
-            "final_fold_s": final_fold_s,
+            "final_fold_s": final_tail_s if world > 1 else 0.0,
+            "final_fold_rank0_merging_s": final_fold_s,
+            "prologue_s_max_over_ranks": prologue_max if world > 1 else 0.0,
+            "sharding": tree,
+            "gpus_shared": bool(getattr(args, "gpus_shared", False)),
             "fold_s": t_fold,
+            "peak_device_bytes": mem["device_bytes"], "peak_host_rss_bytes": mem["host_rss_bytes"], "memory_note": mem["note"],
             "merge_profile_s": merge_prof,
             "one_chain": one_chain,
             "sonobe_backend": sonobe,
@@ -415,6 +452,36 @@ def main_ivc(args, rank, world, dist, torch, ctxs, circuit, params, steps_all, g
         dist.destroy_process_group()
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher's environment: start the N ranks (one process per GPU) the way the driver would —
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...` — as a CHILD
+    process, before anything here has touched a GPU; relay its one JSON line and exit with its code.  (The counterpart of
+    /root/reference benchmark.sh:25-58, which starts and waits for its processes itself.)"""
+    import socket
+    import subprocess
+    import torch
+    if torch.cuda.device_count() < args.gpus and not args.share_gpus:      # (counting devices does not initialise the GPU)
+        print(f"[bench] --gpus {args.gpus} but {torch.cuda.device_count()} device(s) visible; --share-gpus lets ranks share a device (not a scaling measurement)", file=sys.stderr)
+        return 3
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    env = dict(os.environ)
+    if _vimz_lib.HW_QUEUES_DEFAULTED:
+        env.pop("GPU_MAX_HW_QUEUES", None)      # every rank picks its own (8 with a GPU to itself, 4 when ranks share one)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, cwd=os.getcwd())
+    got = False
+    for line in proc.stdout:
+        if line.startswith("{") and '"metric"' in line:
+            got = True
+        sys.stdout.write(line); sys.stdout.flush()
+    rc = proc.wait()
+    if rc == 0 and not got:
+        print("[bench] the ranks exited without printing a result line", file=sys.stderr)
+        rc = 1
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -433,8 +500,17 @@ def main():
     ap.add_argument("--mode", default="ivc", choices=["ivc", "accumulator"])
     ap.add_argument("--window-tables", type=int, default=0, help="window tables of the primary key in HBM (vimz_bases_precompute): 11 = per-window buckets, no host Horner; 13..16 = one shared bucket set; 0 = none")
     ap.add_argument("--proof-set", default="", help="comma-separated transformations: rank r proves proof_set[r %% len] (BASELINE config 5: independent proofs, replicas only)")
+    ap.add_argument("--share-gpus", action="store_true", help="allow more ranks than visible GPUs (ranks r and r + n_devices share a device): evidence lines "
+                    "on a one-GPU box, never a scaling claim; the line says so in `gpus_shared`")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        ap.error("--gpus must be at least 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        print(f"[bench] --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')} ranks: refusing to report a line for another N", file=sys.stderr)
+        sys.exit(2)
     rank = int(os.environ.get("RANK", "0"))
     if args.proof_set:
         ps = [t.strip() for t in args.proof_set.split(",") if t.strip()]
@@ -453,8 +529,12 @@ def main():
             dist.barrier()
         finally:
             sys.stdout.flush(); os.dup2(keep, 1); os.close(keep)
-    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 1
-    device = local_rank % max(1, ndev)            # (several ranks may share a GPU when the node has fewer GPUs than ranks)
+    ndev = torch.cuda.device_count()              # (counting devices does not initialise the GPU)
+    if ndev < world and not args.share_gpus:
+        print(f"[bench] --gpus {world} but {ndev} device(s) visible; --share-gpus lets ranks share a device (not a scaling measurement)", file=sys.stderr)
+        sys.exit(3)
+    args.gpus_shared = ndev < world
+    device = local_rank % max(1, ndev)            # (--share-gpus: several ranks may share a GPU when the node has fewer GPUs than ranks)
     if torch.cuda.is_available():
         torch.cuda.set_device(device)
 

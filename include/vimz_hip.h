@@ -392,28 +392,13 @@ int64_t vimz_cf_merged_export(vimz_cf_merged* m, int side, int what, void* buf, 
 /* KZG openings (vimz_kzg_open over ck_main as the SRS) of the FOLDED main instance: which = 0 comm_W, 1 comm_E.  For a merged proof of one segment the
  * folded instance is U_{i+1} = NIFS(U_i, u_i), the one Sonobe's decider opens (decider.rs:13-21).  Canonical in and out. */
 int vimz_cf_merged_kzg_open(vimz_cf_merged* m, int which, const uint64_t z[4], uint64_t eval_out[4], uint64_t proof_xy[8]);
-/* test hook, host only (no GPU): two runs of made-up, self-consistent segment records replayed by the library; output = digest, word count + records,
- * the accumulator arrived at (layout: cyclefold_merge.hip) — for an outside replay of the merge transcript in the CPU suite.  Returns the byte size. */
-int64_t vimz_cf_selfcheck_merge(int segs_run0, int segs_run1, void* buf, size_t cap);
 /* IVC state chain only (as vimz_ivc_state_chain): the state at which a row segment proven by another vimz_cf starts */
 int vimz_cf_state_chain(vimz_cf* v, const uint64_t* z_start, const uint64_t* step_inputs, size_t nsteps, uint64_t* zs_out);
 /* ... in its two parts, as vimz_ivc_row_digests / vimz_ivc_chain_from_digests */
 size_t vimz_cf_digest_stride(const vimz_cf* v);
 int vimz_cf_row_digests(vimz_cf* v, const uint64_t* step_inputs, size_t nsteps, uint64_t* digests_out);
 int vimz_cf_chain_from_digests(vimz_cf* v, const uint64_t* z_start, const uint64_t* step_inputs, const uint64_t* digests, size_t nsteps, uint64_t* zs_out);
-/* test hooks.  poke: overwrite one element (canonical) of a witness vector on the device — which = 0 running main Z, 1 last fresh main Z,
- * 2 running CycleFold Z, 3 running main E, 4 running CycleFold E.  selfcheck: host only, no GPU — `steps` steps over the trivial step
- * circuit with made-up commitments, every witness checked against its R1CS and every in-circuit fold against field / curve arithmetic
- * (result 0 = good; counts: F' wires, constraints, CycleFold wires, constraints, then of the last step's
- * flip test — every wire incremented by one must violate a row — wires of F' flipped, unnoticed, wires of the CycleFold circuit flipped, unnoticed). */
-int vimz_cf_poke(vimz_cf* v, int which, size_t index, const uint64_t value[4]);
-int vimz_cf_selfcheck(int steps, uint32_t* result, uint64_t counts[8]);
-/* the LAST step of the same host-only run, for an outside restatement of the relation F' enforces: digest, z_0 (one element), then the words of
- * VIMZ_IX_LAST_STEP.  Returns the byte size (copies when buf is large enough); negative on error or when the self-check itself fails. */
-int64_t vimz_cf_selfcheck_last_step(int steps, void* buf, size_t cap);
-/* test hook, host only: `jobs` trivial jobs posted to and awaited from one helper thread of the verifier circuits' witness generators; returns how many
- * ran.  With VIMZ_WORKER_SPIN_US=0 the helper sleeps between jobs, so that every post is a wake-up. */
-int64_t vimz_worker_selftest(int jobs);
+/* (test hooks — vimz_cf_poke, the host-only self-checks — are declared in vimz_hip_testing.h and exist only in libvimz_hip_testing.so) */
 
 /* ---- ONE proof object out of several row segments: the "host-side sequential final fold" of BASELINE.json's north_star for IVC proofs.
  *      fold_input returns ONE RecursiveSNARK (vimz/src/nova_snark_backend/folding.rs:27-43); row segments of an image folded
@@ -438,6 +423,10 @@ int vimz_ivc_merge_merged(vimz_ivc_merged* m, vimz_ivc_merged* next);
  * seconds (optional) = {waiting for start states, merge, total}. */
 int vimz_ivc_fold_segments(vimz_ivc* const* segments, size_t n_segments, const uint64_t* z0, const uint64_t* step_inputs, size_t nsteps,
                            vimz_ivc_merged** out, double seconds[3]);
+/* the same when the caller already holds the rows' digests (vimz_ivc_row_digests over exactly these rows, e.g. a rank of a sharded
+ * proof that has just exchanged them with the other ranks); digests == NULL: as above */
+int vimz_ivc_fold_segments_dg(vimz_ivc* const* segments, size_t n_segments, const uint64_t* z0, const uint64_t* step_inputs, size_t nsteps,
+                              const uint64_t* digests, vimz_ivc_merged** out, double seconds[3]);
 /* RecursiveSNARK::verify(pp, num_steps, z0) for the merged object.  result: 0 = accepted; bit 0 / 1 a segment's primary / secondary chain
  * hash; bit 2 primary relaxed relation; bit 3 / 4 primary comm_W / comm_E; bit 5 secondary relation; bit 6 / 7 secondary comm_W / comm_E;
  * bit 10 public entries of a witness vector differ from the instance; bit 11 kept running products (bookkeeping for further merges);
@@ -453,6 +442,15 @@ int vimz_ivc_merged_profile(const vimz_ivc_merged* m, double seconds[4]);
 size_t vimz_ivc_merged_size(const vimz_ivc_merged* m);
 int vimz_ivc_merged_save(vimz_ivc_merged* m, uint8_t* blob, size_t cap);
 int vimz_ivc_merged_load(vimz_ivc* vk, const uint8_t* blob, size_t len, vimz_ivc_merged** out);
+/* The same hand-over between two processes of ONE node without the host round trip (one rank per GPU; the ranks' final fold as a tree,
+ * the counterpart of benchmark.sh:25-58's processes ending in one proof): _share writes a ticket — the records and a HIP IPC handle of
+ * the object's device allocation (returns its size; copies when cap suffices) — that travels as a small message; _open_shared maps the
+ * allocation, copies the folded witnesses AND the running products device-to-device (over xGMI between GPUs) into an object of its own
+ * and unmaps it.  Records are checked as in _load; the products are taken as they are (vimz_ivc_merged_verify recomputes them).  The
+ * sharing process keeps its object until the receiver is done.  Fails with VIMZ_ERR_HIP where IPC / peer access is unavailable: use
+ * _save / _load then. */
+int64_t vimz_ivc_merged_share(vimz_ivc_merged* m, void* ticket, size_t cap);
+int vimz_ivc_merged_open_shared(vimz_ivc* vk, const uint8_t* ticket, size_t len, vimz_ivc_merged** out);
 /* what an independent verifier replays: header {magic, segments, ops, len_z, n_w1, n_c1, n_w2, n_c2}, per segment {n, z_start, z_end,
  * U1 (W, E, u, X0, X1), U2, u2 (W, x0, x1), T}, per op {kind, leaf [, T_p, T_q]} — canonical little-endian words; returns the byte size */
 int64_t vimz_ivc_merged_records(const vimz_ivc_merged* m, void* buf, size_t cap);

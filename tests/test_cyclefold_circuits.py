@@ -59,9 +59,31 @@ def test_helper_thread_wake_ups_are_not_lost():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = ("import ctypes, sys; sys.path.insert(0, %r); from vimz_amd import _lib; L = _lib.lib(); L.vimz_worker_selftest.restype = ctypes.c_int64; "
+    code = ("import ctypes, sys; sys.path.insert(0, %r); from vimz_amd import _lib; L = _lib.testing_lib(); L.vimz_worker_selftest.restype = ctypes.c_int64; "
             "print(L.vimz_worker_selftest(200000))" % root)
     for spin in ("0", "3"):
         env = dict(os.environ, VIMZ_WORKER_SPIN_US=spin)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0 and r.stdout.strip().splitlines()[-1] == "200000", (spin, r.stdout[-200:], r.stderr[-300:])
+
+
+def test_hash_outputs_are_decomposed_canonically():
+    """the circuits derive their challenges from the bits of a hash output; circom-style Num2Bits(254) also accepts the bits of
+    h + p when that is below 2^254 (about a third of all h), which would let a prover choose between two challenges.  bits_strict compares
+    the bits with p - 1.  On the gadget alone, over both fields: every aliased witness satisfies the plain gadget's rows (the attack is
+    real) and violates rows of the comparison and only those (the fix is what stops it); honest witnesses violate nothing — including
+    h = 0, h = p - 1 and the largest aliasable h.  Inside F' (Nova + CycleFold over the trivial step circuit): every step run with aliased
+    challenge decompositions is unsatisfiable.  Host only."""
+    import ctypes
+    import numpy as np
+    from vimz_amd import _lib
+    L = _lib.testing_lib()
+    L.vimz_strict_bits_selfcheck.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    for field in (0, 1):
+        o = np.zeros(8, dtype=np.uint64)
+        assert L.vimz_strict_bits_selfcheck(field, 64, o.ctypes.data) == 0
+        tried, aliasable, plain_ok, only_strict_bad, honest_bad, steps, sat, steps_aliased = [int(x) for x in o]
+        assert tried == 64 and 8 <= aliasable <= 40, o            # a third of random values, plus h = 0 and h = 2^254 - p - 1
+        assert plain_ok == aliasable and only_strict_bad == aliasable and honest_bad == 0, o
+        if field == 0:
+            assert steps >= 3 and steps_aliased >= 1 and sat == 0, o

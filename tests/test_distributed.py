@@ -226,33 +226,54 @@ class _StubIVCDigests(_StubIVC):
 
 class _StubMerged:
     """What vimz_amd.hip.MergedProof offers: created from the first segment, merge() of the adjacent next one (an IVC or another
-    merged proof), save / load as bytes."""
+    merged proof), save / load as bytes.  It keeps the op sequence the library keeps (post-order: ("L", z_start, z_end, n) pushes a
+    segment, ("N",) folds the two on top), so that a test can replay the TREE the ranks built."""
 
     def __init__(self, first):
         self.zs, self.ze, self.n, self.segments = list(first.z0), list(first.z), first.n, 1
+        self.ops = [("L", tuple(first.z0), tuple(first.z), first.n)]
 
     def merge(self, nxt):
-        zs, ze, n, k = (nxt.zs, nxt.ze, nxt.n, nxt.segments) if isinstance(nxt, _StubMerged) else (nxt.z0, nxt.z, nxt.n, 1)
+        if isinstance(nxt, _StubMerged):
+            zs, ze, n, k, ops = nxt.zs, nxt.ze, nxt.n, nxt.segments, nxt.ops
+        else:
+            zs, ze, n, k, ops = nxt.z0, nxt.z, nxt.n, 1, [("L", tuple(nxt.z0), tuple(nxt.z), nxt.n)]
         if list(zs) != self.ze:
             raise ValueError("segments not adjacent")
         self.ze, self.n, self.segments = list(ze), self.n + n, self.segments + k
+        self.ops = self.ops + list(ops) + [("N",)]
 
     def save(self):
         import pickle
-        return np.frombuffer(pickle.dumps((self.zs, self.ze, self.n, self.segments)), dtype=np.uint8)
+        return np.frombuffer(pickle.dumps((self.zs, self.ze, self.n, self.segments, self.ops)), dtype=np.uint8)
 
     @classmethod
     def load(cls, vk, blob):
         import pickle
         m = cls.__new__(cls)
-        m.zs, m.ze, m.n, m.segments = pickle.loads(np.asarray(blob, dtype=np.uint8).tobytes())
+        m.zs, m.ze, m.n, m.segments, m.ops = pickle.loads(np.asarray(blob, dtype=np.uint8).tobytes())
         return m
 
     def close(self):
         pass
 
 
-def _sharded_worker(rank, world, port, q, shm, digests=False):
+def _replay_stub_ops(ops):
+    """The stand-in's counterpart of tests/_merge.py::replay: evaluates the post-order op sequence, checks adjacency at every node and
+    returns (z_start, z_end, n, the tree as nested tuples of segment lengths)."""
+    st = []
+    for op in ops:
+        if op[0] == "L":
+            st.append((list(op[1]), list(op[2]), op[3], op[3]))
+        else:
+            B, A = st.pop(), st.pop()
+            assert A[1] == B[0], "a node of the merge tree joins runs that are not adjacent"
+            st.append((A[0], B[1], A[2] + B[2], (A[3], B[3])))
+    assert len(st) == 1
+    return st[0]
+
+
+def _sharded_worker(rank, world, port, q, shm, digests=False, n_rows=9):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     from tests import _oracle
@@ -263,16 +284,31 @@ def _sharded_worker(rank, world, port, q, shm, digests=False):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     orc = _oracle.load()
     z0, inputs = step_inputs("hash")
-    rows = np.stack(inputs[:9])
+    rows = np.stack(inputs[:n_rows])
     tm = {}
     proof = prove_sharded([(_StubIVCDigests if digests else _StubIVC)(orc) for _ in range(2)], rows, z0, rank, world, dist, tm, merged_cls=_StubMerged,
-                          shm_prefix=(f"/tmp/vimz_test_{port}_" if shm else None))
+                          shm_dir=("/tmp" if shm else None))
     if rank == 0:
-        q.put((proof.zs, proof.ze, proof.n, proof.segments, sorted(tm)))
+        q.put((proof.zs, proof.ze, proof.n, proof.segments, sorted(tm), proof.ops))
     else:
         assert proof is None
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _run_sharded(world, shm, digests, n_rows):
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, q, shm, digests, n_rows)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return out
 
 
 @pytest.mark.parametrize("shm,digests", [(False, False), (True, False), (True, True)])
@@ -280,25 +316,61 @@ def test_two_ranks_with_two_segments_each_end_in_one_proof_object(oracle, shm, d
     """prove_sharded over gloo, world size 2, two local segments per rank (stand-ins over the oracle's step relation): rank 0's chain
     (or, with the chain in its two parts, every rank's own row digests, all-gathered) gives rank 1 its start state, every rank's segments merge locally, rank 0 folds rank 1's merged proof in — one object about all
     nine rows from z0 that ends where a single chain ends; both ways of moving the bytes."""
-    import torch.multiprocessing as mp
     from tests._oracle import T_HASH
     from tests.test_circuits import step_inputs
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q, shm, digests)) for r in range(2)]
-    for p in procs:
-        p.start()
-    zs, ze, n, segments, keys = q.get(timeout=600)
-    for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
+    zs, ze, n, segments, keys, ops = _run_sharded(2, shm, digests, 9)
     z0, inputs = step_inputs("hash")
     z = list(z0)
     for i in range(9):
         ok, z = oracle.step_eval(T_HASH, z, inputs[i])
     assert (zs, ze, n, segments) == (list(z0), z, 9, 4)
-    assert keys == ["final_fold_s", "merge_s", "state_chain_s"]
+    assert {"final_fold_s", "final_fold_wait_s", "merge_s", "state_chain_s", "t_ready", "t_done"} <= set(keys)
+    assert _replay_stub_ops(ops)[3] == ((3, 2), (2, 2))
+
+
+def test_tree_rounds_pair_adjacent_runs():
+    from vimz_amd.distributed import tree_rounds
+    assert tree_rounds(1) == []
+    assert tree_rounds(2) == [[(0, 1)]]
+    assert tree_rounds(4) == [[(0, 1), (2, 3)], [(0, 2)]]
+    assert tree_rounds(8) == [[(0, 1), (2, 3), (4, 5), (6, 7)], [(0, 2), (4, 6)], [(0, 4)]]
+    assert tree_rounds(5) == [[(0, 1), (2, 3)], [(0, 2)], [(0, 4)]]
+    assert tree_rounds(6) == [[(0, 1), (2, 3), (4, 5)], [(0, 2)], [(0, 4)]]
+    for w in range(1, 20):      # every rank but 0 hands over exactly once; depth = ceil(log2 w)
+        rounds = tree_rounds(w)
+        assert sorted(snd for rnd in rounds for _, snd in rnd) == list(range(1, w))
+        assert len(rounds) == (w - 1).bit_length()
+
+
+@pytest.mark.parametrize("world,shm,digests,n_rows", [(4, True, True, 10), (4, False, False, 10), (3, True, True, 7), (4, True, True, 3)])
+def test_ranks_fold_their_proofs_pairwise_up_a_tree(oracle, world, shm, digests, n_rows):
+    """World size 3 and 4 over gloo: the ranks' merged proofs are folded pairwise up a tree (rank 1 -> 0 and 3 -> 2 side by side, then
+    2 -> 0) instead of one after another on rank 0; the op sequence the final object carries IS that tree (replayed here with the
+    adjacency check at every node), its statement is all rows from z0 and it ends where a single chain ends.  Also with fewer rows than
+    ranks (a rank without rows hands over nothing)."""
+    from tests._oracle import T_HASH
+    from tests.test_circuits import step_inputs
+    from vimz_amd.distributed import segment_bounds
+    zs, ze, n, segments, keys, ops = _run_sharded(world, shm, digests, n_rows)
+    z0, inputs = step_inputs("hash")
+    z = list(z0)
+    for i in range(n_rows):
+        ok, z = oracle.step_eval(T_HASH, z, inputs[i])
+    assert (zs, ze, n) == (list(z0), z, n_rows)
+    r_zs, r_ze, r_n, tree = _replay_stub_ops(ops)
+    assert (r_zs, r_ze, r_n) == (list(z0), z, n_rows)
+
+    def run(k):      # a rank's own proof: its rows as (at most) two local segments
+        b = [hi - lo for lo, hi in segment_bounds(k, 2) if hi > lo]
+        return b[0] if len(b) == 1 else tuple(b)
+    per_rank = [run(hi - lo) for lo, hi in segment_bounds(n_rows, world) if hi > lo]
+    if world == 4 and n_rows == 10:
+        assert tree == ((per_rank[0], per_rank[1]), (per_rank[2], per_rank[3]))
+    elif world == 3:
+        assert tree == ((per_rank[0], per_rank[1]), per_rank[2])
+    else:
+        assert tree == ((1, 1), 1)
+    assert segments == sum(len(r) if isinstance(r, tuple) else 1 for r in per_rank)
 
 
 def test_fold_segments_merged_handles_fewer_rows_than_segments(oracle):
@@ -309,9 +381,9 @@ def test_fold_segments_merged_handles_fewer_rows_than_segments(oracle):
     assert (m.n, m.segments, m.zs) == (2, 2, list(z0))
 
 
-def _gpu_sharded_worker(rank, world, port, q):
+def _gpu_sharded_worker(rank, world, port, q, oracle_replay=False):
     sys.path.insert(0, ROOT)
-    os.environ["LOCAL_WORLD_SIZE"] = str(world)      # (both ranks share the one GPU: vimz_amd/_lib.py halves the hardware queues per process)
+    os.environ["LOCAL_WORLD_SIZE"] = str(world)      # (the ranks share the one GPU: vimz_amd/_lib.py halves the hardware queues per process)
     import torch.distributed as dist
     from tests.test_circuits import step_inputs
     from vimz_amd import _lib, hip
@@ -327,9 +399,18 @@ def _gpu_sharded_worker(rank, world, port, q):
     z0, inputs = step_inputs("hash")
     rows = np.stack(inputs[:9])
     ivcs = [hip.IVC(cx, c, ck1, ck2, max_batch=2) for cx in ctxs]
-    proof = prove_sharded(ivcs, rows, z0, rank, world, dist, shm_prefix=f"/tmp/vimz_test_{port}_")
+    tm = {}
+    proof = prove_sharded(ivcs, rows, z0, rank, world, dist, tm, shm_dir="/tmp")
     if rank == 0:
-        q.put((proof.verify(9, z0), proof.verify(8, z0), proof.state(), proof.info()["segments"]))
+        replay = None
+        if oracle_replay:      # the oracle-side verifier replays the TREE the ranks built (tests/_merge.py) and checks the two folded instances
+            from tests import _merge, _oracle
+            from tests.test_gpu_ivc import _shape_digest
+            orc = _oracle.load()
+            failed, acc = _merge.verify_merged(orc, proof, ivcs[0], ck1, ck2, 9, z0, _shape_digest(ivcs[0], 0), _shape_digest(ivcs[0], 1), check_commitments=False)
+            kinds = "".join("LN"[k] for k, *_ in _merge.parse_records(proof.records(), c.len_z)["ops"])
+            replay = (failed, acc["n"], kinds)
+        q.put((proof.verify(9, z0), proof.verify(8, z0), proof.state(), proof.info()["segments"], tm.get("transports"), replay))
         proof.close()
     dist.barrier()
     for v in ivcs:
@@ -358,7 +439,7 @@ def _gpu_sharded_cyclefold_worker(rank, world, port, q):
     z0, inputs = step_inputs("hash")
     rows = np.stack(inputs[:9])
     cfs = [hip.CycleFoldIVC(cx, c, ck1, ck2, max_batch=2) for cx in ctxs]
-    proof = prove_sharded(cfs, rows, z0, rank, world, dist, merged_cls=hip.CycleFoldMerged, shm_prefix=f"/tmp/vimz_test_cf_{port}_")
+    proof = prove_sharded(cfs, rows, z0, rank, world, dist, merged_cls=hip.CycleFoldMerged, shm_dir="/tmp")
     if rank == 0:
         q.put((proof.verify(9, z0), proof.verify(8, z0), proof.state(), proof.info()["segments"]))
         proof.close()
@@ -396,26 +477,53 @@ def test_two_ranks_on_the_gpu_end_in_one_verified_cyclefold_proof_object(oracle)
     assert state == ([int(x) for x in z0], z, 9)
 
 
-@pytest.mark.gpu
-def test_two_ranks_on_the_gpu_end_in_one_verified_proof_object(oracle):
-    """world_size 2 over gloo with the GPU provers (both ranks share the one GPU of the box): 2 x 2 IVC segments -> two merged proofs
-    -> rank 0's final fold -> ONE object that verifies for (9 steps, z0) and for nothing else."""
+def _run_gpu_sharded(world, oracle_replay):
     import torch.multiprocessing as mp
-    from tests._oracle import T_HASH
-    from tests.test_circuits import step_inputs
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_gpu_sharded_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_gpu_sharded_worker, args=(r, world, port, q, oracle_replay)) for r in range(world)]
     for p in procs:
         p.start()
-    ok9, ok8, state, segments = q.get(timeout=900)
+    out = q.get(timeout=900)
     for p in procs:
         p.join(timeout=300)
         assert p.exitcode == 0
+    return out
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_the_gpu_end_in_one_verified_proof_object(oracle):
+    """world_size 2 over gloo with the GPU provers (both ranks share the one GPU of the box): 2 x 2 IVC segments -> two merged proofs
+    -> rank 1 hands its proof to rank 0 by HIP IPC (device-to-device, running products included) -> ONE object that verifies for
+    (9 steps, z0) and for nothing else."""
+    from tests._oracle import T_HASH
+    from tests.test_circuits import step_inputs
+    ok9, ok8, state, segments, transports, _ = _run_gpu_sharded(2, False)
     z0, inputs = step_inputs("hash")
     z = list(z0)
     for i in range(9):
         ok, z = oracle.step_eval(T_HASH, z, inputs[i])
     assert ok9 == 0 and ok8 != 0 and segments == 4
     assert state == ([int(x) for x in z0], z, 9)
+    assert transports == ["ipc"]
+
+
+@pytest.mark.gpu
+def test_four_ranks_on_the_gpu_fold_their_proofs_up_a_tree(oracle):
+    """world_size 4 (four processes on the one GPU): 4 x 2 IVC segments; rank 1 -> 0 and 3 -> 2 side by side, then 2 -> 0, every
+    hand-over by HIP IPC.  The product's verifier accepts the ONE object for (9 steps, z0) only; the oracle-side verifier
+    (tests/_merge.py) replays the records — whose op sequence must be exactly that tree — and accepts both folded instances."""
+    from tests._oracle import T_HASH
+    from tests.test_circuits import step_inputs
+    ok9, ok8, state, segments, transports, replay = _run_gpu_sharded(4, True)
+    z0, inputs = step_inputs("hash")
+    z = list(z0)
+    for i in range(9):
+        ok, z = oracle.step_eval(T_HASH, z, inputs[i])
+    assert ok9 == 0 and ok8 != 0 and segments == 8
+    assert state == ([int(x) for x in z0], z, 9)
+    assert transports == ["ipc", "ipc"]
+    failed, n, kinds = replay
+    assert failed == [] and n == 9
+    assert kinds == "LLN" "LLN" "N" "LLN" "LLN" "N" "N"      # ((r0 r1) (r2 r3)), every rank's run = two local segments

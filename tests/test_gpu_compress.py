@@ -72,10 +72,10 @@ def test_compressed_proof_of_a_ten_step_hash_ivc(ctx, keys, oracle):
 
 def test_a_correction_hidden_in_a_public_slot_is_rejected():
     """the W opening must not let a prover hide a correction of a public entry under the (live, otherwise unused)
-    generator of that entry's slot.  A cheating prover — the test hook VIMZ_TEST_FORGE_PUBLIC_SLOT of vimz_ivc_compress — claims
+    generator of that entry's slot.  A cheating prover — the test hook vimz_test_forge_public_slot, which exists only in libvimz_hip_testing.so — claims
     x0 + 1 for the last fresh instance, commits to W − ck[n−3] and opens a vector with −1 in the slot of wire n−2: every sum-check
     message is honest for the TRUE z.  Before the mask on b this argument was accepted (bit 4 clear); it must fail.  The hook is
-    read per call, so the honest proof of the same process is the control."""
+    switched per call, so the honest proof of the same process is the control."""
     import os
     import subprocess
     import sys
@@ -94,12 +94,14 @@ z0, inputs = step_inputs("hash")
 ivc = hip.IVC(ctx, c, ck1, ck2, max_batch=4)
 ivc.reset(z0); ivc.fold(np.stack(inputs)[:3])
 honest, _ = ivc.compress()
-os.environ["VIMZ_TEST_FORGE_PUBLIC_SLOT"] = "1"
+assert _lib.SO_PATH == _lib.TESTING_SO_PATH
+ctx.lib.vimz_test_forge_public_slot.restype = None
+ctx.lib.vimz_test_forge_public_slot(1)
 forged, _ = ivc.compress()
-del os.environ["VIMZ_TEST_FORGE_PUBLIC_SLOT"]
+ctx.lib.vimz_test_forge_public_slot(0)
 print("codes", ivc.verify_compressed(honest, 3, z0), ivc.verify_compressed(forged, 3, z0))
 """ % root
-    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, VIMZ_HIP_LIBRARY="testing"))
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     honest, forged = [int(x) for x in [l for l in out.stdout.splitlines() if l.startswith("codes ")][-1].split()[1:]]
     assert honest == 0

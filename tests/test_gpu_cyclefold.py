@@ -59,42 +59,17 @@ def test_cyclefold_ivc_verifies_and_the_oracle_verifier_accepts(ctx, keys, oracl
         cf.close(); ivc.close()
 
 
-def test_cyclefold_verifiers_reject_tampering(ctx, keys, oracle):
-    from vimz_amd import hip
-    ck1, ck2 = keys
-    c = Circuit.for_resolution("contrast", "HD")
-    z0, inputs = step_inputs("contrast")
-    steps = np.stack(inputs)
-    cf = hip.CycleFoldIVC(ctx, c, ck1, ck2, max_batch=4)
-    try:
-        cf.reset(z0)
-        cf.fold(steps[:5])
-        assert cf.verify(5, z0) == 0
-        info = cf.info()
-        rs = np.random.default_rng(3)
-        # one wrong element in any of the five vectors: both verifiers reject
-        for which, n, side, what in ((0, info["main_wires"], 0, hip.IX_RUNNING_Z), (1, info["main_wires"], 0, hip.IX_FRESH_Z), (2, info["cyclefold_wires"], 1, hip.IX_RUNNING_Z),
-                                     (3, info["main_constraints"], 0, hip.IX_RUNNING_E), (4, info["cyclefold_constraints"], 1, hip.IX_RUNNING_E)):
-            vec = from_limbs(cf.export(side, what))
-            for idx in sorted(set([1, n - 1] + [int(x) for x in rs.integers(1, n, size=3)])):
-                old = vec[idx]
-                cf.poke(which, idx, (old + 1) % _lib.MODULUS[side])
-                assert cf.verify(5, z0) != 0, (which, idx)
-                if idx in (1, n - 1):
-                    failed, _ = cfo.verify(oracle, cf, ck1, ck2, 5, z0, check_commitments=False)
-                    assert failed, (which, idx)
-                cf.poke(which, idx, old)
-        assert cf.verify(5, z0) == 0
-        # an unsatisfiable row is refused and leaves the proof where it was
-        bad = steps[5:7].copy(); bad[1, 200, 0] ^= np.uint64(0xFF)      # a transformed pixel that is no longer the contrast of the original
-        with pytest.raises(_lib.VimzError) as e:
-            cf.fold(bad)
-        assert e.value.code == _lib.ERR_UNSAT
-        assert cf.state()[1] == 5 and cf.verify(5, z0) == 0
-        cf.fold(steps[5:])
-        assert cf.verify(10, z0) == 0
-    finally:
-        cf.close()
+def test_cyclefold_verifiers_reject_tampering():
+    """One wrong element in any of the five witness vectors is rejected by the product's verifier and by the oracle-side one; an
+    unsatisfiable row is refused and leaves the proof valid.  Overwriting a prover's vectors needs the test hook vimz_cf_poke, which the
+    product library does not have: the body (tests/_tamper_cyclefold.py) runs in a process of its own on libvimz_hip_testing.so."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VIMZ_HIP_LIBRARY="testing")
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "_tamper_cyclefold.py")], env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0 and "tamper ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
 
 def test_cyclefold_instance_statement(oracle):

@@ -28,10 +28,16 @@ def default_hw_queues(n_devices=None):
     return 8 if per_gpu <= 1 else 4
 
 
+HW_QUEUES_DEFAULTED = "GPU_MAX_HW_QUEUES" not in os.environ      # (a launcher that starts ranks drops a defaulted value so that each rank decides for itself)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", str(default_hw_queues()))
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(HERE, "libvimz_hip.so")
+PRODUCT_SO_PATH = os.path.join(HERE, "libvimz_hip.so")
+# libvimz_hip_testing.so: the same library with the test hooks of include/vimz_hip_testing.h (built from the same objects; the product library
+# has none of them).  A test that needs a hook on a prover object runs in a process started with VIMZ_HIP_LIBRARY=testing; the host-only
+# hooks are reached through testing_lib() beside the product library.
+TESTING_SO_PATH = os.path.join(HERE, "libvimz_hip_testing.so")
+SO_PATH = TESTING_SO_PATH if os.environ.get("VIMZ_HIP_LIBRARY") == "testing" else PRODUCT_SO_PATH
 
 OK = 0
 ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_UNSAT = -1, -2, -3, -4
@@ -56,6 +62,17 @@ class VimzError(RuntimeError):
 
 
 _lib = None
+_testing = None
+
+
+def testing_lib():
+    """libvimz_hip_testing.so, for its GPU-free hooks (self-checks of the circuits, helper-thread test): test infrastructure."""
+    global _testing
+    if _testing is None:
+        if not os.path.exists(TESTING_SO_PATH):
+            raise ImportError(f"{TESTING_SO_PATH} is missing: run `make -C vimz_amd/csrc` (or __graft_entry__.build())")
+        _testing = lib() if SO_PATH == TESTING_SO_PATH else C.CDLL(TESTING_SO_PATH)
+    return _testing
 
 
 def lib():

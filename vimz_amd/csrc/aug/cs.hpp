@@ -168,8 +168,42 @@ struct CS {
 
   // Little-endian bits of x (n of them).  Bit 0 is the substituted signal x - sum_{k>=1} 2^k b_k (circom's convention),
   // so the gadget costs n constraints and n-1 wires and proves x < 2^n.
-  std::vector<N> bits(const N& x, int n) {
-    const F c = F::from_mont(x.v);
+  std::vector<N> bits(const N& x, int n) { return bits_of(x, F::from_mont(x.v), n); }
+  // The decomposition forced CANONICAL (circom's Num2Bits_strict, arkworks' to_bits_le): n = the field's bit length, and the bits are
+  // also compared with p - 1.  Of the two bit vectors with sum 2^k b_k = x mod p — those of x and, when it is below 2^n, of x + p — the
+  // plain gadget accepts both; a hash-to-challenge decomposition that did would let the prover choose between two challenges (ADVICE
+  // r3).  Walking down from the top bit, `run` = the AND of the bits at the positions where p - 1 has a one; at every position where
+  // p - 1 has a zero, run · b_k = 0 (a one there, with everything above equal to p - 1, would make the number exceed it).  One
+  // constraint per bit below the leading ones of p - 1, one wire per further one.
+  std::vector<N> bits_strict(const N& x) {
+    const int n = FP::BITS;
+    F c = F::from_mont(x.v);
+    if (!b && alias_attack) {      // test hook of the negative test (witness mode only): the bits of x + p where they fit n bits
+      F a; uint64_t cy = 0;
+      for (int i = 0; i < 8; i++) { cy += (uint64_t)c.v[i] + FP::MOD.w[i]; a.v[i] = (uint32_t)cy; cy >>= 32; }
+      bool fits = cy == 0;
+      for (int k = n; k < 256; k++) if ((a.v[k >> 5] >> (k & 31)) & 1u) fits = false;
+      if (fits) { c = a; alias_used++; }
+    }
+    std::vector<N> r = bits_of(x, c, n);
+    uint32_t pm1[8];
+    { uint64_t br = 1; for (int i = 0; i < 8; i++) { const uint64_t d = (uint64_t)FP::MOD.w[i] - br; pm1[i] = (uint32_t)d; br = (d >> 32) & 1; } }
+    N run; bool have_run = false;      // (no run yet: the leading ones of p - 1 — the AND of nothing is the constant one)
+    for (int k = n - 1; k >= 0; k--) {
+      if ((pm1[k >> 5] >> (k & 31)) & 1u) {
+        if (!have_run) { run = r[k]; have_run = true; }
+        else run = mul(run, r[k]);
+      } else if (have_run) {
+        enforce(run, r[k], zero());
+        if (!b && !alias_attack && !F::mul(run.v, r[k].v).is_zero()) bad = true;
+      } else {      // (cannot happen for a modulus of n bits: its top bit is a one)
+        enforce_zero(r[k]);
+      }
+    }
+    return r;
+  }
+  bool alias_attack = false; int alias_used = 0;
+  std::vector<N> bits_of(const N& x, const F& c, int n) {
     for (int k = n; k < 256; k++) if ((c.v[k >> 5] >> (k & 31)) & 1u) bad = true;
     std::vector<N> r((size_t)n);
     LC rest;

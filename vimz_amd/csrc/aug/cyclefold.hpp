@@ -180,7 +180,7 @@ inline CfMainOut synthesize_cf_main(CS<BnFr>& cs, const CfMainIn& in, const std:
   std::vector<N> hrin = {h_U};
   push_nn(hrin, uW); hrin.push_back(ux0); hrin.push_back(ux1); push_nn(hrin, T);
   N hr = cs.hash(hrin);
-  std::vector<N> rb = cs.bits(hr, BnFr::BITS);
+  std::vector<N> rb = cs.bits_strict(hr);
   N rho0 = cs.pack(rb, 0, 64), rho1 = cs.pack(rb, 64, 128);
   cf_low128(hr.v, out.r);
   N rho = cs.add(cs.add(rho0, cs.scale(rho1, cb::f_pow2<F>(64))), cs.constant(cb::f_pow2<F>(128)));
@@ -202,13 +202,13 @@ inline CfMainOut synthesize_cf_main(CS<BnFr>& cs, const CfMainIn& in, const std:
   std::vector<N> h1in = {h_cf, hr, c1W.x, c1W.y};
   push_nn(h1in, Wn); h1in.push_back(c1T.x); h1in.push_back(c1T.y);
   N h1 = cs.hash(h1in);
-  std::vector<N> r1b = cs.bits(h1, BnFr::BITS);
+  std::vector<N> r1b = cs.bits_strict(h1);
   N r1_0 = cs.pack(r1b, 0, 64), r1_1 = cs.pack(r1b, 64, 128);
   cf_low128(h1.v, out.r1);
   std::vector<N> h2in = {h1, c2W.x, c2W.y};
   push_nn(h2in, En); h2in.push_back(c2T.x); h2in.push_back(c2T.y);
   N h2 = cs.hash(h2in);
-  std::vector<N> r2b = cs.bits(h2, BnFr::BITS);
+  std::vector<N> r2b = cs.bits_strict(h2);
   N r2_0 = cs.pack(r2b, 0, 64), r2_1 = cs.pack(r2b, 64, 128);
   cf_low128(h2.v, out.r2);
   const F p128 = cb::f_pow2<F>(128), p64 = cb::f_pow2<F>(64);
@@ -340,8 +340,10 @@ struct CfMainCircuit {
     CfFr c; memcpy(c.v, d, 32); c.v[7] &= 0x03ffffffu;
     digest = CfFr::to_mont(c);
   }
-  CfMainOut witness(const CfMainIn& in, const CfFr* z_i, const CfFr* z_next, std::vector<CfFr>& aug, bool* bad) const {
-    CS<BnFr> cs; cs.base = step_wires;
+  // alias_attack (test hook of vimz_strict_bits_selfcheck, never set by the prover): decompose hash outputs as h + p where that fits;
+  // returns how many decompositions were aliased
+  CfMainOut witness(const CfMainIn& in, const CfFr* z_i, const CfFr* z_next, std::vector<CfFr>& aug, bool* bad, int* alias_attack = nullptr) const {
+    CS<BnFr> cs; cs.base = step_wires; cs.alias_attack = alias_attack != nullptr;
     cs.w.reserve(aug_wires());
     if (use_worker) { if (!worker) worker.reset(new Worker()); if (!worker2) worker2.reset(new Worker()); cs.worker = worker.get(); cs.worker2 = worker2.get(); }
     std::vector<Num<CfFr>> zi(len_z), zn(len_z);
@@ -349,6 +351,7 @@ struct CfMainCircuit {
     CfMainOut o = synthesize_cf_main(cs, in, zi, zn, &cache);
     if (cs.w.size() != aug_wires()) throw std::runtime_error("cyclefold main circuit: witness length differs from the shape");
     if (bad) *bad = cs.bad;
+    if (alias_attack) *alias_attack = cs.alias_used;
     aug.swap(cs.w);
     return o;
   }

@@ -15,6 +15,9 @@
 // This is a straight, synchronous schedule (no lookahead, no work queued from inside the circuit evaluation): a first version of the
 // row, measured in DESIGN.md §9d, not a tuned one.
 #include "cyclefold_internal.hpp"
+#ifdef VIMZ_TESTING
+#include "../../include/vimz_hip_testing.h"
+#endif
 
 namespace {
 
@@ -737,6 +740,7 @@ int vimz_cf_kzg_open(vimz_cf* v, int which, const uint64_t z[4], uint64_t eval_o
                     : vz_kzg_open_device(ctx, p->ck, 0, VIMZ_FIELD_BN254_FR, p->E, p->n_c, z, VIMZ_FORM_CANONICAL, eval_out, proof_xy);
 }
 
+#ifdef VIMZ_TESTING      // ---- test hooks: only in libvimz_hip_testing.so (include/vimz_hip_testing.h) ----
 // test hook: overwrite one element of a witness vector on the device (soundness tests flip wires and expect vimz_cf_verify / the
 // oracle verifier to reject).  which: 0 running main Z, 1 last fresh main Z, 2 running CycleFold Z, 3 running main E, 4 running CycleFold E.
 int vimz_cf_poke(vimz_cf* v, int which, size_t index, const uint64_t value[4]) {
@@ -780,7 +784,7 @@ static int cf_selfcheck_core(int steps, uint32_t* result, uint64_t counts[8], st
     b.len_z = 1; b.n_priv = 0; b.n_wires = 3;
     b.enforce(cb::LCT<Fe>::constant(Fe::one()), cb::LCT<Fe>::wire(2), cb::LCT<Fe>::wire(1));
     b.n_linear = 1;
-    CfMainCircuit c1(b); c1.use_worker = false; c1.finish(cf);
+    CfMainCircuit c1(b); c1.use_worker = getenv("VIMZ_CF_SELFCHECK_WORKERS") != nullptr; c1.finish(cf);      // (helper threads on: the sanitizer runs)
     if (counts) { counts[0] = b.n_wires; counts[1] = b.n_constraints(); counts[2] = cf.n_wires(); counts[3] = cf.n_constraints(); }
     auto sat = [](const auto& bld, const auto& z) -> bool {
       typedef std::decay_t<decltype(z[0])> F;
@@ -922,6 +926,128 @@ int64_t vimz_cf_selfcheck_last_step(int steps, void* buf, size_t cap) {
   if (buf && cap >= bytes) memcpy(buf, rec.data(), bytes);
   return (int64_t)bytes;
 }
+
+}  // extern "C"
+// Host only: the canonical decomposition (aug/cs.hpp: bits_strict) against the aliased witness; layout of `out`: include/vimz_hip_testing.h.
+template <class FP>
+static void strict_bits_gadget_check(int values, uint64_t out[8]) {
+  typedef Fp<FP> F;
+  typedef aug::CS<FP> CSx;
+  // shape: wire 0 = 1, wire 1 = x, then the gadget's wires; the first FP::BITS rows are the plain Num2Bits rows, the rest the comparison
+  cb::BuilderT<F> b;
+  b.len_z = 0; b.n_priv = 0; b.n_wires = 2;
+  size_t plain_rows = 0;
+  {
+    CSx cs; cs.b = &b; cs.base = 2;
+    typename CSx::N x = cs.wire(1, F::zero());
+    cs.bits(x, FP::BITS);                       // only to count the plain gadget's rows
+    plain_rows = b.n_constraints();
+  }
+  cb::BuilderT<F> bs;
+  bs.len_z = 0; bs.n_priv = 0; bs.n_wires = 2;
+  { CSx cs; cs.b = &bs; cs.base = 2; typename CSx::N x = cs.wire(1, F::zero()); cs.bits_strict(x); }
+  const cb::Csr* Ms[3] = {&bs.A, &bs.B, &bs.C};
+  auto violated = [&](const std::vector<F>& z, bool* plain_bad, bool* strict_bad) {
+    *plain_bad = *strict_bad = false;
+    for (uint32_t r = 0; r < bs.n_constraints(); r++) {
+      F acc[3];
+      for (int m = 0; m < 3; m++) { acc[m] = F::zero(); for (uint32_t k = Ms[m]->row_ptr[r]; k < Ms[m]->row_ptr[r + 1]; k++) acc[m] = F::add(acc[m], F::mul(bs.dict[Ms[m]->coef[k]], z[Ms[m]->col[k]])); }
+      if (!F::mul(acc[0], acc[1]).eq(acc[2])) { if (r < plain_rows) *plain_bad = true; else *strict_bad = true; }
+    }
+  };
+  uint64_t ctr = 0x243f6a8885a308d3ull;
+  auto next = [&] { ctr = ctr * 6364136223846793005ull + 1442695040888963407ull; return ctr >> 7; };
+  for (int t = 0; t < values; t++) {
+    F x;
+    if (t == 0) x = F::zero();                                             // h = 0: aliased by p itself
+    else if (t == 1) x = F::neg(F::one());                                 // h = p - 1: the largest canonical value, no alias
+    else if (t == 2) { F c = F::zero(); uint64_t br = 0; uint32_t top[8] = {0, 0, 0, 0, 0, 0, 0, 1u << ((FP::BITS - 1) & 31)};      // h = 2^n - p - 1: the largest aliasable value
+      top[7] = 0; uint32_t pw[8] = {0}; pw[(FP::BITS) >> 5] = 1u << (FP::BITS & 31);
+      for (int i = 0; i < 8; i++) { const uint64_t d = (uint64_t)pw[i] - FP::MOD.w[i] - br; c.v[i] = (uint32_t)d; br = (d >> 32) & 1; }
+      { uint64_t b1 = 1; for (int i = 0; i < 8; i++) { const uint64_t d = (uint64_t)c.v[i] - b1; c.v[i] = (uint32_t)d; b1 = (d >> 32) & 1; } }
+      x = F::to_mont(c); }
+    else { x = F::mul(F::mul(cb::f_from_u64<F>(next()), cb::f_from_u64<F>(next())), F::mul(cb::f_from_u64<F>(next()), cb::f_from_u64<F>(next()))); x = F::mul(x, F::mul(cb::f_from_u64<F>(next()), cb::f_from_u64<F>(next()))); }      // (six 57-bit factors: reduced, about uniform)
+    out[0]++;
+    for (int attack = 0; attack < 2; attack++) {
+      CSx cs; cs.base = 2; cs.alias_attack = attack != 0;
+      typename CSx::N xn = cs.wire(1, x);
+      cs.bits_strict(xn);
+      if (attack && !cs.alias_used) continue;
+      std::vector<F> z = {F::one(), x};
+      z.insert(z.end(), cs.w.begin(), cs.w.end());
+      bool pb, sb; violated(z, &pb, &sb);
+      if (!attack) { if (pb || sb || cs.bad) out[4]++; }
+      else { out[1]++; if (!pb) out[2]++; if (!pb && sb) out[3]++; }
+    }
+  }
+}
+extern "C" {
+int vimz_strict_bits_selfcheck(int field, int values, uint64_t out[8]) {
+  if (!out || values < 3 || values > 100000 || (field != 0 && field != 1)) return VIMZ_ERR_INVALID;
+  try {
+    for (int k = 0; k < 8; k++) out[k] = 0;
+    if (field == 0) strict_bits_gadget_check<BnFr>(values, out); else strict_bits_gadget_check<BnFq>(values, out);
+    if (field != 0) return VIMZ_OK;
+    // inside F': the recursion over the trivial step circuit with every challenge decomposition aliased where an alias exists
+    CfCircuit cf; cf.finish();
+    cb::BuilderT<Fe> b;
+    b.len_z = 1; b.n_priv = 0; b.n_wires = 3;
+    b.enforce(cb::LCT<Fe>::constant(Fe::one()), cb::LCT<Fe>::wire(2), cb::LCT<Fe>::wire(1));
+    b.n_linear = 1;
+    CfMainCircuit c1(b); c1.use_worker = false; c1.finish(cf);
+    auto sat = [&](const std::vector<Fe>& z) {
+      const cb::Csr* Ms[3] = {&b.A, &b.B, &b.C};
+      for (uint32_t r = 0; r < b.n_constraints(); r++) {
+        Fe acc[3];
+        for (int m = 0; m < 3; m++) { acc[m] = Fe::zero(); for (uint32_t k = Ms[m]->row_ptr[r]; k < Ms[m]->row_ptr[r + 1]; k++) acc[m] = Fe::add(acc[m], Fe::mul(b.dict[Ms[m]->coef[k]], z[Ms[m]->col[k]])); }
+        if (!Fe::mul(acc[0], acc[1]).eq(acc[2])) return false;
+      }
+      return true;
+    };
+    const G1Aff g1 = CycleSide<BnFq>::G(); const G2Aff g2 = CycleSide<BnFr>::G();
+    auto fake1 = [&](uint64_t k) { const uint32_t w[2] = {(uint32_t)k, (uint32_t)(k >> 32)}; return to_affine(scalar_mul(g1, w, 64)); };
+    auto fake2 = [&](uint64_t k) { const uint32_t w[2] = {(uint32_t)k, (uint32_t)(k >> 32)}; return to_affine(host_mul<Fe>(g2, w, 64)); };
+    std::vector<Fe> z0 = {cb::f_from_u64<Fe>(11)};
+    CfMainRelaxed U = CfMainRelaxed::zero(); G1Aff UW = g1_identity(), UE = g1_identity();
+    CfMainFresh u = CfMainFresh::zero(); G1Aff uW = g1_identity();
+    CfRelaxed cfU = CfRelaxed::zero();
+    const int steps = std::min(12, std::max(4, values / 8));
+    for (int i = 0; i < steps; i++) {
+      CfMainIn in = CfMainIn::zero();
+      in.digest = c1.digest; in.i = (uint64_t)i; in.z0 = z0; in.U = U; in.u = u; in.cfU = cfU;
+      CfChallenges ch; ch.h_U = cf_hash_main(c1.digest, i, z0, z0.data(), U); ch.h_cf = cf_hash_cf(c1.digest, cfU);
+      G1Aff Wn = g1_identity(), En = g1_identity();
+      if (i > 0) {
+        const G1Aff cT = i > 1 ? fake1(0x1100 + i) : g1_identity();
+        in.T = nn_point(cT);
+        cf_challenge_main(ch, u, in.T);
+        Wn = g1_fold(UW, ch.r, uW); En = g1_fold(UE, ch.r, cT);
+        in.Wn = nn_point(Wn); in.En = nn_point(En);
+        in.cf1W = fake2(0x2100 + i); in.cf1T = i > 1 ? fake2(0x3100 + i) : g2_identity();
+        in.cf2W = fake2(0x4100 + i); in.cf2T = fake2(0x5100 + i);
+      }
+      // the honest run carries the recursion forward; the aliased run of the same step must not be satisfiable
+      std::vector<Fe> aug; bool bad = false;
+      CfMainOut o = c1.witness(in, z0.data(), z0.data(), aug, &bad);
+      std::vector<Fe> z = {Fe::one(), z0[0], z0[0]}; z.insert(z.end(), aug.begin(), aug.end());
+      if (bad || !sat(z)) out[4]++;
+      if (i > 0) {
+        std::vector<Fe> aug2; bool bad2 = false; int used = 0;
+        c1.witness(in, z0.data(), z0.data(), aug2, &bad2, &used);
+        out[5]++;
+        if (used) {
+          out[7]++;
+          std::vector<Fe> z2 = {Fe::one(), z0[0], z0[0]}; z2.insert(z2.end(), aug2.begin(), aug2.end());
+          if (sat(z2)) out[6]++;
+        }
+      }
+      U = o.U_new; UW = i > 0 ? Wn : g1_identity(); UE = i > 0 ? En : g1_identity(); cfU = o.cfU_new;
+      uW = fake1(0x6100 + i); u.W = nn_point(uW); u.x0 = o.x0; u.x1 = o.x1;
+    }
+    return VIMZ_OK;
+  } catch (const std::exception& e) { return vz_fail(nullptr, VIMZ_ERR_INVALID, e.what()); }
+}
+#endif      // VIMZ_TESTING
 
 }  // extern "C"
 

@@ -1,6 +1,9 @@
 // ONE proof object out of several row segments' Nova + CycleFold proofs (vimz_cf_merge*): see the protocol comment below.  The prover itself:
 // cyclefold.hip.
 #include "cyclefold_internal.hpp"
+#ifdef VIMZ_TESTING
+#include "../../include/vimz_hip_testing.h"
+#endif
 
 // ---- ONE proof object out of several row segments' CycleFold proofs: the "host-side sequential final fold" of BASELINE.json's north_star for
 // this scheme (what merge.hip is for the Nova IVC).  Row segments of an image folded concurrently — each a vimz_cf of its own, on one GPU or
@@ -493,6 +496,7 @@ int64_t vimz_cf_merged_records(const vimz_cf_merged* m, void* buf, size_t cap) {
   if (buf && cap >= bytes) memcpy(buf, o.data(), bytes);
   return (int64_t)bytes;
 }
+#ifdef VIMZ_TESTING      // (include/vimz_hip_testing.h: only in libvimz_hip_testing.so)
 // Host only, no GPU (test hook for the CPU suite): two runs of made-up segment records — commitments are multiples of the generators, the hashes
 // each segment's last instance carries are the true ones of its made-up statement — replayed by cfm_replay.  Output: digest (4 words), the records
 // (vimz_cf_merged_records' layout, len_z = 1), then the accumulator the replay arrives at: n, z_start, z_end (one element each), comm_W.x, .y, comm_E.x,
@@ -548,6 +552,7 @@ int64_t vimz_cf_selfcheck_merge(int segs_run0, int segs_run1, void* buf, size_t 
     return (int64_t)bytes;
   } catch (const std::exception& e) { return vz_fail(nullptr, VIMZ_ERR_INVALID, e.what()); }
 }
+#endif      // VIMZ_TESTING
 // side 0 / 1 = main / CycleFold; what = VIMZ_IX_RUNNING_Z, VIMZ_IX_RUNNING_E (canonical), VIMZ_IX_INSTANCE (side 0: comm_W.x, .y, comm_E.x, .y,
 // u, x0, x1; side 1: comm_W.x, .y, comm_E.x, .y, u, x[0..7)) of the folded instances
 int64_t vimz_cf_merged_export(vimz_cf_merged* m, int side, int what, void* buf, size_t cap) {

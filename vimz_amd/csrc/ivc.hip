@@ -491,6 +491,7 @@ void vimz_ivc_free(vimz_ivc* v) {
     }
     hipSetDevice(v->ctx->device);
     v->ws2.release(); v->ws3.release();
+    for (auto& mp : v->ipc_mappings) if (mp.ptr) hipIpcCloseMemHandle(mp.ptr);
     if (v->merged_spare_dev) hipFree(v->merged_spare_dev);
     if (v->merged_spare_pin) hipHostFree(v->merged_spare_pin);
     for (void* d : v->owned) hipFree(d);

@@ -94,6 +94,14 @@ struct vimz_ivc {
   // one set of a merged proof's buffers (merge.hip) kept from the last one that was freed: the next vimz_ivc_merged_create over this
   // IVC needs no allocation (device + pinned: 0.5-2 ms next to running kernels, inside a timed fold_input)
   uint32_t* merged_spare_dev = nullptr; void* merged_spare_pin = nullptr;
+  // hand-over of merged proofs between the processes of a node (vimz_ivc_merged_share / _open_shared): a merged proof's device
+  // allocation is recycled from proof to proof (the spare set above), so its IPC handle is made once (export side) and the other
+  // process's mapping of it is kept open (import side: at most IPC_MAPPINGS, oldest closed first) — the second and later proofs of a
+  // pair of ranks pay no hipIpcGetMemHandle / hipIpcOpenMemHandle (1-3 ms each next to running kernels)
+  enum { IPC_MAPPINGS = 8 };
+  struct IpcExport { const void* dev = nullptr; unsigned char handle[64]; };
+  struct IpcMapping { unsigned char handle[64]; void* ptr = nullptr; };
+  std::vector<IpcExport> ipc_exports; std::vector<IpcMapping> ipc_mappings;
   // the merged proofs that use this IVC as their verifier key: freeing the IVC first orphans them (their buffers are released, every
   // later call on them fails cleanly) instead of leaving them with a dangling pointer
   std::vector<struct vimz_ivc_merged*> merged_dependents;

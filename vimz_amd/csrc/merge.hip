@@ -92,7 +92,13 @@ size_t merged_words(const vimz_ivc* v) {      // 32-byte elements of the one dev
 void release_buffers(vimz_ivc_merged* m) {
   vimz_ivc* vk = m->vk;
   if (vk && m->dev && m->pin && !vk->merged_spare_dev) { vk->merged_spare_dev = m->dev; vk->merged_spare_pin = m->pin; }
-  else { if (m->dev) hipFree(m->dev); if (m->pin) hipHostFree(m->pin); }
+  else {
+    if (m->dev) {
+      if (vk) { auto& ex = vk->ipc_exports; ex.erase(std::remove_if(ex.begin(), ex.end(), [&](const vimz_ivc::IpcExport& e) { return e.dev == m->dev; }), ex.end()); }   // (the address may come back as another allocation)
+      hipFree(m->dev);
+    }
+    if (m->pin) hipHostFree(m->pin);
+  }
   m->dev = nullptr; m->pin = nullptr;
 }
 void unregister_merged(vimz_ivc_merged* m) {
@@ -497,6 +503,95 @@ int vimz_ivc_merged_load(vimz_ivc* vk, const uint8_t* blob, size_t len, vimz_ivc
   return VIMZ_OK;
 }
 
+// ---- a merged proof handed to another process of the node WITHOUT a host round trip (the ranks' final fold as a tree) ----
+// The ticket a rank publishes: {magic, elements, 0, 0} ‖ the HIP IPC handle of the object's one device allocation (64 bytes) ‖ records.
+// The receiving rank maps the allocation (dmabuf IPC; between GPUs the copy below runs over xGMI), copies the folded witnesses AND the
+// running products device-to-device into an object of its own and unmaps it: no save -> /dev/shm -> load, no SpMV to recompute the
+// products.  The sender keeps its object alive until the receiver says it is done.
+static const uint64_t SHARE_MAGIC = 0x314853475a56ull;      // "VZGSH1"
+static size_t shared_elements(const vimz_ivc* vk) { return (size_t)vk->pri->n_wires + 4 * (size_t)vk->pri->n_c + vk->sec.n_w + 4 * (size_t)vk->sec.n_c; }
+
+int64_t vimz_ivc_merged_share(vimz_ivc_merged* m, void* buf, size_t cap) {
+  if (!m || !m->vk || !m->dev) return VIMZ_ERR_INVALID;
+  vimz_ivc* vk = m->vk; vimz_ctx* ctx = vk->ctx;
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "ticket layout");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  if (m->broken) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_ivc_merged_share: this merged proof failed in the middle of a merge");
+  const size_t bytes = 8 * (4 + 8 + records_words(m));
+  if (!buf || cap < bytes) return (int64_t)bytes;
+  if (hipSetDevice(ctx->device) != hipSuccess) return VIMZ_ERR_HIP;
+  // everything that wrote the vectors has been waited for by the call that queued it (merged_create / node_merge / load end in a
+  // synchronise); the other process reads them through its own queue
+  hipIpcMemHandle_t h;
+  const vimz_ivc::IpcExport* known = nullptr;
+  for (auto& ex : vk->ipc_exports) if (ex.dev == m->dev) known = &ex;
+  if (known) memcpy(&h, known->handle, 64);
+  else {
+    const hipError_t e = hipIpcGetMemHandle(&h, m->dev);
+    if (e != hipSuccess) return vz_fail(ctx, VIMZ_ERR_HIP, "vimz_ivc_merged_share: hipIpcGetMemHandle", e);
+    vimz_ivc::IpcExport ex; ex.dev = m->dev; memcpy(ex.handle, &h, 64); vk->ipc_exports.push_back(ex);
+  }
+  Writer w; w.word(SHARE_MAGIC); w.word(shared_elements(vk)); w.word(0); w.word(0);
+  uint64_t hw[8]; memcpy(hw, &h, 64); for (int k = 0; k < 8; k++) w.word(hw[k]);
+  write_records(m, w);
+  if (8 * w.w.size() != bytes) return VIMZ_ERR_INVALID;
+  memcpy(buf, w.w.data(), bytes);
+  return (int64_t)bytes;
+}
+
+// vk as for vimz_ivc_merged_load.  The records are parsed and replayed like an untrusted blob's (range and curve checks, instances
+// recomputed); the vectors are range-checked on the device; the running products are TAKEN, not recomputed — they only serve further
+// merges, and vimz_ivc_merged_verify recomputes them (result bit 11) like everything else.
+int vimz_ivc_merged_open_shared(vimz_ivc* vk, const uint8_t* ticket, size_t len, vimz_ivc_merged** out) {
+  if (!vk || !ticket || !out || (len & 7) || len < 8 * (4 + 8 + 8)) return VIMZ_ERR_INVALID;
+  vimz_ctx* ctx = vk->ctx; vimz_prover* p = vk->pri;
+  std::vector<uint64_t> words(len / 8); memcpy(words.data(), ticket, len);
+  if (words[0] != SHARE_MAGIC || words[1] != shared_elements(vk)) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_ivc_merged_open_shared: not a ticket for this verifier key's circuits");
+  hipIpcMemHandle_t h; memcpy(&h, words.data() + 4, 64);
+  Reader in{words.data() + 12, words.size() - 12};
+  std::vector<MSeg> segs; std::vector<MOp> ops;
+  if (!read_records(in, vk, segs, ops) || !in.ok || in.pos != words.size() - 12)
+    return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_ivc_merged_open_shared: malformed records (length, an element not below its modulus, or a point off its curve)");
+  MAcc acc; uint32_t fl = 0;
+  if (!merged_replay(vk, segs, ops, &acc, &fl)) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_ivc_merged_open_shared: malformed op sequence");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  P_TRY(hipSetDevice(ctx->device));
+  MergedPtr m;
+  int rc = merged_alloc(vk, m);
+  if (rc) return rc;
+  void* remote = nullptr;
+  hipError_t e = hipSuccess;
+  for (auto& mp : vk->ipc_mappings) if (!memcmp(mp.handle, &h, 64)) remote = mp.ptr;
+  if (!remote) {
+    e = hipIpcOpenMemHandle(&remote, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess || !remote) return vz_fail(ctx, VIMZ_ERR_HIP, "vimz_ivc_merged_open_shared: hipIpcOpenMemHandle (not the same node, or no peer access between the two GPUs)", e);
+    if (vk->ipc_mappings.size() >= vimz_ivc::IPC_MAPPINGS) { hipIpcCloseMemHandle(vk->ipc_mappings.front().ptr); vk->ipc_mappings.erase(vk->ipc_mappings.begin()); }
+    vimz_ivc::IpcMapping mp; memcpy(mp.handle, &h, 64); mp.ptr = remote; vk->ipc_mappings.push_back(mp);
+  }
+  hipStream_t s = ctx->stream;
+  const size_t nw1 = p->n_wires, nc1 = p->n_c, nw2 = vk->sec.n_w, nc2 = vk->sec.n_c;
+  e = hipMemcpyAsync(m->dev, remote, 32 * shared_elements(vk), hipMemcpyDefault, s);
+  uint32_t nbad = 1;
+  if (e == hipSuccess) {
+    const uint32_t zero2[2] = {0, 0};
+    e = hipMemcpyAsync(p->bad_d, zero2, 8, hipMemcpyHostToDevice, s);
+    // (the layout of merged_alloc: Zp | Ep AZp BZp CZp | Zq | Eq AZq BZq CZq)
+    hipLaunchKernelGGL(k_count_unreduced<Fr>, dim3(stream_grid(nw1 + 4 * nc1)), dim3(256), 0, s, (size_t)(nw1 + 4 * nc1), (const uint32_t*)m->Zp, p->bad_d);
+    hipLaunchKernelGGL(k_count_unreduced<Fq>, dim3(stream_grid(nw2 + 4 * nc2)), dim3(256), 0, s, (size_t)(nw2 + 4 * nc2), (const uint32_t*)m->Zq, p->bad_d);
+    if (e == hipSuccess) e = hipMemcpyAsync(&nbad, p->bad_d, 4, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+  }
+  if (e != hipSuccess) {      // (a mapping that failed once is not kept)
+    auto& mps = vk->ipc_mappings;
+    for (size_t k = 0; k < mps.size(); k++) if (mps[k].ptr == remote) { hipIpcCloseMemHandle(remote); mps.erase(mps.begin() + k); break; }
+    return vz_fail(ctx, VIMZ_ERR_HIP, "vimz_ivc_merged_open_shared: copy from the other process's allocation", e);
+  }
+  if (nbad) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_ivc_merged_open_shared: a vector element is not below its modulus");
+  m->segs = std::move(segs); m->ops = std::move(ops); m->acc = std::move(acc);
+  *out = m.release();
+  return VIMZ_OK;
+}
+
 // The verifier of a merged proof: RecursiveSNARK::verify(pp, num_steps, z0, ...) (reached from folding.rs:53-55) for the object
 // S segments were merged into.  The instances are RECOMPUTED from the records (hash checks of every segment, adjacency, the fold
 // tree) — nothing the prover says about them is used — and then ONE primary and ONE secondary relaxed instance are checked against
@@ -585,6 +680,12 @@ int vimz_ivc_merged_verify(vimz_ivc_merged* m, uint64_t num_steps, const uint64_
 // are computed at once (each on its successor's context) while segment 0 already folds; only the short host chains are serial.
 // seconds (optional) = {waiting for start states, merge, total}.  Segments that get no rows (nsteps < n_seg) are left out.
 int vimz_ivc_fold_segments(vimz_ivc* const* segs, size_t n_seg, const uint64_t* z0, const uint64_t* step_inputs, size_t nsteps, vimz_ivc_merged** out, double seconds[3]) {
+  return vimz_ivc_fold_segments_dg(segs, n_seg, z0, step_inputs, nsteps, nullptr, out, seconds);
+}
+// the same when the caller already holds the rows' digests (vimz_ivc_row_digests over exactly these rows: a rank of a sharded proof
+// has just exchanged them with the other ranks) — they are not computed a second time
+int vimz_ivc_fold_segments_dg(vimz_ivc* const* segs, size_t n_seg, const uint64_t* z0, const uint64_t* step_inputs, size_t nsteps, const uint64_t* digests,
+                              vimz_ivc_merged** out, double seconds[3]) {
   if (!segs || !n_seg || !z0 || !out || !step_inputs || !nsteps) return VIMZ_ERR_INVALID;
   for (size_t k = 0; k < n_seg; k++) if (!segs[k]) return VIMZ_ERR_INVALID;
   vimz_ctx* ctx = segs[0]->ctx;
@@ -601,7 +702,7 @@ int vimz_ivc_fold_segments(vimz_ivc* const* segs, size_t n_seg, const uint64_t* 
   std::vector<int> rc_fold(S, VIMZ_OK), rc_dig(S, VIMZ_OK);
   std::vector<std::vector<uint64_t>> dig(S);
   std::vector<std::thread> th_dig, th_fold;
-  if (stride && S > 1)
+  if (stride && S > 1 && !digests)
     for (size_t k = 0; k + 1 < S; k++) {
       dig[k].resize(4 * stride * (hi[k] - lo[k]));
       th_dig.emplace_back([&, k] { rc_dig[k] = vimz_ivc_row_digests(segs[k + 1], step_inputs + 4 * n_priv * lo[k], hi[k] - lo[k], dig[k].data()); });
@@ -615,7 +716,8 @@ int vimz_ivc_fold_segments(vimz_ivc* const* segs, size_t n_seg, const uint64_t* 
       const double t0 = now_s();
       const size_t n = hi[k - 1] - lo[k - 1];
       zs.assign(4 * lz * (n + 1), 0);
-      if (stride) {
+      if (stride && digests) rc = vimz_ivc_chain_from_digests(segs[k], z.data(), step_inputs + 4 * n_priv * lo[k - 1], digests + 4 * stride * lo[k - 1], n, zs.data());
+      else if (stride) {
         th_dig[k - 1].join();
         rc = rc_dig[k - 1];
         if (!rc) rc = vimz_ivc_chain_from_digests(segs[k], z.data(), step_inputs + 4 * n_priv * lo[k - 1], dig[k - 1].data(), n, zs.data());

@@ -29,6 +29,9 @@
 #include "ec_mem.hpp"
 #include "proof_io.hpp"
 #include "merge_internal.hpp"
+#ifdef VIMZ_TESTING
+#include "../../include/vimz_hip_testing.h"
+#endif
 
 namespace {
 
@@ -637,6 +640,10 @@ size_t vimz_ivc_compressed_size(vimz_ivc* v) {
 }
 
 // CompressedSNARK::prove (mod.rs:56-59): blob receives vimz_ivc_compressed_size(v) bytes.  seconds (optional): {setup, prove}.
+#ifdef VIMZ_TESTING
+static std::atomic<bool> g_forge_public_slot{false};
+void vimz_test_forge_public_slot(int on) { g_forge_public_slot.store(on != 0); }
+#endif
 int vimz_ivc_compress(vimz_ivc* v, uint8_t* blob, size_t cap, double seconds[2]) {
   if (!v || !blob) return VIMZ_ERR_INVALID;
   vimz_ctx* ctx = v->ctx;
@@ -649,8 +656,13 @@ int vimz_ivc_compress(vimz_ivc* v, uint8_t* blob, size_t cap, double seconds[2])
   const double t_setup = now_s() - t0;
   t0 = now_s();
   // Test hook for the negative test of the public-slot binding (tests/test_gpu_compress.py): a cheating prover that claims x0 + 1 for
-  // the last fresh instance and hides the difference in the generator of that wire's slot.  Never set outside that test.
-  const bool forge = getenv("VIMZ_TEST_FORGE_PUBLIC_SLOT") != nullptr;
+  // the last fresh instance and hides the difference in the generator of that wire's slot.  Exists only in libvimz_hip_testing.so
+  // (vimz_test_forge_public_slot, include/vimz_hip_testing.h); the product library has no such prover.
+#ifdef VIMZ_TESTING
+  const bool forge = g_forge_public_slot.load();
+#else
+  const bool forge = false;
+#endif
   G2Aff forge_gen; forge_gen.x = forge_gen.y = Fe::zero();
   if (forge) {
     uint64_t xy[8];

@@ -95,7 +95,7 @@ def _ints(limbs):
     return [int(a[0]) | int(a[1]) << 64 | int(a[2]) << 128 | int(a[3]) << 192 for a in np.asarray(limbs)]
 
 
-def fold_segments_merged(ivcs, step_inputs, z0, timings=None, merged_cls=None):
+def fold_segments_merged(ivcs, step_inputs, z0, timings=None, merged_cls=None, digests=None):
     """ONE proof of all rows from state z0 on one GPU: len(ivcs) contiguous row segments, each folded as a Nova IVC by its own prover
     (own context = own streams, own host thread), then merged in row order (vimz_ivc_merge: out-of-circuit NIFS on both curves).
     Segment j starts at the state segment j-1 ends in; that state comes from the hash-only chain over segment j-1's rows: the row
@@ -105,9 +105,16 @@ def fold_segments_merged(ivcs, step_inputs, z0, timings=None, merged_cls=None):
     import time
     from concurrent.futures import ThreadPoolExecutor
     if merged_cls is None:
-        from .hip import MergedProof as merged_cls
-        if len(step_inputs) and all(hasattr(v, "h") for v in ivcs):       # the library's own fold_input: the same sequence in one C call
-            merged, t = merged_cls.fold_segments(ivcs, step_inputs, z0)
+        from . import hip as _hip
+        merged_cls = {_hip.IVC: _hip.MergedProof, _hip.CycleFoldIVC: _hip.CycleFoldMerged}.get(type(ivcs[0])) if ivcs else None
+        if merged_cls is None or any(type(v) is not type(ivcs[0]) for v in ivcs):
+            raise TypeError("fold_segments_merged: give merged_cls for provers that are not all vimz_amd.hip.IVC or all vimz_amd.hip.CycleFoldIVC")
+    from . import hip as _hip2
+    if merged_cls is _hip2.MergedProof:
+        if not all(isinstance(v, _hip2.IVC) for v in ivcs):
+            raise TypeError("fold_segments_merged: MergedProof merges vimz_amd.hip.IVC provers only (CycleFold provers: merged_cls=CycleFoldMerged)")
+        if len(step_inputs):       # the library's own fold_input: the same sequence in one C call
+            merged, t = merged_cls.fold_segments(ivcs, step_inputs, z0, digests=digests)
             if timings is not None:
                 timings["state_chain_s"] = timings.get("state_chain_s", 0.0) + t["state_chain_s"]
                 timings["merge_s"] = timings.get("merge_s", 0.0) + t["merge_s"]
@@ -124,7 +131,7 @@ def fold_segments_merged(ivcs, step_inputs, z0, timings=None, merged_cls=None):
         if two_part:      # the row hashes of segments 0 .. S-2, each on its successor's context, all at once: only the chains are serial
             for k in range(len(used) - 1):
                 lo, hi = bounds[k]
-                dig[k] = ex.submit(ivcs[used[k + 1]].row_digests, step_inputs[lo:hi])
+                dig[k] = ex.submit((lambda a, b: digests[a:b]) if digests is not None else (lambda a, b, v=ivcs[used[k + 1]]: v.row_digests(step_inputs[a:b])), lo, hi)
         for k, j in enumerate(used):
             lo, hi = bounds[k]
             if k > 0:
@@ -156,21 +163,151 @@ def fold_segments_merged(ivcs, step_inputs, z0, timings=None, merged_cls=None):
     return merged
 
 
-def prove_sharded(ivcs, step_inputs, z0, rank=0, world=1, dist=None, timings=None, merged_cls=None, shm_prefix=None):
+def _send_bytes(dist, b, dst):
+    """A small message to one rank (gloo point-to-point: length, then payload)."""
+    import torch
+    b = bytes(b)
+    dist.send(torch.tensor([len(b)], dtype=torch.int64), dst)
+    if b:
+        dist.send(torch.frombuffer(bytearray(b), dtype=torch.uint8), dst)
+
+
+def _recv_bytes(dist, src):
+    import torch
+    n = torch.zeros(1, dtype=torch.int64)
+    dist.recv(n, src)
+    if int(n[0]) == 0:
+        return b""
+    buf = torch.empty(int(n[0]), dtype=torch.uint8)
+    dist.recv(buf, src)
+    return buf.numpy().tobytes()
+
+
+def tree_rounds(world):
+    """The pairwise tree of the ranks' final fold: [(receiver, sender)] per round; in round k rank r with r % 2^(k+1) == 2^k hands its
+    proof to rank r - 2^k.  Runs of rows stay adjacent at every node (receiver's rows end where the sender's begin); depth ceil(log2 world)."""
+    rounds, step = [], 1
+    while step < world:
+        rounds.append([(r, r + step) for r in range(0, world, 2 * step) if r + step < world])
+        step *= 2
+    return rounds
+
+
+def _offer(proof, merged_cls, transport, shm_dir):
+    """What the handing-over rank sends: {"kind": "none" | "ipc" | "file" | "bytes", ...} and the file it must remove afterwards."""
+    import os
+    import tempfile
+    if proof is None:
+        return {"kind": "none"}, None
+    if transport == "ipc":
+        return {"kind": "ipc", "ticket": np.asarray(proof.share()).tobytes()}, None
+    blob = np.asarray(proof.save())
+    if transport == "file":
+        fd, path = tempfile.mkstemp(prefix="vimz_proof_", dir=shm_dir)      # (O_EXCL, unpredictable name, this user only)
+        with os.fdopen(fd, "wb") as f:
+            blob.tofile(f)
+        return {"kind": "file", "path": path, "bytes": int(blob.size)}, path
+    return {"kind": "bytes", "blob": blob.tobytes()}, None
+
+
+def tree_final_fold(proof, vk, rank, world, dist, merged_cls, shm_dir=None, timings=None):
+    """The ranks' final fold as a log-depth pairwise tree ON THE RANKS' OWN GPUs (the north_star's "host-side sequential final fold" with
+    the sequence shortened to ceil(log2 N) merges on the critical path): in round k rank r + 2^k hands its merged proof to rank r, which
+    folds it in (Node(A, B) of DESIGN.md §6b — one cross term, one large MSM, one fused fold, on r's GPU); pairs start as soon as both
+    sides are ready — no barrier.  Hand-over, in order of preference: a HIP IPC ticket (device-to-device copy incl. the running products,
+    merged_cls.open_shared), a file in node-local shared memory (save -> load), bytes through gloo.  Returns the proof on rank 0."""
+    import os
+    import pickle
+    import time
+    can_ipc = hasattr(merged_cls, "open_shared")
+    t_wait = t_merge = 0.0
+    step = 1
+    try:
+        while step < world:
+            if rank % (2 * step) == 0:
+                src = rank + step
+                if src < world:
+                    t0 = time.time()
+                    msg = pickle.loads(_recv_bytes(dist, src))
+                    t1 = time.time()
+                    t_wait += t1 - t0
+                    err = None
+                    try:
+                        other = None
+                        if msg["kind"] == "ipc":
+                            try:
+                                other = merged_cls.open_shared(vk, msg["ticket"])
+                            except Exception:      # no IPC / peer access between the two devices: ask for the bytes instead
+                                _send_bytes(dist, b"retry", src)
+                                msg = pickle.loads(_recv_bytes(dist, src))
+                        if other is None and msg["kind"] == "file":
+                            other = merged_cls.load(vk, np.fromfile(msg["path"], dtype=np.uint8, count=msg["bytes"]))
+                        elif other is None and msg["kind"] == "bytes":
+                            other = merged_cls.load(vk, np.frombuffer(msg["blob"], dtype=np.uint8))
+                        t_open = time.time()
+                        if other is not None:
+                            if proof is None:
+                                proof = other
+                            else:
+                                try:
+                                    proof.merge(other)
+                                finally:
+                                    other.close()
+                        if timings is not None:
+                            timings.setdefault("transports", []).append(msg["kind"])
+                            timings.setdefault("hand_overs", []).append({"from": src, "kind": msg["kind"], "open_s": t_open - t1, "merge_s": time.time() - t_open})
+                    except Exception as e:      # (the sender must not be left waiting: answer first, raise afterwards)
+                        err = e
+                    _send_bytes(dist, b"done" if err is None else b"fail", src)
+                    if err is not None:
+                        raise err
+                    t_merge += time.time() - t1
+            else:
+                dst = rank - step
+                transport = "ipc" if (can_ipc and proof is not None and hasattr(proof, "share")) else ("file" if shm_dir else "bytes")
+                path = None
+                try:
+                    offer, path = _offer(proof, merged_cls, transport, shm_dir)
+                    _send_bytes(dist, pickle.dumps(offer), dst)
+                    if _recv_bytes(dist, dst) == b"retry":
+                        offer, path = _offer(proof, merged_cls, "file" if shm_dir else "bytes", shm_dir)
+                        _send_bytes(dist, pickle.dumps(offer), dst)
+                        _recv_bytes(dist, dst)
+                finally:
+                    if path is not None and os.path.exists(path):
+                        os.unlink(path)
+                    if proof is not None:
+                        proof.close()
+                return None
+            step *= 2
+        return proof
+    finally:
+        if timings is not None:
+            timings["final_fold_s"] = timings.get("final_fold_s", 0.0) + t_merge
+            timings["final_fold_wait_s"] = timings.get("final_fold_wait_s", 0.0) + t_wait
+
+
+def prove_sharded(ivcs, step_inputs, z0, rank=0, world=1, dist=None, timings=None, merged_cls=None, shm_prefix=None, shm_dir=None):
     """ONE proof object of all rows from z0 over `world` ranks (one process per GPU; BASELINE.json north_star: "independent row-folds
     shard embarrassingly across the 8 GPUs ... host-side sequential final fold; no RCCL collectives needed").  Rank r proves the r-th
     contiguous run of rows with fold_segments_merged (len(ivcs) concurrent segments on its GPU); the runs' start states: every rank
     hashes its own rows, the digests are all-gathered, each rank chains over the rows before it (circuits whose digests depend on
-    the state: one chain on rank 0, scattered); the ranks' merged proofs travel as bytes (gloo gather, or node-local shared memory when
-    shm_prefix is given) and rank 0 folds them in row order (vimz_ivc_merge_merged).  Returns the proof on rank 0, None elsewhere.
-    timings: state_chain_s (rank 0's chain + scatter, plus the local segments' chains), merge_s, final_fold_s."""
+    the state: one chain on rank 0, scattered); the ranks' merged proofs are then folded pairwise up a tree on the ranks' own GPUs
+    (tree_final_fold: HIP IPC hand-over where the merged class offers it, else node-local shared memory under shm_dir, else gloo).
+    Returns the proof on rank 0, None elsewhere.
+    timings: state_chain_s (digests + all-gather + chain, plus the local segments' chains; also split as digests_s / allgather_s /
+    chain_s), merge_s, final_fold_s (this rank's opening + merging of other ranks' proofs), final_fold_wait_s (waiting for them),
+    t_ready / t_done (wall clock: local proof made / this rank's part of the tree finished)."""
     import os
     import time
     if merged_cls is None:
         from .hip import MergedProof as merged_cls
+    if shm_dir is None and shm_prefix:
+        shm_dir = os.path.dirname(shm_prefix) or "."
     n = len(step_inputs)
     bounds = segment_bounds(n, world)
     z_start = [int(x) for x in z0]
+    my_digests = None
     if world > 1:
         t0 = time.time()
         stride = ivcs[0].digest_stride() if hasattr(ivcs[0], "digest_stride") else 0
@@ -179,15 +316,26 @@ def prove_sharded(ivcs, step_inputs, z0, rank=0, world=1, dist=None, timings=Non
             # side on all GPUs), the digests are exchanged (a few hundred KB), and rank r runs the serial part — two or three small
             # permutations per row on the host — over the rows of the ranks before it.  (Rank 0 hashing everybody's rows on its GPU
             # cost 138 µs per row at 8K: 260 ms before the last of eight ranks could start a 650 ms fold.)
+            import torch
             lo, hi = bounds[rank]
-            mine = np.ascontiguousarray(ivcs[0].row_digests(step_inputs[lo:hi])) if hi > lo else np.zeros((0, stride, 4), dtype=np.uint64)
-            allg = [None] * world
-            dist.all_gather_object(allg, mine.tobytes())
+            kmax = max(h - l for l, h in bounds)
+            mine = np.zeros((kmax, stride, 4), dtype=np.uint64)
+            if hi > lo:
+                mine[:hi - lo] = np.asarray(ivcs[0].row_digests(step_inputs[lo:hi])).reshape(hi - lo, stride, 4)
+                my_digests = mine[:hi - lo]
+            t1 = time.time()
+            allg = [torch.empty(mine.size, dtype=torch.int64) for _ in range(world)]
+            dist.all_gather(allg, torch.from_numpy(mine.view(np.int64).reshape(-1)))
+            t2 = time.time()
             for r in range(rank):
                 plo, phi = bounds[r]
                 if phi > plo:
-                    dg = np.frombuffer(allg[r], dtype=np.uint64).reshape(phi - plo, stride, 4)
+                    dg = allg[r].numpy().view(np.uint64).reshape(kmax, stride, 4)[:phi - plo]
                     z_start = _ints(ivcs[0].chain_from_digests(z_start, step_inputs[plo:phi], dg)[-1])
+            if timings is not None:
+                timings["digests_s"] = timings.get("digests_s", 0.0) + t1 - t0
+                timings["allgather_s"] = timings.get("allgather_s", 0.0) + t2 - t1
+                timings["chain_s"] = timings.get("chain_s", 0.0) + time.time() - t2
         else:
             starts = [None] * world
             if rank == 0:
@@ -203,41 +351,15 @@ def prove_sharded(ivcs, step_inputs, z0, rank=0, world=1, dist=None, timings=Non
         if timings is not None:
             timings["state_chain_s"] = timings.get("state_chain_s", 0.0) + time.time() - t0
     lo, hi = bounds[rank]
-    proof = fold_segments_merged(ivcs, step_inputs[lo:hi], z_start, timings, merged_cls) if hi > lo else None
+    proof = fold_segments_merged(ivcs, step_inputs[lo:hi], z_start, timings, merged_cls, digests=my_digests) if hi > lo else None
+    if timings is not None:
+        timings["t_ready"] = time.time()
     if world == 1:
         return proof
-    dist.barrier()                      # (every rank has its proof: what follows is the final fold alone, not the wait for the slowest rank)
-    t0 = time.time()
-    blob = np.asarray(proof.save()) if (proof is not None and rank > 0) else None
-    if shm_prefix:
-        if blob is not None:
-            blob.tofile(f"{shm_prefix}{rank}")
-        dist.barrier()
-        blobs = [None] + [np.fromfile(f"{shm_prefix}{r}", dtype=np.uint8) if os.path.exists(f"{shm_prefix}{r}") else None for r in range(1, world)] if rank == 0 else None
-    else:
-        blobs = [None] * world if rank == 0 else None
-        dist.gather_object(blob.tobytes() if blob is not None else None, blobs, dst=0)
-    if rank != 0:
-        if proof is not None:
-            proof.close()
-        if shm_prefix:
-            dist.barrier()              # (rank 0 has read the files)
-            if blob is not None:
-                os.unlink(f"{shm_prefix}{rank}")
-        return None
-    for r in range(1, world):           # host-side sequential final fold, in row order
-        if blobs[r] is None:
-            continue
-        other = merged_cls.load(ivcs[0], np.frombuffer(blobs[r], dtype=np.uint8) if isinstance(blobs[r], (bytes, bytearray)) else blobs[r])
-        if proof is None:
-            proof = other
-        else:
-            proof.merge(other)
-            other.close()
-    if shm_prefix:
-        dist.barrier()
+    proof = tree_final_fold(proof, ivcs[0], rank, world, dist, merged_cls, shm_dir, timings)
     if timings is not None:
-        timings["final_fold_s"] = timings.get("final_fold_s", 0.0) + time.time() - t0
+        timings["t_done"] = time.time()
+        timings.setdefault("final_fold_s", 0.0)
     return proof
 
 

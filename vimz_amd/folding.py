@@ -238,8 +238,13 @@ def compress_proof(params, proof):
 def verify_compressed_proof(verifier_key, compressed, num_steps, initial_state):
     """compressed_proof.verify(&vk, num_steps, initial_state, secondary_initial_state) (mod.rs:63-67).  verifier_key: an IVC object
     created for the same step circuit and keys (e.g. proof.prover, or a fresh hip.IVC in another process)."""
-    words = np.frombuffer(np.ascontiguousarray(compressed, dtype=np.uint8)[:8].tobytes(), dtype=np.uint64)
-    if len(words) and int(words[0]) == 0x31474D43565A:      # a compressed MERGED proof (vimz_ivc_merged_compress)
+    if isinstance(compressed, (bytes, bytearray, memoryview)):
+        compressed = np.frombuffer(bytes(compressed), dtype=np.uint8)
+    head = np.ascontiguousarray(compressed, dtype=np.uint8).reshape(-1)[:8]
+    if head.size < 8:
+        raise _lib.VimzError(_lib.ERR_INVALID, "Failed to verify proof: the blob is shorter than its header")
+    words = np.frombuffer(head.tobytes(), dtype=np.uint64)
+    if int(words[0]) == 0x31474D43565A:      # a compressed MERGED proof (vimz_ivc_merged_compress)
         from .hip import MergedProof
         r = MergedProof.verify_compressed(verifier_key, compressed, num_steps, initial_state)
     else:

@@ -550,7 +550,6 @@ class CycleFoldIVC:
         lib.vimz_cf_profile.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
         lib.vimz_cf_export.argtypes = [vp, C.c_int, C.c_int, vp, sz]
         lib.vimz_cf_export.restype = C.c_int64
-        lib.vimz_cf_poke.argtypes = [vp, C.c_int, sz, vp]
         h = vp()
         ctx._chk(lib.vimz_cf_create(ctx.h, circuit.h, ck_main.h, ck_cyclefold.h, max_batch, C.byref(h)))
         self.h = h
@@ -598,7 +597,13 @@ class CycleFoldIVC:
         return _r1cs_tables(self.ctx.lib.vimz_cf_export, self.h, side)
 
     def poke(self, which, index, value):
-        self.ctx._chk(self.ctx.lib.vimz_cf_poke(self.h, which, index, _ptr(_zlimbs([value], 1))))
+        """Test hook (vimz_cf_poke, include/vimz_hip_testing.h): exists only when the process runs on libvimz_hip_testing.so
+        (VIMZ_HIP_LIBRARY=testing); the product library has no way to overwrite a prover's vectors."""
+        lib = self.ctx.lib
+        if not hasattr(lib, "vimz_cf_poke"):
+            raise L.VimzError(L.ERR_INVALID, "vimz_cf_poke is a test hook: start the process with VIMZ_HIP_LIBRARY=testing")
+        lib.vimz_cf_poke.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]
+        self.ctx._chk(lib.vimz_cf_poke(self.h, which, index, _ptr(_zlimbs([value], 1))))
 
     def state_chain(self, z_start, inputs):
         a = _u64(inputs).reshape(-1, self.circuit.n_priv, 4)
@@ -661,7 +666,7 @@ class CycleFoldIVC:
 def cyclefold_selfcheck_last_step(steps=4):
     """vimz_cf_selfcheck_last_step (host only): (digest, z_0, uint64 words of the last step's VIMZ_IX_LAST_STEP record)."""
     from . import _lib
-    lib = _lib.lib()
+    lib = _lib.testing_lib()
     lib.vimz_cf_selfcheck_last_step.argtypes = [C.c_int, C.c_void_p, C.c_size_t]
     lib.vimz_cf_selfcheck_last_step.restype = C.c_int64
     n = lib.vimz_cf_selfcheck_last_step(int(steps), None, 0)
@@ -676,7 +681,7 @@ def cyclefold_selfcheck_last_step(steps=4):
 def cyclefold_selfcheck_merge(segs_run0=3, segs_run1=2):
     """vimz_cf_selfcheck_merge (host only): (digest, record words, accumulator dict) of made-up segment records replayed by the library."""
     from . import _lib
-    lib = _lib.lib()
+    lib = _lib.testing_lib()
     lib.vimz_cf_selfcheck_merge.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_size_t]
     lib.vimz_cf_selfcheck_merge.restype = C.c_int64
     n = lib.vimz_cf_selfcheck_merge(segs_run0, segs_run1, None, 0)
@@ -820,7 +825,7 @@ class CycleFoldMerged:
 def cyclefold_selfcheck(steps=4):
     """vimz_cf_selfcheck (host only, no GPU): (result bits, {"main_wires", "main_constraints", "cyclefold_wires", "cyclefold_constraints"})."""
     from . import _lib
-    lib = _lib.lib()
+    lib = _lib.testing_lib()
     lib.vimz_cf_selfcheck.argtypes = [C.c_int, C.POINTER(C.c_uint32), C.c_void_p]
     r = C.c_uint32()
     counts = np.zeros(8, dtype=np.uint64)
@@ -882,22 +887,32 @@ class MergedProof:
     def of(cls, ivcs):
         """The merged proof of the segments' IVCs, in row order."""
         m = cls(ivcs[0])
-        for v in ivcs[1:]:
-            m.merge(v)
+        try:
+            for v in ivcs[1:]:
+                m.merge(v)
+        except Exception:
+            m.close()
+            raise
         return m
 
     @classmethod
-    def fold_segments(cls, ivcs, step_inputs, z0):
+    def fold_segments(cls, ivcs, step_inputs, z0, digests=None):
         """vimz_ivc_fold_segments: fold_input in one call — the rows as len(ivcs) concurrent segments (own context each), merged.
+        digests (optional): the rows' digests as vimz_ivc_row_digests returns them, when the caller has them already.
         Returns (MergedProof, {"state_chain_s", "merge_s", "total_s"}); its verifier key is ivcs[0]."""
         vk = ivcs[0]
         lib = vk.ctx.lib
-        lib.vimz_ivc_fold_segments.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_double)]
+        lib.vimz_ivc_fold_segments_dg.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_double)]
         a = _u64(step_inputs).reshape(-1, vk.circuit.n_priv, 4)
         arr = (C.c_void_p * len(ivcs))(*[v.h for v in ivcs])
         h = C.c_void_p()
         sec = (C.c_double * 3)()
-        vk.ctx._chk(lib.vimz_ivc_fold_segments(arr, len(ivcs), _ptr(_zlimbs(z0, vk.circuit.len_z)), _ptr(a), a.shape[0], C.byref(h), sec))
+        dg = None
+        if digests is not None:
+            dg = np.ascontiguousarray(digests, dtype=np.uint64)
+            if dg.size != a.shape[0] * vk.digest_stride() * 4:
+                raise ValueError("fold_segments: digests do not match the rows")
+        vk.ctx._chk(lib.vimz_ivc_fold_segments_dg(arr, len(ivcs), _ptr(_zlimbs(z0, vk.circuit.len_z)), _ptr(a), a.shape[0], _ptr(dg) if dg is not None else None, C.byref(h), sec))
         m = cls.__new__(cls)
         cls.__init__(m, _handle=h, _vk=vk)
         return m, {"state_chain_s": sec[0], "merge_s": sec[1], "total_s": sec[2]}
@@ -910,6 +925,27 @@ class MergedProof:
         cls.__init__(m, _handle=C.c_void_p(0), _vk=vk)
         h = C.c_void_p()
         vk.ctx._chk(vk.ctx.lib.vimz_ivc_merged_load(vk.h, _ptr(b), b.size, C.byref(h)))
+        m.h = h
+        return m
+
+    def share(self):
+        """vimz_ivc_merged_share: the ticket (records + HIP IPC handle of the device allocation) another process of this node opens
+        with MergedProof.open_shared; keep this object open until that process is done."""
+        lib = self.ctx.lib
+        lib.vimz_ivc_merged_share.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        lib.vimz_ivc_merged_share.restype = C.c_int64
+        return _export(lib.vimz_ivc_merged_share, self.h)
+
+    @classmethod
+    def open_shared(cls, vk, ticket):
+        """vimz_ivc_merged_open_shared: an object of this process's own out of another process's shared one (device-to-device copy)."""
+        b = np.ascontiguousarray(np.frombuffer(bytes(ticket), dtype=np.uint8) if isinstance(ticket, (bytes, bytearray)) else ticket, dtype=np.uint8)
+        m = cls.__new__(cls)
+        cls.__init__(m, _handle=C.c_void_p(0), _vk=vk)
+        lib = vk.ctx.lib
+        lib.vimz_ivc_merged_open_shared.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+        h = C.c_void_p()
+        vk.ctx._chk(lib.vimz_ivc_merged_open_shared(vk.h, _ptr(b), b.size, C.byref(h)))
         m.h = h
         return m
 
