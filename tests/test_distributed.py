@@ -22,6 +22,28 @@ def test_segment_bounds_cover_all_rows():
             assert max(sizes) - min(sizes) <= 1
 
 
+def _get_or_fail(q, procs, timeout):
+    """The result a rank put on the queue — or a failure as soon as any rank has died (not after the whole timeout)."""
+    import queue
+    import time
+    t0 = time.time()
+    while True:
+        try:
+            return q.get(timeout=2)
+        except queue.Empty:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            if dead:
+                for p in procs:
+                    if p.is_alive():
+                        p.kill()
+                raise AssertionError(f"a rank exited with {dead} before the result arrived (its traceback is in the captured stderr)")
+            if time.time() - t0 > timeout:
+                for p in procs:
+                    if p.is_alive():
+                        p.kill()
+                raise AssertionError("timed out waiting for the ranks")
+
+
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
@@ -88,7 +110,7 @@ def test_two_rank_fold_on_the_gpu_prover(oracle):
     procs = [ctx.Process(target=_gpu_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res, z_final, steps, vflags = q.get(timeout=900)
+    res, z_final, steps, vflags = _get_or_fail(q, procs, 900)
     for p in procs:
         p.join(timeout=300)
         assert p.exitcode == 0
@@ -108,7 +130,7 @@ def test_two_rank_fold_merges_and_verifies(oracle):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res, z_final, steps, vflags = q.get(timeout=600)
+    res, z_final, steps, vflags = _get_or_fail(q, procs, 600)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -304,7 +326,7 @@ def _run_sharded(world, shm, digests, n_rows):
     procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, q, shm, digests, n_rows)) for r in range(world)]
     for p in procs:
         p.start()
-    out = q.get(timeout=600)
+    out = _get_or_fail(q, procs, 600)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -465,7 +487,7 @@ def test_two_ranks_on_the_gpu_end_in_one_verified_cyclefold_proof_object(oracle)
     procs = [ctx.Process(target=_gpu_sharded_cyclefold_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    ok9, ok8, state, segments = q.get(timeout=900)
+    ok9, ok8, state, segments = _get_or_fail(q, procs, 900)
     for p in procs:
         p.join(timeout=300)
         assert p.exitcode == 0
@@ -485,7 +507,7 @@ def _run_gpu_sharded(world, oracle_replay):
     procs = [ctx.Process(target=_gpu_sharded_worker, args=(r, world, port, q, oracle_replay)) for r in range(world)]
     for p in procs:
         p.start()
-    out = q.get(timeout=900)
+    out = _get_or_fail(q, procs, 900)
     for p in procs:
         p.join(timeout=300)
         assert p.exitcode == 0

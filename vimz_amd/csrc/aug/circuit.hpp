@@ -151,7 +151,7 @@ AugOut<FP> synthesize_augmented(CS<FP>& cs, const AugIn<FP>& in, const std::vect
   hin.push_back(UW.x); hin.push_back(UW.y); hin.push_back(UE.x); hin.push_back(UE.y);
   N h_chk = cs.hash_cached(hin, cache ? &cache->rest : nullptr, nullptr);
   VZ_T(1, "hash_in");
-  std::vector<N> hb = cs.bits_strict(h_chk);
+  std::vector<N> hb = cs.bits(h_chk, FP::BITS);
   N h250 = cs.pack(hb, 0, 250);
   cs.enforce(nb, cs.sub(h250, ux0), cs.zero());
   if (!base && !h250.v.eq(ux0.v)) cs.bad = true;
@@ -160,7 +160,7 @@ AugOut<FP> synthesize_augmented(CS<FP>& cs, const AugIn<FP>& in, const std::vect
   // ---- challenge ----------------------------------------------------------------------------------------------------------
   N hr = cs.hash({h_chk, uW.x, uW.y, ux0, ux1, T.x, T.y});
   VZ_T(3, "hash_rho");
-  std::vector<N> rb = cs.bits_strict(hr);
+  std::vector<N> rb = cs.bits_strict(hr);      // (canonical: of the two bit vectors that sum to hr mod p only one is accepted — ADVICE r3; the truncated instance hashes above and below stay plain: both of their candidate values are functions of the same preimage)
   N rho0 = cs.pack(rb, 0, 64), rho1 = cs.pack(rb, 64, 128);
   { F c = F::from_mont(hr.v); for (int k = 0; k < 4; k++) out.rho_low[k] = c.v[k]; }
   N rho = cs.add(cs.add(rho0, cs.scale(rho1, cb::f_pow2<F>(64))), cs.constant(cb::f_pow2<F>(128)));
@@ -243,7 +243,7 @@ AugOut<FP> synthesize_augmented(CS<FP>& cs, const AugIn<FP>& in, const std::vect
     hc.out = h_new.v; hc.valid = true;
   }
   VZ_T(11, "hash_out_2");
-  std::vector<N> hnb = cs.bits_strict(h_new);
+  std::vector<N> hnb = cs.bits(h_new, FP::BITS);
   N hn250 = cs.pack(hnb, 0, 250);
 
   // ---- public IO (the last two wires of the circuit) -------------------------------------------------------------------------

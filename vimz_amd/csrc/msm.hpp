@@ -16,7 +16,8 @@
 //   6. k_reduce    per window: chunked running sums + LDS tree -> sum_b b*B_b.
 //      (unit scalars, when split: k_ones_partial + k_tree256 -> one extra "window sum")
 //   7. host        Horner over the K window sums (K*c doublings) and one inversion to affine (msm_finish).
-// Optional window tables (k_build_tables, vimz_bases_precompute): one bucket set for all windows, k_reduce_big1/2, no Horner.
+// Optional window tables (k_build_tables, vimz_bases_precompute): one bucket set for all windows, reduced as virtual windows of
+// MSM_VWIN buckets by k_reduce (R_v, S_v), no Horner.
 // Addition order inside a bucket is arbitrary, but the result is an exact group element, so the affine output is
 // bit-identical run to run and to the CPU oracle.
 #pragma once
@@ -404,10 +405,13 @@ __global__ void __launch_bounds__(256) k_combine_heavy2(uint32_t* __restrict__ p
   if (lane == 0 && mine) store_xyzz(partial, sub_off[heavy[1 + h]], sh[t]);
 }
 // grid = K workgroups of T threads (T = min(256, nbw)); window sum = Σ_{idx} (idx+1)·B_idx
+// plain_sums (optional): also Σ_idx B_idx of every window — with window tables and ONE bucket set shared by all windows (c = 13..16)
+// the 2^(c-1) buckets are reduced as V = 2^(c-1)/1024 "virtual windows" of 1024 buckets each by this same kernel (V workgroups side by
+// side, the depth of the c = 11 reduce), and the host finishes  Σ_v R_v + 1024·Σ_v v·S_v  (msm_finish).
 template <class F>
 __global__ void __launch_bounds__(256) k_reduce(const uint32_t* __restrict__ partial, const uint32_t* __restrict__ counts,
                                                 const uint32_t* __restrict__ sub_off, uint32_t nbw,
-                                                uint32_t* __restrict__ window_sums) {
+                                                uint32_t* __restrict__ window_sums, uint32_t* __restrict__ plain_sums = nullptr) {
   __shared__ XYZZ<F> sh[256];
   const uint32_t w = blockIdx.x, t = threadIdx.x, T = blockDim.x;
   const uint32_t ch = nbw / T;
@@ -435,7 +439,7 @@ __global__ void __launch_bounds__(256) k_reduce(const uint32_t* __restrict__ par
     XYZZ<F> sfx = sh[t];
     for (uint32_t k = 1; k < ch; k <<= 1) sfx = dbl(sfx);     // ch is a power of two
     add_full(sum, sfx);
-  }
+  } else if (plain_sums) store_xyzz(plain_sums, w, sh[0]);    // (the suffix sum at 0 is the sum of all the window's buckets)
   __syncthreads();
   sh[t] = sum;
   __syncthreads();
@@ -766,53 +770,6 @@ __device__ __forceinline__ XYZZ<F> small_mul(const XYZZ<F>& p, uint32_t k) {
   for (int bit = 31 - __clz(k); bit >= 0; bit--) { acc = dbl(acc); if ((k >> bit) & 1) add_full(acc, p); }
   return acc;
 }
-template <class F>
-__global__ void __launch_bounds__(256) k_reduce_big1(const uint32_t* __restrict__ partial, const uint32_t* __restrict__ counts,
-                                                     const uint32_t* __restrict__ sub_off, uint32_t* __restrict__ rs /* [2][gridDim.x] */) {
-  __shared__ XYZZ<F> sh[256];
-  const uint32_t w = blockIdx.x, t = threadIdx.x, g = w * 256 + t;
-  XYZZ<F> B = XYZZ<F>::identity();
-  if (counts[g]) B = load_xyzz<F>(partial, sub_off[g]);
-  XYZZ<F> v = small_mul(B, t + 1);
-  for (int pass = 0; pass < 2; pass++) {
-    sh[t] = pass == 0 ? v : B;
-    __syncthreads();
-    for (uint32_t d = 128; d > 0; d >>= 1) {
-      if (t < d) { XYZZ<F> a = sh[t]; add_full(a, sh[t + d]); sh[t] = a; }
-      __syncthreads();
-    }
-    if (t == 0) store_xyzz(rs, (size_t)pass * gridDim.x + w, sh[0]);
-    __syncthreads();
-  }
-}
-template <class F>
-__global__ void __launch_bounds__(256) k_reduce_big2(const uint32_t* __restrict__ rs, uint32_t nwg, uint32_t* __restrict__ window_sums) {
-  __shared__ XYZZ<F> sh[256];
-  const uint32_t t = threadIdx.x;
-  XYZZ<F> total = XYZZ<F>::identity();
-  for (int pass = 0; pass < 2; pass++) {
-    XYZZ<F> acc = XYZZ<F>::identity();
-    for (uint32_t w = t; w < nwg; w += 256) {
-      XYZZ<F> p = load_xyzz<F>(rs, (size_t)pass * nwg + w);
-      if (pass == 1) p = small_mul(p, w);
-      add_full(acc, p);
-    }
-    sh[t] = acc;
-    __syncthreads();
-    for (uint32_t d = 128; d > 0; d >>= 1) {
-      if (t < d) { XYZZ<F> a = sh[t]; add_full(a, sh[t + d]); sh[t] = a; }
-      __syncthreads();
-    }
-    if (t == 0) {
-      XYZZ<F> r = sh[0];
-      if (pass == 1) for (int k = 0; k < 8; k++) r = dbl(r);   // x 256
-      add_full(total, r);
-    }
-    __syncthreads();
-  }
-  if (t == 0) store_xyzz(window_sums, 0, total);
-}
-
 // Table construction: tables[j][i] = 2^(c j) * P_i in affine internal form (row 0 = the key itself).
 template <class F>
 __global__ void __launch_bounds__(256) k_build_tables(const uint32_t* __restrict__ bases, size_t n, int c, int K, uint32_t* __restrict__ tables) {
@@ -888,6 +845,7 @@ hipError_t msm_launch(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_ba
   MsmPlan pl = msm_plan(n, S::Params::BITS, tabled ? tb->c : c_override);
   if (tabled) {            // one bucket set shared by all windows — or (own) the usual ones, whose sums then need no Horner
     if (tb->K != pl.K || pl.nbw < 256 || (size_t)tb->K * tb->n_total >= (1u << 31)) return hipErrorInvalidValue;
+    if (!own && 2 * (pl.nbw / std::min<uint32_t>(pl.nbw, MSM_VWIN)) + 1 > (uint32_t)MSM_MAX_WINDOWS) return hipErrorInvalidValue;
     if (own) pl.tabled = 3; else { pl.nb = pl.nbw; pl.tabled = 1; }
     d_bases = tb->d + (size_t)AFFINE_WORDS * tb->offset;
   }
@@ -965,11 +923,11 @@ hipError_t msm_launch(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_ba
   VZ_EV(5);
   const unsigned T = pl.nbw < 256 ? pl.nbw : 256;
   uint32_t* wsum = direct ? reinterpret_cast<uint32_t*>(pinned_dst) : reinterpret_cast<uint32_t*>(ws.window_sums);
-  const int kout = tabled && !own ? 1 : pl.K;     // window sums produced
+  const uint32_t vw = std::min<uint32_t>(pl.nbw, MSM_VWIN);      // shared bucket set: virtual windows of vw buckets
+  const int V = (int)(pl.nbw / vw);
+  const int kout = tabled && !own ? 2 * V : pl.K;     // sums produced: (R_v, S_v) per virtual window, or one per window
   if (tabled && !own) {
-    uint32_t* rs = reinterpret_cast<uint32_t*>(ws.ones_partial);   // scratch: 2 x (nbw/256) points (<= 2 x 128 of the 16448)
-    hipLaunchKernelGGL(k_reduce_big1<F>, dim3(pl.nbw / 256), dim3(256), 0, stream, partial, ws.counts, ws.sub_off, rs + (size_t)XYZZ_WORDS * 16448);
-    hipLaunchKernelGGL(k_reduce_big2<F>, dim3(1), dim3(256), 0, stream, rs + (size_t)XYZZ_WORDS * 16448, pl.nbw / 256, wsum);
+    hipLaunchKernelGGL(k_reduce<F>, dim3(V), dim3(vw < 256 ? vw : 256), 0, stream, partial, ws.counts, ws.sub_off, vw, wsum, wsum + (size_t)XYZZ_WORDS * V);
   } else
   hipLaunchKernelGGL(k_reduce<F>, dim3(pl.K), dim3(T), 0, stream, partial, ws.counts, ws.sub_off, pl.nbw, wsum);
   VZ_EV(6);
@@ -1000,7 +958,19 @@ Affine<typename C::Base> msm_finish(const MsmPlan& pl, const void* pinned) {
     return p;
   };
   XYZZ<FS> acc = XYZZ<FS>::identity();
-  const int kout = pl.tabled == 1 ? 1 : pl.K;      // tabled == 2, 3: K sums of one bucket set each, already weighted
+  if (pl.tabled == 1) {
+    // one bucket set shared by all windows, reduced as V virtual windows of MSM_VWIN buckets: bucket b = MSM_VWIN·v + idx weighs
+    // (idx + 1) + MSM_VWIN·v, so the sum is  Σ_v R_v + MSM_VWIN·Σ_v v·S_v  with  Σ_v v·S_v = Σ_{s>=1} Σ_{v>=s} S_v
+    const uint32_t vw = pl.nbw < MSM_VWIN ? pl.nbw : MSM_VWIN;
+    const int V = (int)(pl.nbw / vw);
+    XYZZ<FS> run = XYZZ<FS>::identity();
+    for (int v = V - 1; v >= 1; v--) { add_full(run, host_point(V + v)); add_full(acc, run); }
+    for (uint32_t k = 1; k < vw; k <<= 1) acc = dbl(acc);
+    for (int v = 0; v < V; v++) add_full(acc, host_point(v));
+    if (pl.split_ones) add_full(acc, host_point(2 * V));
+    return to_affine(acc);
+  }
+  const int kout = pl.K;      // tabled == 2, 3: K sums of one bucket set each, already weighted
   for (int w = kout - 1; w >= 0; w--) {
     if (!pl.tabled) for (int k = 0; k < pl.c; k++) acc = dbl(acc);
     add_full(acc, host_point(w));

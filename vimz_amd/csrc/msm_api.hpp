@@ -31,6 +31,7 @@ constexpr int MSM_SUB = 16;          // max entries one thread accumulates in k_
                                      // (shorter pieces: k_accum wastes fewer lanes at its end, k_combine has more partials to fold —
                                      // in the bench 0.27 + 0.31, 0.29 + 0.25, 0.32 + 0.25, 0.53 + 0.19 ms)
 constexpr int MSM_MAX_WINDOWS = 96;
+constexpr uint32_t MSM_VWIN = 1024;  // window tables with one shared bucket set: its 2^(c-1) buckets are reduced as virtual windows of this many
 
 struct MsmPlan {
   int c;            // window bits
@@ -38,7 +39,7 @@ struct MsmPlan {
   uint32_t nbw;     // buckets per window = 2^(c-1)
   uint32_t nb;      // total buckets
   int split_ones;   // unit scalars summed separately (window_sums[K])
-  int tabled;       // 1: window tables, one bucket set, one window sum, no Horner; 2: tables of the fused small path (K sums, no Horner)
+  int tabled;       // 1: window tables, one bucket set, (R_v, S_v) of nbw / MSM_VWIN virtual windows, no Horner; 2: tables of the fused small path (K sums, no Horner)
 };
 
 // The fused single-launch path for small MSMs (k_msm_small): window, points per workgroup chunk, chunks, size limit.
