@@ -209,6 +209,8 @@ def main_ivc(args, rank, world, dist, torch, ctxs, circuit, params, steps_all, g
             pw.close()
     tm = {}
     sync_all()
+    if world == 1:
+        ctxs[0].trace_marker(1)      # (an empty kernel in a profiler's trace: tools/trace_busy.py cuts the timed region out between markers 1 and 2)
     t0 = time.time()
     # the timed job: ONE proof of world x K rows from z0 (proof sets: every rank its own proof of K rows).  Rank r's rows start at the
     # state after the r·K rows of the ranks before it: rank 0 runs that hash-only chain once and hands every rank its start state;
@@ -221,6 +223,8 @@ def main_ivc(args, rank, world, dist, torch, ctxs, circuit, params, steps_all, g
         tm["t_ready"] = tm["t_done"] = time.time()
     sync_all()
     dt = time.time() - t0
+    if world == 1:
+        ctxs[0].trace_marker(2)
     mem = memory_now(torch, ctxs[0].device)
     state_chain_s, final_fold_s = tm.get("state_chain_s", 0.0), tm.get("final_fold_s", 0.0)
     prof1 = [ivc.profile() for ivc in ivcs]
@@ -235,6 +239,8 @@ def main_ivc(args, rank, world, dist, torch, ctxs, circuit, params, steps_all, g
         dt, t_ready_max, prologue_max = float(t[0]), float(t[1]), float(t[2])
         tree = {"hand_overs_to_rank0": tm.get("hand_overs"), "digests_s_max": float(t[3]), "allgather_s_max": float(t[4]), "chain_s_max": float(t[5]), "merging_s_max_over_ranks": float(t[6]),
                 "waiting_for_partner_s_max_over_ranks": float(t[7])}
+    if os.environ.get("VIMZ_BENCH_DEBUG"):      # every rank's own view of the timed job
+        print(f"[bench rank {rank}] " + json.dumps({k: (round(v - t0, 4) if k in ("t_ready", "t_done") else v) for k, v in tm.items()}), file=sys.stderr, flush=True)
     final_tail_s = max(0.0, t_done_0 - t_ready_max) if world > 1 else 0.0
     t_fold = dt - final_tail_s
     timed_rows = K
@@ -498,7 +504,7 @@ def main():
     ap.add_argument("--no-compress", action="store_true", help="skip CompressedSNARK::prove / verify of the folded proof")
     ap.add_argument("--no-extras", action="store_true", help="skip the one-chain and Sonobe-backend extras of the default IVC run")
     ap.add_argument("--mode", default="ivc", choices=["ivc", "accumulator"])
-    ap.add_argument("--window-tables", type=int, default=0, help="window tables of the primary key in HBM (vimz_bases_precompute): 11 = per-window buckets, no host Horner; 13..16 = one shared bucket set; 0 = none")
+    ap.add_argument("--window-tables", type=int, default=15, help="window tables of the primary key in HBM (vimz_bases_precompute): 11 = per-window buckets, no host Horner; 13..16 = one shared bucket set; 0 = none")
     ap.add_argument("--proof-set", default="", help="comma-separated transformations: rank r proves proof_set[r %% len] (BASELINE config 5: independent proofs, replicas only)")
     ap.add_argument("--share-gpus", action="store_true", help="allow more ranks than visible GPUs (ranks r and r + n_devices share a device): evidence lines "
                     "on a one-GPU box, never a scaling claim; the line says so in `gpus_shared`")

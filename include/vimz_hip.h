@@ -65,6 +65,9 @@ const char* vimz_version(void);
 int vimz_device_info(vimz_ctx* ctx, char* name, size_t name_len, int* cus, uint64_t* hbm_bytes);
 int vimz_sync(vimz_ctx* ctx);
 
+/* A marker for a profiler's kernel trace: an empty kernel `k_trace_marker` of `id` (1..1024) workgroups on the context's stream, waited for
+ * (bench.py brackets its timed region with ids 1 and 2; tools/trace_busy.py cuts the trace there). */
+int vimz_trace_marker(vimz_ctx* ctx, int id);
 /* Stream-ordered timing with HIP events on the context's stream (used by bench.py for the roofline). */
 int vimz_timer_start(vimz_ctx* ctx);
 int vimz_timer_stop(vimz_ctx* ctx, float* ms_out);

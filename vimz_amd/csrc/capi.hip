@@ -279,6 +279,20 @@ int vimz_sync(vimz_ctx* c) {
   return VIMZ_OK;
 }
 
+// A marker in a profiler's kernel trace: an empty kernel named k_trace_marker with `id` workgroups on the context's stream, waited for.
+// bench.py brackets its timed region with markers 1 and 2 so that tools/trace_busy.py measures the fold itself, not the set-up,
+// the compression and the extras around it.
+namespace vz { __global__ void k_trace_marker() {} }
+int vimz_trace_marker(vimz_ctx* c, int id) {
+  if (!c || id < 1 || id > 1024) return VIMZ_ERR_INVALID;
+  std::lock_guard<std::mutex> g(c->mu);
+  HIP_TRY(c, hipSetDevice(c->device));
+  hipLaunchKernelGGL(vz::k_trace_marker, dim3((unsigned)id), dim3(64), 0, c->stream);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return VIMZ_OK;
+}
+
 int vimz_timer_start(vimz_ctx* c) {
   if (!c) return VIMZ_ERR_INVALID;
   std::lock_guard<std::mutex> g(c->mu);

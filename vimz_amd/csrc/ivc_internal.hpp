@@ -93,7 +93,10 @@ struct vimz_ivc {
   std::vector<MsmHelper> helpers; hipEvent_t ev_T = nullptr; size_t t1_main_n = 0;
   // one set of a merged proof's buffers (merge.hip) kept from the last one that was freed: the next vimz_ivc_merged_create over this
   // IVC needs no allocation (device + pinned: 0.5-2 ms next to running kernels, inside a timed fold_input)
-  uint32_t* merged_spare_dev = nullptr; void* merged_spare_pin = nullptr;
+  // (two sets: a rank of a sharded proof holds its own merged proof and, while it folds another rank's in, that one's copy —
+  //  a hipMalloc of 50 MB next to four processes' kernels was measured at 30-60 ms inside a 20-row timed window)
+  enum { MERGED_SPARES = 2 };
+  uint32_t* merged_spare_dev[MERGED_SPARES] = {nullptr, nullptr}; void* merged_spare_pin[MERGED_SPARES] = {nullptr, nullptr};
   // hand-over of merged proofs between the processes of a node (vimz_ivc_merged_share / _open_shared): a merged proof's device
   // allocation is recycled from proof to proof (the spare set above), so its IPC handle is made once (export side) and the other
   // process's mapping of it is kept open (import side: at most IPC_MAPPINGS, oldest closed first) — the second and later proofs of a

@@ -91,7 +91,9 @@ size_t merged_words(const vimz_ivc* v) {      // 32-byte elements of the one dev
 // (its buffers go back to the verifier-key IVC as the spare set when that has none)
 void release_buffers(vimz_ivc_merged* m) {
   vimz_ivc* vk = m->vk;
-  if (vk && m->dev && m->pin && !vk->merged_spare_dev) { vk->merged_spare_dev = m->dev; vk->merged_spare_pin = m->pin; }
+  int slot = -1;
+  if (vk && m->dev && m->pin) for (int k = 0; k < vimz_ivc::MERGED_SPARES && slot < 0; k++) if (!vk->merged_spare_dev[k]) slot = k;
+  if (slot >= 0) { vk->merged_spare_dev[slot] = m->dev; vk->merged_spare_pin[slot] = m->pin; }
   else {
     if (m->dev) {
       if (vk) { auto& ex = vk->ipc_exports; ex.erase(std::remove_if(ex.begin(), ex.end(), [&](const vimz_ivc::IpcExport& e) { return e.dev == m->dev; }), ex.end()); }   // (the address may come back as another allocation)
@@ -127,7 +129,9 @@ int merged_alloc(vimz_ivc* vk, MergedPtr& m) {
   m->vk = vk;
   vk->merged_dependents.push_back(m.get()); vk->orphan_merged = orphan_dependents;
   const size_t nw1 = vk->pri->n_wires, nc1 = vk->pri->n_c, nw2 = vk->sec.n_w, nc2 = vk->sec.n_c;
-  if (vk->merged_spare_dev) { m->dev = vk->merged_spare_dev; m->pin = vk->merged_spare_pin; vk->merged_spare_dev = nullptr; vk->merged_spare_pin = nullptr; }
+  int slot = -1;
+  for (int k = 0; k < vimz_ivc::MERGED_SPARES && slot < 0; k++) if (vk->merged_spare_dev[k]) slot = k;
+  if (slot >= 0) { m->dev = vk->merged_spare_dev[slot]; m->pin = vk->merged_spare_pin[slot]; vk->merged_spare_dev[slot] = nullptr; vk->merged_spare_pin[slot] = nullptr; }
   else P_TRY(hipMalloc((void**)&m->dev, 32 * merged_words(vk)));
   uint32_t* d = m->dev;
   auto take = [&](size_t n) { uint32_t* r = d; d += 8 * n; return r; };

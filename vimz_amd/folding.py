@@ -94,10 +94,12 @@ class FoldingParams:
         self.ck.free()
 
 
-def prepare_folding(ctx, transformation, resolution="HD", ck_label=b"ck", window_tables=0, backend="nova-snark"):
+def prepare_folding(ctx, transformation, resolution="HD", ck_label=b"ck", window_tables=15, backend="nova-snark"):
     """prepare_folding (folding.rs:20-25): build the step circuit and derive the commitment key on the GPU.
-    window_tables: 0 = none; 11 = tables 2^(11j)·P_i with the usual per-window buckets (24 x the key in HBM, 1 GB at HD: the
-    window sums need no Horner on the host); 13..16 = one bucket set shared by all windows (vimz_bases_precompute).
+    window_tables: 13..16 = window tables T_j[i] = 2^(c j)·P_i of the key in HBM with ONE bucket set shared by all windows
+    (vimz_bases_precompute; default 15: 17 x the key = 0.7 GB at HD, 17 digits per scalar instead of 24 — the large MSM of a step
+    1.10 -> 0.84 ms alone, the three-segment bench 964 -> 1095 steps/s, profiles/r04_msm_phases_tables.txt); 11 = tables with the usual
+    per-window buckets (no Horner on the host); 0 = none.
     backend: "nova-snark" (vimz/src/nova_snark_backend) or "sonobe" (vimz/src/sonobe_backend: Nova + CycleFold, fold_input(mode="cyclefold"));
     it only sizes the key (the reference's two backends size theirs the same way: for the augmented circuit)."""
     t0 = time.time()

@@ -91,6 +91,11 @@ class Context:
         self._chk(self.lib.vimz_device_info(self.h, name, 256, C.byref(cus), C.byref(hbm)))
         return {"name": name.value.decode(), "cus": cus.value, "hbm_bytes": hbm.value}
 
+    def trace_marker(self, ident):
+        """vimz_trace_marker: an empty kernel of `ident` workgroups in the profiler's kernel trace (bench.py: 1 / 2 around the timed region)."""
+        self.lib.vimz_trace_marker.argtypes = [C.c_void_p, C.c_int]
+        self._chk(self.lib.vimz_trace_marker(self.h, int(ident)))
+
     def sync(self):
         self._chk(self.lib.vimz_sync(self.h))
 
