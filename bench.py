@@ -60,40 +60,90 @@ def build_inputs(transformation, resolution):
     return steps, z0
 
 
-def cpu_baseline(circuit, steps, z0, ck_host, budget_s, threads):
-    """The oracle (CPU restatement, kind "port") timed on the same workload for about `budget_s` seconds: witness,
-    (A,B,C)·z, MSM(W), cross term, MSM(T), folds.  Reported beside the GPU number; never the thing measured as `value`.
+def cpu_baseline(circuit, steps, z0, ck_host, budget_s, threads, ivc=None, ck2_host=None):
+    """The oracle (CPU restatement, kind "port") timed on the same workload for about `budget_s` seconds, like for like with what `value`
+    counts as a step: per row the step circuit's witness (rows of a batch evaluated side by side on the host threads, after
+    the hash-only state chain — the way the GPU path batches them), (A,B,C)·z, MSM(W), cross term, MSM(T) and the five folds of the primary
+    instance, AND the recursion's share — the two verifier circuits: their (A,B,C)·z (the oracle's pass over the exported secondary shape,
+    once per circuit: 7 925 / 7 912 rows), the four commitments over their wires / rows (two on BN254 G1, two on Grumpkin), their cross terms
+    and folds, and the native arithmetic their witness generation is made of (four instance hashes, four 128-bit scalar multiplications:
+    oracle/nova.hpp).  Reported beside the GPU number; never the thing measured as `value`.
     Returns (steps/s, seconds, steps, per-phase seconds per step)."""
+    from concurrent.futures import ThreadPoolExecutor
     from tests import _oracle
     orc = _oracle.load()
     aux0 = 1 + 2 * circuit.len_z
     key_m = orc.to_mont(1, ck_host.reshape(-1, 4)).reshape(-1, 8)      # Montgomery bases, as the product keeps them
-    z = list(z0)
-    ph = {"witness_1_thread": 0.0, "spmv": 0.0, "msm_w": 0.0, "cross_term": 0.0, "msm_t": 0.0, "folds": 0.0}
+    ph = {"state_chain": 0.0, "witness": 0.0, "spmv": 0.0, "msm_w": 0.0, "cross_term": 0.0, "msm_t": 0.0, "folds": 0.0, "verifier_circuits": 0.0}
+    rec = None
+    if ivc is not None and ck2_host is not None:      # the recursion's share: shapes and witness vectors of the two verifier circuits as the prover holds them
+        from vimz_amd import hip
+        tabs2 = ivc.r1cs(1)
+        Z2 = np.ascontiguousarray(ivc.export(1, hip.IX_FRESH_Z))
+        n2w, n2c = len(Z2), len(tabs2["A_rowptr"]) - 1
+        key2_m = orc.to_mont(0, ck2_host.reshape(-1, 4)).reshape(-1, 8)
+        rs = np.random.default_rng(11)
+        dense = lambda n: np.ascontiguousarray(np.concatenate([rs.integers(0, 1 << 63, size=(n, 3), dtype=np.uint64), rs.integers(0, 1 << 59, size=(n, 1), dtype=np.uint64)], axis=1))
+        info = ivc.info()
+        nvw, nvc = info["verifier_wires"], info["primary_constraints"] - info["step_constraints"]
+        rec = {"tabs2": tabs2, "Z2": Z2, "n2w": n2w, "n2c": n2c, "key2": key2_m, "w1": dense(nvw), "t1": dense(nvc), "t2": dense(n2c), "e2": dense(n2c), "off": info["step_wires"] - 1,
+               "g1": (1, 2), "g2": (1, 17631683881184975370165255887551781615748388533673675138860)}
+    if len(steps):
+        _oracle.witness_execute(orc, circuit, [int(x) for x in z0], steps[0])      # (builds the executor's tables once, before the threads share them)
     t0 = time.time()
     run, n = None, 0
-    while n < len(steps) and (n < 2 or time.time() - t0 < budget_s):
-        t = time.time()
-        st, w, z = _oracle.witness_execute(orc, circuit, z, steps[n])
-        ph["witness_1_thread"] += time.time() - t; t = time.time()
-        bad, (a2, b2, c2) = _oracle.r1cs_check(orc, circuit, w, want_products=True, threads=threads)
-        assert st == 0 and bad == -1
-        ph["spmv"] += time.time() - t; t = time.time()
-        _, cW = orc.msm_mont_timed(0, key_m, np.ascontiguousarray(w[aux0:]), threads)
-        ph["msm_w"] += time.time() - t
-        n += 1
-        if run is None:
-            run = [w, a2, b2, c2, np.zeros_like(a2), 1]
-            continue
-        t = time.time()
-        T = orc.cross_term(0, run[1], run[2], run[3], run[5], a2, b2, c2, 1, threads=threads)
-        ph["cross_term"] += time.time() - t; t = time.time()
-        _, cT = orc.msm_mont_timed(0, key_m, T, threads)
-        ph["msm_t"] += time.time() - t; t = time.time()
-        r = (cT[0] ^ cW[0]) & ((1 << 128) - 1)        # any 128-bit challenge: the arithmetic cost does not depend on it
-        run = [orc.axpy(0, run[0], r, w, threads), orc.axpy(0, run[1], r, a2, threads), orc.axpy(0, run[2], r, b2, threads), orc.axpy(0, run[3], r, c2, threads),
-               orc.axpy(0, run[4], r, T, threads), (run[5] + r) % orc.modulus[0]]
-        ph["folds"] += time.time() - t
+    z = [int(x) for x in z0]
+    with ThreadPoolExecutor(max(1, threads)) as ex:
+        while n < len(steps) and (n < 2 or time.time() - t0 < budget_s):
+            batch = steps[n:n + max(1, threads)]
+            t = time.time()
+            zs = [z]
+            for row in batch:      # hash-only state chain of the batch (serial), then the witnesses side by side
+                ok, zn = orc.step_eval(circuit.t, zs[-1], row, *circuit.shape)
+                assert ok
+                zs.append(zn)
+            ph["state_chain"] += time.time() - t; t = time.time()
+            wits = list(ex.map(lambda a: _oracle.witness_execute(orc, circuit, a[0], a[1]), zip(zs[:-1], batch)))
+            ph["witness"] += time.time() - t
+            z = zs[-1]
+            for st, w, z_out in wits:
+                if time.time() - t0 >= budget_s and n >= 2:
+                    break
+                t = time.time()
+                bad, (a2, b2, c2) = _oracle.r1cs_check(orc, circuit, w, want_products=True, threads=threads)
+                assert st == 0 and bad == -1
+                ph["spmv"] += time.time() - t; t = time.time()
+                _, cW = orc.msm_mont_timed(0, key_m, np.ascontiguousarray(w[aux0:]), threads)
+                ph["msm_w"] += time.time() - t
+                n += 1
+                if run is None:
+                    run = [w, a2, b2, c2, np.zeros_like(a2), 1]
+                else:
+                    t = time.time()
+                    T = orc.cross_term(0, run[1], run[2], run[3], run[5], a2, b2, c2, 1, threads=threads)
+                    ph["cross_term"] += time.time() - t; t = time.time()
+                    _, cT = orc.msm_mont_timed(0, key_m, T, threads)
+                    ph["msm_t"] += time.time() - t; t = time.time()
+                    r = (cT[0] ^ cW[0]) & ((1 << 128) - 1)        # any 128-bit challenge: the arithmetic cost does not depend on it
+                    run = [orc.axpy(0, run[0], r, w, threads), orc.axpy(0, run[1], r, a2, threads), orc.axpy(0, run[2], r, b2, threads), orc.axpy(0, run[3], r, c2, threads),
+                           orc.axpy(0, run[4], r, T, threads), (run[5] + r) % orc.modulus[0]]
+                    ph["folds"] += time.time() - t
+                if rec is not None:
+                    t = time.time()
+                    r128 = (1 << 128) | (cW[0] & ((1 << 128) - 1))
+                    for _ in range(2):      # (A,B,C)·z of a verifier circuit: once per circuit
+                        orc.r1cs_check_relaxed(1, rec["tabs2"], rec["n2w"], rec["Z2"], u=1, threads=threads)
+                    orc.msm_mont_timed(0, key_m[rec["off"]:], rec["w1"], threads); orc.msm_mont_timed(0, key_m[circuit.n_constraints:], rec["t1"], threads)
+                    orc.msm_mont_timed(1, rec["key2"], np.ascontiguousarray(rec["Z2"][1:rec["n2w"] - 2]), threads); orc.msm_mont_timed(1, rec["key2"], rec["t2"], threads)
+                    for fid in (0, 1):
+                        T2 = orc.cross_term(fid, rec["t2"], rec["e2"], rec["t2"], 3, rec["e2"], rec["t2"], rec["e2"], 1)
+                        for _ in range(5):
+                            orc.axpy(fid, rec["e2"], r128 % orc.modulus[fid], T2)
+                    for cid, g in ((0, rec["g1"]), (1, rec["g2"])):      # NIFS.V inside the circuits: W + rho·W', E + rho·T on the other curve
+                        orc.curve_mul(cid, g, r128); orc.curve_mul(cid, g, r128 ^ 5)
+                    for fid in (0, 1):
+                        orc.nova_instance_hash(fid, 7, n, [1], [2], [1, 2, 1, 2, 1, 3, 4]); orc.nova_instance_hash(fid, 7, n + 1, [1], [3], [1, 2, 1, 2, 2, 3, 4])
+                    ph["verifier_circuits"] += time.time() - t
     dt = time.time() - t0
     return n / dt, dt, n, {k: v / max(1, n) for k, v in ph.items()}
 
@@ -415,6 +465,7 @@ def main_ivc(args, rank, world, dist, torch, ctxs, circuit, params, steps_all, g
             "prologue_s_max_over_ranks": prologue_max if world > 1 else 0.0,
             "sharding": tree,
             "gpus_shared": bool(getattr(args, "gpus_shared", False)),
+            "host_cores_per_rank": usable_cores(),
             "fold_s": t_fold,
             "peak_device_bytes": mem["device_bytes"], "peak_host_rss_bytes": mem["host_rss_bytes"], "memory_note": mem["note"],
             "merge_profile_s": merge_prof,
@@ -441,11 +492,14 @@ def main_ivc(args, rank, world, dist, torch, ctxs, circuit, params, steps_all, g
         }
         if not args.no_cpu_baseline and world == 1:      # the CPU baseline is timed at N = 1 only
             cores = usable_cores()
-            ck_host = params.ck.download(0, max(circuit.n_constraints, circuit.n_wires))
-            sps, secs, n_cpu, cph = cpu_baseline(circuit, mine, z0, ck_host, args.cpu_seconds, cores)
+            ck_host = params.ck.download(0, info["primary_constraints"] + 8)
+            ck2_host = ck2.download(0, max(info["secondary_wires"], info["secondary_constraints"]))
+            sps, secs, n_cpu, cph = cpu_baseline(circuit, mine, z0, ck_host, args.cpu_seconds, cores, ivc=ivcs[0], ck2_host=ck2_host)
             out["cpu_baseline"] = {"value": sps, "unit": "steps/s", "cores": cores, "kind": "port",
-                                   "sample": f"{n_cpu} folding steps of the step circuit's instances with the CPU oracle (C++ restatement, std::thread over the usable cores (affinity and cgroup quota) for SpMV / MSM / vector ops, "
-                                             f"witness executor single-threaded; not the Rust binary; without the augmented circuits, i.e. less work per step than the GPU number), {secs:.1f} s",
+                                   "sample": f"{n_cpu} folding steps with the CPU oracle (C++ restatement; not the Rust binary), like for like with a GPU step: per row the step circuit's witness "
+                                             f"(rows of a batch side by side on the host threads), (A,B,C)·z, MSM(W), cross term, MSM(T) and folds of the primary instance, plus the two verifier "
+                                             f"circuits' share — their (A,B,C)·z, four commitments, cross terms, folds and the hashes / scalar multiplications of their witness generation; "
+                                             f"std::thread over the usable cores (affinity and cgroup quota), {secs:.1f} s",
                                    "seconds_per_step_by_phase": cph}
         print(json.dumps(out), flush=True)
     for v in ivcs:
@@ -508,6 +562,8 @@ def main():
     ap.add_argument("--proof-set", default="", help="comma-separated transformations: rank r proves proof_set[r %% len] (BASELINE config 5: independent proofs, replicas only)")
     ap.add_argument("--share-gpus", action="store_true", help="allow more ranks than visible GPUs (ranks r and r + n_devices share a device): evidence lines "
                     "on a one-GPU box, never a scaling claim; the line says so in `gpus_shared`")
+    ap.add_argument("--cores", type=int, default=0, help="restrict this process (every rank: its own share) to this many host cores before anything starts — "
+                    "what a rank has when eight ranks share a 16-core quota (VERDICT r3 #3); 0 = no restriction")
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -517,6 +573,11 @@ def main():
     if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
         print(f"[bench] --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')} ranks: refusing to report a line for another N", file=sys.stderr)
         sys.exit(2)
+    if args.cores > 0 and hasattr(os, "sched_setaffinity"):      # (before any thread exists: helper pools and the HIP runtime inherit the mask)
+        cpus = sorted(os.sched_getaffinity(0))
+        r = int(os.environ.get("LOCAL_RANK", "0"))
+        mine = cpus[(r * args.cores) % len(cpus):][:args.cores] or cpus[:args.cores]
+        os.sched_setaffinity(0, mine)
     rank = int(os.environ.get("RANK", "0"))
     if args.proof_set:
         ps = [t.strip() for t in args.proof_set.split(",") if t.strip()]

@@ -5,7 +5,7 @@
 #   4K / 8K shapes —, whole-image runs, the bench windows of the other configurations, the N > 1 lines on the one GPU of the box.
 #   usage: tools/refresh_profiles.sh [round tag, default r03] [parts: all | bench | rocprof | pmc | valu | e2e | configs | ranks | cyclefold]
 set -u
-R=${1:-r03}
+R=${1:-r04}
 PARTS=${2:-all}
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/refresh; mkdir -p $O

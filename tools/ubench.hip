@@ -112,6 +112,62 @@ __global__ void k_madd29(uint32_t* out, uint32_t seed, int iters) {
   out[blockIdx.x * blockDim.x + threadIdx.x] = r;
 }
 
+// ---- gated experiment: the Montgomery reduction's two multiplications by constants (m = T_lo·p' mod R, then m·p) as
+// byte-limb i8 MFMA products with Toeplitz matrices of p' and p, shared by a wave's 64 elements.  An UPPER BOUND on what that variant
+// could reach: this kernel does everything the VALU would still have to do — the variable x variable product a·b (81 v_mad_u64_u32,
+// no matrix form: both operands differ per lane), its carries, the repacking of T_lo into byte lanes, the carry resolution of the
+// 33 and 66 int32 column sums an i8 MFMA returns (8-bit granularity: the matrix cores take 8-bit integers), the repacking into
+// 29-bit limbs and the addition of T_hi — and treats the two MFMA products themselves, the operand staging and the cross-lane
+// exchange their output layout needs as FREE (the "MFMA results" are opaque register values).  If even this is not 1.3x Fp29::mul,
+// the real thing cannot be.
+__device__ __forceinline__ uint32_t opaque(uint32_t x) { asm volatile("" : "+v"(x)); return x; }
+__device__ __forceinline__ G mfma_bound_mul(const G& a, const G& b) {
+  uint64_t acc[18];
+#pragma unroll
+  for (int k = 0; k < 18; k++) acc[k] = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++)
+#pragma unroll
+    for (int j = 0; j < 9; j++) acc[i + j] += (uint64_t)a.v[i] * b.v[j];
+  uint32_t t[18];
+#pragma unroll
+  for (int k = 0; k < 18; k++) { t[k] = (uint32_t)acc[k] & 0x1fffffffu; if (k < 17) acc[k + 1] += acc[k] >> 29; }
+  // T_lo (261 bits) as contiguous 32-bit words = packed byte lanes of the MFMA operand
+  uint32_t w[9]; { uint64_t buf = 0; int have = 0, o = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) { buf |= (uint64_t)t[i] << have; have += 29; if (have >= 32) { w[o++] = (uint32_t)buf; buf >>= 32; have -= 32; } }
+    w[o] = (uint32_t)buf; }
+  // [MFMA 1: 33 int32 column sums of T_lo·p' — free]  ->  m as 33 bytes, packed
+  uint32_t mw[9]; { uint32_t c = 0;
+#pragma unroll
+    for (int k = 0; k < 33; k++) { const uint32_t s = opaque(w[k % 9] >> (k & 7)) + c; c = s >> 8; const uint32_t byte = s & 255u; if ((k & 3) == 0) mw[k >> 2] = byte; else mw[k >> 2] |= byte << (8 * (k & 3)); } }
+  // [MFMA 2: 66 int32 column sums of m·p — free]  ->  (T + m·p) / 2^261: carries through the low 33 columns, bytes of the high 33
+  uint32_t hw[9]; { uint32_t c = 0;
+#pragma unroll
+    for (int k = 0; k < 33; k++) { const uint32_t s = opaque(mw[k % 9] >> (k & 7)) + c; c = s >> 8; }
+#pragma unroll
+    for (int k = 0; k < 33; k++) { const uint32_t s = opaque(mw[(k + 3) % 9] >> (k & 7)) + c; c = s >> 8; const uint32_t byte = s & 255u; if ((k & 3) == 0) hw[k >> 2] = byte; else hw[k >> 2] |= byte << (8 * (k & 3)); } }
+  // back to 29-bit limbs, plus T_hi
+  G r; { uint32_t cy = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      const int bit = 29 * i, ww = bit >> 5, off = bit & 31;
+      uint64_t x = (uint64_t)hw[ww] >> off;
+      if (off > 3 && ww + 1 < 9) x |= (uint64_t)hw[ww + 1] << (32 - off);
+      const uint32_t y = ((uint32_t)x & 0x1fffffffu) + t[9 + i] + cy; cy = y >> 29; r.v[i] = y & 0x1fffffffu;
+    } }
+  return r;
+}
+__global__ void k_fp29_mfma_bound(uint32_t* out, uint32_t seed, int iters) {
+  G a = G::one(), b = G::one();
+  a.v[0] ^= (threadIdx.x + seed) & 0xffff; b.v[1] ^= blockIdx.x & 0xffff;
+  G c = a, d = b;
+  for (int i = 0; i < iters; i++) { a = mfma_bound_mul(a, b); c = mfma_bound_mul(c, d); }
+  a = G::add(a, c);
+  uint32_t r = 0; for (int k = 0; k < 9; k++) r ^= a.v[k];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
+
 template <class K, class... A>
 double time_kernel(K k, dim3 g, dim3 b, A... args) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -142,6 +198,9 @@ int main() {
   t = time_kernel(k_fpmul, dim3(blocks), dim3(tb), (uint32_t*)buf, 1u, it); printf("Fp::mul (BN254 Fq, 8x32 CIOS): %8.2f Gmul/s  (%.1f ns per wave-mul-pair)\n", lanes * it * 2 / t * 1e-9, t / it * 1e9);
   t = time_kernel(k_madd, dim3(blocks), dim3(tb), (uint32_t*)buf, 1u, it);  printf("XYZZ mixed add               : %8.2f Gadd/s\n", lanes * it / t * 1e-9);
   t = time_kernel(k_fp29mul, dim3(blocks), dim3(tb), (uint32_t*)buf, 1u, it); printf("Fp29::mul (BN254 Fq, 9x29 columns): %8.2f Gmul/s\n", lanes * it * 2 / t * 1e-9);
+  { const double t29 = t;
+    t = time_kernel(k_fp29_mfma_bound, dim3(blocks), dim3(tb), (uint32_t*)buf, 1u, it);
+    printf("Fp29 product + byte-limb conversions of an i8-MFMA reduction, MFMA itself free (upper bound): %8.2f Gmul/s = %.2fx Fp29::mul\n", lanes * it * 2 / t * 1e-9, t29 / t); }
   t = time_kernel(k_madd29, dim3(blocks), dim3(tb), (uint32_t*)buf, 1u, it);  printf("XYZZ mixed add (Fp29)             : %8.2f Gadd/s\n", lanes * it / t * 1e-9);
   t = time_kernel(k_madd29, dim3(p.multiProcessorCount), dim3(tb), (uint32_t*)buf, 1u, it);
   printf("  mixed add (Fp29) @ 1 WG/CU       : %8.2f Gadd/s  (%.2f us per dependent add)\n", (double)p.multiProcessorCount * tb * it / t * 1e-9, t / it * 1e6);

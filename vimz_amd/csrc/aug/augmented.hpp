@@ -65,7 +65,7 @@ struct AugCircuit {
   mutable std::unique_ptr<Worker> worker, worker2;     // helper threads for the two scalar-multiplication chains (created on first use)
   mutable std::function<void(const uint32_t*)> on_challenge;      // witness(): called with the challenge once the parts of the circuit that only need it are done
   Worker *shared_w = nullptr, *shared_w2 = nullptr;    // ... or the owner's (an IVC hands both of its circuits the same two)
-  bool use_worker = std::thread::hardware_concurrency() > 1 && !getenv("VIMZ_AUG_NO_THREADS");
+  bool use_worker = affinity_cpus() > 2 && !getenv("VIMZ_AUG_NO_THREADS");      // (two helper threads per circuit: pointless on one or two cores)
 
   uint32_t n_wires() const { return b.n_wires; }
   uint32_t n_constraints() const { return b.n_constraints(); }

@@ -19,6 +19,10 @@
 #include <stdexcept>
 #include <thread>
 #include <vector>
+#include <algorithm>
+#if defined(__linux__)
+#include <sched.h>
+#endif
 #include "../circuit/builder.hpp"
 #include "../circuit/poseidon_params.hpp"
 #include "../ec.hpp"
@@ -103,6 +107,17 @@ inline void batch_inv(std::vector<F>& a) {
     a[i] = F::mul(inv, pre[i]);
     inv = F::mul(inv, ai);
   }
+}
+
+// Host CPUs this process may run on: the scheduler's affinity mask (what `taskset`, a launcher's binding or a container's cpuset
+// leave), not the machine's count — helper threads beyond it only take turns with the threads they are meant to help.
+inline unsigned affinity_cpus() {
+  unsigned n = std::max(1u, std::thread::hardware_concurrency());
+#if defined(__linux__)
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) { const int k = CPU_COUNT(&set); if (k >= 1) n = std::min<unsigned>(n, (unsigned)k); }
+#endif
+  return n;
 }
 
 template <class FP>

@@ -319,7 +319,7 @@ struct CfMainCircuit {
   CfFr digest;                 // SHA3-256 of both shapes, truncated to 250 bits
   mutable std::unique_ptr<Worker> worker, worker2;
   mutable CfHashCache cache;            // the output hashes of the last witness() call, replayed by the next
-  bool use_worker = std::thread::hardware_concurrency() > 1 && !getenv("VIMZ_AUG_NO_THREADS");
+  bool use_worker = affinity_cpus() > 2 && !getenv("VIMZ_AUG_NO_THREADS");      // (two helper threads per circuit: pointless on one or two cores)
   uint32_t n_wires() const { return b.n_wires; }
   uint32_t n_constraints() const { return b.n_constraints(); }
   uint32_t aug_wires() const { return b.n_wires - step_wires; }

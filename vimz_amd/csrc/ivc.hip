@@ -76,7 +76,7 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
   };
   static const bool dbg_timing = getenv("VIMZ_DEBUG_TIMING") != nullptr;
   const double t_prep = now_s() - t_all;
-  double t_first = 0, t_wait0 = 0, t_hook = 0;
+  double t_first = 0, t_wait0 = 0, t_hook = 0, t_hk[5] = {0, 0, 0, 0, 0};      // (t_hk: fused fold launch, event records, large-MSM launches, fold5 launch, row-flag waits)
   const std::vector<Fe>& zs = job.zs;
   const size_t pin_stride = FoldJob::pin_stride;
   char* pin_aug1 = v->pin + 5 * v->pin_res;
@@ -105,10 +105,13 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
       }
       P_TRY(hipSetDevice(ctx->device));
     }
+    double tq = now_s();
     P_TRY(msm_launch<BnG1>(v->s3, v->ws3, p->ck->d, S.buf, v->t1_main_n, 1, 0, S.pin, &S.plan, ctx->profiling ? S.ev : nullptr, 0,
                            p->ck->tables && v->helpers.empty() ? &job.tbl : nullptr));
+    t_hk[2] += now_s() - tq; tq = now_s();
     if (ctx->profiling) P_TRY(hipMemcpyAsync(S.pin + v->pin_res, v->ws3.totals, 8, hipMemcpyDeviceToHost, v->s3));   // (pinned: stays asynchronous)
     P_TRY(hipEventRecord(S.done, v->s3));
+    t_hk[1] += now_s() - tq;
     return VIMZ_OK;
   };
   // the cross term of step `step` = row `row` of `b2` against the running instance as it is now (first row of a call)
@@ -137,7 +140,9 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
     // first output of the pass: next1 into the other slot if it is needed, else the lookahead into this slot (read, then overwritten)
     const RowAt* t = a.need1 ? &a.next1 : a.look ? &a.next2 : nullptr;
     uint32_t* out = a.need1 ? Soth.buf : a.look ? Scur.buf : nullptr;
+    double tq = now_s();
     if (t) P_TRY(wait_row_flag(*t->b, t->row, t->b->ev[t->row]));      // (the producer is a batch ahead: no wait in the steady state)
+    t_hk[4] += now_s() - tq; tq = now_s();
     hipLaunchKernelGGL(k_fold_cross<Fr>, dim3(stream_grid(sc)), dim3(256), 0, v->s3, sc, p->AZ, p->BZ, p->CZ, p->E, (const uint32_t*)Scur.buf, fold_E ? 1 : 0, a.rho,
                        hasB ? 1 : 0, v->rho_prev, hasB ? (const uint32_t*)(a.cur->d + 8 * a.r * sc) : (const uint32_t*)nullptr, v->u1_run, az, bz, cz,
                        out, t ? t->b->az + 8 * t->row * nc : nullptr, t ? t->b->bz + 8 * t->row * nc : nullptr, t ? t->b->cz + 8 * t->row * nc : nullptr, Fe::one());
@@ -148,7 +153,9 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
                          a.next2.b->az + 8 * a.next2.row * nc, a.next2.b->bz + 8 * a.next2.row * nc, a.next2.b->cz + 8 * a.next2.row * nc, Fe::one(), Scur.buf);
       P_TRY(hipGetLastError());
     }
+    t_hk[0] += now_s() - tq; tq = now_s();
     P_TRY(hipEventRecord(v->ev_fused, v->s3)); v->fused_recorded = true;
+    t_hk[1] += now_s() - tq;
     if (a.need1) { Soth.step = (int64_t)a.i + 1; Soth.hasB = false; int rc2 = queue_msm(par ^ 1); if (rc2) return rc2; }
     if (a.look) { Scur.step = (int64_t)a.i + 2; Scur.hasB = true; int rc2 = queue_msm(par); if (rc2) return rc2; }
     return VIMZ_OK;
@@ -392,8 +399,11 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
         if ((rc2 = launch_fold_and_cross(fa))) return rc2;
         // on stream 2, idle until the secondary witness is uploaded: this pass overlaps that upload instead of preceding it
         // (everything it reads is complete — the host has waited for all three streams)
+        double tq = now_s();
         hipLaunchKernelGGL(k_fold5<Fr>, dim3(512), dim3(256), 0, v->s2, f, rho1);
+        t_hk[3] += now_s() - tq; tq = now_s();
         P_TRY(hipEventRecord(v->ev_fold, v->s2));  // the verifier rows of the next step may start here
+        t_hk[1] += now_s() - tq;
         return VIMZ_OK;
       };
       v->c2.on_challenge = [&](const uint32_t* rho_low) { const double th = now_s(); hook_ran = true; hook_rc = queue_folds(rho_low); t_hook += now_s() - th; };
@@ -447,7 +457,8 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
   for (uint32_t k = 0; k < p->len_z; k++) p->z_cur[k] = zs[nsteps * p->len_z + k];
   guard.armed = false;
   v->ph_s[IP_TOTAL] += now_s() - t_all; v->ph_n[IP_TOTAL] += nsteps;
-  if (dbg_timing) fprintf(stderr, "[timing] fold of %zu steps: %.1f ms (prepare %.1f, first batch ready at %.1f after waiting %.1f; launches queued from inside the secondary circuit: %.3f ms per step)\n", nsteps, 1e3 * (now_s() - t_all), 1e3 * t_prep, 1e3 * t_first, 1e3 * t_wait0, 1e3 * t_hook / (double)nsteps);
+  if (dbg_timing) fprintf(stderr, "[timing] fold of %zu steps: %.1f ms (prepare %.1f, first batch ready at %.1f after waiting %.1f; launches queued from inside the secondary circuit: %.3f ms per step = fused fold %.3f + 3 event records %.3f + large MSM %.3f + fold5 %.3f + row flags %.3f)\n", nsteps, 1e3 * (now_s() - t_all), 1e3 * t_prep, 1e3 * t_first, 1e3 * t_wait0, 1e3 * t_hook / (double)nsteps,
+                          1e3 * t_hk[0] / (double)nsteps, 1e3 * t_hk[1] / (double)nsteps, 1e3 * t_hk[2] / (double)nsteps, 1e3 * t_hk[3] / (double)nsteps, 1e3 * t_hk[4] / (double)nsteps);
   return VIMZ_OK;
 }
 

@@ -34,13 +34,17 @@ namespace vz {
 // bucket in k_combine).  Results never depend on them — tests/test_gpu_ivc.py folds the same rows under other values and requires
 // the identical proof.  (The switches of rounds 1-2 whose A/B is settled — launcher thread, copied window sums, CU masks, stream
 // priorities, sub-bucket length, late folds, one producer stream — are gone; DESIGN.md §9 keeps what they measured.)
-struct MsmTuning { int sort_blocks = 0, combine_lane_bits = -1; };
+// small_lean (0: off, the default): the fused small MSM's wide tail levels by one lane per addition instead of four — 15-20 % fewer
+// instructions per small MSM, 7-27 µs more latency: measured SLOWER in every regime (three segments 1095-1101 -> 1054-1078 -> 1029-1051
+// steps/s for lean = 0 / 1 / 2, one chain 819 -> 799 -> 770): with the GPU 98 % busy the step is still bound by its latency chains.
+struct MsmTuning { int sort_blocks = 0, combine_lane_bits = -1, small_lean = 0; };
 inline const MsmTuning& msm_tuning() {
   static const MsmTuning t = [] {
     MsmTuning r;
     if (const char* e = getenv("VIMZ_TUNE")) {
       if (const char* q = strstr(e, "sort_blocks=")) r.sort_blocks = atoi(q + 12);
       if (const char* q = strstr(e, "combine_lane_bits=")) r.combine_lane_bits = atoi(q + 18);
+      if (const char* q = strstr(e, "small_lean=")) r.small_lean = atoi(q + 11);
     }
     return r;
   }();
@@ -499,7 +503,8 @@ __global__ void __launch_bounds__(SMALL_THREADS) k_msm_small(const uint32_t* __r
                                                    uint32_t Q, uint32_t chunk, uint32_t* __restrict__ chunk_out /* K*Q points */,
                                                    uint32_t* __restrict__ done /* K counters, zero between launches; nullptr: k_msm_small_sum follows */,
                                                    uint32_t* __restrict__ window_sums,
-                                                   const uint32_t* __restrict__ tables /* or nullptr: row w holds 2^(7w)·P_i, row length tstride */, uint32_t tstride) {
+                                                   const uint32_t* __restrict__ tables /* or nullptr: row w holds 2^(7w)·P_i, row length tstride */, uint32_t tstride,
+                                                   int lean /* levels with a wave's worth of additions by one lane each instead of four: half the instructions, 3.4 µs more per level */) {
   __shared__ XYZZ<F> sh[SMALL_THREADS];
   __shared__ uint32_t cnt[SMALL_NBW], off[SMALL_NBW + 1], soff[SMALL_NBW + 1], cur[SMALL_NBW];
   __shared__ uint16_t list[SMALL_CHUNK];
@@ -588,6 +593,18 @@ __global__ void __launch_bounds__(SMALL_THREADS) k_msm_small(const uint32_t* __r
     for (uint32_t wv = 0; wv < SMALL_THREADS / 64; wv++) { before += wv < (t >> 6) ? wcnt[wv] : 0u; total += wcnt[wv]; }
     if (act) list[before + (uint32_t)__popcll(bal & ((1ull << (t & 63)) - 1ull))] = (uint16_t)t;
     __syncthreads();
+    if (lean && total >= 48) {
+      // one lane per addition, the pairs packed into the first waves: a wave's 64 additions cost what 16 cost four lanes each
+      const uint32_t wave0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(t & ~63u));
+      XYZZ<F> a; uint32_t ia = 0; bool mine = false;
+      if (wave0 < total) {
+        mine = t < total;
+        if (mine) { ia = list[t]; a = sh[ia]; add_full(a, sh[ia + d]); }
+      }
+      __syncthreads();
+      if (mine) sh[ia] = a;
+      __syncthreads();
+    } else
     for (uint32_t base = 0; base < total; base += 64)
       quad_level<F>(sh, min(64u, total - base), [&](uint32_t e) { return (uint32_t)list[base + e]; }, [&](uint32_t e) { return (uint32_t)list[base + e] + d; });
   }
@@ -621,9 +638,17 @@ __global__ void __launch_bounds__(SMALL_THREADS) k_msm_small(const uint32_t* __r
         sh[t] = load_xyzz<F>(chunk_out, ((size_t)w * Q + loaded + sl - slot0) * SMALL_NBW + b);
       }
       __syncthreads();
+      if (lean) {
+        // slots (0 += 1) and (2 += 3) side by side on waves 0 and 2, one lane per bucket; then 0 += 2 on wave 0
+        if ((sl == 0 && m >= 2) || (sl == 2 && m == 4)) { XYZZ<F> a = sh[t]; add_full(a, sh[t + SMALL_NBW]); sh[t] = a; }      // (a wave reads and writes its own slot pair only)
+        __syncthreads();
+        if (sl == 0 && m >= 3) { XYZZ<F> a = sh[t]; add_full(a, sh[t + 2 * SMALL_NBW]); sh[t] = a; }
+        __syncthreads();
+      } else {
       if (m >= 2) quad_level<F>(sh, SMALL_NBW, [](uint32_t e) { return e; }, [](uint32_t e) { return e + SMALL_NBW; });
       if (m == 4) quad_level<F>(sh, SMALL_NBW, [](uint32_t e) { return e + 2 * SMALL_NBW; }, [](uint32_t e) { return e + 3 * SMALL_NBW; });
       if (m >= 3) quad_level<F>(sh, SMALL_NBW, [](uint32_t e) { return e; }, [](uint32_t e) { return e + 2 * SMALL_NBW; });
+      }
       loaded += k;
     }
     if (t == 0) __hip_atomic_store(&done[w], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -632,6 +657,15 @@ __global__ void __launch_bounds__(SMALL_THREADS) k_msm_small(const uint32_t* __r
     __syncthreads();
   }
   // The rest is twelve levels of at most 64 dependent additions: four lanes per addition (ec_mem.hpp: quad_level), all four waves busy.
+  if (lean >= 2) {      // (experiment: the six scan levels by one lane per bucket on wave 0: 19 k fewer instructions per window, 20 µs more latency)
+    for (uint32_t d = 1; d < SMALL_NBW; d <<= 1) {
+      XYZZ<F> a; const bool mine = t < SMALL_NBW - d;
+      if (t < 64) { if (mine) { a = sh[t]; add_full(a, sh[t + d]); } }
+      __syncthreads();
+      if (mine) sh[t] = a;
+      __syncthreads();
+    }
+  } else
   for (uint32_t d = 1; d < SMALL_NBW; d <<= 1)      // inclusive suffix sums of the buckets
     quad_level<F>(sh, SMALL_NBW - d, [](uint32_t e) { return e; }, [d](uint32_t e) { return e + d; });
   for (uint32_t d = SMALL_NBW / 2; d > 0; d >>= 1)  // sum_b (b+1)·B_b = sum of the suffix sums
@@ -835,7 +869,7 @@ hipError_t msm_launch(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_ba
     static const bool sum_kernel = getenv("VIMZ_DEBUG_SMALL_SUM_KERNEL") != nullptr;
     hipLaunchKernelGGL((k_msm_small<S, F>), dim3(ps.K, Q), dim3(SMALL_THREADS), 0, stream, d_bases, d_scalars, (uint32_t)n, scalars_mont, Q, chunk, chunk_out,
                        sum_kernel ? (uint32_t*)nullptr : done, direct ? reinterpret_cast<uint32_t*>(pinned_dst) : reinterpret_cast<uint32_t*>(ws.window_sums),
-                       small_tb ? tb->d + (size_t)AFFINE_WORDS * tb->offset : (const uint32_t*)nullptr, small_tb ? (uint32_t)tb->n_total : 0u);
+                       small_tb ? tb->d + (size_t)AFFINE_WORDS * tb->offset : (const uint32_t*)nullptr, small_tb ? (uint32_t)tb->n_total : 0u, msm_tuning().small_lean);
     if (Q > 1 && sum_kernel) hipLaunchKernelGGL(k_msm_small_sum<F>, dim3(ps.K), dim3(64), 0, stream, chunk_out, Q, direct ? reinterpret_cast<uint32_t*>(pinned_dst) : reinterpret_cast<uint32_t*>(ws.window_sums));
     if (ev) for (int i = 4; i < 7; i++) VZ_HIP_CHECK(hipEventRecord(ev[i], stream));
     VZ_HIP_CHECK(hipGetLastError());

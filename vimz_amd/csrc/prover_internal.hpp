@@ -20,6 +20,7 @@
 #include "circuit_handle.hpp"
 #include "r1cs_ops.hpp"
 #include "witness.hpp"
+#include "aug/cs.hpp"      // (affinity_cpus)
 
 using namespace vz;
 typedef cb::Fe Fe;                 // host Montgomery Fr
@@ -489,7 +490,7 @@ static bool getenv_once(const char* name) {      // (debugging switches are read
 }
 static unsigned usable_cpus() {
   static const unsigned v = [] {
-    unsigned n = std::max(1u, std::thread::hardware_concurrency());
+    unsigned n = aug::affinity_cpus();      // (the affinity mask, not the machine: aug/cs.hpp)
     if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
       char q[32] = {0}; long per = 0;
       if (fscanf(f, "%31s %ld", q, &per) == 2 && strcmp(q, "max") != 0 && per > 0) { const long k = atol(q) / per; if (k >= 1) n = std::min<unsigned>(n, (unsigned)k); }
