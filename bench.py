@@ -425,7 +425,7 @@ def main_ivc(args, rank, world, dist, torch, ctxs, circuit, params, steps_all, g
                 one = runs[1]
                 sonobe = {"one_chain_steps_per_s": one["steps_per_s"], "steps": one["steps"], "verified": bool(one["verified"]), "fold_s": one["spans_s"]["Fold input"],
                           "main_constraints": one["info"]["main_constraints"], "cyclefold_constraints": one["info"]["cyclefold_constraints"],
-                          "one_chain_ms_per_step": one["ms_per_step_first_segment"],
+                          "one_chain_ms_per_step": one["ms_per_step_first_segment"], "decider": one.get("decider"),
                           "note": "Nova + CycleFold IVC (the Sonobe backend's prove_step loop, vimz/src/sonobe_backend/folding.rs:52-66) over the whole image, same kernels; own process"}
                 if S > 1:
                     mg = runs[S]

@@ -403,6 +403,28 @@ int vimz_cf_row_digests(vimz_cf* v, const uint64_t* step_inputs, size_t nsteps, 
 int vimz_cf_chain_from_digests(vimz_cf* v, const uint64_t* z_start, const uint64_t* step_inputs, const uint64_t* digests, size_t nsteps, uint64_t* zs_out);
 /* (test hooks — vimz_cf_poke, the host-only self-checks — are declared in vimz_hip_testing.h and exist only in libvimz_hip_testing.so) */
 
+/* ---- the decider of the Nova + CycleFold path: `Decider::preprocess` / `Decider::prove` of the Sonobe backend (vimz/src/sonobe_backend/mod.rs:72-78;
+ *      `DeciderEth<.., Groth16<Bn254>, ..>`, decider.rs:13-21) — the Groth16 proof that fills eight of the 25 calldata words (solidity.rs:13-27,
+ *      contracts/*Verifier.sol:785-810).  Groth16 over BN254 as published; the circuit (vimz_amd/csrc/aug/decider.hpp: the hashes the last instance
+ *      carries, NIFS.V on the scalars, the folded main instance's relaxed R1CS row by row, the two KZG evaluations, one hash binding the words the
+ *      contract sees) and the deterministic TEST setup (trapdoor derived from `seed`) are ours, parity unpinned: Sonobe's keys come out of crates
+ *      that are not vendored.  NTTs, the G1 / G2 multi-scalar multiplications and the key's fixed-base multiplications run on the GPU. ---------- */
+typedef struct vimz_decider vimz_decider;
+/* prover: supplies shapes, keys and context (must outlive the object).  seconds (optional) = {circuit synthesis, QAP evaluation at the trapdoor,
+ * key points on the GPU, total} */
+int vimz_decider_setup(vimz_cf* prover, const uint8_t* seed, size_t seed_len, vimz_decider** out, double seconds[4]);
+void vimz_decider_free(vimz_decider* d);
+/* info = {constraints, wires, public inputs (i, z_0, z_i, h_inst), domain size, non-zeros of A, B, C, 0} */
+int vimz_decider_info(const vimz_decider* d, uint64_t info[8]);
+/* the verifying key, canonical words: alpha (G1: x, y), beta, gamma, delta (G2: x.c0, x.c1, y.c0, y.c1), the number of IC points, the IC points;
+ * returns the byte size (copies when cap suffices) */
+int64_t vimz_decider_vk(const vimz_decider* d, void* buf, size_t cap);
+/* m: a merged proof of ONE segment over the same prover (U_{i+1} = NIFS.V(U_i, u_i), vimz_cf_merged_create); kzg = {c_W, c_E, e_W, e_E} canonical (the
+ * challenges and evaluations of vimz_cf_merged_kzg_open the same calldata carries).  public_out: the public inputs (info[2] canonical elements);
+ * proof_out: A.x, A.y, B.x.c0, B.x.c1, B.y.c0, B.y.c1, C.x, C.y canonical.  VIMZ_ERR_UNSAT when the proof does not satisfy the decider's statement.
+ * seconds (optional) = {witness + sparse products on the host, NTTs, multi-scalar multiplications, total} */
+int vimz_decider_prove(vimz_decider* d, vimz_cf_merged* m, const uint64_t kzg[16], uint64_t* public_out, uint64_t proof_out[32], double seconds[4]);
+
 /* ---- ONE proof object out of several row segments: the "host-side sequential final fold" of BASELINE.json's north_star for IVC proofs.
  *      fold_input returns ONE RecursiveSNARK (vimz/src/nova_snark_backend/folding.rs:27-43); row segments of an image folded
  *      concurrently (S proofs on one GPU, or one per GPU) are merged into one verifiable object by out-of-circuit NIFS on both curves —

@@ -24,6 +24,11 @@ def test_committed_proofs_round_trip_and_their_points_are_on_the_curve(oracle, n
     assert (d["steps"], d["z0"], d["z_i"], d["proof"], d["len_z"]) == (720, z0, zf, words, len(z0))
     for ix, iy in calldata.G1_POINTS:                     # U_i.cmW, U_i.cmE, u_i.cmW, cmT, Groth16 A and C, both KZG proofs
         assert oracle.on_curve(0, (words[ix], words[iy])), (name, calldata.WORD_NAMES[ix])
+    # ... and the four words between Groth16's A and C are a point of BN254 G2 in the EVM's order (imaginary parts first): x = x0 + x1 u
+    from tests import _pairing as bp
+    B = ((d["named"]["groth16.B.x0"], d["named"]["groth16.B.x1"]), (d["named"]["groth16.B.y0"], d["named"]["groth16.B.y1"]))
+    assert bp.g2_on_curve(B), name
+    assert not bp.g2_on_curve(((B[0][1], B[0][0]), (B[1][1], B[1][0])))      # (the other order is not on the twist: the layout's order is pinned)
     assert 0 < d["named"]["r"] < 1 << 128                 # the folding challenge is a 128-bit value
     q = oracle.modulus[0]
     assert all(d["named"][k] < q for k in ("kzg.challenge_W", "kzg.challenge_E", "kzg.eval_W", "kzg.eval_E"))

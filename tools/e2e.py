@@ -7,7 +7,7 @@ ivc (default): ONE proof object — the rows are proven as `segments` Nova IVCs 
 merged (vimz_ivc_merge), then compressed;
 accumulator: NIFS accumulators of the segments merged by a final fold;
 cyclefold: the Sonobe backend's sequence (vimz/src/sonobe_backend/mod.rs:52-95: prepare folding, fold input, verify folded proof) with Nova +
-CycleFold on one chain (the decider is not built)."""
+CycleFold; with one segment also the decider (Prepare decider, Generate decider proof: vimz_decider_*) and the calldata bytes."""
 import json
 import sys
 import time
@@ -87,8 +87,24 @@ def main():
         ze = proof.state()[1] if S > 1 else proof.state()[0]
         if save and S > 1:
             proof.save().tofile(f"{save}.cfmerged.bin")       # verify elsewhere: tools/verify_proof.py
+        decider = None
+        if S == 1:      # the reference's next two spans (mod.rs:72-78): Decider::preprocess, Decider::prove -> the 25 calldata words (solidity.rs:13-27)
+            from vimz_amd import calldata
+            t0 = time.time()
+            dec = hip.Decider(cfs[0], seed=bytes([41] * 32))
+            spans["Prepare decider"] = time.time() - t0
+            t0 = time.time()
+            words, _, pub = calldata.decider_words(cfs[0], decider=dec)
+            spans["Generate decider proof"] = time.time() - t0
+            _, _, tp = dec.prove(hip.CycleFoldMerged(cfs[0]), (words[17], words[18], words[19], words[20]))      # (again, for the prover's own phase split)
+            raw = calldata.encode(len(rows), z0, ze, words)
+            decider = {"circuit": dec.info(), "setup_s": dec.setup_seconds, "prove_s": tp, "calldata_bytes": len(raw), "groth16_words_filled": all(isinstance(w, int) for w in words),
+                       "note": "Groth16 over BN254 for this library's decider circuit with a deterministic test setup (vimz_amd/csrc/groth16.hip); checked by the oracle-side pairing in tests/test_gpu_decider.py"}
+            if save:
+                open(f"{save}.calldata.bin", "wb").write(raw)
+            dec.close()
         print(json.dumps({"config": f"{t}_step_{res}", "mode": "cyclefold", "steps": len(rows), "segments": S, "witness_batch": batch, "proof_objects": 1, "verified": ok, "spans_s": spans,
-                          "state_chain_s": t_chain, "merge_s": t_merge, "info": cfs[0].info(),
+                          "state_chain_s": t_chain, "merge_s": t_merge, "info": cfs[0].info(), "decider": decider,
                           "ms_per_step_first_segment": {k: 1e3 * sec / max(1, cfs[0].info()["steps"]) for k, (sec, n) in cfs[0].profile().items()},
                           "steps_per_s": len(rows) / spans["Fold input"], "total_s": sum(spans.values()), "final_state": [hex(z) for z in ze]}))
         return

@@ -74,11 +74,18 @@ WORD_NAMES = ["U_i.cmW.x", "U_i.cmW.y", "U_i.cmE.x", "U_i.cmE.y", "u_i.cmW.x", "
 G1_POINTS = [(0, 1), (2, 3), (4, 5), (6, 7), (9, 10), (15, 16), (21, 22), (23, 24)]      # word indices of the BN254 G1 points
 
 
-GROTH16_WORDS = list(range(9, 17))      # the eight words of the decider's Groth16 proof: not produced here
+GROTH16_WORDS = list(range(9, 17))      # the eight words of the decider's Groth16 proof (decider_words(..., decider=...) fills them)
 
 
-def decider_words(cf_prover):
-    """The 17 of the 25 proof words that do not come out of the Groth16 prover, for a Nova + CycleFold proof made by `cf_prover`
+def decider_public_hash_inputs(words):
+    """The values h_inst binds (vimz_amd/csrc/aug/decider.hpp), in its order, from the 25 words: rho, then the six commitments' 64-bit limbs
+    (U_i.cmW, U_i.cmE, u_i.cmW, cmT, and U_{i+1}.cmW / cmE which the verifier computes itself), then the four KZG scalars."""
+    return {"rho": words[8], "points": [(words[0], words[1]), (words[2], words[3]), (words[4], words[5]), (words[6], words[7])], "kzg": [words[17], words[18], words[19], words[20]]}
+
+
+def decider_words(cf_prover, decider=None):
+    """The 17 of the 25 proof words that do not come out of the Groth16 prover — and, given a vimz_amd.hip.Decider set up over the same
+    prover, the eight that do (then also returns its public inputs as a third value) —, for a Nova + CycleFold proof made by `cf_prover`
     (vimz_amd.hip.CycleFoldIVC, its commitment key being the KZG SRS's powers) — in THIS library's protocol, so a statement of
     what the GPU pipeline covers of `Decider::prove` (vimz/src/sonobe_backend/decider.rs:13-21), not bytes a contract generated for Sonobe accepts:
         U_i.cmW, U_i.cmE, u_i.cmW                       the running and the last instance's commitments
@@ -112,6 +119,12 @@ def decider_words(cf_prover):
             ev, proof = m.kzg_open(which, ch)
             words[17 + k], words[19 + k] = ch, ev
             words[21 + 2 * k], words[22 + 2 * k] = proof
+        if decider is not None:      # Decider::prove: the Groth16 proof of the final fold (A; B with the imaginary parts first, as the EVM's precompile takes G2; C)
+            pub, (A, B, Cp), _ = decider.prove(m, (words[17], words[18], words[19], words[20]))
+            words[9:11] = list(A)
+            words[11:15] = [B[0][1], B[0][0], B[1][1], B[1][0]]
+            words[15:17] = list(Cp)
+            return words, ((folded[0], folded[1]), (folded[2], folded[3])), pub
         return words, ((folded[0], folded[1]), (folded[2], folded[3]))
     finally:
         m.close()

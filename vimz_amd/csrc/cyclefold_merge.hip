@@ -1,6 +1,7 @@
 // ONE proof object out of several row segments' Nova + CycleFold proofs (vimz_cf_merge*): see the protocol comment below.  The prover itself:
 // cyclefold.hip.
 #include "cyclefold_internal.hpp"
+#include "decider_view.hpp"
 #ifdef VIMZ_TESTING
 #include "../../include/vimz_hip_testing.h"
 #endif
@@ -640,6 +641,25 @@ int vimz_cf_merged_verify(vimz_cf_merged* m, uint64_t num_steps, const uint64_t*
 }
 // KZG openings of the FOLDED main instance of a merged object (vimz_cf_kzg_open for a merged proof).  For a merged proof of ONE segment that is
 // U_{i+1} = NIFS(U_i, u_i): the instance Sonobe's decider opens (decider.rs:13-21).  which = 0: comm_W, 1: comm_E; canonical in and out.
+}  // extern "C"
+int vz_cf_merged_decider_view(vimz_cf_merged* m, CfDeciderView* out) {
+  if (!m || !m->vk || !out) return VIMZ_ERR_INVALID;
+  vimz_ctx* ctx = m->vk->ctx;
+  if (m->broken || m->segs.size() != 1 || m->run_start.size() != 1) return vz_fail(ctx, VIMZ_ERR_INVALID, "decider: the merged proof must hold exactly one segment (U_{i+1} = NIFS.V(U_i, u_i))");
+  const CfSegRec& s = m->segs[0];
+  out->vk = m->vk; out->n = s.n; out->zs = s.zs; out->ze = s.ze;
+  out->U = s.U; out->u = s.u; out->cfU = s.cfU; out->UW = s.UW; out->UE = s.UE; out->uW = s.uW; out->cmT = s.T2;
+  // the challenge as cfm_absorb derives it for the first segment of a run
+  uint8_t prev[32], h[32], hn[32];
+  { Sha3 h0; const char* tag = "vimz-cf-merge-v1"; h0.update(tag, strlen(tag)); cfm_fe(h0, m->vk->c1->digest); const uint64_t lz = m->vk->c1->len_z; h0.update(&lz, 8); h0.finish(prev); }
+  cfm_segment_hash(prev, s, h);
+  CfmChallenges ch; cfm_challenges(h, s, ch, hn);
+  memcpy(out->r, ch.r2, 16);
+  out->cW = m->acc.cW; out->cE = m->acc.cE; out->un = m->acc.u; out->x0n = m->acc.x0; out->x1n = m->acc.x1;
+  out->Zp = m->Zp; out->Ep = m->Ep;
+  return VIMZ_OK;
+}
+extern "C" {
 int vimz_cf_merged_kzg_open(vimz_cf_merged* m, int which, const uint64_t z[4], uint64_t eval_out[4], uint64_t proof_xy[8]) {
   if (!m || !m->vk || !z || !eval_out || !proof_xy || (which != 0 && which != 1)) return VIMZ_ERR_INVALID;
   vimz_ctx* ctx = m->vk->ctx; vimz_prover* p = m->vk->pri;

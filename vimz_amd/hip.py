@@ -707,6 +707,63 @@ def cyclefold_selfcheck_merge(segs_run0=3, segs_run1=2):
     return dg, rec, acc
 
 
+class Decider:
+    """vimz_decider: `Decider::preprocess` / `Decider::prove` of the Sonobe backend (vimz/src/sonobe_backend/mod.rs:72-78) — the Groth16 proof of
+    the final fold, eight of the 25 calldata words.  prover: a CycleFoldIVC (shapes, keys, context; keep it open).  The setup is a deterministic
+    TEST setup: the trapdoor is derived from `seed`."""
+
+    def __init__(self, prover, seed=b"vimz-test-setup"):
+        self.prover, self.ctx = prover, prover.ctx
+        lib = self.ctx.lib
+        vp = C.c_void_p
+        lib.vimz_decider_setup.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(vp), C.POINTER(C.c_double)]
+        lib.vimz_decider_free.argtypes = [vp]
+        lib.vimz_decider_free.restype = None
+        lib.vimz_decider_info.argtypes = [vp, vp]
+        lib.vimz_decider_vk.argtypes = [vp, vp, C.c_size_t]
+        lib.vimz_decider_vk.restype = C.c_int64
+        lib.vimz_decider_prove.argtypes = [vp, vp, vp, vp, vp, C.POINTER(C.c_double)]
+        h = vp()
+        sec = (C.c_double * 4)()
+        seed = bytes(seed)
+        self.ctx._chk(lib.vimz_decider_setup(prover.h, seed, len(seed), C.byref(h), sec))
+        self.h = h
+        self.setup_seconds = {"circuit_synthesis": sec[0], "qap_at_trapdoor_host": sec[1], "key_points_gpu": sec[2], "total": sec[3]}
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.vimz_decider_free(self.h)
+            self.h = None
+
+    def info(self):
+        a = np.zeros(8, dtype=np.uint64)
+        self.ctx._chk(self.ctx.lib.vimz_decider_info(self.h, _ptr(a)))
+        return dict(zip(["constraints", "wires", "public_inputs", "domain", "nnz_a", "nnz_b", "nnz_c"], (int(x) for x in a[:7])))
+
+    def verifying_key(self):
+        """{"alpha": G1, "beta": G2, "gamma": G2, "delta": G2, "ic": [G1 ...]} as Python integers; G2 points ((x.c0, x.c1), (y.c0, y.c1))."""
+        w = [int(x) for x in _export(self.ctx.lib.vimz_decider_vk, self.h).view(np.uint64)]
+        el = lambda k: sum(w[4 * k + q] << (64 * q) for q in range(4))
+        g2 = lambda k: ((el(k), el(k + 1)), (el(k + 2), el(k + 3)))
+        n_ic = w[4 * 14]
+        base = 14 * 4 + 1
+        ic = [(sum(w[base + 8 * j + q] << (64 * q) for q in range(4)), sum(w[base + 8 * j + 4 + q] << (64 * q) for q in range(4))) for j in range(n_ic)]
+        return {"alpha": (el(0), el(1)), "beta": g2(2), "gamma": g2(6), "delta": g2(10), "ic": ic}
+
+    def prove(self, merged, kzg):
+        """merged: a CycleFoldMerged of ONE segment over the same prover; kzg = (c_W, c_E, e_W, e_E).  Returns (public inputs: ints,
+        proof: (A: G1, B: G2 as ((x.c0, x.c1), (y.c0, y.c1)), C: G1), seconds dict)."""
+        k = _zlimbs(list(kzg), 4)
+        n_pub = self.info()["public_inputs"]
+        pub = np.zeros((n_pub, 4), dtype=np.uint64)
+        pr = np.zeros((8, 4), dtype=np.uint64)
+        sec = (C.c_double * 4)()
+        self.ctx._chk(self.ctx.lib.vimz_decider_prove(self.h, merged.h, _ptr(k), _ptr(pub), _ptr(pr), sec))
+        ints = lambda a: [sum(int(a[i, q]) << (64 * q) for q in range(4)) for i in range(a.shape[0])]
+        p = ints(pr)
+        return ints(pub), ((p[0], p[1]), ((p[2], p[3]), (p[4], p[5])), (p[6], p[7])), {"witness_host": sec[0], "ntt": sec[1], "msm": sec[2], "total": sec[3]}
+
+
 class CycleFoldMerged:
     """vimz_cf_merged: ONE proof object out of the CycleFold proofs of contiguous row segments (vimz_cf_merge).  `first`: the prover of the
     first segment (left unchanged; supplies shapes, keys and context and must stay open)."""
