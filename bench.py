@@ -550,7 +550,7 @@ def main():
     ap.add_argument("--transformation", default="contrast")
     ap.add_argument("--resolution", default="HD")
     ap.add_argument("--batch", type=int, default=0, help="rows whose witnesses are generated together (0: folding.default_batch — 64 at HD, 128 for the 4K / 8K widths)")
-    ap.add_argument("--segments", type=int, default=0, help="row segments folded concurrently on each GPU, own context + streams each, and merged into one proof (default: 3 in IVC mode, 2 accumulators)")
+    ap.add_argument("--segments", type=int, default=0, help="row segments folded concurrently on each GPU, own context + streams each, and merged into one proof (default: 3 in IVC mode — 2 when the rank has fewer than six host cores —, 2 accumulators)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--msm-helpers", type=int, default=0, help="IVC mode: split every step's large MSM(T) by base range over this many helper contexts "
@@ -607,7 +607,9 @@ def main():
 
     from vimz_amd import folding, hip
     from vimz_amd.distributed import segment_bounds
-    S = args.segments if args.segments > 0 else (3 if args.mode == "ivc" else 2)
+    # three concurrent segments fill the GPU when the host has the cores to drive them (each: a fold thread, a launch-issuing thread, two
+    # helpers); on two to five cores two segments do better — 865 against 541 steps/s on two cores, 636 as one chain (profiles/r04_cores.txt)
+    S = args.segments if args.segments > 0 else ((3 if usable_cores() >= 6 else 2) if args.mode == "ivc" else 2)
     ctxs = [hip.Context(device) for _ in range(S)]
     ctx = ctxs[0]
     t_setup = time.time()

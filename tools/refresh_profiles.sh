@@ -3,7 +3,7 @@
 #   the driver-style bench line and the long-window one, rocprofv3 kernel stats + the k_accum split of the same command, the
 #   FETCH_SIZE / WRITE_SIZE counter passes (separate runs, counters only) summarised per kernel — for the HD headline and for the
 #   4K / 8K shapes —, whole-image runs, the bench windows of the other configurations, the N > 1 lines on the one GPU of the box.
-#   usage: tools/refresh_profiles.sh [round tag, default r03] [parts: all | bench | rocprof | pmc | valu | e2e | configs | ranks | cyclefold]
+#   usage: tools/refresh_profiles.sh [round tag, default r04] [parts: all | bench | rocprof | pmc | valu | e2e | configs | ranks | cores | cyclefold]
 set -u
 R=${1:-r04}
 PARTS=${2:-all}
@@ -13,6 +13,9 @@ T="timeout 900"
 want() { [ "$PARTS" = all ] || echo "$PARTS" | grep -q "$1"; }
 if want bench; then
   $T python3 bench.py --steps 20 --warmup 5 > $O/${R}_bench_driver_window.json 2> $O/bench.err
+  for rep in b c d e; do $T python3 bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline > $O/${R}_bench_driver_window_$rep.json 2>> $O/bench.err; done
+  $T ./tools/ubench > $O/${R}_ubench_mfma_bound.txt 2>&1
+  $T python3 tools/msm_bench.py 305185 > $O/${R}_msm_phases_tables.txt 2>&1
   $T python3 bench.py > $O/${R}_bench.json 2>> $O/bench.err
   $T python3 bench.py --segments 1 --no-cpu-baseline > $O/${R}_bench_one_chain.json 2>> $O/bench.err
   $T python3 bench.py --mode accumulator --no-cpu-baseline > $O/${R}_bench_accumulator.json 2>> $O/bench.err
@@ -68,12 +71,27 @@ if want configs; then  # bench windows of the other BASELINE.json configurations
   run --transformation sharpness --resolution 4K --steps 96
   run --transformation blur --resolution 4K --steps 96
 fi
-if want ranks; then    # N > 1 on the one GPU of the box: ONE object out of two ranks' segments; the proof set of BASELINE config 5
-  TR="timeout 1200 python3 -m torch.distributed.run --nnodes=1 --master-addr 127.0.0.1"
-  $TR --nproc-per-node 2 --master-port 29621 bench.py --gpus 2 --no-cpu-baseline > $O/${R}_bench_2ranks_on_1gpu_ivc.json 2> $O/ranks.err
-  $TR --nproc-per-node 2 --master-port 29622 bench.py --gpus 2 --no-cpu-baseline --segments 1 > $O/${R}_bench_2ranks_on_1gpu_ivc_one_chain_each.json 2>> $O/ranks.err
-  $TR --nproc-per-node 2 --master-port 29623 bench.py --gpus 2 --no-cpu-baseline --mode accumulator > $O/${R}_bench_2ranks_on_1gpu_accumulator.json 2>> $O/ranks.err
-  $TR --nproc-per-node 4 --master-port 29624 bench.py --gpus 4 --no-cpu-baseline --no-compress --proof-set contrast,brightness,sharpness,blur --resolution 4K --steps 48 --warmup 8 --segments 1 > $O/${R}_bench_proof_set_4K_4ranks_on_1gpu.json 2>> $O/ranks.err
+if want ranks; then    # N > 1 on the one GPU of the box (--share-gpus: evidence of the sharded path, not of scaling): ONE object out of the ranks' segments,
+                       # HIP IPC hand-over up a tree; the proof set of BASELINE config 5; the 8K shapes; ranks on two host cores each
+  B="timeout 1200 python3 bench.py --share-gpus --no-extras --no-cpu-baseline"
+  $B --gpus 2 > $O/${R}_bench_2ranks_on_1gpu_ivc.json 2> $O/ranks.err
+  for rep in a b c; do $B --gpus 2 --steps 20 --warmup 5 > $O/${R}_bench_2ranks_on_1gpu_driver_window_$rep.json 2>> $O/ranks.err; done
+  for rep in a b c; do $B --gpus 4 --steps 20 --warmup 5 > $O/${R}_bench_4ranks_on_1gpu_driver_window_$rep.json 2>> $O/ranks.err; done
+  $B --gpus 4 > $O/${R}_bench_4ranks_on_1gpu_ivc.json 2>> $O/ranks.err
+  $B --gpus 2 --cores 2 > $O/${R}_bench_2ranks_on_1gpu_2cores_each.json 2>> $O/ranks.err
+  $B --gpus 2 --transformation resize --resolution 8K --steps 64 --warmup 8 --no-compress > $O/${R}_bench_2ranks_on_1gpu_8K.json 2>> $O/ranks.err
+  $B --gpus 4 --transformation resize --resolution 8K --steps 32 --warmup 8 --segments 2 --batch 32 --no-compress > $O/${R}_bench_4ranks_on_1gpu_8K.json 2>> $O/ranks.err
+  $B --gpus 2 --mode accumulator > $O/${R}_bench_2ranks_on_1gpu_accumulator.json 2>> $O/ranks.err
+  $B --gpus 4 --no-compress --proof-set contrast,brightness,sharpness,blur --resolution 4K --steps 48 --warmup 8 --segments 1 > $O/${R}_bench_proof_set_4K_4ranks_on_1gpu.json 2>> $O/ranks.err
+  timeout 300 python3 bench.py --gpus 2 --steps 20 --warmup 5 --no-extras --no-cpu-baseline > $O/${R}_bench_plain_gpus2_on_1gpu.json 2> $O/${R}_bench_plain_gpus2_on_1gpu.txt; echo "exit code $?" >> $O/${R}_bench_plain_gpus2_on_1gpu.txt
+fi
+if want cores; then    # what a rank has when the ranks of a node share a small CPU quota: the same bench on 2 / 4 host cores (sched_setaffinity before anything starts)
+  : > $O/${R}_cores.txt
+  for c in 2 4 8; do for seg in 1 2 3; do
+    timeout 900 python3 bench.py --cores $c --segments $seg --no-extras --no-cpu-baseline 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('cores $c segments $seg: %.1f steps/s over 256 rows, verified %s, host phases %s' % (d['value'], d['verified'], {k: round(v, 3) for k, v in d['phase_ms_per_step_per_proof'].items() if 'host' in k}))" >> $O/${R}_cores.txt
+  done; done
+  timeout 900 python3 bench.py --cores 2 --no-extras --no-cpu-baseline > $O/${R}_bench_2cores.json 2>/dev/null
+  timeout 900 python3 bench.py --cores 2 --steps 20 --warmup 5 --no-extras --no-cpu-baseline > $O/${R}_bench_2cores_driver_window.json 2>/dev/null
 fi
 if want cyclefold; then  # the Sonobe backend's path: Nova + CycleFold on one chain
   : > $O/${R}_cyclefold.jsonl
