@@ -380,6 +380,10 @@ int vimz_cf_merge_merged(vimz_cf_merged* m, vimz_cf_merged* other);
 size_t vimz_cf_merged_size(const vimz_cf_merged* m);
 int vimz_cf_merged_save(vimz_cf_merged* m, uint8_t* blob, size_t cap);
 int vimz_cf_merged_load(vimz_cf* vk, const uint8_t* blob, size_t len, vimz_cf_merged** out);
+/* the hand-over between two processes of one node without the host round trip, as vimz_ivc_merged_share / _open_shared: a ticket (records + HIP IPC
+ * handle), a device-to-device copy of the ten vectors on the receiving side */
+int64_t vimz_cf_merged_share(vimz_cf_merged* m, void* ticket, size_t cap);
+int vimz_cf_merged_open_shared(vimz_cf* vk, const uint8_t* ticket, size_t len, vimz_cf_merged** out);
 /* result: 0 = accepted; bit 0 / 1 a segment's main / CycleFold hash; bit 2 / 3 / 4 main relaxed relation / comm_W / comm_E; bit 5 / 6 / 7 the
  * same of the CycleFold instance; bit 10 instance scalars differ from the vectors; bit 12 statement (step count, initial state, adjacency);
  * bit 13 the stored folded instances differ from the replay of the records */
@@ -405,7 +409,7 @@ int vimz_cf_chain_from_digests(vimz_cf* v, const uint64_t* z_start, const uint64
 
 /* ---- the decider of the Nova + CycleFold path: `Decider::preprocess` / `Decider::prove` of the Sonobe backend (vimz/src/sonobe_backend/mod.rs:72-78;
  *      `DeciderEth<.., Groth16<Bn254>, ..>`, decider.rs:13-21) — the Groth16 proof that fills eight of the 25 calldata words (solidity.rs:13-27,
- *      contracts/*Verifier.sol:785-810).  Groth16 over BN254 as published; the circuit (vimz_amd/csrc/aug/decider.hpp: the hashes the last instance
+ *      contracts/ContrastVerifier.sol:785-810 and its siblings).  Groth16 over BN254 as published; the circuit (vimz_amd/csrc/aug/decider.hpp: the hashes the last instance
  *      carries, NIFS.V on the scalars, the folded main instance's relaxed R1CS row by row, the two KZG evaluations, one hash binding the words the
  *      contract sees) and the deterministic TEST setup (trapdoor derived from `seed`) are ours, parity unpinned: Sonobe's keys come out of crates
  *      that are not vendored.  NTTs, the G1 / G2 multi-scalar multiplications and the key's fixed-base multiplications run on the GPU. ---------- */

@@ -461,9 +461,10 @@ def _gpu_sharded_cyclefold_worker(rank, world, port, q):
     z0, inputs = step_inputs("hash")
     rows = np.stack(inputs[:9])
     cfs = [hip.CycleFoldIVC(cx, c, ck1, ck2, max_batch=2) for cx in ctxs]
-    proof = prove_sharded(cfs, rows, z0, rank, world, dist, merged_cls=hip.CycleFoldMerged, shm_dir="/tmp")
+    tm = {}
+    proof = prove_sharded(cfs, rows, z0, rank, world, dist, tm, merged_cls=hip.CycleFoldMerged, shm_dir="/tmp")
     if rank == 0:
-        q.put((proof.verify(9, z0), proof.verify(8, z0), proof.state(), proof.info()["segments"]))
+        q.put((proof.verify(9, z0), proof.verify(8, z0), proof.state(), proof.info()["segments"], tm.get("transports")))
         proof.close()
     dist.barrier()
     for v in cfs:
@@ -487,7 +488,7 @@ def test_two_ranks_on_the_gpu_end_in_one_verified_cyclefold_proof_object(oracle)
     procs = [ctx.Process(target=_gpu_sharded_cyclefold_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    ok9, ok8, state, segments = _get_or_fail(q, procs, 900)
+    ok9, ok8, state, segments, transports = _get_or_fail(q, procs, 900)
     for p in procs:
         p.join(timeout=300)
         assert p.exitcode == 0
@@ -497,6 +498,7 @@ def test_two_ranks_on_the_gpu_end_in_one_verified_cyclefold_proof_object(oracle)
         ok, z = oracle.step_eval(T_HASH, z, inputs[i])
     assert ok9 == 0 and ok8 != 0 and segments == 4
     assert state == ([int(x) for x in z0], z, 9)
+    assert transports == ["ipc"]      # (vimz_cf_merged_share / _open_shared: device-to-device, no host round trip)
 
 
 def _run_gpu_sharded(world, oracle_replay):

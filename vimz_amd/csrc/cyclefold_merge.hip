@@ -384,24 +384,21 @@ int vimz_cf_merged_save(vimz_cf_merged* m, uint8_t* blob, size_t cap) {
   P_TRY(hipStreamSynchronize(s));
   return VIMZ_OK;
 }
-int vimz_cf_merged_load(vimz_cf* vk, const uint8_t* blob, size_t len, vimz_cf_merged** out) {
-  if (!vk || !blob || !out || len < 64) return VIMZ_ERR_INVALID;
+// parse and replay the records of an untrusted blob / ticket (w: 8-byte words) into m (vk set); *rec_words_out = their length
+static int cfm_parse_records(vimz_cf* vk, const uint64_t* w, size_t nwords, vimz_cf_merged* m, size_t* rec_words_out, const char* who) {
   vimz_ctx* ctx = vk->ctx; vimz_prover* p = vk->pri;
   const size_t lz = p->len_z, nw = p->n_wires, nc = p->n_c, nw2 = vk->sec.n_w, nc2 = vk->sec.n_c;
-  const uint64_t* w = reinterpret_cast<const uint64_t*>(blob);      // (blobs come from numpy / malloc: 8-byte aligned)
-  if ((uintptr_t)blob % 8) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_cf_merged_load: blob not 8-byte aligned");
+  if (nwords < 8) return vz_fail(ctx, VIMZ_ERR_INVALID, who);
   const uint64_t S = w[1], R = w[7];
   if (w[0] != CF_MERGED_MAGIC || w[2] != lz || w[3] != nw || w[4] != nc || w[5] != nw2 || w[6] != nc2 || S == 0 || S > 4096 || R == 0 || R > S)
-    return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_cf_merged_load: the blob does not match this prover's circuits");
+    return vz_fail(ctx, VIMZ_ERR_INVALID, "merged CycleFold proof: the records do not match this prover's circuits");
   const size_t seg_words = 1 + 4 * (2 * lz + 7 + 4 + 5 + CF_IO + 6);
   const size_t rec_words = 8 + R + S * seg_words + (R - 1) * 16;
-  if (len < 8 * rec_words + 32 * (nw + 4 * nc + nw2 + 4 * nc2)) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_cf_merged_load: blob too short");
-  std::unique_ptr<vimz_cf_merged> m(new vimz_cf_merged());
-  m->vk = vk;
+  if (nwords < rec_words) return vz_fail(ctx, VIMZ_ERR_INVALID, "merged CycleFold proof: records too short");
   m->run_start.clear();
   size_t pos = 8;
-  for (uint64_t k = 0; k < R; k++) { if (w[pos] >= S || (k && w[pos] <= m->run_start.back())) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_cf_merged_load: malformed runs"); m->run_start.push_back((uint32_t)w[pos++]); }
-  if (m->run_start[0] != 0) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_cf_merged_load: malformed runs");
+  for (uint64_t k = 0; k < R; k++) { if (w[pos] >= S || (k && w[pos] <= m->run_start.back())) return vz_fail(ctx, VIMZ_ERR_INVALID, "merged CycleFold proof: malformed runs"); m->run_start.push_back((uint32_t)w[pos++]); }
+  if (m->run_start[0] != 0) return vz_fail(ctx, VIMZ_ERR_INVALID, "merged CycleFold proof: malformed runs");
   bool ok = true;
   auto fe = [&](auto* dst) { typedef std::decay_t<decltype(*dst)> F; F c; memcpy(c.v, w + pos, 32); pos += 4; if (!c.is_reduced()) ok = false; *dst = F::to_mont(c); };
   auto u256 = [&](U256w* dst) { memcpy(dst->w, w + pos, 32); pos += 4; Fq c; memcpy(c.v, dst->w, 32); if (!c.is_reduced()) ok = false; };
@@ -420,9 +417,25 @@ int vimz_cf_merged_load(vimz_cf* vk, const uint8_t* blob, size_t len, vimz_cf_me
   }
   m->junctions.assign(R - 1, CfJunction());
   for (auto& j : m->junctions) { g1(&j.Tp); g2(&j.Tq); }
-  if (!ok || pos != rec_words) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_cf_merged_load: an element of the records is not below its modulus, or a point is not on its curve");
+  if (!ok || pos != rec_words) return vz_fail(ctx, VIMZ_ERR_INVALID, "merged CycleFold proof: an element of the records is not below its modulus, or a point is not on its curve");
   uint32_t fl = 0;
-  if (!cfm_replay(vk, m->segs, m->run_start, m->junctions, m->acc, &fl)) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_cf_merged_load: malformed records");
+  if (!cfm_replay(vk, m->segs, m->run_start, m->junctions, m->acc, &fl)) return vz_fail(ctx, VIMZ_ERR_INVALID, "merged CycleFold proof: malformed records");
+  *rec_words_out = rec_words;
+  return VIMZ_OK;
+}
+
+int vimz_cf_merged_load(vimz_cf* vk, const uint8_t* blob, size_t len, vimz_cf_merged** out) {
+  if (!vk || !blob || !out || len < 64) return VIMZ_ERR_INVALID;
+  vimz_ctx* ctx = vk->ctx; vimz_prover* p = vk->pri;
+  const size_t nw = p->n_wires, nc = p->n_c, nw2 = vk->sec.n_w, nc2 = vk->sec.n_c;
+  const uint64_t* w = reinterpret_cast<const uint64_t*>(blob);      // (blobs come from numpy / malloc: 8-byte aligned)
+  if ((uintptr_t)blob % 8) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_cf_merged_load: blob not 8-byte aligned");
+  std::unique_ptr<vimz_cf_merged> m(new vimz_cf_merged());
+  m->vk = vk;
+  size_t rec_words = 0;
+  int rcp = cfm_parse_records(vk, w, len / 8, m.get(), &rec_words, "vimz_cf_merged_load: blob too short");
+  if (rcp) return rcp;
+  if (len < 8 * rec_words + 32 * (nw + 4 * nc + nw2 + 4 * nc2)) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_cf_merged_load: blob too short");
   // (hash / adjacency failures of the replay are the verifier's to report: the object loads and vimz_cf_merged_verify rejects it)
   std::lock_guard<std::mutex> g(ctx->mu);
   P_TRY(hipSetDevice(ctx->device));
@@ -446,6 +459,71 @@ int vimz_cf_merged_load(vimz_cf* vk, const uint8_t* blob, size_t len, vimz_cf_me
   if (e == hipSuccess) e = hipMemcpyAsync(&nbad, badc, 4, hipMemcpyDeviceToHost, s);
   if (e == hipSuccess) e = hipStreamSynchronize(s);
   if (e != hipSuccess || nbad) { hipFree(m->dev); m->dev = nullptr; return e != hipSuccess ? vz_fail(ctx, VIMZ_ERR_HIP, "vimz_cf_merged_load: upload", e) : vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_cf_merged_load: a vector element is not below its modulus"); }
+  vk->merged_dependents.push_back(m.get()); vk->orphan_merged = cfm_orphan_dependents;
+  *out = m.release();
+  return VIMZ_OK;
+}
+
+static std::vector<uint64_t> cfm_records_words(const uint64_t shape[5], const std::vector<CfSegRec>& segs, const std::vector<uint32_t>& run_start, const std::vector<CfJunction>& junctions);
+// The hand-over between the processes of one node without the host round trip (as vimz_ivc_merged_share / _open_shared: the ticket = the
+// records and a HIP IPC handle of the object's one device allocation; the receiver copies the ten vectors device-to-device).
+static const uint64_t CF_SHARE_MAGIC = 0x3148534643565aull;      // "ZVCFSH1"
+int64_t vimz_cf_merged_share(vimz_cf_merged* m, void* buf, size_t cap) {
+  if (!m || !m->vk || !m->dev) return VIMZ_ERR_INVALID;
+  vimz_cf* vk = m->vk; vimz_ctx* ctx = vk->ctx;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  if (m->broken) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_cf_merged_share: this object failed in the middle of a merge");
+  const uint64_t shape[5] = {vk->pri->len_z, vk->pri->n_wires, vk->pri->n_c, vk->sec.n_w, vk->sec.n_c};
+  const std::vector<uint64_t> rec = cfm_records_words(shape, m->segs, m->run_start, m->junctions);
+  const size_t bytes = 8 * (4 + 8 + rec.size());
+  if (!buf || cap < bytes) return (int64_t)bytes;
+  if (hipSetDevice(ctx->device) != hipSuccess) return VIMZ_ERR_HIP;
+  hipIpcMemHandle_t h;
+  const hipError_t e = hipIpcGetMemHandle(&h, m->dev);
+  if (e != hipSuccess) return vz_fail(ctx, VIMZ_ERR_HIP, "vimz_cf_merged_share: hipIpcGetMemHandle", e);
+  std::vector<uint64_t> o = {CF_SHARE_MAGIC, (uint64_t)(vk->pri->n_wires + 5 * (size_t)vk->pri->n_c + vk->sec.n_w + 5 * (size_t)vk->sec.n_c), 0, 0};
+  uint64_t hw[8]; memcpy(hw, &h, 64); o.insert(o.end(), hw, hw + 8);
+  o.insert(o.end(), rec.begin(), rec.end());
+  memcpy(buf, o.data(), bytes);
+  return (int64_t)bytes;
+}
+int vimz_cf_merged_open_shared(vimz_cf* vk, const uint8_t* ticket, size_t len, vimz_cf_merged** out) {
+  if (!vk || !ticket || !out || (len & 7) || len < 8 * 20) return VIMZ_ERR_INVALID;
+  vimz_ctx* ctx = vk->ctx; vimz_prover* p = vk->pri;
+  const size_t nw = p->n_wires, nc = p->n_c, nw2 = vk->sec.n_w, nc2 = vk->sec.n_c;
+  std::vector<uint64_t> words(len / 8); memcpy(words.data(), ticket, len);
+  const size_t elements = nw + 5 * nc + nw2 + 5 * nc2;
+  if (words[0] != CF_SHARE_MAGIC || words[1] != elements) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_cf_merged_open_shared: not a ticket for this prover's circuits");
+  hipIpcMemHandle_t h; memcpy(&h, words.data() + 4, 64);
+  std::unique_ptr<vimz_cf_merged> m(new vimz_cf_merged());
+  m->vk = vk;
+  size_t rec_words = 0;
+  int rcp = cfm_parse_records(vk, words.data() + 12, words.size() - 12, m.get(), &rec_words, "vimz_cf_merged_open_shared: ticket too short");
+  if (rcp) return rcp;
+  if (rec_words != words.size() - 12) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_cf_merged_open_shared: malformed ticket");
+  std::lock_guard<std::mutex> g(ctx->mu);
+  P_TRY(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  void* remote = nullptr;
+  hipError_t e = hipIpcOpenMemHandle(&remote, h, hipIpcMemLazyEnablePeerAccess);
+  if (e != hipSuccess || !remote) return vz_fail(ctx, VIMZ_ERR_HIP, "vimz_cf_merged_open_shared: hipIpcOpenMemHandle (not the same node, or no peer access between the two GPUs)", e);
+  e = hipMalloc((void**)&m->dev, 32 * elements);
+  if (e != hipSuccess) { hipIpcCloseMemHandle(remote); return vz_fail(ctx, VIMZ_ERR_HIP, "vimz_cf_merged_open_shared: hipMalloc", e); }
+  uint32_t* q = m->dev;
+  m->Zp = q; q += 8 * nw; m->Ep = q; q += 8 * nc; m->AZp = q; q += 8 * nc; m->BZp = q; q += 8 * nc; m->CZp = q; q += 8 * nc; m->Tp = q; q += 8 * nc;
+  m->Zq = q; q += 8 * nw2; m->Eq = q; q += 8 * nc2; m->AZq = q; q += 8 * nc2; m->BZq = q; q += 8 * nc2; m->CZq = q; q += 8 * nc2; m->Tq = q;
+  e = hipMemcpyAsync(m->dev, remote, 32 * elements, hipMemcpyDefault, s);
+  uint32_t* badc = m->Tq;      // (scratch until the first merge; the copied value there is scratch too)
+  uint32_t nbad = 1;
+  if (e == hipSuccess) e = hipMemsetAsync(badc, 0, 8, s);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_count_unreduced<Fr>, dim3(stream_grid(nw + 4 * nc)), dim3(256), 0, s, (size_t)(nw + 4 * nc), (const uint32_t*)m->Zp, badc);
+    hipLaunchKernelGGL(k_count_unreduced<Fq>, dim3(stream_grid(nw2 + 4 * nc2)), dim3(256), 0, s, (size_t)(nw2 + 4 * nc2), (const uint32_t*)m->Zq, badc);
+    e = hipMemcpyAsync(&nbad, badc, 4, hipMemcpyDeviceToHost, s);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  hipIpcCloseMemHandle(remote);
+  if (e != hipSuccess || nbad) { hipFree(m->dev); m->dev = nullptr; return e != hipSuccess ? vz_fail(ctx, VIMZ_ERR_HIP, "vimz_cf_merged_open_shared: copy", e) : vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_cf_merged_open_shared: a vector element is not below its modulus"); }
   vk->merged_dependents.push_back(m.get()); vk->orphan_merged = cfm_orphan_dependents;
   *out = m.release();
   return VIMZ_OK;

@@ -865,6 +865,23 @@ class CycleFoldMerged:
         self.ctx._chk(self.ctx.lib.vimz_cf_merged_profile(self.h, s))
         return dict(zip(self.PHASES, s))
 
+    def share(self):
+        """vimz_cf_merged_share: the ticket (records + HIP IPC handle) another process of this node opens with CycleFoldMerged.open_shared."""
+        lib = self.ctx.lib
+        lib.vimz_cf_merged_share.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        lib.vimz_cf_merged_share.restype = C.c_int64
+        return _export(lib.vimz_cf_merged_share, self.h)
+
+    @classmethod
+    def open_shared(cls, vk, ticket):
+        """vimz_cf_merged_open_shared: an object of this process's own out of another process's shared one (device-to-device copy)."""
+        b = np.ascontiguousarray(np.frombuffer(bytes(ticket), dtype=np.uint8) if isinstance(ticket, (bytes, bytearray)) else ticket, dtype=np.uint8)
+        lib = vk.ctx.lib
+        lib.vimz_cf_merged_open_shared.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+        h = C.c_void_p()
+        vk.ctx._chk(lib.vimz_cf_merged_open_shared(vk.h, _ptr(b), b.size, C.byref(h)))
+        return cls(_handle=h, _vk=vk)
+
     def kzg_open(self, which, z):
         """vimz_cf_merged_kzg_open: (eval, proof point) of the folded main instance's comm_W (which = 0) or comm_E (1) at z."""
         lib = self.ctx.lib
