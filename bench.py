@@ -181,6 +181,12 @@ def usable_cores():
             n = min(n, max(1, q // per))
     except (OSError, ValueError):
         pass
+    # the ranks of a node share the quota: a rank's share (a launcher that binds every rank to cores of its own has already narrowed the mask;
+    # --cores does so here)
+    local = int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1)
+    bound = hasattr(os, "sched_getaffinity") and len(os.sched_getaffinity(0)) < (os.cpu_count() or 1)
+    if local > 1 and not bound:
+        n = max(1, n // local)
     return n
 
 

@@ -501,7 +501,17 @@ def test_two_ranks_on_the_gpu_end_in_one_verified_cyclefold_proof_object(oracle)
     assert transports == ["ipc"]      # (vimz_cf_merged_share / _open_shared: device-to-device, no host round trip)
 
 
-def _run_gpu_sharded(world, oracle_replay):
+def _run_gpu_sharded(world, oracle_replay, transport=None):
+    import torch.multiprocessing as mp
+    if transport:
+        os.environ["VIMZ_SHARD_TRANSPORT"] = transport      # (inherited by the spawned ranks)
+    try:
+        return _run_gpu_sharded_inner(world, oracle_replay)
+    finally:
+        os.environ.pop("VIMZ_SHARD_TRANSPORT", None)
+
+
+def _run_gpu_sharded_inner(world, oracle_replay):
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
@@ -551,3 +561,14 @@ def test_four_ranks_on_the_gpu_fold_their_proofs_up_a_tree(oracle):
     failed, n, kinds = replay
     assert failed == [] and n == 9
     assert kinds == "LLN" "LLN" "N" "LLN" "LLN" "N" "N"      # ((r0 r1) (r2 r3)), every rank's run = two local segments
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("transport,seen", [("ipc-fail", ["file"]), ("bytes", ["bytes"])])
+def test_ranks_fall_back_to_bytes_where_ipc_is_unavailable(oracle, transport, seen):
+    """A node where HIP IPC or peer access between two GPUs is not to be had: the receiving rank's open fails, it asks for the bytes, the
+    sender writes them (node-local file with an unpredictable name, or through gloo) and the proof is loaded the round-3 way — the ONE
+    object verifies for (9 steps, z0) all the same."""
+    ok9, ok8, state, segments, transports, _ = _run_gpu_sharded(2, False, transport)
+    assert ok9 == 0 and ok8 != 0 and segments == 4 and state[2] == 9
+    assert transports == seen

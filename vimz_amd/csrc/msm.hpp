@@ -37,7 +37,7 @@ namespace vz {
 // small_lean (0: off, the default): the fused small MSM's wide tail levels by one lane per addition instead of four — 15-20 % fewer
 // instructions per small MSM, 7-27 µs more latency: measured SLOWER in every regime (three segments 1095-1101 -> 1054-1078 -> 1029-1051
 // steps/s for lean = 0 / 1 / 2, one chain 819 -> 799 -> 770): with the GPU 98 % busy the step is still bound by its latency chains.
-struct MsmTuning { int sort_blocks = 0, combine_lane_bits = -1, small_lean = 0; };
+struct MsmTuning { int sort_blocks = 0, combine_lane_bits = -1, small_lean = 0, witness_sub = 0; };
 inline const MsmTuning& msm_tuning() {
   static const MsmTuning t = [] {
     MsmTuning r;
@@ -45,6 +45,7 @@ inline const MsmTuning& msm_tuning() {
       if (const char* q = strstr(e, "sort_blocks=")) r.sort_blocks = atoi(q + 12);
       if (const char* q = strstr(e, "combine_lane_bits=")) r.combine_lane_bits = atoi(q + 18);
       if (const char* q = strstr(e, "small_lean=")) r.small_lean = atoi(q + 11);
+      if (const char* q = strstr(e, "witness_sub=")) { const int v = atoi(q + 12); if (v >= 2 && v <= MSM_SUB) r.witness_sub = v; }
     }
     return r;
   }();
@@ -888,7 +889,11 @@ hipError_t msm_launch(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_ba
   *plan_out = pl;
   const size_t entries = (size_t)pl.K * n;
   // small MSMs are latency-bound (one dependent addition ~ 6-10 us): shorter chains per thread, more threads
-  const uint32_t sub = n < (1u << 15) ? 8u : (uint32_t)MSM_SUB;   // MSM_SUB for everything large
+  // (a witness commitment — split_ones — of an HD-sized circuit is a few 10^5 entries spread thinly over the buckets: one thread per bucket and a
+  //  chain of a dozen additions each on a quarter of the GPU; pieces of 8 give twice the threads half the chain: 1 045-1 061 -> 1 088-1 097 steps/s at
+  //  contrast HD, one chain 808 -> 823; at 4K the buckets are three times as full and the long pieces stay (558 against 542).  VIMZ_TUNE=witness_sub=N pins it.)
+  const int wsub = msm_tuning().witness_sub;
+  const uint32_t sub = n < (1u << 15) ? 8u : split_ones ? (uint32_t)(wsub > 0 ? wsub : n < (1u << 19) ? 8 : MSM_SUB) : (uint32_t)MSM_SUB;   // MSM_SUB for everything large
   const size_t max_subs = entries / sub + pl.nb + 1;
   VZ_HIP_CHECK(ws.reserve(pl.nb, entries, max_subs));
   const int TB = 256;

@@ -502,6 +502,10 @@ static unsigned usable_cpus() {
       if (FILE* h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(h, "%ld", &per) != 1) per = 100000; fclose(h); }
       if (quota > 0 && per > 0 && quota / per >= 1) n = std::min<unsigned>(n, (unsigned)(quota / per));
     }
+    // the ranks of a node share the quota (and, unless the launcher binds them, the affinity mask): a rank's share is what its helper pools may count on
+    // (a mask narrower than the machine means the launcher has bound this rank to cores of its own: that IS its share)
+    const bool bound = aug::affinity_cpus() < std::max(1u, std::thread::hardware_concurrency());
+    if (const char* lw = getenv("LOCAL_WORLD_SIZE")) { const long k = atol(lw); if (k > 1 && !bound) n = std::max(1u, n / (unsigned)k); }
     return n;
   }();
   return v;

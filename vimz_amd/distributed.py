@@ -219,7 +219,9 @@ def tree_final_fold(proof, vk, rank, world, dist, merged_cls, shm_dir=None, timi
     import os
     import pickle
     import time
-    can_ipc = hasattr(merged_cls, "open_shared")
+    # VIMZ_SHARD_TRANSPORT = ipc | file | bytes pins the hand-over; "ipc-fail" makes the receiver's IPC open fail, to exercise the fallback
+    forced = os.environ.get("VIMZ_SHARD_TRANSPORT", "")
+    can_ipc = hasattr(merged_cls, "open_shared") and forced in ("", "ipc", "ipc-fail")
     t_wait = t_merge = 0.0
     step = 1
     try:
@@ -236,6 +238,8 @@ def tree_final_fold(proof, vk, rank, world, dist, merged_cls, shm_dir=None, timi
                         other = None
                         if msg["kind"] == "ipc":
                             try:
+                                if forced == "ipc-fail":
+                                    raise RuntimeError("IPC open refused (VIMZ_SHARD_TRANSPORT=ipc-fail)")
                                 other = merged_cls.open_shared(vk, msg["ticket"])
                             except Exception:      # no IPC / peer access between the two devices: ask for the bytes instead
                                 _send_bytes(dist, b"retry", src)
@@ -264,7 +268,7 @@ def tree_final_fold(proof, vk, rank, world, dist, merged_cls, shm_dir=None, timi
                     t_merge += time.time() - t1
             else:
                 dst = rank - step
-                transport = "ipc" if (can_ipc and proof is not None and hasattr(proof, "share")) else ("file" if shm_dir else "bytes")
+                transport = "ipc" if (can_ipc and proof is not None and hasattr(proof, "share")) else ("bytes" if (forced == "bytes" or not shm_dir) else "file")
                 path = None
                 try:
                     offer, path = _offer(proof, merged_cls, transport, shm_dir)
