@@ -2,17 +2,18 @@
 // behind `CommitmentEngine::commit` in nova-snark 0.23.0 (SURVEY.md §8a rows M1/M2, §8b "MSM" seam).
 //
 // Pipeline (all on one HIP stream, no host round trip until the window sums come back):
-//   1. k_hist_lds / k_block_prefix   signed-digit recode of every scalar (window c bits, digits in [-2^(c-1), 2^(c-1)]);
+//   1. k_hist_lds / k_prefix_scan    signed-digit recode of every scalar (window c bits, digits in [-2^(c-1), 2^(c-1)]);
 //                  per-workgroup LDS histograms of the (window, |digit|) buckets, then bucket totals and per-workgroup
 //                  offsets — no global atomics (k_hist / k_scatter with wave-aggregated global atomics remain as the
 //                  fallback for windows whose counters do not fit LDS).
-//   2. k_scan      one workgroup: exclusive scan of bucket sizes -> entry offsets, and of ceil(size/SUB) -> sub-bucket
-//                  offsets.  Buckets are split into sub-buckets of at most SUB entries so no thread owns a long chain.
+//   2. (scan)      exclusive scan of bucket sizes -> entry offsets, and of ceil(size/SUB) -> sub-bucket offsets, by the last workgroup
+//                  of k_prefix_scan to finish (k_scan, a launch of its own, on the fallback path).  Buckets are split into sub-buckets of
+//                  at most SUB entries so no thread owns a long chain.
 //   3. k_scatter_lds  counting-sort scatter of (point index | sign) into bucket order, ranks from LDS counters.
 //   4. k_accum     one thread per sub-bucket: gathers its affine bases (80 B each, from L2 / Infinity Cache — the key is
 //                  re-read by every window) and accumulates in XYZZ over the 9x29-bit coordinate field.
-//   5. k_combine (+ k_combine_heavy2) folds the sub-bucket partials of each bucket; hot buckets (listed by k_scan) by workgroup trees
-//                  in the same launch.
+//   5. k_combine   folds the sub-bucket partials of each bucket; hot buckets (listed by the scan) by workgroup trees in the same launch;
+//                  the second stage of the very heavy ones rides in k_reduce's prologue.
 //   6. k_reduce    per window: chunked running sums + LDS tree -> sum_b b*B_b.
 //      (unit scalars, when split: k_ones_partial + k_tree256 -> one extra "window sum")
 //   7. host        Horner over the K window sums (K*c doublings) and one inversion to affine (msm_finish).
@@ -133,8 +134,7 @@ __global__ void k_hist(const uint32_t* __restrict__ scalars, size_t n, int mont,
 }
 
 // One workgroup of 1024 threads; nb is a few 10^4..10^6.
-template <int SUB>
-__global__ void __launch_bounds__(1024) k_scan(const uint32_t* __restrict__ counts, uint32_t nb,
+__device__ __forceinline__ void scan_body(const uint32_t* __restrict__ counts, uint32_t nb,
                                                uint32_t* __restrict__ bucket_off, uint32_t* __restrict__ sub_off,
                                                uint32_t* __restrict__ totals, uint32_t sub,
                                                uint32_t* __restrict__ heavy /* [0] = count (zeroed by the caller), then ids of buckets with > heavy_min sub-buckets */,
@@ -166,6 +166,11 @@ __global__ void __launch_bounds__(1024) k_scan(const uint32_t* __restrict__ coun
     carry_e += te; carry_s += ts;
   }
   if (t == 0) { bucket_off[nb] = carry_e; sub_off[nb] = carry_s; totals[0] = carry_s; totals[1] = carry_e; }
+}
+template <int SUB>
+__global__ void __launch_bounds__(1024) k_scan(const uint32_t* __restrict__ counts, uint32_t nb, uint32_t* __restrict__ bucket_off, uint32_t* __restrict__ sub_off,
+                                               uint32_t* __restrict__ totals, uint32_t sub, uint32_t* __restrict__ heavy, uint32_t heavy_min, uint32_t heavy_cap) {
+  scan_body(counts, nb, bucket_off, sub_off, totals, sub, heavy, heavy_min, heavy_cap);
 }
 
 template <class S>
@@ -213,21 +218,35 @@ __global__ void __launch_bounds__(SORT_THREADS) k_hist_lds(const uint32_t* __res
   for (uint32_t g = threadIdx.x; g < nb; g += SORT_THREADS) out[g] = lds_cnt[g];
 }
 
-// per bucket: total over workgroups -> counts[g]; block_hist[blk][g] becomes the exclusive prefix over workgroups
+// The per-bucket prefix over the sort workgroups' histograms and the scan in ONE launch (round 4; k_block_prefix + k_scan before): every workgroup
+// turns its 1024 buckets' per-workgroup histograms into exclusive prefixes (block_hist[blk][g]) and totals (counts[g]); the LAST workgroup to finish (a ticket in totals[2]) runs the scan over all totals.  In a fold a launch — however small — waits ~0.1 ms for
+// its turn next to three segments' kernels (profiles/r04_msm_chain_gaps_HD.txt: k_scan 93 µs, k_block_prefix 120 µs, an EMPTY k_combine_heavy2 114 µs):
+// the large MSM's chain is two launches shorter.  Release / acquire as in k_msm_small: stores, fence, agent-scope ticket; fence, plain loads.
 template <int DUMMY>
-__global__ void __launch_bounds__(256) k_block_prefix(uint32_t* __restrict__ block_hist, uint32_t nb, uint32_t* __restrict__ counts, uint32_t nblocks,
-                                                      uint32_t* __restrict__ heavy) {
+__global__ void __launch_bounds__(1024) k_prefix_scan(uint32_t* __restrict__ block_hist, uint32_t nb, uint32_t* __restrict__ counts, uint32_t nblocks,
+                                                      uint32_t* __restrict__ heavy, uint32_t* __restrict__ bucket_off, uint32_t* __restrict__ sub_off,
+                                                      uint32_t* __restrict__ totals, uint32_t sub, uint32_t heavy_min, uint32_t heavy_cap) {
+  __shared__ uint32_t s_last;
   const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g == 0) heavy[0] = 0;                       // k_scan's heavy-bucket list starts empty (saves a fill launch per MSM)
-  if (g >= nb) return;
-  uint32_t run = 0;
-  for (uint32_t blk = 0; blk < nblocks; blk++) {
-    const size_t idx = (size_t)blk * nb + g;
-    const uint32_t v = block_hist[idx];
-    block_hist[idx] = run;
-    run += v;
+  if (g < nb) {
+    uint32_t run = 0;
+    for (uint32_t blk = 0; blk < nblocks; blk++) {
+      const size_t idx = (size_t)blk * nb + g;
+      const uint32_t v = block_hist[idx];
+      block_hist[idx] = run;
+      run += v;
+    }
+    counts[g] = run;
   }
-  counts[g] = run;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = atomicAdd(&totals[2], 1u) == gridDim.x - 1 ? 1u : 0u;
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  if (threadIdx.x == 0) { __hip_atomic_store(&totals[2], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); heavy[0] = 0; }      // (the ticket for the next MSM; the heavy list starts empty)
+  __syncthreads();
+  scan_body(counts, nb, bucket_off, sub_off, totals, sub, heavy, heavy_min, heavy_cap);
 }
 
 template <class S>
@@ -414,11 +433,31 @@ __global__ void __launch_bounds__(256) k_combine_heavy2(uint32_t* __restrict__ p
 // the 2^(c-1) buckets are reduced as V = 2^(c-1)/1024 "virtual windows" of 1024 buckets each by this same kernel (V workgroups side by
 // side, the depth of the c = 11 reduce), and the host finishes  Σ_v R_v + 1024·Σ_v v·S_v  (msm_finish).
 template <class F>
-__global__ void __launch_bounds__(256) k_reduce(const uint32_t* __restrict__ partial, const uint32_t* __restrict__ counts,
+__global__ void __launch_bounds__(256) k_reduce(const uint32_t* partial /* (== partial_rw: no restrict) */, const uint32_t* __restrict__ counts,
                                                 const uint32_t* __restrict__ sub_off, uint32_t nbw,
-                                                uint32_t* __restrict__ window_sums, uint32_t* __restrict__ plain_sums = nullptr) {
+                                                uint32_t* __restrict__ window_sums, uint32_t* __restrict__ plain_sums = nullptr,
+                                                const uint32_t* __restrict__ heavy = nullptr, uint32_t heavy_cap = 0, const uint32_t* __restrict__ scratch = nullptr,
+                                                uint32_t* partial_rw = nullptr) {
   __shared__ XYZZ<F> sh[256];
   const uint32_t w = blockIdx.x, t = threadIdx.x, T = blockDim.x;
+  if (heavy && T == 256) {
+    // Stage 2 of the very heavy buckets (k_combine left MSM_HEAVY_PARTS partial sums of each in a scratch row): the workgroup whose window the
+    // bucket belongs to folds the row — a 32-leaf tree of four-lane additions — before it reads the bucket's sum.  (Until round 4 a kernel of its
+    // own, k_combine_heavy2: an almost always empty launch that still waited ~0.1 ms for its turn inside a fold.)
+    const uint32_t count = heavy[0] <= heavy_cap ? min(heavy[0], MSM_HEAVY_SPLIT) : 0u;
+    for (uint32_t h = 0; h < count; h++) {
+      const uint32_t b = heavy[1 + h];
+      if (b < w * nbw || b >= (w + 1) * nbw) continue;
+      const uint32_t s0 = sub_off[b], m = sub_off[b + 1] - s0;
+      if (m < MSM_HEAVY_SPLIT_MIN) continue;
+      sh[t] = t < MSM_HEAVY_PARTS ? load_xyzz<F>(scratch, (size_t)h * MSM_HEAVY_PARTS + t) : XYZZ<F>::identity();
+      __syncthreads();
+      for (uint32_t d = MSM_HEAVY_PARTS / 2; d > 0; d >>= 1) quad_level<F>(sh, d, [](uint32_t e) { return e; }, [d](uint32_t e) { return e + d; });
+      if (t == 0) store_xyzz(partial_rw, s0, sh[0]);
+      __syncthreads();
+    }
+    __threadfence_block();
+  }
   const uint32_t ch = nbw / T;
   const uint32_t lo = t * ch;
   XYZZ<F> run = XYZZ<F>::identity(), sum = XYZZ<F>::identity();
@@ -929,7 +968,6 @@ hipError_t msm_launch(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_ba
       }
     }
     hipLaunchKernelGGL(k_hist_lds<S>, dim3(sort_blocks), dim3(SORT_THREADS), pl.nb * 4, stream, d_scalars, n, scalars_mont, split_ones, pl.c, pl.K, bstride, pl.nb, ws.block_hist);
-    hipLaunchKernelGGL(k_block_prefix<0>, dim3((pl.nb + 255) / 256), dim3(256), 0, stream, ws.block_hist, pl.nb, ws.counts, sort_blocks, ws.heavy);
   } else {
     hipLaunchKernelGGL(k_hist<S>, dim3(gs), dim3(TB), 0, stream, d_scalars, n, scalars_mont, split_ones, pl.c, pl.K, bstride, ws.counts);
   }
@@ -941,7 +979,11 @@ hipError_t msm_launch(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_ba
   const int lane_bits_env = msm_tuning().combine_lane_bits;
   const uint32_t lane_bits = lane_bits_env >= 0 ? (uint32_t)lane_bits_env : mean_parts > 96 ? 4u : mean_parts > 48 ? 3u : mean_parts > 24 ? 2u : 1u;
   const uint32_t heavy_min = 16u << lane_bits;
-  hipLaunchKernelGGL(k_scan<MSM_SUB>, dim3(1), dim3(1024), 0, stream, ws.counts, pl.nb, ws.bucket_off, ws.sub_off, ws.totals, sub, ws.heavy, heavy_min, MsmWorkspace::HEAVY_CAP);
+  if (lds_sort)      // per-workgroup histograms -> prefixes and totals, and (last workgroup) the scan: one launch
+    hipLaunchKernelGGL(k_prefix_scan<0>, dim3((pl.nb + 1023) / 1024), dim3(1024), 0, stream, ws.block_hist, pl.nb, ws.counts, sort_blocks, ws.heavy, ws.bucket_off, ws.sub_off,
+                       ws.totals, sub, heavy_min, MsmWorkspace::HEAVY_CAP);
+  else
+    hipLaunchKernelGGL(k_scan<MSM_SUB>, dim3(1), dim3(1024), 0, stream, ws.counts, pl.nb, ws.bucket_off, ws.sub_off, ws.totals, sub, ws.heavy, heavy_min, MsmWorkspace::HEAVY_CAP);
   VZ_EV(2);
   if (lds_sort)
     hipLaunchKernelGGL(k_scatter_lds<S>, dim3(sort_blocks), dim3(SORT_THREADS), pl.nb * 4, stream, d_scalars, n, scalars_mont, split_ones, pl.c, pl.K, bstride, pl.nb,
@@ -958,17 +1000,22 @@ hipError_t msm_launch(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_ba
   const unsigned per_wg = 256u >> lane_bits, nbn = (pl.nb + per_wg - 1) / per_wg;
   hipLaunchKernelGGL(k_combine<F>, dim3(nbn + COMBINE_HEAVY_BLOCKS + COMBINE_SPLIT_BLOCKS), dim3(256), 0, stream, partial, ws.sub_off, pl.nb, nbn,
                      (const uint32_t*)ws.heavy, MsmWorkspace::HEAVY_CAP, ws.heavy_scratch, lane_bits, heavy_min);
-  hipLaunchKernelGGL(k_combine_heavy2<F>, dim3(MSM_HEAVY_SPLIT / 8), dim3(256), 0, stream, partial, ws.sub_off, ws.heavy, MsmWorkspace::HEAVY_CAP, ws.heavy_scratch);
-  VZ_EV(5);
+  VZ_EV(5);      // (stage 2 of the very heavy buckets rides in k_reduce's prologue)
   const unsigned T = pl.nbw < 256 ? pl.nbw : 256;
   uint32_t* wsum = direct ? reinterpret_cast<uint32_t*>(pinned_dst) : reinterpret_cast<uint32_t*>(ws.window_sums);
   const uint32_t vw = std::min<uint32_t>(pl.nbw, MSM_VWIN);      // shared bucket set: virtual windows of vw buckets
   const int V = (int)(pl.nbw / vw);
   const int kout = tabled && !own ? 2 * V : pl.K;     // sums produced: (R_v, S_v) per virtual window, or one per window
   if (tabled && !own) {
-    hipLaunchKernelGGL(k_reduce<F>, dim3(V), dim3(vw < 256 ? vw : 256), 0, stream, partial, ws.counts, ws.sub_off, vw, wsum, wsum + (size_t)XYZZ_WORDS * V);
-  } else
-  hipLaunchKernelGGL(k_reduce<F>, dim3(pl.K), dim3(T), 0, stream, partial, ws.counts, ws.sub_off, pl.nbw, wsum);
+    hipLaunchKernelGGL(k_reduce<F>, dim3(V), dim3(vw < 256 ? vw : 256), 0, stream, (const uint32_t*)partial, (const uint32_t*)ws.counts, (const uint32_t*)ws.sub_off, vw, wsum, wsum + (size_t)XYZZ_WORDS * V,
+                       (const uint32_t*)ws.heavy, (uint32_t)MsmWorkspace::HEAVY_CAP, (const uint32_t*)ws.heavy_scratch, partial);
+  } else if (T == 256)
+    hipLaunchKernelGGL(k_reduce<F>, dim3(pl.K), dim3(T), 0, stream, (const uint32_t*)partial, (const uint32_t*)ws.counts, (const uint32_t*)ws.sub_off, pl.nbw, wsum, (uint32_t*)nullptr,
+                       (const uint32_t*)ws.heavy, (uint32_t)MsmWorkspace::HEAVY_CAP, (const uint32_t*)ws.heavy_scratch, partial);
+  else {      // (windows of fewer than 256 buckets: small MSMs through the general pipeline; the stage-2 kernel of its own)
+    hipLaunchKernelGGL(k_combine_heavy2<F>, dim3(MSM_HEAVY_SPLIT / 8), dim3(256), 0, stream, partial, ws.sub_off, ws.heavy, MsmWorkspace::HEAVY_CAP, ws.heavy_scratch);
+    hipLaunchKernelGGL(k_reduce<F>, dim3(pl.K), dim3(T), 0, stream, (const uint32_t*)partial, (const uint32_t*)ws.counts, (const uint32_t*)ws.sub_off, pl.nbw, wsum);
+  }
   VZ_EV(6);
 #undef VZ_EV
   if (split_ones) {   // sum of the bases with unit scalar -> window_sums[K]

@@ -110,7 +110,9 @@ struct MsmWorkspace {  // device buffers, grown on demand and reused across call
       VZ_HIP_CHECK(hipMalloc(&partial, 4 * XYZZ_WORDS * subs)); cap_subs = subs;
     }
     if (!window_sums) VZ_HIP_CHECK(hipMalloc(&window_sums, 4 * XYZZ_WORDS * MSM_MAX_WINDOWS));
-    if (!totals) VZ_HIP_CHECK(hipMalloc(&totals, 64));
+    // (totals[2] is the ticket of k_prefix_scan: zero between launches.  hipMemset on device memory is a null-stream operation that may
+    //  return before it has run and the MSM streams are non-blocking: synchronise)
+    if (!totals) { VZ_HIP_CHECK(hipMalloc(&totals, 64)); VZ_HIP_CHECK(hipMemset(totals, 0, 64)); VZ_HIP_CHECK(hipStreamSynchronize(nullptr)); }
     if (!heavy) VZ_HIP_CHECK(hipMalloc(&heavy, 4 * (HEAVY_CAP + 1)));
     if (!heavy_scratch) VZ_HIP_CHECK(hipMalloc(&heavy_scratch, 4 * (size_t)XYZZ_WORDS * 1024 * 32));
     if (!ones_partial) VZ_HIP_CHECK(hipMalloc(&ones_partial, 4 * (size_t)XYZZ_WORDS * (16384 + 64 + 512)));
