@@ -17,7 +17,7 @@ ev.sort()
 if not grid:      # the most common k_accum grid among the larger ones = MSM(T)
     c = collections.Counter(e[3] for e in ev if e[2] == "k_accum")
     grid = max(c, key=lambda g: (c[g] > 20, g))
-seq = ["k_fold_cross", "k_hist_lds", "k_block_prefix", "k_scan", "k_scatter_lds", "k_accum", "k_combine", "k_combine_heavy2", "k_reduce"]
+seq = ["k_fold_cross", "k_hist_lds", "k_block_prefix", "k_scan", "k_prefix_scan", "k_scatter_lds", "k_accum", "k_combine", "k_combine_heavy2", "k_reduce"]
 by_q = collections.defaultdict(list)
 for e in ev:
     by_q[e[4]].append(e)

@@ -4,8 +4,8 @@
 // Pipeline (all on one HIP stream, no host round trip until the K window sums come back):
 //   1. k_hist      signed-digit recode of every scalar (window c bits, digits in [-2^(c-1), 2^(c-1)]),
 //                  histogram of (window, |digit|) buckets with global atomics.
-//   2. k_scan      one workgroup: exclusive scan of bucket sizes -> entry offsets, and of
-//                  ceil(size/SUB) -> sub-bucket offsets.  Large buckets (witness scalars are ~95 % bits
+//   2. (scan)      exclusive scan of bucket sizes -> entry offsets, and of ceil(size/SUB) -> sub-bucket offsets (k_scan; on the
+//                  LDS-sort path the last workgroup of k_prefix_scan).  Large buckets (witness scalars are ~95 % bits
 //                  and bytes, so bucket "1" of window 0 can hold a third of all points) are split into
 //                  sub-buckets of at most SUB entries so no thread owns an unbounded chain.
 //   3. k_scatter   counting-sort scatter of (point index | sign) into bucket order.
