@@ -76,7 +76,7 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
   };
   static const bool dbg_timing = getenv("VIMZ_DEBUG_TIMING") != nullptr;
   const double t_prep = now_s() - t_all;
-  double t_first = 0, t_wait0 = 0, t_hook = 0, t_hk[5] = {0, 0, 0, 0, 0};      // (t_hk: fused fold launch, event records, large-MSM launches, fold5 launch, row-flag waits)
+  double t_first = 0, t_wait0 = 0, t_hook = 0, t_hk[5] = {0, 0, 0, 0, 0}, t_wp[5] = {0, 0, 0, 0, 0};      // (t_wp: the parts of wait_primary_msm)      // (t_hk: fused fold launch, event records, large-MSM launches, fold5 launch, row-flag waits)
   const std::vector<Fe>& zs = job.zs;
   const size_t pin_stride = FoldJob::pin_stride;
   char* pin_aug1 = v->pin + 5 * v->pin_res;
@@ -294,6 +294,8 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
       // rho_{i-1}·comm(T(u_{i-1}, u_i)) = −rho_{i-1}·comm(negB_i) — one 129-bit scalar multiplication on the host, done here, while
       // the device works on the verifier rows (the producer committed to negB_i long ago)
       G1 lookB = G1::identity();
+      double tw = now_s();
+      t_wp[0] += tw - t0;
       if (i > 0 && slot.hasB) {
         P_TRY(wait_row_flag(bb, bb.flag_rows + r, bb.ev_d[r]));
         const G1Aff cD = msm_finish<BnG1>(p->planD, (char*)bb.pin_d + r * pin_stride);
@@ -303,11 +305,14 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
           lookB = acc;
         }
       }
+      t_wp[1] += now_s() - tw; tw = now_s();
       P_TRY(take_T1_step(false));
       P_TRY(hipStreamSynchronize(v->s2));
+      t_wp[2] += now_s() - tw; tw = now_s();
       G1Aff cW_aug = msm_finish<BnG1>(v->plan_aug, v->pin);      // the small MSM is back first: its tail overlaps the other one
       P_TRY(take_T1_step(false));
       P_TRY(hipEventSynchronize(v->ev_a));
+      t_wp[3] += now_s() - tw;
       v->ph_s[IP_WAIT_PRI] += now_s() - t0; v->ph_n[IP_WAIT_PRI]++;
       t0 = now_s();
       {
@@ -329,6 +334,7 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
         t0 = now_s();
         P_TRY(take_T1_step(true));
         v->ph_s[IP_WAIT_PRI] += now_s() - t0;
+        t_wp[4] += now_s() - t0;
         G1 ts = from_affine(T1_step); add_mixed(ts, Tv);
         if (slot.hasB) { G1 nb = lookB; if (!nb.is_identity()) nb.Y = Fq::neg(nb.Y); add_full(ts, nb); }
         T1 = to_affine(ts);
@@ -457,6 +463,8 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
   for (uint32_t k = 0; k < p->len_z; k++) p->z_cur[k] = zs[nsteps * p->len_z + k];
   guard.armed = false;
   v->ph_s[IP_TOTAL] += now_s() - t_all; v->ph_n[IP_TOTAL] += nsteps;
+  if (dbg_timing) fprintf(stderr, "[timing] wait_primary_msm per step: finish(W) + statement %.3f, lookahead's host share %.3f, small MSM(W aug) %.3f, verifier rows + small MSM(T) %.3f, large MSM(T) %.3f ms\n",
+                          1e3 * t_wp[0] / (double)nsteps, 1e3 * t_wp[1] / (double)nsteps, 1e3 * t_wp[2] / (double)nsteps, 1e3 * t_wp[3] / (double)nsteps, 1e3 * t_wp[4] / (double)nsteps);
   if (dbg_timing) fprintf(stderr, "[timing] fold of %zu steps: %.1f ms (prepare %.1f, first batch ready at %.1f after waiting %.1f; launches queued from inside the secondary circuit: %.3f ms per step = fused fold %.3f + 3 event records %.3f + large MSM %.3f + fold5 %.3f + row flags %.3f)\n", nsteps, 1e3 * (now_s() - t_all), 1e3 * t_prep, 1e3 * t_first, 1e3 * t_wait0, 1e3 * t_hook / (double)nsteps,
                           1e3 * t_hk[0] / (double)nsteps, 1e3 * t_hk[1] / (double)nsteps, 1e3 * t_hk[2] / (double)nsteps, 1e3 * t_hk[3] / (double)nsteps, 1e3 * t_hk[4] / (double)nsteps);
   return VIMZ_OK;

@@ -38,7 +38,7 @@ namespace vz {
 // small_lean (0: off, the default): the fused small MSM's wide tail levels by one lane per addition instead of four — 15-20 % fewer
 // instructions per small MSM, 7-27 µs more latency: measured SLOWER in every regime (three segments 1095-1101 -> 1054-1078 -> 1029-1051
 // steps/s for lean = 0 / 1 / 2, one chain 819 -> 799 -> 770): with the GPU 98 % busy the step is still bound by its latency chains.
-struct MsmTuning { int sort_blocks = 0, combine_lane_bits = -1, small_lean = 0, witness_sub = 0; };
+struct MsmTuning { int sort_blocks = 0, combine_lane_bits = -1, small_lean = 0, witness_sub = 0, ones_dense = 1; };
 inline const MsmTuning& msm_tuning() {
   static const MsmTuning t = [] {
     MsmTuning r;
@@ -47,6 +47,7 @@ inline const MsmTuning& msm_tuning() {
       if (const char* q = strstr(e, "combine_lane_bits=")) r.combine_lane_bits = atoi(q + 18);
       if (const char* q = strstr(e, "small_lean=")) r.small_lean = atoi(q + 11);
       if (const char* q = strstr(e, "witness_sub=")) { const int v = atoi(q + 12); if (v >= 2 && v <= MSM_SUB) r.witness_sub = v; }
+      if (const char* q = strstr(e, "ones_dense=")) r.ones_dense = atoi(q + 11);
     }
     return r;
   }();
@@ -306,20 +307,52 @@ __global__ void __launch_bounds__(256, 3) k_accum(const uint32_t* __restrict__ b
 // address.  Instead the units are summed directly: thread t adds the bases of the unit scalars among t, t+G, t+2G, ...
 // (coalesced scalar reads; which subset a thread takes is irrelevant, everything is summed), then a two-level LDS tree.
 constexpr uint32_t ONES_THREADS = 16384;   // partial sums of level 0
+template <class S>
+__device__ __forceinline__ bool scalar_is_one(const uint32_t* __restrict__ scalars, size_t i, int mont) {
+  const uint4* p = reinterpret_cast<const uint4*>(scalars + 8 * i);
+  const uint4 a = p[0], b = p[1];
+  if (mont) return a.x == S::Params::R1.w[0] && a.y == S::Params::R1.w[1] && a.z == S::Params::R1.w[2] && a.w == S::Params::R1.w[3] &&
+                   b.x == S::Params::R1.w[4] && b.y == S::Params::R1.w[5] && b.z == S::Params::R1.w[6] && b.w == S::Params::R1.w[7];
+  return a.x == 1u && (a.y | a.z | a.w | b.x | b.y | b.z | b.w) == 0u;
+}
 template <class S, class F>
 __global__ void __launch_bounds__(256) k_ones_partial(const uint32_t* __restrict__ scalars, const uint32_t* __restrict__ bases, size_t n, int mont,
                                                       uint32_t* __restrict__ out /* ONES_THREADS XYZZ */) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   XYZZ<F> acc = XYZZ<F>::identity();
-  for (size_t i = t; i < n; i += ONES_THREADS) {
-    const uint4* p = reinterpret_cast<const uint4*>(scalars + 8 * i);
-    const uint4 a = p[0], b = p[1];
-    bool one;
-    if (mont) one = a.x == S::Params::R1.w[0] && a.y == S::Params::R1.w[1] && a.z == S::Params::R1.w[2] && a.w == S::Params::R1.w[3] &&
-                    b.x == S::Params::R1.w[4] && b.y == S::Params::R1.w[5] && b.z == S::Params::R1.w[6] && b.w == S::Params::R1.w[7];
-    else one = a.x == 1u && (a.y | a.z | a.w | b.x | b.y | b.z | b.w) == 0u;
-    if (one) { Affine<F> q = load_affine<F>(bases, (uint32_t)i); add_mixed(acc, q); }
+  for (size_t i = t; i < n; i += ONES_THREADS)
+    if (scalar_is_one<S>(scalars, i, mont)) { Affine<F> q = load_affine<F>(bases, (uint32_t)i); add_mixed(acc, q); }
+  store_xyzz(out, t, acc);
+}
+// The same sums with the unit scalars COMPACTED first (round 4): in the loop above a wave runs an addition whenever one of its 64 lanes
+// holds a unit — at 40 % units that is every iteration, 19 additions per lane for 7.5 useful ones.  Here a wave walks 64 consecutive scalars
+// at a time, queues the indices of the units in LDS (ballot + prefix count) and adds 64 queued bases at a time, one per lane; which lane
+// adds which base is irrelevant, everything is summed.  The queue is the wave's own: LDS operations of one wave execute in order.
+template <class S, class F>
+__global__ void __launch_bounds__(256) k_ones_dense(const uint32_t* __restrict__ scalars, const uint32_t* __restrict__ bases, size_t n, int mont,
+                                                    uint32_t* __restrict__ out /* ONES_THREADS XYZZ */) {
+  __shared__ uint32_t queue[4][128];
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+  const size_t wave = t >> 6, nwaves = ONES_THREADS / 64;
+  volatile uint32_t* q = queue[wv];
+  XYZZ<F> acc = XYZZ<F>::identity();
+  uint32_t cnt = 0;                                     // (wave-uniform)
+  for (size_t base = wave * 64; base < n; base += nwaves * 64) {
+    const size_t i = base + lane;
+    const bool one = i < n && scalar_is_one<S>(scalars, i, mont);
+    const uint64_t m = __ballot(one);
+    if (one) q[cnt + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)i;
+    cnt += (uint32_t)__popcll(m);
+    __builtin_amdgcn_wave_barrier();
+    if (cnt >= 64) {
+      cnt -= 64;
+      const uint32_t idx = q[cnt + lane];
+      __builtin_amdgcn_wave_barrier();
+      Affine<F> pt = load_affine<F>(bases, idx);
+      add_mixed(acc, pt);
+    }
   }
+  if (lane < cnt) { Affine<F> pt = load_affine<F>(bases, q[lane]); add_mixed(acc, pt); }
   store_xyzz(out, t, acc);
 }
 // in: m points, out: ceil(m/256) points (one LDS tree per workgroup)
@@ -932,6 +965,8 @@ hipError_t msm_launch(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_ba
   //  chain of a dozen additions each on a quarter of the GPU; pieces of 8 give twice the threads half the chain: 1 045-1 061 -> 1 088-1 097 steps/s at
   //  contrast HD, one chain 808 -> 823; at 4K the buckets are three times as full and the long pieces stay (558 against 542).  VIMZ_TUNE=witness_sub=N pins it.)
   const int wsub = msm_tuning().witness_sub;
+  // (longer pieces for the dense MSM(T) — 24 / 32 entries, half the partials for k_combine — measured within the noise at 256 rows and
+  //  worse in the 20-row window and on one chain: 842 against 876, 786 against 812)
   const uint32_t sub = n < (1u << 15) ? 8u : split_ones ? (uint32_t)(wsub > 0 ? wsub : n < (1u << 19) ? 8 : MSM_SUB) : (uint32_t)MSM_SUB;   // MSM_SUB for everything large
   const size_t max_subs = entries / sub + pl.nb + 1;
   VZ_HIP_CHECK(ws.reserve(pl.nb, entries, max_subs));
@@ -1020,7 +1055,8 @@ hipError_t msm_launch(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_ba
 #undef VZ_EV
   if (split_ones) {   // sum of the bases with unit scalar -> window_sums[K]
     uint32_t* lvl0 = reinterpret_cast<uint32_t*>(ws.ones_partial);
-    hipLaunchKernelGGL((k_ones_partial<S, F>), dim3(ONES_THREADS / 256), dim3(256), 0, stream, d_scalars, d_bases, n, scalars_mont, lvl0);
+    if (msm_tuning().ones_dense) hipLaunchKernelGGL((k_ones_dense<S, F>), dim3(ONES_THREADS / 256), dim3(256), 0, stream, d_scalars, d_bases, n, scalars_mont, lvl0);
+    else hipLaunchKernelGGL((k_ones_partial<S, F>), dim3(ONES_THREADS / 256), dim3(256), 0, stream, d_scalars, d_bases, n, scalars_mont, lvl0);
     uint32_t* lvl1 = lvl0 + (size_t)XYZZ_WORDS * ONES_THREADS;
     hipLaunchKernelGGL(k_tree256<F>, dim3(ONES_THREADS / 256), dim3(256), 0, stream, lvl0, ONES_THREADS, lvl1);
     hipLaunchKernelGGL(k_tree256<F>, dim3(1), dim3(256), 0, stream, lvl1, ONES_THREADS / 256, wsum + (size_t)XYZZ_WORDS * kout);
