@@ -515,9 +515,14 @@ static unsigned usable_cpus() {
 // 24: the first GPU-produced batch needs one Poseidon-chain latency on the low-priority producer stream — 10 ms alone, 16-18 ms
 // next to the first folds — and 8 head rows were folded after 14 ms (driver window of 20 rows: 530 steps/s with 8, 580-594 with 20-24,
 // 513-596 with 32-48; 256-row window 609 -> 628).
-static size_t head_rows_wanted() {
-  static const long v = getenv("VIMZ_HEAD_ROWS") ? atol(getenv("VIMZ_HEAD_ROWS")) : 24;
-  return v < 0 ? 0 : (size_t)v;
+// With few host cores (a rank's share below six) the head's Poseidon work — 1.8 ms per row and core — competes with the folds for the cores:
+// a call that is longer than the head keeps 8 head rows (two cores, 256 rows, two segments: 858 -> 935 steps/s), a call that fits
+// in the head stays there whole (two cores, 20 rows: 440 steps/s against 300-400 with 2-8 head rows and the rest waiting for the GPU's chains).
+static size_t head_rows_wanted(size_t nsteps = 0) {
+  static const long env = getenv("VIMZ_HEAD_ROWS") ? atol(getenv("VIMZ_HEAD_ROWS")) : -1;
+  if (env >= 0) return (size_t)env;
+  static const bool few_cores = usable_cpus() < 6;
+  return few_cores && nsteps > 24 ? 8 : 24;
 }
 
 // The IVC's lookahead schedule (ivc.hip) is an option: VIMZ_IVC_LOOKAHEAD=1 (read once).  It takes the large MSM off a
@@ -690,7 +695,7 @@ static int fold_prepare(vimz_prover* p, FoldJob& J, bool start_batch0 = false) {
   P_TRY(hipMemsetAsync(p->job_all_d, 0, 32 * nsteps * jstride, s));
   { static const bool dbg_t = getenv("VIMZ_DEBUG_TIMING") != nullptr; if (dbg_t) fprintf(stderr, "[timing] prepare: buffers + upload of the inputs %.2f ms\n", 1e3 * (now_s() - t0)); }
   const bool plain = J.nA && !J.nE && !J.early_fops;           // no ahead-of-time witness pass needed (everything but crop)
-  const size_t head = start_batch0 && plain && p->head_eligible ? std::min(std::min(head_rows_wanted(), B), nsteps) : 0;
+  const size_t head = start_batch0 && plain && p->head_eligible ? std::min(std::min(head_rows_wanted(nsteps), B), nsteps) : 0;
   if (head) {
     J.head = true;
     plan_batches(J, 0, head, B);
