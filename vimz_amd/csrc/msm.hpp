@@ -1010,7 +1010,9 @@ hipError_t msm_launch(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_ba
   // lanes per ordinary bucket in k_combine, from the mean number of partials per bucket (upper bound: every digit non-zero): two
   // lanes up to ~24 partials (measured at 312 k dense points, 19 per bucket: 16 lanes 0.28 ms, 8: 0.155, 4: 0.137, 2: 0.117;
   // one lane and a heavy list of every bucket: 3.5 ms); buckets above 16 partials per lane go to the heavy list
-  const size_t mean_parts = entries / sub / pl.nb + 1;
+  // (a witness — split_ones — has far fewer entries than its upper bound: an eighth is assumed, which gives its buckets two lanes where
+  //  the bound gave four: k_combine 31.4 -> 29.1 M instructions per step)
+  const size_t mean_parts = (split_ones ? entries / 8 : entries) / sub / pl.nb + 1;
   const int lane_bits_env = msm_tuning().combine_lane_bits;
   const uint32_t lane_bits = lane_bits_env >= 0 ? (uint32_t)lane_bits_env : mean_parts > 96 ? 4u : mean_parts > 48 ? 3u : mean_parts > 24 ? 2u : 1u;
   const uint32_t heavy_min = 16u << lane_bits;
