@@ -267,6 +267,7 @@ def main_ivc(args, rank, world, dist, torch, ctxs, circuit, params, steps_all, g
     sync_all()
     if world == 1:
         ctxs[0].trace_marker(1)      # (an empty kernel in a profiler's trace: tools/trace_busy.py cuts the timed region out between markers 1 and 2)
+    cpu0 = time.process_time()      # (user + system time of every thread of this process: what the timed job costs the host)
     t0 = time.time()
     # the timed job: ONE proof of world x K rows from z0 (proof sets: every rank its own proof of K rows).  Rank r's rows start at the
     # state after the r·K rows of the ranks before it: rank 0 runs that hash-only chain once and hands every rank its start state;
@@ -279,6 +280,7 @@ def main_ivc(args, rank, world, dist, torch, ctxs, circuit, params, steps_all, g
         tm["t_ready"] = tm["t_done"] = time.time()
     sync_all()
     dt = time.time() - t0
+    host_cpu_s = time.process_time() - cpu0
     if world == 1:
         ctxs[0].trace_marker(2)
     mem = memory_now(torch, ctxs[0].device)
@@ -474,6 +476,8 @@ def main_ivc(args, rank, world, dist, torch, ctxs, circuit, params, steps_all, g
             "host_cores_per_rank": usable_cores(),
             "fold_s": t_fold,
             "peak_device_bytes": mem["device_bytes"], "peak_host_rss_bytes": mem["host_rss_bytes"], "memory_note": mem["note"],
+            "host_cpu": {"core_seconds_rank0": host_cpu_s, "cores_busy_rank0": host_cpu_s / dt, "core_ms_per_step_rank0": 1e3 * host_cpu_s / max(1, K),
+                         "note": "process CPU time (all threads: folding threads, helpers, issuers, pools, HIP runtime) of rank 0 inside the timed region"},
             "merge_profile_s": merge_prof,
             "one_chain": one_chain,
             "sonobe_backend": sonobe,

@@ -171,9 +171,14 @@ def test_msm_split_ones_path(ctx, oracle):
     from vimz_amd import _lib
     r = MODULI[0]
     rng = random.Random(17)
-    for n, mk in ((1, lambda: 1), (64, lambda: 1), (40000, lambda: rng.choice([0, 1, 1, 1, rng.randrange(256), rng.randrange(r)])), (3000, lambda: 0)):
-        sc = [mk() for _ in range(n)]
+    # (the units are compacted through a per-wave LDS queue, 64 at a time — k_ones_dense: sizes that are no multiple of 64, queues that
+    #  never fill, a lone unit in the last partial block, a lane that meets the same base twice)
+    for n, mk in ((1, lambda: 1), (64, lambda: 1), (40000, lambda: rng.choice([0, 1, 1, 1, rng.randrange(256), rng.randrange(r)])), (3000, lambda: 0),
+                  (4133, lambda: 1), (70001, lambda: 1 if rng.random() < 0.4 else rng.randrange(1 << 16)), (129, None), (128, lambda: 1)):
+        sc = [mk() for _ in range(n)] if mk else [0] * 128 + [1]
         bases = oracle.seq_bases(0, n)
+        if n == 128:
+            bases[:] = to_limbs(GENERATORS[0]).reshape(1, 8)         # every base the same: a lane adds P to P
         if n == 64:
             bases[::2] = to_limbs(GENERATORS[0]).reshape(1, 8)       # repeated bases: doubling inside the ones tree
             bases[1::2] = to_limbs(oracle.curve_mul(0, GENERATORS[0], r - 1)).reshape(1, 8)   # and cancellation

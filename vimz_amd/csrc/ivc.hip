@@ -27,9 +27,9 @@ int finish_secondary(vimz_ivc* v) {
   if (!v->pending_sec) return VIMZ_OK;
   vimz_ctx* ctx = v->ctx;
   double t0 = now_s();
-  P_TRY(hipStreamSynchronize(v->s2));
+  P_TRY(vz_wait_stream(v->s2));
   v->u2.W = msm_finish<Grumpkin>(v->plan_W2, v->pin + 2 * v->pin_res);      // overlaps the rest of MSM(T2)
-  P_TRY(hipStreamSynchronize(ctx->stream));
+  P_TRY(vz_wait_stream(ctx->stream));
   v->ph_s[IP_WAIT_SEC] += now_s() - t0; v->ph_n[IP_WAIT_SEC]++;
   if (ctx->profiling) { float ms = 0; if (hipEventElapsedTime(&ms, v->ev_b0, v->ev_b1) == hipSuccess) { v->ph_s[IP_RESERVED] += ms * 1e-3; v->ph_n[IP_RESERVED]++; } }
   if (v->sec_T_valid) v->T2 = msm_finish<Grumpkin>(v->plan_T2, v->pin + 3 * v->pin_res);
@@ -201,7 +201,7 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
     double t0 = now_s();
     allowed.store(k + 2, std::memory_order_release);       // the next batch is produced while this one is folded
     if ((rc = wait_issued(k))) return rc;                  // (batch 0 of a head-batch call is already out)
-    P_TRY(hipEventSynchronize(bb.wit_done));
+    P_TRY(vz_wait_event(bb.wit_done));
     v->ph_s[IP_PRODUCER] += now_s() - t0;
     if (k == 0) { t_wait0 = now_s() - t0; t_first = now_s() - t_all; }
     for (size_t r = 0; r < rows; r++) if (bb.status_host[r]) {
@@ -307,11 +307,11 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
       }
       t_wp[1] += now_s() - tw; tw = now_s();
       P_TRY(take_T1_step(false));
-      P_TRY(hipStreamSynchronize(v->s2));
+      P_TRY(vz_wait_stream(v->s2));
       t_wp[2] += now_s() - tw; tw = now_s();
       G1Aff cW_aug = msm_finish<BnG1>(v->plan_aug, v->pin);      // the small MSM is back first: its tail overlaps the other one
       P_TRY(take_T1_step(false));
-      P_TRY(hipEventSynchronize(v->ev_a));
+      P_TRY(vz_wait_event(v->ev_a));
       t_wp[3] += now_s() - tw;
       v->ph_s[IP_WAIT_PRI] += now_s() - t0; v->ph_n[IP_WAIT_PRI]++;
       t0 = now_s();
@@ -449,9 +449,9 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
       v->i++; p->steps++;
     }
     // this buffer is rewritten by batch k+2: the folds that read it must have finished
-    P_TRY(hipStreamSynchronize(s));
-    P_TRY(hipStreamSynchronize(v->s2));
-    P_TRY(hipEventSynchronize(v->ev_fold));
+    P_TRY(vz_wait_stream(s));
+    P_TRY(vz_wait_stream(v->s2));
+    P_TRY(vz_wait_event(v->ev_fold));
     // (the fused fold of the last row sits on stream 3 behind up to two large MSMs: the producers wait for it, not the host)
     if (v->fused_recorded) { P_TRY(hipStreamWaitEvent(p->sB, v->ev_fused, 0)); P_TRY(hipStreamWaitEvent(p->sH, v->ev_fused, 0)); }
   }

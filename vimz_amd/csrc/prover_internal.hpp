@@ -511,6 +511,18 @@ static unsigned usable_cpus() {
   return v;
 }
 
+// Waits of the folding thread.  With few host cores (a rank's share below six) the runtime's own waits hold a core while the threads that
+// have work — the other segment, issuers, helpers — queue for it: there the stream / event is polled with a yield between polls.
+static inline bool vz_few_cores() { static const bool few = getenv("VIMZ_DEBUG_POLL_WAITS") ? atoi(getenv("VIMZ_DEBUG_POLL_WAITS")) != 0 : usable_cpus() < 6; return few; }
+static inline hipError_t vz_wait_stream(hipStream_t s) {
+  if (!vz_few_cores()) return hipStreamSynchronize(s);
+  for (;;) { const hipError_t q = hipStreamQuery(s); if (q != hipErrorNotReady) return q; std::this_thread::yield(); }
+}
+static inline hipError_t vz_wait_event(hipEvent_t e) {
+  if (!vz_few_cores()) return hipEventSynchronize(e);
+  for (;;) { const hipError_t q = hipEventQuery(e); if (q != hipErrorNotReady) return q; std::this_thread::yield(); }
+}
+
 // Rows of a call whose Poseidon jobs are evaluated on the host (VIMZ_HEAD_ROWS overrides; 0 switches the head batch off).
 // 24: the first GPU-produced batch needs one Poseidon-chain latency on the low-priority producer stream — 10 ms alone, 16-18 ms
 // next to the first folds — and 8 head rows were folded after 14 ms (driver window of 20 rows: 530 steps/s with 8, 580-594 with 20-24,
