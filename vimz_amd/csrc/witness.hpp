@@ -325,7 +325,7 @@ static __global__ void __launch_bounds__(64) k_wit_chains(WitnessDev P, uint32_t
       else s = wit_value(P, ref, Zrow, jrow, prow);
     }
     // the four chains of a wave may mix widths: run both variants under wave-uniform votes so shuffles stay convergent
-    const bool any9 = __any(live && t == 9), any3 = __any(!(live && t == 9));
+    const bool any9 = __any(live && t == 9), any3 = __any(live && t != 9);      // (idle 16-lane groups and finished chains run neither: a wave of row-hash chains used to run the narrow variant beside the wide one)
     Fr out = Fr::zero();
     if (any9) { Fr o = poseidon_group<9>(P, J, live && t == 9, s, in_const, li, lane_base, Zrow); if (t == 9) out = o; }
     if (any3) { Fr o = poseidon_group<3>(P, J, live && t == 3, s, in_const, li, lane_base, Zrow); if (t != 9) out = o; }
