@@ -251,8 +251,8 @@ __device__ __forceinline__ Fr poseidon_group(const WitnessDev& P, const HashJob&
   };
   for (uint32_t r = 0; r < 4; r++) full_round(r);
   // Partial rounds in sparse form: only lane 0 goes through the S-box, and its value is the one the dense form has; the other
-  // lanes live in a changed basis (undone by PF below).  Four multiplication slots per round instead of twelve:
-  //   [x2 on lane 0 | row_i·s_i on the others]  [x4]  [x5]  [row_0·x5 on lane 0 | col_i·x5 on the others],
+  // lanes live in a changed basis (undone by PF below).  Three dependent multiplication slots per round instead of twelve:
+  //   [x2 on lane 0 | row_i·s_i on the others, and beside them row_0·s | col_i·s_0]  [x4]  [x4·(row_0·s) on lane 0 | x4·(col_i·s_0) on the others],
   // then the lanes' row products are added by a shuffle butterfly.
   const bool l0 = li == 0;
   Fr ct = Fr::zero(), rw = Fr::zero(), cl = Fr::zero();
@@ -261,11 +261,15 @@ __device__ __forceinline__ Fr poseidon_group(const WitnessDev& P, const HashJob&
     Fr ctn = Fr::zero(), rwn = Fr::zero(), cln = Fr::zero();       // next round's constants: in flight during this round
     if (mine && r + 1 < rp) { const size_t q = 3 * ((size_t)(r + 1) * T + li); ctn = load_fe<Fr>(PS, q); rwn = load_fe<Fr>(PS, q + 1); cln = load_fe<Fr>(PS, q + 2); }
     s = Fr::add(s, ct);
+    // Three dependent multiplications per round instead of four: x5 = x4·s is needed only multiplied by a constant, and s·(that constant)
+    // does not wait for the S-box — lane 0: x2 | row_0·s, then x4, then x4·(row_0·s); lane i: row_i·s_i | col_i·s_0, then x4·(col_i·s_0).
+    const Fr sl0 = shfl_fe(s, lane_base);                          // lane 0's state, before its S-box
     const Fr m1 = Fr::mul(l0 ? s : rw, s);                         // lane 0: x2; lane i: row_i·s_i
-    Fr x4 = Fr::zero(), x5 = Fr::zero();
-    if (l0) { x4 = Fr::sqr(m1); x5 = Fr::mul(x4, s); if (live && Zrow) emit(nf0 + 3 * T + r, m1, x4, x5); }
-    const Fr s0 = shfl_fe(x5, lane_base);
-    const Fr m2 = Fr::mul(l0 ? rw : cl, s0);                       // lane 0: row_0·x5; lane i: col_i·x5
+    const Fr u = Fr::mul(l0 ? rw : cl, sl0);                       // lane 0: row_0·s; lane i: col_i·s_0
+    Fr x4 = Fr::zero();
+    if (l0) { x4 = Fr::sqr(m1); if (live && Zrow) emit(nf0 + 3 * T + r, m1, x4, Fr::mul(x4, s)); }
+    const Fr x4b = shfl_fe(x4, lane_base);
+    const Fr m2 = Fr::mul(x4b, u);                                 // lane 0: row_0·x5; lane i: col_i·x5
     Fr p = l0 ? m2 : (mine ? m1 : Fr::zero());
 #pragma unroll
     for (int off = 8; off >= 1; off >>= 1) {
