@@ -115,7 +115,20 @@ int vz_prover_create_layout(vimz_ctx* ctx, const vimz_circuit* circuit, const vi
         }
       UP(packed, d); (t == 3 ? W.ps3 : W.ps9) = (const uint32_t*)d;
       UP(S.Pfin, d); (t == 3 ? W.pf3 : W.pf9) = (const uint32_t*)d;
+      // the same four tables in the reduced-radix form the chain kernel computes in (witness.hpp: poseidon_group29)
+      auto to29 = [](const std::vector<Fe>& v) {
+        std::vector<uint32_t> o(v.size() * (size_t)F29_STRIDE, 0u);
+        for (size_t i = 0; i < v.size(); i++) { const F29 x = F29::from_std(v[i]); for (int k = 0; k < 9; k++) o[i * F29_STRIDE + k] = x.v[k]; }
+        return o;
+      };
+      const uint32_t* w;
+      const std::vector<uint32_t> c29 = to29(t == 3 ? t3.C : t9.C), m29 = to29(t == 3 ? t3.M : t9.M), s29 = to29(packed), f29 = to29(S.Pfin);
+      UP(c29, w); (t == 3 ? W.pc3_29 : W.pc9_29) = w;
+      UP(m29, w); (t == 3 ? W.pm3_29 : W.pm9_29) = w;
+      UP(s29, w); (t == 3 ? W.ps3_29 : W.ps9_29) = w;
+      UP(f29, w); (t == 3 ? W.pf3_29 : W.pf9_29) = w;
     }
+    W.poseidon29 = getenv("VIMZ_DEBUG_POSEIDON_STD") ? 0u : 1u;
   }
 #undef UP
   auto dalloc = [&](uint32_t** dst, size_t bytes) { e = hipMalloc((void**)dst, bytes ? bytes : 32); if (e == hipSuccess) { p->owned.push_back(*dst); e = hipMemset(*dst, 0, bytes ? bytes : 32); } return e; };   // (null-stream fills: synchronised below)

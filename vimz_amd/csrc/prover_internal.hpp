@@ -412,6 +412,10 @@ static int launch_witness(vimz_prover* p, hipStream_t st, uint32_t* Z, uint32_t*
   const cb::Builder& b = p->circuit->build->b;
   const WitnessDev& W = p->wd;
   const unsigned R = (unsigned)rows;
+  // (the chains compute in the reduced-radix form and leave their S-box wires in it: converted right behind each chain launch)
+  auto chain_wires_std = [&](uint32_t phase) {
+    if (W.poseidon29 && p->n_jobs) hipLaunchKernelGGL(k_wit_chain_wires_std, dim3(p->n_jobs, R), dim3(128), 0, st, W, p->job_stage_off_d, phase, Z);
+  };
   if (part != 2)
     for (uint32_t gI = 0; gI < W.n_decomp; gI++) {
       const uint32_t total = (b.decomp[gI].nbits - 1) * b.decomp[gI].count;
@@ -420,19 +424,20 @@ static int launch_witness(vimz_prover* p, hipStream_t st, uint32_t* Z, uint32_t*
   hipLaunchKernelGGL(k_wit_inputs, dim3(((1 + 2 * p->len_z + p->n_priv) + 255) / 256, R), dim3(256), 0, st, W, priv, (const uint32_t*)p->zs_all_d, Z, (uint32_t)first);
   if (part == 1) {
     hipLaunchKernelGGL(k_wit_chains, dim3((J.nA + 3) / 4, R), dim3(64), 0, st, W, 0u, Z, job_out, (const uint32_t*)nullptr);
+    chain_wires_std(0u);
     P_TRY(hipGetLastError());
     return VIMZ_OK;
   }
   for (uint32_t gI = 0; gI < W.n_groups; gI++)
     hipLaunchKernelGGL(k_wit_lanes, dim3((b.lane_groups[gI].lanes + LANE_TB - 1) / LANE_TB, R), dim3(LANE_TB), 0, st, W, gI, priv, (const uint32_t*)p->zs_all_d, (uint32_t)first, Z, status);
-  if (J.nA && !ahead && part != 2) hipLaunchKernelGGL(k_wit_chains, dim3((J.nA + 3) / 4, R), dim3(64), 0, st, W, 0u, Z, job_out, (const uint32_t*)nullptr);
+  if (J.nA && !ahead && part != 2) { hipLaunchKernelGGL(k_wit_chains, dim3((J.nA + 3) / 4, R), dim3(64), 0, st, W, 0u, Z, job_out, (const uint32_t*)nullptr); chain_wires_std(0u); }
   if (J.early_fops) {
     hipLaunchKernelGGL(k_wit_fops_lc, dim3(p->n_fops, R), dim3(64), 0, st, W, (const uint32_t*)Z, job_out, 1u);
     hipLaunchKernelGGL(k_wit_fops, dim3((R + 63) / 64), dim3(64), 0, st, W, Z, job_out, (uint32_t)rows, 1u);
   }
-  if (J.nE) hipLaunchKernelGGL(k_wit_chains, dim3((J.nE + 3) / 4, R), dim3(64), 0, st, W, 2u, Z, job_out, (const uint32_t*)nullptr);
+  if (J.nE) { hipLaunchKernelGGL(k_wit_chains, dim3((J.nE + 3) / 4, R), dim3(64), 0, st, W, 2u, Z, job_out, (const uint32_t*)nullptr); chain_wires_std(2u); }
   if (!ahead) {
-    if (J.nB) hipLaunchKernelGGL(k_wit_chains, dim3((J.nB + 3) / 4, R), dim3(64), 0, st, W, 1u, Z, job_out, (const uint32_t*)nullptr);
+    if (J.nB) { hipLaunchKernelGGL(k_wit_chains, dim3((J.nB + 3) / 4, R), dim3(64), 0, st, W, 1u, Z, job_out, (const uint32_t*)nullptr); chain_wires_std(1u); }
     if (p->n_fops) hipLaunchKernelGGL(k_wit_fops, dim3((R + 63) / 64), dim3(64), 0, st, W, Z, job_out, (uint32_t)rows, 0u);
   }
   P_TRY(hipGetLastError());
@@ -524,17 +529,20 @@ static inline hipError_t vz_wait_event(hipEvent_t e) {
 }
 
 // Rows of a call whose Poseidon jobs are evaluated on the host (VIMZ_HEAD_ROWS overrides; 0 switches the head batch off).
-// 24: the first GPU-produced batch needs one Poseidon-chain latency on the low-priority producer stream — 10 ms alone, 16-18 ms
-// next to the first folds — and 8 head rows were folded after 14 ms (driver window of 20 rows: 530 steps/s with 8, 580-594 with 20-24,
-// 513-596 with 32-48; 256-row window 609 -> 628).
-// With few host cores (a rank's share below six) the head's Poseidon work — 1.8 ms per row and core — competes with the folds for the cores:
-// a call that is longer than the head keeps 8 head rows (two cores, 256 rows, two segments: 858 -> 935 steps/s), a call that fits
-// in the head stays there whole (two cores, 20 rows: 440 steps/s against 300-400 with 2-8 head rows and the rest waiting for the GPU's chains).
+// Round 2 chose 24: the first GPU-produced batch then needed one Poseidon-chain latency on the low-priority producer stream — 10 ms alone,
+// 16-18 ms next to the first folds.  Since round 4 the chains run in the reduced-radix arithmetic (witness.hpp: poseidon_group29) and a
+// GPU-produced first batch is ready after 6 ms; the head's Poseidon work — 1.8 ms per row and core — now only pays where the whole call
+// fits in it on a machine with cores to spare:
+//   a rank's share of the cores below six: no head (two cores, 20 rows: 667-707 steps/s against 441-445 with all rows in the head; 256 rows: 950-1 007 / 925);
+//   otherwise calls of at most 48 rows: 24 head rows (20-row window, 16 cores: 837-899 against 646-664 without); longer calls: none
+//   (256 rows: 1 174-1 176 against 1 087-1 100).  A head shorter than the call AND short (2-8 rows of 10) is the one thing to avoid: the rest
+//   then waits for two chain latencies, the hash-only pass and the batch's own (210-450 steps/s).
 static size_t head_rows_wanted(size_t nsteps = 0) {
   static const long env = getenv("VIMZ_HEAD_ROWS") ? atol(getenv("VIMZ_HEAD_ROWS")) : -1;
   if (env >= 0) return (size_t)env;
   static const bool few_cores = usable_cpus() < 6;
-  return few_cores && nsteps > 24 ? 8 : 24;
+  if (few_cores) return 0;
+  return nsteps == 0 || nsteps <= 48 ? 24 : 0;
 }
 
 // The IVC's lookahead schedule (ivc.hip) is an option: VIMZ_IVC_LOOKAHEAD=1 (read once).  It takes the large MSM off a

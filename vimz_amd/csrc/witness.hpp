@@ -15,6 +15,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "fp.hpp"
+#include "fp29.hpp"
 #include "circuit/program.hpp"
 #include "vecops.hpp"
 
@@ -38,6 +39,10 @@ struct WitnessDev {  // device copies of the program tables
   const uint32_t* ps3; const uint32_t* pf3;
   const uint32_t* ps9; const uint32_t* pf9;
   uint32_t rp3, rp9;
+  // the same tables in the reduced-radix form of fp29.hpp (9 limbs of 29 bits, R' = 2^261; 12 words per element): the chains' permutations
+  // run in it (poseidon_group29) unless VIMZ_DEBUG_POSEIDON_STD is set
+  const uint32_t *pc3_29, *pm3_29, *ps3_29, *pf3_29, *pc9_29, *pm9_29, *ps9_29, *pf9_29;
+  uint32_t poseidon29;
   uint32_t n_wires, len_z, n_priv;
 };
 
@@ -294,6 +299,132 @@ __device__ __forceinline__ Fr poseidon_group(const WitnessDev& P, const HashJob&
   return s;
 }
 
+// ---- the same permutation in the reduced-radix arithmetic of the curve code (fp29.hpp) ----------------------------------------------
+// A chain is ONE dependent sequence of multiplications — 17 permutations of 65 rounds for a row hash — on one wave per SIMD, so what
+// counts is the latency of a multiplication, not its instruction count.  The saturated CIOS of fp.hpp is one carry chain of 128
+// dependent multiply-adds (measured here: 7.2 µs per partial round, 8.0 ms for a row-hash chain); the 29-bit-limb product accumulates
+// its 17 columns independently and reduces lazily.  Values stay below 2 p between rounds (weak_reduce29), products take operands whose
+// bounds multiply to at most 64 (fp29.hpp), sums of at most nine products stay below 14 p.
+typedef Fp29<BnFr> F29;
+constexpr int F29_STRIDE = 12;      // words per table element (three 16-byte loads)
+__device__ __forceinline__ F29 load29(const uint32_t* __restrict__ base, size_t idx) {
+  const uint4* q = reinterpret_cast<const uint4*>(base + (size_t)F29_STRIDE * idx);
+  const uint4 a = q[0], b = q[1], c = q[2];
+  F29 r; r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w; r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w; r.v[8] = c.x;
+  return r;
+}
+__device__ __forceinline__ F29 shfl29(const F29& v, int src_lane) {
+  F29 r;
+#pragma unroll
+  for (int k = 0; k < 9; k++) r.v[k] = __shfl(v.v[k], src_lane);
+  return r;
+}
+// a (normalised limbs, below 2^261 — any sum of a few dozen residues) -> the same residue below 2 p: k = floor(floor(a / 2^253)·169/256) never
+// exceeds a / p (2^253 / p = 0.66127 > 169/256) and leaves less than 1.89 p (1.65 p for a < 14 p); one multiply-subtract chain, no comparison.
+VZ_HD inline F29 weak_reduce29(const F29& a) {
+  static_assert(BnFr::MOD.w[7] == 0x30644e72u, "the quotient estimate is BN254 Fr's");
+  const uint32_t k = ((a.v[8] >> 21) * 169u) >> 8;
+  F29 r; int64_t c = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) { c += (int64_t)a.v[i] - (int64_t)((uint64_t)k * F29::MOD29.l[i]); r.v[i] = (uint32_t)c & F29::MASK; c >>= 29; }
+  return r;
+}
+// a wire of the S-boxes as it leaves the chain kernel: the 256-bit integer x·2^261 mod p (+ p at most once); k_wit_chain_wires_std turns
+// the job's wires into the standard form afterwards, all of them side by side (a conversion per wire inside the chain would sit in its way)
+__device__ __forceinline__ void store29_raw(uint32_t* __restrict__ Zrow, uint32_t wire, const F29& x) {
+  uint32_t w[8]; x.unpack(w);
+  uint4* q = reinterpret_cast<uint4*>(Zrow + 8 * (size_t)wire);
+  q[0] = make_uint4(w[0], w[1], w[2], w[3]); q[1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+
+template <int T>
+__device__ __forceinline__ F29 poseidon_group29(const WitnessDev& P, const HashJob& J, bool live, F29 s, bool in_const, uint32_t li, int lane_base,
+                                                uint32_t* __restrict__ Zrow) {   // as poseidon_group; s below 2 p in, below 2 p out
+  const uint32_t* PC = T == 3 ? P.pc3_29 : P.pc9_29;
+  const uint32_t* PM = T == 3 ? P.pm3_29 : P.pm9_29;
+  const uint32_t* PS = T == 3 ? P.ps3_29 : P.ps9_29;
+  const uint32_t* PF = T == 3 ? P.pf3_29 : P.pf9_29;
+  const uint32_t rp = T == 3 ? P.rp3 : P.rp9;
+  const uint32_t R = 8 + rp;
+  const bool mine = li < (uint32_t)T;
+  F29 Mrow[T];
+#pragma unroll
+  for (int j = 0; j < T; j++) Mrow[j] = mine ? load29(PM, (size_t)li * T + j) : F29::zero();
+  const unsigned long long nf_mask = __ballot(live && li >= 1 && mine && !in_const);
+  const uint32_t grp_mask16 = (uint32_t)((nf_mask >> lane_base) & 0xffffull);
+  const uint32_t nf_before = __popc(grp_mask16 & ((1u << li) - 1u));
+  const uint32_t nf0 = __popc(grp_mask16);
+  const uint32_t elim_slot = 3 * (nf0 + 3 * T + rp + 3 * T) + 2;
+  const bool bound = J.out_wire != 0;
+  auto emit = [&](uint32_t index, const F29& x2, const F29& x4, const F29& x5) {      // (each below 1.5 p < 2^256)
+    const uint32_t slot = 3 * index;
+    auto wire_of = [&](uint32_t sl) { return J.wire_base + sl - ((bound && sl > elim_slot) ? 1u : 0u); };
+    store29_raw(Zrow, wire_of(slot), x2);
+    store29_raw(Zrow, wire_of(slot + 1), x4);
+    if (!(bound && slot + 2 == elim_slot)) store29_raw(Zrow, wire_of(slot + 2), x5);
+  };
+  auto full_round = [&](uint32_t r) {
+    if (mine) {
+      s = F29::add(s, load29(PC, (size_t)r * T + li));                         // < 3
+      const F29 x2 = F29::sqr(s), x4 = F29::sqr(x2), x5 = F29::mul(x4, s);     // 9, 2.25, 4.5 -> each < 1.5
+      const bool folded = r == 0 && in_const;
+      if (live && !folded && Zrow) {
+        uint32_t index;
+        if (r == 0) index = nf_before;
+        else if (r < 4) index = nf0 + (r - 1) * T + li;
+        else index = nf0 + 3 * T + rp + (r - 4 - rp) * T + li;
+        emit(index, x2, x4, x5);
+      }
+      s = x5;
+    }
+    F29 prod[T];
+#pragma unroll
+    for (int j = 0; j < T; j++) prod[j] = F29::mul(Mrow[j], shfl29(s, lane_base + j));      // 1 · 1.5
+#pragma unroll
+    for (int stride = 1; stride < T; stride <<= 1)
+#pragma unroll
+      for (int j = 0; j + stride < T; j += 2 * stride) prod[j] = F29::add(prod[j], prod[j + stride]);
+    s = weak_reduce29(prod[0]);                                                // T · 1.5 <= 13.5 -> < 1.65
+  };
+  for (uint32_t r = 0; r < 4; r++) full_round(r);
+  const bool l0 = li == 0;
+  F29 ct = F29::zero(), rw = F29::zero(), cl = F29::zero();
+  if (mine) { const size_t q = 3 * (size_t)li; ct = load29(PS, q); rw = load29(PS, q + 1); cl = load29(PS, q + 2); }
+  for (uint32_t r = 0; r < rp; r++) {
+    F29 ctn = F29::zero(), rwn = F29::zero(), cln = F29::zero();
+    if (mine && r + 1 < rp) { const size_t q = 3 * ((size_t)(r + 1) * T + li); ctn = load29(PS, q); rwn = load29(PS, q + 1); cln = load29(PS, q + 2); }
+    s = F29::add(s, ct);                                           // < 3
+    const F29 sl0 = shfl29(s, lane_base);
+    const F29 m1 = F29::mul(l0 ? s : rw, s);                       // lane 0: x2 (3·3); lane i: row_i·s_i
+    const F29 u = F29::mul(l0 ? rw : cl, sl0);                     // lane 0: row_0·s; lane i: col_i·s_0
+    F29 x4 = F29::zero();
+    if (l0) { x4 = F29::sqr(m1); if (live && Zrow) emit(nf0 + 3 * T + r, m1, x4, F29::mul(x4, s)); }
+    const F29 x4b = shfl29(x4, lane_base);
+    const F29 m2 = F29::mul(x4b, u);                               // lane 0: row_0·x5; lane i: col_i·x5
+    F29 p = l0 ? m2 : (mine ? m1 : F29::zero());
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) {
+      F29 o;
+#pragma unroll
+      for (int k = 0; k < 9; k++) o.v[k] = __shfl_xor(p.v[k], off);
+      p = F29::add(p, o);                                          // <= T terms below 1.5
+    }
+    s = weak_reduce29(l0 ? p : (mine ? F29::add(s, m2) : s));      // 13.5 | 3 + 1.5 -> < 1.65
+    ct = ctn; rw = rwn; cl = cln;
+  }
+  {
+    F29 acc = F29::zero();
+#pragma unroll
+    for (int j = 0; j < T - 1; j++) {
+      const F29 sj = shfl29(s, lane_base + 1 + j);
+      if (mine && !l0) acc = F29::add(acc, F29::mul(load29(PF, (size_t)(li - 1) * (T - 1) + j), sj));      // <= 8 terms below 1.5
+    }
+    if (mine && !l0) s = weak_reduce29(acc);
+  }
+  for (uint32_t r = 4 + rp; r < R; r++) full_round(r);
+  return s;
+}
+
 // grid.x covers chains of `phase` in groups of 16 lanes (4 chains per wave); grid.y = row.
 // job_out: [row][n_jobs + n_fops] Montgomery.
 // priv_rows != nullptr selects the hash-only pass: inputs come from the canonical private-input rows, no wire is written
@@ -314,6 +445,34 @@ static __global__ void __launch_bounds__(64) k_wit_chains(WitnessDev P, uint32_t
   uint32_t max_jobs = njobs;
   for (int off = 32; off >= 16; off >>= 1) max_jobs = max(max_jobs, (uint32_t)__shfl_xor((int)max_jobs, off));
   Fr prev_out = Fr::zero();  // output of the previous job of this chain, kept in registers (no memory round trip)
+  if (P.poseidon29) {        // (wave-uniform)
+    F29 prev29 = F29::zero();
+    for (uint32_t k = 0; k < max_jobs; k++) {
+      const bool live = k < njobs;
+      HashJob J;
+      if (live) J = P.jobs[P.chains[cid].job_off + k]; else { J.t = 3; J.wire_base = 0; J.out_wire = 0; }
+      const uint32_t t = J.t;
+      F29 s = F29::zero();
+      bool in_const = true;
+      if (live && li >= 1 && li < t) {
+        const ValRef ref = J.in[li - 1];
+        in_const = ref.kind == REF_CONST_ZERO;
+        if (ref.kind == REF_JOB && k > 0 && ref.idx == P.chains[cid].job_off + k - 1) s = prev29;
+        else s = F29::from_std(wit_value(P, ref, Zrow, jrow, prow));
+      }
+      const bool any9 = __any(live && t == 9), any3 = __any(live && t != 9);
+      F29 out = F29::zero();
+      if (any9) { F29 o = poseidon_group29<9>(P, J, live && t == 9, s, in_const, li, lane_base, Zrow); if (t == 9) out = o; }
+      if (any3) { F29 o = poseidon_group29<3>(P, J, live && t == 3, s, in_const, li, lane_base, Zrow); if (t != 9) out = o; }
+      prev29 = shfl29(out, lane_base);
+      if (live && li == 0) {
+        const Fr o = out.to_std();
+        store_fe(jrow, P.chains[cid].job_off + k, o);
+        if (J.out_wire && Zrow) store_fe(Zrow, J.out_wire, o);
+      }
+    }
+    return;
+  }
   for (uint32_t k = 0; k < max_jobs; k++) {
     const bool live = k < njobs;
     HashJob J;
@@ -339,6 +498,20 @@ static __global__ void __launch_bounds__(64) k_wit_chains(WitnessDev P, uint32_t
       if (J.out_wire && Zrow) store_fe(Zrow, J.out_wire, out);
     }
   }
+}
+
+// After k_wit_chains in the reduced-radix form: the S-box wires of the jobs of `phase` hold x·2^261 mod p (store29_raw); x·2^256 is that
+// times 2^-5 — one Montgomery product with the plain integer 2^251 mod p.  grid (jobs, rows); job_off as for k_wit_scatter.
+static __global__ void __launch_bounds__(128) k_wit_chain_wires_std(WitnessDev P, const uint32_t* __restrict__ job_off, uint32_t phase, uint32_t* __restrict__ Z) {
+  const uint32_t j = blockIdx.x, row = blockIdx.y;
+  uint32_t ph = 0xffffffffu;
+  for (uint32_t c = 0; c < P.n_chains; c++) if (j >= P.chains[c].job_off && j < P.chains[c].job_off + P.chains[c].job_cnt) { ph = P.chains[c].phase; break; }
+  if (ph != phase) return;
+  constexpr U256 C251 = ct_pow2_mod(251, BnFr::MOD);
+  Fr c; for (int i = 0; i < 8; i++) c.v[i] = C251.w[i];
+  const uint32_t cnt = job_off[j + 1] - job_off[j];
+  uint32_t* dst = Z + 8 * ((size_t)row * P.n_wires + P.jobs[j].wire_base);
+  for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) store_fe(dst, i, Fr::mul(load_fe<Fr>(dst, i), c));
 }
 
 // Head batch of a fold call (prover_internal.hpp: fold_head_batch): its Poseidon jobs were evaluated on the host — a sequential
