@@ -50,8 +50,8 @@ if want pmc; then
   pmc ivc_8K --transformation resize --resolution 8K --steps 48 --warmup 12
 fi
 if want valu; then     # vector instructions per step and kernel (the instruction budget of DESIGN.md §8)
-  $T rocprofv3 --pmc SQ_INSTS_VALU --output-format csv -d $O/pv -o pv -- python3 bench.py --no-cpu-baseline --no-extras --no-compress --steps 96 > /dev/null 2>> $O/rocprof.err
-  python3 tools/valu_budget.py $(find $O/pv -name "*counter_collection.csv" | head -1) 224 > $O/${R}_valu_budget.txt
+  $T rocprofv3 --pmc SQ_INSTS_VALU --output-format csv -d $O/pv -o pv -- python3 bench.py --no-cpu-baseline --no-extras --no-compress --steps 96 --warmup 32 > /dev/null 2>> $O/rocprof.err
+  python3 tools/valu_budget.py $(find $O/pv -name "*counter_collection.csv" | head -1) 224 SQ_INSTS_VALU split > $O/${R}_valu_budget.txt
   rm -rf $O/pv
 fi
 if want e2e; then      # whole images the way `vimz -b nova-snark -f <t>` sequences them
