@@ -82,7 +82,7 @@ if want ranks; then    # N > 1 on the one GPU of the box (--share-gpus: evidence
   $B --gpus 2 --transformation resize --resolution 8K --steps 64 --warmup 8 --no-compress > $O/${R}_bench_2ranks_on_1gpu_8K.json 2>> $O/ranks.err
   $B --gpus 4 --transformation resize --resolution 8K --steps 32 --warmup 8 --segments 2 --batch 32 --no-compress > $O/${R}_bench_4ranks_on_1gpu_8K.json 2>> $O/ranks.err
   $B --gpus 2 --mode accumulator > $O/${R}_bench_2ranks_on_1gpu_accumulator.json 2>> $O/ranks.err
-  $B --gpus 4 --no-compress --proof-set contrast,brightness,sharpness,blur --resolution 4K --steps 48 --warmup 8 --segments 1 > $O/${R}_bench_proof_set_4K_4ranks_on_1gpu.json 2>> $O/ranks.err
+  $B --gpus 4 --no-compress --proof-set contrast,brightness,sharpness,blur --resolution 4K --steps 48 --warmup 8 > $O/${R}_bench_proof_set_4K_4ranks_on_1gpu.json 2>> $O/ranks.err
   timeout 300 python3 bench.py --gpus 2 --steps 20 --warmup 5 --no-extras --no-cpu-baseline > $O/${R}_bench_plain_gpus2_on_1gpu.json 2> $O/${R}_bench_plain_gpus2_on_1gpu.txt; echo "exit code $?" >> $O/${R}_bench_plain_gpus2_on_1gpu.txt
 fi
 if want cores; then    # what a rank has when the ranks of a node share a small CPU quota: the same bench on 2 / 4 host cores (sched_setaffinity before anything starts)

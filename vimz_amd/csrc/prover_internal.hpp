@@ -516,17 +516,11 @@ static unsigned usable_cpus() {
   return v;
 }
 
-// Waits of the folding thread.  With few host cores (a rank's share below six) the runtime's own waits hold a core while the threads that
-// have work — the other segment, issuers, helpers — queue for it: there the stream / event is polled with a yield between polls.
-static inline bool vz_few_cores() { static const bool few = getenv("VIMZ_DEBUG_POLL_WAITS") ? atoi(getenv("VIMZ_DEBUG_POLL_WAITS")) != 0 : usable_cpus() < 6; return few; }
-static inline hipError_t vz_wait_stream(hipStream_t s) {
-  if (!vz_few_cores()) return hipStreamSynchronize(s);
-  for (;;) { const hipError_t q = hipStreamQuery(s); if (q != hipErrorNotReady) return q; std::this_thread::yield(); }
-}
-static inline hipError_t vz_wait_event(hipEvent_t e) {
-  if (!vz_few_cores()) return hipEventSynchronize(e);
-  for (;;) { const hipError_t q = hipEventQuery(e); if (q != hipErrorNotReady) return q; std::this_thread::yield(); }
-}
+// Waits of the folding thread: the runtime's own.  (Round 4 tried polling the stream / event with a yield between polls on ranks with few
+// cores: +3 % on two cores — and, with four ranks sharing one GPU, ONE of the four then waited 14-28 ms per step for its small MSM,
+// every run: 65 instead of 540 steps/s for the proof set.  Removed.)
+static inline hipError_t vz_wait_stream(hipStream_t s) { return hipStreamSynchronize(s); }
+static inline hipError_t vz_wait_event(hipEvent_t e) { return hipEventSynchronize(e); }
 
 // Rows of a call whose Poseidon jobs are evaluated on the host (VIMZ_HEAD_ROWS overrides; 0 switches the head batch off).
 // Round 2 chose 24: the first GPU-produced batch then needed one Poseidon-chain latency on the low-priority producer stream — 10 ms alone,
