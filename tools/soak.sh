@@ -1,0 +1,16 @@
+#!/bin/bash
+# Soak of the final code of a round on one GPU box: repeated merged proofs on the same provers (times flat, device memory flat), generations of
+# provers on the same contexts, the MSM stress tools, whole images; every proof verified by the tools.  usage: tools/soak.sh > profiles/rNN_soak.txt
+cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT" || exit 1
+echo "== stress_merge: 60 merged proofs of 48 rows, then 20 of 150 rows (the long-call schedule: no head batch)"
+timeout 900 python3 tools/stress_merge.py 60 48 2>&1 | tail -4 | cut -c1-400
+timeout 900 python3 tools/stress_merge.py 20 150 2>&1 | tail -4 | cut -c1-400
+echo "== prover_generations nova2cf"
+timeout 900 python3 tools/prover_generations.py nova2cf 2>&1 | grep -E "steps/s|verified|generation" | tail -8 | cut -c1-300
+echo "== stress_small_msm / stress_cyclefold"
+timeout 600 python3 tools/stress_small_msm.py 2>&1 | tail -2 | cut -c1-300
+timeout 900 python3 tools/stress_cyclefold.py 2>&1 | tail -3 | cut -c1-400
+echo "== whole images"
+for cfg in "contrast HD 3 ivc" "contrast HD 3 ivc" "contrast HD 1 ivc" "crop HD 3 ivc" "contrast HD 2 accumulator" "contrast HD 3 cyclefold"; do timeout 600 python3 tools/e2e.py $cfg 2>/dev/null | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('whole image', d['config'], d['mode'], d['segments'], d['steps'], round(d['steps_per_s'],1), d['verified'], d['final_state'][0][:18])"; done
+echo "== bench, three times"
+for rep in 1 2 3; do timeout 600 python3 bench.py --no-extras --no-cpu-baseline 2>/dev/null | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('bench', round(d['value'],1), d['verified'], 'compressed', d['compressed_snark']['verified'] if d.get('compressed_snark') else None)"; done
