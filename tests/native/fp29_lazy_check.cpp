@@ -62,6 +62,15 @@ template <class P> int field_checks(const char* name) {
     if (!a.is_zero() && xl.is_zero_mod()) bad++;
     G nz = G::neg(x);
     if (!G::add(nz, x).is_zero_mod() || !limbs_ok<P>(nz)) bad++;
+    // weak_reduce: any representative below 2^261 comes back below 3 p as the same residue (sums of lazily reduced products)
+    {
+      const uint32_t kw = (uint32_t)(rng() % 120);             // x + kw·p < 121 p < 2^261
+      const G big = lift<P>(x, kw), w = big.weak_reduce();
+      if (!limbs_ok<P>(w) || ratio<P>(w) >= 3.0L || !w.canon().eq(x)) bad++;
+      G top; for (int i = 0; i < 9; i++) top.v[i] = 0x1fffffffu;            // 2^261 − 1 itself
+      const G wt = top.weak_reduce();
+      if (!limbs_ok<P>(wt) || ratio<P>(wt) >= 3.0L) bad++;
+    }
   }
   printf("%s: field %d mismatches\n", name, bad);
   return bad;

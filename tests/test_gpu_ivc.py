@@ -312,7 +312,7 @@ def test_proof_does_not_depend_on_the_schedule():
     """The same rows give the same proof (running instances, fresh instance, state) whichever way the step's work is spread over
     streams, kernels and the host: default (three streams, fused small MSMs over window tables, large MSM queued behind the fused fold, the
     Poseidon jobs of a call's first 24 rows evaluated on host threads) against no / a shorter host-evaluated head batch and the
-    debugging switches that serialise or replace each of those pieces, and the lookahead schedule (the large MSM's cross term taken one
+    debugging switches that serialise or replace each of those pieces (the Poseidon chains' arithmetic among them), and the lookahead schedule (the large MSM's cross term taken one
     step ahead against the previous running instance and completed by the producer's fresh x fresh commitment).  Each variant runs in a process of its own (the switches
     are read once)."""
     import os
@@ -321,7 +321,9 @@ def test_proof_does_not_depend_on_the_schedule():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     variants = [{}, {"VIMZ_HEAD_ROWS": "0"}, {"VIMZ_HEAD_ROWS": "3"}, {"VIMZ_DEBUG_NO_S2": "1"}, {"VIMZ_DEBUG_NO_SMALL_TABLES": "1"}, {"VIMZ_IVC_MULT_TABLES": "1"}, {"VIMZ_DEBUG_NO_SMALL_MSM": "1"},
                 {"VIMZ_DEBUG_SMALL_SUM_KERNEL": "1", "VIMZ_AUG_NO_THREADS": "1"}, {"VIMZ_TUNE": "sort_blocks=256,combine_lane_bits=4"},
-                {"VIMZ_IVC_LOOKAHEAD": "1"}, {"VIMZ_TUNE": "sort_blocks=40,combine_lane_bits=2", "VIMZ_DEBUG_CHECK_MSM": "1"}]
+                {"VIMZ_IVC_LOOKAHEAD": "1"}, {"VIMZ_TUNE": "sort_blocks=40,combine_lane_bits=2", "VIMZ_DEBUG_CHECK_MSM": "1"},
+                # the Poseidon chains in the standard 8 x 32-bit arithmetic instead of the reduced-radix one, with the GPU producing every row
+                {"VIMZ_DEBUG_POSEIDON_STD": "1", "VIMZ_HEAD_ROWS": "0"}, {"VIMZ_TUNE": "ones_dense=0"}]
     # (the lookahead also with batches of two and three rows and no host-evaluated head: every way a row two steps ahead can fall into
     #  the same batch, the next one, or not exist)
     variants += [{"VIMZ_IVC_LOOKAHEAD": "1", "VIMZ_HEAD_ROWS": "0", "_batch": "2"}, {"VIMZ_IVC_LOOKAHEAD": "1", "VIMZ_HEAD_ROWS": "0", "_batch": "3"}]

@@ -90,6 +90,18 @@ struct Fp29 {
     r = cond_sub(r.v, P2);
     return cond_sub(r.v, MOD29);
   }
+  // ANY value below 2^261 (normalised limbs) -> the same residue below 3 p (below 1.9 p for BN254's two fields), without a comparison:
+  // q = floor(v / 2^253), k = floor(q·KNUM / 256) with KNUM = floor(2^29 / (top limb of p + 1)) <= 2^261 / p, so k·p <= q·2^253 <= v, and what is
+  // left is below 2^253 + p + q·(2^253 − KNUM·p/256).  One multiply-subtract chain — for sums of a few dozen lazily reduced products
+  // (witness.hpp: the Poseidon rounds), where canon()'s comparisons would sit on a chain of dependent operations.
+  static constexpr uint32_t KNUM = (1u << 29) / (MOD29.l[8] + 1u);
+  VZ_HD Fp29 weak_reduce() const {
+    const uint32_t k = ((v[8] >> 21) * KNUM) >> 8;
+    Fp29 r; int64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) { c += (int64_t)v[i] - (int64_t)((uint64_t)k * MOD29.l[i]); r.v[i] = (uint32_t)c & MASK; c >>= 29; }
+    return r;
+  }
   // a + b (no reduction): bound Ba + Bb
   static VZ_HD Fp29 add(const Fp29& a, const Fp29& b) {
     Fp29 r; uint32_t c = 0;

@@ -319,16 +319,9 @@ __device__ __forceinline__ F29 shfl29(const F29& v, int src_lane) {
   for (int k = 0; k < 9; k++) r.v[k] = __shfl(v.v[k], src_lane);
   return r;
 }
-// a (normalised limbs, below 2^261 — any sum of a few dozen residues) -> the same residue below 2 p: k = floor(floor(a / 2^253)·169/256) never
-// exceeds a / p (2^253 / p = 0.66127 > 169/256) and leaves less than 1.89 p (1.65 p for a < 14 p); one multiply-subtract chain, no comparison.
-VZ_HD inline F29 weak_reduce29(const F29& a) {
-  static_assert(BnFr::MOD.w[7] == 0x30644e72u, "the quotient estimate is BN254 Fr's");
-  const uint32_t k = ((a.v[8] >> 21) * 169u) >> 8;
-  F29 r; int64_t c = 0;
-#pragma unroll
-  for (int i = 0; i < 9; i++) { c += (int64_t)a.v[i] - (int64_t)((uint64_t)k * F29::MOD29.l[i]); r.v[i] = (uint32_t)c & F29::MASK; c >>= 29; }
-  return r;
-}
+// (a sum of up to nine products, below 14 p, back below 2 p: Fp29::weak_reduce — 1.65 p for BN254 Fr, KNUM = 169)
+static_assert(F29::KNUM == 169u, "the bounds in poseidon_group29 are written for BN254 Fr's quotient estimate");
+__device__ __forceinline__ F29 weak_reduce29(const F29& a) { return a.weak_reduce(); }
 // a wire of the S-boxes as it leaves the chain kernel: the 256-bit integer x·2^261 mod p (+ p at most once); k_wit_chain_wires_std turns
 // the job's wires into the standard form afterwards, all of them side by side (a conversion per wire inside the chain would sit in its way)
 __device__ __forceinline__ void store29_raw(uint32_t* __restrict__ Zrow, uint32_t wire, const F29& x) {
