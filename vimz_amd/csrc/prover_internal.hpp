@@ -815,7 +815,9 @@ static int fold_prepare(vimz_prover* p, FoldJob& J, bool start_batch0 = false) {
     }
   }
   std::vector<Fe> jobA(nsteps * jstride);
-  if (J.started_batch >= 0) P_TRY(hipStreamWaitEvent(s, p->buf[J.started_batch & 1].wit_done, 0));
+  // (waited for on the HOST: a barrier on this high-priority stream behind the producer's low-priority event is the inversion of DESIGN.md §5c —
+  //  the stalled barrier keeps the low-priority queue from being served, and with four processes on one GPU one of them then ran at 60 ms per step)
+  if (J.started_batch >= 0) P_TRY(hipEventSynchronize(p->buf[J.started_batch & 1].wit_done));
   P_TRY(hipMemcpyAsync(jobA.data(), p->job_all_d, 32 * nsteps * jstride, hipMemcpyDeviceToHost, s));
   P_TRY(hipStreamSynchronize(s));
   p->phase_s[PH_WITNESS] += now_s() - t0; t0 = now_s();
