@@ -339,6 +339,15 @@ def test_fold_segments_in_one_call_edge_cases(ctx, keys, oracle):
         assert e.value.code == _lib.ERR_UNSAT
         m3, _ = hip.MergedProof.fold_segments(ivcs, rows, z0); objs.append(m3)       # the provers are usable afterwards
         assert m3.verify(10, z0) == 0
+        # short segments have their head rows hashed once, ahead of their folds (merge.hip: head_precompute); the other schedule — row
+        # digests and head batches apart — gives the same object
+        import os
+        os.environ["VIMZ_DEBUG_NO_HEAD_PRECOMPUTE"] = "1"
+        try:
+            m4, _ = hip.MergedProof.fold_segments(ivcs, rows, z0); objs.append(m4)
+        finally:
+            del os.environ["VIMZ_DEBUG_NO_HEAD_PRECOMPUTE"]
+        assert m4.verify(10, z0) == 0 and (m4.records() == m.records()).all() and (m3.records() == m.records()).all()
     finally:
         for o in objs:
             o.close()

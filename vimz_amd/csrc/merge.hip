@@ -706,7 +706,9 @@ int vimz_ivc_fold_segments_dg(vimz_ivc* const* segs, size_t n_seg, const uint64_
   std::vector<int> rc_fold(S, VIMZ_OK), rc_dig(S, VIMZ_OK);
   std::vector<std::vector<uint64_t>> dig(S);
   std::vector<std::thread> th_dig, th_fold;
-  if (stride && S > 1 && !digests)
+  bool pre_mode = stride && S > 1 && !digests && getenv("VIMZ_DEBUG_NO_HEAD_PRECOMPUTE") == nullptr;
+  for (size_t k = 0; k < S && pre_mode; k++) pre_mode = head_takes_whole_call(segs[k]->pri, hi[k] - lo[k]) && !segs[k]->broken;
+  if (stride && S > 1 && !digests && !pre_mode)
     for (size_t k = 0; k + 1 < S; k++) {
       dig[k].resize(4 * stride * (hi[k] - lo[k]));
       th_dig.emplace_back([&, k] { rc_dig[k] = vimz_ivc_row_digests(segs[k + 1], step_inputs + 4 * n_priv * lo[k], hi[k] - lo[k], dig[k].data()); });
@@ -715,7 +717,37 @@ int vimz_ivc_fold_segments_dg(vimz_ivc* const* segs, size_t n_seg, const uint64_
   double t_chain = 0;
   int rc = VIMZ_OK;
   size_t started = 0;
-  for (size_t k = 0; k < S && !rc; k++) {
+  // Short calls whose segments fit whole into the host-evaluated head batch (the driver's 20-row window: 7 rows per segment): each
+  // segment's row-hash chains are evaluated ONCE, with their wires, into its head staging right before its fold is started — their
+  // outputs are the digests the NEXT segment's start state needs, and the fold finds its head rows hashed.  In segment order, so the GPU
+  // gets its first fold after one round of the host pool (14 tasks) and the later segments follow a round apart; before, the rows of
+  // all but the last segment were hashed twice (70 pool tasks in front of the last segment's first fold instead of 42).
+  const bool pre = pre_mode;
+  auto drop_pre = [&] { for (size_t k = 0; k < S; k++) { std::lock_guard<std::mutex> g(segs[k]->ctx->mu); segs[k]->pri->pre_rows = 0; segs[k]->pri->pre_inputs = nullptr; } };   // (on an early return: no later call may take these over)
+  std::vector<uint64_t> dig_prev;      // the previous segment's digests, copied out of its staging before its fold may touch it
+  for (size_t k = 0; k < S && !rc && pre; k++) {
+    if (k > 0) {
+      const double t0 = now_s();
+      const size_t n = hi[k - 1] - lo[k - 1];
+      zs.assign(4 * lz * (n + 1), 0);
+      rc = vimz_ivc_chain_from_digests(segs[k], z.data(), step_inputs + 4 * n_priv * lo[k - 1], dig_prev.data(), n, zs.data());
+      if (rc) { if (segs[k]->ctx != ctx) ctx->err = segs[k]->ctx->err; break; }
+      z.assign(zs.end() - 4 * lz, zs.end());
+      t_chain += now_s() - t0;
+    }
+    {
+      vimz_ctx* c = segs[k]->ctx;
+      std::lock_guard<std::mutex> g(c->mu);
+      if (hipSetDevice(c->device) != hipSuccess) { rc = vz_fail(c, VIMZ_ERR_HIP, "vimz_ivc_fold_segments: hipSetDevice"); if (c != ctx) ctx->err = c->err; break; }
+      rc = head_precompute(segs[k]->pri, step_inputs + 4 * n_priv * lo[k], hi[k] - lo[k]);
+      if (rc) { if (c != ctx) ctx->err = c->err; break; }
+      if (k + 1 < S) { const uint64_t* jv = reinterpret_cast<const uint64_t*>(segs[k]->pri->jobvals_host); dig_prev.assign(jv, jv + 4 * stride * (hi[k] - lo[k])); }
+    }
+    if ((rc = vimz_ivc_reset(segs[k], z.data()))) break;
+    th_fold.emplace_back([&, k] { rc_fold[k] = vimz_ivc_fold(segs[k], step_inputs + 4 * n_priv * lo[k], hi[k] - lo[k]); });
+    started = k + 1;
+  }
+  for (size_t k = 0; k < S && !rc && !pre; k++) {
     if (k > 0) {
       const double t0 = now_s();
       const size_t n = hi[k - 1] - lo[k - 1];
@@ -737,7 +769,7 @@ int vimz_ivc_fold_segments_dg(vimz_ivc* const* segs, size_t n_seg, const uint64_
   for (auto& t : th_fold) t.join();
   for (size_t k = 0; k < th_dig.size(); k++) if (th_dig[k].joinable()) th_dig[k].join();
   for (size_t k = 0; k < started && !rc; k++) if (rc_fold[k]) { rc = rc_fold[k]; if (segs[k]->ctx != ctx) ctx->err = segs[k]->ctx->err; }
-  if (rc) return rc;
+  if (rc) { if (pre) drop_pre(); return rc; }
   const double t_m = now_s();
   vimz_ivc_merged* m = nullptr;
   if ((rc = vimz_ivc_merged_create(segs[0], &m))) return rc;

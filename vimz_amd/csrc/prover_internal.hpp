@@ -165,6 +165,8 @@ struct vimz_prover {
   Fe* stage_host = nullptr; Fe* jobvals_host = nullptr; Fe* zs_host = nullptr;   // pinned
   uint32_t *stage_d = nullptr, *jobvals_d = nullptr;
   size_t head_rows_cap = 0;
+  // row-hash jobs of a coming call's head rows, evaluated ahead (head_precompute): the call over exactly these inputs finds them done
+  const uint64_t* pre_inputs = nullptr; size_t pre_rows = 0;
   bool head_eligible = false;
   // per fold call: all private inputs, all IVC states and all row hashes resident
   uint32_t *priv_all_d = nullptr, *zs_all_d = nullptr, *job_all_d = nullptr;
@@ -388,6 +390,7 @@ struct FoldJob {
   size_t rows(size_t k) const { return brows[k]; }
   uint32_t nA = 0, nB = 0, nE = 0;         // Poseidon chains of phase A (row data only) / B (need the hashed state) / 2 (after the early field ops)
   bool early_fops = false;
+  size_t pre_rows = 0;            // head rows whose row-hash jobs were evaluated ahead of this call (head_precompute), taken over in fold_prepare
   BaseTables tbl{};
   // head batch on the host (fold_head_batch): batch 0 is already issued when fold_prepare returns, and the IVC states of the rows
   // after it arrive later, from a helper thread (the hash-only pass over those rows takes one Poseidon-chain latency on the GPU)
@@ -577,41 +580,33 @@ static int fold_issue_d(vimz_prover* p, const FoldJob& J, size_t k, size_t r, hi
 // decompositions, lane programs, field ops) on a stream of its own and, on the producer's stream, already runs the chains of the
 // NEXT batch.  The first fold of a call starts after ~3 ms instead of ~20 ms (VIMZ_DEBUG_TIMING=1 prints it).
 // Leaves batch 0 fully issued (events bb.wit_done, bb.ev[r] recorded on p->sH) and the IVC states zs[0..rows] filled in.
-static int fold_head_batch(vimz_prover* p, FoldJob& J, size_t rows) {
+// pinned + device staging for the largest head this prover can see (first use; kept: pinned allocations take milliseconds and must not
+// recur in later calls).  Caller holds the context's lock and has set the device.
+static int head_reserve(vimz_prover* p, size_t rows) {
   vimz_ctx* ctx = p->ctx;
+  if (rows <= p->head_rows_cap) return VIMZ_OK;
+  const size_t jstride = p->n_jobs + p->n_fops, stage_row = p->job_stage_off.back();
+  const size_t cap_rows = std::max(rows, std::min(head_rows_wanted(), p->max_batch));
+  if (p->stage_host) { hipHostFree(p->stage_host); hipHostFree(p->jobvals_host); hipHostFree(p->zs_host); p->retired.push_back(p->stage_d); p->retired.push_back(p->jobvals_d); }
+  p->stage_host = nullptr; p->jobvals_host = nullptr; p->zs_host = nullptr; p->stage_d = nullptr; p->jobvals_d = nullptr; p->head_rows_cap = 0;
+  p->pre_rows = 0; p->pre_inputs = nullptr;
+  P_TRY(hipHostMalloc((void**)&p->stage_host, 32 * cap_rows * stage_row));
+  P_TRY(hipHostMalloc((void**)&p->jobvals_host, 32 * cap_rows * jstride));
+  P_TRY(hipHostMalloc((void**)&p->zs_host, 32 * (cap_rows + 1) * (size_t)p->len_z));
+  P_TRY(hipMalloc((void**)&p->stage_d, 32 * cap_rows * stage_row));
+  P_TRY(hipMalloc((void**)&p->jobvals_d, 32 * cap_rows * jstride));
+  p->head_rows_cap = cap_rows;
+  return VIMZ_OK;
+}
+// The row-hash chains (phase A) of `rows` head rows on the host pool, one task per (row, chain): outputs into jobvals_host, every S-box wire
+// into stage_host in the witness program's own wire order.  Depends on the rows' private inputs only — not on the IVC state.
+static void head_rowhash_jobs(vimz_prover* p, const uint64_t* inputs, size_t rows) {
   const cb::Builder& b = p->circuit->build->b;
-  const WitnessDev& W = p->wd;
-  const size_t jstride = p->n_jobs + p->n_fops, stage_row = p->job_stage_off.back(), nw = p->n_wires, nc = p->n_c, sw = p->step_wires;
-  if (rows > p->head_rows_cap) {       // (first use: pinned + device staging for the largest head this prover can see, kept —
-                                       //  pinned allocations take milliseconds and must not recur in later calls)
-    const size_t cap_rows = std::max(rows, std::min(head_rows_wanted(), p->max_batch));
-    if (p->stage_host) { hipHostFree(p->stage_host); hipHostFree(p->jobvals_host); hipHostFree(p->zs_host); p->retired.push_back(p->stage_d); p->retired.push_back(p->jobvals_d); }
-    p->stage_host = nullptr; p->jobvals_host = nullptr; p->zs_host = nullptr; p->stage_d = nullptr; p->jobvals_d = nullptr; p->head_rows_cap = 0;
-    P_TRY(hipHostMalloc((void**)&p->stage_host, 32 * cap_rows * stage_row));
-    P_TRY(hipHostMalloc((void**)&p->jobvals_host, 32 * cap_rows * jstride));
-    P_TRY(hipHostMalloc((void**)&p->zs_host, 32 * (cap_rows + 1) * (size_t)p->len_z));
-    P_TRY(hipMalloc((void**)&p->stage_d, 32 * cap_rows * stage_row));
-    P_TRY(hipMalloc((void**)&p->jobvals_d, 32 * cap_rows * jstride));
-    p->head_rows_cap = cap_rows;
-  }
-  auto& bb = p->buf[0];
-  bb.gen++;      // (row flags of this filling: wait_row_flag)
-  hipStream_t sh = p->sH;
-  static const bool dbg_t = getenv("VIMZ_DEBUG_TIMING") != nullptr;
-  const double th0 = now_s();
-  // the state-independent GPU part of these rows starts now, under the host's Poseidon work
-  P_TRY(hipStreamWaitEvent(sh, bb.wit_done, 0));          // (recorded by the caller behind the upload of the private inputs)
-  P_TRY(hipMemsetAsync(bb.status, 0, 4 * rows, sh));
-  for (uint32_t gI = 0; gI < W.n_decomp; gI++) {
-    const uint32_t total = (b.decomp[gI].nbits - 1) * b.decomp[gI].count;
-    hipLaunchKernelGGL(k_wit_decomp, dim3((total + 255) / 256, (unsigned)rows), dim3(256), 0, sh, W, gI, (const uint32_t*)p->priv_all_d, bb.Z, bb.status);
-  }
-  // 1. row-hash chains (phase A) of every head row, one task per (row, chain)
+  const size_t jstride = p->n_jobs + p->n_fops, stage_row = p->job_stage_off.back();
   std::vector<uint32_t> chainsA;
   for (uint32_t c = 0; c < b.chains.size(); c++) if (b.chains[c].phase == 0) chainsA.push_back(c);
   Fe* stage = p->stage_host; Fe* jobvals = p->jobvals_host;
   memset(jobvals, 0, 32 * rows * jstride);
-  const uint64_t* inputs = J.step_inputs;
   const uint32_t priv0 = 1 + 2 * b.len_z;
   vz_shared_pool().run(rows * chainsA.size(), [&](size_t task) {
     const size_t r = task / chainsA.size();
@@ -632,6 +627,49 @@ static int fold_head_batch(vimz_prover* p, FoldJob& J, size_t rows) {
       jobvals[r * jstride + j] = st[0];
     }
   });
+}
+// Would a fold call of `nsteps` rows on this prover put ALL its rows into the host-evaluated head batch (fold_prepare's rule)?
+static bool head_takes_whole_call(const vimz_prover* p, size_t nsteps) {
+  const cb::Builder& b = p->circuit->build->b;
+  bool nA = false, nE = false, early = false;
+  for (auto& c : b.chains) { if (c.phase == 0) nA = true; else if (c.phase != 1) nE = true; }
+  for (auto& f : b.fops) if (f.early) early = true;
+  return nsteps && p->head_eligible && nA && !nE && !early && std::min(std::min(head_rows_wanted(nsteps), p->max_batch), nsteps) == nsteps;
+}
+// The head rows' row-hash jobs evaluated AHEAD of the fold call over exactly these inputs (same pointer): the call's head batch finds
+// them done, and jobvals_host holds these rows' digests meanwhile (what vimz_prover_row_digests would return) — the segments of a short
+// call hash every row once instead of twice (merge.hip: vimz_ivc_fold_segments).  Caller holds the lock, device set.
+static int head_precompute(vimz_prover* p, const uint64_t* inputs, size_t rows) {
+  int rc = head_reserve(p, rows);
+  if (rc) return rc;
+  head_rowhash_jobs(p, inputs, rows);
+  p->pre_inputs = inputs; p->pre_rows = rows;
+  return VIMZ_OK;
+}
+
+static int fold_head_batch(vimz_prover* p, FoldJob& J, size_t rows) {
+  vimz_ctx* ctx = p->ctx;
+  const cb::Builder& b = p->circuit->build->b;
+  const WitnessDev& W = p->wd;
+  const size_t jstride = p->n_jobs + p->n_fops, stage_row = p->job_stage_off.back(), nw = p->n_wires, nc = p->n_c, sw = p->step_wires;
+  const bool pre = J.pre_rows >= rows && rows <= p->head_rows_cap;      // (evaluated ahead: head_precompute)
+  { int rc = head_reserve(p, rows); if (rc) return rc; }
+  auto& bb = p->buf[0];
+  bb.gen++;      // (row flags of this filling: wait_row_flag)
+  hipStream_t sh = p->sH;
+  static const bool dbg_t = getenv("VIMZ_DEBUG_TIMING") != nullptr;
+  const double th0 = now_s();
+  // the state-independent GPU part of these rows starts now, under the host's Poseidon work
+  P_TRY(hipStreamWaitEvent(sh, bb.wit_done, 0));          // (recorded by the caller behind the upload of the private inputs)
+  P_TRY(hipMemsetAsync(bb.status, 0, 4 * rows, sh));
+  for (uint32_t gI = 0; gI < W.n_decomp; gI++) {
+    const uint32_t total = (b.decomp[gI].nbits - 1) * b.decomp[gI].count;
+    hipLaunchKernelGGL(k_wit_decomp, dim3((total + 255) / 256, (unsigned)rows), dim3(256), 0, sh, W, gI, (const uint32_t*)p->priv_all_d, bb.Z, bb.status);
+  }
+  // 1. row-hash chains (phase A) of every head row, one task per (row, chain) — unless they were evaluated ahead
+  Fe* stage = p->stage_host; Fe* jobvals = p->jobvals_host;
+  const uint64_t* inputs = J.step_inputs;
+  if (!pre) head_rowhash_jobs(p, inputs, rows);
   const double th1 = now_s();
   // 2. the IVC state chain of these rows, with the wires of the state hashes
   host_state_chain(p, inputs, rows, jobvals, jstride, J.zs, 0, stage, stage_row, jobvals);
@@ -678,6 +716,9 @@ static int fold_prepare(vimz_prover* p, FoldJob& J, bool start_batch0 = false) {
   const cb::Builder& b = p->circuit->build->b;
   const WitnessDev& W = p->wd;
   const size_t nsteps = J.nsteps, jstride = p->n_jobs + p->n_fops, B = p->max_batch, sw = p->step_wires;
+  // (a head evaluated ahead belongs to the one call that follows it, over the very same input buffer: taken over or dropped here)
+  J.pre_rows = p->pre_inputs && p->pre_inputs == J.step_inputs ? p->pre_rows : 0;
+  p->pre_rows = 0; p->pre_inputs = nullptr;
   for (auto& c : b.chains) (c.phase == 0 ? J.nA : c.phase == 1 ? J.nB : J.nE)++;
   for (auto& f : b.fops) if (f.early) J.early_fops = true;
   J.zs.assign((nsteps + 1) * p->len_z, Fe::zero());
