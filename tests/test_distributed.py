@@ -364,9 +364,9 @@ def test_tree_rounds_pair_adjacent_runs():
         assert len(rounds) == (w - 1).bit_length()
 
 
-@pytest.mark.parametrize("world,shm,digests,n_rows", [(4, True, True, 10), (4, False, False, 10), (3, True, True, 7), (4, True, True, 3)])
+@pytest.mark.parametrize("world,shm,digests,n_rows", [(4, True, True, 10), (4, False, False, 10), (3, True, True, 7), (4, True, True, 3), (8, True, True, 10)])
 def test_ranks_fold_their_proofs_pairwise_up_a_tree(oracle, world, shm, digests, n_rows):
-    """World size 3 and 4 over gloo: the ranks' merged proofs are folded pairwise up a tree (rank 1 -> 0 and 3 -> 2 side by side, then
+    """World size 3, 4 and 8 over gloo: the ranks' merged proofs are folded pairwise up a tree (rank 1 -> 0 and 3 -> 2 side by side, then
     2 -> 0) instead of one after another on rank 0; the op sequence the final object carries IS that tree (replayed here with the
     adjacency check at every node), its statement is all rows from z0 and it ends where a single chain ends.  Also with fewer rows than
     ranks (a rank without rows hands over nothing)."""
@@ -386,7 +386,10 @@ def test_ranks_fold_their_proofs_pairwise_up_a_tree(oracle, world, shm, digests,
         b = [hi - lo for lo, hi in segment_bounds(k, 2) if hi > lo]
         return b[0] if len(b) == 1 else tuple(b)
     per_rank = [run(hi - lo) for lo, hi in segment_bounds(n_rows, world) if hi > lo]
-    if world == 4 and n_rows == 10:
+    if world == 8:      # (ten rows over eight ranks: 2, 2, 1, 1, 1, 1, 1, 1 — three levels, the shape the driver's eight-GPU run takes)
+        q = per_rank
+        assert tree == (((q[0], q[1]), (q[2], q[3])), ((q[4], q[5]), (q[6], q[7])))
+    elif world == 4 and n_rows == 10:
         assert tree == ((per_rank[0], per_rank[1]), (per_rank[2], per_rank[3]))
     elif world == 3:
         assert tree == ((per_rank[0], per_rank[1]), per_rank[2])
