@@ -81,6 +81,8 @@ if want ranks; then    # N > 1 on the one GPU of the box (--share-gpus: evidence
   $B --gpus 2 --cores 2 > $O/${R}_bench_2ranks_on_1gpu_2cores_each.json 2>> $O/ranks.err
   $B --gpus 2 --transformation resize --resolution 8K --steps 64 --warmup 8 --no-compress > $O/${R}_bench_2ranks_on_1gpu_8K.json 2>> $O/ranks.err
   $B --gpus 4 --transformation resize --resolution 8K --steps 32 --warmup 8 --segments 2 --batch 32 --no-compress > $O/${R}_bench_4ranks_on_1gpu_8K.json 2>> $O/ranks.err
+  $B --gpus 8 --steps 20 --warmup 5 > $O/${R}_bench_8ranks_on_1gpu_driver_window.json 2>> $O/ranks.err      # (eight processes on the one GPU: the eight-rank tree end to end, nothing about speed)
+  $B --gpus 8 --steps 64 --warmup 8 > $O/${R}_bench_8ranks_on_1gpu_w64.json 2>> $O/ranks.err
   $B --gpus 2 --mode accumulator > $O/${R}_bench_2ranks_on_1gpu_accumulator.json 2>> $O/ranks.err
   $B --gpus 4 --no-compress --proof-set contrast,brightness,sharpness,blur --resolution 4K --steps 48 --warmup 8 > $O/${R}_bench_proof_set_4K_4ranks_on_1gpu.json 2>> $O/ranks.err
   timeout 300 python3 bench.py --gpus 2 --steps 20 --warmup 5 --no-extras --no-cpu-baseline > $O/${R}_bench_plain_gpus2_on_1gpu.json 2> $O/${R}_bench_plain_gpus2_on_1gpu.txt; echo "exit code $?" >> $O/${R}_bench_plain_gpus2_on_1gpu.txt
