@@ -706,7 +706,7 @@ int vimz_ivc_fold_segments_dg(vimz_ivc* const* segs, size_t n_seg, const uint64_
   std::vector<int> rc_fold(S, VIMZ_OK), rc_dig(S, VIMZ_OK);
   std::vector<std::vector<uint64_t>> dig(S);
   std::vector<std::thread> th_dig, th_fold;
-  bool pre_mode = stride && S > 1 && !digests && getenv("VIMZ_DEBUG_NO_HEAD_PRECOMPUTE") == nullptr;
+  bool pre_mode = stride && S > 1 && getenv("VIMZ_DEBUG_NO_HEAD_PRECOMPUTE") == nullptr;      // (also with the caller's digests: the folds then start a pool round apart instead of together after three)
   for (size_t k = 0; k < S && pre_mode; k++) pre_mode = head_takes_whole_call(segs[k]->pri, hi[k] - lo[k]) && !segs[k]->broken;
   if (stride && S > 1 && !digests && !pre_mode)
     for (size_t k = 0; k + 1 < S; k++) {
@@ -730,7 +730,7 @@ int vimz_ivc_fold_segments_dg(vimz_ivc* const* segs, size_t n_seg, const uint64_
       const double t0 = now_s();
       const size_t n = hi[k - 1] - lo[k - 1];
       zs.assign(4 * lz * (n + 1), 0);
-      rc = vimz_ivc_chain_from_digests(segs[k], z.data(), step_inputs + 4 * n_priv * lo[k - 1], dig_prev.data(), n, zs.data());
+      rc = vimz_ivc_chain_from_digests(segs[k], z.data(), step_inputs + 4 * n_priv * lo[k - 1], digests ? digests + 4 * stride * lo[k - 1] : dig_prev.data(), n, zs.data());
       if (rc) { if (segs[k]->ctx != ctx) ctx->err = segs[k]->ctx->err; break; }
       z.assign(zs.end() - 4 * lz, zs.end());
       t_chain += now_s() - t0;
@@ -741,7 +741,7 @@ int vimz_ivc_fold_segments_dg(vimz_ivc* const* segs, size_t n_seg, const uint64_
       if (hipSetDevice(c->device) != hipSuccess) { rc = vz_fail(c, VIMZ_ERR_HIP, "vimz_ivc_fold_segments: hipSetDevice"); if (c != ctx) ctx->err = c->err; break; }
       rc = head_precompute(segs[k]->pri, step_inputs + 4 * n_priv * lo[k], hi[k] - lo[k]);
       if (rc) { if (c != ctx) ctx->err = c->err; break; }
-      if (k + 1 < S) { const uint64_t* jv = reinterpret_cast<const uint64_t*>(segs[k]->pri->jobvals_host); dig_prev.assign(jv, jv + 4 * stride * (hi[k] - lo[k])); }
+      if (k + 1 < S && !digests) { const uint64_t* jv = reinterpret_cast<const uint64_t*>(segs[k]->pri->jobvals_host); dig_prev.assign(jv, jv + 4 * stride * (hi[k] - lo[k])); }
     }
     if ((rc = vimz_ivc_reset(segs[k], z.data()))) break;
     th_fold.emplace_back([&, k] { rc_fold[k] = vimz_ivc_fold(segs[k], step_inputs + 4 * n_priv * lo[k], hi[k] - lo[k]); });
