@@ -68,6 +68,9 @@ int vimz_sync(vimz_ctx* ctx);
 /* A marker for a profiler's kernel trace: an empty kernel `k_trace_marker` of `id` (1..1024) workgroups on the context's stream, waited for
  * (bench.py brackets its timed region with ids 1 and 2; tools/trace_busy.py cuts the trace there). */
 int vimz_trace_marker(vimz_ctx* ctx, int id);
+/* A fingerprint of the host a benchmark line was measured on: out[0] = µs per Poseidon permutation (t = 9) on one host core, out[1] = µs per
+ * empty kernel launch + stream synchronise (median of 200), out[2] = host cores this process may use, out[3] = µs per event record + synchronise. */
+int vimz_host_fingerprint(vimz_ctx* ctx, double out[4]);
 /* Stream-ordered timing with HIP events on the context's stream (used by bench.py for the roofline). */
 int vimz_timer_start(vimz_ctx* ctx);
 int vimz_timer_stop(vimz_ctx* ctx, float* ms_out);
@@ -288,7 +291,7 @@ int vimz_ivc_fold_witness(vimz_ivc* v, const uint64_t* witnesses, size_t nsteps)
  * fold violate the relation (prover-side bookkeeping, not part of the proof). */
 int vimz_ivc_verify(vimz_ivc* v, uint64_t num_steps, const uint64_t* z0, uint32_t* result);
 /* info[0..11]: steps, primary wires, primary constraints, step wires, step constraints, secondary wires, secondary constraints,
- * len_z, verifier-circuit wires (primary), nnz(A+B+C) primary, nnz secondary, reserved */
+ * len_z, verifier-circuit wires (primary), nnz(A+B+C) primary, nnz secondary, rows of the last fold call whose Poseidon chains ran on the host */
 int vimz_ivc_info(const vimz_ivc* v, uint64_t info[12]);
 int vimz_ivc_state(const vimz_ivc* v, uint64_t* z_current /* len_z x 4 */, uint64_t* steps);
 /* IVC state chain only (as vimz_prover_state_chain): where a row segment proven by another IVC starts */
@@ -407,27 +410,42 @@ int vimz_cf_row_digests(vimz_cf* v, const uint64_t* step_inputs, size_t nsteps, 
 int vimz_cf_chain_from_digests(vimz_cf* v, const uint64_t* z_start, const uint64_t* step_inputs, const uint64_t* digests, size_t nsteps, uint64_t* zs_out);
 /* (test hooks — vimz_cf_poke, the host-only self-checks — are declared in vimz_hip_testing.h and exist only in libvimz_hip_testing.so) */
 
-/* ---- the decider of the Nova + CycleFold path: `Decider::preprocess` / `Decider::prove` of the Sonobe backend (vimz/src/sonobe_backend/mod.rs:72-78;
- *      `DeciderEth<.., Groth16<Bn254>, ..>`, decider.rs:13-21) — the Groth16 proof that fills eight of the 25 calldata words (solidity.rs:13-27,
- *      contracts/ContrastVerifier.sol:785-810 and its siblings).  Groth16 over BN254 as published; the circuit (vimz_amd/csrc/aug/decider.hpp: the hashes the last instance
- *      carries, NIFS.V on the scalars, the folded main instance's relaxed R1CS row by row, the two KZG evaluations, one hash binding the words the
- *      contract sees) and the deterministic TEST setup (trapdoor derived from `seed`) are ours, parity unpinned: Sonobe's keys come out of crates
- *      that are not vendored.  NTTs, the G1 / G2 multi-scalar multiplications and the key's fixed-base multiplications run on the GPU. ---------- */
+/* ---- the decider of the Nova + CycleFold path: `Decider::preprocess` / `Decider::prove` / `Decider::verify` of the Sonobe backend
+ *      (vimz/src/sonobe_backend/mod.rs:72-80; `DeciderEth<.., Groth16<Bn254>, ..>`, decider.rs:13-21; verify_final_proof, decider.rs:31-50) — the 25 words
+ *      `contracts/<T>Verifier.sol::verifyOpaqueNovaProofWithInputs` takes (ContrastVerifier.sol:785-810; solidity.rs:13-27).  Groth16 over BN254 as
+ *      published, with the PUBLIC-INPUT LAYOUT of the reference's contracts (pp_hash, i, z_0, z_i, the folded commitments and cmT as 5 x 55-bit
+ *      limbs per coordinate, the KZG challenges and evaluations: ContrastVerifier.sol:700-772) — pinned: tests/_novadecider.py restates the
+ *      contract, accepts the reference's six committed proofs with the reference's keys, and accepts this library's words with this library's
+ *      key.  The circuit's CONSTRAINTS (vimz_amd/csrc/aug/decider.hpp) are ours, parity unpinned: Sonobe's circuit and keys come out of crates
+ *      that are not vendored, so the committed `.proof` bytes cannot be reproduced.  NTTs, the G1 / G2 multi-scalar multiplications, the final
+ *      fold, the KZG openings and the keys' fixed-base multiplications run on the GPU; verification is host code (pairing.hpp). ---------- */
 typedef struct vimz_decider vimz_decider;
-/* prover: supplies shapes, keys and context (must outlive the object).  seconds (optional) = {circuit synthesis, QAP evaluation at the trapdoor,
- * key points on the GPU, total} */
-int vimz_decider_setup(vimz_cf* prover, const uint8_t* seed, size_t seed_len, vimz_decider** out, double seconds[4]);
+/* KZG::setup (inside `prepare_folding`, vimz/src/sonobe_backend/folding.rs:36-48): srs = [tau^i]G1 for i < n as a commitment key (use it as
+ * ck_main of vimz_cf_create), vk_g2_out = [tau]G2 (x.c0, x.c1, y.c0, y.c1 canonical).  tau comes from the OS's randomness and is forgotten. */
+int vimz_kzg_setup(vimz_ctx* ctx, size_t n, vimz_bases** srs_out, uint64_t vk_g2_out[16]);
+/* Decider::preprocess.  prover: supplies shapes, keys and context (must outlive the object).  kzg_vk_g2 (optional): [tau]G2 of the SRS the prover's
+ * ck_main is made of (needed by vimz_decider_verify; part of vimz_decider_vk).  The Groth16 trapdoor comes from the OS's randomness and is forgotten
+ * (a locally trusted setup; seeded test setups exist only in libvimz_hip_testing.so).  seconds (optional) = {circuit synthesis, QAP evaluation at
+ * the trapdoor, key points on the GPU, total} */
+int vimz_decider_setup(vimz_cf* prover, const uint64_t kzg_vk_g2[16], vimz_decider** out, double seconds[4]);
 void vimz_decider_free(vimz_decider* d);
-/* info = {constraints, wires, public inputs (i, z_0, z_i, h_inst), domain size, non-zeros of A, B, C, 0} */
+/* info = {constraints, wires, public inputs (36 + 2 len_z), domain size, non-zeros of A, B, C, 0} */
 int vimz_decider_info(const vimz_decider* d, uint64_t info[8]);
-/* the verifying key, canonical words: alpha (G1: x, y), beta, gamma, delta (G2: x.c0, x.c1, y.c0, y.c1), the number of IC points, the IC points;
- * returns the byte size (copies when cap suffices) */
+/* the verifying key — the constants of a contract generated for this circuit — as canonical words: pp_hash (4), len_z (1), alpha (G1: x, y), beta,
+ * gamma, delta (G2: x.c0, x.c1, y.c0, y.c1), the number of IC points, the IC points, KZG G_1 (G1), G_2, VK (G2); returns the byte size (copies
+ * when cap suffices) */
 int64_t vimz_decider_vk(const vimz_decider* d, void* buf, size_t cap);
-/* m: a merged proof of ONE segment over the same prover (U_{i+1} = NIFS.V(U_i, u_i), vimz_cf_merged_create); kzg = {c_W, c_E, e_W, e_E} canonical (the
- * challenges and evaluations of vimz_cf_merged_kzg_open the same calldata carries).  public_out: the public inputs (info[2] canonical elements);
- * proof_out: A.x, A.y, B.x.c0, B.x.c1, B.y.c0, B.y.c1, C.x, C.y canonical.  VIMZ_ERR_UNSAT when the proof does not satisfy the decider's statement.
- * seconds (optional) = {witness + sparse products on the host, NTTs, multi-scalar multiplications, total} */
-int vimz_decider_prove(vimz_decider* d, vimz_cf_merged* m, const uint64_t kzg[16], uint64_t* public_out, uint64_t proof_out[32], double seconds[4]);
+/* Decider::prove for the IVC proof `ivc` holds (same shapes and keys as the decider's prover; left unchanged; at least one step): final fold, KZG
+ * openings, Groth16 proof.  words_out: the 25 calldata words (vimz_amd/calldata.py names them), public_out: the info[2] public inputs; canonical,
+ * 4 little-endian limbs each.  VIMZ_ERR_UNSAT when the proof does not satisfy the decider's statement.
+ * seconds (optional) = {final fold + KZG openings, witness + sparse products on the host, NTTs, multi-scalar multiplications, total, 0} */
+int vimz_decider_prove(vimz_decider* d, vimz_cf* ivc, uint64_t* public_out, uint64_t words_out[100], double seconds[6]);
+/* Decider::verify (verify_final_proof, decider.rs:31-50): the checks of contracts/ContrastVerifier.sol:685-783 on (steps, z_0, z_i, 25 words).
+ * *result = 0: accepted; else bits: 1 fewer than two steps, 2 KZG opening of cmW, 4 of cmE, 8 Groth16, 16 a word pair is not a curve point. */
+int vimz_decider_verify(const vimz_decider* d, uint64_t steps, const uint64_t* z0, const uint64_t* zi, const uint64_t words[100], uint32_t* result);
+/* the same against a key given as words (vimz_decider_vk's layout): no context, no GPU */
+int vimz_decider_verify_key(const uint64_t* key_words, size_t n_key_words, uint64_t steps, const uint64_t* z0, const uint64_t* zi, uint32_t len_z,
+                            const uint64_t words[100], uint32_t* result);
 
 /* ---- ONE proof object out of several row segments: the "host-side sequential final fold" of BASELINE.json's north_star for IVC proofs.
  *      fold_input returns ONE RecursiveSNARK (vimz/src/nova_snark_backend/folding.rs:27-43); row segments of an image folded

@@ -40,6 +40,10 @@ int vimz_strict_bits_selfcheck(int field, int values, uint64_t out[8]);
 /* the negative test of the compressed proof's public-slot binding (tests/test_gpu_compress.py): while on, vimz_ivc_compress plays a cheating
  * prover that claims x0 + 1 for the last fresh instance and hides the difference under the generator of that wire's slot */
 void vimz_test_forge_public_slot(int on);
+/* deterministic TEST setups of the decider path (vimz_kzg_setup / vimz_decider_setup with the toxic waste derived from `seed`: anyone who knows the
+ * seed can forge) — for reproducible keys in tests and benchmarks only */
+int vimz_testing_kzg_setup_seeded(vimz_ctx* ctx, const uint8_t* seed, size_t seed_len, size_t n, vimz_bases** srs_out, uint64_t vk_g2_out[16]);
+int vimz_testing_decider_setup_seeded(vimz_cf* prover, const uint64_t kzg_vk_g2[16], const uint8_t* seed, size_t seed_len, vimz_decider** out, double seconds[4]);
 
 #ifdef __cplusplus
 }

@@ -263,18 +263,6 @@ def test_kzg_openings_of_a_cyclefold_proof_over_an_srs(ctx, oracle):
                 lhs = oracle.curve_mul(0, proof, (tau - z) % r)
                 rhs = oracle.curve_add(0, comm, oracle.curve_mul(0, G, (r - ev) % r))
                 assert lhs == rhs, (which, z)
-        # the decider's words that do not come from its Groth16 prover (vimz_amd/calldata.py::decider_words): the final fold
-        # U_{i+1} = NIFS(U_i, u_i) and the KZG openings of U_{i+1}'s commitments, in the 25-word layout of the on-chain verifiers
-        from vimz_amd import calldata
-        words, (cW1, cE1) = calldata.decider_words(cf)
-        u = from_limbs(cf.export(0, hip.IX_FRESH_INSTANCE))
-        assert words[0:4] == U[0:4] and words[4:6] == u[0:2] and all(words[k] is None for k in calldata.GROTH16_WORDS)
-        rr, cmT = words[8], (words[6], words[7])
-        assert cW1 == oracle.curve_add(0, (U[0], U[1]), oracle.curve_mul(0, (u[0], u[1]), rr))
-        assert cE1 == oracle.curve_add(0, (U[2], U[3]), oracle.curve_mul(0, cmT, rr))
-        for k, comm in enumerate((cW1, cE1)):
-            ch, ev, proof = words[17 + k], words[19 + k], (words[21 + 2 * k], words[22 + 2 * k])
-            assert oracle.curve_mul(0, proof, (tau - ch) % r) == oracle.curve_add(0, comm, oracle.curve_mul(0, G, (r - ev) % r))
         assert cf.verify(4, z0) == 0                         # (the prover is left as it was)
     finally:
         cf.close(); B.free(); ck2.free()

@@ -1,12 +1,11 @@
-"""The decider of the Nova + CycleFold path (vimz_decider_*, vimz_amd/csrc/groth16.hip, aug/decider.hpp): `Decider::preprocess` / `prove` of the
-reference's Sonobe backend (vimz/src/sonobe_backend/mod.rs:72-78, decider.rs:13-21) — Groth16 over BN254 for OUR statement of the final fold, with a
-deterministic test setup.  The verifier here is the oracle-side pairing (tests/_pairing.py: what the EVM's precompile behind contracts/*Verifier.sol
-computes): it accepts the proof for exactly the public inputs the 25 calldata words imply, and nothing else."""
+"""The decider of the Nova + CycleFold path (vimz_kzg_setup, vimz_decider_*; vimz_amd/csrc/groth16.hip, aug/decider.hpp, pairing.hpp): `Decider::preprocess` /
+`prove` / `verify` of the reference's Sonobe backend (vimz/src/sonobe_backend/mod.rs:72-80, decider.rs:13-50).  The checker is tests/_novadecider.py —
+the restatement of contracts/*Verifier.sol that the CPU suite pins on the reference's six committed proofs: with THIS library's verifying key as the
+contract's constants it must accept THIS library's 25 words, and reject each changed word.  The product's own verifier (vimz_decider_verify) must agree."""
 import numpy as np
 import pytest
 
-from tests import _pairing as bp
-from tests._oracle import from_limbs
+from tests import _novadecider as nd
 from tests.test_circuits import step_inputs
 from vimz_amd import _lib, calldata
 from vimz_amd.circuit import Circuit
@@ -22,95 +21,120 @@ def ctx():
     c.close()
 
 
-def _limbs64(v):
-    return [(v >> (64 * k)) & 0xFFFFFFFFFFFFFFFF for k in range(4)]
-
-
-def test_groth16_proof_of_the_final_fold_fills_the_calldata_and_the_pairing_check_accepts_it(ctx, oracle):
-    from tests import _cyclefold as cfo
-    from tests._oracle import T_HASH
+def _prove_and_check(ctx, oracle, op, n_srs, steps, z0, inputs, t_oracle=None, full_negative=False):
     from vimz_amd import hip
-    c = Circuit.for_resolution("hash", "HD")
-    ck1 = ctx.bases_generate(_lib.CURVE_BN254_G1, 1 << 16)
+    c = Circuit.for_resolution(op, "HD")
+    srs, kzg_vk = hip.kzg_setup(ctx, n_srs)
     ck2 = ctx.bases_generate(_lib.CURVE_GRUMPKIN, 1 << 13, b"ck-cyclefold")
-    z0, inputs = step_inputs("hash")
-    cf = hip.CycleFoldIVC(ctx, c, ck1, ck2, max_batch=2)
+    cf = hip.CycleFoldIVC(ctx, c, srs, ck2, max_batch=2)
     dec = None
     try:
-        cf.reset(z0); cf.fold(np.stack(inputs[:4]))
-        assert cf.verify(4, z0) == 0
-        dec = hip.Decider(cf, seed=b"test setup, not a ceremony")
-        info = dec.info()
-        ci = cf.info()
-        # the circuit: the relaxed R1CS of F' + step circuit row by row (one or two constraints a row), two Horner chains, five hashes
-        assert info["public_inputs"] == 2 * c.len_z + 2
+        cf.reset(z0); cf.fold(np.stack(inputs[:steps]))
+        assert cf.verify(steps, z0) == 0
+        dec = hip.Decider(cf, kzg_vk=kzg_vk)
+        info, ci = dec.info(), cf.info()
+        lz = c.len_z
+        assert info["public_inputs"] == 36 + 2 * lz          # the contract's layout: pp_hash, i, z_0, z_i, 4 x 5 limbs, 4 scalars, 2 x 5 limbs
         assert ci["main_constraints"] + ci["main_wires"] < info["constraints"] < 3 * ci["main_constraints"] + ci["main_wires"] + 20000
         assert info["domain"] >= info["constraints"] + info["public_inputs"] + 1 and info["domain"] & (info["domain"] - 1) == 0
-        words, (cW1, cE1), pub = calldata.decider_words(cf, decider=dec)
-        assert all(isinstance(w, int) for w in words)
-        # the statement the public inputs make: (i, z_0, z_i) and the hash that binds the other words
-        z = list(z0)
-        for i in range(4):
-            ok, z = oracle.step_eval(T_HASH, z, inputs[i])
-        lz = c.len_z
-        assert pub[0] == 4 and pub[1:1 + lz] == [int(x) for x in z0] and pub[1 + lz:1 + 2 * lz] == z
-        dg = cfo.shape_digest(cf)
-        pts = [(words[0], words[1]), (words[2], words[3]), (words[4], words[5]), (words[6], words[7]), cW1, cE1]
-        # (U_{i+1}'s commitments are what the contract computes itself: U_i.cm + rho·(u_i.cmW | cmT))
-        assert cW1 == oracle.curve_add(0, pts[0], oracle.curve_mul(0, pts[2], words[8])) and cE1 == oracle.curve_add(0, pts[1], oracle.curve_mul(0, pts[3], words[8]))
-        h_in = [dg, words[8]]
-        for x, y in pts:
-            h_in += _limbs64(x) + _limbs64(y)
-        h_in += [words[17], words[18], words[19], words[20]]
-        assert pub[-1] == oracle.nova_hash(0, h_in)
-        # Groth16: e(A, B) = e(alpha, beta) · e(sum x_i IC_i, gamma) · e(C, delta)
-        vk = dec.verifying_key()
-        assert len(vk["ic"]) == len(pub) + 1
-        A, C = (words[9], words[10]), (words[15], words[16])
-        B = ((words[12], words[11]), (words[14], words[13]))          # the calldata carries the imaginary parts first
-        assert bp.g1_on_curve(A) and bp.g1_on_curve(C) and bp.g2_on_curve(B)
-        assert bp.groth16_verify(vk, pub, (A, B, C))
-        # another statement, another word, another proof element: rejected
-        assert not bp.groth16_verify(vk, [pub[0] + 1] + pub[1:], (A, B, C))
-        assert not bp.groth16_verify(vk, pub[:-1] + [(pub[-1] + 1) % bp.R], (A, B, C))
-        assert not bp.groth16_verify(vk, pub, (A, B, bp.g1_add(C, bp.G1)))
-        # the 25 words travel in the reference's calldata layout
-        raw = calldata.encode(4, z0, z, words)
-        d = calldata.decode(raw)
-        assert d["proof"] == words and d["steps"] == 4
-        assert cf.verify(4, z0) == 0                         # (the prover is left as it was)
-        # the same proof again is the same proof (deterministic randomizers), a further step gives another
-        words2, _, pub2 = calldata.decider_words(cf, decider=dec)
-        assert words2 == words and pub2 == pub
+        raw, d = calldata.decider_calldata(dec)
+        words, pub = d["words"], d["public_inputs"]
+        # the statement: (i, z_0, z_i) as the oracle's step function gives them
+        if t_oracle is not None:
+            z = list(z0)
+            for i in range(steps):
+                ok, z = oracle.step_eval(t_oracle, z, inputs[i])
+            assert d["steps"] == steps and d["z0"] == [int(x) for x in z0] and d["z_i"] == z
+        assert len(raw) == 4 + 32 * (1 + 2 * lz + 25) and calldata.decode(raw)["proof"] == words
+        # the restated contract, with this library's key as its constants
+        key = dec.verifying_key()
+        assert key["len_z"] == lz and len(key["groth16"]["ic"]) == len(pub) + 1
+        pub_contract, cmW, cmE = nd.public_inputs(key, d["steps"], d["z0"], d["z_i"], words)
+        assert pub_contract == pub                             # the prover's public inputs are the ones the contract assembles from the words
+        assert words[8] >> 128 == 1                            # r = 2^128 + 128 bits, as F' derives its challenges
+        assert nd.verify(key, d["steps"], d["z0"], d["z_i"], words) == (True, "ok")
+        assert nd.verify_calldata({"k": key}, "k", raw) == (True, "ok")
+        assert dec.verify(d["steps"], d["z0"], d["z_i"], words) == 0
+        from vimz_amd.hip import decider_verify_key
+        assert decider_verify_key(dec.key_words(), d["steps"], d["z0"], d["z_i"], words) == 0
+        # a changed statement or word: rejected by the restated contract and, for the same reason, by the product
+        q, r = nd.bp.Q, nd.bp.R
+        cases = [("steps", 8), ("z_i", 8), ("eval_W", 2), ("neg_proof_E", 4), ("neg_C", 8), ("r", 6)]
+        if full_negative:
+            cases += [("z0", 8), ("eval_E", 4), ("challenge_W", 2 | 8), ("neg_cmT", 4 | 8), ("neg_UW", 2 | 8), ("neg_A", 8)]
+        for what, bits in cases:
+            st, a0, ai, w = d["steps"], list(d["z0"]), list(d["z_i"]), list(words)
+            if what == "steps": st += 1
+            elif what == "z_i": ai[-1] = (ai[-1] + 1) % r
+            elif what == "z0": a0[0] = (a0[0] + 1) % r
+            elif what == "eval_W": w[19] = (w[19] + 1) % r
+            elif what == "eval_E": w[20] = (w[20] + 1) % r
+            elif what == "challenge_W": w[17] = (w[17] + 1) % r
+            elif what == "neg_proof_E": w[24] = q - w[24]
+            elif what == "neg_C": w[16] = q - w[16]
+            elif what == "neg_A": w[10] = q - w[10]
+            elif what == "neg_cmT": w[7] = q - w[7]
+            elif what == "neg_UW": w[1] = q - w[1]
+            elif what == "r": w[8] += 1
+            got = dec.verify(st, a0, ai, w)
+            ok, why = nd.verify(key, st, a0, ai, w)
+            assert not ok and got != 0, what
+            # the restated contract stops at its first failing `require`; the product reports every failing check
+            first = {"KZG: verifying proof for challenge W": 2, "KZG: verifying proof for challenge E": 4, "Groth16": 8}
+            assert any(why.startswith(k) and (got & v) for k, v in first.items()), (what, why, got)
+            assert got & bits, (what, got)
+        w = list(words); w[0] ^= 1                               # off the curve: the precompile reverts / the product says malformed
+        assert dec.verify(d["steps"], d["z0"], d["z_i"], w) & 16 and nd.verify(key, d["steps"], d["z0"], d["z_i"], w)[1].startswith("precompile reverted")
+        assert dec.verify(1, d["z0"], d["z_i"], words) & 1
+        assert cf.verify(steps, z0) == 0                         # (the prover is left as it was)
+        # a second proof of the same statement: other blinding, same public inputs, accepted
+        words2, pub2, _ = dec.prove()
+        assert pub2 == pub and words2[:9] == words[:9] and words2[17:] == words[17:] and words2[9:17] != words[9:17]
+        assert dec.verify(d["steps"], d["z0"], d["z_i"], words2) == 0
+        return info, d["seconds"], dec.setup_seconds
     finally:
         if dec is not None:
             dec.close()
-        cf.close(); ck1.free(); ck2.free()
+        cf.close(); srs.free(); ck2.free()
 
 
-def test_decider_refuses_a_proof_that_does_not_satisfy_its_statement(ctx, oracle):
-    """Wrong KZG evaluations (the e_W the calldata would carry is not p(c_W)): vimz_decider_prove reports UNSAT instead of proving a false statement."""
+def test_decider_words_are_accepted_by_the_restated_contract_hash_step(ctx, oracle):
+    from tests._oracle import T_HASH
+    z0, inputs = step_inputs("hash")
+    _prove_and_check(ctx, oracle, "hash", 36000, 4, z0, inputs, t_oracle=T_HASH, full_negative=True)
+
+
+def test_decider_at_contrast_hd(ctx, oracle):
+    """BASELINE.json's headline circuit: contrast HD (1.04 M decider constraints, domain 2^20, SRS of 2^19 powers made on the GPU)."""
+    from tests._oracle import T_CONTRAST
+    z0, inputs = step_inputs("contrast")
+    info, sec, setup = _prove_and_check(ctx, oracle, "contrast", 1 << 19, 3, z0, inputs, t_oracle=T_CONTRAST)
+    assert info["constraints"] > 1_000_000 and info["domain"] == 1 << 20
+
+
+def test_decider_refuses_other_shapes_and_a_prover_without_steps(ctx):
     from vimz_amd import hip
     c = Circuit.for_resolution("hash", "HD")
-    ck1 = ctx.bases_generate(_lib.CURVE_BN254_G1, 1 << 16)
+    srs, kzg_vk = hip.kzg_setup(ctx, 36000)
     ck2 = ctx.bases_generate(_lib.CURVE_GRUMPKIN, 1 << 13, b"ck-cyclefold")
     z0, inputs = step_inputs("hash")
-    cf = hip.CycleFoldIVC(ctx, c, ck1, ck2, max_batch=2)
-    dec = m = None
+    cf = hip.CycleFoldIVC(ctx, c, srs, ck2, max_batch=2)
+    dec = nokey = None
     try:
-        cf.reset(z0); cf.fold(np.stack(inputs[:2]))
-        dec = hip.Decider(cf, seed=b"s")
-        m = hip.CycleFoldMerged(cf)
-        ev, _ = m.kzg_open(0, 12345)
-        ev2, _ = m.kzg_open(1, 6789)
-        pub, proof, _ = dec.prove(m, (12345, 6789, ev, ev2))
-        assert bp.groth16_verify(dec.verifying_key(), pub, proof)
-        with pytest.raises(_lib.VimzError) as e:
-            dec.prove(m, (12345, 6789, (ev + 1) % _lib.MODULUS[0], ev2))
-        assert e.value.code == _lib.ERR_UNSAT
+        cf.reset(z0)
+        dec = hip.Decider(cf, kzg_vk=kzg_vk)
+        with pytest.raises(_lib.VimzError):
+            dec.prove()                                          # no steps
+        nokey = hip.Decider(cf)
+        cf.fold(np.stack(inputs[:2]))
+        words, pub, _ = nokey.prove()
+        with pytest.raises(_lib.VimzError):
+            nokey.verify(2, pub[2:3], pub[3:4], words)           # set up without the SRS's verifying key
+        bad = np.array(kzg_vk); bad[0, 0] ^= 1
+        with pytest.raises(_lib.VimzError):
+            hip.Decider(cf, kzg_vk=bad)                          # not a point of G2
     finally:
-        if m is not None:
-            m.close()
-        if dec is not None:
-            dec.close()
-        cf.close(); ck1.free(); ck2.free()
+        for o in (dec, nokey):
+            if o is not None:
+                o.close()
+        cf.close(); srs.free(); ck2.free()

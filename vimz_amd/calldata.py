@@ -12,12 +12,11 @@ uint256[25] proof)` takes (ContrastVerifier.sol:785-810) and marketplace/proofs/
 
 What this module is and is not.  The statement part — selector, steps, z_0, z_i — is the SAME for every backend: the GPU prover's
 (steps, z_0, z_n) for an image are bit-identical to the committed proofs' (tests/test_gpu_fold.py, tests/test_gpu_merge.py pin that
-on marketplace/proofs).  The 25 proof words are Sonobe's Nova+CycleFold instance commitments over a KZG SRS drawn from
-`StdRng::from_seed([41; 32])` (sonobe_backend/mod.rs:54) and a Groth16 decider proof: they cannot be produced without that SRS and
-the decider circuit's proving key, neither of which exists in this repository or image.  So `encode` takes the 25 words from the
-caller; this library's own proofs (vimz_ivc_*, vimz_ivc_merge*, vimz_cf_*) are NOT accepted by those contracts.  `decider_words` fills the 17
-words that do not come from the Groth16 prover for a proof of this library's Nova + CycleFold scheme: what of
-`Decider::prove` the GPU pipeline covers — the final fold and the KZG openings —, in our protocol's values.
+on marketplace/proofs).  The 25 proof words of the COMMITTED proofs are Sonobe's Nova+CycleFold instance commitments over a KZG SRS drawn
+from `StdRng::from_seed([41; 32])` (sonobe_backend/mod.rs:54) and a Groth16 proof under Sonobe's decider key: they cannot be reproduced
+without those keys.  This library's decider (vimz_decider_*, vimz_amd.hip.Decider) fills the same 25 words for ITS circuit and ITS keys,
+with the public-input layout of the reference's contracts: a contract generated from the reference's template with this library's
+verifying key as constants accepts them — which tests/_novadecider.py (the restated contract, pinned on the six committed proofs) checks.
 """
 
 MASK64 = (1 << 64) - 1
@@ -74,60 +73,17 @@ WORD_NAMES = ["U_i.cmW.x", "U_i.cmW.y", "U_i.cmE.x", "U_i.cmE.y", "u_i.cmW.x", "
 G1_POINTS = [(0, 1), (2, 3), (4, 5), (6, 7), (9, 10), (15, 16), (21, 22), (23, 24)]      # word indices of the BN254 G1 points
 
 
-GROTH16_WORDS = list(range(9, 17))      # the eight words of the decider's Groth16 proof (decider_words(..., decider=...) fills them)
+GROTH16_WORDS = list(range(9, 17))      # the eight words of the decider's Groth16 proof
 
 
-def decider_public_hash_inputs(words):
-    """The values h_inst binds (vimz_amd/csrc/aug/decider.hpp), in its order, from the 25 words: rho, then the six commitments' 64-bit limbs
-    (U_i.cmW, U_i.cmE, u_i.cmW, cmT, and U_{i+1}.cmW / cmE which the verifier computes itself), then the four KZG scalars."""
-    return {"rho": words[8], "points": [(words[0], words[1]), (words[2], words[3]), (words[4], words[5]), (words[6], words[7])], "kzg": [words[17], words[18], words[19], words[20]]}
-
-
-def decider_words(cf_prover, decider=None):
-    """The 17 of the 25 proof words that do not come out of the Groth16 prover — and, given a vimz_amd.hip.Decider set up over the same
-    prover, the eight that do (then also returns its public inputs as a third value) —, for a Nova + CycleFold proof made by `cf_prover`
-    (vimz_amd.hip.CycleFoldIVC, its commitment key being the KZG SRS's powers) — in THIS library's protocol, so a statement of
-    what the GPU pipeline covers of `Decider::prove` (vimz/src/sonobe_backend/decider.rs:13-21), not bytes a contract generated for Sonobe accepts:
-        U_i.cmW, U_i.cmE, u_i.cmW                       the running and the last instance's commitments
-        cmT, r                                          the decider's final fold U_{i+1} = NIFS(U_i, u_i): cross-term commitment and challenge
-        kzg.challenge / eval / proof (W, E)             openings of U_{i+1}'s two commitments at challenges derived from them
-    Returns a list of 25 entries (ints; None in the Groth16 slots) and the folded commitments (U_{i+1}.cmW, U_{i+1}.cmE)."""
-    import hashlib
-    import numpy as np
-    from . import _lib
-    from .hip import CycleFoldMerged, IX_INSTANCE
-    r_mod = _lib.MODULUS[0]
-    m = CycleFoldMerged(cf_prover)              # one segment: acc = U_i (+) u_i
-    try:
-        w = [int(x) for x in m.records()]
-        lz = w[2]
-        pos = 8 + w[7] + 1 + 8 * lz               # header, run starts, n, z_start, z_end
-        el = lambda k: sum(w[pos + 4 * k + q] << (64 * q) for q in range(4))
-        U, u = [el(k) for k in range(7)], [el(7 + k) for k in range(4)]
-        T2 = (el(7 + 4 + 12 + 2), el(7 + 4 + 12 + 3))
-        folded = [sum(int(a[q]) << (64 * q) for q in range(4)) for a in np.asarray(m.export(0, IX_INSTANCE))]
-        # r as the merge derives it: recomputed by the verifier from the records (cyclefold_merge.hip: cfm_challenges); taken from u' - U.u here
-        r = (folded[4] - U[4]) % r_mod
-        words = [None] * PROOF_WORDS
-        words[0:4] = U[0:4]
-        words[4:6] = u[0:2]
-        words[6:8] = list(T2)
-        words[8] = r
-        for k, which in enumerate((0, 1)):
-            comm = (folded[2 * which], folded[2 * which + 1])
-            ch = int.from_bytes(hashlib.sha3_256(b"vimz-kzg-challenge" + comm[0].to_bytes(32, "little") + comm[1].to_bytes(32, "little")).digest(), "little") % r_mod
-            ev, proof = m.kzg_open(which, ch)
-            words[17 + k], words[19 + k] = ch, ev
-            words[21 + 2 * k], words[22 + 2 * k] = proof
-        if decider is not None:      # Decider::prove: the Groth16 proof of the final fold (A; B with the imaginary parts first, as the EVM's precompile takes G2; C)
-            pub, (A, B, Cp), _ = decider.prove(m, (words[17], words[18], words[19], words[20]))
-            words[9:11] = list(A)
-            words[11:15] = [B[0][1], B[0][0], B[1][1], B[1][0]]
-            words[15:17] = list(Cp)
-            return words, ((folded[0], folded[1]), (folded[2], folded[3])), pub
-        return words, ((folded[0], folded[1]), (folded[2], folded[3]))
-    finally:
-        m.close()
+def decider_calldata(decider, ivc=None):
+    """`Decider::prove` + `prepare_contract_calldata` (vimz/src/sonobe_backend/mod.rs:76-78, solidity.rs:13-27) for the IVC proof `ivc` (default: the
+    prover `decider` — a vimz_amd.hip.Decider — was set up over) holds: (calldata bytes, {steps, z0, z_i, words, public_inputs, seconds})."""
+    ivc = decider.prover if ivc is None else ivc
+    words, pub, sec = decider.prove(ivc)
+    lz = ivc.len_z if hasattr(ivc, "len_z") else (len(pub) - 36) // 2
+    steps, z0, z_i = pub[1], pub[2:2 + lz], pub[2 + lz:2 + 2 * lz]
+    return encode(steps, z0, z_i, words), {"steps": steps, "z0": z0, "z_i": z_i, "words": words, "public_inputs": pub, "seconds": sec}
 
 
 def selector(len_z):

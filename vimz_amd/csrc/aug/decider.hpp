@@ -1,42 +1,64 @@
 // The decider circuit of the Nova + CycleFold path — the statement the reference's Sonobe backend proves with Groth16 before it goes on
 // chain (`DeciderEth<.., Groth16<Bn254>, ..>`, vimz/src/sonobe_backend/decider.rs:13-21; `Decider::prove`, mod.rs:72-78; checked by
-// contracts/*Verifier.sol:785-810).  Sonobe (folding-schemes @ d312916) is not vendored, so — like F' and the CycleFold circuit (aug/cyclefold.hpp) —
-// this is OUR statement of the construction its documentation describes, parity unpinned: what the on-chain decider's SNARK attests about the
-// final fold U_{i+1} = NIFS.V(U_i, u_i) of an IVC proof (U_i, u_i, cfU_i) for the statement (i, z_0, z_i):
+// contracts/*Verifier.sol:685-810).  Sonobe (folding-schemes @ d312916) is not vendored, so the CONSTRAINTS are our statement of the construction
+// its documentation describes; the PUBLIC-INPUT LAYOUT is the contract's, word for word (ContrastVerifier.sol:700-772; restated and pinned on the
+// six committed proofs in tests/_novadecider.py), so that a contract generated for this circuit's key has the reference's interface:
 //
-//   public inputs   i, z_0, z_i, h_inst
-//                   h_inst = H(dg, rho, U_i.cmW, U_i.cmE, u_i.cmW, cmT, U_{i+1}.cmW, U_{i+1}.cmE, c_W, c_E, e_W, e_E) binds the words the contract sees
-//                   (commitments as 64-bit limbs): the verifier recomputes it from the calldata and checks U_{i+1}.cm* = U_i.cm* + rho·(u_i.cmW | cmT)
-//                   with the curve precompiles, the two KZG openings with the pairing precompile, and this proof with the pairing precompile
+//   public inputs   pp_hash, i, z_0, z_i,                                                        (pp_hash = dg, the digest of both shapes)
+//                   U_{i+1}.cmW.x, .y, U_{i+1}.cmE.x, .y   as 5 limbs of 55 bits each, little end first (LimbsDecomposition, :632-640),
+//                   c_W, c_E, e_W, e_E,                                                           (KZG challenges and evaluations)
+//                   cmT.x, cmT.y                           as 5 limbs of 55 bits each
+//                   The contract computes U_{i+1}.cmW = U_i.cmW + r·u_i.cmW and U_{i+1}.cmE = U_i.cmE + r·cmT itself from the calldata words
+//                   (curve precompiles), checks the two KZG openings and this proof (pairing precompile).
 //   1. u_i.x0 = H(H(dg, i, z_0, z_i), U_i)  and  u_i.x1 = H(dg, cfU_i)         the hashes the last instance of F' carries (aug/cyclefold.hpp)
-//   2. rho < 2^128;  u' = U.u + rho,  x' = U.x + rho·u_i.x                      NIFS.V on the scalars (the challenge itself is derived by the
-//                                                                              verifier from the transcript of the records, outside)
+//   2. r = 2^128 + low128(H(u_i.x0, limbs64(u_i.cmW), u_i.x0, u_i.x1, limbs64(cmT)))          the challenge of the final fold, derived in the circuit by
+//                                                                              the transcript F' uses for its own folds (cf_challenge_main); cmT's
+//                                                                              64-bit limbs are tied to the public 55-bit limbs bit by bit
+//      u' = U.u + r,  x' = U.x + r·u_i.x                                       NIFS.V on the scalars
 //   3. (A·Z)∘(B·Z) = u'·(C·Z) + E   for Z = (u', W', x0', x1')                  the folded main instance satisfies F' ∪ step circuit, row by row
-//   4. e_W = Σ_j W'_j c_W^j,  e_E = Σ_k E_k c_E^k                               the evaluations the two KZG openings are about
-// The CycleFold instance cfU_i is bound through its hash (1) and checked outside the circuit (vimz_cf_verify: its relaxed relation over Fq);
-// Sonobe's circuit checks it in non-native arithmetic.
+//   4. c_W = H(dg, limbs55(U_{i+1}.cmW)),  c_E = H(dg, limbs55(U_{i+1}.cmE))    the KZG challenges follow from the commitments they open
+//      e_W = Σ_j W'_j c_W^j,  e_E = Σ_k E_k c_E^k                               the evaluations the two KZG openings are about
+// What the circuit does NOT attest (README): (a) the CycleFold instance cfU_i is bound through its hash (1) only — its relaxed
+// relation over Fq is checked outside (vimz_cf_verify), where Sonobe's circuit checks it in non-native arithmetic; (b) as in the contract's
+// layout, U_i's and u_i's commitments are private here: the calldata's copies are tied to this proof only through U_{i+1}'s commitments.
 #pragma once
 #include "cyclefold.hpp"
 
 namespace vz {
 namespace aug {
 
+constexpr int DEC_LIMBS = 5, DEC_LIMB_BITS = 55;      // LimbsDecomposition of contracts/*Verifier.sol (:632-640)
 struct DeciderIn {
   CfFr digest; uint64_t i = 0; std::vector<CfFr> z0, zi;
   CfMainRelaxed U; CfMainFresh u; CfRelaxed cfU;
-  uint32_t r_low[4] = {0, 0, 0, 0};            // rho: the 128-bit challenge of the final fold (cyclefold_merge.hip: chal 'b')
-  NnPoint cmT, Wn, En;                         // cross-term commitment, folded commitments
-  CfFr cW, cE, eW, eE;                         // KZG challenges and evaluations
+  NnPoint cmT, Wn, En;                         // cross-term commitment of the final fold, folded commitments U_{i+1}.cmW / cmE
+  CfFr eW, eE;                                 // KZG evaluations (the challenges follow from Wn, En: decider_kzg_challenge)
   const CfFr* Wf = nullptr; const CfFr* Ef = nullptr;      // folded witness (wires 1 .. n_wires-3 of Z) and error vector; nullptr in shape mode
 };
 
-inline CfFr decider_rho(const uint32_t low[4]) { CfFr c = CfFr::zero(); for (int k = 0; k < 4; k++) c.v[k] = low[k]; return CfFr::to_mont(c); }      // the final fold's 128-bit challenge
-inline CfFr decider_instance_hash(const DeciderIn& in) {
-  std::vector<CfFr> h = {in.digest, decider_rho(in.r_low)};
-  for (const NnPoint* p : {&in.U.W, &in.U.E, &in.u.W, &in.cmT, &in.Wn, &in.En}) { cf_push_limbs(p->x, h); cf_push_limbs(p->y, h); }
-  h.push_back(in.cW); h.push_back(in.cE); h.push_back(in.eW); h.push_back(in.eE);
+inline void decider_limbs55(const U256w& v, uint64_t out[DEC_LIMBS]) {
+  for (int k = 0; k < DEC_LIMBS; k++) {
+    const int lo = DEC_LIMB_BITS * k, wi = lo >> 6, sh = lo & 63;
+    uint64_t x = v.w[wi] >> sh;
+    if (sh && wi + 1 < 4) x |= v.w[wi + 1] << (64 - sh);
+    out[k] = x & ((1ull << DEC_LIMB_BITS) - 1);
+  }
+}
+// the final fold's challenge as F' would derive it for this pair (cf_challenge_main with h_U = u.x0): low 128 bits; r = 2^128 + low
+inline void decider_challenge(const CfMainFresh& u, const NnPoint& cmT, uint32_t low[4]) {
+  CfChallenges c; c.h_U = u.x0;
+  cf_challenge_main(c, u, cmT);
+  memcpy(low, c.r, 16);
+}
+// c = H(dg, limbs55(P.x), limbs55(P.y)): the KZG challenge for the opening of commitment P
+inline CfFr decider_kzg_challenge(const CfFr& dg, const NnPoint& P) {
+  std::vector<CfFr> h = {dg};
+  uint64_t l[DEC_LIMBS];
+  decider_limbs55(P.x, l); for (int k = 0; k < DEC_LIMBS; k++) h.push_back(cb::f_from_u64<CfFr>(l[k]));
+  decider_limbs55(P.y, l); for (int k = 0; k < DEC_LIMBS; k++) h.push_back(cb::f_from_u64<CfFr>(l[k]));
   return hash_native<BnFr>(h);
 }
+inline uint32_t decider_n_public(uint32_t len_z) { return 2 + 2 * len_z + 4 * DEC_LIMBS + 4 + 2 * DEC_LIMBS; }
 
 // shape mode (cs.b set): appends the circuit to cs.b, public inputs first;  witness mode: cs.w = the assignment after wire 0
 inline void synthesize_decider(CS<BnFr>& cs, const cb::BuilderT<CfFr>& main, uint32_t len_z, const DeciderIn& in) {
@@ -45,34 +67,37 @@ inline void synthesize_decider(CS<BnFr>& cs, const cb::BuilderT<CfFr>& main, uin
   typedef cb::LCT<F> LC;
   const bool shape = cs.shape();
   const uint32_t nw = main.n_wires, nc = main.n_constraints();
-  // ---- public inputs: i, z_0, z_i, h_inst -------------------------------------------------------------------------------------------
+  // ---- public inputs, in the contract's order -------------------------------------------------------------------------------------------
+  struct L55 { N l[DEC_LIMBS]; };
+  auto alloc55 = [&](const U256w& v) { L55 r; uint64_t l[DEC_LIMBS]; decider_limbs55(v, l); for (int k = 0; k < DEC_LIMBS; k++) r.l[k] = cs.alloc(cb::f_from_u64<F>(l[k])); return r; };
+  N dg = cs.alloc(in.digest);
   N iN = cs.alloc(cb::f_from_u64<F>(in.i));
   std::vector<N> z0(len_z), zi(len_z);
   for (uint32_t k = 0; k < len_z; k++) z0[k] = cs.alloc(k < in.z0.size() ? in.z0[k] : F::zero());
   for (uint32_t k = 0; k < len_z; k++) zi[k] = cs.alloc(k < in.zi.size() ? in.zi[k] : F::zero());
-  N h_pub = cs.alloc(shape ? F::zero() : decider_instance_hash(in));
+  L55 WnX = alloc55(in.Wn.x), WnY = alloc55(in.Wn.y), EnX = alloc55(in.En.x), EnY = alloc55(in.En.y);
+  const F cWv = shape ? F::zero() : decider_kzg_challenge(in.digest, in.Wn), cEv = shape ? F::zero() : decider_kzg_challenge(in.digest, in.En);
+  N cW = cs.alloc(cWv), cE = cs.alloc(cEv), eW = cs.alloc(in.eW), eE = cs.alloc(in.eE);
+  L55 TX = alloc55(in.cmT.x), TY = alloc55(in.cmT.y);
   // ---- private inputs ----------------------------------------------------------------------------------------------------------------
   struct NnVar { N x[4], y[4]; };
   auto nn_alloc = [&](const NnPoint& p) { NnVar r; for (int j = 0; j < 4; j++) r.x[j] = cs.alloc(cb::f_from_u64<F>(p.x.w[j])); for (int j = 0; j < 4; j++) r.y[j] = cs.alloc(cb::f_from_u64<F>(p.y.w[j])); return r; };
   auto push_nn = [](std::vector<N>& h, const NnVar& p) { for (int j = 0; j < 4; j++) h.push_back(p.x[j]); for (int j = 0; j < 4; j++) h.push_back(p.y[j]); };
-  N dg = cs.alloc(in.digest);
-  NnVar UW = nn_alloc(in.U.W), UE = nn_alloc(in.U.E), uW = nn_alloc(in.u.W), T = nn_alloc(in.cmT), Wn = nn_alloc(in.Wn), En = nn_alloc(in.En);
+  NnVar UW = nn_alloc(in.U.W), UE = nn_alloc(in.U.E), uW = nn_alloc(in.u.W);
   N Uu = cs.alloc(in.U.u), Ux0 = cs.alloc(in.U.x0), Ux1 = cs.alloc(in.U.x1), ux0 = cs.alloc(in.u.x0), ux1 = cs.alloc(in.u.x1);
   N cu = cs.alloc(in.cfU.u);
   N cx[CF_IO][4];
   for (int k = 0; k < CF_IO; k++) for (int j = 0; j < 4; j++) cx[k][j] = cs.alloc(cb::f_from_u64<F>(in.cfU.x[k].w[j]));
   N cWx = cs.alloc(in.cfU.W.x), cWy = cs.alloc(in.cfU.W.y), cEx = cs.alloc(in.cfU.E.x), cEy = cs.alloc(in.cfU.E.y);
-  N cW = cs.alloc(in.cW), cE = cs.alloc(in.cE), eW = cs.alloc(in.eW), eE = cs.alloc(in.eE);
-  F rl = F::zero(); for (int k = 0; k < 4; k++) rl.v[k] = in.r_low[k];
-  N r_lo = cs.alloc(F::to_mont(rl));
   // ---- 1. the hashes the last instance of F' carries ----------------------------------------------------------------------------------
+  N hU;
   {
     std::vector<N> hst = {dg, iN};
     hst.insert(hst.end(), z0.begin(), z0.end());
     hst.insert(hst.end(), zi.begin(), zi.end());
     std::vector<N> hin = {cs.hash(hst), Uu, Ux0, Ux1};
     push_nn(hin, UW); push_nn(hin, UE);
-    N hU = cs.hash(hin);
+    hU = cs.hash(hin);
     cs.enforce_equal(hU, ux0);
     if (!shape && !hU.v.eq(ux0.v)) cs.bad = true;
     std::vector<N> hc = {dg, cu};
@@ -82,19 +107,36 @@ inline void synthesize_decider(CS<BnFr>& cs, const cb::BuilderT<CfFr>& main, uin
     cs.enforce_equal(hcf, ux1);
     if (!shape && !hcf.v.eq(ux1.v)) cs.bad = true;
   }
-  // ---- 2. NIFS.V on the scalars ---------------------------------------------------------------------------------------------------------
-  cs.bits(r_lo, 128);
-  N rho = r_lo;
+  // ---- 2. the final fold's challenge (F''s transcript) and NIFS.V on the scalars -------------------------------------------------------------
+  // cmT's public 55-bit limbs -> its 256 bits -> the four 64-bit limbs the transcript absorbs
+  auto limbs64_of = [&](const L55& p, N out[4]) {
+    std::vector<N> bits;
+    for (int k = 0; k < DEC_LIMBS; k++) { std::vector<N> bk = cs.bits(p.l[k], k + 1 < DEC_LIMBS ? DEC_LIMB_BITS : 256 - DEC_LIMB_BITS * (DEC_LIMBS - 1)); bits.insert(bits.end(), bk.begin(), bk.end()); }
+    for (int j = 0; j < 4; j++) out[j] = cs.pack(bits, 64 * j, 64 * (j + 1));
+  };
+  NnVar T;
+  limbs64_of(TX, T.x); limbs64_of(TY, T.y);
+  std::vector<N> hrin = {hU};
+  push_nn(hrin, uW); hrin.push_back(ux0); hrin.push_back(ux1); push_nn(hrin, T);
+  N hr = cs.hash(hrin);
+  std::vector<N> rb = cs.bits_strict(hr);
+  N rho = cs.add(cs.pack(rb, 0, 128), cs.constant(cb::f_pow2<F>(128)));
   N un = cs.add(Uu, rho);                                   // (u_i.u = 1)
   N x0n = cs.add(Ux0, cs.mul(rho, ux0)), x1n = cs.add(Ux1, cs.mul(rho, ux1));
-  // ---- the instance hash the public input carries --------------------------------------------------------------------------------------
+  // ---- 4a. the KZG challenges follow from the commitments they open ------------------------------------------------------------------------
   {
-    std::vector<N> h = {dg, rho};
-    for (const NnVar* p : {&UW, &UE, &uW, &T, &Wn, &En}) push_nn(h, *p);
-    h.push_back(cW); h.push_back(cE); h.push_back(eW); h.push_back(eE);
-    N hi = cs.hash(h);
-    cs.enforce_equal(hi, h_pub);
-    if (!shape && !hi.v.eq(h_pub.v)) cs.bad = true;
+    std::vector<N> h = {dg};
+    for (int k = 0; k < DEC_LIMBS; k++) h.push_back(WnX.l[k]);
+    for (int k = 0; k < DEC_LIMBS; k++) h.push_back(WnY.l[k]);
+    N c1 = cs.hash(h);
+    cs.enforce_equal(c1, cW);
+    if (!shape && !c1.v.eq(cW.v)) cs.bad = true;
+    h = {dg};
+    for (int k = 0; k < DEC_LIMBS; k++) h.push_back(EnX.l[k]);
+    for (int k = 0; k < DEC_LIMBS; k++) h.push_back(EnY.l[k]);
+    N c2 = cs.hash(h);
+    cs.enforce_equal(c2, cE);
+    if (!shape && !c2.v.eq(cE.v)) cs.bad = true;
   }
   // ---- 3. the folded main instance satisfies its relaxed R1CS ---------------------------------------------------------------------------
   // Z = (u', W'_1 .. W'_{nw-3}, x0', x1'): the witness entries are this circuit's variables, the three instance scalars the values above
@@ -148,10 +190,10 @@ struct DeciderCircuit {
   cb::BuilderT<CfFr> b;
   uint32_t n_public = 0, len_z = 0;
   void finish(const cb::BuilderT<CfFr>& main, uint32_t lz) {
-    b = cb::BuilderT<CfFr>(); len_z = lz; n_public = 2 * lz + 2;
+    b = cb::BuilderT<CfFr>(); len_z = lz; n_public = decider_n_public(lz);
     CS<BnFr> cs; cs.b = &b; cs.base = b.n_wires;
     DeciderIn in; in.digest = CfFr::zero(); in.U = CfMainRelaxed::zero(); in.u = CfMainFresh::zero(); in.cfU = CfRelaxed::zero();
-    in.cmT = in.Wn = in.En = NnPoint::zero(); in.cW = in.cE = in.eW = in.eE = CfFr::zero();
+    in.cmT = in.Wn = in.En = NnPoint::zero(); in.eW = in.eE = CfFr::zero();
     synthesize_decider(cs, main, lz, in);
   }
   // the full assignment (wire 0 = 1, then the public inputs); *bad: some check of the statement fails on these inputs

@@ -10,43 +10,18 @@
 // multiplications of a proof over the key's queries (the Pippenger of msm.hpp), the G2 one (per-point double-and-add over Fq2 and a host sum:
 // one MSM of ~10^6 points per proof, not a hot loop), and the fixed-base multiplications that make the keys.  On the host: the circuit
 // (synthesis, witness, its sparse products — 10^6 rows of a few terms), the QAP evaluation at the trapdoor, the final point arithmetic.
+#include <sys/random.h>
 #include <thread>
 #include "cyclefold_internal.hpp"
 #include "decider_view.hpp"
 #include "aug/decider.hpp"
+#include "pairing.hpp"
 #include "vecops_api.hpp"
 
 namespace {
 
-// ---- Fq2 = Fq[u] / (u² + 1): coordinates of G2 (the twist y² = x³ + 3/(9 + u)) ------------------------------------------------------------
-struct Fq2 {
-  Fq c0, c1;
-  static constexpr bool LAZY = false;
-  static VZ_HD Fq2 zero() { Fq2 r; r.c0 = Fq::zero(); r.c1 = Fq::zero(); return r; }
-  static VZ_HD Fq2 one() { Fq2 r; r.c0 = Fq::one(); r.c1 = Fq::zero(); return r; }
-  VZ_HD bool is_zero() const { return c0.is_zero() && c1.is_zero(); }
-  VZ_HD bool is_zero_mod() const { return is_zero(); }
-  VZ_HD bool eq(const Fq2& b) const { return c0.eq(b.c0) && c1.eq(b.c1); }
-  VZ_HD Fq2 canon() const { return *this; }
-  static VZ_HD Fq2 add(const Fq2& a, const Fq2& b) { Fq2 r; r.c0 = Fq::add(a.c0, b.c0); r.c1 = Fq::add(a.c1, b.c1); return r; }
-  static VZ_HD Fq2 sub(const Fq2& a, const Fq2& b) { Fq2 r; r.c0 = Fq::sub(a.c0, b.c0); r.c1 = Fq::sub(a.c1, b.c1); return r; }
-  template <int K> static VZ_HD Fq2 sub(const Fq2& a, const Fq2& b) { return sub(a, b); }
-  static VZ_HD Fq2 neg(const Fq2& a) { return sub(zero(), a); }
-  static VZ_HD Fq2 dbl(const Fq2& a) { return add(a, a); }
-  static VZ_HD Fq2 mul(const Fq2& a, const Fq2& b) {      // Karatsuba: three base-field products
-    const Fq t0 = Fq::mul(a.c0, b.c0), t1 = Fq::mul(a.c1, b.c1);
-    const Fq t2 = Fq::mul(Fq::add(a.c0, a.c1), Fq::add(b.c0, b.c1));
-    Fq2 r; r.c0 = Fq::sub(t0, t1); r.c1 = Fq::sub(Fq::sub(t2, t0), t1); return r;
-  }
-  static VZ_HD Fq2 sqr(const Fq2& a) {
-    const Fq t = Fq::mul(a.c0, a.c1);
-    Fq2 r; r.c0 = Fq::mul(Fq::add(a.c0, a.c1), Fq::sub(a.c0, a.c1)); r.c1 = Fq::dbl(t); return r;
-  }
-  static VZ_HD Fq2 pow_pm2(const Fq2& a) {      // the inverse (0 -> 0): conj(a) / (c0² + c1²)
-    const Fq n = Fq::pow_pm2(Fq::add(Fq::sqr(a.c0), Fq::sqr(a.c1)));
-    Fq2 r; r.c0 = Fq::mul(a.c0, n); r.c1 = Fq::neg(Fq::mul(a.c1, n)); return r;
-  }
-};
+// ---- Fq2 = Fq[u] / (u² + 1): coordinates of G2 (the twist y² = x³ + 3/(9 + u)) — pairing.hpp ------------------------------------------------
+using vz::pairing::Fq2;
 typedef Affine<Fq2> G2PAff;      // a point of BN254 G2
 typedef XYZZ<Fq2> G2P;
 
@@ -62,13 +37,7 @@ G2PAff g2_generator() {
   return g;
 }
 G1Aff g1_generator() { G1Aff g; g.x = Fq::one(); g.y = Fq::dbl(Fq::one()); return g; }
-bool g2_on_curve(const G2PAff& p) {      // y² = x³ + 3/(9 + u)
-  if (aff_is_identity(p)) return true;
-  Fq2 nine_u; nine_u.c0 = cb::f_from_u64<Fq>(9); nine_u.c1 = Fq::one();
-  Fq2 three = Fq2::zero(); three.c0 = cb::f_from_u64<Fq>(3);
-  const Fq2 b = Fq2::mul(three, Fq2::pow_pm2(nine_u));
-  return Fq2::sqr(p.y).eq(Fq2::add(Fq2::mul(Fq2::sqr(p.x), p.x), b));
-}
+using vz::pairing::g2_on_curve;
 
 // ---- host helpers over Fr -----------------------------------------------------------------------------------------------------------------
 Fe fr_pow(Fe base, const uint32_t e[8]) {
@@ -173,14 +142,25 @@ struct G16Key {
   G1Aff alpha1, beta1, delta1; G2PAff beta2, gamma2, delta2;
   std::vector<G1Aff> ic;                                        // n_pub + 1 points
 };
+void free_key_raw(G16Key& K) {      // (not vimz_bases_free: it takes the context's lock, which callers on an error path hold)
+  for (vimz_bases** b : {&K.a_q, &K.b1_q, &K.l_q, &K.h_q}) if (*b) {
+    if ((*b)->d) hipFree((*b)->d);
+    if ((*b)->tables) hipFree((*b)->tables);
+    for (auto& t : (*b)->small) { if (t.rows) hipFree(t.rows); if (t.mult) hipFree(t.mult); }
+    delete *b; *b = nullptr;
+  }
+  if (K.b2_q) hipFree(K.b2_q); K.b2_q = nullptr;
+  if (K.tw) hipFree(K.tw); if (K.tw_inv) hipFree(K.tw_inv); K.tw = K.tw_inv = nullptr;
+}
 }  // namespace
 
 struct vimz_decider {
   vimz_cf* vk = nullptr; vimz_ctx* ctx = nullptr;
   aug::DeciderCircuit circ;
   G16Key key;
-  std::vector<uint8_t> seed;
+  G2PAff kzg_vk;                         // [tau]G2 of the SRS the prover's ck_main is made of (identity: not given — KZG checks are refused)
   double setup_s[4] = {0, 0, 0, 0};      // circuit synthesis, QAP evaluation at the trapdoor (host), key points (GPU), total
+  ~vimz_decider() { if (ctx) { hipSetDevice(ctx->device); free_key_raw(key); } }      // (error paths of the setup end here too)
 };
 
 namespace {
@@ -241,17 +221,6 @@ hipError_t ntt(hipStream_t s, uint32_t* d, const G16Key& K, bool inverse) {
   return hipGetLastError();
 }
 
-void free_key(vimz_ctx* ctx, G16Key& K) {
-  (void)ctx;      // (not vimz_bases_free: it takes the context's lock, which callers on an error path hold)
-  for (vimz_bases** b : {&K.a_q, &K.b1_q, &K.l_q, &K.h_q}) if (*b) {
-    if ((*b)->d) hipFree((*b)->d);
-    if ((*b)->tables) hipFree((*b)->tables);
-    for (auto& t : (*b)->small) { if (t.rows) hipFree(t.rows); if (t.mult) hipFree(t.mult); }
-    delete *b; *b = nullptr;
-  }
-  if (K.b2_q) hipFree(K.b2_q); K.b2_q = nullptr;
-  if (K.tw) hipFree(K.tw); if (K.tw_inv) hipFree(K.tw_inv); K.tw = K.tw_inv = nullptr;
-}
 
 // (A,B,C)·z of a builder's CSR on the host threads
 void host_spmv3(const cb::BuilderT<Fe>& b, const std::vector<Fe>& z, std::vector<Fe>* out /* [3] of n_c */) {
@@ -273,29 +242,67 @@ void host_spmv3(const cb::BuilderT<Fe>& b, const std::vector<Fe>& z, std::vector
 
 }  // namespace
 
-extern "C" {
 
-void vimz_decider_free(vimz_decider* d) {
-  if (!d) return;
-  if (d->ctx) {
-    std::unique_lock<std::mutex> g(d->ctx->mu);
-    hipSetDevice(d->ctx->device);
-    hipStreamSynchronize(d->ctx->stream);
-    g.unlock();
-    free_key(d->ctx, d->key);
-  }
-  delete d;
+namespace {
+
+// ---- randomness: the toxic waste of a locally run setup and a proof's blinding scalars come from the OS -------------------------------------------
+bool os_random(void* buf, size_t n) {
+  uint8_t* p = (uint8_t*)buf;
+  while (n) { const ssize_t k = getrandom(p, n, 0); if (k <= 0) return false; p += k; n -= (size_t)k; }
+  return true;
+}
+struct Trapdoor { Fe tau, alpha, beta, gamma, delta; };
+bool trapdoor_random(Trapdoor& t) {
+  uint8_t raw[5][32];
+  if (!os_random(raw, sizeof(raw))) return false;
+  Fe* dst[5] = {&t.tau, &t.alpha, &t.beta, &t.gamma, &t.delta};
+  for (int k = 0; k < 5; k++) { raw[k][31] = 0; raw[k][0] |= 1; Fe c; memcpy(c.v, raw[k], 32); *dst[k] = Fe::to_mont(c); }      // 248 bits, never zero
+  return true;
+}
+Trapdoor trapdoor_seeded(const uint8_t* seed, size_t n) {
+  Trapdoor t;
+  t.tau = fr_from_hash(seed, n, "vimz-decider-tau"); t.alpha = fr_from_hash(seed, n, "vimz-decider-alpha"); t.beta = fr_from_hash(seed, n, "vimz-decider-beta");
+  t.gamma = fr_from_hash(seed, n, "vimz-decider-gamma"); t.delta = fr_from_hash(seed, n, "vimz-decider-delta");
+  return t;
+}
+void put_fq(uint64_t* dst, const Fq& mont) { const Fq c = Fq::from_mont(mont); memcpy(dst, c.v, 32); }
+bool get_fq(const uint64_t* src, Fq* out) { Fq c; memcpy(c.v, src, 32); if (!c.is_reduced()) return false; *out = Fq::to_mont(c); return true; }
+void put_g2(uint64_t* dst, const G2PAff& p) { put_fq(dst, p.x.c0); put_fq(dst + 4, p.x.c1); put_fq(dst + 8, p.y.c0); put_fq(dst + 12, p.y.c1); }
+bool get_g2(const uint64_t* src, G2PAff* p) { return get_fq(src, &p->x.c0) && get_fq(src + 4, &p->x.c1) && get_fq(src + 8, &p->y.c0) && get_fq(src + 12, &p->y.c1); }
+bool get_g1(const uint64_t* src, G1Aff* p) { return get_fq(src, &p->x) && get_fq(src + 4, &p->y); }
+U256w u256_of(const uint64_t* w) { U256w r; memcpy(r.w, w, 32); return r; }
+
+// KZG::setup: srs[i] = [tau^i]G1 for i < n (resident MSM form), vk = [tau]G2
+int kzg_setup_impl(vimz_ctx* ctx, const Fe& tau, size_t n, vimz_bases** srs_out, uint64_t vk_g2_out[16]) {
+  std::vector<Fe> pw(n);
+  { Fe t = Fe::one(); for (size_t i = 0; i < n; i++) { pw[i] = t; t = Fe::mul(t, tau); } }
+  std::lock_guard<std::mutex> g(ctx->mu);
+  P_TRY(hipSetDevice(ctx->device));
+  const std::vector<G1Aff> T1 = fixed_table<Fq>(g1_generator());
+  G1Aff* dT1 = nullptr;
+  P_TRY(hipMalloc((void**)&dT1, sizeof(G1Aff) * T1.size()));
+  struct Tab { G1Aff* a; ~Tab() { hipFree(a); } } tab{dT1};
+  P_TRY(hipMemcpy(dT1, T1.data(), sizeof(G1Aff) * T1.size(), hipMemcpyHostToDevice));
+  G1Aff* pts = nullptr;
+  hipError_t e = fixed_base_batch<Fq>(ctx->stream, pw, dT1, &pts);
+  if (e != hipSuccess) { if (pts) hipFree(pts); return vz_fail(ctx, VIMZ_ERR_HIP, "vimz_kzg_setup: powers of tau", e); }
+  const int rc = bases_from_device(ctx, pts, n, srs_out);
+  hipFree(pts);
+  if (rc) return rc;
+  put_g2(vk_g2_out, to_affine(host_mul_fr<Fq2>(g2_generator(), tau)));
+  return VIMZ_OK;
 }
 
-// Decider::preprocess (vimz/src/sonobe_backend/mod.rs:72-75): the decider circuit for this prover's shapes and a Groth16 key pair from a
-// deterministic TEST setup (the trapdoor is derived from `seed`: anyone who knows the seed can forge — what a ceremony is for).
-// seconds (optional) = {circuit synthesis, QAP evaluation at the trapdoor, key points on the GPU, total}.
-int vimz_decider_setup(vimz_cf* v, const uint8_t* seed, size_t seed_len, vimz_decider** out, double seconds[4]) {
-  if (!v || !out || (!seed && seed_len)) return VIMZ_ERR_INVALID;
+int decider_setup_impl(vimz_cf* v, const uint64_t kzg_vk_g2[16], const Trapdoor& td, vimz_decider** out, double seconds[4]) {
   vimz_ctx* ctx = v->ctx;
   const double t_all = now_s();
   std::unique_ptr<vimz_decider> d(new vimz_decider());
-  d->vk = v; d->ctx = ctx; d->seed.assign(seed, seed + seed_len);
+  d->vk = v; d->ctx = ctx;
+  d->kzg_vk.x = d->kzg_vk.y = Fq2::zero();
+  if (kzg_vk_g2) {
+    if (!get_g2(kzg_vk_g2, &d->kzg_vk) || !vz::pairing::g2_on_curve(d->kzg_vk) || !vz::pairing::g2_in_subgroup(d->kzg_vk))
+      return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_decider_setup: the KZG verifying key is not a point of G2");
+  }
   try {
     const cb::BuilderT<Fe>& main = v->circ->build->b;
     d->circ.finish(main, v->c1->len_z);
@@ -307,9 +314,7 @@ int vimz_decider_setup(vimz_cf* v, const uint8_t* seed, size_t seed_len, vimz_de
   K.n = 1; K.logn = 0;
   while (K.n < K.n_c + K.n_pub + 1) { K.n <<= 1; K.logn++; }
   if (K.logn > 26) return vz_fail(ctx, VIMZ_ERR_INVALID, "decider: circuit too large for the domain");
-  // trapdoor
-  const Fe tau = fr_from_hash(seed, seed_len, "vimz-decider-tau"), alpha = fr_from_hash(seed, seed_len, "vimz-decider-alpha"), beta = fr_from_hash(seed, seed_len, "vimz-decider-beta"),
-           gamma = fr_from_hash(seed, seed_len, "vimz-decider-gamma"), delta = fr_from_hash(seed, seed_len, "vimz-decider-delta");
+  const Fe tau = td.tau, alpha = td.alpha, beta = td.beta, gamma = td.gamma, delta = td.delta;
   const Fe gamma_inv = Fe::pow_pm2(gamma), delta_inv = Fe::pow_pm2(delta);
   K.omega = fr_root_of_unity(K.logn); K.omega_inv = Fe::pow_pm2(K.omega);
   K.n_inv = Fe::pow_pm2(cb::f_from_u64<Fe>(K.n));
@@ -318,6 +323,7 @@ int vimz_decider_setup(vimz_cf* v, const uint8_t* seed, size_t seed_len, vimz_de
   { Fe chk = fr_pow_u64(K.omega, K.n / 2); if (K.n > 1 && !Fe::add(chk, Fe::one()).is_zero()) return vz_fail(ctx, VIMZ_ERR_INVALID, "decider: root of unity"); }
   // Lagrange basis at tau: L_j(tau) = Z(tau)/n · ω^j / (tau − ω^j)   (batch inversion)
   const Fe z_tau = Fe::sub(fr_pow_u64(tau, K.n), Fe::one());
+  if (z_tau.is_zero()) return vz_fail(ctx, VIMZ_ERR_INVALID, "decider: tau lies in the domain");
   std::vector<Fe> L(K.n), den(K.n);
   { Fe w = Fe::one(); for (uint32_t j = 0; j < K.n; j++) { den[j] = Fe::sub(tau, w); L[j] = w; w = Fe::mul(w, K.omega); } }
   { std::vector<Fe> pre(K.n); Fe run = Fe::one();
@@ -344,28 +350,27 @@ int vimz_decider_setup(vimz_cf* v, const uint8_t* seed, size_t seed_len, vimz_de
   }
   { Fe t = Fe::mul(z_tau, delta_inv); for (uint32_t j = 0; j + 1 < K.n; j++) { hq[j] = t; t = Fe::mul(t, tau); } }
   const double t_qap = now_s();
-  // key points on the GPU
+  // key points on the GPU (any failure below: ~vimz_decider releases what was built)
   std::lock_guard<std::mutex> g(ctx->mu);
   P_TRY(hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
   const G1Aff g1 = g1_generator(); const G2PAff g2 = g2_generator();
   if (!g2_on_curve(g2)) return vz_fail(ctx, VIMZ_ERR_INVALID, "decider: G2 generator constant");
   const std::vector<G1Aff> T1 = fixed_table<Fq>(g1); const std::vector<G2PAff> T2 = fixed_table<Fq2>(g2);
-  G1Aff* dT1 = nullptr; G2PAff* dT2 = nullptr;
-  P_TRY(hipMalloc((void**)&dT1, sizeof(G1Aff) * T1.size())); P_TRY(hipMalloc((void**)&dT2, sizeof(G2PAff) * T2.size()));
-  P_TRY(hipMemcpy(dT1, T1.data(), sizeof(G1Aff) * T1.size(), hipMemcpyHostToDevice)); P_TRY(hipMemcpy(dT2, T2.data(), sizeof(G2PAff) * T2.size(), hipMemcpyHostToDevice));
-  struct Tables { G1Aff* a; G2PAff* b; ~Tables() { hipFree(a); hipFree(b); } } tables{dT1, dT2};
+  struct Tables { G1Aff* a = nullptr; G2PAff* b = nullptr; ~Tables() { if (a) hipFree(a); if (b) hipFree(b); } } tables;
+  P_TRY(hipMalloc((void**)&tables.a, sizeof(G1Aff) * T1.size())); P_TRY(hipMalloc((void**)&tables.b, sizeof(G2PAff) * T2.size()));
+  P_TRY(hipMemcpy(tables.a, T1.data(), sizeof(G1Aff) * T1.size(), hipMemcpyHostToDevice)); P_TRY(hipMemcpy(tables.b, T2.data(), sizeof(G2PAff) * T2.size(), hipMemcpyHostToDevice));
   auto g1_query = [&](const std::vector<Fe>& sc, vimz_bases** outb) -> int {
     G1Aff* pts = nullptr;
-    hipError_t e = fixed_base_batch<Fq>(s, sc, dT1, &pts);
+    hipError_t e = fixed_base_batch<Fq>(s, sc, tables.a, &pts);
     if (e != hipSuccess) { if (pts) hipFree(pts); return vz_fail(ctx, VIMZ_ERR_HIP, "decider: key points", e); }
     const int rc = bases_from_device(ctx, pts, sc.size(), outb);
     hipFree(pts);
     return rc;
   };
   int rc;
-  if ((rc = g1_query(uvw[0], &K.a_q)) || (rc = g1_query(uvw[1], &K.b1_q)) || (rc = g1_query(lq, &K.l_q)) || (rc = g1_query(hq, &K.h_q))) { free_key(ctx, K); return rc; }
-  { hipError_t e = fixed_base_batch<Fq2>(s, uvw[1], dT2, &K.b2_q); if (e != hipSuccess) { free_key(ctx, K); return vz_fail(ctx, VIMZ_ERR_HIP, "decider: G2 key points", e); } }
+  if ((rc = g1_query(uvw[0], &K.a_q)) || (rc = g1_query(uvw[1], &K.b1_q)) || (rc = g1_query(lq, &K.l_q)) || (rc = g1_query(hq, &K.h_q))) return rc;
+  { hipError_t e = fixed_base_batch<Fq2>(s, uvw[1], tables.b, &K.b2_q); if (e != hipSuccess) return vz_fail(ctx, VIMZ_ERR_HIP, "decider: G2 key points", e); }
   // domain tables
   P_TRY(hipMalloc((void**)&K.tw, 32 * (size_t)std::max<uint32_t>(K.n / 2, 1))); P_TRY(hipMalloc((void**)&K.tw_inv, 32 * (size_t)std::max<uint32_t>(K.n / 2, 1)));
   { Fr w, wi; memcpy(w.v, K.omega.v, 32); memcpy(wi.v, K.omega_inv.v, 32);
@@ -384,6 +389,133 @@ int vimz_decider_setup(vimz_cf* v, const uint8_t* seed, size_t seed_len, vimz_de
   return VIMZ_OK;
 }
 
+// ---- the verifier: what contracts/*Verifier.sol::verifyNovaProof does with the 25 words (ContrastVerifier.sol:685-783) ---------------------------------
+struct VerifierKey {
+  Fe pp_hash; uint32_t len_z = 0;
+  G1Aff alpha; G2PAff beta, gamma, delta; std::vector<G1Aff> ic;
+  G1Aff kzg_g1; G2PAff kzg_g2, kzg_vk;
+};
+enum { DV_STEPS = 1, DV_KZG_W = 2, DV_KZG_E = 4, DV_GROTH16 = 8, DV_MALFORMED = 16 };
+G1Aff g1_lin(const G1Aff& a, const uint64_t* k256, const G1Aff& b) {      // a + k·b
+  G1 acc = aff_is_identity(a) ? G1::identity() : from_affine(a);
+  if (!aff_is_identity(b)) { G1 t = host_mul<Fq>(b, (const uint32_t*)k256, 256); add_full(acc, t); }
+  return to_affine(acc);
+}
+G1Aff g1_negate(const G1Aff& p) { G1Aff r = p; if (!aff_is_identity(p)) r.y = Fq::neg(p.y); return r; }
+// KZG10Verifier.check (:167-189): e(pi, VK) · e(x·(−pi) − c + y·G_1, G_2) == 1
+bool kzg_check(const VerifierKey& K, const G1Aff& c, const G1Aff& pi, const uint64_t* x, const uint64_t* y) {
+  G1 acc = host_mul<Fq>(g1_negate(pi), (const uint32_t*)x, 256);
+  { const G1Aff nc = g1_negate(c); if (!aff_is_identity(nc)) add_mixed(acc, nc); }
+  { G1 t = host_mul<Fq>(K.kzg_g1, (const uint32_t*)y, 256); add_full(acc, t); }
+  return vz::pairing::product_is_one({{pi, K.kzg_vk}, {to_affine(acc), K.kzg_g2}});
+}
+// words: the 25 calldata words as 4 little-endian limbs each.  Returns a bit set of DV_* (0 = accepted)
+uint32_t verify_words(const VerifierKey& K, uint64_t steps, const uint64_t* z0, const uint64_t* zi, const uint64_t* w) {
+  using namespace vz::pairing;
+  if (!consts().ok) return DV_MALFORMED;
+  uint32_t res = 0;
+  if (steps < 2) res |= DV_STEPS;                                                    // :697
+  G1Aff P[8]; static const int at[8] = {0, 2, 4, 6, 9, 15, 21, 23};              // U_i.cmW, U_i.cmE, u_i.cmW, cmT, A, C, proof_W, proof_E
+  for (int k = 0; k < 8; k++) if (!get_g1(w + 4 * at[k], &P[k]) || !g1_on_curve(P[k])) return res | DV_MALFORMED;
+  G2PAff B;      // calldata: x imaginary, x real, y imaginary, y real
+  if (!get_fq(w + 4 * 11, &B.x.c1) || !get_fq(w + 4 * 12, &B.x.c0) || !get_fq(w + 4 * 13, &B.y.c1) || !get_fq(w + 4 * 14, &B.y.c0) || !g2_on_curve(B) || !g2_in_subgroup(B)) return res | DV_MALFORMED;
+  Fe pub_el; std::vector<Fe> pub;
+  auto push_canon = [&](const uint64_t* c) { Fe x; memcpy(x.v, c, 32); if (!x.is_reduced()) return false; pub.push_back(Fe::to_mont(x)); return true; };      // checkField
+  pub.push_back(K.pp_hash); pub.push_back(cb::f_from_u64<Fe>(steps));
+  for (uint32_t k = 0; k < K.len_z; k++) if (!push_canon(z0 + 4 * k)) return res | DV_GROTH16;
+  for (uint32_t k = 0; k < K.len_z; k++) if (!push_canon(zi + 4 * k)) return res | DV_GROTH16;
+  const uint64_t* r = w + 4 * 8;
+  const G1Aff cmW = g1_lin(P[0], r, P[2]), cmE = g1_lin(P[1], r, P[3]);              // :712-713, :735-736
+  auto push_limbs = [&](const Fq& coord) { const Fq c = Fq::from_mont(coord); U256w u; memcpy(u.w, c.v, 32); uint64_t l[aug::DEC_LIMBS]; aug::decider_limbs55(u, l); for (int k = 0; k < aug::DEC_LIMBS; k++) pub.push_back(cb::f_from_u64<Fe>(l[k])); };
+  push_limbs(cmW.x); push_limbs(cmW.y); push_limbs(cmE.x); push_limbs(cmE.y);
+  for (int k = 17; k <= 20; k++) if (!push_canon(w + 4 * k)) res |= DV_GROTH16;
+  if (res & DV_GROTH16) return res;
+  push_limbs(P[3].x); push_limbs(P[3].y);
+  if (pub.size() + 1 != K.ic.size()) return res | DV_MALFORMED;
+  if (!kzg_check(K, cmW, P[6], w + 4 * 17, w + 4 * 19)) res |= DV_KZG_W;             // :725-730
+  if (!kzg_check(K, cmE, P[7], w + 4 * 18, w + 4 * 20)) res |= DV_KZG_E;             // :748-753
+  // Groth16 (:386-620): vk_x = IC_0 + Σ pub_k·IC_{k+1};  e(−A, B)·e(alpha, beta)·e(vk_x, gamma)·e(C, delta) == 1
+  G1 vkx = from_affine(K.ic[0]);
+  if (aff_is_identity(K.ic[0])) vkx = G1::identity();
+  for (size_t k = 0; k < pub.size(); k++) { if (pub[k].is_zero() || aff_is_identity(K.ic[k + 1])) continue; G1 t = host_mul_fr<Fq>(K.ic[k + 1], pub[k]); add_full(vkx, t); }
+  if (!product_is_one({{g1_negate(P[4]), B}, {K.alpha, K.beta}, {to_affine(vkx), K.gamma}, {P[5], K.delta}})) res |= DV_GROTH16;
+  return res;
+}
+// key blob (vimz_decider_vk): pp_hash, len_z, alpha (G1), beta, gamma, delta (G2: x.c0, x.c1, y.c0, y.c1), n_ic, IC points, KZG G_1 (G1), G_2, VK (G2)
+bool parse_key(const uint64_t* w, size_t n, VerifierKey* K) {
+  using namespace vz::pairing;
+  size_t pos = 0;
+  auto need = [&](size_t k) { return pos + k <= n; };
+  if (!need(5)) return false;
+  { Fe c; memcpy(c.v, w, 32); if (!c.is_reduced()) return false; K->pp_hash = Fe::to_mont(c); } pos += 4;
+  K->len_z = (uint32_t)w[pos++];
+  if (!need(8 + 48 + 1) || !get_g1(w + pos, &K->alpha)) return false; pos += 8;
+  for (G2PAff* p : {&K->beta, &K->gamma, &K->delta}) { if (!get_g2(w + pos, p)) return false; pos += 16; }
+  const uint64_t n_ic = w[pos++];
+  if (n_ic != 1 + (uint64_t)aug::decider_n_public(K->len_z) || !need(8 * n_ic + 8 + 32)) return false;
+  K->ic.resize(n_ic);
+  for (auto& p : K->ic) { if (!get_g1(w + pos, &p)) return false; pos += 8; }
+  if (!get_g1(w + pos, &K->kzg_g1)) return false; pos += 8;
+  if (!get_g2(w + pos, &K->kzg_g2) || !get_g2(w + pos + 16, &K->kzg_vk)) return false; pos += 32;
+  if (pos != n) return false;
+  if (!g1_on_curve(K->alpha) || !g1_on_curve(K->kzg_g1)) return false;
+  for (auto& p : K->ic) if (!g1_on_curve(p)) return false;
+  for (const G2PAff* p : {&K->beta, &K->gamma, &K->delta, &K->kzg_g2, &K->kzg_vk}) if (!g2_on_curve(*p) || !g2_in_subgroup(*p)) return false;
+  return true;
+}
+VerifierKey key_of(const vimz_decider* d) {
+  VerifierKey K; const G16Key& G = d->key;
+  K.pp_hash = d->vk->c1->digest; K.len_z = d->circ.len_z;
+  K.alpha = G.alpha1; K.beta = G.beta2; K.gamma = G.gamma2; K.delta = G.delta2; K.ic = G.ic;
+  K.kzg_g1 = g1_generator(); K.kzg_g2 = g2_generator(); K.kzg_vk = d->kzg_vk;
+  return K;
+}
+
+}  // namespace
+
+extern "C" {
+
+void vimz_decider_free(vimz_decider* d) {
+  if (!d) return;
+  if (d->ctx) {
+    std::unique_lock<std::mutex> g(d->ctx->mu);
+    hipSetDevice(d->ctx->device);
+    hipStreamSynchronize(d->ctx->stream);
+  }
+  delete d;
+}
+
+// KZG::setup (Sonobe's `KZG::setup(rng, n)` inside vimz/src/sonobe_backend/folding.rs:36-48 `prepare_folding`): tau from the OS, used and forgotten
+int vimz_kzg_setup(vimz_ctx* ctx, size_t n, vimz_bases** srs_out, uint64_t vk_g2_out[16]) {
+  if (!ctx || !srs_out || !vk_g2_out || !n) return VIMZ_ERR_INVALID;
+  Trapdoor t;
+  if (!trapdoor_random(t)) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_kzg_setup: no randomness from the OS");
+  return kzg_setup_impl(ctx, t.tau, n, srs_out, vk_g2_out);
+}
+
+// Decider::preprocess (vimz/src/sonobe_backend/mod.rs:72-75): the decider circuit for this prover's shapes and a Groth16 key pair.  The toxic
+// waste is drawn from the OS's randomness, used and forgotten: a LOCALLY TRUSTED setup (whoever runs it could have kept it) — what the
+// reference's own `StdRng::from_seed([41; 32])` (mod.rs:54) is, too; a deployment would import keys from a ceremony instead.
+// kzg_vk_g2 (optional): [tau]G2 of the SRS the prover's ck_main is made of (vimz_kzg_setup) — needed by vimz_decider_verify and part of vimz_decider_vk.
+// seconds (optional) = {circuit synthesis, QAP evaluation at the trapdoor, key points on the GPU, total}.
+int vimz_decider_setup(vimz_cf* v, const uint64_t kzg_vk_g2[16], vimz_decider** out, double seconds[4]) {
+  if (!v || !out) return VIMZ_ERR_INVALID;
+  Trapdoor t;
+  if (!trapdoor_random(t)) return vz_fail(v->ctx, VIMZ_ERR_INVALID, "vimz_decider_setup: no randomness from the OS");
+  return decider_setup_impl(v, kzg_vk_g2, t, out, seconds);
+}
+#ifdef VIMZ_TESTING
+// deterministic TEST setups: the trapdoor is derived from `seed` — anyone who knows the seed can forge.  Not in the product library.
+int vimz_testing_kzg_setup_seeded(vimz_ctx* ctx, const uint8_t* seed, size_t seed_len, size_t n, vimz_bases** srs_out, uint64_t vk_g2_out[16]) {
+  if (!ctx || !srs_out || !vk_g2_out || !n || (!seed && seed_len)) return VIMZ_ERR_INVALID;
+  return kzg_setup_impl(ctx, fr_from_hash(seed, seed_len, "vimz-kzg-tau"), n, srs_out, vk_g2_out);
+}
+int vimz_testing_decider_setup_seeded(vimz_cf* v, const uint64_t kzg_vk_g2[16], const uint8_t* seed, size_t seed_len, vimz_decider** out, double seconds[4]) {
+  if (!v || !out || (!seed && seed_len)) return VIMZ_ERR_INVALID;
+  return decider_setup_impl(v, kzg_vk_g2, trapdoor_seeded(seed, seed_len), out, seconds);
+}
+#endif
+
 // info = {constraints, wires, public inputs, domain size, non-zeros of A, B, C, 0}
 int vimz_decider_info(const vimz_decider* d, uint64_t info[8]) {
   if (!d || !info) return VIMZ_ERR_INVALID;
@@ -392,60 +524,104 @@ int vimz_decider_info(const vimz_decider* d, uint64_t info[8]) {
   return VIMZ_OK;
 }
 
-// The verifying key as canonical little-endian words: alpha (G1: x, y), beta, gamma, delta (G2: x.c0, x.c1, y.c0, y.c1), the number of IC
-// points, then the IC points (G1).  Returns the byte size (copies when buf is large enough).
+// The verifying key — everything a contract generated for this circuit would hold as constants (contracts/ContrastVerifier.sol:140-160 KZG G_1 / G_2 / VK,
+// :238-… alpha…delta and IC_k, :703 the public-parameter hash) — as canonical little-endian words: pp_hash (4), len_z (1), alpha (G1: x, y), beta,
+// gamma, delta (G2: x.c0, x.c1, y.c0, y.c1), the number of IC points, the IC points (G1), then KZG G_1 (G1), G_2, VK (G2; zeros when the decider was
+// set up without one).  Returns the byte size (copies when buf is large enough).
 int64_t vimz_decider_vk(const vimz_decider* d, void* buf, size_t cap) {
   if (!d) return VIMZ_ERR_INVALID;
   Writer w;
   const G16Key& K = d->key;
+  w.fe(d->vk->c1->digest); w.word(d->circ.len_z);
   w.point(K.alpha1);
-  for (const G2PAff* p : {&K.beta2, &K.gamma2, &K.delta2}) { w.fe(p->x.c0); w.fe(p->x.c1); w.fe(p->y.c0); w.fe(p->y.c1); }
+  auto g2w = [&](const G2PAff& p) { w.fe(p.x.c0); w.fe(p.x.c1); w.fe(p.y.c0); w.fe(p.y.c1); };
+  for (const G2PAff* p : {&K.beta2, &K.gamma2, &K.delta2}) g2w(*p);
   w.word(K.ic.size());
   for (auto& p : K.ic) w.point(p);
+  w.point(g1_generator()); g2w(g2_generator()); g2w(d->kzg_vk);
   const size_t bytes = 8 * w.w.size();
   if (buf && cap >= bytes) memcpy(buf, w.w.data(), bytes);
   return (int64_t)bytes;
 }
 
-// Decider::prove (mod.rs:76-78) for the final fold a merged proof of ONE segment holds.  kzg = {c_W, c_E, e_W, e_E} (canonical): the challenges
-// and evaluations of the two KZG openings the same calldata carries (vimz_cf_merged_kzg_open).  public_out: n_public canonical elements
-// (i, z_0, z_i, h_inst); proof_out: A.x, A.y, B.x.c0, B.x.c1, B.y.c0, B.y.c1, C.x, C.y (canonical).
-// seconds (optional) = {witness + sparse products (host), NTTs, MSMs, total}.
-int vimz_decider_prove(vimz_decider* d, vimz_cf_merged* m, const uint64_t kzg[16], uint64_t* public_out, uint64_t proof_out[32], double seconds[4]) {
-  if (!d || !m || !kzg || !public_out || !proof_out) return VIMZ_ERR_INVALID;
+// Decider::prove (mod.rs:76-78) for the IVC proof `ivc` holds after i >= 1 steps (left unchanged): the final fold U_{i+1} = NIFS(U_i, u_i) on the GPU
+// (cross term, its commitment, the challenge of aug/decider.hpp, the folded witness and error vector), the KZG openings of U_{i+1}'s two commitments at
+// the challenges that follow from them, and the Groth16 proof of the decider circuit — ALL 25 calldata words (contracts/*Verifier.sol:785-810;
+// vimz_amd/calldata.py names them), canonical, 4 little-endian limbs each.  public_out: the info[2] public inputs (canonical), as the contract
+// assembles them from the words.  VIMZ_ERR_UNSAT when the IVC proof does not satisfy the decider's statement.
+// seconds (optional) = {final fold + KZG openings (GPU), witness + sparse products (host), NTTs, MSMs, total, 0}.
+int vimz_decider_prove(vimz_decider* d, vimz_cf* ivc, uint64_t* public_out, uint64_t words_out[100], double seconds[6]) {
+  if (!d || !ivc || !public_out || !words_out) return VIMZ_ERR_INVALID;
   vimz_ctx* ctx = d->ctx; vimz_cf* v = d->vk;
   const G16Key& K = d->key;
   const double t_all = now_s();
-  CfDeciderView V;
-  int rc = vz_cf_merged_decider_view(m, &V);
-  if (rc) return rc;
-  if (V.vk != v) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_decider_prove: the merged proof belongs to another prover than the decider was set up for");
-  const size_t nw = v->pri->n_wires, nc = v->pri->n_c;
+  if (ivc->ctx != ctx || ivc->pri->n_wires != v->pri->n_wires || ivc->pri->n_c != v->pri->n_c || !ivc->c1->digest.eq(v->c1->digest) || ivc->ck1 != v->ck1)
+    return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_decider_prove: the IVC proof belongs to other shapes / keys than the decider was set up for");
+  if (ivc->broken) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_decider_prove: the IVC failed in the middle of a step");
+  if (ivc->i == 0) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_decider_prove: the IVC has no steps");
+  vimz_prover* p = ivc->pri;
+  const size_t nw = p->n_wires, nc = p->n_c;
   std::vector<Fe> Wf(nw), Ef(nc);
+  aug::DeciderIn in;
+  G1Aff cmT, cWn, cEn;
+  uint32_t r_low[4];
+  uint64_t kzg_out[2][12];      // eval (4), proof (8)
+  Fe cW, cE;
   {
     std::lock_guard<std::mutex> g(ctx->mu);
     P_TRY(hipSetDevice(ctx->device));
-    P_TRY(hipMemcpyAsync(Wf.data(), V.Zp, 32 * nw, hipMemcpyDeviceToHost, ctx->stream));
-    P_TRY(hipMemcpyAsync(Ef.data(), V.Ep, 32 * nc, hipMemcpyDeviceToHost, ctx->stream));
-    P_TRY(hipStreamSynchronize(ctx->stream));
+    hipStream_t s = ctx->stream;
+    for (hipStream_t q : {ivc->s2, ivc->s3, ivc->s4}) if (q) P_TRY(hipStreamSynchronize(q));
+    P_TRY(hipStreamSynchronize(s));
+    uint32_t* dev = nullptr;
+    P_TRY(hipMalloc((void**)&dev, 32 * (nw + 2 * nc)));
+    struct FreeDev { uint32_t* q; ~FreeDev() { hipFree(q); } } fd{dev};
+    uint32_t *Wd = dev, *Ed = dev + 8 * nw, *Td = Ed + 8 * nc;
+    P_TRY(hipMemcpyAsync(Wd, p->Zrun, 32 * nw, hipMemcpyDeviceToDevice, s));
+    P_TRY(hipMemcpyAsync(Ed, p->E, 32 * nc, hipMemcpyDeviceToDevice, s));
+    // cross term of (U_i, W_i) and the last instance of F' (strict: u = 1), its commitment
+    hipLaunchKernelGGL(k_cross_term<Fr>, dim3(stream_grid(nc)), dim3(256), 0, s, nc, p->AZ, p->BZ, p->CZ, ivc->u_run, ivc->azl, ivc->bzl, ivc->czl, Fe::one(), Td);
+    P_TRY(hipGetLastError());
+    uint64_t pt[8];
+    int rc = vz_msm_device(ctx, p->ck, 0, Td, nc, 1, 0, pt, VIMZ_FORM_MONTGOMERY);
+    if (rc) return rc;
+    memcpy(cmT.x.v, pt, 32); memcpy(cmT.y.v, pt + 4, 32);
+    // the challenge, as the decider circuit derives it
+    aug::decider_challenge(ivc->u, nn_point(cmT), r_low);
+    const Fe rho = cf_r_element_fr(r_low);
+    Fold5 f; for (int k = 0; k < 5; k++) { f.x1[k] = nullptr; f.x2[k] = nullptr; f.n[k] = 0; }
+    f.x1[0] = Wd; f.x2[0] = ivc->Zl; f.n[0] = nw;
+    f.x1[1] = Ed; f.x2[1] = Td; f.n[1] = nc;
+    hipLaunchKernelGGL(k_fold5<Fr>, dim3(1024), dim3(256), 0, s, f, rho);
+    P_TRY(hipGetLastError());
+    cWn = g1_fold(ivc->UW, r_low, ivc->uW); cEn = g1_fold(ivc->UE, r_low, cmT);
+    in.digest = v->c1->digest;
+    in.Wn = nn_point(cWn); in.En = nn_point(cEn); in.cmT = nn_point(cmT);
+    cW = aug::decider_kzg_challenge(in.digest, in.Wn); cE = aug::decider_kzg_challenge(in.digest, in.En);
+    uint64_t ch[4];
+    { const Fe c = Fe::from_mont(cW); memcpy(ch, c.v, 32); }
+    if ((rc = vz_kzg_open_device(ctx, p->ck, 0, VIMZ_FIELD_BN254_FR, Wd + 8, nw - 3, ch, VIMZ_FORM_CANONICAL, kzg_out[0], kzg_out[0] + 4))) return rc;
+    { const Fe c = Fe::from_mont(cE); memcpy(ch, c.v, 32); }
+    if ((rc = vz_kzg_open_device(ctx, p->ck, 0, VIMZ_FIELD_BN254_FR, Ed, nc, ch, VIMZ_FORM_CANONICAL, kzg_out[1], kzg_out[1] + 4))) return rc;
+    P_TRY(hipMemcpyAsync(Wf.data(), Wd, 32 * nw, hipMemcpyDeviceToHost, s));
+    P_TRY(hipMemcpyAsync(Ef.data(), Ed, 32 * nc, hipMemcpyDeviceToHost, s));
+    P_TRY(hipStreamSynchronize(s));
   }
-  aug::DeciderIn in;
-  in.digest = v->c1->digest; in.i = V.n; in.z0 = V.zs; in.zi = V.ze;
-  in.U = V.U; in.u = V.u; in.cfU = V.cfU; memcpy(in.r_low, V.r, 16);
-  in.cmT = nn_point(V.cmT); in.Wn = nn_point(V.cW); in.En = nn_point(V.cE);
-  Fe k4[4];
-  for (int q = 0; q < 4; q++) { Fe c; memcpy(c.v, kzg + 4 * q, 32); if (!c.is_reduced()) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_decider_prove: a KZG word is not below the modulus"); k4[q] = Fe::to_mont(c); }
-  in.cW = k4[0]; in.cE = k4[1]; in.eW = k4[2]; in.eE = k4[3];
+  const double t_fold = now_s();
+  in.i = ivc->i; in.z0 = ivc->z0; in.zi = p->z_cur;
+  in.U = ivc->U; in.u = ivc->u; in.cfU = ivc->cfU;
+  { Fe c; memcpy(c.v, kzg_out[0], 32); in.eW = Fe::to_mont(c); memcpy(c.v, kzg_out[1], 32); in.eE = Fe::to_mont(c); }
   in.Wf = Wf.data() + 1; in.Ef = Ef.data();
   std::vector<Fe> z;
   bool bad = false;
   try { z = d->circ.witness(v->circ->build->b, in, &bad); } catch (const std::exception& e) { return vz_fail(ctx, VIMZ_ERR_INVALID, e.what()); }
-  if (bad) return vz_fail(ctx, VIMZ_ERR_UNSAT, "vimz_decider_prove: the proof does not satisfy the decider's statement (hashes, relaxed relation or KZG evaluations)");
+  if (bad) return vz_fail(ctx, VIMZ_ERR_UNSAT, "vimz_decider_prove: the IVC proof does not satisfy the decider's statement (hashes, relaxed relation or KZG evaluations)");
   std::vector<Fe> abc[3];
   host_spmv3(d->circ.b, z, abc);
   for (int q = 0; q < 3; q++) abc[q].resize(K.n, Fe::zero());
   for (uint32_t i = 0; i <= K.n_pub; i++) abc[0][K.n_c + i] = z[i];
   const double t_wit = now_s();
+  int rc;
   std::lock_guard<std::mutex> g(ctx->mu);
   P_TRY(hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
@@ -485,12 +661,12 @@ int vimz_decider_prove(vimz_decider* d, vimz_cf_merged* m, const uint64_t kzg[16
   P_TRY(hipMemcpyAsync(part.data(), dpart, sizeof(G2P) * PT, hipMemcpyDeviceToHost, s));
   P_TRY(hipStreamSynchronize(s));
   G2P sb2 = G2P::identity();
-  for (auto& p : part) add_full(sb2, p);
+  for (auto& pp : part) add_full(sb2, pp);
   const double t_msm = now_s();
-  // A = alpha + Σ z_i a_i + r·delta;  B = beta + Σ z_i b_i + s·delta;  C = Σ_priv z_i l_i + Σ h_j hq_j + s·A + r·B1 − r·s·delta
-  Sha3 hs; hs.update(d->seed.data(), d->seed.size()); hs.update("vimz-decider-rs", 15); hs.update(z.data(), 32 * (size_t)(K.n_pub + 1));
-  uint8_t dg[32]; hs.finish(dg);
-  const Fe r = fr_from_hash(dg, 32, "r"), sr = fr_from_hash(dg, 32, "s");
+  // A = alpha + Σ z_i a_i + r·delta;  B = beta + Σ z_i b_i + s·delta;  C = Σ_priv z_i l_i + Σ h_j hq_j + s·A + r·B1 − r·s·delta;  r, s fresh from the OS (zero knowledge)
+  Fe r, sr;
+  { uint8_t raw[2][32]; if (!os_random(raw, sizeof(raw))) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_decider_prove: no randomness from the OS");
+    raw[0][31] = raw[1][31] = 0; Fe c; memcpy(c.v, raw[0], 32); r = Fe::to_mont(c); memcpy(c.v, raw[1], 32); sr = Fe::to_mont(c); }
   G1 A = from_affine(K.alpha1); add_mixed(A, sa); { G1 t = host_mul_fr<Fq>(K.delta1, r); add_full(A, t); }
   G1 B1 = from_affine(K.beta1); add_mixed(B1, sb1); { G1 t = host_mul_fr<Fq>(K.delta1, sr); add_full(B1, t); }
   G2P B2 = from_affine(K.beta2); add_full(B2, sb2); { G2P t = host_mul_fr<Fq2>(K.delta2, sr); add_full(B2, t); }
@@ -500,12 +676,41 @@ int vimz_decider_prove(vimz_decider* d, vimz_cf_merged* m, const uint64_t kzg[16
   { G1 t = host_mul_fr<Fq>(B1a, r); add_full(C, t); }
   { G1 t = host_mul_fr<Fq>(K.delta1, Fe::mul(r, sr)); if (!t.is_identity()) t.Y = Fq::neg(t.Y); add_full(C, t); }
   const G1Aff Ca = to_affine(C); const G2PAff Ba = to_affine(B2);
-  auto put = [&](uint64_t* dst, const Fq& mont) { const Fq c = Fq::from_mont(mont); memcpy(dst, c.v, 32); };
-  put(proof_out, Aa.x); put(proof_out + 4, Aa.y);
-  put(proof_out + 8, Ba.x.c0); put(proof_out + 12, Ba.x.c1); put(proof_out + 16, Ba.y.c0); put(proof_out + 20, Ba.y.c1);
-  put(proof_out + 24, Ca.x); put(proof_out + 28, Ca.y);
+  // the 25 words
+  uint64_t* w = words_out;
+  memset(w, 0, 800);
+  put_fq(w + 0, ivc->UW.x); put_fq(w + 4, ivc->UW.y); put_fq(w + 8, ivc->UE.x); put_fq(w + 12, ivc->UE.y);
+  put_fq(w + 16, ivc->uW.x); put_fq(w + 20, ivc->uW.y); put_fq(w + 24, cmT.x); put_fq(w + 28, cmT.y);
+  w[32] = (uint64_t)r_low[0] | ((uint64_t)r_low[1] << 32); w[33] = (uint64_t)r_low[2] | ((uint64_t)r_low[3] << 32); w[34] = 1;      // r = 2^128 + low
+  put_fq(w + 36, Aa.x); put_fq(w + 40, Aa.y);
+  put_fq(w + 44, Ba.x.c1); put_fq(w + 48, Ba.x.c0); put_fq(w + 52, Ba.y.c1); put_fq(w + 56, Ba.y.c0);      // imaginary parts first, as the EVM's precompile takes G2
+  put_fq(w + 60, Ca.x); put_fq(w + 64, Ca.y);
+  { const Fe c = Fe::from_mont(cW); memcpy(w + 68, c.v, 32); } { const Fe c = Fe::from_mont(cE); memcpy(w + 72, c.v, 32); }
+  memcpy(w + 76, kzg_out[0], 32); memcpy(w + 80, kzg_out[1], 32);
+  memcpy(w + 84, kzg_out[0] + 4, 64); memcpy(w + 92, kzg_out[1] + 4, 64);
   for (uint32_t i = 0; i < K.n_pub; i++) { const Fe c = Fe::from_mont(z[1 + i]); memcpy(public_out + 4 * i, c.v, 32); }
-  if (seconds) { seconds[0] = t_wit - t_all; seconds[1] = t_ntt - t_wit; seconds[2] = t_msm - t_ntt; seconds[3] = now_s() - t_all; }
+  if (seconds) { seconds[0] = t_fold - t_all; seconds[1] = t_wit - t_fold; seconds[2] = t_ntt - t_wit; seconds[3] = t_msm - t_ntt; seconds[4] = now_s() - t_all; seconds[5] = 0; }
+  return VIMZ_OK;
+}
+
+// Decider::verify (reached from `verify_final_proof`, vimz/src/sonobe_backend/decider.rs:31-50, mod.rs:80): what the contract generated for this key
+// does with (steps, z_0, z_i, 25 words) — contracts/ContrastVerifier.sol:685-783 — on the host: steps >= 2, the two folded commitments, their
+// KZG openings, the Groth16 proof for the public inputs the words imply.  *result = 0 accepted; else a bit set: 1 fewer than two steps, 2 KZG
+// opening of cmW, 4 of cmE, 8 Groth16, 16 a word pair is not a curve point (the contract's precompile would revert).  Host only.
+int vimz_decider_verify(const vimz_decider* d, uint64_t steps, const uint64_t* z0, const uint64_t* zi, const uint64_t words[100], uint32_t* result) {
+  if (!d || !z0 || !zi || !words || !result) return VIMZ_ERR_INVALID;
+  if (aff_is_identity(d->kzg_vk)) return vz_fail(d->ctx, VIMZ_ERR_INVALID, "vimz_decider_verify: the decider was set up without the SRS's verifying key");
+  *result = verify_words(key_of(d), steps, z0, zi, words);
+  return VIMZ_OK;
+}
+// the same with the key as bytes (vimz_decider_vk's layout; also how a contract's constants are fed in: tests/test_decider_verify_host.py runs the
+// reference's six committed proofs through this with the constants of contracts/*Verifier.sol).  No context, no GPU.
+int vimz_decider_verify_key(const uint64_t* key_words, size_t n_key_words, uint64_t steps, const uint64_t* z0, const uint64_t* zi, uint32_t len_z,
+                            const uint64_t words[100], uint32_t* result) {
+  if (!key_words || !z0 || !zi || !words || !result) return VIMZ_ERR_INVALID;
+  VerifierKey K;
+  if (!parse_key(key_words, n_key_words, &K) || K.len_z != len_z) return VIMZ_ERR_INVALID;
+  *result = verify_words(K, steps, z0, zi, words);
   return VIMZ_OK;
 }
 

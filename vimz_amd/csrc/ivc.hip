@@ -669,12 +669,48 @@ int vimz_ivc_fold_witness(vimz_ivc* v, const uint64_t* witnesses, size_t nsteps)
   try { return ivc_fold_core(v, nullptr, witnesses, nsteps); } catch (const std::exception& e) { return vz_fail(v->ctx, VIMZ_ERR_INVALID, e.what()); }
 }
 
+// A fingerprint of the HOST a benchmark line was measured on, so that a box-to-box gap is attributable from the line alone (bench.py):
+// out[0] = µs per Poseidon permutation (t = 9, BN254 Fr) on one host core — the unit of the verifier circuits' witness generation;
+// out[1] = µs per empty kernel launch + stream synchronise on the context's stream (median of 200) — the unit of every host/GPU hand-over;
+// out[2] = host cores this process may use (affinity mask and cgroup quota); out[3] = µs per hipEventRecord + hipEventSynchronize (median of 200).
+namespace vz { __global__ void k_fingerprint_empty() {} }
+int vimz_host_fingerprint(vimz_ctx* ctx, double out[4]) {
+  if (!ctx || !out) return VIMZ_ERR_INVALID;
+  {
+    std::vector<Fe> in(8);
+    for (int k = 0; k < 8; k++) in[k] = cb::f_from_u64<Fe>(0x9e3779b97f4a7c15ull * (k + 1));
+    const int N = 2000;
+    const double t0 = now_s();
+    for (int i = 0; i < N; i++) in[i & 7] = hash_native<BnFr>(in);
+    out[0] = 1e6 * (now_s() - t0) / N;
+    if (in[0].is_zero()) out[0] = -1;      // (keeps the loop)
+  }
+  std::lock_guard<std::mutex> g(ctx->mu);
+  P_TRY(hipSetDevice(ctx->device));
+  P_TRY(hipStreamSynchronize(ctx->stream));
+  std::vector<double> a(200), b(200);
+  hipEvent_t ev; P_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  for (int i = 0; i < 200; i++) {
+    double t0 = now_s();
+    hipLaunchKernelGGL(vz::k_fingerprint_empty, dim3(1), dim3(64), 0, ctx->stream);
+    hipStreamSynchronize(ctx->stream);
+    a[i] = 1e6 * (now_s() - t0);
+    t0 = now_s();
+    hipEventRecord(ev, ctx->stream); hipEventSynchronize(ev);
+    b[i] = 1e6 * (now_s() - t0);
+  }
+  hipEventDestroy(ev);
+  P_TRY(hipGetLastError());
+  std::sort(a.begin(), a.end()); std::sort(b.begin(), b.end());
+  out[1] = a[100]; out[2] = (double)usable_cpus(); out[3] = b[100];
+  return VIMZ_OK;
+}
 int vimz_ivc_info(const vimz_ivc* v, uint64_t info[12]) {
   if (!v || !info) return VIMZ_ERR_INVALID;
   const cb::Builder& b1 = v->circ1->build->b; const cb::BuilderT<Fq>& b2 = v->c2.b;
   info[0] = v->i; info[1] = b1.n_wires; info[2] = b1.n_constraints(); info[3] = v->c1->step_wires; info[4] = v->c1->step_constraints;
   info[5] = b2.n_wires; info[6] = b2.n_constraints(); info[7] = v->c1->len_z; info[8] = v->c1->aug_wires();
-  info[9] = b1.A.col.size() + b1.B.col.size() + b1.C.col.size(); info[10] = b2.A.col.size() + b2.B.col.size() + b2.C.col.size(); info[11] = 0;
+  info[9] = b1.A.col.size() + b1.B.col.size() + b1.C.col.size(); info[10] = b2.A.col.size() + b2.B.col.size() + b2.C.col.size(); info[11] = v->pri->last_head_rows;
   return VIMZ_OK;
 }
 int vimz_ivc_state(const vimz_ivc* v, uint64_t* z_current, uint64_t* steps) {

@@ -165,6 +165,7 @@ struct vimz_prover {
   Fe* stage_host = nullptr; Fe* jobvals_host = nullptr; Fe* zs_host = nullptr;   // pinned
   uint32_t *stage_d = nullptr, *jobvals_d = nullptr;
   size_t head_rows_cap = 0;
+  size_t last_head_rows = 0;             // rows of the last fold call whose Poseidon chains were evaluated on the host (the head batch)
   // row-hash jobs of a coming call's head rows, evaluated ahead (head_precompute): the call over exactly these inputs finds them done
   const uint64_t* pre_inputs = nullptr; size_t pre_rows = 0;
   bool head_eligible = false;
@@ -751,6 +752,7 @@ static int fold_prepare(vimz_prover* p, FoldJob& J, bool start_batch0 = false) {
   { static const bool dbg_t = getenv("VIMZ_DEBUG_TIMING") != nullptr; if (dbg_t) fprintf(stderr, "[timing] prepare: buffers + upload of the inputs %.2f ms\n", 1e3 * (now_s() - t0)); }
   const bool plain = J.nA && !J.nE && !J.early_fops;           // no ahead-of-time witness pass needed (everything but crop)
   const size_t head = start_batch0 && plain && p->head_eligible ? std::min(std::min(head_rows_wanted(nsteps), B), nsteps) : 0;
+  p->last_head_rows = head;
   if (head) {
     J.head = true;
     plan_batches(J, 0, head, B);

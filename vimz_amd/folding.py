@@ -79,8 +79,9 @@ class FoldingParams:
     """The analogue of nova-snark's PublicParams: R1CS shape + both commitment keys (BN254 G1 for the primary circuit, Grumpkin for
     the secondary), resident on one GPU."""
 
-    def __init__(self, ctx, circuit, ck, keygen_seconds, ck_secondary=None):
+    def __init__(self, ctx, circuit, ck, keygen_seconds, ck_secondary=None, kzg_vk=None):
         self.ctx, self.circuit, self.ck, self.keygen_seconds, self.ck_secondary = ctx, circuit, ck, keygen_seconds, ck_secondary
+        self.kzg_vk = kzg_vk      # backend "sonobe": [tau]G2 of the KZG SRS `ck` is (the decider's verifier needs it)
 
     def secondary_key(self):
         if self.ck_secondary is None:
@@ -101,15 +102,22 @@ def prepare_folding(ctx, transformation, resolution="HD", ck_label=b"ck", window
     1.10 -> 0.84 ms alone, the three-segment bench 964 -> 1095 steps/s, profiles/r04_msm_phases_tables.txt); 11 = tables with the usual
     per-window buckets (no Horner on the host); 0 = none.
     backend: "nova-snark" (vimz/src/nova_snark_backend) or "sonobe" (vimz/src/sonobe_backend: Nova + CycleFold, fold_input(mode="cyclefold"));
-    it only sizes the key (the reference's two backends size theirs the same way: for the augmented circuit)."""
+    the reference's two backends size their keys the same way (for the augmented circuit); Sonobe's is a KZG SRS (`KZG::setup` inside
+    `prepare_folding`, vimz/src/sonobe_backend/folding.rs:36-48): powers of a tau drawn from the OS's randomness and forgotten
+    (vimz_kzg_setup), whose [tau]G2 is kept in FoldingParams.kzg_vk for the decider's verifier."""
     t0 = time.time()
     circuit = Circuit(transformation, *default_shape(transformation, resolution))
     # next power of two, as nova-snark sizes ck — of the AUGMENTED circuit: the verifier circuit adds 7.7 k wires / rows
     n = 1 << (max(circuit.n_wires, circuit.n_constraints) + (CYCLEFOLD_ROOM if backend == "sonobe" else AUGMENTED_ROOM) - 1).bit_length()
-    ck = ctx.bases_generate(_lib.CURVE_BN254_G1, n, ck_label)
+    kzg_vk = None
+    if backend == "sonobe":
+        from . import hip
+        ck, kzg_vk = hip.kzg_setup(ctx, n)
+    else:
+        ck = ctx.bases_generate(_lib.CURVE_BN254_G1, n, ck_label)
     if window_tables:
         ck.precompute(16 if window_tables is True else int(window_tables))
-    return circuit, FoldingParams(ctx, circuit, ck, time.time() - t0)
+    return circuit, FoldingParams(ctx, circuit, ck, time.time() - t0, kzg_vk=kzg_vk)
 
 
 def default_batch(circuit):

@@ -91,6 +91,22 @@ class Context:
         self._chk(self.lib.vimz_device_info(self.h, name, 256, C.byref(cus), C.byref(hbm)))
         return {"name": name.value.decode(), "cus": cus.value, "hbm_bytes": hbm.value}
 
+    def host_fingerprint(self):
+        """vimz_host_fingerprint: what a benchmark line says about the HOST it was measured on."""
+        out = (C.c_double * 4)()
+        self.lib.vimz_host_fingerprint.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        self._chk(self.lib.vimz_host_fingerprint(self.h, out))
+        model = "?"
+        try:
+            for line in open("/proc/cpuinfo"):
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+        except OSError:
+            pass
+        return {"cpu_model": model, "us_per_host_poseidon_t9": out[0], "us_per_empty_launch_and_sync": out[1], "usable_cores": int(out[2]),
+                "us_per_event_record_and_sync": out[3]}
+
     def trace_marker(self, ident):
         """vimz_trace_marker: an empty kernel of `ident` workgroups in the profiler's kernel trace (bench.py: 1 / 2 around the timed region)."""
         self.lib.vimz_trace_marker.argtypes = [C.c_void_p, C.c_int]
@@ -430,7 +446,7 @@ class IVC:
         a = np.zeros(12, dtype=np.uint64)
         self.ctx._chk(self.ctx.lib.vimz_ivc_info(self.h, _ptr(a)))
         keys = ["steps", "primary_wires", "primary_constraints", "step_wires", "step_constraints", "secondary_wires", "secondary_constraints",
-                "len_z", "verifier_wires", "primary_nnz", "secondary_nnz"]
+                "len_z", "verifier_wires", "primary_nnz", "secondary_nnz", "head_rows"]
         return {k: int(a[i]) for i, k in enumerate(keys)}
 
     def state(self):
@@ -707,26 +723,57 @@ def cyclefold_selfcheck_merge(segs_run0=3, segs_run1=2):
     return dg, rec, acc
 
 
-class Decider:
-    """vimz_decider: `Decider::preprocess` / `Decider::prove` of the Sonobe backend (vimz/src/sonobe_backend/mod.rs:72-78) — the Groth16 proof of
-    the final fold, eight of the 25 calldata words.  prover: a CycleFoldIVC (shapes, keys, context; keep it open).  The setup is a deterministic
-    TEST setup: the trapdoor is derived from `seed`."""
+def kzg_setup(ctx, n, seed=None):
+    """KZG::setup: (srs as Bases — use it as ck_main of a CycleFoldIVC —, vk_g2 = [tau]G2 as a (4, 4) uint64 array for Decider).  tau comes from the
+    OS's randomness and is forgotten; `seed` (bytes) selects the deterministic TEST setup of libvimz_hip_testing.so instead."""
+    vp = C.c_void_p
+    h = vp()
+    vk = np.zeros((4, 4), dtype=np.uint64)
+    if seed is None:
+        ctx.lib.vimz_kzg_setup.argtypes = [vp, C.c_size_t, C.POINTER(vp), vp]
+        ctx._chk(ctx.lib.vimz_kzg_setup(ctx.h, n, C.byref(h), _ptr(vk)))
+    else:
+        fn = _seeded(ctx, "vimz_testing_kzg_setup_seeded")
+        fn.argtypes = [vp, C.c_char_p, C.c_size_t, C.c_size_t, C.POINTER(vp), vp]
+        ctx._chk(fn(ctx.h, bytes(seed), len(seed), n, C.byref(h), _ptr(vk)))
+    return Bases(ctx, h, L.CURVE_BN254_G1, n), vk
 
-    def __init__(self, prover, seed=b"vimz-test-setup"):
+
+def _seeded(ctx, name):
+    if not hasattr(ctx.lib, name):
+        raise RuntimeError(f"{name} exists only in libvimz_hip_testing.so (start the process with VIMZ_HIP_LIBRARY=testing): seeded setups are test hooks")
+    return getattr(ctx.lib, name)
+
+
+class Decider:
+    """vimz_decider: `Decider::preprocess` / `prove` / `verify` of the Sonobe backend (vimz/src/sonobe_backend/mod.rs:72-80) — the 25 calldata words of
+    contracts/*Verifier.sol and their local verification.  prover: a CycleFoldIVC (shapes, keys, context; keep it open); kzg_vk: [tau]G2 of the SRS
+    its ck_main is made of (kzg_setup), or None (no verify).  The Groth16 trapdoor is drawn from the OS's randomness and forgotten; `seed` selects
+    the deterministic TEST setup of libvimz_hip_testing.so."""
+    RESULT_BITS = {1: "fewer than two steps", 2: "KZG opening of cmW", 4: "KZG opening of cmE", 8: "Groth16", 16: "a word pair is not a curve point"}
+
+    def __init__(self, prover, kzg_vk=None, seed=None):
         self.prover, self.ctx = prover, prover.ctx
         lib = self.ctx.lib
         vp = C.c_void_p
-        lib.vimz_decider_setup.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(vp), C.POINTER(C.c_double)]
+        lib.vimz_decider_setup.argtypes = [vp, vp, C.POINTER(vp), C.POINTER(C.c_double)]
         lib.vimz_decider_free.argtypes = [vp]
         lib.vimz_decider_free.restype = None
         lib.vimz_decider_info.argtypes = [vp, vp]
         lib.vimz_decider_vk.argtypes = [vp, vp, C.c_size_t]
         lib.vimz_decider_vk.restype = C.c_int64
-        lib.vimz_decider_prove.argtypes = [vp, vp, vp, vp, vp, C.POINTER(C.c_double)]
+        lib.vimz_decider_prove.argtypes = [vp, vp, vp, vp, C.POINTER(C.c_double)]
+        lib.vimz_decider_verify.argtypes = [vp, C.c_uint64, vp, vp, vp, C.POINTER(C.c_uint32)]
         h = vp()
         sec = (C.c_double * 4)()
-        seed = bytes(seed)
-        self.ctx._chk(lib.vimz_decider_setup(prover.h, seed, len(seed), C.byref(h), sec))
+        self._kzg_vk = None if kzg_vk is None else np.ascontiguousarray(kzg_vk, dtype=np.uint64)
+        kp = None if self._kzg_vk is None else _ptr(self._kzg_vk)
+        if seed is None:
+            self.ctx._chk(lib.vimz_decider_setup(prover.h, kp, C.byref(h), sec))
+        else:
+            fn = _seeded(self.ctx, "vimz_testing_decider_setup_seeded")
+            fn.argtypes = [vp, vp, C.c_char_p, C.c_size_t, C.POINTER(vp), C.POINTER(C.c_double)]
+            self.ctx._chk(fn(prover.h, kp, bytes(seed), len(seed), C.byref(h), sec))
         self.h = h
         self.setup_seconds = {"circuit_synthesis": sec[0], "qap_at_trapdoor_host": sec[1], "key_points_gpu": sec[2], "total": sec[3]}
 
@@ -740,28 +787,98 @@ class Decider:
         self.ctx._chk(self.ctx.lib.vimz_decider_info(self.h, _ptr(a)))
         return dict(zip(["constraints", "wires", "public_inputs", "domain", "nnz_a", "nnz_b", "nnz_c"], (int(x) for x in a[:7])))
 
-    def verifying_key(self):
-        """{"alpha": G1, "beta": G2, "gamma": G2, "delta": G2, "ic": [G1 ...]} as Python integers; G2 points ((x.c0, x.c1), (y.c0, y.c1))."""
-        w = [int(x) for x in _export(self.ctx.lib.vimz_decider_vk, self.h).view(np.uint64)]
-        el = lambda k: sum(w[4 * k + q] << (64 * q) for q in range(4))
-        g2 = lambda k: ((el(k), el(k + 1)), (el(k + 2), el(k + 3)))
-        n_ic = w[4 * 14]
-        base = 14 * 4 + 1
-        ic = [(sum(w[base + 8 * j + q] << (64 * q) for q in range(4)), sum(w[base + 8 * j + 4 + q] << (64 * q) for q in range(4))) for j in range(n_ic)]
-        return {"alpha": (el(0), el(1)), "beta": g2(2), "gamma": g2(6), "delta": g2(10), "ic": ic}
+    def key_words(self):
+        """vimz_decider_vk's words (uint64 array): what vimz_decider_verify_key takes."""
+        return _export(self.ctx.lib.vimz_decider_vk, self.h).view(np.uint64)
 
-    def prove(self, merged, kzg):
-        """merged: a CycleFoldMerged of ONE segment over the same prover; kzg = (c_W, c_E, e_W, e_E).  Returns (public inputs: ints,
-        proof: (A: G1, B: G2 as ((x.c0, x.c1), (y.c0, y.c1)), C: G1), seconds dict)."""
-        k = _zlimbs(list(kzg), 4)
+    def verifying_key(self):
+        """The constants of a contract generated for this circuit, as Python integers, in the shape tests/_novadecider.py's `verify` takes:
+        {"len_z", "pp_hash", "groth16": {"alpha": G1, "beta", "gamma", "delta": G2, "ic": [G1 ...]}, "kzg": {"G_1": G1, "G_2": G2, "VK": G2}};
+        G2 points ((x.c0, x.c1), (y.c0, y.c1)) = (real, imaginary)."""
+        return parse_verifying_key(self.key_words())
+
+    def prove(self, ivc=None):
+        """Decider::prove for the IVC proof `ivc` (default: the prover the decider was set up over) holds.  Returns (25 words: ints, public inputs:
+        ints, seconds dict)."""
+        ivc = self.prover if ivc is None else ivc
         n_pub = self.info()["public_inputs"]
         pub = np.zeros((n_pub, 4), dtype=np.uint64)
-        pr = np.zeros((8, 4), dtype=np.uint64)
-        sec = (C.c_double * 4)()
-        self.ctx._chk(self.ctx.lib.vimz_decider_prove(self.h, merged.h, _ptr(k), _ptr(pub), _ptr(pr), sec))
+        words = np.zeros((25, 4), dtype=np.uint64)
+        sec = (C.c_double * 6)()
+        self.ctx._chk(self.ctx.lib.vimz_decider_prove(self.h, ivc.h, _ptr(pub), _ptr(words), sec))
         ints = lambda a: [sum(int(a[i, q]) << (64 * q) for q in range(4)) for i in range(a.shape[0])]
-        p = ints(pr)
-        return ints(pub), ((p[0], p[1]), ((p[2], p[3]), (p[4], p[5])), (p[6], p[7])), {"witness_host": sec[0], "ntt": sec[1], "msm": sec[2], "total": sec[3]}
+        return ints(words), ints(pub), {"final_fold_and_kzg": sec[0], "witness_host": sec[1], "ntt": sec[2], "msm": sec[3], "total": sec[4]}
+
+    def verify(self, steps, z0, z_i, words):
+        """Decider::verify: 0 = accepted, else the bit set of RESULT_BITS."""
+        z0a, zia, wa = _zlimbs([int(x) for x in z0], len(z0)), _zlimbs([int(x) for x in z_i], len(z_i)), _zlimbs([int(x) for x in words], 25)
+        res = C.c_uint32(0)
+        self.ctx._chk(self.ctx.lib.vimz_decider_verify(self.h, int(steps), _ptr(z0a), _ptr(zia), _ptr(wa), C.byref(res)))
+        return int(res.value)
+
+
+def parse_verifying_key(w):
+    w = [int(x) for x in w]
+    pos = [0]
+
+    def el():
+        v = sum(w[pos[0] + q] << (64 * q) for q in range(4))
+        pos[0] += 4
+        return v
+
+    def g1():
+        return (el(), el())
+
+    def g2():
+        return ((el(), el()), (el(), el()))
+
+    pp = el()
+    len_z = w[pos[0]]
+    pos[0] += 1
+    alpha, beta, gamma, delta = g1(), g2(), g2(), g2()
+    n_ic = w[pos[0]]
+    pos[0] += 1
+    ic = [g1() for _ in range(n_ic)]
+    kz = {"G_1": g1(), "G_2": g2(), "VK": g2()}
+    assert pos[0] == len(w)
+    return {"len_z": len_z, "pp_hash": pp, "groth16": {"alpha": alpha, "beta": beta, "gamma": gamma, "delta": delta, "ic": ic}, "kzg": kz}
+
+
+def verifying_key_words(key):
+    """The inverse of parse_verifying_key: a key in tests/_novadecider.py's shape as the words vimz_decider_verify_key takes."""
+    out = []
+
+    def el(v):
+        out.extend((int(v) >> (64 * q)) & 0xFFFFFFFFFFFFFFFF for q in range(4))
+
+    def g1(p):
+        el(p[0]); el(p[1])
+
+    def g2(p):
+        el(p[0][0]); el(p[0][1]); el(p[1][0]); el(p[1][1])
+
+    g = key["groth16"]
+    el(key["pp_hash"]); out.append(int(key["len_z"]))
+    g1(g["alpha"]); g2(g["beta"]); g2(g["gamma"]); g2(g["delta"])
+    out.append(len(g["ic"]))
+    for p in g["ic"]:
+        g1(p)
+    g1(key["kzg"]["G_1"]); g2(key["kzg"]["G_2"]); g2(key["kzg"]["VK"])
+    return np.array(out, dtype=np.uint64)
+
+
+def decider_verify_key(key_words, steps, z0, z_i, words):
+    """vimz_decider_verify_key: host only, no context, no GPU.  Returns the result bits (0 = accepted); raises VimzError on a malformed key."""
+    lib = L.lib()
+    vp = C.c_void_p
+    lib.vimz_decider_verify_key.argtypes = [vp, C.c_size_t, C.c_uint64, vp, vp, C.c_uint32, vp, C.POINTER(C.c_uint32)]
+    kw = np.ascontiguousarray(key_words, dtype=np.uint64)
+    z0a, zia, wa = _zlimbs([int(x) for x in z0], len(z0)), _zlimbs([int(x) for x in z_i], len(z_i)), _zlimbs([int(x) for x in words], 25)
+    res = C.c_uint32(0)
+    rc = lib.vimz_decider_verify_key(_ptr(kw), kw.size, int(steps), _ptr(z0a), _ptr(zia), len(z0), _ptr(wa), C.byref(res))
+    if rc:
+        raise L.VimzError(rc, "vimz_decider_verify_key: malformed key or arguments")
+    return int(res.value)
 
 
 class CycleFoldMerged:
