@@ -62,6 +62,7 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
   int rc;
   const double t_all = now_s();
   FoldJob job; job.step_inputs = step_inputs; job.witnesses = witnesses; job.nsteps = nsteps;
+  dbg_stamp(p, "ivc fold: lock taken");
   if ((rc = fold_prepare(p, job, true))) return rc;
   // Any return between here and the end that does not first restore a consistent state (rows folded so far, no cross term queued
   // ahead, state = that of the last folded row) leaves work of a half-done step behind: such an IVC refuses further folds.
@@ -201,9 +202,10 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
     double t0 = now_s();
     allowed.store(k + 2, std::memory_order_release);       // the next batch is produced while this one is folded
     if ((rc = wait_issued(k))) return rc;                  // (batch 0 of a head-batch call is already out)
+    if (k == 0) dbg_stamp(p, "ivc fold: first batch issued");
     P_TRY(vz_wait_event(bb.wit_done));
     v->ph_s[IP_PRODUCER] += now_s() - t0;
-    if (k == 0) { t_wait0 = now_s() - t0; t_first = now_s() - t_all; }
+    if (k == 0) { t_wait0 = now_s() - t0; t_first = now_s() - t_all; dbg_stamp(p, "ivc fold: first batch's witnesses ready"); }
     for (size_t r = 0; r < rows; r++) if (bb.status_host[r]) {
       char msg[128]; snprintf(msg, sizeof(msg), "step %llu: the step relation is not satisfiable for these rows", (unsigned long long)(v->i + r));
       // the batches folded so far stay folded: leave the IVC consistent at that point (cross terms of this batch's rows were queued ahead)

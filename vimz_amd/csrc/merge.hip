@@ -708,7 +708,7 @@ int vimz_ivc_fold_segments_dg(vimz_ivc* const* segs, size_t n_seg, const uint64_
   std::vector<std::thread> th_dig, th_fold;
   bool pre_mode = stride && S > 1 && getenv("VIMZ_DEBUG_NO_HEAD_PRECOMPUTE") == nullptr;      // (also with the caller's digests: the folds then start a pool round apart instead of together after three)
   for (size_t k = 0; k < S && pre_mode; k++) pre_mode = head_takes_whole_call(segs[k]->pri, hi[k] - lo[k]) && !segs[k]->broken;
-  if (stride && S > 1 && !digests && !pre_mode)
+  if (stride && S > 1 && !digests && !pre_mode && getenv("VIMZ_DEBUG_NO_DEFERRED_START") != nullptr)
     for (size_t k = 0; k + 1 < S; k++) {
       dig[k].resize(4 * stride * (hi[k] - lo[k]));
       th_dig.emplace_back([&, k] { rc_dig[k] = vimz_ivc_row_digests(segs[k + 1], step_inputs + 4 * n_priv * lo[k], hi[k] - lo[k], dig[k].data()); });
@@ -747,7 +747,26 @@ int vimz_ivc_fold_segments_dg(vimz_ivc* const* segs, size_t n_seg, const uint64_
     th_fold.emplace_back([&, k] { rc_fold[k] = vimz_ivc_fold(segs[k], step_inputs + 4 * n_priv * lo[k], hi[k] - lo[k]); });
     started = k + 1;
   }
-  for (size_t k = 0; k < S && !rc && !pre; k++) {
+  // GPU-evaluated row hashes, every row hashed ONCE: all segments' fold calls begin now — inputs uploaded, the row-hash chains of their first
+  // batches running side by side, with their wires — and segment k takes its start state from segment k-1's host state chain the moment that
+  // exists (vimz_prover::start_from / end_to), one chain latency after the start.  (Until round 5 segment k first waited for a hash-only pass over
+  // segment k-1's rows on its own context and then hashed its own rows: two chain latencies in front of the later segments' first folds.)
+  const bool deferred = !pre && stride && S > 1 && !digests && getenv("VIMZ_DEBUG_NO_DEFERRED_START") == nullptr;
+  std::vector<std::unique_ptr<StartLink>> links;
+  if (deferred) {
+    for (size_t k = 0; k + 1 < S; k++) links.emplace_back(new StartLink());
+    for (size_t k = 0; k < S && !rc; k++) {
+      if ((rc = vimz_ivc_reset(segs[k], z.data()))) break;      // (segments after the first: a placeholder, replaced when their start state arrives)
+      vimz_prover* pk = segs[k]->pri; vimz_ivc* vk = segs[k];
+      pk->start_from = k > 0 ? links[k - 1].get() : nullptr; pk->end_to = k + 1 < S ? links[k].get() : nullptr;
+      pk->on_start = [vk] { for (uint32_t q = 0; q < vk->c1->len_z; q++) vk->z0[q] = vk->pri->z_cur[q]; };
+    }
+    for (size_t k = 0; k < S && !rc; k++) {
+      th_fold.emplace_back([&, k] { rc_fold[k] = vimz_ivc_fold(segs[k], step_inputs + 4 * n_priv * lo[k], hi[k] - lo[k]); if (rc_fold[k] && k + 1 < S) links[k]->fail(); });
+      started = k + 1;
+    }
+  }
+  for (size_t k = 0; k < S && !rc && !pre && !deferred; k++) {
     if (k > 0) {
       const double t0 = now_s();
       const size_t n = hi[k - 1] - lo[k - 1];
@@ -767,6 +786,7 @@ int vimz_ivc_fold_segments_dg(vimz_ivc* const* segs, size_t n_seg, const uint64_
     started = k + 1;
   }
   for (auto& t : th_fold) t.join();
+  for (size_t k = 0; k < S; k++) { segs[k]->pri->start_from = nullptr; segs[k]->pri->end_to = nullptr; segs[k]->pri->on_start = nullptr; }
   for (size_t k = 0; k < th_dig.size(); k++) if (th_dig[k].joinable()) th_dig[k].join();
   for (size_t k = 0; k < started && !rc; k++) if (rc_fold[k]) { rc = rc_fold[k]; if (segs[k]->ctx != ctx) ctx->err = segs[k]->ctx->err; }
   if (rc) { if (pre) drop_pre(); return rc; }

@@ -206,15 +206,13 @@ int vimz_prover_reset(vimz_prover* p, const uint64_t* z0) {
   std::lock_guard<std::mutex> g(ctx->mu);
   P_TRY(hipSetDevice(ctx->device));
   for (uint32_t i = 0; i < p->len_z; i++) p->z_cur[i] = fe_from_canon(z0 + 4 * i);
-  p->z0 = p->z_cur;
   p->steps = 0; p->u = Fe::zero();
   p->comm_W.x = Fq::zero(); p->comm_W.y = Fq::zero(); p->comm_E = p->comm_W;
   // RO state seeded with a digest of the shape (stand-in for nova-snark's pp digest)
   Fe seed[6] = {cb::fe_from_u64(0x56494d7a), cb::fe_from_u64(p->n_c), cb::fe_from_u64(p->n_wires), cb::fe_from_u64(p->len_z),
                 cb::fe_from_u64((uint64_t)p->circuit->transformation), cb::fe_from_u64((uint64_t)p->circuit->shape.width)};
   p->ro = cb::poseidon_hash(seed, 6);
-  p->zdigest = Fe::zero();
-  for (uint32_t i = 0; i < p->len_z; i++) { Fe in[2] = {p->zdigest, p->z_cur[i]}; p->zdigest = cb::poseidon_hash(in, 2); }
+  prover_start_state_changed(p);
   memset(p->phase_s, 0, sizeof(p->phase_s)); memset(p->phase_n, 0, sizeof(p->phase_n));
   P_TRY(hipMemsetAsync(p->Zrun, 0, 32 * (size_t)p->n_wires, ctx->stream));
   P_TRY(hipMemsetAsync(p->E, 0, 32 * (size_t)p->n_c, ctx->stream));

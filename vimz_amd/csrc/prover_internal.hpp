@@ -108,6 +108,14 @@ HostPool& vz_shared_pool();
 
 enum { PH_WITNESS = 0, PH_ZCHAIN, PH_SPMV, PH_MSM_W, PH_CROSS, PH_MSM_T, PH_RO, PH_FOLD, PH_HOST_EC, PH_COUNT };
 
+// one segment's end state handed to the next (vimz_prover::start_from / end_to)
+struct StartLink {
+  std::mutex mu; std::condition_variable cv; bool ready = false, failed = false; std::vector<vz::cb::Fe> z;
+  void publish(const vz::cb::Fe* zz, size_t n) { { std::lock_guard<std::mutex> g(mu); z.assign(zz, zz + n); ready = true; } cv.notify_all(); }
+  void fail() { { std::lock_guard<std::mutex> g(mu); if (!ready) { failed = true; ready = true; } } cv.notify_all(); }
+  bool wait(std::vector<vz::cb::Fe>& out) { std::unique_lock<std::mutex> g(mu); cv.wait(g, [&] { return ready; }); if (failed) return false; out = z; return true; }
+};
+
 struct vimz_prover {
   vimz_ctx* ctx = nullptr;
   const vimz_circuit* circuit = nullptr;
@@ -169,6 +177,12 @@ struct vimz_prover {
   // row-hash jobs of a coming call's head rows, evaluated ahead (head_precompute): the call over exactly these inputs finds them done
   const uint64_t* pre_inputs = nullptr; size_t pre_rows = 0;
   bool head_eligible = false;
+  // DEFERRED START STATE of a fold call (vimz_ivc_fold_segments): the segments of one proof are folded concurrently, and segment k starts at the
+  // state segment k-1 ends in — which follows from the row hashes of k-1's rows, one Poseidon-chain latency (4-5 ms) after ITS call began.  So
+  // every segment's call begins at once (inputs uploaded, the row-hash chains of its first batch running, with their wires), and only where the
+  // host state chain needs the start state does segment k wait for its predecessor's end state (start_from), set it (on_start: the IVC
+  // layer's z_0) and hand its own end state on (end_to).  Every row is hashed once; no segment waits for a hash-only pass of another's rows.
+  StartLink* start_from = nullptr; StartLink* end_to = nullptr; std::function<void()> on_start;
   // per fold call: all private inputs, all IVC states and all row hashes resident
   uint32_t *priv_all_d = nullptr, *zs_all_d = nullptr, *job_all_d = nullptr;
   size_t cap_priv_all = 0, cap_zs_all = 0, cap_job_all = 0;
@@ -711,8 +725,21 @@ static int fold_head_batch(vimz_prover* p, FoldJob& J, size_t rows) {
 // start_batch0 (the fold calls): the first batch is issued from here — as a host-evaluated head batch where the circuit allows it
 // (fold_head_batch), in which case the states of the remaining rows are finished by a helper thread (fold_states_wait) —, else
 // with its state-independent part started ahead.
+// z_cur was replaced as the state the NEXT rows start from before any row was folded (reset; a deferred start): what hangs on it
+static void prover_start_state_changed(vimz_prover* p) {
+  p->z0 = p->z_cur;
+  p->zdigest = Fe::zero();
+  for (uint32_t i = 0; i < p->len_z; i++) { Fe in[2] = {p->zdigest, p->z_cur[i]}; p->zdigest = cb::poseidon_hash(in, 2); }
+}
+// VIMZ_DEBUG_TIMING: where a fold call's prologue spends its time, on one clock for all the provers of a process
+static inline void dbg_stamp(const vimz_prover* p, const char* what) {
+  static const bool on = getenv("VIMZ_DEBUG_TIMING") != nullptr;
+  static const double t_origin = now_s();
+  if (on) fprintf(stderr, "[timing] %p %10.3f ms  %s\n", (const void*)p, 1e3 * (now_s() - t_origin), what);
+}
 static int fold_prepare(vimz_prover* p, FoldJob& J, bool start_batch0 = false) {
   vimz_ctx* ctx = p->ctx;
+  dbg_stamp(p, "fold_prepare: enter");
   hipStream_t s = ctx->stream;
   const cb::Builder& b = p->circuit->build->b;
   const WitnessDev& W = p->wd;
@@ -722,6 +749,8 @@ static int fold_prepare(vimz_prover* p, FoldJob& J, bool start_batch0 = false) {
   p->pre_rows = 0; p->pre_inputs = nullptr;
   for (auto& c : b.chains) (c.phase == 0 ? J.nA : c.phase == 1 ? J.nB : J.nE)++;
   for (auto& f : b.fops) if (f.early) J.early_fops = true;
+  struct EndGuard { StartLink* l; ~EndGuard() { if (l) l->fail(); } } end_guard{p->end_to};      // (a call that stops early must not leave its successor waiting)
+  if ((p->start_from || p->end_to) && (J.witnesses || !start_batch0 || J.nE || J.early_fops)) return vz_fail(ctx, VIMZ_ERR_INVALID, "fold: a deferred start state needs the plain witness schedule");
   J.zs.assign((nsteps + 1) * p->len_z, Fe::zero());
   std::vector<Fe>& zs = J.zs;
   for (uint32_t i = 0; i < p->len_z; i++) zs[i] = p->z_cur[i];
@@ -747,11 +776,14 @@ static int fold_prepare(vimz_prover* p, FoldJob& J, bool start_batch0 = false) {
   P_TRY(grow(p->retired, &p->priv_all_d, &p->cap_priv_all, 32 * nsteps * (size_t)p->n_priv, 32 * 1024 * (size_t)p->n_priv));
   P_TRY(grow(p->retired, &p->zs_all_d, &p->cap_zs_all, 32 * (nsteps + 1) * (size_t)p->len_z, 32 * 1025 * (size_t)p->len_z));
   P_TRY(grow(p->retired, &p->job_all_d, &p->cap_job_all, 32 * nsteps * jstride, 32 * 1024 * jstride));
+  dbg_stamp(p, "fold_prepare: buffers grown");
   P_TRY(hipMemcpyAsync(p->priv_all_d, J.step_inputs, 32 * nsteps * (size_t)p->n_priv, hipMemcpyHostToDevice, s));
+  dbg_stamp(p, "fold_prepare: inputs upload queued");
   P_TRY(hipMemsetAsync(p->job_all_d, 0, 32 * nsteps * jstride, s));
   { static const bool dbg_t = getenv("VIMZ_DEBUG_TIMING") != nullptr; if (dbg_t) fprintf(stderr, "[timing] prepare: buffers + upload of the inputs %.2f ms\n", 1e3 * (now_s() - t0)); }
   const bool plain = J.nA && !J.nE && !J.early_fops;           // no ahead-of-time witness pass needed (everything but crop)
-  const size_t head = start_batch0 && plain && p->head_eligible ? std::min(std::min(head_rows_wanted(nsteps), B), nsteps) : 0;
+  const bool deferred = p->start_from || p->end_to;      // (vimz_prover: deferred start state — needs the plain schedule: the head batch wants the state at once)
+  const size_t head = start_batch0 && plain && p->head_eligible && !deferred ? std::min(std::min(head_rows_wanted(nsteps), B), nsteps) : 0;
   p->last_head_rows = head;
   if (head) {
     J.head = true;
@@ -860,11 +892,25 @@ static int fold_prepare(vimz_prover* p, FoldJob& J, bool start_batch0 = false) {
   std::vector<Fe> jobA(nsteps * jstride);
   // (waited for on the HOST: a barrier on this high-priority stream behind the producer's low-priority event is the inversion of DESIGN.md §5c —
   //  the stalled barrier keeps the low-priority queue from being served, and with four processes on one GPU one of them then ran at 60 ms per step)
+  dbg_stamp(p, "fold_prepare: first batch's chains launched");
   if (J.started_batch >= 0) P_TRY(hipEventSynchronize(p->buf[J.started_batch & 1].wit_done));
+  dbg_stamp(p, "fold_prepare: chains done");
   P_TRY(hipMemcpyAsync(jobA.data(), p->job_all_d, 32 * nsteps * jstride, hipMemcpyDeviceToHost, s));
   P_TRY(hipStreamSynchronize(s));
+  dbg_stamp(p, "fold_prepare: row hashes on the host");
   p->phase_s[PH_WITNESS] += now_s() - t0; t0 = now_s();
+  if (p->start_from) {      // the state this call starts from: the predecessor segment's end state (it follows from ITS row hashes, ready about now)
+    std::vector<Fe> zst;
+    if (!p->start_from->wait(zst) || zst.size() != p->len_z) return vz_fail(ctx, VIMZ_ERR_INVALID, "fold: the segment before this one failed before its end state was known");
+    for (uint32_t i = 0; i < p->len_z; i++) { p->z_cur[i] = zst[i]; zs[i] = zst[i]; }
+    prover_start_state_changed(p);
+    if (p->on_start) p->on_start();
+    p->phase_s[PH_ZCHAIN] += now_s() - t0;
+    dbg_stamp(p, "fold_prepare: start state arrived");
+  }
   host_state_chain(p, J.step_inputs, nsteps, jobA.data(), jstride, zs);
+  if (p->end_to) { p->end_to->publish(zs.data() + nsteps * (size_t)p->len_z, p->len_z); end_guard.l = nullptr; }
+  dbg_stamp(p, "fold_prepare: state chain done");
   {
     std::vector<Fe> zc(zs.size());
     for (size_t i = 0; i < zs.size(); i++) zc[i] = Fe::from_mont(zs[i]);
@@ -873,6 +919,7 @@ static int fold_prepare(vimz_prover* p, FoldJob& J, bool start_batch0 = false) {
   }
   p->phase_s[PH_ZCHAIN] += now_s() - t0; p->phase_n[PH_ZCHAIN] += nsteps; p->phase_n[PH_WITNESS] += nsteps;
   J.states_upto = nsteps;
+  dbg_stamp(p, "fold_prepare: states uploaded, return");
   return VIMZ_OK;
 }
 
