@@ -438,6 +438,27 @@ def main_ivc(args, rank, world, dist, torch, ctxs, circuit, params, steps_all, g
                              "note": "the same rows as one IVC chain on one set of streams (bench.py --segments 1)"}
             except Exception as e:
                 print(f"[bench] one-chain extra skipped: {e}", file=sys.stderr)
+        # extra (N = 1): the same timed passes with EVERY row's witness on the GPU (no host-evaluated head batch) — where the default schedule used one
+        all_hip = None
+        if world == 1 and not args.no_extras and info.get("head_rows", 0):
+            try:
+                hip.set_head_rows(0)
+                pw = prove(rows_timed, z0); pw.close()      # (first use of this schedule's buffers)
+                ds = []
+                for _ in range(R):
+                    sync_all()
+                    t4 = time.time()
+                    pa = prove(rows_timed, z0)
+                    sync_all()
+                    ds.append(time.time() - t4)
+                    ok_a = pa.verify(K, z0) == 0
+                    pa.close()
+                all_hip = {"steps_per_s": K / sorted(ds)[R // 2], "samples_steps_per_s": [K / d for d in ds], "verified": bool(ok_a), "head_rows": int(ivcs[0].info().get("head_rows", -1)),
+                           "note": "the same passes with vimz_set_head_rows(0): every row's Poseidon chains on the GPU; segments start together with deferred start states"}
+            except Exception as e:
+                print(f"[bench] all-HIP extra skipped: {e}", file=sys.stderr)
+            finally:
+                hip.set_head_rows(-1)
         # extra (N = 1): the reference's second backend on the same image — Nova + CycleFold (vimz_cf_*): the whole image as one
         # chain and as ONE merged proof of S concurrent segments (vimz_cf_merge), each in a process of its own the way `vimz -b sonobe` would run
         # (tools/e2e.py; a child process, started the ordinary way — this one keeps its GPU state)
@@ -515,6 +536,7 @@ def main_ivc(args, rank, world, dist, torch, ctxs, circuit, params, steps_all, g
                          "note": "process CPU time (all threads: folding threads, helpers, issuers, pools, HIP runtime) of rank 0 inside the timed region"},
             "merge_profile_s": merge_prof,
             "one_chain": one_chain,
+            "all_hip_schedule": all_hip,
             "sonobe_backend": sonobe,
             "compressed_snark": compress,
             "end_to_end_estimate_s": {"keygen_and_setup": setup_s, "fold_720_steps_one_gpu": 720 * dt / max(1, timed_total),

@@ -68,6 +68,10 @@ int vimz_sync(vimz_ctx* ctx);
 /* A marker for a profiler's kernel trace: an empty kernel `k_trace_marker` of `id` (1..1024) workgroups on the context's stream, waited for
  * (bench.py brackets its timed region with ids 1 and 2; tools/trace_busy.py cuts the trace there). */
 int vimz_trace_marker(vimz_ctx* ctx, int id);
+/* Rows of a short fold call whose Poseidon chains are evaluated on the host (the "head batch"; the proof is bit-identical either way): rows >= 0 pins
+ * the number for every later call of this process (0: every row's witness entirely on the GPU), -1 restores the library's policy (24 for calls of at
+ * most 48 rows on six or more host cores, else 0).  Returns the previous setting. */
+long vimz_set_head_rows(long rows);
 /* A fingerprint of the host a benchmark line was measured on: out[0] = µs per Poseidon permutation (t = 9) on one host core, out[1] = µs per
  * empty kernel launch + stream synchronise (median of 200), out[2] = host cores this process may use, out[3] = µs per event record + synchronise. */
 int vimz_host_fingerprint(vimz_ctx* ctx, double out[4]);

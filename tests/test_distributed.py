@@ -350,6 +350,56 @@ def test_two_ranks_with_two_segments_each_end_in_one_proof_object(oracle, shm, d
     assert _replay_stub_ops(ops)[3] == ((3, 2), (2, 2))
 
 
+def _failing_worker(rank, world, port, q, fail_rank):
+    """tree_final_fold with a merge that fails on `fail_rank`: every rank must come back (with an error or, for ranks whose hand-over was taken, None)
+    long before the process group's timeout."""
+    sys.path.insert(0, ROOT)
+    import time
+    import torch.distributed as dist
+    from tests import _oracle
+    from tests.test_circuits import step_inputs
+    from vimz_amd.distributed import prove_sharded
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["VIMZ_SHARD_TRANSPORT"] = f"merge-fail:{fail_rank}"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    orc = _oracle.load()
+    z0, inputs = step_inputs("hash")
+    rows = np.stack(inputs[:10])
+    t0 = time.time()
+    try:
+        proof = prove_sharded([_StubIVCDigests(orc) for _ in range(2)], rows, z0, rank, world, dist, {}, merged_cls=_StubMerged, shm_dir="/tmp")
+        q.put((rank, "returned", proof is None, time.time() - t0))
+    except Exception as e:
+        q.put((rank, "raised", str(e)[:200], time.time() - t0))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,fail_rank", [(4, 2), (4, 0), (8, 4)])
+def test_a_failed_merge_travels_up_the_tree_instead_of_hanging_it(world, fail_rank):
+    """a failure in tree_final_fold used to stay inside its pair — the ranks above waited in a blocking receive until the process group's
+    timeout.  Now the failing rank answers its sender "fail", tells the rank waiting for it, and refuses the ranks that would hand over to it later."""
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_failing_worker, args=(r, world, port, q, fail_rank)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        r, what, info, dt = q.get(timeout=240)
+        got[r] = (what, info, dt)
+    for p in procs:
+        p.join(timeout=60)
+    assert got[fail_rank][0] == "raised" and "merge refused" in got[fail_rank][1], got
+    assert got[0][0] == "raised", got                                     # rank 0 never gets the ONE object — and says so, promptly
+    assert got[fail_rank + 1][0] == "raised" and "could not take over" in got[fail_rank + 1][1], got      # the rank whose proof was refused
+    assert all(dt < 120 for _, _, dt in got.values()), got              # (gloo's default timeout is 30 minutes)
+    # ranks whose hand-over was taken before the failure simply returned None
+    assert all(v[0] == "raised" or v[1] is True for v in got.values()), got
+
+
 def test_tree_rounds_pair_adjacent_runs():
     from vimz_amd.distributed import tree_rounds
     assert tree_rounds(1) == []

@@ -138,3 +138,16 @@ def test_decider_refuses_other_shapes_and_a_prover_without_steps(ctx):
             if o is not None:
                 o.close()
         cf.close(); srs.free(); ck2.free()
+
+
+def test_what_the_decider_proof_does_not_attest():
+    """The decider circuit binds the CycleFold instance by hash only (Sonobe checks it in-circuit): a CycleFold witness that violates its
+    relation passes the contract's checks and is caught only by the full IVC verifier; a violated MAIN relation is refused by the prover.  Also: seeded
+    setups are reproducible.  Body: tests/_tamper_decider.py on libvimz_hip_testing.so (vimz_cf_poke, seeded setups)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VIMZ_HIP_LIBRARY="testing")
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "_tamper_decider.py")], env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0 and "tamper ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]

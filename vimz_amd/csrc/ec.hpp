@@ -162,7 +162,11 @@ inline bool aff_on_curve(const Affine<Fp<P>>& q) {      // the identity's encodi
 
 // Device storage of curve data: coordinates at a stride of 10 words (40 B): affine = 20 words, XYZZ = 40 words.
 constexpr int COORD_WORDS = 10;
-constexpr int AFFINE_WORDS = 2 * COORD_WORDS;
+// A resident AFFINE point (commitment keys, window tables — the data the large MSM's accumulation GATHERS, 0.6 GB of tables at HD) is 64 bytes:
+// x then y as 256-bit integers (the canonical Montgomery residues x·2^261 mod p), ONE 64-byte sector per point, 64-byte aligned; the nine 29-bit
+// limbs are cut out after the load (Fp29::pack: shifts and masks).  Until round 5 it was 80 bytes (nine limbs in ten words per coordinate): two
+// sectors per gathered point.  XYZZ accumulators (lazily reduced, up to 261 bits) keep ten words per coordinate.
+constexpr int AFFINE_WORDS = 16;
 constexpr int XYZZ_WORDS = 4 * COORD_WORDS;
 
 }  // namespace vz

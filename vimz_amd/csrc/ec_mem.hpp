@@ -1,5 +1,5 @@
-// Loads / stores of curve data in its resident form: coordinates of COORD_WORDS (10) words, 9 used (fp29.hpp) — every point
-// starts 16-byte aligned: affine 80 B (five 16-byte accesses), XYZZ 160 B.
+// Loads / stores of curve data in its resident form.  Affine points (keys, window tables): 64 B — x, y as 256-bit integers, one sector, four
+// 16-byte accesses, limbs cut out after the load.  XYZZ accumulators: coordinates of COORD_WORDS (10) words, 9 used (fp29.hpp), 160 B.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "ec.hpp"
@@ -20,19 +20,41 @@ __device__ __forceinline__ void store_words20(uint32_t* __restrict__ p, const F&
   q[2] = make_uint4(a.v[8], 0u, b.v[0], b.v[1]); q[3] = make_uint4(b.v[2], b.v[3], b.v[4], b.v[5]);
   q[4] = make_uint4(b.v[6], b.v[7], b.v[8], 0u);
 }
-template <class F>
-__device__ __forceinline__ Affine<F> load_affine(const uint32_t* __restrict__ bases, uint32_t idx) {
-  Affine<F> q; load_words20(bases + (size_t)AFFINE_WORDS * idx, q.x, q.y); return q;
+// the 64 bytes of a point as they come out of memory: a gather keeps THESE in flight (16 registers) and cuts the limbs out when the point is used
+struct RawAffine { uint4 w0, w1, w2, w3; };
+__device__ __forceinline__ RawAffine load_affine_raw(const uint32_t* __restrict__ bases, size_t idx) {
+  const uint4* q = reinterpret_cast<const uint4*>(bases + (size_t)AFFINE_WORDS * idx);
+  RawAffine r; r.w0 = q[0]; r.w1 = q[1]; r.w2 = q[2]; r.w3 = q[3]; return r;
 }
+template <class F>
+__device__ __forceinline__ Affine<F> affine_of_raw(const RawAffine& a) {
+  const uint32_t x[8] = {a.w0.x, a.w0.y, a.w0.z, a.w0.w, a.w1.x, a.w1.y, a.w1.z, a.w1.w}, y[8] = {a.w2.x, a.w2.y, a.w2.z, a.w2.w, a.w3.x, a.w3.y, a.w3.z, a.w3.w};
+  Affine<F> r; r.x = F::pack(x); r.y = F::pack(y); return r;
+}
+template <class F>
+__device__ __forceinline__ Affine<F> load_affine_at(const uint32_t* __restrict__ p) { return affine_of_raw<F>(load_affine_raw(p, 0)); }
+template <class F>
+__device__ __forceinline__ Affine<F> load_affine(const uint32_t* __restrict__ bases, size_t idx) { return load_affine_at<F>(bases + (size_t)AFFINE_WORDS * idx); }
+// (coordinates canonical — below p, so below 2^256: what to_affine and the key generators produce)
+template <class F>
+__device__ __forceinline__ void store_affine_at(uint32_t* __restrict__ p, const Affine<F>& a) {
+  uint32_t x[8], y[8]; a.x.unpack(x); a.y.unpack(y);
+  uint4* q = reinterpret_cast<uint4*>(p);
+  q[0] = make_uint4(x[0], x[1], x[2], x[3]); q[1] = make_uint4(x[4], x[5], x[6], x[7]);
+  q[2] = make_uint4(y[0], y[1], y[2], y[3]); q[3] = make_uint4(y[4], y[5], y[6], y[7]);
+}
+template <class F>
+__device__ __forceinline__ void store_affine(uint32_t* __restrict__ bases, size_t idx, const Affine<F>& a) { store_affine_at<F>(bases + (size_t)AFFINE_WORDS * idx, a); }
+constexpr int XYZZ_HALF_WORDS = 2 * COORD_WORDS;
 template <class F>
 __device__ __forceinline__ void store_xyzz(uint32_t* __restrict__ base, size_t idx, const XYZZ<F>& p) {
   uint32_t* d = base + (size_t)XYZZ_WORDS * idx;
-  store_words20(d, p.X, p.Y); store_words20(d + AFFINE_WORDS, p.ZZ, p.ZZZ);
+  store_words20(d, p.X, p.Y); store_words20(d + XYZZ_HALF_WORDS, p.ZZ, p.ZZZ);
 }
 template <class F>
 __device__ __forceinline__ XYZZ<F> load_xyzz(const uint32_t* __restrict__ base, size_t idx) {
   const uint32_t* d = base + (size_t)XYZZ_WORDS * idx;
-  XYZZ<F> p; load_words20(d, p.X, p.Y); load_words20(d + AFFINE_WORDS, p.ZZ, p.ZZZ); return p;
+  XYZZ<F> p; load_words20(d, p.X, p.Y); load_words20(d + XYZZ_HALF_WORDS, p.ZZ, p.ZZZ); return p;
 }
 
 // ---- four lanes, one full addition ---------------------------------------------------------------------------------------------------

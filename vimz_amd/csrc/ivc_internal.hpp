@@ -102,8 +102,11 @@ struct vimz_ivc {
   // process's mapping of it is kept open (import side: at most IPC_MAPPINGS, oldest closed first) — the second and later proofs of a
   // pair of ranks pay no hipIpcGetMemHandle / hipIpcOpenMemHandle (1-3 ms each next to running kernels)
   enum { IPC_MAPPINGS = 8 };
-  struct IpcExport { const void* dev = nullptr; unsigned char handle[64]; };
-  struct IpcMapping { unsigned char handle[64]; void* ptr = nullptr; };
+  // gen: the GENERATION of an exported allocation — (exporter's pid << 32) | a counter, new for every allocation that is exported; it travels in the
+  // ticket, and an importer whose cached mapping carries the same handle bytes under another generation (the exporter freed that allocation and the
+  // runtime reissued the handle for a new one) closes the stale mapping and opens the new allocation instead of reading freed memory through the old one
+  struct IpcExport { const void* dev = nullptr; unsigned char handle[64]; uint64_t gen = 0; };
+  struct IpcMapping { unsigned char handle[64]; void* ptr = nullptr; uint64_t gen = 0; };
   std::vector<IpcExport> ipc_exports; std::vector<IpcMapping> ipc_mappings;
   // the merged proofs that use this IVC as their verifier key: freeing the IVC first orphans them (their buffers are released, every
   // later call on them fails cleanly) instead of leaving them with a dangling pointer

@@ -6,6 +6,7 @@
 #include <thread>
 #include "ivc_internal.hpp"
 #include "proof_io.hpp"
+#include <unistd.h>
 #include "merge_internal.hpp"
 
 namespace {
@@ -529,13 +530,16 @@ int64_t vimz_ivc_merged_share(vimz_ivc_merged* m, void* buf, size_t cap) {
   hipIpcMemHandle_t h;
   const vimz_ivc::IpcExport* known = nullptr;
   for (auto& ex : vk->ipc_exports) if (ex.dev == m->dev) known = &ex;
-  if (known) memcpy(&h, known->handle, 64);
+  uint64_t gen = 0;
+  if (known) { memcpy(&h, known->handle, 64); gen = known->gen; }
   else {
     const hipError_t e = hipIpcGetMemHandle(&h, m->dev);
     if (e != hipSuccess) return vz_fail(ctx, VIMZ_ERR_HIP, "vimz_ivc_merged_share: hipIpcGetMemHandle", e);
-    vimz_ivc::IpcExport ex; ex.dev = m->dev; memcpy(ex.handle, &h, 64); vk->ipc_exports.push_back(ex);
+    static std::atomic<uint64_t> next_gen{1};
+    gen = ((uint64_t)getpid() << 32) | (next_gen.fetch_add(1) & 0xffffffffull);
+    vimz_ivc::IpcExport ex; ex.dev = m->dev; memcpy(ex.handle, &h, 64); ex.gen = gen; vk->ipc_exports.push_back(ex);
   }
-  Writer w; w.word(SHARE_MAGIC); w.word(shared_elements(vk)); w.word(0); w.word(0);
+  Writer w; w.word(SHARE_MAGIC); w.word(shared_elements(vk)); w.word(gen); w.word(0);
   uint64_t hw[8]; memcpy(hw, &h, 64); for (int k = 0; k < 8; k++) w.word(hw[k]);
   write_records(m, w);
   if (8 * w.w.size() != bytes) return VIMZ_ERR_INVALID;
@@ -565,12 +569,18 @@ int vimz_ivc_merged_open_shared(vimz_ivc* vk, const uint8_t* ticket, size_t len,
   if (rc) return rc;
   void* remote = nullptr;
   hipError_t e = hipSuccess;
-  for (auto& mp : vk->ipc_mappings) if (!memcmp(mp.handle, &h, 64)) remote = mp.ptr;
+  const uint64_t gen = words[2];
+  { auto& mps = vk->ipc_mappings;
+    for (size_t k = 0; k < mps.size(); k++) if (!memcmp(mps[k].handle, &h, 64)) {
+      if (mps[k].gen == gen) remote = mps[k].ptr;
+      else { hipIpcCloseMemHandle(mps[k].ptr); mps.erase(mps.begin() + k); }      // same handle bytes, another allocation: the cached mapping is stale
+      break;
+    } }
   if (!remote) {
     e = hipIpcOpenMemHandle(&remote, h, hipIpcMemLazyEnablePeerAccess);
     if (e != hipSuccess || !remote) return vz_fail(ctx, VIMZ_ERR_HIP, "vimz_ivc_merged_open_shared: hipIpcOpenMemHandle (not the same node, or no peer access between the two GPUs)", e);
     if (vk->ipc_mappings.size() >= vimz_ivc::IPC_MAPPINGS) { hipIpcCloseMemHandle(vk->ipc_mappings.front().ptr); vk->ipc_mappings.erase(vk->ipc_mappings.begin()); }
-    vimz_ivc::IpcMapping mp; memcpy(mp.handle, &h, 64); mp.ptr = remote; vk->ipc_mappings.push_back(mp);
+    vimz_ivc::IpcMapping mp; memcpy(mp.handle, &h, 64); mp.ptr = remote; mp.gen = gen; vk->ipc_mappings.push_back(mp);
   }
   hipStream_t s = ctx->stream;
   const size_t nw1 = p->n_wires, nc1 = p->n_c, nw2 = vk->sec.n_w, nc2 = vk->sec.n_c;

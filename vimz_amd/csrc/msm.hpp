@@ -10,7 +10,7 @@
 //                  of k_prefix_scan to finish (k_scan, a launch of its own, on the fallback path).  Buckets are split into sub-buckets of
 //                  at most SUB entries so no thread owns a long chain.
 //   3. k_scatter_lds  counting-sort scatter of (point index | sign) into bucket order, ranks from LDS counters.
-//   4. k_accum     one thread per sub-bucket: gathers its affine bases (80 B each, from L2 / Infinity Cache — the key is
+//   4. k_accum     one thread per sub-bucket: gathers its affine bases (64 B each — one sector —, from L2 / Infinity Cache — the key is
 //                  re-read by every window) and accumulates in XYZZ over the 9x29-bit coordinate field.
 //   5. k_combine   folds the sub-bucket partials of each bucket; hot buckets (listed by the scan) by workgroup trees in the same launch;
 //                  the second stage of the very heavy ones rides in k_reduce's prologue.
@@ -38,7 +38,12 @@ namespace vz {
 // small_lean (0: off, the default): the fused small MSM's wide tail levels by one lane per addition instead of four — 15-20 % fewer
 // instructions per small MSM, 7-27 µs more latency: measured SLOWER in every regime (three segments 1095-1101 -> 1054-1078 -> 1029-1051
 // steps/s for lean = 0 / 1 / 2, one chain 819 -> 799 -> 770): with the GPU 98 % busy the step is still bound by its latency chains.
-struct MsmTuning { int sort_blocks = 0, combine_lane_bits = -1, small_lean = 0, witness_sub = 0, ones_dense = 1; };
+// reduce_planes (0: off, the default): the shared bucket set of a table MSM reduced by bit planes (k_reduce_planes) instead of chunked running sums
+// (k_reduce) — alone on the GPU the reduce falls from 0.171 to 0.083 ms (305 k dense points, c = 15) and the whole MSM from 0.873 to 0.786 ms, but
+// every bucket is then added into half of the 14 planes: 131 k full additions instead of 32 k, a tenth of the accumulation's work on top — and inside
+// a fold, where the GPU is busy throughout, that costs more than the shorter tail gains: 1 176 against 1 198 steps/s over 256 rows, 936 against 938 in
+// the 20-row window, one chain 829 against 822 (round 5, same box, profiles/r05_reduce_planes.txt).
+struct MsmTuning { int sort_blocks = 0, combine_lane_bits = -1, small_lean = 0, witness_sub = 0, ones_dense = 1, reduce_planes = 0; };
 inline const MsmTuning& msm_tuning() {
   static const MsmTuning t = [] {
     MsmTuning r;
@@ -48,6 +53,7 @@ inline const MsmTuning& msm_tuning() {
       if (const char* q = strstr(e, "small_lean=")) r.small_lean = atoi(q + 11);
       if (const char* q = strstr(e, "witness_sub=")) { const int v = atoi(q + 12); if (v >= 2 && v <= MSM_SUB) r.witness_sub = v; }
       if (const char* q = strstr(e, "ones_dense=")) r.ones_dense = atoi(q + 11);
+      if (const char* q = strstr(e, "reduce_planes=")) r.reduce_planes = atoi(q + 14);
     }
     return r;
   }();
@@ -288,15 +294,16 @@ __global__ void __launch_bounds__(256, 3) k_accum(const uint32_t* __restrict__ b
   const uint32_t beg = bucket_off[b] + k * sub;
   const uint32_t end = min(bucket_off[b + 1], beg + sub);
   XYZZ<F> acc = XYZZ<F>::identity();
-  // software pipeline: the gather of entry e+1 (index, then 80-byte base) is in flight while entry e is added
+  // software pipeline: the gather of entry e+1 (index, then the 64-byte base: one sector) is in flight while entry e is added
   uint32_t ent = beg < end ? sorted[beg] : 0u;
-  Affine<F> q = load_affine<F>(bases, ent & 0x7fffffffu);
+  RawAffine raw = load_affine_raw(bases, ent & 0x7fffffffu);
   for (uint32_t e = beg; e < end; e++) {
     const uint32_t ent_n = e + 1 < end ? sorted[e + 1] : ent;
-    const Affine<F> q_n = load_affine<F>(bases, ent_n & 0x7fffffffu);
+    const RawAffine raw_n = load_affine_raw(bases, ent_n & 0x7fffffffu);
+    Affine<F> q = affine_of_raw<F>(raw);
     if ((ent >> 31) && !aff_is_identity(q)) q.y = F::neg(q.y);
     add_mixed(acc, q);
-    ent = ent_n; q = q_n;
+    ent = ent_n; raw = raw_n;
   }
   store_xyzz(partial, s, acc);
 }
@@ -377,14 +384,16 @@ constexpr uint32_t COMBINE_HEAVY_BLOCKS = 512, COMBINE_SPLIT_BLOCKS = 1024;
 //   next COMBINE_HEAVY_BLOCKS            heavy buckets (list written by k_scan), one workgroup each: strided sums + 8-level tree;
 //   next COMBINE_SPLIT_BLOCKS            very heavy buckets (>= MSM_HEAVY_SPLIT_MIN partials; among the first MSM_HEAVY_SPLIT of the list):
 //                                        stage 1 of a two-stage fold, MSM_HEAVY_PARTS workgroups per bucket into a scratch row
-//                                        (k_combine_heavy2 finishes them).
+//                                        the last of a bucket's workgroups to finish folds the row (ticket in heavy_done).
 // Why buckets get that heavy: with 254-bit scalars and c = 11 the top window holds one bit plus a carry, so a third of ALL points
 // of a dense MSM meet in one or two buckets; repeated cross-term values and the small values of a witness add hot buckets.
 template <class F>
 __global__ void __launch_bounds__(256) k_combine(uint32_t* __restrict__ partial, const uint32_t* __restrict__ sub_off, uint32_t nb, uint32_t nbn,
-                                                 const uint32_t* __restrict__ heavy, uint32_t heavy_cap, uint32_t* __restrict__ scratch,
-                                                 uint32_t lane_bits /* log2 of the lanes per ordinary bucket: 0..4 */, uint32_t heavy_min) {
+                                                 const uint32_t* __restrict__ heavy, uint32_t heavy_cap, uint32_t* scratch /* (written and, by the last part, read: no restrict) */,
+                                                 uint32_t lane_bits /* log2 of the lanes per ordinary bucket: 0..4 */, uint32_t heavy_min,
+                                                 uint32_t* __restrict__ heavy_done /* one ticket per split bucket */) {
   __shared__ XYZZ<F> sh[256];
+  __shared__ uint32_t s_last;
   const uint32_t t = threadIdx.x;
   if (blockIdx.x < nbn) {
     // The lanes of a bucket are idle for most of an LDS tree (8, 4, 2, 1 of 16 active), and an addition costs the wave the same
@@ -438,59 +447,33 @@ __global__ void __launch_bounds__(256) k_combine(uint32_t* __restrict__ partial,
     __syncthreads();
     quad_tree256<F>(sh);
     if (t == 0) store_xyzz(scratch, it, sh[0]);
+    // Stage 2 by the LAST of the bucket's MSM_HEAVY_PARTS workgroups to get here (a ticket per bucket): a 32-leaf tree of four-lane additions over
+    // the scratch row, into the bucket's slot.  (Until round 5 in k_reduce's prologue — which every workgroup that reads the bucket would now repeat.)
+    const uint32_t hsl = it / MSM_HEAVY_PARTS;
+    if (t == 0) { __threadfence(); s_last = atomicAdd(&heavy_done[hsl], 1u) == MSM_HEAVY_PARTS - 1 ? 1u : 0u; }
+    __syncthreads();
+    if (s_last) {
+      __threadfence();
+      if (t == 0) __hip_atomic_store(&heavy_done[hsl], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (the ticket for the next MSM)
+      sh[t] = t < MSM_HEAVY_PARTS ? load_xyzz<F>(scratch, (size_t)hsl * MSM_HEAVY_PARTS + t) : XYZZ<F>::identity();
+      __syncthreads();
+      for (uint32_t d = MSM_HEAVY_PARTS / 2; d > 0; d >>= 1) quad_level<F>(sh, d, [](uint32_t e) { return e; }, [d](uint32_t e) { return e + d; });
+      if (t == 0) store_xyzz(partial, s0, sh[0]);
+    }
+    __syncthreads();
   }
 }
 
-// stage 2 of the very heavy buckets: one 32-lane tree per bucket over its scratch row
-template <class F>
-__global__ void __launch_bounds__(256) k_combine_heavy2(uint32_t* __restrict__ partial, const uint32_t* __restrict__ sub_off,
-                                                        const uint32_t* __restrict__ heavy, uint32_t heavy_cap, const uint32_t* __restrict__ scratch) {
-  __shared__ XYZZ<F> sh[256];
-  const uint32_t count = heavy[0] <= heavy_cap ? min(heavy[0], MSM_HEAVY_SPLIT) : 0u, t = threadIdx.x, lane = t & 31u;
-  const uint32_t h = blockIdx.x * 8u + (t >> 5);
-  bool mine = false;
-  if (h < count) { const uint32_t b = heavy[1 + h]; mine = sub_off[b + 1] - sub_off[b] >= MSM_HEAVY_SPLIT_MIN; }
-  if (!__syncthreads_or(mine ? 1 : 0)) return;       // nothing split among this workgroup's eight buckets
-  sh[t] = mine ? load_xyzz<F>(scratch, h * MSM_HEAVY_PARTS + lane) : XYZZ<F>::identity();
-  __syncthreads();
-  // eight 32-lane trees side by side, four lanes per addition: 128 pairs (two rounds), then 64, 32, 16, 8
-  for (uint32_t d = 16; d > 0; d >>= 1) {
-    const uint32_t pairs = 8 * d;
-    for (uint32_t base = 0; base < pairs; base += 64)
-      quad_level<F>(sh, min(64u, pairs - base), [=](uint32_t e) { return 32u * ((base + e) / d) + (base + e) % d; }, [=](uint32_t e) { return 32u * ((base + e) / d) + (base + e) % d + d; });
-  }
-  if (lane == 0 && mine) store_xyzz(partial, sub_off[heavy[1 + h]], sh[t]);
-}
 // grid = K workgroups of T threads (T = min(256, nbw)); window sum = Σ_{idx} (idx+1)·B_idx
 // plain_sums (optional): also Σ_idx B_idx of every window — with window tables and ONE bucket set shared by all windows (c = 13..16)
 // the 2^(c-1) buckets are reduced as V = 2^(c-1)/1024 "virtual windows" of 1024 buckets each by this same kernel (V workgroups side by
 // side, the depth of the c = 11 reduce), and the host finishes  Σ_v R_v + 1024·Σ_v v·S_v  (msm_finish).
 template <class F>
-__global__ void __launch_bounds__(256) k_reduce(const uint32_t* partial /* (== partial_rw: no restrict) */, const uint32_t* __restrict__ counts,
+__global__ void __launch_bounds__(256) k_reduce(const uint32_t* __restrict__ partial, const uint32_t* __restrict__ counts,
                                                 const uint32_t* __restrict__ sub_off, uint32_t nbw,
-                                                uint32_t* __restrict__ window_sums, uint32_t* __restrict__ plain_sums = nullptr,
-                                                const uint32_t* __restrict__ heavy = nullptr, uint32_t heavy_cap = 0, const uint32_t* __restrict__ scratch = nullptr,
-                                                uint32_t* partial_rw = nullptr) {
+                                                uint32_t* __restrict__ window_sums, uint32_t* __restrict__ plain_sums = nullptr) {
   __shared__ XYZZ<F> sh[256];
   const uint32_t w = blockIdx.x, t = threadIdx.x, T = blockDim.x;
-  if (heavy && T == 256) {
-    // Stage 2 of the very heavy buckets (k_combine left MSM_HEAVY_PARTS partial sums of each in a scratch row): the workgroup whose window the
-    // bucket belongs to folds the row — a 32-leaf tree of four-lane additions — before it reads the bucket's sum.  (Until round 4 a kernel of its
-    // own, k_combine_heavy2: an almost always empty launch that still waited ~0.1 ms for its turn inside a fold.)
-    const uint32_t count = heavy[0] <= heavy_cap ? min(heavy[0], MSM_HEAVY_SPLIT) : 0u;
-    for (uint32_t h = 0; h < count; h++) {
-      const uint32_t b = heavy[1 + h];
-      if (b < w * nbw || b >= (w + 1) * nbw) continue;
-      const uint32_t s0 = sub_off[b], m = sub_off[b + 1] - s0;
-      if (m < MSM_HEAVY_SPLIT_MIN) continue;
-      sh[t] = t < MSM_HEAVY_PARTS ? load_xyzz<F>(scratch, (size_t)h * MSM_HEAVY_PARTS + t) : XYZZ<F>::identity();
-      __syncthreads();
-      for (uint32_t d = MSM_HEAVY_PARTS / 2; d > 0; d >>= 1) quad_level<F>(sh, d, [](uint32_t e) { return e; }, [d](uint32_t e) { return e + d; });
-      if (t == 0) store_xyzz(partial_rw, s0, sh[0]);
-      __syncthreads();
-    }
-    __threadfence_block();
-  }
   const uint32_t ch = nbw / T;
   const uint32_t lo = t * ch;
   XYZZ<F> run = XYZZ<F>::identity(), sum = XYZZ<F>::identity();
@@ -526,6 +509,48 @@ __global__ void __launch_bounds__(256) k_reduce(const uint32_t* partial /* (== p
     __syncthreads();
   }
   if (t == 0) store_xyzz(window_sums, w, sh[0]);
+}
+
+
+// The shared bucket set of a table MSM reduced by BIT PLANES:  Σ_g (g + 1)·B_g = Σ_g B_g + Σ_p 2^p · Σ_{g: bit p of g set} B_g.  Every plane sum (and
+// the plain sum, as two halves) is a TREE over its buckets — workgroup (plane, q) sums 256·lpt of them: lpt per thread, then an eight-level tree of
+// four-lane additions — all (P + 2)·G workgroups side by side, and the last one to finish (a ticket in totals[3]) folds each plane's G partial sums.
+// Depth: lpt + 8 + log2 G dependent additions, against the chunked running sums of k_reduce (2·nbw/256/V + 8 + 3 + 8); more additions in total
+// (every bucket is read by half the planes), but this tail is latency, not throughput.  Output: P + 2 sums (planes 0..P-1, plain low half, plain
+// high half); msm_finish does the Horner over the planes.
+template <class F>
+__global__ void __launch_bounds__(256) k_reduce_planes(const uint32_t* __restrict__ partial, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ sub_off,
+                                                       uint32_t nbw, uint32_t P /* log2 nbw */, uint32_t G /* workgroups per plane */, uint32_t lpt,
+                                                       uint32_t* stage /* (P + 2)·G partial sums: written by all, read by the last */, uint32_t* __restrict__ ticket,
+                                                       uint32_t* __restrict__ out /* P + 2 sums */) {
+  __shared__ XYZZ<F> sh[256];
+  __shared__ uint32_t s_last;
+  const uint32_t t = threadIdx.x, plane = blockIdx.x / G, q = blockIdx.x % G;
+  XYZZ<F> acc = XYZZ<F>::identity();
+  for (uint32_t i = 0; i < lpt; i++) {
+    const uint32_t j = q * (256u * lpt) + i * 256u + t;      // leaf of this plane: 0 .. nbw/2
+    uint32_t g;
+    if (plane < P) g = ((j >> plane) << (plane + 1)) | (1u << plane) | (j & ((1u << plane) - 1u));      // the j-th bucket index with bit `plane` set
+    else g = (plane - P) * (nbw >> 1) + j;                                                            // plain sum, low / high half
+    if (counts[g]) { XYZZ<F> B = load_xyzz<F>(partial, sub_off[g]); add_full(acc, B); }
+  }
+  sh[t] = acc;
+  __syncthreads();
+  quad_tree256<F>(sh);
+  if (t == 0) { store_xyzz(stage, blockIdx.x, sh[0]); __threadfence(); s_last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u; }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  if (t == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (for the next MSM)
+  const uint32_t total = (P + 2) * G;      // <= 256
+  sh[t] = t < total ? load_xyzz<F>(stage, t) : XYZZ<F>::identity();
+  __syncthreads();
+  for (uint32_t d = G >> 1; d > 0; d >>= 1) {
+    const uint32_t pairs = (P + 2) * d;
+    for (uint32_t base = 0; base < pairs; base += 64)
+      quad_level<F>(sh, min(64u, pairs - base), [=](uint32_t e) { return ((base + e) / d) * G + (base + e) % d; }, [=](uint32_t e) { return ((base + e) / d) * G + (base + e) % d + d; });
+  }
+  if (t < P + 2) store_xyzz(out, t, sh[t * G]);
 }
 
 // ---- fused small MSM -------------------------------------------------------------------------------------------------
@@ -781,7 +806,7 @@ __global__ void __launch_bounds__(256) k_build_multiples(const uint32_t* __restr
   uint32_t* dst = mult + (size_t)AFFINE_WORDS * (g * nm);
   for (uint32_t m = 0; m < nm; m++) {
     const Affine<F> a = to_affine(acc);
-    store_words20(dst + (size_t)AFFINE_WORDS * m, a.x, a.y);
+    store_affine_at<F>(dst + (size_t)AFFINE_WORDS * m, a);
     add_mixed(acc, B);
   }
 }
@@ -819,7 +844,7 @@ __global__ void __launch_bounds__(256) k_msm_fixed(const uint32_t* __restrict__ 
           have[k] = true; neg[k] = d < 0;
           const uint32_t m = (uint32_t)(d < 0 ? -d : d) - 1u;
           const uint32_t* src = mult + (size_t)AFFINE_WORDS * (((size_t)w * tstride + i) * NM + m);
-          load_words20(src, pt[k].x, pt[k].y);
+          pt[k] = load_affine_at<F>(src);
         }
       }
     }
@@ -883,12 +908,12 @@ __global__ void __launch_bounds__(256) k_build_tables(const uint32_t* __restrict
   const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (i >= n) return;
   Affine<F> p = load_affine<F>(bases, (uint32_t)i);
-  store_words20(tables + (size_t)AFFINE_WORDS * i, p.x, p.y);
+  store_affine<F>(tables, i, p);
   for (int j = 1; j < K; j++) {
     XYZZ<F> acc = from_affine(p);
     for (int k = 0; k < c; k++) acc = dbl(acc);
     p = to_affine(acc);
-    store_words20(tables + (size_t)AFFINE_WORDS * ((size_t)j * n + i), p.x, p.y);
+    store_affine<F>(tables, (size_t)j * n + i, p);
   }
 }
 template <class C>
@@ -958,6 +983,15 @@ hipError_t msm_launch(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_ba
   }
   if (pl.K + 1 > MSM_MAX_WINDOWS || pl.c > 16 || pl.c < 2) return hipErrorInvalidValue;
   pl.split_ones = split_ones;
+  // shared bucket set: as virtual windows (k_reduce), or — VIMZ_TUNE=reduce_planes=1 — by bit planes (k_reduce_planes) where the plane workgroups' partial sums fit one tree
+  const bool no_planes = !msm_tuning().reduce_planes;
+  uint32_t Pl = 0; while ((1u << Pl) < pl.nbw) Pl++;
+  uint32_t Gp = std::min<uint32_t>(16u, pl.nbw / 1024u);
+  while (Gp > 1 && (Pl + 2) * Gp > 256) Gp >>= 1;
+  const bool planes = tabled && !own && !no_planes && pl.nbw >= 1024 && (1u << Pl) == pl.nbw && (Pl + 2) * Gp <= 256 && (int)Pl + 2 + 1 <= MSM_MAX_WINDOWS;
+  if (planes) pl.tabled = 4;
+  // (ONE assignment, every field final: the plan object is often shared — the producer's issuer thread launches row r + k while the folding thread
+  //  finishes row r with the same plan, msm_finish — and a launch must never be seen half-described)
   *plan_out = pl;
   const size_t entries = (size_t)pl.K * n;
   // small MSMs are latency-bound (one dependent addition ~ 6-10 us): shorter chains per thread, more threads
@@ -1036,23 +1070,20 @@ hipError_t msm_launch(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_ba
   VZ_EV(4);
   const unsigned per_wg = 256u >> lane_bits, nbn = (pl.nb + per_wg - 1) / per_wg;
   hipLaunchKernelGGL(k_combine<F>, dim3(nbn + COMBINE_HEAVY_BLOCKS + COMBINE_SPLIT_BLOCKS), dim3(256), 0, stream, partial, ws.sub_off, pl.nb, nbn,
-                     (const uint32_t*)ws.heavy, MsmWorkspace::HEAVY_CAP, ws.heavy_scratch, lane_bits, heavy_min);
-  VZ_EV(5);      // (stage 2 of the very heavy buckets rides in k_reduce's prologue)
+                     (const uint32_t*)ws.heavy, MsmWorkspace::HEAVY_CAP, ws.heavy_scratch, lane_bits, heavy_min, ws.heavy_done);
+  VZ_EV(5);      // (stage 2 of the very heavy buckets: the last of a bucket's workgroups, inside k_combine)
   const unsigned T = pl.nbw < 256 ? pl.nbw : 256;
   uint32_t* wsum = direct ? reinterpret_cast<uint32_t*>(pinned_dst) : reinterpret_cast<uint32_t*>(ws.window_sums);
   const uint32_t vw = std::min<uint32_t>(pl.nbw, MSM_VWIN);      // shared bucket set: virtual windows of vw buckets
   const int V = (int)(pl.nbw / vw);
-  const int kout = tabled && !own ? 2 * V : pl.K;     // sums produced: (R_v, S_v) per virtual window, or one per window
-  if (tabled && !own) {
-    hipLaunchKernelGGL(k_reduce<F>, dim3(V), dim3(vw < 256 ? vw : 256), 0, stream, (const uint32_t*)partial, (const uint32_t*)ws.counts, (const uint32_t*)ws.sub_off, vw, wsum, wsum + (size_t)XYZZ_WORDS * V,
-                       (const uint32_t*)ws.heavy, (uint32_t)MsmWorkspace::HEAVY_CAP, (const uint32_t*)ws.heavy_scratch, partial);
-  } else if (T == 256)
-    hipLaunchKernelGGL(k_reduce<F>, dim3(pl.K), dim3(T), 0, stream, (const uint32_t*)partial, (const uint32_t*)ws.counts, (const uint32_t*)ws.sub_off, pl.nbw, wsum, (uint32_t*)nullptr,
-                       (const uint32_t*)ws.heavy, (uint32_t)MsmWorkspace::HEAVY_CAP, (const uint32_t*)ws.heavy_scratch, partial);
-  else {      // (windows of fewer than 256 buckets: small MSMs through the general pipeline; the stage-2 kernel of its own)
-    hipLaunchKernelGGL(k_combine_heavy2<F>, dim3(MSM_HEAVY_SPLIT / 8), dim3(256), 0, stream, partial, ws.sub_off, ws.heavy, MsmWorkspace::HEAVY_CAP, ws.heavy_scratch);
+  const int kout = planes ? (int)Pl + 2 : tabled && !own ? 2 * V : pl.K;     // sums produced: planes + two plain halves; (R_v, S_v) per virtual window; or one per window
+  if (planes) {
+    hipLaunchKernelGGL(k_reduce_planes<F>, dim3((Pl + 2) * Gp), dim3(256), 0, stream, (const uint32_t*)partial, (const uint32_t*)ws.counts, (const uint32_t*)ws.sub_off, pl.nbw, Pl, Gp,
+                       pl.nbw / (512u * Gp), ws.plane_scratch, ws.totals + 3, wsum);
+  } else if (tabled && !own) {
+    hipLaunchKernelGGL(k_reduce<F>, dim3(V), dim3(vw < 256 ? vw : 256), 0, stream, (const uint32_t*)partial, (const uint32_t*)ws.counts, (const uint32_t*)ws.sub_off, vw, wsum, wsum + (size_t)XYZZ_WORDS * V);
+  } else
     hipLaunchKernelGGL(k_reduce<F>, dim3(pl.K), dim3(T), 0, stream, (const uint32_t*)partial, (const uint32_t*)ws.counts, (const uint32_t*)ws.sub_off, pl.nbw, wsum);
-  }
   VZ_EV(6);
 #undef VZ_EV
   if (split_ones) {   // sum of the bases with unit scalar -> window_sums[K]
@@ -1082,6 +1113,14 @@ Affine<typename C::Base> msm_finish(const MsmPlan& pl, const void* pinned) {
     return p;
   };
   XYZZ<FS> acc = XYZZ<FS>::identity();
+  if (pl.tabled == 4) {
+    // bit planes of the shared bucket set (k_reduce_planes): Σ_p 2^p·S_p + plain low + plain high
+    int P = 0; while ((1u << P) < pl.nbw) P++;
+    for (int q = P - 1; q >= 0; q--) { acc = dbl(acc); add_full(acc, host_point(q)); }
+    add_full(acc, host_point(P)); add_full(acc, host_point(P + 1));
+    if (pl.split_ones) add_full(acc, host_point(P + 2));
+    return to_affine(acc);
+  }
   if (pl.tabled == 1) {
     // one bucket set shared by all windows, reduced as V virtual windows of MSM_VWIN buckets: bucket b = MSM_VWIN·v + idx weighs
     // (idx + 1) + MSM_VWIN·v, so the sum is  Σ_v R_v + MSM_VWIN·Σ_v v·S_v  with  Σ_v v·S_v = Σ_{s>=1} Σ_{v>=s} S_v

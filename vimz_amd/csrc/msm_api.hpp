@@ -39,7 +39,8 @@ struct MsmPlan {
   uint32_t nbw;     // buckets per window = 2^(c-1)
   uint32_t nb;      // total buckets
   int split_ones;   // unit scalars summed separately (window_sums[K])
-  int tabled;       // 1: window tables, one bucket set, (R_v, S_v) of nbw / MSM_VWIN virtual windows, no Horner; 2: tables of the fused small path (K sums, no Horner)
+  int tabled;       // 1: window tables, one bucket set, (R_v, S_v) of nbw / MSM_VWIN virtual windows, no Horner; 2: tables of the fused small path (K sums, no Horner);
+                    // 3: tables with per-window bucket sets; 4: one bucket set reduced by BIT PLANES (k_reduce_planes: log2(nbw) + 2 sums)
 };
 
 // The fused single-launch path for small MSMs (k_msm_small): window, points per workgroup chunk, chunks, size limit.
@@ -91,6 +92,8 @@ struct MsmWorkspace {  // device buffers, grown on demand and reused across call
   void* ones_partial = nullptr;    // (16384 + 64) XYZZ partial sums of the unit-scalar path
   uint32_t* heavy = nullptr;       // [0] = count, then ids of buckets with many sub-buckets
   uint32_t* heavy_scratch = nullptr;   // 1024 x 32 partial sums of the split heavy buckets
+  uint32_t* heavy_done = nullptr;      // 1024 tickets: the last of a split bucket's 32 workgroups folds its scratch row (k_combine); zero between launches
+  uint32_t* plane_scratch = nullptr;   // 256 partial sums of k_reduce_planes
   static constexpr uint32_t HEAVY_CAP = 65536;
   size_t cap_nb = 0, cap_entries = 0, cap_subs = 0;
   void* host_pinned = nullptr;     // MSM_MAX_WINDOWS * 128 B
@@ -115,6 +118,8 @@ struct MsmWorkspace {  // device buffers, grown on demand and reused across call
     if (!totals) { VZ_HIP_CHECK(hipMalloc(&totals, 64)); VZ_HIP_CHECK(hipMemset(totals, 0, 64)); VZ_HIP_CHECK(hipStreamSynchronize(nullptr)); }
     if (!heavy) VZ_HIP_CHECK(hipMalloc(&heavy, 4 * (HEAVY_CAP + 1)));
     if (!heavy_scratch) VZ_HIP_CHECK(hipMalloc(&heavy_scratch, 4 * (size_t)XYZZ_WORDS * 1024 * 32));
+    if (!heavy_done) { VZ_HIP_CHECK(hipMalloc(&heavy_done, 4 * 1024)); VZ_HIP_CHECK(hipMemset(heavy_done, 0, 4 * 1024)); VZ_HIP_CHECK(hipStreamSynchronize(nullptr)); }
+    if (!plane_scratch) VZ_HIP_CHECK(hipMalloc(&plane_scratch, 4 * (size_t)XYZZ_WORDS * 256));
     if (!ones_partial) VZ_HIP_CHECK(hipMalloc(&ones_partial, 4 * (size_t)XYZZ_WORDS * (16384 + 64 + 512)));
     if (!host_pinned) VZ_HIP_CHECK(hipHostMalloc(&host_pinned, 4 * XYZZ_WORDS * MSM_MAX_WINDOWS));
     return hipSuccess;
@@ -142,7 +147,7 @@ struct MsmWorkspace {  // device buffers, grown on demand and reused across call
   }
   void release() {
     hipFree(counts); hipFree(cursor); hipFree(bucket_off); hipFree(sub_off); hipFree(sorted);
-    hipFree(partial); hipFree(window_sums); hipFree(totals); hipFree(heavy); hipFree(heavy_scratch); hipFree(small_buf); hipFree(ones_partial); hipFree(block_hist);
+    hipFree(partial); hipFree(window_sums); hipFree(totals); hipFree(heavy); hipFree(heavy_scratch); hipFree(heavy_done); hipFree(plane_scratch); hipFree(small_buf); hipFree(ones_partial); hipFree(block_hist);
     if (host_pinned) hipHostFree(host_pinned);
     *this = MsmWorkspace();
   }

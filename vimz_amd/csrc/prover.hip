@@ -18,6 +18,8 @@ HostPool& vz_shared_pool() {
   return *pool;
 }
 
+std::atomic<long>& vz_head_rows_override() { static std::atomic<long> v{-1}; return v; }
+
 extern "C" {
 
 void vimz_prover_free(vimz_prover* p) {
@@ -200,6 +202,10 @@ int vz_prover_create_layout(vimz_ctx* ctx, const vimz_circuit* circuit, const vi
 
 extern "C" {
 // Start a new IVC: z0 (len_z canonical elements).
+// Rows of a short fold call whose Poseidon chains are evaluated on the HOST (the head batch, prover_internal.hpp): rows >= 0 pins the number for
+// every later call of this process (0 = every row's witness entirely on the GPU), -1 restores the library's policy.  Returns the previous setting.
+long vimz_set_head_rows(long rows) { return vz_head_rows_override().exchange(rows < 0 ? -1 : rows); }
+
 int vimz_prover_reset(vimz_prover* p, const uint64_t* z0) {
   if (!p || !z0) return VIMZ_ERR_INVALID;
   vimz_ctx* ctx = p->ctx;

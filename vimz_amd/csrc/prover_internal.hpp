@@ -549,8 +549,11 @@ static inline hipError_t vz_wait_event(hipEvent_t e) { return hipEventSynchroniz
 //   otherwise calls of at most 48 rows: 24 head rows (20-row window, 16 cores: 837-899 against 646-664 without); longer calls: none
 //   (256 rows: 1 174-1 176 against 1 087-1 100).  A head shorter than the call AND short (2-8 rows of 10) is the one thing to avoid: the rest
 //   then waits for two chain latencies, the hash-only pass and the batch's own (210-450 steps/s).
+std::atomic<long>& vz_head_rows_override();      // vimz_set_head_rows: -1 = the policy below
 static size_t head_rows_wanted(size_t nsteps = 0) {
   static const long env = getenv("VIMZ_HEAD_ROWS") ? atol(getenv("VIMZ_HEAD_ROWS")) : -1;
+  const long ov = vz_head_rows_override().load(std::memory_order_relaxed);
+  if (ov >= 0) return (size_t)ov;
   if (env >= 0) return (size_t)env;
   static const bool few_cores = usable_cpus() < 6;
   if (few_cores) return 0;

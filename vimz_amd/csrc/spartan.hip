@@ -147,7 +147,7 @@ __global__ void __launch_bounds__(256) k_ipa_fold_bases(uint32_t* __restrict__ b
     }
     add_mixed(acc, lo);
     const Affine<G> r = to_affine(acc);
-    store_words20(bases + (size_t)AFFINE_WORDS * i, r.x, r.y);
+    store_affine<G>(bases, i, r);
   }
 }
 // out = x + r·y + r2·z

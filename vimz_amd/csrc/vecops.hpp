@@ -66,17 +66,15 @@ __global__ void k_points_to_internal(const uint32_t* __restrict__ in, int canoni
     F x = load_fe<F>(in, 2 * i), y = load_fe<F>(in, 2 * i + 1);
     if (canonical) { x = F::to_mont(x); y = F::to_mont(y); }
     const Fp29<typename F::Params> a = Fp29<typename F::Params>::from_std(x), b = Fp29<typename F::Params>::from_std(y);
-    uint32_t* o = out + (size_t)AFFINE_WORDS * i;
-    for (int k = 0; k < 9; k++) { o[k] = a.v[k]; o[COORD_WORDS + k] = b.v[k]; }
-    o[9] = 0; o[COORD_WORDS + 9] = 0;
+    uint32_t* o = out + (size_t)AFFINE_WORDS * i;      // 64 B: x, y as 256-bit integers (ec.hpp)
+    a.unpack(o); b.unpack(o + 8);
   }
 }
 template <class F>
 __global__ void k_points_from_internal(const uint32_t* __restrict__ in, int canonical, uint32_t* __restrict__ out, size_t n) {
   VZ_GRID_STRIDE(i, n) {
-    Fp29<typename F::Params> a, b;
     const uint32_t* p = in + (size_t)AFFINE_WORDS * i;
-    for (int k = 0; k < 9; k++) { a.v[k] = p[k]; b.v[k] = p[COORD_WORDS + k]; }
+    const Fp29<typename F::Params> a = Fp29<typename F::Params>::pack(p), b = Fp29<typename F::Params>::pack(p + 8);
     F x = a.to_std(), y = b.to_std();
     if (canonical) { x = F::from_mont(x); y = F::from_mont(y); }
     store_fe(out, 2 * i, x); store_fe(out, 2 * i + 1, y);

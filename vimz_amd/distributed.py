@@ -194,20 +194,42 @@ def tree_rounds(world):
 
 
 def _offer(proof, merged_cls, transport, shm_dir):
-    """What the handing-over rank sends: {"kind": "none" | "ipc" | "file" | "bytes", ...} and the file it must remove afterwards."""
+    """What the handing-over rank sends: {"kind": "none" | "ipc" | "file" | "bytes", ...} (+ a binary payload) and the file it must remove afterwards."""
     import os
     import tempfile
     if proof is None:
-        return {"kind": "none"}, None
+        return {"kind": "none"}, b"", None
     if transport == "ipc":
-        return {"kind": "ipc", "ticket": np.asarray(proof.share()).tobytes()}, None
+        return {"kind": "ipc"}, np.asarray(proof.share()).tobytes(), None
     blob = np.asarray(proof.save())
     if transport == "file":
         fd, path = tempfile.mkstemp(prefix="vimz_proof_", dir=shm_dir)      # (O_EXCL, unpredictable name, this user only)
         with os.fdopen(fd, "wb") as f:
             blob.tofile(f)
-        return {"kind": "file", "path": path, "bytes": int(blob.size)}, path
-    return {"kind": "bytes", "blob": blob.tobytes()}, None
+        return {"kind": "file", "path": path, "bytes": int(blob.size)}, b"", path
+    return {"kind": "bytes"}, blob.tobytes(), None
+
+
+def _encode_offer(header, payload=b""):
+    """A hand-over message: 4-byte little-endian header length ‖ JSON header ‖ binary payload (an IPC ticket or a proof blob).  No pickle: what a
+    peer sends is parsed as data, never executed."""
+    import json
+    h = json.dumps(header).encode()
+    return len(h).to_bytes(4, "little") + h + bytes(payload)
+
+
+def _decode_offer(raw):
+    import json
+    raw = bytes(raw)
+    if len(raw) < 4:
+        raise ValueError("hand-over message: truncated")
+    n = int.from_bytes(raw[:4], "little")
+    if n > len(raw) - 4 or n > 1 << 16:
+        raise ValueError("hand-over message: bad header length")
+    header = json.loads(raw[4:4 + n].decode())
+    if not isinstance(header, dict) or header.get("kind") not in ("none", "ipc", "file", "bytes", "abort"):
+        raise ValueError("hand-over message: unknown kind")
+    return header, raw[4 + n:]
 
 
 def tree_final_fold(proof, vk, rank, world, dist, merged_cls, shm_dir=None, timings=None):
@@ -215,24 +237,55 @@ def tree_final_fold(proof, vk, rank, world, dist, merged_cls, shm_dir=None, timi
     the sequence shortened to ceil(log2 N) merges on the critical path): in round k rank r + 2^k hands its merged proof to rank r, which
     folds it in (Node(A, B) of DESIGN.md §6b — one cross term, one large MSM, one fused fold, on r's GPU); pairs start as soon as both
     sides are ready — no barrier.  Hand-over, in order of preference: a HIP IPC ticket (device-to-device copy incl. the running products,
-    merged_cls.open_shared), a file in node-local shared memory (save -> load), bytes through gloo.  Returns the proof on rank 0."""
+    merged_cls.open_shared), a file in node-local shared memory (save -> load), bytes through gloo.  Returns the proof on rank 0.
+    A failure anywhere travels UP the tree: the failing rank answers its sender "fail" (which raises there), sends an abort marker to the rank
+    that is waiting for ITS hand-over, and raises; a rank that receives an abort marker does the same — nobody is left in a blocking receive."""
     import os
-    import pickle
     import time
-    # VIMZ_SHARD_TRANSPORT = ipc | file | bytes pins the hand-over; "ipc-fail" makes the receiver's IPC open fail, to exercise the fallback
+    # VIMZ_SHARD_TRANSPORT = ipc | file | bytes pins the hand-over; "ipc-fail" makes the receiver's IPC open fail, to exercise the fallback;
+    # "merge-fail:<rank>" makes that rank's merge raise, to exercise the failure path
     forced = os.environ.get("VIMZ_SHARD_TRANSPORT", "")
-    can_ipc = hasattr(merged_cls, "open_shared") and forced in ("", "ipc", "ipc-fail")
+    fail_rank = int(forced.split(":", 1)[1]) if forced.startswith("merge-fail:") else -1
+    can_ipc = hasattr(merged_cls, "open_shared") and (forced in ("", "ipc", "ipc-fail") or fail_rank >= 0)
     t_wait = t_merge = 0.0
     step = 1
+
+    def abort_upwards(why):
+        """tell the rank that will wait for this rank's hand-over that it is not coming"""
+        if rank != 0:
+            try:
+                _send_bytes(dist, _encode_offer({"kind": "abort", "error": str(why)[:500], "from": rank}), rank - (rank & -rank))
+            except Exception:      # (best effort: the process group may already be gone)
+                pass
+
+    def refuse_later_senders(after_step):
+        """the ranks that would hand over to this rank in later rounds: take their offers and answer "fail", so that they raise instead of waiting"""
+        st = 2 * after_step
+        while st < world and rank % (2 * st) == 0:
+            src2 = rank + st
+            if src2 < world:
+                try:
+                    m2, _ = _decode_offer(_recv_bytes(dist, src2))
+                    if m2["kind"] != "abort":
+                        _send_bytes(dist, b"fail", src2)
+                except Exception:
+                    pass
+            st *= 2
+
     try:
         while step < world:
             if rank % (2 * step) == 0:
                 src = rank + step
                 if src < world:
                     t0 = time.time()
-                    msg = pickle.loads(_recv_bytes(dist, src))
+                    msg, payload = _decode_offer(_recv_bytes(dist, src))
                     t1 = time.time()
                     t_wait += t1 - t0
+                    if msg["kind"] == "abort":      # (its sender is not waiting for an answer)
+                        err = RuntimeError(f"sharded proof: rank {msg.get('from', src)} failed: {msg.get('error', '')}")
+                        abort_upwards(err)
+                        refuse_later_senders(step)
+                        raise err
                     err = None
                     try:
                         other = None
@@ -240,30 +293,34 @@ def tree_final_fold(proof, vk, rank, world, dist, merged_cls, shm_dir=None, timi
                             try:
                                 if forced == "ipc-fail":
                                     raise RuntimeError("IPC open refused (VIMZ_SHARD_TRANSPORT=ipc-fail)")
-                                other = merged_cls.open_shared(vk, msg["ticket"])
+                                other = merged_cls.open_shared(vk, payload)
                             except Exception:      # no IPC / peer access between the two devices: ask for the bytes instead
                                 _send_bytes(dist, b"retry", src)
-                                msg = pickle.loads(_recv_bytes(dist, src))
+                                msg, payload = _decode_offer(_recv_bytes(dist, src))
                         if other is None and msg["kind"] == "file":
-                            other = merged_cls.load(vk, np.fromfile(msg["path"], dtype=np.uint8, count=msg["bytes"]))
+                            other = merged_cls.load(vk, np.fromfile(msg["path"], dtype=np.uint8, count=int(msg["bytes"])))
                         elif other is None and msg["kind"] == "bytes":
-                            other = merged_cls.load(vk, np.frombuffer(msg["blob"], dtype=np.uint8))
+                            other = merged_cls.load(vk, np.frombuffer(payload, dtype=np.uint8))
                         t_open = time.time()
                         if other is not None:
                             if proof is None:
                                 proof = other
                             else:
                                 try:
+                                    if rank == fail_rank:
+                                        raise RuntimeError(f"merge refused (VIMZ_SHARD_TRANSPORT={forced})")
                                     proof.merge(other)
                                 finally:
                                     other.close()
                         if timings is not None:
                             timings.setdefault("transports", []).append(msg["kind"])
                             timings.setdefault("hand_overs", []).append({"from": src, "kind": msg["kind"], "open_s": t_open - t1, "merge_s": time.time() - t_open})
-                    except Exception as e:      # (the sender must not be left waiting: answer first, raise afterwards)
+                    except Exception as e:      # (the sender must not be left waiting: answer first, then tell the rank above, raise afterwards)
                         err = e
                     _send_bytes(dist, b"done" if err is None else b"fail", src)
                     if err is not None:
+                        abort_upwards(err)
+                        refuse_later_senders(step)
                         raise err
                     t_merge += time.time() - t1
             else:
@@ -271,12 +328,15 @@ def tree_final_fold(proof, vk, rank, world, dist, merged_cls, shm_dir=None, timi
                 transport = "ipc" if (can_ipc and proof is not None and hasattr(proof, "share")) else ("bytes" if (forced == "bytes" or not shm_dir) else "file")
                 path = None
                 try:
-                    offer, path = _offer(proof, merged_cls, transport, shm_dir)
-                    _send_bytes(dist, pickle.dumps(offer), dst)
-                    if _recv_bytes(dist, dst) == b"retry":
-                        offer, path = _offer(proof, merged_cls, "file" if shm_dir else "bytes", shm_dir)
-                        _send_bytes(dist, pickle.dumps(offer), dst)
-                        _recv_bytes(dist, dst)
+                    offer, payload, path = _offer(proof, merged_cls, transport, shm_dir)
+                    _send_bytes(dist, _encode_offer(offer, payload), dst)
+                    reply = bytes(_recv_bytes(dist, dst))
+                    if reply == b"retry":
+                        offer, payload, path = _offer(proof, merged_cls, "file" if shm_dir else "bytes", shm_dir)
+                        _send_bytes(dist, _encode_offer(offer, payload), dst)
+                        reply = bytes(_recv_bytes(dist, dst))
+                    if reply != b"done":
+                        raise RuntimeError(f"sharded proof: rank {dst} could not take over this rank's proof")
                 finally:
                     if path is not None and os.path.exists(path):
                         os.unlink(path)

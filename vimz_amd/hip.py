@@ -745,6 +745,14 @@ def _seeded(ctx, name):
     return getattr(ctx.lib, name)
 
 
+def set_head_rows(rows):
+    """vimz_set_head_rows: rows of a short fold call whose Poseidon chains run on the host (0: all on the GPU; -1: the library's policy)."""
+    lib = L.lib()
+    lib.vimz_set_head_rows.argtypes = [C.c_long]
+    lib.vimz_set_head_rows.restype = C.c_long
+    return int(lib.vimz_set_head_rows(int(rows)))
+
+
 class Decider:
     """vimz_decider: `Decider::preprocess` / `prove` / `verify` of the Sonobe backend (vimz/src/sonobe_backend/mod.rs:72-80) — the 25 calldata words of
     contracts/*Verifier.sol and their local verification.  prover: a CycleFoldIVC (shapes, keys, context; keep it open); kzg_vk: [tau]G2 of the SRS
