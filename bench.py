@@ -227,7 +227,7 @@ def main_ivc(args, rank, world, dist, torch, ctxs, circuit, params, steps_all, g
     S = len(ctxs)
     W, K = args.warmup, args.steps
     ck2 = params.secondary_key()
-    ivcs = [hip.IVC(c, circuit, params.ck, ck2, max_batch=args.batch) for c in ctxs]
+    ivcs = args.made_provers or [hip.IVC(c, circuit, params.ck, ck2, max_batch=args.batch) for c in ctxs]
     helper_ctxs, helper_keys = [], []
     for hidx in range(args.msm_helpers):      # one proof on several GPUs — the large MSM(T) split by base range
         ndev = max(1, torch.cuda.device_count())
@@ -539,7 +539,7 @@ def main_ivc(args, rank, world, dist, torch, ctxs, circuit, params, steps_all, g
             "all_hip_schedule": all_hip,
             "sonobe_backend": sonobe,
             "compressed_snark": compress,
-            "end_to_end_estimate_s": {"keygen_and_setup": setup_s, "fold_720_steps_one_gpu": 720 * dt / max(1, timed_total),
+            "end_to_end_estimate_s": {"keygen_and_setup": setup_s, "setup_split": getattr(args, "setup_split", None), "fold_720_steps_one_gpu": 720 * dt / max(1, timed_total),
                                       "compress": (compress["setup_s"] + compress["prove_s"]) if compress else None,
                                       "total_720_steps": (setup_s + 720 * dt / max(1, timed_total) + compress["setup_s"] + compress["prove_s"]) if compress else None,
                                       "reference_cpu_server": {"keygen_s": 6.5, "fold_s": 371.7, "compress_s_sample_run": 13.0, "source": "README.md:52, sample-output.png"}},
@@ -680,10 +680,14 @@ def main():
     # three concurrent segments fill the GPU when the host has the cores to drive them (each: a fold thread, a launch-issuing thread, two
     # helpers); on two to five cores two segments do better — 865 against 541 steps/s on two cores, 636 as one chain (profiles/r04_cores.txt)
     S = args.segments if args.segments > 0 else ((3 if usable_cores() >= 6 else 2) if args.mode == "ivc" else 2)
-    ctxs = [hip.Context(device) for _ in range(S)]
-    ctx = ctxs[0]
+    # set-up with its parts side by side (folding.prepare_folding_overlapped): contexts and the step circuit together, then the keys, then — in IVC
+    # mode — the segments' provers together; `setup_s` of the result line counts all of it
     t_setup = time.time()
-    circuit, params = folding.prepare_folding(ctx, args.transformation, args.resolution, window_tables=args.window_tables)
+    ctxs, circuit, params, made_provers, setup_split = folding.prepare_folding_overlapped(device, S, args.transformation, args.resolution, window_tables=args.window_tables,
+                                                                                         mode=("ivc" if args.mode == "ivc" and not args.msm_helpers else "none"), batch=max(0, args.batch))
+    ctx = ctxs[0]
+    args.setup_split = setup_split
+    args.made_provers = made_provers if made_provers and made_provers[0] is not None else None
     if args.batch <= 0:
         args.batch = folding.default_batch(circuit)
     steps_all, z0 = build_inputs(args.transformation, args.resolution)

@@ -3,9 +3,9 @@
 #   the driver-style bench line and the long-window one, rocprofv3 kernel stats + the k_accum split of the same command, the
 #   FETCH_SIZE / WRITE_SIZE counter passes (separate runs, counters only) summarised per kernel — for the HD headline and for the
 #   4K / 8K shapes —, whole-image runs, the bench windows of the other configurations, the N > 1 lines on the one GPU of the box.
-#   usage: tools/refresh_profiles.sh [round tag, default r04] [parts: all | bench | rocprof | pmc | valu | e2e | configs | ranks | cores | cyclefold]
+#   usage: tools/refresh_profiles.sh [round tag, default r05] [parts: all | bench | rocprof | pmc | valu | e2e | configs | ranks | cores | cyclefold | round5]
 set -u
-R=${1:-r04}
+R=${1:-r05}
 PARTS=${2:-all}
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/refresh; mkdir -p $O
@@ -106,5 +106,20 @@ if want cyclefold; then  # the Sonobe backend's path: Nova + CycleFold on one ch
   python3 tools/trace_busy.py $(find $O/kt -name "*kernel_trace.csv" | head -1) > $O/${R}_trace_busy_cyclefold_HD.txt 2>/dev/null
   rm -rf $O/kt
   python3 tools/small_msm_crossover.py > $O/${R}_small_msm_crossover.txt 2>/dev/null
+fi
+if want round5; then   # round 5's own evidence: the large MSM's tails under stress, the plane reduce A/B, set-up split, memory against batch size, the T-multiplicity experiment
+  $T python3 tools/stress_large_msm.py 305185 30 3 > $O/${R}_stress_large_msm.txt 2>&1
+  { echo "# shared bucket set reduced as virtual windows (k_reduce, default) vs by bit planes (VIMZ_TUNE=reduce_planes=1): alone on the GPU, then inside the bench";
+    python3 tools/msm_bench.py 305185 2>&1 | grep tables; VIMZ_TUNE=reduce_planes=1 python3 tools/msm_bench.py 305185 2>&1 | grep tables | sed 's/^/planes: /';
+    for pl in 0 1; do for args in "--steps 256 --repeats 3 --no-extras" "--steps 20 --warmup 5"; do
+      VIMZ_TUNE=reduce_planes=$pl timeout 600 python3 bench.py --no-cpu-baseline --no-compress $args 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('reduce_planes=$pl $args: %.0f steps/s, samples %s, one chain %s, reduce %.3f ms in the bench' % (d['value'], [round(x) for x in d['samples_steps_per_s']], round(d['one_chain']['steps_per_s']) if d.get('one_chain') else None, d['roofline']['msm_phase_ms']['reduce']))"
+    done; done; } > $O/${R}_reduce_planes.txt
+  : > $O/${R}_setup_breakdown.jsonl
+  for cfg in "contrast HD 3" "contrast 4K 3" "resize 8K 3"; do timeout 600 python3 tools/setup_breakdown.py $cfg 2>/dev/null | tail -1 >> $O/${R}_setup_breakdown.jsonl; done
+  { echo "# steps/s and peak device memory against the witness batch size (three provers per GPU; bench.py --batch B)";
+    for cfg in "contrast HD 256" "contrast 4K 128" "resize 8K 128"; do set -- $cfg; for b in 32 64 128; do
+      timeout 900 python3 bench.py --transformation $1 --resolution $2 --steps $3 --warmup 32 --repeats 3 --batch $b --no-extras --no-cpu-baseline --no-compress 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1 $2 batch $b: %.0f steps/s over $3 rows, peak device memory %.1f GB, verified %s' % (d['value'], d['peak_device_bytes'] / 1e9, d['verified']))"
+    done; done; } > $O/${R}_batch_sweep.txt
+  timeout 900 python3 tools/t_multiplicity.py 256 150 > $O/${R}_t_multiplicity.json 2> $O/t_mult.err
 fi
 ls -la $O

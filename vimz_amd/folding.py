@@ -120,6 +120,83 @@ def prepare_folding(ctx, transformation, resolution="HD", ck_label=b"ck", window
     return circuit, FoldingParams(ctx, circuit, ck, time.time() - t0, kzg_vk=kzg_vk)
 
 
+def prepare_folding_overlapped(device, segments, transformation, resolution="HD", window_tables=15, backend="nova-snark", mode="ivc", batch=0, ctxs=None):
+    """prepare_folding for a proof made as `segments` concurrent row segments, with its parts side by side instead of one after another
+    (once the fold takes 0.6 s the set-up is the largest span of an HD run).  What depends on what:
+        contexts (HIP runtime, streams)      — nothing; one thread each
+        step circuit (host builder, 0.09 s)   — nothing: runs under the contexts' creation
+        commitment key + window tables (GPU) — the circuit's size, context 0
+        one prover per segment                — circuit, keys, its context: the verifier circuits' synthesis (host) and the device buffers of the
+                                                segments' provers are made side by side (ctypes releases the GIL around every library call)
+    Returns (ctxs, circuit, params, provers, seconds: {contexts_and_circuit, keys, provers, total}).  mode: "ivc" (hip.IVC), "cyclefold"
+    (hip.CycleFoldIVC over a KZG SRS), "accumulator" (hip.Prover).  Sequential equivalent: prepare_folding + one prover per context."""
+    import threading
+    from . import hip
+    t_all = time.time()
+    out, err = {}, []
+
+    def guarded(fn):
+        def run(*a):
+            try:
+                fn(*a)
+            except BaseException as e:      # noqa: BLE001 (re-raised on the calling thread)
+                err.append(e)
+        return run
+
+    own_ctxs = ctxs is None
+    ctxs = [None] * segments if own_ctxs else list(ctxs)
+
+    def make_ctx(k):
+        ctxs[k] = hip.Context(device)
+
+    def make_circuit():
+        out["circuit"] = Circuit(transformation, *default_shape(transformation, resolution))
+
+    th = [threading.Thread(target=guarded(make_circuit))] + ([threading.Thread(target=guarded(make_ctx), args=(k,)) for k in range(segments)] if own_ctxs else [])
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    if err:
+        raise err[0]
+    circuit = out["circuit"]
+    t_cc = time.time()
+    sonobe = backend == "sonobe" or mode == "cyclefold"
+    n = 1 << (max(circuit.n_wires, circuit.n_constraints) + (CYCLEFOLD_ROOM if sonobe else AUGMENTED_ROOM) - 1).bit_length()
+    kzg_vk = None
+    if sonobe:
+        ck, kzg_vk = hip.kzg_setup(ctxs[0], n)
+    else:
+        ck = ctxs[0].bases_generate(_lib.CURVE_BN254_G1, n, b"ck")
+    if window_tables:
+        ck.precompute(16 if window_tables is True else int(window_tables))
+    params = FoldingParams(ctxs[0], circuit, ck, time.time() - t_cc, kzg_vk=kzg_vk)
+    ck2 = params.secondary_key() if mode in ("ivc", "cyclefold") else None      # (mode "none": keys only, the caller makes its provers)
+    t_keys = time.time()
+    batch = batch or default_batch(circuit)
+    provers = [None] * segments
+
+    def make_prover(k):
+        if mode == "none":
+            return
+        if mode == "ivc":
+            provers[k] = hip.IVC(ctxs[k], circuit, ck, ck2, max_batch=batch)
+        elif mode == "cyclefold":
+            provers[k] = hip.CycleFoldIVC(ctxs[k], circuit, ck, ck2, max_batch=batch)
+        else:
+            provers[k] = hip.Prover(ctxs[k], circuit, ck, max_batch=batch)
+
+    th = [threading.Thread(target=guarded(make_prover), args=(k,)) for k in range(segments)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    if err:
+        raise err[0]
+    t_end = time.time()
+    return ctxs, circuit, params, provers, {"contexts_and_circuit": t_cc - t_all, "keys": t_keys - t_cc, "provers": t_end - t_keys, "total": t_end - t_all}
+
+
 def default_batch(circuit):
     """Rows whose witnesses are generated together (and whose (A,B,C)·z and commitments the producer keeps ahead of the folds).  A batch
     costs one Poseidon-chain latency whatever its size, so wide circuits want large batches — 288 GB of HBM is what allows them: at 4K /
