@@ -427,17 +427,31 @@ def main_ivc(args, rank, world, dist, torch, ctxs, circuit, params, steps_all, g
         # extra (N = 1): the same K rows as ONE chain (one IVC, no segments, no merge) — what a single sequential prove_step loop reaches
         one_chain = None
         if world == 1 and S > 1 and not args.no_extras:
+            # a chain of its OWN — a context and a prover made for it, the way `--segments 1` runs — not one of the three segments' provers: the streams of
+            # provers that were created side by side are interleaved over the hardware queues, which suits the three-segment schedule (+5 %) and costs a lone
+            # chain 8 % (profiles/r05_setup_ab.txt)
+            c1 = iv1 = None
             try:
-                ivcs[0].reset(z0)
-                ctxs[0].sync()
-                t3 = time.time()
-                ivcs[0].fold(rows_timed)
-                ctxs[0].sync()
-                d3 = time.time() - t3
-                one_chain = {"steps_per_s": K / d3, "verified": ivcs[0].verify(K, z0) == 0,
-                             "note": "the same rows as one IVC chain on one set of streams (bench.py --segments 1)"}
+                c1 = hip.Context(ctxs[0].device)
+                iv1 = hip.IVC(c1, circuit, params.ck, ck2, max_batch=args.batch)
+                ds = []
+                for rep in range(4):      # the first pass warms the prover's buffers and thread pools
+                    iv1.reset(z0)
+                    c1.sync()
+                    t3 = time.time()
+                    iv1.fold(rows_timed)
+                    c1.sync()
+                    if rep:
+                        ds.append(time.time() - t3)
+                one_chain = {"steps_per_s": K / sorted(ds)[len(ds) // 2], "samples_steps_per_s": [K / d for d in ds], "verified": iv1.verify(K, z0) == 0,
+                             "note": "the same rows as ONE IVC chain on a prover of its own (what bench.py --segments 1 measures); median of three passes"}
             except Exception as e:
                 print(f"[bench] one-chain extra skipped: {e}", file=sys.stderr)
+            finally:
+                if iv1 is not None:
+                    iv1.close()
+                if c1 is not None:
+                    c1.close()
         # extra (N = 1): the same timed passes with EVERY row's witness on the GPU (no host-evaluated head batch) — where the default schedule used one
         all_hip = None
         if world == 1 and not args.no_extras and info.get("head_rows", 0):
@@ -619,7 +633,7 @@ def main():
                          "schedule - no host-evaluated head batch - and a 32-row warm-up left that path's first use inside the timed region)")
     ap.add_argument("--transformation", default="contrast")
     ap.add_argument("--resolution", default="HD")
-    ap.add_argument("--batch", type=int, default=0, help="rows whose witnesses are generated together (0: folding.default_batch — 64 at HD, 128 for the 4K / 8K widths)")
+    ap.add_argument("--batch", type=int, default=0, help="rows whose witnesses are generated together (0: folding.default_batch = 64: every BASELINE configuration below 64 GB of device memory, profiles/r05_batch_sweep.txt)")
     ap.add_argument("--segments", type=int, default=0, help="row segments folded concurrently on each GPU, own context + streams each, and merged into one proof (default: 3 in IVC mode — 2 when the rank has fewer than six host cores —, 2 accumulators)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -683,8 +697,10 @@ def main():
     # set-up with its parts side by side (folding.prepare_folding_overlapped): contexts and the step circuit together, then the keys, then — in IVC
     # mode — the segments' provers together; `setup_s` of the result line counts all of it
     t_setup = time.time()
+    pre_ctxs = [hip.Context(device) for _ in range(S)] if os.environ.get("VIMZ_BENCH_SEQUENTIAL_CONTEXTS") else None      # (A/B: contexts one after another)
     ctxs, circuit, params, made_provers, setup_split = folding.prepare_folding_overlapped(device, S, args.transformation, args.resolution, window_tables=args.window_tables,
-                                                                                         mode=("ivc" if args.mode == "ivc" and not args.msm_helpers else "none"), batch=max(0, args.batch))
+                                                                                         mode=("ivc" if args.mode == "ivc" and not args.msm_helpers and not os.environ.get("VIMZ_BENCH_SEQUENTIAL_PROVERS") else "none"),
+                                                                                         batch=max(0, args.batch), ctxs=pre_ctxs)
     ctx = ctxs[0]
     args.setup_split = setup_split
     args.made_provers = made_provers if made_provers and made_provers[0] is not None else None

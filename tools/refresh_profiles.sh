@@ -3,7 +3,7 @@
 #   the driver-style bench line and the long-window one, rocprofv3 kernel stats + the k_accum split of the same command, the
 #   FETCH_SIZE / WRITE_SIZE counter passes (separate runs, counters only) summarised per kernel — for the HD headline and for the
 #   4K / 8K shapes —, whole-image runs, the bench windows of the other configurations, the N > 1 lines on the one GPU of the box.
-#   usage: tools/refresh_profiles.sh [round tag, default r05] [parts: all | bench | rocprof | pmc | valu | e2e | configs | ranks | cores | cyclefold | round5]
+#   usage: tools/refresh_profiles.sh [round tag, default r05] [parts: all | bench | rocprof | pmc | valu | e2e | configs | ranks | cores | cyclefold | round5 | stalls]
 set -u
 R=${1:-r05}
 PARTS=${2:-all}
@@ -121,5 +121,13 @@ if want round5; then   # round 5's own evidence: the large MSM's tails under str
       timeout 900 python3 bench.py --transformation $1 --resolution $2 --steps $3 --warmup 32 --repeats 3 --batch $b --no-extras --no-cpu-baseline --no-compress 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1 $2 batch $b: %.0f steps/s over $3 rows, peak device memory %.1f GB, verified %s' % (d['value'], d['peak_device_bytes'] / 1e9, d['verified']))"
     done; done; } > $O/${R}_batch_sweep.txt
   timeout 900 python3 tools/t_multiplicity.py 256 150 > $O/${R}_t_multiplicity.json 2> $O/t_mult.err
+fi
+if want stalls; then   # k_accum alone on the GPU (tools/msm_bench.py: 305 185 dense scalars): where its wave cycles go, and the bytes it fetches per launch (64-byte table entries)
+  $T rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU --output-format csv -d $O/ps -o ps -- python3 tools/msm_bench.py 305185 > /dev/null 2>> $O/rocprof.err
+  { echo "# k_accum over window tables, alone on the GPU (msm_bench.py 305185): SQ counters per launch, by grid size"; python3 tools/stall_summary.py $(find $O/ps -name "*counter_collection.csv" | head -1) k_accum; } > $O/${R}_k_accum_stalls_alone.txt
+  rm -rf $O/ps
+  $T rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pf -o pf -- python3 tools/msm_bench.py 305185 > /dev/null 2>> $O/rocprof.err
+  { echo "# FETCH_SIZE per k_accum launch, alone (units as rocprofv3 reports them; pmc_summary.py applies the guide's correction for the bench passes)"; python3 tools/stall_summary.py $(find $O/pf -name "*counter_collection.csv" | head -1) k_accum; } >> $O/${R}_k_accum_stalls_alone.txt
+  rm -rf $O/pf
 fi
 ls -la $O

@@ -198,11 +198,15 @@ def prepare_folding_overlapped(device, segments, transformation, resolution="HD"
 
 
 def default_batch(circuit):
-    """Rows whose witnesses are generated together (and whose (A,B,C)·z and commitments the producer keeps ahead of the folds).  A batch
-    costs one Poseidon-chain latency whatever its size, so wide circuits want large batches — 288 GB of HBM is what allows them: at 4K /
-    8K whole images run at 370 / 284 steps/s with 32 rows, 408 / 359 with 64, 420 / 381 with 128, 427 / 398 with 256 (which is 54 GB per
-    prover, and three provers share a GPU); at HD the size does not matter (742-768 from 64 to 256).  (profiles/r03_batch_sweep.txt)"""
-    return 64 if circuit.n_wires < 500_000 else 128
+    """Rows whose witnesses are generated together (and whose (A,B,C)·z and commitments the producer keeps ahead of the folds).  A batch costs one
+    Poseidon-chain latency whatever its size, so wide circuits want large batches — and a batch buffer is rows x wires x 32 B, three provers per GPU.
+    Round 5, measured as a trade-off (profiles/r05_batch_sweep.txt; three provers, steps/s over 256 / 128 / 128 rows and peak device memory):
+        contrast HD   32: 1 160 / 13.8 GB    64: 1 181 / 21.4 GB    128: 1 219 / 35.6 GB
+        contrast 4K   32:   673 / 31.4 GB    64:   693 / 52.8 GB    128:   704 / 97.6 GB
+        resize 8K     32:   583 / 29.6 GB    64:   613 / 49.2 GB    128:   610 / 90.3 GB
+    64 keeps every BASELINE configuration below 64 GB at a loss of at most 1.6 % against 128 (which was the default above 500 k wires until round 4:
+    98-105 GB for three provers).  `--batch` / max_batch override it."""
+    return 64
 
 
 class FoldingProof:
