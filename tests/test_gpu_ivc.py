@@ -323,7 +323,11 @@ def test_proof_does_not_depend_on_the_schedule():
                 {"VIMZ_DEBUG_SMALL_SUM_KERNEL": "1", "VIMZ_AUG_NO_THREADS": "1"}, {"VIMZ_TUNE": "sort_blocks=256,combine_lane_bits=4"},
                 {"VIMZ_IVC_LOOKAHEAD": "1"}, {"VIMZ_TUNE": "sort_blocks=40,combine_lane_bits=2", "VIMZ_DEBUG_CHECK_MSM": "1"},
                 # the Poseidon chains in the standard 8 x 32-bit arithmetic instead of the reduced-radix one, with the GPU producing every row
-                {"VIMZ_DEBUG_POSEIDON_STD": "1", "VIMZ_HEAD_ROWS": "0"}, {"VIMZ_TUNE": "ones_dense=0"}]
+                {"VIMZ_DEBUG_POSEIDON_STD": "1", "VIMZ_HEAD_ROWS": "0"}, {"VIMZ_TUNE": "ones_dense=0"},
+                # round 5: the shared bucket set reduced by bit planes, with batches of two rows — the producer's issuer thread then launches MSMs of later rows
+                # while the folding thread finishes earlier ones with the SAME plan object (a half-written plan once gave wrong commitments here)
+                {"VIMZ_DIGEST_TABLES": "15"}, {"VIMZ_DIGEST_TABLES": "15", "VIMZ_TUNE": "reduce_planes=1", "VIMZ_HEAD_ROWS": "0", "_batch": "2"},
+                {"VIMZ_DIGEST_TABLES": "14", "VIMZ_TUNE": "reduce_planes=1"}]
     # (the lookahead also with batches of two and three rows and no host-evaluated head: every way a row two steps ahead can fall into
     #  the same batch, the next one, or not exist)
     variants += [{"VIMZ_IVC_LOOKAHEAD": "1", "VIMZ_HEAD_ROWS": "0", "_batch": "2"}, {"VIMZ_IVC_LOOKAHEAD": "1", "VIMZ_HEAD_ROWS": "0", "_batch": "3"}]

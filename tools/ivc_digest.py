@@ -27,6 +27,9 @@ def main():
     while n < max(c.n_wires, c.n_constraints) + 8192:
         n *= 2
     ck = ctx.bases_generate(L.CURVE_BN254_G1, n)
+    import os
+    if int(os.environ.get("VIMZ_DIGEST_TABLES", "0")):      # window tables of the key (the large MSM's default in folding.prepare_folding): same proof
+        ck.precompute(int(os.environ["VIMZ_DIGEST_TABLES"]))
     ck2 = ctx.bases_generate(L.CURVE_GRUMPKIN, 8192, b"ck-secondary")
     ivc = hip.IVC(ctx, c, ck, ck2, max_batch=max_batch)
     ivc.reset(z0)

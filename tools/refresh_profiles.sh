@@ -36,10 +36,16 @@ if want rocprof; then
   kstats 4K --transformation contrast --resolution 4K --steps 96 --warmup 12
   kstats 8K --transformation resize --resolution 8K --steps 96 --warmup 12
 fi
+# (counter passes: one timed pass, and contexts / provers created one after another on the main thread — with the set-up's short-lived threads issuing HIP
+#  calls rocprofv3's counter collection aborted on a dangling correlation id and hung, round 5)
+export_seq() { export VIMZ_BENCH_SEQUENTIAL_CONTEXTS=1 VIMZ_BENCH_SEQUENTIAL_PROVERS=1; }
+unset_seq() { unset VIMZ_BENCH_SEQUENTIAL_CONTEXTS VIMZ_BENCH_SEQUENTIAL_PROVERS; }
 pmc() {      # pmc <tag> <bench args...>: FETCH_SIZE and WRITE_SIZE in separate passes (counters only)
   local tag=$1; shift
-  $T rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pf -o pf -- python3 bench.py --no-cpu-baseline --no-extras --no-compress "$@" > /dev/null 2>> $O/rocprof.err
-  $T rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pw -o pw -- python3 bench.py --no-cpu-baseline --no-extras --no-compress "$@" > /dev/null 2>> $O/rocprof.err
+  export_seq
+  timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pf -o pf -- python3 bench.py --no-cpu-baseline --no-extras --no-compress --repeats 1 "$@" > /dev/null 2>> $O/rocprof.err
+  timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pw -o pw -- python3 bench.py --no-cpu-baseline --no-extras --no-compress --repeats 1 "$@" > /dev/null 2>> $O/rocprof.err
+  unset_seq
   python3 tools/pmc_summary.py $(find $O/pf -name "*counter_collection.csv" | head -1) $(find $O/pw -name "*counter_collection.csv" | head -1) $O/${R}_pmc_summary_$tag.json > $O/${R}_pmc_summary_$tag.txt
   rm -rf $O/pf $O/pw
 }
@@ -50,7 +56,9 @@ if want pmc; then
   pmc ivc_8K --transformation resize --resolution 8K --steps 48 --warmup 12
 fi
 if want valu; then     # vector instructions per step and kernel (the instruction budget of DESIGN.md §8)
-  $T rocprofv3 --pmc SQ_INSTS_VALU --output-format csv -d $O/pv -o pv -- python3 bench.py --no-cpu-baseline --no-extras --no-compress --steps 96 --warmup 32 > /dev/null 2>> $O/rocprof.err
+  export_seq
+  timeout 600 rocprofv3 --pmc SQ_INSTS_VALU --output-format csv -d $O/pv -o pv -- python3 bench.py --no-cpu-baseline --no-extras --no-compress --repeats 1 --steps 96 --warmup 32 > /dev/null 2>> $O/rocprof.err
+  unset_seq
   python3 tools/valu_budget.py $(find $O/pv -name "*counter_collection.csv" | head -1) 224 SQ_INSTS_VALU split > $O/${R}_valu_budget.txt
   rm -rf $O/pv
 fi

@@ -152,12 +152,17 @@ def prepare_folding_overlapped(device, segments, transformation, resolution="HD"
     def make_circuit():
         out["circuit"] = Circuit(transformation, *default_shape(transformation, resolution))
 
-    th = [threading.Thread(target=guarded(make_circuit))] + ([threading.Thread(target=guarded(make_ctx), args=(k,)) for k in range(segments)] if own_ctxs else [])
-    for x in th:
+    # the step circuit and contexts 1.. on threads; context 0 here: the keys need only it and the circuit's size, and are made while the others still come up
+    th_circ = threading.Thread(target=guarded(make_circuit))
+    th_ctx = [threading.Thread(target=guarded(make_ctx), args=(k,)) for k in range(1, segments)] if own_ctxs else []
+    for x in [th_circ] + th_ctx:
         x.start()
-    for x in th:
-        x.join()
+    if own_ctxs:
+        guarded(make_ctx)(0)
+    th_circ.join()
     if err:
+        for x in th_ctx:
+            x.join()
         raise err[0]
     circuit = out["circuit"]
     t_cc = time.time()
@@ -170,6 +175,10 @@ def prepare_folding_overlapped(device, segments, transformation, resolution="HD"
         ck = ctxs[0].bases_generate(_lib.CURVE_BN254_G1, n, b"ck")
     if window_tables:
         ck.precompute(16 if window_tables is True else int(window_tables))
+    for x in th_ctx:
+        x.join()
+    if err:
+        raise err[0]
     params = FoldingParams(ctxs[0], circuit, ck, time.time() - t_cc, kzg_vk=kzg_vk)
     ck2 = params.secondary_key() if mode in ("ivc", "cyclefold") else None      # (mode "none": keys only, the caller makes its provers)
     t_keys = time.time()
