@@ -87,3 +87,21 @@ def test_hash_outputs_are_decomposed_canonically():
         assert plain_ok == aliasable and only_strict_bad == aliasable and honest_bad == 0, o
         if field == 0:
             assert steps >= 3 and steps_aliased >= 1 and sat == 0, o
+
+
+def test_decider_circuit_on_the_host():
+    """The decider circuit (aug/decider.hpp) without a GPU: over the recursion of the trivial step circuit (the running witness folded on the host) its witness
+    satisfies its R1CS, the public inputs are the reference contracts' layout (pp_hash, i, z_0, z_i, 4 x 5 limbs of the folded commitments, the KZG
+    challenges and evaluations, 2 x 5 limbs of cmT: 36 + 2·len_z — contracts/ContrastVerifier.sol:700-772), a wrong KZG evaluation and a cmT other than the
+    one the challenge was derived from are flagged, and every public input is noticed by some row (vimz_decider_selfcheck, testing library)."""
+    import ctypes as C
+    import numpy as np
+    from vimz_amd import _lib
+    T = _lib.testing_lib()
+    T.vimz_decider_selfcheck.argtypes = [C.c_int, C.POINTER(C.c_uint32), C.c_void_p]
+    for steps in (2, 4):
+        res, cnt = C.c_uint32(0xFFFF), np.zeros(4, dtype=np.uint64)
+        assert T.vimz_decider_selfcheck(steps, C.byref(res), cnt.ctypes.data) == 0
+        assert res.value == 0, f"decider self-check bits {res.value:#x}"
+        # one or two constraints per row of the main relation + the Horner chains + the hashes and bit decompositions
+        assert int(cnt[2]) == 36 + 2 * 1 and int(cnt[3]) + 20000 < int(cnt[0]) < 4 * int(cnt[3]) + 30000

@@ -505,6 +505,102 @@ int vimz_decider_setup(vimz_cf* v, const uint64_t kzg_vk_g2[16], vimz_decider** 
   return decider_setup_impl(v, kzg_vk_g2, t, out, seconds);
 }
 #ifdef VIMZ_TESTING
+// Host only, no GPU: the decider circuit (aug/decider.hpp) over the Nova + CycleFold recursion of the trivial step circuit with made-up commitments — the
+// run of vimz_cf_selfcheck, with the running relaxed witness kept by folding on the host — then the decider's final fold, its witness, and the checks:
+// result bit 0 a step's F' witness is bad, 1 the folded scalars differ from F''s, 2 the decider's witness generator flags the honest input, 3 its witness
+// violates a row of the decider's R1CS, 4 the public inputs are not the contract's layout (pp_hash, i, z_0, z_i, 4 x 5 limbs, c_W, c_E, e_W, e_E, 2 x 5 limbs),
+// 5 a wrong KZG evaluation / a wrong challenge / a changed cmT limb is NOT flagged, 6 a changed public input leaves every row satisfied.
+// counts = {decider constraints, wires, public inputs, main constraints}.
+int vimz_decider_selfcheck(int steps, uint32_t* result, uint64_t counts[4]) {
+  if (!result || steps < 2 || steps > 32) return VIMZ_ERR_INVALID;
+  try {
+    CfCircuit cf; cf.finish();
+    cb::BuilderT<Fe> b;
+    b.len_z = 1; b.n_priv = 0; b.n_wires = 3;
+    b.enforce(cb::LCT<Fe>::constant(Fe::one()), cb::LCT<Fe>::wire(2), cb::LCT<Fe>::wire(1));
+    b.n_linear = 1;
+    CfMainCircuit c1(b); c1.use_worker = false; c1.finish(cf);
+    const uint32_t nw = b.n_wires, nc = b.n_constraints();
+    uint32_t res = 0;
+    const G1Aff g1 = CycleSide<BnFq>::G(); const G2Aff g2 = CycleSide<BnFr>::G();
+    auto fake1 = [&](uint64_t k) { const uint32_t w[2] = {(uint32_t)k, (uint32_t)(k >> 32)}; return to_affine(scalar_mul(g1, w, 64)); };
+    auto fake2 = [&](uint64_t k) { const uint32_t w[2] = {(uint32_t)k, (uint32_t)(k >> 32)}; return to_affine(host_mul<Fe>(g2, w, 64)); };
+    std::vector<Fe> z0 = {cb::f_from_u64<Fe>(7)};
+    CfMainRelaxed U = CfMainRelaxed::zero(); G1Aff UW = g1_identity(), UE = g1_identity();
+    CfMainFresh u = CfMainFresh::zero(); G1Aff uW = g1_identity();
+    CfRelaxed cfU = CfRelaxed::zero();
+    std::vector<Fe> Zrun(nw, Fe::zero()), Erun(nc, Fe::zero()), z_last;
+    // x1 += r·x2 over the main shape, with the cross term folded into E:  returns nothing, updates Zrun / Erun
+    auto fold_in = [&](const std::vector<Fe>& z2, const Fe& r) {
+      std::vector<Fe> p1[3], p2[3];
+      host_spmv3(b, Zrun, p1); host_spmv3(b, z2, p2);
+      const Fe u1 = Zrun[0];
+      for (uint32_t k = 0; k < nc; k++) {
+        const Fe T = Fe::sub(Fe::sub(Fe::add(Fe::mul(p1[0][k], p2[1][k]), Fe::mul(p2[0][k], p1[1][k])), Fe::mul(u1, p2[2][k])), p1[2][k]);      // u_2 = 1
+        Erun[k] = Fe::add(Erun[k], Fe::mul(r, T));
+      }
+      for (uint32_t w = 0; w < nw; w++) Zrun[w] = Fe::add(Zrun[w], Fe::mul(r, z2[w]));
+    };
+    for (int i = 0; i < steps; i++) {
+      CfMainIn in = CfMainIn::zero();
+      in.digest = c1.digest; in.i = (uint64_t)i; in.z0 = z0; in.U = U; in.u = u; in.cfU = cfU;
+      CfChallenges ch; ch.h_U = cf_hash_main(c1.digest, i, z0, z0.data(), U); ch.h_cf = cf_hash_cf(c1.digest, cfU);
+      G1Aff Wn = g1_identity(), En = g1_identity();
+      if (i > 0) {
+        const G1Aff cT = i > 1 ? fake1(0x1000 + i) : g1_identity();
+        in.T = nn_point(cT);
+        cf_challenge_main(ch, u, in.T);
+        Wn = g1_fold(UW, ch.r, uW); En = g1_fold(UE, ch.r, cT);
+        in.Wn = nn_point(Wn); in.En = nn_point(En);
+        in.cf1W = fake2(0x2000 + i); in.cf1T = i > 1 ? fake2(0x3000 + i) : g2_identity();
+        in.cf2W = fake2(0x4000 + i); in.cf2T = fake2(0x5000 + i);
+        fold_in(z_last, rho_element<Fe>(ch.r));      // what this step's F' verifies: U_i = U_{i-1} (+) u_{i-1}
+      }
+      std::vector<Fe> augw; bool bad = false;
+      CfMainOut o = c1.witness(in, z0.data(), z0.data(), augw, &bad);
+      if (bad) res |= 1;
+      std::vector<Fe> z = {Fe::one(), z0[0], z0[0]};
+      z.insert(z.end(), augw.begin(), augw.end());
+      if (i > 0 && (!o.U_new.u.eq(Zrun[0]) || !o.U_new.x0.eq(Zrun[nw - 2]) || !o.U_new.x1.eq(Zrun[nw - 1]))) res |= 2;
+      U = o.U_new; UW = i > 0 ? Wn : g1_identity(); UE = i > 0 ? En : g1_identity(); cfU = o.cfU_new;
+      uW = fake1(0x6000 + i); u.W = nn_point(uW); u.x0 = o.x0; u.x1 = o.x1;
+      z_last = z;
+    }
+    // the decider's final fold U_{n+1} = U_n (+) u_n, on the host
+    aug::DeciderIn in;
+    in.digest = c1.digest; in.i = (uint64_t)steps; in.z0 = z0; in.zi = z0; in.U = U; in.u = u; in.cfU = cfU;
+    const G1Aff cmT = fake1(0x7777);
+    in.cmT = nn_point(cmT);
+    uint32_t r_low[4]; aug::decider_challenge(u, in.cmT, r_low);
+    fold_in(z_last, rho_element<Fe>(r_low));
+    in.Wn = nn_point(g1_fold(UW, r_low, uW)); in.En = nn_point(g1_fold(UE, r_low, cmT));
+    const Fe cW = aug::decider_kzg_challenge(in.digest, in.Wn), cE = aug::decider_kzg_challenge(in.digest, in.En);
+    auto horner = [](const Fe* v, size_t n, const Fe& c) { Fe acc = Fe::zero(); for (size_t j = n; j-- > 0;) acc = Fe::add(Fe::mul(acc, c), v[j]); return acc; };
+    in.eW = horner(Zrun.data() + 1, nw - 3, cW); in.eE = horner(Erun.data(), nc, cE);
+    in.Wf = Zrun.data() + 1; in.Ef = Erun.data();
+    aug::DeciderCircuit dc; dc.finish(b, 1);
+    if (counts) { counts[0] = dc.b.n_constraints(); counts[1] = dc.b.n_wires; counts[2] = dc.n_public; counts[3] = nc; }
+    bool bad = false;
+    std::vector<Fe> zd = dc.witness(b, in, &bad);
+    if (bad) res |= 4;
+    auto violated = [&](const std::vector<Fe>& zz) { std::vector<Fe> p[3]; host_spmv3(dc.b, zz, p); for (uint32_t k = 0; k < dc.b.n_constraints(); k++) if (!Fe::mul(p[0][k], p[1][k]).eq(p[2][k])) return true; return false; };
+    if (violated(zd)) res |= 8;
+    // the public inputs, in the contract's order
+    { std::vector<Fe> want = {in.digest, cb::f_from_u64<Fe>((uint64_t)steps), z0[0], z0[0]};
+      for (const U256w* c : {&in.Wn.x, &in.Wn.y, &in.En.x, &in.En.y}) { uint64_t l[aug::DEC_LIMBS]; aug::decider_limbs55(*c, l); for (int k = 0; k < aug::DEC_LIMBS; k++) want.push_back(cb::f_from_u64<Fe>(l[k])); }
+      want.push_back(cW); want.push_back(cE); want.push_back(in.eW); want.push_back(in.eE);
+      for (const U256w* c : {&in.cmT.x, &in.cmT.y}) { uint64_t l[aug::DEC_LIMBS]; aug::decider_limbs55(*c, l); for (int k = 0; k < aug::DEC_LIMBS; k++) want.push_back(cb::f_from_u64<Fe>(l[k])); }
+      if (want.size() != dc.n_public || dc.n_public != aug::decider_n_public(1)) res |= 16;
+      else for (size_t k = 0; k < want.size(); k++) if (!zd[1 + k].eq(want[k])) res |= 16; }
+    // negatives: the witness generator flags a wrong evaluation and a cross-term commitment other than the one the challenge was derived from
+    { aug::DeciderIn t = in; t.eW = Fe::add(t.eW, Fe::one()); bool b2 = false; dc.witness(b, t, &b2); if (!b2) res |= 32; }
+    { aug::DeciderIn t = in; t.cmT = nn_point(fake1(0x7778)); bool b2 = false; dc.witness(b, t, &b2); if (!b2) res |= 32; }      // (another r: the folded scalars no longer match W')
+    // ... and every public input matters to some row
+    for (uint32_t k = 0; k < dc.n_public; k++) { std::vector<Fe> zz = zd; zz[1 + k] = Fe::add(zz[1 + k], Fe::one()); if (!violated(zz)) res |= 64; }
+    *result = res;
+    return VIMZ_OK;
+  } catch (const std::exception& e) { return vz_fail(nullptr, VIMZ_ERR_INVALID, e.what()); }
+}
 // deterministic TEST setups: the trapdoor is derived from `seed` — anyone who knows the seed can forge.  Not in the product library.
 int vimz_testing_kzg_setup_seeded(vimz_ctx* ctx, const uint8_t* seed, size_t seed_len, size_t n, vimz_bases** srs_out, uint64_t vk_g2_out[16]) {
   if (!ctx || !srs_out || !vk_g2_out || !n || (!seed && seed_len)) return VIMZ_ERR_INVALID;
