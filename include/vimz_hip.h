@@ -478,6 +478,17 @@ int vimz_ivc_fold_segments(vimz_ivc* const* segments, size_t n_segments, const u
  * proof that has just exchanged them with the other ranks); digests == NULL: as above */
 int vimz_ivc_fold_segments_dg(vimz_ivc* const* segments, size_t n_segments, const uint64_t* z0, const uint64_t* step_inputs, size_t nsteps,
                               const uint64_t* digests, vimz_ivc_merged** out, double seconds[3]);
+/* fold_input for a run of rows whose START STATE is not known yet — a rank of a sharded proof: the segments' fold calls begin at once, the rows' digests (what
+ * vimz_ivc_row_digests returns for them) are handed out as soon as the calls' own chain passes have produced them, the caller exchanges digests with the other
+ * ranks, chains over the rows before its own (vimz_ivc_chain_from_digests) and provides the state; every row is hashed once.  _digests blocks; _finish joins the
+ * folds, merges them into ONE object and frees the handle (out == NULL, or no start state given: cancels).  Circuits whose digests depend on the state: refused. */
+typedef struct vimz_ivc_pending vimz_ivc_pending;
+int vimz_ivc_fold_segments_begin(vimz_ivc* const* segs, size_t n_seg, const uint64_t* step_inputs, size_t nsteps, vimz_ivc_pending** out);
+int vimz_ivc_pending_digests(vimz_ivc_pending* p, uint64_t* digests_out);
+int vimz_ivc_pending_start(vimz_ivc_pending* p, const uint64_t* z_start);
+int vimz_ivc_pending_finish(vimz_ivc_pending* p, vimz_ivc_merged** out, double seconds[3]);
+/* rows of a fold call of `nsteps` rows whose Poseidon chains the library would evaluate on the host (its policy, or what vimz_set_head_rows pinned) */
+size_t vimz_head_rows_policy(size_t nsteps);
 /* RecursiveSNARK::verify(pp, num_steps, z0) for the merged object.  result: 0 = accepted; bit 0 / 1 a segment's primary / secondary chain
  * hash; bit 2 primary relaxed relation; bit 3 / 4 primary comm_W / comm_E; bit 5 secondary relation; bit 6 / 7 secondary comm_W / comm_E;
  * bit 10 public entries of a witness vector differ from the instance; bit 11 kept running products (bookkeeping for further merges);

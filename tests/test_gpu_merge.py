@@ -355,3 +355,61 @@ def test_fold_segments_in_one_call_edge_cases(ctx, keys, oracle):
             v.close()
         for c_ in cx[1:]:
             c_.close()
+
+
+def test_a_run_of_rows_begun_before_its_start_state_is_known(ctx, keys, oracle):
+    """vimz_ivc_fold_segments_begin / _pending_digests / _pending_start / _pending_finish — a rank of a sharded proof: the segments' folds begin, the rows'
+    digests come out of the folds' own chain passes (equal to vimz_ivc_row_digests' on the chains' slots), the start state arrives later; the object is the
+    one vimz_ivc_fold_segments makes from that state (same records), also for a run that does not start at z_0; every schedule with and without the library's
+    host-evaluated head batch gives the same object; a run cancelled before its state arrived leaves the provers usable; an unsatisfiable row is reported."""
+    from vimz_amd import hip
+    ck1, ck2 = keys
+    c = Circuit.for_resolution("grayscale", "HD")
+    z0, inputs = step_inputs("grayscale")
+    rows = np.stack(inputs)
+    cx = [ctx, hip.Context(0), hip.Context(0)]
+    ivcs = [hip.IVC(c_, c, ck1, ck2, max_batch=4) for c_ in cx]
+    objs = []
+    try:
+        ref, _ = hip.MergedProof.fold_segments(ivcs, rows, z0); objs.append(ref)
+        assert ref.verify(10, z0) == 0
+        p = hip.MergedProof.fold_segments_begin(ivcs, rows)
+        dg = p.digests()
+        want = np.asarray(ivcs[0].row_digests(rows)).reshape(dg.shape)
+        nz = np.any(want.reshape(len(rows), -1, 4) != 0, axis=2)                 # the slots row_digests fills: the chains' outputs
+        assert (dg[nz] == want[nz]).all() and not np.any(dg[~nz])
+        p.start(z0)
+        m, t = p.finish(); objs.append(m)
+        assert m.verify(10, z0) == 0 and m.verify(9, z0) != 0 and (m.records() == ref.records()).all()
+        # a run in the middle of an image: rows 3..9 from the state after rows 0..2 (what rank 1 of two ranks does)
+        zs = ivcs[0].chain_from_digests(z0, rows[:3], want[:3])
+        z3 = [sum(int(zs[-1][i][k]) << (64 * k) for k in range(4)) for i in range(len(z0))]
+        p = hip.MergedProof.fold_segments_begin(ivcs, rows[3:])
+        assert (p.digests()[nz[3:]] == want[3:][nz[3:]]).all()
+        p.start(z3)
+        m2, _ = p.finish(); objs.append(m2)
+        ref2, _ = hip.MergedProof.fold_segments(ivcs, rows[3:], z3); objs.append(ref2)
+        assert m2.verify(7, z3) == 0 and m2.verify(7, z0) != 0 and (m2.records() == ref2.records()).all()
+        # cancelled before the state arrived: nothing is returned, the provers fold again afterwards
+        p = hip.MergedProof.fold_segments_begin(ivcs, rows)
+        p.digests()
+        p.cancel()
+        m3, _ = hip.MergedProof.fold_segments(ivcs, rows, z0); objs.append(m3)
+        assert (m3.records() == ref.records()).all()
+        # an unsatisfiable row: the error comes back from finish, no object
+        bad = rows.copy(); bad[8, 200, 0] ^= np.uint64(0xFF)
+        p = hip.MergedProof.fold_segments_begin(ivcs, bad)
+        p.start(z0)
+        with pytest.raises(_lib.VimzError) as e:
+            p.finish()
+        assert e.value.code == _lib.ERR_UNSAT
+        m4, _ = hip.MergedProof.fold_segments(ivcs, rows, z0); objs.append(m4)
+        assert m4.verify(10, z0) == 0
+        assert hip.head_rows_policy(7) in (0, 7) and hip.head_rows_policy(1000) == 0
+    finally:
+        for o in objs:
+            o.close()
+        for v in ivcs:
+            v.close()
+        for c_ in cx[1:]:
+            c_.close()

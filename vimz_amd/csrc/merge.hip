@@ -809,4 +809,103 @@ int vimz_ivc_fold_segments_dg(vimz_ivc* const* segs, size_t n_seg, const uint64_
   return VIMZ_OK;
 }
 
+
+// ---- fold_input for a run of rows whose START STATE is not known yet: a rank of a sharded proof (vimz_amd/distributed.py::prove_sharded) ----------------
+// The rank's state follows from the digests of the rows of the ranks before it, which those ranks are hashing right now.  Instead of hashing its own rows
+// for the exchange and then again inside its fold, the rank BEGINS its fold: the segments' calls start at once (inputs uploaded, the row-hash chains of their
+// first batches running, with their wires), the rows' digests are handed out the moment those chain passes have produced them (vimz_ivc_pending_digests),
+// the caller exchanges them, chains over the rows before its own and provides the start state (vimz_ivc_pending_start); the segments continue — segment k
+// from segment k−1's end state, as in vimz_ivc_fold_segments — and vimz_ivc_pending_finish joins and merges.  Every row is hashed once on every rank.
+struct vimz_ivc_pending {
+  std::vector<vimz_ivc*> segs; size_t S = 0; std::vector<size_t> lo, hi;
+  size_t nsteps = 0, stride = 0, lz = 0;
+  std::vector<std::unique_ptr<StartLink>> links;      // links[k]: the state segment k starts from (links[0]: the caller's)
+  std::vector<std::thread> th; std::vector<int> rc_fold;
+  std::vector<Fe> digests; std::mutex mu; std::condition_variable cv; size_t delivered = 0; bool failed = false, started = false;
+  double t_all = 0;
+};
+int vimz_ivc_fold_segments_begin(vimz_ivc* const* segs, size_t n_seg, const uint64_t* step_inputs, size_t nsteps, vimz_ivc_pending** out) {
+  if (!segs || !n_seg || !out || !step_inputs || !nsteps) return VIMZ_ERR_INVALID;
+  for (size_t k = 0; k < n_seg; k++) if (!segs[k]) return VIMZ_ERR_INVALID;
+  vimz_ctx* ctx = segs[0]->ctx;
+  for (size_t k = 1; k < n_seg; k++) {
+    if (!same_shapes(segs[0], segs[k])) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_ivc_fold_segments_begin: the segments' IVCs must be of the same circuits and on the same device");
+    for (size_t j = 0; j < k; j++) if (segs[j]->ctx == segs[k]->ctx) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_ivc_fold_segments_begin: every segment needs a context of its own");
+  }
+  const size_t stride = vimz_ivc_digest_stride(segs[0]);
+  if (!stride) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_ivc_fold_segments_begin: this circuit's row digests depend on the IVC state (use vimz_ivc_state_chain and vimz_ivc_fold_segments)");
+  std::unique_ptr<vimz_ivc_pending> P(new vimz_ivc_pending());
+  P->t_all = now_s();
+  const size_t S = std::min(n_seg, nsteps), base = nsteps / S, rem = nsteps % S;
+  P->S = S; P->nsteps = nsteps; P->stride = stride; P->lz = segs[0]->pri->len_z;
+  P->segs.assign(segs, segs + S); P->lo.resize(S); P->hi.resize(S); P->rc_fold.assign(S, VIMZ_OK);
+  for (size_t k = 0, at = 0; k < S; k++) { P->lo[k] = at; at += base + (k < rem ? 1 : 0); P->hi[k] = at; }
+  P->digests.assign(nsteps * stride, Fe::zero());
+  for (size_t k = 0; k < S; k++) P->links.emplace_back(new StartLink());
+  const size_t n_priv = segs[0]->pri->n_priv;
+  std::vector<uint64_t> zero(4 * P->lz, 0);
+  vimz_ivc_pending* q = P.get();
+  for (size_t k = 0; k < S; k++) {
+    const int rc = vimz_ivc_reset(segs[k], zero.data());      // (a placeholder: replaced when the segment's start state arrives)
+    if (rc) { for (size_t j = 0; j < k; j++) { vimz_prover* pj = segs[j]->pri; pj->start_from = pj->end_to = nullptr; pj->on_start = nullptr; pj->on_digests = nullptr; } return rc; }
+    vimz_prover* pk = segs[k]->pri; vimz_ivc* vk = segs[k];
+    pk->start_from = q->links[k].get(); pk->end_to = k + 1 < S ? q->links[k + 1].get() : nullptr;
+    pk->on_start = [vk] { for (uint32_t i = 0; i < vk->c1->len_z; i++) vk->z0[i] = vk->pri->z_cur[i]; };
+    // only the chains' own outputs travel (the other slots of a job row are scratch of earlier batches)
+    const cb::Builder& b = pk->circuit->build->b;
+    pk->on_digests = [q, k, &b](const Fe* jv, size_t n, size_t js) {
+      { std::lock_guard<std::mutex> g(q->mu);
+        for (size_t r = 0; r < n; r++) for (auto& c : b.chains) if (c.phase == 0) for (uint32_t j = c.job_off; j < c.job_off + c.job_cnt; j++) q->digests[(q->lo[k] + r) * js + j] = jv[r * js + j];
+        q->delivered++; }
+      q->cv.notify_all();
+    };
+  }
+  for (size_t k = 0; k < S; k++)
+    P->th.emplace_back([q, k, step_inputs, n_priv] {
+      q->rc_fold[k] = vimz_ivc_fold(q->segs[k], step_inputs + 4 * n_priv * q->lo[k], q->hi[k] - q->lo[k]);
+      if (q->rc_fold[k]) { { std::lock_guard<std::mutex> g(q->mu); q->failed = true; } q->cv.notify_all(); if (k + 1 < q->S) q->links[k + 1]->fail(); }
+    });
+  *out = P.release();
+  return VIMZ_OK;
+}
+// digests_out: nsteps x vimz_ivc_digest_stride elements (what vimz_ivc_row_digests returns for these rows); blocks until every segment's chain pass is done
+int vimz_ivc_pending_digests(vimz_ivc_pending* p, uint64_t* digests_out) {
+  if (!p || !digests_out) return VIMZ_ERR_INVALID;
+  std::unique_lock<std::mutex> g(p->mu);
+  p->cv.wait(g, [&] { return p->delivered == p->S || p->failed; });
+  if (p->delivered != p->S) return vz_fail(p->segs[0]->ctx, VIMZ_ERR_INVALID, "vimz_ivc_pending_digests: a segment's fold failed before its rows were hashed");
+  memcpy(digests_out, p->digests.data(), 32 * p->digests.size());
+  return VIMZ_OK;
+}
+int vimz_ivc_pending_start(vimz_ivc_pending* p, const uint64_t* z_start) {
+  if (!p || !z_start || p->started) return VIMZ_ERR_INVALID;
+  std::vector<Fe> z(p->lz);
+  for (size_t i = 0; i < p->lz; i++) { Fe c; memcpy(c.v, z_start + 4 * i, 32); if (!c.is_reduced()) return vz_fail(p->segs[0]->ctx, VIMZ_ERR_INVALID, "vimz_ivc_pending_start: a state element is not below the modulus"); z[i] = Fe::to_mont(c); }
+  p->started = true;
+  p->links[0]->publish(z.data(), z.size());
+  return VIMZ_OK;
+}
+// joins the segments' folds and merges them into ONE object (out may be nullptr: cancel — also what happens when no start state was ever given); frees p.
+// seconds (optional) = {0, merge, total since begin}.
+int vimz_ivc_pending_finish(vimz_ivc_pending* p, vimz_ivc_merged** out, double seconds[3]) {
+  if (!p) return VIMZ_ERR_INVALID;
+  std::unique_ptr<vimz_ivc_pending> P(p);
+  if (!p->started) p->links[0]->fail();
+  for (auto& t : p->th) t.join();
+  for (size_t k = 0; k < p->S; k++) { vimz_prover* pk = p->segs[k]->pri; pk->start_from = pk->end_to = nullptr; pk->on_start = nullptr; pk->on_digests = nullptr; }
+  vimz_ctx* ctx = p->segs[0]->ctx;
+  int rc = VIMZ_OK;
+  for (size_t k = 0; k < p->S && !rc; k++) if (p->rc_fold[k]) { rc = p->rc_fold[k]; if (p->segs[k]->ctx != ctx) ctx->err = p->segs[k]->ctx->err; }
+  if (rc || !out) return rc ? rc : (p->started ? VIMZ_OK : VIMZ_ERR_INVALID);
+  const double t_m = now_s();
+  vimz_ivc_merged* m = nullptr;
+  if ((rc = vimz_ivc_merged_create(p->segs[0], &m))) return rc;
+  for (size_t k = 1; k < p->S; k++) if ((rc = vimz_ivc_merge(m, p->segs[k]))) { vimz_ivc_merged_free(m); return rc; }
+  if (seconds) { seconds[0] = 0; seconds[1] = now_s() - t_m; seconds[2] = now_s() - p->t_all; }
+  *out = m;
+  return VIMZ_OK;
+}
+// Rows of a fold call of `nsteps` rows whose Poseidon chains the library would evaluate on the host (its policy, or what vimz_set_head_rows pinned)
+size_t vimz_head_rows_policy(size_t nsteps) { return std::min(head_rows_wanted(nsteps), nsteps); }
+
 }  // extern "C"

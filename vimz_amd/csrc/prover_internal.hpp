@@ -183,6 +183,9 @@ struct vimz_prover {
   // host state chain needs the start state does segment k wait for its predecessor's end state (start_from), set it (on_start: the IVC
   // layer's z_0) and hand its own end state on (end_to).  Every row is hashed once; no segment waits for a hash-only pass of another's rows.
   StartLink* start_from = nullptr; StartLink* end_to = nullptr; std::function<void()> on_start;
+  // ... and (a rank of a sharded proof, vimz_ivc_fold_segments_begin) the rows' digests — the job values the state chain reads — are handed to the caller
+  // the moment the call's own chain pass has produced them: the rank exchanges them with the other ranks instead of hashing its rows a second time
+  std::function<void(const Fe* job_values, size_t nsteps, size_t jstride)> on_digests;
   // per fold call: all private inputs, all IVC states and all row hashes resident
   uint32_t *priv_all_d = nullptr, *zs_all_d = nullptr, *job_all_d = nullptr;
   size_t cap_priv_all = 0, cap_zs_all = 0, cap_job_all = 0;
@@ -753,7 +756,7 @@ static int fold_prepare(vimz_prover* p, FoldJob& J, bool start_batch0 = false) {
   for (auto& c : b.chains) (c.phase == 0 ? J.nA : c.phase == 1 ? J.nB : J.nE)++;
   for (auto& f : b.fops) if (f.early) J.early_fops = true;
   struct EndGuard { StartLink* l; ~EndGuard() { if (l) l->fail(); } } end_guard{p->end_to};      // (a call that stops early must not leave its successor waiting)
-  if ((p->start_from || p->end_to) && (J.witnesses || !start_batch0 || J.nE || J.early_fops)) return vz_fail(ctx, VIMZ_ERR_INVALID, "fold: a deferred start state needs the plain witness schedule");
+  if ((p->start_from || p->end_to || p->on_digests) && (J.witnesses || !start_batch0 || J.nE || J.early_fops)) return vz_fail(ctx, VIMZ_ERR_INVALID, "fold: a deferred start state needs the plain witness schedule");
   J.zs.assign((nsteps + 1) * p->len_z, Fe::zero());
   std::vector<Fe>& zs = J.zs;
   for (uint32_t i = 0; i < p->len_z; i++) zs[i] = p->z_cur[i];
@@ -785,7 +788,7 @@ static int fold_prepare(vimz_prover* p, FoldJob& J, bool start_batch0 = false) {
   P_TRY(hipMemsetAsync(p->job_all_d, 0, 32 * nsteps * jstride, s));
   { static const bool dbg_t = getenv("VIMZ_DEBUG_TIMING") != nullptr; if (dbg_t) fprintf(stderr, "[timing] prepare: buffers + upload of the inputs %.2f ms\n", 1e3 * (now_s() - t0)); }
   const bool plain = J.nA && !J.nE && !J.early_fops;           // no ahead-of-time witness pass needed (everything but crop)
-  const bool deferred = p->start_from || p->end_to;      // (vimz_prover: deferred start state — needs the plain schedule: the head batch wants the state at once)
+  const bool deferred = p->start_from || p->end_to || p->on_digests;      // (vimz_prover: deferred start state — needs the plain schedule: the head batch wants the state at once)
   const size_t head = start_batch0 && plain && p->head_eligible && !deferred ? std::min(std::min(head_rows_wanted(nsteps), B), nsteps) : 0;
   p->last_head_rows = head;
   if (head) {
@@ -901,6 +904,7 @@ static int fold_prepare(vimz_prover* p, FoldJob& J, bool start_batch0 = false) {
   P_TRY(hipMemcpyAsync(jobA.data(), p->job_all_d, 32 * nsteps * jstride, hipMemcpyDeviceToHost, s));
   P_TRY(hipStreamSynchronize(s));
   dbg_stamp(p, "fold_prepare: row hashes on the host");
+  if (p->on_digests) p->on_digests(jobA.data(), nsteps, jstride);
   p->phase_s[PH_WITNESS] += now_s() - t0; t0 = now_s();
   if (p->start_from) {      // the state this call starts from: the predecessor segment's end state (it follows from ITS row hashes, ready about now)
     std::vector<Fe> zst;

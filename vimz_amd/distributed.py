@@ -372,6 +372,7 @@ def prove_sharded(ivcs, step_inputs, z0, rank=0, world=1, dist=None, timings=Non
     bounds = segment_bounds(n, world)
     z_start = [int(x) for x in z0]
     my_digests = None
+    pending = None
     if world > 1:
         t0 = time.time()
         stride = ivcs[0].digest_stride() if hasattr(ivcs[0], "digest_stride") else 0
@@ -384,18 +385,40 @@ def prove_sharded(ivcs, step_inputs, z0, rank=0, world=1, dist=None, timings=Non
             lo, hi = bounds[rank]
             kmax = max(h - l for l, h in bounds)
             mine = np.zeros((kmax, stride, 4), dtype=np.uint64)
-            if hi > lo:
+            # Where the library hashes rows on the GPU anyway (calls it gives no host-evaluated head batch: long calls, ranks with few host cores), the rank
+            # BEGINS its fold now and takes the digests from the folds' own chain passes (MergedProof.fold_segments_begin): its rows are hashed once, and
+            # the exchange, the chain over the other ranks' rows and the wait for them all run under the rank's own Poseidon-chain latency.
+            per_seg = -(-(hi - lo) // max(1, len(ivcs)))
+            use_pending = (hi > lo and hasattr(merged_cls, "fold_segments_begin") and all(hasattr(v, "h") for v in ivcs)
+                           and os.environ.get("VIMZ_SHARD_NO_PENDING") is None and _head_policy(per_seg) == 0)
+            if use_pending:
+                pending = merged_cls.fold_segments_begin(ivcs, step_inputs[lo:hi])
+                try:
+                    if rank == 0:
+                        pending.start(z_start)      # (its state is the proof's z_0: known)
+                    mine[:hi - lo] = pending.digests()
+                except BaseException:
+                    pending.cancel()
+                    raise
+            elif hi > lo:
                 mine[:hi - lo] = np.asarray(ivcs[0].row_digests(step_inputs[lo:hi])).reshape(hi - lo, stride, 4)
                 my_digests = mine[:hi - lo]
             t1 = time.time()
-            allg = [torch.empty(mine.size, dtype=torch.int64) for _ in range(world)]
-            dist.all_gather(allg, torch.from_numpy(mine.view(np.int64).reshape(-1)))
-            t2 = time.time()
-            for r in range(rank):
-                plo, phi = bounds[r]
-                if phi > plo:
-                    dg = allg[r].numpy().view(np.uint64).reshape(kmax, stride, 4)[:phi - plo]
-                    z_start = _ints(ivcs[0].chain_from_digests(z_start, step_inputs[plo:phi], dg)[-1])
+            try:
+                allg = [torch.empty(mine.size, dtype=torch.int64) for _ in range(world)]
+                dist.all_gather(allg, torch.from_numpy(mine.view(np.int64).reshape(-1)))
+                t2 = time.time()
+                for r in range(rank):
+                    plo, phi = bounds[r]
+                    if phi > plo:
+                        dg = allg[r].numpy().view(np.uint64).reshape(kmax, stride, 4)[:phi - plo]
+                        z_start = _ints(ivcs[0].chain_from_digests(z_start, step_inputs[plo:phi], dg)[-1])
+                if pending is not None and rank != 0:
+                    pending.start(z_start)
+            except BaseException:
+                if pending is not None:
+                    pending.cancel()      # (the begun folds must not outlive a failed exchange)
+                raise
             if timings is not None:
                 timings["digests_s"] = timings.get("digests_s", 0.0) + t1 - t0
                 timings["allgather_s"] = timings.get("allgather_s", 0.0) + t2 - t1
@@ -415,7 +438,13 @@ def prove_sharded(ivcs, step_inputs, z0, rank=0, world=1, dist=None, timings=Non
         if timings is not None:
             timings["state_chain_s"] = timings.get("state_chain_s", 0.0) + time.time() - t0
     lo, hi = bounds[rank]
-    proof = fold_segments_merged(ivcs, step_inputs[lo:hi], z_start, timings, merged_cls, digests=my_digests) if hi > lo else None
+    if pending is not None:
+        proof, tp = pending.finish()
+        if timings is not None:
+            timings["merge_s"] = timings.get("merge_s", 0.0) + tp["merge_s"]
+            timings["pending_fold"] = True
+    else:
+        proof = fold_segments_merged(ivcs, step_inputs[lo:hi], z_start, timings, merged_cls, digests=my_digests) if hi > lo else None
     if timings is not None:
         timings["t_ready"] = time.time()
     if world == 1:
@@ -425,6 +454,14 @@ def prove_sharded(ivcs, step_inputs, z0, rank=0, world=1, dist=None, timings=Non
         timings["t_done"] = time.time()
         timings.setdefault("final_fold_s", 0.0)
     return proof
+
+
+def _head_policy(nsteps):
+    try:
+        from . import hip
+        return hip.head_rows_policy(nsteps)
+    except Exception:      # (stand-in provers in the CPU tests: no library)
+        return 1
 
 
 def fold_concurrently(jobs):

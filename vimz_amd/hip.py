@@ -889,6 +889,57 @@ def decider_verify_key(key_words, steps, z0, z_i, words):
     return int(res.value)
 
 
+class PendingFold:
+    """vimz_ivc_pending: the segments' folds of a run of rows, begun before the state they start from is known (MergedProof.fold_segments_begin)."""
+
+    def __init__(self, merged_cls, ivcs, step_inputs):
+        self.merged_cls, self.vk, self.ctx = merged_cls, ivcs[0], ivcs[0].ctx
+        lib = self.ctx.lib
+        vp = C.c_void_p
+        lib.vimz_ivc_fold_segments_begin.argtypes = [vp, C.c_size_t, vp, C.c_size_t, C.POINTER(vp)]
+        lib.vimz_ivc_pending_digests.argtypes = [vp, vp]
+        lib.vimz_ivc_pending_start.argtypes = [vp, vp]
+        lib.vimz_ivc_pending_finish.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_double)]
+        self.rows = np.ascontiguousarray(_u64(step_inputs).reshape(-1, self.vk.circuit.n_priv, 4))      # (kept alive: the folds read it until finish)
+        arr = (vp * len(ivcs))(*[v.h for v in ivcs])
+        h = vp()
+        self.ctx._chk(lib.vimz_ivc_fold_segments_begin(arr, len(ivcs), _ptr(self.rows), self.rows.shape[0], C.byref(h)))
+        self.h = h
+
+    def digests(self):
+        """(rows, stride, 4) uint64: the rows' digests, as IVC.row_digests returns them.  Blocks until the folds' chain passes have produced them."""
+        stride = self.vk.digest_stride()
+        out = np.zeros((self.rows.shape[0], stride, 4), dtype=np.uint64)
+        self.ctx._chk(self.ctx.lib.vimz_ivc_pending_digests(self.h, _ptr(out)))
+        return out
+
+    def start(self, z_start):
+        self.ctx._chk(self.ctx.lib.vimz_ivc_pending_start(self.h, _ptr(_zlimbs(z_start, self.vk.circuit.len_z))))
+
+    def finish(self):
+        """Joins the folds and merges: (MergedProof, {"merge_s", "total_s"})."""
+        h, self.h = self.h, None
+        mh = C.c_void_p()
+        sec = (C.c_double * 3)()
+        self.ctx._chk(self.ctx.lib.vimz_ivc_pending_finish(h, C.byref(mh), sec))
+        m = self.merged_cls.__new__(self.merged_cls)
+        self.merged_cls.__init__(m, _handle=mh, _vk=self.vk)
+        return m, {"state_chain_s": 0.0, "merge_s": sec[1], "total_s": sec[2]}
+
+    def cancel(self):
+        if self.h:
+            h, self.h = self.h, None
+            self.ctx.lib.vimz_ivc_pending_finish(h, None, None)
+
+
+def head_rows_policy(nsteps):
+    """vimz_head_rows_policy: rows of a fold call of nsteps rows whose Poseidon chains the library would evaluate on the host."""
+    lib = L.lib()
+    lib.vimz_head_rows_policy.argtypes = [C.c_size_t]
+    lib.vimz_head_rows_policy.restype = C.c_size_t
+    return int(lib.vimz_head_rows_policy(int(nsteps)))
+
+
 class CycleFoldMerged:
     """vimz_cf_merged: ONE proof object out of the CycleFold proofs of contiguous row segments (vimz_cf_merge).  `first`: the prover of the
     first segment (left unchanged; supplies shapes, keys and context and must stay open)."""
@@ -1120,6 +1171,12 @@ class MergedProof:
         m = cls.__new__(cls)
         cls.__init__(m, _handle=h, _vk=vk)
         return m, {"state_chain_s": sec[0], "merge_s": sec[1], "total_s": sec[2]}
+
+    @classmethod
+    def fold_segments_begin(cls, ivcs, step_inputs):
+        """vimz_ivc_fold_segments_begin: fold_input for a run of rows whose start state is not known yet (a rank of a sharded proof).  Returns a
+        PendingFold: .digests() blocks until the rows are hashed (by the folds' own chain passes), .start(z) provides the state, .finish() -> (MergedProof, seconds)."""
+        return PendingFold(cls, ivcs, step_inputs)
 
     @classmethod
     def load(cls, vk, blob):
