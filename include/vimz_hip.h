@@ -481,7 +481,9 @@ int vimz_ivc_fold_segments_dg(vimz_ivc* const* segments, size_t n_segments, cons
 /* fold_input for a run of rows whose START STATE is not known yet — a rank of a sharded proof: the segments' fold calls begin at once, the rows' digests (what
  * vimz_ivc_row_digests returns for them) are handed out as soon as the calls' own chain passes have produced them, the caller exchanges digests with the other
  * ranks, chains over the rows before its own (vimz_ivc_chain_from_digests) and provides the state; every row is hashed once.  _digests blocks; _finish joins the
- * folds, merges them into ONE object and frees the handle (out == NULL, or no start state given: cancels).  Circuits whose digests depend on the state: refused. */
+ * folds, merges them into ONE object and frees the handle (out == NULL, or no start state given: cancels).  Circuits whose digests depend on the state: refused.
+ * Between _begin and _start the segments hold their contexts (their folds wait for the state inside their calls): call nothing else on those IVCs meanwhile
+ * (vimz_ivc_chain_from_digests is host-only and takes no context: fine). */
 typedef struct vimz_ivc_pending vimz_ivc_pending;
 int vimz_ivc_fold_segments_begin(vimz_ivc* const* segs, size_t n_seg, const uint64_t* step_inputs, size_t nsteps, vimz_ivc_pending** out);
 int vimz_ivc_pending_digests(vimz_ivc_pending* p, uint64_t* digests_out);

@@ -373,9 +373,10 @@ def test_a_run_of_rows_begun_before_its_start_state_is_known(ctx, keys, oracle):
     try:
         ref, _ = hip.MergedProof.fold_segments(ivcs, rows, z0); objs.append(ref)
         assert ref.verify(10, z0) == 0
+        want = np.asarray(ivcs[0].row_digests(rows))      # (before the run begins: a prover's context is taken while its fold waits for the start state)
         p = hip.MergedProof.fold_segments_begin(ivcs, rows)
         dg = p.digests()
-        want = np.asarray(ivcs[0].row_digests(rows)).reshape(dg.shape)
+        want = want.reshape(dg.shape)
         nz = np.any(want.reshape(len(rows), -1, 4) != 0, axis=2)                 # the slots row_digests fills: the chains' outputs
         assert (dg[nz] == want[nz]).all() and not np.any(dg[~nz])
         p.start(z0)
