@@ -597,6 +597,28 @@ def test_two_ranks_on_the_gpu_end_in_one_verified_proof_object(oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+def test_ranks_that_begin_their_folds_before_their_start_state_is_known(oracle, world):
+    """The same with the rank-level deferred start forced on (VIMZ_SHARD_PENDING=1, every row's witness on the GPU): every rank begins its segments' folds,
+    takes its row digests from the folds' own chain passes (vimz_ivc_fold_segments_begin), exchanges them, chains over the rows before its own and provides the
+    start state; ONE verified object for (9 steps, z0), oracle-side replay of its records included."""
+    from tests._oracle import T_HASH
+    from tests.test_circuits import step_inputs
+    os.environ["VIMZ_SHARD_PENDING"] = "1"; os.environ["VIMZ_HEAD_ROWS"] = "0"      # (inherited by the spawned ranks)
+    try:
+        ok9, ok8, state, segments, transports, replay = _run_gpu_sharded(world, True)
+    finally:
+        os.environ.pop("VIMZ_SHARD_PENDING", None); os.environ.pop("VIMZ_HEAD_ROWS", None)
+    z0, inputs = step_inputs("hash")
+    z = list(z0)
+    for i in range(9):
+        ok, z = oracle.step_eval(T_HASH, z, inputs[i])
+    assert ok9 == 0 and ok8 != 0 and state == ([int(x) for x in z0], z, 9)
+    failed, n, kinds = replay
+    assert failed == [] and n == 9 and kinds.count("L") == segments      # the oracle-side verifier accepts the tree the ranks built
+
+
+@pytest.mark.gpu
 def test_four_ranks_on_the_gpu_fold_their_proofs_up_a_tree(oracle):
     """world_size 4 (four processes on the one GPU): 4 x 2 IVC segments; rank 1 -> 0 and 3 -> 2 side by side, then 2 -> 0, every
     hand-over by HIP IPC.  The product's verifier accepts the ONE object for (9 steps, z0) only; the oracle-side verifier

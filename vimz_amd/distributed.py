@@ -389,8 +389,11 @@ def prove_sharded(ivcs, step_inputs, z0, rank=0, world=1, dist=None, timings=Non
             # BEGINS its fold now and takes the digests from the folds' own chain passes (MergedProof.fold_segments_begin): its rows are hashed once, and
             # the exchange, the chain over the other ranks' rows and the wait for them all run under the rank's own Poseidon-chain latency.
             per_seg = -(-(hi - lo) // max(1, len(ivcs)))
+            # ... only where every rank has a GPU of its own: with two processes on ONE GPU (four hardware queues each) the begun folds' copies and chain passes
+            # queue behind the other process's kernels — digests after 18 ms instead of 5, 750 against 947 steps/s for 2 x 256 rows (profiles/r05_pending_ab.txt)
             use_pending = (hi > lo and hasattr(merged_cls, "fold_segments_begin") and all(hasattr(v, "h") for v in ivcs)
-                           and os.environ.get("VIMZ_SHARD_NO_PENDING") is None and _head_policy(per_seg) == 0)
+                           and os.environ.get("VIMZ_SHARD_NO_PENDING") is None and _head_policy(per_seg) == 0
+                           and (os.environ.get("VIMZ_SHARD_PENDING") == "1" or _own_gpu_per_rank()))
             if use_pending:
                 pending = merged_cls.fold_segments_begin(ivcs, step_inputs[lo:hi])
                 try:
@@ -454,6 +457,14 @@ def prove_sharded(ivcs, step_inputs, z0, rank=0, world=1, dist=None, timings=Non
         timings["t_done"] = time.time()
         timings.setdefault("final_fold_s", 0.0)
     return proof
+
+
+def _own_gpu_per_rank():
+    try:
+        from . import _lib
+        return _lib.default_hw_queues() == 8      # (its rule: at most one rank per visible device)
+    except Exception:
+        return False
 
 
 def _head_policy(nsteps):
