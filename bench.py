@@ -629,7 +629,7 @@ def main():
     ap.add_argument("--steps", type=int, default=256)
     ap.add_argument("--repeats", type=int, default=7, help="timed passes of exactly --steps rows each (ivc mode); `value` is the median pass")
     ap.add_argument("--warmup", type=int, default=150,
-                    help="untimed rows proven first, the same way (default 150: calls of more than 48 rows per segment take the library's long-call "
+                    help="untimed rows proven first, the same way (default 150: proofs of more than 28 rows take the library's long-call "
                          "schedule - no host-evaluated head batch - and a 32-row warm-up left that path's first use inside the timed region)")
     ap.add_argument("--transformation", default="contrast")
     ap.add_argument("--resolution", default="HD")

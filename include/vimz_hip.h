@@ -70,7 +70,7 @@ int vimz_sync(vimz_ctx* ctx);
 int vimz_trace_marker(vimz_ctx* ctx, int id);
 /* Rows of a short fold call whose Poseidon chains are evaluated on the host (the "head batch"; the proof is bit-identical either way): rows >= 0 pins
  * the number for every later call of this process (0: every row's witness entirely on the GPU), -1 restores the library's policy (24 for calls of at
- * most 48 rows on six or more host cores, else 0).  Returns the previous setting. */
+ * most 24 rows — for the segments of one proof: proofs of at most 28 rows in all — on six or more host cores, else 0).  Returns the previous setting. */
 long vimz_set_head_rows(long rows);
 /* A fingerprint of the host a benchmark line was measured on: out[0] = µs per Poseidon permutation (t = 9) on one host core, out[1] = µs per
  * empty kernel launch + stream synchronise (median of 200), out[2] = host cores this process may use, out[3] = µs per event record + synchronise. */
@@ -491,6 +491,8 @@ int vimz_ivc_pending_start(vimz_ivc_pending* p, const uint64_t* z_start);
 int vimz_ivc_pending_finish(vimz_ivc_pending* p, vimz_ivc_merged** out, double seconds[3]);
 /* rows of a fold call of `nsteps` rows whose Poseidon chains the library would evaluate on the host (its policy, or what vimz_set_head_rows pinned) */
 size_t vimz_head_rows_policy(size_t nsteps);
+/* the same for a proof of `nsteps` rows made as concurrent segments (vimz_ivc_fold_segments): non-zero while its segments take head batches */
+size_t vimz_head_rows_policy_segments(size_t nsteps);
 /* RecursiveSNARK::verify(pp, num_steps, z0) for the merged object.  result: 0 = accepted; bit 0 / 1 a segment's primary / secondary chain
  * hash; bit 2 primary relaxed relation; bit 3 / 4 primary comm_W / comm_E; bit 5 secondary relation; bit 6 / 7 secondary comm_W / comm_E;
  * bit 10 public entries of a witness vector differ from the instance; bit 11 kept running products (bookkeeping for further merges);

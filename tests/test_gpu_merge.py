@@ -406,7 +406,7 @@ def test_a_run_of_rows_begun_before_its_start_state_is_known(ctx, keys, oracle):
         assert e.value.code == _lib.ERR_UNSAT
         m4, _ = hip.MergedProof.fold_segments(ivcs, rows, z0); objs.append(m4)
         assert m4.verify(10, z0) == 0
-        assert hip.head_rows_policy(7) in (0, 7) and hip.head_rows_policy(1000) == 0
+        assert hip.head_rows_policy(7) in (0, 7) and hip.head_rows_policy(1000) == 0 and hip.head_rows_policy(100, segments=True) == 0
     finally:
         for o in objs:
             o.close()

@@ -717,6 +717,9 @@ int vimz_ivc_fold_segments_dg(vimz_ivc* const* segs, size_t n_seg, const uint64_
   std::vector<std::vector<uint64_t>> dig(S);
   std::vector<std::thread> th_dig, th_fold;
   bool pre_mode = stride && S > 1 && getenv("VIMZ_DEBUG_NO_HEAD_PRECOMPUTE") == nullptr;      // (also with the caller's digests: the folds then start a pool round apart instead of together after three)
+  const bool too_long_for_head = nsteps > HEAD_JOB_MAX;
+  for (size_t k = 0; k < S; k++) segs[k]->pri->suppress_head = too_long_for_head;      // (cleared after the folds)
+  if (too_long_for_head) pre_mode = false;      // (the segments share ONE host pool: past four rounds of it the GPU's chain pass is the shorter wait — profiles/r05_head_crossover.txt)
   for (size_t k = 0; k < S && pre_mode; k++) pre_mode = head_takes_whole_call(segs[k]->pri, hi[k] - lo[k]) && !segs[k]->broken;
   if (stride && S > 1 && !digests && !pre_mode && getenv("VIMZ_DEBUG_NO_DEFERRED_START") != nullptr)
     for (size_t k = 0; k + 1 < S; k++) {
@@ -796,7 +799,7 @@ int vimz_ivc_fold_segments_dg(vimz_ivc* const* segs, size_t n_seg, const uint64_
     started = k + 1;
   }
   for (auto& t : th_fold) t.join();
-  for (size_t k = 0; k < S; k++) { segs[k]->pri->start_from = nullptr; segs[k]->pri->end_to = nullptr; segs[k]->pri->on_start = nullptr; }
+  for (size_t k = 0; k < S; k++) { segs[k]->pri->start_from = nullptr; segs[k]->pri->end_to = nullptr; segs[k]->pri->on_start = nullptr; segs[k]->pri->suppress_head = false; }
   for (size_t k = 0; k < th_dig.size(); k++) if (th_dig[k].joinable()) th_dig[k].join();
   for (size_t k = 0; k < started && !rc; k++) if (rc_fold[k]) { rc = rc_fold[k]; if (segs[k]->ctx != ctx) ctx->err = segs[k]->ctx->err; }
   if (rc) { if (pre) drop_pre(); return rc; }
@@ -907,5 +910,7 @@ int vimz_ivc_pending_finish(vimz_ivc_pending* p, vimz_ivc_merged** out, double s
 }
 // Rows of a fold call of `nsteps` rows whose Poseidon chains the library would evaluate on the host (its policy, or what vimz_set_head_rows pinned)
 size_t vimz_head_rows_policy(size_t nsteps) { return std::min(head_rows_wanted(nsteps), nsteps); }
+// ... and for a proof of `nsteps` rows made as concurrent segments (vimz_ivc_fold_segments): non-zero while the segments take head batches
+size_t vimz_head_rows_policy_segments(size_t nsteps) { return nsteps <= HEAD_JOB_MAX ? std::min(head_rows_wanted(1), nsteps) : 0; }
 
 }  // extern "C"

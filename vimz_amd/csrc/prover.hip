@@ -477,7 +477,7 @@ static int compute_row_digests(vimz_prover* p, const uint64_t* step_inputs, size
   const size_t jstride = p->n_jobs + p->n_fops;
   std::vector<uint32_t> chainsA;
   for (uint32_t c = 0; c < b.chains.size(); c++) if (b.chains[c].phase == 0) chainsA.push_back(c);
-  if (nsteps <= 96 && p->head_eligible && head_rows_wanted()) {
+  if (nsteps <= 24 && p->head_eligible && head_rows_wanted()) {      // (48 chains: four rounds of the pool, about one chain latency of the GPU; 96 rows until round 4)
     // Short inputs: the row-hash chains on the host's thread pool (0.4 ms per chain of 17 permutations and core) instead of one
     // Poseidon-chain latency of the GPU (≈10 ms whatever the row count) — the start states of a few short row segments that are
     // about to be folded concurrently must not cost as much as folding them.

@@ -186,6 +186,7 @@ struct vimz_prover {
   // ... and (a rank of a sharded proof, vimz_ivc_fold_segments_begin) the rows' digests — the job values the state chain reads — are handed to the caller
   // the moment the call's own chain pass has produced them: the rank exchanges them with the other ranks instead of hashing its rows a second time
   std::function<void(const Fe* job_values, size_t nsteps, size_t jstride)> on_digests;
+  bool suppress_head = false;      // this call is one of several concurrent segments of a proof too long for a head batch (HEAD_JOB_MAX): its rows are hashed on the GPU
   // per fold call: all private inputs, all IVC states and all row hashes resident
   uint32_t *priv_all_d = nullptr, *zs_all_d = nullptr, *job_all_d = nullptr;
   size_t cap_priv_all = 0, cap_zs_all = 0, cap_job_all = 0;
@@ -549,10 +550,16 @@ static inline hipError_t vz_wait_event(hipEvent_t e) { return hipEventSynchroniz
 // GPU-produced first batch is ready after 6 ms; the head's Poseidon work — 1.8 ms per row and core — now only pays where the whole call
 // fits in it on a machine with cores to spare:
 //   a rank's share of the cores below six: no head (two cores, 20 rows: 667-707 steps/s against 441-445 with all rows in the head; 256 rows: 950-1 007 / 925);
-//   otherwise calls of at most 48 rows: 24 head rows (20-row window, 16 cores: 837-899 against 646-664 without); longer calls: none
+//   otherwise lone calls of at most HEAD_CALL_MAX = 24 rows, and the segments of one proof (vimz_ivc_fold_segments) while the proof has at most HEAD_JOB_MAX = 28
+//   rows in all: every row in the head; longer calls / proofs: none.  (Rounds 2-4: calls of at most 48 rows.  Since round 5 the
+//   segments of one proof start together and hash every row once on the GPU — deferred start states, merge.hip — and the crossover moved: three segments of
+//   7 / 8 / 10 / 12 / 14 / 16 rows each run at 950 / 901 / 923 / 952 / 967 / 966 steps/s with a head batch against 852 / 878 / 930 / 972 / 997 / 1 018 without,
+//   profiles/r05_head_crossover.txt)
 //   (256 rows: 1 174-1 176 against 1 087-1 100).  A head shorter than the call AND short (2-8 rows of 10) is the one thing to avoid: the rest
 //   then waits for two chain latencies, the hash-only pass and the batch's own (210-450 steps/s).
 std::atomic<long>& vz_head_rows_override();      // vimz_set_head_rows: -1 = the policy below
+constexpr size_t HEAD_CALL_MAX = 24;      // a lone call: its rows' 2 x 24 chains are four rounds of the 14-worker pool, about one chain latency of the GPU
+constexpr size_t HEAD_JOB_MAX = 28;       // the concurrent segments of ONE proof share that pool: a head batch only while ALL their rows fit four rounds
 static size_t head_rows_wanted(size_t nsteps = 0) {
   static const long env = getenv("VIMZ_HEAD_ROWS") ? atol(getenv("VIMZ_HEAD_ROWS")) : -1;
   const long ov = vz_head_rows_override().load(std::memory_order_relaxed);
@@ -560,7 +567,7 @@ static size_t head_rows_wanted(size_t nsteps = 0) {
   if (env >= 0) return (size_t)env;
   static const bool few_cores = usable_cpus() < 6;
   if (few_cores) return 0;
-  return nsteps == 0 || nsteps <= 48 ? 24 : 0;
+  return nsteps == 0 || nsteps <= HEAD_CALL_MAX ? 24 : 0;
 }
 
 // The IVC's lookahead schedule (ivc.hip) is an option: VIMZ_IVC_LOOKAHEAD=1 (read once).  It takes the large MSM off a
@@ -789,7 +796,7 @@ static int fold_prepare(vimz_prover* p, FoldJob& J, bool start_batch0 = false) {
   { static const bool dbg_t = getenv("VIMZ_DEBUG_TIMING") != nullptr; if (dbg_t) fprintf(stderr, "[timing] prepare: buffers + upload of the inputs %.2f ms\n", 1e3 * (now_s() - t0)); }
   const bool plain = J.nA && !J.nE && !J.early_fops;           // no ahead-of-time witness pass needed (everything but crop)
   const bool deferred = p->start_from || p->end_to || p->on_digests;      // (vimz_prover: deferred start state — needs the plain schedule: the head batch wants the state at once)
-  const size_t head = start_batch0 && plain && p->head_eligible && !deferred ? std::min(std::min(head_rows_wanted(nsteps), B), nsteps) : 0;
+  const size_t head = start_batch0 && plain && p->head_eligible && !deferred && !p->suppress_head ? std::min(std::min(head_rows_wanted(nsteps), B), nsteps) : 0;
   p->last_head_rows = head;
   if (head) {
     J.head = true;

@@ -388,11 +388,10 @@ def prove_sharded(ivcs, step_inputs, z0, rank=0, world=1, dist=None, timings=Non
             # Where the library hashes rows on the GPU anyway (calls it gives no host-evaluated head batch: long calls, ranks with few host cores), the rank
             # BEGINS its fold now and takes the digests from the folds' own chain passes (MergedProof.fold_segments_begin): its rows are hashed once, and
             # the exchange, the chain over the other ranks' rows and the wait for them all run under the rank's own Poseidon-chain latency.
-            per_seg = -(-(hi - lo) // max(1, len(ivcs)))
             # ... only where every rank has a GPU of its own: with two processes on ONE GPU (four hardware queues each) the begun folds' copies and chain passes
             # queue behind the other process's kernels — digests after 18 ms instead of 5, 750 against 947 steps/s for 2 x 256 rows (profiles/r05_pending_ab.txt)
             use_pending = (hi > lo and hasattr(merged_cls, "fold_segments_begin") and all(hasattr(v, "h") for v in ivcs)
-                           and os.environ.get("VIMZ_SHARD_NO_PENDING") is None and _head_policy(per_seg) == 0
+                           and os.environ.get("VIMZ_SHARD_NO_PENDING") is None and _head_policy(hi - lo) == 0
                            and (os.environ.get("VIMZ_SHARD_PENDING") == "1" or _own_gpu_per_rank()))
             if use_pending:
                 pending = merged_cls.fold_segments_begin(ivcs, step_inputs[lo:hi])
@@ -470,7 +469,7 @@ def _own_gpu_per_rank():
 def _head_policy(nsteps):
     try:
         from . import hip
-        return hip.head_rows_policy(nsteps)
+        return hip.head_rows_policy(nsteps, segments=True)
     except Exception:      # (stand-in provers in the CPU tests: no library)
         return 1
 

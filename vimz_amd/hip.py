@@ -932,12 +932,14 @@ class PendingFold:
             self.ctx.lib.vimz_ivc_pending_finish(h, None, None)
 
 
-def head_rows_policy(nsteps):
-    """vimz_head_rows_policy: rows of a fold call of nsteps rows whose Poseidon chains the library would evaluate on the host."""
+def head_rows_policy(nsteps, segments=False):
+    """vimz_head_rows_policy(_segments): rows of a lone fold call of nsteps rows (segments=True: of a proof of nsteps rows made as concurrent segments) whose
+    Poseidon chains the library would evaluate on the host."""
     lib = L.lib()
-    lib.vimz_head_rows_policy.argtypes = [C.c_size_t]
-    lib.vimz_head_rows_policy.restype = C.c_size_t
-    return int(lib.vimz_head_rows_policy(int(nsteps)))
+    fn = lib.vimz_head_rows_policy_segments if segments else lib.vimz_head_rows_policy
+    fn.argtypes = [C.c_size_t]
+    fn.restype = C.c_size_t
+    return int(fn(int(nsteps)))
 
 
 class CycleFoldMerged:
