@@ -439,6 +439,11 @@ int vimz_decider_info(const vimz_decider* d, uint64_t info[8]);
  * gamma, delta (G2: x.c0, x.c1, y.c0, y.c1), the number of IC points, the IC points, KZG G_1 (G1), G_2, VK (G2); returns the byte size (copies
  * when cap suffices) */
 int64_t vimz_decider_vk(const vimz_decider* d, void* buf, size_t cap);
+/* The key pair at rest (bytes; layout: vimz_amd/csrc/groth16.hip): a set-up made once per circuit, or keys made elsewhere — a ceremony's, converted to this
+ * layout: the library then never sees a trapdoor.  _save returns the byte size (copies when cap suffices); _load checks sizes, the public-parameter hash and the
+ * verifying part's points, and takes the queries as they are (a loaded key is trusted like any common reference string). */
+int64_t vimz_decider_key_save(vimz_decider* d, void* buf, size_t cap);
+int vimz_decider_key_load(vimz_cf* prover, const void* buf, size_t len, vimz_decider** out);
 /* Decider::prove for the IVC proof `ivc` holds (same shapes and keys as the decider's prover; left unchanged; at least one step): final fold, KZG
  * openings, Groth16 proof.  words_out: the 25 calldata words (vimz_amd/calldata.py names them), public_out: the info[2] public inputs; canonical,
  * 4 little-endian limbs each.  VIMZ_ERR_UNSAT when the proof does not satisfy the decider's statement.

@@ -91,6 +91,22 @@ def _prove_and_check(ctx, oracle, op, n_srs, steps, z0, inputs, t_oracle=None, f
         words2, pub2, _ = dec.prove()
         assert pub2 == pub and words2[:9] == words[:9] and words2[17:] == words[17:] and words2[9:17] != words[9:17]
         assert dec.verify(d["steps"], d["z0"], d["z_i"], words2) == 0
+        if full_negative:      # the key pair at rest: saved, loaded into a decider of its own (no trapdoor involved), which proves under the same verifying key
+            blob = dec.save_key()
+            dec3 = hip.Decider.load_key(cf, blob)
+            try:
+                assert dec3.key_words().tolist() == dec.key_words().tolist() and dec3.info() == info
+                words3, pub3, _ = dec3.prove()
+                assert pub3 == pub and dec.verify(d["steps"], d["z0"], d["z_i"], words3) == 0 and dec3.verify(d["steps"], d["z0"], d["z_i"], words) == 0
+                assert nd.verify(key, d["steps"], d["z0"], d["z_i"], words3) == (True, "ok")
+            finally:
+                dec3.close()
+            for bad in (blob[:-8], np.concatenate([blob[:8] ^ np.uint8(1), blob[8:]])):      # wrong length, wrong magic
+                with pytest.raises(_lib.VimzError):
+                    hip.Decider.load_key(cf, bad)
+            b2 = blob.copy(); b2[8 * 6] ^= 1                                         # another public-parameter hash
+            with pytest.raises(_lib.VimzError):
+                hip.Decider.load_key(cf, b2)
         return info, d["seconds"], dec.setup_seconds
     finally:
         if dec is not None:

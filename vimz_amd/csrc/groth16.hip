@@ -201,12 +201,12 @@ hipError_t fixed_base_batch(hipStream_t s, const std::vector<Fe>& sc, const Affi
   return e;
 }
 // device std-form G1 points -> a commitment key in the MSM's resident form
-int bases_from_device(vimz_ctx* ctx, const G1Aff* d_pts, size_t n, vimz_bases** out) {
+int bases_from_device(vimz_ctx* ctx, const G1Aff* d_pts, size_t n, vimz_bases** out, int canonical = 0) {
   vimz_bases* b = new vimz_bases(); b->curve = VIMZ_CURVE_BN254_G1; b->n = n; b->d = nullptr;
   if (n) {
     hipError_t e = hipMalloc(&b->d, 4 * (size_t)AFFINE_WORDS * n);
     if (e != hipSuccess) { delete b; return vz_fail(ctx, VIMZ_ERR_HIP, "decider: hipMalloc(query)", e); }
-    launch_points_to_internal<Fq>(ctx->stream, (const uint32_t*)d_pts, 0, b->d, n);
+    launch_points_to_internal<Fq>(ctx->stream, (const uint32_t*)d_pts, canonical, b->d, n);
     e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) { hipFree(b->d); delete b; return vz_fail(ctx, VIMZ_ERR_HIP, "decider: query conversion", e); }
   }
@@ -638,6 +638,108 @@ int64_t vimz_decider_vk(const vimz_decider* d, void* buf, size_t cap) {
   const size_t bytes = 8 * w.w.size();
   if (buf && cap >= bytes) memcpy(buf, w.w.data(), bytes);
   return (int64_t)bytes;
+}
+
+// ---- the key at rest: vimz_decider_key_save / _load -------------------------------------------------------------------------------------------------------
+// A Groth16 key pair for the decider circuit as bytes, so that a set-up is made ONCE per circuit and shape (0.4 s instead of 0.8 s per run at contrast HD) and —
+// the point of ADVICE r4 — so that keys made ELSEWHERE (a ceremony's, converted to this layout) can be used: the library then never sees a trapdoor.
+// Layout (little-endian u64 words; curve points canonical, G1 (x, y), G2 (x.c0, x.c1, y.c0, y.c1)): magic, m, n_pub, n_c, n, len_z, pp_hash (4), KZG [tau]G2 (16),
+// alpha1, beta1, delta1 (8 each), beta2, gamma2, delta2 (16 each), IC (8 x (n_pub + 1)), then the queries a (8 m), b1 (8 m), l (8 (m - n_pub - 1)), h (8 (n - 1)), b2 (16 m).
+// A loaded key is TRUSTED like any common reference string: its points are range- and curve-checked for the verifying part, the queries are taken as they are
+// (a wrong query makes proofs that do not verify, nothing worse).
+static const uint64_t G16_KEY_MAGIC = 0x3159454b36314756ull;      // "VG16KEY1"
+int64_t vimz_decider_key_save(vimz_decider* d, void* buf, size_t cap) {
+  if (!d) return VIMZ_ERR_INVALID;
+  const G16Key& K = d->key; vimz_ctx* ctx = d->ctx;
+  const size_t nq[4] = {K.m, K.m, (size_t)K.m - K.n_pub - 1, (size_t)K.n - 1};
+  const size_t words = 6 + 4 + 16 + 24 + 48 + 8 * (size_t)(K.n_pub + 1) + 8 * (nq[0] + nq[1] + nq[2] + nq[3]) + 16 * (size_t)K.m;
+  if (!buf || cap < 8 * words) return (int64_t)(8 * words);
+  uint64_t* w = (uint64_t*)buf; size_t pos = 0;
+  w[pos++] = G16_KEY_MAGIC; w[pos++] = K.m; w[pos++] = K.n_pub; w[pos++] = K.n_c; w[pos++] = K.n; w[pos++] = d->circ.len_z;
+  { const Fe c = Fe::from_mont(d->vk->c1->digest); memcpy(w + pos, c.v, 32); pos += 4; }
+  put_g2(w + pos, d->kzg_vk); pos += 16;
+  for (const G1Aff* p : {&K.alpha1, &K.beta1, &K.delta1}) { put_fq(w + pos, p->x); put_fq(w + pos + 4, p->y); pos += 8; }
+  for (const G2PAff* p : {&K.beta2, &K.gamma2, &K.delta2}) { put_g2(w + pos, *p); pos += 16; }
+  for (auto& p : K.ic) { put_fq(w + pos, p.x); put_fq(w + pos + 4, p.y); pos += 8; }
+  std::lock_guard<std::mutex> g(ctx->mu);
+  P_TRY(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  const vimz_bases* qs[4] = {K.a_q, K.b1_q, K.l_q, K.h_q};
+  uint32_t* tmp = nullptr;
+  P_TRY(hipMalloc((void**)&tmp, 64 * (size_t)std::max<size_t>(K.m, K.n)));
+  struct FreeTmp { uint32_t* q; ~FreeTmp() { hipFree(q); } } ft{tmp};
+  for (int q = 0; q < 4; q++) {
+    if (nq[q]) {
+      launch_points_from_internal<Fq>(s, qs[q]->d, 1, tmp, nq[q]);
+      P_TRY(hipGetLastError());
+      P_TRY(hipMemcpyAsync(w + pos, tmp, 64 * nq[q], hipMemcpyDeviceToHost, s));
+      P_TRY(hipStreamSynchronize(s));
+    }
+    pos += 8 * nq[q];
+  }
+  std::vector<G2PAff> b2(K.m);
+  P_TRY(hipMemcpyAsync(b2.data(), K.b2_q, sizeof(G2PAff) * (size_t)K.m, hipMemcpyDeviceToHost, s));
+  P_TRY(hipStreamSynchronize(s));
+  for (uint32_t i = 0; i < K.m; i++) { put_g2(w + pos, b2[i]); pos += 16; }
+  return pos == words ? (int64_t)(8 * words) : (int64_t)VIMZ_ERR_INVALID;
+}
+// prover: as for vimz_decider_setup (shapes, keys, context).  The key must be for exactly this prover's circuits (sizes and public-parameter hash are checked).
+int vimz_decider_key_load(vimz_cf* v, const void* buf, size_t len, vimz_decider** out) {
+  if (!v || !buf || !out || (len & 7)) return VIMZ_ERR_INVALID;
+  vimz_ctx* ctx = v->ctx;
+  const uint64_t* w = (const uint64_t*)buf; const size_t nwords = len / 8;
+  if (nwords < 6 + 4 + 16 + 24 + 48 || w[0] != G16_KEY_MAGIC) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_decider_key_load: not a decider key");
+  std::unique_ptr<vimz_decider> d(new vimz_decider());
+  d->vk = v; d->ctx = ctx;
+  try { d->circ.finish(v->circ->build->b, v->c1->len_z); } catch (const std::exception& e) { return vz_fail(ctx, VIMZ_ERR_INVALID, e.what()); }
+  G16Key& K = d->key;
+  const cb::BuilderT<Fe>& b = d->circ.b;
+  K.m = b.n_wires; K.n_pub = d->circ.n_public; K.n_c = b.n_constraints();
+  K.n = 1; K.logn = 0;
+  while (K.n < K.n_c + K.n_pub + 1) { K.n <<= 1; K.logn++; }
+  size_t pos = 1;
+  if (w[pos] != K.m || w[pos + 1] != K.n_pub || w[pos + 2] != K.n_c || w[pos + 3] != K.n || w[pos + 4] != d->circ.len_z)
+    return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_decider_key_load: the key is for a decider circuit of other sizes");
+  pos += 5;
+  { Fe c; memcpy(c.v, w + pos, 32); if (!c.is_reduced() || !Fe::to_mont(c).eq(v->c1->digest)) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_decider_key_load: the key is for other circuits (public-parameter hash)"); pos += 4; }
+  const size_t nq[4] = {K.m, K.m, (size_t)K.m - K.n_pub - 1, (size_t)K.n - 1};
+  const size_t words = 6 + 4 + 16 + 24 + 48 + 8 * (size_t)(K.n_pub + 1) + 8 * (nq[0] + nq[1] + nq[2] + nq[3]) + 16 * (size_t)K.m;
+  if (nwords != words) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_decider_key_load: wrong length");
+  using vz::pairing::g1_on_curve; using vz::pairing::g2_in_subgroup;
+  if (!get_g2(w + pos, &d->kzg_vk) || !g2_on_curve(d->kzg_vk) || !g2_in_subgroup(d->kzg_vk)) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_decider_key_load: KZG verifying key"); pos += 16;
+  for (G1Aff* p : {&K.alpha1, &K.beta1, &K.delta1}) { if (!get_g1(w + pos, p) || !g1_on_curve(*p)) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_decider_key_load: a G1 key point"); pos += 8; }
+  for (G2PAff* p : {&K.beta2, &K.gamma2, &K.delta2}) { if (!get_g2(w + pos, p) || !g2_on_curve(*p) || !g2_in_subgroup(*p)) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_decider_key_load: a G2 key point"); pos += 16; }
+  K.ic.resize(K.n_pub + 1);
+  for (auto& p : K.ic) { if (!get_g1(w + pos, &p) || !g1_on_curve(p)) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_decider_key_load: an IC point"); pos += 8; }
+  // domain constants (as in the set-up)
+  K.omega = fr_root_of_unity(K.logn); K.omega_inv = Fe::pow_pm2(K.omega);
+  K.n_inv = Fe::pow_pm2(cb::f_from_u64<Fe>(K.n));
+  K.coset = cb::f_from_u64<Fe>(5); K.coset_inv = Fe::pow_pm2(K.coset);
+  K.zinv = Fe::pow_pm2(Fe::sub(fr_pow_u64(K.coset, K.n), Fe::one()));
+  std::lock_guard<std::mutex> g(ctx->mu);
+  P_TRY(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  uint32_t* tmp = nullptr;
+  P_TRY(hipMalloc((void**)&tmp, 64 * (size_t)std::max<size_t>(K.m, K.n)));
+  struct FreeTmp { uint32_t* q; ~FreeTmp() { hipFree(q); } } ft{tmp};
+  vimz_bases** qs[4] = {&K.a_q, &K.b1_q, &K.l_q, &K.h_q};
+  for (int q = 0; q < 4; q++) {
+    if (nq[q]) { P_TRY(hipMemcpyAsync(tmp, w + pos, 64 * nq[q], hipMemcpyHostToDevice, s)); P_TRY(hipStreamSynchronize(s)); }
+    const int rc = bases_from_device(ctx, (const G1Aff*)tmp, nq[q], qs[q], 1);
+    if (rc) return rc;
+    pos += 8 * nq[q];
+  }
+  { std::vector<G2PAff> b2(K.m);
+    for (uint32_t i = 0; i < K.m; i++) { if (!get_g2(w + pos, &b2[i])) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_decider_key_load: a G2 query coordinate is not below the modulus"); pos += 16; }
+    P_TRY(hipMalloc((void**)&K.b2_q, sizeof(G2PAff) * (size_t)K.m));
+    P_TRY(hipMemcpy(K.b2_q, b2.data(), sizeof(G2PAff) * (size_t)K.m, hipMemcpyHostToDevice)); }
+  P_TRY(hipMalloc((void**)&K.tw, 32 * (size_t)std::max<uint32_t>(K.n / 2, 1))); P_TRY(hipMalloc((void**)&K.tw_inv, 32 * (size_t)std::max<uint32_t>(K.n / 2, 1)));
+  { Fr tw, twi; memcpy(tw.v, K.omega.v, 32); memcpy(twi.v, K.omega_inv.v, 32);
+    hipLaunchKernelGGL(k_pow_table, dim3((K.n / 2 + 255) / 256), dim3(256), 0, s, K.tw, (size_t)K.n / 2, tw);
+    hipLaunchKernelGGL(k_pow_table, dim3((K.n / 2 + 255) / 256), dim3(256), 0, s, K.tw_inv, (size_t)K.n / 2, twi);
+    P_TRY(hipGetLastError()); P_TRY(hipStreamSynchronize(s)); }
+  *out = d.release();
+  return VIMZ_OK;
 }
 
 // Decider::prove (mod.rs:76-78) for the IVC proof `ivc` holds after i >= 1 steps (left unchanged): the final fold U_{i+1} = NIFS(U_i, u_i) on the GPU

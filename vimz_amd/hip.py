@@ -790,6 +790,43 @@ class Decider:
             self.ctx.lib.vimz_decider_free(self.h)
             self.h = None
 
+    def save_key(self):
+        """vimz_decider_key_save: the key pair as bytes (uint8 array; 0.5 GB at contrast HD)."""
+        lib = self.ctx.lib
+        lib.vimz_decider_key_save.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        lib.vimz_decider_key_save.restype = C.c_int64
+        n = lib.vimz_decider_key_save(self.h, None, 0)
+        if n < 0:
+            self.ctx._chk(int(n))
+        buf = np.zeros(n, dtype=np.uint8)
+        got = lib.vimz_decider_key_save(self.h, _ptr(buf), n)
+        if got != n:
+            self.ctx._chk(int(got) if got < 0 else L.ERR_INVALID)
+        return buf
+
+    @classmethod
+    def load_key(cls, prover, blob):
+        """vimz_decider_key_load: a decider over `prover` (a CycleFoldIVC) from a saved — or externally made — key pair; no trapdoor is involved."""
+        d = cls.__new__(cls)
+        d.prover, d.ctx = prover, prover.ctx
+        lib = d.ctx.lib
+        vp = C.c_void_p
+        lib.vimz_decider_key_load.argtypes = [vp, vp, C.c_size_t, C.POINTER(vp)]
+        lib.vimz_decider_free.argtypes = [vp]
+        lib.vimz_decider_free.restype = None
+        lib.vimz_decider_info.argtypes = [vp, vp]
+        lib.vimz_decider_vk.argtypes = [vp, vp, C.c_size_t]
+        lib.vimz_decider_vk.restype = C.c_int64
+        lib.vimz_decider_prove.argtypes = [vp, vp, vp, vp, C.POINTER(C.c_double)]
+        lib.vimz_decider_verify.argtypes = [vp, C.c_uint64, vp, vp, vp, C.POINTER(C.c_uint32)]
+        b = np.ascontiguousarray(blob, dtype=np.uint8)
+        h = vp()
+        d.ctx._chk(lib.vimz_decider_key_load(prover.h, _ptr(b), b.size, C.byref(h)))
+        d.h = h
+        d._kzg_vk = None
+        d.setup_seconds = {"circuit_synthesis": 0.0, "qap_at_trapdoor_host": 0.0, "key_points_gpu": 0.0, "total": 0.0}
+        return d
+
     def info(self):
         a = np.zeros(8, dtype=np.uint64)
         self.ctx._chk(self.ctx.lib.vimz_decider_info(self.h, _ptr(a)))
