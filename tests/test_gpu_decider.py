@@ -128,6 +128,16 @@ def test_decider_at_contrast_hd(ctx, oracle):
     assert info["constraints"] > 1_000_000 and info["domain"] == 1 << 20
 
 
+@pytest.mark.parametrize("op,n_srs", [("grayscale", 1 << 18), ("blur", 1 << 19)])
+def test_decider_at_the_other_state_widths(ctx, oracle, op, n_srs):
+    """The reference's nine contracts come in four state widths (tests/golden/verifier_keys.json: len_z 1, 2, 3, 4 — 38, 40, 42, 44 public inputs);
+    hash and contrast above are 1 and 3, these are 2 (grayscale, as Grayscale/Redact/ResizeVerifier.sol) and 4 (blur, as Blur/SharpnessVerifier.sol)."""
+    from tests.test_circuits import ORC_T
+    z0, inputs = step_inputs(op)
+    info, _, _ = _prove_and_check(ctx, oracle, op, n_srs, 3, z0, inputs, t_oracle=ORC_T[op])
+    assert info["public_inputs"] == {"grayscale": 40, "blur": 44}[op] == len(nd.verifier_keys()[op]["groth16"]["ic"]) - 1
+
+
 def test_decider_refuses_other_shapes_and_a_prover_without_steps(ctx):
     from vimz_amd import hip
     c = Circuit.for_resolution("hash", "HD")
