@@ -27,7 +27,11 @@ namespace cb {
 
 template <class F> inline F f_from_u64(uint64_t v) { F x = F::zero(); x.v[0] = (uint32_t)v; x.v[1] = (uint32_t)(v >> 32); return F::to_mont(x); }
 template <class F> inline F f_from_i64(int64_t v) { return v >= 0 ? f_from_u64<F>((uint64_t)v) : F::neg(f_from_u64<F>((uint64_t)(-v))); }
-template <class F> inline F f_pow2(int k) { F x = F::zero(); x.v[k >> 5] = 1u << (k & 31); return F::to_mont(x); }
+template <class F> inline F f_pow2(int k) {      // 2^k, k < 256 (a table: the builders ask for the same few powers millions of times)
+  struct Table { F v[256]; Table() { for (int i = 0; i < 256; i++) { F x = F::zero(); x.v[i >> 5] = 1u << (i & 31); v[i] = F::to_mont(x); } } };
+  static const Table T;
+  return T.v[k];
+}
 
 template <class Fe> struct TermT { uint32_t w; Fe c; };
 
@@ -51,17 +55,27 @@ struct LCT {
   }
   static LCT axpy(const LCT& a, const Fe& k, const LCT& b) {  // a + k*b
     LCT r; r.t.reserve(a.t.size() + b.t.size());
+    // (sums and differences are nearly all of a builder's calls: k = ±1 needs no multiplication — 56 M of them, 2 of the 3.5 s of building crop_step(HD))
+    const bool k1 = k.eq(Fe::one()), km1 = !k1 && k.eq(Fe::neg(Fe::one()));
+    auto kb = [&](const Fe& c) { return k1 ? c : km1 ? Fe::neg(c) : Fe::mul(c, k); };
     size_t i = 0, j = 0;
     while (i < a.t.size() || j < b.t.size()) {
       if (j >= b.t.size() || (i < a.t.size() && a.t[i].w < b.t[j].w)) r.t.push_back(a.t[i++]);
-      else if (i >= a.t.size() || b.t[j].w < a.t[i].w) { Fe c = Fe::mul(b.t[j].c, k); if (!c.is_zero()) r.t.push_back({b.t[j].w, c}); j++; }
-      else { Fe c = Fe::add(a.t[i].c, Fe::mul(b.t[j].c, k)); if (!c.is_zero()) r.t.push_back({a.t[i].w, c}); i++; j++; }
+      else if (i >= a.t.size() || b.t[j].w < a.t[i].w) { Fe c = kb(b.t[j].c); if (!c.is_zero()) r.t.push_back({b.t[j].w, c}); j++; }
+      else { Fe c = Fe::add(a.t[i].c, kb(b.t[j].c)); if (!c.is_zero()) r.t.push_back({a.t[i].w, c}); i++; j++; }
     }
     return r;
   }
   LCT operator+(const LCT& b) const { return axpy(*this, Fe::one(), b); }
   LCT operator-(const LCT& b) const { return axpy(*this, Fe::neg(Fe::one()), b); }
   LCT add_const(int64_t v) const { return *this + constant_i(v); }
+  // *this += b.  Sums that grow one fresh wire at a time (a multiplexer's products, a decoder's outputs) append — `a = a + b` merged, and copied, the
+  // whole sum for every term: quadratic in the sum's length.  Same terms in the same order either way.
+  void add_in_place(const LCT& b) {
+    if (b.t.empty()) return;
+    if (t.empty() || t.back().w < b.t.front().w) t.insert(t.end(), b.t.begin(), b.t.end());
+    else *this = *this + b;
+  }
 };
 
 typedef Fp<BnFr> Fe;                 // the step circuits' field (the reference compiles them for bn128)

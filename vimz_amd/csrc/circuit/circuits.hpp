@@ -253,7 +253,7 @@ inline std::unique_ptr<CircuitBuild> build_step_circuit(int t, const StepShape& 
         L.enforce(o.lc, xv.lc - k.lc, LC());
         if (!L.counting) dec[L.lane + 1] = o.lc;
       });
-      { LC sum; for (int k = 1; k < W10; k++) sum = sum + dec[k]; dec[0] = LC::constant(Fe::one()) - sum; b.enforce(dec[0], x_lc, LC()); }
+      { LC sum; for (int k = 1; k < W10; k++) sum.add_in_place(dec[k]); dec[0] = LC::constant(Fe::one()) - sum; b.enforce(dec[0], x_lc, LC()); }
       // --- EscalarProduct rows: out[h] = sum_k inp[k+h] * dec[k]   (one constraint per non-constant product)
       std::vector<LC> mux_out(C10);
       for (int h = 0; h < C10; h++) {
@@ -264,7 +264,7 @@ inline std::unique_ptr<CircuitBuild> build_step_circuit(int t, const StepShape& 
           LV k = L.lane_index(0);
           LV dv = L.eq_value(xv, k, L.counting ? LC() : dec[L.lane]);
           LV aux = L.mul(inp, dv);
-          if (!L.counting) mux_out[h] = mux_out[h] + aux.lc;
+          if (!L.counting) mux_out[h].add_in_place(aux.lc);
         });
       }
       // --- CompressorCrop: Num2Bits(24) of every selected value

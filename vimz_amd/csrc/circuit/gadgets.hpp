@@ -249,8 +249,8 @@ struct Gadgets {
     LC r;
     for (int m = 0; m < 8; m++) {
       const int k = 8 * byte_idx + m;
-      if (k == 0) r = r + bit0_lc(d, j);
-      else r = r + LC::wire(bit_wire(d, j, k), fe_pow2(m));
+      if (k == 0) r.add_in_place(bit0_lc(d, j));
+      else r.add_in_place(LC::wire(bit_wire(d, j, k), fe_pow2(m)));
     }
     return r;
   }
