@@ -43,7 +43,7 @@ namespace vz {
 // every bucket is then added into half of the 14 planes: 131 k full additions instead of 32 k, a tenth of the accumulation's work on top — and inside
 // a fold, where the GPU is busy throughout, that costs more than the shorter tail gains: 1 176 against 1 198 steps/s over 256 rows, 936 against 938 in
 // the 20-row window, one chain 829 against 822 (round 5, same box, profiles/r05_reduce_planes.txt).
-struct MsmTuning { int sort_blocks = 0, combine_lane_bits = -1, small_lean = 0, witness_sub = 0, ones_dense = 1, reduce_planes = 0; };
+struct MsmTuning { int sort_blocks = 0, combine_lane_bits = -1, small_lean = 0, witness_sub = 0, ones_dense = 1, reduce_planes = 0, accum_lds_kb = 0; };
 inline const MsmTuning& msm_tuning() {
   static const MsmTuning t = [] {
     MsmTuning r;
@@ -54,6 +54,7 @@ inline const MsmTuning& msm_tuning() {
       if (const char* q = strstr(e, "witness_sub=")) { const int v = atoi(q + 12); if (v >= 2 && v <= MSM_SUB) r.witness_sub = v; }
       if (const char* q = strstr(e, "ones_dense=")) r.ones_dense = atoi(q + 11);
       if (const char* q = strstr(e, "reduce_planes=")) r.reduce_planes = atoi(q + 14);
+      if (const char* q = strstr(e, "accum_lds_kb=")) { const int v = atoi(q + 13); if (v >= 0 && v <= 160) r.accum_lds_kb = v; }
     }
     return r;
   }();
@@ -1065,7 +1066,12 @@ hipError_t msm_launch(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_ba
   VZ_EV(3);
   uint32_t* partial = reinterpret_cast<uint32_t*>(ws.partial);
   const unsigned ga = (unsigned)((max_subs + TB - 1) / TB);
-  hipLaunchKernelGGL(k_accum<F>, dim3(ga), dim3(TB), 0, stream, d_bases, ws.sorted, ws.bucket_off, ws.sub_off, pl.nb,
+  // (accum_lds_kb, an experiment kept as an option: LDS the kernel never touches, so that only 160 / kb of its workgroups fit a CU whatever the number of
+  //  launches in flight and the critical chain's kernels — 180-230 registers a lane — always find room.  Measured zero-sum at two workgroups per CU and 2 %
+  //  worse at one, in the 20-row window, over 256 rows and on one chain: profiles/r05_segments_queues_sweep.txt)
+  const size_t accum_lds = (size_t)msm_tuning().accum_lds_kb * 1024;
+  if (accum_lds > 65536) { static const hipError_t once = hipFuncSetAttribute((const void*)k_accum<F>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); (void)once; }
+  hipLaunchKernelGGL(k_accum<F>, dim3(ga), dim3(TB), accum_lds, stream, d_bases, ws.sorted, ws.bucket_off, ws.sub_off, pl.nb,
                      ws.totals, partial, sub);
   VZ_EV(4);
   const unsigned per_wg = 256u >> lane_bits, nbn = (pl.nb + per_wg - 1) / per_wg;
