@@ -550,7 +550,7 @@ int vimz_ivc_create(vimz_ctx* ctx, const vimz_circuit* step_circuit, const vimz_
   UP2(b2.A.row_ptr, S.A.row_ptr); UP2(b2.A.col, S.A.col); UP2(b2.A.coef, S.A.coef);
   UP2(b2.B.row_ptr, S.B.row_ptr); UP2(b2.B.col, S.B.col); UP2(b2.B.coef, S.B.coef);
   UP2(b2.C.row_ptr, S.C.row_ptr); UP2(b2.C.col, S.C.col); UP2(b2.C.coef, S.C.coef);
-  { const Fq* d = nullptr; UP2(b2.dict, d); S.dict = (const uint32_t*)d; }
+  { const Fq* d = nullptr; const std::vector<Fq> dd = dict_for_device(b2.dict); UP2(dd, d); S.dict = (const uint32_t*)d; }
   {
     std::vector<uint32_t> items;
     const cb::Csr* Ms[3] = {&b2.A, &b2.B, &b2.C};

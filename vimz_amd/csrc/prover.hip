@@ -82,7 +82,7 @@ int vz_prover_create_layout(vimz_ctx* ctx, const vimz_circuit* circuit, const vi
   UP(b.A.row_ptr, p->A.row_ptr); UP(b.A.col, p->A.col); UP(b.A.coef, p->A.coef);
   UP(b.B.row_ptr, p->B.row_ptr); UP(b.B.col, p->B.col); UP(b.B.coef, p->B.coef);
   UP(b.C.row_ptr, p->C.row_ptr); UP(b.C.col, p->C.col); UP(b.C.coef, p->C.coef);
-  { const Fe* d = nullptr; UP(b.dict, d); p->dict = (const uint32_t*)d; }
+  { const Fe* d = nullptr; const std::vector<Fe> dd = dict_for_device(b.dict); UP(dd, d); p->dict = (const uint32_t*)d; }      // (both forms of every coefficient: r1cs_ops.hpp)
   {
     std::vector<uint32_t> items, items_aug;
     const cb::Csr* Ms[3] = {&b.A, &b.B, &b.C};

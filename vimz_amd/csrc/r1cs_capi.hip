@@ -89,8 +89,9 @@ int upload_shape(vimz_ctx* ctx, vimz_r1cs* S, const uint32_t* const rows[3], con
     R_TRY(hipMemcpy(S->long_items, items.data(), 4 * items.size(), hipMemcpyHostToDevice));
   }
   S->ndict = dict.size();
-  R_TRY(hipMalloc((void**)&S->dict, 32 * std::max<size_t>(dict.size(), 1))); S->owned.push_back(S->dict);
-  if (!dict.empty()) R_TRY(hipMemcpy(S->dict, dict.data(), 32 * dict.size(), hipMemcpyHostToDevice));
+  const std::vector<F> dd = dict_for_device(dict);      // (both forms of every coefficient: r1cs_ops.hpp)
+  R_TRY(hipMalloc((void**)&S->dict, 32 * std::max<size_t>(dd.size(), 1))); S->owned.push_back(S->dict);
+  if (!dd.empty()) R_TRY(hipMemcpy(S->dict, dd.data(), 32 * dd.size(), hipMemcpyHostToDevice));
   R_TRY(hipMalloc((void**)&S->scratch, 32 * 6 * std::max<size_t>(nr, 1))); S->owned.push_back(S->scratch);
   return VIMZ_OK;
 }

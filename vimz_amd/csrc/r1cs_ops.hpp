@@ -12,27 +12,56 @@
 #include <algorithm>
 #include <vector>
 #include "vecops.hpp"
+#include "fp29.hpp"
 
 namespace vz {
 
 struct CsrDev { const uint32_t* row_ptr; const uint32_t* col; const uint32_t* coef; };
 
+// The coefficient dictionary as the device holds it: entry i = [c·2^256 mod p | c·2^261 mod p], 8 words each (index 2i and 2i + 1 of an array of field
+// elements).  The second form is the coefficient for the reduced-radix product below: Fp29::mul(c·2^261, z·2^256) = c·z·2^256, the vectors' own form.
+template <class F>
+inline std::vector<F> dict_for_device(const std::vector<F>& dict) {
+  std::vector<F> out(2 * dict.size());
+  for (size_t i = 0; i < dict.size(); i++) { F t = dict[i]; out[2 * i] = t; for (int k = 0; k < 5; k++) t = F::dbl(t); out[2 * i + 1] = t; }
+  return out;
+}
+template <class F> using R29 = Fp29<typename F::Params>;
+// x·2^256 (canonical, 8 words) -> x·2^261 in reduced radix: five modular doublings, then shifts and masks
+template <class F> __device__ __forceinline__ R29<F> r29_of(const F& y) { F t = y; for (int k = 0; k < 5; k++) t = F::dbl(t); return R29<F>::pack(t.v); }
+// a sum of lazily reduced terms back to 8 canonical words
+template <class F> __device__ __forceinline__ F fe_of29(const R29<F>& a) { F r; a.weak_reduce().canon().unpack(r.v); return r; }
+
 constexpr uint32_t SPMV_LONG = 6;    // (matrix,row) items with more terms than this go to the wave-per-item kernel: the short
                                      // kernel's duration is its longest serial row (≈1 µs per dependent gather + multiply)
 
-// acc += c * v, skipping the multiply for the values a fresh witness is made of (0 and 1)
+// acc += c * v, skipping the multiply for the values a fresh witness is made of (0 and 1).  The product runs in the curve code's reduced-radix arithmetic
+// (fp29.hpp: 162 multiply-adds and ~65 other instructions against the 8 x 32-bit CIOS's 585) and the row's sum stays lazily reduced — every term is below
+// 1.5 p, a lane adds at most a few dozen — until fe_of29 (round 5; the vectors keep their 8-word Montgomery form in HBM).
 template <class F>
-__device__ __forceinline__ void spmv_term(F& acc, const uint32_t* __restrict__ dict, uint32_t coef, const uint32_t* __restrict__ z, uint32_t col) {
+__device__ __forceinline__ void spmv_term(R29<F>& acc, const uint32_t* __restrict__ dict, uint32_t coef, const uint32_t* __restrict__ z, uint32_t col) {
   const F v = load_fe<F>(z, col);
   const bool zr = v.is_zero(), on = v.eq(F::one());
   if (__ballot(!zr) == 0ull) return;                 // (wave-uniform tests: per-lane branches around a multiplication are flattened
-  F t = load_fe<F>(dict, coef);                      //  into predicated code that every wave executes in full)
+  F t = load_fe<F>(dict, 2 * (size_t)coef);          //  into predicated code that every wave executes in full)
   // most coefficients are ±1 as well (differences, selections): c·v is then ±v
   const bool cp = t.eq(F::one()), cm = t.eq(F::neg(F::one()));
-  if (__ballot(!(zr || on || cp || cm)) != 0ull) { const F m = F::mul(t, v); if (!(on || cp || cm)) t = m; }
   if (!on && cp) t = v;
   if (!on && cm) t = F::neg(v);
-  if (!zr) acc = F::add(acc, t);
+  R29<F> term = R29<F>::pack(t.v);
+  if (__ballot(!(zr || on || cp || cm)) != 0ull) {
+    const R29<F> m = R29<F>::mul(R29<F>::pack(load_fe<F>(dict, 2 * (size_t)coef + 1).v), R29<F>::pack(v.v));
+    if (!(on || cp || cm)) term = m;
+  }
+  if (!zr) acc = R29<F>::add(acc, term);
+}
+// butterfly step of a row's partial sums: lanes `off` apart exchange and add
+template <class F>
+__device__ __forceinline__ void spmv_exchange_add(R29<F>& acc, int off) {
+  R29<F> o;
+#pragma unroll
+  for (int w = 0; w < 9; w++) o.v[w] = __shfl_xor(acc.v[w], off);
+  acc = R29<F>::add(acc, o);
 }
 
 // x·y where y comes from a FRESH instance — a witness wire or a row of (A,B,C)·z of one step: nineteen in twenty of the step
@@ -63,9 +92,9 @@ __global__ void __launch_bounds__(256) k_spmv3(CsrDev A, CsrDev B, CsrDev C, con
     uint32_t* out = m == 0 ? az : (m == 1 ? bz : cz);
     const uint32_t lo = M.row_ptr[r], hi = M.row_ptr[r + 1];
     if (hi - lo > SPMV_LONG) continue;
-    F acc = F::zero();
+    R29<F> acc = R29<F>::zero();
     for (uint32_t k = lo; k < hi; k++) spmv_term<F>(acc, dict, M.coef[k], z, M.col[k]);
-    store_fe(out, r, acc);
+    store_fe(out, r, fe_of29<F>(acc));
   }
 }
 
@@ -90,17 +119,20 @@ __global__ void __launch_bounds__(256) k_spmv_long(CsrDev A, CsrDev B, CsrDev C,
     const CsrDev M = m == 0 ? A : (m == 1 ? B : C);
     uint32_t lo = 0, hi = 0;
     if (live) { lo = M.row_ptr[r]; hi = M.row_ptr[r + 1]; }
-    F acc = F::zero();
-    for (uint32_t k = lo + l; k < hi; k += step) spmv_term<F>(acc, dict, M.coef[k], z, M.col[k]);
+    R29<F> acc = R29<F>::zero();
+    uint32_t added = 0;
+    for (uint32_t k = lo + l; k < hi; k += step) {
+      spmv_term<F>(acc, dict, M.coef[k], z, M.col[k]);
+      if ((++added & 31u) == 0) acc = acc.weak_reduce();      // (a lane of a very long row: keep the lazy sum far below 2^261)
+    }
+    acc = acc.weak_reduce();                             // below 3 p; six doublings of the bound stay below 2^261 / p = 128
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
       if (quad && off >= 16) continue;                 // (uniform per wave)
-      F o;
-#pragma unroll
-      for (int w = 0; w < 8; w++) o.v[w] = __shfl_xor(acc.v[w], off);
-      acc = F::add(acc, o);
+      spmv_exchange_add<F>(acc, off);
+      if (off == 8) acc = acc.weak_reduce();
     }
-    if (live && l == 0) store_fe(m == 0 ? az : (m == 1 ? bz : cz), r, acc);
+    if (live && l == 0) store_fe(m == 0 ? az : (m == 1 ? bz : cz), r, fe_of29<F>(acc));
   }
 }
 // Host side of the list: items of at most SPMV_MED terms first; returns their number.
@@ -130,11 +162,11 @@ __global__ void __launch_bounds__(256) k_spmv_cross16(CsrDev A, CsrDev B, CsrDev
   const uint32_t g = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, l = threadIdx.x & 15u;
   const bool live = g < nrows;
   const uint32_t r = row0 + (live ? g : 0u);
-  F acc[3];
+  R29<F> acc[3];
 #pragma unroll
   for (int m = 0; m < 3; m++) {
     const CsrDev M = m == 0 ? A : (m == 1 ? B : C);
-    acc[m] = F::zero();
+    acc[m] = R29<F>::zero();
     if (live) {
       const uint32_t lo = M.row_ptr[r], hi = M.row_ptr[r + 1];
       // four terms of this lane at a time: their index loads, then their value / coefficient gathers, are in flight together (one
@@ -145,39 +177,46 @@ __global__ void __launch_bounds__(256) k_spmv_cross16(CsrDev A, CsrDev B, CsrDev
         for (int j = 0; j < 4; j++) { const uint32_t kk = k0 + 16u * j; const bool on = kk < hi; col[j] = on ? M.col[kk] : 0xffffffffu; cf[j] = on ? M.coef[kk] : 0u; }
         F v[4], c[4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) { v[j] = col[j] != 0xffffffffu ? load_fe<F>(z, col[j]) : F::zero(); c[j] = load_fe<F>(dict, cf[j]); }
+        for (int j = 0; j < 4; j++) { v[j] = col[j] != 0xffffffffu ? load_fe<F>(z, col[j]) : F::zero(); c[j] = load_fe<F>(dict, 2 * (size_t)cf[j]); }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
           const bool zr = v[j].is_zero(), on = v[j].eq(F::one());
           if (__ballot(!zr) == 0ull) continue;
           F t = c[j];
           const bool cp = t.eq(F::one()), cm = t.eq(F::neg(F::one()));      // (the verifier circuits' rows are wires with coefficient ±1 almost throughout)
-          if (__ballot(!(zr || on || cp || cm)) != 0ull) { const F mm = F::mul(c[j], v[j]); if (!(on || cp || cm)) t = mm; }
           if (!on && cp) t = v[j];
           if (!on && cm) t = F::neg(v[j]);
-          if (!zr) acc[m] = F::add(acc[m], t);
+          R29<F> term = R29<F>::pack(t.v);
+          if (__ballot(!(zr || on || cp || cm)) != 0ull) {      // (spmv_term's product: the coefficient's second form, reduced radix)
+            const R29<F> mm = R29<F>::mul(R29<F>::pack(load_fe<F>(dict, 2 * (size_t)cf[j] + 1).v), R29<F>::pack(v[j].v));
+            if (!(on || cp || cm)) term = mm;
+          }
+          if (!zr) acc[m] = R29<F>::add(acc[m], term);
         }
+        acc[m] = acc[m].weak_reduce();      // (four terms a round: a 254-term row's lane never holds more than 3 p + 4 · 1.5 p)
       }
     }
   }
 #pragma unroll
   for (int m = 0; m < 3; m++) {
 #pragma unroll
-    for (int off = 8; off >= 1; off >>= 1) {
-      F o;
-#pragma unroll
-      for (int w = 0; w < 8; w++) o.v[w] = __shfl_xor(acc[m].v[w], off);
-      acc[m] = F::add(acc[m], o);
-    }
+    for (int off = 8; off >= 1; off >>= 1) spmv_exchange_add<F>(acc[m], off);      // below 16 · 3 p
+    acc[m] = acc[m].weak_reduce().canon();
   }
   if (!live || l != 0) return;
-  store_fe(az, r, acc[0]); store_fe(bz, r, acc[1]); store_fe(cz, r, acc[2]);
+  F a2, b2, c2;
+  acc[0].unpack(a2.v); acc[1].unpack(b2.v); acc[2].unpack(c2.v);
+  store_fe(az, r, a2); store_fe(bz, r, b2); store_fe(cz, r, c2);
   if (!az1) return;
-  F t = F::mul(load_fe<F>(az1, r), acc[1]);
-  t = F::add(t, F::mul(acc[0], load_fe<F>(bz1, r)));
-  t = F::sub(t, F::mul(u1, acc[2]));
-  t = F::sub(t, mul_fresh(load_fe<F>(cz1, r), u2));
-  store_fe(T, r, t);
+  // T = az1·bz2 + az2·bz1 − u1·cz2 − u2·cz1 with two reductions: the running instance's entries and the scalars moved to the 2^261 form (r29_of), the fresh
+  // products as they stand (canonical, 2^256 form), so that every product comes out in the vectors' 2^256 form
+  typedef R29<F> G;
+  const G t1 = G::mul_add2(r29_of<F>(load_fe<F>(az1, r)), acc[1], acc[0], r29_of<F>(load_fe<F>(bz1, r)));       // < 1.5 p
+  const F c1 = load_fe<F>(cz1, r);
+  G t2;
+  if (u2.eq(F::one())) t2 = G::add(G::mul(r29_of<F>(u1), acc[2]), G::pack(c1.v));                                // the fresh instance's u is one: < 2.5 p
+  else t2 = G::mul_add2(r29_of<F>(u1), acc[2], r29_of<F>(u2), G::pack(c1.v));
+  store_fe(T, r, fe_of29<F>(G::template sub<3>(t1, t2)));
 }
 
 template <class F>

@@ -562,7 +562,7 @@ static __global__ void __launch_bounds__(64) k_wit_fops_lc(WitnessDev P, const u
     const LcTerm T = P.lc_terms[F.a.idx + k];
     const Fr v = load_fe<Fr>(Z, zrow + T.wire);
     if (v.is_zero()) continue;
-    acc = Fr::add(acc, Fr::mul(load_fe<Fr>(P.dict, T.coef), v));
+    acc = Fr::add(acc, Fr::mul(load_fe<Fr>(P.dict, 2 * (size_t)T.coef), v));      // (the dictionary holds two forms per coefficient: r1cs_ops.hpp)
   }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {
