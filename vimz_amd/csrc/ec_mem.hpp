@@ -78,6 +78,12 @@ __device__ __forceinline__ F quad_bcast(const F& v) {
   for (int i = 0; i < 9; i++) r.v[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.v[i], K * 0x55, 0xf, 0xf, true);
   return r;
 }
+// The rare case of a four-lane addition (equal x: doubling or cancellation) is a FUNCTION: inlined, its 3.5 k instructions sat in every one of the dozens of
+// unrolled tree levels of k_msm_small / k_combine / k_reduce (74 k -> 42 k, 73 k -> 35 k, 52 k -> 36 k instructions of code).  Its result goes through a local
+// of the rare branch: handing it `&out.full` put the whole QuadRes — the common path's values — into scratch, 22 % slower (profiles/r05_segments_queues_sweep.txt).
+// With the local: one chain +1.5 %, three segments unchanged.
+template <class F>
+__device__ __noinline__ void quad_add_rare(const XYZZ<F>* A, const XYZZ<F>* B, XYZZ<F>* out) { XYZZ<F> a = *A; add_full(a, *B); *out = a; }
 template <class F>
 __device__ __forceinline__ QuadRes<F> quad_add_compute(const XYZZ<F>* __restrict__ sh, uint32_t ia, uint32_t ib, bool active) {
   const int q = (int)(threadIdx.x & 3u);
@@ -119,7 +125,7 @@ __device__ __forceinline__ QuadRes<F> quad_add_compute(const XYZZ<F>* __restrict
   if (a_id) { out.mode = 1; out.c0 = q == 0 ? B.X : q == 1 ? B.Y : q == 2 ? B.ZZ : B.ZZZ; return out; }
   if (pz) {                                          // same x: doubling or cancellation — rare, the scalar formula on lane 0
     out.mode = 3;
-    if (q == 0) { XYZZ<F> a = A; add_full(a, B); out.full = a; }
+    if (q == 0) { XYZZ<F> tmp; quad_add_rare<F>(&A, &B, &tmp); out.full = tmp; }
     return out;
   }
   out.mode = 2;
