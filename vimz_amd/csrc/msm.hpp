@@ -597,13 +597,13 @@ __device__ __forceinline__ int signed_digit(const uint32_t* s, int w) {
   return d > (1u << (C - 1)) ? (int)d - (1 << C) : (int)d;
 }
 
-template <class S, class F>
+template <class S, class F, int LEAN /* the option small_lean: its code is only in the instantiations that run it */>
 __global__ void __launch_bounds__(SMALL_THREADS) k_msm_small(const uint32_t* __restrict__ bases, const uint32_t* __restrict__ scalars, uint32_t n, int mont,
                                                    uint32_t Q, uint32_t chunk, uint32_t* __restrict__ chunk_out /* K*Q points */,
                                                    uint32_t* __restrict__ done /* K counters, zero between launches; nullptr: k_msm_small_sum follows */,
                                                    uint32_t* __restrict__ window_sums,
-                                                   const uint32_t* __restrict__ tables /* or nullptr: row w holds 2^(7w)·P_i, row length tstride */, uint32_t tstride,
-                                                   int lean /* levels with a wave's worth of additions by one lane each instead of four: half the instructions, 3.4 µs more per level */) {
+                                                   const uint32_t* __restrict__ tables /* or nullptr: row w holds 2^(7w)·P_i, row length tstride */, uint32_t tstride) {
+  constexpr int lean = LEAN;      // (levels with a wave's worth of additions by one lane each instead of four: half the instructions, 3.4 µs more per level)
   __shared__ XYZZ<F> sh[SMALL_THREADS];
   __shared__ uint32_t cnt[SMALL_NBW], off[SMALL_NBW + 1], soff[SMALL_NBW + 1], cur[SMALL_NBW];
   __shared__ uint16_t list[SMALL_CHUNK];
@@ -966,9 +966,11 @@ hipError_t msm_launch(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_ba
     }
     if (ev) for (int i = 0; i < 4; i++) VZ_HIP_CHECK(hipEventRecord(ev[i], stream));
     static const bool sum_kernel = getenv("VIMZ_DEBUG_SMALL_SUM_KERNEL") != nullptr;
-    hipLaunchKernelGGL((k_msm_small<S, F>), dim3(ps.K, Q), dim3(SMALL_THREADS), 0, stream, d_bases, d_scalars, (uint32_t)n, scalars_mont, Q, chunk, chunk_out,
-                       sum_kernel ? (uint32_t*)nullptr : done, direct ? reinterpret_cast<uint32_t*>(pinned_dst) : reinterpret_cast<uint32_t*>(ws.window_sums),
-                       small_tb ? tb->d + (size_t)AFFINE_WORDS * tb->offset : (const uint32_t*)nullptr, small_tb ? (uint32_t)tb->n_total : 0u, msm_tuning().small_lean);
+#define VZ_SMALL(LEAN) hipLaunchKernelGGL((k_msm_small<S, F, LEAN>), dim3(ps.K, Q), dim3(SMALL_THREADS), 0, stream, d_bases, d_scalars, (uint32_t)n, scalars_mont, Q, chunk, chunk_out, \
+                       sum_kernel ? (uint32_t*)nullptr : done, direct ? reinterpret_cast<uint32_t*>(pinned_dst) : reinterpret_cast<uint32_t*>(ws.window_sums), \
+                       small_tb ? tb->d + (size_t)AFFINE_WORDS * tb->offset : (const uint32_t*)nullptr, small_tb ? (uint32_t)tb->n_total : 0u)
+    switch (msm_tuning().small_lean) { case 0: VZ_SMALL(0); break; case 1: VZ_SMALL(1); break; default: VZ_SMALL(2); break; }
+#undef VZ_SMALL
     if (Q > 1 && sum_kernel) hipLaunchKernelGGL(k_msm_small_sum<F>, dim3(ps.K), dim3(64), 0, stream, chunk_out, Q, direct ? reinterpret_cast<uint32_t*>(pinned_dst) : reinterpret_cast<uint32_t*>(ws.window_sums));
     if (ev) for (int i = 4; i < 7; i++) VZ_HIP_CHECK(hipEventRecord(ev[i], stream));
     VZ_HIP_CHECK(hipGetLastError());
