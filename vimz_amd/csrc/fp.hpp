@@ -72,6 +72,13 @@ VZ_FIELD(BnFq, 0x30644e72u, 0xe131a029u, 0xb85045b6u, 0x8181585du, 0x97816a91u, 
 VZ_FIELD(PallasFp, 0x40000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x224698fcu, 0x094cf91bu, 0x992d30edu, 0x00000001u)
 VZ_FIELD(VestaFq, 0x40000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x224698fcu, 0x0994a8ddu, 0x8c46eb21u, 0x00000001u)
 
+// Wave issue priority of the kernels on a step's critical chain (k_msm_small, k_spmv_cross16, k_msm_fixed) over the bulk waves on the same SIMDs.
+// tools/ubench_icache.hip: at priority 3 a chain of dependent additions runs at its stand-alone speed beside the accumulation's loop — and the loop at 45 % of its own.
+#ifndef VZ_CRIT_PRIO
+#define VZ_CRIT_PRIO 3
+#endif
+#define VZ_SET_CRIT_PRIO() do { if (VZ_CRIT_PRIO) __builtin_amdgcn_s_setprio(VZ_CRIT_PRIO); } while (0)
+
 template <class P>
 struct Fp {
   typedef P Params;

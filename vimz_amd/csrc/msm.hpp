@@ -611,7 +611,7 @@ __global__ void __launch_bounds__(SMALL_THREADS) k_msm_small(const uint32_t* __r
   __shared__ uint32_t s_maxm, s_ticket, wcnt[SMALL_THREADS / 64];
   // These waves sit on the critical path of a folding step while bulk kernels (the large MSM's accumulation, the batch
   // producer) fill the same SIMDs: raise their issue priority over the resident bulk waves.
-  __builtin_amdgcn_s_setprio(3);
+  VZ_SET_CRIT_PRIO();
   const uint32_t t = threadIdx.x, w = blockIdx.x, q = blockIdx.y;
   const uint32_t lo = q * chunk, hi = min(n, lo + chunk);
   const uint32_t* __restrict__ wbases = tables ? tables + (size_t)AFFINE_WORDS * ((size_t)w * tstride) : bases;
@@ -827,7 +827,7 @@ __global__ void __launch_bounds__(256) k_msm_fixed(const uint32_t* __restrict__ 
                                                    uint32_t* __restrict__ window_sums) {
   __shared__ XYZZ<F> sh[256];
   __shared__ uint32_t s_ticket;
-  __builtin_amdgcn_s_setprio(3);
+  VZ_SET_CRIT_PRIO();
   const uint32_t t = threadIdx.x, q = blockIdx.x, w = blockIdx.y;
   constexpr uint32_t NM = SMALL_NBW;
   // the four table entries of this thread are requested before the first of them is needed

@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(256) k_spmv_cross16(CsrDev A, CsrDev B, CsrDev
                                                       const uint32_t* __restrict__ z, uint32_t* __restrict__ az, uint32_t* __restrict__ bz, uint32_t* __restrict__ cz,
                                                       const uint32_t* __restrict__ az1, const uint32_t* __restrict__ bz1, const uint32_t* __restrict__ cz1, F u1, F u2,
                                                       uint32_t* __restrict__ T) {
-  __builtin_amdgcn_s_setprio(3);       // critical path of a step, next to bulk kernels on the same SIMDs
+  VZ_SET_CRIT_PRIO();       // critical path of a step, next to bulk kernels on the same SIMDs
   const uint32_t g = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, l = threadIdx.x & 15u;
   const bool live = g < nrows;
   const uint32_t r = row0 + (live ? g : 0u);
