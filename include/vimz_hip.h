@@ -420,20 +420,27 @@ int vimz_cf_chain_from_digests(vimz_cf* v, const uint64_t* z_start, const uint64
  *      published, with the PUBLIC-INPUT LAYOUT of the reference's contracts (pp_hash, i, z_0, z_i, the folded commitments and cmT as 5 x 55-bit
  *      limbs per coordinate, the KZG challenges and evaluations: ContrastVerifier.sol:700-772) — pinned: tests/_novadecider.py restates the
  *      contract, accepts the reference's six committed proofs with the reference's keys, and accepts this library's words with this library's
- *      key.  The circuit's CONSTRAINTS (vimz_amd/csrc/aug/decider.hpp) are ours, parity unpinned: Sonobe's circuit and keys come out of crates
- *      that are not vendored, so the committed `.proof` bytes cannot be reproduced.  NTTs, the G1 / G2 multi-scalar multiplications, the final
- *      fold, the KZG openings and the keys' fixed-base multiplications run on the GPU; verification is host code (pairing.hpp). ---------- */
+ *      key.  The circuit's CONSTRAINTS (vimz_amd/csrc/aug/decider.hpp, decider_cf.hpp) are ours, parity unpinned: Sonobe's circuit and keys come out
+ *      of crates that are not vendored, so the committed `.proof` bytes cannot be reproduced.  Two variants, as in the reference: the FULL decider
+ *      (decider.rs:13-21: also opens the running CycleFold instance's two commitments and checks its relaxed relation inside the circuit — natively over
+ *      Grumpkin, non-natively over Fq; ≈ 2.75 M constraints on top of the step circuit's) and the LIGHT one (the opt-in `light-test` feature,
+ *      vimz/Cargo.toml:56-59, vimz/Makefile:1-2, the contracts under contracts/light-test/: the CycleFold instance bound by its hash only).  Same public inputs, same
+ *      25 words.  NTTs, the G1 / G2 multi-scalar multiplications, the final fold, the KZG openings and the keys' fixed-base multiplications run on
+ *      the GPU; verification is host code (pairing.hpp).  The 25-word layout is the reference contracts' INTERFACE, not by itself a sound on-chain
+ *      decider: U_i's and u_i's commitments and the fold's r reach the contract as unconstrained calldata (aug/decider.hpp). ---------- */
 typedef struct vimz_decider vimz_decider;
 /* KZG::setup (inside `prepare_folding`, vimz/src/sonobe_backend/folding.rs:36-48): srs = [tau^i]G1 for i < n as a commitment key (use it as
  * ck_main of vimz_cf_create), vk_g2_out = [tau]G2 (x.c0, x.c1, y.c0, y.c1 canonical).  tau comes from the OS's randomness and is forgotten. */
 int vimz_kzg_setup(vimz_ctx* ctx, size_t n, vimz_bases** srs_out, uint64_t vk_g2_out[16]);
 /* Decider::preprocess.  prover: supplies shapes, keys and context (must outlive the object).  kzg_vk_g2 (optional): [tau]G2 of the SRS the prover's
- * ck_main is made of (needed by vimz_decider_verify; part of vimz_decider_vk).  The Groth16 trapdoor comes from the OS's randomness and is forgotten
- * (a locally trusted setup; seeded test setups exist only in libvimz_hip_testing.so).  seconds (optional) = {circuit synthesis, QAP evaluation at
- * the trapdoor, key points on the GPU, total} */
-int vimz_decider_setup(vimz_cf* prover, const uint64_t kzg_vk_g2[16], vimz_decider** out, double seconds[4]);
+ * ck_main is made of (needed by vimz_decider_verify; part of vimz_decider_vk; checked against that SRS: e(srs[1], G2) = e(G1, [tau]G2)).
+ * light: 0 = the full decider (the reference's default), non-zero = the `light-test` variant.  The full decider bakes the first generators of the
+ * prover's CycleFold commitment key into the circuit.  The Groth16 trapdoor comes from the OS's randomness and is wiped after use (a locally trusted
+ * setup; seeded test setups exist only in libvimz_hip_testing.so).  seconds (optional) = {circuit synthesis, QAP evaluation at the trapdoor, key
+ * points on the GPU, total} */
+int vimz_decider_setup(vimz_cf* prover, const uint64_t kzg_vk_g2[16], int light, vimz_decider** out, double seconds[4]);
 void vimz_decider_free(vimz_decider* d);
-/* info = {constraints, wires, public inputs (36 + 2 len_z), domain size, non-zeros of A, B, C, 0} */
+/* info = {constraints, wires, public inputs (36 + 2 len_z), domain size, non-zeros of A, B, C, rows of the CycleFold checks (0: light decider)} */
 int vimz_decider_info(const vimz_decider* d, uint64_t info[8]);
 /* the verifying key — the constants of a contract generated for this circuit — as canonical words: pp_hash (4), len_z (1), alpha (G1: x, y), beta,
  * gamma, delta (G2: x.c0, x.c1, y.c0, y.c1), the number of IC points, the IC points, KZG G_1 (G1), G_2, VK (G2); returns the byte size (copies
@@ -446,7 +453,8 @@ int64_t vimz_decider_key_save(vimz_decider* d, void* buf, size_t cap);
 int vimz_decider_key_load(vimz_cf* prover, const void* buf, size_t len, vimz_decider** out);
 /* Decider::prove for the IVC proof `ivc` holds (same shapes and keys as the decider's prover; left unchanged; at least one step): final fold, KZG
  * openings, Groth16 proof.  words_out: the 25 calldata words (vimz_amd/calldata.py names them), public_out: the info[2] public inputs; canonical,
- * 4 little-endian limbs each.  VIMZ_ERR_UNSAT when the proof does not satisfy the decider's statement.
+ * 4 little-endian limbs each.  VIMZ_ERR_UNSAT when the proof does not satisfy the decider's statement (full decider: including a running CycleFold
+ * witness that violates its relation or does not open its commitments).
  * seconds (optional) = {final fold + KZG openings, witness + sparse products on the host, NTTs, multi-scalar multiplications, total, 0} */
 int vimz_decider_prove(vimz_decider* d, vimz_cf* ivc, uint64_t* public_out, uint64_t words_out[100], double seconds[6]);
 /* Decider::verify (verify_final_proof, decider.rs:31-50): the checks of contracts/ContrastVerifier.sol:685-783 on (steps, z_0, z_i, 25 words).

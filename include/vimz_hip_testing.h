@@ -43,11 +43,11 @@ void vimz_test_forge_public_slot(int on);
 /* deterministic TEST setups of the decider path (vimz_kzg_setup / vimz_decider_setup with the toxic waste derived from `seed`: anyone who knows the
  * seed can forge) — for reproducible keys in tests and benchmarks only */
 /* host only, no GPU: the decider circuit over `steps` steps of the Nova + CycleFold recursion of the trivial step circuit (made-up commitments, the running
- * witness folded on the host), its final fold, witness and R1CS; result 0 = good (bits: vimz_amd/csrc/groth16.hip); counts = {decider constraints, wires,
- * public inputs, main constraints} */
-int vimz_decider_selfcheck(int steps, uint32_t* result, uint64_t counts[4]);
+ * witness folded on the host), its final fold, witness and R1CS; full != 0: the FULL decider, over real CycleFold instances kept on the host; result 0 = good
+ * (bits: vimz_amd/csrc/groth16.hip); counts = {decider constraints, wires, public inputs, main constraints} */
+int vimz_decider_selfcheck(int steps, int full, uint32_t* result, uint64_t counts[4]);
 int vimz_testing_kzg_setup_seeded(vimz_ctx* ctx, const uint8_t* seed, size_t seed_len, size_t n, vimz_bases** srs_out, uint64_t vk_g2_out[16]);
-int vimz_testing_decider_setup_seeded(vimz_cf* prover, const uint64_t kzg_vk_g2[16], const uint8_t* seed, size_t seed_len, vimz_decider** out, double seconds[4]);
+int vimz_testing_decider_setup_seeded(vimz_cf* prover, const uint64_t kzg_vk_g2[16], int light, const uint8_t* seed, size_t seed_len, vimz_decider** out, double seconds[4]);
 
 #ifdef __cplusplus
 }

@@ -1,10 +1,10 @@
 """Body of tests/test_gpu_decider.py::test_what_the_decider_proof_does_not_attest, run as a process of its own with VIMZ_HIP_LIBRARY=testing (vimz_cf_poke and the
 seeded setups exist only in libvimz_hip_testing.so).  Test infrastructure.
 
-Records a LIMIT of the decider as built: the circuit binds the CycleFold running instance cfU_i by its hash only — Sonobe's checks it
-in non-native arithmetic — so a CycleFold WITNESS that does not satisfy its relaxed relation is invisible to the 25 calldata words: the contract's checks
-(vimz_decider_verify, tests/_novadecider.py) still pass, and only the full IVC verification (vimz_cf_verify), which needs the witnesses, rejects.  A wrong
-MAIN witness, in contrast, is refused by the prover (VIMZ_ERR_UNSAT: no proof of a false relaxed relation)."""
+The FULL decider (round 6; `DeciderEth`, vimz/src/sonobe_backend/decider.rs:13-21) attests the running CycleFold instance cfU_i inside the circuit: a CycleFold
+WITNESS that does not satisfy its relaxed relation — or does not open cfU_i's commitments — gets no proof (VIMZ_ERR_UNSAT), like a wrong MAIN witness.  The LIGHT
+variant (the reference's opt-in `light-test` feature, vimz/Cargo.toml:56-59) binds cfU_i by its hash only: there such a witness is invisible to the 25 calldata
+words — the contract's checks (vimz_decider_verify, tests/_novadecider.py) still pass and only the full IVC verification (vimz_cf_verify) rejects.  Both recorded."""
 import os
 import sys
 
@@ -27,7 +27,7 @@ def main():
     c = Circuit.for_resolution("hash", "HD")
     z0, inputs = step_inputs("hash")
     cf = hip.CycleFoldIVC(ctx, c, srs, ck2, max_batch=2)
-    dec = dec2 = None
+    dec = dec2 = light = None
     try:
         cf.reset(z0); cf.fold(np.stack(inputs[:3]))
         assert cf.verify(3, z0) == 0
@@ -41,15 +41,36 @@ def main():
         assert dec2.key_words().tolist() == dec.key_words().tolist()
         dec2.close(); dec2 = hip.Decider(cf, kzg_vk=kzg_vk, seed=b"another key")
         assert dec2.key_words().tolist() != dec.key_words().tolist() and dec2.verify(steps, a0, ai, words) == 8      # another key: Groth16 fails, KZG passes
-        # (1) a CycleFold witness that no longer satisfies its relation: the IVC verifier rejects, the decider's words do not notice
+        assert dec.info()["cyclefold_rows"] > 2_700_000
+        light = hip.Decider(cf, kzg_vk=kzg_vk, seed=b"tamper-decider key", light=True)
+        assert light.info()["cyclefold_rows"] == 0 and light.info()["public_inputs"] == dec.info()["public_inputs"]
+        words_l, pub_l, _ = light.prove()
+        assert pub_l == pub and light.verify(steps, a0, ai, words_l) == 0 and dec.verify(steps, a0, ai, words_l) == 8      # (another circuit: another key)
+        # (1) a CycleFold witness that no longer satisfies its relation: the IVC verifier rejects; the FULL decider refuses to prove; the LIGHT one's words do not notice
         vec = from_limbs(cf.export(1, hip.IX_RUNNING_Z))
         idx = 5
         cf.poke(2, idx, (vec[idx] + 1) % _lib.MODULUS[1])
         assert cf.verify(3, z0) != 0
-        words_b, pub_b, _ = dec.prove()
-        assert pub_b == pub and dec.verify(steps, a0, ai, words_b) == 0
-        assert nd.verify(dec.verifying_key(), steps, a0, ai, words_b) == (True, "ok")
+        try:
+            dec.prove()
+            raise AssertionError("the full decider proved over a CycleFold witness that violates its relation")
+        except _lib.VimzError as e:
+            assert e.code == _lib.ERR_UNSAT, e
+        words_b, pub_b, _ = light.prove()
+        assert pub_b == pub and light.verify(steps, a0, ai, words_b) == 0
+        assert nd.verify(light.verifying_key(), steps, a0, ai, words_b) == (True, "ok")
         cf.poke(2, idx, vec[idx])
+        assert cf.verify(3, z0) == 0
+        # ... and a changed element of its error vector likewise
+        evec = from_limbs(cf.export(1, hip.IX_RUNNING_E))
+        cf.poke(4, 7, (evec[7] + 1) % _lib.MODULUS[1])
+        assert cf.verify(3, z0) != 0
+        try:
+            dec.prove()
+            raise AssertionError("the full decider proved over a CycleFold error vector that violates its relation")
+        except _lib.VimzError as e:
+            assert e.code == _lib.ERR_UNSAT, e
+        cf.poke(4, 7, evec[7])
         assert cf.verify(3, z0) == 0
         # (2) a main witness that no longer satisfies the relaxed relation: no proof
         vec = from_limbs(cf.export(0, hip.IX_RUNNING_Z))
@@ -64,7 +85,7 @@ def main():
         words_c, pub_c, _ = dec.prove()
         assert pub_c == pub and dec.verify(steps, a0, ai, words_c) == 0
     finally:
-        for o in (dec, dec2):
+        for o in (dec, dec2, light):
             if o is not None:
                 o.close()
         cf.close(); srs.free(); ck2.free(); ctx.close()

@@ -98,10 +98,31 @@ def test_decider_circuit_on_the_host():
     import numpy as np
     from vimz_amd import _lib
     T = _lib.testing_lib()
-    T.vimz_decider_selfcheck.argtypes = [C.c_int, C.POINTER(C.c_uint32), C.c_void_p]
+    T.vimz_decider_selfcheck.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_uint32), C.c_void_p]
     for steps in (2, 4):
         res, cnt = C.c_uint32(0xFFFF), np.zeros(4, dtype=np.uint64)
-        assert T.vimz_decider_selfcheck(steps, C.byref(res), cnt.ctypes.data) == 0
+        assert T.vimz_decider_selfcheck(steps, 0, C.byref(res), cnt.ctypes.data) == 0
         assert res.value == 0, f"decider self-check bits {res.value:#x}"
         # one or two constraints per row of the main relation + the Horner chains + the hashes and bit decompositions
         assert int(cnt[2]) == 36 + 2 * 1 and int(cnt[3]) + 20000 < int(cnt[0]) < 4 * int(cnt[3]) + 30000
+
+
+def test_full_decider_circuit_on_the_host():
+    """The FULL decider (aug/decider_cf.hpp: what `DeciderEth` of vimz/src/sonobe_backend/decider.rs:13-21 attests beyond the `light-test` variant): the running
+    CycleFold instance's two Pedersen commitments opened over Grumpkin and its relaxed relation checked over Fq in non-native limbs, inside the circuit.  Host
+    only: three steps of the recursion with REAL CycleFold instances (witnesses of the CycleFold circuit for both folds of a step, committed and folded on
+    the host; the running instance must equal the one F' folds in-circuit), then the decider's witness satisfies all 2.86 M rows with the same 38 public
+    inputs; a changed CycleFold witness element, a changed error element, and a witness changed so that its commitment still opens are each flagged by the
+    witness generator (-> VIMZ_ERR_UNSAT in vimz_decider_prove) and violate a row."""
+    import ctypes as C
+    import numpy as np
+    from vimz_amd import _lib
+    T = _lib.testing_lib()
+    T.vimz_decider_selfcheck.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_uint32), C.c_void_p]
+    res, cnt, light = C.c_uint32(0xFFFF), np.zeros(4, dtype=np.uint64), np.zeros(4, dtype=np.uint64)
+    assert T.vimz_decider_selfcheck(3, 1, C.byref(res), cnt.ctypes.data) == 0
+    assert res.value == 0, f"full decider self-check bits {res.value:#x}"
+    r2 = C.c_uint32(0xFFFF)
+    assert T.vimz_decider_selfcheck(3, 0, C.byref(r2), light.ctypes.data) == 0
+    # the same interface; 1 306 + 1 313 scalars at 3 rows a bit (2.0 M) + 1 313 rows at ~570 (0.75 M) more constraints, whatever the step circuit
+    assert int(cnt[2]) == int(light[2]) == 38 and 2_700_000 < int(cnt[0]) - int(light[0]) < 2_800_000

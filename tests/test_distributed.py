@@ -350,7 +350,7 @@ def test_two_ranks_with_two_segments_each_end_in_one_proof_object(oracle, shm, d
     assert _replay_stub_ops(ops)[3] == ((3, 2), (2, 2))
 
 
-def _failing_worker(rank, world, port, q, fail_rank):
+def _failing_worker(rank, world, port, q, fail_rank, mode="merge-fail"):
     """tree_final_fold with a merge that fails on `fail_rank`: every rank must come back (with an error or, for ranks whose hand-over was taken, None)
     long before the process group's timeout."""
     sys.path.insert(0, ROOT)
@@ -361,7 +361,7 @@ def _failing_worker(rank, world, port, q, fail_rank):
     from vimz_amd.distributed import prove_sharded
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    os.environ["VIMZ_SHARD_TRANSPORT"] = f"merge-fail:{fail_rank}"
+    os.environ["VIMZ_SHARD_TRANSPORT"] = f"{mode}:{fail_rank}"
     dist.init_process_group("gloo", rank=rank, world_size=world)
     orc = _oracle.load()
     z0, inputs = step_inputs("hash")
@@ -398,6 +398,36 @@ def test_a_failed_merge_travels_up_the_tree_instead_of_hanging_it(world, fail_ra
     assert all(dt < 120 for _, _, dt in got.values()), got              # (gloo's default timeout is 30 minutes)
     # ranks whose hand-over was taken before the failure simply returned None
     assert all(v[0] == "raised" or v[1] is True for v in got.values()), got
+
+
+@pytest.mark.parametrize("world,fail_rank,mode", [(4, 2, "fold-fail"), (4, 1, "fold-fail"), (8, 0, "fold-fail"), (4, 3, "offer-fail"), (8, 4, "offer-fail")])
+def test_a_failed_fold_or_offer_reaches_every_waiting_rank(world, fail_rank, mode):
+    """only failures inside a receiver's merge used to be reported.  A rank whose own FOLD raises (an unsatisfiable row, a HIP error) never
+    enters the tree, and a sender whose offer cannot be made (save / share raising) sent nothing: the peer sat in a blocking gloo receive until the
+    process group's timeout.  Now prove_sharded calls tree_abort for a failed fold and the sender sends the abort marker in place of its offer."""
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_failing_worker, args=(r, world, port, q, fail_rank, mode)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        r, what, info, dt = q.get(timeout=240)
+        got[r] = (what, info, dt)
+    for p in procs:
+        p.join(timeout=60)
+    assert got[fail_rank][0] == "raised" and ("fold refused" if mode == "fold-fail" else "offer refused") in got[fail_rank][1], got
+    assert got[0][0] == "raised", got                                     # rank 0 never gets the ONE object — and says so, promptly
+    assert all(dt < 120 for _, _, dt in got.values()), got              # (nobody waited for gloo's 30-minute timeout)
+    assert all(v[0] == "raised" or v[1] is True for v in got.values()), got
+    if mode == "fold-fail":      # the ranks that would have handed over to the failed rank were answered "fail"
+        st = 1
+        while st < world and fail_rank % (2 * st) == 0:
+            if fail_rank + st < world:
+                assert got[fail_rank + st][0] == "raised" and "could not take over" in got[fail_rank + st][1], got
+            st *= 2
 
 
 def test_tree_rounds_pair_adjacent_runs():

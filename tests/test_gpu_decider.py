@@ -21,7 +21,7 @@ def ctx():
     c.close()
 
 
-def _prove_and_check(ctx, oracle, op, n_srs, steps, z0, inputs, t_oracle=None, full_negative=False):
+def _prove_and_check(ctx, oracle, op, n_srs, steps, z0, inputs, t_oracle=None, full_negative=False, light=False):
     from vimz_amd import hip
     c = Circuit.for_resolution(op, "HD")
     srs, kzg_vk = hip.kzg_setup(ctx, n_srs)
@@ -31,11 +31,14 @@ def _prove_and_check(ctx, oracle, op, n_srs, steps, z0, inputs, t_oracle=None, f
     try:
         cf.reset(z0); cf.fold(np.stack(inputs[:steps]))
         assert cf.verify(steps, z0) == 0
-        dec = hip.Decider(cf, kzg_vk=kzg_vk)
+        dec = hip.Decider(cf, kzg_vk=kzg_vk, light=light)
         info, ci = dec.info(), cf.info()
         lz = c.len_z
         assert info["public_inputs"] == 36 + 2 * lz          # the contract's layout: pp_hash, i, z_0, z_i, 4 x 5 limbs, 4 scalars, 2 x 5 limbs
-        assert ci["main_constraints"] + ci["main_wires"] < info["constraints"] < 3 * ci["main_constraints"] + ci["main_wires"] + 20000
+        # the full decider's extra rows do not depend on the step circuit: 2 619 scalars at 3 rows a bit, 1 313 rows of the CycleFold shape at ~570
+        assert info["cyclefold_rows"] == 0 if light else 2_700_000 < info["cyclefold_rows"] < 2_800_000
+        light_rows = info["constraints"] - info["cyclefold_rows"]
+        assert ci["main_constraints"] + ci["main_wires"] < light_rows < 3 * ci["main_constraints"] + ci["main_wires"] + 20000
         assert info["domain"] >= info["constraints"] + info["public_inputs"] + 1 and info["domain"] & (info["domain"] - 1) == 0
         raw, d = calldata.decider_calldata(dec)
         words, pub = d["words"], d["public_inputs"]
@@ -114,27 +117,44 @@ def _prove_and_check(ctx, oracle, op, n_srs, steps, z0, inputs, t_oracle=None, f
         cf.close(); srs.free(); ck2.free()
 
 
-def test_decider_words_are_accepted_by_the_restated_contract_hash_step(ctx, oracle):
+def test_full_decider_words_are_accepted_by_the_restated_contract_hash_step(ctx, oracle):
+    """The FULL decider (the reference's default, decider.rs:13-21): same 25 words, same public inputs; the key pair (1.3 GB at rest) saves and loads."""
     from tests._oracle import T_HASH
     z0, inputs = step_inputs("hash")
-    _prove_and_check(ctx, oracle, "hash", 36000, 4, z0, inputs, t_oracle=T_HASH, full_negative=True)
+    info, _, _ = _prove_and_check(ctx, oracle, "hash", 36000, 4, z0, inputs, t_oracle=T_HASH, full_negative=True)
+    assert info["domain"] == 1 << 22
 
 
-def test_decider_at_contrast_hd(ctx, oracle):
-    """BASELINE.json's headline circuit: contrast HD (1.04 M decider constraints, domain 2^20, SRS of 2^19 powers made on the GPU)."""
+def test_light_decider_words_are_accepted_by_the_restated_contract_hash_step(ctx, oracle):
+    """The reference's opt-in `light-test` variant (vimz/Cargo.toml:56-59): the circuit of checks 1-4 only."""
+    from tests._oracle import T_HASH
+    z0, inputs = step_inputs("hash")
+    _prove_and_check(ctx, oracle, "hash", 36000, 4, z0, inputs, t_oracle=T_HASH, full_negative=True, light=True)
+
+
+def test_full_decider_at_contrast_hd(ctx, oracle):
+    """BASELINE.json's headline circuit: contrast HD — 1.04 M rows for the folded main instance, the hashes and the KZG evaluations + 2.75 M for the
+    CycleFold instance: domain 2^22, SRS of 2^19 powers made on the GPU."""
     from tests._oracle import T_CONTRAST
     z0, inputs = step_inputs("contrast")
     info, sec, setup = _prove_and_check(ctx, oracle, "contrast", 1 << 19, 3, z0, inputs, t_oracle=T_CONTRAST)
+    assert 3_700_000 < info["constraints"] < (1 << 22) - 64 and info["domain"] == 1 << 22
+
+
+def test_light_decider_at_contrast_hd(ctx, oracle):
+    from tests._oracle import T_CONTRAST
+    z0, inputs = step_inputs("contrast")
+    info, sec, setup = _prove_and_check(ctx, oracle, "contrast", 1 << 19, 3, z0, inputs, t_oracle=T_CONTRAST, light=True)
     assert info["constraints"] > 1_000_000 and info["domain"] == 1 << 20
 
 
-@pytest.mark.parametrize("op,n_srs", [("grayscale", 1 << 18), ("blur", 1 << 19)])
-def test_decider_at_the_other_state_widths(ctx, oracle, op, n_srs):
+@pytest.mark.parametrize("op,n_srs,light", [("grayscale", 1 << 18, True), ("blur", 1 << 19, False)])
+def test_decider_at_the_other_state_widths(ctx, oracle, op, n_srs, light):
     """The reference's nine contracts come in four state widths (tests/golden/verifier_keys.json: len_z 1, 2, 3, 4 — 38, 40, 42, 44 public inputs);
-    hash and contrast above are 1 and 3, these are 2 (grayscale, as Grayscale/Redact/ResizeVerifier.sol) and 4 (blur, as Blur/SharpnessVerifier.sol)."""
+    hash and contrast above are 1 and 3, these are 2 (grayscale, as Grayscale/Redact/ResizeVerifier.sol; light) and 4 (blur, as Blur/SharpnessVerifier.sol; full)."""
     from tests.test_circuits import ORC_T
     z0, inputs = step_inputs(op)
-    info, _, _ = _prove_and_check(ctx, oracle, op, n_srs, 3, z0, inputs, t_oracle=ORC_T[op])
+    info, _, _ = _prove_and_check(ctx, oracle, op, n_srs, 3, z0, inputs, t_oracle=ORC_T[op], light=light)
     assert info["public_inputs"] == {"grayscale": 40, "blur": 44}[op] == len(nd.verifier_keys()[op]["groth16"]["ic"]) - 1
 
 
@@ -148,17 +168,21 @@ def test_decider_refuses_other_shapes_and_a_prover_without_steps(ctx):
     dec = nokey = None
     try:
         cf.reset(z0)
-        dec = hip.Decider(cf, kzg_vk=kzg_vk)
+        dec = hip.Decider(cf, kzg_vk=kzg_vk, light=True)
         with pytest.raises(_lib.VimzError):
             dec.prove()                                          # no steps
-        nokey = hip.Decider(cf)
+        nokey = hip.Decider(cf, light=True)
         cf.fold(np.stack(inputs[:2]))
         words, pub, _ = nokey.prove()
         with pytest.raises(_lib.VimzError):
             nokey.verify(2, pub[2:3], pub[3:4], words)           # set up without the SRS's verifying key
         bad = np.array(kzg_vk); bad[0, 0] ^= 1
         with pytest.raises(_lib.VimzError):
-            hip.Decider(cf, kzg_vk=bad)                          # not a point of G2
+            hip.Decider(cf, kzg_vk=bad, light=True)              # not a point of G2
+        srs2, vk2 = hip.kzg_setup(ctx, 16)
+        srs2.free()
+        with pytest.raises(_lib.VimzError, match="not .tau.G2 of the SRS"):
+            hip.Decider(cf, kzg_vk=vk2, light=True)              # [tau']G2 of another SRS than the prover commits with
     finally:
         for o in (dec, nokey):
             if o is not None:
@@ -166,14 +190,15 @@ def test_decider_refuses_other_shapes_and_a_prover_without_steps(ctx):
         cf.close(); srs.free(); ck2.free()
 
 
-def test_what_the_decider_proof_does_not_attest():
-    """The decider circuit binds the CycleFold instance by hash only (Sonobe checks it in-circuit): a CycleFold witness that violates its
-    relation passes the contract's checks and is caught only by the full IVC verifier; a violated MAIN relation is refused by the prover.  Also: seeded
-    setups are reproducible.  Body: tests/_tamper_decider.py on libvimz_hip_testing.so (vimz_cf_poke, seeded setups)."""
+def test_what_the_full_and_the_light_decider_attest():
+    """The FULL decider refuses (VIMZ_ERR_UNSAT) a CycleFold witness or error vector that violates its relation — the instance is attested inside the
+    circuit, as Sonobe's `DeciderEth` does; the LIGHT variant binds it by hash only, so there the contract's checks still pass and only the full IVC
+    verifier objects; a violated MAIN relation is refused by both.  Also: seeded setups are reproducible.  Body: tests/_tamper_decider.py on
+    libvimz_hip_testing.so (vimz_cf_poke, seeded setups)."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, VIMZ_HIP_LIBRARY="testing")
-    r = subprocess.run([sys.executable, os.path.join(root, "tests", "_tamper_decider.py")], env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "_tamper_decider.py")], env=env, capture_output=True, text=True, timeout=1500, cwd=root)
     assert r.returncode == 0 and "tamper ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]

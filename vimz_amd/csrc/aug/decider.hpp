@@ -18,11 +18,18 @@
 //   3. (A·Z)∘(B·Z) = u'·(C·Z) + E   for Z = (u', W', x0', x1')                  the folded main instance satisfies F' ∪ step circuit, row by row
 //   4. c_W = H(dg, limbs55(U_{i+1}.cmW)),  c_E = H(dg, limbs55(U_{i+1}.cmE))    the KZG challenges follow from the commitments they open
 //      e_W = Σ_j W'_j c_W^j,  e_E = Σ_k E_k c_E^k                               the evaluations the two KZG openings are about
-// What the circuit does NOT attest (README): (a) the CycleFold instance cfU_i is bound through its hash (1) only — its relaxed
-// relation over Fq is checked outside (vimz_cf_verify), where Sonobe's circuit checks it in non-native arithmetic; (b) as in the contract's
-// layout, U_i's and u_i's commitments are private here: the calldata's copies are tied to this proof only through U_{i+1}'s commitments.
+//   5. cfU_i.cmW, cfU_i.cmE open to the running CycleFold witness and error vector        FULL decider only (aug/decider_cf.hpp): Pedersen over Grumpkin, native
+//   6. the running CycleFold instance satisfies its relaxed R1CS over Fq                  FULL decider only: non-native, limb by limb
+// Two variants, as in the reference: the FULL decider (1-6: what `DeciderEth` of vimz/src/sonobe_backend/decider.rs:13-21 attests) and the LIGHT one
+// (1-4: the reference's opt-in `light-test` feature, vimz/Cargo.toml:56-59, contracts/light-test/*.sol), which binds the CycleFold instance cfU_i through
+// its hash (1) only and leaves its relation to the IVC verifier (vimz_cf_verify).
+// INTERFACE PARITY, NOT A SOUND ON-CHAIN DECIDER: as in the contract's layout, U_i's and u_i's commitments are private here, the contract
+// recomputes U_{i+1}'s commitments from the calldata's (U_i.cm*, u_i.cmW, cmT, r), and that r is neither a public input nor tied to the challenge this
+// circuit derives: calldata that adds up to the commitments of a self-chosen (W', E') is accepted.  The 25 words reproduce the reference's interface;
+// acceptance by the contract's checks alone does not imply an IVC behind them — vimz_cf_verify + this proof do.
 #pragma once
 #include "cyclefold.hpp"
+#include "decider_cf.hpp"
 
 namespace vz {
 namespace aug {
@@ -34,6 +41,7 @@ struct DeciderIn {
   NnPoint cmT, Wn, En;                         // cross-term commitment of the final fold, folded commitments U_{i+1}.cmW / cmE
   CfFr eW, eE;                                 // KZG evaluations (the challenges follow from Wn, En: decider_kzg_challenge)
   const CfFr* Wf = nullptr; const CfFr* Ef = nullptr;      // folded witness (wires 1 .. n_wires-3 of Z) and error vector; nullptr in shape mode
+  CfFullIn full;                                           // full decider: the opening key, the CycleFold shape, the running CycleFold witness and error vector (key == nullptr: light)
 };
 
 inline void decider_limbs55(const U256w& v, uint64_t out[DEC_LIMBS]) {
@@ -61,7 +69,7 @@ inline CfFr decider_kzg_challenge(const CfFr& dg, const NnPoint& P) {
 inline uint32_t decider_n_public(uint32_t len_z) { return 2 + 2 * len_z + 4 * DEC_LIMBS + 4 + 2 * DEC_LIMBS; }
 
 // shape mode (cs.b set): appends the circuit to cs.b, public inputs first;  witness mode: cs.w = the assignment after wire 0
-inline void synthesize_decider(CS<BnFr>& cs, const cb::BuilderT<CfFr>& main, uint32_t len_z, const DeciderIn& in) {
+inline void synthesize_decider(CS<BnFr>& cs, const cb::BuilderT<CfFr>& main, uint32_t len_z, const DeciderIn& in, uint32_t* light_rows = nullptr) {
   typedef CfFr F;
   typedef Num<F> N;
   typedef cb::LCT<F> LC;
@@ -188,20 +196,37 @@ inline void synthesize_decider(CS<BnFr>& cs, const cb::BuilderT<CfFr>& main, uin
   };
   horner(Wv, cW, eW);
   horner(Ev, cE, eE);
+  // ---- 5, 6. the running CycleFold instance: its commitments opened, its relaxed relation checked (full decider) -----------------------------------
+  if (light_rows && cs.b) *light_rows = cs.b->n_constraints();
+  if (in.full.key) { DeciderCfGadget g(cs); g.synthesize(in.full, cu, cx, cWx, cWy, cEx, cEy, in.cfU); }
 }
 
 struct DeciderCircuit {
   cb::BuilderT<CfFr> b;
   uint32_t n_public = 0, len_z = 0;
-  void finish(const cb::BuilderT<CfFr>& main, uint32_t lz) {
+  bool full = false;                                   // checks 5 and 6 included
+  CfOpeningKey okey; const cb::BuilderT<CfFq>* cf_shape = nullptr;
+  uint32_t light_constraints = 0;                      // rows of checks 1-4 (the rest: 5 and 6)
+  // light: finish(main, lz).  full: also the CycleFold shape and the first max(its witness length, its rows) generators of its commitment key
+  void finish(const cb::BuilderT<CfFr>& main, uint32_t lz, const cb::BuilderT<CfFq>* cf = nullptr, const Affine<CfFr>* gens = nullptr, uint32_t n_gens = 0) {
     b = cb::BuilderT<CfFr>(); len_z = lz; n_public = decider_n_public(lz);
+    full = cf != nullptr; cf_shape = cf;
+    if (full) {
+      const uint32_t need = std::max(cf->n_wires - 1 - CF_IO, cf->n_constraints());
+      if (!gens || n_gens < need) throw std::runtime_error("decider: the CycleFold commitment key is shorter than the vectors it commits to");
+      okey.build(gens, need);
+    }
     CS<BnFr> cs; cs.b = &b; cs.base = b.n_wires;
     DeciderIn in; in.digest = CfFr::zero(); in.U = CfMainRelaxed::zero(); in.u = CfMainFresh::zero(); in.cfU = CfRelaxed::zero();
     in.cmT = in.Wn = in.En = NnPoint::zero(); in.eW = in.eE = CfFr::zero();
-    synthesize_decider(cs, main, lz, in);
+    if (full) { in.full.key = &okey; in.full.shape = cf; }
+    synthesize_decider(cs, main, lz, in, &light_constraints);
   }
-  // the full assignment (wire 0 = 1, then the public inputs); *bad: some check of the statement fails on these inputs
-  std::vector<CfFr> witness(const cb::BuilderT<CfFr>& main, const DeciderIn& in, bool* bad) const {
+  // the full assignment (wire 0 = 1, then the public inputs); *bad: some check of the statement fails on these inputs.
+  // Full decider: in.full.W / .E = the running CycleFold witness and error vector (key and shape are filled in here)
+  std::vector<CfFr> witness(const cb::BuilderT<CfFr>& main, const DeciderIn& in_, bool* bad) const {
+    DeciderIn in = in_;
+    if (full) { in.full.key = &okey; in.full.shape = cf_shape; } else in.full = CfFullIn();
     CS<BnFr> cs; cs.base = 1;
     cs.w.reserve(b.n_wires);
     synthesize_decider(cs, main, len_z, in);

@@ -63,11 +63,9 @@ SqrtParams sqrt_params() {
   return sp;
 }
 
+// generator `idx` of the key labelled `label` (ckgen.hpp: try-and-increment over SHAKE256), Montgomery coordinates.  Host and device.
 template <class F>
-__global__ void __launch_bounds__(256) k_ckgen(CkLabel label, SqrtParams sp, int b_small, size_t first, size_t n, uint32_t* __restrict__ out) {
-  size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  if (t >= n) return;
-  const uint64_t idx = first + t;
+VZ_HD void ckgen_point(const CkLabel& label, const SqrtParams& sp, int b_small, uint64_t idx, F* xo, F* yo) {
   uint8_t msg[80];
   for (int i = 0; i < label.len; i++) msg[i] = label.bytes[i];
   for (int i = 0; i < 8; i++) msg[label.len + i] = (uint8_t)(idx >> (8 * i));
@@ -91,11 +89,20 @@ __global__ void __launch_bounds__(256) k_ckgen(CkLabel label, SqrtParams sp, int
     if (!fp_sqrt(rhs, sp, &y)) continue;
     F yc = F::from_mont(y);
     if ((yc.v[0] & 1) != sign) y = F::neg(y);
-    uint4* o = reinterpret_cast<uint4*>(out + 16 * t);
-    o[0] = make_uint4(xm.v[0], xm.v[1], xm.v[2], xm.v[3]); o[1] = make_uint4(xm.v[4], xm.v[5], xm.v[6], xm.v[7]);
-    o[2] = make_uint4(y.v[0], y.v[1], y.v[2], y.v[3]); o[3] = make_uint4(y.v[4], y.v[5], y.v[6], y.v[7]);
+    *xo = xm; *yo = y;
     return;
   }
+}
+
+template <class F>
+__global__ void __launch_bounds__(256) k_ckgen(CkLabel label, SqrtParams sp, int b_small, size_t first, size_t n, uint32_t* __restrict__ out) {
+  size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  F xm, y;
+  ckgen_point<F>(label, sp, b_small, first + t, &xm, &y);
+  uint4* o = reinterpret_cast<uint4*>(out + 16 * t);
+  o[0] = make_uint4(xm.v[0], xm.v[1], xm.v[2], xm.v[3]); o[1] = make_uint4(xm.v[4], xm.v[5], xm.v[6], xm.v[7]);
+  o[2] = make_uint4(y.v[0], y.v[1], y.v[2], y.v[3]); o[3] = make_uint4(y.v[4], y.v[5], y.v[6], y.v[7]);
 }
 
 template <class F>

@@ -20,6 +20,11 @@
 
 namespace {
 
+// Secrets are wiped when they go out of scope: the trapdoor, everything derived from it that still determines it (powers of tau, the
+// Lagrange basis at tau, the query scalars), a proof's blinders.
+void wipe(void* p, size_t n) { explicit_bzero(p, n); }
+template <class T> void wipe(std::vector<T>& v) { if (!v.empty()) explicit_bzero(v.data(), v.size() * sizeof(T)); }
+
 // ---- Fq2 = Fq[u] / (u² + 1): coordinates of G2 (the twist y² = x³ + 3/(9 + u)) — pairing.hpp ------------------------------------------------
 using vz::pairing::Fq2;
 typedef Affine<Fq2> G2PAff;      // a point of BN254 G2
@@ -198,6 +203,7 @@ hipError_t fixed_base_batch(hipStream_t s, const std::vector<Fe>& sc, const Affi
   if (e == hipSuccess) e = hipGetLastError();
   if (e == hipSuccess) e = hipStreamSynchronize(s);
   hipFree(d_sc);
+  wipe(canon);
   return e;
 }
 // device std-form G1 points -> a commitment key in the MSM's resident form
@@ -223,7 +229,9 @@ hipError_t ntt(hipStream_t s, uint32_t* d, const G16Key& K, bool inverse) {
 
 
 // (A,B,C)·z of a builder's CSR on the host threads
-void host_spmv3(const cb::BuilderT<Fe>& b, const std::vector<Fe>& z, std::vector<Fe>* out /* [3] of n_c */) {
+template <class FF>
+void host_spmv3(const cb::BuilderT<FF>& b, const std::vector<FF>& z, std::vector<FF>* out /* [3] of n_c */) {
+  typedef FF Fe;
   const uint32_t nc = b.n_constraints();
   const cb::Csr* Ms[3] = {&b.A, &b.B, &b.C};
   for (int m = 0; m < 3; m++) out[m].assign(nc, Fe::zero());
@@ -251,12 +259,24 @@ bool os_random(void* buf, size_t n) {
   while (n) { const ssize_t k = getrandom(p, n, 0); if (k <= 0) return false; p += k; n -= (size_t)k; }
   return true;
 }
-struct Trapdoor { Fe tau, alpha, beta, gamma, delta; };
+struct Trapdoor { Fe tau, alpha, beta, gamma, delta; ~Trapdoor() { wipe(this, sizeof(*this)); } };
+// a uniform non-zero element of Fr by rejection (254-bit draws below the modulus: accepted with probability 0.76)
+bool fr_random(Fe* out) {
+  for (;;) {
+    uint8_t raw[32];
+    if (!os_random(raw, sizeof(raw))) return false;
+    raw[31] &= 0x3f;
+    Fe c; memcpy(c.v, raw, 32);
+    wipe(raw, sizeof(raw));
+    if (!c.is_reduced() || c.is_zero()) continue;
+    *out = Fe::to_mont(c);
+    wipe(&c, sizeof(c));
+    return true;
+  }
+}
 bool trapdoor_random(Trapdoor& t) {
-  uint8_t raw[5][32];
-  if (!os_random(raw, sizeof(raw))) return false;
   Fe* dst[5] = {&t.tau, &t.alpha, &t.beta, &t.gamma, &t.delta};
-  for (int k = 0; k < 5; k++) { raw[k][31] = 0; raw[k][0] |= 1; Fe c; memcpy(c.v, raw[k], 32); *dst[k] = Fe::to_mont(c); }      // 248 bits, never zero
+  for (int k = 0; k < 5; k++) if (!fr_random(dst[k])) return false;
   return true;
 }
 Trapdoor trapdoor_seeded(const uint8_t* seed, size_t n) {
@@ -275,6 +295,7 @@ U256w u256_of(const uint64_t* w) { U256w r; memcpy(r.w, w, 32); return r; }
 // KZG::setup: srs[i] = [tau^i]G1 for i < n (resident MSM form), vk = [tau]G2
 int kzg_setup_impl(vimz_ctx* ctx, const Fe& tau, size_t n, vimz_bases** srs_out, uint64_t vk_g2_out[16]) {
   std::vector<Fe> pw(n);
+  struct Wipe { std::vector<Fe>& v; ~Wipe() { wipe(v); } } wp{pw};
   { Fe t = Fe::one(); for (size_t i = 0; i < n; i++) { pw[i] = t; t = Fe::mul(t, tau); } }
   std::lock_guard<std::mutex> g(ctx->mu);
   P_TRY(hipSetDevice(ctx->device));
@@ -293,7 +314,61 @@ int kzg_setup_impl(vimz_ctx* ctx, const Fe& tau, size_t n, vimz_bases** srs_out,
   return VIMZ_OK;
 }
 
-int decider_setup_impl(vimz_cf* v, const uint64_t kzg_vk_g2[16], const Trapdoor& td, vimz_decider** out, double seconds[4]) {
+// the decider circuit for this prover's shapes: light (checks 1-4) or full (also the CycleFold instance's commitments and relation: the first
+// generators of the prover's CycleFold commitment key become constants of the circuit)
+int decider_circuit_build(vimz_cf* v, bool light, aug::DeciderCircuit& circ) {
+  vimz_ctx* ctx = v->ctx;
+  const cb::BuilderT<Fe>& main = v->circ->build->b;
+  std::vector<G2Aff> gens;
+  if (!light) {
+    const cb::BuilderT<Fq>& cfb = v->cf.b;
+    const size_t need = std::max<size_t>(cfb.n_wires - 1 - aug::CF_IO, cfb.n_constraints());
+    if (!v->ck2 || v->ck2->n < need) return vz_fail(ctx, VIMZ_ERR_INVALID, "decider: the CycleFold commitment key is shorter than the vectors it commits to");
+    gens.resize(need);
+    std::lock_guard<std::mutex> g(ctx->mu);
+    P_TRY(hipSetDevice(ctx->device));
+    uint32_t* tmp = nullptr;
+    P_TRY(hipMalloc((void**)&tmp, 64 * need));
+    struct FreeTmp { uint32_t* q; ~FreeTmp() { hipFree(q); } } ft{tmp};
+    launch_points_from_internal<Fe>(ctx->stream, v->ck2->d, 0, tmp, need);
+    P_TRY(hipGetLastError());
+    P_TRY(hipMemcpyAsync(gens.data(), tmp, 64 * need, hipMemcpyDeviceToHost, ctx->stream));
+    P_TRY(hipStreamSynchronize(ctx->stream));
+  }
+  try {
+    if (light) circ.finish(main, v->c1->len_z);
+    else circ.finish(main, v->c1->len_z, &v->cf.b, gens.data(), (uint32_t)gens.size());
+  } catch (const std::exception& e) { return vz_fail(ctx, VIMZ_ERR_INVALID, e.what()); }
+  return VIMZ_OK;
+}
+// [tau]G2 given with a prover whose main key is not the SRS it belongs to makes every later KZG check fail far from its cause:
+// e(srs[1], G2) == e(G1, [tau]G2) once, at set-up / load.  (srs[0] = G1 for an SRS made by vimz_kzg_setup; any other key fails here.)
+int kzg_vk_matches_srs(vimz_cf* v, const G2PAff& vk, const char* who) {
+  vimz_ctx* ctx = v->ctx;
+  G1Aff p01[2];
+  if (!v->ck1 || v->ck1->n < 2) return vz_fail(ctx, VIMZ_ERR_INVALID, "decider: the main commitment key is too short to be an SRS");
+  {
+    std::lock_guard<std::mutex> g(ctx->mu);
+    P_TRY(hipSetDevice(ctx->device));
+    uint32_t* tmp = nullptr;
+    P_TRY(hipMalloc((void**)&tmp, 128));
+    struct FreeTmp { uint32_t* q; ~FreeTmp() { hipFree(q); } } ft{tmp};
+    launch_points_from_internal<Fq>(ctx->stream, v->ck1->d, 0, tmp, 2);
+    P_TRY(hipGetLastError());
+    P_TRY(hipMemcpyAsync(p01, tmp, 128, hipMemcpyDeviceToHost, ctx->stream));
+    P_TRY(hipStreamSynchronize(ctx->stream));
+  }
+  const G1Aff g1 = g1_generator();
+  G1Aff ng = g1; ng.y = Fq::neg(g1.y);
+  if (!vz::pairing::consts().ok) return vz_fail(ctx, VIMZ_ERR_INVALID, "decider: pairing constants");
+  if (!p01[0].x.eq(g1.x) || !p01[0].y.eq(g1.y) || !vz::pairing::g1_on_curve(p01[1]) || !vz::pairing::product_is_one({{p01[1], g2_generator()}, {ng, vk}})) {
+    std::string m = std::string(who) + ": the KZG verifying key is not [tau]G2 of the SRS the prover commits with";
+    return vz_fail(ctx, VIMZ_ERR_INVALID, m.c_str());
+  }
+  return VIMZ_OK;
+}
+
+int decider_setup_impl(vimz_cf* v, const uint64_t kzg_vk_g2[16], const Trapdoor& td, bool light, vimz_decider** out, double seconds[4]) {
   vimz_ctx* ctx = v->ctx;
   const double t_all = now_s();
   std::unique_ptr<vimz_decider> d(new vimz_decider());
@@ -302,11 +377,10 @@ int decider_setup_impl(vimz_cf* v, const uint64_t kzg_vk_g2[16], const Trapdoor&
   if (kzg_vk_g2) {
     if (!get_g2(kzg_vk_g2, &d->kzg_vk) || !vz::pairing::g2_on_curve(d->kzg_vk) || !vz::pairing::g2_in_subgroup(d->kzg_vk))
       return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_decider_setup: the KZG verifying key is not a point of G2");
+    const int rcv = kzg_vk_matches_srs(v, d->kzg_vk, "vimz_decider_setup");
+    if (rcv) return rcv;
   }
-  try {
-    const cb::BuilderT<Fe>& main = v->circ->build->b;
-    d->circ.finish(main, v->c1->len_z);
-  } catch (const std::exception& e) { return vz_fail(ctx, VIMZ_ERR_INVALID, e.what()); }
+  { const int rcb = decider_circuit_build(v, light, d->circ); if (rcb) return rcb; }
   const double t_syn = now_s();
   G16Key& K = d->key;
   const cb::BuilderT<Fe>& b = d->circ.b;
@@ -325,6 +399,9 @@ int decider_setup_impl(vimz_cf* v, const uint64_t kzg_vk_g2[16], const Trapdoor&
   const Fe z_tau = Fe::sub(fr_pow_u64(tau, K.n), Fe::one());
   if (z_tau.is_zero()) return vz_fail(ctx, VIMZ_ERR_INVALID, "decider: tau lies in the domain");
   std::vector<Fe> L(K.n), den(K.n);
+  std::vector<Fe> uvw[3];
+  std::vector<Fe> lq, icq, hq;
+  struct WipeAll { std::vector<Fe>*v[8]; ~WipeAll() { for (auto* x : v) wipe(*x); } } wa{{&L, &den, &uvw[0], &uvw[1], &uvw[2], &lq, &icq, &hq}};
   { Fe w = Fe::one(); for (uint32_t j = 0; j < K.n; j++) { den[j] = Fe::sub(tau, w); L[j] = w; w = Fe::mul(w, K.omega); } }
   { std::vector<Fe> pre(K.n); Fe run = Fe::one();
     for (uint32_t j = 0; j < K.n; j++) { pre[j] = run; run = Fe::mul(run, den[j]); }
@@ -332,7 +409,6 @@ int decider_setup_impl(vimz_cf* v, const uint64_t kzg_vk_g2[16], const Trapdoor&
     for (uint32_t j = K.n; j-- > 0;) { const Fe dj = den[j]; den[j] = Fe::mul(inv, pre[j]); inv = Fe::mul(inv, dj); } }
   { const Fe c = Fe::mul(z_tau, K.n_inv); for (uint32_t j = 0; j < K.n; j++) L[j] = Fe::mul(Fe::mul(L[j], den[j]), c); }
   // u_i = A_i(tau), v_i = B_i(tau), w_i = C_i(tau); the constant and the public inputs get a row of their own (a = z_i, b = c = 0)
-  std::vector<Fe> uvw[3];
   for (int q = 0; q < 3; q++) uvw[q].assign(K.m, Fe::zero());
   { const cb::Csr* Ms[3] = {&b.A, &b.B, &b.C};
     std::vector<std::thread> th;
@@ -343,7 +419,7 @@ int decider_setup_impl(vimz_cf* v, const uint64_t kzg_vk_g2[16], const Trapdoor&
     });
     for (auto& x : th) x.join();
     for (uint32_t i = 0; i <= K.n_pub; i++) uvw[0][i] = Fe::add(uvw[0][i], L[K.n_c + i]); }
-  std::vector<Fe> lq(K.m - K.n_pub - 1), icq(K.n_pub + 1), hq(K.n - 1);
+  lq.assign(K.m - K.n_pub - 1, Fe::zero()); icq.assign(K.n_pub + 1, Fe::zero()); hq.assign(K.n - 1, Fe::zero());
   for (uint32_t i = 0; i < K.m; i++) {
     const Fe k = Fe::add(Fe::add(Fe::mul(beta, uvw[0][i]), Fe::mul(alpha, uvw[1][i])), uvw[2][i]);
     if (i <= K.n_pub) icq[i] = Fe::mul(k, gamma_inv); else lq[i - K.n_pub - 1] = Fe::mul(k, delta_inv);
@@ -498,11 +574,13 @@ int vimz_kzg_setup(vimz_ctx* ctx, size_t n, vimz_bases** srs_out, uint64_t vk_g2
 // reference's own `StdRng::from_seed([41; 32])` (mod.rs:54) is, too; a deployment would import keys from a ceremony instead.
 // kzg_vk_g2 (optional): [tau]G2 of the SRS the prover's ck_main is made of (vimz_kzg_setup) — needed by vimz_decider_verify and part of vimz_decider_vk.
 // seconds (optional) = {circuit synthesis, QAP evaluation at the trapdoor, key points on the GPU, total}.
-int vimz_decider_setup(vimz_cf* v, const uint64_t kzg_vk_g2[16], vimz_decider** out, double seconds[4]) {
+// light != 0: the shrunken circuit of the reference's opt-in `light-test` feature (vimz/Cargo.toml:56-59; checks 1-4 of aug/decider.hpp: the CycleFold
+// instance is bound by its hash only); light == 0: the full decider, as `decider.rs:13-21` instantiates it (≈ 2.75 M constraints more: set-up in seconds).
+int vimz_decider_setup(vimz_cf* v, const uint64_t kzg_vk_g2[16], int light, vimz_decider** out, double seconds[4]) {
   if (!v || !out) return VIMZ_ERR_INVALID;
   Trapdoor t;
   if (!trapdoor_random(t)) return vz_fail(v->ctx, VIMZ_ERR_INVALID, "vimz_decider_setup: no randomness from the OS");
-  return decider_setup_impl(v, kzg_vk_g2, t, out, seconds);
+  return decider_setup_impl(v, kzg_vk_g2, t, light != 0, out, seconds);
 }
 #ifdef VIMZ_TESTING
 // Host only, no GPU: the decider circuit (aug/decider.hpp) over the Nova + CycleFold recursion of the trivial step circuit with made-up commitments — the
@@ -510,8 +588,12 @@ int vimz_decider_setup(vimz_cf* v, const uint64_t kzg_vk_g2[16], vimz_decider** 
 // result bit 0 a step's F' witness is bad, 1 the folded scalars differ from F''s, 2 the decider's witness generator flags the honest input, 3 its witness
 // violates a row of the decider's R1CS, 4 the public inputs are not the contract's layout (pp_hash, i, z_0, z_i, 4 x 5 limbs, c_W, c_E, e_W, e_E, 2 x 5 limbs),
 // 5 a wrong KZG evaluation / a wrong challenge / a changed cmT limb is NOT flagged, 6 a changed public input leaves every row satisfied.
+// full != 0: the FULL decider (aug/decider_cf.hpp) — the CycleFold instances of every step are real here (witnesses of the CycleFold circuit for the step's
+// two folds, committed under a made-up key G_k = (k + 1)·G, folded on the host into a running witness and error vector): 7 the host's running CycleFold
+// instance differs from the one F' folds in-circuit, 8 a running CycleFold witness / error vector that violates its relation, or a commitment that does not
+// open to it, is NOT flagged by the witness generator, 9 such a witness leaves every row of the decider satisfied.
 // counts = {decider constraints, wires, public inputs, main constraints}.
-int vimz_decider_selfcheck(int steps, uint32_t* result, uint64_t counts[4]) {
+int vimz_decider_selfcheck(int steps, int full, uint32_t* result, uint64_t counts[4]) {
   if (!result || steps < 2 || steps > 32) return VIMZ_ERR_INVALID;
   try {
     CfCircuit cf; cf.finish();
@@ -530,6 +612,40 @@ int vimz_decider_selfcheck(int steps, uint32_t* result, uint64_t counts[4]) {
     CfMainFresh u = CfMainFresh::zero(); G1Aff uW = g1_identity();
     CfRelaxed cfU = CfRelaxed::zero();
     std::vector<Fe> Zrun(nw, Fe::zero()), Erun(nc, Fe::zero()), z_last;
+    // full: the running CycleFold pair on the host, committed under G_k = (k + 1)·G (a made-up key: Σ v_k·G_k is one multiplication by Σ (k + 1)·v_k)
+    const uint32_t cnw = cf.b.n_wires, cnc = cf.b.n_constraints(), cnW = cnw - 1 - aug::CF_IO;
+    std::vector<Fq> cfZ(cnw, Fq::zero()), cfE(cnc, Fq::zero());
+    G2Aff cf_cmW = g2_identity(), cf_cmE = g2_identity();
+    auto cf_commit = [&](const Fq* v, size_t n) {
+      Fq s = Fq::zero();
+      for (size_t k = 0; k < n; k++) s = Fq::add(s, Fq::mul(v[k], cb::f_from_u64<Fq>(k + 1)));
+      const Fq c = Fq::from_mont(s);
+      return to_affine(host_mul<Fe>(g2, c.v, 256));
+    };
+    auto g2_fold = [&](const G2Aff& P, const uint32_t low[4], const G2Aff& Q) {
+      const uint32_t k[5] = {low[0], low[1], low[2], low[3], 1u};
+      G2 a = aff_is_identity(P) ? G2::identity() : from_affine(P);
+      if (!aff_is_identity(Q)) { G2 t = host_mul<Fe>(Q, k, 129); add_full(a, t); }
+      return to_affine(a);
+    };
+    // one CycleFold instance (r, P1, P2 -> P3 = P1 + r·P2): witness, commitments, and — once the caller has the challenge — the fold into the running pair
+    struct CfInst { std::vector<Fq> z, T; G2Aff cmW, cmT; };
+    auto cf_instance = [&](const uint32_t r_low[4], const G1Aff& P1, const G1Aff& P2, CfInst& o) {
+      bool bad = false;
+      cf.witness(r_low, P1, P2, o.z, &bad);
+      if (bad) res |= 1;
+      std::vector<Fq> p1[3], p2[3];
+      host_spmv3(cf.b, cfZ, p1); host_spmv3(cf.b, o.z, p2);
+      o.T.resize(cnc);
+      for (uint32_t k = 0; k < cnc; k++) o.T[k] = Fq::sub(Fq::sub(Fq::add(Fq::mul(p1[0][k], p2[1][k]), Fq::mul(p2[0][k], p1[1][k])), Fq::mul(cfZ[0], p2[2][k])), p1[2][k]);
+      o.cmW = cf_commit(o.z.data() + 1, cnW); o.cmT = cf_commit(o.T.data(), cnc);
+    };
+    auto cf_fold_in = [&](const CfInst& o, const uint32_t r_low[4]) {
+      const Fq r = rho_element<Fq>(r_low);
+      for (uint32_t k = 0; k < cnw; k++) cfZ[k] = Fq::add(cfZ[k], Fq::mul(r, o.z[k]));
+      for (uint32_t k = 0; k < cnc; k++) cfE[k] = Fq::add(cfE[k], Fq::mul(r, o.T[k]));
+      cf_cmW = g2_fold(cf_cmW, r_low, o.cmW); cf_cmE = g2_fold(cf_cmE, r_low, o.cmT);
+    };
     // x1 += r·x2 over the main shape, with the cross term folded into E:  returns nothing, updates Zrun / Erun
     auto fold_in = [&](const std::vector<Fe>& z2, const Fe& r) {
       std::vector<Fe> p1[3], p2[3];
@@ -552,13 +668,30 @@ int vimz_decider_selfcheck(int steps, uint32_t* result, uint64_t counts[4]) {
         cf_challenge_main(ch, u, in.T);
         Wn = g1_fold(UW, ch.r, uW); En = g1_fold(UE, ch.r, cT);
         in.Wn = nn_point(Wn); in.En = nn_point(En);
-        in.cf1W = fake2(0x2000 + i); in.cf1T = i > 1 ? fake2(0x3000 + i) : g2_identity();
-        in.cf2W = fake2(0x4000 + i); in.cf2T = fake2(0x5000 + i);
+        if (full) {
+          CfInst i1, i2;
+          cf_instance(ch.r, UW, uW, i1);
+          in.cf1W = i1.cmW; in.cf1T = i1.cmT;
+          cf_challenge_cf1(ch, in.cf1W, in.Wn, in.cf1T);
+          cf_fold_in(i1, ch.r1);
+          cf_instance(ch.r, UE, cT, i2);
+          in.cf2W = i2.cmW; in.cf2T = i2.cmT;
+          cf_challenge_cf2(ch, in.cf2W, in.En, in.cf2T);
+          cf_fold_in(i2, ch.r2);
+        } else {
+          in.cf1W = fake2(0x2000 + i); in.cf1T = i > 1 ? fake2(0x3000 + i) : g2_identity();
+          in.cf2W = fake2(0x4000 + i); in.cf2T = fake2(0x5000 + i);
+        }
         fold_in(z_last, rho_element<Fe>(ch.r));      // what this step's F' verifies: U_i = U_{i-1} (+) u_{i-1}
       }
       std::vector<Fe> augw; bool bad = false;
       CfMainOut o = c1.witness(in, z0.data(), z0.data(), augw, &bad);
       if (bad) res |= 1;
+      if (full && i > 0) {      // the instance F' folded in-circuit is the one the host keeps
+        const CfRelaxed& n = o.cfU_new;
+        if (!n.W.x.eq(cf_cmW.x) || !n.W.y.eq(cf_cmW.y) || !n.E.x.eq(cf_cmE.x) || !n.E.y.eq(cf_cmE.y) || !cross_field<Fe>(cfZ[0]).eq(n.u)) res |= 128;
+        for (int k = 0; k < aug::CF_IO; k++) if (memcmp(to_u256(cfZ[cnw - aug::CF_IO + k]).w, n.x[k].w, 32)) res |= 128;
+      }
       std::vector<Fe> z = {Fe::one(), z0[0], z0[0]};
       z.insert(z.end(), augw.begin(), augw.end());
       if (i > 0 && (!o.U_new.u.eq(Zrun[0]) || !o.U_new.x0.eq(Zrun[nw - 2]) || !o.U_new.x1.eq(Zrun[nw - 1]))) res |= 2;
@@ -578,7 +711,14 @@ int vimz_decider_selfcheck(int steps, uint32_t* result, uint64_t counts[4]) {
     auto horner = [](const Fe* v, size_t n, const Fe& c) { Fe acc = Fe::zero(); for (size_t j = n; j-- > 0;) acc = Fe::add(Fe::mul(acc, c), v[j]); return acc; };
     in.eW = horner(Zrun.data() + 1, nw - 3, cW); in.eE = horner(Erun.data(), nc, cE);
     in.Wf = Zrun.data() + 1; in.Ef = Erun.data();
-    aug::DeciderCircuit dc; dc.finish(b, 1);
+    aug::DeciderCircuit dc;
+    if (full) {
+      std::vector<G2Aff> gens(std::max(cnW, cnc));
+      G2 acc = from_affine(g2);
+      for (auto& p : gens) { p = to_affine(acc); add_mixed(acc, g2); }
+      dc.finish(b, 1, &cf.b, gens.data(), (uint32_t)gens.size());
+      in.full.W = cfZ.data() + 1; in.full.E = cfE.data();
+    } else dc.finish(b, 1);
     if (counts) { counts[0] = dc.b.n_constraints(); counts[1] = dc.b.n_wires; counts[2] = dc.n_public; counts[3] = nc; }
     bool bad = false;
     std::vector<Fe> zd = dc.witness(b, in, &bad);
@@ -597,6 +737,21 @@ int vimz_decider_selfcheck(int steps, uint32_t* result, uint64_t counts[4]) {
     { aug::DeciderIn t = in; t.cmT = nn_point(fake1(0x7778)); bool b2 = false; dc.witness(b, t, &b2); if (!b2) res |= 32; }      // (another r: the folded scalars no longer match W')
     // ... and every public input matters to some row
     for (uint32_t k = 0; k < dc.n_public; k++) { std::vector<Fe> zz = zd; zz[1 + k] = Fe::add(zz[1 + k], Fe::one()); if (!violated(zz)) res |= 64; }
+    if (full) {
+      // negatives of checks 5 and 6: a changed witness element (the commitment no longer opens, a row no longer holds), a changed error element,
+      // and a witness changed TOGETHER with its commitment (opens, but the relation fails: check 6 alone)
+      auto flagged = [&](const std::vector<Fq>& Zc, const std::vector<Fq>& Ec) {
+        aug::DeciderIn t = in; t.full.W = Zc.data() + 1; t.full.E = Ec.data();
+        bool b2 = false; std::vector<Fe> zz = dc.witness(b, t, &b2);
+        return std::make_pair(b2, violated(zz));
+      };
+      { std::vector<Fq> Zc = cfZ; Zc[5] = Fq::add(Zc[5], Fq::one()); auto f = flagged(Zc, cfE); if (!f.first) res |= 256; if (!f.second) res |= 512; }
+      { std::vector<Fq> Ec = cfE; Ec[3] = Fq::add(Ec[3], Fq::one()); auto f = flagged(cfZ, Ec); if (!f.first) res |= 256; if (!f.second) res |= 512; }
+      // (under G_k = (k + 1)·G, adding b + 1 to element a and taking a + 1 off element b leaves the commitment as it was: only the relation can object)
+      { std::vector<Fq> Zc = cfZ; Zc[1 + 4] = Fq::add(Zc[1 + 4], cb::f_from_u64<Fq>(10)); Zc[1 + 9] = Fq::sub(Zc[1 + 9], cb::f_from_u64<Fq>(5));
+        if (!(cf_commit(Zc.data() + 1, cnW).x.eq(cf_cmW.x))) res |= 256;
+        auto f = flagged(Zc, cfE); if (!f.first) res |= 256; if (!f.second) res |= 512; }
+    }
     *result = res;
     return VIMZ_OK;
   } catch (const std::exception& e) { return vz_fail(nullptr, VIMZ_ERR_INVALID, e.what()); }
@@ -606,17 +761,17 @@ int vimz_testing_kzg_setup_seeded(vimz_ctx* ctx, const uint8_t* seed, size_t see
   if (!ctx || !srs_out || !vk_g2_out || !n || (!seed && seed_len)) return VIMZ_ERR_INVALID;
   return kzg_setup_impl(ctx, fr_from_hash(seed, seed_len, "vimz-kzg-tau"), n, srs_out, vk_g2_out);
 }
-int vimz_testing_decider_setup_seeded(vimz_cf* v, const uint64_t kzg_vk_g2[16], const uint8_t* seed, size_t seed_len, vimz_decider** out, double seconds[4]) {
+int vimz_testing_decider_setup_seeded(vimz_cf* v, const uint64_t kzg_vk_g2[16], int light, const uint8_t* seed, size_t seed_len, vimz_decider** out, double seconds[4]) {
   if (!v || !out || (!seed && seed_len)) return VIMZ_ERR_INVALID;
-  return decider_setup_impl(v, kzg_vk_g2, trapdoor_seeded(seed, seed_len), out, seconds);
+  return decider_setup_impl(v, kzg_vk_g2, trapdoor_seeded(seed, seed_len), light != 0, out, seconds);
 }
 #endif
 
-// info = {constraints, wires, public inputs, domain size, non-zeros of A, B, C, 0}
+// info = {constraints, wires, public inputs, domain size, non-zeros of A, B, C, rows of checks 5 and 6 (0: the light decider)}
 int vimz_decider_info(const vimz_decider* d, uint64_t info[8]) {
   if (!d || !info) return VIMZ_ERR_INVALID;
   const cb::BuilderT<Fe>& b = d->circ.b;
-  info[0] = d->key.n_c; info[1] = d->key.m; info[2] = d->key.n_pub; info[3] = d->key.n; info[4] = b.A.col.size(); info[5] = b.B.col.size(); info[6] = b.C.col.size(); info[7] = 0;
+  info[0] = d->key.n_c; info[1] = d->key.m; info[2] = d->key.n_pub; info[3] = d->key.n; info[4] = b.A.col.size(); info[5] = b.B.col.size(); info[6] = b.C.col.size(); info[7] = d->circ.full ? d->key.n_c - d->circ.light_constraints : 0;
   return VIMZ_OK;
 }
 
@@ -643,19 +798,20 @@ int64_t vimz_decider_vk(const vimz_decider* d, void* buf, size_t cap) {
 // ---- the key at rest: vimz_decider_key_save / _load -------------------------------------------------------------------------------------------------------
 // A Groth16 key pair for the decider circuit as bytes, so that a set-up is made ONCE per circuit and shape (0.4 s instead of 0.8 s per run at contrast HD) and —
 // the point of ADVICE r4 — so that keys made ELSEWHERE (a ceremony's, converted to this layout) can be used: the library then never sees a trapdoor.
-// Layout (little-endian u64 words; curve points canonical, G1 (x, y), G2 (x.c0, x.c1, y.c0, y.c1)): magic, m, n_pub, n_c, n, len_z, pp_hash (4), KZG [tau]G2 (16),
+// Layout (little-endian u64 words; curve points canonical, G1 (x, y), G2 (x.c0, x.c1, y.c0, y.c1)): magic, m, n_pub, n_c, n, len_z, mode (0 full, 1 light), pp_hash (4), KZG [tau]G2 (16),
 // alpha1, beta1, delta1 (8 each), beta2, gamma2, delta2 (16 each), IC (8 x (n_pub + 1)), then the queries a (8 m), b1 (8 m), l (8 (m - n_pub - 1)), h (8 (n - 1)), b2 (16 m).
 // A loaded key is TRUSTED like any common reference string: its points are range- and curve-checked for the verifying part, the queries are taken as they are
 // (a wrong query makes proofs that do not verify, nothing worse).
-static const uint64_t G16_KEY_MAGIC = 0x3159454b36314756ull;      // "VG16KEY1"
+static const uint64_t G16_KEY_MAGIC = 0x3259454b36314756ull;      // "VG16KEY2"
+static const size_t G16_KEY_HEADER = 7;
 int64_t vimz_decider_key_save(vimz_decider* d, void* buf, size_t cap) {
   if (!d) return VIMZ_ERR_INVALID;
   const G16Key& K = d->key; vimz_ctx* ctx = d->ctx;
   const size_t nq[4] = {K.m, K.m, (size_t)K.m - K.n_pub - 1, (size_t)K.n - 1};
-  const size_t words = 6 + 4 + 16 + 24 + 48 + 8 * (size_t)(K.n_pub + 1) + 8 * (nq[0] + nq[1] + nq[2] + nq[3]) + 16 * (size_t)K.m;
+  const size_t words = G16_KEY_HEADER + 4 + 16 + 24 + 48 + 8 * (size_t)(K.n_pub + 1) + 8 * (nq[0] + nq[1] + nq[2] + nq[3]) + 16 * (size_t)K.m;
   if (!buf || cap < 8 * words) return (int64_t)(8 * words);
   uint64_t* w = (uint64_t*)buf; size_t pos = 0;
-  w[pos++] = G16_KEY_MAGIC; w[pos++] = K.m; w[pos++] = K.n_pub; w[pos++] = K.n_c; w[pos++] = K.n; w[pos++] = d->circ.len_z;
+  w[pos++] = G16_KEY_MAGIC; w[pos++] = K.m; w[pos++] = K.n_pub; w[pos++] = K.n_c; w[pos++] = K.n; w[pos++] = d->circ.len_z; w[pos++] = d->circ.full ? 0 : 1;
   { const Fe c = Fe::from_mont(d->vk->c1->digest); memcpy(w + pos, c.v, 32); pos += 4; }
   put_g2(w + pos, d->kzg_vk); pos += 16;
   for (const G1Aff* p : {&K.alpha1, &K.beta1, &K.delta1}) { put_fq(w + pos, p->x); put_fq(w + pos + 4, p->y); pos += 8; }
@@ -688,10 +844,10 @@ int vimz_decider_key_load(vimz_cf* v, const void* buf, size_t len, vimz_decider*
   if (!v || !buf || !out || (len & 7)) return VIMZ_ERR_INVALID;
   vimz_ctx* ctx = v->ctx;
   const uint64_t* w = (const uint64_t*)buf; const size_t nwords = len / 8;
-  if (nwords < 6 + 4 + 16 + 24 + 48 || w[0] != G16_KEY_MAGIC) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_decider_key_load: not a decider key");
+  if (nwords < G16_KEY_HEADER + 4 + 16 + 24 + 48 || w[0] != G16_KEY_MAGIC || w[6] > 1) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_decider_key_load: not a decider key");
   std::unique_ptr<vimz_decider> d(new vimz_decider());
   d->vk = v; d->ctx = ctx;
-  try { d->circ.finish(v->circ->build->b, v->c1->len_z); } catch (const std::exception& e) { return vz_fail(ctx, VIMZ_ERR_INVALID, e.what()); }
+  { const int rcb = decider_circuit_build(v, w[6] == 1, d->circ); if (rcb) return rcb; }
   G16Key& K = d->key;
   const cb::BuilderT<Fe>& b = d->circ.b;
   K.m = b.n_wires; K.n_pub = d->circ.n_public; K.n_c = b.n_constraints();
@@ -700,13 +856,14 @@ int vimz_decider_key_load(vimz_cf* v, const void* buf, size_t len, vimz_decider*
   size_t pos = 1;
   if (w[pos] != K.m || w[pos + 1] != K.n_pub || w[pos + 2] != K.n_c || w[pos + 3] != K.n || w[pos + 4] != d->circ.len_z)
     return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_decider_key_load: the key is for a decider circuit of other sizes");
-  pos += 5;
+  pos += 6;
   { Fe c; memcpy(c.v, w + pos, 32); if (!c.is_reduced() || !Fe::to_mont(c).eq(v->c1->digest)) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_decider_key_load: the key is for other circuits (public-parameter hash)"); pos += 4; }
   const size_t nq[4] = {K.m, K.m, (size_t)K.m - K.n_pub - 1, (size_t)K.n - 1};
-  const size_t words = 6 + 4 + 16 + 24 + 48 + 8 * (size_t)(K.n_pub + 1) + 8 * (nq[0] + nq[1] + nq[2] + nq[3]) + 16 * (size_t)K.m;
+  const size_t words = G16_KEY_HEADER + 4 + 16 + 24 + 48 + 8 * (size_t)(K.n_pub + 1) + 8 * (nq[0] + nq[1] + nq[2] + nq[3]) + 16 * (size_t)K.m;
   if (nwords != words) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_decider_key_load: wrong length");
   using vz::pairing::g1_on_curve; using vz::pairing::g2_in_subgroup;
   if (!get_g2(w + pos, &d->kzg_vk) || !g2_on_curve(d->kzg_vk) || !g2_in_subgroup(d->kzg_vk)) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_decider_key_load: KZG verifying key"); pos += 16;
+  if (!aff_is_identity(d->kzg_vk)) { const int rcv = kzg_vk_matches_srs(v, d->kzg_vk, "vimz_decider_key_load"); if (rcv) return rcv; }
   for (G1Aff* p : {&K.alpha1, &K.beta1, &K.delta1}) { if (!get_g1(w + pos, p) || !g1_on_curve(*p)) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_decider_key_load: a G1 key point"); pos += 8; }
   for (G2PAff* p : {&K.beta2, &K.gamma2, &K.delta2}) { if (!get_g2(w + pos, p) || !g2_on_curve(*p) || !g2_in_subgroup(*p)) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_decider_key_load: a G2 key point"); pos += 16; }
   K.ic.resize(K.n_pub + 1);
@@ -810,10 +967,23 @@ int vimz_decider_prove(vimz_decider* d, vimz_cf* ivc, uint64_t* public_out, uint
   in.U = ivc->U; in.u = ivc->u; in.cfU = ivc->cfU;
   { Fe c; memcpy(c.v, kzg_out[0], 32); in.eW = Fe::to_mont(c); memcpy(c.v, kzg_out[1], 32); in.eE = Fe::to_mont(c); }
   in.Wf = Wf.data() + 1; in.Ef = Ef.data();
+  std::vector<Fq> cfZ, cfE;
+  if (d->circ.full) {      // checks 5 and 6: the running CycleFold pair's witness and error vector
+    const SecDev& S = ivc->sec;
+    if (ivc->ck2 != v->ck2 || S.n_w != v->cf.b.n_wires || S.n_c != v->cf.b.n_constraints())
+      return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_decider_prove: the IVC proof's CycleFold key / shape is not the one the full decider was set up for");
+    cfZ.resize(S.n_w); cfE.resize(S.n_c);
+    std::lock_guard<std::mutex> g(ctx->mu);
+    P_TRY(hipSetDevice(ctx->device));
+    P_TRY(hipMemcpyAsync(cfZ.data(), S.Zrun, 32 * (size_t)S.n_w, hipMemcpyDeviceToHost, ctx->stream));
+    P_TRY(hipMemcpyAsync(cfE.data(), S.E, 32 * (size_t)S.n_c, hipMemcpyDeviceToHost, ctx->stream));
+    P_TRY(hipStreamSynchronize(ctx->stream));
+    in.full.W = cfZ.data() + 1; in.full.E = cfE.data();
+  }
   std::vector<Fe> z;
   bool bad = false;
   try { z = d->circ.witness(v->circ->build->b, in, &bad); } catch (const std::exception& e) { return vz_fail(ctx, VIMZ_ERR_INVALID, e.what()); }
-  if (bad) return vz_fail(ctx, VIMZ_ERR_UNSAT, "vimz_decider_prove: the IVC proof does not satisfy the decider's statement (hashes, relaxed relation or KZG evaluations)");
+  if (bad) return vz_fail(ctx, VIMZ_ERR_UNSAT, "vimz_decider_prove: the IVC proof does not satisfy the decider's statement (hashes, relaxed relations, CycleFold commitments or KZG evaluations)");
   std::vector<Fe> abc[3];
   host_spmv3(d->circ.b, z, abc);
   for (int q = 0; q < 3; q++) abc[q].resize(K.n, Fe::zero());
@@ -842,15 +1012,17 @@ int vimz_decider_prove(vimz_decider* d, vimz_cf* ivc, uint64_t* public_out, uint
   const double t_ntt = now_s();
   // the multi-scalar multiplications
   uint64_t pt[8];
-  auto g1_msm = [&](const vimz_bases* q, const uint32_t* sc, size_t n, G1Aff* outp) -> int {
+  // (the wires' MSMs take unit scalars out first: a third of the full decider's wires are bits)
+  auto g1_msm = [&](const vimz_bases* q, const uint32_t* sc, size_t n, G1Aff* outp, int split_ones) -> int {
     if (!n) { outp->x = Fq::zero(); outp->y = Fq::zero(); return VIMZ_OK; }
-    const int r2 = vz_msm_device(ctx, q, 0, sc, n, 1, 0, pt, VIMZ_FORM_MONTGOMERY);
+    const int r2 = vz_msm_device(ctx, q, 0, sc, n, 1, 0, pt, VIMZ_FORM_MONTGOMERY, split_ones);
     if (!r2) { memcpy(outp->x.v, pt, 32); memcpy(outp->y.v, pt + 4, 32); }
     return r2;
   };
   G1Aff sa, sb1, sl, sh;
-  if ((rc = g1_msm(K.a_q, dz, K.m, &sa)) || (rc = g1_msm(K.b1_q, dz, K.m, &sb1)) || (rc = g1_msm(K.l_q, dz + 8 * (size_t)(K.n_pub + 1), K.m - K.n_pub - 1, &sl)) ||
-      (rc = g1_msm(K.h_q, dv[0], K.n - 1, &sh))) return rc;
+  const int so = d->circ.full ? 1 : 0;
+  if ((rc = g1_msm(K.a_q, dz, K.m, &sa, so)) || (rc = g1_msm(K.b1_q, dz, K.m, &sb1, so)) || (rc = g1_msm(K.l_q, dz + 8 * (size_t)(K.n_pub + 1), K.m - K.n_pub - 1, &sl, so)) ||
+      (rc = g1_msm(K.h_q, dv[0], K.n - 1, &sh, 0))) return rc;
   const unsigned PT = 128 * 256;
   P_TRY(hipMalloc((void**)&dpart, sizeof(G2P) * PT));
   hipLaunchKernelGGL(k_msm_naive<Fq2>, dim3(PT / 128), dim3(128), 0, s, (const G2PAff*)K.b2_q, (const uint32_t*)dz, (size_t)K.m, dpart);
@@ -863,8 +1035,8 @@ int vimz_decider_prove(vimz_decider* d, vimz_cf* ivc, uint64_t* public_out, uint
   const double t_msm = now_s();
   // A = alpha + Σ z_i a_i + r·delta;  B = beta + Σ z_i b_i + s·delta;  C = Σ_priv z_i l_i + Σ h_j hq_j + s·A + r·B1 − r·s·delta;  r, s fresh from the OS (zero knowledge)
   Fe r, sr;
-  { uint8_t raw[2][32]; if (!os_random(raw, sizeof(raw))) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_decider_prove: no randomness from the OS");
-    raw[0][31] = raw[1][31] = 0; Fe c; memcpy(c.v, raw[0], 32); r = Fe::to_mont(c); memcpy(c.v, raw[1], 32); sr = Fe::to_mont(c); }
+  struct WipeRs { Fe *a, *b; ~WipeRs() { wipe(a, sizeof(Fe)); wipe(b, sizeof(Fe)); } } wrs{&r, &sr};
+  if (!fr_random(&r) || !fr_random(&sr)) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_decider_prove: no randomness from the OS");
   G1 A = from_affine(K.alpha1); add_mixed(A, sa); { G1 t = host_mul_fr<Fq>(K.delta1, r); add_full(A, t); }
   G1 B1 = from_affine(K.beta1); add_mixed(B1, sb1); { G1 t = host_mul_fr<Fq>(K.delta1, sr); add_full(B1, t); }
   G2P B2 = from_affine(K.beta2); add_full(B2, sb2); { G2P t = host_mul_fr<Fq2>(K.delta2, sr); add_full(B2, t); }

@@ -232,14 +232,49 @@ def _decode_offer(raw):
     return header, raw[4 + n:]
 
 
+def _abort_upwards(dist, rank, why):
+    """tell the rank that will wait for this rank's hand-over that it is not coming"""
+    if rank != 0:
+        try:
+            _send_bytes(dist, _encode_offer({"kind": "abort", "error": str(why)[:500], "from": rank}), rank - (rank & -rank))
+        except Exception:      # (best effort: the process group may already be gone)
+            pass
+
+
+def _refuse_senders(dist, rank, world, first_step):
+    """the ranks that would hand over to this rank in rounds first_step, 2·first_step, ...: take their offers and answer "fail", so that they raise
+    instead of waiting (an abort marker needs no answer)"""
+    st = max(1, first_step)
+    while st < world and rank % (2 * st) == 0:
+        src2 = rank + st
+        if src2 < world:
+            try:
+                m2, _ = _decode_offer(_recv_bytes(dist, src2))
+                if m2["kind"] != "abort":
+                    _send_bytes(dist, b"fail", src2)
+            except Exception:
+                pass
+        st *= 2
+
+
+def tree_abort(rank, world, dist, why):
+    """A rank that cannot even ENTER the tree (its own fold raised): the same courtesy as a failed merge — the rank above learns that the hand-over is not
+    coming, the ranks below are answered "fail" — so that nobody sits in a blocking receive until the process group's timeout."""
+    _abort_upwards(dist, rank, why)
+    _refuse_senders(dist, rank, world, 1)
+
+
 def tree_final_fold(proof, vk, rank, world, dist, merged_cls, shm_dir=None, timings=None):
     """The ranks' final fold as a log-depth pairwise tree ON THE RANKS' OWN GPUs (the north_star's "host-side sequential final fold" with
     the sequence shortened to ceil(log2 N) merges on the critical path): in round k rank r + 2^k hands its merged proof to rank r, which
     folds it in (Node(A, B) of DESIGN.md §6b — one cross term, one large MSM, one fused fold, on r's GPU); pairs start as soon as both
     sides are ready — no barrier.  Hand-over, in order of preference: a HIP IPC ticket (device-to-device copy incl. the running products,
     merged_cls.open_shared), a file in node-local shared memory (save -> load), bytes through gloo.  Returns the proof on rank 0.
-    A failure anywhere travels UP the tree: the failing rank answers its sender "fail" (which raises there), sends an abort marker to the rank
-    that is waiting for ITS hand-over, and raises; a rank that receives an abort marker does the same — nobody is left in a blocking receive."""
+    A failure travels UP the tree: a rank whose merge, IPC open or decode fails answers its sender "fail" (which raises there), sends an abort marker to
+    the rank that is waiting for ITS hand-over, refuses its later senders, and raises; a rank that receives an abort marker does the same; a sender that
+    cannot make its offer (save / share raised) sends the abort marker instead of the offer; a rank whose own FOLD raised never gets here — prove_sharded
+    calls tree_abort for it.  Nobody is left in a blocking receive.  (Failures before the digest exchange — a collective — surface at the peers as the
+    process group's error when the failing rank exits.)"""
     import os
     import time
     # VIMZ_SHARD_TRANSPORT = ipc | file | bytes pins the hand-over; "ipc-fail" makes the receiver's IPC open fail, to exercise the fallback;
@@ -251,26 +286,10 @@ def tree_final_fold(proof, vk, rank, world, dist, merged_cls, shm_dir=None, timi
     step = 1
 
     def abort_upwards(why):
-        """tell the rank that will wait for this rank's hand-over that it is not coming"""
-        if rank != 0:
-            try:
-                _send_bytes(dist, _encode_offer({"kind": "abort", "error": str(why)[:500], "from": rank}), rank - (rank & -rank))
-            except Exception:      # (best effort: the process group may already be gone)
-                pass
+        _abort_upwards(dist, rank, why)
 
     def refuse_later_senders(after_step):
-        """the ranks that would hand over to this rank in later rounds: take their offers and answer "fail", so that they raise instead of waiting"""
-        st = 2 * after_step
-        while st < world and rank % (2 * st) == 0:
-            src2 = rank + st
-            if src2 < world:
-                try:
-                    m2, _ = _decode_offer(_recv_bytes(dist, src2))
-                    if m2["kind"] != "abort":
-                        _send_bytes(dist, b"fail", src2)
-                except Exception:
-                    pass
-            st *= 2
+        _refuse_senders(dist, rank, world, 2 * after_step)
 
     try:
         while step < world:
@@ -278,15 +297,23 @@ def tree_final_fold(proof, vk, rank, world, dist, merged_cls, shm_dir=None, timi
                 src = rank + step
                 if src < world:
                     t0 = time.time()
-                    msg, payload = _decode_offer(_recv_bytes(dist, src))
+                    raw = _recv_bytes(dist, src)
                     t1 = time.time()
                     t_wait += t1 - t0
+                    try:
+                        msg, payload = _decode_offer(raw)
+                    except Exception as e:      # (a message that does not parse: its sender IS waiting for an answer)
+                        _send_bytes(dist, b"fail", src)
+                        abort_upwards(e)
+                        refuse_later_senders(step)
+                        raise
                     if msg["kind"] == "abort":      # (its sender is not waiting for an answer)
                         err = RuntimeError(f"sharded proof: rank {msg.get('from', src)} failed: {msg.get('error', '')}")
                         abort_upwards(err)
                         refuse_later_senders(step)
                         raise err
                     err = None
+                    answer = True      # (False: the sender has told us it gave up and is not waiting for a reply)
                     try:
                         other = None
                         if msg["kind"] == "ipc":
@@ -297,6 +324,9 @@ def tree_final_fold(proof, vk, rank, world, dist, merged_cls, shm_dir=None, timi
                             except Exception:      # no IPC / peer access between the two devices: ask for the bytes instead
                                 _send_bytes(dist, b"retry", src)
                                 msg, payload = _decode_offer(_recv_bytes(dist, src))
+                                if msg["kind"] == "abort":
+                                    answer = False
+                                    raise RuntimeError(f"sharded proof: rank {msg.get('from', src)} failed: {msg.get('error', '')}")
                         if other is None and msg["kind"] == "file":
                             other = merged_cls.load(vk, np.fromfile(msg["path"], dtype=np.uint8, count=int(msg["bytes"])))
                         elif other is None and msg["kind"] == "bytes":
@@ -317,7 +347,8 @@ def tree_final_fold(proof, vk, rank, world, dist, merged_cls, shm_dir=None, timi
                             timings.setdefault("hand_overs", []).append({"from": src, "kind": msg["kind"], "open_s": t_open - t1, "merge_s": time.time() - t_open})
                     except Exception as e:      # (the sender must not be left waiting: answer first, then tell the rank above, raise afterwards)
                         err = e
-                    _send_bytes(dist, b"done" if err is None else b"fail", src)
+                    if answer:
+                        _send_bytes(dist, b"done" if err is None else b"fail", src)
                     if err is not None:
                         abort_upwards(err)
                         refuse_later_senders(step)
@@ -327,12 +358,24 @@ def tree_final_fold(proof, vk, rank, world, dist, merged_cls, shm_dir=None, timi
                 dst = rank - step
                 transport = "ipc" if (can_ipc and proof is not None and hasattr(proof, "share")) else ("bytes" if (forced == "bytes" or not shm_dir) else "file")
                 path = None
+                if os.environ.get("VIMZ_SHARD_TRANSPORT", "") == f"offer-fail:{rank}":      # (test hook: this rank cannot make its offer)
+                    transport = "offer-fail"
                 try:
-                    offer, payload, path = _offer(proof, merged_cls, transport, shm_dir)
+                    try:
+                        if transport == "offer-fail":
+                            raise RuntimeError("offer refused (VIMZ_SHARD_TRANSPORT=offer-fail)")
+                        offer, payload, path = _offer(proof, merged_cls, transport, shm_dir)
+                    except Exception as e:      # (the receiver is waiting for an offer: it gets the abort marker instead)
+                        _send_bytes(dist, _encode_offer({"kind": "abort", "error": str(e)[:500], "from": rank}), dst)
+                        raise
                     _send_bytes(dist, _encode_offer(offer, payload), dst)
                     reply = bytes(_recv_bytes(dist, dst))
                     if reply == b"retry":
-                        offer, payload, path = _offer(proof, merged_cls, "file" if shm_dir else "bytes", shm_dir)
+                        try:
+                            offer, payload, path = _offer(proof, merged_cls, "file" if shm_dir else "bytes", shm_dir)
+                        except Exception as e:
+                            _send_bytes(dist, _encode_offer({"kind": "abort", "error": str(e)[:500], "from": rank}), dst)
+                            raise
                         _send_bytes(dist, _encode_offer(offer, payload), dst)
                         reply = bytes(_recv_bytes(dist, dst))
                     if reply != b"done":
@@ -440,13 +483,22 @@ def prove_sharded(ivcs, step_inputs, z0, rank=0, world=1, dist=None, timings=Non
         if timings is not None:
             timings["state_chain_s"] = timings.get("state_chain_s", 0.0) + time.time() - t0
     lo, hi = bounds[rank]
-    if pending is not None:
-        proof, tp = pending.finish()
-        if timings is not None:
-            timings["merge_s"] = timings.get("merge_s", 0.0) + tp["merge_s"]
-            timings["pending_fold"] = True
-    else:
-        proof = fold_segments_merged(ivcs, step_inputs[lo:hi], z_start, timings, merged_cls, digests=my_digests) if hi > lo else None
+    try:
+        if os.environ.get("VIMZ_SHARD_TRANSPORT", "") == f"fold-fail:{rank}":      # (test hook: this rank's own fold raises)
+            if pending is not None:
+                pending.cancel()
+            raise RuntimeError("fold refused (VIMZ_SHARD_TRANSPORT=fold-fail)")
+        if pending is not None:
+            proof, tp = pending.finish()
+            if timings is not None:
+                timings["merge_s"] = timings.get("merge_s", 0.0) + tp["merge_s"]
+                timings["pending_fold"] = True
+        else:
+            proof = fold_segments_merged(ivcs, step_inputs[lo:hi], z_start, timings, merged_cls, digests=my_digests) if hi > lo else None
+    except BaseException as e:      # (an unsatisfiable row, a HIP error: the ranks of the tree must not wait for this one — ADVICE r5)
+        if world > 1:
+            tree_abort(rank, world, dist, e)
+        raise
     if timings is not None:
         timings["t_ready"] = time.time()
     if world == 1:

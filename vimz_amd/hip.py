@@ -756,15 +756,17 @@ def set_head_rows(rows):
 class Decider:
     """vimz_decider: `Decider::preprocess` / `prove` / `verify` of the Sonobe backend (vimz/src/sonobe_backend/mod.rs:72-80) — the 25 calldata words of
     contracts/*Verifier.sol and their local verification.  prover: a CycleFoldIVC (shapes, keys, context; keep it open); kzg_vk: [tau]G2 of the SRS
-    its ck_main is made of (kzg_setup), or None (no verify).  The Groth16 trapdoor is drawn from the OS's randomness and forgotten; `seed` selects
+    its ck_main is made of (kzg_setup), or None (no verify).  light=False: the FULL decider (decider.rs:13-21: the running CycleFold instance's commitments
+    and relation are checked inside the circuit); light=True: the reference's opt-in `light-test` variant (vimz/Cargo.toml:56-59).  The Groth16 trapdoor is drawn from the OS's randomness and forgotten; `seed` selects
     the deterministic TEST setup of libvimz_hip_testing.so."""
     RESULT_BITS = {1: "fewer than two steps", 2: "KZG opening of cmW", 4: "KZG opening of cmE", 8: "Groth16", 16: "a word pair is not a curve point"}
 
-    def __init__(self, prover, kzg_vk=None, seed=None):
+    def __init__(self, prover, kzg_vk=None, seed=None, light=False):
         self.prover, self.ctx = prover, prover.ctx
+        self.light = bool(light)
         lib = self.ctx.lib
         vp = C.c_void_p
-        lib.vimz_decider_setup.argtypes = [vp, vp, C.POINTER(vp), C.POINTER(C.c_double)]
+        lib.vimz_decider_setup.argtypes = [vp, vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_double)]
         lib.vimz_decider_free.argtypes = [vp]
         lib.vimz_decider_free.restype = None
         lib.vimz_decider_info.argtypes = [vp, vp]
@@ -777,11 +779,11 @@ class Decider:
         self._kzg_vk = None if kzg_vk is None else np.ascontiguousarray(kzg_vk, dtype=np.uint64)
         kp = None if self._kzg_vk is None else _ptr(self._kzg_vk)
         if seed is None:
-            self.ctx._chk(lib.vimz_decider_setup(prover.h, kp, C.byref(h), sec))
+            self.ctx._chk(lib.vimz_decider_setup(prover.h, kp, int(self.light), C.byref(h), sec))
         else:
             fn = _seeded(self.ctx, "vimz_testing_decider_setup_seeded")
-            fn.argtypes = [vp, vp, C.c_char_p, C.c_size_t, C.POINTER(vp), C.POINTER(C.c_double)]
-            self.ctx._chk(fn(prover.h, kp, bytes(seed), len(seed), C.byref(h), sec))
+            fn.argtypes = [vp, vp, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(vp), C.POINTER(C.c_double)]
+            self.ctx._chk(fn(prover.h, kp, int(self.light), bytes(seed), len(seed), C.byref(h), sec))
         self.h = h
         self.setup_seconds = {"circuit_synthesis": sec[0], "qap_at_trapdoor_host": sec[1], "key_points_gpu": sec[2], "total": sec[3]}
 
@@ -830,7 +832,7 @@ class Decider:
     def info(self):
         a = np.zeros(8, dtype=np.uint64)
         self.ctx._chk(self.ctx.lib.vimz_decider_info(self.h, _ptr(a)))
-        return dict(zip(["constraints", "wires", "public_inputs", "domain", "nnz_a", "nnz_b", "nnz_c"], (int(x) for x in a[:7])))
+        return dict(zip(["constraints", "wires", "public_inputs", "domain", "nnz_a", "nnz_b", "nnz_c", "cyclefold_rows"], (int(x) for x in a[:8])))
 
     def key_words(self):
         """vimz_decider_vk's words (uint64 array): what vimz_decider_verify_key takes."""
