@@ -7,7 +7,7 @@ ivc (default): ONE proof object — the rows are proven as `segments` Nova IVCs 
 merged (vimz_ivc_merge), then compressed;
 accumulator: NIFS accumulators of the segments merged by a final fold;
 cyclefold: the Sonobe backend's sequence (vimz/src/sonobe_backend/mod.rs:52-95: prepare folding, fold input, verify folded proof) with Nova +
-CycleFold; with one segment also the decider (Prepare decider, Generate decider proof: vimz_decider_*) and the calldata bytes."""
+CycleFold; with one segment also the decider (Prepare decider, Generate decider proof: vimz_decider_*; the full one, or VIMZ_E2E_DECIDER=light) and the calldata bytes."""
 import json
 import sys
 import time
@@ -83,13 +83,15 @@ def main():
         # Decider::preprocess (mod.rs:72-75) depends on the shapes only, not on the fold: its host part — circuit synthesis, the QAP at the trapdoor,
         # 0.6 s at contrast HD — runs on a thread of its own UNDER the fold; its GPU part (the key's points) takes the context when the fold has left it
         dec_box, dec_thread = {}, None
+        import os
+        light_decider = os.environ.get("VIMZ_E2E_DECIDER", "full") == "light"      # (the reference's opt-in `light-test` feature, vimz/Cargo.toml:56-59)
         if S == 1:
             import threading
 
             def _prep_decider():
                 t_d = time.time()
                 try:
-                    dec_box["dec"] = hip.Decider(cfs[0], kzg_vk=params.kzg_vk)
+                    dec_box["dec"] = hip.Decider(cfs[0], kzg_vk=params.kzg_vk, light=light_decider)
                 except BaseException as e:      # noqa: BLE001
                     dec_box["err"] = e
                 dec_box["seconds"] = time.time() - t_d
@@ -128,7 +130,7 @@ def main():
             spans["Verify decider proof"] = time.time() - t0
             if dec_ok != 0:
                 raise SystemExit(f"the decider proof does not verify: result bits {dec_ok}")
-            decider = {"circuit": dec.info(), "setup_s": dec.setup_seconds, "prepare_thread_s": dec_box["seconds"], "prove_s": dd["seconds"], "calldata_bytes": len(raw), "verified": dec_ok == 0,
+            decider = {"variant": "light" if light_decider else "full", "circuit": dec.info(), "setup_s": dec.setup_seconds, "prepare_thread_s": dec_box["seconds"], "prove_s": dd["seconds"], "calldata_bytes": len(raw), "verified": dec_ok == 0,
                        "note": "Groth16 over BN254 for this library's decider circuit (contract's public-input layout; locally trusted setup), final fold + KZG openings on the GPU; "
                                "verified by vimz_decider_verify = the checks of contracts/*Verifier.sol (tests/_novadecider.py restates the contract and is pinned on the reference's six proofs)"}
             if save:

@@ -1021,8 +1021,13 @@ int vimz_decider_prove(vimz_decider* d, vimz_cf* ivc, uint64_t* public_out, uint
   };
   G1Aff sa, sb1, sl, sh;
   const int so = d->circ.full ? 1 : 0;
-  if ((rc = g1_msm(K.a_q, dz, K.m, &sa, so)) || (rc = g1_msm(K.b1_q, dz, K.m, &sb1, so)) || (rc = g1_msm(K.l_q, dz + 8 * (size_t)(K.n_pub + 1), K.m - K.n_pub - 1, &sl, so)) ||
-      (rc = g1_msm(K.h_q, dv[0], K.n - 1, &sh, 0))) return rc;
+  static const bool dbg_t = getenv("VIMZ_DEBUG_TIMING") != nullptr;
+  double tm0 = now_s();
+  auto lap = [&](const char* what) { if (dbg_t) { const double t = now_s(); fprintf(stderr, "[decider] %s %.1f ms\n", what, 1e3 * (t - tm0)); tm0 = t; } };
+  if ((rc = g1_msm(K.a_q, dz, K.m, &sa, so))) return rc; lap("msm a");
+  if ((rc = g1_msm(K.b1_q, dz, K.m, &sb1, so))) return rc; lap("msm b1");
+  if ((rc = g1_msm(K.l_q, dz + 8 * (size_t)(K.n_pub + 1), K.m - K.n_pub - 1, &sl, so))) return rc; lap("msm l");
+  if ((rc = g1_msm(K.h_q, dv[0], K.n - 1, &sh, 0))) return rc; lap("msm h");
   const unsigned PT = 128 * 256;
   P_TRY(hipMalloc((void**)&dpart, sizeof(G2P) * PT));
   hipLaunchKernelGGL(k_msm_naive<Fq2>, dim3(PT / 128), dim3(128), 0, s, (const G2PAff*)K.b2_q, (const uint32_t*)dz, (size_t)K.m, dpart);
@@ -1032,6 +1037,7 @@ int vimz_decider_prove(vimz_decider* d, vimz_cf* ivc, uint64_t* public_out, uint
   P_TRY(hipStreamSynchronize(s));
   G2P sb2 = G2P::identity();
   for (auto& pp : part) add_full(sb2, pp);
+  lap("msm b2 (G2)");
   const double t_msm = now_s();
   // A = alpha + Σ z_i a_i + r·delta;  B = beta + Σ z_i b_i + s·delta;  C = Σ_priv z_i l_i + Σ h_j hq_j + s·A + r·B1 − r·s·delta;  r, s fresh from the OS (zero knowledge)
   Fe r, sr;
