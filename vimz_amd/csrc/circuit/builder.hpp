@@ -106,6 +106,7 @@ struct BuilderT {
   std::vector<Fe> dict;
   std::unordered_map<FeKey, uint32_t, FeKeyHash> dict_ix;
   uint32_t n_linear = 0;  // constraints kept although linear (circom reports them separately)
+  uint32_t n_bool = 0;    // rows [0, n_bool) are b·(b − 1) = 0 with A = the wire b, B = b − 1, C empty (group_boolean_rows_first)
 
   // witness program
   std::vector<DecompGroup> decomp;
@@ -172,6 +173,7 @@ inline uint32_t group_boolean_rows_first(BuilderT<Fe>& b) {
     M = std::move(o);
   };
   permute(b.A); permute(b.B); permute(b.C);
+  b.n_bool = nb;
   return nb;
 }
 

@@ -80,24 +80,56 @@ __global__ void __launch_bounds__(128) k_fixed_mul(const uint32_t* __restrict__ 
   }
   out[i] = to_affine(acc);
 }
-// partial[t] = Σ_{i ≡ t (mod T)} s_i · P_i by double-and-add per point (scalars in Montgomery form; zero scalars and identity points cost nothing)
-template <class F>
-__global__ void __launch_bounds__(128) k_msm_naive(const Affine<F>* __restrict__ bases, const uint32_t* __restrict__ scalars, size_t n, XYZZ<F>* __restrict__ partial) {
-  const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x, T = (size_t)gridDim.x * blockDim.x;
-  XYZZ<F> acc = XYZZ<F>::identity();
-  for (size_t i = t; i < n; i += T) {
-    Fr sm; for (int k = 0; k < 8; k++) sm.v[k] = scalars[8 * i + k];
-    if (sm.is_zero()) continue;
-    const Affine<F> P = bases[i];
-    if (aff_is_identity(P)) continue;
-    const Fr s = Fr::from_mont(sm);
-    int top = 255;
-    while (top > 0 && !((s.v[top >> 5] >> (top & 31)) & 1u)) top--;
-    XYZZ<F> r = from_affine(P);
-    for (int b = top - 1; b >= 0; b--) { r = dbl(r); if ((s.v[b >> 5] >> (b & 31)) & 1u) add_mixed(r, P); }
-    add_full(acc, r);
+// The G2 multi-scalar multiplication of a proof, Σ z_i·[b_i]_2 over the wires whose query point is not the identity, BIT PLANE BY BIT PLANE:
+//     Σ_i s_i·P_i = Σ_j 2^j·S_j,   S_j = Σ_{i: bit j of s_i} P_i
+// — no doublings on the device (a per-point double-and-add spends two thirds of its additions on them and ran 2.0 s for the full decider's 0.7 M
+// full-size scalars: a quarter of the threads held all the work), no sorting: plane j is a filtered sum.  A wave walks 64 consecutive scalars at a time,
+// queues the indices whose bit j is set in LDS (ballot + prefix count: the compaction of msm.hpp's k_ones_dense) and adds 64 queued bases at a time, one per
+// lane.  blockIdx.y = the plane; partial[plane][thread]; k_g2_plane_tree folds a plane's partials; the host adds the 254 plane sums by Horner.
+constexpr uint32_t G2_PLANE_THREADS = 2048, G2_PLANES = 254;
+__global__ void __launch_bounds__(256) k_g2_canon(const uint32_t* __restrict__ scalars_mont, const uint32_t* __restrict__ idx, uint32_t n, uint32_t* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  store_fe(out, i, Fr::from_mont(load_fe<Fr>(scalars_mont, idx[i])));
+}
+__global__ void __launch_bounds__(256) k_g2_planes(const Affine<Fq2>* __restrict__ bases, const uint32_t* __restrict__ canon, uint32_t n, XYZZ<Fq2>* __restrict__ partial) {
+  __shared__ uint32_t queue[4][128];
+  const uint32_t plane = blockIdx.y, word = plane >> 5, bit = plane & 31u;
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+  const uint32_t wave = t >> 6, nwaves = G2_PLANE_THREADS / 64;
+  volatile uint32_t* q = queue[wv];
+  XYZZ<Fq2> acc = XYZZ<Fq2>::identity();
+  uint32_t cnt = 0;                                     // (wave-uniform)
+  for (uint32_t base = wave * 64; base < n; base += nwaves * 64) {
+    const uint32_t i = base + lane;
+    const bool on = i < n && ((canon[8 * (size_t)i + word] >> bit) & 1u);
+    const uint64_t m = __ballot(on);
+    if (on) q[cnt + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = i;
+    cnt += (uint32_t)__popcll(m);
+    __builtin_amdgcn_wave_barrier();
+    if (cnt >= 64) {
+      cnt -= 64;
+      const uint32_t ix = q[cnt + lane];
+      __builtin_amdgcn_wave_barrier();
+      const Affine<Fq2> pt = bases[ix];
+      add_mixed(acc, pt);
+    }
   }
-  partial[t] = acc;
+  if (lane < cnt) { const Affine<Fq2> pt = bases[q[lane]]; add_mixed(acc, pt); }
+  partial[(size_t)plane * G2_PLANE_THREADS + t] = acc;
+}
+__global__ void __launch_bounds__(128) k_g2_plane_tree(const XYZZ<Fq2>* __restrict__ partial, XYZZ<Fq2>* __restrict__ out) {
+  __shared__ XYZZ<Fq2> sh[128];
+  const uint32_t plane = blockIdx.x, t = threadIdx.x;
+  XYZZ<Fq2> acc = XYZZ<Fq2>::identity();
+  for (uint32_t k = t; k < G2_PLANE_THREADS; k += 128) add_full(acc, partial[(size_t)plane * G2_PLANE_THREADS + k]);
+  sh[t] = acc;
+  __syncthreads();
+  for (uint32_t h = 64; h >= 1; h >>= 1) {
+    if (t < h) { XYZZ<Fq2> a = sh[t]; add_full(a, sh[t + h]); sh[t] = a; }
+    __syncthreads();
+  }
+  if (t == 0) out[plane] = sh[0];
 }
 // tw[k] = base^k
 __global__ void k_pow_table(uint32_t* __restrict__ out, size_t n, Fr base) {
@@ -143,7 +175,7 @@ struct G16Key {
   Fe omega, omega_inv, n_inv, coset, coset_inv, zinv;           // domain constants (coset generator 5: Z(5·ω^i) = 5^n − 1)
   uint32_t *tw = nullptr, *tw_inv = nullptr;                    // ω^k, ω^-k for k < n/2
   vimz_bases *a_q = nullptr, *b1_q = nullptr, *l_q = nullptr, *h_q = nullptr;      // G1 queries (a, b: m points; l: private wires; h: n − 1)
-  G2PAff* b2_q = nullptr;                                       // G2 query (m points, device)
+  G2PAff* b2_q = nullptr; uint32_t* b2_idx = nullptr; uint32_t n_b2 = 0;      // G2 query: the n_b2 wires whose point is not the identity (device: points, wire numbers)
   G1Aff alpha1, beta1, delta1; G2PAff beta2, gamma2, delta2;
   std::vector<G1Aff> ic;                                        // n_pub + 1 points
 };
@@ -155,6 +187,7 @@ void free_key_raw(G16Key& K) {      // (not vimz_bases_free: it takes the contex
     delete *b; *b = nullptr;
   }
   if (K.b2_q) hipFree(K.b2_q); K.b2_q = nullptr;
+  if (K.b2_idx) hipFree(K.b2_idx); K.b2_idx = nullptr;
   if (K.tw) hipFree(K.tw); if (K.tw_inv) hipFree(K.tw_inv); K.tw = K.tw_inv = nullptr;
 }
 }  // namespace
@@ -446,7 +479,15 @@ int decider_setup_impl(vimz_cf* v, const uint64_t kzg_vk_g2[16], const Trapdoor&
   };
   int rc;
   if ((rc = g1_query(uvw[0], &K.a_q)) || (rc = g1_query(uvw[1], &K.b1_q)) || (rc = g1_query(lq, &K.l_q)) || (rc = g1_query(hq, &K.h_q))) return rc;
-  { hipError_t e = fixed_base_batch<Fq2>(s, uvw[1], tables.b, &K.b2_q); if (e != hipSuccess) return vz_fail(ctx, VIMZ_ERR_HIP, "decider: G2 key points", e); }
+  { // the G2 query holds only the wires that occur in B (the others' points are the identity)
+    std::vector<uint32_t> ix; std::vector<Fe> sc;
+    for (uint32_t i = 0; i < K.m; i++) if (!uvw[1][i].is_zero()) { ix.push_back(i); sc.push_back(uvw[1][i]); }
+    K.n_b2 = (uint32_t)ix.size();
+    hipError_t e = fixed_base_batch<Fq2>(s, sc, tables.b, &K.b2_q);
+    wipe(sc);
+    if (e != hipSuccess) return vz_fail(ctx, VIMZ_ERR_HIP, "decider: G2 key points", e);
+    P_TRY(hipMalloc((void**)&K.b2_idx, 4 * std::max<size_t>(ix.size(), 1)));
+    P_TRY(hipMemcpy(K.b2_idx, ix.data(), 4 * ix.size(), hipMemcpyHostToDevice)); }
   // domain tables
   P_TRY(hipMalloc((void**)&K.tw, 32 * (size_t)std::max<uint32_t>(K.n / 2, 1))); P_TRY(hipMalloc((void**)&K.tw_inv, 32 * (size_t)std::max<uint32_t>(K.n / 2, 1)));
   { Fr w, wi; memcpy(w.v, K.omega.v, 32); memcpy(wi.v, K.omega_inv.v, 32);
@@ -833,10 +874,13 @@ int64_t vimz_decider_key_save(vimz_decider* d, void* buf, size_t cap) {
     }
     pos += 8 * nq[q];
   }
-  std::vector<G2PAff> b2(K.m);
-  P_TRY(hipMemcpyAsync(b2.data(), K.b2_q, sizeof(G2PAff) * (size_t)K.m, hipMemcpyDeviceToHost, s));
-  P_TRY(hipStreamSynchronize(s));
-  for (uint32_t i = 0; i < K.m; i++) { put_g2(w + pos, b2[i]); pos += 16; }
+  { std::vector<G2PAff> b2c(K.n_b2); std::vector<uint32_t> ix(K.n_b2);
+    P_TRY(hipMemcpyAsync(b2c.data(), K.b2_q, sizeof(G2PAff) * (size_t)K.n_b2, hipMemcpyDeviceToHost, s));
+    P_TRY(hipMemcpyAsync(ix.data(), K.b2_idx, 4 * (size_t)K.n_b2, hipMemcpyDeviceToHost, s));
+    P_TRY(hipStreamSynchronize(s));
+    memset(w + pos, 0, 128 * (size_t)K.m);      // (the identity: (0, 0))
+    for (uint32_t k = 0; k < K.n_b2; k++) put_g2(w + pos + 16 * (size_t)ix[k], b2c[k]);
+    pos += 16 * (size_t)K.m; }
   return pos == words ? (int64_t)(8 * words) : (int64_t)VIMZ_ERR_INVALID;
 }
 // prover: as for vimz_decider_setup (shapes, keys, context).  The key must be for exactly this prover's circuits (sizes and public-parameter hash are checked).
@@ -886,10 +930,18 @@ int vimz_decider_key_load(vimz_cf* v, const void* buf, size_t len, vimz_decider*
     if (rc) return rc;
     pos += 8 * nq[q];
   }
-  { std::vector<G2PAff> b2(K.m);
-    for (uint32_t i = 0; i < K.m; i++) { if (!get_g2(w + pos, &b2[i])) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_decider_key_load: a G2 query coordinate is not below the modulus"); pos += 16; }
-    P_TRY(hipMalloc((void**)&K.b2_q, sizeof(G2PAff) * (size_t)K.m));
-    P_TRY(hipMemcpy(K.b2_q, b2.data(), sizeof(G2PAff) * (size_t)K.m, hipMemcpyHostToDevice)); }
+  { std::vector<G2PAff> b2; std::vector<uint32_t> ix;
+    for (uint32_t i = 0; i < K.m; i++) {
+      G2PAff pt;
+      if (!get_g2(w + pos, &pt)) return vz_fail(ctx, VIMZ_ERR_INVALID, "vimz_decider_key_load: a G2 query coordinate is not below the modulus");
+      pos += 16;
+      if (!aff_is_identity(pt)) { b2.push_back(pt); ix.push_back(i); }
+    }
+    K.n_b2 = (uint32_t)ix.size();
+    P_TRY(hipMalloc((void**)&K.b2_q, sizeof(G2PAff) * std::max<size_t>(b2.size(), 1)));
+    P_TRY(hipMemcpy(K.b2_q, b2.data(), sizeof(G2PAff) * b2.size(), hipMemcpyHostToDevice));
+    P_TRY(hipMalloc((void**)&K.b2_idx, 4 * std::max<size_t>(ix.size(), 1)));
+    P_TRY(hipMemcpy(K.b2_idx, ix.data(), 4 * ix.size(), hipMemcpyHostToDevice)); }
   P_TRY(hipMalloc((void**)&K.tw, 32 * (size_t)std::max<uint32_t>(K.n / 2, 1))); P_TRY(hipMalloc((void**)&K.tw_inv, 32 * (size_t)std::max<uint32_t>(K.n / 2, 1)));
   { Fr tw, twi; memcpy(tw.v, K.omega.v, 32); memcpy(twi.v, K.omega_inv.v, 32);
     hipLaunchKernelGGL(k_pow_table, dim3((K.n / 2 + 255) / 256), dim3(256), 0, s, K.tw, (size_t)K.n / 2, tw);
@@ -1028,15 +1080,21 @@ int vimz_decider_prove(vimz_decider* d, vimz_cf* ivc, uint64_t* public_out, uint
   if ((rc = g1_msm(K.b1_q, dz, K.m, &sb1, so))) return rc; lap("msm b1");
   if ((rc = g1_msm(K.l_q, dz + 8 * (size_t)(K.n_pub + 1), K.m - K.n_pub - 1, &sl, so))) return rc; lap("msm l");
   if ((rc = g1_msm(K.h_q, dv[0], K.n - 1, &sh, 0))) return rc; lap("msm h");
-  const unsigned PT = 128 * 256;
-  P_TRY(hipMalloc((void**)&dpart, sizeof(G2P) * PT));
-  hipLaunchKernelGGL(k_msm_naive<Fq2>, dim3(PT / 128), dim3(128), 0, s, (const G2PAff*)K.b2_q, (const uint32_t*)dz, (size_t)K.m, dpart);
-  P_TRY(hipGetLastError());
-  std::vector<G2P> part(PT);
-  P_TRY(hipMemcpyAsync(part.data(), dpart, sizeof(G2P) * PT, hipMemcpyDeviceToHost, s));
-  P_TRY(hipStreamSynchronize(s));
+  // the G2 one, bit plane by bit plane (k_g2_planes): dv[1] (the quotient's inputs are spent) holds the canonical scalars of the query's wires
   G2P sb2 = G2P::identity();
-  for (auto& pp : part) add_full(sb2, pp);
+  if (K.n_b2) {
+    if ((size_t)K.n_b2 > (size_t)K.n) return vz_fail(ctx, VIMZ_ERR_INVALID, "decider: the G2 query is longer than the domain");
+    P_TRY(hipMalloc((void**)&dpart, sizeof(G2P) * ((size_t)G2_PLANES * G2_PLANE_THREADS + G2_PLANES)));
+    G2P* dsum = dpart + (size_t)G2_PLANES * G2_PLANE_THREADS;
+    hipLaunchKernelGGL(k_g2_canon, dim3((K.n_b2 + 255) / 256), dim3(256), 0, s, (const uint32_t*)dz, (const uint32_t*)K.b2_idx, K.n_b2, dv[1]);
+    hipLaunchKernelGGL(k_g2_planes, dim3(G2_PLANE_THREADS / 256, G2_PLANES), dim3(256), 0, s, (const G2PAff*)K.b2_q, (const uint32_t*)dv[1], K.n_b2, dpart);
+    hipLaunchKernelGGL(k_g2_plane_tree, dim3(G2_PLANES), dim3(128), 0, s, (const G2P*)dpart, dsum);
+    P_TRY(hipGetLastError());
+    std::vector<G2P> planes(G2_PLANES);
+    P_TRY(hipMemcpyAsync(planes.data(), dsum, sizeof(G2P) * G2_PLANES, hipMemcpyDeviceToHost, s));
+    P_TRY(hipStreamSynchronize(s));
+    for (int j = (int)G2_PLANES - 1; j >= 0; j--) { sb2 = dbl(sb2); add_full(sb2, planes[j]); }
+  }
   lap("msm b2 (G2)");
   const double t_msm = now_s();
   // A = alpha + Σ z_i a_i + r·delta;  B = beta + Σ z_i b_i + s·delta;  C = Σ_priv z_i l_i + Σ h_j hq_j + s·A + r·B1 − r·s·delta;  r, s fresh from the OS (zero knowledge)

@@ -87,6 +87,17 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
   // ---- the step rows' cross term and its commitment (the one large MSM of a step), on stream 3 ------------------------------------
   // (a helper thread for these launches measured no gain once the producer had its issuer thread, and costs a spinning core)
   typedef vimz_prover::BatchBuf BufRef;
+  // Boolean-row form of the step rows' commitment (r1cs_ops.hpp: bool_row_masked): needs the producer's S_1 per row and C_A of the running instance.
+  // Not with MSM helpers (base-range split) and not over caller-supplied witnesses (the producer's own rows have bits on the boolean rows by construction).
+  const bool trick = v->bool_rows && v->helpers.empty() && !witnesses;
+  if (trick && v->i > 0 && !v->ca_valid) {      // (after an import: C_A = Σ_{i<n_bool} AZ[i]·ck_i by one MSM)
+    G1Aff r; MsmStats st;
+    P_TRY(hipStreamSynchronize(v->s3));
+    P_TRY(msm_run<BnG1>(s, ctx->msm_ws, p->ck->d, p->AZ, p->n_bool, 1, 0, &r, &st, nullptr, 0, p->ck->tables ? &job.tbl : nullptr));
+    v->CA = from_affine(r);
+  }
+  v->ca_valid = false;      // (valid again when this call ends with C_A kept up to its last fold)
+  G1Aff S1_row; S1_row.x = S1_row.y = Fq::zero();      // S_1 of the row being folded: Σ ck_i over the boolean rows whose fresh bit is one (producer, pinned)
   // commitment to the vector of slot `par` (base-range split: the first share stays here, helper h commits to rows [off_h, off_h + n_h)
   // with its replica of the key)
   auto queue_msm = [&](int par) -> int {
@@ -107,7 +118,7 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
       P_TRY(hipSetDevice(ctx->device));
     }
     double tq = now_s();
-    P_TRY(msm_launch<BnG1>(v->s3, v->ws3, p->ck->d, S.buf, v->t1_main_n, 1, 0, S.pin, &S.plan, ctx->profiling ? S.ev : nullptr, 0,
+    P_TRY(msm_launch<BnG1>(v->s3, v->ws3, p->ck->d, S.tricked ? S.bufm : S.buf, v->t1_main_n, 1, 0, S.pin, &S.plan, ctx->profiling ? S.ev : nullptr, 0,
                            p->ck->tables && v->helpers.empty() ? &job.tbl : nullptr));
     t_hk[2] += now_s() - tq; tq = now_s();
     if (ctx->profiling) P_TRY(hipMemcpyAsync(S.pin + v->pin_res, v->ws3.totals, 8, hipMemcpyDeviceToHost, v->s3));   // (pinned: stays asynchronous)
@@ -122,9 +133,10 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
     P_TRY(hipStreamWaitEvent(v->s3, v->ev_fold, 0));
     P_TRY(wait_row_flag(b2, row, b2.ev[row]));      // (on the host: prover_internal.hpp, wait_row_flag)
     hipLaunchKernelGGL(k_cross_term<Fr>, dim3(stream_grid(sc)), dim3(256), 0, v->s3, sc, p->AZ, p->BZ, p->CZ, v->u1_run,
-                       b2.az + 8 * row * nc, b2.bz + 8 * row * nc, b2.cz + 8 * row * nc, Fe::one(), S.buf);
+                       b2.az + 8 * row * nc, b2.bz + 8 * row * nc, b2.cz + 8 * row * nc, Fe::one(), S.buf, trick ? S.bufm : (uint32_t*)nullptr, p->n_bool);
     P_TRY(hipGetLastError());
     S.step = (int64_t)step; S.hasB = false;
+    S.tricked = trick; S.u_at = v->u1_run; S.ca_at = v->CA;
     return queue_msm((int)(step & 1));
   };
   // When step i's challenge is known: k_fold_cross folds the step rows (running products, error vector) and writes the cross term(s)
@@ -141,24 +153,28 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
     // first output of the pass: next1 into the other slot if it is needed, else the lookahead into this slot (read, then overwritten)
     const RowAt* t = a.need1 ? &a.next1 : a.look ? &a.next2 : nullptr;
     uint32_t* out = a.need1 ? Soth.buf : a.look ? Scur.buf : nullptr;
+    uint32_t* outm = !trick ? nullptr : a.need1 ? Soth.bufm : a.look ? Scur.bufm : nullptr;
     double tq = now_s();
     if (t) P_TRY(wait_row_flag(*t->b, t->row, t->b->ev[t->row]));      // (the producer is a batch ahead: no wait in the steady state)
     t_hk[4] += now_s() - tq; tq = now_s();
     hipLaunchKernelGGL(k_fold_cross<Fr>, dim3(stream_grid(sc)), dim3(256), 0, v->s3, sc, p->AZ, p->BZ, p->CZ, p->E, (const uint32_t*)Scur.buf, fold_E ? 1 : 0, a.rho,
                        hasB ? 1 : 0, v->rho_prev, hasB ? (const uint32_t*)(a.cur->d + 8 * a.r * sc) : (const uint32_t*)nullptr, v->u1_run, az, bz, cz,
-                       out, t ? t->b->az + 8 * t->row * nc : nullptr, t ? t->b->bz + 8 * t->row * nc : nullptr, t ? t->b->cz + 8 * t->row * nc : nullptr, Fe::one());
+                       out, t ? t->b->az + 8 * t->row * nc : nullptr, t ? t->b->bz + 8 * t->row * nc : nullptr, t ? t->b->cz + 8 * t->row * nc : nullptr, Fe::one(),
+                       outm, p->n_bool);
     P_TRY(hipGetLastError());
     if (a.need1 && a.look) {      // both (the first step of a call): the lookahead as a pass of its own, after this slot's vector was read
       P_TRY(wait_row_flag(*a.next2.b, a.next2.row, a.next2.b->ev[a.next2.row]));
       hipLaunchKernelGGL(k_cross_term<Fr>, dim3(stream_grid(sc)), dim3(256), 0, v->s3, sc, p->AZ, p->BZ, p->CZ, v->u1_run,
-                         a.next2.b->az + 8 * a.next2.row * nc, a.next2.b->bz + 8 * a.next2.row * nc, a.next2.b->cz + 8 * a.next2.row * nc, Fe::one(), Scur.buf);
+                         a.next2.b->az + 8 * a.next2.row * nc, a.next2.b->bz + 8 * a.next2.row * nc, a.next2.b->cz + 8 * a.next2.row * nc, Fe::one(), Scur.buf,
+                         trick ? Scur.bufm : (uint32_t*)nullptr, p->n_bool);
       P_TRY(hipGetLastError());
     }
     t_hk[0] += now_s() - tq; tq = now_s();
     P_TRY(hipEventRecord(v->ev_fused, v->s3)); v->fused_recorded = true;
     t_hk[1] += now_s() - tq;
-    if (a.need1) { Soth.step = (int64_t)a.i + 1; Soth.hasB = false; int rc2 = queue_msm(par ^ 1); if (rc2) return rc2; }
-    if (a.look) { Scur.step = (int64_t)a.i + 2; Scur.hasB = true; int rc2 = queue_msm(par); if (rc2) return rc2; }
+    // (boolean-row form: u_at is the running instance's u after this fold; ca_at follows once C_A has this fold in it — queue_folds, after the launches)
+    if (a.need1) { Soth.step = (int64_t)a.i + 1; Soth.hasB = false; Soth.tricked = trick; Soth.u_at = v->u1_run; int rc2 = queue_msm(par ^ 1); if (rc2) return rc2; }
+    if (a.look) { Scur.step = (int64_t)a.i + 2; Scur.hasB = true; Scur.tricked = trick; Scur.u_at = v->u1_run; int rc2 = queue_msm(par); if (rc2) return rc2; }
     return VIMZ_OK;
   };
   // ---- the batch producer's launches (some forty per row, sixty with the lookahead's commitment) come from a thread of their own: issued
@@ -234,6 +250,7 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
       // (waited for on the HOST, not by a barrier on this stream: a high-priority queue stalled behind the producer's event keeps the
       //  producer's low-priority queues from being served — once a producer fell behind it stayed behind, 10× slower: DESIGN.md §5c)
       P_TRY(wait_row_flag(bb, r, bb.ev[r]));
+      if (trick) S1_row = to_affine(ones_finish<BnG1>((const char*)bb.pin + r * pin_stride + vimz_prover::S1_SLOT));
       P_TRY(upload_pinned(s, Zi + 8 * sw, pin_aug1, 32 * aw1));
       // the commitment to the verifier wires needs the upload only: it starts first, on stream 2
       P_TRY(hipEventRecord(v->ev_fork, s));
@@ -307,6 +324,14 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
           lookB = acc;
         }
       }
+      // boolean-row form: the commitment of this step's vector is completed by u·S_1(row i) − C_A, both as they were when the vector was computed — one
+      // 254-bit scalar multiplication on the host, here, while the device works on the verifier rows
+      G1 boolCorr = G1::identity();
+      if (i > 0 && slot.tricked) {
+        if (!aff_is_identity(S1_row)) { const Fe uc = Fe::from_mont(slot.u_at); boolCorr = scalar_mul(S1_row, uc.v, 254); }
+        G1 nca = slot.ca_at; if (!nca.is_identity()) nca.Y = Fq::neg(nca.Y);
+        add_full(boolCorr, nca);
+      }
       t_wp[1] += now_s() - tw; tw = now_s();
       P_TRY(take_T1_step(false));
       P_TRY(vz_wait_stream(v->s2));
@@ -338,6 +363,7 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
         v->ph_s[IP_WAIT_PRI] += now_s() - t0;
         t_wp[4] += now_s() - t0;
         G1 ts = from_affine(T1_step); add_mixed(ts, Tv);
+        if (slot.tricked) add_full(ts, boolCorr);
         if (slot.hasB) { G1 nb = lookB; if (!nb.is_identity()) nb.Y = Fq::neg(nb.Y); add_full(ts, nb); }
         T1 = to_affine(ts);
         t0 = now_s();
@@ -412,6 +438,11 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
         t_hk[3] += now_s() - tq; tq = now_s();
         P_TRY(hipEventRecord(v->ev_fold, v->s2));  // the verifier rows of the next step may start here
         t_hk[1] += now_s() - tq;
+        if (trick) {      // C_A of the running instance now holds this fold: C_A += rho·S_1(row i); the vectors just queued were computed against it
+          if (!aff_is_identity(S1_row)) { const uint32_t k[5] = {rho_low[0], rho_low[1], rho_low[2], rho_low[3], 1u}; G1 t = scalar_mul(S1_row, k, 129); add_full(v->CA, t); }
+          if (fa.need1) v->t1[(i + 1) & 1].ca_at = v->CA;
+          if (fa.look) v->t1[i & 1].ca_at = v->CA;
+        }
         return VIMZ_OK;
       };
       v->c2.on_challenge = [&](const uint32_t* rho_low) { const double th = now_s(); hook_ran = true; hook_rc = queue_folds(rho_low); t_hook += now_s() - th; };
@@ -464,6 +495,7 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
   v->t1[0].step = v->t1[1].step = -1;
   for (uint32_t k = 0; k < p->len_z; k++) p->z_cur[k] = zs[nsteps * p->len_z + k];
   guard.armed = false;
+  v->ca_valid = trick;
   v->ph_s[IP_TOTAL] += now_s() - t_all; v->ph_n[IP_TOTAL] += nsteps;
   if (dbg_timing) fprintf(stderr, "[timing] wait_primary_msm per step: finish(W) + statement %.3f, lookahead's host share %.3f, small MSM(W aug) %.3f, verifier rows + small MSM(T) %.3f, large MSM(T) %.3f ms\n",
                           1e3 * t_wp[0] / (double)nsteps, 1e3 * t_wp[1] / (double)nsteps, 1e3 * t_wp[2] / (double)nsteps, 1e3 * t_wp[3] / (double)nsteps, 1e3 * t_wp[4] / (double)nsteps);
@@ -600,6 +632,12 @@ int vimz_ivc_create(vimz_ctx* ctx, const vimz_circuit* step_circuit, const vimz_
     if ((e = hipEventCreateWithFlags(&v->t1[q].done, hipEventDisableTiming)) != hipSuccess) return fail("event");
     v->t1[q].pin = v->pin_t1b + q * (v->pin_res + 64);
   }
+  {   // boolean-row form of the step rows' cross-term commitment: a second vector per slot (the one the MSM takes)
+    const char* e2 = getenv("VIMZ_IVC_BOOL_ROWS");
+    v->bool_rows = v->pri->n_bool > 0 && !(e2 && atoi(e2) == 0);
+    if (v->bool_rows) for (int q = 0; q < 2; q++) if (dalloc(&v->t1[q].bufm, 32 * (size_t)v->c1->step_constraints) != hipSuccess) return fail("device allocation");
+    v->pri->want_s1 = v->bool_rows;
+  }
   for (int q = 0; q < 7; q++) if ((e = hipEventCreate(&v->ev_alt[q])) != hipSuccess) return fail("event");
   v->t1[0].ev = ctx->ev; v->t1[1].ev = v->ev_alt;
   if (v->c2.use_worker) {       // one pair of helper threads for both circuits
@@ -654,6 +692,7 @@ int vimz_ivc_reset(vimz_ivc* v, const uint64_t* z0) {
   for (uint32_t k = 0; k < v->c1->len_z; k++) v->z0[k] = v->pri->z_cur[k];
   v->U1 = RelaxedInst<Fq>::zero(); v->U2 = RelaxedInst<Fe>::zero(); v->u2 = FreshInst<Fe>::zero(); v->T2.x = v->T2.y = Fe::zero();
   v->u1_run = Fe::zero(); v->u2_run = Fq::zero();
+  v->CA = G1::identity(); v->ca_valid = true;
   v->pending_sec = false; v->sec_T_valid = false; v->t1[0].step = v->t1[1].step = -1; v->broken = false;
   memset(v->ph_s, 0, sizeof(v->ph_s)); memset(v->ph_n, 0, sizeof(v->ph_n));
   return VIMZ_OK;
@@ -979,6 +1018,7 @@ int vimz_ivc_proof_import(vimz_ivc* v, const uint8_t* blob, size_t len) {
   memcpy(p->z_cur.data(), zp + 32 * p->len_z, 32 * p->len_z);
   p->z0 = v->z0;
   v->i = h.steps; p->steps = h.steps;
+  v->ca_valid = false;
   v->U2 = hs.U2; v->U1 = hs.U1; v->u2 = hs.u2; v->T2 = hs.T2; v->u1_run = hs.u1_run; v->u2_run = hs.u2_run;
   v->sec_T_valid = (h.flags & 1) != 0; v->pending_sec = false; v->t1[0].step = v->t1[1].step = -1; v->broken = false;
   v->c1->cache = aug::AugCache<Fe>(); v->c2.cache = aug::AugCache<Fq>();

@@ -61,7 +61,12 @@ struct vimz_ivc {
   hipStream_t s3 = nullptr; hipEvent_t ev_fold = nullptr; MsmWorkspace ws3;
   // The step rows' cross term of step i (against the running instance of step i, or — lookahead — of step i-1) lives in slot i & 1:
   // its vector, the pinned window sums and plan of its commitment, the events of that MSM.  step = the step it belongs to (-1: none).
-  struct T1Slot { int64_t step = -1; bool hasB = false; uint32_t* buf = nullptr; char* pin = nullptr; MsmPlan plan{}; hipEvent_t done = nullptr; hipEvent_t* ev = nullptr; };
+  // Boolean-row form (r1cs_ops.hpp: bool_row_masked; VERDICT r5 #2a): the MSM takes `bufm` — half the points of `buf` — and the commitment is completed on the
+  // host by u_at·S_1(row) − ca_at, with u_at / ca_at = the running instance's u and C_A = Σ_{i<n_bool} AZ[i]·ck_i at the time the vector was computed.
+  struct T1Slot { int64_t step = -1; bool hasB = false; uint32_t* buf = nullptr; char* pin = nullptr; MsmPlan plan{}; hipEvent_t done = nullptr; hipEvent_t* ev = nullptr;
+                  uint32_t* bufm = nullptr; bool tricked = false; Fe u_at = Fe::zero(); G1 ca_at = G1::identity(); };
+  bool bool_rows = false;          // the boolean-row form is in use (step circuits built here: their boolean rows come first; VIMZ_IVC_BOOL_ROWS=0 turns it off)
+  G1 CA = G1::identity(); bool ca_valid = false;      // C_A of the running instance, kept by linearity (C_A += rho·S_1 per fold); recomputed by one MSM when not valid
   T1Slot t1[2];
   hipEvent_t ev_alt[7] = {};       // profiling events of slot 1 (slot 0 uses the context's)
   char* pin_t1b = nullptr;         // pinned window sums (+ totals) of slot 1

@@ -43,7 +43,7 @@ namespace vz {
 // every bucket is then added into half of the 14 planes: 131 k full additions instead of 32 k, a tenth of the accumulation's work on top — and inside
 // a fold, where the GPU is busy throughout, that costs more than the shorter tail gains: 1 176 against 1 198 steps/s over 256 rows, 936 against 938 in
 // the 20-row window, one chain 829 against 822 (round 5, same box, profiles/r05_reduce_planes.txt).
-struct MsmTuning { int sort_blocks = 0, combine_lane_bits = -1, small_lean = 0, witness_sub = 0, ones_dense = 1, reduce_planes = 0, accum_lds_kb = 0; };
+struct MsmTuning { int sort_blocks = 0, combine_lane_bits = -1, small_lean = 0, witness_sub = 0, ones_dense = 1, reduce_planes = 0, accum_lds_kb = 0, dense_sub = 0; };
 inline const MsmTuning& msm_tuning() {
   static const MsmTuning t = [] {
     MsmTuning r;
@@ -52,6 +52,7 @@ inline const MsmTuning& msm_tuning() {
       if (const char* q = strstr(e, "combine_lane_bits=")) r.combine_lane_bits = atoi(q + 18);
       if (const char* q = strstr(e, "small_lean=")) r.small_lean = atoi(q + 11);
       if (const char* q = strstr(e, "witness_sub=")) { const int v = atoi(q + 12); if (v >= 2 && v <= MSM_SUB) r.witness_sub = v; }
+      if (const char* q = strstr(e, "dense_sub=")) { const int v = atoi(q + 10); if (v >= 2 && v <= MSM_SUB) r.dense_sub = v; }
       if (const char* q = strstr(e, "ones_dense=")) r.ones_dense = atoi(q + 11);
       if (const char* q = strstr(e, "reduce_planes=")) r.reduce_planes = atoi(q + 14);
       if (const char* q = strstr(e, "accum_lds_kb=")) { const int v = atoi(q + 13); if (v >= 0 && v <= 160) r.accum_lds_kb = v; }
@@ -1004,7 +1005,8 @@ hipError_t msm_launch(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_ba
   const int wsub = msm_tuning().witness_sub;
   // (longer pieces for the dense MSM(T) — 24 / 32 entries, half the partials for k_combine — measured within the noise at 256 rows and
   //  worse in the 20-row window and on one chain: 842 against 876, 786 against 812)
-  const uint32_t sub = n < (1u << 15) ? 8u : split_ones ? (uint32_t)(wsub > 0 ? wsub : n < (1u << 19) ? 8 : MSM_SUB) : (uint32_t)MSM_SUB;   // MSM_SUB for everything large
+  const int dsub = tb && tb->sub_hint > 0 ? tb->sub_hint : msm_tuning().dense_sub;      // (a caller that knows its vector is sparse — ivc.hip's boolean-row form — asks for shorter pieces)
+  const uint32_t sub = n < (1u << 15) ? 8u : split_ones ? (uint32_t)(wsub > 0 ? wsub : n < (1u << 19) ? 8 : MSM_SUB) : (uint32_t)(dsub >= 2 && dsub <= (int)MSM_SUB ? dsub : MSM_SUB);   // MSM_SUB for everything large
   const size_t max_subs = entries / sub + pl.nb + 1;
   VZ_HIP_CHECK(ws.reserve(pl.nb, entries, max_subs));
   const int TB = 256;
@@ -1148,6 +1150,32 @@ Affine<typename C::Base> msm_finish(const MsmPlan& pl, const void* pinned) {
   }
   if (pl.split_ones) add_full(acc, host_point(kout));
   return to_affine(acc);
+}
+
+// Σ_{scalar_i = 1} P_i as a call of its own (the unit-scalar tail of msm_launch without a Pippenger around it): the sum S_1 of the key's points on the
+// boolean rows whose fresh bit is one (ivc.hip: the boolean-row form of the cross term's commitment).  Result: one XYZZ point at pinned_dst.
+template <class C>
+hipError_t ones_launch(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_bases, const uint32_t* d_scalars, size_t n, int scalars_mont, void* pinned_dst) {
+  typedef typename C::Coord F;
+  typedef typename C::Scalar S;
+  VZ_HIP_CHECK(ws.reserve(1, 1, 1));
+  uint32_t* lvl0 = reinterpret_cast<uint32_t*>(ws.ones_partial);
+  uint32_t* lvl1 = lvl0 + (size_t)XYZZ_WORDS * ONES_THREADS;
+  uint32_t* top = lvl1 + (size_t)XYZZ_WORDS * (ONES_THREADS / 256);      // (inside the spare slots of ones_partial)
+  hipLaunchKernelGGL((k_ones_dense<S, F>), dim3(ONES_THREADS / 256), dim3(256), 0, stream, d_scalars, d_bases, n, scalars_mont, lvl0);
+  hipLaunchKernelGGL(k_tree256<F>, dim3(ONES_THREADS / 256), dim3(256), 0, stream, lvl0, ONES_THREADS, lvl1);
+  hipLaunchKernelGGL(k_tree256<F>, dim3(1), dim3(256), 0, stream, lvl1, ONES_THREADS / 256, top);
+  VZ_HIP_CHECK(hipGetLastError());
+  return hipMemcpyAsync(pinned_dst, top, 4 * (size_t)XYZZ_WORDS, hipMemcpyDeviceToHost, stream);
+}
+template <class C>
+XYZZ<typename C::Base> ones_finish(const void* pinned) {
+  typedef typename C::Coord F;
+  typedef typename C::Base FS;
+  const uint32_t* d = reinterpret_cast<const uint32_t*>(pinned);
+  XYZZ<FS> p; FS* f[4] = {&p.X, &p.Y, &p.ZZ, &p.ZZZ};
+  for (int k = 0; k < 4; k++) { F t; for (int i = 0; i < 9; i++) t.v[i] = d[COORD_WORDS * k + i]; *f[k] = t.to_std(); }
+  return p;
 }
 
 template <class C>

@@ -59,6 +59,7 @@ struct BaseTables {
   // fused small path only: every multiple of the table rows — mult[(w·n_total + i)·2^(c−1) + (m−1)] = m·2^(c·w)·P_i, m = 1..2^(c−1) —
   // so that a digit SELECTS its point: no buckets, no sort, the MSM is one sum (k_msm_fixed).  189 KB per base point at c = 7.
   const uint32_t* mult = nullptr;
+  int sub_hint = 0;      // large path: entries per accumulation thread (0: the default, 16); a caller whose vector is mostly zeros asks for shorter pieces
 };
 
 static inline MsmPlan msm_plan(size_t n, int scalar_bits, int c_override) {
@@ -171,5 +172,10 @@ template <class C>
 hipError_t msm_run(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_bases, const uint32_t* d_scalars, size_t n,
                    int scalars_mont, int c_override, Affine<typename C::Base>* out_affine_mont, MsmStats* stats,
                    hipEvent_t* ev /* 7 events or nullptr */, int split_ones, const BaseTables* tb = nullptr);
+// Σ_{scalar_i = 1} P_i alone: one XYZZ point (device form) at pinned_dst; ones_finish converts it
+template <class C>
+hipError_t ones_launch(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_bases, const uint32_t* d_scalars, size_t n, int scalars_mont, void* pinned_dst);
+template <class C>
+XYZZ<typename C::Base> ones_finish(const void* pinned);
 
 }  // namespace vz

@@ -76,6 +76,7 @@ int vz_prover_create_layout(vimz_ctx* ctx, const vimz_circuit* circuit, const vi
   p->n_wires = b.n_wires; p->n_c = b.n_constraints(); p->len_z = b.len_z; p->n_priv = b.n_priv; p->n_aux = n_aux;
   p->n_jobs = (uint32_t)b.jobs.size(); p->n_fops = (uint32_t)b.fops.size();
   p->ivc = ivc != 0; p->c0 = c0; p->step_wires = ivc ? step_wires : b.n_wires; p->step_c = ivc ? step_c : b.n_constraints();
+  p->n_bool = std::min<uint32_t>(b.n_bool, p->step_c);
   auto fail_free = [&](const char* what, hipError_t e) { for (void* d : p->owned) hipFree(d); delete p; return vz_fail(ctx, VIMZ_ERR_HIP, what, e); };
   hipError_t e;
 #define UP(vec, dst) do { e = upload(vec, &dst); if (dst) p->owned.push_back((void*)dst); if (e != hipSuccess) return fail_free("upload " #vec, e); } while (0)

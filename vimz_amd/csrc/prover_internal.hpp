@@ -127,6 +127,10 @@ struct vimz_prover {
   // The batch producer only touches the step part: wires [c0, step_wires) and rows [0, step_c).
   bool ivc = false;
   uint32_t c0 = 0, step_wires = 0, step_c = 0;
+  // rows [0, n_bool) of the step circuit are b·(b − 1) = 0 (builder.hpp); want_s1: the producer also sums, per row, the key's points on those rows whose
+  // fresh bit is one (S_1 of the boolean-row form of the cross term's commitment, ivc.hip) into the row's pinned slot S1_SLOT
+  uint32_t n_bool = 0; bool want_s1 = false;
+  static constexpr size_t S1_SLOT = 4 * (size_t)XYZZ_WORDS * (MSM_MAX_WINDOWS - 1);
   const uint32_t* long_items_aug = nullptr; uint32_t n_long_aug = 0, n_med_aug = 0;   // long (matrix,row) items of the verifier rows
   size_t max_batch = 0;
   // device: shape
@@ -723,6 +727,7 @@ static int fold_head_batch(vimz_prover* p, FoldJob& J, size_t rows) {
     const uint32_t* Zi = bb.Z + 8 * r * nw;
     launch_spmv(p, sh, Zi, bb.az + 8 * r * nc, bb.bz + 8 * r * nc, bb.cz + 8 * r * nc, 1);
     if (p->ivc) P_TRY(hipEventRecord(bb.ev_p[r], sh));
+    if (p->want_s1) P_TRY(ones_launch<BnG1>(sh, p->wsH, p->ck->d, bb.az + 8 * r * nc, p->n_bool, 1, (char*)bb.pin + r * FoldJob::pin_stride + vimz_prover::S1_SLOT));
     P_TRY(msm_launch<BnG1>(sh, p->wsH, p->ck->d, Zi + 8 * (size_t)p->c0, sw - p->c0, 1, 0, (char*)bb.pin + r * FoldJob::pin_stride, &p->planB, nullptr, 1, p->ck->tables ? &J.tbl : nullptr));
     P_TRY(mark_row(sh, bb, r));
     P_TRY(hipEventRecord(bb.ev[r], sh));
@@ -998,6 +1003,7 @@ static int fold_issue(vimz_prover* p, const FoldJob& J, size_t k) {
     MsmWorkspace& ws = two && (r & 1) ? p->wsH : p->wsB;
     launch_spmv(p, st, Zi, bb.az + 8 * r * nc, bb.bz + 8 * r * nc, bb.cz + 8 * r * nc, 1);
     if (p->ivc) P_TRY(hipEventRecord(bb.ev_p[r], st));
+    if (p->want_s1) P_TRY(ones_launch<BnG1>(st, ws, p->ck->d, bb.az + 8 * r * nc, p->n_bool, 1, (char*)bb.pin + r * FoldJob::pin_stride + vimz_prover::S1_SLOT));
     P_TRY(msm_launch<BnG1>(st, ws, p->ck->d, Zi + 8 * (size_t)p->c0, sw - p->c0, 1, 0, (char*)bb.pin + r * FoldJob::pin_stride, &p->planB, nullptr, 1, p->ck->tables ? &J.tbl : nullptr));
     P_TRY(mark_row(st, bb, r));
     P_TRY(hipEventRecord(bb.ev[r], st));

@@ -219,16 +219,32 @@ __global__ void __launch_bounds__(256) k_spmv_cross16(CsrDev A, CsrDev B, CsrDev
   store_fe(T, r, fe_of29<F>(G::template sub<3>(t1, t2)));
 }
 
+// The BOOLEAN-ROW form of a cross term's commitment (ivc.hip).  On a row b·(b − 1) = 0 — rows [0, nb) of a step circuit, circuit/builder.hpp — the cross term
+// of the running instance (a = AZ_1[i], u_1) and a fresh one (b = az_2[i] in {0, 1}) is  T_i = b ? a − u_1 : −a,  so with C_A = Σ_{i<nb} a_i·ck_i (kept by
+// linearity) and S_1 = Σ_{b_i = 1} ck_i (a unit-scalar sum)
+//     Σ_{i<nb} T_i·ck_i = 2·Σ_{b_i = 1} T_i·ck_i + u_1·S_1 − C_A:
+// the dense MSM runs over the vector T' = (2·T_i where b_i = 1, 0 where b_i = 0; T_i on the other rows) — half the points — and the host adds u_1·S_1 − C_A.
+// Exact for ANY fresh value: a row whose az is neither 0 nor 1 gets T_i + a_i (its −a_i is inside −C_A).
+template <class F>
+__device__ __forceinline__ F bool_row_masked(const F& t, const F& a, const F& az_fresh) {
+  const bool z = az_fresh.is_zero(), o = az_fresh.eq(F::one());
+  F r = F::zero();
+  if (o) r = F::dbl(t);
+  if (!z && !o) r = F::add(t, a);
+  return r;
+}
 template <class F>
 __global__ void __launch_bounds__(256) k_cross_term(size_t n, const uint32_t* __restrict__ az1, const uint32_t* __restrict__ bz1, const uint32_t* __restrict__ cz1, F u1,
                                                     const uint32_t* __restrict__ az2, const uint32_t* __restrict__ bz2, const uint32_t* __restrict__ cz2, F u2,
-                                                    uint32_t* __restrict__ T) {
+                                                    uint32_t* __restrict__ T, uint32_t* __restrict__ Tm = nullptr, uint32_t nb = 0) {
   VZ_GRID_STRIDE(i, n) {
-    F t = mul_fresh(load_fe<F>(az1, i), load_fe<F>(bz2, i));            // (instance 2 is the fresh one wherever a fold calls this)
-    t = F::add(t, mul_fresh(load_fe<F>(bz1, i), load_fe<F>(az2, i)));
+    const F a1 = load_fe<F>(az1, i), a2 = load_fe<F>(az2, i);
+    F t = mul_fresh(a1, load_fe<F>(bz2, i));            // (instance 2 is the fresh one wherever a fold calls this)
+    t = F::add(t, mul_fresh(load_fe<F>(bz1, i), a2));
     t = F::sub(t, mul_fresh(u1, load_fe<F>(cz2, i)));
     t = F::sub(t, mul_fresh(load_fe<F>(cz1, i), u2));
     store_fe(T, i, t);
+    if (Tm) store_fe(Tm, i, i < nb ? bool_row_masked(t, a1, a2) : t);
   }
 }
 
@@ -242,7 +258,8 @@ template <class F>
 __global__ void __launch_bounds__(256) k_fold_cross(size_t n, uint32_t* __restrict__ AZ, uint32_t* __restrict__ BZ, uint32_t* __restrict__ CZ, uint32_t* __restrict__ E,
                                                     const uint32_t* Tin, int fold_E, F r, int hasB, F r_prev, const uint32_t* __restrict__ negB, F u1_new,
                                                     const uint32_t* __restrict__ az, const uint32_t* __restrict__ bz, const uint32_t* __restrict__ cz,
-                                                    uint32_t* out, const uint32_t* __restrict__ azn, const uint32_t* __restrict__ bzn, const uint32_t* __restrict__ czn, F u2) {
+                                                    uint32_t* out, const uint32_t* __restrict__ azn, const uint32_t* __restrict__ bzn, const uint32_t* __restrict__ czn, F u2,
+                                                    uint32_t* __restrict__ outm = nullptr, uint32_t nb = 0) {
   VZ_GRID_STRIDE(i, n) {
     // (az, bz, cz and the coming row's are fresh products: mul_fresh; the cross term Tin is zero on every linear row)
     const F a = F::add(load_fe<F>(AZ, i), mul_fresh(r, load_fe<F>(az, i)));
@@ -255,11 +272,13 @@ __global__ void __launch_bounds__(256) k_fold_cross(size_t n, uint32_t* __restri
       if (__ballot(!t.is_zero()) != 0ull) { const F e = F::add(load_fe<F>(E, i), F::mul(r, t)); if (!t.is_zero()) store_fe(E, i, e); }
     }
     if (out) {
+      const F an = load_fe<F>(azn, i);
       F t = mul_fresh(a, load_fe<F>(bzn, i));
-      t = F::add(t, mul_fresh(b, load_fe<F>(azn, i)));
+      t = F::add(t, mul_fresh(b, an));
       t = F::sub(t, mul_fresh(u1_new, load_fe<F>(czn, i)));
       t = F::sub(t, mul_fresh(c, u2));
       store_fe(out, i, t);
+      if (outm) store_fe(outm, i, i < nb ? bool_row_masked(t, a, an) : t);      // (the vector the MSM takes: boolean-row form, see k_cross_term)
     }
   }
 }
