@@ -98,6 +98,13 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
   }
   v->ca_valid = false;      // (valid again when this call ends with C_A kept up to its last fold)
   G1Aff S1_row; S1_row.x = S1_row.y = Fq::zero();      // S_1 of the row being folded: Σ ck_i over the boolean rows whose fresh bit is one (producer, pinned)
+  bool pend_ca = false; uint32_t pend_rho[4] = {0, 0, 0, 0}; G1Aff pend_S1 = S1_row; int pend_slot[2] = {-1, -1};
+  auto apply_pending_ca = [&]() {
+    if (!pend_ca) return;
+    if (!aff_is_identity(pend_S1)) { const uint32_t k[5] = {pend_rho[0], pend_rho[1], pend_rho[2], pend_rho[3], 1u}; G1 t = scalar_mul(pend_S1, k, 129); add_full(v->CA, t); }
+    for (int q : pend_slot) if (q >= 0) v->t1[q].ca_at = v->CA;
+    pend_ca = false;
+  };
   // commitment to the vector of slot `par` (base-range split: the first share stays here, helper h commits to rows [off_h, off_h + n_h)
   // with its replica of the key)
   auto queue_msm = [&](int par) -> int {
@@ -235,6 +242,20 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
       // ---- 1. the previous fresh secondary instance is complete once its two MSMs are back -------------------------------------
       // (while they run: the statement part of this step's output hash, which depends on nothing they produce)
       v->c1->precompute_statement(i + 1, v->z0, zs.data() + (first + r + 1) * p->len_z);
+      // Boolean-row form, the host's share — three scalar multiplications of S_1 points per step, done HERE, where the thread would otherwise wait for the
+      // previous step's secondary MSMs (0.5 ms): C_A takes in the previous fold (rho_{i-1}·S_1(row i-1)), then this step's completion u·S_1(row i) − C_A
+      G1 boolCorr = G1::identity();
+      if (trick) {
+        apply_pending_ca();
+        P_TRY(wait_row_flag(bb, r, bb.ev[r]));      // (the producer is a batch ahead: no wait in the steady state)
+        S1_row = to_affine(ones_finish<BnG1>((const char*)bb.pin + r * pin_stride + vimz_prover::S1_SLOT));
+        auto& sl = v->t1[i & 1];
+        if (i > 0 && sl.step == (int64_t)i && sl.tricked) {
+          if (!aff_is_identity(S1_row)) { const Fe uc = Fe::from_mont(sl.u_at); boolCorr = scalar_mul(S1_row, uc.v, 254); }
+          G1 nca = sl.ca_at; if (!nca.is_identity()) nca.Y = Fq::neg(nca.Y);
+          add_full(boolCorr, nca);
+        }
+      }
       if ((rc = finish_secondary(v))) return rc;
       // ---- 2. primary verifier circuit on the host: folds (U2, u2) and hashes the result ----------------------------------------
       t0 = now_s();
@@ -250,7 +271,6 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
       // (waited for on the HOST, not by a barrier on this stream: a high-priority queue stalled behind the producer's event keeps the
       //  producer's low-priority queues from being served — once a producer fell behind it stayed behind, 10× slower: DESIGN.md §5c)
       P_TRY(wait_row_flag(bb, r, bb.ev[r]));
-      if (trick) S1_row = to_affine(ones_finish<BnG1>((const char*)bb.pin + r * pin_stride + vimz_prover::S1_SLOT));
       P_TRY(upload_pinned(s, Zi + 8 * sw, pin_aug1, 32 * aw1));
       // the commitment to the verifier wires needs the upload only: it starts first, on stream 2
       P_TRY(hipEventRecord(v->ev_fork, s));
@@ -263,7 +283,16 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
                          Zi, az, bz, cz, i > 0 ? p->AZ : nullptr, p->BZ, p->CZ, v->u1_run, Fe::one(), p->T);
       P_TRY(hipGetLastError());
       if (i > 0) {
-        if (v->t1[i & 1].step != (int64_t)i && (rc = launch_direct(bb, r, i))) return rc;       // first row of a call: nothing was queued ahead
+        if (v->t1[i & 1].step != (int64_t)i) {       // first row of a call: nothing was queued ahead
+          if ((rc = launch_direct(bb, r, i))) return rc;
+          auto& sl = v->t1[i & 1];
+          if (sl.tricked) {      // (its completion: u·S_1(row i) − C_A as they are now)
+            boolCorr = G1::identity();
+            if (!aff_is_identity(S1_row)) { const Fe uc = Fe::from_mont(sl.u_at); boolCorr = scalar_mul(S1_row, uc.v, 254); }
+            G1 nca = sl.ca_at; if (!nca.is_identity()) nca.Y = Fq::neg(nca.Y);
+            add_full(boolCorr, nca);
+          }
+        }
         P_TRY(msm_launch<BnG1>(s, ctx->msm_ws, p->ck->d + (size_t)AFFINE_WORDS * sc, p->T + 8 * sc, nc - sc, 1, 0, v->pin + 4 * v->pin_res, &v->plan_T1v, nullptr, 0, v->tb_T1v.d ? &v->tb_T1v : nullptr));
       }
       P_TRY(hipEventRecord(v->ev_a, s));
@@ -323,14 +352,6 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
           for (int bit = 127; bit >= 0; bit--) { acc = dbl(acc); if ((v->rho_prev_low[bit >> 5] >> (bit & 31)) & 1u) add_mixed(acc, cD); }
           lookB = acc;
         }
-      }
-      // boolean-row form: the commitment of this step's vector is completed by u·S_1(row i) − C_A, both as they were when the vector was computed — one
-      // 254-bit scalar multiplication on the host, here, while the device works on the verifier rows
-      G1 boolCorr = G1::identity();
-      if (i > 0 && slot.tricked) {
-        if (!aff_is_identity(S1_row)) { const Fe uc = Fe::from_mont(slot.u_at); boolCorr = scalar_mul(S1_row, uc.v, 254); }
-        G1 nca = slot.ca_at; if (!nca.is_identity()) nca.Y = Fq::neg(nca.Y);
-        add_full(boolCorr, nca);
       }
       t_wp[1] += now_s() - tw; tw = now_s();
       P_TRY(take_T1_step(false));
@@ -438,10 +459,9 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
         t_hk[3] += now_s() - tq; tq = now_s();
         P_TRY(hipEventRecord(v->ev_fold, v->s2));  // the verifier rows of the next step may start here
         t_hk[1] += now_s() - tq;
-        if (trick) {      // C_A of the running instance now holds this fold: C_A += rho·S_1(row i); the vectors just queued were computed against it
-          if (!aff_is_identity(S1_row)) { const uint32_t k[5] = {rho_low[0], rho_low[1], rho_low[2], rho_low[3], 1u}; G1 t = scalar_mul(S1_row, k, 129); add_full(v->CA, t); }
-          if (fa.need1) v->t1[(i + 1) & 1].ca_at = v->CA;
-          if (fa.look) v->t1[i & 1].ca_at = v->CA;
+        if (trick) {      // C_A of the running instance takes this fold in — C_A += rho·S_1(row i) — at the top of the next step (apply_pending_ca); the vectors just queued were computed against it
+          pend_ca = true; memcpy(pend_rho, rho_low, 16); pend_S1 = S1_row;
+          pend_slot[0] = fa.need1 ? (int)((i + 1) & 1) : -1; pend_slot[1] = fa.look ? (int)(i & 1) : -1;
         }
         return VIMZ_OK;
       };
@@ -495,6 +515,7 @@ int ivc_fold_core(vimz_ivc* v, const uint64_t* step_inputs, const uint64_t* witn
   v->t1[0].step = v->t1[1].step = -1;
   for (uint32_t k = 0; k < p->len_z; k++) p->z_cur[k] = zs[nsteps * p->len_z + k];
   guard.armed = false;
+  if (trick) apply_pending_ca();
   v->ca_valid = trick;
   v->ph_s[IP_TOTAL] += now_s() - t_all; v->ph_n[IP_TOTAL] += nsteps;
   if (dbg_timing) fprintf(stderr, "[timing] wait_primary_msm per step: finish(W) + statement %.3f, lookahead's host share %.3f, small MSM(W aug) %.3f, verifier rows + small MSM(T) %.3f, large MSM(T) %.3f ms\n",

@@ -1158,7 +1158,7 @@ template <class C>
 hipError_t ones_launch(hipStream_t stream, MsmWorkspace& ws, const uint32_t* d_bases, const uint32_t* d_scalars, size_t n, int scalars_mont, void* pinned_dst) {
   typedef typename C::Coord F;
   typedef typename C::Scalar S;
-  VZ_HIP_CHECK(ws.reserve(1, 1, 1));
+  if (!ws.ones_partial) VZ_HIP_CHECK(hipMalloc(&ws.ones_partial, 4 * (size_t)XYZZ_WORDS * (16384 + 64 + 512)));      // (only this: a general reserve() here would be freed and re-made — hipFree synchronises the device — by the first real MSM on this workspace)
   uint32_t* lvl0 = reinterpret_cast<uint32_t*>(ws.ones_partial);
   uint32_t* lvl1 = lvl0 + (size_t)XYZZ_WORDS * ONES_THREADS;
   uint32_t* top = lvl1 + (size_t)XYZZ_WORDS * (ONES_THREADS / 256);      // (inside the spare slots of ones_partial)
