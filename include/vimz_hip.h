@@ -193,6 +193,10 @@ int vimz_wtns_load(const uint8_t* data, size_t len, uint64_t* out, size_t cap_el
 #define VIMZ_CIRCUIT_INFO_LEN 16
 /* info = {wires, constraints (incl. linear), linear constraints, len_z, private inputs, nnz A, nnz B, nnz C,
  *         dictionary size, decomposition groups, lane groups, lane instructions, lane rows, hash jobs, chains, field ops} */
+/* Optional, host only: synthesises ahead of time what vimz_ivc_create needs of this circuit — the augmented primary circuit (the step circuit with Nova's
+ * verifier circuit appended, nova-snark's `circuit_primary` of `PublicParams::setup`, reached from vimz/src/nova_snark_backend/folding.rs:20-25) and its digest —
+ * and keeps it with the circuit object; the IVCs of a proof made as several segments then share one synthesis.  Call it on the thread that built the circuit. */
+int vimz_circuit_prepare_ivc(const vimz_circuit* c);
 int vimz_circuit_info(const vimz_circuit* c, uint64_t info[VIMZ_CIRCUIT_INFO_LEN]);
 /* raw tables (CSR of A,B,C with a coefficient dictionary; witness-program tables of vimz_amd/csrc/circuit/program.hpp) */
 #define VIMZ_CX_A_ROWPTR 0

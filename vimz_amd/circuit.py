@@ -54,6 +54,13 @@ class Circuit:
          self.n_dict, self.n_decomp, self.n_lane_groups, self.n_lane_instr, self.n_lane_rows, self.n_jobs, self.n_chains,
          self.n_fops) = [int(x) for x in info]
 
+    def prepare_ivc(self):
+        """vimz_circuit_prepare_ivc: synthesise the augmented circuits of a Nova IVC over this circuit now (host only; vimz_ivc_create otherwise does it on first use)."""
+        self.lib.vimz_circuit_prepare_ivc.argtypes = [C.c_void_p]
+        rc = self.lib.vimz_circuit_prepare_ivc(self.h)
+        if rc != L.OK:
+            raise L.VimzError(rc, "vimz_circuit_prepare_ivc")
+
     @classmethod
     def for_resolution(cls, transformation, resolution="HD"):
         return cls(transformation, *default_shape(transformation, resolution))

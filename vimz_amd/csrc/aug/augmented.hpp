@@ -98,6 +98,9 @@ struct AugCircuit {
     digest = F::to_mont(c);
   }
 
+  // `b` already holds a finished augmented circuit (a copy of one that finish() made): take over its description instead of synthesising it again
+  void adopt(bool is_primary, uint32_t lz, uint32_t sw, uint32_t sc, const F& dg) { primary = is_primary; len_z = lz; step_wires = sw; step_constraints = sc; digest = dg; }
+
   // Witness of the verifier part for one step.  z_i / z_next: the step circuit's state (values).  aug: receives the
   // aug_wires() values (Montgomery) in wire order, the public IOs last.
   AugOut<FP> witness(const AugIn<FP>& in, const F* z_i, const F* z_next, std::vector<F>& aug, bool* bad) const {

@@ -73,6 +73,9 @@ int vz_prover_create_layout(vimz_ctx* ctx, const vimz_circuit* circuit, const vi
   P_TRY(hipSetDevice(ctx->device));
   auto* p = new vimz_prover();
   p->ctx = ctx; p->circuit = circuit; p->ck = ck; p->max_batch = max_batch;
+  static const bool dbg_create = getenv("VIMZ_DEBUG_TIMING") != nullptr;
+  double t_c = now_s();
+  auto lap = [&](const char* what) { if (dbg_create) { const double t = now_s(); fprintf(stderr, "[timing] prover_create(%p): %s %.1f ms\n", (void*)ctx, what, 1e3 * (t - t_c)); t_c = t; } };
   p->n_wires = b.n_wires; p->n_c = b.n_constraints(); p->len_z = b.len_z; p->n_priv = b.n_priv; p->n_aux = n_aux;
   p->n_jobs = (uint32_t)b.jobs.size(); p->n_fops = (uint32_t)b.fops.size();
   p->ivc = ivc != 0; p->c0 = c0; p->step_wires = ivc ? step_wires : b.n_wires; p->step_c = ivc ? step_c : b.n_constraints();
@@ -95,6 +98,7 @@ int vz_prover_create_layout(vimz_ctx* ctx, const vimz_circuit* circuit, const vi
     p->n_long = (uint32_t)items.size(); p->n_long_aug = (uint32_t)items_aug.size();
     UP(items, p->long_items); UP(items_aug, p->long_items_aug);
   }
+  lap("CSR + dictionary uploads");
   WitnessDev& W = p->wd;
   UP(b.decomp, W.decomp); UP(b.lane_groups, W.groups); UP(b.lane_instr, W.instr); UP(b.lane_rows, W.rows);
   UP(b.jobs, W.jobs); UP(b.chains, W.chains); UP(b.fops, W.fops); UP(b.lc_terms, W.lc_terms);
@@ -134,6 +138,7 @@ int vz_prover_create_layout(vimz_ctx* ctx, const vimz_circuit* circuit, const vi
     W.poseidon29 = getenv("VIMZ_DEBUG_POSEIDON_STD") ? 0u : 1u;
   }
 #undef UP
+  lap("witness program + Poseidon tables");
   auto dalloc = [&](uint32_t** dst, size_t bytes) { e = hipMalloc((void**)dst, bytes ? bytes : 32); if (e == hipSuccess) { p->owned.push_back(*dst); e = hipMemset(*dst, 0, bytes ? bytes : 32); } return e; };   // (null-stream fills: synchronised below)
   const size_t B = max_batch;
   if (dalloc(&p->priv_d, 32 * B * p->n_priv) != hipSuccess || dalloc(&p->zs_d, 32 * (B + 1) * p->len_z) != hipSuccess ||
@@ -145,6 +150,7 @@ int vz_prover_create_layout(vimz_ctx* ctx, const vimz_circuit* circuit, const vi
       dalloc(&p->bz2, 32 * (size_t)p->n_c) != hipSuccess || dalloc(&p->cz2, 32 * (size_t)p->n_c) != hipSuccess ||
       dalloc(&p->bad_d, 64) != hipSuccess)
     return fail_free("device allocation", e);
+  lap("device buffers (running instance, batch 0)");
   { int lo = 0, hi = 0; hipDeviceGetStreamPriorityRange(&lo, &hi);
     // (the producer sits on the lowest of HIP's three priority levels; confining it to a CU mask instead measured no better: DESIGN.md §9)
     if ((e = vz_stream_acquire(ctx, lo, &p->sB)) != hipSuccess) return fail_free("stream", e); }
@@ -174,6 +180,7 @@ int vz_prover_create_layout(vimz_ctx* ctx, const vimz_circuit* circuit, const vi
       for (size_t i = 0; i < B; i++) if ((e = hipEventCreateWithFlags(&bb.ev_d[i], hipEventDisableTiming)) != hipSuccess) return fail_free("event", e);
     }
   }
+  lap("batch buffers, events, pinned");
   {   // head batch of a fold call (prover_internal.hpp: fold_head_batch): staging layout of the Poseidon jobs' wires, its stream
     int lo = 0, hi = 0; hipDeviceGetStreamPriorityRange(&lo, &hi);
     if ((e = vz_stream_acquire(ctx, lo, &p->sH)) != hipSuccess) return fail_free("stream", e);
@@ -196,6 +203,7 @@ int vz_prover_create_layout(vimz_ctx* ctx, const vimz_circuit* circuit, const vi
     p->head_eligible = ok;
   }
   if ((e = hipStreamSynchronize(nullptr)) != hipSuccess) return fail_free("sync", e);   // the hipMemset fills above ran on the null stream
+  lap("head-batch layout + sync of the fills");
   p->z_cur.assign(p->len_z, Fe::zero()); p->z0 = p->z_cur;
   *out = p;
   return VIMZ_OK;

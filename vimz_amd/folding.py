@@ -149,8 +149,15 @@ def prepare_folding_overlapped(device, segments, transformation, resolution="HD"
     def make_ctx(k):
         ctxs[k] = hip.Context(device)
 
+    circuit_built = threading.Event()
+
     def make_circuit():
-        out["circuit"] = Circuit(transformation, *default_shape(transformation, resolution))
+        try:
+            out["circuit"] = Circuit(transformation, *default_shape(transformation, resolution))
+        finally:
+            circuit_built.set()      # (the keys need its SIZE only: they are made while this thread goes on)
+        if mode == "ivc":      # (the augmented circuits + their digests: 0.12 s of host work the segments' IVCs share — under the keys' generation)
+            out["circuit"].prepare_ivc()
 
     # the step circuit and contexts 1.. on threads; context 0 here: the keys need only it and the circuit's size, and are made while the others still come up
     th_circ = threading.Thread(target=guarded(make_circuit))
@@ -159,11 +166,12 @@ def prepare_folding_overlapped(device, segments, transformation, resolution="HD"
         x.start()
     if own_ctxs:
         guarded(make_ctx)(0)
-    th_circ.join()
-    if err:
+    circuit_built.wait()
+    if err or "circuit" not in out:
+        th_circ.join()
         for x in th_ctx:
             x.join()
-        raise err[0]
+        raise err[0] if err else RuntimeError("the step circuit could not be built")
     circuit = out["circuit"]
     t_cc = time.time()
     sonobe = backend == "sonobe" or mode == "cyclefold"
@@ -175,7 +183,7 @@ def prepare_folding_overlapped(device, segments, transformation, resolution="HD"
         ck = ctxs[0].bases_generate(_lib.CURVE_BN254_G1, n, b"ck")
     if window_tables:
         ck.precompute(16 if window_tables is True else int(window_tables))
-    for x in th_ctx:
+    for x in th_ctx + [th_circ]:
         x.join()
     if err:
         raise err[0]
