@@ -3,9 +3,9 @@
 #   the driver-style bench line and the long-window one, rocprofv3 kernel stats + the k_accum split of the same command, the
 #   FETCH_SIZE / WRITE_SIZE counter passes (separate runs, counters only) summarised per kernel — for the HD headline and for the
 #   4K / 8K shapes —, whole-image runs, the bench windows of the other configurations, the N > 1 lines on the one GPU of the box.
-#   usage: tools/refresh_profiles.sh [round tag, default r05] [parts: all | bench | rocprof | pmc | valu | e2e | configs | ranks | cores | cyclefold | round5 | stalls]
+#   usage: tools/refresh_profiles.sh [round tag, default r06] [parts: all | bench | rocprof | pmc | valu | e2e | configs | ranks | cores | cyclefold | round5 | round6 | stalls]
 set -u
-R=${1:-r05}
+R=${1:-r06}
 PARTS=${2:-all}
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/refresh; mkdir -p $O
@@ -14,7 +14,6 @@ want() { [ "$PARTS" = all ] || echo "$PARTS" | grep -q "$1"; }
 if want bench; then
   $T python3 bench.py --steps 20 --warmup 5 > $O/${R}_bench_driver_window.json 2> $O/bench.err
   for rep in b c d e; do $T python3 bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline > $O/${R}_bench_driver_window_$rep.json 2>> $O/bench.err; done
-  $T ./tools/ubench > $O/${R}_ubench_mfma_bound.txt 2>&1
   $T python3 tools/msm_bench.py 305185 > $O/${R}_msm_phases_tables.txt 2>&1
   $T python3 bench.py > $O/${R}_bench.json 2>> $O/bench.err
   $T python3 bench.py --segments 1 --no-cpu-baseline > $O/${R}_bench_one_chain.json 2>> $O/bench.err
@@ -129,6 +128,18 @@ if want round5; then   # round 5's own evidence: the large MSM's tails under str
       timeout 900 python3 bench.py --transformation $1 --resolution $2 --steps $3 --warmup 32 --repeats 3 --batch $b --no-extras --no-cpu-baseline --no-compress 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1 $2 batch $b: %.0f steps/s over $3 rows, peak device memory %.1f GB, verified %s' % (d['value'], d['peak_device_bytes'] / 1e9, d['verified']))"
     done; done; } > $O/${R}_batch_sweep.txt
   timeout 900 python3 tools/t_multiplicity.py 256 150 > $O/${R}_t_multiplicity.json 2> $O/t_mult.err
+fi
+if want round6; then   # round 6's own evidence: the full and the light decider end to end, the boolean-row form of the cross term (gate count, on / off on the same box)
+  (python3 tools/e2e.py contrast HD 1 cyclefold 2>/dev/null | tail -1; VIMZ_E2E_DECIDER=light python3 tools/e2e.py contrast HD 1 cyclefold 2>/dev/null | tail -1;
+   python3 tools/e2e.py hash HD 1 cyclefold 2>/dev/null | tail -1; python3 tools/e2e.py blur HD 1 cyclefold 2>/dev/null | tail -1) > $O/${R}_e2e_decider.jsonl
+  timeout 900 python3 tools/t_boolean_rows.py 256 150 > $O/${R}_t_boolean_rows.json 2> $O/t_bool.err
+  { echo "# the boolean-row form of the step rows' cross-term commitment (VIMZ_IVC_BOOL_ROWS=1, default) against the plain vector (=0), same box, same commands";
+    for v in 1 0; do for args in "--steps 20 --warmup 5" "--steps 256 --warmup 16" "--steps 720 --warmup 16 --repeats 3"; do
+      VIMZ_IVC_BOOL_ROWS=$v timeout 600 python3 bench.py --no-cpu-baseline --no-extras --no-compress $args 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('bool_rows=$v $args: %.0f steps/s, samples %s, MSM(T) phases in the bench %s, bucket additions per launch %.0f' % (d['value'], [round(x) for x in d['samples_steps_per_s']], {k: round(x, 3) for k, x in d['roofline']['msm_phase_ms'].items()}, d['roofline']['mixed_adds_per_launch']))"
+    done; done
+    for v in 1 0; do for cfg in "contrast HD 3 ivc" "crop HD 3 ivc" "contrast 4K 3 ivc"; do
+      VIMZ_IVC_BOOL_ROWS=$v timeout 600 python3 tools/e2e.py $cfg 2>/dev/null | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('bool_rows=$v whole image', d['config'], '%.0f steps/s, fold %.3f s, prepare folding %.3f s, wall %.2f s' % (d['steps_per_s'], d['spans_s']['Fold input'], d['spans_s']['Prepare folding'], d['wall_total_s']))"
+    done; done; } > $O/${R}_bool_rows_ab.txt
 fi
 if want stalls; then   # k_accum alone on the GPU (tools/msm_bench.py: 305 185 dense scalars): where its wave cycles go, and the bytes it fetches per launch (64-byte table entries)
   $T rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU --output-format csv -d $O/ps -o ps -- python3 tools/msm_bench.py 305185 > /dev/null 2>> $O/rocprof.err
