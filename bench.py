@@ -642,7 +642,7 @@ def main():
     ap.add_argument("--transformation", default="contrast")
     ap.add_argument("--resolution", default="HD")
     ap.add_argument("--batch", type=int, default=0, help="rows whose witnesses are generated together (0: folding.default_batch = 64: every BASELINE configuration below 64 GB of device memory, profiles/r05_batch_sweep.txt)")
-    ap.add_argument("--segments", type=int, default=0, help="row segments folded concurrently on each GPU, own context + streams each, and merged into one proof (default: 3 in IVC mode — 2 when the rank has fewer than six host cores —, 2 accumulators)")
+    ap.add_argument("--segments", type=int, default=0, help="row segments folded concurrently on each GPU, own context + streams each, and merged into one proof (default in IVC mode: 3, 4 for 192 rows or more per GPU on eight or more host cores, 2 when the rank has fewer than six; 2 accumulators)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--msm-helpers", type=int, default=0, help="IVC mode: split every step's large MSM(T) by base range over this many helper contexts "
@@ -703,7 +703,10 @@ def main():
     from vimz_amd.distributed import segment_bounds
     # three concurrent segments fill the GPU when the host has the cores to drive them (each: a fold thread, a launch-issuing thread, two
     # helpers); on two to five cores two segments do better — 865 against 541 steps/s on two cores, 636 as one chain (profiles/r04_cores.txt)
-    S = args.segments if args.segments > 0 else ((3 if usable_cores() >= 6 else 2) if args.mode == "ivc" else 2)
+    # (IVC: three segments; FOUR for a proof of 192 rows or more per GPU on eight or more host cores — since the boolean-row form took 13 % of a step's instructions
+    #  away a fourth chain finds room: 720 rows 1 312 -> 1 384 steps/s, 256 rows 1 272 -> 1 309, the 20-row window 871 -> 865; 27.6 instead of 21.1 GB at HD —
+    #  profiles/r06_segments_sweep.txt)
+    S = args.segments if args.segments > 0 else (((4 if args.steps >= 192 and usable_cores() >= 8 else 3) if usable_cores() >= 6 else 2) if args.mode == "ivc" else 2)
     # set-up with its parts side by side (folding.prepare_folding_overlapped): contexts and the step circuit together, then the keys, then — in IVC
     # mode — the segments' provers together; `setup_s` of the result line counts all of it
     t_setup = time.time()
