@@ -63,7 +63,7 @@ if want valu; then     # vector instructions per step and kernel (the instructio
 fi
 if want e2e; then      # whole images the way `vimz -b nova-snark -f <t>` sequences them
   : > $O/${R}_e2e.jsonl
-  for cfg in "contrast HD 3 ivc" "contrast HD 1 ivc" "grayscale HD 3 ivc" "blur HD 3 ivc" "crop HD 3 ivc" "contrast 4K 3 ivc" "contrast 4K 1 ivc" "resize 8K 3 ivc" "resize 8K 1 ivc" "contrast HD 2 accumulator"; do
+  for cfg in "contrast HD 4 ivc" "contrast HD 3 ivc" "contrast HD 1 ivc" "grayscale HD 4 ivc" "blur HD 4 ivc" "crop HD 4 ivc" "crop HD 3 ivc" "contrast 4K 4 ivc" "contrast 4K 3 ivc" "contrast 4K 1 ivc" "resize 8K 4 ivc" "resize 8K 3 ivc" "resize 8K 1 ivc" "contrast HD 2 accumulator"; do
     timeout 900 python3 tools/e2e.py $cfg 2>/dev/null | tail -1 >> $O/${R}_e2e.jsonl
   done
 fi
