@@ -22,7 +22,7 @@ from vimz_amd.distributed import fold_local_segments, fold_segments_merged  # no
 
 def main():
     t, res = sys.argv[1], sys.argv[2]
-    S = int(sys.argv[3]) if len(sys.argv) > 3 else 4      # (whole images: four concurrent segments since round 6, profiles/r06_segments_sweep.txt)
+    S = int(sys.argv[3]) if len(sys.argv) > 3 else 3      # (a lone, cold image: three segments — a fourth pays for itself only over repeated proofs, profiles/r06_segments_sweep.txt)
     mode = sys.argv[4] if len(sys.argv) > 4 else "ivc"
     save = sys.argv[5] if len(sys.argv) > 5 and sys.argv[5] != "-" else None
     batch = int(sys.argv[6]) if len(sys.argv) > 6 else 0            # rows whose witnesses are generated together (0: folding.default_batch)
