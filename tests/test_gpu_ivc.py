@@ -331,6 +331,9 @@ def test_proof_does_not_depend_on_the_schedule():
     # (the lookahead also with batches of two and three rows and no host-evaluated head: every way a row two steps ahead can fall into
     #  the same batch, the next one, or not exist)
     variants += [{"VIMZ_IVC_LOOKAHEAD": "1", "VIMZ_HEAD_ROWS": "0", "_batch": "2"}, {"VIMZ_IVC_LOOKAHEAD": "1", "VIMZ_HEAD_ROWS": "0", "_batch": "3"}]
+    # round 6: the default commits to the step rows' cross term in its boolean-row form (half the points through the MSM, the rest from a unit-scalar sum and a
+    # running commitment kept by linearity); the plain vector, alone and under the lookahead, must give the same commitment — the same proof
+    variants += [{"VIMZ_IVC_BOOL_ROWS": "0"}, {"VIMZ_IVC_BOOL_ROWS": "0", "VIMZ_IVC_LOOKAHEAD": "1", "VIMZ_HEAD_ROWS": "0", "_batch": "2"}]
     lines = []
     for env in variants:
         env = dict(env)
