@@ -211,16 +211,22 @@ struct DeciderCircuit {
   void finish(const cb::BuilderT<CfFr>& main, uint32_t lz, const cb::BuilderT<CfFq>* cf = nullptr, const Affine<CfFr>* gens = nullptr, uint32_t n_gens = 0) {
     b = cb::BuilderT<CfFr>(); len_z = lz; n_public = decider_n_public(lz);
     full = cf != nullptr; cf_shape = cf;
+    static const bool dbg_t = getenv("VIMZ_DEBUG_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_l = now();
+    auto lap = [&](const char* what) { if (dbg_t) { const double t = now(); fprintf(stderr, "[timing] decider circuit: %s %.0f ms\n", what, 1e3 * (t - t_l)); t_l = t; } };
     if (full) {
       const uint32_t need = std::max(cf->n_wires - 1 - CF_IO, cf->n_constraints());
       if (!gens || n_gens < need) throw std::runtime_error("decider: the CycleFold commitment key is shorter than the vectors it commits to");
       okey.build(gens, need);
+      lap("window tables of the CycleFold key");
     }
     CS<BnFr> cs; cs.b = &b; cs.base = b.n_wires;
     DeciderIn in; in.digest = CfFr::zero(); in.U = CfMainRelaxed::zero(); in.u = CfMainFresh::zero(); in.cfU = CfRelaxed::zero();
     in.cmT = in.Wn = in.En = NnPoint::zero(); in.eW = in.eE = CfFr::zero();
     if (full) { in.full.key = &okey; in.full.shape = cf; }
     synthesize_decider(cs, main, lz, in, &light_constraints);
+    lap("synthesis (checks 1-4, then 5-6)");
   }
   // the full assignment (wire 0 = 1, then the public inputs); *bad: some check of the statement fails on these inputs.
   // Full decider: in.full.W / .E = the running CycleFold witness and error vector (key and shape are filled in here)

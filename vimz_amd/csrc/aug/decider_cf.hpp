@@ -19,8 +19,11 @@
 //      ≈ 570 rows per row of the CycleFold shape.
 // Together ≈ 2.75 M constraints on top of the light circuit, whatever the step circuit.
 #pragma once
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <mutex>
+#include <string>
 #include <thread>
 #include "cyclefold.hpp"
 #include "../ckgen_impl.hpp"
@@ -197,24 +200,8 @@ struct DeciderCfGadget {
         continue;
       }
       if (k == 0 && !tmpl.have) { tmpl.row0 = cs.b->n_constraints(); tmpl.bits0 = bits_k; tmpl.chain0 = cs.base + (uint32_t)cs.w.size(); }
-      XY acc; acc.x = cs.constant(key.H.x); acc.y = cs.constant(key.H.y);
-      for (int j = 0; j < CFO_WINDOWS; j++) {
-        const N& b0 = bits[(size_t)k * CFO_BITS + 2 * j]; const N& b1 = bits[(size_t)k * CFO_BITS + 2 * j + 1];
-        N p = cs.alloc(F::zero());
-        cs.enforce(b0, b1, p);
-        const Affine<F>*e = &key.entry(k, j, 0);      // e[d], d = b0 + 2 b1
-        auto lookup = [&](const F& c00, const F& c10, const F& c01, const F& c11) {
-          N r = cs.constant(c00);
-          r = cs.add(r, cs.scale(b0, F::sub(c10, c00)));
-          r = cs.add(r, cs.scale(b1, F::sub(c01, c00)));
-          r = cs.add(r, cs.scale(p, F::sub(F::add(c11, c00), F::add(c10, c01))));
-          r.konst = false;
-          return r;
-        };
-        XY q; q.x = lookup(e[0].x, e[1].x, e[2].x, e[3].x); q.y = lookup(e[0].y, e[1].y, e[2].y, e[3].y);
-        acc = add_incomplete(acc, q);
-      }
-      Sn[k] = acc;
+      if (!tmpl.have && !no_copy && parallel_first_opening(key, bits, cnt, Sn)) break;      // (every scalar's chain synthesised on the host's threads and merged in order)
+      Sn[k] = scalar_chain(cs, key, k, &bits[(size_t)k * CFO_BITS]);
     }
     if (sh && !tmpl.have) { tmpl.have = true; tmpl.cnt = cnt; }
     // the sum over the scalars
@@ -223,21 +210,103 @@ struct DeciderCfGadget {
     return tot;
   }
   // P + Q for two finite points with different x (3 rows; the slope multiplies from the right: it is the only full-size wire of the B matrix)
-  XY add_incomplete(const XY& p, const XY& q) {
+  XY add_incomplete(const XY& p, const XY& q) { return add_incomplete(cs, p, q); }
+  static XY add_incomplete(CS<BnFr>& c, const XY& p, const XY& q) {
     F lamv = F::zero();
-    if (!cs.b) {
+    if (!c.b) {
       const F d = F::sub(q.x.v, p.x.v);
-      if (d.is_zero()) cs.bad = true;
+      if (d.is_zero()) c.bad = true;
       lamv = F::mul(F::sub(q.y.v, p.y.v), F::pow_pm2(d));
     }
-    N l = cs.alloc(lamv);
-    cs.enforce(cs.sub(q.x, p.x), l, cs.sub(q.y, p.y));
+    N l = c.alloc(lamv);
+    c.enforce(c.sub(q.x, p.x), l, c.sub(q.y, p.y));
     XY r;
-    r.x = cs.alloc(F::sub(F::sub(F::sqr(lamv), p.x.v), q.x.v));
-    cs.enforce(l, l, cs.add(r.x, cs.add(p.x, q.x)));
-    r.y = cs.alloc(F::sub(F::mul(lamv, F::sub(p.x.v, r.x.v)), p.y.v));
-    cs.enforce(cs.sub(p.x, r.x), l, cs.add(r.y, p.y));
+    r.x = c.alloc(F::sub(F::sub(F::sqr(lamv), p.x.v), q.x.v));
+    c.enforce(l, l, c.add(r.x, c.add(p.x, q.x)));
+    r.y = c.alloc(F::sub(F::mul(lamv, F::sub(p.x.v, r.x.v)), p.y.v));
+    c.enforce(c.sub(p.x, r.x), l, c.add(r.y, p.y));
     return r;
+  }
+  // shape mode: the chain of scalar k — per window the product of its two bits, the table entry as a linear combination, the addition — appended to c
+  static XY scalar_chain(CS<BnFr>& c, const CfOpeningKey& key, uint32_t k, const N* kbits) {
+    XY acc; acc.x = c.constant(key.H.x); acc.y = c.constant(key.H.y);
+    for (int j = 0; j < CFO_WINDOWS; j++) {
+      const N& b0 = kbits[2 * j]; const N& b1 = kbits[2 * j + 1];
+      N p = c.alloc(F::zero());
+      c.enforce(b0, b1, p);
+      const Affine<F>* e = &key.entry(k, j, 0);      // e[d], d = b0 + 2 b1
+      auto lookup = [&](const F& c00, const F& c10, const F& c01, const F& c11) {
+        N r = c.constant(c00);
+        r = c.add(r, c.scale(b0, F::sub(c10, c00)));
+        r = c.add(r, c.scale(b1, F::sub(c01, c00)));
+        r = c.add(r, c.scale(p, F::sub(F::add(c11, c00), F::add(c10, c01))));
+        r.konst = false;
+        return r;
+      };
+      XY q; q.x = lookup(e[0].x, e[1].x, e[2].x, e[3].x); q.y = lookup(e[0].y, e[1].y, e[2].y, e[3].y);
+      acc = add_incomplete(c, acc, q);
+    }
+    return acc;
+  }
+  // The first opening's chains on the host's threads (1.0 s of a 3 s set-up on one): every thread synthesises a run of scalars into a builder of its own — wire 0,
+  // then the run's bits, then its chain wires — and the runs are merged in order: rows copied with the wire numbers moved, coefficients appended to the dictionary
+  // (no search: a table constant occurs once).  Same rows, same wires, same coefficient VALUES as the sequential synthesis whatever the number of threads.
+  bool parallel_first_opening(const CfOpeningKey& key, const std::vector<N>& bits, uint32_t cnt, std::vector<XY>& Sn) {
+    const unsigned T = std::max(1u, std::min(16u, affinity_cpus()));
+    if (T < 2 || cnt < 4 * T) return false;
+    constexpr uint32_t PER = 4 * CFO_WINDOWS;
+    struct Part { cb::BuilderT<F> b; uint32_t k0 = 0, k1 = 0; std::string err; };
+    std::vector<Part> parts(T);
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < T; t++) {
+      parts[t].k0 = (uint32_t)((uint64_t)cnt * t / T); parts[t].k1 = (uint32_t)((uint64_t)cnt * (t + 1) / T);
+      th.emplace_back([&, t] {
+        Part& P = parts[t];
+        try {
+          const uint32_t n = P.k1 - P.k0;
+          P.b.n_wires = 1 + n * (uint32_t)CFO_BITS;
+          CS<BnFr> c; c.b = &P.b; c.base = P.b.n_wires;
+          std::vector<N> kb((size_t)CFO_BITS);
+          for (uint32_t k = P.k0; k < P.k1; k++) {
+            for (int i = 0; i < CFO_BITS; i++) kb[i] = c.wire(1 + (k - P.k0) * (uint32_t)CFO_BITS + (uint32_t)i, F::zero());
+            scalar_chain(c, key, k, kb.data());
+          }
+        } catch (const std::exception& e) { P.err = e.what(); }
+      });
+    }
+    const double t_th0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    for (auto& x : th) x.join();
+    if (getenv("VIMZ_DEBUG_TIMING")) fprintf(stderr, "[timing] decider: %u threads' chains joined after %.0f ms\n", T, 1e3 * (std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t_th0));
+    for (auto& P : parts) if (!P.err.empty()) throw std::runtime_error(P.err);
+    cb::BuilderT<F>& B = *cs.b;
+    for (auto& P : parts) {
+      const uint32_t n = P.k1 - P.k0, lbits = 1, lchain = 1 + n * (uint32_t)CFO_BITS;
+      if (P.b.n_constraints() != n * PER || P.b.n_wires != lchain + n * PER) throw std::runtime_error("decider: a run of chains has an unexpected size");
+      const uint32_t d0 = (uint32_t)B.dict.size();
+      B.dict.insert(B.dict.end(), P.b.dict.begin(), P.b.dict.end());
+      for (uint32_t k = P.k0; k < P.k1; k++) {
+        const uint32_t j = k - P.k0, bits_k = bits[(size_t)k * CFO_BITS].lc.t[0].w;
+        const uint32_t nb0 = B.alloc(PER);
+        if (nb0 != cs.base + (uint32_t)cs.w.size()) throw std::runtime_error("decider: wire allocation out of step");
+        cs.w.insert(cs.w.end(), PER, F::zero());
+        const uint32_t ob = lbits + j * (uint32_t)CFO_BITS, oc = lchain + j * PER;
+        auto move = [&](uint32_t w) -> uint32_t {
+          if (w == 0) return 0;
+          if (w >= ob && w < ob + (uint32_t)CFO_BITS) return w - ob + bits_k;
+          if (w >= oc && w < oc + PER) return w - oc + nb0;
+          throw std::runtime_error("decider: a chain row reaches outside its scalar");
+        };
+        for (uint32_t r = j * PER; r < (j + 1) * PER; r++) {
+          const cb::Csr* Ms[3] = {&P.b.A, &P.b.B, &P.b.C}; cb::Csr* Md[3] = {&B.A, &B.B, &B.C};
+          for (int m = 0; m < 3; m++) {
+            for (uint32_t q = Ms[m]->row_ptr[r]; q < Ms[m]->row_ptr[r + 1]; q++) { Md[m]->col.push_back(move(Ms[m]->col[q])); Md[m]->coef.push_back(d0 + Ms[m]->coef[q]); }
+            Md[m]->row_ptr.push_back((uint32_t)Md[m]->col.size());
+          }
+        }
+        Sn[k].x = cs.wire(nb0 + PER - 2, F::zero()); Sn[k].y = cs.wire(nb0 + PER - 1, F::zero());
+      }
+    }
+    return true;
   }
 
   // ---- check 6: non-native integers -------------------------------------------------------------------------------------------------------------
@@ -449,12 +518,17 @@ struct DeciderCfGadget {
     const uint32_t nW = sh.n_wires - 1 - CF_IO, nE = sh.n_constraints();
     if (in.key->n < std::max(nW, nE)) throw std::runtime_error("decider: the opening key holds fewer generators than the CycleFold vectors need");
     const bool have = !cs.b && in.W && in.E;
+    static const bool dbg_t = getenv("VIMZ_DEBUG_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_l = now();
+    auto lap = [&](const char* what) { if (dbg_t) { const double t = now(); fprintf(stderr, "[timing] decider checks 5-6 (%s): %s %.0f ms\n", cs.b ? "shape" : "witness", what, 1e3 * (t - t_l)); t_l = t; } };
     // the scalars and their bits
     std::vector<U256w> wv(nW, U256w{{0, 0, 0, 0}}), ev(nE, U256w{{0, 0, 0, 0}});
     if (have) { for (uint32_t k = 0; k < nW; k++) wv[k] = to_u256(in.W[k]); for (uint32_t k = 0; k < nE; k++) ev[k] = to_u256(in.E[k]); }
     std::vector<N> wbits((size_t)nW * CFO_BITS), ebits((size_t)nE * CFO_BITS);
     for (uint32_t k = 0; k < nW; k++) for (int i = 0; i < CFO_BITS; i++) wbits[(size_t)k * CFO_BITS + i] = bool_wire(bit_of(wv[k], i));
     for (uint32_t k = 0; k < nE; k++) for (int i = 0; i < CFO_BITS; i++) ebits[(size_t)k * CFO_BITS + i] = bool_wire(bit_of(ev[k], i));
+    lap("bits");
     // check 5
     Ec ec(cs, CycleSide<BnFr>::b(), CycleSide<BnFr>::G());
     auto opened = [&](const std::vector<N>& bits, const U256w* vals, uint32_t cnt, const N& cx_, const N& cy_) {
@@ -467,7 +541,9 @@ struct DeciderCfGadget {
       if (!cs.b && (!s.x.v.eq(tot.x.v) || !s.y.v.eq(tot.y.v))) cs.bad = true;
     };
     opened(wbits, wv.data(), nW, cWx, cWy);
+    lap("opening of cmW");
     opened(ebits, ev.data(), nE, cEx, cEy);
+    lap("opening of cmE");
     // check 6: z = (u, W, x) as integers
     std::vector<Big> z(sh.n_wires);
     { const F uc = F::from_mont(cu.v);
@@ -487,7 +563,9 @@ struct DeciderCfGadget {
       g.nat = cs.add(cs.add(cx[k][0], cs.scale(cx[k][1], cb::f_pow2<F>(64))), cs.add(cs.scale(cx[k][2], cb::f_pow2<F>(128)), cs.scale(cx[k][3], cb::f_pow2<F>(192))));
       z[1 + nW + k] = g;
     }
+    lap("integers of z");
     relation(sh, z, ebits, have ? in.E : nullptr);
+    lap("relation");
   }
 };
 

@@ -359,15 +359,18 @@ int decider_circuit_build(vimz_cf* v, bool light, aug::DeciderCircuit& circ) {
     const size_t need = std::max<size_t>(cfb.n_wires - 1 - aug::CF_IO, cfb.n_constraints());
     if (!v->ck2 || v->ck2->n < need) return vz_fail(ctx, VIMZ_ERR_INVALID, "decider: the CycleFold commitment key is shorter than the vectors it commits to");
     gens.resize(need);
-    std::lock_guard<std::mutex> g(ctx->mu);
+    // (a stream of its own and NOT the context's lock: the key is immutable, and the prover whose context this is may be in the middle of a fold that holds the
+    //  lock for seconds — the set-up's host part is meant to run under that fold: tools/e2e.py)
     P_TRY(hipSetDevice(ctx->device));
+    hipStream_t ts = nullptr;
+    P_TRY(hipStreamCreateWithFlags(&ts, hipStreamNonBlocking));
     uint32_t* tmp = nullptr;
+    struct FreeTmp { uint32_t** q; hipStream_t* s; ~FreeTmp() { if (*q) hipFree(*q); hipStreamDestroy(*s); } } ft{&tmp, &ts};
     P_TRY(hipMalloc((void**)&tmp, 64 * need));
-    struct FreeTmp { uint32_t* q; ~FreeTmp() { hipFree(q); } } ft{tmp};
-    launch_points_from_internal<Fe>(ctx->stream, v->ck2->d, 0, tmp, need);
+    launch_points_from_internal<Fe>(ts, v->ck2->d, 0, tmp, need);
     P_TRY(hipGetLastError());
-    P_TRY(hipMemcpyAsync(gens.data(), tmp, 64 * need, hipMemcpyDeviceToHost, ctx->stream));
-    P_TRY(hipStreamSynchronize(ctx->stream));
+    P_TRY(hipMemcpyAsync(gens.data(), tmp, 64 * need, hipMemcpyDeviceToHost, ts));
+    P_TRY(hipStreamSynchronize(ts));
   }
   try {
     if (light) circ.finish(main, v->c1->len_z);
@@ -381,16 +384,17 @@ int kzg_vk_matches_srs(vimz_cf* v, const G2PAff& vk, const char* who) {
   vimz_ctx* ctx = v->ctx;
   G1Aff p01[2];
   if (!v->ck1 || v->ck1->n < 2) return vz_fail(ctx, VIMZ_ERR_INVALID, "decider: the main commitment key is too short to be an SRS");
-  {
-    std::lock_guard<std::mutex> g(ctx->mu);
+  {      // (a stream of its own, not the context's lock: see decider_circuit_build)
     P_TRY(hipSetDevice(ctx->device));
+    hipStream_t ts = nullptr;
+    P_TRY(hipStreamCreateWithFlags(&ts, hipStreamNonBlocking));
     uint32_t* tmp = nullptr;
+    struct FreeTmp { uint32_t** q; hipStream_t* s; ~FreeTmp() { if (*q) hipFree(*q); hipStreamDestroy(*s); } } ft{&tmp, &ts};
     P_TRY(hipMalloc((void**)&tmp, 128));
-    struct FreeTmp { uint32_t* q; ~FreeTmp() { hipFree(q); } } ft{tmp};
-    launch_points_from_internal<Fq>(ctx->stream, v->ck1->d, 0, tmp, 2);
+    launch_points_from_internal<Fq>(ts, v->ck1->d, 0, tmp, 2);
     P_TRY(hipGetLastError());
-    P_TRY(hipMemcpyAsync(p01, tmp, 128, hipMemcpyDeviceToHost, ctx->stream));
-    P_TRY(hipStreamSynchronize(ctx->stream));
+    P_TRY(hipMemcpyAsync(p01, tmp, 128, hipMemcpyDeviceToHost, ts));
+    P_TRY(hipStreamSynchronize(ts));
   }
   const G1Aff g1 = g1_generator();
   G1Aff ng = g1; ng.y = Fq::neg(g1.y);
