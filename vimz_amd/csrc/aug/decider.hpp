@@ -42,6 +42,9 @@ struct DeciderIn {
   CfFr eW, eE;                                 // KZG evaluations (the challenges follow from Wn, En: decider_kzg_challenge)
   const CfFr* Wf = nullptr; const CfFr* Ef = nullptr;      // folded witness (wires 1 .. n_wires-3 of Z) and error vector; nullptr in shape mode
   CfFullIn full;                                           // full decider: the opening key, the CycleFold shape, the running CycleFold witness and error vector (key == nullptr: light)
+  // witness mode, optional: (A, B, C)·Z' of the main shape over the folded Z' = (u', W', x0', x1') computed ahead (on the host's threads); used when Z'[0], Z'[n-2], Z'[n-1]
+  // are the values the circuit derives (an honest fold), else the rows are evaluated here one by one
+  const CfFr* pre_az = nullptr; const CfFr* pre_bz = nullptr; const CfFr* pre_cz = nullptr; const CfFr* pre_z = nullptr;
 };
 
 inline void decider_limbs55(const U256w& v, uint64_t out[DEC_LIMBS]) {
@@ -170,11 +173,13 @@ inline void synthesize_decider(CS<BnFr>& cs, const cb::BuilderT<CfFr>& main, uin
     }
     return acc;
   };
+  const bool pre = !shape && in.pre_az && in.pre_bz && in.pre_cz && in.pre_z && in.pre_z[0].eq(un.v) && in.pre_z[nw - 2].eq(x0n.v) && in.pre_z[nw - 1].eq(x1n.v);
+  auto row_val = [&](const cb::Csr& M, const CfFr* prev, uint32_t r) { if (!pre) return row_lc(M, r); N a; a.v = prev[r]; a.konst = false; return a; };
   for (uint32_t r = 0; r < nc; r++) {
-    N az = row_lc(main.A, r), bz = row_lc(main.B, r);
+    N az = row_val(main.A, in.pre_az, r), bz = row_val(main.B, in.pre_bz, r);
     N rhs = Ev[r];
     if (main.C.row_ptr[r + 1] > main.C.row_ptr[r]) {
-      N cz = row_lc(main.C, r);
+      N cz = row_val(main.C, in.pre_cz, r);
       N t = cs.alloc(F::mul(un.v, cz.v));
       cs.enforce(un, cz, t);
       rhs = cs.add(t, Ev[r]);

@@ -1056,6 +1056,10 @@ int vimz_decider_prove(vimz_decider* d, vimz_cf* ivc, uint64_t* public_out, uint
     P_TRY(hipStreamSynchronize(ctx->stream));
     in.full.W = cfZ.data() + 1; in.full.E = cfE.data();
   }
+  // (the main relation's rows are a third of the witness's time when evaluated one by one inside the circuit: their products come from the host's threads)
+  std::vector<Fe> pre_abc[3];
+  host_spmv3(v->circ->build->b, Wf, pre_abc);
+  in.pre_az = pre_abc[0].data(); in.pre_bz = pre_abc[1].data(); in.pre_cz = pre_abc[2].data(); in.pre_z = Wf.data();
   std::vector<Fe> z;
   bool bad = false;
   try { z = d->circ.witness(v->circ->build->b, in, &bad); } catch (const std::exception& e) { return vz_fail(ctx, VIMZ_ERR_INVALID, e.what()); }
