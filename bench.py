@@ -239,6 +239,11 @@ def main_ivc(args, rank, world, dist, torch, ctxs, circuit, params, steps_all, g
     setup_s = time.time() - t_setup
     z0 = [int(x) for x in z0]
     rows_warm, rows_timed, rows_prof = mine[:W], mine[W:W + K], mine[W + K:W + 2 * K]
+    if os.environ.get("VIMZ_BENCH_REGISTER_ROWS"):      # experiment (the slow pass): the rows in page-locked memory, so that their upload is a plain DMA
+        import ctypes
+        _hip = ctypes.CDLL("libamdhip64.so")
+        _hip.hipHostRegister.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint]
+        print(f"[bench] hipHostRegister(rows) -> {_hip.hipHostRegister(mine.ctypes.data, mine.nbytes, 0)}", file=sys.stderr)
     # `value` is the ALL-HIP schedule: every row's witness — Poseidon chains included — on the GPU, whatever the length of the call.  The
     # library's default policy evaluates the chains of a SHORT call's rows (proofs of <= 28 rows: the driver's 20-row window, no real image) on a host pool
     # while the GPU does the rest; that hybrid is reported as an extra (`host_head_batch_schedule`), or becomes `value` with --host-head-batch.
