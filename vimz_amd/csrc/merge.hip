@@ -774,6 +774,9 @@ int vimz_ivc_fold_segments_dg(vimz_ivc* const* segs, size_t n_seg, const uint64_
       pk->start_from = k > 0 ? links[k - 1].get() : nullptr; pk->end_to = k + 1 < S ? links[k].get() : nullptr;
       pk->on_start = [vk] { for (uint32_t q = 0; q < vk->c1->len_z; q++) vk->z0[q] = vk->pri->z_cur[q]; };
     }
+    // (every segment's rows on its device before any segment's call starts: prover_internal.hpp, vz_prover_preload_inputs)
+    static const bool no_preload = getenv("VIMZ_DEBUG_NO_PRELOAD") != nullptr;
+    for (size_t k = 0; k < S && !rc && !no_preload; k++) rc = vz_prover_preload_inputs(segs[k]->pri, step_inputs + 4 * n_priv * lo[k], hi[k] - lo[k]);
     for (size_t k = 0; k < S && !rc; k++) {
       th_fold.emplace_back([&, k] { rc_fold[k] = vimz_ivc_fold(segs[k], step_inputs + 4 * n_priv * lo[k], hi[k] - lo[k]); if (rc_fold[k] && k + 1 < S) links[k]->fail(); });
       started = k + 1;
@@ -799,7 +802,7 @@ int vimz_ivc_fold_segments_dg(vimz_ivc* const* segs, size_t n_seg, const uint64_
     started = k + 1;
   }
   for (auto& t : th_fold) t.join();
-  for (size_t k = 0; k < S; k++) { segs[k]->pri->start_from = nullptr; segs[k]->pri->end_to = nullptr; segs[k]->pri->on_start = nullptr; segs[k]->pri->suppress_head = false; }
+  for (size_t k = 0; k < S; k++) { segs[k]->pri->start_from = nullptr; segs[k]->pri->end_to = nullptr; segs[k]->pri->on_start = nullptr; segs[k]->pri->suppress_head = false; segs[k]->pri->preloaded_inputs = nullptr; segs[k]->pri->preloaded_rows = 0; }
   for (size_t k = 0; k < th_dig.size(); k++) if (th_dig[k].joinable()) th_dig[k].join();
   for (size_t k = 0; k < started && !rc; k++) if (rc_fold[k]) { rc = rc_fold[k]; if (segs[k]->ctx != ctx) ctx->err = segs[k]->ctx->err; }
   if (rc) { if (pre) drop_pre(); return rc; }

@@ -194,6 +194,7 @@ struct vimz_prover {
   // per fold call: all private inputs, all IVC states and all row hashes resident
   uint32_t *priv_all_d = nullptr, *zs_all_d = nullptr, *job_all_d = nullptr;
   size_t cap_priv_all = 0, cap_zs_all = 0, cap_job_all = 0;
+  const uint64_t* preloaded_inputs = nullptr; size_t preloaded_rows = 0;      // rows already in priv_all_d (vz_prover_preload_inputs): the next fold call over exactly them skips its upload
   std::vector<void*> retired;      // outgrown per-call buffers (see grow())
   // host: running instance
   G1Aff comm_W{}, comm_E{};
@@ -399,6 +400,10 @@ static hipError_t grow(std::vector<void*>& retired, uint32_t** d, size_t* cap, s
 }
 
 int vz_prover_create_layout(vimz_ctx* ctx, const vimz_circuit* circuit, const vimz_bases* ck, size_t max_batch, int ivc, uint32_t step_wires, uint32_t step_c, vimz_prover** out);
+// The rows of the prover's NEXT fold call, uploaded now (blocking, on the calling thread): a caller that is about to start several segments' calls side by side does this
+// for each of them first, while nothing runs — an upload issued from a segment's own thread while its siblings' first kernels start was seen to sit in the runtime for 7 ms
+// once in eight proofs (profiles/r06_slow_pass_trace.txt).
+static int vz_prover_preload_inputs(vimz_prover* p, const uint64_t* step_inputs, size_t nsteps);
 
 // One call of vimz_prover_fold / vimz_ivc_fold: the inputs, the IVC state chain and the batch schedule.
 struct FoldJob {
@@ -755,6 +760,18 @@ static inline void dbg_stamp(const vimz_prover* p, const char* what) {
   static const double t_origin = now_s();
   if (on) fprintf(stderr, "[timing] %p %10.3f ms  %s\n", (const void*)p, 1e3 * (now_s() - t_origin), what);
 }
+static int vz_prover_preload_inputs(vimz_prover* p, const uint64_t* step_inputs, size_t nsteps) {
+  vimz_ctx* ctx = p->ctx;
+  if (!nsteps || !step_inputs) return VIMZ_OK;
+  std::lock_guard<std::mutex> g(ctx->mu);
+  P_TRY(hipSetDevice(ctx->device));
+  P_TRY(grow(p->retired, &p->priv_all_d, &p->cap_priv_all, 32 * nsteps * (size_t)p->n_priv, 32 * 1024 * (size_t)p->n_priv));
+  P_TRY(hipMemcpyAsync(p->priv_all_d, step_inputs, 32 * nsteps * (size_t)p->n_priv, hipMemcpyHostToDevice, ctx->stream));
+  P_TRY(hipStreamSynchronize(ctx->stream));
+  p->preloaded_inputs = step_inputs; p->preloaded_rows = nsteps;
+  return VIMZ_OK;
+}
+
 static int fold_prepare(vimz_prover* p, FoldJob& J, bool start_batch0 = false) {
   vimz_ctx* ctx = p->ctx;
   dbg_stamp(p, "fold_prepare: enter");
@@ -795,7 +812,8 @@ static int fold_prepare(vimz_prover* p, FoldJob& J, bool start_batch0 = false) {
   P_TRY(grow(p->retired, &p->zs_all_d, &p->cap_zs_all, 32 * (nsteps + 1) * (size_t)p->len_z, 32 * 1025 * (size_t)p->len_z));
   P_TRY(grow(p->retired, &p->job_all_d, &p->cap_job_all, 32 * nsteps * jstride, 32 * 1024 * jstride));
   dbg_stamp(p, "fold_prepare: buffers grown");
-  P_TRY(hipMemcpyAsync(p->priv_all_d, J.step_inputs, 32 * nsteps * (size_t)p->n_priv, hipMemcpyHostToDevice, s));
+  if (p->preloaded_inputs == J.step_inputs && p->preloaded_rows == nsteps) { p->preloaded_inputs = nullptr; p->preloaded_rows = 0; }      // (uploaded ahead by the caller that starts several segments together)
+  else { p->preloaded_inputs = nullptr; P_TRY(hipMemcpyAsync(p->priv_all_d, J.step_inputs, 32 * nsteps * (size_t)p->n_priv, hipMemcpyHostToDevice, s)); }
   dbg_stamp(p, "fold_prepare: inputs upload queued");
   P_TRY(hipMemsetAsync(p->job_all_d, 0, 32 * nsteps * jstride, s));
   { static const bool dbg_t = getenv("VIMZ_DEBUG_TIMING") != nullptr; if (dbg_t) fprintf(stderr, "[timing] prepare: buffers + upload of the inputs %.2f ms\n", 1e3 * (now_s() - t0)); }
